@@ -1,0 +1,294 @@
+/*
+ * sailor_hip.h -- C-ABI of the MI355X-native Forward+ lighting path for the Sailor engine.
+ *
+ * This is the drop-in boundary: the only thing `Runtime/GraphicsDriver/HIP` (the new RHI backend that sits
+ * beside the reference's `Runtime/GraphicsDriver/Vulkan`) calls.  Style follows the reference's own exported
+ * C surface, Lib/DllMain.cpp:9-160: `extern "C"`, cdecl, POD arguments, integer status returns.
+ *
+ * Conventions
+ *   - every entry point returns `int`: 0 = SAILOR_HIP_OK, negative = error class (table below); nothing throws;
+ *   - entry points RECORD work on the context's stream and return without synchronising (mirrors the reference's
+ *     record-then-submit model: RHI/GraphicsDriver.h:310-314 Dispatch, :149 SubmitCommandList); only
+ *     sailor_hip_context_synchronize / sailor_hip_buffer_download wait;
+ *   - no allocation on the caller's behalf except through sailor_hip_buffer_create; kernels take raw device
+ *     pointers, so memory owned by another allocator (a torch tensor, an engine heap) is accepted as is;
+ *   - thread-compatible per context (one stream per context; the reference calls from the one Render thread,
+ *     RHI/Renderer.cpp:264-303);
+ *   - matrices are column-major float[16] exactly as glm::mat4 lies in memory.
+ *
+ * There is NO CPU fallback behind this header: if the HIP runtime or a gfx950 device is missing every
+ * device entry point fails with SAILOR_HIP_ERR_NO_DEVICE.
+ */
+#ifndef SAILOR_HIP_H
+#define SAILOR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(SAILOR_HIP_BUILD)
+#define SAILOR_HIP_API __attribute__((visibility("default")))
+#else
+#define SAILOR_HIP_API
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------------------ */
+#define SAILOR_HIP_OK 0
+#define SAILOR_HIP_ERR_INVALID_ARGUMENT (-1)
+#define SAILOR_HIP_ERR_NO_DEVICE (-2)       /* HIP runtime present but no usable device / wrong ordinal     */
+#define SAILOR_HIP_ERR_OUT_OF_MEMORY (-3)
+#define SAILOR_HIP_ERR_LAUNCH (-4)          /* kernel launch or stream operation failed                      */
+#define SAILOR_HIP_ERR_WORKSPACE_TOO_SMALL (-5)
+#define SAILOR_HIP_ERR_RCCL (-6)
+#define SAILOR_HIP_ERR_UNSUPPORTED (-7)
+
+/* ---- constants generated into Constants.glsl by AssetRegistry/Shader/ShaderCompiler.cpp:141-167 -------- */
+#define SAILOR_LIGHTS_CULLING_TILE_SIZE 16     /* Constants.glsl:13 ; FrameGraph/LightCullingNode.h:16 */
+#define SAILOR_LIGHTS_CANDIDATES_PER_TILE 196  /* Constants.glsl:14 */
+#define SAILOR_LIGHTS_PER_TILE 128             /* Constants.glsl:15 ; FrameGraph/LightCullingNode.h:15 */
+#define SAILOR_GPU_CULLING_GROUP_SIZE 256      /* Constants.glsl:18 ; RHI/Renderer.h:32 */
+#define SAILOR_NUM_CSM_CASCADES 4              /* Constants.glsl:23 ; ECS/LightingECS.h:65 */
+#define SAILOR_LIGHTS_MAX_NUM 65535            /* ECS/LightingECS.h:54 (the reference's SSBO capacity) */
+
+/* ---- POD mirrors of the reference's GPU-visible structs ------------------------------------------------ */
+
+/* RHI/Types.h:751-761 UboFrameData, filled at FrameGraph/RHIFrameGraph.cpp:60-67.  232 bytes. */
+typedef struct SailorUboFrameData {
+    float view[16];
+    float projection[16];
+    float invProjection[16];
+    float cameraPosition[4];
+    int32_t viewportSize[2];
+    float cameraZNearZFar[2];
+    float currentTime;
+    float deltaTime;
+} SailorUboFrameData;
+
+/* FrameGraph/LightCullingNode.h:25-31 PushConstants == ComputeLightCulling.shader:12-18.  88 bytes. */
+typedef struct SailorLightCullPushConstants {
+    float invViewProjection[16]; /* never read by the shader; kept for layout */
+    int32_t viewportSize[2];
+    int32_t numTiles[2];
+    int32_t lightsNum;
+    int32_t _pad;
+} SailorLightCullPushConstants;
+
+/* ECS/LightingECS.h:71-81 LightShaderData == Lighting.glsl:4-15 LightData.  std430, 112 bytes. */
+typedef struct SailorLightShaderData {
+    uint32_t type;       /* Engine/Types.h:31-37: 0 Directional, 1 Point, 2 Spot, 3 Area */
+    uint32_t shadowType; /* RHI/SceneView.h:13-18: 0 None, 1 PCF, 2 EVSM */
+    uint32_t _pad0[2];
+    float worldPosition[3]; float _pad1;
+    float direction[3];     float _pad2;
+    float intensity[3];     float _pad3;
+    float attenuation[3];   float _pad4;
+    float cutOff[2];        float _pad5[2]; /* cosines, ECS/LightingECS.cpp:171 */
+    float bounds[3];        float _pad6;
+} SailorLightShaderData;
+
+/* Lighting.glsl:17-22 LightsGrid */
+typedef struct SailorLightsGrid {
+    uint32_t offset;
+    uint32_t num;
+} SailorLightsGrid;
+
+/* FrameGraph/RenderSceneNode.h:16-33 PerInstanceData == ComputeMeshCulling.shader:20-26.  96 bytes. */
+typedef struct SailorPerInstanceData {
+    float model[16];
+    float sphereBounds[4];
+    uint32_t materialInstance;
+    uint32_t isCulled;
+    uint32_t _pad[2];
+} SailorPerInstanceData;
+
+/* Math/Transform.h: {vec4 m_position; quat m_rotation (memory x,y,z,w); vec4 m_scale}.  48 bytes. */
+typedef struct SailorTransform {
+    float position[4];
+    float rotation[4];
+    float scale[4];
+} SailorTransform;
+
+/* Math/Bounds.h:110-113 AABB {vec3 m_min; vec3 m_max}.  24 bytes. */
+typedef struct SailorAABB {
+    float min[3];
+    float max[3];
+} SailorAABB;
+
+/* Shadow-map texel formats (ECS/LightingECS.h:57-58 + a plain fp32 form for tests) */
+#define SAILOR_SHADOWMAP_R16_SFLOAT 0
+#define SAILOR_SHADOWMAP_R32G32B32A32_SFLOAT 1
+#define SAILOR_SHADOWMAP_R32_SFLOAT 2
+
+/* The CSM inputs of Standard.shader: binding 6 `lightsMatrices` and binding 8 `shadowMaps[cascade]`
+ * (Standard.shader:223-233).  Maps are linear row-major images in device memory, row 0 first. */
+typedef struct SailorCsmDesc {
+    float lightsMatrices[SAILOR_NUM_CSM_CASCADES][16];
+    const void* maps[SAILOR_NUM_CSM_CASCADES]; /* device pointers; NULL = no map bound => shadow factor 1 */
+    int32_t width[SAILOR_NUM_CSM_CASCADES];
+    int32_t height[SAILOR_NUM_CSM_CASCADES];
+    int32_t format[SAILOR_NUM_CSM_CASCADES];
+} SailorCsmDesc;
+
+/*
+ * A horizontal band of the frame: tile rows [tileRowBegin, tileRowEnd) of the light grid.  Tile row t covers
+ * framebuffer rows H-1-16t-15 .. H-1-16t, so the band's pixels are framebuffer rows
+ * [fbRowBegin, fbRowBegin + fbRowCount).  Per-pixel device buffers handed to the band entry points (linear
+ * depth, surface planes, radiance) hold exactly those rows, first row = fbRowBegin.  The whole frame is the
+ * band {0, Ty, 0, H}; use sailor_hip_band_whole_frame / sailor_hip_band_for_rank to fill one.
+ */
+typedef struct SailorBand {
+    int32_t tileRowBegin;
+    int32_t tileRowEnd;
+    int32_t fbRowBegin;
+    int32_t fbRowCount;
+} SailorBand;
+
+typedef struct SailorHipContext SailorHipContext; /* opaque */
+
+/* ---- library / context --------------------------------------------------------------------------------- */
+
+SAILOR_HIP_API int sailor_hip_version(void);                 /* 1000*major + minor */
+SAILOR_HIP_API const char* sailor_hip_status_string(int status);
+SAILOR_HIP_API int sailor_hip_device_count(int* outCount);
+
+/* Replaces: RHI/Renderer.cpp:60-63 (backend instantiation) + IGraphicsDriver::Initialize (RHI/GraphicsDriver.h:63).
+ * `stream` is a hipStream_t the caller owns, or NULL to let the context create (and own) one. */
+SAILOR_HIP_API int sailor_hip_context_create(int deviceOrdinal, void* stream, SailorHipContext** outContext);
+SAILOR_HIP_API int sailor_hip_context_destroy(SailorHipContext* ctx);
+/* Replaces: IGraphicsDriver::WaitIdle (RHI/GraphicsDriver.h:83) */
+SAILOR_HIP_API int sailor_hip_context_synchronize(SailorHipContext* ctx);
+SAILOR_HIP_API int sailor_hip_context_stream(SailorHipContext* ctx, void** outStream);
+/* Text of the last HIP/RCCL error seen by this context (never NULL). */
+SAILOR_HIP_API const char* sailor_hip_context_last_error(SailorHipContext* ctx);
+
+/* ---- buffers: IGraphicsDriver::CreateBuffer (RHI/GraphicsDriver.h:89-90), AddSsboToShaderBindings (:154),
+ *      IGraphicsDriverCommands::UpdateShaderBinding / UpdateBuffer (:303-304) -------------------------------- */
+SAILOR_HIP_API int sailor_hip_buffer_create(SailorHipContext* ctx, size_t bytes, void** outDevicePtr);
+SAILOR_HIP_API int sailor_hip_buffer_free(SailorHipContext* ctx, void* devicePtr);
+/* async host->device copy on the context stream; `src` bytes are staged at record time (the reference copies
+ * push-constant / update payloads at record time too: VulkanCommandBuffer.cpp:679-685) */
+SAILOR_HIP_API int sailor_hip_buffer_upload(SailorHipContext* ctx, void* dstDevice, size_t dstOffset, const void* src, size_t bytes);
+/* synchronous device->host copy (waits for the stream) */
+SAILOR_HIP_API int sailor_hip_buffer_download(SailorHipContext* ctx, void* dstHost, const void* srcDevice, size_t srcOffset, size_t bytes);
+SAILOR_HIP_API int sailor_hip_buffer_fill_u32(SailorHipContext* ctx, void* dstDevice, size_t dstOffset, uint32_t value, size_t count);
+
+/* ---- bands ---------------------------------------------------------------------------------------------- */
+SAILOR_HIP_API int sailor_hip_num_tiles(int32_t width, int32_t height, int32_t* outTilesX, int32_t* outTilesY); /* LightCullingNode.cpp:56-57 */
+SAILOR_HIP_API int sailor_hip_band_whole_frame(int32_t width, int32_t height, SailorBand* outBand);
+/* contiguous tile-row bands: rank g of G gets rows [floor(g*Ty/G), floor((g+1)*Ty/G)) */
+SAILOR_HIP_API int sailor_hip_band_for_rank(int32_t width, int32_t height, int32_t rank, int32_t worldSize, SailorBand* outBand);
+
+/* ---- K0 + K1: tile light cull ---------------------------------------------------------------------------
+ * Replaces: the Dispatch recorded by LightCullingNode::Process (FrameGraph/LightCullingNode.cpp:74-77) and the
+ * whole of Content/Shaders/ComputeLightCulling.shader, under the canonical sequential semantics of SURVEY.md
+ * Appendix A (ascending-light-index candidates, first 196, nearest-128 selection, prefix-sum offsets).
+ *
+ *   frame, pc      : host structs, copied at record time
+ *   dLights        : device, pc->lightsNum x SailorLightShaderData (binding set 0 / binding 0 `light`)
+ *   dLinearDepth   : device, R32F linear depth rows of `band` (binding set 1 / binding 2 `sceneDepth`)
+ *   dLightsGrid    : device out, one SailorLightsGrid per tile OF THE BAND (band-local tile index
+ *                    (ty - tileRowBegin)*Tx + tx); offset is band-local: 1 + sum of num over earlier band tiles
+ *   dCulledLights  : device out, uint32: [0] = sum of num over the band, [offset+i] = i-th light of the tile;
+ *                    capacity culledCapacity uints, needs 1 + bandTiles*128 (the reference allocates one short,
+ *                    LightCullingNode.cpp:64)
+ *   dWorkspace     : device scratch of at least sailor_hip_light_cull_workspace_size(...) bytes
+ *   flags          : SAILOR_CULL_* bits
+ * For the whole-frame band the outputs ARE the reference's `lightsGrid` / `culledLights` buffers.
+ */
+#define SAILOR_CULL_DEFAULT 0u
+#define SAILOR_CULL_BRUTE_FORCE 1u /* skip the conservative macro-tile pre-filter (same results, for validation) */
+
+SAILOR_HIP_API size_t sailor_hip_light_cull_workspace_size(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band);
+SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
+                                         const SailorUboFrameData* frame, const SailorLightCullPushConstants* pc,
+                                         const SailorLightShaderData* dLights, const float* dLinearDepth,
+                                         SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity,
+                                         void* dWorkspace, size_t workspaceBytes,
+                                         const SailorBand* band, uint32_t flags);
+
+/* Multi-GPU stitch helpers.  After an all-gather of the per-band totals, rebase a band's grid
+ * to the canonical global offsets: offset += globalBase (globalBase = sum of num over all earlier bands). */
+SAILOR_HIP_API int sailor_hip_light_grid_rebase(SailorHipContext* ctx, SailorLightsGrid* dLightsGrid, int32_t numTiles, uint32_t globalBase);
+
+/* ---- K2 + K3: PBR shade over per-tile light lists, with CSM sampling --------------------------------------
+ * Replaces: the fragment work of Content/Shaders/Standard.shader main() (:377-439) + CalculateLighting (:259-341)
+ * + Lighting.glsl:39-76,168-284 for the draws recorded by RenderSceneNode::Process (FrameGraph/RenderSceneNode.cpp:109),
+ * executed as compute over a surface buffer instead of rasterised fragments (ambient/IBL term == 0).
+ *
+ *   dSurface       : device, 3 planes of float4 per pixel, plane-major, each plane = band rows x width:
+ *                    P0 = (worldPos.xyz, albedo.a)  P1 = (normal.xyz, roughness)  P2 = (albedo.rgb, metallic)
+ *   surfacePlaneStride : distance between planes in float4 elements (>= band rows * width)
+ *   dLightsGrid / dCulledLights : the lists of the SAME band as produced by sailor_hip_light_cull (band-local)
+ *   csm            : host struct or NULL (no directional shadowing: factor 1)
+ *   dRadiance      : device out, float4 per pixel of the band (rgb = sum over lights, a = albedo.a)
+ */
+SAILOR_HIP_API int sailor_hip_shade(SailorHipContext* ctx, const SailorUboFrameData* frame,
+                                    const float* dSurface, size_t surfacePlaneStride,
+                                    const SailorLightShaderData* dLights, int32_t lightsNum,
+                                    const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
+                                    const SailorCsmDesc* csm, float* dRadiance,
+                                    const SailorBand* band);
+
+/* ---- K4: ECS transform + bounds + frustum-cull sweep -------------------------------------------------------
+ * Replaces: TransformECS::Tick full-sweep branch + CalculateMatrices (ECS/TransformECS.cpp:144-212),
+ * Transform::Matrix (Math/Transform.cpp:39-42), the AABB::Apply of StaticMeshRendererECS::Tick
+ * (ECS/StaticMeshRendererECS.cpp:40-58, Math/Bounds.cpp:479-492) and the Frustum::OverlapsAABB sweep that
+ * RHISceneView::TraceScene performs through the octree (RHI/SceneView.cpp:56, Math/Bounds.cpp:245-260), over flat
+ * level-sorted arrays.
+ *
+ *   entities are level-sorted: levelOffsets[l]..levelOffsets[l+1] is hierarchy level l (host array of
+ *   numLevels+1 entries), dParent[i] = index of the parent (in an earlier level) or 0xFFFFFFFF for roots
+ *   planes         : host, 6 x vec4 (L,R,T,B,N,F) from sailor_host_extract_frustum_planes
+ *   dWorld         : device out, mat4 per entity (m_cachedWorldMatrix)
+ *   dWorldAabb     : device out, SailorAABB per entity
+ *   dVisibility    : device out, 1 bit per entity, LSB-first in uint64 words, ceil(n/64) words
+ *   [entityBegin, entityEnd) restricts the sweep to a slice of every level (multi-GPU entity sharding needs the
+ *   parents' world matrices, so a slice must contain its ancestors: use whole levels or root-closed ranges).
+ */
+SAILOR_HIP_API int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntities,
+                                        const SailorTransform* dTransforms, const uint32_t* dParent,
+                                        const uint32_t* levelOffsets, uint32_t numLevels,
+                                        const SailorAABB* dLocalAabb, const float* planes,
+                                        float* dWorld, SailorAABB* dWorldAabb, uint64_t* dVisibility);
+
+/* Replaces: FrustumCulling of Content/Shaders/ComputeMeshCulling.shader:96-110 (+ CreateViewFrustum, Math.glsl:185-222)
+ * for the Dispatch at RHI/Batch.hpp:188; writes PerInstanceData::isCulled in place.  Hi-Z occlusion and the
+ * indirect-draw compaction of that shader are out of scope. */
+SAILOR_HIP_API int sailor_hip_mesh_frustum_cull(SailorHipContext* ctx, const SailorUboFrameData* frame,
+                                                SailorPerInstanceData* dInstances, uint32_t numInstances, uint32_t firstInstanceIndex);
+
+/* ---- RCCL exchange for split frames (only when the frame is split AND a consumer needs the global list) ----
+ * `comm` is an ncclComm_t created by the host.  Collective 1: all-gather of one uint32 (band total) per rank.
+ * Collective 2: all-gather of the padded band index segments (each rank contributes `segmentCapacity` uints). */
+SAILOR_HIP_API int sailor_hip_allgather_u32(SailorHipContext* ctx, void* comm, const uint32_t* dSend, uint32_t* dRecv, size_t countPerRank);
+
+/* ---- host-side math of the path (pure CPU, no device needed) ----------------------------------------------- */
+/* Math/Math.cpp:18-21 PerspectiveRH (reversed Z) */
+SAILOR_HIP_API int sailor_host_perspective_rh(float fovRadians, float aspect, float zNear, float zFar, float* outMat4);
+/* glm::inverse(mat4) as used at ECS/CameraECS.cpp:20,33 */
+SAILOR_HIP_API int sailor_host_mat4_inverse(const float* m, float* outMat4);
+SAILOR_HIP_API int sailor_host_mat4_mul(const float* a, const float* b, float* outMat4);
+/* Math/Transform.cpp:39-42 */
+SAILOR_HIP_API int sailor_host_transform_matrix(const SailorTransform* t, float* outMat4);
+/* FrameGraph/RHIFrameGraph.cpp:60-67 FillFrameData from a camera world matrix + lens */
+SAILOR_HIP_API int sailor_host_fill_frame_data(const float* cameraWorld, float fovDegrees, float aspect, float zNear, float zFar,
+                                               int32_t viewportWidth, int32_t viewportHeight, float currentTime, float deltaTime,
+                                               SailorUboFrameData* outFrame);
+/* Math/Bounds.cpp:142-193 Frustum::ExtractFrustumPlanes(world, aspect, fovY[deg], zNear, zFar): 6 planes, 8 corners (may be NULL) */
+SAILOR_HIP_API int sailor_host_extract_frustum_planes(const float* worldMatrix, float aspect, float fovYDegrees, float zNear, float zFar,
+                                                      float* outPlanes24, float* outCorners24);
+/* FrameGraph/ShadowPrepassNode.cpp:387-404 + Math/Bounds.cpp:78-109 + ECS/LightingECS.cpp:292: the 4 lightsMatrices */
+SAILOR_HIP_API int sailor_host_csm_matrices(const float* lightView, const float* cameraWorld, float aspect, float fovYDegrees,
+                                            float cameraNear, float cameraFar, float* outMatrices64);
+/* ECS/LightingECS.cpp:163-172: pack one light (cutOff in degrees -> cosines) */
+SAILOR_HIP_API int sailor_host_pack_light(uint32_t type, uint32_t shadowType, const float* worldPosition, const float* direction,
+                                          const float* intensity, const float* attenuation, const float* cutOffDegrees, const float* bounds,
+                                          SailorLightShaderData* outLight);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAILOR_HIP_H */

@@ -1,0 +1,165 @@
+"""ctypes front-end of oracle/liboracle.so (the C restatement in sailor_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of sailor_oracle.c.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never from the sailor_amd package.  PARITY UNPINNED (the reference has no golden vectors).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_DIR = Path(__file__).resolve().parent
+LIB_PATH = _DIR / "liboracle.so"
+TILE, CAND, KEEP = 16, 196, 128
+_lib = None
+
+
+def build(force: bool = False) -> Path:
+    if force or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < (_DIR / "sailor_oracle.c").stat().st_mtime:
+        subprocess.run(["make", "-C", str(_DIR), "liboracle.so"] + (["-B"] if force else []), check=True, capture_output=True)
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            build()
+        L = C.CDLL(str(LIB_PATH))
+        L.oracle_const_cascade_level_glsl.restype = C.c_float
+        L.oracle_const_cascade_level_cpp.restype = C.c_float
+        L.oracle_const_poisson.restype = C.c_float
+        L.oracle_canonical_expf.restype = C.c_float
+        L.oracle_canonical_expf.argtypes = [C.c_float]
+        L.oracle_directional_shadow.restype = C.c_float
+        L.oracle_perspective_rh_reversed_z.argtypes = [C.c_float] * 4 + [C.c_void_p]
+        L.oracle_extract_frustum_planes.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.oracle_csm_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _frame_bytes(frame) -> np.ndarray:
+    """Accepts a ctypes UboFrameData (or raw 232 bytes) and returns a uint8[232] copy."""
+    b = np.frombuffer(bytes(frame), np.uint8).copy()
+    assert b.size == 232
+    return b
+
+
+def num_tiles(W: int, H: int):
+    return (W - 1) // TILE + 1, (H - 1) // TILE + 1
+
+
+class OracleCsm(C.Structure):
+    _fields_ = [("lightsMatrices", (C.c_float * 16) * 4), ("maps", C.c_void_p * 4), ("width", C.c_int32 * 4),
+                ("height", C.c_int32 * 4), ("format", C.c_int32 * 4)]
+
+
+def make_csm(lights_matrices: np.ndarray, maps: list) -> tuple[OracleCsm, list]:
+    """maps: 4 numpy arrays (float16[S,S] -> R16F, float32[S,S,4] -> RGBA32F, float32[S,S] -> R32F) or None."""
+    d = OracleCsm()
+    keep = []
+    lm = np.ascontiguousarray(lights_matrices, np.float32).reshape(4, 16)
+    for k in range(4):
+        for i in range(16):
+            d.lightsMatrices[k][i] = float(lm[k, i])
+        m = maps[k]
+        if m is None:
+            d.maps[k] = None
+            continue
+        m = np.ascontiguousarray(m)
+        keep.append(m)
+        d.maps[k] = m.ctypes.data
+        d.height[k], d.width[k] = m.shape[0], m.shape[1]
+        d.format[k] = 0 if m.dtype == np.float16 else (1 if m.ndim == 3 else 2)
+    return d, keep
+
+
+def light_cull(frame, W: int, H: int, lights: np.ndarray, depth: np.ndarray, tile_rows=None, literal_select: bool = False, want_counts: bool = False):
+    """-> (grid uint32[T,2], indices uint32[1+T*128], counts uint32[T] | None) for the band of tile rows."""
+    Tx, Ty = num_tiles(W, H)
+    r0, r1 = (0, Ty) if tile_rows is None else tile_rows
+    T = (r1 - r0) * Tx
+    fb = _frame_bytes(frame)
+    lights = np.ascontiguousarray(lights)
+    depth = np.ascontiguousarray(depth, np.float32)
+    assert depth.shape == (H, W) and lights.dtype.itemsize == 112
+    grid = np.zeros((max(T, 1), 2), np.uint32)
+    indices = np.zeros(1 + max(T, 1) * KEEP, np.uint32)
+    counts = np.zeros(max(T, 1), np.uint32) if want_counts else None
+    lib().oracle_light_cull(_p(fb), W, H, len(lights), _p(lights), _p(depth), _p(grid), _p(indices), _p(counts), r0, r1, int(literal_select))
+    return grid[:T], indices, (counts[:T] if want_counts else None)
+
+
+def shade(frame, W: int, H: int, surface: np.ndarray, lights: np.ndarray, grid: np.ndarray, indices: np.ndarray, csm=None, rows=None) -> np.ndarray:
+    """surface float32[3,H,W,4]; grid/indices in the global canonical layout -> radiance float32[H,W,4] (rows outside `rows` are 0)."""
+    fb = _frame_bytes(frame)
+    surface = np.ascontiguousarray(surface, np.float32)
+    assert surface.shape == (3, H, W, 4)
+    out = np.zeros((H, W, 4), np.float32)
+    r0, r1 = (0, H) if rows is None else rows
+    lights = np.ascontiguousarray(lights)
+    grid = np.ascontiguousarray(grid, np.uint32)
+    indices = np.ascontiguousarray(indices, np.uint32)
+    lib().oracle_shade(_p(fb), W, H, _p(surface), _p(lights), _p(grid), _p(indices), C.byref(csm) if csm is not None else None, _p(out), r0, r1)
+    return out
+
+
+def ecs_sweep(trs: np.ndarray, parent: np.ndarray, local_aabb: np.ndarray, planes: np.ndarray, begin: int = 0, end: int | None = None,
+              world=None, world_aabb=None, visibility=None):
+    n = len(parent)
+    end = n if end is None else end
+    trs = np.ascontiguousarray(trs, np.float32); parent = np.ascontiguousarray(parent, np.uint32)
+    local_aabb = np.ascontiguousarray(local_aabb, np.float32); planes = np.ascontiguousarray(planes, np.float32).reshape(24)
+    world = np.zeros((n, 16), np.float32) if world is None else world
+    world_aabb = np.zeros((n, 6), np.float32) if world_aabb is None else world_aabb
+    visibility = np.zeros((n + 63) // 64, np.uint64) if visibility is None else visibility
+    lib().oracle_ecs_sweep(C.c_uint32(begin), C.c_uint32(end), _p(trs), _p(parent), _p(local_aabb), _p(planes), _p(world), _p(world_aabb), _p(visibility))
+    return world, world_aabb, visibility
+
+
+def mesh_frustum_cull(frame, instances: np.ndarray) -> np.ndarray:
+    fb = _frame_bytes(frame)
+    inst = np.ascontiguousarray(instances).copy()
+    assert inst.dtype.itemsize == 96
+    lib().oracle_mesh_frustum_cull(_p(fb), _p(inst), C.c_uint32(len(inst)))
+    return inst
+
+
+def extract_frustum_planes(world_matrix, aspect, fov_y, z_near, z_far):
+    wm = np.ascontiguousarray(world_matrix, np.float32).reshape(16)
+    planes = np.zeros(24, np.float32); corners = np.zeros(24, np.float32)
+    lib().oracle_extract_frustum_planes(_p(wm), aspect, fov_y, z_near, z_far, _p(planes), _p(corners))
+    return planes.reshape(6, 4), corners.reshape(8, 3)
+
+
+def csm_matrices(light_view, camera_world, aspect, fov_y, near, far):
+    lv = np.ascontiguousarray(light_view, np.float32).reshape(16); cw = np.ascontiguousarray(camera_world, np.float32).reshape(16)
+    out = np.zeros(64, np.float32)
+    lib().oracle_csm_matrices(_p(lv), _p(cw), aspect, fov_y, near, far, _p(out), None)
+    return out.reshape(4, 16)
+
+
+def mat4_inverse(m):
+    m = np.ascontiguousarray(m, np.float32).reshape(16); out = np.zeros(16, np.float32)
+    lib().oracle_mat4_inverse(_p(m), _p(out))
+    return out
+
+
+def perspective_rh(fov_radians, aspect, z_near, z_far):
+    out = np.zeros(16, np.float32)
+    lib().oracle_perspective_rh_reversed_z(fov_radians, aspect, z_near, z_far, _p(out))
+    return out
+
+
+def transform_matrix(trs12):
+    t = np.ascontiguousarray(trs12, np.float32).reshape(12); out = np.zeros(16, np.float32)
+    lib().oracle_transform_matrix(_p(t), _p(out))
+    return out

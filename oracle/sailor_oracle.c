@@ -1,0 +1,1062 @@
+/*
+ * sailor_oracle.c -- CPU restatement of the reference's Forward+ lighting path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and there only
+ * as the checker / the CPU baseline -- never as the thing shipped or measured as the GPU path.
+ *
+ * PARITY UNPINNED: aantropov/Sailor ships no tests, golden vectors or fixtures for this path
+ *  and cannot be built here (Win32 + MSVC + Vulkan + un-vendored glm).
+ * This file therefore restates the algorithm from the reference's shader / C++ text, function by
+ * function, with the reference file:line each function follows.  The only reference-owned facts
+ * it can be checked against are the constants and layouts of SURVEY.md Appendix B (tests do so).
+ *
+ * Third-party arithmetic not present under /root/reference: glm (git submodule External/glm,
+ * .gitmodules:4-6, commit unrecorded).  The glm routines used by the path (mat4*mat4, mat4*vec4,
+ * inverse, perspectiveRH_ZO, orthoRH_NO, mat4_cast, translate, scale, normalize, cross, dot)
+ * are restated from glm's published algorithms (0.9.9 / 1.0 series headers) below.
+ *
+ * Canonical numeric rules: IEEE-754 binary32, round-to-nearest-even, NO FMA
+ * contraction (build with -ffp-contract=off -fno-fast-math), evaluation in the order written.
+ *   GLSL  mat4*vec4 :  ((c0*x + c1*y) + c2*z) + c3*w          (shader-side code)
+ *   glm   mat4*vec4 :  (c0*x + c1*y) + (c2*z + c3*w)          (host-side code, glm's own order)
+ *   dot3            :  (a.x*b.x + a.y*b.y) + a.z*b.z
+ *   length          :  sqrtf(dot)          normalize (GLSL) : v / length(v)
+ *   glm::normalize  :  v * (1.0f / sqrtf(dot(v,v)))
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <stdlib.h>
+#include <math.h>
+#include <float.h>
+#include <xmmintrin.h>
+#include <emmintrin.h>
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* Content/Shaders/Constants.glsl:13-15,23-24 ; FrameGraph/LightCullingNode.h:15-16 */
+#define TILE 16
+#define CAND 196
+#define KEEP 128
+#define NUM_CASCADES 4
+
+ORACLE_API int oracle_const_tile_size(void) { return TILE; }
+ORACLE_API int oracle_const_candidates_per_tile(void) { return CAND; }
+ORACLE_API int oracle_const_lights_per_tile(void) { return KEEP; }
+ORACLE_API int oracle_const_num_cascades(void) { return NUM_CASCADES; }
+/* Constants.glsl:24 (GLSL literal; the C++ side uses 1/20,1/10,1/3,1/2 -- ECS/LightingECS.h:66) */
+static const float kShadowCascadeLevelsGlsl[4] = { 0.05f, 0.1f, 0.333333f, 0.5f };
+static const float kShadowCascadeLevelsCpp[4] = { 1.0f / 20.0f, 1.0f / 10.0f, 1.0f / 3.0f, 1.0f / 2.0f };
+ORACLE_API float oracle_const_cascade_level_glsl(int i) { return kShadowCascadeLevelsGlsl[i]; }
+ORACLE_API float oracle_const_cascade_level_cpp(int i) { return kShadowCascadeLevelsCpp[i]; }
+
+/* ------------------------------------------------------------------------------------------- */
+/* Layouts                                                               */
+/* ------------------------------------------------------------------------------------------- */
+
+/* RHI/Types.h:751-761 -- 232 bytes */
+typedef struct {
+    float view[16];
+    float projection[16];
+    float invProjection[16];
+    float cameraPosition[4];
+    int32_t viewportSize[2];
+    float cameraZNearZFar[2];
+    float currentTime;
+    float deltaTime;
+} UboFrameData;
+
+/* Lighting.glsl:4-15 == ECS/LightingECS.h:71-81 -- std430, stride 112 */
+typedef struct {
+    uint32_t type;          /* @0  */
+    uint32_t shadowType;    /* @4  */
+    uint32_t _pad0[2];
+    float worldPosition[3]; /* @16 */
+    float _pad1;
+    float direction[3];     /* @32 */
+    float _pad2;
+    float intensity[3];     /* @48 */
+    float _pad3;
+    float attenuation[3];   /* @64 */
+    float _pad4;
+    float cutOff[2];        /* @80 */
+    float _pad5[2];
+    float bounds[3];        /* @96 */
+    float _pad6;
+} LightData;
+
+ORACLE_API int oracle_sizeof_ubo(void) { return (int)sizeof(UboFrameData); }
+ORACLE_API int oracle_sizeof_light(void) { return (int)sizeof(LightData); }
+ORACLE_API int oracle_offsetof_light(int field)
+{
+    switch (field) {
+    case 0: return (int)offsetof(LightData, type);
+    case 1: return (int)offsetof(LightData, shadowType);
+    case 2: return (int)offsetof(LightData, worldPosition);
+    case 3: return (int)offsetof(LightData, direction);
+    case 4: return (int)offsetof(LightData, intensity);
+    case 5: return (int)offsetof(LightData, attenuation);
+    case 6: return (int)offsetof(LightData, cutOff);
+    case 7: return (int)offsetof(LightData, bounds);
+    }
+    return -1;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Small vector helpers                                                                         */
+/* ------------------------------------------------------------------------------------------- */
+
+static inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline float length3(const float* a) { return sqrtf(dot3(a, a)); }
+static inline void cross3(const float* a, const float* b, float* o)
+{
+    /* GLSL / glm cross: (a.y*b.z - b.y*a.z, a.z*b.x - b.z*a.x, a.x*b.y - b.x*a.y) */
+    float x = a[1] * b[2] - b[1] * a[2];
+    float y = a[2] * b[0] - b[2] * a[0];
+    float z = a[0] * b[1] - b[0] * a[1];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void normalize3_glsl(const float* a, float* o)
+{
+    float l = length3(a);
+    o[0] = a[0] / l; o[1] = a[1] / l; o[2] = a[2] / l;
+}
+static inline void normalize3_glm(const float* a, float* o)
+{
+    /* glm::normalize(v) = v * inversesqrt(dot(v, v)); inversesqrt(x) = 1 / sqrt(x) */
+    float inv = 1.0f / sqrtf(dot3(a, a));
+    o[0] = a[0] * inv; o[1] = a[1] * inv; o[2] = a[2] * inv;
+}
+static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+/* column-major mat4: element (col c, row r) = m[c*4 + r] */
+static inline void glsl_mat4_mul_vec4(const float* m, const float* v, float* o)
+{
+    float r[4];
+    for (int i = 0; i < 4; i++)
+        r[i] = ((m[0 * 4 + i] * v[0] + m[1 * 4 + i] * v[1]) + m[2 * 4 + i] * v[2]) + m[3 * 4 + i] * v[3];
+    o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
+}
+static inline void glm_mat4_mul_vec4(const float* m, const float* v, float* o)
+{
+    /* glm type_mat4x4.inl operator*(mat4, vec4): Add0 = m0*v0 + m1*v1; Add1 = m2*v2 + m3*v3; Add0 + Add1 */
+    float r[4];
+    for (int i = 0; i < 4; i++)
+        r[i] = (m[0 * 4 + i] * v[0] + m[1 * 4 + i] * v[1]) + (m[2 * 4 + i] * v[2] + m[3 * 4 + i] * v[3]);
+    o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
+}
+static inline void glm_mat4_mul_mat4(const float* a, const float* b, float* o)
+{
+    /* glm operator*(mat4, mat4): Result[c] = A0*B[c][0] + A1*B[c][1] + A2*B[c][2] + A3*B[c][3], left to right */
+    float r[16];
+    for (int c = 0; c < 4; c++)
+        for (int i = 0; i < 4; i++)
+            r[c * 4 + i] = ((a[0 * 4 + i] * b[c * 4 + 0] + a[1 * 4 + i] * b[c * 4 + 1]) + a[2 * 4 + i] * b[c * 4 + 2]) + a[3 * 4 + i] * b[c * 4 + 3];
+    memcpy(o, r, sizeof r);
+}
+
+ORACLE_API void oracle_mat4_mul_mat4(const float* a, const float* b, float* o) { glm_mat4_mul_mat4(a, b, o); }
+
+/* glm::inverse(mat4) -- glm/detail/func_matrix.inl compute_inverse<4,4> (cofactor form).
+ * Call sites: ECS/CameraECS.cpp:20,33,38 ; Math/Bounds.cpp:113 ; ECS/LightingECS.cpp:227 */
+ORACLE_API void oracle_mat4_inverse(const float* m_, float* out)
+{
+#define M(c, r) m_[(c) * 4 + (r)]
+    float Coef00 = M(2, 2) * M(3, 3) - M(3, 2) * M(2, 3);
+    float Coef02 = M(1, 2) * M(3, 3) - M(3, 2) * M(1, 3);
+    float Coef03 = M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3);
+    float Coef04 = M(2, 1) * M(3, 3) - M(3, 1) * M(2, 3);
+    float Coef06 = M(1, 1) * M(3, 3) - M(3, 1) * M(1, 3);
+    float Coef07 = M(1, 1) * M(2, 3) - M(2, 1) * M(1, 3);
+    float Coef08 = M(2, 1) * M(3, 2) - M(3, 1) * M(2, 2);
+    float Coef10 = M(1, 1) * M(3, 2) - M(3, 1) * M(1, 2);
+    float Coef11 = M(1, 1) * M(2, 2) - M(2, 1) * M(1, 2);
+    float Coef12 = M(2, 0) * M(3, 3) - M(3, 0) * M(2, 3);
+    float Coef14 = M(1, 0) * M(3, 3) - M(3, 0) * M(1, 3);
+    float Coef15 = M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3);
+    float Coef16 = M(2, 0) * M(3, 2) - M(3, 0) * M(2, 2);
+    float Coef18 = M(1, 0) * M(3, 2) - M(3, 0) * M(1, 2);
+    float Coef19 = M(1, 0) * M(2, 2) - M(2, 0) * M(1, 2);
+    float Coef20 = M(2, 0) * M(3, 1) - M(3, 0) * M(2, 1);
+    float Coef22 = M(1, 0) * M(3, 1) - M(3, 0) * M(1, 1);
+    float Coef23 = M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1);
+
+    float Fac0[4] = { Coef00, Coef00, Coef02, Coef03 };
+    float Fac1[4] = { Coef04, Coef04, Coef06, Coef07 };
+    float Fac2[4] = { Coef08, Coef08, Coef10, Coef11 };
+    float Fac3[4] = { Coef12, Coef12, Coef14, Coef15 };
+    float Fac4[4] = { Coef16, Coef16, Coef18, Coef19 };
+    float Fac5[4] = { Coef20, Coef20, Coef22, Coef23 };
+
+    float Vec0[4] = { M(1, 0), M(0, 0), M(0, 0), M(0, 0) };
+    float Vec1[4] = { M(1, 1), M(0, 1), M(0, 1), M(0, 1) };
+    float Vec2[4] = { M(1, 2), M(0, 2), M(0, 2), M(0, 2) };
+    float Vec3[4] = { M(1, 3), M(0, 3), M(0, 3), M(0, 3) };
+
+    static const float SignA[4] = { +1, -1, +1, -1 };
+    static const float SignB[4] = { -1, +1, -1, +1 };
+    float Inv[16];
+    for (int i = 0; i < 4; i++) {
+        float Inv0 = (Vec1[i] * Fac0[i] - Vec2[i] * Fac1[i]) + Vec3[i] * Fac2[i];
+        float Inv1 = (Vec0[i] * Fac0[i] - Vec2[i] * Fac3[i]) + Vec3[i] * Fac4[i];
+        float Inv2 = (Vec0[i] * Fac1[i] - Vec1[i] * Fac3[i]) + Vec3[i] * Fac5[i];
+        float Inv3 = (Vec0[i] * Fac2[i] - Vec1[i] * Fac4[i]) + Vec2[i] * Fac5[i];
+        Inv[0 * 4 + i] = Inv0 * SignA[i];
+        Inv[1 * 4 + i] = Inv1 * SignB[i];
+        Inv[2 * 4 + i] = Inv2 * SignA[i];
+        Inv[3 * 4 + i] = Inv3 * SignB[i];
+    }
+    float Row0[4] = { Inv[0], Inv[4], Inv[8], Inv[12] };
+    float Dot0[4] = { M(0, 0) * Row0[0], M(0, 1) * Row0[1], M(0, 2) * Row0[2], M(0, 3) * Row0[3] };
+    float Dot1 = (Dot0[0] + Dot0[1]) + (Dot0[2] + Dot0[3]);
+    float OneOverDeterminant = 1.0f / Dot1;
+    for (int i = 0; i < 16; i++) out[i] = Inv[i] * OneOverDeterminant;
+#undef M
+}
+
+/* Math/Math.cpp:18-21: PerspectiveRH(fov, aspect, zNear, zFar) = glm::perspectiveRH(fov, aspect, zFar, zNear)
+ * under GLM_FORCE_DEPTH_ZERO_TO_ONE + GLM_FORCE_RIGHT_HANDED (Core/Defines.h:17-26) = perspectiveRH_ZO
+ * with near/far swapped (reversed Z). */
+ORACLE_API void oracle_perspective_rh_reversed_z(float fovRadians, float aspect, float zNear, float zFar, float* out)
+{
+    /* glm::perspectiveRH_ZO(fovy, aspect, zNear', zFar') with zNear' = zFar, zFar' = zNear */
+    const float n = zFar, f = zNear;
+    const float tanHalfFovy = tanf(fovRadians / 2.0f);
+    memset(out, 0, 16 * sizeof(float));
+    out[0 * 4 + 0] = 1.0f / (aspect * tanHalfFovy);
+    out[1 * 4 + 1] = 1.0f / (tanHalfFovy);
+    out[2 * 4 + 2] = f / (n - f);
+    out[2 * 4 + 3] = -1.0f;
+    out[3 * 4 + 2] = -(f * n) / (f - n);
+}
+
+/* glm::orthoRH_NO(left, right, bottom, top, zNear, zFar) -- glm/ext/matrix_clip_space.inl */
+static void ortho_rh_no(float left, float right, float bottom, float top, float zNear, float zFar, float* out)
+{
+    memset(out, 0, 16 * sizeof(float));
+    out[0] = 1.0f; out[5] = 1.0f; out[10] = 1.0f; out[15] = 1.0f;
+    out[0 * 4 + 0] = 2.0f / (right - left);
+    out[1 * 4 + 1] = 2.0f / (top - bottom);
+    out[2 * 4 + 2] = -2.0f / (zFar - zNear);
+    out[3 * 4 + 0] = -(right + left) / (right - left);
+    out[3 * 4 + 1] = -(top + bottom) / (top - bottom);
+    out[3 * 4 + 2] = -(zFar + zNear) / (zFar - zNear);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* K1 -- tile light cull: Content/Shaders/ComputeLightCulling.shader:49-240 under the canonical  */
+/* sequential semantics of SURVEY.md Appendix A                                                  */
+/* ------------------------------------------------------------------------------------------- */
+
+typedef struct {
+    float planes[4][4];
+    float center[2];
+} ViewFrustum; /* Math.glsl:116-120 */
+
+/* Math.glsl:143-154 ClipSpaceToViewSpace + :164-173 ScreenSpaceToViewSpace(vec4, vec2, mat4) */
+static void screen_space_to_view_space(const float* screen, int vpW, int vpH, const float* invProjection, float* out)
+{
+    float tx = screen[0] / (float)vpW;
+    float ty = screen[1] / (float)vpH;
+    float clip[4] = { tx * 2.0f - 1.0f, ty * 2.0f - 1.0f, screen[2], screen[3] };
+    float v[4];
+    glsl_mat4_mul_vec4(invProjection, clip, v);
+    float w = v[3];
+    v[0] = v[0] / w; v[1] = v[1] / w; v[2] = v[2] / w; v[3] = v[3] / w;
+    v[2] = v[2] * -1.0f;
+    out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+}
+
+/* Math.glsl:122-134 ComputePlane */
+static void compute_plane(const float* p0, const float* p1, const float* p2, float* plane)
+{
+    float v0[3] = { p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2] };
+    float v2[3] = { p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2] };
+    float c[3];
+    cross3(v0, v2, c);
+    normalize3_glsl(c, plane);
+    plane[3] = dot3(plane, p0);
+}
+
+/* ComputeLightCulling.shader:57-95 CreateFrustum(tileId); also Math.glsl:185-222 CreateViewFrustum when
+ * called with the whole viewport as one "tile" */
+static void create_frustum_rect(float x0, float y0, float x1, float y1, int vpW, int vpH, const float* invProjection, ViewFrustum* f)
+{
+    const float eye[3] = { 0.0f, 0.0f, 0.0f };
+    float ss[5][4] = {
+        { x0, y0, -1.0f, 1.0f }, /* "top left"     */
+        { x1, y0, -1.0f, 1.0f }, /* "top right"    */
+        { x0, y1, -1.0f, 1.0f }, /* "bottom left"  */
+        { x1, y1, -1.0f, 1.0f }, /* "bottom right" */
+        { 0, 0, 0, 0 }
+    };
+    for (int k = 0; k < 4; k++) ss[4][k] = (ss[0][k] + ss[3][k]) * 0.5f;
+    float vs[5][4];
+    for (int i = 0; i < 5; i++) screen_space_to_view_space(ss[i], vpW, vpH, invProjection, vs[i]);
+    compute_plane(eye, vs[2], vs[0], f->planes[0]); /* left   */
+    compute_plane(eye, vs[1], vs[3], f->planes[1]); /* right  */
+    compute_plane(eye, vs[0], vs[1], f->planes[2]); /* top    */
+    compute_plane(eye, vs[3], vs[2], f->planes[3]); /* bottom */
+    f->center[0] = vs[4][0];
+    f->center[1] = vs[4][1];
+}
+
+static void create_tile_frustum(int tx, int ty, int vpW, int vpH, const float* invProjection, ViewFrustum* f)
+{
+    /* ivec2 * int -> float conversions are exact for any sane viewport */
+    create_frustum_rect((float)(tx * TILE), (float)(ty * TILE), (float)((tx + 1) * TILE), (float)((ty + 1) * TILE),
+                        vpW, vpH, invProjection, f);
+}
+
+/* Math.glsl:224-239 */
+static int sphere_frustum_overlaps(const float* p, float radius, const ViewFrustum* f, float zNear, float zFar)
+{
+    if (p[2] - radius > zNear || p[2] + radius < zFar) return 0;
+    for (int i = 0; i < 4; i++)
+        if (dot3(f->planes[i], p) - f->planes[i][3] < -radius) return 0;
+    return 1;
+}
+
+ORACLE_API void oracle_tile_frustum(const void* ubo_, int tx, int ty, float* outPlanes16, float* outCenter2)
+{
+    const UboFrameData* ubo = (const UboFrameData*)ubo_;
+    ViewFrustum f;
+    create_tile_frustum(tx, ty, ubo->viewportSize[0], ubo->viewportSize[1], ubo->invProjection, &f);
+    memcpy(outPlanes16, f.planes, sizeof f.planes);
+    outCenter2[0] = f.center[0]; outCenter2[1] = f.center[1];
+}
+
+/* Appendix A step 1: depth bounds of one tile (ComputeLightCulling.shader:119-128).  The shader compares
+ * float BITS as uints (atomicMin/atomicMax on floatBitsToUint); reproduced literally. */
+static void tile_depth_bounds(const float* depth, int W, int H, int tx, int ty, float* outMin, float* outMax)
+{
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    for (int ly = 0; ly < TILE; ly++) {
+        int gy = TILE * ty + ly;
+        int row = H - 1 - gy;
+        if (row < 0) row = 0;
+        if (row > H - 1) row = H - 1;
+        for (int lx = 0; lx < TILE; lx++) {
+            int gx = TILE * tx + lx;
+            int col = gx < W - 1 ? gx : W - 1;
+            uint32_t bits;
+            memcpy(&bits, &depth[(size_t)row * W + col], 4);
+            if (bits > mx) mx = bits;
+            if (bits < mn) mn = bits;
+        }
+    }
+    memcpy(outMin, &mn, 4);
+    memcpy(outMax, &mx, 4);
+}
+
+ORACLE_API void oracle_tile_depth_bounds(const float* depth, int W, int H, int tx, int ty, float* outMinMax)
+{
+    tile_depth_bounds(depth, W, H, tx, ty, &outMinMax[0], &outMinMax[1]);
+}
+
+/* Appendix A step 4, literal form: ComputeLightCulling.shader:198-225 */
+static void select_literal_bubble(uint32_t* idx, float* imp, uint32_t n)
+{
+    uint32_t numSorted = KEEP;
+    for (uint32_t i = 0; i + 1 < n; i++) {
+        for (uint32_t j = 0; j < n - i - 1; j++) {
+            if (imp[j] < imp[j + 1]) {
+                float v = imp[j]; imp[j] = imp[j + 1]; imp[j + 1] = v;
+                uint32_t t = idx[j]; idx[j] = idx[j + 1]; idx[j + 1] = t;
+            }
+        }
+        --numSorted;
+        if (numSorted == 0) break;
+    }
+}
+
+/* Appendix A step 4, closed form: emitted list[i] (i < 128) = candidate of rank i under the total order
+ * (impact ascending, candidate position descending). */
+static void select_closed_form(const uint32_t* idx, const float* imp, uint32_t n, uint32_t* list)
+{
+    for (uint32_t k = 0; k < n; k++) {
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < n; q++)
+            if (imp[q] < imp[k] || (imp[q] == imp[k] && q > k)) rank++;
+        if (rank < KEEP) list[rank] = idx[k];
+    }
+}
+
+ORACLE_API void oracle_select_emit(const uint32_t* candIdx, const float* candImpact, uint32_t n, int literal, uint32_t* outList, uint32_t* outNum)
+{
+    uint32_t idx[CAND]; float imp[CAND];
+    memcpy(idx, candIdx, n * 4); memcpy(imp, candImpact, n * 4);
+    uint32_t num = n < KEEP ? n : KEEP;
+    if (n > KEEP && !literal) {
+        select_closed_form(idx, imp, n, outList);
+    } else {
+        if (n > KEEP) select_literal_bubble(idx, imp, n);
+        for (uint32_t i = 0; i < num; i++) outList[i] = idx[n - i - 1]; /* :235-238 */
+    }
+    *outNum = num;
+}
+
+/*
+ * Full light cull over tile rows [tileRowBegin, tileRowEnd).
+ *   outGrid      : 2 uints per tile of the band {offset, num}; offset = 1 + sum of num over earlier tiles of the band
+ *   outIndices   : [0] = sum of num over the band; [offset + i] = list[i]
+ *   outCandCount : optional, per tile: number of lights that PASS the test, uncapped (statistics only)
+ *   literalSelect: 1 = run the shader's partial bubble sort literally, 0 = closed form (must agree)
+ */
+ORACLE_API void oracle_light_cull(const void* ubo_, int W, int H, int lightsNum, const void* lights_, const float* depth,
+                                  uint32_t* outGrid, uint32_t* outIndices, uint32_t* outCandCount,
+                                  int tileRowBegin, int tileRowEnd, int literalSelect)
+{
+    const UboFrameData* ubo = (const UboFrameData*)ubo_;
+    const LightData* lights = (const LightData*)lights_;
+    const int Tx = (W - 1) / TILE + 1; /* FrameGraph/LightCullingNode.cpp:56-57 */
+    const int vpW = ubo->viewportSize[0], vpH = ubo->viewportSize[1];
+
+    /* the per-light view transform does not depend on the tile (ComputeLightCulling.shader:164-169) */
+    float* pv = (float*)malloc((size_t)(lightsNum > 0 ? lightsNum : 1) * 4 * sizeof(float));
+    for (int j = 0; j < lightsNum; j++) {
+        float wp[4] = { lights[j].worldPosition[0], lights[j].worldPosition[1], lights[j].worldPosition[2], 1.0f };
+        float p[4];
+        glsl_mat4_mul_vec4(ubo->view, wp, p);
+        float w = p[3];
+        p[0] = p[0] / w; p[1] = p[1] / w; p[2] = p[2] / w; p[3] = p[3] / w;
+        p[2] = p[2] * -1.0f;
+        memcpy(&pv[j * 4], p, 16);
+    }
+
+    uint32_t running = 0;
+    for (int ty = tileRowBegin; ty < tileRowEnd; ty++) {
+        for (int tx = 0; tx < Tx; tx++) {
+            const int bandTile = (ty - tileRowBegin) * Tx + tx;
+            float minD, maxD;
+            tile_depth_bounds(depth, W, H, tx, ty, &minD, &maxD);
+            ViewFrustum fr;
+            create_tile_frustum(tx, ty, vpW, vpH, ubo->invProjection, &fr);
+
+            /* :171-177 "Add extra bounds" -- swaps near and far, in fp32 */
+            float zFar = maxD, zNear = minD;
+            const float diff = zFar - zNear;
+            zFar -= diff;
+            zNear += diff;
+
+            uint32_t candIdx[CAND]; float candImp[CAND];
+            uint32_t count = 0, passing = 0;
+            for (int j = 0; j < lightsNum; j++) {
+                int pass; float impact;
+                if (lights[j].type == 0) { pass = 1; impact = 0.0f; } /* :153-162 */
+                else {
+                    const float radius = lights[j].bounds[0];
+                    const float* p = &pv[j * 4];
+                    pass = sphere_frustum_overlaps(p, radius, &fr, zNear, zFar);
+                    if (pass) {
+                        float c[3] = { fr.center[0], fr.center[1], (zFar + zNear) * 0.5f };
+                        float d[3] = { p[0] - c[0], p[1] - c[1], p[2] - c[2] };
+                        impact = length3(d); /* :187 */
+                    } else impact = 0.0f;
+                }
+                if (pass) {
+                    passing++;
+                    if (count < CAND) { candIdx[count] = (uint32_t)j; candImp[count] = impact; count++; }
+                    if (count == CAND && !outCandCount) break; /* canonical early-out (:147) */
+                }
+            }
+            uint32_t list[KEEP], num;
+            oracle_select_emit(candIdx, candImp, count, literalSelect, list, &num);
+            const uint32_t offset = running + 1; /* :229 canonicalised: prefix sum in tile order */
+            outGrid[2 * bandTile + 0] = offset;
+            outGrid[2 * bandTile + 1] = num;
+            for (uint32_t i = 0; i < num; i++) outIndices[offset + i] = list[i];
+            running += num;
+            if (outCandCount) outCandCount[bandTile] = passing;
+        }
+    }
+    outIndices[0] = running;
+    free(pv);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* K2 + K3 -- shade over per-tile lists with CSM: Standard.shader:253-341,377-439 ;             */
+/* Lighting.glsl:39-76,168-284                                                                  */
+/* ------------------------------------------------------------------------------------------- */
+
+enum { MAP_R16F = 0, MAP_RGBA32F = 1, MAP_R32F = 2 };
+
+typedef struct {
+    float lightsMatrices[NUM_CASCADES][16]; /* Standard.shader:223-226 (binding 6) */
+    const void* maps[NUM_CASCADES];         /* Standard.shader:233 shadowMaps[cascade] */
+    int32_t width[NUM_CASCADES];
+    int32_t height[NUM_CASCADES];
+    int32_t format[NUM_CASCADES];
+} OracleCsm;
+
+static inline float half_to_float(uint16_t h)
+{
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1Fu;
+    uint32_t man = h & 0x3FFu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else { /* subnormal */
+            int e = -1;
+            do { e++; man <<= 1; } while ((man & 0x400u) == 0);
+            bits = sign | (uint32_t)(127 - 15 - e) << 23 | ((man & 0x3FFu) << 13);
+        }
+    } else if (exp == 31) bits = sign | 0x7F800000u | (man << 13);
+    else bits = sign | ((exp + 112u) << 23) | (man << 13);
+    float f; memcpy(&f, &bits, 4); return f;
+}
+
+static inline void fetch_texel(const void* map, int fmt, int W, int x, int y, float* rgba)
+{
+    size_t i = (size_t)y * W + x;
+    if (fmt == MAP_R16F) { rgba[0] = half_to_float(((const uint16_t*)map)[i]); rgba[1] = 0; rgba[2] = 0; rgba[3] = 1; }
+    else if (fmt == MAP_R32F) { rgba[0] = ((const float*)map)[i]; rgba[1] = 0; rgba[2] = 0; rgba[3] = 1; }
+    else { const float* p = &((const float*)map)[i * 4]; rgba[0] = p[0]; rgba[1] = p[1]; rgba[2] = p[2]; rgba[3] = p[3]; }
+}
+
+/* texture(sampler2D, uv): bilinear, clamp-to-edge (ECS/LightingECS.cpp:58-60: Linear + Clamp), fp32 weights.
+ * Canonical order: top = t00*(1-ax) + t10*ax ; bot = t01*(1-ax) + t11*ax ; top*(1-ay) + bot*ay */
+static void sample_bilinear(const void* map, int fmt, int W, int H, float u, float v, float* rgba)
+{
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    float fx = floorf(x), fy = floorf(y);
+    float ax = x - fx, ay = y - fy;
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1);
+    y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+    float t00[4], t10[4], t01[4], t11[4];
+    fetch_texel(map, fmt, W, x0, y0, t00); fetch_texel(map, fmt, W, x1, y0, t10);
+    fetch_texel(map, fmt, W, x0, y1, t01); fetch_texel(map, fmt, W, x1, y1, t11);
+    const int nc = fmt == MAP_RGBA32F ? 4 : 1;
+    for (int c = 0; c < nc; c++) {
+        float top = t00[c] * (1.0f - ax) + t10[c] * ax;
+        float bot = t01[c] * (1.0f - ax) + t11[c] * ax;
+        rgba[c] = top * (1.0f - ay) + bot * ay;
+    }
+    for (int c = nc; c < 4; c++) rgba[c] = c == 3 ? 1.0f : 0.0f;
+}
+
+/* exp() for the EVSM warp (Lighting.glsl:277-278).  GLSL exp precision is implementation-defined; the compared
+ * quantity d = exp(40 z) - moment is ill-conditioned, so the path is specified with ONE fixed fp32 algorithm
+ * (Cephes-style range reduction + degree-5 polynomial, no FMA) that both sides evaluate bit-identically. */
+static float canonical_expf(float x)
+{
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) x = -87.0f;
+    float n = floorf(x * 1.44269504088896341f + 0.5f);
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    float y = (p * z + r) + 1.0f;
+    return ldexpf(y, (int)n);
+}
+ORACLE_API float oracle_canonical_expf(float x) { return canonical_expf(x); }
+
+/* Lighting.glsl:168-197 */
+static const float kPoissonDisk[16][2] = {
+    { -0.94201624f, -0.39906216f }, { 0.94558609f, -0.76890725f },
+    { -0.094184101f, -0.92938870f }, { 0.34495938f, 0.29387760f },
+    { -0.91588581f, 0.45771432f }, { -0.81544232f, -0.87912464f },
+    { -0.38277543f, 0.27676845f }, { 0.97484398f, 0.75648379f },
+    { 0.44323325f, -0.97511554f }, { 0.53742981f, -0.47373420f },
+    { -0.26496911f, -0.41893023f }, { 0.79197514f, 0.19090188f },
+    { -0.24188840f, 0.99706507f }, { -0.81409955f, 0.91437590f },
+    { 0.19984126f, 0.78641367f }, { 0.14383161f, -0.14100790f }
+};
+ORACLE_API float oracle_const_poisson(int i, int c) { return kPoissonDisk[i][c]; }
+
+static float manual_pcf(const void* map, int fmt, int W, int H, const float* projCoords, float currentDepth, float bias)
+{
+    float shadow = 0.0f;
+    float texel[2] = { 1.0f / (float)W, 1.0f / (float)H };
+    const float radius = 2.0f;
+    for (int i = 0; i < 16; i++) {
+        float ox = kPoissonDisk[i][0] * radius * texel[0];
+        float oy = kPoissonDisk[i][1] * radius * texel[1];
+        float t[4];
+        sample_bilinear(map, fmt, W, H, projCoords[0] + ox, projCoords[1] + oy, t);
+        float pcfDepth = t[0] * 0.5f + 0.5f;
+        shadow += (currentDepth + bias > pcfDepth) ? 1.0f : 0.0f;
+    }
+    shadow /= 16.0f;
+    return shadow;
+}
+
+/* Lighting.glsl:242-261 */
+static float shadow_pcf(const void* map, int fmt, int W, int H, const float* fragPosLightSpace, float bias)
+{
+    float pc[3] = { fragPosLightSpace[0] / fragPosLightSpace[3], fragPosLightSpace[1] / fragPosLightSpace[3], fragPosLightSpace[2] / fragPosLightSpace[3] };
+    pc[0] = pc[0] * 0.5f + 0.5f; pc[1] = pc[1] * 0.5f + 0.5f; pc[2] = pc[2] * 0.5f + 0.5f;
+    pc[1] = 1.0f - pc[1];
+    if (pc[0] > 1.0f || pc[1] > 1.0f || pc[0] < 0.0f || pc[1] < 0.0f || pc[2] < 0.5f) return 1.0f;
+    return manual_pcf(map, fmt, W, H, pc, pc[2], bias);
+}
+
+/* Lighting.glsl:218-240 */
+static float chebyshev(float m0, float m1, float currentDepth, float minVariance, float lin)
+{
+    float d = currentDepth - m0;
+    if (d < 0) return 1.0f;
+    float variance = fmaxf(minVariance, m1 - m0 * m0);
+    float pmax = variance / (variance + d * d);
+    return clampf((pmax - lin) / (1.0f - lin), 0.0f, 1.0f);
+}
+
+/* Lighting.glsl:263-284 */
+static float shadow_evsm(const void* map, int fmt, int W, int H, const float* fragPosLightSpace, float bias, int cascadeLayer)
+{
+    float pc[3] = { fragPosLightSpace[0] / fragPosLightSpace[3], fragPosLightSpace[1] / fragPosLightSpace[3], fragPosLightSpace[2] / fragPosLightSpace[3] };
+    pc[0] = pc[0] * 0.5f + 0.5f; pc[1] = pc[1] * 0.5f + 0.5f;
+    pc[1] = 1.0f - pc[1];
+    if (pc[0] > 1.0f || pc[1] > 1.0f || pc[0] < 0.0f || pc[1] < 0.0f || pc[2] < 0.0f) return 1.0f;
+    float s[4];
+    sample_bilinear(map, fmt, W, H, pc[0], pc[1], s);
+    float p05 = 1.0f; /* pow(0.5, cascadeLayer) -- exact powers of two */
+    for (int i = 0; i < cascadeLayer; i++) p05 = p05 * 0.5f;
+    const float currentDepth = canonical_expf(40.0f * (pc[2] + 0.003f * bias * p05));
+    const float negCurrentDepth = -canonical_expf(-40.0f * (pc[2] + 0.0001f * bias));
+    float posValue = chebyshev(s[0], s[1], currentDepth, 0.01f, 0.0f);
+    float negValue = chebyshev(s[2], s[3], negCurrentDepth, 0.0f, 0.0f) * (cascadeLayer > 2 ? 0.0f : 1.0f);
+    return clampf(1.0f - fmaxf(posValue, negValue), 0.0f, 1.0f);
+}
+
+/* Lighting.glsl:200-216 */
+static int select_cascade(const float* view, const float* worldPos, const float* zNearZFar)
+{
+    float wp[4] = { worldPos[0], worldPos[1], worldPos[2], 1.0f }, p[4];
+    glsl_mat4_mul_vec4(view, wp, p);
+    float depthValue = fabsf(p[2] / p[3]);
+    int layer = NUM_CASCADES;
+    for (int i = 0; i < NUM_CASCADES; i++)
+        if (depthValue < zNearZFar[1] * kShadowCascadeLevelsGlsl[i]) { layer = i; break; }
+    return layer;
+}
+
+/* Shadow factor of a directional light (Standard.shader:266-283).  Returns the cascade in *outCascade. */
+static float directional_shadow(const UboFrameData* ubo, const LightData* L, const OracleCsm* csm, const float* normal, const float* worldPos, int* outCascade)
+{
+    int cascade = select_cascade(ubo->view, worldPos, ubo->cameraZNearZFar);
+    if (cascade > NUM_CASCADES - 1) cascade = NUM_CASCADES - 1;
+    if (outCascade) *outCascade = cascade;
+    if (!csm || !csm->maps[cascade]) return 1.0f; /* no shadow maps bound: synthetic frames without CSM */
+    float wp[4] = { worldPos[0], worldPos[1], worldPos[2], 1.0f }, lp[4];
+    glsl_mat4_mul_vec4(csm->lightsMatrices[cascade], wp, lp);
+    const float ndl = dot3(normal, L->direction);
+    if (L->shadowType == 2 && cascade == 0) {
+        const float bias = (1.0f - ndl) * (float)(1 + cascade);
+        return shadow_evsm(csm->maps[cascade], csm->format[cascade], csm->width[cascade], csm->height[cascade], lp, bias, cascade);
+    }
+    const float bias = fmaxf(0.000075f * (1.0f - ndl), 0.000005f);
+    return shadow_pcf(csm->maps[cascade], csm->format[cascade], csm->width[cascade], csm->height[cascade], lp, bias);
+}
+
+ORACLE_API float oracle_directional_shadow(const void* ubo, const void* light, const void* csm, const float* normal, const float* worldPos, int* outCascade)
+{
+    return directional_shadow((const UboFrameData*)ubo, (const LightData*)light, (const OracleCsm*)csm, normal, worldPos, outCascade);
+}
+
+/* Lighting.glsl:41-76 */
+static float ndf_ggx(float cosLh, float roughness)
+{
+    float alpha = roughness * roughness;
+    float alphaSq = alpha * alpha;
+    float denom = (cosLh * cosLh) * (alphaSq - 1.0f) + 1.0f;
+    return alphaSq / (3.14159265359f * denom * denom);
+}
+static float geometry_schlick_g1(float cosTheta, float k) { return cosTheta / (cosTheta * (1.0f - k) + k); }
+static float geometry_schlick_ggx(float cosLi, float cosLo, float roughness)
+{
+    float r = roughness + 1.0f;
+    float k = (r * r) / 8.0f;
+    return geometry_schlick_g1(cosLi, k) * geometry_schlick_g1(cosLo, k);
+}
+
+/* Standard.shader:259-341 */
+static void calculate_lighting(const UboFrameData* ubo, const LightData* L, const OracleCsm* csm,
+                               const float* albedo, float metallic, float roughness,
+                               const float* F0, const float* Lo, float cosLo, const float* normal, const float* worldPos, float* out)
+{
+    float falloff = 1.0f, shadow = 1.0f;
+    if (L->type == 0) {
+        shadow = directional_shadow(ubo, L, csm, normal, worldPos, NULL);
+    } else if (L->type == 1) {
+        float d[3] = { L->worldPosition[0] - worldPos[0], L->worldPosition[1] - worldPos[1], L->worldPosition[2] - worldPos[2] };
+        const float distance = length3(d);
+        const float attenuation = 1.0f / (L->attenuation[0] + L->attenuation[1] * distance + L->attenuation[2] * (distance * distance));
+        falloff = attenuation * (1.0f - powf(clampf(distance / L->bounds[0], 0.0f, 1.0f), 2.0f));
+    } else if (L->type == 2) {
+        float d[3] = { L->worldPosition[0] - worldPos[0], L->worldPosition[1] - worldPos[1], L->worldPosition[2] - worldPos[2] };
+        float lightDir[3]; normalize3_glsl(d, lightDir);
+        float epsilon = L->cutOff[0] - L->cutOff[1];
+        float nd[3] = { -L->direction[0], -L->direction[1], -L->direction[2] }, ndn[3];
+        normalize3_glsl(nd, ndn);
+        float theta = dot3(lightDir, ndn);
+        const float distance = length3(d);
+        const float attenuation = 1.0f / (L->attenuation[0] + L->attenuation[1] * distance + L->attenuation[2] * (distance * distance));
+        falloff = attenuation * clampf((theta - L->cutOff[1]) / epsilon, 0.0f, 1.0f);
+        if (theta < L->cutOff[1]) falloff = 0.0f;
+    }
+    float Li[3] = { -L->direction[0], -L->direction[1], -L->direction[2] };
+    float s[3] = { Li[0] + Lo[0], Li[1] + Lo[1], Li[2] + Lo[2] }, Lh[3];
+    normalize3_glsl(s, Lh);
+    float cosLi = fmaxf(0.0f, dot3(normal, Li));
+    float cosLh = fmaxf(0.0f, dot3(normal, Lh));
+    float f5 = powf(1.0f - fmaxf(0.0f, dot3(Lh, Lo)), 5.0f);
+    float F[3];
+    for (int c = 0; c < 3; c++) F[c] = F0[c] + (1.0f - F0[c]) * f5;
+    float D = ndf_ggx(cosLh, roughness);
+    float G = geometry_schlick_ggx(cosLi, cosLo, roughness);
+    float denom = fmaxf(0.00001f, 4.0f * cosLi * cosLo);
+    for (int c = 0; c < 3; c++) {
+        float kd = (1.0f - F[c]) * (1.0f - metallic) + 0.0f * metallic; /* mix(1-F, 0, metallic) */
+        float diffuse = kd * albedo[c];
+        float specular = (F[c] * D * G) / denom;
+        out[c] = shadow * ((diffuse + specular) * L->intensity[c] * cosLi) * falloff;
+    }
+}
+
+/*
+ * Shade framebuffer rows [fbRowBegin, fbRowEnd).  surface = 3 planes of W*H float4 (plane-major):
+ *   P0 = (worldPos.xyz, albedo.a)  P1 = (normal.xyz, roughness)  P2 = (albedo.rgb, metallic)   
+ * out = W*H float4 (rgb = sum of lights, ambient == 0; a = albedo.a -- Standard.shader:425-438).
+ * grid/indices are in the GLOBAL canonical layout (tile index = ty*Tx + tx).
+ */
+ORACLE_API void oracle_shade(const void* ubo_, int W, int H, const float* surface, const void* lights_,
+                             const uint32_t* grid, const uint32_t* indices, const void* csm_, float* out,
+                             int fbRowBegin, int fbRowEnd)
+{
+    const UboFrameData* ubo = (const UboFrameData*)ubo_;
+    const LightData* lights = (const LightData*)lights_;
+    const OracleCsm* csm = (const OracleCsm*)csm_;
+    const size_t plane = (size_t)W * H * 4;
+    const int vpW = ubo->viewportSize[0], vpH = ubo->viewportSize[1];
+    /* Standard.shader:413-420 */
+    const int numTilesX = vpW / TILE + ((vpW % TILE) < 1 ? (vpW % TILE) : 1);
+    for (int py = fbRowBegin; py < fbRowEnd; py++) {
+        for (int px = 0; px < W; px++) {
+            const size_t pix = ((size_t)py * W + px) * 4;
+            const float* P0 = &surface[pix];
+            const float* P1 = &surface[plane + pix];
+            const float* P2 = &surface[2 * plane + pix];
+            const float worldPos[3] = { P0[0], P0[1], P0[2] };
+            const float normal[3] = { P1[0], P1[1], P1[2] };
+            const float roughness = P1[3], metallic = P2[3];
+            const float albedo[3] = { P2[0], P2[1], P2[2] };
+            float vd[3] = { worldPos[0] - ubo->cameraPosition[0], worldPos[1] - ubo->cameraPosition[1], worldPos[2] - ubo->cameraPosition[2] };
+            float viewDir[3]; normalize3_glsl(vd, viewDir);
+            float Lo[3] = { -viewDir[0], -viewDir[1], -viewDir[2] };
+            float cosLo = fmaxf(0.0f, dot3(normal, Lo));
+            float F0[3];
+            for (int c = 0; c < 3; c++) F0[c] = 0.04f * (1.0f - metallic) + albedo[c] * metallic; /* mix(Fdielectric, albedo, metallic) */
+            /* gl_FragCoord = (px + 0.5, py + 0.5), origin upper-left */
+            const float fragX = (float)px + 0.5f, fragY = (float)py + 0.5f;
+            const int sx = (int)fragX, sy = (int)((float)vpH - fragY);
+            const int tileX = sx / TILE, tileY = sy / TILE;
+            const uint32_t tileIndex = (uint32_t)(tileY * numTilesX + tileX);
+            const uint32_t offset = grid[2 * tileIndex + 0];
+            const uint32_t numLights = grid[2 * tileIndex + 1];
+            float acc[3] = { 0.0f, 0.0f, 0.0f };
+            for (uint32_t i = 0; i < numLights; i++) {
+                uint32_t index = indices[offset + i];
+                if (index == 0xFFFFFFFFu) break;
+                float c[3];
+                calculate_lighting(ubo, &lights[index], csm, albedo, metallic, roughness, F0, Lo, cosLo, normal, worldPos, c);
+                acc[0] += c[0]; acc[1] += c[1]; acc[2] += c[2];
+            }
+            out[pix + 0] = acc[0]; out[pix + 1] = acc[1]; out[pix + 2] = acc[2]; out[pix + 3] = P0[3];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* K4 + CPU baseline -- ECS transform sweep, bounds update and frustum cull                      */
+/* ------------------------------------------------------------------------------------------- */
+
+/* Math/Transform.cpp:39-42: translate(I, pos) * toMat4(rot) * scale(I, scale).
+ * trs = { vec4 position, quat rotation (memory x,y,z,w), vec4 scale } = 48 B (Math/Transform.h) */
+static void transform_matrix(const float* trs, float* out)
+{
+    const float* pos = trs; const float* q = trs + 4; const float* sc = trs + 8;
+    /* glm::translate(mat4(1), v): Result[3] = m[0]*v[0] + m[1]*v[1] + m[2]*v[2] + m[3] */
+    float T[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+    for (int i = 0; i < 4; i++) {
+        float I0 = (i == 0), I1 = (i == 1), I2 = (i == 2), I3 = (i == 3);
+        T[12 + i] = ((I0 * pos[0] + I1 * pos[1]) + I2 * pos[2]) + I3;
+    }
+    /* glm::mat4_cast(quat) -- gtc/quaternion.inl mat3_cast */
+    const float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+    float qxx = qx * qx, qyy = qy * qy, qzz = qz * qz, qxz = qx * qz, qxy = qx * qy, qyz = qy * qz, qwx = qw * qx, qwy = qw * qy, qwz = qw * qz;
+    float R[16] = { 0 };
+    R[0] = 1.0f - 2.0f * (qyy + qzz); R[1] = 2.0f * (qxy + qwz); R[2] = 2.0f * (qxz - qwy);
+    R[4] = 2.0f * (qxy - qwz); R[5] = 1.0f - 2.0f * (qxx + qzz); R[6] = 2.0f * (qyz + qwx);
+    R[8] = 2.0f * (qxz + qwy); R[9] = 2.0f * (qyz - qwx); R[10] = 1.0f - 2.0f * (qxx + qyy);
+    R[15] = 1.0f;
+    /* glm::scale(mat4(1), v): Result[i] = m[i] * v[i], Result[3] = m[3] */
+    float S[16] = { 0 };
+    for (int i = 0; i < 4; i++) {
+        S[0 + i] = (float)(i == 0) * sc[0];
+        S[4 + i] = (float)(i == 1) * sc[1];
+        S[8 + i] = (float)(i == 2) * sc[2];
+    }
+    S[15] = 1.0f;
+    float TR[16];
+    glm_mat4_mul_mat4(T, R, TR);
+    glm_mat4_mul_mat4(TR, S, out);
+}
+ORACLE_API void oracle_transform_matrix(const float* trs, float* out) { transform_matrix(trs, out); }
+
+/* Math/Bounds.cpp:479-492 AABB::Apply + Bounds.h:119-130 GetPoints.  aabb = {min.xyz, max.xyz}.
+ * Quirk reproduced: m_max is seeded with numeric_limits<float>::min() (smallest POSITIVE float). */
+static void aabb_apply(const float* aabb, const float* M, float* out)
+{
+    const float* mn = aabb; const float* mx = aabb + 3;
+    const float pts[8][3] = {
+        { mn[0], mn[1], mn[2] }, { mx[0], mx[1], mx[2] }, { mn[0], mx[1], mx[2] }, { mx[0], mn[1], mx[2] },
+        { mx[0], mx[1], mn[2] }, { mx[0], mn[1], mn[2] }, { mn[0], mx[1], mn[2] }, { mn[0], mn[1], mx[2] }
+    };
+    float omax[3] = { FLT_MIN, FLT_MIN, FLT_MIN };
+    float omin[3] = { FLT_MAX, FLT_MAX, FLT_MAX };
+    for (int k = 0; k < 8; k++) {
+        float v[4] = { pts[k][0], pts[k][1], pts[k][2], 1.0f }, t[4];
+        glm_mat4_mul_vec4(M, v, t);
+        for (int c = 0; c < 3; c++) {
+            /* Extend: m_min = glm::min(inner, m_min) = (m_min < inner) ? m_min : inner ; m_max = glm::max(inner, m_max) = (inner < m_max) ? m_max : inner */
+            omin[c] = (omin[c] < t[c]) ? omin[c] : t[c];
+            omax[c] = (t[c] < omax[c]) ? omax[c] : t[c];
+        }
+    }
+    out[0] = omin[0]; out[1] = omin[1]; out[2] = omin[2];
+    out[3] = omax[0]; out[4] = omax[1]; out[5] = omax[2];
+}
+ORACLE_API void oracle_aabb_apply(const float* aabb, const float* M, float* out) { aabb_apply(aabb, M, out); }
+
+static inline float glm_dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+static void plane_from_normal_point(const float* n, const float* p, float* plane)
+{
+    /* Bounds.h:80-87 Plane(normal, point): w = -dot(point, normal) */
+    plane[0] = n[0]; plane[1] = n[1]; plane[2] = n[2];
+    plane[3] = -glm_dot3(p, n);
+}
+static void plane_normalize(float* plane)
+{
+    /* Bounds.cpp:9-13 */
+    const float mag = sqrtf(glm_dot3(plane, plane));
+    plane[0] /= mag; plane[1] /= mag; plane[2] /= mag; plane[3] /= mag;
+}
+
+/* Math/Bounds.cpp:142-193 Frustum::ExtractFrustumPlanes(worldMatrix, aspect, fovY[deg], zNear, zFar).
+ * outPlanes: 6 x vec4 (L,R,T,B,N,F), outCorners: 8 x vec3 (may be NULL). */
+ORACLE_API void oracle_extract_frustum_planes(const float* worldMatrix, float aspect, float fovY, float zNear, float zFar, float* outPlanes, float* outCorners)
+{
+    const float radians = fovY * 0.01745329251994329576923690768489f; /* glm::radians */
+    const float halfVSide = zFar * tanf(radians * .5f);
+    const float halfHSide = halfVSide * aspect;
+    const float right[3] = { worldMatrix[0], worldMatrix[1], worldMatrix[2] };
+    const float up[3] = { worldMatrix[4], worldMatrix[5], worldMatrix[6] };
+    const float forward[3] = { -worldMatrix[8], -worldMatrix[9], -worldMatrix[10] };
+    const float pos[3] = { worldMatrix[12], worldMatrix[13], worldMatrix[14] };
+    float frontMultFar[3], t[3], u[3], c[3], n[3];
+    for (int i = 0; i < 3; i++) frontMultFar[i] = zFar * forward[i];
+
+    for (int i = 0; i < 3; i++) t[i] = pos[i] + forward[i] * zNear;
+    plane_from_normal_point(forward, t, outPlanes + 4 * 4);
+    for (int i = 0; i < 3; i++) { t[i] = pos[i] + forward[i] * zFar; u[i] = -forward[i]; }
+    plane_from_normal_point(u, t, outPlanes + 5 * 4);
+
+    for (int i = 0; i < 3; i++) t[i] = frontMultFar[i] - right[i] * halfHSide;
+    cross3(t, up, c); normalize3_glm(c, n); plane_from_normal_point(n, pos, outPlanes + 0 * 4);     /* left  */
+    for (int i = 0; i < 3; i++) t[i] = frontMultFar[i] + right[i] * halfHSide;
+    cross3(up, t, c); normalize3_glm(c, n); plane_from_normal_point(n, pos, outPlanes + 1 * 4);     /* right */
+    for (int i = 0; i < 3; i++) t[i] = frontMultFar[i] - up[i] * halfVSide;
+    cross3(right, t, c); normalize3_glm(c, n); plane_from_normal_point(n, pos, outPlanes + 3 * 4);  /* bottom */
+    for (int i = 0; i < 3; i++) t[i] = frontMultFar[i] + up[i] * halfVSide;
+    cross3(t, right, c); normalize3_glm(c, n); plane_from_normal_point(n, pos, outPlanes + 2 * 4);  /* top   */
+
+    for (int i = 0; i < 6; i++) plane_normalize(outPlanes + 4 * i);
+
+    if (outCorners) {
+        const float halfVSideNear = zNear * tanf(radians * .5f);
+        const float halfHSideNear = halfVSideNear * aspect;
+        const float sgn[4][2] = { { +1, +1 }, { -1, +1 }, { -1, -1 }, { +1, -1 } };
+        for (int k = 0; k < 8; k++) {
+            const int far_ = k < 4;
+            const float hx = far_ ? halfHSide : halfHSideNear, hy = far_ ? halfVSide : halfVSideNear;
+            const float z = far_ ? -zFar : -zNear;
+            /* farEnd +- endSizeHorizontal +- endSizeVertical, componentwise, left to right */
+            float v[4] = { (0.0f + sgn[k & 3][0] * hx) + 0.0f, (0.0f + 0.0f) + sgn[k & 3][1] * hy, (z + 0.0f) + 0.0f, 1.0f }, r[4];
+            glm_mat4_mul_vec4(worldMatrix, v, r);
+            outCorners[3 * k + 0] = r[0]; outCorners[3 * k + 1] = r[1]; outCorners[3 * k + 2] = r[2];
+        }
+    }
+}
+
+/* Math/Bounds.cpp:245-260 Frustum::OverlapsAABB(const AABB&) */
+static inline int overlaps_aabb(const float* planes, const float* aabb)
+{
+    int inside = 1;
+    for (int i = 0; i < 6; i++) {
+        const float* p = planes + 4 * i;
+        float ax = aabb[0] * p[0], bx = aabb[3] * p[0];
+        float ay = aabb[1] * p[1], by = aabb[4] * p[1];
+        float az = aabb[2] * p[2], bz = aabb[5] * p[2];
+        const float d = (ax < bx ? bx : ax) + (ay < by ? by : ay) + (az < bz ? bz : az) + p[3];
+        inside &= d > 0;
+    }
+    return inside;
+}
+ORACLE_API int oracle_overlaps_aabb(const float* planes, const float* aabb) { return overlaps_aabb(planes, aabb); }
+
+/* Math/Bounds.cpp:211-243 Frustum::OverlapsSphere / ContainsSphere (scalar) */
+ORACLE_API int oracle_overlaps_sphere(const float* planes, const float* sphere)
+{
+    int res = 1;
+    for (int p = 0; p < 6; p++)
+        if (planes[4 * p + 0] * sphere[0] + planes[4 * p + 1] * sphere[1] + planes[4 * p + 2] * sphere[2] + planes[4 * p + 3] < -sphere[3]) res = 0;
+    return res;
+}
+ORACLE_API int oracle_contains_sphere(const float* planes, const float* sphere)
+{
+    int res = 1;
+    for (int p = 0; p < 6; p++)
+        if (planes[4 * p + 0] * sphere[0] + planes[4 * p + 1] * sphere[1] + planes[4 * p + 2] * sphere[2] + planes[4 * p + 3] < sphere[3]) res = 0;
+    return res;
+}
+
+/* Math/Bounds.cpp:264-325 Frustum::OverlapsAABB(AABB*, n, int32*) -- the SSE batch form, restated LITERALLY.
+ * NOTE (reference behaviour, reproduced): the code loads 4 consecutive 24-byte AABBs as six __m128 rows at float
+ * offsets 0,4,8,12,16,20 and transposes them as if each row were one box's (x,y,z,_) -- it was adapted from a
+ * {vec4 min, vec4 max} layout -- and _MM_TRANSPOSE4_PS overwrites the `zero` register that is later used as the
+ * comparison operand.  Its lane results therefore do NOT correspond to boxes i..i+3; no caller uses it.
+ * It is kept as the reference's "most optimized" cost proxy for the CPU baseline; outputs: 0x80000000 where any
+ * plane compare was true, 0 otherwise.  Requires 16-byte aligned input and numObjects % 4 == 0. */
+ORACLE_API void oracle_overlaps_aabb_sse(const float* planes, const float* aabbs, uint32_t numObjects, int32_t* outResults)
+{
+    const float* pAabbData = aabbs;
+    __m128 planesX[6], planesY[6], planesZ[6], planesD[6];
+    for (int i = 0; i < 6; i++) {
+        planesX[i] = _mm_set1_ps(planes[4 * i + 0]);
+        planesY[i] = _mm_set1_ps(planes[4 * i + 1]);
+        planesZ[i] = _mm_set1_ps(planes[4 * i + 2]);
+        planesD[i] = _mm_set1_ps(planes[4 * i + 3]);
+    }
+    __m128 zero = _mm_setzero_ps();
+    for (uint32_t i = 0; i < numObjects; i += 4) {
+        __m128 aabbMinX = _mm_load_ps(pAabbData);
+        __m128 aabbMinY = _mm_load_ps(pAabbData + 4);
+        __m128 aabbMinZ = _mm_load_ps(pAabbData + 8);
+        __m128 aabbMaxX = _mm_load_ps(pAabbData + 12);
+        __m128 aabbMaxY = _mm_load_ps(pAabbData + 16);
+        __m128 aabbMaxZ = _mm_load_ps(pAabbData + 20);
+        pAabbData += 24;
+        _MM_TRANSPOSE4_PS(aabbMinX, aabbMinY, aabbMinZ, zero);
+        _MM_TRANSPOSE4_PS(aabbMaxX, aabbMaxY, aabbMaxZ, zero);
+        __m128 intersectionRes = _mm_setzero_ps();
+        for (int j = 0; j < 6; j++) {
+            __m128 resX = _mm_max_ps(_mm_mul_ps(aabbMinX, planesX[j]), _mm_mul_ps(aabbMaxX, planesX[j]));
+            __m128 resY = _mm_max_ps(_mm_mul_ps(aabbMinY, planesY[j]), _mm_mul_ps(aabbMaxY, planesY[j]));
+            __m128 resZ = _mm_max_ps(_mm_mul_ps(aabbMinZ, planesZ[j]), _mm_mul_ps(aabbMaxZ, planesZ[j]));
+            __m128 sumXy = _mm_add_ps(resX, resY);
+            __m128 sumZw = _mm_add_ps(resZ, planesD[j]);
+            __m128 distanceToPlane = _mm_add_ps(sumXy, sumZw);
+            __m128 planeRes = _mm_cmple_ps(distanceToPlane, zero);
+            intersectionRes = _mm_or_ps(intersectionRes, planeRes);
+        }
+        __m128i intersectionResI = _mm_cvtps_epi32(intersectionRes);
+        _mm_storeu_si128((__m128i*)&outResults[i], intersectionResI);
+    }
+}
+
+/*
+ * The ECS sweep over level-sorted entities (ECS/TransformECS.cpp:144-212 full-sweep branch with every component
+ * dirty + ECS/StaticMeshRendererECS.cpp:40-58 + RHI/SceneView.cpp:56 cull with flat float AABBs):
+ *   relative = Transform::Matrix(trs[i]);  world = parent == 0xFFFFFFFF ? relative : world[parent] * relative
+ *   worldAabb = AABB::Apply(localAabb, world);  visible = Frustum::OverlapsAABB(worldAabb)
+ * parent[i] < i is required (level-sorted).  visibility: 1 bit per entity, LSB-first in uint64 words.
+ * Entities [begin, end) are processed; world[] of parents outside the range must already be filled.
+ */
+ORACLE_API void oracle_ecs_sweep(uint32_t begin, uint32_t end, const float* trs, const uint32_t* parent, const float* localAabb,
+                                 const float* planes, float* world, float* worldAabb, uint64_t* visibility)
+{
+    for (uint32_t i = begin; i < end; i++) {
+        float rel[16];
+        transform_matrix(trs + 12 * (size_t)i, rel);
+        if (parent[i] == 0xFFFFFFFFu) memcpy(world + 16 * (size_t)i, rel, sizeof rel);
+        else glm_mat4_mul_mat4(world + 16 * (size_t)parent[i], rel, world + 16 * (size_t)i);
+        aabb_apply(localAabb + 6 * (size_t)i, world + 16 * (size_t)i, worldAabb + 6 * (size_t)i);
+        const int vis = overlaps_aabb(planes, worldAabb + 6 * (size_t)i);
+        uint64_t bit = 1ull << (i & 63);
+        if (vis) __atomic_fetch_or(&visibility[i >> 6], bit, __ATOMIC_RELAXED);
+        else __atomic_fetch_and(&visibility[i >> 6], ~bit, __ATOMIC_RELAXED);
+    }
+}
+
+/* Content/Shaders/ComputeMeshCulling.shader:96-110 FrustumCulling over PerInstanceData (96 B: mat4 model@0,
+ * vec4 sphereBounds@64, u32 materialInstance@80, u32 isCulled@84 -- FrameGraph/RenderSceneNode.h:16-33).
+ * Writes isCulled in place (1 = culled). */
+ORACLE_API void oracle_mesh_frustum_cull(const void* ubo_, void* instances, uint32_t numInstances)
+{
+    const UboFrameData* ubo = (const UboFrameData*)ubo_;
+    ViewFrustum fr;
+    /* Math.glsl:185-222 CreateViewFrustum(viewportSize, invProjection) */
+    create_frustum_rect(0.0f, 0.0f, (float)ubo->viewportSize[0], (float)ubo->viewportSize[1], ubo->viewportSize[0], ubo->viewportSize[1], ubo->invProjection, &fr);
+    for (uint32_t i = 0; i < numInstances; i++) {
+        uint8_t* inst = (uint8_t*)instances + 96 * (size_t)i;
+        const float* model = (const float*)inst;
+        const float* sb = (const float*)(inst + 64);
+        float c[4] = { sb[0], sb[1], sb[2], 1.0f }, wc[4], vc[4];
+        glsl_mat4_mul_vec4(model, c, wc);
+        glsl_mat4_mul_vec4(ubo->view, wc, vc);
+        float center[3] = { vc[0] / vc[3], vc[1] / vc[3], vc[2] / vc[3] };
+        center[2] = center[2] * -1.0f;
+        const float lossyScale = length3(model);
+        const float radius = sb[3] * lossyScale;
+        const int overlaps = sphere_frustum_overlaps(center, radius, &fr, ubo->cameraZNearZFar[1], ubo->cameraZNearZFar[0]);
+        uint32_t culled = overlaps ? 0u : 1u;
+        memcpy(inst + 84, &culled, 4);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* CSM matrix set-up (S9): FrameGraph/ShadowPrepassNode.cpp:378-404 ; Math/Bounds.cpp:78-109 ;  */
+/* ECS/LightingECS.cpp:276-298                                                                  */
+/* ------------------------------------------------------------------------------------------- */
+
+static void calculate_ortho_matrix_by_view(const float* corners, const float* view, float zMult, float* out)
+{
+    float minX = FLT_MAX, maxX = -FLT_MAX, minY = FLT_MAX, maxY = -FLT_MAX, minZ = FLT_MAX, maxZ = -FLT_MAX;
+    for (int k = 0; k < 8; k++) {
+        float v[4] = { corners[3 * k], corners[3 * k + 1], corners[3 * k + 2], 1.0f }, t[4];
+        glm_mat4_mul_vec4(view, v, t);
+        minX = t[0] < minX ? t[0] : minX; maxX = maxX < t[0] ? t[0] : maxX; /* std::min(a,b) = (b<a)?b:a ; std::max(a,b) = (a<b)?b:a */
+        minY = t[1] < minY ? t[1] : minY; maxY = maxY < t[1] ? t[1] : maxY;
+        minZ = t[2] < minZ ? t[2] : minZ; maxZ = maxZ < t[2] ? t[2] : maxZ;
+    }
+    minZ = minZ < 0 ? minZ * zMult : minZ / zMult;
+    maxZ = maxZ < 0 ? maxZ / zMult : maxZ * zMult;
+    const float zFar = -minZ, zNear = -maxZ;
+    ortho_rh_no(minX, maxX, minY, maxY, zFar, zNear, out);
+}
+
+/* out = 4 mat4: lightsMatrices[k] = ortho_k * lightView (LightingECS.cpp:292), lightView = inverse(lightWorld) (:227).
+ * outOrtho (optional) = the 4 bare ortho matrices. */
+ORACLE_API void oracle_csm_matrices(const float* lightView, const float* cameraWorld, float aspect, float fovY, float cameraNear, float cameraFar, float* out, float* outOrtho)
+{
+    for (int k = 0; k < NUM_CASCADES; k++) {
+        const float n = k == 0 ? cameraNear : cameraFar * kShadowCascadeLevelsCpp[k - 1];
+        const float f = cameraFar * kShadowCascadeLevelsCpp[k];
+        float planes[24], corners[24], ortho[16];
+        oracle_extract_frustum_planes(cameraWorld, aspect, fovY, n, f, planes, corners);
+        calculate_ortho_matrix_by_view(corners, lightView, 10.0f, ortho);
+        if (outOrtho) memcpy(outOrtho + 16 * k, ortho, sizeof ortho);
+        glm_mat4_mul_mat4(ortho, lightView, out + 16 * k);
+    }
+}

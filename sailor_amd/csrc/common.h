@@ -1,0 +1,74 @@
+// Internal helpers shared by the HIP translation units of libsailor_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+#define SAILOR_HIP_BUILD 1
+#include "../../include/sailor_hip.h"
+
+#define TILE SAILOR_LIGHTS_CULLING_TILE_SIZE
+#define CAND SAILOR_LIGHTS_CANDIDATES_PER_TILE
+#define KEEP SAILOR_LIGHTS_PER_TILE
+
+struct SailorHipContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownsStream = false;
+    int numCUs = 256;
+    std::string lastError;
+};
+
+static inline int sailor_map_hip_error(SailorHipContext* ctx, hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return SAILOR_HIP_OK;
+    if (ctx) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        ctx->lastError = buf;
+    }
+    switch (e) {
+    case hipErrorOutOfMemory: return SAILOR_HIP_ERR_OUT_OF_MEMORY;
+    case hipErrorNoDevice:
+    case hipErrorInvalidDevice:
+    case hipErrorInsufficientDriver:
+    case hipErrorNotInitialized: return SAILOR_HIP_ERR_NO_DEVICE;
+    case hipErrorInvalidValue: return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    default: return SAILOR_HIP_ERR_LAUNCH;
+    }
+}
+
+#define SAILOR_TRY_HIP(ctx, expr)                                                   \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) return sailor_map_hip_error((ctx), _e, #expr);        \
+    } while (0)
+
+#define SAILOR_CHECK_LAUNCH(ctx, name)                                              \
+    do {                                                                            \
+        hipError_t _e = hipGetLastError();                                          \
+        if (_e != hipSuccess) return sailor_map_hip_error((ctx), _e, name);         \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- canonical fp32 helpers: this library is compiled with -ffp-contract=off, so the
+// expressions below evaluate exactly as written, one IEEE rounding per operation. -----------------------
+struct Mat4 { float m[16]; }; // column-major: (col c, row r) = m[c*4 + r]
+
+__device__ __forceinline__ float dot3f(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return (ax * bx + ay * by) + az * bz;
+}
+// GLSL mat4 * vec4:  ((c0*x + c1*y) + c2*z) + c3*w
+__device__ __forceinline__ float4 glsl_mul(const Mat4& M, float x, float y, float z, float w)
+{
+    float4 r;
+    r.x = ((M.m[0] * x + M.m[4] * y) + M.m[8] * z) + M.m[12] * w;
+    r.y = ((M.m[1] * x + M.m[5] * y) + M.m[9] * z) + M.m[13] * w;
+    r.z = ((M.m[2] * x + M.m[6] * y) + M.m[10] * z) + M.m[14] * w;
+    r.w = ((M.m[3] * x + M.m[7] * y) + M.m[11] * z) + M.m[15] * w;
+    return r;
+}

@@ -1,0 +1,179 @@
+// Context, buffers and band helpers of the C-ABI (include/sailor_hip.h).
+#include "common.h"
+#include <vector>
+#include <new>
+
+extern "C" {
+
+int sailor_hip_version(void) { return 1000 * 0 + 1; }
+
+const char* sailor_hip_status_string(int status)
+{
+    switch (status) {
+    case SAILOR_HIP_OK: return "ok";
+    case SAILOR_HIP_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case SAILOR_HIP_ERR_NO_DEVICE: return "no usable HIP device";
+    case SAILOR_HIP_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case SAILOR_HIP_ERR_LAUNCH: return "kernel launch / stream operation failed";
+    case SAILOR_HIP_ERR_WORKSPACE_TOO_SMALL: return "workspace too small";
+    case SAILOR_HIP_ERR_RCCL: return "RCCL error";
+    case SAILOR_HIP_ERR_UNSUPPORTED: return "unsupported configuration";
+    }
+    return "unknown status";
+}
+
+int sailor_hip_device_count(int* outCount)
+{
+    if (!outCount) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *outCount = 0; return SAILOR_HIP_ERR_NO_DEVICE; }
+    *outCount = n;
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_context_create(int deviceOrdinal, void* stream, SailorHipContext** outContext)
+{
+    if (!outContext) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    *outContext = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SAILOR_HIP_ERR_NO_DEVICE;
+    if (deviceOrdinal < 0 || deviceOrdinal >= n) return SAILOR_HIP_ERR_NO_DEVICE;
+    SailorHipContext* ctx = new (std::nothrow) SailorHipContext();
+    if (!ctx) return SAILOR_HIP_ERR_OUT_OF_MEMORY;
+    ctx->device = deviceOrdinal;
+    if (hipSetDevice(deviceOrdinal) != hipSuccess) { delete ctx; return SAILOR_HIP_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, deviceOrdinal) == hipSuccess) ctx->numCUs = prop.multiProcessorCount;
+    if (stream) { ctx->stream = (hipStream_t)stream; ctx->ownsStream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SAILOR_HIP_ERR_LAUNCH; }
+        ctx->ownsStream = true;
+    }
+    *outContext = ctx;
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_context_destroy(SailorHipContext* ctx)
+{
+    if (!ctx) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (ctx->ownsStream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    delete ctx;
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_context_synchronize(SailorHipContext* ctx)
+{
+    if (!ctx) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_context_stream(SailorHipContext* ctx, void** outStream)
+{
+    if (!ctx || !outStream) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    *outStream = (void*)ctx->stream;
+    return SAILOR_HIP_OK;
+}
+
+const char* sailor_hip_context_last_error(SailorHipContext* ctx)
+{
+    return ctx ? ctx->lastError.c_str() : "null context";
+}
+
+int sailor_hip_buffer_create(SailorHipContext* ctx, size_t bytes, void** outDevicePtr)
+{
+    if (!ctx || !outDevicePtr) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    *outDevicePtr = nullptr;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    SAILOR_TRY_HIP(ctx, hipMalloc(outDevicePtr, bytes ? bytes : 16));
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_buffer_free(SailorHipContext* ctx, void* devicePtr)
+{
+    if (!ctx) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (!devicePtr) return SAILOR_HIP_OK;
+    SAILOR_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SAILOR_TRY_HIP(ctx, hipFree(devicePtr));
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_buffer_upload(SailorHipContext* ctx, void* dstDevice, size_t dstOffset, const void* src, size_t bytes)
+{
+    if (!ctx || !dstDevice || (!src && bytes)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (!bytes) return SAILOR_HIP_OK;
+    // Pageable-source hipMemcpyAsync stages the bytes before returning, i.e. the payload is captured at record time.
+    SAILOR_TRY_HIP(ctx, hipMemcpyAsync((char*)dstDevice + dstOffset, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_buffer_download(SailorHipContext* ctx, void* dstHost, const void* srcDevice, size_t srcOffset, size_t bytes)
+{
+    if (!ctx || !srcDevice || (!dstHost && bytes)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (!bytes) return SAILOR_HIP_OK;
+    SAILOR_TRY_HIP(ctx, hipMemcpyAsync(dstHost, (const char*)srcDevice + srcOffset, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SAILOR_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SAILOR_HIP_OK;
+}
+
+__global__ void k_fill_u32(uint32_t* dst, uint32_t value, size_t count)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) dst[i] = value;
+}
+
+int sailor_hip_buffer_fill_u32(SailorHipContext* ctx, void* dstDevice, size_t dstOffset, uint32_t value, size_t count)
+{
+    if (!ctx || !dstDevice || (dstOffset & 3)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (!count) return SAILOR_HIP_OK;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (uint32_t*)((char*)dstDevice + dstOffset), value, count);
+    SAILOR_CHECK_LAUNCH(ctx, "k_fill_u32");
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_num_tiles(int32_t width, int32_t height, int32_t* outTilesX, int32_t* outTilesY)
+{
+    if (width <= 0 || height <= 0 || !outTilesX || !outTilesY) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    *outTilesX = (width - 1) / TILE + 1;  // FrameGraph/LightCullingNode.cpp:56
+    *outTilesY = (height - 1) / TILE + 1; // :57
+    return SAILOR_HIP_OK;
+}
+
+static void band_from_rows(int32_t height, int32_t r0, int32_t r1, SailorBand* b)
+{
+    b->tileRowBegin = r0;
+    b->tileRowEnd = r1;
+    // tile row t covers framebuffer rows H-1-16t-15 .. H-1-16t, clamped to [0, H)
+    int32_t lo = height - TILE * r1;
+    int32_t hi = height - TILE * r0;
+    if (lo < 0) lo = 0;
+    if (hi > height) hi = height;
+    if (hi < lo) hi = lo;
+    b->fbRowBegin = lo;
+    b->fbRowCount = hi - lo;
+}
+
+int sailor_hip_band_whole_frame(int32_t width, int32_t height, SailorBand* outBand)
+{
+    int32_t tx, ty;
+    if (!outBand || sailor_hip_num_tiles(width, height, &tx, &ty) != SAILOR_HIP_OK) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    band_from_rows(height, 0, ty, outBand);
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_band_for_rank(int32_t width, int32_t height, int32_t rank, int32_t worldSize, SailorBand* outBand)
+{
+    int32_t tx, ty;
+    if (!outBand || worldSize <= 0 || rank < 0 || rank >= worldSize) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (sailor_hip_num_tiles(width, height, &tx, &ty) != SAILOR_HIP_OK) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const int32_t r0 = (int32_t)(((int64_t)rank * ty) / worldSize);
+    const int32_t r1 = (int32_t)(((int64_t)(rank + 1) * ty) / worldSize);
+    band_from_rows(height, r0, r1, outBand);
+    return SAILOR_HIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,371 @@
+// K2 + K3 -- PBR shade over per-tile light lists with cascaded-shadow sampling, for gfx950.
+//
+// Replaces the fragment work of Content/Shaders/Standard.shader (main :377-439, CalculateLighting :259-341) and
+// Lighting.glsl (BRDF :39-76, CSM :168-284) for the draws of RenderSceneNode::Process
+// (FrameGraph/RenderSceneNode.cpp:109), as compute over a surface buffer (ambient == 0).
+//
+// Shape: one 256-thread block per 16x16 tile -- the unit the light list is defined on -- so the tile's <=128
+// light records are fetched from HBM once, derived per-light constants (normalised spot axis, cone width) are
+// computed once by 128 lanes, and the records sit in LDS (128 x 80 B = 10 KB) where every lane reads the SAME
+// address per step (LDS broadcast, conflict-free).  Each wave covers 4 framebuffer rows x 16 pixels, i.e. four
+// 256-byte row segments per float4 plane; radiance goes out as one float4 per lane.  The light type branch is
+// wave-uniform (all lanes walk the same list), and a wave skips the BRDF of a light whose falloff is zero on
+// all of its 64 pixels (the list is conservative: sphere-vs-tile-frustum).
+//
+// Numerics: the BRDF is tolerance-checked (1e-4 relative), so it uses v_rcp/v_rsq and explicit FMAs.  The shadow
+// factor is a step function of its inputs (cascade select, PCF compares, EVSM's exp(40 z) - moment), so K3 is
+// evaluated in the canonical fp32 order with true divisions and the fixed exp algorithm of the oracle, bit for bit.
+// The translation unit is compiled with -ffp-contract=off; every fused multiply-add below is written explicitly.
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+struct CsmArgs {
+    Mat4 lightsMatrices[SAILOR_NUM_CSM_CASCADES];
+    const void* maps[SAILOR_NUM_CSM_CASCADES];
+    int width[SAILOR_NUM_CSM_CASCADES];
+    int height[SAILOR_NUM_CSM_CASCADES];
+    int format[SAILOR_NUM_CSM_CASCADES];
+};
+
+struct ShadeArgs {
+    Mat4 view;
+    float camX, camY, camZ;
+    float zFar;
+    int vpW, vpH;     // frame.viewportSize
+    int W;            // surface width in pixels
+    int H;            // full frame height
+    int Tx;
+    int tileRow0;     // band.tileRowBegin
+    int fbRow0;       // band.fbRowBegin
+    int fbRows;       // band.fbRowCount
+    int lightsNum;
+};
+
+// ---- K3: canonical-order helpers (must match oracle/sailor_oracle.c bit for bit) -----------------------------
+__device__ __forceinline__ float texel_r(const void* __restrict__ map, int fmt, int W, int x, int y)
+{
+    const size_t i = (size_t)y * W + x;
+    if (fmt == SAILOR_SHADOWMAP_R16_SFLOAT) return __half2float(reinterpret_cast<const __half*>(map)[i]);
+    if (fmt == SAILOR_SHADOWMAP_R32_SFLOAT) return reinterpret_cast<const float*>(map)[i];
+    return reinterpret_cast<const float*>(map)[i * 4];
+}
+
+struct BilinearTaps { int x0, x1, y0, y1; float ax, ay; };
+
+__device__ __forceinline__ BilinearTaps bilinear_taps(int W, int H, float u, float v)
+{
+    BilinearTaps t;
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    t.ax = x - fx; t.ay = y - fy;
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    t.x0 = min(max(x0, 0), W - 1); t.x1 = min(max(x1, 0), W - 1);
+    t.y0 = min(max(y0, 0), H - 1); t.y1 = min(max(y1, 0), H - 1);
+    return t;
+}
+
+__device__ __forceinline__ float lerp2(float t00, float t10, float t01, float t11, float ax, float ay)
+{
+    const float top = t00 * (1.0f - ax) + t10 * ax;
+    const float bot = t01 * (1.0f - ax) + t11 * ax;
+    return top * (1.0f - ay) + bot * ay;
+}
+
+__device__ __forceinline__ float sample_r(const void* __restrict__ map, int fmt, int W, int H, float u, float v)
+{
+    const BilinearTaps t = bilinear_taps(W, H, u, v);
+    return lerp2(texel_r(map, fmt, W, t.x0, t.y0), texel_r(map, fmt, W, t.x1, t.y0),
+                 texel_r(map, fmt, W, t.x0, t.y1), texel_r(map, fmt, W, t.x1, t.y1), t.ax, t.ay);
+}
+
+__device__ __forceinline__ float4 sample_rgba(const void* __restrict__ map, int fmt, int W, int H, float u, float v)
+{
+    const BilinearTaps t = bilinear_taps(W, H, u, v);
+    if (fmt != SAILOR_SHADOWMAP_R32G32B32A32_SFLOAT) {
+        const float r = lerp2(texel_r(map, fmt, W, t.x0, t.y0), texel_r(map, fmt, W, t.x1, t.y0),
+                              texel_r(map, fmt, W, t.x0, t.y1), texel_r(map, fmt, W, t.x1, t.y1), t.ax, t.ay);
+        return make_float4(r, 0.0f, 0.0f, 1.0f);
+    }
+    const float4* m = reinterpret_cast<const float4*>(map);
+    const float4 a = m[(size_t)t.y0 * W + t.x0], b = m[(size_t)t.y0 * W + t.x1];
+    const float4 c = m[(size_t)t.y1 * W + t.x0], d = m[(size_t)t.y1 * W + t.x1];
+    return make_float4(lerp2(a.x, b.x, c.x, d.x, t.ax, t.ay), lerp2(a.y, b.y, c.y, d.y, t.ax, t.ay),
+                       lerp2(a.z, b.z, c.z, d.z, t.ax, t.ay), lerp2(a.w, b.w, c.w, d.w, t.ax, t.ay));
+}
+
+// The one exp() of the path (Lighting.glsl:277-278): fixed fp32 algorithm shared with the oracle.
+__device__ __forceinline__ float canonical_expf(float x)
+{
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) x = -87.0f;
+    const float n = floorf(x * 1.44269504088896341f + 0.5f);
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    const float y = (p * z + r) + 1.0f;
+    return ldexpf(y, (int)n);
+}
+
+__constant__ float kPoissonDisk[16][2] = { // Lighting.glsl:176-185
+    { -0.94201624f, -0.39906216f }, { 0.94558609f, -0.76890725f }, { -0.094184101f, -0.92938870f }, { 0.34495938f, 0.29387760f },
+    { -0.91588581f, 0.45771432f }, { -0.81544232f, -0.87912464f }, { -0.38277543f, 0.27676845f }, { 0.97484398f, 0.75648379f },
+    { 0.44323325f, -0.97511554f }, { 0.53742981f, -0.47373420f }, { -0.26496911f, -0.41893023f }, { 0.79197514f, 0.19090188f },
+    { -0.24188840f, 0.99706507f }, { -0.81409955f, 0.91437590f }, { 0.19984126f, 0.78641367f }, { 0.14383161f, -0.14100790f }
+};
+
+// Lighting.glsl:242-261 ShadowCalculation_Pcf + :168-197 ManualPCF
+__device__ float shadow_pcf(const void* __restrict__ map, int fmt, int W, int H, float4 lp, float bias)
+{
+    float px = lp.x / lp.w, py = lp.y / lp.w, pz = lp.z / lp.w;
+    px = px * 0.5f + 0.5f; py = py * 0.5f + 0.5f; pz = pz * 0.5f + 0.5f;
+    py = 1.0f - py;
+    if (px > 1.0f || py > 1.0f || px < 0.0f || py < 0.0f || pz < 0.5f) return 1.0f;
+    const float tsx = 1.0f / (float)W, tsy = 1.0f / (float)H;
+    float shadow = 0.0f;
+#pragma unroll 4
+    for (int i = 0; i < 16; i++) {
+        const float ox = kPoissonDisk[i][0] * 2.0f * tsx, oy = kPoissonDisk[i][1] * 2.0f * tsy;
+        const float pcfDepth = sample_r(map, fmt, W, H, px + ox, py + oy) * 0.5f + 0.5f;
+        shadow += (pz + bias > pcfDepth) ? 1.0f : 0.0f;
+    }
+    return shadow / 16.0f;
+}
+
+// Lighting.glsl:218-240
+__device__ __forceinline__ float chebyshev(float m0, float m1, float currentDepth, float minVariance, float lin)
+{
+    const float d = currentDepth - m0;
+    if (d < 0.0f) return 1.0f;
+    const float variance = fmaxf(minVariance, m1 - m0 * m0);
+    const float pmax = variance / (variance + d * d);
+    return fminf(fmaxf((pmax - lin) / (1.0f - lin), 0.0f), 1.0f);
+}
+
+// Lighting.glsl:263-284 ShadowCalculation_Evsm
+__device__ float shadow_evsm(const void* __restrict__ map, int fmt, int W, int H, float4 lp, float bias, int cascade)
+{
+    float px = lp.x / lp.w, py = lp.y / lp.w;
+    const float pz = lp.z / lp.w;
+    px = px * 0.5f + 0.5f; py = py * 0.5f + 0.5f;
+    py = 1.0f - py;
+    if (px > 1.0f || py > 1.0f || px < 0.0f || py < 0.0f || pz < 0.0f) return 1.0f;
+    const float4 s = sample_rgba(map, fmt, W, H, px, py);
+    float p05 = 1.0f;
+    for (int i = 0; i < cascade; i++) p05 = p05 * 0.5f;
+    const float currentDepth = canonical_expf(40.0f * (pz + 0.003f * bias * p05));
+    const float negCurrentDepth = -canonical_expf(-40.0f * (pz + 0.0001f * bias));
+    const float posValue = chebyshev(s.x, s.y, currentDepth, 0.01f, 0.0f);
+    const float negValue = chebyshev(s.z, s.w, negCurrentDepth, 0.0f, 0.0f) * (cascade > 2 ? 0.0f : 1.0f);
+    return fminf(fmaxf(1.0f - fmaxf(posValue, negValue), 0.0f), 1.0f);
+}
+
+// Standard.shader:266-283 + Lighting.glsl:200-216 SelectCascade
+__device__ float directional_shadow(const ShadeArgs& A, const CsmArgs& C, uint32_t shadowType,
+                                    float dirX, float dirY, float dirZ, float nx, float ny, float nz, float wx, float wy, float wz)
+{
+    const float4 pv = glsl_mul(A.view, wx, wy, wz, 1.0f);
+    const float depthValue = fabsf(pv.z / pv.w);
+    int cascade = SAILOR_NUM_CSM_CASCADES;
+    const float levels[4] = { 0.05f, 0.1f, 0.333333f, 0.5f }; // Constants.glsl:24
+#pragma unroll
+    for (int i = SAILOR_NUM_CSM_CASCADES - 1; i >= 0; i--)
+        if (depthValue < A.zFar * levels[i]) cascade = i;
+    cascade = min(cascade, SAILOR_NUM_CSM_CASCADES - 1);
+    const void* map = C.maps[cascade];
+    if (!map) return 1.0f;
+    const float4 lp = glsl_mul(C.lightsMatrices[cascade], wx, wy, wz, 1.0f);
+    const float ndl = dot3f(nx, ny, nz, dirX, dirY, dirZ);
+    if (shadowType == 2u && cascade == 0) {
+        const float bias = (1.0f - ndl) * (float)(1 + cascade);
+        return shadow_evsm(map, C.format[cascade], C.width[cascade], C.height[cascade], lp, bias, cascade);
+    }
+    const float bias = fmaxf(0.000075f * (1.0f - ndl), 0.000005f);
+    return shadow_pcf(map, C.format[cascade], C.width[cascade], C.height[cascade], lp, bias);
+}
+
+// ---- K2 ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
+
+#define LREC 5 // float4 per staged light
+
+template <bool HAS_CSM>
+__global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const float4* __restrict__ surface, size_t planeStride,
+                                                 const SailorLightShaderData* __restrict__ lights,
+                                                 const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled,
+                                                 float4* __restrict__ radiance)
+{
+    __shared__ float4 sL[KEEP * LREC];
+    __shared__ uint32_t sNum;
+
+    const int bandTile = blockIdx.x;
+    const int tx = bandTile % A.Tx, ty = A.tileRow0 + bandTile / A.Tx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gx = tx * TILE + (lane & 15);
+    const int gy = ty * TILE + wave * 4 + (lane >> 4);
+    const int py = A.H - 1 - gy;            // framebuffer row (Standard.shader:414: screenUv.y = H - fragY)
+    const bool active = gx < A.W && py >= 0;
+    const size_t pix = active ? ((size_t)(py - A.fbRow0) * A.W + gx) : 0;
+
+    // issue the surface loads first; the list staging below overlaps their latency
+    float4 P0 = make_float4(0, 0, 0, 0), P1 = make_float4(0, 0, 1, 1), P2 = make_float4(0, 0, 0, 0);
+    if (active) {
+        P0 = surface[pix];
+        P1 = surface[planeStride + pix];
+        P2 = surface[2 * planeStride + pix];
+    }
+
+    const SailorLightsGrid g = grid[bandTile]; // Standard.shader:422-423
+    const uint32_t listNum = g.num < (uint32_t)KEEP ? g.num : (uint32_t)KEEP;
+    if (threadIdx.x == 0) sNum = listNum;
+    __syncthreads();
+    if (threadIdx.x < listNum) {
+        const uint32_t index = culled[g.offset + threadIdx.x];
+        if (index >= (uint32_t)A.lightsNum) {
+            atomicMin(&sNum, threadIdx.x); // Standard.shader:430-433 "index == uint(-1) -> break" (and out-of-range guard)
+        } else {
+            const float4* L = reinterpret_cast<const float4*>(lights + index);
+            const float4 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3], q4 = L[4], q5 = L[5], q6 = L[6];
+            const uint32_t type = __float_as_uint(q0.x), shadowType = __float_as_uint(q0.y);
+            const float ndx = -q2.x, ndy = -q2.y, ndz = -q2.z;         // Li = -light.direction (:309)
+            const float len = sqrtf(dot3f(ndx, ndy, ndz, ndx, ndy, ndz)); // normalize(-light.direction) (:298)
+            float4* o = sL + threadIdx.x * LREC;
+            o[0] = make_float4(q1.x, q1.y, q1.z, q6.x);                                  // worldPosition, bounds.x
+            o[1] = make_float4(ndx, ndy, ndz, __uint_as_float(type | (shadowType << 8)));
+            o[2] = make_float4(q3.x, q3.y, q3.z, q5.y);                                  // intensity, cutOff.y
+            o[3] = make_float4(q4.x, q4.y, q4.z, q5.x - q5.y);                           // attenuation, epsilon (:297)
+            o[4] = make_float4(ndx / len, ndy / len, ndz / len, 0.0f);
+        }
+    }
+    __syncthreads();
+    const uint32_t numLights = sNum;
+
+    // ---- per-pixel invariants (Standard.shader:379-401) ----
+    const float wx = P0.x, wy = P0.y, wz = P0.z;
+    const float nx = P1.x, ny = P1.y, nz = P1.z, roughness = P1.w;
+    const float metallic = P2.w;
+    float vx = wx - A.camX, vy = wy - A.camY, vz = wz - A.camZ;
+    const float vinv = rsq_fast(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
+    const float Lox = -vx * vinv, Loy = -vy * vinv, Loz = -vz * vinv; // Lo = -viewDirection
+    const float cosLo = fmaxf(0.0f, fmaf(nx, Lox, fmaf(ny, Loy, nz * Loz)));
+    const float oneMinusMetal = 1.0f - metallic;
+    const float F0x = fmaf(P2.x, metallic, 0.04f * oneMinusMetal);
+    const float F0y = fmaf(P2.y, metallic, 0.04f * oneMinusMetal);
+    const float F0z = fmaf(P2.z, metallic, 0.04f * oneMinusMetal);
+    const float alpha = roughness * roughness, alphaSq = alpha * alpha;
+    const float rr = roughness + 1.0f, k = (rr * rr) * 0.125f, oneMinusK = 1.0f - k;
+    const float g1Lo = cosLo * rcp_fast(fmaf(cosLo, oneMinusK, k)); // GeometrySchlickG1(cosLo, k)
+    const bool brdfFinite = alphaSq > 0.0f;                       // roughness 0 makes NdfGGX 0/0 in the reference
+
+    float accX = 0.0f, accY = 0.0f, accZ = 0.0f;
+    for (uint32_t i = 0; i < numLights; i++) {
+        const float4* R = sL + i * LREC;
+        const float4 r0 = R[0], r1 = R[1];
+        const uint32_t bits = __float_as_uint(r1.w);
+        const uint32_t type = bits & 0xFFu;
+        float falloff = 1.0f, shadow = 1.0f;
+        if (type == 1u || type == 2u) {
+            const float dx = r0.x - wx, dy = r0.y - wy, dz = r0.z - wz;
+            const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+            const float dist = sqrtf(d2);
+            const float4 r3 = R[3];
+            const float att = rcp_fast(fmaf(r3.z, d2, fmaf(r3.y, dist, r3.x))); // 1/(a.x + a.y d + a.z d^2) (:289,:300)
+            if (type == 1u) {
+                const float q = fminf(fmaxf(dist / r0.w, 0.0f), 1.0f);
+                falloff = att * (1.0f - q * q);                              // (:290)
+            } else {
+                const float4 r4 = R[4];
+                const float dinv = rcp_fast(dist);
+                const float theta = fmaf(dx, r4.x, fmaf(dy, r4.y, dz * r4.z)) * dinv; // dot(normalize(pos - wp), normalize(-dir))
+                const float cutY = R[2].w;
+                falloff = att * fminf(fmaxf((theta - cutY) / r3.w, 0.0f), 1.0f);     // (:301)
+                if (theta < cutY) falloff = 0.0f;                                     // (:303-306)
+            }
+            // conservative list: skip the BRDF when no pixel of this wave is reached by the light
+            if (__ballot(active && (falloff != 0.0f || !brdfFinite)) == 0ull) continue;
+        } else if (type == 0u) {
+            if (HAS_CSM) shadow = directional_shadow(A, C, (bits >> 8) & 0xFFu, -r1.x, -r1.y, -r1.z, nx, ny, nz, wx, wy, wz);
+        }
+        // ---- Cook-Torrance (Standard.shader:309-340) ----
+        const float Lix = r1.x, Liy = r1.y, Liz = r1.z;
+        float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;
+        const float hinv = rsq_fast(fmaf(hx, hx, fmaf(hy, hy, hz * hz)));
+        hx *= hinv; hy *= hinv; hz *= hinv;
+        const float cosLi = fmaxf(0.0f, fmaf(nx, Lix, fmaf(ny, Liy, nz * Liz)));
+        const float cosLh = fmaxf(0.0f, fmaf(nx, hx, fmaf(ny, hy, nz * hz)));
+        const float x1 = 1.0f - fmaxf(0.0f, fmaf(hx, Lox, fmaf(hy, Loy, hz * Loz)));
+        const float x2 = x1 * x1, x5 = x2 * x2 * x1;                              // pow(1 - cosTheta, 5)
+        const float Fx = fmaf(1.0f - F0x, x5, F0x), Fy = fmaf(1.0f - F0y, x5, F0y), Fz = fmaf(1.0f - F0z, x5, F0z);
+        const float dn = fmaf(cosLh * cosLh, alphaSq - 1.0f, 1.0f);
+        const float D = alphaSq * rcp_fast(3.14159265359f * dn * dn);              // NdfGGX
+        const float G = cosLi * rcp_fast(fmaf(cosLi, oneMinusK, k)) * g1Lo;        // GeometrySchlickGGX
+        const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * cosLo));
+        const float4 r2 = R[2];
+        const float scale = shadow * cosLi * falloff;
+        // shadow * ((kd*albedo + F*D*G/denom) * Lradiance * cosLi) * falloff ; kd = mix(1 - F, 0, metallic)
+        accX = fmaf(fmaf((1.0f - Fx) * oneMinusMetal, P2.x, Fx * spec) * r2.x, scale, accX);
+        accY = fmaf(fmaf((1.0f - Fy) * oneMinusMetal, P2.y, Fy * spec) * r2.y, scale, accY);
+        accZ = fmaf(fmaf((1.0f - Fz) * oneMinusMetal, P2.z, Fz * spec) * r2.z, scale, accZ);
+    }
+    if (active) radiance[pix] = make_float4(accX, accY, accZ, P0.w); // outColor.a = material.albedo.a (:438)
+}
+
+extern "C" int sailor_hip_shade(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
+                                const SailorLightShaderData* dLights, int32_t lightsNum,
+                                const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
+                                const SailorCsmDesc* csm, float* dRadiance, const SailorBand* band)
+{
+    if (!ctx || !frame || !dSurface || !dLightsGrid || !dCulledLights || !dRadiance) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (lightsNum < 0 || (lightsNum > 0 && !dLights)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const int W = frame->viewportSize[0], H = frame->viewportSize[1];
+    if (W <= 0 || H <= 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SailorBand whole;
+    if (!band) { sailor_hip_band_whole_frame(W, H, &whole); band = &whole; }
+    const int Ty = (H - 1) / TILE + 1;
+    if (band->tileRowBegin < 0 || band->tileRowEnd > Ty || band->tileRowBegin > band->tileRowEnd) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (surfacePlaneStride < (size_t)band->fbRowCount * W) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (((uintptr_t)dSurface & 15) || ((uintptr_t)dRadiance & 15) || ((uintptr_t)dLights & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+
+    ShadeArgs A;
+    memcpy(A.view.m, frame->view, 64);
+    A.camX = frame->cameraPosition[0]; A.camY = frame->cameraPosition[1]; A.camZ = frame->cameraPosition[2];
+    A.zFar = frame->cameraZNearZFar[1];
+    A.vpW = W; A.vpH = H; A.W = W; A.H = H;
+    // Standard.shader:413-420: numTiles.x + padding.x == LightCullingNode's numTiles.x
+    A.Tx = W / TILE + ((W % TILE) ? 1 : 0);
+    A.tileRow0 = band->tileRowBegin;
+    A.fbRow0 = band->fbRowBegin;
+    A.fbRows = band->fbRowCount;
+    A.lightsNum = lightsNum;
+    const int bandTiles = (band->tileRowEnd - band->tileRowBegin) * A.Tx;
+    if (bandTiles == 0) return SAILOR_HIP_OK;
+
+    CsmArgs C;
+    memset(&C, 0, sizeof C);
+    bool hasCsm = false;
+    if (csm) {
+        for (int k = 0; k < SAILOR_NUM_CSM_CASCADES; k++) {
+            memcpy(C.lightsMatrices[k].m, csm->lightsMatrices[k], 64);
+            C.maps[k] = csm->maps[k];
+            C.width[k] = csm->width[k]; C.height[k] = csm->height[k]; C.format[k] = csm->format[k];
+            if (csm->maps[k]) {
+                if (csm->width[k] <= 0 || csm->height[k] <= 0 || csm->format[k] < 0 || csm->format[k] > 2) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+                hasCsm = true;
+            }
+        }
+    }
+    if (hasCsm)
+        hipLaunchKernelGGL(k2_shade<true>, dim3(bandTiles), dim3(256), 0, ctx->stream, A, C, (const float4*)dSurface, surfacePlaneStride,
+                           dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
+    else
+        hipLaunchKernelGGL(k2_shade<false>, dim3(bandTiles), dim3(256), 0, ctx->stream, A, C, (const float4*)dSurface, surfacePlaneStride,
+                           dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
+    SAILOR_CHECK_LAUNCH(ctx, "k2_shade");
+    return SAILOR_HIP_OK;
+}

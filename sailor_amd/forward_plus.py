@@ -1,0 +1,154 @@
+"""Torch-facing handle on the HIP Forward+ path: device memory and streams come from torch, every kernel comes from
+libsailor_hip.so through the C-ABI (include/sailor_hip.h).  One object = one GPU = one band of the frame.
+
+Mirrors the two reference passes that own these buffers:
+  * LightCullingNode (FrameGraph/LightCullingNode.cpp:59-77): owns `culledLights` / `lightsGrid`, dispatches the cull;
+  * RenderSceneNode + Standard.shader (FrameGraph/RenderSceneNode.cpp:109): consumes them while shading.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, host
+from ._lib import Band, CsmDesc, UboFrameData
+
+LIGHTS_PER_TILE = _lib.LIGHTS_PER_TILE
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+class HipContext:
+    """RAII wrapper of SailorHipContext bound to a torch device and stream."""
+
+    def __init__(self, device: torch.device | str | int = "cuda:0", stream: torch.cuda.Stream | None = None):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.SailorHipError(-2, "HipContext", "a HIP device is required (there is no CPU fallback)")
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", index)
+        self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        handle = C.c_void_p()
+        lib = _lib.load()
+        _lib.check(lib.sailor_hip_context_create(index, C.c_void_p(self.stream.cuda_stream), C.byref(handle)), "sailor_hip_context_create")
+        self.handle = handle
+        self._lib = lib
+
+    def synchronize(self):
+        _lib.check(self._lib.sailor_hip_context_synchronize(self.handle), "synchronize", self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.sailor_hip_context_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ForwardPlus:
+    """Cull + shade for one band of a W x H frame on one GPU."""
+
+    def __init__(self, ctx: HipContext, width: int, height: int, max_lights: int, band: Band | None = None):
+        self.ctx, self.W, self.H, self.max_lights = ctx, width, height, max_lights
+        self.Tx, self.Ty = host.num_tiles(width, height)
+        self.band = band if band is not None else host.band_whole_frame(width, height)
+        self.band_tiles = (self.band.tileRowEnd - self.band.tileRowBegin) * self.Tx
+        lib = ctx._lib
+        ws = lib.sailor_hip_light_cull_workspace_size(width, height, max_lights, C.byref(self.band))
+        if ws == 0:
+            raise _lib.SailorHipError(-1, "light_cull_workspace_size")
+        dev = ctx.device
+        self.workspace = torch.empty(ws, dtype=torch.uint8, device=dev)
+        # LightCullingNode.cpp:64-65 (+1: the reference's buffer is one uint short when every tile is full)
+        self.grid = torch.zeros(max(self.band_tiles, 1) * 2, dtype=torch.int32, device=dev)
+        self.culled = torch.zeros(1 + max(self.band_tiles, 1) * LIGHTS_PER_TILE, dtype=torch.int32, device=dev)
+        self.radiance = None
+
+    # -- K0 + K1 --------------------------------------------------------------------------------------------------
+    def cull(self, frame: UboFrameData, lights: torch.Tensor, lights_num: int, depth: torch.Tensor, flags: int = _lib.CULL_DEFAULT):
+        """lights: uint8/any tensor holding lights_num 112-byte records; depth: float32 [band rows, W]."""
+        assert depth.dtype == torch.float32 and depth.is_contiguous() and depth.shape == (self.band.fbRowCount, self.W), depth.shape
+        assert lights_num <= self.max_lights
+        pc = host.push_constants(frame, self.W, self.H, lights_num)
+        lib = self.ctx._lib
+        _lib.check(lib.sailor_hip_light_cull(self.ctx.handle, C.byref(frame), C.byref(pc), _ptr(lights), _ptr(depth), _ptr(self.grid), _ptr(self.culled),
+                                             self.culled.numel(), _ptr(self.workspace), self.workspace.numel(), C.byref(self.band), flags),
+                   "sailor_hip_light_cull", self.ctx.handle)
+        return self.grid, self.culled
+
+    # -- K2 + K3 --------------------------------------------------------------------------------------------------
+    def shade(self, frame: UboFrameData, surface: torch.Tensor, lights: torch.Tensor, lights_num: int, csm: CsmDesc | None = None,
+              out: torch.Tensor | None = None) -> torch.Tensor:
+        """surface: float32 [3, band rows, W, 4]; returns radiance float32 [band rows, W, 4]."""
+        rows = self.band.fbRowCount
+        assert surface.dtype == torch.float32 and surface.is_contiguous() and surface.shape == (3, rows, self.W, 4), surface.shape
+        if out is None:
+            if self.radiance is None:
+                self.radiance = torch.empty((rows, self.W, 4), dtype=torch.float32, device=self.ctx.device)
+            out = self.radiance
+        lib = self.ctx._lib
+        _lib.check(lib.sailor_hip_shade(self.ctx.handle, C.byref(frame), _ptr(surface), rows * self.W, _ptr(lights), lights_num, _ptr(self.grid),
+                                        _ptr(self.culled), C.byref(csm) if csm is not None else None, _ptr(out), C.byref(self.band)),
+                   "sailor_hip_shade", self.ctx.handle)
+        return out
+
+    # -- helpers ----------------------------------------------------------------------------------------------------
+    def lists_to_host(self):
+        """(grid uint32[T,2], indices uint32[1 + total]) of this band, band-local offsets."""
+        self.ctx.synchronize()
+        g = self.grid.cpu().numpy().view(np.uint32).reshape(-1, 2)[: self.band_tiles]
+        c = self.culled.cpu().numpy().view(np.uint32)
+        return g.copy(), c[: 1 + int(c[0])].copy()
+
+
+def upload_lights(lights: np.ndarray, device) -> torch.Tensor:
+    assert lights.dtype.itemsize == 112
+    raw = np.ascontiguousarray(lights).view(np.uint8).reshape(-1)
+    if raw.size == 0:
+        raw = np.zeros(112, np.uint8)
+    return torch.from_numpy(raw.copy()).to(device)
+
+
+def upload_shadow_maps(shadows, device) -> tuple[CsmDesc, list]:
+    """-> (CsmDesc with device pointers, tensors to keep alive)."""
+    keep, maps = [], []
+    for m in shadows.maps:
+        t = torch.from_numpy(np.ascontiguousarray(m)).to(device)
+        keep.append(t)
+        fmt = _lib.SHADOWMAP_R16F if m.dtype == np.float16 else (_lib.SHADOWMAP_RGBA32F if m.ndim == 3 else _lib.SHADOWMAP_R32F)
+        maps.append((t.data_ptr(), m.shape[1], m.shape[0], fmt))
+    return host.make_csm_desc(shadows.lights_matrices, maps), keep
+
+
+class EcsSweep:
+    """K4 on one GPU over level-sorted entities."""
+
+    def __init__(self, ctx: HipContext, entities):
+        self.ctx = ctx
+        dev = ctx.device
+        self.n = len(entities.parent)
+        self.trs = torch.from_numpy(entities.transforms).to(dev)
+        self.parent = torch.from_numpy(entities.parent.view(np.int32)).to(dev)
+        self.local_aabb = torch.from_numpy(entities.local_aabb).to(dev)
+        self.level_offsets = np.ascontiguousarray(entities.level_offsets, np.uint32)
+        self.world = torch.empty((self.n, 16), dtype=torch.float32, device=dev)
+        self.world_aabb = torch.empty((self.n, 6), dtype=torch.float32, device=dev)
+        self.visibility = torch.zeros((self.n + 63) // 64, dtype=torch.int64, device=dev)
+
+    def run(self, planes: np.ndarray):
+        planes = np.ascontiguousarray(planes, np.float32).reshape(24)
+        lib = self.ctx._lib
+        _lib.check(lib.sailor_hip_ecs_sweep(self.ctx.handle, self.n, _ptr(self.trs), _ptr(self.parent),
+                                            self.level_offsets.ctypes.data_as(C.POINTER(C.c_uint32)), len(self.level_offsets) - 1,
+                                            _ptr(self.local_aabb), planes.ctypes.data_as(C.POINTER(C.c_float)),
+                                            _ptr(self.world), _ptr(self.world_aabb), _ptr(self.visibility)),
+                   "sailor_hip_ecs_sweep", self.ctx.handle)
+        return self.world, self.world_aabb, self.visibility

@@ -1,0 +1,352 @@
+"""Deterministic synthetic frames for the Forward+ path (SURVEY.md 8d "Synthetic frame generator").
+
+RNG = counter-based SplitMix64 -> 24-bit uniforms u = (x >> 40) * 2^-24; seed 20250114; one stream per input class
+(camera 0, depth 1, surface 2, lights 3, shadow 4, entities 5).  Everything is plain numpy: the generator feeds the HIP
+path, the oracle and the benchmarks with the SAME bytes; it performs none of the path's arithmetic.
+
+Defaults harvested from the reference: camera at (0,150,0), identity rotation, fov 90, zNear 1, zFar 20000
+(Content/Editor.world:5-9,29-31); light attenuation (1, 0.022, 0.0019) and cut-off (30, 45) degrees
+(ECS/LightingECS.h:24-26); integer light intensities 0..255 (Components/TestComponent.cpp:117); the directional
+light's intensity from Content/Editor.world:123-126 (its rotation: see directional_rotation()).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import host
+
+SEED = 20250114
+STREAM_CAMERA, STREAM_DEPTH, STREAM_SURFACE, STREAM_LIGHTS, STREAM_SHADOW, STREAM_ENTITIES = range(6)
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def _mix(z: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def _stream_base(seed: int, stream: int) -> np.uint64:
+    return _mix(np.array([(seed * 0x100000001B3 + stream * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF], np.uint64))[0]
+
+
+def uniforms(stream: int, count: int, offset: int = 0, seed: int = SEED) -> np.ndarray:
+    """count uniforms in [0,1) (float32, exact 24-bit values): element k is output k+offset of the stream."""
+    k = np.arange(offset + 1, offset + count + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = _mix(_stream_base(seed, stream) + k * _GOLDEN)
+    return ((x >> np.uint64(40)).astype(np.float32)) * np.float32(2.0 ** -24)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@dataclass
+class Camera:
+    world: np.ndarray            # float32[16], column-major
+    fov: float
+    z_near: float
+    z_far: float
+    width: int
+    height: int
+    frame: object = None         # _lib.UboFrameData
+
+    @property
+    def aspect(self) -> float:
+        return float(np.float32(self.width) / np.float32(self.height))
+
+
+def make_camera(width: int, height: int, fov: float = 90.0, z_near: float = 1.0, z_far: float = 20000.0) -> Camera:
+    world = host.transform_matrix([0.0, 150.0, 0.0, 1.0], [0.0, 0.0, 0.0, 1.0], [1.0, 1.0, 1.0, 1.0])
+    cam = Camera(world=world, fov=fov, z_near=z_near, z_far=z_far, width=width, height=height)
+    cam.frame = host.fill_frame_data(world, fov, z_near, z_far, width, height)
+    return cam
+
+
+def _value_noise(width: int, height: int, cell: int, stream: int, offset: int, seed: int) -> np.ndarray:
+    """bilinear value noise in [0,1), float64[height, width]."""
+    gw, gh = width // cell + 2, height // cell + 2
+    lattice = uniforms(stream, gw * gh, offset, seed).astype(np.float64).reshape(gh, gw)
+    xs = (np.arange(width) + 0.5) / cell
+    ys = (np.arange(height) + 0.5) / cell
+    x0 = np.floor(xs).astype(np.int64); fx = xs - x0
+    y0 = np.floor(ys).astype(np.int64); fy = ys - y0
+    a = lattice[np.ix_(y0, x0)]; b = lattice[np.ix_(y0, x0 + 1)]
+    c = lattice[np.ix_(y0 + 1, x0)]; d = lattice[np.ix_(y0 + 1, x0 + 1)]
+    top = a * (1 - fx)[None, :] + b * fx[None, :]
+    bot = c * (1 - fx)[None, :] + d * fx[None, :]
+    return top * (1 - fy)[:, None] + bot * fy[:, None]
+
+
+def make_linear_depth(width: int, height: int, seed: int = SEED, d_min: float = 10.0, d_max: float = 3000.0) -> np.ndarray:
+    """The `LinearDepth` render target (R32F positive view distance, LinearizeDepth.shader:69-73): row 0 = top.
+
+    Value noise on a 64-px lattice mapped log-uniformly to [d_min, d_max]; 5 % of 16x16 blocks (offset by 8 px so
+    that they straddle light tiles) are overwritten by a second, independent layer => depth discontinuities
+    inside tiles, so the min/max window of the cull matters."""
+    t = _value_noise(width, height, 64, STREAM_DEPTH, 0, seed)
+    depth = d_min * (d_max / d_min) ** t
+    t2 = _value_noise(width, height, 64, STREAM_DEPTH, 1 << 20, seed)
+    depth2 = d_min * (d_max / d_min) ** t2
+    bw, bh = (width + 8) // 16 + 1, (height + 8) // 16 + 1
+    pick = uniforms(STREAM_DEPTH, bw * bh, 1 << 21, seed).reshape(bh, bw) < 0.05
+    by = (np.arange(height) + 8) // 16
+    bx = (np.arange(width) + 8) // 16
+    mask = pick[np.ix_(by, bx)]
+    depth = np.where(mask, depth2, depth)
+    return np.ascontiguousarray(depth.astype(np.float32))
+
+
+def pixel_rays(cam: Camera) -> tuple[np.ndarray, np.ndarray]:
+    """Appendix D: pixel (px, py) (py = 0 top) has NDC (2(px+.5)/W - 1, 1 - 2(py+.5)/H); view ray (ndc.x/P00, ndc.y/P11, -1)."""
+    proj = np.frombuffer(bytes(cam.frame.projection), np.float32)
+    p00, p11 = proj[0], proj[5]
+    W, H = cam.width, cam.height
+    ndc_x = (2.0 * (np.arange(W, dtype=np.float32) + np.float32(0.5)) / np.float32(W) - 1.0).astype(np.float32)
+    ndc_y = (1.0 - 2.0 * (np.arange(H, dtype=np.float32) + np.float32(0.5)) / np.float32(H)).astype(np.float32)
+    return (ndc_x / p00).astype(np.float32), (ndc_y / p11).astype(np.float32)
+
+
+def make_surface(cam: Camera, depth: np.ndarray, seed: int = SEED, row_begin: int = 0, row_end: int | None = None) -> np.ndarray:
+    """Surface planes float32[3, rows, W, 4] for framebuffer rows [row_begin, row_end):
+    P0 = (worldPos.xyz, albedo.a in U[0.5,1]); P1 = (normalize(-viewDir + 0.8*noise), roughness in U[0.05,1]);
+    P2 = (albedo.rgb in U[0.05,1]^3, metallic: 0 w.p. 0.8 else U[0,1])."""
+    W, H = cam.width, cam.height
+    row_end = H if row_end is None else row_end
+    rows = row_end - row_begin
+    rx, ry = pixel_rays(cam)
+    world = cam.world.reshape(4, 4)  # world[c] = column c
+    d = depth[row_begin:row_end].astype(np.float32)
+    vx = rx[None, :] * d
+    vy = ry[row_begin:row_end, None] * d
+    vz = -d
+    out = np.empty((3, rows, W, 4), np.float32)
+    for i in range(3):  # worldPos = cameraWorld * (view, 1)
+        out[0, :, :, i] = world[0, i] * vx + world[1, i] * vy + world[2, i] * vz + world[3, i]
+    u = uniforms(STREAM_SURFACE, rows * W * 10, row_begin * W * 10, seed).reshape(rows, W, 10)
+    out[0, :, :, 3] = 0.5 + 0.5 * u[:, :, 0]
+    cam_pos = world[3, :3]
+    vd = out[0, :, :, :3] - cam_pos[None, None, :]
+    vd /= np.sqrt((vd * vd).sum(-1, keepdims=True))
+    n = -vd + np.float32(0.8) * (2.0 * u[:, :, 1:4] - 1.0)
+    n /= np.sqrt((n * n).sum(-1, keepdims=True))
+    out[1, :, :, :3] = n
+    out[1, :, :, 3] = 0.05 + 0.95 * u[:, :, 4]
+    out[2, :, :, :3] = 0.05 + 0.95 * u[:, :, 5:8]
+    out[2, :, :, 3] = np.where(u[:, :, 8] < 0.8, np.float32(0.0), u[:, :, 9])
+    return out
+
+
+@dataclass
+class LightSetConfig:
+    count: int
+    spot_fraction: float = 0.0        # C2: 0, C3/C5: 0.25
+    radius_scale: float = 1.0         # "s" of SURVEY 8d, frozen per config below
+    cluster_lights: int = 0           # dense cluster(s) guaranteeing tiles with > 196 candidates
+    cluster_count: int = 1
+    directional_first: bool = False   # C4: light 0 = directional, EVSM
+    d_min: float = 10.0
+    d_max: float = 3000.0
+
+
+def make_lights(cam: Camera, depth: np.ndarray, cfg: LightSetConfig, seed: int = SEED) -> np.ndarray:
+    """LightShaderData records (host.LIGHT_DTYPE).  View depth log-uniform in [d_min, d_max]; x/y uniform in the
+    frustum cross-section x 1.1; r = z * (2/240) * U[2,10] * s."""
+    N = cfg.count
+    u = uniforms(STREAM_LIGHTS, N * 12, 0, seed).reshape(N, 12).astype(np.float64)
+    z = cfg.d_min * (cfg.d_max / cfg.d_min) ** u[:, 0]
+    tan_half = np.tan(np.radians(cam.fov) * 0.5)
+    x = (2 * u[:, 1] - 1) * 1.1 * z * tan_half * cam.aspect
+    y = (2 * u[:, 2] - 1) * 1.1 * z * tan_half
+    r = z * (2.0 / 240.0) * (2 + 8 * u[:, 3]) * cfg.radius_scale
+
+    if cfg.cluster_lights > 0:
+        # clusters sit on the visible surface: pick a pixel, read its depth, scatter lights around that point
+        W, H = cam.width, cam.height
+        rx, ry = pixel_rays(cam)
+        per = cfg.cluster_lights // cfg.cluster_count
+        cu = uniforms(STREAM_LIGHTS, cfg.cluster_count * 2 + cfg.cluster_lights * 4, N * 12, seed).astype(np.float64)
+        for c in range(cfg.cluster_count):
+            px = int((0.15 + 0.7 * cu[2 * c]) * W)
+            py = int((0.15 + 0.7 * cu[2 * c + 1]) * H)
+            dz = float(depth[py, px])
+            idx = (np.arange(per) * (N // max(per, 1)) + c * 7 + 3) % N
+            o = cfg.cluster_count * 2 + c * per * 4
+            j = cu[o:o + per * 4].reshape(per, 4)
+            spread = dz * (2.0 / 240.0) * 3.0
+            z[idx] = dz + (2 * j[:, 0] - 1) * spread * 0.25
+            x[idx] = rx[px] * dz + (2 * j[:, 1] - 1) * spread
+            y[idx] = ry[py] * dz + (2 * j[:, 2] - 1) * spread
+            r[idx] = dz * (2.0 / 240.0) * (3 + 3 * j[:, 3])
+
+    world = cam.world.reshape(4, 4).astype(np.float64)
+    lights = np.zeros(N, host.LIGHT_DTYPE)
+    pos = np.empty((N, 3))
+    for i in range(3):
+        pos[:, i] = world[0, i] * x + world[1, i] * y + world[2, i] * (-z) + world[3, i]
+    lights["worldPosition"] = pos.astype(np.float32)
+    lights["bounds"] = np.repeat(r.astype(np.float32)[:, None], 3, axis=1)
+    lights["intensity"] = np.floor(u[:, 4:7] * 256.0).astype(np.float32)
+    lights["attenuation"] = np.array([1.0, 0.022, 0.0019], np.float32)
+    c_in, c_out = host.cutoff_cosines(30.0, 45.0)
+    lights["cutOff"] = np.array([c_in, c_out], np.float32)
+    # random unit direction
+    zz = 2 * u[:, 7] - 1
+    phi = 2 * np.pi * u[:, 8]
+    rr = np.sqrt(np.maximum(0.0, 1 - zz * zz))
+    lights["direction"] = np.stack([rr * np.cos(phi), rr * np.sin(phi), zz], 1).astype(np.float32)
+    lights["type"] = np.where(u[:, 9] < cfg.spot_fraction, host.LIGHT_SPOT, host.LIGHT_POINT).astype(np.uint32)
+    lights["shadowType"] = host.SHADOW_PCF
+    if cfg.directional_first and N > 0:
+        q = directional_rotation().astype(np.float64)
+        lights["type"][0] = host.LIGHT_DIRECTIONAL
+        lights["shadowType"][0] = host.SHADOW_EVSM
+        lights["direction"][0] = directional_forward(q).astype(np.float32)
+        lights["intensity"][0] = np.array([17.0, 17.0, 17.0], np.float32)  # Editor.world:123-126
+        lights["worldPosition"][0] = 0.0
+    return lights
+
+
+def directional_rotation() -> np.ndarray:
+    """Unit quaternion (x,y,z,w) of the directional light: yaw 25 deg about +Y, then pitch -50 deg about +X, i.e. the
+    light looks into the camera's frustum and down.  (The quaternion serialised at Content/Editor.world:110-114 is not
+    unit length and, fed through the reference's own CSM math with the default camera, puts every visible fragment at
+    light-clip z < 0 where Lighting.glsl:248-252,269-274 return 1 -- no pixel would exercise the shadow lookups.)"""
+    yaw, pitch = np.radians(25.0), np.radians(-50.0)
+    qy = np.array([0.0, np.sin(yaw / 2), 0.0, np.cos(yaw / 2)])
+    qx = np.array([np.sin(pitch / 2), 0.0, 0.0, np.cos(pitch / 2)])
+    ax, ay, az, aw = qy
+    bx, by, bz, bw = qx
+    q = np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                  aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+    return (q / np.linalg.norm(q)).astype(np.float32)
+
+
+def directional_forward(q) -> np.ndarray:
+    """glm::rotate(q, vec3_Forward = (0,0,-1)) (Math/Transform.cpp:74, Math/Math.h:20)."""
+    x, y, z, w = [float(v) for v in q]
+    # third column of the rotation matrix, negated
+    return -np.array([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)])
+
+
+@dataclass
+class ShadowSet:
+    lights_matrices: np.ndarray                 # float32[4,16]
+    maps: list = field(default_factory=list)    # 4 numpy arrays: [0] float32[S,S,4], [1..3] float16[S,S]
+    size: int = 0
+
+
+def make_shadow_set(cam: Camera, size: int, seed: int = SEED) -> ShadowSet:
+    """lightsMatrices via the native S9 path; maps from an analytic occluder field (64 discs), no rasteriser.
+    Cascade 0: RGBA32F (e^{40z}, e^{80z}, -e^{-40z}, e^{-80z}) (ShadowCaster.shader:71-75); cascades 1-3: R16F z."""
+    light_world = host.transform_matrix([0, 0, 0, 0], directional_rotation(), [1, 1, 1, 1])
+    light_view = host.mat4_inverse(light_world)
+    lm = host.csm_matrices(light_view, cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+    maps = []
+    for k in range(4):
+        u = uniforms(STREAM_SHADOW, 64 * 4, k * 1024, seed).reshape(64, 4).astype(np.float64)
+        ys, xs = np.meshgrid((np.arange(size) + 0.5) / size, (np.arange(size) + 0.5) / size, indexing="ij")
+        zf = np.full((size, size), 0.25)
+        for d in range(64):
+            cx, cy, rad, h = u[d, 0], u[d, 1], 0.03 + 0.12 * u[d, 2], 0.3 + 0.55 * u[d, 3]
+            inside = (xs - cx) ** 2 + (ys - cy) ** 2 < rad * rad
+            zf = np.where(inside, np.maximum(zf, h), zf)
+        if k == 0:
+            z32 = zf.astype(np.float32)
+            e = np.exp(np.float32(40.0) * z32).astype(np.float32)
+            n = (-np.exp(np.float32(-40.0) * z32)).astype(np.float32)
+            maps.append(np.ascontiguousarray(np.stack([e, e * e, n, n * n], -1).astype(np.float32)))
+        else:
+            maps.append(np.ascontiguousarray(zf.astype(np.float16)))
+    return ShadowSet(lights_matrices=lm, maps=maps, size=size)
+
+
+@dataclass
+class EntitySet:
+    transforms: np.ndarray     # float32[N, 12]  (position4, rotation xyzw, scale4)
+    parent: np.ndarray         # uint32[N], 0xFFFFFFFF = root, level-sorted
+    level_offsets: np.ndarray  # uint32[L+1]
+    local_aabb: np.ndarray     # float32[N, 6]
+
+
+def make_entities(count: int, seed: int = SEED, editor_world: bool = True) -> EntitySet:
+    """TRS with position U[-8000,8000]^3, unit quaternion, scale U[0.5,4]; local AABB centre 0, extents U[0.5,50]^3;
+    hierarchy depth <= 3, level-sorted, 70 % roots.  With editor_world the first 4 roots are the Editor.world objects
+    (Content/Editor.world:4,46,75,104: Camera at (0,150,0), Sponza, Box, Light)."""
+    n0 = max(1, int(round(count * 0.7)))
+    n1 = int(round(count * 0.2))
+    n2 = count - n0 - n1
+    if n2 < 0:
+        n1 += n2; n2 = 0
+    levels = [n0, n1, n2]
+    offs = np.cumsum([0] + levels).astype(np.uint32)
+    u = uniforms(STREAM_ENTITIES, count * 16, 0, seed).reshape(count, 16).astype(np.float64)
+    trs = np.zeros((count, 12), np.float32)
+    trs[:, 0:3] = (-8000 + 16000 * u[:, 0:3]).astype(np.float32)
+    trs[:, 3] = 1.0
+    q = u[:, 3:7] * 2 - 1
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    trs[:, 4:8] = q.astype(np.float32)
+    s = (0.5 + 3.5 * u[:, 7:10]).astype(np.float32)
+    trs[:, 8:11] = s
+    trs[:, 11] = 1.0
+    ext = (0.5 + 49.5 * u[:, 10:13]).astype(np.float32)
+    aabb = np.concatenate([-ext, ext], 1).astype(np.float32)
+    parent = np.full(count, 0xFFFFFFFF, np.uint32)
+    pu = u[:, 13]
+    for lvl in (1, 2):
+        lo, hi = int(offs[lvl]), int(offs[lvl + 1])
+        plo, phi = int(offs[lvl - 1]), int(offs[lvl])
+        if hi > lo:
+            parent[lo:hi] = (plo + np.floor(pu[lo:hi] * (phi - plo))).astype(np.uint32)
+            trs[lo:hi, 0:3] *= np.float32(0.01)  # children live near their parent
+    if editor_world and count >= 4:
+        trs[0] = [0, 150, 0, 1, 0, 0, 0, 1, 1, 1, 1, 1]
+        for i in (1, 2):
+            trs[i] = [0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1]
+        trs[3] = [0, 0, 0, 0, *directional_rotation(), 1, 1, 1, 1]
+    level_offsets = offs if n2 > 0 else (offs[:3] if n1 > 0 else offs[:2])
+    return EntitySet(transforms=np.ascontiguousarray(trs), parent=parent, level_offsets=np.ascontiguousarray(level_offsets.astype(np.uint32)),
+                     local_aabb=np.ascontiguousarray(aabb))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The BASELINE.json configurations (C1..C5).  radius_scale ("s") is FROZEN here; the realised list
+# statistics of each configuration are recorded in DESIGN.md and in the golden fixtures.
+# ---------------------------------------------------------------------------------------------------------------
+CONFIGS = {
+    "C2": dict(width=1920, height=1080, lights=LightSetConfig(count=4096, spot_fraction=0.0, radius_scale=3.0)),
+    "C3": dict(width=3840, height=2160, lights=LightSetConfig(count=65536, spot_fraction=0.25, radius_scale=1.25, cluster_lights=1200, cluster_count=3)),
+    "C4": dict(width=3840, height=2160, lights=LightSetConfig(count=65536, spot_fraction=0.25, radius_scale=1.25, cluster_lights=1200, cluster_count=3,
+                                                              directional_first=True), shadow_size=4096),
+    "C5": dict(width=7680, height=4320, lights=LightSetConfig(count=1048576, spot_fraction=0.25, radius_scale=0.5, cluster_lights=1200, cluster_count=3),
+               entities=1048576),
+    # small fixtures used by the CPU/GPU parity suites
+    "tiny": dict(width=128, height=96, lights=LightSetConfig(count=512, spot_fraction=0.25, radius_scale=6.0, cluster_lights=300, cluster_count=1)),
+    "tiny_csm": dict(width=128, height=96, lights=LightSetConfig(count=512, spot_fraction=0.25, radius_scale=6.0, cluster_lights=300, cluster_count=1,
+                                                                 directional_first=True), shadow_size=64),
+}
+
+
+@dataclass
+class Frame:
+    name: str
+    cam: Camera
+    depth: np.ndarray
+    lights: np.ndarray
+    surface: np.ndarray | None = None
+    shadows: ShadowSet | None = None
+
+
+def make_frame(name: str, with_surface: bool = True, seed: int = SEED, **override) -> Frame:
+    cfg = dict(CONFIGS[name]); cfg.update(override)
+    cam = make_camera(cfg["width"], cfg["height"])
+    depth = make_linear_depth(cam.width, cam.height, seed)
+    lights = make_lights(cam, depth, cfg["lights"], seed)
+    surface = make_surface(cam, depth, seed) if with_surface else None
+    shadows = make_shadow_set(cam, cfg["shadow_size"], seed) if cfg.get("shadow_size") else None
+    return Frame(name=name, cam=cam, depth=depth, lights=lights, surface=surface, shadows=shadows)

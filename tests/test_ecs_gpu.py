@@ -1,0 +1,97 @@
+"""K4 parity (GPU): ECS transform + bounds + frustum cull sweep and the sphere-vs-view-frustum instance cull, through the
+C-ABI, against the CPU oracle -- bit-exact world matrices, world AABBs and visibility words."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from sailor_amd import _lib, host, synth
+from sailor_amd.forward_plus import EcsSweep
+
+pytestmark = pytest.mark.gpu
+
+
+def camera_planes(cam):
+    planes, _ = host.extract_frustum_planes(cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+    return planes
+
+
+@pytest.mark.parametrize("count", [1024, 1000, 65, 7, 100000])
+def test_sweep_bit_exact(ctx, count):
+    """configs[0] (1 024 entities, the Editor.world objects first) and ragged sizes."""
+    ents = synth.make_entities(count)
+    cam = synth.make_camera(1920, 1080)
+    planes = camera_planes(cam)
+    sweep = EcsSweep(ctx, ents)
+    world, aabb, vis = sweep.run(planes)
+    ctx.synchronize()
+    ow, oa, ov = oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes)
+    np.testing.assert_array_equal(world.cpu().numpy().view(np.uint32), ow.view(np.uint32))
+    np.testing.assert_array_equal(aabb.cpu().numpy().view(np.uint32), oa.view(np.uint32))
+    np.testing.assert_array_equal(vis.cpu().numpy().view(np.uint64), ov)
+    nvis = int(np.unpackbits(ov.view(np.uint8)).sum())
+    if count >= 1000:
+        assert 0 < nvis < count
+
+
+def test_flt_min_quirk_all_negative_box(ctx):
+    """Math/Bounds.cpp:484: max is seeded with the smallest POSITIVE float, so an all-negative box keeps max ~ 1.18e-38."""
+    ents = synth.make_entities(64, editor_world=False)
+    ents.transforms[:, 0:3] = -np.abs(ents.transforms[:, 0:3]) - 100.0
+    ents.transforms[:, 4:8] = [0, 0, 0, 1]
+    ents.parent[:] = 0xFFFFFFFF
+    ents.level_offsets = np.array([0, 64], np.uint32)
+    cam = synth.make_camera(640, 360)
+    planes = camera_planes(cam)
+    sweep = EcsSweep(ctx, ents)
+    _, aabb, _ = sweep.run(planes)
+    ctx.synchronize()
+    _, oa, _ = oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes)
+    got = aabb.cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint32), oa.view(np.uint32))
+    assert (got[:, 3:] == np.finfo(np.float32).tiny).all()
+
+
+def test_mesh_frustum_cull_matches_shader_semantics(ctx):
+    cam = synth.make_camera(1920, 1080)
+    ents = synth.make_entities(5000)
+    planes = camera_planes(cam)
+    ow, _, _ = oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes)
+    inst = np.zeros(5000, host.INSTANCE_DTYPE)
+    inst["model"] = ow
+    u = synth.uniforms(synth.STREAM_ENTITIES, 5000 * 4, 1 << 24).reshape(5000, 4)
+    inst["sphereBounds"][:, :3] = (u[:, :3] - 0.5) * 10
+    inst["sphereBounds"][:, 3] = 1 + 60 * u[:, 3]
+    inst["isCulled"] = 7
+    ref = oracle.mesh_frustum_cull(cam.frame, inst)
+    t = torch.from_numpy(inst.view(np.uint8).reshape(-1).copy()).to(ctx.device)
+    lib = _lib.load()
+    _lib.check(lib.sailor_hip_mesh_frustum_cull(ctx.handle, C.byref(cam.frame), t.data_ptr(), 5000, 0), "mesh_frustum_cull", ctx.handle)
+    ctx.synchronize()
+    got = t.cpu().numpy().view(host.INSTANCE_DTYPE)
+    np.testing.assert_array_equal(got["isCulled"], ref["isCulled"])
+    assert 0 < int(ref["isCulled"].sum()) < 5000
+    # firstInstanceIndex / numInstances window: only [100, 300) is touched
+    inst["isCulled"] = 7
+    t = torch.from_numpy(inst.view(np.uint8).reshape(-1).copy()).to(ctx.device)
+    _lib.check(lib.sailor_hip_mesh_frustum_cull(ctx.handle, C.byref(cam.frame), t.data_ptr(), 200, 100), "mesh_frustum_cull", ctx.handle)
+    ctx.synchronize()
+    got = t.cpu().numpy().view(host.INSTANCE_DTYPE)
+    assert (got["isCulled"][:100] == 7).all() and (got["isCulled"][300:] == 7).all()
+    np.testing.assert_array_equal(got["isCulled"][100:300], ref["isCulled"][100:300])
+
+
+def test_sweep_1m_entities_visibility_checksum(ctx):
+    """configs[4] entity count: 1 048 576 entities, compared word for word with the oracle (a second of CPU time)."""
+    ents = synth.make_entities(1 << 20)
+    cam = synth.make_camera(7680, 4320)
+    planes = camera_planes(cam)
+    sweep = EcsSweep(ctx, ents)
+    world, aabb, vis = sweep.run(planes)
+    ctx.synchronize()
+    ow, oa, ov = oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes)
+    np.testing.assert_array_equal(vis.cpu().numpy().view(np.uint64), ov)
+    np.testing.assert_array_equal(aabb.cpu().numpy().view(np.uint32), oa.view(np.uint32))
+    np.testing.assert_array_equal(world.cpu().numpy().view(np.uint32), ow.view(np.uint32))
