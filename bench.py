@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the MI355X-native Forward+ lighting path (BASELINE.json: "lit Mpixels/s + Mlights culled/s at
+4K / 65 536 lights; 1/2/4/8-GPU scaling").
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one pass of the hot path over one synthetic frame: K0 light view transform + K1 tile light cull + K2 PBR shade
+over the per-tile lists (BASELINE.json configs[2]: 4K, 65 536 point+spot lights, synthetic G-buffer/surface tiles), with
+every input already resident in HBM.  With N > 1 the SAME frame is split into N contiguous tile-row bands, one per rank
+(strong scaling: total work is fixed); cull + shade need no collective on a band partition, so none is in
+the timed region; after timing, the band lists are exchanged once over RCCL (count all-gather + index all-gather) and
+the stitched global buffers are checked against a checksum so the distributed path is exercised end to end.
+
+Rank 0 prints ONE JSON line.  `value` = W*H*K / max-over-ranks(time) in Mpixels/s.  `roofline` is for the dominant
+kernel (k2_shade): algorithmic bytes per launch / its average launch duration measured with HIP events
+on the launch stream.  `cpu_baseline` = the CPU oracle (a port: the reference cannot be built here) timed on a bounded
+sample of the same workload on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from sailor_amd import _lib, host, synth  # noqa: E402
+from sailor_amd.forward_plus import EcsSweep, ForwardPlus, HipContext, upload_lights  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0       # same table: 6.29 TB/s measured float4 copy
+FP32_VALU_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-tile-rows", type=int, default=12)
+    ap.add_argument("--exchange-every-step", action="store_true", help="include the RCCL list exchange in the timed region (N > 1)")
+    return ap.parse_args()
+
+
+def event_ms(fn, steps):
+    """average duration of fn() in ms, HIP events on the current (= launch) stream, one pair per call."""
+    pairs = []
+    for _ in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    t = np.array([a.elapsed_time(b) for a, b in pairs])
+    return float(t.mean()), float(np.median(t)), float(np.percentile(t, 10)), float(np.percentile(t, 90))
+
+
+def cpu_baseline(frame, sample_rows: int):
+    """The oracle (CPU restatement of the reference algorithm) on a bounded band of the same frame, 1 thread."""
+    from oracle import oracle
+    cam, W, H = frame.cam, frame.cam.width, frame.cam.height
+    Tx, Ty = host.num_tiles(W, H)
+    r0 = (Ty - sample_rows) // 2
+    r1 = r0 + sample_rows
+    fb0, fb1 = H - 16 * r1, H - 16 * r0
+    surface = frame.surface_rows(fb0, fb1)
+    t0 = time.perf_counter()
+    g, idx, _ = oracle.light_cull(cam.frame, W, H, frame.lights, frame.depth, tile_rows=(r0, r1))
+    t_cull = time.perf_counter() - t0
+    grid = np.zeros((Tx * Ty, 2), np.uint32); grid[:, 0] = 1
+    grid[r0 * Tx:r1 * Tx] = g
+    planes = np.zeros((3, H, W, 4), np.float32)  # the oracle addresses rows of full-frame planes; untouched pages stay virtual
+    planes[:, fb0:fb1] = surface
+    t0 = time.perf_counter()
+    oracle.shade(cam.frame, W, H, planes, frame.lights, grid, idx, None, rows=(fb0, fb1))
+    t_shade = time.perf_counter() - t0
+    pixels = (fb1 - fb0) * W
+    return {"value": pixels / (t_cull + t_shade) / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": f"tile rows [{r0},{r1}) of {Ty} ({pixels} pixels): oracle cull {t_cull:.2f} s + shade {t_shade:.2f} s, scalar C, gcc -O2 -ffp-contract=off",
+            "mlights_culled_per_s": len(frame.lights) * (sample_rows / Ty) / t_cull / 1e6,
+            "host_cpu": _cpu_model(), "host_cores": os.cpu_count()}
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def ecs_baseline(ctx, count: int, steps: int):
+    """K4 next to the reference's CPU ECS/frustum-cull loop: oracle port, 1 thread and all host cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    ents = synth.make_entities(count)
+    cam = synth.make_camera(3840, 2160)
+    planes, _ = host.extract_frustum_planes(cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+    sweep = EcsSweep(ctx, ents)
+    for _ in range(3):
+        sweep.run(planes)
+    mean, med, _, _ = event_ms(lambda: sweep.run(planes), steps)
+    world = np.zeros((count, 16), np.float32); aabb = np.zeros((count, 6), np.float32); vis = np.zeros((count + 63) // 64, np.uint64)
+    t0 = time.perf_counter()
+    oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes, world=world, world_aabb=aabb, visibility=vis)
+    t1 = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    offs = [int(v) for v in ents.level_offsets]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as pool:
+        for lo, hi in zip(offs[:-1], offs[1:]):  # levels in order; 1024-entity chunks like StaticMeshRendererECS.cpp:19
+            chunks = [(b, min(b + 1024, hi)) for b in range(lo, hi, 1024)]
+            list(pool.map(lambda c: oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes, c[0], c[1], world, aabb, vis), chunks))
+    tn = time.perf_counter() - t0
+    bytes_per_entity = 164.125
+    return {"entities": count, "gpu_ms": med, "gpu_mentities_per_s": count / med / 1e3, "gpu_hbm_gbs": count * bytes_per_entity / med / 1e6,
+            "gpu_hbm_frac": count * bytes_per_entity / med / 1e6 / HBM_PEAK_GBS,
+            "cpu_1thread_mentities_per_s": count / t1 / 1e6, "cpu_ns_per_entity_1thread": t1 / count * 1e9,
+            "cpu_allcores_mentities_per_s": count / tn / 1e6, "cpu_cores": cores, "cpu_model": _cpu_model(), "kind": "port"}
+
+
+class BenchFrame:
+    """Synthetic frame with lazily generated surface rows (the full 4K surface is 531 MB; ranks only make their band)."""
+
+    def __init__(self, name):
+        cfg = synth.CONFIGS[name]
+        self.cfg = cfg
+        self.cam = synth.make_camera(cfg["width"], cfg["height"])
+        self.depth = synth.make_linear_depth(self.cam.width, self.cam.height)
+        self.lights = synth.make_lights(self.cam, self.depth, cfg["lights"])
+
+    def surface_rows(self, r0, r1):
+        return synth.make_surface(self.cam, self.depth, row_begin=r0, row_end=r1)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    frame = BenchFrame(args.config)
+    cam, W, H = frame.cam, frame.cam.width, frame.cam.height
+    N = len(frame.lights)
+    band = host.band_for_rank(W, H, rank, world)
+    rows = slice(band.fbRowBegin, band.fbRowBegin + band.fbRowCount)
+    ctx = HipContext(dev)
+    fp = ForwardPlus(ctx, W, H, N, band=band)
+    d_depth = torch.from_numpy(np.ascontiguousarray(frame.depth[rows])).to(dev)
+    d_lights = upload_lights(frame.lights, dev)
+    d_surface = torch.from_numpy(frame.surface_rows(rows.start, rows.stop)).to(dev)
+    csm = keep = None
+    if frame.cfg.get("shadow_size"):
+        from sailor_amd.forward_plus import upload_shadow_maps
+        shadows = synth.make_shadow_set(cam, frame.cfg["shadow_size"])
+        csm, keep = upload_shadow_maps(shadows, dev)
+
+    def cull():
+        fp.cull(cam.frame, d_lights, N, d_depth)
+
+    def shade():
+        fp.shade(cam.frame, d_surface, d_lights, N, csm)
+
+    def exchange():
+        from sailor_amd import dist as sdist
+        return sdist.exchange_lists(fp.grid[: fp.band_tiles * 2], fp.culled)
+
+    def step():
+        cull()
+        shade()
+        if world > 1 and args.exchange_every_step:
+            exchange()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = W * H * args.steps / elapsed / 1e6
+
+    # ---- per-kernel timing on the launch stream (HIP events) + algorithmic bytes ----
+    cull_ms = event_ms(cull, args.steps)
+    shade_ms = event_ms(shade, args.steps)
+    g, idx = fp.lists_to_host()
+    sum_nt = int(idx[0])
+    distinct = int(len(np.unique(idx[1:]))) if sum_nt else 0
+    band_pixels = band.fbRowCount * W
+    b_shade = 64 * band_pixels + 8 * fp.band_tiles + 4 * sum_nt + 112 * distinct
+    b_cull = 20 * N + 4 * band_pixels + 8 * fp.band_tiles + 4 * sum_nt + 4
+    evals = int((g[:, 1].astype(np.int64) * 256).sum())
+    shade_gbs = b_shade / (shade_ms[0] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k2_shade", "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
+                "traffic": None, "bytes_per_launch": b_shade, "avg_launch_ms": shade_ms[0], "median_launch_ms": shade_ms[1],
+                "frac_of_measured_copy_peak": shade_gbs / HBM_COPY_GBS,
+                "valu_sidebar": {"pixel_light_evals": evals, "gevals_per_s": evals / (shade_ms[0] * 1e-3) / 1e9,
+                                 "note": "~110 fp32 ops per (pixel,light): VALU-bound once mean list length exceeds ~10 (SURVEY.md 7, hard part 2)"},
+                "cull": {"kernels": "k0_light_view+k1_*", "avg_ms": cull_ms[0], "median_ms": cull_ms[1], "bytes": b_cull,
+                         "achieved_gbs": b_cull / (cull_ms[0] * 1e-3) / 1e9, "frac": b_cull / (cull_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+
+    exchange_info = None
+    if world > 1:
+        gg, gi = exchange()
+        torch.cuda.synchronize()
+        tot = int(gi[0].item())
+        exchange_info = {"global_sum_num": tot, "checksum": int(gi[1:1 + tot].to(torch.int64).sum().item()), "tiles": int(gg.numel() // 2)}
+
+    if rank == 0:
+        out = {
+            "metric": "lit Mpixels/s (K0+K1 tile light cull + K2 PBR shade over per-tile lists)", "value": value, "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {W}x{H}, {N} point+spot lights, 16x16 tiles ({fp.Tx}x{fp.Ty}), cull + PBR shade"
+                                   + (" + 4-cascade CSM" if csm is not None else ""),
+                       "width": W, "height": H, "lights": N, "parallelism": f"tile-row bands x{world}",
+                       "mean_list_length": sum_nt / max(fp.band_tiles, 1), "sum_num_rank0_band": sum_nt, "distinct_lights_rank0_band": distinct,
+                       "generator": {"seed": synth.SEED, "radius_scale": frame.cfg["lights"].radius_scale}},
+            "mlights_culled_per_s": N / (cull_ms[1] * 1e-3) / 1e6,
+            "cull_ms": cull_ms[1], "shade_ms": shade_ms[1],
+            "roofline": roofline,
+        }
+        if exchange_info:
+            out["exchange"] = exchange_info
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frame, args.cpu_sample_tile_rows)
+            out["ecs_sweep"] = ecs_baseline(ctx, 1 << 20, 20)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

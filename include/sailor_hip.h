@@ -155,8 +155,11 @@ SAILOR_HIP_API const char* sailor_hip_status_string(int status);
 SAILOR_HIP_API int sailor_hip_device_count(int* outCount);
 
 /* Replaces: RHI/Renderer.cpp:60-63 (backend instantiation) + IGraphicsDriver::Initialize (RHI/GraphicsDriver.h:63).
- * `stream` is a hipStream_t the caller owns, or NULL to let the context create (and own) one. */
-SAILOR_HIP_API int sailor_hip_context_create(int deviceOrdinal, void* stream, SailorHipContext** outContext);
+ * flags = 0: record on `stream`, a hipStream_t the caller owns (NULL = the device's default stream, which is what
+ * torch.cuda.current_stream() is unless the caller switched streams).  flags = SAILOR_CTX_OWN_STREAM: `stream` is
+ * ignored and the context creates (and owns) a non-blocking stream -- the graphics-queue analogue of the reference. */
+#define SAILOR_CTX_OWN_STREAM 1u
+SAILOR_HIP_API int sailor_hip_context_create(int deviceOrdinal, void* stream, uint32_t flags, SailorHipContext** outContext);
 SAILOR_HIP_API int sailor_hip_context_destroy(SailorHipContext* ctx);
 /* Replaces: IGraphicsDriver::WaitIdle (RHI/GraphicsDriver.h:83) */
 SAILOR_HIP_API int sailor_hip_context_synchronize(SailorHipContext* ctx);

@@ -128,6 +128,16 @@ static inline void normalize3_glm(const float* a, float* o)
     float inv = 1.0f / sqrtf(dot3(a, a));
     o[0] = a[0] * inv; o[1] = a[1] * inv; o[2] = a[2] * inv;
 }
+/* normalize() inside the SHADE path (K2).  GLSL leaves normalize's rounding to the implementation; the Vulkan spec's
+ * "Precision of GLSL.std.450 instructions" table defines it as inherited from x * inversesqrt(dot(x, x)).  K2 is checked
+ * to a tolerance, but NdfGGX's denominator (cosLh^2 (a^2 - 1) + 1) cancels catastrophically at the specular peak of
+ * smooth surfaces, amplifying a 1-ulp difference in Lh ~10^4 times -- so the half-vector chain is specified exactly:
+ * inversesqrt(x) = 1.0f / sqrtf(x), both correctly rounded, then three multiplies.  (K1 keeps SURVEY 8c's v / length(v).) */
+static inline void normalize3_vk(const float* a, float* o)
+{
+    const float inv = 1.0f / sqrtf(dot3(a, a));
+    o[0] = a[0] * inv; o[1] = a[1] * inv; o[2] = a[2] * inv;
+}
 static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 /* column-major mat4: element (col c, row r) = m[c*4 + r] */
@@ -694,10 +704,10 @@ static void calculate_lighting(const UboFrameData* ubo, const LightData* L, cons
         falloff = attenuation * (1.0f - powf(clampf(distance / L->bounds[0], 0.0f, 1.0f), 2.0f));
     } else if (L->type == 2) {
         float d[3] = { L->worldPosition[0] - worldPos[0], L->worldPosition[1] - worldPos[1], L->worldPosition[2] - worldPos[2] };
-        float lightDir[3]; normalize3_glsl(d, lightDir);
+        float lightDir[3]; normalize3_vk(d, lightDir);
         float epsilon = L->cutOff[0] - L->cutOff[1];
         float nd[3] = { -L->direction[0], -L->direction[1], -L->direction[2] }, ndn[3];
-        normalize3_glsl(nd, ndn);
+        normalize3_vk(nd, ndn);
         float theta = dot3(lightDir, ndn);
         const float distance = length3(d);
         const float attenuation = 1.0f / (L->attenuation[0] + L->attenuation[1] * distance + L->attenuation[2] * (distance * distance));
@@ -706,7 +716,7 @@ static void calculate_lighting(const UboFrameData* ubo, const LightData* L, cons
     }
     float Li[3] = { -L->direction[0], -L->direction[1], -L->direction[2] };
     float s[3] = { Li[0] + Lo[0], Li[1] + Lo[1], Li[2] + Lo[2] }, Lh[3];
-    normalize3_glsl(s, Lh);
+    normalize3_vk(s, Lh);
     float cosLi = fmaxf(0.0f, dot3(normal, Li));
     float cosLh = fmaxf(0.0f, dot3(normal, Lh));
     float f5 = powf(1.0f - fmaxf(0.0f, dot3(Lh, Lo)), 5.0f);
@@ -751,7 +761,7 @@ ORACLE_API void oracle_shade(const void* ubo_, int W, int H, const float* surfac
             const float roughness = P1[3], metallic = P2[3];
             const float albedo[3] = { P2[0], P2[1], P2[2] };
             float vd[3] = { worldPos[0] - ubo->cameraPosition[0], worldPos[1] - ubo->cameraPosition[1], worldPos[2] - ubo->cameraPosition[2] };
-            float viewDir[3]; normalize3_glsl(vd, viewDir);
+            float viewDir[3]; normalize3_vk(vd, viewDir);
             float Lo[3] = { -viewDir[0], -viewDir[1], -viewDir[2] };
             float cosLo = fmaxf(0.0f, dot3(normal, Lo));
             float F0[3];

@@ -19,6 +19,7 @@ CANDIDATES = 196     # Constants.glsl:14
 LIGHTS_PER_TILE = 128  # Constants.glsl:15
 NUM_CASCADES = 4     # Constants.glsl:23
 
+CTX_OWN_STREAM = 1
 CULL_DEFAULT = 0
 CULL_BRUTE_FORCE = 1
 
@@ -74,7 +75,7 @@ SIGNATURES = {
     "sailor_hip_version": (C.c_int, []),
     "sailor_hip_status_string": (C.c_char_p, [C.c_int]),
     "sailor_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
-    "sailor_hip_context_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    "sailor_hip_context_create": (C.c_int, [C.c_int, _P, C.c_uint32, C.POINTER(_P)]),
     "sailor_hip_context_destroy": (C.c_int, [_P]),
     "sailor_hip_context_synchronize": (C.c_int, [_P]),
     "sailor_hip_context_stream": (C.c_int, [_P, C.POINTER(_P)]),

@@ -32,7 +32,7 @@ int sailor_hip_device_count(int* outCount)
     return SAILOR_HIP_OK;
 }
 
-int sailor_hip_context_create(int deviceOrdinal, void* stream, SailorHipContext** outContext)
+int sailor_hip_context_create(int deviceOrdinal, void* stream, uint32_t flags, SailorHipContext** outContext)
 {
     if (!outContext) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     *outContext = nullptr;
@@ -45,7 +45,7 @@ int sailor_hip_context_create(int deviceOrdinal, void* stream, SailorHipContext*
     if (hipSetDevice(deviceOrdinal) != hipSuccess) { delete ctx; return SAILOR_HIP_ERR_NO_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, deviceOrdinal) == hipSuccess) ctx->numCUs = prop.multiProcessorCount;
-    if (stream) { ctx->stream = (hipStream_t)stream; ctx->ownsStream = false; }
+    if (!(flags & SAILOR_CTX_OWN_STREAM)) { ctx->stream = (hipStream_t)stream; ctx->ownsStream = false; }
     else {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SAILOR_HIP_ERR_LAUNCH; }
         ctx->ownsStream = true;

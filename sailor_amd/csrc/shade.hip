@@ -12,9 +12,15 @@
 // wave-uniform (all lanes walk the same list), and a wave skips the BRDF of a light whose falloff is zero on
 // all of its 64 pixels (the list is conservative: sphere-vs-tile-frustum).
 //
-// Numerics: the BRDF is tolerance-checked (1e-4 relative), so it uses v_rcp/v_rsq and explicit FMAs.  The shadow
-// factor is a step function of its inputs (cascade select, PCF compares, EVSM's exp(40 z) - moment), so K3 is
-// evaluated in the canonical fp32 order with true divisions and the fixed exp algorithm of the oracle, bit for bit.
+// Numerics: the BRDF is tolerance-checked (1e-4 relative), so its well-conditioned parts use v_rcp and explicit
+// FMAs.  Two places are NOT well-conditioned and are evaluated in the oracle's exact fp32 order instead:
+//   * the shadow factor is a step function of its inputs (cascade select, PCF compares, EVSM's exp(40 z) - moment):
+//     K3 uses true divisions and the fixed exp algorithm, bit for bit;
+//   * NdfGGX's denominator cosLh^2 (a^2 - 1) + 1 cancels catastrophically at the specular peak of smooth surfaces
+//     (a^2 down to 6e-6), amplifying 1 ulp of the half vector ~10^4 times: the chain viewDir -> Lo -> Lh -> cosLh ->
+//     denominator uses normalize(v) = v * (1 / sqrt(dot(v, v))) with IEEE sqrt and divide (the Vulkan spec's definition
+//     of GLSL.std.450 Normalize) and unfused dot products; likewise distance / bounds.x of the radius window and the
+//     spot cone's (theta - cutOff.y) / epsilon, which cancel at the edge of a light's reach.
 // The translation unit is compiled with -ffp-contract=off; every fused multiply-add below is written explicitly.
 #include "common.h"
 #include <hip/hip_fp16.h>
@@ -240,7 +246,8 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
             o[1] = make_float4(ndx, ndy, ndz, __uint_as_float(type | (shadowType << 8)));
             o[2] = make_float4(q3.x, q3.y, q3.z, q5.y);                                  // intensity, cutOff.y
             o[3] = make_float4(q4.x, q4.y, q4.z, q5.x - q5.y);                           // attenuation, epsilon (:297)
-            o[4] = make_float4(ndx / len, ndy / len, ndz / len, 0.0f);
+            const float linv = 1.0f / len;
+            o[4] = make_float4(ndx * linv, ndy * linv, ndz * linv, 0.0f);
         }
     }
     __syncthreads();
@@ -250,10 +257,10 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
     const float wx = P0.x, wy = P0.y, wz = P0.z;
     const float nx = P1.x, ny = P1.y, nz = P1.z, roughness = P1.w;
     const float metallic = P2.w;
-    float vx = wx - A.camX, vy = wy - A.camY, vz = wz - A.camZ;
-    const float vinv = rsq_fast(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
-    const float Lox = -vx * vinv, Loy = -vy * vinv, Loz = -vz * vinv; // Lo = -viewDirection
-    const float cosLo = fmaxf(0.0f, fmaf(nx, Lox, fmaf(ny, Loy, nz * Loz)));
+    const float vx = wx - A.camX, vy = wy - A.camY, vz = wz - A.camZ;
+    const float vinv = 1.0f / sqrtf(dot3f(vx, vy, vz, vx, vy, vz));          // exact chain (see header)
+    const float Lox = -(vx * vinv), Loy = -(vy * vinv), Loz = -(vz * vinv);  // Lo = -viewDirection
+    const float cosLo = fmaxf(0.0f, dot3f(nx, ny, nz, Lox, Loy, Loz));
     const float oneMinusMetal = 1.0f - metallic;
     const float F0x = fmaf(P2.x, metallic, 0.04f * oneMinusMetal);
     const float F0y = fmaf(P2.y, metallic, 0.04f * oneMinusMetal);
@@ -272,8 +279,8 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
         float falloff = 1.0f, shadow = 1.0f;
         if (type == 1u || type == 2u) {
             const float dx = r0.x - wx, dy = r0.y - wy, dz = r0.z - wz;
-            const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-            const float dist = sqrtf(d2);
+            const float d2 = dot3f(dx, dy, dz, dx, dy, dz);
+            const float dist = sqrtf(d2);                                       // exact: feeds 1 - (dist / bounds.x)^2
             const float4 r3 = R[3];
             const float att = rcp_fast(fmaf(r3.z, d2, fmaf(r3.y, dist, r3.x))); // 1/(a.x + a.y d + a.z d^2) (:289,:300)
             if (type == 1u) {
@@ -281,8 +288,8 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
                 falloff = att * (1.0f - q * q);                              // (:290)
             } else {
                 const float4 r4 = R[4];
-                const float dinv = rcp_fast(dist);
-                const float theta = fmaf(dx, r4.x, fmaf(dy, r4.y, dz * r4.z)) * dinv; // dot(normalize(pos - wp), normalize(-dir))
+                const float dinv = 1.0f / dist; // exact chain: (theta - cutOff.y) cancels at the cone edge
+                const float theta = dot3f(dx * dinv, dy * dinv, dz * dinv, r4.x, r4.y, r4.z); // dot(normalize(pos - wp), normalize(-dir))
                 const float cutY = R[2].w;
                 falloff = att * fminf(fmaxf((theta - cutY) / r3.w, 0.0f), 1.0f);     // (:301)
                 if (theta < cutY) falloff = 0.0f;                                     // (:303-306)
@@ -295,14 +302,14 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
         // ---- Cook-Torrance (Standard.shader:309-340) ----
         const float Lix = r1.x, Liy = r1.y, Liz = r1.z;
         float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;
-        const float hinv = rsq_fast(fmaf(hx, hx, fmaf(hy, hy, hz * hz)));
+        const float hinv = 1.0f / sqrtf(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
         hx *= hinv; hy *= hinv; hz *= hinv;
-        const float cosLi = fmaxf(0.0f, fmaf(nx, Lix, fmaf(ny, Liy, nz * Liz)));
-        const float cosLh = fmaxf(0.0f, fmaf(nx, hx, fmaf(ny, hy, nz * hz)));
-        const float x1 = 1.0f - fmaxf(0.0f, fmaf(hx, Lox, fmaf(hy, Loy, hz * Loz)));
+        const float cosLi = fmaxf(0.0f, dot3f(nx, ny, nz, Lix, Liy, Liz));
+        const float cosLh = fmaxf(0.0f, dot3f(nx, ny, nz, hx, hy, hz));
+        const float x1 = 1.0f - fmaxf(0.0f, dot3f(hx, hy, hz, Lox, Loy, Loz));
         const float x2 = x1 * x1, x5 = x2 * x2 * x1;                              // pow(1 - cosTheta, 5)
         const float Fx = fmaf(1.0f - F0x, x5, F0x), Fy = fmaf(1.0f - F0y, x5, F0y), Fz = fmaf(1.0f - F0z, x5, F0z);
-        const float dn = fmaf(cosLh * cosLh, alphaSq - 1.0f, 1.0f);
+        const float dn = (cosLh * cosLh) * (alphaSq - 1.0f) + 1.0f;                // exact: the cancelling denominator
         const float D = alphaSq * rcp_fast(3.14159265359f * dn * dn);              // NdfGGX
         const float G = cosLi * rcp_fast(fmaf(cosLi, oneMinusK, k)) * g1Lo;        // GeometrySchlickGGX
         const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * cosLo));

@@ -1,0 +1,74 @@
+"""Split-frame exchange: tile-row bands, one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Cull and shade need NO communication on a band partition: every rank culls and shades its own tile rows.  Only a consumer
+that wants the reference's *global* compact buffers (`lightsGrid` + `culledLights` in canonical tile order) triggers the
+two collectives below:
+  1. all-gather of one uint32 per rank (the band total sum(num)) -> every rank prefix-sums the global base offsets
+     (Appendix A step 6: offset(tile) = 1 + sum of num over earlier tiles);
+  2. all-gather of the band index segments, padded to the largest band total, placed at their canonical offsets.
+Message sizes at 4K / 65 536 lights: 4 B and <= 2.1 MB per rank -- latency-bound on xGMI, so they are issued once per
+frame, never per tile.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import host
+
+
+def bands(width: int, height: int, world_size: int):
+    return [host.band_for_rank(width, height, r, world_size) for r in range(world_size)]
+
+
+def exchange_lists(band_grid: torch.Tensor, band_culled: torch.Tensor, group=None):
+    """band_grid: int32[bandTiles*2] ({offset, num} pairs, band-local offsets); band_culled: int32[1 + ...] with [0] = band total.
+    Returns (global_grid int32[T*2], global_culled int32[1 + sum]) in the reference's canonical layout, on every rank."""
+    world = dist.get_world_size(group)
+    dev = band_culled.device
+    total = band_culled[:1].clone()
+    totals = [torch.zeros_like(total) for _ in range(world)]
+    dist.all_gather(totals, total, group=group)                      # collective 1
+    totals_host = torch.stack(totals).reshape(-1).cpu().tolist()
+    max_total = max(max(totals_host), 1)
+    seg = torch.zeros(max_total, dtype=band_culled.dtype, device=dev)
+    my_total = int(totals_host[dist.get_rank(group)])
+    seg[:my_total] = band_culled[1:1 + my_total]
+    segs = [torch.empty_like(seg) for _ in range(world)]
+    dist.all_gather(segs, seg, group=group)                          # collective 2
+    # grids differ in size per band: gather them padded as well (8 B per tile)
+    tiles = torch.tensor([band_grid.numel()], dtype=torch.int64, device=dev)
+    all_tiles = [torch.zeros_like(tiles) for _ in range(world)]
+    dist.all_gather(all_tiles, tiles, group=group)
+    tiles_host = [int(t.item()) for t in all_tiles]
+    gpad = torch.zeros(max(max(tiles_host), 1), dtype=band_grid.dtype, device=dev)
+    gpad[: band_grid.numel()] = band_grid
+    grids = [torch.empty_like(gpad) for _ in range(world)]
+    dist.all_gather(grids, gpad, group=group)
+    out_grid, out_idx, base = [], [torch.zeros(1, dtype=band_culled.dtype, device=dev)], 0
+    for r in range(world):
+        g = grids[r][: tiles_host[r]].clone().reshape(-1, 2)
+        g[:, 0] += base                                              # rebase to the canonical global offsets
+        out_grid.append(g.reshape(-1))
+        out_idx.append(segs[r][: int(totals_host[r])])
+        base += int(totals_host[r])
+    culled = torch.cat(out_idx)
+    culled[0] = base
+    return torch.cat(out_grid), culled
+
+
+def gather_rows(band_rows: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather per-band framebuffer rows (e.g. radiance) into the full frame.  Band 0 is the BOTTOM of the framebuffer
+    (tile row 0 = last framebuffer rows), so bands are concatenated in reverse rank order."""
+    world = dist.get_world_size(group)
+    dev = band_rows.device
+    n = torch.tensor([band_rows.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    pad = torch.zeros((max(counts),) + tuple(band_rows.shape[1:]), dtype=band_rows.dtype, device=dev)
+    pad[: band_rows.shape[0]] = band_rows
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([parts[r][: counts[r]] for r in reversed(range(world))], 0)

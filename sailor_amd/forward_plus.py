@@ -34,7 +34,7 @@ class HipContext:
         self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
         handle = C.c_void_p()
         lib = _lib.load()
-        _lib.check(lib.sailor_hip_context_create(index, C.c_void_p(self.stream.cuda_stream), C.byref(handle)), "sailor_hip_context_create")
+        _lib.check(lib.sailor_hip_context_create(index, C.c_void_p(self.stream.cuda_stream), 0, C.byref(handle)), "sailor_hip_context_create")
         self.handle = handle
         self._lib = lib
 

@@ -148,6 +148,8 @@ class LightSetConfig:
     radius_scale: float = 1.0         # "s" of SURVEY 8d, frozen per config below
     cluster_lights: int = 0           # dense cluster(s) guaranteeing tiles with > 196 candidates
     cluster_count: int = 1
+    cluster_spread: float = 3.0       # cluster half-width in tiles
+    cluster_radius: tuple = (1.7, 3.4)  # cluster light radii in tiles
     directional_first: bool = False   # C4: light 0 = directional, EVSM
     d_min: float = 10.0
     d_max: float = 3000.0
@@ -165,23 +167,27 @@ def make_lights(cam: Camera, depth: np.ndarray, cfg: LightSetConfig, seed: int =
     r = z * (2.0 / 240.0) * (2 + 8 * u[:, 3]) * cfg.radius_scale
 
     if cfg.cluster_lights > 0:
-        # clusters sit on the visible surface: pick a pixel, read its depth, scatter lights around that point
+        # clusters hug the visible surface: every cluster light sits on the depth image at its own pixel, so the
+        # tiles around a cluster centre see far more than 196 candidates (Appendix A's ">196" regime)
         W, H = cam.width, cam.height
         rx, ry = pixel_rays(cam)
         per = cfg.cluster_lights // cfg.cluster_count
         cu = uniforms(STREAM_LIGHTS, cfg.cluster_count * 2 + cfg.cluster_lights * 4, N * 12, seed).astype(np.float64)
+        half = cfg.cluster_spread * 16.0                  # half-width in pixels (cluster_spread is in tiles)
+        tile_w = cam.aspect * tan_half * 32.0 / W         # view-space width of one tile at unit depth
         for c in range(cfg.cluster_count):
-            px = int((0.15 + 0.7 * cu[2 * c]) * W)
-            py = int((0.15 + 0.7 * cu[2 * c + 1]) * H)
-            dz = float(depth[py, px])
+            cx = (0.15 + 0.7 * cu[2 * c]) * W
+            cy = (0.15 + 0.7 * cu[2 * c + 1]) * H
             idx = (np.arange(per) * (N // max(per, 1)) + c * 7 + 3) % N
             o = cfg.cluster_count * 2 + c * per * 4
             j = cu[o:o + per * 4].reshape(per, 4)
-            spread = dz * (2.0 / 240.0) * 3.0
-            z[idx] = dz + (2 * j[:, 0] - 1) * spread * 0.25
-            x[idx] = rx[px] * dz + (2 * j[:, 1] - 1) * spread
-            y[idx] = ry[py] * dz + (2 * j[:, 2] - 1) * spread
-            r[idx] = dz * (2.0 / 240.0) * (3 + 3 * j[:, 3])
+            px = np.clip((cx + (2 * j[:, 0] - 1) * half).astype(np.int64), 0, W - 1)
+            py = np.clip((cy + (2 * j[:, 1] - 1) * half).astype(np.int64), 0, H - 1)
+            dz = depth[py, px].astype(np.float64) * (0.98 + 0.04 * j[:, 2])
+            z[idx] = dz
+            x[idx] = rx[px] * dz
+            y[idx] = ry[py] * dz
+            r[idx] = dz * tile_w * (cfg.cluster_radius[0] + (cfg.cluster_radius[1] - cfg.cluster_radius[0]) * j[:, 3])
 
     world = cam.world.reshape(4, 4).astype(np.float64)
     lights = np.zeros(N, host.LIGHT_DTYPE)
@@ -319,16 +325,16 @@ def make_entities(count: int, seed: int = SEED, editor_world: bool = True) -> En
 # statistics of each configuration are recorded in DESIGN.md and in the golden fixtures.
 # ---------------------------------------------------------------------------------------------------------------
 CONFIGS = {
-    "C2": dict(width=1920, height=1080, lights=LightSetConfig(count=4096, spot_fraction=0.0, radius_scale=3.0)),
-    "C3": dict(width=3840, height=2160, lights=LightSetConfig(count=65536, spot_fraction=0.25, radius_scale=1.25, cluster_lights=1200, cluster_count=3)),
-    "C4": dict(width=3840, height=2160, lights=LightSetConfig(count=65536, spot_fraction=0.25, radius_scale=1.25, cluster_lights=1200, cluster_count=3,
+    "C2": dict(width=1920, height=1080, lights=LightSetConfig(count=4096, spot_fraction=0.0, radius_scale=3.5)),
+    "C3": dict(width=3840, height=2160, lights=LightSetConfig(count=65536, spot_fraction=0.25, radius_scale=0.85, cluster_lights=7200, cluster_count=12)),
+    "C4": dict(width=3840, height=2160, lights=LightSetConfig(count=65536, spot_fraction=0.25, radius_scale=0.85, cluster_lights=7200, cluster_count=12,
                                                               directional_first=True), shadow_size=4096),
-    "C5": dict(width=7680, height=4320, lights=LightSetConfig(count=1048576, spot_fraction=0.25, radius_scale=0.5, cluster_lights=1200, cluster_count=3),
+    "C5": dict(width=7680, height=4320, lights=LightSetConfig(count=1048576, spot_fraction=0.25, radius_scale=0.2, cluster_lights=7200, cluster_count=12),
                entities=1048576),
     # small fixtures used by the CPU/GPU parity suites
-    "tiny": dict(width=128, height=96, lights=LightSetConfig(count=512, spot_fraction=0.25, radius_scale=6.0, cluster_lights=300, cluster_count=1)),
+    "tiny": dict(width=128, height=96, lights=LightSetConfig(count=512, spot_fraction=0.25, radius_scale=6.0, cluster_lights=300, cluster_count=1, cluster_spread=1.5, cluster_radius=(0.5, 1.2))),
     "tiny_csm": dict(width=128, height=96, lights=LightSetConfig(count=512, spot_fraction=0.25, radius_scale=6.0, cluster_lights=300, cluster_count=1,
-                                                                 directional_first=True), shadow_size=64),
+                                                                 cluster_spread=1.5, cluster_radius=(0.5, 1.2), directional_first=True), shadow_size=64),
 }
 
 

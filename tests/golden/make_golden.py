@@ -1,0 +1,43 @@
+"""Regenerates tests/golden/*.npz: frozen synthetic inputs + the CPU oracle's outputs for them.
+
+The reference (aantropov/Sailor) has no tests, golden vectors or fixtures for this path and cannot be built or run here
+(SURVEY.md 4, 8c), so these are NOT reference outputs: they pin (a) the synthetic generator -- inputs must regenerate
+byte-identically -- and (b) the oracle's results on them, so a change of either is caught.  Run from the repo root:
+    python tests/golden/make_golden.py
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+from oracle import oracle  # noqa: E402
+from sailor_amd import synth  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+
+
+def make(name: str) -> None:
+    f = synth.make_frame(name)
+    W, H = f.cam.width, f.cam.height
+    g, idx, cnt = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, want_counts=True)
+    csm = None
+    extra = {}
+    if f.shadows is not None:
+        csm, _keep = oracle.make_csm(f.shadows.lights_matrices, f.shadows.maps)
+        extra["lights_matrices"] = f.shadows.lights_matrices
+        for k in range(4):
+            extra[f"shadow_map{k}"] = f.shadows.maps[k]
+    rad = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, g, idx, csm)
+    np.savez_compressed(OUT / f"{name}.npz",
+                        frame_ubo=np.frombuffer(bytes(f.cam.frame), np.uint8), depth=f.depth,
+                        lights=np.frombuffer(f.lights.tobytes(), np.uint8), surface=f.surface,
+                        grid=g, indices=idx[: 1 + int(idx[0])], passing=cnt, radiance=rad, **extra)
+    print(f"{name}: {W}x{H}, {len(f.lights)} lights, sum(num) = {int(idx[0])}, mean list {g[:, 1].mean():.2f}, "
+          f"tiles >128 candidates {(cnt > 128).sum()}, >196 {(cnt > 196).sum()}, lit pixels {(rad[..., :3].sum(-1) > 0).mean():.3f}")
+
+
+if __name__ == "__main__":
+    for n in ("tiny", "tiny_csm"):
+        make(n)

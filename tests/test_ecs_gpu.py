@@ -39,7 +39,7 @@ def test_sweep_bit_exact(ctx, count):
 def test_flt_min_quirk_all_negative_box(ctx):
     """Math/Bounds.cpp:484: max is seeded with the smallest POSITIVE float, so an all-negative box keeps max ~ 1.18e-38."""
     ents = synth.make_entities(64, editor_world=False)
-    ents.transforms[:, 0:3] = -np.abs(ents.transforms[:, 0:3]) - 100.0
+    ents.transforms[:, 0:3] = -np.abs(ents.transforms[:, 0:3]) - 1000.0
     ents.transforms[:, 4:8] = [0, 0, 0, 1]
     ents.parent[:] = 0xFFFFFFFF
     ents.level_offsets = np.array([0, 64], np.uint32)

@@ -1,0 +1,196 @@
+"""CPU suite for the oracle itself (no GPU): the C restatement against
+  * every constant / layout the reference lets us assert -- read from the reference files at test
+    time when /root/reference is mounted (this container), from their recorded values otherwise (the GPU box);
+  * the independent NumPy restatement, bit for bit (the reference has no golden vectors: parity is otherwise unpinned);
+  * the literal shader bubble sort vs the closed-form selection;
+  * the committed golden fixtures under tests/golden/.
+"""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import oracle, oracle_np
+from sailor_amd import host, synth
+
+REF = Path("/root/reference")
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Appendix B: constants and layouts
+# ---------------------------------------------------------------------------------------------------------------
+def test_tile_constants():
+    L = oracle.lib()
+    assert (L.oracle_const_tile_size(), L.oracle_const_candidates_per_tile(), L.oracle_const_lights_per_tile()) == (16, 196, 128)
+    assert L.oracle_const_num_cascades() == 4
+    if REF.exists():
+        txt = (REF / "Content/Shaders/Constants.glsl").read_text()
+        assert int(re.search(r"LIGHTS_CULLING_TILE_SIZE (\d+)", txt).group(1)) == L.oracle_const_tile_size()
+        assert int(re.search(r"LIGHTS_CANDIDATES_PER_TILE (\d+)", txt).group(1)) == L.oracle_const_candidates_per_tile()
+        assert int(re.search(r"LIGHTS_PER_TILE (\d+)", txt).group(1)) == L.oracle_const_lights_per_tile()
+        assert int(re.search(r"NUM_CSM_CASCADES (\d+)", txt).group(1)) == L.oracle_const_num_cascades()
+        levels = [float(x) for x in re.search(r"ShadowCascadeLevels\[4\] = \{([^}]*)\}", txt).group(1).split(",")]
+        assert [np.float32(v) for v in levels] == [np.float32(L.oracle_const_cascade_level_glsl(i)) for i in range(4)]
+        hdr = (REF / "Runtime/FrameGraph/LightCullingNode.h").read_text()
+        assert "LightsPerTile = 128" in hdr and "TileSize = 16" in hdr
+
+
+def test_cascade_levels_glsl_literal_vs_cpp_fraction():
+    L = oracle.lib()
+    assert [L.oracle_const_cascade_level_glsl(i) for i in range(4)] == [np.float32(v) for v in (0.05, 0.1, 0.333333, 0.5)]
+    assert [L.oracle_const_cascade_level_cpp(i) for i in range(4)] == [np.float32(1) / np.float32(d) for d in (20, 10, 3, 2)]
+    assert L.oracle_const_cascade_level_glsl(2) != L.oracle_const_cascade_level_cpp(2)  # 0.333333 is not 1/3
+
+
+def test_light_and_frame_layouts():
+    L = oracle.lib()
+    assert L.oracle_sizeof_light() == 112 and L.oracle_sizeof_ubo() == 232
+    assert [L.oracle_offsetof_light(i) for i in range(8)] == [0, 4, 16, 32, 48, 64, 80, 96]
+    assert host.LIGHT_DTYPE.itemsize == 112
+    assert [host.LIGHT_DTYPE.fields[n][1] for n in host.LIGHT_DTYPE.names] == [0, 4, 16, 32, 48, 64, 80, 96]
+    assert host.INSTANCE_DTYPE.itemsize == 96
+    if REF.exists():
+        glsl = (REF / "Content/Shaders/Lighting.glsl").read_text()
+        order = re.findall(r"^\s*(?:uint|vec3|vec2)\s+(\w+);", glsl.split("struct LightData")[1].split("};")[0], re.M)
+        assert order == ["type", "shadowType", "worldPosition", "direction", "intensity", "attenuation", "cutOff", "bounds"]
+
+
+def test_poisson_disk_and_evsm_constants():
+    L = oracle.lib()
+    disk = np.array([[L.oracle_const_poisson(i, c) for c in range(2)] for i in range(16)], np.float32)
+    assert disk.shape == (16, 2) and np.float32(disk[0, 0]) == np.float32(-0.94201624) and np.float32(disk[15, 1]) == np.float32(-0.14100790)
+    if REF.exists():
+        glsl = (REF / "Content/Shaders/Lighting.glsl").read_text()
+        block = glsl.split("vec2 poissonDisk[16] = vec2[](")[1].split(");")[0]
+        vals = np.array([float(v) for v in re.findall(r"-?\d+\.\d+", block)], np.float32).reshape(16, 2)
+        np.testing.assert_array_equal(vals, disk)
+        assert "EVSM_C1 = 40.0f" in glsl and "EVSM_C2 = 40.0f" in glsl
+
+
+def test_canonical_exp_is_an_accurate_exp():
+    L = oracle.lib()
+    xs = np.linspace(-45.0, 45.0, 20001).astype(np.float32)
+    got = np.array([L.oracle_canonical_expf(float(x)) for x in xs], np.float64)
+    ref = np.exp(xs.astype(np.float64))
+    assert np.max(np.abs(got - ref) / ref) < 2.5e-7  # ~2 ulp
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# C restatement vs the independent NumPy restatement: bit for bit
+# ---------------------------------------------------------------------------------------------------------------
+def _frame(w, h, n, seed, **kw):
+    cam = synth.make_camera(w, h)
+    depth = synth.make_linear_depth(w, h, seed)
+    lights = synth.make_lights(cam, depth, synth.LightSetConfig(count=n, **kw), seed)
+    return cam, depth, lights
+
+
+@pytest.mark.parametrize("case", [
+    dict(w=128, h=96, n=512, seed=synth.SEED, radius_scale=6.0, spot_fraction=0.25, cluster_lights=300),
+    dict(w=131, h=77, n=700, seed=5, radius_scale=8.0, spot_fraction=0.5),
+    dict(w=320, h=200, n=3000, seed=9, radius_scale=4.0, cluster_lights=500, cluster_count=2),
+    dict(w=16, h=16, n=300, seed=2, radius_scale=20.0),
+    dict(w=40, h=24, n=0, seed=2),
+])
+def test_c_and_numpy_restatements_agree_bitwise(case):
+    w, h, n, seed = case.pop("w"), case.pop("h"), case.pop("n"), case.pop("seed")
+    cam, depth, lights = _frame(w, h, n, seed, **case)
+    if n >= 300:
+        lights["type"][7] = host.LIGHT_DIRECTIONAL
+    cg, ci, cnt = oracle.light_cull(cam.frame, w, h, lights, depth, want_counts=True)
+    ng, ni = oracle_np.light_cull(bytes(cam.frame), w, h, lights, depth)
+    np.testing.assert_array_equal(cg, ng)
+    np.testing.assert_array_equal(ci[: 1 + int(ci[0])], ni)
+    lg, li, _ = oracle.light_cull(cam.frame, w, h, lights, depth, literal_select=True)
+    np.testing.assert_array_equal(cg, lg)
+    np.testing.assert_array_equal(ci, li)
+
+
+def test_bands_of_the_oracle_compose():
+    cam, depth, lights = _frame(320, 200, 2000, 4, radius_scale=5.0, cluster_lights=300)
+    g, idx, _ = oracle.light_cull(cam.frame, 320, 200, lights, depth)
+    Ty = 13
+    base, grids, segs = 0, [], []
+    for r0, r1 in [(0, 4), (4, 9), (9, Ty)]:
+        bg, bi, _ = oracle.light_cull(cam.frame, 320, 200, lights, depth, tile_rows=(r0, r1))
+        ng, ni = oracle_np.light_cull(bytes(cam.frame), 320, 200, lights, depth, tile_rows=(r0, r1))
+        np.testing.assert_array_equal(bg, ng)
+        np.testing.assert_array_equal(bi[: 1 + int(bi[0])], ni)
+        bg = bg.copy(); bg[:, 0] += base
+        grids.append(bg); segs.append(bi[1: 1 + int(bi[0])]); base += int(bi[0])
+    np.testing.assert_array_equal(np.concatenate(grids), g)
+    np.testing.assert_array_equal(np.concatenate(segs), idx[1: 1 + int(idx[0])])
+
+
+def test_selection_closed_form_equals_the_shaders_bubble_sort():
+    """Appendix A step 4 / Appendix E: heavy ties included."""
+    rng = np.random.default_rng(42)
+    L = oracle.lib()
+    for trial in range(400):
+        n = int(rng.integers(1, 197))
+        idx = rng.permutation(100000)[:n].astype(np.uint32)
+        imp = rng.choice([0.0, 1.0, 2.5, 2.5, 7.0, rng.random()], n).astype(np.float32) if trial % 2 else rng.random(n).astype(np.float32)
+        outs = []
+        for literal in (0, 1):
+            lst = np.zeros(128, np.uint32); num = C.c_uint32()
+            L.oracle_select_emit(idx.ctypes.data_as(C.c_void_p), imp.ctypes.data_as(C.c_void_p), C.c_uint32(n), literal, lst.ctypes.data_as(C.c_void_p), C.byref(num))
+            outs.append(lst[: num.value].copy())
+        np.testing.assert_array_equal(outs[0], outs[1])
+        assert len(outs[0]) == min(n, 128)
+        if n <= 128:
+            np.testing.assert_array_equal(outs[0], idx[::-1])       # descending candidate position
+        else:
+            kept = imp[np.searchsorted(idx[np.argsort(idx)], outs[0], sorter=None)] if False else None
+            order = np.argsort(-imp, kind="stable")
+            np.testing.assert_array_equal(outs[0], idx[order][::-1][:128])
+
+
+def test_tile_and_pixel_conventions_agree():
+    """Appendix D invariant: pixel (px, py) lies inside the frustum of tile (px/16, (H-1-py)/16)."""
+    cam = synth.make_camera(640, 360)
+    depth = synth.make_linear_depth(640, 360)
+    surf = synth.make_surface(cam, depth)
+    view = np.frombuffer(bytes(cam.frame.view), np.float32).reshape(4, 4).astype(np.float64)
+    fb = np.frombuffer(bytes(cam.frame), np.uint8).copy()
+    rng = np.random.default_rng(0)
+    planes = np.zeros(16, np.float32); center = np.zeros(2, np.float32)
+    for _ in range(300):
+        px, py = int(rng.integers(0, 640)), int(rng.integers(0, 360))
+        wp = np.append(surf[0, py, px, :3].astype(np.float64), 1.0)
+        pv = wp @ view
+        pv[2] = -pv[2]
+        oracle.lib().oracle_tile_frustum(fb.ctypes.data_as(C.c_void_p), px // 16, (360 - 1 - py) // 16, planes.ctypes.data_as(C.c_void_p), center.ctypes.data_as(C.c_void_p))
+        d = planes.reshape(4, 4)[:, :3].astype(np.float64) @ pv[:3]
+        assert (d > -1e-3 * depth[py, px]).all(), (px, py, d)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# golden fixtures (inputs regenerated from the frozen generator, outputs committed)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["tiny", "tiny_csm"])
+def test_golden_fixture(name):
+    path = GOLDEN / f"{name}.npz"
+    assert path.exists(), "run tests/golden/make_golden.py"
+    z = np.load(path)
+    f = synth.make_frame(name)
+    W, H = f.cam.width, f.cam.height
+    # the generator is frozen: inputs must regenerate byte-identically
+    assert z["frame_ubo"].tobytes() == bytes(f.cam.frame)
+    np.testing.assert_array_equal(z["depth"], f.depth)
+    assert z["lights"].tobytes() == f.lights.tobytes()
+    np.testing.assert_array_equal(z["surface"], f.surface)
+    g, idx, cnt = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, want_counts=True)
+    np.testing.assert_array_equal(g, z["grid"])
+    np.testing.assert_array_equal(idx[: 1 + int(idx[0])], z["indices"])
+    np.testing.assert_array_equal(cnt, z["passing"])
+    csm = None
+    if f.shadows is not None:
+        np.testing.assert_array_equal(z["lights_matrices"], f.shadows.lights_matrices)
+        for k in range(4):
+            np.testing.assert_array_equal(z[f"shadow_map{k}"], f.shadows.maps[k])
+        csm, _keep = oracle.make_csm(f.shadows.lights_matrices, f.shadows.maps)
+    rad = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, g, idx, csm)
+    np.testing.assert_allclose(rad, z["radiance"], rtol=2e-6, atol=1e-6)  # libm powf may differ by an ulp across hosts
