@@ -116,6 +116,10 @@ def load() -> C.CDLL:
     """Load libsailor_hip.so (built in-tree by __graft_entry__.build() / `make -C sailor_amd/csrc`)."""
     global _lib
     if _lib is None:
+        # torch ships its own HIP runtime (torch/lib/libamdhip64.so).  Streams and device pointers are handed across this
+        # boundary, so both sides must live in ONE runtime instance: import torch first and let the loader resolve our
+        # libamdhip64 dependency to the copy that is already mapped.
+        import torch  # noqa: F401
         path = Path(os.environ.get("SAILOR_HIP_LIB", LIB_PATH))
         if not path.exists():
             raise SailorHipError(-2, "load", f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
