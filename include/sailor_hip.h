@@ -212,6 +212,12 @@ SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
                                          void* dWorkspace, size_t workspaceBytes,
                                          const SailorBand* band, uint32_t flags);
 
+/* Tuning diagnostics (synchronises): out8 = {numBands, mask bits set, numGroups, sum of group list lengths, overflowed
+ * groups, longest group list, 64-bit words per band, bits set in the column masks} for the intermediate pre-filter state
+ * left in dWorkspace by the last sailor_hip_light_cull of the same geometry. */
+SAILOR_HIP_API int sailor_hip_light_cull_diagnostics(SailorHipContext* ctx, int32_t width, int32_t height, int32_t lightsNum, const SailorBand* band,
+                                                     const void* dWorkspace, uint64_t* out8);
+
 /* Multi-GPU stitch helpers.  After an all-gather of the per-band totals, rebase a band's grid
  * to the canonical global offsets: offset += globalBase (globalBase = sum of num over all earlier bands). */
 SAILOR_HIP_API int sailor_hip_light_grid_rebase(SailorHipContext* ctx, SailorLightsGrid* dLightsGrid, int32_t numTiles, uint32_t globalBase);

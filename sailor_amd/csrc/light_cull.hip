@@ -11,30 +11,38 @@
 //   k1_tile_setup      streaming pass over the linear-depth image (the only large HBM stream of the cull):
 //                      16 tiles per 256-thread block, 1 KiB coalesced float4 row segments, wave shuffles + a
 //                      4-entry LDS combine for min/max, then 16 lanes build the 16 tile frusta
-//   k1_macro_setup     8x8-tile macro tiles: union depth window + macro frustum
-//   k1_macro_cull      conservative pre-filter: (macro tile, 2048-light chunk) blocks, wave-ballot ordered
-//                      compaction into LDS, one bump allocation per block from a shared pool
-//   k1_tile_cull       one 64-lane wave per tile walks its macro tile's survivor lists in ascending light index,
-//                      exact test, ballot/popcount ordered append into LDS, rank-based nearest-128 selection
-//   k1_scan / k1_pack  canonical offsets = prefix sum over tiles in tile-index order, then compaction
+//   k1_band_masks      conservative pre-filter as BITMASKS: one 64-bit ballot per (64 lights, tile column) and per
+//                      (64 lights, tile row): "this light's sphere may reach this column / row of tiles".  Pure
+//                      streaming, no atomics, no compaction, no inter-block order: 3 MB of masks at 4K / 65 536 lights
+//   k1_group_lists     one wave per 4x4-tile group: (OR of 4 column masks) AND (OR of 4 row masks), 4096 lights per
+//                      step; the few surviving bits become an ordered, contiguous candidate list (ballot, readlane, mbcnt)
+//   k1_tile_cull       one 1024-thread block per group, one wave per tile: the group's candidate records are gathered
+//                      into LDS once (40 KB), each wave streams them through the exact test, 64 per step;
+//                      ballot/popcount ordered append; rank-based nearest-128 selection
+//                      (groups denser than 2048 candidates fall back to walking the two masks of the tile itself)
+//   k1_block_sums / k1_pack  canonical offsets = prefix sum over tiles in tile-index order, then compaction
 //
-// Bit-exactness: the pre-filter only ever removes lights that every member tile's exact test would reject
-// (depth window: the very same fp32 expressions compared against the max/min of the member tiles' windows;
-// side planes: only for spheres entirely in front of the eye, with a relative margin 1000x the fp32 error), so
-// the candidate sequence of every tile -- and therefore its first 196, its selection and its order -- is the
-// sequence the brute-force walk produces.  tests/test_light_cull_gpu.py checks default == brute force == oracle.
+// Bit-exactness: the pre-filter only ever removes lights that every tile of the column (row) would reject by its own
+// left/right (top/bottom) plane: the band's planes are the same planes through the eye (screen x = const, resp.
+// y = const), used only for spheres entirely in front of the eye and with a relative margin ~1000x the fp32 error;
+// depth is left entirely to the exact test.  So the candidate sequence of every tile -- and therefore its first 196,
+// its selection and its order -- is the sequence the brute-force walk produces.  tests/test_light_cull_gpu.py checks
+// default == brute force == oracle.
 //
 // No MFMA: sphere/plane tests and compaction, not a contraction.  Compiled with -ffp-contract=off.
 #include "common.h"
+#include <vector>
 
-#define MACRO 8            // tiles per macro-tile edge
-#define CHUNK 2048         // lights per macro-cull block
-#define SEG_RAW 0xFFFFFFFFu // segment marker: pool overflow, walk the raw light range instead
+#define BANDS_PER_GROUP 25   // tile columns / rows handled per k1_band_masks wave (grid.y = ceil(bands / 25))
+#define QCAP 128             // LDS candidate queue of k1_tile_cull (ring buffer: < 64 pending + <= 64 new)
+#define SCAN_BLOCK 1024      // tiles per k1_block_sums block
+#define GROUP 4              // k1_group_lists: tiles per group edge (4x4 tiles share one candidate list)
+#define CAPG 2048            // entries per group list; a denser group falls back to walking the masks per tile
+#define GROUP_OVERFLOW 0xFFFFFFFFu
 
 struct CullLayout {
-    int Tx, Ty, bandTiles, macroX, macroY0, macroRows, numMacros, numChunks;
-    size_t poolEntries;
-    size_t offLightView, offLightType, offTileInfo, offMacroInfo, offSegTable, offCursor, offTileNum, offTileList, offPool, total;
+    int Tx, Ty, bandRows, bandTiles, numBands, words, sumBlocks, groupsX, groupsY, numGroups;
+    size_t offLightView, offLightType, offTileInfo, offBandPlanes, offMasks, offDirWords, offTileNum, offTilePrefix, offTileList, offBlockSums, offGroupCount, offGroupList, total;
 };
 
 static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
@@ -42,49 +50,33 @@ static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
     CullLayout L;
     L.Tx = (W - 1) / TILE + 1;
     L.Ty = (H - 1) / TILE + 1;
-    const int rows = band.tileRowEnd - band.tileRowBegin;
-    L.bandTiles = rows * L.Tx;
-    L.macroX = (L.Tx + MACRO - 1) / MACRO;
-    L.macroY0 = band.tileRowBegin / MACRO;
-    const int macroY1 = rows > 0 ? (band.tileRowEnd - 1) / MACRO + 1 : L.macroY0;
-    L.macroRows = macroY1 - L.macroY0;
-    L.numMacros = L.macroX * L.macroRows;
-    L.numChunks = (N + CHUNK - 1) / CHUNK;
-    if (L.numChunks < 1) L.numChunks = 1;
+    L.bandRows = band.tileRowEnd - band.tileRowBegin;
+    L.bandTiles = L.bandRows * L.Tx;
+    L.numBands = L.Tx + L.bandRows;          // tile columns first, then the band's tile rows
+    L.words = (N + 63) / 64;
+    if (L.words < 1) L.words = 1;
     const size_t n = (size_t)(N > 0 ? N : 1);
-    // Survivor pool: the expected load is a few percent of numMacros*N; 48*N entries (+ slack) covers scenes far
-    // denser than the reference's cap; overflow degrades to the raw walk per segment, never to wrong results.
-    L.poolEntries = n * 48 + (size_t)L.numMacros * 64 + 4096;
+    const size_t tiles = (size_t)(L.bandTiles > 0 ? L.bandTiles : 1);
+    L.sumBlocks = (int)((tiles + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    L.groupsX = (L.Tx + GROUP - 1) / GROUP;
+    L.groupsY = (L.bandRows + GROUP - 1) / GROUP;
+    L.numGroups = L.groupsX * L.groupsY;
+    const size_t groups = (size_t)(L.numGroups > 0 ? L.numGroups : 1);
     size_t o = 0;
     L.offLightView = o; o = align_up(o + n * 16, 256);
     L.offLightType = o; o = align_up(o + n * 4, 256);
-    L.offTileInfo = o; o = align_up(o + (size_t)(L.bandTiles > 0 ? L.bandTiles : 1) * 64, 256);
-    L.offMacroInfo = o; o = align_up(o + (size_t)(L.numMacros > 0 ? L.numMacros : 1) * 80, 256);
-    L.offSegTable = o; o = align_up(o + (size_t)(L.numMacros > 0 ? L.numMacros : 1) * L.numChunks * 8, 256);
-    L.offCursor = o; o = align_up(o + 256, 256);
-    L.offTileNum = o; o = align_up(o + (size_t)(L.bandTiles > 0 ? L.bandTiles : 1) * 4, 256);
-    L.offTileList = o; o = align_up(o + (size_t)(L.bandTiles > 0 ? L.bandTiles : 1) * KEEP * 4, 256);
-    L.offPool = o; o = align_up(o + L.poolEntries * 4, 256);
+    L.offTileInfo = o; o = align_up(o + tiles * 64, 256);
+    L.offBandPlanes = o; o = align_up(o + (size_t)(L.numBands > 0 ? L.numBands : 1) * 32, 256);
+    L.offMasks = o; o = align_up(o + (size_t)(L.numBands > 0 ? L.numBands : 1) * L.words * 8, 256);
+    L.offDirWords = o; o = align_up(o + (size_t)L.words * 8, 256);
+    L.offTileNum = o; o = align_up(o + tiles * 4, 256);
+    L.offTilePrefix = o; o = align_up(o + tiles * 4, 256);
+    L.offTileList = o; o = align_up(o + tiles * KEEP * 4, 256);
+    L.offBlockSums = o; o = align_up(o + (size_t)L.sumBlocks * 4, 256);
+    L.offGroupCount = o; o = align_up(o + groups * 4, 256);
+    L.offGroupList = o; o = align_up(o + groups * CAPG * 4, 256);
     L.total = o;
     return L;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// K0: ComputeLightCulling.shader:164-169 hoisted out of the per-tile loop (it does not depend on the tile)
-// ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k0_light_view(Mat4 view, const SailorLightShaderData* __restrict__ lights, int N,
-                                                      float4* __restrict__ lightView, uint32_t* __restrict__ lightType)
-{
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
-    const SailorLightShaderData* L = lights + j;
-    const float x = L->worldPosition[0], y = L->worldPosition[1], z = L->worldPosition[2];
-    float4 p = glsl_mul(view, x, y, z, 1.0f);
-    const float w = p.w;
-    p.x = p.x / w; p.y = p.y / w; p.z = p.z / w;
-    p.z = p.z * -1.0f; // "Reverse Z"
-    lightView[j] = make_float4(p.x, p.y, p.z, L->bounds[0]);
-    lightType[j] = L->type;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -130,6 +122,43 @@ __device__ void frustum_from_rect(const Mat4& invProj, float x0, float y0, float
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// K0: ComputeLightCulling.shader:164-169 hoisted out of the per-tile loop (it does not depend on the tile).
+// The tail blocks of the same launch build the conservative band planes (one thread per tile column / tile row).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k0_light_view(Mat4 view, const SailorLightShaderData* __restrict__ lights, int N, int lightBlocks,
+                                                      float4* __restrict__ lightView, uint32_t* __restrict__ lightType,
+                                                      Mat4 invProj, int vpW, int vpH, int Tx, int Ty, int tileRow0, int numBands,
+                                                      float4* __restrict__ bandPlanes)
+{
+    if ((int)blockIdx.x >= lightBlocks) {
+        const int b = ((int)blockIdx.x - lightBlocks) * 256 + threadIdx.x;
+        if (b >= numBands) return;
+        Frustum4 f;
+        if (b < Tx) { // tile column b: planes through the eye and the screen lines x = 16 b, x = 16 (b + 1)
+            frustum_from_rect(invProj, (float)(b * TILE), 0.0f, (float)((b + 1) * TILE), (float)(Ty * TILE), vpW, vpH, f);
+            bandPlanes[2 * b + 0] = make_float4(f.n[0][0], f.n[0][1], f.n[0][2], 0.0f);
+            bandPlanes[2 * b + 1] = make_float4(f.n[1][0], f.n[1][1], f.n[1][2], 0.0f);
+        } else {      // tile row: y = 16 ty, y = 16 (ty + 1)
+            const int ty = tileRow0 + (b - Tx);
+            frustum_from_rect(invProj, 0.0f, (float)(ty * TILE), (float)(Tx * TILE), (float)((ty + 1) * TILE), vpW, vpH, f);
+            bandPlanes[2 * b + 0] = make_float4(f.n[2][0], f.n[2][1], f.n[2][2], 0.0f);
+            bandPlanes[2 * b + 1] = make_float4(f.n[3][0], f.n[3][1], f.n[3][2], 0.0f);
+        }
+        return;
+    }
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const SailorLightShaderData* L = lights + j;
+    const float x = L->worldPosition[0], y = L->worldPosition[1], z = L->worldPosition[2];
+    float4 p = glsl_mul(view, x, y, z, 1.0f);
+    const float w = p.w;
+    p.x = p.x / w; p.y = p.y / w; p.z = p.z / w;
+    p.z = p.z * -1.0f; // "Reverse Z"
+    lightView[j] = make_float4(p.x, p.y, p.z, L->bounds[0]);
+    lightType[j] = L->type;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // K1a: depth bounds (ComputeLightCulling.shader:119-128) + tile frustum, 16 tiles per block.
 // tileInfo[t] = { (n0, cx), (n1, cy), (n2, zNear'), (n3, zFar') } with the near/far swap of :171-177 applied.
 // ------------------------------------------------------------------------------------------------------------
@@ -142,7 +171,7 @@ __device__ __forceinline__ uint32_t depth_bits(const float* __restrict__ depth, 
 }
 
 __global__ __launch_bounds__(256) void k1_tile_setup(Mat4 invProj, int vpW, int vpH, const float* __restrict__ depth, int W, int H,
-                                                      int Tx, int tileRow0, int bandRow0, int stripsPerRow, float4* __restrict__ tileInfo)
+                                                      int Tx, int tileRow0, int bandRow0, int stripsPerRow, int vecOK, float4* __restrict__ tileInfo)
 {
     __shared__ uint32_t sMin[4][16], sMax[4][16];
     const int strip = blockIdx.x % stripsPerRow;
@@ -151,7 +180,7 @@ __global__ __launch_bounds__(256) void k1_tile_setup(Mat4 invProj, int vpW, int 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gx0 = strip * 256 + lane * 4; // 4 pixels per lane, 4 lanes per tile
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-    const bool vec = ((W & 3) == 0) && (gx0 + 3 < W);
+    const bool vec = vecOK && (gx0 + 3 < W);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int gy = ty * TILE + wave * 4 + k;
@@ -198,50 +227,42 @@ __global__ __launch_bounds__(256) void k1_tile_setup(Mat4 invProj, int vpW, int 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1a2: macro tiles.  macroInfo[m] = 5 float4: 4 x (plane normal, -) + (maxZNear', minZFar', -, -)
+// K1b: band masks.  masks[b][word] bit k = "light 64*word + k may reach tile column / row b".
+// A light is dropped from a band only if its sphere is entirely in front of the eye AND entirely outside one of the
+// band's two planes by more than the margin; directional lights and everything doubtful stay in.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void k1_macro_setup(Mat4 invProj, int vpW, int vpH, int Tx, int tileRow0, int tileRow1, int macroX, int macroY0, int numMacros,
-                               const float4* __restrict__ tileInfo, float4* __restrict__ macroInfo)
+__global__ __launch_bounds__(256) void k1_band_masks(const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType, int N, int words,
+                                                      const float4* __restrict__ bandPlanes, int numBands, float planeMargin,
+                                                      unsigned long long* __restrict__ masks, unsigned long long* __restrict__ dirWords)
 {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= numMacros) return;
-    const int mx = m % macroX, my = macroY0 + m / macroX;
-    float zN = -__builtin_inff(), zF = __builtin_inff();
-    bool any = false;
-    for (int ty = max(my * MACRO, tileRow0); ty < min(my * MACRO + MACRO, tileRow1); ty++)
-        for (int tx = mx * MACRO; tx < min(mx * MACRO + MACRO, Tx); tx++) {
-            const float4* ti = tileInfo + (size_t)((ty - tileRow0) * Tx + tx) * 4;
-            const float a = ti[2].w, b = ti[3].w;
-            // NaN windows never reject in the exact test (comparisons false) => widen to "never reject"
-            zN = (a != a) ? __builtin_inff() : fmaxf(zN, a);
-            zF = (b != b) ? -__builtin_inff() : fminf(zF, b);
-            any = true;
-        }
-    if (!any) { zN = __builtin_inff(); zF = -__builtin_inff(); }
-    Frustum4 f;
-    frustum_from_rect(invProj, (float)(mx * MACRO * TILE), (float)(my * MACRO * TILE), (float)((mx + 1) * MACRO * TILE), (float)((my + 1) * MACRO * TILE), vpW, vpH, f);
-    float4* o = macroInfo + (size_t)m * 5;
-    for (int k = 0; k < 4; k++) o[k] = make_float4(f.n[k][0], f.n[k][1], f.n[k][2], 0.0f);
-    o[4] = make_float4(zN, zF, 0.0f, 0.0f);
-}
-
-// Conservative macro-tile test: true = "some member tile might accept this light".
-__device__ __forceinline__ bool macro_may_overlap(const float4 lv, const float4* __restrict__ mi, float planeMargin)
-{
+    __shared__ float4 sPl[2 * BANDS_PER_GROUP];
+    const int b0 = blockIdx.y * BANDS_PER_GROUP;
+    const int nb = min(BANDS_PER_GROUP, numBands - b0);
+    if ((int)threadIdx.x < 2 * nb) sPl[threadIdx.x] = bandPlanes[2 * b0 + threadIdx.x]; // this block's planes, read once
+    __syncthreads();
+    const int word = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (word >= words) return;
+    const int lane = threadIdx.x & 63;
+    const int j = word * 64 + lane;
+    const bool valid = j < N;
+    float4 lv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t type = 1u;
+    if (valid) { lv = lightView[j]; type = lightType[j]; }
     const float r = lv.w;
-    const float zlo = lv.z - r, zhi = lv.z + r; // the exact test's own expressions (Math.glsl:226)
-    const float4 zw = mi[4];
-    if (zlo > zw.x || zhi < zw.y) return false; // beyond every member tile's window
-    // Side planes: valid as an outer bound only for spheres entirely in front of the eye; margin >> fp32 error.
     const float m = planeMargin * ((fabsf(lv.x) + fabsf(lv.y)) + (fabsf(lv.z) + fabsf(r)));
-    if (zlo > m) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float4 n = mi[k];
-            if (dot3f(n.x, n.y, n.z, lv.x, lv.y, lv.z) < -(r + m)) return false;
-        }
+    const bool inFront = (lv.z - r) > m; // false for NaN => never plane-culled
+    const float thr = -(r + m);
+    const bool keepAlways = valid && (type == 0u || !inFront);
+    if (blockIdx.y == 0) { // one bit per light: "directional" (rides along into the group lists, saves a gather per candidate)
+        const unsigned long long dm = __ballot(valid && type == 0u);
+        if (lane == 0) dirWords[word] = dm;
     }
-    return true;
+    for (int b = 0; b < nb; b++) {
+        const float4 nA = sPl[2 * b + 0], nB = sPl[2 * b + 1]; // LDS broadcast reads
+        const bool out = dot3f(nA.x, nA.y, nA.z, lv.x, lv.y, lv.z) < thr || dot3f(nB.x, nB.y, nB.z, lv.x, lv.y, lv.z) < thr;
+        const unsigned long long mask = __ballot(keepAlways || (valid && !out));
+        if (lane == 0) masks[(size_t)(b0 + b) * words + word] = mask;
+    }
 }
 
 __device__ __forceinline__ uint64_t lanemask_lt()
@@ -251,55 +272,60 @@ __device__ __forceinline__ uint64_t lanemask_lt()
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1b: macro cull.  grid = (numChunks, numMacros); survivors of the chunk, ascending, -> pool segment.
-// Pool entries: light index | (directional ? 1<<31 : 0).
+// K1b2: candidate lists of 4x4-tile groups.  One 256-thread block per group ORs the group's 4 column masks, ORs its
+// 4 row masks, ANDs them (256 words = 16 384 lights per step) and writes the set bits -- ascending light index -- as a
+// contiguous list: a block-wide prefix sum of the words' popcounts gives every word its output position, so the
+// sparse-bits -> dense-list conversion is fully parallel.  Done once per 16 tiles, not per tile (profiles/r01: the
+// per-tile scalar version saturated the CUs' scalar ALUs; a per-group scalar version was tail-bound by cluster groups).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k1_macro_cull(const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType, int N,
-                                                      const float4* __restrict__ macroInfo, int numChunks, float planeMargin,
-                                                      uint32_t* __restrict__ pool, uint32_t poolEntries, uint32_t* __restrict__ cursor,
-                                                      uint2* __restrict__ segTable)
+__global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ dirWords,
+                                                       int words, int Tx, int bandRows, int groupsX,
+                                                       uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList)
 {
-    __shared__ uint32_t sSurv[CHUNK];
-    __shared__ uint32_t sWave[4];
-    __shared__ uint32_t sBase;
-    const int chunk = blockIdx.x, m = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ float4 sInfo[5];
-    if (threadIdx.x < 5) sInfo[threadIdx.x] = macroInfo[(size_t)m * 5 + threadIdx.x];
-    __syncthreads();
-    uint32_t count = 0;
-    const int j0 = chunk * CHUNK;
-    const int jEnd = min(j0 + CHUNK, N);
-    for (int base = j0; base < jEnd; base += 256) {
-        const int j = base + threadIdx.x;
-        bool pass = false;
-        uint32_t entry = 0;
-        if (j < jEnd) {
-            const float4 lv = lightView[j];
-            const uint32_t type = lightType[j];
-            if (type == 0u) { pass = true; entry = (uint32_t)j | 0x80000000u; }
-            else { pass = macro_may_overlap(lv, sInfo, planeMargin); entry = (uint32_t)j; }
+    __shared__ uint32_t sW[4];
+    const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tx0 = (g % groupsX) * GROUP, ty0 = (g / groupsX) * GROUP;
+    const unsigned long long* c[GROUP];
+    const unsigned long long* r[GROUP];
+#pragma unroll
+    for (int k = 0; k < GROUP; k++) {
+        c[k] = masks + (size_t)min(tx0 + k, Tx - 1) * words;              // clamped duplicates are harmless under OR
+        r[k] = masks + (size_t)(Tx + min(ty0 + k, bandRows - 1)) * words;
+    }
+    uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
+    uint32_t base = 0; // entries written by earlier chunks (block-uniform)
+    for (int w0 = 0; w0 < words; w0 += 256) {
+        const int w = w0 + threadIdx.x;
+        unsigned long long m = 0ull, dm = 0ull;
+        if (w < words) {
+            m = ((c[0][w] | c[1][w]) | (c[2][w] | c[3][w])) & ((r[0][w] | r[1][w]) | (r[2][w] | r[3][w]));
+            dm = dirWords[w];
         }
-        const uint64_t mask = __ballot(pass);
-        if (lane == 0) sWave[wave] = (uint32_t)__popcll(mask);
+        // block-wide exclusive prefix sum of the popcounts: word order == light order
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) sW[wave] = incl;
         __syncthreads();
         uint32_t before = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) { const uint32_t c = sWave[w]; before += (w < wave) ? c : 0u; total += c; }
-        if (pass) sSurv[count + before + (uint32_t)__popcll(mask & lanemask_lt())] = entry;
-        count += total;
+        for (int k = 0; k < 4; k++) { const uint32_t v = sW[k]; before += (k < wave) ? v : 0u; total += v; }
+        uint32_t pos = base + before + incl - cnt;
+        const uint32_t first = (uint32_t)w * 64u;
+        while (m != 0ull) { // this word's set bits, ascending
+            const int bit = __builtin_ctzll(m);
+            m &= m - 1ull;
+            if (pos < CAPG) list[pos] = (first + (uint32_t)bit) | (uint32_t)((dm >> bit) & 1ull) << 31; // bit 31 = directional
+            pos++;
+        }
+        base += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        uint32_t b = count ? atomicAdd(cursor, count) : 0u;
-        if (count && (b > poolEntries || count > poolEntries - b)) b = SEG_RAW;
-        sBase = b;
-        segTable[(size_t)m * numChunks + chunk] = make_uint2(b, count);
-    }
-    __syncthreads();
-    const uint32_t b = sBase;
-    if (b != SEG_RAW)
-        for (uint32_t i = threadIdx.x; i < count; i += 256) pool[b + i] = sSurv[i];
+    if (threadIdx.x == 0) groupCount[g] = base > CAPG ? GROUP_OVERFLOW : base;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -331,36 +357,47 @@ __device__ __forceinline__ void wave_append(bool pass, uint32_t j, float impact,
     count += (uint32_t)__popcll(mask);
 }
 
-// walk the raw light range [j0, j1) in ascending order (brute force / overflowed segment)
-__device__ __forceinline__ void walk_raw(const TileCtx& t, const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType,
-                                         int j0, int j1, uint32_t& count, uint32_t* sIdx, float* sImp)
+// exact test of one candidate per lane (ascending light index across lanes), ordered append
+__device__ __forceinline__ void test_candidates(const TileCtx& t, const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType,
+                                                bool have, uint32_t j, uint32_t& count, uint32_t* sIdx, float* sImp)
 {
-    const int lane = threadIdx.x & 63;
-    for (int base = j0; base < j1 && count < CAND; base += 64) {
-        const int j = base + lane;
-        bool pass = false;
-        float impact = 0.0f;
-        if (j < j1) {
-            const float4 lv = lightView[j];
-            if (lightType[j] == 0u) pass = true; // directional: always a candidate, impact 0 (:153-162)
-            else pass = tile_test(t, lv, impact);
-        }
-        wave_append(pass, (uint32_t)j, impact, count, sIdx, sImp);
+    bool pass = false;
+    float impact = 0.0f;
+    if (have) {
+        const float4 lv = lightView[j];
+        if (lightType[j] == 0u) pass = true; // directional: always a candidate, impact 0 (:153-162)
+        else pass = tile_test(t, lv, impact);
     }
+    wave_append(pass, j, impact, count, sIdx, sImp);
 }
 
+// LDS hand-off between the lanes of ONE wave: the wave's DS operations execute in order, so only the compiler has to be
+// told not to move accesses across this point (and to wait for outstanding DS results).
+#define WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
+
 template <bool BRUTE>
-__global__ __launch_bounds__(64) void k1_tile_cull(const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType, int N,
-                                                    const float4* __restrict__ tileInfo, int Tx, int tileRow0, int macroX, int macroY0,
-                                                    int numChunks, const uint2* __restrict__ segTable, const uint32_t* __restrict__ pool,
-                                                    uint32_t* __restrict__ tileNum, uint32_t* __restrict__ tileList)
+__global__ __launch_bounds__(1024) void k1_tile_cull(const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType, int N, int words,
+                                                     const float4* __restrict__ tileInfo, int Tx, int bandRows,
+                                                     const unsigned long long* __restrict__ masks,
+                                                     const uint32_t* __restrict__ groupCount, const uint32_t* __restrict__ groupList, int groupsX,
+                                                     uint32_t* __restrict__ tileNum, uint32_t* __restrict__ tileList)
 {
-    __shared__ uint32_t sIdx[CAND];
-    __shared__ float sImp[CAND];
-    const int bandTile = blockIdx.x;
-    const int lane = threadIdx.x;
+    // One 1024-thread block per 4x4-tile group, one wave per tile.  The group's candidate light records are gathered
+    // from global memory ONCE, by all 16 waves together, into LDS; every tile then streams them out of LDS.  (A
+    // per-tile gather measured 42 us of the 70 us kernel at 4K / 65 536 lights: 16x the scattered 16-byte requests.)
+    __shared__ float4 sLV[CAPG];                                    // 32 KB: candidate (view pos, radius)
+    __shared__ uint32_t sE[CAPG];                                   //  8 KB: candidate light index | directional << 31
+    __shared__ uint32_t sIdxAll[16][CAND];
+    __shared__ __attribute__((aligned(16))) float sImpAll[16][CAND];
+    const int g = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* sIdx = sIdxAll[wave];
+    float* sImp = sImpAll[wave];
+    const int tx = (g % groupsX) * GROUP + (wave & 3), tyLocal = (g / groupsX) * GROUP + (wave >> 2);
+    const bool active = tx < Tx && tyLocal < bandRows;
+    const int bandTile = tyLocal * Tx + tx;
     TileCtx t;
-    {
+    if (active) {
         const float4* ti = tileInfo + (size_t)bandTile * 4;
         const float4 a = ti[0], b = ti[1], c = ti[2], d = ti[3];
         t.n[0][0] = a.x; t.n[0][1] = a.y; t.n[0][2] = a.z; t.cx = a.w;
@@ -371,98 +408,160 @@ __global__ __launch_bounds__(64) void k1_tile_cull(const float4* __restrict__ li
     }
     uint32_t count = 0;
     if (BRUTE) {
-        walk_raw(t, lightView, lightType, 0, N, count, sIdx, sImp);
+        if (!active) return;
+        for (int base = 0; base < N && count < CAND; base += 64) {
+            const int j = base + lane;
+            test_candidates(t, lightView, lightType, j < N, (uint32_t)j, count, sIdx, sImp);
+        }
     } else {
-        const int tx = bandTile % Tx, ty = tileRow0 + bandTile / Tx;
-        const int m = (ty / MACRO - macroY0) * macroX + tx / MACRO;
-        const uint2* segs = segTable + (size_t)m * numChunks;
-        for (int c = 0; c < numChunks && count < CAND; c++) {
-            const uint2 seg = segs[c];
-            if (seg.y == 0u) continue;
-            if (seg.x == SEG_RAW) {
-                walk_raw(t, lightView, lightType, c * CHUNK, min((c + 1) * CHUNK, N), count, sIdx, sImp);
-                continue;
+        const uint32_t gn = groupCount[g];
+        if (gn != GROUP_OVERFLOW) {
+            const uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
+            for (uint32_t i = threadIdx.x; i < gn; i += 1024u) {
+                const uint32_t e = list[i];
+                sE[i] = e;
+                sLV[i] = lightView[e & 0x7FFFFFFFu];
             }
-            const uint32_t* __restrict__ list = pool + seg.x;
-            for (uint32_t base = 0; base < seg.y && count < CAND; base += 64) {
-                const uint32_t i = base + lane;
+            __syncthreads();
+            if (!active) return;
+            for (uint32_t base = 0; base < gn && count < CAND; base += 64u) {
+                const uint32_t i = base + (uint32_t)lane;
                 bool pass = false;
                 float impact = 0.0f;
-                uint32_t j = 0;
-                if (i < seg.y) {
-                    const uint32_t e = list[i];
-                    j = e & 0x7FFFFFFFu;
-                    if (e & 0x80000000u) pass = true;
-                    else pass = tile_test(t, lightView[j], impact);
+                uint32_t e = 0u;
+                if (i < gn) {
+                    e = sE[i];
+                    if (e & 0x80000000u) pass = true; // directional: always a candidate, impact 0 (:153-162)
+                    else pass = tile_test(t, sLV[i], impact);
                 }
-                wave_append(pass, j, impact, count, sIdx, sImp);
+                wave_append(pass, e & 0x7FFFFFFFu, impact, count, sIdx, sImp);
             }
+        } else {
+        // overflowed group (very dense region / lights around the eye): every tile walks its own two masks
+        if (!active) return;
+        uint32_t* sQ = reinterpret_cast<uint32_t*>(sLV) + wave * QCAP; // sLV is unused on this path
+        const unsigned long long* __restrict__ col = masks + (size_t)tx * words;
+        const unsigned long long* __restrict__ row = masks + (size_t)(Tx + tyLocal) * words;
+        uint32_t qHead = 0, qTail = 0; // ring buffer indices (wave-uniform)
+        unsigned long long next = (lane < words) ? (col[lane] & row[lane]) : 0ull;
+        for (int w0 = 0; w0 < words && count < CAND; w0 += 64) {
+            const unsigned long long m = next;
+            const int wn = w0 + 64 + lane;
+            next = (wn < words) ? (col[wn] & row[wn]) : 0ull; // prefetch the next 4096 lights' masks
+            // Scalar walk over the non-empty words of this step, in ascending order.  Each word's set bits go to the
+            // ordered queue with one mbcnt (bit k of word L = light 64 (w0 + L) + k lands behind the k' < k bits).
+            unsigned long long nz = __ballot(m != 0ull);
+            while (nz != 0ull && count < CAND) {
+                const int L = __builtin_ctzll(nz);
+                nz &= nz - 1ull;
+                const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)m, L);
+                const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(m >> 32), L);
+                const unsigned long long mk = ((unsigned long long)hi << 32) | lo;
+                if ((mk >> lane) & 1ull)
+                    sQ[(qTail + (uint32_t)__popcll(mk & lanemask_lt())) & (QCAP - 1)] = (uint32_t)(w0 + L) * 64u + (uint32_t)lane;
+                qTail += (uint32_t)__popcll(mk);
+                if (qTail - qHead >= 64u) { // a full wave of candidates is waiting: exact-test them
+                    WAVE_SYNC();
+                    const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
+                    test_candidates(t, lightView, lightType, true, j, count, sIdx, sImp);
+                    qHead += 64u;
+                    WAVE_SYNC();
+                }
+            }
+        }
+        WAVE_SYNC();
+        if (qTail != qHead && count < CAND) { // final partial round (< 64 pending)
+            const uint32_t n = qTail - qHead;
+            const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
+            test_candidates(t, lightView, lightType, (uint32_t)lane < n, j, count, sIdx, sImp);
+        }
         }
     }
     const uint32_t n = count < CAND ? count : CAND;
     const uint32_t num = n < KEEP ? n : KEEP;
-    __syncthreads(); // single wave: orders the LDS writes above with the reads below
+    WAVE_SYNC(); // orders the wave's LDS writes above with the reads below
     uint32_t* out = tileList + (size_t)bandTile * KEEP;
     if (n <= KEEP) {
         // :235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]
         for (uint32_t i = lane; i < num; i += 64) out[i] = sIdx[n - 1 - i];
     } else {
         // :198-225 partial bubble sort == rank under (impact ascending, candidate position descending); keep rank < 128
-        for (uint32_t k = lane; k < n; k += 64) {
-            const float f = sImp[k];
-            uint32_t rank = 0;
-            for (uint32_t q = 0; q < n; q++) {
-                const float g = sImp[q];
-                rank += (g < f || (g == f && q > k)) ? 1u : 0u;
+        // each lane ranks up to 4 candidates (k = lane + 64 i) against all n, 4 impacts per LDS read
+        float f[4];
+        uint32_t rank[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const uint32_t k = lane + 64u * i; f[i] = (k < n) ? sImp[k] : 0.0f; }
+        const float4* sImp4 = reinterpret_cast<const float4*>(sImp);
+        for (uint32_t q4 = 0; q4 < (n + 3u) / 4u; q4++) {
+            const float4 gv = sImp4[q4];
+            const float g[4] = { gv.x, gv.y, gv.z, gv.w };
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t q = q4 * 4u + e;
+                if (q < n) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t k = lane + 64u * i;
+                        rank[i] += (g[e] < f[i] || (g[e] == f[i] && q > k)) ? 1u : 0u;
+                    }
+                }
             }
-            if (rank < KEEP) out[rank] = sIdx[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t k = lane + 64u * i;
+            if (k < n && rank[i] < KEEP) out[rank[i]] = sIdx[k];
         }
     }
     if (lane == 0) tileNum[bandTile] = num;
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1d: canonical offsets (Appendix A step 6) and compaction
+// K1d: canonical offsets (Appendix A step 6) and compaction: per-1024-tile block sums, then every tile's wave
+// rebuilds its own exclusive prefix (block sums before its block + tiles before it inside the block).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k1_scan(const uint32_t* __restrict__ tileNum, int T, SailorLightsGrid* __restrict__ grid, uint32_t* __restrict__ culled)
+__global__ __launch_bounds__(1024) void k1_block_sums(const uint32_t* __restrict__ tileNum, int T, uint32_t* __restrict__ tilePrefix,
+                                                       uint32_t* __restrict__ blockSums)
 {
-    __shared__ uint32_t sWave[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (T + 1023) / 1024;
-    const int b = tid * per, e = min(b + per, T);
-    uint32_t sum = 0;
-    for (int i = b; i < e; i++) sum += tileNum[i];
-    uint32_t incl = sum;
+    __shared__ uint32_t sW[16];
+    const int t = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t v = (t < T) ? tileNum[t] : 0u;
+    uint32_t incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t v = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += v;
+        const uint32_t u = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += u;
     }
-    if (lane == 63) sWave[wave] = incl;
+    if (lane == 63) sW[wave] = incl;
     __syncthreads();
-    uint32_t waveBase = 0, total = 0;
+    uint32_t before = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) { const uint32_t c = sWave[w]; waveBase += (w < wave) ? c : 0u; total += c; }
-    uint32_t run = waveBase + incl - sum;
-    for (int i = b; i < e; i++) {
-        const uint32_t n = tileNum[i];
-        grid[i].offset = run + 1u;
-        grid[i].num = n;
-        run += n;
-    }
-    if (tid == 0) culled[0] = total;
+    for (int w = 0; w < 16; w++) { const uint32_t c = sW[w]; before += (w < wave) ? c : 0u; total += c; }
+    if (t < T) tilePrefix[t] = before + incl - v; // exclusive prefix inside the 1024-tile block
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(256) void k1_pack(const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ tileList, int T,
+__global__ __launch_bounds__(256) void k1_pack(const uint32_t* __restrict__ tileNum, const uint32_t* __restrict__ tilePrefix,
+                                                const uint32_t* __restrict__ blockSums, int sumBlocks,
+                                                const uint32_t* __restrict__ tileList, int T, SailorLightsGrid* __restrict__ grid,
                                                 uint32_t* __restrict__ culled, uint32_t capacity)
 {
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= T) return;
     const int lane = threadIdx.x & 63;
-    const SailorLightsGrid g = grid[tile];
+    const int blk = tile / SCAN_BLOCK;
+    uint32_t s = 0, tot = 0;
+    for (int i = lane; i < sumBlocks; i += 64) { const uint32_t b = blockSums[i]; tot += b; s += (i < blk) ? b : 0u; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { s += (uint32_t)__shfl_xor((int)s, d); tot += (uint32_t)__shfl_xor((int)tot, d); }
+    const uint32_t offset = s + tilePrefix[tile] + 1u;
+    const uint32_t num = tileNum[tile];
+    if (lane == 0) { grid[tile].offset = offset; grid[tile].num = num; }
     const uint32_t* src = tileList + (size_t)tile * KEEP;
-    for (uint32_t i = lane; i < g.num; i += 64)
-        if (g.offset + i < capacity) culled[g.offset + i] = src[i];
+    for (uint32_t i = lane; i < num; i += 64)
+        if (offset + i < capacity) culled[offset + i] = src[i];
+    if (tile == 0 && lane == 0) culled[0] = tot;
 }
 
 __global__ void k_grid_rebase(SailorLightsGrid* grid, int T, uint32_t base)
@@ -505,6 +604,7 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
     if (!ctx || !frame || !pc || !dLinearDepth || !dLightsGrid || !dCulledLights || !dWorkspace) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     const int W = pc->viewportSize[0], H = pc->viewportSize[1], N = pc->lightsNum;
     if (W <= 0 || H <= 0 || N < 0 || (N > 0 && !dLights)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (N > 0x3FFFFFFF) return SAILOR_HIP_ERR_UNSUPPORTED; // bit 31 of a candidate entry carries the "directional" flag
     // Appendix A: the depth extent (push constants) and the window viewport (frame UBO) must agree
     if (frame->viewportSize[0] != W || frame->viewportSize[1] != H) return SAILOR_HIP_ERR_UNSUPPORTED;
     SailorBand whole;
@@ -521,12 +621,15 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
     float4* lightView = (float4*)(ws + L.offLightView);
     uint32_t* lightType = (uint32_t*)(ws + L.offLightType);
     float4* tileInfo = (float4*)(ws + L.offTileInfo);
-    float4* macroInfo = (float4*)(ws + L.offMacroInfo);
-    uint2* segTable = (uint2*)(ws + L.offSegTable);
-    uint32_t* cursor = (uint32_t*)(ws + L.offCursor);
+    float4* bandPlanes = (float4*)(ws + L.offBandPlanes);
+    unsigned long long* masks = (unsigned long long*)(ws + L.offMasks);
+    unsigned long long* dirWords = (unsigned long long*)(ws + L.offDirWords);
     uint32_t* tileNum = (uint32_t*)(ws + L.offTileNum);
+    uint32_t* tilePrefix = (uint32_t*)(ws + L.offTilePrefix);
     uint32_t* tileList = (uint32_t*)(ws + L.offTileList);
-    uint32_t* pool = (uint32_t*)(ws + L.offPool);
+    uint32_t* blockSums = (uint32_t*)(ws + L.offBlockSums);
+    uint32_t* groupCount = (uint32_t*)(ws + L.offGroupCount);
+    uint32_t* groupList = (uint32_t*)(ws + L.offGroupList);
 
     if (L.bandTiles == 0) {
         SAILOR_TRY_HIP(ctx, hipMemsetAsync(dCulledLights, 0, 4, s));
@@ -537,42 +640,78 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
     memcpy(view.m, frame->view, 64);
     memcpy(invProj.m, frame->invProjection, 64);
 
-    if (N > 0) {
-        hipLaunchKernelGGL(k0_light_view, dim3((N + 255) / 256), dim3(256), 0, s, view, dLights, N, lightView, lightType);
+    // The side-plane margin argument needs a sane perspective; tiny light counts are cheaper brute force.
+    const float p00 = fabsf(frame->projection[0]), p11 = fabsf(frame->projection[5]);
+    const bool sane = p00 > 1e-2f && p11 > 1e-2f && p00 < 1e4f && p11 < 1e4f;
+    const bool brute = (flags & SAILOR_CULL_BRUTE_FORCE) || !sane || N < 512;
+
+    const int lightBlocks = (N + 255) / 256;
+    const int bandBlocks = brute ? 0 : (L.numBands + 255) / 256;
+    if (lightBlocks + bandBlocks > 0) {
+        hipLaunchKernelGGL(k0_light_view, dim3(lightBlocks + bandBlocks), dim3(256), 0, s, view, dLights, N, lightBlocks, lightView, lightType,
+                           invProj, frame->viewportSize[0], frame->viewportSize[1], L.Tx, L.Ty, band->tileRowBegin, L.numBands, bandPlanes);
         SAILOR_CHECK_LAUNCH(ctx, "k0_light_view");
     }
     const int stripsPerRow = (L.Tx + 15) / 16;
-    const int rows = band->tileRowEnd - band->tileRowBegin;
-    hipLaunchKernelGGL(k1_tile_setup, dim3(stripsPerRow * rows), dim3(256), 0, s, invProj, frame->viewportSize[0], frame->viewportSize[1],
-                       dLinearDepth, W, H, L.Tx, band->tileRowBegin, band->fbRowBegin, stripsPerRow, tileInfo);
+    const int vecOK = (((uintptr_t)dLinearDepth & 15) == 0 && (W & 3) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k1_tile_setup, dim3(stripsPerRow * L.bandRows), dim3(256), 0, s, invProj, frame->viewportSize[0], frame->viewportSize[1],
+                       dLinearDepth, W, H, L.Tx, band->tileRowBegin, band->fbRowBegin, stripsPerRow, vecOK, tileInfo);
     SAILOR_CHECK_LAUNCH(ctx, "k1_tile_setup");
 
-    // The side-plane margin argument needs a sane perspective (|N_tile| / |N_macro| bounded); otherwise brute force.
-    const float p00 = fabsf(frame->projection[0]), p11 = fabsf(frame->projection[5]);
-    const bool sane = p00 > 1e-2f && p11 > 1e-2f && p00 < 1e4f && p11 < 1e4f;
-    const bool brute = (flags & SAILOR_CULL_BRUTE_FORCE) || !sane || N < 4 * CHUNK / 8;
     if (brute) {
-        hipLaunchKernelGGL(k1_tile_cull<true>, dim3(L.bandTiles), dim3(64), 0, s, lightView, lightType, N, tileInfo, L.Tx, band->tileRowBegin,
-                           L.macroX, L.macroY0, L.numChunks, segTable, pool, tileNum, tileList);
+        hipLaunchKernelGGL(k1_tile_cull<true>, dim3(L.numGroups), dim3(1024), 0, s, lightView, lightType, N, L.words, tileInfo, L.Tx, L.bandRows, masks,
+                           groupCount, groupList, L.groupsX, tileNum, tileList);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull<brute>");
     } else {
-        SAILOR_TRY_HIP(ctx, hipMemsetAsync(cursor, 0, 4, s));
-        hipLaunchKernelGGL(k1_macro_setup, dim3((L.numMacros + 63) / 64), dim3(64), 0, s, invProj, frame->viewportSize[0], frame->viewportSize[1],
-                           L.Tx, band->tileRowBegin, band->tileRowEnd, L.macroX, L.macroY0, L.numMacros, tileInfo, macroInfo);
-        SAILOR_CHECK_LAUNCH(ctx, "k1_macro_setup");
         const float planeMargin = 1e-3f;
-        hipLaunchKernelGGL(k1_macro_cull, dim3(L.numChunks, L.numMacros), dim3(256), 0, s, lightView, lightType, N, macroInfo, L.numChunks, planeMargin,
-                           pool, (uint32_t)(L.poolEntries > 0xFFFFFFF0u ? 0xFFFFFFF0u : L.poolEntries), cursor, segTable);
-        SAILOR_CHECK_LAUNCH(ctx, "k1_macro_cull");
-        hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.bandTiles), dim3(64), 0, s, lightView, lightType, N, tileInfo, L.Tx, band->tileRowBegin,
-                           L.macroX, L.macroY0, L.numChunks, segTable, pool, tileNum, tileList);
+        const int groups = (L.numBands + BANDS_PER_GROUP - 1) / BANDS_PER_GROUP;
+        hipLaunchKernelGGL(k1_band_masks, dim3((L.words + 3) / 4, groups), dim3(256), 0, s, lightView, lightType, N, L.words, bandPlanes, L.numBands,
+                           planeMargin, masks, dirWords);
+        SAILOR_CHECK_LAUNCH(ctx, "k1_band_masks");
+        hipLaunchKernelGGL(k1_group_lists, dim3(L.numGroups), dim3(256), 0, s, masks, dirWords, L.words, L.Tx, L.bandRows, L.groupsX, groupCount, groupList);
+        SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
+        hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.numGroups), dim3(1024), 0, s, lightView, lightType, N, L.words, tileInfo, L.Tx, L.bandRows, masks,
+                           groupCount, groupList, L.groupsX, tileNum, tileList);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
     }
-    hipLaunchKernelGGL(k1_scan, dim3(1), dim3(1024), 0, s, tileNum, L.bandTiles, dLightsGrid, dCulledLights);
-    SAILOR_CHECK_LAUNCH(ctx, "k1_scan");
-    hipLaunchKernelGGL(k1_pack, dim3((L.bandTiles + 3) / 4), dim3(256), 0, s, dLightsGrid, tileList, L.bandTiles, dCulledLights,
-                       (uint32_t)(culledCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : culledCapacity));
+    hipLaunchKernelGGL(k1_block_sums, dim3(L.sumBlocks), dim3(SCAN_BLOCK), 0, s, tileNum, L.bandTiles, tilePrefix, blockSums);
+    SAILOR_CHECK_LAUNCH(ctx, "k1_block_sums");
+    hipLaunchKernelGGL(k1_pack, dim3((L.bandTiles + 3) / 4), dim3(256), 0, s, tileNum, tilePrefix, blockSums, L.sumBlocks, tileList, L.bandTiles, dLightsGrid,
+                       dCulledLights, (uint32_t)(culledCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : culledCapacity));
     SAILOR_CHECK_LAUNCH(ctx, "k1_pack");
+    return SAILOR_HIP_OK;
+}
+
+// Diagnostics for benchmarks / tuning (synchronises): density of the band masks and of the group candidate lists left in
+// `dWorkspace` by the last sailor_hip_light_cull with the same geometry.
+// out[0] = numBands, out[1] = mask bits set (all bands), out[2] = numGroups, out[3] = sum of group list lengths,
+// out[4] = overflowed groups, out[5] = longest group list, out[6] = words per band, out[7] = bits set in column masks only
+int sailor_hip_light_cull_diagnostics(SailorHipContext* ctx, int32_t width, int32_t height, int32_t lightsNum, const SailorBand* band,
+                                      const void* dWorkspace, uint64_t* out8)
+{
+    if (!ctx || !dWorkspace || !out8 || width <= 0 || height <= 0 || lightsNum < 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SailorBand whole;
+    if (!band) { sailor_hip_band_whole_frame(width, height, &whole); band = &whole; }
+    if (!band_valid(width, height, band)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const CullLayout L = make_layout(width, height, lightsNum, *band);
+    std::vector<unsigned long long> masks((size_t)L.numBands * L.words);
+    std::vector<uint32_t> counts((size_t)L.numGroups);
+    SAILOR_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SAILOR_TRY_HIP(ctx, hipMemcpy(masks.data(), (const char*)dWorkspace + L.offMasks, masks.size() * 8, hipMemcpyDeviceToHost));
+    SAILOR_TRY_HIP(ctx, hipMemcpy(counts.data(), (const char*)dWorkspace + L.offGroupCount, counts.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t bits = 0, colBits = 0, sum = 0, over = 0, longest = 0;
+    for (size_t i = 0; i < masks.size(); i++) {
+        const uint64_t c = (uint64_t)__builtin_popcountll(masks[i]);
+        bits += c;
+        if (i < (size_t)L.Tx * L.words) colBits += c;
+    }
+    for (uint32_t c : counts) {
+        if (c == GROUP_OVERFLOW) { over++; continue; }
+        sum += c;
+        if (c > longest) longest = c;
+    }
+    out8[0] = (uint64_t)L.numBands; out8[1] = bits; out8[2] = (uint64_t)L.numGroups; out8[3] = sum;
+    out8[4] = over; out8[5] = longest; out8[6] = (uint64_t)L.words; out8[7] = colBits;
     return SAILOR_HIP_OK;
 }
 

@@ -101,6 +101,13 @@ class ForwardPlus:
         return out
 
     # -- helpers ----------------------------------------------------------------------------------------------------
+    def cull_diagnostics(self, lights_num: int) -> dict:
+        out = (C.c_uint64 * 8)()
+        _lib.check(self.ctx._lib.sailor_hip_light_cull_diagnostics(self.ctx.handle, self.W, self.H, lights_num, C.byref(self.band),
+                                                                   _ptr(self.workspace), out), "light_cull_diagnostics", self.ctx.handle)
+        keys = ["bands", "mask_bits", "groups", "group_list_sum", "groups_overflowed", "group_list_max", "words_per_band", "column_mask_bits"]
+        return dict(zip(keys, [int(v) for v in out]))
+
     def lists_to_host(self):
         """(grid uint32[T,2], indices uint32[1 + total]) of this band, band-local offsets."""
         self.ctx.synchronize()

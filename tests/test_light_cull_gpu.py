@@ -98,7 +98,7 @@ def test_lights_behind_and_around_the_camera(ctx):
     cam, depth, lights = frame(640, 360, 6000, radius_scale=2.0, seed=5)
     view = np.frombuffer(bytes(cam.frame.view), np.float32).reshape(4, 4)
     rng = np.random.default_rng(1)
-    k = 1500
+    k = 3000  # > 2048 always-kept lights per 4x4-tile group: exercises the per-tile mask-walk fallback
     # world positions scattered in a box around the camera (0,150,0), big radii
     lights["worldPosition"][:k] = (rng.uniform(-400, 400, (k, 3)) + np.array([0, 150, 0])).astype(np.float32)
     lights["bounds"][:k] = rng.uniform(5, 600, (k, 1)).astype(np.float32)
