@@ -5,12 +5,14 @@
 // (FrameGraph/RenderSceneNode.cpp:109), as compute over a surface buffer (ambient == 0).
 //
 // Shape: one 256-thread block per 16x16 tile -- the unit the light list is defined on -- so the tile's <=128
-// light records are fetched from HBM once, derived per-light constants (normalised spot axis, cone width) are
-// computed once by 128 lanes, and the records sit in LDS (128 x 80 B = 10 KB) where every lane reads the SAME
-// address per step (LDS broadcast, conflict-free).  Each wave covers 4 framebuffer rows x 16 pixels, i.e. four
-// 256-byte row segments per float4 plane; radiance goes out as one float4 per lane.  The light type branch is
-// wave-uniform (all lanes walk the same list), and a wave skips the BRDF of a light whose falloff is zero on
-// all of its 64 pixels (the list is conservative: sphere-vs-tile-frustum).
+// light records are fetched from HBM once, derived per-light constants (normalised spot axis, cone width, reach
+// thresholds) are computed once by 128 lanes, and the records sit in LDS (129 x 80 B = 10 KB) where every lane reads
+// the SAME address per step (LDS broadcast, conflict-free).  Each wave covers one 8x8 quadrant of the tile (eight
+// 128-byte row segments per float4 plane); radiance goes out as one float4 per lane.  The light type branch is
+// wave-uniform (all lanes walk the same list).  The tile list is conservative (sphere vs tile frustum) while the
+// surface is a thin sheet inside that frustum: on the 4K / 65 536-light frame only ~3 % of the (pixel, light) pairs are
+// actually lit.  So every step starts with a ~12-instruction conservative "can any of my 64 pixels be reached" test
+// and most steps end there; the exact falloff and the BRDF only run for lights that reach the quadrant.
 //
 // Numerics: the BRDF is tolerance-checked (1e-4 relative), so its well-conditioned parts use v_rcp and explicit
 // FMAs.  Two places are NOT well-conditioned and are evaluated in the oracle's exact fp32 order instead:
@@ -201,20 +203,30 @@ __device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsq
 
 #define LREC 5 // float4 per staged light
 
+// Staged light record (LDS, 5 float4):
+//   rec0 = (worldPosition.xyz, bits: type | shadowType << 8 | finite << 16)
+//   rec1 = (normalize(-direction).xyz, A)  A = point: r^2 (1 + 1e-5) "out of reach" threshold (+inf = never reject)
+//                                              spot : cutOff.y - 1e-5  (conservative cone threshold)
+//   rec2 = (attenuation.xyz, B)            B = point: bounds.x          spot: epsilon = cutOff.x - cutOff.y (:297)
+//   rec3 = (Li = -direction.xyz, cutOff.y)
+//   rec4 = (intensity.xyz, -)
+// Stage A of the light loop touches rec0/rec1 only, and both are prefetched one light ahead.
 template <bool HAS_CSM>
 __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const float4* __restrict__ surface, size_t planeStride,
                                                  const SailorLightShaderData* __restrict__ lights,
                                                  const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled,
                                                  float4* __restrict__ radiance)
 {
-    __shared__ float4 sL[KEEP * LREC];
+    __shared__ float4 sL[(KEEP + 1) * LREC];
     __shared__ uint32_t sNum;
 
     const int bandTile = blockIdx.x;
     const int tx = bandTile % A.Tx, ty = A.tileRow0 + bandTile / A.Tx;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gx = tx * TILE + (lane & 15);
-    const int gy = ty * TILE + wave * 4 + (lane >> 4);
+    // each wave shades one 8x8 quadrant of the tile: the most compact 64-pixel footprint, so that "no pixel of the wave
+    // is within reach of this light" holds as often as possible
+    const int gx = tx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int gy = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
     const int py = A.H - 1 - gy;            // framebuffer row (Standard.shader:414: screenUv.y = H - fragY)
     const bool active = gx < A.W && py >= 0;
     const size_t pix = active ? ((size_t)(py - A.fbRow0) * A.W + gx) : 0;
@@ -239,17 +251,28 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
             const float4* L = reinterpret_cast<const float4*>(lights + index);
             const float4 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3], q4 = L[4], q5 = L[5], q6 = L[6];
             const uint32_t type = __float_as_uint(q0.x), shadowType = __float_as_uint(q0.y);
-            const float ndx = -q2.x, ndy = -q2.y, ndz = -q2.z;         // Li = -light.direction (:309)
+            const float ndx = -q2.x, ndy = -q2.y, ndz = -q2.z;            // Li = -light.direction (:309)
             const float len = sqrtf(dot3f(ndx, ndy, ndz, ndx, ndy, ndz)); // normalize(-light.direction) (:298)
-            float4* o = sL + threadIdx.x * LREC;
-            o[0] = make_float4(q1.x, q1.y, q1.z, q6.x);                                  // worldPosition, bounds.x
-            o[1] = make_float4(ndx, ndy, ndz, __uint_as_float(type | (shadowType << 8)));
-            o[2] = make_float4(q3.x, q3.y, q3.z, q5.y);                                  // intensity, cutOff.y
-            o[3] = make_float4(q4.x, q4.y, q4.z, q5.x - q5.y);                           // attenuation, epsilon (:297)
             const float linv = 1.0f / len;
-            o[4] = make_float4(ndx * linv, ndy * linv, ndz * linv, 0.0f);
+            // A zero factor only annihilates a FINITE product (inf * 0 = NaN in the reference): lights with a non-finite
+            // intensity are never skipped.
+            const bool finite = fabsf(q3.x) < __builtin_inff() && fabsf(q3.y) < __builtin_inff() && fabsf(q3.z) < __builtin_inff();
+            // Conservative "out of reach" threshold of a point light: d^2 > r^2 (1 + 1e-5) => fl(dist / r) >= 1 => the radius
+            // window (:290) is exactly 0.  Only for r > 0 (a negative radius clamps to the FULL window in the reference).
+            const float r = q6.x;
+            float a = __builtin_inff(), b = r;
+            if (type == 1u) { if (finite && r > 0.0f) a = (r * r) * 1.00001f; }
+            else { a = finite ? q5.y - 1e-5f : -__builtin_inff(); b = q5.x - q5.y; }
+            const uint32_t bits = (type < 255u ? type : 255u) | ((shadowType < 255u ? shadowType : 255u) << 8) | (finite ? 0x10000u : 0u);
+            float4* o = sL + threadIdx.x * LREC;
+            o[0] = make_float4(q1.x, q1.y, q1.z, __uint_as_float(bits));
+            o[1] = make_float4(ndx * linv, ndy * linv, ndz * linv, a);
+            o[2] = make_float4(q4.x, q4.y, q4.z, b);
+            o[3] = make_float4(ndx, ndy, ndz, q5.y);
+            o[4] = make_float4(q3.x, q3.y, q3.z, 0.0f);
         }
     }
+    if (threadIdx.x < LREC) sL[KEEP * LREC + threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // prefetch target past the last light
     __syncthreads();
     const uint32_t numLights = sNum;
 
@@ -270,37 +293,98 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
     const float g1Lo = cosLo * rcp_fast(fmaf(cosLo, oneMinusK, k)); // GeometrySchlickG1(cosLo, k)
     const bool brdfFinite = alphaSq > 0.0f;                       // roughness 0 makes NdfGGX 0/0 in the reference
 
+    // ---- which lights can reach this quadrant at all?  One LANE per LIGHT: sphere (centre, r sqrt(1 + 1e-4)) against the
+    // world-space bounding box of the quadrant's 64 surface points.  Two ballots cover the whole <= 128-entry list, and
+    // the per-pixel loop below then visits only the surviving lights.  (Conservative: a point light whose sphere misses
+    // the box has d^2 > r^2 (1 + 1e-5) for every pixel, i.e. an exact-zero radius window -- see rec1.w.)
+    float bminx = active ? wx : __builtin_inff(), bminy = active ? wy : __builtin_inff(), bminz = active ? wz : __builtin_inff();
+    float bmaxx = active ? wx : -__builtin_inff(), bmaxy = active ? wy : -__builtin_inff(), bmaxz = active ? wz : -__builtin_inff();
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        bminx = fminf(bminx, __shfl_xor(bminx, d)); bminy = fminf(bminy, __shfl_xor(bminy, d)); bminz = fminf(bminz, __shfl_xor(bminz, d));
+        bmaxx = fmaxf(bmaxx, __shfl_xor(bmaxx, d)); bmaxy = fmaxf(bmaxy, __shfl_xor(bmaxy, d)); bmaxz = fmaxf(bmaxz, __shfl_xor(bmaxz, d));
+    }
+    const bool anyNonFinitePixel = __ballot(active && !brdfFinite) != 0ull; // such pixels must see every light (0 * NaN)
+    unsigned long long survivors[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t li = (uint32_t)(h * 64 + lane);
+        bool keep = false;
+        if (li < numLights) {
+            const float4 c0 = sL[li * LREC + 0], c1 = sL[li * LREC + 1];
+            const uint32_t cb = __float_as_uint(c0.w);
+            keep = true;
+            if ((cb & 0xFFu) == 1u && !anyNonFinitePixel) {
+                const float ex = fmaxf(fmaxf(bminx - c0.x, c0.x - bmaxx), 0.0f);
+                const float ey = fmaxf(fmaxf(bminy - c0.y, c0.y - bmaxy), 0.0f);
+                const float ez = fmaxf(fmaxf(bminz - c0.z, c0.z - bmaxz), 0.0f);
+                // c1.w = r^2 (1 + 1e-5) (+inf: never reject); another 1e-4 covers the rounding of this estimate
+                keep = !(fmaf(ex, ex, fmaf(ey, ey, ez * ez)) > c1.w * 1.0001f);
+            }
+        }
+        survivors[h] = __ballot(keep);
+    }
+
     float accX = 0.0f, accY = 0.0f, accZ = 0.0f;
-    for (uint32_t i = 0; i < numLights; i++) {
+    for (int h = 0; h < 2; h++) {
+    unsigned long long todo = survivors[h];
+    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0;
+    if (todo) { const uint32_t f = (uint32_t)(h * 64 + __builtin_ctzll(todo)); n0 = sL[f * LREC + 0]; n1 = sL[f * LREC + 1]; }
+    while (todo) {
+        const uint32_t i = (uint32_t)(h * 64 + __builtin_ctzll(todo));
+        todo &= todo - 1ull;
         const float4* R = sL + i * LREC;
-        const float4 r0 = R[0], r1 = R[1];
-        const uint32_t bits = __float_as_uint(r1.w);
+        const float4 r0 = n0, r1 = n1;
+        { // next surviving light's stage-A data is in flight while this one is processed
+            const uint32_t nx_ = todo ? (uint32_t)(h * 64 + __builtin_ctzll(todo)) : (uint32_t)KEEP;
+            n0 = sL[nx_ * LREC + 0]; n1 = sL[nx_ * LREC + 1];
+        }
+        const uint32_t bits = __float_as_uint(r0.w);
         const uint32_t type = bits & 0xFFu;
+        const bool lightFinite = (bits & 0x10000u) != 0u;
         float falloff = 1.0f, shadow = 1.0f;
+        float4 r3;
         if (type == 1u || type == 2u) {
             const float dx = r0.x - wx, dy = r0.y - wy, dz = r0.z - wz;
             const float d2 = dot3f(dx, dy, dz, dx, dy, dz);
+            // Stage A -- cheap, conservative: is ANY pixel of this wave within reach of the light?  (Measured on the 4K /
+            // 65 536-light frame: 71 % of the (wave, light) steps have no pixel in reach -- the tile list is a sphere-vs-
+            // frustum overlap, the surface is a thin sheet inside that frustum.)
+            bool reach;
+            if (type == 1u) reach = !(d2 > r1.w);                    // r1.w = r^2 (1 + 1e-5), +inf when not applicable
+            else {
+                // spot: falloff is exactly 0 iff theta < cutOff.y (:303-306); theta ~ dot(d, axis) / |d| to a few ulp
+                const float thetaApprox = fmaf(dx, r1.x, fmaf(dy, r1.y, dz * r1.z)) * rsq_fast(d2);
+                reach = !(thetaApprox < r1.w);                       // r1.w = cutOff.y - 1e-5 (-inf when not applicable)
+            }
+            if (__ballot(active && (reach || !brdfFinite)) == 0ull) continue;
+            // Stage B -- exact falloff (the oracle's op order where it is ill-conditioned)
             const float dist = sqrtf(d2);                                       // exact: feeds 1 - (dist / bounds.x)^2
-            const float4 r3 = R[3];
-            const float att = rcp_fast(fmaf(r3.z, d2, fmaf(r3.y, dist, r3.x))); // 1/(a.x + a.y d + a.z d^2) (:289,:300)
+            const float4 r2 = R[2];
+            r3 = R[3];
+            const float att = rcp_fast(fmaf(r2.z, d2, fmaf(r2.y, dist, r2.x))); // 1/(a.x + a.y d + a.z d^2) (:289,:300)
             if (type == 1u) {
-                const float q = fminf(fmaxf(dist / r0.w, 0.0f), 1.0f);
+                const float q = fminf(fmaxf(dist / r2.w, 0.0f), 1.0f);
                 falloff = att * (1.0f - q * q);                              // (:290)
             } else {
-                const float4 r4 = R[4];
                 const float dinv = 1.0f / dist; // exact chain: (theta - cutOff.y) cancels at the cone edge
-                const float theta = dot3f(dx * dinv, dy * dinv, dz * dinv, r4.x, r4.y, r4.z); // dot(normalize(pos - wp), normalize(-dir))
-                const float cutY = R[2].w;
-                falloff = att * fminf(fmaxf((theta - cutY) / r3.w, 0.0f), 1.0f);     // (:301)
+                const float theta = dot3f(dx * dinv, dy * dinv, dz * dinv, r1.x, r1.y, r1.z); // dot(normalize(pos - wp), normalize(-dir))
+                const float cutY = r3.w;
+                falloff = att * fminf(fmaxf((theta - cutY) / r2.w, 0.0f), 1.0f);     // (:301)
                 if (theta < cutY) falloff = 0.0f;                                     // (:303-306)
             }
-            // conservative list: skip the BRDF when no pixel of this wave is reached by the light
-            if (__ballot(active && (falloff != 0.0f || !brdfFinite)) == 0ull) continue;
-        } else if (type == 0u) {
-            if (HAS_CSM) shadow = directional_shadow(A, C, (bits >> 8) & 0xFFu, -r1.x, -r1.y, -r1.z, nx, ny, nz, wx, wy, wz);
+            // skip the BRDF when every pixel of the wave gets an exact zero from this light: out of reach, or facing away
+            // (cosLi = max(0, n . Li) = 0 zeroes both the specular G term and the final product)
+            const float cosLiEarly = fmaxf(0.0f, dot3f(nx, ny, nz, r3.x, r3.y, r3.z));
+            if (__ballot(active && ((falloff != 0.0f && cosLiEarly != 0.0f) || !brdfFinite || !lightFinite)) == 0ull) continue;
+        } else {
+            r3 = R[3];
+            if (type == 0u) {
+                if (HAS_CSM) shadow = directional_shadow(A, C, (bits >> 8) & 0xFFu, -r3.x, -r3.y, -r3.z, nx, ny, nz, wx, wy, wz);
+            }
         }
         // ---- Cook-Torrance (Standard.shader:309-340) ----
-        const float Lix = r1.x, Liy = r1.y, Liz = r1.z;
+        const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
         float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;
         const float hinv = 1.0f / sqrtf(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
         hx *= hinv; hy *= hinv; hz *= hinv;
@@ -313,12 +397,13 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
         const float D = alphaSq * rcp_fast(3.14159265359f * dn * dn);              // NdfGGX
         const float G = cosLi * rcp_fast(fmaf(cosLi, oneMinusK, k)) * g1Lo;        // GeometrySchlickGGX
         const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * cosLo));
-        const float4 r2 = R[2];
+        const float4 r4 = R[4];
         const float scale = shadow * cosLi * falloff;
         // shadow * ((kd*albedo + F*D*G/denom) * Lradiance * cosLi) * falloff ; kd = mix(1 - F, 0, metallic)
-        accX = fmaf(fmaf((1.0f - Fx) * oneMinusMetal, P2.x, Fx * spec) * r2.x, scale, accX);
-        accY = fmaf(fmaf((1.0f - Fy) * oneMinusMetal, P2.y, Fy * spec) * r2.y, scale, accY);
-        accZ = fmaf(fmaf((1.0f - Fz) * oneMinusMetal, P2.z, Fz * spec) * r2.z, scale, accZ);
+        accX = fmaf(fmaf((1.0f - Fx) * oneMinusMetal, P2.x, Fx * spec) * r4.x, scale, accX);
+        accY = fmaf(fmaf((1.0f - Fy) * oneMinusMetal, P2.y, Fy * spec) * r4.y, scale, accY);
+        accZ = fmaf(fmaf((1.0f - Fz) * oneMinusMetal, P2.z, Fz * spec) * r4.z, scale, accZ);
+    }
     }
     if (active) radiance[pix] = make_float4(accX, accY, accZ, P0.w); // outColor.a = material.albedo.a (:438)
 }
