@@ -1,0 +1,65 @@
+"""The split-frame exchange on CPU: world_size-2 and -3 `gloo` process groups stitch per-band light lists (produced by the
+oracle here; by the HIP path on the GPU box) into the reference's global canonical buffers."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, w, h, n, out_dir):
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    from oracle import oracle
+    from sailor_amd import dist as sdist, host, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cam = synth.make_camera(w, h)
+        depth = synth.make_linear_depth(w, h, 31)
+        lights = synth.make_lights(cam, depth, synth.LightSetConfig(count=n, spot_fraction=0.25, radius_scale=5.0, cluster_lights=300), 31)
+        band = host.band_for_rank(w, h, rank, world)
+        # this rank's band, exactly as sailor_hip_light_cull returns it: band-local grid + culled[0] = band total
+        g, idx, _ = oracle.light_cull(cam.frame, w, h, lights, depth, tile_rows=(band.tileRowBegin, band.tileRowEnd))
+        band_grid = torch.from_numpy(g.astype(np.int64).astype(np.int32).reshape(-1).copy())
+        band_culled = torch.from_numpy(idx.view(np.int32).copy())
+        gg, gc = sdist.exchange_lists(band_grid, band_culled)
+        # a per-band payload (stand-in for radiance rows): row index pattern
+        rows = torch.arange(band.fbRowBegin, band.fbRowBegin + band.fbRowCount, dtype=torch.float32).reshape(-1, 1).repeat(1, 3)
+        full = sdist.gather_rows(rows)
+        np.savez(Path(out_dir) / f"rank{rank}.npz", grid=gg.numpy(), culled=gc.numpy(), rows=full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_band_lists_stitch_to_the_canonical_global_buffers(world, tmp_path):
+    w, h, n = 320, 200, 2500
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, w, h, n, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, str(ROOT))
+    from oracle import oracle
+    from sailor_amd import synth
+    cam = synth.make_camera(w, h)
+    depth = synth.make_linear_depth(w, h, 31)
+    lights = synth.make_lights(cam, depth, synth.LightSetConfig(count=n, spot_fraction=0.25, radius_scale=5.0, cluster_lights=300), 31)
+    ref_g, ref_i, _ = oracle.light_cull(cam.frame, w, h, lights, depth)
+    total = int(ref_i[0])
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        np.testing.assert_array_equal(z["grid"].view(np.uint32).reshape(-1, 2), ref_g)
+        np.testing.assert_array_equal(z["culled"].view(np.uint32), ref_i[: 1 + total])
+        np.testing.assert_array_equal(z["rows"][:, 0], np.arange(h, dtype=np.float32))  # bands re-assembled top to bottom
