@@ -1,0 +1,142 @@
+#include "FrameGraphNode.h"
+#include "LightCullingNode.h"
+#include "RHIFrameGraph.h"
+#include "../RHI/Renderer.h"
+
+using namespace Sailor;
+using namespace Sailor::RHI;
+using namespace Sailor::Framegraph;
+
+// ---- FrameGraphBuilder (FrameGraph/FrameGraphNode.cpp:16-41) -----------------------------------------------------------------
+std::map<std::string, std::function<FrameGraphNodePtr(void)>>& FrameGraphBuilder::Registry()
+{
+    static std::map<std::string, std::function<FrameGraphNodePtr(void)>> s_nodes; // function-local: safe during static init
+    return s_nodes;
+}
+
+void FrameGraphBuilder::RegisterFrameGraphNode(const std::string& nodeName, std::function<FrameGraphNodePtr(void)> factoryMethod)
+{
+    Registry()[nodeName] = std::move(factoryMethod);
+}
+
+FrameGraphNodePtr FrameGraphBuilder::CreateNode(const std::string& nodeName)
+{
+    auto it = Registry().find(nodeName);
+    return it == Registry().end() ? FrameGraphNodePtr() : it->second();
+}
+
+bool FrameGraphBuilder::IsRegistered(const std::string& nodeName) { return Registry().count(nodeName) != 0; }
+
+// force the registration objects of the path's nodes into the library
+template class Sailor::Framegraph::TFrameGraphNode<LightCullingNode>;
+template class Sailor::Framegraph::TFrameGraphNode<RenderSceneNode>;
+
+// ---- RHIFrameGraph ----------------------------------------------------------------------------------------------------------
+UboFrameData RHIFrameGraph::FillFrameData(RHICommandListPtr transferCmdList, RHISceneViewSnapshot& snapshot, float deltaTime, float worldTime) const
+{
+    // RHIFrameGraph.cpp:56-70
+    UboFrameData frameData {};
+    snapshot.m_frameBindings = Renderer::GetDriver()->CreateShaderBindings();
+    Renderer::GetDriver()->AddBufferToShaderBindings(snapshot.m_frameBindings, "frameData", sizeof(UboFrameData), 0, EShaderBindingType::UniformBuffer);
+    sailor_host_fill_frame_data(snapshot.m_camera.m_world, snapshot.m_camera.m_fov, snapshot.m_camera.m_aspect, snapshot.m_camera.m_zNear,
+                                snapshot.m_camera.m_zFar, m_viewport.x, m_viewport.y, worldTime, deltaTime, &frameData);
+    Renderer::GetDriverCommands()->UpdateShaderBinding(transferCmdList, snapshot.m_frameBindings->GetOrAddShaderBinding("frameData"), &frameData, sizeof(frameData));
+    return frameData;
+}
+
+void RHIFrameGraph::Process(RHISceneViewSnapshot& snapshot)
+{
+    auto driver = Renderer::GetDriver();
+    auto transferCmdList = driver->CreateCommandList();
+    auto cmdList = driver->CreateCommandList();
+    FillFrameData(transferCmdList, snapshot, snapshot.m_deltaTime, snapshot.m_currentTime);
+    for (auto& node : m_graph) node->Prepare(this, snapshot);
+    for (auto& node : m_graph) node->Process(this, transferCmdList, cmdList, snapshot); // RHIFrameGraph.cpp:250-252
+    driver->SubmitCommandList(transferCmdList);
+    driver->SubmitCommandList(cmdList);
+}
+
+void RHIFrameGraph::Clear()
+{
+    for (auto& node : m_graph) node->Clear();
+    m_graph.clear();
+    m_renderTargets.clear();
+}
+
+// ---- LightCullingNode (FrameGraph/LightCullingNode.cpp:17-87) ------------------------------------------------------------------
+const char* LightCullingNode::m_name = "LightCulling";
+
+void LightCullingNode::Process(RHIFrameGraphPtr frameGraph, RHICommandListPtr, RHICommandListPtr commandList, const RHISceneViewSnapshot& sceneView)
+{
+    if (!sceneView.m_rhiLightsData) return; // no point to cull lights if we have no lights in the scene (:24-28)
+
+    auto driver = Renderer::GetDriver();
+    if (!m_pComputeShader) m_pComputeShader = driver->CreateShader("Shaders/ComputeLightCulling.shader"); // (:30-34)
+
+    auto commands = Renderer::GetDriverCommands();
+    commands->BeginDebugRegion(commandList, GetName());
+
+    auto depthAttachment = GetRHIResource("depthStencil").DynamicCast<RHITexture>(); // DefaultRenderer.renderer:127-130 -> LinearDepth
+    if (!depthAttachment) depthAttachment = frameGraph->GetRenderTarget("DepthBuffer");
+    if (depthAttachment) {
+        PushConstants pushConstants {};
+        pushConstants.lightsNum = (int32_t)sceneView.m_totalNumLights;
+        pushConstants.viewportSize[0] = depthAttachment->GetExtent().x;
+        pushConstants.viewportSize[1] = depthAttachment->GetExtent().y;
+        pushConstants.numTiles[0] = (depthAttachment->GetExtent().x - 1) / (int32_t)TileSize + 1; // (:56)
+        pushConstants.numTiles[1] = (depthAttachment->GetExtent().y - 1) / (int32_t)TileSize + 1; // (:57)
+
+        if (!m_culledLights) {
+            const size_t numTiles = (size_t)pushConstants.numTiles[0] * pushConstants.numTiles[1];
+            m_culledLights = driver->CreateShaderBindings();
+            // +1: the reference's buffer is one uint short when every tile is full (:64)
+            auto culledLightsSSBO = driver->AddSsboToShaderBindings(m_culledLights, "culledLights", sizeof(uint32_t) * (numTiles * LightsPerTile + 1), 1, 0, true);
+            auto lightsGridSSBO = driver->AddSsboToShaderBindings(m_culledLights, "lightsGrid", sizeof(uint32_t) * (numTiles * 2 + 1), 1, 1, true);
+            driver->AddSamplerToShaderBindings(m_culledLights, "sceneDepth", depthAttachment, 2);
+            auto shaderBindingSet = sceneView.m_rhiLightsData;
+            driver->AddShaderBinding(shaderBindingSet, culledLightsSSBO, "culledLights", 1); // (:69) so that Standard.shader sees them
+            driver->AddShaderBinding(shaderBindingSet, lightsGridSSBO, "lightsGrid", 2);      // (:70)
+        }
+
+        commands->ImageMemoryBarrier(commandList, depthAttachment, EImageLayout::ShaderReadOnlyOptimal);
+        commands->Dispatch(commandList, m_pComputeShader, (uint32_t)pushConstants.numTiles[0], (uint32_t)pushConstants.numTiles[1], 1,
+                           { sceneView.m_rhiLightsData, m_culledLights, sceneView.m_frameBindings }, &pushConstants, sizeof(PushConstants));
+    }
+    commands->EndDebugRegion(commandList);
+}
+
+void LightCullingNode::Clear()
+{
+    m_pComputeShader.Clear();
+    m_culledLights.Clear();
+}
+
+// ---- RenderSceneNode (shading consumer) ---------------------------------------------------------------------------------------
+const char* RenderSceneNode::m_name = "RenderScene";
+
+void RenderSceneNode::Process(RHIFrameGraphPtr, RHICommandListPtr, RHICommandListPtr commandList, const RHISceneViewSnapshot& sceneView)
+{
+    if (!sceneView.m_rhiLightsData || !sceneView.m_rhiLightsData->Find("culledLights")) return; // RenderSceneNode.cpp:142-146: silent early return
+    auto driver = Renderer::GetDriver();
+    auto commands = Renderer::GetDriverCommands();
+    if (!m_pShader) m_pShader = driver->CreateShader("Shaders/Standard.shader");
+    auto surface = GetRHIResource("surface").DynamicCast<RHIBuffer>();
+    auto radiance = GetRHIResource("radiance").DynamicCast<RHIBuffer>();
+    if (!surface || !radiance) return;
+    if (!m_surfaceBindings) {
+        m_surfaceBindings = driver->CreateShaderBindings();
+        m_surfaceBindings->GetOrAddShaderBinding("surface")->m_buffer = surface;
+        m_surfaceBindings->GetOrAddShaderBinding("radiance")->m_buffer = radiance;
+    }
+    std::string tag;
+    commands->BeginDebugRegion(commandList, std::string(GetName()) + (TryGetString("Tag", tag) ? " QueueTag:" + tag : ""));
+    // binding sets as RenderSceneNode.cpp:181-185: { frame, lights(+culled+grid+shadowMaps+lightsMatrices), per-draw data }
+    commands->Dispatch(commandList, m_pShader, 0, 0, 0, { sceneView.m_frameBindings, sceneView.m_rhiLightsData, m_surfaceBindings });
+    commands->EndDebugRegion(commandList);
+}
+
+void RenderSceneNode::Clear()
+{
+    m_pShader.Clear();
+    m_surfaceBindings.Clear();
+}

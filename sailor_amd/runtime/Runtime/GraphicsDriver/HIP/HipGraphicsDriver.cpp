@@ -1,0 +1,269 @@
+#include "HipGraphicsDriver.h"
+#include "../../RHI/Renderer.h"
+
+#include <cstdio>
+
+using namespace Sailor;
+using namespace Sailor::RHI;
+using namespace Sailor::GraphicsDriver::HIP;
+
+IGraphicsDriver* Renderer::s_driver = nullptr;
+IGraphicsDriverCommands* Renderer::s_commands = nullptr;
+
+Renderer::Renderer(int deviceOrdinal, void* stream, bool ownStream)
+{
+    auto* hip = new HipGraphicsDriver(deviceOrdinal, stream, ownStream);
+    m_driverInstance.reset(hip);
+    m_status = hip->GetStatus();
+    s_driver = hip;
+    s_commands = hip; // the reference dynamic_casts the same object (RHI/Renderer.cpp:156-164)
+}
+
+Renderer::~Renderer()
+{
+    s_driver = nullptr;
+    s_commands = nullptr;
+}
+
+RHIBuffer::~RHIBuffer()
+{
+    if (m_hip.m_bOwned && m_hip.m_devicePtr && m_ctx) sailor_hip_buffer_free(m_ctx, m_hip.m_devicePtr);
+}
+
+HipGraphicsDriver::HipGraphicsDriver(int deviceOrdinal, void* stream, bool ownStream)
+{
+    m_status = sailor_hip_context_create(deviceOrdinal, stream, ownStream ? SAILOR_CTX_OWN_STREAM : 0u, &m_ctx);
+}
+
+HipGraphicsDriver::~HipGraphicsDriver()
+{
+    m_cullWorkspace.Clear();
+    if (m_ctx) sailor_hip_context_destroy(m_ctx);
+}
+
+void HipGraphicsDriver::WaitIdle() { if (m_ctx) sailor_hip_context_synchronize(m_ctx); }
+
+RHICommandListPtr HipGraphicsDriver::CreateCommandList(bool) { return RHICommandListPtr::Make(); }
+
+RHIBufferPtr HipGraphicsDriver::CreateBuffer(size_t size)
+{
+    auto b = RHIBufferPtr::Make();
+    b->m_ctx = m_ctx;
+    b->m_size = size;
+    if (!m_ctx || sailor_hip_buffer_create(m_ctx, size, &b->m_hip.m_devicePtr) != SAILOR_HIP_OK) return RHIBufferPtr();
+    b->m_hip.m_bOwned = true;
+    return b;
+}
+
+RHIBufferPtr HipGraphicsDriver::WrapBuffer(void* devicePtr, size_t size)
+{
+    auto b = RHIBufferPtr::Make();
+    b->m_ctx = m_ctx;
+    b->m_size = size;
+    b->m_hip.m_devicePtr = devicePtr;
+    b->m_hip.m_bOwned = false;
+    return b;
+}
+
+RHIShaderPtr HipGraphicsDriver::CreateShader(const std::string& assetPath) { return RHIShaderPtr::Make(assetPath); }
+
+static size_t texel_size(EFormat f) { return f == EFormat::R16_SFLOAT ? 2 : (f == EFormat::R32_SFLOAT ? 4 : 16); }
+
+RHITexturePtr HipGraphicsDriver::CreateTexture(const void* pData, size_t size, ivec2 extent, EFormat format)
+{
+    auto t = RHITexturePtr::Make();
+    t->m_extent = extent;
+    t->m_format = format;
+    const size_t bytes = (size_t)extent.x * extent.y * texel_size(format);
+    t->m_buffer = CreateBuffer(bytes);
+    if (!t->m_buffer) return RHITexturePtr();
+    if (pData) sailor_hip_buffer_upload(m_ctx, t->m_buffer->m_hip.m_devicePtr, 0, pData, size < bytes ? size : bytes);
+    return t;
+}
+
+RHITexturePtr HipGraphicsDriver::WrapTexture(void* devicePtr, ivec2 extent, EFormat format)
+{
+    auto t = RHITexturePtr::Make();
+    t->m_extent = extent;
+    t->m_format = format;
+    t->m_buffer = WrapBuffer(devicePtr, (size_t)extent.x * extent.y * texel_size(format));
+    return t;
+}
+
+void HipGraphicsDriver::SubmitCommandList(RHICommandListPtr commandList)
+{
+    // the recorded closures enqueue on the context stream; GPU work runs asynchronously after this returns
+    for (auto& c : commandList->m_hip.m_commands) {
+        const int st = c();
+        if (st != SAILOR_HIP_OK) { m_lastDispatchStatus = st; fprintf(stderr, "[HIP driver] command failed: %s (%s)\n", sailor_hip_status_string(st), sailor_hip_context_last_error(m_ctx)); }
+    }
+    commandList->m_hip.m_commands.clear();
+}
+
+RHIShaderBindingSetPtr HipGraphicsDriver::CreateShaderBindings() { return RHIShaderBindingSetPtr::Make(); }
+
+RHIShaderBindingPtr HipGraphicsDriver::AddSsboToShaderBindings(RHIShaderBindingSetPtr& set, const std::string& name, size_t elementSize,
+                                                               size_t numElements, uint32_t shaderBinding, bool)
+{
+    auto b = set->GetOrAddShaderBinding(name);
+    b->m_type = EShaderBindingType::StorageBuffer;
+    b->m_binding = shaderBinding;
+    b->m_buffer = CreateBuffer(elementSize * numElements);
+    return b;
+}
+
+RHIShaderBindingPtr HipGraphicsDriver::AddBufferToShaderBindings(RHIShaderBindingSetPtr& set, const std::string& name, size_t size, uint32_t shaderBinding,
+                                                                 EShaderBindingType bufferType)
+{
+    auto b = set->GetOrAddShaderBinding(name);
+    b->m_type = bufferType;
+    b->m_binding = shaderBinding;
+    if (bufferType == EShaderBindingType::UniformBuffer) b->m_hostCopy.assign(size, 0); // passed by value to the kernels
+    else b->m_buffer = CreateBuffer(size);
+    return b;
+}
+
+RHIShaderBindingPtr HipGraphicsDriver::AddSamplerToShaderBindings(RHIShaderBindingSetPtr& set, const std::string& name, RHITexturePtr texture, uint32_t shaderBinding)
+{
+    auto b = set->GetOrAddShaderBinding(name);
+    b->m_type = EShaderBindingType::CombinedImageSampler;
+    b->m_binding = shaderBinding;
+    b->m_textures = { texture };
+    return b;
+}
+
+RHIShaderBindingPtr HipGraphicsDriver::AddSamplerToShaderBindings(RHIShaderBindingSetPtr& set, const std::string& name, const TVector<RHITexturePtr>& array,
+                                                                  uint32_t shaderBinding)
+{
+    auto b = set->GetOrAddShaderBinding(name);
+    b->m_type = EShaderBindingType::CombinedImageSampler;
+    b->m_binding = shaderBinding;
+    b->m_textures = array;
+    return b;
+}
+
+RHIShaderBindingPtr HipGraphicsDriver::AddShaderBinding(RHIShaderBindingSetPtr& set, const RHIShaderBindingPtr& binding, const std::string& name, uint32_t shaderBinding)
+{
+    // share the SAME resource under another set/slot (LightCullingNode.cpp:69-70 registers its SSBOs into the lights set)
+    auto b = set->GetOrAddShaderBinding(name);
+    b->m_type = binding->m_type;
+    b->m_binding = shaderBinding;
+    b->m_buffer = binding->m_buffer;
+    b->m_textures = binding->m_textures;
+    return b;
+}
+
+void HipGraphicsDriver::BeginDebugRegion(RHICommandListPtr cmdList, const std::string& title) { cmdList->m_debugRegions.push_back(title); }
+void HipGraphicsDriver::EndDebugRegion(RHICommandListPtr) {}
+void HipGraphicsDriver::ImageMemoryBarrier(RHICommandListPtr, RHITexturePtr, EImageLayout) {} // one in-order stream: nothing to do
+
+void HipGraphicsDriver::UpdateShaderBinding(RHICommandListPtr cmd, RHIShaderBindingPtr binding, const void* data, size_t size, size_t variableOffset)
+{
+    if (binding->m_type == EShaderBindingType::UniformBuffer) {
+        if (binding->m_hostCopy.size() < variableOffset + size) binding->m_hostCopy.resize(variableOffset + size);
+        memcpy(binding->m_hostCopy.data() + variableOffset, data, size); // copied at record time, like push constants
+        return;
+    }
+    UpdateBuffer(cmd, binding->m_buffer, data, size, variableOffset);
+}
+
+void HipGraphicsDriver::UpdateBuffer(RHICommandListPtr cmd, RHIBufferPtr buffer, const void* data, size_t size, size_t offset)
+{
+    TVector<uint8_t> staged((const uint8_t*)data, (const uint8_t*)data + size); // payload captured at record time
+    SailorHipContext* ctx = m_ctx;
+    cmd->m_hip.m_commands.push_back([ctx, buffer, staged = std::move(staged), offset]() {
+        return sailor_hip_buffer_upload(ctx, buffer->m_hip.m_devicePtr, offset, staged.data(), staged.size());
+    });
+}
+
+void HipGraphicsDriver::Dispatch(RHICommandListPtr cmd, RHIShaderPtr computeShader, uint32_t, uint32_t, uint32_t,
+                                 const TVector<RHIShaderBindingSetPtr>& bindings, const void* pPushConstantsData, uint32_t sizePushConstantsData)
+{
+    TVector<uint8_t> pc((const uint8_t*)pPushConstantsData, (const uint8_t*)pPushConstantsData + sizePushConstantsData); // VulkanCommandBuffer.cpp:679-685
+    const std::string name = computeShader->m_name;
+    // The workgroup grid of the reference dispatch (numTiles.x, numTiles.y, 1) is implied by the push constants; the HIP
+    // kernels choose their own launch geometry.
+    cmd->m_hip.m_commands.push_back([this, name, bindings, pc = std::move(pc)]() {
+        if (name == "Shaders/ComputeLightCulling.shader") return RecordLightCulling(bindings, pc);
+        if (name == "Shaders/Standard.shader") return RecordShade(bindings);
+        if (name == "Shaders/ComputeMeshCulling.shader") return RecordMeshCulling(bindings, pc);
+        return (int)SAILOR_HIP_ERR_UNSUPPORTED;
+    });
+}
+
+static void* buffer_of(const RHIShaderBindingSetPtr& set, const char* name)
+{
+    auto b = set->Find(name);
+    return (b && b->m_buffer) ? b->m_buffer->m_hip.m_devicePtr : nullptr;
+}
+
+int HipGraphicsDriver::RecordLightCulling(const TVector<RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pcBytes)
+{
+    // LightCullingNode.cpp:76: { sceneView.m_rhiLightsData, m_culledLights, sceneView.m_frameBindings }
+    if (bindings.size() != 3 || pcBytes.size() < sizeof(SailorLightCullPushConstants) - 4) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SailorLightCullPushConstants pc {};
+    memcpy(&pc, pcBytes.data(), pcBytes.size() < sizeof pc ? pcBytes.size() : sizeof pc);
+    auto frameB = bindings[2]->Find("frameData");
+    auto depthB = bindings[1]->Find("sceneDepth");
+    auto culledB = bindings[1]->Find("culledLights");
+    if (!frameB || frameB->m_hostCopy.size() < sizeof(SailorUboFrameData) || !depthB || depthB->m_textures.empty() || !culledB) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SailorUboFrameData frame;
+    memcpy(&frame, frameB->m_hostCopy.data(), sizeof frame);
+    SailorBand band;
+    sailor_hip_band_whole_frame(pc.viewportSize[0], pc.viewportSize[1], &band);
+    const size_t need = sailor_hip_light_cull_workspace_size(pc.viewportSize[0], pc.viewportSize[1], pc.lightsNum, &band);
+    if (!m_cullWorkspace || m_cullWorkspace->m_size < need) m_cullWorkspace = CreateBuffer(need);
+    if (!m_cullWorkspace) return SAILOR_HIP_ERR_OUT_OF_MEMORY;
+    return sailor_hip_light_cull(m_ctx, &frame, &pc, (const SailorLightShaderData*)buffer_of(bindings[0], "light"),
+                                 (const float*)depthB->m_textures[0]->m_buffer->m_hip.m_devicePtr,
+                                 (SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (uint32_t*)buffer_of(bindings[1], "culledLights"),
+                                 culledB->m_buffer->m_size / 4, m_cullWorkspace->m_hip.m_devicePtr, m_cullWorkspace->m_size, &band, SAILOR_CULL_DEFAULT);
+}
+
+int HipGraphicsDriver::RecordShade(const TVector<RHIShaderBindingSetPtr>& bindings)
+{
+    // Standard.shader:180-251: set 0 frame, set 1 lights {0 light, 1 culledLights, 2 lightsGrid, 6 lightsMatrices, 8 shadowMaps},
+    // set 2 the surface/radiance buffers that stand in for the rasterised fragments (per-instance / material / textures sets)
+    if (bindings.size() != 3) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    auto frameB = bindings[0]->Find("frameData");
+    auto surfaceB = bindings[2]->Find("surface");
+    auto countB = bindings[1]->Find("light");
+    if (!frameB || frameB->m_hostCopy.size() < sizeof(SailorUboFrameData) || !surfaceB || !surfaceB->m_buffer || !countB) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SailorUboFrameData frame;
+    memcpy(&frame, frameB->m_hostCopy.data(), sizeof frame);
+    const int W = frame.viewportSize[0], H = frame.viewportSize[1];
+    SailorCsmDesc csm {};
+    bool hasCsm = false;
+    auto mats = bindings[1]->Find("lightsMatrices");
+    auto maps = bindings[1]->Find("shadowMaps");
+    if (mats && mats->m_hostCopy.size() >= 256 && maps) {
+        memcpy(csm.lightsMatrices, mats->m_hostCopy.data(), 256);
+        for (size_t k = 0; k < SAILOR_NUM_CSM_CASCADES && k < maps->m_textures.size(); k++) {
+            const auto& t = maps->m_textures[k];
+            if (!t) continue;
+            csm.maps[k] = t->m_buffer->m_hip.m_devicePtr;
+            csm.width[k] = t->m_extent.x; csm.height[k] = t->m_extent.y;
+            csm.format[k] = t->m_format == EFormat::R16_SFLOAT ? SAILOR_SHADOWMAP_R16_SFLOAT
+                          : (t->m_format == EFormat::R32_SFLOAT ? SAILOR_SHADOWMAP_R32_SFLOAT : SAILOR_SHADOWMAP_R32G32B32A32_SFLOAT);
+            hasCsm = true;
+        }
+    }
+    const int32_t lightsNum = (int32_t)(countB->m_buffer->m_size / sizeof(SailorLightShaderData));
+    return sailor_hip_shade(m_ctx, &frame, (const float*)surfaceB->m_buffer->m_hip.m_devicePtr, (size_t)W * H,
+                            (const SailorLightShaderData*)buffer_of(bindings[1], "light"), lightsNum,
+                            (const SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (const uint32_t*)buffer_of(bindings[1], "culledLights"),
+                            hasCsm ? &csm : nullptr, (float*)buffer_of(bindings[2], "radiance"), nullptr);
+}
+
+int HipGraphicsDriver::RecordMeshCulling(const TVector<RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pcBytes)
+{
+    // ComputeMeshCulling.shader:13-18 push constants {numBatches, numInstances, firstInstanceIndex}; set 1 `data`, set 3 frame
+    if (bindings.size() < 2 || pcBytes.size() < 12) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    uint32_t pc[3];
+    memcpy(pc, pcBytes.data(), 12);
+    auto frameB = bindings.back()->Find("frameData");
+    if (!frameB || frameB->m_hostCopy.size() < sizeof(SailorUboFrameData)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SailorUboFrameData frame;
+    memcpy(&frame, frameB->m_hostCopy.data(), sizeof frame);
+    return sailor_hip_mesh_frustum_cull(m_ctx, &frame, (SailorPerInstanceData*)buffer_of(bindings[0], "data"), pc[1], pc[2]);
+}

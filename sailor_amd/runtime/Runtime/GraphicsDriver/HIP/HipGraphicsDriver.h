@@ -1,0 +1,64 @@
+// Runtime/GraphicsDriver/HIP -- the new RHI backend, sibling of Runtime/GraphicsDriver/Vulkan.
+// Like `class VulkanGraphicsDriver : public IGraphicsDriver, public IGraphicsDriverCommands`
+// (GraphicsDriver/Vulkan/VulkanGraphicsDriver.h:22) one object implements both interfaces.  It owns a SailorHipContext and
+// translates recorded Dispatches of the path's shaders into calls of the C-ABI (include/sailor_hip.h):
+//   "Shaders/ComputeLightCulling.shader" -> sailor_hip_light_cull        (binding contract: ComputeLightCulling.shader:20-47)
+//   "Shaders/Standard.shader"            -> sailor_hip_shade             (binding contract: Standard.shader:180-251)
+//   "Shaders/ComputeMeshCulling.shader"  -> sailor_hip_mesh_frustum_cull (binding contract: ComputeMeshCulling.shader:37-58)
+#pragma once
+#include "../../RHI/GraphicsDriver.h"
+
+namespace Sailor::GraphicsDriver::HIP {
+
+class HipGraphicsDriver : public RHI::IGraphicsDriver, public RHI::IGraphicsDriverCommands {
+public:
+    HipGraphicsDriver(int deviceOrdinal, void* stream, bool ownStream);
+    ~HipGraphicsDriver() override;
+    int GetStatus() const { return m_status; }
+    SailorHipContext* GetContext() const { return m_ctx; }
+    int GetLastDispatchStatus() const { return m_lastDispatchStatus; }
+
+    // IGraphicsDriver
+    void WaitIdle() override;
+    RHI::RHICommandListPtr CreateCommandList(bool bIsSecondary = false) override;
+    RHI::RHIBufferPtr CreateBuffer(size_t size) override;
+    RHI::RHIShaderPtr CreateShader(const std::string& assetPath) override;
+    RHI::RHITexturePtr CreateTexture(const void* pData, size_t size, RHI::ivec2 extent, RHI::EFormat format) override;
+    void SubmitCommandList(RHI::RHICommandListPtr commandList) override;
+    RHI::RHIShaderBindingSetPtr CreateShaderBindings() override;
+    RHI::RHIShaderBindingPtr AddSsboToShaderBindings(RHI::RHIShaderBindingSetPtr& set, const std::string& name, size_t elementSize, size_t numElements,
+                                                     uint32_t shaderBinding, bool bBindSsboWithOffset = false) override;
+    RHI::RHIShaderBindingPtr AddBufferToShaderBindings(RHI::RHIShaderBindingSetPtr& set, const std::string& name, size_t size, uint32_t shaderBinding,
+                                                       RHI::EShaderBindingType bufferType) override;
+    RHI::RHIShaderBindingPtr AddSamplerToShaderBindings(RHI::RHIShaderBindingSetPtr& set, const std::string& name, RHI::RHITexturePtr texture,
+                                                        uint32_t shaderBinding) override;
+    RHI::RHIShaderBindingPtr AddSamplerToShaderBindings(RHI::RHIShaderBindingSetPtr& set, const std::string& name,
+                                                        const TVector<RHI::RHITexturePtr>& array, uint32_t shaderBinding) override;
+    RHI::RHIShaderBindingPtr AddShaderBinding(RHI::RHIShaderBindingSetPtr& set, const RHI::RHIShaderBindingPtr& binding, const std::string& name,
+                                              uint32_t shaderBinding) override;
+    // wrap memory owned by someone else (a torch tensor in the tests, an engine heap in the real thing)
+    RHI::RHIBufferPtr WrapBuffer(void* devicePtr, size_t size);
+    RHI::RHITexturePtr WrapTexture(void* devicePtr, RHI::ivec2 extent, RHI::EFormat format);
+
+    // IGraphicsDriverCommands
+    void BeginDebugRegion(RHI::RHICommandListPtr cmdList, const std::string& title) override;
+    void EndDebugRegion(RHI::RHICommandListPtr cmdList) override;
+    void ImageMemoryBarrier(RHI::RHICommandListPtr cmd, RHI::RHITexturePtr image, RHI::EImageLayout newLayout) override;
+    void UpdateShaderBinding(RHI::RHICommandListPtr cmd, RHI::RHIShaderBindingPtr binding, const void* data, size_t size, size_t variableOffset = 0) override;
+    void UpdateBuffer(RHI::RHICommandListPtr cmd, RHI::RHIBufferPtr buffer, const void* data, size_t size, size_t offset = 0) override;
+    void Dispatch(RHI::RHICommandListPtr cmd, RHI::RHIShaderPtr computeShader, uint32_t groupSizeX, uint32_t groupSizeY, uint32_t groupSizeZ,
+                  const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const void* pPushConstantsData = nullptr,
+                  uint32_t sizePushConstantsData = 0) override;
+
+private:
+    int RecordLightCulling(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pc);
+    int RecordShade(const TVector<RHI::RHIShaderBindingSetPtr>& bindings);
+    int RecordMeshCulling(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pc);
+
+    SailorHipContext* m_ctx = nullptr;
+    int m_status = 0;
+    int m_lastDispatchStatus = 0;
+    RHI::RHIBufferPtr m_cullWorkspace;
+};
+
+} // namespace Sailor::GraphicsDriver::HIP

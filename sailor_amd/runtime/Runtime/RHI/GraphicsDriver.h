@@ -1,0 +1,44 @@
+// The two interfaces every FrameGraph node talks to -- the subset the Forward+ path calls.
+// Mirrors Runtime/RHI/GraphicsDriver.h:59-224 (IGraphicsDriver) and :226-346 (IGraphicsDriverCommands): same method names,
+// argument order and meaning; methods the path never calls (swapchain, materials, render passes, ...) are omitted.
+#pragma once
+#include "Types.h"
+
+namespace Sailor::RHI {
+
+class IGraphicsDriver {
+public:
+    virtual ~IGraphicsDriver() = default;
+    virtual void WaitIdle() = 0;                                                                           // :83
+    virtual RHICommandListPtr CreateCommandList(bool bIsSecondary = false) = 0;                            // :88
+    virtual RHIBufferPtr CreateBuffer(size_t size) = 0;                                                    // :89
+    virtual RHIShaderPtr CreateShader(const std::string& assetPath) = 0;                                   // :97 (SPIR-V there, a kernel name here)
+    virtual RHITexturePtr CreateTexture(const void* pData, size_t size, ivec2 extent, EFormat format) = 0; // :98-108
+    virtual void SubmitCommandList(RHICommandListPtr commandList) = 0;                                     // :149
+    virtual RHIShaderBindingSetPtr CreateShaderBindings() = 0;                                             // :152
+    virtual RHIShaderBindingPtr AddSsboToShaderBindings(RHIShaderBindingSetPtr& pShaderBindings, const std::string& name, size_t elementSize,
+                                                        size_t numElements, uint32_t shaderBinding, bool bBindSsboWithOffset = false) = 0; // :154
+    virtual RHIShaderBindingPtr AddBufferToShaderBindings(RHIShaderBindingSetPtr& pShaderBindings, const std::string& name, size_t size,
+                                                          uint32_t shaderBinding, EShaderBindingType bufferType) = 0;                       // :155
+    virtual RHIShaderBindingPtr AddSamplerToShaderBindings(RHIShaderBindingSetPtr& pShaderBindings, const std::string& name, RHITexturePtr texture,
+                                                           uint32_t shaderBinding) = 0;                                                     // :156
+    virtual RHIShaderBindingPtr AddSamplerToShaderBindings(RHIShaderBindingSetPtr& pShaderBindings, const std::string& name,
+                                                           const TVector<RHITexturePtr>& array, uint32_t shaderBinding) = 0;               // :157
+    virtual RHIShaderBindingPtr AddShaderBinding(RHIShaderBindingSetPtr& pShaderBindings, const RHIShaderBindingPtr& binding, const std::string& name,
+                                                 uint32_t shaderBinding) = 0;                                                               // :160
+};
+
+class IGraphicsDriverCommands {
+public:
+    virtual ~IGraphicsDriverCommands() = default;
+    virtual void BeginDebugRegion(RHICommandListPtr cmdList, const std::string& title) = 0; // :238
+    virtual void EndDebugRegion(RHICommandListPtr cmdList) = 0;                              // :239
+    virtual void ImageMemoryBarrier(RHICommandListPtr cmd, RHITexturePtr image, EImageLayout newLayout) = 0; // :290
+    virtual void UpdateShaderBinding(RHICommandListPtr cmd, RHIShaderBindingPtr binding, const void* data, size_t size, size_t variableOffset = 0) = 0; // :303
+    virtual void UpdateBuffer(RHICommandListPtr cmd, RHIBufferPtr buffer, const void* data, size_t size, size_t offset = 0) = 0;                       // :304
+    virtual void Dispatch(RHICommandListPtr cmd, RHIShaderPtr computeShader, uint32_t groupSizeX, uint32_t groupSizeY, uint32_t groupSizeZ,
+                          const TVector<RHIShaderBindingSetPtr>& bindings, const void* pPushConstantsData = nullptr,
+                          uint32_t sizePushConstantsData = 0) = 0;                                                                                       // :310-314
+};
+
+} // namespace Sailor::RHI

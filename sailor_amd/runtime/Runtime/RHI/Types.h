@@ -1,0 +1,137 @@
+// Linux-buildable mirror of the slice of Sailor's RHI that the Forward+ lighting path touches.
+// Mirrors (signatures, names, argument meaning): Runtime/RHI/Types.h:14-30,751-761,781-799 (RHIResource + TRefPtr aliases,
+// UboFrameData), RHI/Buffer.h, RHI/Shader.h, RHI/CommandList.h -- with an `m_hip` member where the reference's classes
+// carry `m_vulkan` (RHI/Shader.h:17-27,71-76, RHI/Buffer.h:15-24, RHI/CommandList.h:15-20).
+#pragma once
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../../../include/sailor_hip.h"
+
+namespace Sailor {
+
+// minimal intrusive pointer (the reference: Memory/RefPtr.hpp, TRefPtr<T> over TRefBase)
+class TRefBase {
+public:
+    virtual ~TRefBase() = default;
+    void AddRef() const { m_refs.fetch_add(1, std::memory_order_relaxed); }
+    void Release() const { if (m_refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this; }
+private:
+    mutable std::atomic<int> m_refs { 0 };
+};
+
+template <typename T>
+class TRefPtr {
+public:
+    TRefPtr() = default;
+    TRefPtr(T* p) : m_p(p) { if (m_p) m_p->AddRef(); }
+    TRefPtr(const TRefPtr& o) : m_p(o.m_p) { if (m_p) m_p->AddRef(); }
+    template <typename U> TRefPtr(const TRefPtr<U>& o) : m_p(o.GetRawPtr()) { if (m_p) m_p->AddRef(); }
+    TRefPtr(TRefPtr&& o) noexcept : m_p(o.m_p) { o.m_p = nullptr; }
+    ~TRefPtr() { if (m_p) m_p->Release(); }
+    TRefPtr& operator=(TRefPtr o) { std::swap(m_p, o.m_p); return *this; }
+    template <typename... A> static TRefPtr Make(A&&... a) { return TRefPtr(new T(std::forward<A>(a)...)); }
+    T* operator->() const { return m_p; }
+    T& operator*() const { return *m_p; }
+    T* GetRawPtr() const { return m_p; }
+    explicit operator bool() const { return m_p != nullptr; }
+    bool IsValid() const { return m_p != nullptr; }
+    void Clear() { if (m_p) m_p->Release(); m_p = nullptr; }
+    template <typename U> TRefPtr<U> DynamicCast() const { return TRefPtr<U>(dynamic_cast<U*>(m_p)); }
+private:
+    T* m_p = nullptr;
+};
+
+template <typename T> using TVector = std::vector<T>;
+
+namespace RHI {
+
+class RHIResource : public TRefBase {};
+using RHIResourcePtr = TRefPtr<RHIResource>;
+
+struct ivec2 { int32_t x = 0, y = 0; };
+
+using UboFrameData = SailorUboFrameData; // RHI/Types.h:751-761
+
+// RHI/Buffer.h: a device allocation.  m_hip.m_devicePtr is either owned (created through IGraphicsDriver) or wrapped.
+class RHIBuffer : public RHIResource {
+public:
+    struct { void* m_devicePtr = nullptr; bool m_bOwned = false; } m_hip;
+    size_t m_size = 0;
+    ~RHIBuffer() override;
+    SailorHipContext* m_ctx = nullptr;
+};
+using RHIBufferPtr = TRefPtr<RHIBuffer>;
+
+enum class EFormat { R32_SFLOAT, R16_SFLOAT, R32G32B32A32_SFLOAT };
+enum class EImageLayout { Undefined, ShaderReadOnlyOptimal, General };
+
+// RHI/Texture.h: here a linear row-major image in device memory (row 0 = top)
+class RHITexture : public RHIResource {
+public:
+    RHIBufferPtr m_buffer;
+    ivec2 m_extent;
+    EFormat m_format = EFormat::R32_SFLOAT;
+    ivec2 GetExtent() const { return m_extent; }
+};
+using RHITexturePtr = TRefPtr<RHITexture>;
+
+enum class EShaderBindingType { UniformBuffer, StorageBuffer, CombinedImageSampler };
+
+// RHI/ShaderBinding.h: one named resource at one binding slot
+class RHIShaderBinding : public RHIResource {
+public:
+    std::string m_name;
+    EShaderBindingType m_type = EShaderBindingType::StorageBuffer;
+    uint32_t m_binding = 0;
+    RHIBufferPtr m_buffer;              // SSBO / UBO storage
+    TVector<RHITexturePtr> m_textures;  // sampler (array)
+    TVector<uint8_t> m_hostCopy;        // UBOs keep the last uploaded bytes: the HIP entry points take them by value
+    size_t GetBufferOffset() const { return 0; }
+};
+using RHIShaderBindingPtr = TRefPtr<RHIShaderBinding>;
+
+class RHIShaderBindingSet : public RHIResource {
+public:
+    RHIShaderBindingPtr GetOrAddShaderBinding(const std::string& name)
+    {
+        auto it = m_bindings.find(name);
+        if (it != m_bindings.end()) return it->second;
+        auto b = RHIShaderBindingPtr::Make();
+        b->m_name = name;
+        m_bindings[name] = b;
+        return b;
+    }
+    RHIShaderBindingPtr Find(const std::string& name) const
+    {
+        auto it = m_bindings.find(name);
+        return it == m_bindings.end() ? RHIShaderBindingPtr() : it->second;
+    }
+    std::map<std::string, RHIShaderBindingPtr> m_bindings;
+};
+using RHIShaderBindingSetPtr = TRefPtr<RHIShaderBindingSet>;
+
+// RHI/Shader.h: identified by the asset path the reference loads it from (e.g. "Shaders/ComputeLightCulling.shader")
+class RHIShader : public RHIResource {
+public:
+    explicit RHIShader(std::string name) : m_name(std::move(name)) {}
+    std::string m_name;
+};
+using RHIShaderPtr = TRefPtr<RHIShader>;
+
+// RHI/CommandList.h: recorded work, executed at SubmitCommandList (record-then-submit, RHI/GraphicsDriver.h:149)
+class RHICommandList : public RHIResource {
+public:
+    struct { TVector<std::function<int()>> m_commands; } m_hip;
+    TVector<std::string> m_debugRegions; // names seen by BeginDebugRegion, for tests
+};
+using RHICommandListPtr = TRefPtr<RHICommandList>;
+
+} // namespace RHI
+} // namespace Sailor

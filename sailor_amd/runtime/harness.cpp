@@ -1,0 +1,160 @@
+// C entry points that let the Python test-suite drive the C++ host mirror exactly the way the engine would:
+// create the renderer (HIP backend), build a frame graph BY NODE NAME, hand it a scene snapshot, process frames, read back.
+#include <memory>
+#include <string>
+#include "Runtime/ECS/LightingECS.h"
+#include "Runtime/FrameGraph/LightCullingNode.h"
+#include "Runtime/FrameGraph/RHIFrameGraph.h"
+#include "Runtime/GraphicsDriver/HIP/HipGraphicsDriver.h"
+#include "Runtime/RHI/Renderer.h"
+
+using namespace Sailor;
+using namespace Sailor::RHI;
+using namespace Sailor::Framegraph;
+
+#define RT_API extern "C" __attribute__((visibility("default")))
+
+struct SailorRuntime {
+    std::unique_ptr<Renderer> renderer;
+    std::unique_ptr<LightingECS> lighting;
+    RHIFrameGraph graph;
+    RHISceneViewSnapshot snapshot;
+    FrameGraphNodePtr lightCulling, renderScene;
+    RHITexturePtr depth;
+    RHIBufferPtr surface, radiance;
+    std::unique_ptr<EcsSweepSystem> sweep;
+    int frames = 0;
+};
+
+RT_API SailorRuntime* sailor_rt_create(int device, void* stream, int ownStream, int* outStatus)
+{
+    auto* rt = new SailorRuntime();
+    rt->renderer.reset(new Renderer(device, stream, ownStream != 0));
+    if (outStatus) *outStatus = rt->renderer->GetStatus();
+    if (rt->renderer->GetStatus() != SAILOR_HIP_OK) { delete rt; return nullptr; }
+    rt->lighting.reset(new LightingECS());
+    return rt;
+}
+
+RT_API void sailor_rt_destroy(SailorRuntime* rt)
+{
+    if (!rt) return;
+    Renderer::GetDriver()->WaitIdle();
+    rt->graph.Clear();
+    rt->sweep.reset();
+    rt->lighting.reset();
+    rt->depth.Clear(); rt->surface.Clear(); rt->radiance.Clear();
+    rt->lightCulling.Clear(); rt->renderScene.Clear();
+    rt->snapshot = RHISceneViewSnapshot();
+    delete rt;
+}
+
+RT_API int sailor_rt_node_registered(const char* name) { return FrameGraphBuilder::IsRegistered(name) ? 1 : 0; }
+
+// builds the graph from node names, as FrameGraphImporter does from the .renderer YAML (FrameGraphParser.cpp:153)
+RT_API int sailor_rt_build_graph(SailorRuntime* rt, const char** nodeNames, int count)
+{
+    for (int i = 0; i < count; i++) {
+        auto node = FrameGraphBuilder::CreateNode(nodeNames[i]);
+        if (!node) return -1;
+        if (std::string(nodeNames[i]) == "LightCulling") rt->lightCulling = node;
+        if (std::string(nodeNames[i]) == "RenderScene") { node->SetString("Tag", "Opaque"); rt->renderScene = node; }
+        rt->graph.AddNode(node);
+    }
+    return 0;
+}
+
+RT_API void sailor_rt_set_camera(SailorRuntime* rt, const float* world16, float fov, float aspect, float zNear, float zFar, int width, int height)
+{
+    memcpy(rt->snapshot.m_camera.m_world, world16, 64);
+    rt->snapshot.m_camera.m_fov = fov; rt->snapshot.m_camera.m_aspect = aspect;
+    rt->snapshot.m_camera.m_zNear = zNear; rt->snapshot.m_camera.m_zFar = zFar;
+    rt->graph.SetViewport(width, height);
+}
+
+// lights: packed LightShaderData records (host memory); goes through UpdateShaderBinding like LightingECS::Tick
+RT_API void sailor_rt_set_lights(SailorRuntime* rt, const void* records, int count)
+{
+    auto cmd = Renderer::GetDriver()->CreateCommandList();
+    rt->lighting->SetPacked(cmd, (const SailorLightShaderData*)records, (size_t)count);
+    Renderer::GetDriver()->SubmitCommandList(cmd);
+    rt->lighting->FillLightingData(rt->snapshot);
+}
+
+// lights as components (degrees, defaults of ECS/LightingECS.h:23-28), packed by LightingECS::Tick
+RT_API int sailor_rt_add_light(SailorRuntime* rt, uint32_t type, uint32_t shadowType, const float* pos, const float* dir, const float* intensity,
+                               const float* bounds, const float* cutOffDegrees)
+{
+    LightData d;
+    d.m_type = (ELightType)type; d.m_shadowType = (EShadowType)shadowType;
+    memcpy(d.m_worldPosition, pos, 12); memcpy(d.m_direction, dir, 12); memcpy(d.m_intensity, intensity, 12); memcpy(d.m_bounds, bounds, 12);
+    if (cutOffDegrees) memcpy(d.m_cutOff, cutOffDegrees, 8);
+    return (int)rt->lighting->RegisterComponent(d);
+}
+
+RT_API void sailor_rt_tick_lights(SailorRuntime* rt)
+{
+    auto cmd = Renderer::GetDriver()->CreateCommandList();
+    rt->lighting->Tick(cmd);
+    Renderer::GetDriver()->SubmitCommandList(cmd);
+    rt->lighting->FillLightingData(rt->snapshot);
+}
+
+// the LinearDepth render target (device memory owned by the caller), wired as the node's "depthStencil" parameter
+RT_API void sailor_rt_set_depth(SailorRuntime* rt, void* devicePtr, int width, int height)
+{
+    auto* hip = static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver());
+    rt->depth = hip->WrapTexture(devicePtr, { width, height }, EFormat::R32_SFLOAT);
+    if (rt->lightCulling) rt->lightCulling->SetRHIResource("depthStencil", rt->depth);
+}
+
+RT_API void sailor_rt_set_surface(SailorRuntime* rt, void* surfaceDevicePtr, void* radianceDevicePtr, int width, int height)
+{
+    auto* hip = static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver());
+    rt->surface = hip->WrapBuffer(surfaceDevicePtr, (size_t)width * height * 48);
+    rt->radiance = hip->WrapBuffer(radianceDevicePtr, (size_t)width * height * 16);
+    if (rt->renderScene) { rt->renderScene->SetRHIResource("surface", rt->surface); rt->renderScene->SetRHIResource("radiance", rt->radiance); }
+}
+
+RT_API void sailor_rt_set_shadow_maps(SailorRuntime* rt, void* const* mapDevicePtrs, const int* sizes, const int* formats, const float* lightsMatrices64)
+{
+    auto* hip = static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver());
+    TVector<RHITexturePtr> maps;
+    for (int k = 0; k < SAILOR_NUM_CSM_CASCADES; k++) {
+        const EFormat f = formats[k] == SAILOR_SHADOWMAP_R16_SFLOAT ? EFormat::R16_SFLOAT : (formats[k] == SAILOR_SHADOWMAP_R32_SFLOAT ? EFormat::R32_SFLOAT : EFormat::R32G32B32A32_SFLOAT);
+        maps.push_back(hip->WrapTexture(mapDevicePtrs[k], { sizes[k], sizes[k] }, f));
+    }
+    rt->lighting->SetShadowMaps(maps, lightsMatrices64);
+}
+
+RT_API int sailor_rt_process_frame(SailorRuntime* rt)
+{
+    rt->graph.Process(rt->snapshot);
+    rt->frames++;
+    return static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver())->GetLastDispatchStatus();
+}
+
+RT_API void sailor_rt_wait_idle(SailorRuntime*) { Renderer::GetDriver()->WaitIdle(); }
+
+// device pointers of the node-owned SSBOs, for read-back by the tests
+RT_API void* sailor_rt_buffer(SailorRuntime* rt, const char* name, size_t* outBytes)
+{
+    auto node = rt->lightCulling.DynamicCast<LightCullingNode>();
+    if (!node || !node->GetCulledLights()) return nullptr;
+    auto b = node->GetCulledLights()->Find(name);
+    if (!b || !b->m_buffer) return nullptr;
+    if (outBytes) *outBytes = b->m_buffer->m_size;
+    return b->m_buffer->m_hip.m_devicePtr;
+}
+
+RT_API int sailor_rt_ecs_sweep(SailorRuntime* rt, const void* transforms, const uint32_t* parent, const void* localAabb, uint32_t count,
+                               const uint32_t* levelOffsets, uint32_t numLevels, void** outWorld, void** outWorldAabb, void** outVisibility)
+{
+    rt->sweep.reset(new EcsSweepSystem((const SailorTransform*)transforms, parent, (const SailorAABB*)localAabb, count, levelOffsets, numLevels));
+    const auto& c = rt->snapshot.m_camera;
+    const int st = rt->sweep->Tick(c.m_world, c.m_aspect, c.m_fov, c.m_zNear, c.m_zFar);
+    *outWorld = rt->sweep->m_world->m_hip.m_devicePtr;
+    *outWorldAabb = rt->sweep->m_worldAabb->m_hip.m_devicePtr;
+    *outVisibility = rt->sweep->m_visibility->m_hip.m_devicePtr;
+    return st;
+}

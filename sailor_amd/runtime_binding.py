@@ -1,0 +1,96 @@
+"""ctypes binding of sailor_amd/runtime/libsailor_runtime.so -- the C++ host mirror (RHI / FrameGraph / GraphicsDriver/HIP / ECS).
+
+The harness drives the path the way the engine does: a Renderer with the HIP backend, a frame graph built from node NAMES
+("LightCulling", "RenderScene"), a scene snapshot, `RHIFrameGraph::Process` per frame.  Used by the tests; device memory is
+torch's."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import _lib
+
+LIB_PATH = Path(__file__).resolve().parent / "runtime" / "libsailor_runtime.so"
+_rt = None
+
+
+def load() -> C.CDLL:
+    global _rt
+    if _rt is None:
+        _lib.load()  # torch's HIP runtime + libsailor_hip.so first
+        if not LIB_PATH.exists():
+            raise _lib.SailorHipError(-2, "runtime", f"{LIB_PATH} is missing: make -C sailor_amd/runtime")
+        rt = C.CDLL(str(LIB_PATH))
+        P = C.c_void_p
+        rt.sailor_rt_create.restype = P
+        rt.sailor_rt_create.argtypes = [C.c_int, P, C.c_int, C.POINTER(C.c_int)]
+        rt.sailor_rt_destroy.argtypes = [P]
+        rt.sailor_rt_node_registered.argtypes = [C.c_char_p]
+        rt.sailor_rt_build_graph.argtypes = [P, C.POINTER(C.c_char_p), C.c_int]
+        rt.sailor_rt_set_camera.argtypes = [P, P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+        rt.sailor_rt_set_lights.argtypes = [P, P, C.c_int]
+        rt.sailor_rt_add_light.argtypes = [P, C.c_uint32, C.c_uint32, P, P, P, P, P]
+        rt.sailor_rt_tick_lights.argtypes = [P]
+        rt.sailor_rt_set_depth.argtypes = [P, P, C.c_int, C.c_int]
+        rt.sailor_rt_set_surface.argtypes = [P, P, P, C.c_int, C.c_int]
+        rt.sailor_rt_set_shadow_maps.argtypes = [P, P, P, P, P]
+        rt.sailor_rt_process_frame.argtypes = [P]
+        rt.sailor_rt_wait_idle.argtypes = [P]
+        rt.sailor_rt_buffer.restype = P
+        rt.sailor_rt_buffer.argtypes = [P, C.c_char_p, C.POINTER(C.c_size_t)]
+        rt.sailor_rt_ecs_sweep.argtypes = [P, P, P, P, C.c_uint32, P, C.c_uint32, C.POINTER(P), C.POINTER(P), C.POINTER(P)]
+        _rt = rt
+    return _rt
+
+
+class Runtime:
+    def __init__(self, device_index: int = 0, stream_handle: int = 0):
+        self.rt = load()
+        st = C.c_int(0)
+        self.h = self.rt.sailor_rt_create(device_index, C.c_void_p(stream_handle), 0, C.byref(st))
+        if not self.h:
+            raise _lib.SailorHipError(st.value, "sailor_rt_create")
+
+    def close(self):
+        if self.h:
+            self.rt.sailor_rt_destroy(self.h)
+            self.h = None
+
+    def build_graph(self, names):
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        if self.rt.sailor_rt_build_graph(self.h, arr, len(names)) != 0:
+            raise ValueError(f"unknown frame graph node in {names}")
+
+    def set_camera(self, cam):
+        w = np.ascontiguousarray(cam.world, np.float32)
+        self.rt.sailor_rt_set_camera(self.h, w.ctypes.data, cam.fov, cam.aspect, cam.z_near, cam.z_far, cam.width, cam.height)
+
+    def set_lights(self, lights: np.ndarray):
+        raw = np.ascontiguousarray(lights).view(np.uint8)
+        self.rt.sailor_rt_set_lights(self.h, raw.ctypes.data, len(lights))
+
+    def set_depth(self, depth_tensor):
+        self.rt.sailor_rt_set_depth(self.h, depth_tensor.data_ptr(), depth_tensor.shape[1], depth_tensor.shape[0])
+
+    def set_surface(self, surface_tensor, radiance_tensor):
+        self.rt.sailor_rt_set_surface(self.h, surface_tensor.data_ptr(), radiance_tensor.data_ptr(), surface_tensor.shape[2], surface_tensor.shape[1])
+
+    def set_shadow_maps(self, map_tensors, formats, lights_matrices):
+        ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in map_tensors])
+        sizes = (C.c_int * 4)(*[t.shape[0] for t in map_tensors])
+        fmts = (C.c_int * 4)(*formats)
+        lm = np.ascontiguousarray(lights_matrices, np.float32).reshape(64)
+        self.rt.sailor_rt_set_shadow_maps(self.h, ptrs, sizes, fmts, lm.ctypes.data)
+
+    def process_frame(self) -> int:
+        return self.rt.sailor_rt_process_frame(self.h)
+
+    def wait_idle(self):
+        self.rt.sailor_rt_wait_idle(self.h)
+
+    def buffer(self, name: str):
+        n = C.c_size_t(0)
+        p = self.rt.sailor_rt_buffer(self.h, name.encode(), C.byref(n))
+        return p, n.value

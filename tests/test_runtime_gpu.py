@@ -1,0 +1,71 @@
+"""The C++ host mirror end to end (GPU): Renderer(HIP backend) + frame graph built from node names + LightingECS upload,
+`RHIFrameGraph::Process` per frame -- the lists in the node-owned `culledLights` / `lightsGrid` SSBOs and the radiance written by
+the RenderScene node must equal the oracle's, i.e. the path really is a drop-in behind BaseFrameGraphNode::Process /
+IGraphicsDriverCommands::Dispatch."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from sailor_amd import _lib, host, synth
+from sailor_amd.runtime_binding import Runtime
+
+pytestmark = pytest.mark.gpu
+
+
+def read_u32(ptr, nbytes):
+    """synchronous device->host copy of a driver-owned buffer through the C-ABI (sailor_hip_buffer_download)"""
+    out = np.empty(nbytes // 4, np.uint32)
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    _lib.check(lib.sailor_hip_context_create(0, None, 0, C.byref(ctx)), "context_create")
+    try:
+        _lib.check(lib.sailor_hip_buffer_download(ctx, out.ctypes.data, ptr, 0, nbytes), "buffer_download", ctx)
+    finally:
+        lib.sailor_hip_context_destroy(ctx)
+    return out
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_csm"])
+def test_frame_graph_nodes_drive_the_hip_path(name):
+    f = synth.make_frame(name)
+    W, H = f.cam.width, f.cam.height
+    rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        rt.build_graph(["LightCulling", "RenderScene"])
+        rt.set_camera(f.cam)
+        rt.set_lights(f.lights)
+        depth = torch.from_numpy(f.depth).cuda()
+        surface = torch.from_numpy(f.surface).cuda()
+        radiance = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        rt.set_depth(depth)
+        rt.set_surface(surface, radiance)
+        keep = None
+        if f.shadows is not None:
+            keep = [torch.from_numpy(np.ascontiguousarray(m)).cuda() for m in f.shadows.maps]
+            fmts = [_lib.SHADOWMAP_RGBA32F if m.ndim == 3 else _lib.SHADOWMAP_R16F for m in f.shadows.maps]
+            rt.set_shadow_maps(keep, fmts, f.shadows.lights_matrices)
+        for _ in range(2):  # second frame reuses the node's lazily created SSBOs
+            assert rt.process_frame() == 0
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth)
+        gp, gbytes = rt.buffer("lightsGrid")
+        cp, cbytes = rt.buffer("culledLights")
+        Tx, Ty = host.num_tiles(W, H)
+        assert gbytes == 4 * (Tx * Ty * 2 + 1) and cbytes == 4 * (Tx * Ty * 128 + 1)   # LightCullingNode.cpp:64-65 (+1)
+        grid = read_u32(gp, Tx * Ty * 8).reshape(-1, 2)
+        culled = read_u32(cp, 4 * (1 + int(oi[0])))
+        np.testing.assert_array_equal(grid, og)
+        np.testing.assert_array_equal(culled, oi[: 1 + int(oi[0])])
+        csm = None
+        if f.shadows is not None:
+            csm, _k = oracle.make_csm(f.shadows.lights_matrices, f.shadows.maps)
+        ref = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, og, oi, csm)
+        got = radiance.cpu().numpy()
+        err = np.abs(got.astype(np.float64) - ref)
+        assert (err <= 1e-4 * np.abs(ref) + 1e-5).all(), err.max()
+    finally:
+        rt.close()
