@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-tile-rows", type=int, default=12)
+    ap.add_argument("--cpu-sample-tile-rows", type=int, default=96)
     ap.add_argument("--exchange-every-step", action="store_true", help="include the RCCL list exchange in the timed region (N > 1)")
     return ap.parse_args()
 
@@ -64,6 +64,21 @@ def event_ms(fn, steps):
     torch.cuda.synchronize()
     t = np.array([a.elapsed_time(b) for a, b in pairs])
     return float(t.mean()), float(np.median(t)), float(np.percentile(t, 10)), float(np.percentile(t, 90))
+
+
+def measured_traffic(kernel: str, config: str, world: int):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01/traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes).
+    bench.py cannot sample PMC counters itself; None when no matching profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("config") == config and world == 1:
+            return t["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(frame, sample_rows: int):
@@ -231,7 +246,7 @@ def main():
     evals = int((g[:, 1].astype(np.int64) * 256).sum())
     shade_gbs = b_shade / (shade_ms[0] * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "k2_shade", "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
-                "traffic": None, "bytes_per_launch": b_shade, "avg_launch_ms": shade_ms[0], "median_launch_ms": shade_ms[1],
+                "traffic": measured_traffic("k2_shade<false>" if csm is None else "k2_shade<true>", args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_ms[0], "median_launch_ms": shade_ms[1],
                 "frac_of_measured_copy_peak": shade_gbs / HBM_COPY_GBS,
                 "valu_sidebar": {"pixel_light_evals": evals, "gevals_per_s": evals / (shade_ms[0] * 1e-3) / 1e9,
                                  "note": "~110 fp32 ops per (pixel,light): VALU-bound once mean list length exceeds ~10 (SURVEY.md 7, hard part 2)"},
