@@ -51,6 +51,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tile-rows", type=int, default=96)
     ap.add_argument("--exchange-every-step", action="store_true", help="include the RCCL list exchange in the timed region (N > 1)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
+    ap.add_argument("--equal-bands", action="store_true", help="N > 1: equal tile-row bands instead of cost-balanced ones")
+    ap.add_argument("--simulate-split", type=int, default=0, help="G: time each band of a cost-balanced G-way split one after the other on this GPU and print the predicted speed-up; diagnostic")
+    ap.add_argument("--simulate-band", default=None, help="R/G: time only band R of a G-way split in this single process (no collectives); diagnostic")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the list exchange even with one rank")
     return ap.parse_args()
 
 
@@ -148,6 +153,46 @@ def ecs_baseline(ctx, count: int, steps: int):
             "cpu_allcores_mentities_per_s": count / tn / 1e6, "cpu_cores": cores, "cpu_model": _cpu_model(), "kind": "port"}
 
 
+def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev):
+    """Single-GPU estimate of the G-way split: per-band step time (hipGraph replay), equal vs cost-balanced bands."""
+    from sailor_amd import dist as sdist
+    cam, W, H, N, G = frame.cam, frame.cam.width, frame.cam.height, len(frame.lights), args.simulate_split
+    Tx, Ty = host.num_tiles(W, H)
+    fp_full.cull(cam.frame, d_lights, N, d_depth_full)
+    g, _ = fp_full.lists_to_host()
+    row_entries = g[:, 1].astype(np.int64).reshape(Ty, Tx).sum(1)
+    out = {"config": args.config, "split": G}
+
+    def time_band(b):
+        f = ForwardPlus(ctx, W, H, N, band=b)
+        dd = torch.from_numpy(np.ascontiguousarray(frame.depth[b.fbRowBegin:b.fbRowBegin + b.fbRowCount])).to(dev)
+        ds = torch.from_numpy(frame.surface_rows(b.fbRowBegin, b.fbRowBegin + b.fbRowCount)).to(dev)
+
+        def step():
+            f.cull(cam.frame, d_lights, N, dd)
+            f.shade(cam.frame, ds, d_lights, N, None)
+        step(); torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=torch.cuda.current_stream()):
+            step()
+        for _ in range(args.warmup):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps * 1e3
+
+    whole = time_band(host.band_whole_frame(W, H))
+    for name, bounds in (("equal", [host.band_for_rank(W, H, r, G).tileRowBegin for r in range(G)] + [Ty]),
+                         ("balanced", sdist.balanced_tile_rows(row_entries, Tx, G))):
+        ms = [time_band(host.band_from_tile_rows(W, H, bounds[r], bounds[r + 1])) for r in range(G)]
+        out[name] = {"bounds": [int(b) for b in bounds], "band_ms": ms, "max_ms": max(ms), "predicted_speedup": whole / max(ms)}
+    out["whole_frame_ms"] = whole
+    print(json.dumps(out), flush=True)
+
+
 class BenchFrame:
     """Synthetic frame with lazily generated surface rows (the full 4K surface is 531 MB; ranks only make their band)."""
 
@@ -176,26 +221,60 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     frame = BenchFrame(args.config)
     cam, W, H = frame.cam, frame.cam.width, frame.cam.height
     N = len(frame.lights)
-    band = host.band_for_rank(W, H, rank, world)
-    rows = slice(band.fbRowBegin, band.fbRowBegin + band.fbRowCount)
-    ctx = HipContext(dev)
-    fp = ForwardPlus(ctx, W, H, N, band=band)
-    d_depth = torch.from_numpy(np.ascontiguousarray(frame.depth[rows])).to(dev)
+    # everything runs on one side stream: the C-ABI records on it, torch events time it, and a hipGraph can capture it
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(side)
+    ctx = HipContext(dev, stream=side)
     d_lights = upload_lights(frame.lights, dev)
+    Tx, Ty = host.num_tiles(W, H)
+
+    def resident(b):
+        """ForwardPlus for band b with the band's depth rows resident"""
+        f = ForwardPlus(ctx, W, H, N, band=b)
+        dd = torch.from_numpy(np.ascontiguousarray(frame.depth[b.fbRowBegin:b.fbRowBegin + b.fbRowCount])).to(dev)
+        return f, dd
+
+    band = host.band_for_rank(W, H, rank, world)
+    partition = "whole frame"
+    if world > 1 and not args.equal_bands:
+        # Cost-balanced bands (sailor_amd/dist.py:balanced_tile_rows): one calibration cull on equal bands, all ranks learn
+        # every tile row's list volume (a renderer would use the previous frame's), and re-split.  Not in the timed region.
+        from sailor_amd import dist as sdist
+        f0, d0 = resident(band)
+        f0.cull(cam.frame, d_lights, N, d0)
+        torch.cuda.synchronize()
+        rows_entries = sdist.gather_row_entries(f0.grid[: f0.band_tiles * 2], Tx, band.tileRowEnd - band.tileRowBegin, Ty, band.tileRowBegin)
+        bounds = sdist.balanced_tile_rows(rows_entries, Tx, world)
+        band = host.band_from_tile_rows(W, H, bounds[rank], bounds[rank + 1])
+        partition = f"cost-balanced tile rows {bounds}"
+        del f0, d0
+    elif world > 1:
+        partition = "equal tile rows"
+    if args.simulate_band:
+        r_, g_ = (int(v) for v in args.simulate_band.split("/"))
+        band = host.band_for_rank(W, H, r_, g_)
+    rows = slice(band.fbRowBegin, band.fbRowBegin + band.fbRowCount)
+    fp, d_depth = resident(band)
     d_surface = torch.from_numpy(frame.surface_rows(rows.start, rows.stop)).to(dev)
     csm = keep = None
     if frame.cfg.get("shadow_size"):
         from sailor_amd.forward_plus import upload_shadow_maps
         shadows = synth.make_shadow_set(cam, frame.cfg["shadow_size"])
         csm, keep = upload_shadow_maps(shadows, dev)
+
+    if args.simulate_split:
+        simulate_split(args, ctx, frame, d_lights, fp, d_depth, dev)
+        return
 
     def cull():
         fp.cull(cam.frame, d_lights, N, d_depth)
@@ -218,12 +297,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # One frame = 8 short kernels: at N = 8 a band's kernels last ~50 us in total, less than eight eager launches cost
+    # on the host.  Capture the step once and replay it (launch-bound inner loop -> hipGraph).
+    graph = None
+    if not args.no_graph and not args.exchange_every_step:
+        try:
+            step(); torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                step()
+        except Exception as e:  # capture unsupported: stay eager, say so in the JSON line
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def run_step():
+        if graph is not None:
+            graph.replay()
+        else:
+            step()
+
     for _ in range(args.warmup):
-        step()
+        run_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run_step()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -254,7 +353,7 @@ def main():
                          "achieved_gbs": b_cull / (cull_ms[0] * 1e-3) / 1e9, "frac": b_cull / (cull_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
     exchange_info = None
-    if world > 1:
+    if dist is not None:
         gg, gi = exchange()
         torch.cuda.synchronize()
         tot = int(gi[0].item())
@@ -264,10 +363,10 @@ def main():
         out = {
             "metric": "lit Mpixels/s (K0+K1 tile light cull + K2 PBR shade over per-tile lists)", "value": value, "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "launch": "hipGraph replay" if graph is not None else "eager", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H}, {N} point+spot lights, 16x16 tiles ({fp.Tx}x{fp.Ty}), cull + PBR shade"
                                    + (" + 4-cascade CSM" if csm is not None else ""),
-                       "width": W, "height": H, "lights": N, "parallelism": f"tile-row bands x{world}",
+                       "width": W, "height": H, "lights": N, "parallelism": f"tile-row bands x{world}", "partition": partition,
                        "mean_list_length": sum_nt / max(fp.band_tiles, 1), "sum_num_rank0_band": sum_nt, "distinct_lights_rank0_band": distinct,
                        "generator": {"seed": synth.SEED, "radius_scale": frame.cfg["lights"].radius_scale}},
             "mlights_culled_per_s": N / (cull_ms[1] * 1e-3) / 1e6,

@@ -181,6 +181,8 @@ SAILOR_HIP_API int sailor_hip_buffer_fill_u32(SailorHipContext* ctx, void* dstDe
 /* ---- bands ---------------------------------------------------------------------------------------------- */
 SAILOR_HIP_API int sailor_hip_num_tiles(int32_t width, int32_t height, int32_t* outTilesX, int32_t* outTilesY); /* LightCullingNode.cpp:56-57 */
 SAILOR_HIP_API int sailor_hip_band_whole_frame(int32_t width, int32_t height, SailorBand* outBand);
+/* an arbitrary contiguous run of tile rows [tileRowBegin, tileRowEnd) -- for cost-balanced partitions */
+SAILOR_HIP_API int sailor_hip_band_from_tile_rows(int32_t width, int32_t height, int32_t tileRowBegin, int32_t tileRowEnd, SailorBand* outBand);
 /* contiguous tile-row bands: rank g of G gets rows [floor(g*Ty/G), floor((g+1)*Ty/G)) */
 SAILOR_HIP_API int sailor_hip_band_for_rank(int32_t width, int32_t height, int32_t rank, int32_t worldSize, SailorBand* outBand);
 

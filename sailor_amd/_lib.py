@@ -87,6 +87,7 @@ SIGNATURES = {
     "sailor_hip_buffer_fill_u32": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.c_size_t]),
     "sailor_hip_num_tiles": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sailor_hip_band_whole_frame": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(Band)]),
+    "sailor_hip_band_from_tile_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band)]),
     "sailor_hip_band_for_rank": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band)]),
     "sailor_hip_light_cull_workspace_size": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band)]),
     "sailor_hip_light_cull": (C.c_int, [_P, C.POINTER(UboFrameData), C.POINTER(LightCullPushConstants), _P, _P, _P, _P, C.c_size_t,

@@ -165,6 +165,15 @@ int sailor_hip_band_whole_frame(int32_t width, int32_t height, SailorBand* outBa
     return SAILOR_HIP_OK;
 }
 
+int sailor_hip_band_from_tile_rows(int32_t width, int32_t height, int32_t tileRowBegin, int32_t tileRowEnd, SailorBand* outBand)
+{
+    int32_t tx, ty;
+    if (!outBand || sailor_hip_num_tiles(width, height, &tx, &ty) != SAILOR_HIP_OK) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (tileRowBegin < 0 || tileRowEnd > ty || tileRowBegin > tileRowEnd) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    band_from_rows(height, tileRowBegin, tileRowEnd, outBand);
+    return SAILOR_HIP_OK;
+}
+
 int sailor_hip_band_for_rank(int32_t width, int32_t height, int32_t rank, int32_t worldSize, SailorBand* outBand)
 {
     int32_t tx, ty;

@@ -55,6 +55,12 @@ def band_whole_frame(width: int, height: int) -> Band:
     return b
 
 
+def band_from_tile_rows(width: int, height: int, row_begin: int, row_end: int) -> Band:
+    b = Band()
+    _lib.check(_lib.load().sailor_hip_band_from_tile_rows(width, height, row_begin, row_end, C.byref(b)), "band_from_tile_rows")
+    return b
+
+
 def band_for_rank(width: int, height: int, rank: int, world_size: int) -> Band:
     b = Band()
     _lib.check(_lib.load().sailor_hip_band_for_rank(width, height, rank, world_size, C.byref(b)), "band_for_rank")

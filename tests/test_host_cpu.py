@@ -203,3 +203,23 @@ def test_cpp_runtime_registers_the_reference_node_names_and_refuses_to_run_witho
     if not torch.cuda.is_available():
         with pytest.raises(_lib.SailorHipError):
             runtime_binding.Runtime(0, 0)
+
+
+def test_cost_balanced_tile_rows():
+    """sailor_amd/dist.py:balanced_tile_rows -- contiguous, covering, monotone, and balanced to within one row's cost."""
+    from sailor_amd import dist as sdist
+    rng = np.random.default_rng(3)
+    rows = np.concatenate([rng.integers(500, 2000, 30), rng.integers(8000, 20000, 60), rng.integers(500, 3000, 45)])
+    for world in (1, 2, 3, 8):
+        b = sdist.balanced_tile_rows(rows, 240, world)
+        assert b[0] == 0 and b[-1] == len(rows) and len(b) == world + 1 and all(x <= y for x, y in zip(b, b[1:]))
+        cost = 240 * sdist.TILE_COST + rows * sdist.ENTRY_COST
+        per = [cost[b[i]:b[i + 1]].sum() for i in range(world)]
+        assert max(per) - min(per) <= 2 * cost.max()
+    assert sdist.balanced_tile_rows(np.zeros(135), 240, 8) == [0, 17, 34, 51, 67, 84, 101, 118, 135]  # uniform cost -> equal rows
+    b = sdist.balanced_tile_rows(np.ones(3), 2, 8)                                                  # more ranks than rows: empty bands allowed
+    assert b[0] == 0 and b[-1] == 3 and all(x <= y for x, y in zip(b, b[1:]))
+    band = host.band_from_tile_rows(3840, 2160, 17, 34)
+    assert (band.tileRowBegin, band.tileRowEnd, band.fbRowBegin, band.fbRowCount) == (17, 34, 2160 - 16 * 34, 16 * 17)
+    with pytest.raises(_lib.SailorHipError):
+        host.band_from_tile_rows(3840, 2160, 100, 136)
