@@ -486,23 +486,33 @@ __global__ __launch_bounds__(1024) void k1_tile_cull(const float4* __restrict__ 
         for (uint32_t i = lane; i < num; i += 64) out[i] = sIdx[n - 1 - i];
     } else {
         // :198-225 partial bubble sort == rank under (impact ascending, candidate position descending); keep rank < 128
-        // each lane ranks up to 4 candidates (k = lane + 64 i) against all n, 4 impacts per LDS read
+        // each lane ranks up to 4 candidates (k = lane + 64 i) against all n, 4 impacts per LDS read.  Candidates q of
+        // an earlier 64-block all have q < k (count g < f), of a later block all have q > k (count g <= f); only the
+        // lane's own block needs the position tie-break.  Slots past n are padded with +inf and never counted.
+        if (lane < 4 && (n & ~3u) + lane >= n && (n & ~3u) + lane < (uint32_t)CAND) sImp[(n & ~3u) + lane] = __builtin_inff();
+        WAVE_SYNC();
         float f[4];
         uint32_t rank[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const uint32_t k = lane + 64u * i; f[i] = (k < n) ? sImp[k] : 0.0f; }
+        for (int i = 0; i < 4; i++) { const uint32_t k = lane + 64u * i; f[i] = (k < n) ? sImp[k] : -1.0f; }
         const float4* sImp4 = reinterpret_cast<const float4*>(sImp);
-        for (uint32_t q4 = 0; q4 < (n + 3u) / 4u; q4++) {
-            const float4 gv = sImp4[q4];
-            const float g[4] = { gv.x, gv.y, gv.z, gv.w };
+        const uint32_t n4 = (n + 3u) / 4u;
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const uint32_t q = q4 * 4u + e;
-                if (q < n) {
+        for (int jb = 0; jb < 4; jb++) {
+            const uint32_t qEnd = min(n4, (uint32_t)(jb + 1) * 16u);
+            for (uint32_t q4 = (uint32_t)jb * 16u; q4 < qEnd; q4++) {
+                const float4 gv = sImp4[q4];
+                const float g[4] = { gv.x, gv.y, gv.z, gv.w };
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const uint32_t k = lane + 64u * i;
-                        rank[i] += (g[e] < f[i] || (g[e] == f[i] && q > k)) ? 1u : 0u;
+                        if (jb < i) rank[i] += (g[e] < f[i]) ? 1u : 0u;
+                        else if (jb > i) rank[i] += (g[e] <= f[i]) ? 1u : 0u;
+                        else {
+                            const uint32_t q = q4 * 4u + e, k = lane + 64u * i;
+                            rank[i] += (g[e] < f[i] || (g[e] == f[i] && q > k)) ? 1u : 0u;
+                        }
                     }
                 }
             }
