@@ -146,11 +146,25 @@ def ecs_baseline(ctx, count: int, steps: int):
             chunks = [(b, min(b + 1024, hi)) for b in range(lo, hi, 1024)]
             list(pool.map(lambda c: oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes, c[0], c[1], world, aabb, vis), chunks))
     tn = time.perf_counter() - t0
+    # the cull loop alone, scalar (Math/Bounds.cpp:245-260) and the reference's SSE batch form (:264-325, restated literally --
+    # including its layout bug -- purely as a cost proxy): 16-byte aligned input, n % 4 == 0
+    import ctypes as C
+    L = oracle.lib()
+    n4 = count & ~3
+    boxes = np.zeros(n4 * 6 + 4, np.float32)
+    off = (-boxes.ctypes.data % 16) // 4
+    al = boxes[off:off + n4 * 6]
+    al[:] = aabb[:n4].reshape(-1)
+    res = np.zeros(n4, np.int32)
+    pl = np.ascontiguousarray(planes, np.float32).reshape(24)
+    t0 = time.perf_counter()
+    L.oracle_overlaps_aabb_sse(pl.ctypes.data_as(C.c_void_p), al.ctypes.data_as(C.c_void_p), C.c_uint32(n4), res.ctypes.data_as(C.c_void_p))
+    t_sse = time.perf_counter() - t0
     bytes_per_entity = 164.125
     return {"entities": count, "gpu_ms": med, "gpu_mentities_per_s": count / med / 1e3, "gpu_hbm_gbs": count * bytes_per_entity / med / 1e6,
             "gpu_hbm_frac": count * bytes_per_entity / med / 1e6 / HBM_PEAK_GBS,
             "cpu_1thread_mentities_per_s": count / t1 / 1e6, "cpu_ns_per_entity_1thread": t1 / count * 1e9,
-            "cpu_allcores_mentities_per_s": count / tn / 1e6, "cpu_cores": cores, "cpu_model": _cpu_model(), "kind": "port"}
+            "cpu_allcores_mentities_per_s": count / tn / 1e6, "cpu_sse_cull_only_mboxes_per_s_1thread": n4 / t_sse / 1e6, "cpu_cores": cores, "cpu_model": _cpu_model(), "kind": "port"}
 
 
 def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev):
