@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tile-rows", type=int, default=96)
     ap.add_argument("--exchange-every-step", action="store_true", help="include the RCCL list exchange in the timed region (N > 1)")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
+                    help="2 (the reference's MaxFramesInQueue, RHI/Renderer.h:34): frame k+1's cull is recorded on a second stream beside frame k's shade")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--equal-bands", action="store_true", help="N > 1: equal tile-row bands instead of cost-balanced ones")
     ap.add_argument("--simulate-split", type=int, default=0, help="G: time each band of a cost-balanced G-way split one after the other on this GPU and print the predicted speed-up; diagnostic")
@@ -313,8 +315,38 @@ def main():
 
     # One frame = 8 short kernels: at N = 8 a band's kernels last ~50 us in total, less than eight eager launches cost
     # on the host.  Capture the step once and replay it (launch-bound inner loop -> hipGraph).
+    # Frames in flight = 2 (the reference keeps MaxFramesInQueue = 2, RHI/Renderer.h:34): a step then shades frame k from
+    # one set of list buffers while frame k+1's cull -- a chain of short, latency-bound kernels -- fills the other set on
+    # a second stream.  Every step still performs exactly one cull and one shade of a frame.
+    pipelined = args.frames_in_flight == 2 and not args.no_graph and not args.exchange_every_step
+    graphs = []
+    if pipelined:
+        try:
+            side2 = torch.cuda.Stream(device=dev)
+            ctx2 = HipContext(dev, stream=side2)
+            fp2, _dd = resident(band)   # second set of grid / culledLights / workspace
+            fps = (fp, fp2)
+            for f in fps:               # eager warm-up of both sets (also sizes every internal buffer before capture)
+                f.cull(cam.frame, d_lights, N, d_depth)
+                f.shade(cam.frame, d_surface, d_lights, N, csm)
+            torch.cuda.synchronize()
+            for p in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    side2.wait_stream(side)                                  # fork
+                    with torch.cuda.stream(side2):
+                        fps[1 - p].cull(cam.frame, d_lights, N, d_depth, ctx=ctx2)   # frame k+1 -> the other buffer set
+                    fps[p].shade(cam.frame, d_surface, d_lights, N, csm)             # frame k
+                    side.wait_stream(side2)                                  # join
+                graphs.append(g)
+            fps[0].cull(cam.frame, d_lights, N, d_depth)                     # prologue: frame 0's lists
+            torch.cuda.synchronize()
+        except Exception as e:
+            print(f"[bench] two-frames-in-flight capture failed ({type(e).__name__}: {e}); falling back to one frame in flight", file=sys.stderr)
+            graphs, pipelined = [], False
+            torch.cuda.synchronize()
     graph = None
-    if not args.no_graph and not args.exchange_every_step:
+    if not pipelined and not args.no_graph and not args.exchange_every_step:
         try:
             step(); torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
@@ -325,8 +357,13 @@ def main():
             graph = None
             torch.cuda.synchronize()
 
+    step_counter = [0]
+
     def run_step():
-        if graph is not None:
+        if pipelined:
+            graphs[step_counter[0] & 1].replay()
+            step_counter[0] += 1
+        elif graph is not None:
             graph.replay()
         else:
             step()
@@ -377,7 +414,7 @@ def main():
         out = {
             "metric": "lit Mpixels/s (K0+K1 tile light cull + K2 PBR shade over per-tile lists)", "value": value, "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "launch": "hipGraph replay" if graph is not None else "eager", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "launch": "hipGraph replay, 2 frames in flight" if pipelined else ("hipGraph replay" if graph is not None else "eager"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H}, {N} point+spot lights, 16x16 tiles ({fp.Tx}x{fp.Ty}), cull + PBR shade"
                                    + (" + 4-cascade CSM" if csm is not None else ""),
                        "width": W, "height": H, "lights": N, "parallelism": f"tile-row bands x{world}", "partition": partition,

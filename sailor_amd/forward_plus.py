@@ -73,15 +73,18 @@ class ForwardPlus:
         self.radiance = None
 
     # -- K0 + K1 --------------------------------------------------------------------------------------------------
-    def cull(self, frame: UboFrameData, lights: torch.Tensor, lights_num: int, depth: torch.Tensor, flags: int = _lib.CULL_DEFAULT):
-        """lights: uint8/any tensor holding lights_num 112-byte records; depth: float32 [band rows, W]."""
+    def cull(self, frame: UboFrameData, lights: torch.Tensor, lights_num: int, depth: torch.Tensor, flags: int = _lib.CULL_DEFAULT,
+             ctx: "HipContext | None" = None):
+        """lights: uint8/any tensor holding lights_num 112-byte records; depth: float32 [band rows, W].
+        ctx: record on another context's stream (frames in flight: next frame's cull beside this frame's shade)."""
         assert depth.dtype == torch.float32 and depth.is_contiguous() and depth.shape == (self.band.fbRowCount, self.W), depth.shape
         assert lights_num <= self.max_lights
         pc = host.push_constants(frame, self.W, self.H, lights_num)
-        lib = self.ctx._lib
-        _lib.check(lib.sailor_hip_light_cull(self.ctx.handle, C.byref(frame), C.byref(pc), _ptr(lights), _ptr(depth), _ptr(self.grid), _ptr(self.culled),
+        ctx = ctx or self.ctx
+        lib = ctx._lib
+        _lib.check(lib.sailor_hip_light_cull(ctx.handle, C.byref(frame), C.byref(pc), _ptr(lights), _ptr(depth), _ptr(self.grid), _ptr(self.culled),
                                              self.culled.numel(), _ptr(self.workspace), self.workspace.numel(), C.byref(self.band), flags),
-                   "sailor_hip_light_cull", self.ctx.handle)
+                   "sailor_hip_light_cull", ctx.handle)
         return self.grid, self.culled
 
     # -- K2 + K3 --------------------------------------------------------------------------------------------------
