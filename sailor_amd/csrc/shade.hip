@@ -203,21 +203,51 @@ __device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsq
 
 #define LREC 5 // float4 per staged light
 
+// Order-preserving float <-> int32 map (an involution), so that the wave-wide bounding box can be reduced with
+// v_min_i32 / v_max_i32 DPP steps: one instruction per step and value, no NaN canonicalisation, no LDS round trips.
+__device__ __forceinline__ int f2key(float f) { const int b = __float_as_int(f); return b ^ ((b >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float key2f(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+
+#define DPP6_STEP(ctrl)                                                                                               \
+    asm volatile("v_min_i32_dpp %0, %0, %0 " ctrl "\n\tv_min_i32_dpp %1, %1, %1 " ctrl "\n\tv_min_i32_dpp %2, %2, %2 " ctrl \
+                 "\n\tv_max_i32_dpp %3, %3, %3 " ctrl "\n\tv_max_i32_dpp %4, %4, %4 " ctrl "\n\tv_max_i32_dpp %5, %5, %5 " ctrl \
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f))
+
+// min of a, b, c and max of d, e, f over the 64 lanes; every lane of row 3 (lanes 48..63) ends up with the result.
+// (xor-1, xor-2, mirror within 8, mirror within 16, then the gfx9 row broadcasts 15 -> row+1 and 31 -> rows 2,3.)
+__device__ __forceinline__ void wave_minmax6(int& a, int& b, int& c, int& d, int& e, int& f)
+{
+    asm volatile("s_nop 1" ::: "memory"); // a DPP read of a VGPR needs 2 wait states after the VALU write
+    DPP6_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    DPP6_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    DPP6_STEP("row_half_mirror row_mask:0xf bank_mask:0xf");
+    DPP6_STEP("row_mirror row_mask:0xf bank_mask:0xf");
+    DPP6_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    DPP6_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+    asm volatile("s_nop 1" ::: "memory");
+}
+
 // Staged light record (LDS, 5 float4):
-//   rec0 = (worldPosition.xyz, bits: type | shadowType << 8 | finite << 16)
-//   rec1 = (normalize(-direction).xyz, A)  A = point: r^2 (1 + 1e-5) "out of reach" threshold (+inf = never reject)
-//                                              spot : cutOff.y - 1e-5  (conservative cone threshold)
-//   rec2 = (attenuation.xyz, B)            B = point: bounds.x          spot: epsilon = cutOff.x - cutOff.y (:297)
+//   rec0 = (worldPosition.xyz, A)   the conservative reach test of both types is  !(v < A):
+//                                     point: v = -d^2,  A = -r^2 (1 + 1e-5)   (out of reach => exact-zero radius window)
+//                                     spot : v ~ theta, A = cutOff.y - 1e-5   (outside the cone => falloff exactly 0)
+//                                     A = -inf: never reject
+//   rec1 = (normalize(-direction).xyz, bits: type | shadowType << 8 | finite << 16)
+//   rec2 = (attenuation.xyz, B)     B = point: bounds.x          spot: epsilon = cutOff.x - cutOff.y (:297)
 //   rec3 = (Li = -direction.xyz, cutOff.y)
 //   rec4 = (intensity.xyz, -)
-// Stage A of the light loop touches rec0/rec1 only, and both are prefetched one light ahead.
+//
+// The kernel is VALU-bound (rocprofv3: SQ_INSTS_VALU x 4 cycles on 1024 SIMDs == the kernel's duration), so the shape
+// below is about vector instructions per (wave, light) step: light type, finiteness and "survived the box test" are
+// wave-uniform 64-bit masks (scalar registers, scalar branches), the reach test feeds s_cbranch_vccz directly, and most
+// steps end after ~10 vector instructions.
 template <bool HAS_CSM>
 __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const float4* __restrict__ surface, size_t planeStride,
                                                  const SailorLightShaderData* __restrict__ lights,
                                                  const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled,
                                                  float4* __restrict__ radiance)
 {
-    __shared__ float4 sL[(KEEP + 1) * LREC];
+    __shared__ float4 sL[KEEP * LREC];
     __shared__ uint32_t sNum;
 
     const int bandTile = blockIdx.x;
@@ -260,19 +290,18 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
             // Conservative "out of reach" threshold of a point light: d^2 > r^2 (1 + 1e-5) => fl(dist / r) >= 1 => the radius
             // window (:290) is exactly 0.  Only for r > 0 (a negative radius clamps to the FULL window in the reference).
             const float r = q6.x;
-            float a = __builtin_inff(), b = r;
-            if (type == 1u) { if (finite && r > 0.0f) a = (r * r) * 1.00001f; }
-            else { a = finite ? q5.y - 1e-5f : -__builtin_inff(); b = q5.x - q5.y; }
+            float a = -__builtin_inff(), b = r;
+            if (type == 1u) { if (finite && r > 0.0f) a = -((r * r) * 1.00001f); }
+            else { if (finite) a = q5.y - 1e-5f; b = q5.x - q5.y; }
             const uint32_t bits = (type < 255u ? type : 255u) | ((shadowType < 255u ? shadowType : 255u) << 8) | (finite ? 0x10000u : 0u);
             float4* o = sL + threadIdx.x * LREC;
-            o[0] = make_float4(q1.x, q1.y, q1.z, __uint_as_float(bits));
-            o[1] = make_float4(ndx * linv, ndy * linv, ndz * linv, a);
+            o[0] = make_float4(q1.x, q1.y, q1.z, a);
+            o[1] = make_float4(ndx * linv, ndy * linv, ndz * linv, __uint_as_float(bits));
             o[2] = make_float4(q4.x, q4.y, q4.z, b);
             o[3] = make_float4(ndx, ndy, ndz, q5.y);
             o[4] = make_float4(q3.x, q3.y, q3.z, 0.0f);
         }
     }
-    if (threadIdx.x < LREC) sL[KEEP * LREC + threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // prefetch target past the last light
     __syncthreads();
     const uint32_t numLights = sNum;
 
@@ -288,6 +317,7 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
     const float F0x = fmaf(P2.x, metallic, 0.04f * oneMinusMetal);
     const float F0y = fmaf(P2.y, metallic, 0.04f * oneMinusMetal);
     const float F0z = fmaf(P2.z, metallic, 0.04f * oneMinusMetal);
+    const float kdAx = oneMinusMetal * P2.x, kdAy = oneMinusMetal * P2.y, kdAz = oneMinusMetal * P2.z; // kd = (1 - F)(1 - metallic)
     const float alpha = roughness * roughness, alphaSq = alpha * alpha;
     const float rr = roughness + 1.0f, k = (rr * rr) * 0.125f, oneMinusK = 1.0f - k;
     const float g1Lo = cosLo * rcp_fast(fmaf(cosLo, oneMinusK, k)); // GeometrySchlickG1(cosLo, k)
@@ -296,114 +326,114 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
     // ---- which lights can reach this quadrant at all?  One LANE per LIGHT: sphere (centre, r sqrt(1 + 1e-4)) against the
     // world-space bounding box of the quadrant's 64 surface points.  Two ballots cover the whole <= 128-entry list, and
     // the per-pixel loop below then visits only the surviving lights.  (Conservative: a point light whose sphere misses
-    // the box has d^2 > r^2 (1 + 1e-5) for every pixel, i.e. an exact-zero radius window -- see rec1.w.)
-    float bminx = active ? wx : __builtin_inff(), bminy = active ? wy : __builtin_inff(), bminz = active ? wz : __builtin_inff();
-    float bmaxx = active ? wx : -__builtin_inff(), bmaxy = active ? wy : -__builtin_inff(), bmaxz = active ? wz : -__builtin_inff();
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        bminx = fminf(bminx, __shfl_xor(bminx, d)); bminy = fminf(bminy, __shfl_xor(bminy, d)); bminz = fminf(bminz, __shfl_xor(bminz, d));
-        bmaxx = fmaxf(bmaxx, __shfl_xor(bmaxx, d)); bmaxy = fmaxf(bmaxy, __shfl_xor(bmaxy, d)); bmaxz = fmaxf(bmaxz, __shfl_xor(bmaxz, d));
-    }
-    const bool anyNonFinitePixel = __ballot(active && !brdfFinite) != 0ull; // such pixels must see every light (0 * NaN)
-    unsigned long long survivors[2];
+    // the box has d^2 > r^2 (1 + 1e-5) for every pixel, i.e. an exact-zero radius window -- see rec0.w.)
+    int k0 = f2key(active ? wx : __builtin_inff()), k1 = f2key(active ? wy : __builtin_inff()), k2 = f2key(active ? wz : __builtin_inff());
+    int k3 = f2key(active ? wx : -__builtin_inff()), k4 = f2key(active ? wy : -__builtin_inff()), k5 = f2key(active ? wz : -__builtin_inff());
+    wave_minmax6(k0, k1, k2, k3, k4, k5);
+    const float bminx = key2f(__builtin_amdgcn_readlane(k0, 63)), bminy = key2f(__builtin_amdgcn_readlane(k1, 63)), bminz = key2f(__builtin_amdgcn_readlane(k2, 63));
+    const float bmaxx = key2f(__builtin_amdgcn_readlane(k3, 63)), bmaxy = key2f(__builtin_amdgcn_readlane(k4, 63)), bmaxz = key2f(__builtin_amdgcn_readlane(k5, 63));
+    const unsigned long long activeMask = __ballot(active);
+    const unsigned long long forceMask = __ballot(active && !brdfFinite); // such pixels must see every light (0 * NaN)
+    unsigned long long survivors[2] = { 0ull, 0ull }, pointM[2] = { 0ull, 0ull }, spotM[2] = { 0ull, 0ull }, nonFiniteM[2] = { 0ull, 0ull };
 #pragma unroll
     for (int h = 0; h < 2; h++) {
+        if ((uint32_t)(h * 64) >= numLights) break;
         const uint32_t li = (uint32_t)(h * 64 + lane);
         bool keep = false;
+        uint32_t bits = 0x10000u;
         if (li < numLights) {
-            const float4 c0 = sL[li * LREC + 0], c1 = sL[li * LREC + 1];
-            const uint32_t cb = __float_as_uint(c0.w);
+            const float4 c0 = sL[li * LREC + 0];
+            bits = __float_as_uint(sL[li * LREC + 1].w);
             keep = true;
-            if ((cb & 0xFFu) == 1u && !anyNonFinitePixel) {
+            if ((bits & 0xFFu) == 1u && forceMask == 0ull) {
                 const float ex = fmaxf(fmaxf(bminx - c0.x, c0.x - bmaxx), 0.0f);
                 const float ey = fmaxf(fmaxf(bminy - c0.y, c0.y - bmaxy), 0.0f);
                 const float ez = fmaxf(fmaxf(bminz - c0.z, c0.z - bmaxz), 0.0f);
-                // c1.w = r^2 (1 + 1e-5) (+inf: never reject); another 1e-4 covers the rounding of this estimate
-                keep = !(fmaf(ex, ex, fmaf(ey, ey, ez * ez)) > c1.w * 1.0001f);
+                // -c0.w = r^2 (1 + 1e-5) (+inf: never reject); another 1e-4 covers the rounding of this estimate
+                keep = !(fmaf(ex, ex, fmaf(ey, ey, ez * ez)) > c0.w * -1.0001f);
             }
         }
         survivors[h] = __ballot(keep);
+        pointM[h] = __ballot(keep && (bits & 0xFFu) == 1u);
+        spotM[h] = __ballot(keep && (bits & 0xFFu) == 2u);
+        nonFiniteM[h] = __ballot(keep && !(bits & 0x10000u));
     }
 
     float accX = 0.0f, accY = 0.0f, accZ = 0.0f;
+#pragma unroll 1
     for (int h = 0; h < 2; h++) {
-    unsigned long long todo = survivors[h];
-    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0;
-    if (todo) { const uint32_t f = (uint32_t)(h * 64 + __builtin_ctzll(todo)); n0 = sL[f * LREC + 0]; n1 = sL[f * LREC + 1]; }
-    while (todo) {
-        const uint32_t i = (uint32_t)(h * 64 + __builtin_ctzll(todo));
-        todo &= todo - 1ull;
-        const float4* R = sL + i * LREC;
-        const float4 r0 = n0, r1 = n1;
-        { // next surviving light's stage-A data is in flight while this one is processed
-            const uint32_t nx_ = todo ? (uint32_t)(h * 64 + __builtin_ctzll(todo)) : (uint32_t)KEEP;
-            n0 = sL[nx_ * LREC + 0]; n1 = sL[nx_ * LREC + 1];
-        }
-        const uint32_t bits = __float_as_uint(r0.w);
-        const uint32_t type = bits & 0xFFu;
-        const bool lightFinite = (bits & 0x10000u) != 0u;
-        float falloff = 1.0f, shadow = 1.0f;
-        float4 r3;
-        if (type == 1u || type == 2u) {
-            const float dx = r0.x - wx, dy = r0.y - wy, dz = r0.z - wz;
-            const float d2 = dot3f(dx, dy, dz, dx, dy, dz);
-            // Stage A -- cheap, conservative: is ANY pixel of this wave within reach of the light?  (Measured on the 4K /
-            // 65 536-light frame: 71 % of the (wave, light) steps have no pixel in reach -- the tile list is a sphere-vs-
-            // frustum overlap, the surface is a thin sheet inside that frustum.)
-            bool reach;
-            if (type == 1u) reach = !(d2 > r1.w);                    // r1.w = r^2 (1 + 1e-5), +inf when not applicable
-            else {
-                // spot: falloff is exactly 0 iff theta < cutOff.y (:303-306); theta ~ dot(d, axis) / |d| to a few ulp
-                const float thetaApprox = fmaf(dx, r1.x, fmaf(dy, r1.y, dz * r1.z)) * rsq_fast(d2);
-                reach = !(thetaApprox < r1.w);                       // r1.w = cutOff.y - 1e-5 (-inf when not applicable)
-            }
-            if (__ballot(active && (reach || !brdfFinite)) == 0ull) continue;
-            // Stage B -- exact falloff (the oracle's op order where it is ill-conditioned)
-            const float dist = sqrtf(d2);                                       // exact: feeds 1 - (dist / bounds.x)^2
-            const float4 r2 = R[2];
-            r3 = R[3];
-            const float att = rcp_fast(fmaf(r2.z, d2, fmaf(r2.y, dist, r2.x))); // 1/(a.x + a.y d + a.z d^2) (:289,:300)
-            if (type == 1u) {
-                const float q = fminf(fmaxf(dist / r2.w, 0.0f), 1.0f);
-                falloff = att * (1.0f - q * q);                              // (:290)
+        unsigned long long todo = survivors[h];
+        const unsigned long long pm = pointM[h], sm = spotM[h], nfm = nonFiniteM[h];
+        while (todo) {
+            const int bit = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const float4* R = sL + (uint32_t)(h * 64 + bit) * LREC;
+            const bool isPoint = (pm >> bit) & 1ull, isSpot = (sm >> bit) & 1ull;
+            const unsigned long long lightForce = ((nfm >> bit) & 1ull) ? activeMask : forceMask; // lanes that may not skip
+            float falloff = 1.0f, shadow = 1.0f;
+            const float4 r3 = R[3];
+            const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
+            float cosLi;
+            if (isPoint || isSpot) {
+                const float4 r0 = R[0];
+                const float dx = r0.x - wx, dy = r0.y - wy, dz = r0.z - wz;
+                const float d2 = dot3f(dx, dy, dz, dx, dy, dz);
+                // Stage A -- cheap, conservative: is ANY pixel of this wave within reach of the light?  (Measured on the 4K /
+                // 65 536-light frame: about half of the (wave, light) steps that survive the box test have no pixel in
+                // reach -- the tile list is a sphere-vs-frustum overlap, the surface is a thin sheet inside that frustum.)
+                float4 r1;
+                float v = -d2;
+                if (isSpot) {
+                    // spot: falloff is exactly 0 iff theta < cutOff.y (:303-306); theta ~ dot(d, axis) / |d| to a few ulp
+                    r1 = R[1];
+                    v = fmaf(dx, r1.x, fmaf(dy, r1.y, dz * r1.z)) * rsq_fast(d2);
+                }
+                const unsigned long long reach = __ballot(!(v < r0.w));
+                if (((reach | lightForce) & activeMask) == 0ull) continue;
+                // ... and facing it?  cosLi = max(0, n . Li) = 0 zeroes both the specular G term and the final product.
+                cosLi = fmaxf(0.0f, dot3f(nx, ny, nz, Lix, Liy, Liz));
+                const unsigned long long lit = __ballot(cosLi != 0.0f) & reach;
+                if (((lit | lightForce) & activeMask) == 0ull) continue;
+                // Stage B -- exact falloff (the oracle's op order where it is ill-conditioned)
+                const float dist = sqrtf(d2);                                       // exact: feeds 1 - (dist / bounds.x)^2
+                const float4 r2 = R[2];
+                const float att = rcp_fast(fmaf(r2.z, d2, fmaf(r2.y, dist, r2.x))); // 1/(a.x + a.y d + a.z d^2) (:289,:300)
+                if (isPoint) {
+                    const float q = fminf(fmaxf(dist / r2.w, 0.0f), 1.0f);
+                    falloff = att * (1.0f - q * q);                              // (:290)
+                } else {
+                    const float dinv = 1.0f / dist; // exact chain: (theta - cutOff.y) cancels at the cone edge
+                    const float theta = dot3f(dx * dinv, dy * dinv, dz * dinv, r1.x, r1.y, r1.z); // dot(normalize(pos - wp), normalize(-dir))
+                    const float cutY = r3.w;
+                    falloff = att * fminf(fmaxf((theta - cutY) / r2.w, 0.0f), 1.0f);     // (:301)
+                    if (theta < cutY) falloff = 0.0f;                                     // (:303-306)
+                }
             } else {
-                const float dinv = 1.0f / dist; // exact chain: (theta - cutOff.y) cancels at the cone edge
-                const float theta = dot3f(dx * dinv, dy * dinv, dz * dinv, r1.x, r1.y, r1.z); // dot(normalize(pos - wp), normalize(-dir))
-                const float cutY = r3.w;
-                falloff = att * fminf(fmaxf((theta - cutY) / r2.w, 0.0f), 1.0f);     // (:301)
-                if (theta < cutY) falloff = 0.0f;                                     // (:303-306)
+                cosLi = fmaxf(0.0f, dot3f(nx, ny, nz, Lix, Liy, Liz));
+                if (HAS_CSM) {
+                    const uint32_t bits = __float_as_uint(R[1].w);
+                    if ((bits & 0xFFu) == 0u) shadow = directional_shadow(A, C, (bits >> 8) & 0xFFu, -r3.x, -r3.y, -r3.z, nx, ny, nz, wx, wy, wz);
+                }
             }
-            // skip the BRDF when every pixel of the wave gets an exact zero from this light: out of reach, or facing away
-            // (cosLi = max(0, n . Li) = 0 zeroes both the specular G term and the final product)
-            const float cosLiEarly = fmaxf(0.0f, dot3f(nx, ny, nz, r3.x, r3.y, r3.z));
-            if (__ballot(active && ((falloff != 0.0f && cosLiEarly != 0.0f) || !brdfFinite || !lightFinite)) == 0ull) continue;
-        } else {
-            r3 = R[3];
-            if (type == 0u) {
-                if (HAS_CSM) shadow = directional_shadow(A, C, (bits >> 8) & 0xFFu, -r3.x, -r3.y, -r3.z, nx, ny, nz, wx, wy, wz);
-            }
+            // ---- Cook-Torrance (Standard.shader:309-340) ----
+            float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;
+            const float hinv = 1.0f / sqrtf(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
+            hx *= hinv; hy *= hinv; hz *= hinv;
+            const float cosLh = fmaxf(0.0f, dot3f(nx, ny, nz, hx, hy, hz));
+            const float x1 = 1.0f - fmaxf(0.0f, dot3f(hx, hy, hz, Lox, Loy, Loz));
+            const float x2 = x1 * x1, x5 = x2 * x2 * x1;                              // pow(1 - cosTheta, 5)
+            const float Fx = fmaf(1.0f - F0x, x5, F0x), Fy = fmaf(1.0f - F0y, x5, F0y), Fz = fmaf(1.0f - F0z, x5, F0z);
+            const float dn = (cosLh * cosLh) * (alphaSq - 1.0f) + 1.0f;                // exact: the cancelling denominator
+            const float D = alphaSq * rcp_fast(3.14159265359f * dn * dn);              // NdfGGX
+            const float G = cosLi * rcp_fast(fmaf(cosLi, oneMinusK, k)) * g1Lo;        // GeometrySchlickGGX
+            const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * cosLo));
+            const float4 r4 = R[4];
+            const float scale = shadow * cosLi * falloff;
+            // shadow * ((kd*albedo + F*D*G/denom) * Lradiance * cosLi) * falloff ; kd = mix(1 - F, 0, metallic)
+            accX = fmaf(fmaf(1.0f - Fx, kdAx, Fx * spec) * r4.x, scale, accX);
+            accY = fmaf(fmaf(1.0f - Fy, kdAy, Fy * spec) * r4.y, scale, accY);
+            accZ = fmaf(fmaf(1.0f - Fz, kdAz, Fz * spec) * r4.z, scale, accZ);
         }
-        // ---- Cook-Torrance (Standard.shader:309-340) ----
-        const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
-        float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;
-        const float hinv = 1.0f / sqrtf(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
-        hx *= hinv; hy *= hinv; hz *= hinv;
-        const float cosLi = fmaxf(0.0f, dot3f(nx, ny, nz, Lix, Liy, Liz));
-        const float cosLh = fmaxf(0.0f, dot3f(nx, ny, nz, hx, hy, hz));
-        const float x1 = 1.0f - fmaxf(0.0f, dot3f(hx, hy, hz, Lox, Loy, Loz));
-        const float x2 = x1 * x1, x5 = x2 * x2 * x1;                              // pow(1 - cosTheta, 5)
-        const float Fx = fmaf(1.0f - F0x, x5, F0x), Fy = fmaf(1.0f - F0y, x5, F0y), Fz = fmaf(1.0f - F0z, x5, F0z);
-        const float dn = (cosLh * cosLh) * (alphaSq - 1.0f) + 1.0f;                // exact: the cancelling denominator
-        const float D = alphaSq * rcp_fast(3.14159265359f * dn * dn);              // NdfGGX
-        const float G = cosLi * rcp_fast(fmaf(cosLi, oneMinusK, k)) * g1Lo;        // GeometrySchlickGGX
-        const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * cosLo));
-        const float4 r4 = R[4];
-        const float scale = shadow * cosLi * falloff;
-        // shadow * ((kd*albedo + F*D*G/denom) * Lradiance * cosLi) * falloff ; kd = mix(1 - F, 0, metallic)
-        accX = fmaf(fmaf((1.0f - Fx) * oneMinusMetal, P2.x, Fx * spec) * r4.x, scale, accX);
-        accY = fmaf(fmaf((1.0f - Fy) * oneMinusMetal, P2.y, Fy * spec) * r4.y, scale, accY);
-        accZ = fmaf(fmaf((1.0f - Fz) * oneMinusMetal, P2.z, Fz * spec) * r4.z, scale, accZ);
-    }
     }
     if (active) radiance[pix] = make_float4(accX, accY, accZ, P0.w); // outColor.a = material.albedo.a (:438)
 }
