@@ -202,6 +202,9 @@ __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
 
 #define LREC 5 // float4 per staged light
+#define PENDK 3  // queued pairs per pixel in one window
+#define QMAX 128 // queued pairs per wave in one window
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Order-preserving float <-> int32 map (an involution), so that the wave-wide bounding box can be reduced with
 // v_min_i32 / v_max_i32 DPP steps: one instruction per step and value, no NaN canonicalisation, no LDS round trips.
@@ -228,10 +231,10 @@ __device__ __forceinline__ void wave_minmax6(int& a, int& b, int& c, int& d, int
 }
 
 // Staged light record (LDS, 5 float4):
-//   rec0 = (worldPosition.xyz, A)   the conservative reach test of both types is  !(v < A):
-//                                     point: v = -d^2,  A = -r^2 (1 + 1e-5)   (out of reach => exact-zero radius window)
-//                                     spot : v ~ theta, A = cutOff.y - 1e-5   (outside the cone => falloff exactly 0)
-//                                     A = -inf: never reject
+//   rec0 = (worldPosition.xyz, A)   the conservative reach test of both types is  !(v > A):
+//                                     point: v = d^2,    A = r^2 (1 + 1e-5)      (out of reach => exact-zero radius window)
+//                                     spot : v ~ -theta, A = -(cutOff.y - 1e-5)  (outside the cone => falloff exactly 0)
+//                                     A = +inf: never reject
 //   rec1 = (normalize(-direction).xyz, bits: type | shadowType << 8 | finite << 16)
 //   rec2 = (attenuation.xyz, B)     B = point: bounds.x          spot: epsilon = cutOff.x - cutOff.y (:297)
 //   rec3 = (Li = -direction.xyz, cutOff.y)
@@ -248,6 +251,8 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
                                                  float4* __restrict__ radiance)
 {
     __shared__ float4 sL[KEEP * LREC];
+    __shared__ float sRes[3 * PENDK * 256];
+    __shared__ uint16_t sQ[4 * QMAX];
     __shared__ uint32_t sNum;
 
     const int bandTile = blockIdx.x;
@@ -290,9 +295,9 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
             // Conservative "out of reach" threshold of a point light: d^2 > r^2 (1 + 1e-5) => fl(dist / r) >= 1 => the radius
             // window (:290) is exactly 0.  Only for r > 0 (a negative radius clamps to the FULL window in the reference).
             const float r = q6.x;
-            float a = -__builtin_inff(), b = r;
-            if (type == 1u) { if (finite && r > 0.0f) a = -((r * r) * 1.00001f); }
-            else { if (finite) a = q5.y - 1e-5f; b = q5.x - q5.y; }
+            float a = __builtin_inff(), b = r;
+            if (type == 1u) { if (finite && r > 0.0f) a = (r * r) * 1.00001f; }
+            else { if (finite) a = -(q5.y - 1e-5f); b = q5.x - q5.y; }
             const uint32_t bits = (type < 255u ? type : 255u) | ((shadowType < 255u ? shadowType : 255u) << 8) | (finite ? 0x10000u : 0u);
             float4* o = sL + threadIdx.x * LREC;
             o[0] = make_float4(q1.x, q1.y, q1.z, a);
@@ -307,6 +312,7 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
 
     // ---- per-pixel invariants (Standard.shader:379-401) ----
     const float wx = P0.x, wy = P0.y, wz = P0.z;
+    const v2f wxy = { wx, wy };
     const float nx = P1.x, ny = P1.y, nz = P1.z, roughness = P1.w;
     const float metallic = P2.w;
     const float vx = wx - A.camX, vy = wy - A.camY, vz = wz - A.camZ;
@@ -334,7 +340,9 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
     const float bmaxx = key2f(__builtin_amdgcn_readlane(k3, 63)), bmaxy = key2f(__builtin_amdgcn_readlane(k4, 63)), bmaxz = key2f(__builtin_amdgcn_readlane(k5, 63));
     const unsigned long long activeMask = __ballot(active);
     const unsigned long long forceMask = __ballot(active && !brdfFinite); // such pixels must see every light (0 * NaN)
-    unsigned long long survivors[2] = { 0ull, 0ull }, pointM[2] = { 0ull, 0ull }, spotM[2] = { 0ull, 0ull }, nonFiniteM[2] = { 0ull, 0ull };
+    // survivors by kind: [0,1] finite point lights, [2,3] finite spot lights, [4,5] the rest (directional, unknown type,
+    // non-finite intensity: every pixel is a pair) -- for list slots 0..63 and 64..127
+    unsigned long long seg[6] = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull };
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         if ((uint32_t)(h * 64) >= numLights) break;
@@ -349,91 +357,162 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
                 const float ex = fmaxf(fmaxf(bminx - c0.x, c0.x - bmaxx), 0.0f);
                 const float ey = fmaxf(fmaxf(bminy - c0.y, c0.y - bmaxy), 0.0f);
                 const float ez = fmaxf(fmaxf(bminz - c0.z, c0.z - bmaxz), 0.0f);
-                // -c0.w = r^2 (1 + 1e-5) (+inf: never reject); another 1e-4 covers the rounding of this estimate
-                keep = !(fmaf(ex, ex, fmaf(ey, ey, ez * ez)) > c0.w * -1.0001f);
+                // c0.w = r^2 (1 + 1e-5) (+inf: never reject); another 1e-4 covers the rounding of this estimate
+                keep = !(fmaf(ex, ex, fmaf(ey, ey, ez * ez)) > c0.w * 1.0001f);
             }
         }
-        survivors[h] = __ballot(keep);
-        pointM[h] = __ballot(keep && (bits & 0xFFu) == 1u);
-        spotM[h] = __ballot(keep && (bits & 0xFFu) == 2u);
-        nonFiniteM[h] = __ballot(keep && !(bits & 0x10000u));
+        const bool fin = (bits & 0x10000u) != 0u;
+        const unsigned long long all = __ballot(keep);
+        seg[h] = __ballot(keep && fin && (bits & 0xFFu) == 1u);
+        seg[2 + h] = __ballot(keep && fin && (bits & 0xFFu) == 2u);
+        seg[4 + h] = all & ~(seg[h] | seg[2 + h]);
     }
 
+    // ---- 2 + 3. queue the (pixel, light) pairs that can be lit, then shade them one LANE per PAIR ----
+    // Window = up to QMAX queued pairs, at most PENDK per pixel; a light whose pairs do not fit ends the window (it is
+    // tested again in the next one -- rare: a quadrant of the 4K frame queues ~50 pairs).  A pair's result goes to slot
+    // [its ordinal among the pixel's queued pairs][pixel], which the pixel's own lane adds up afterwards: no atomics
+    // (ds_add_f32 is serialised per lane on this LDS: ~170 cycles per wave instruction, scripts/microbench/lds_ops.hip).
+    uint16_t* Q = sQ + wave * QMAX;
+    float* res = sRes + threadIdx.x - lane; // this wave's [3 colours][PENDK][64 pixels] slots, 256 floats apart
     float accX = 0.0f, accY = 0.0f, accZ = 0.0f;
-#pragma unroll 1
-    for (int h = 0; h < 2; h++) {
-        unsigned long long todo = survivors[h];
-        const unsigned long long pm = pointM[h], sm = spotM[h], nfm = nonFiniteM[h];
-        while (todo) {
-            const int bit = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            const float4* R = sL + (uint32_t)(h * 64 + bit) * LREC;
-            const bool isPoint = (pm >> bit) & 1ull, isSpot = (sm >> bit) & 1ull;
-            const unsigned long long lightForce = ((nfm >> bit) & 1ull) ? activeMask : forceMask; // lanes that may not skip
+    for (;;) {
+        uint32_t cnt = 0u;      // queued pairs (wave-uniform)
+        uint32_t pc = 0u;       // this pixel's queued pairs
+        bool overflow = false;
+#pragma unroll
+        for (int kind = 0; kind < 3 && !overflow; kind++) {
+#pragma unroll
+            for (int h = 0; h < 2 && !overflow; h++) {
+                unsigned long long todo = seg[kind * 2 + h];
+                while (todo) {
+                    const int bit = __builtin_ctzll(todo);
+                    const uint32_t s = (uint32_t)(h * 64 + bit);
+                    unsigned long long m = activeMask; // "the rest": every pixel is a pair
+                    if (kind < 2) {
+                        const float4* R = sL + s * LREC;
+                        const float4 r0 = R[0];
+                        const v2f dxy = v2f{ r0.x, r0.y } - wxy;
+                        const float dz = r0.z - wz;
+                        const float d2 = fmaf(dxy.x, dxy.x, fmaf(dxy.y, dxy.y, dz * dz));
+                        float v = d2;
+                        if (kind == 1) {
+                            // spot: falloff is exactly 0 iff theta < cutOff.y (:303-306); theta ~ dot(d, axis) / |d| to a few ulp
+                            const float4 r1 = R[1];
+                            v = -(fmaf(dxy.x, r1.x, fmaf(dxy.y, r1.y, dz * r1.z)) * rsq_fast(d2));
+                        }
+                        const unsigned long long reach = __ballot(!(v > r0.w));
+                        m = 0ull;
+                        if (((reach | forceMask) & activeMask) != 0ull) {
+                            // ... and facing it?  cosLi = max(0, n . Li) = 0 zeroes both the specular G term and the final product.
+                            const float4 r3 = R[3];
+                            const unsigned long long facing = __ballot(dot3f(nx, ny, nz, r3.x, r3.y, r3.z) > 0.0f);
+                            m = ((reach & facing) | forceMask) & activeMask;
+                        }
+                    }
+                    if (m != 0ull) {
+                        const bool mine = (m >> lane) & 1ull;
+                        if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || __ballot(mine && pc >= (uint32_t)PENDK) != 0ull) { overflow = true; break; }
+                        if (mine) {
+                            const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            Q[pos] = (uint16_t)((uint32_t)lane | (s << 6) | (pc << 13));
+                            pc++;
+                        }
+                        cnt += (uint32_t)__popcll(m);
+                    }
+                    todo &= todo - 1ull;
+                }
+                seg[kind * 2 + h] = todo; // what the next window still has to look at
+            }
+        }
+        if (cnt == 0u) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t base = 0u; base < cnt; base += 64u) {
+            // one LANE per PAIR.  The pixel's invariants are pulled from its lane's registers (ds_bpermute: the LDS crossbar,
+            // no LDS memory), the light record from LDS.  All 64 lanes execute the pulls (a disabled source lane returns 0).
+            const uint32_t e = Q[base + (uint32_t)lane];
+            const bool valid = base + (uint32_t)lane < cnt;
+            const int pa = (int)((e & 63u) << 2);
+            const uint32_t s = (e >> 6) & (uint32_t)(KEEP - 1);
+            const float4* R = sL + s * LREC;
+#define PULL(x) __int_as_float(__builtin_amdgcn_ds_bpermute(pa, __float_as_int(x)))
             float falloff = 1.0f, shadow = 1.0f;
             const float4 r3 = R[3];
-            const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
-            float cosLi;
-            if (isPoint || isSpot) {
-                const float4 r0 = R[0];
-                const float dx = r0.x - wx, dy = r0.y - wy, dz = r0.z - wz;
-                const float d2 = dot3f(dx, dy, dz, dx, dy, dz);
-                // Stage A -- cheap, conservative: is ANY pixel of this wave within reach of the light?  (Measured on the 4K /
-                // 65 536-light frame: about half of the (wave, light) steps that survive the box test have no pixel in
-                // reach -- the tile list is a sphere-vs-frustum overlap, the surface is a thin sheet inside that frustum.)
-                float4 r1;
-                float v = -d2;
-                if (isSpot) {
-                    // spot: falloff is exactly 0 iff theta < cutOff.y (:303-306); theta ~ dot(d, axis) / |d| to a few ulp
-                    r1 = R[1];
-                    v = fmaf(dx, r1.x, fmaf(dy, r1.y, dz * r1.z)) * rsq_fast(d2);
-                }
-                const unsigned long long reach = __ballot(!(v < r0.w));
-                if (((reach | lightForce) & activeMask) == 0ull) continue;
-                // ... and facing it?  cosLi = max(0, n . Li) = 0 zeroes both the specular G term and the final product.
-                cosLi = fmaxf(0.0f, dot3f(nx, ny, nz, Lix, Liy, Liz));
-                const unsigned long long lit = __ballot(cosLi != 0.0f) & reach;
-                if (((lit | lightForce) & activeMask) == 0ull) continue;
-                // Stage B -- exact falloff (the oracle's op order where it is ill-conditioned)
-                const float dist = sqrtf(d2);                                       // exact: feeds 1 - (dist / bounds.x)^2
-                const float4 r2 = R[2];
-                const float att = rcp_fast(fmaf(r2.z, d2, fmaf(r2.y, dist, r2.x))); // 1/(a.x + a.y d + a.z d^2) (:289,:300)
-                if (isPoint) {
-                    const float q = fminf(fmaxf(dist / r2.w, 0.0f), 1.0f);
-                    falloff = att * (1.0f - q * q);                              // (:290)
-                } else {
-                    const float dinv = 1.0f / dist; // exact chain: (theta - cutOff.y) cancels at the cone edge
-                    const float theta = dot3f(dx * dinv, dy * dinv, dz * dinv, r1.x, r1.y, r1.z); // dot(normalize(pos - wp), normalize(-dir))
-                    const float cutY = r3.w;
-                    falloff = att * fminf(fmaxf((theta - cutY) / r2.w, 0.0f), 1.0f);     // (:301)
-                    if (theta < cutY) falloff = 0.0f;                                     // (:303-306)
-                }
-            } else {
-                cosLi = fmaxf(0.0f, dot3f(nx, ny, nz, Lix, Liy, Liz));
-                if (HAS_CSM) {
-                    const uint32_t bits = __float_as_uint(R[1].w);
-                    if ((bits & 0xFFu) == 0u) shadow = directional_shadow(A, C, (bits >> 8) & 0xFFu, -r3.x, -r3.y, -r3.z, nx, ny, nz, wx, wy, wz);
+            const float pwx = PULL(wx), pwy = PULL(wy), pwz = PULL(wz);
+            if (valid) {
+                const float4 r0 = R[0], r1 = R[1];
+                const uint32_t type = __float_as_uint(r1.w) & 0xFFu;
+                if (type == 1u || type == 2u) {
+                    // exact falloff (the oracle's op order where it is ill-conditioned)
+                    const float4 r2 = R[2];
+                    const float dx = r0.x - pwx, dy = r0.y - pwy, dz = r0.z - pwz;
+                    const float d2 = dot3f(dx, dy, dz, dx, dy, dz);
+                    const float dist = sqrtf(d2);                                       // exact: feeds 1 - (dist / bounds.x)^2
+                    const float att = rcp_fast(fmaf(r2.z, d2, fmaf(r2.y, dist, r2.x))); // 1/(a.x + a.y d + a.z d^2) (:289,:300)
+                    const bool isPoint = type == 1u;
+                    // one IEEE division serves both types: point dist / bounds.x (:290), spot 1 / dist (normalize, :298)
+                    const float x = (isPoint ? dist : 1.0f) / (isPoint ? r2.w : dist);
+                    if (isPoint) {
+                        const float q = fminf(fmaxf(x, 0.0f), 1.0f);
+                        falloff = att * (1.0f - q * q);                                  // (:290)
+                    } else {
+                        const float theta = dot3f(dx * x, dy * x, dz * x, r1.x, r1.y, r1.z); // dot(normalize(pos - wp), normalize(-dir))
+                        const float cutY = r3.w;
+                        falloff = att * fminf(fmaxf((theta - cutY) / r2.w, 0.0f), 1.0f);     // (:301); exact: cancels at the cone edge
+                        if (theta < cutY) falloff = 0.0f;                                     // (:303-306)
+                    }
                 }
             }
-            // ---- Cook-Torrance (Standard.shader:309-340) ----
-            float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;
-            const float hinv = 1.0f / sqrtf(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
-            hx *= hinv; hy *= hinv; hz *= hinv;
-            const float cosLh = fmaxf(0.0f, dot3f(nx, ny, nz, hx, hy, hz));
-            const float x1 = 1.0f - fmaxf(0.0f, dot3f(hx, hy, hz, Lox, Loy, Loz));
-            const float x2 = x1 * x1, x5 = x2 * x2 * x1;                              // pow(1 - cosTheta, 5)
-            const float Fx = fmaf(1.0f - F0x, x5, F0x), Fy = fmaf(1.0f - F0y, x5, F0y), Fz = fmaf(1.0f - F0z, x5, F0z);
-            const float dn = (cosLh * cosLh) * (alphaSq - 1.0f) + 1.0f;                // exact: the cancelling denominator
-            const float D = alphaSq * rcp_fast(3.14159265359f * dn * dn);              // NdfGGX
-            const float G = cosLi * rcp_fast(fmaf(cosLi, oneMinusK, k)) * g1Lo;        // GeometrySchlickGGX
-            const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * cosLo));
-            const float4 r4 = R[4];
-            const float scale = shadow * cosLi * falloff;
-            // shadow * ((kd*albedo + F*D*G/denom) * Lradiance * cosLi) * falloff ; kd = mix(1 - F, 0, metallic)
-            accX = fmaf(fmaf(1.0f - Fx, kdAx, Fx * spec) * r4.x, scale, accX);
-            accY = fmaf(fmaf(1.0f - Fy, kdAy, Fy * spec) * r4.y, scale, accY);
-            accZ = fmaf(fmaf(1.0f - Fz, kdAz, Fz * spec) * r4.z, scale, accZ);
+            {
+                const float pnx = PULL(nx), pny = PULL(ny), pnz = PULL(nz);
+                const float pLox = PULL(Lox), pLoy = PULL(Loy), pLoz = PULL(Loz);
+                const float pcosLo = PULL(cosLo), pg1Lo = PULL(g1Lo), palphaSq = PULL(alphaSq), pk = PULL(k);
+                const float pF0x = PULL(F0x), pF0y = PULL(F0y), pF0z = PULL(F0z);
+                const float pkdAx = PULL(kdAx), pkdAy = PULL(kdAy), pkdAz = PULL(kdAz);
+                if (valid) {
+                    if (HAS_CSM) {
+                        const uint32_t bits = __float_as_uint(R[1].w);
+                        if ((bits & 0xFFu) == 0u)
+                            shadow = directional_shadow(A, C, (bits >> 8) & 0xFFu, -r3.x, -r3.y, -r3.z, pnx, pny, pnz, pwx, pwy, pwz);
+                    }
+                    // ---- Cook-Torrance (Standard.shader:309-340) ----
+                    const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
+                    float hx = Lix + pLox, hy = Liy + pLoy, hz = Liz + pLoz;
+                    const float hinv = 1.0f / sqrtf(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
+                    hx *= hinv; hy *= hinv; hz *= hinv;
+                    const float cosLi = fmaxf(0.0f, dot3f(pnx, pny, pnz, Lix, Liy, Liz));
+                    const float cosLh = fmaxf(0.0f, dot3f(pnx, pny, pnz, hx, hy, hz));
+                    const float x1 = 1.0f - fmaxf(0.0f, dot3f(hx, hy, hz, pLox, pLoy, pLoz));
+                    const float x2 = x1 * x1, x5 = x2 * x2 * x1;                              // pow(1 - cosTheta, 5)
+                    const float Fx = fmaf(1.0f - pF0x, x5, pF0x), Fy = fmaf(1.0f - pF0y, x5, pF0y), Fz = fmaf(1.0f - pF0z, x5, pF0z);
+                    const float dn = (cosLh * cosLh) * (palphaSq - 1.0f) + 1.0f;                // exact: the cancelling denominator
+                    const float D = palphaSq * rcp_fast(3.14159265359f * dn * dn);              // NdfGGX
+                    const float G = cosLi * rcp_fast(fmaf(cosLi, 1.0f - pk, pk)) * pg1Lo;      // GeometrySchlickGGX
+                    const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * pcosLo));
+                    const float4 r4 = R[4];
+                    const float scale = shadow * cosLi * falloff;
+                    // shadow * ((kd*albedo + F*D*G/denom) * Lradiance * cosLi) * falloff ; kd = mix(1 - F, 0, metallic)
+                    float* o = res + ((e >> 13) * 256u + (e & 63u));
+                    o[0] = (fmaf(1.0f - Fx, pkdAx, Fx * spec) * r4.x) * scale;
+                    o[PENDK * 256] = (fmaf(1.0f - Fy, pkdAy, Fy * spec) * r4.y) * scale;
+                    o[2 * PENDK * 256] = (fmaf(1.0f - Fz, pkdAz, Fz * spec) * r4.z) * scale;
+                }
+            }
+#undef PULL
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // each pixel adds up the results of its own pairs, in the order they were queued
+#pragma unroll
+        for (uint32_t j = 0; j < (uint32_t)PENDK; j++) {
+            if (__ballot(pc > j) == 0ull) break;
+            if (pc > j) {
+                accX += res[j * 256u + lane];
+                accY += res[(PENDK + j) * 256u + lane];
+                accZ += res[(2 * PENDK + j) * 256u + lane];
+            }
+        }
+        if (!overflow) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (active) radiance[pix] = make_float4(accX, accY, accZ, P0.w); // outColor.a = material.albedo.a (:438)
 }
