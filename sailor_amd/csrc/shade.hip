@@ -203,7 +203,7 @@ __device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsq
 
 #define LREC 5 // float4 per staged light
 #define PENDK 3  // queued pairs per pixel in one window
-#define QMAX 128 // queued pairs per wave in one window
+#define QMAX 120 // queued pairs per wave in one window (120: the block stays within 20 KB of LDS, 8 blocks per CU)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Order-preserving float <-> int32 map (an involution), so that the wave-wide bounding box can be reduced with
@@ -463,12 +463,12 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
                     }
                 }
             }
+            // (the pulls are spread out so that at most ten pulled values are live at a time: 64 VGPRs = 8 waves per SIMD)
+            float spec = 0.0f, x5 = 0.0f, scale = 0.0f;
             {
                 const float pnx = PULL(nx), pny = PULL(ny), pnz = PULL(nz);
                 const float pLox = PULL(Lox), pLoy = PULL(Loy), pLoz = PULL(Loz);
                 const float pcosLo = PULL(cosLo), pg1Lo = PULL(g1Lo), palphaSq = PULL(alphaSq), pk = PULL(k);
-                const float pF0x = PULL(F0x), pF0y = PULL(F0y), pF0z = PULL(F0z);
-                const float pkdAx = PULL(kdAx), pkdAy = PULL(kdAy), pkdAz = PULL(kdAz);
                 if (valid) {
                     if (HAS_CSM) {
                         const uint32_t bits = __float_as_uint(R[1].w);
@@ -483,14 +483,22 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
                     const float cosLi = fmaxf(0.0f, dot3f(pnx, pny, pnz, Lix, Liy, Liz));
                     const float cosLh = fmaxf(0.0f, dot3f(pnx, pny, pnz, hx, hy, hz));
                     const float x1 = 1.0f - fmaxf(0.0f, dot3f(hx, hy, hz, pLox, pLoy, pLoz));
-                    const float x2 = x1 * x1, x5 = x2 * x2 * x1;                              // pow(1 - cosTheta, 5)
-                    const float Fx = fmaf(1.0f - pF0x, x5, pF0x), Fy = fmaf(1.0f - pF0y, x5, pF0y), Fz = fmaf(1.0f - pF0z, x5, pF0z);
+                    const float x2 = x1 * x1;
+                    x5 = x2 * x2 * x1;                                                        // pow(1 - cosTheta, 5)
                     const float dn = (cosLh * cosLh) * (palphaSq - 1.0f) + 1.0f;                // exact: the cancelling denominator
                     const float D = palphaSq * rcp_fast(3.14159265359f * dn * dn);              // NdfGGX
                     const float G = cosLi * rcp_fast(fmaf(cosLi, 1.0f - pk, pk)) * pg1Lo;      // GeometrySchlickGGX
-                    const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * pcosLo));
+                    spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * pcosLo));
+                    scale = shadow * cosLi * falloff;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float pF0x = PULL(F0x), pF0y = PULL(F0y), pF0z = PULL(F0z);
+                const float pkdAx = PULL(kdAx), pkdAy = PULL(kdAy), pkdAz = PULL(kdAz);
+                if (valid) {
+                    const float Fx = fmaf(1.0f - pF0x, x5, pF0x), Fy = fmaf(1.0f - pF0y, x5, pF0y), Fz = fmaf(1.0f - pF0z, x5, pF0z);
                     const float4 r4 = R[4];
-                    const float scale = shadow * cosLi * falloff;
                     // shadow * ((kd*albedo + F*D*G/denom) * Lradiance * cosLi) * falloff ; kd = mix(1 - F, 0, metallic)
                     float* o = res + ((e >> 13) * 256u + (e & 63u));
                     o[0] = (fmaf(1.0f - Fx, pkdAx, Fx * spec) * r4.x) * scale;
@@ -514,7 +522,7 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
         if (!overflow) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    if (active) radiance[pix] = make_float4(accX, accY, accZ, P0.w); // outColor.a = material.albedo.a (:438)
+    if (active) radiance[(size_t)(py - A.fbRow0) * A.W + gx] = make_float4(accX, accY, accZ, P0.w); // outColor.a = material.albedo.a (:438)
 }
 
 extern "C" int sailor_hip_shade(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
