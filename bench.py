@@ -396,7 +396,7 @@ def main():
     evals = int((g[:, 1].astype(np.int64) * 256).sum())
     shade_gbs = b_shade / (shade_ms[0] * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "k2_shade", "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
-                "traffic": measured_traffic("k2_shade<false>" if csm is None else "k2_shade<true>", args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_ms[0], "median_launch_ms": shade_ms[1],
+                "traffic": measured_traffic("k2_shade" if csm is None else "k2_shade_csm", args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_ms[0], "median_launch_ms": shade_ms[1],
                 "frac_of_measured_copy_peak": shade_gbs / HBM_COPY_GBS,
                 "valu_sidebar": {"pixel_light_evals": evals, "gevals_per_s": evals / (shade_ms[0] * 1e-3) / 1e9,
                                  "note": "~110 fp32 ops per (pixel,light): VALU-bound once mean list length exceeds ~10 (SURVEY.md 7, hard part 2)"},

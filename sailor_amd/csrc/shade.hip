@@ -245,7 +245,7 @@ __device__ __forceinline__ void wave_minmax6(int& a, int& b, int& c, int& d, int
 // wave-uniform 64-bit masks (scalar registers, scalar branches), the reach test feeds s_cbranch_vccz directly, and most
 // steps end after ~10 vector instructions.
 template <bool HAS_CSM>
-__global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const float4* __restrict__ surface, size_t planeStride,
+__device__ __forceinline__ void k2_shade_body(const ShadeArgs& A, const CsmArgs& C, const float4* __restrict__ surface, size_t planeStride,
                                                  const SailorLightShaderData* __restrict__ lights,
                                                  const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled,
                                                  float4* __restrict__ radiance)
@@ -255,8 +255,8 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
     __shared__ uint16_t sQ[4 * QMAX];
     __shared__ uint32_t sNum;
 
-    const int bandTile = blockIdx.x;
-    const int tx = bandTile % A.Tx, ty = A.tileRow0 + bandTile / A.Tx;
+    const int tx = blockIdx.x, ty = A.tileRow0 + blockIdx.y; // grid = (tiles per row, tile rows of the band): no division
+    const int bandTile = blockIdx.y * A.Tx + blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // each wave shades one 8x8 quadrant of the tile: the most compact 64-pixel footprint, so that "no pixel of the wave
     // is within reach of this light" holds as often as possible
@@ -266,13 +266,11 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
     const bool active = gx < A.W && py >= 0;
     const size_t pix = active ? ((size_t)(py - A.fbRow0) * A.W + gx) : 0;
 
-    // issue the surface loads first; the list staging below overlaps their latency
-    float4 P0 = make_float4(0, 0, 0, 0), P1 = make_float4(0, 0, 1, 1), P2 = make_float4(0, 0, 0, 0);
-    if (active) {
-        P0 = surface[pix];
-        P1 = surface[planeStride + pix];
-        P2 = surface[2 * planeStride + pix];
-    }
+    // issue the surface loads first -- unconditionally (lanes outside the frame read pixel 0 of the band and are masked
+    // out of every ballot and of the store), so that nothing waits on them before the list staging below is under way
+    const float4 P0 = surface[pix];
+    const float4 P1 = surface[planeStride + pix];
+    const float4 P2 = surface[2 * planeStride + pix];
 
     const SailorLightsGrid g = grid[bandTile]; // Standard.shader:422-423
     const uint32_t listNum = g.num < (uint32_t)KEEP ? g.num : (uint32_t)KEEP;
@@ -525,6 +523,22 @@ __global__ __launch_bounds__(256) void k2_shade(ShadeArgs A, CsmArgs C, const fl
     if (active) radiance[(size_t)(py - A.fbRow0) * A.W + gx] = make_float4(accX, accY, accZ, P0.w); // outColor.a = material.albedo.a (:438)
 }
 
+// Two entry points: without shadow maps the pair pass fits 64 VGPRs, and the register allocator is told to stay there
+// (8 waves per SIMD); with the 16-tap PCF inlined it does not, and forcing it would spill.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k2_shade(ShadeArgs A, CsmArgs C, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
+              const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
+{
+    k2_shade_body<false>(A, C, surface, planeStride, lights, grid, culled, radiance);
+}
+
+__global__ __launch_bounds__(256)
+void k2_shade_csm(ShadeArgs A, CsmArgs C, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
+                  const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
+{
+    k2_shade_body<true>(A, C, surface, planeStride, lights, grid, culled, radiance);
+}
+
 extern "C" int sailor_hip_shade(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
                                 const SailorLightShaderData* dLights, int32_t lightsNum,
                                 const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
@@ -569,11 +583,12 @@ extern "C" int sailor_hip_shade(SailorHipContext* ctx, const SailorUboFrameData*
             }
         }
     }
+    const dim3 grid((unsigned)A.Tx, (unsigned)(band->tileRowEnd - band->tileRowBegin));
     if (hasCsm)
-        hipLaunchKernelGGL(k2_shade<true>, dim3(bandTiles), dim3(256), 0, ctx->stream, A, C, (const float4*)dSurface, surfacePlaneStride,
+        hipLaunchKernelGGL(k2_shade_csm, grid, dim3(256), 0, ctx->stream, A, C, (const float4*)dSurface, surfacePlaneStride,
                            dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
     else
-        hipLaunchKernelGGL(k2_shade<false>, dim3(bandTiles), dim3(256), 0, ctx->stream, A, C, (const float4*)dSurface, surfacePlaneStride,
+        hipLaunchKernelGGL(k2_shade, grid, dim3(256), 0, ctx->stream, A, C, (const float4*)dSurface, surfacePlaneStride,
                            dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
     SAILOR_CHECK_LAUNCH(ctx, "k2_shade");
     return SAILOR_HIP_OK;
