@@ -11,13 +11,13 @@
 //   k1_tile_setup      streaming pass over the linear-depth image (the only large HBM stream of the cull):
 //                      16 tiles per 256-thread block, 1 KiB coalesced float4 row segments, wave shuffles + a
 //                      4-entry LDS combine for min/max, then 16 lanes build the 16 tile frusta
-//   k1_band_masks      conservative pre-filter as BITMASKS: one 64-bit ballot per (64 lights, tile column) and per
-//                      (64 lights, tile row): "this light's sphere may reach this column / row of tiles".  Pure
+//   k1_band_masks      conservative pre-filter as BITMASKS: one 64-bit ballot per (64 lights, column of 4x4-tile groups)
+//                      and per (64 lights, row of groups): "this light's sphere may reach this 64-pixel band".  Pure
 //                      streaming, no atomics, no compaction, no inter-block order: 3 MB of masks at 4K / 65 536 lights
-//   k1_group_lists     one wave per 4x4-tile group: (OR of 4 column masks) AND (OR of 4 row masks), 4096 lights per
+//   k1_group_lists     one block per 4x4-tile group: (its column's mask) AND (its row's mask), 16 384 lights per
 //                      step; the few surviving bits become an ordered, contiguous candidate list (ballot, readlane, mbcnt)
-//   k1_tile_cull       one 1024-thread block per group, one wave per tile: the group's candidate records are gathered
-//                      into LDS once (40 KB), each wave streams them through the exact test, 64 per step;
+//   k1_tile_cull       one 256-thread block per 2x2 quarter of a group, one wave per tile: the group's candidate records
+//                      are staged in LDS 1024 at a time, each wave streams them through the exact test, 64 per step;
 //                      ballot/popcount ordered append; rank-based nearest-128 selection
 //                      (groups denser than 2048 candidates fall back to walking the two masks of the tile itself)
 //   k1_block_sums / k1_pack  canonical offsets = prefix sum over tiles in tile-index order, then compaction
@@ -33,12 +33,13 @@
 #include "common.h"
 #include <vector>
 
-#define BANDS_PER_GROUP 25   // tile columns / rows handled per k1_band_masks wave (grid.y = ceil(bands / 25))
+#define BANDS_PER_GROUP 24   // group columns / rows handled per k1_band_masks wave (grid.y = ceil(bands / 24))
 #define QCAP 128             // LDS candidate queue of k1_tile_cull (ring buffer: < 64 pending + <= 64 new)
 #define SCAN_BLOCK 1024      // tiles per k1_block_sums block
 #define GROUP 4              // k1_group_lists: tiles per group edge (4x4 tiles share one candidate list)
 #define CAPG 2048            // entries per group list; a denser group falls back to walking the masks per tile
 #define GROUP_OVERFLOW 0xFFFFFFFFu
+#define CHUNK 1024           // group candidates staged in LDS per step of k1_tile_cull
 
 struct CullLayout {
     int Tx, Ty, bandRows, bandTiles, numBands, words, sumBlocks, groupsX, groupsY, numGroups;
@@ -52,7 +53,6 @@ static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
     L.Ty = (H - 1) / TILE + 1;
     L.bandRows = band.tileRowEnd - band.tileRowBegin;
     L.bandTiles = L.bandRows * L.Tx;
-    L.numBands = L.Tx + L.bandRows;          // tile columns first, then the band's tile rows
     L.words = (N + 63) / 64;
     if (L.words < 1) L.words = 1;
     const size_t n = (size_t)(N > 0 ? N : 1);
@@ -61,6 +61,7 @@ static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
     L.groupsX = (L.Tx + GROUP - 1) / GROUP;
     L.groupsY = (L.bandRows + GROUP - 1) / GROUP;
     L.numGroups = L.groupsX * L.groupsY;
+    L.numBands = L.groupsX + L.groupsY;      // group columns first, then the band's group rows (4 tiles wide / high)
     const size_t groups = (size_t)(L.numGroups > 0 ? L.numGroups : 1);
     size_t o = 0;
     L.offLightView = o; o = align_up(o + n * 16, 256);
@@ -123,24 +124,25 @@ __device__ void frustum_from_rect(const Mat4& invProj, float x0, float y0, float
 
 // ------------------------------------------------------------------------------------------------------------
 // K0: ComputeLightCulling.shader:164-169 hoisted out of the per-tile loop (it does not depend on the tile).
-// The tail blocks of the same launch build the conservative band planes (one thread per tile column / tile row).
+// The tail blocks of the same launch build the conservative band planes (one thread per column / row of tile groups).
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k0_light_view(Mat4 view, const SailorLightShaderData* __restrict__ lights, int N, int lightBlocks,
                                                       float4* __restrict__ lightView, uint32_t* __restrict__ lightType,
-                                                      Mat4 invProj, int vpW, int vpH, int Tx, int Ty, int tileRow0, int numBands,
+                                                      Mat4 invProj, int vpW, int vpH, int Tx, int Ty, int tileRow0, int bandRows, int groupsX, int numBands,
                                                       float4* __restrict__ bandPlanes)
 {
     if ((int)blockIdx.x >= lightBlocks) {
         const int b = ((int)blockIdx.x - lightBlocks) * 256 + threadIdx.x;
         if (b >= numBands) return;
         Frustum4 f;
-        if (b < Tx) { // tile column b: planes through the eye and the screen lines x = 16 b, x = 16 (b + 1)
-            frustum_from_rect(invProj, (float)(b * TILE), 0.0f, (float)((b + 1) * TILE), (float)(Ty * TILE), vpW, vpH, f);
+        if (b < groupsX) { // group column b (tile columns 4b .. 4b+3): planes through the eye and the screen lines x = 64 b, x = 64 (b + 1)
+            frustum_from_rect(invProj, (float)(b * GROUP * TILE), 0.0f, (float)(min((b + 1) * GROUP, Tx) * TILE), (float)(Ty * TILE), vpW, vpH, f);
             bandPlanes[2 * b + 0] = make_float4(f.n[0][0], f.n[0][1], f.n[0][2], 0.0f);
             bandPlanes[2 * b + 1] = make_float4(f.n[1][0], f.n[1][1], f.n[1][2], 0.0f);
-        } else {      // tile row: y = 16 ty, y = 16 (ty + 1)
-            const int ty = tileRow0 + (b - Tx);
-            frustum_from_rect(invProj, 0.0f, (float)(ty * TILE), (float)(Tx * TILE), (float)((ty + 1) * TILE), vpW, vpH, f);
+        } else {           // group row: the band's tile rows 4 gy .. 4 gy + 3
+            const int gy = b - groupsX;
+            const int ty = tileRow0 + gy * GROUP, tyEnd = tileRow0 + min((gy + 1) * GROUP, bandRows);
+            frustum_from_rect(invProj, 0.0f, (float)(ty * TILE), (float)(Tx * TILE), (float)(tyEnd * TILE), vpW, vpH, f);
             bandPlanes[2 * b + 0] = make_float4(f.n[2][0], f.n[2][1], f.n[2][2], 0.0f);
             bandPlanes[2 * b + 1] = make_float4(f.n[3][0], f.n[3][1], f.n[3][2], 0.0f);
         }
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void k1_tile_setup(Mat4 invProj, int vpW, int 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1b: band masks.  masks[b][word] bit k = "light 64*word + k may reach tile column / row b".
+// K1b: band masks.  masks[b][word] bit k = "light 64*word + k may reach group column / group row b".
 // A light is dropped from a band only if its sphere is entirely in front of the eye AND entirely outside one of the
 // band's two planes by more than the margin; directional lights and everything doubtful stay in.
 // ------------------------------------------------------------------------------------------------------------
@@ -272,8 +274,8 @@ __device__ __forceinline__ uint64_t lanemask_lt()
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1b2: candidate lists of 4x4-tile groups.  One 256-thread block per group ORs the group's 4 column masks, ORs its
-// 4 row masks, ANDs them (256 words = 16 384 lights per step) and writes the set bits -- ascending light index -- as a
+// K1b2: candidate lists of 4x4-tile groups.  One 256-thread block per group ANDs the masks of the group's column and
+// row (256 words = 16 384 lights per step) and writes the set bits -- ascending light index -- as a
 // contiguous list: a block-wide prefix sum of the words' popcounts gives every word its output position, so the
 // sparse-bits -> dense-list conversion is fully parallel.  Done once per 16 tiles, not per tile (profiles/r01: the
 // per-tile scalar version saturated the CUs' scalar ALUs; a per-group scalar version was tail-bound by cluster groups).
@@ -284,21 +286,15 @@ __global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* 
 {
     __shared__ uint32_t sW[4];
     const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tx0 = (g % groupsX) * GROUP, ty0 = (g / groupsX) * GROUP;
-    const unsigned long long* c[GROUP];
-    const unsigned long long* r[GROUP];
-#pragma unroll
-    for (int k = 0; k < GROUP; k++) {
-        c[k] = masks + (size_t)min(tx0 + k, Tx - 1) * words;              // clamped duplicates are harmless under OR
-        r[k] = masks + (size_t)(Tx + min(ty0 + k, bandRows - 1)) * words;
-    }
+    const unsigned long long* __restrict__ c = masks + (size_t)(g % groupsX) * words;
+    const unsigned long long* __restrict__ r = masks + (size_t)(groupsX + g / groupsX) * words;
     uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
     uint32_t base = 0; // entries written by earlier chunks (block-uniform)
     for (int w0 = 0; w0 < words; w0 += 256) {
         const int w = w0 + threadIdx.x;
         unsigned long long m = 0ull, dm = 0ull;
         if (w < words) {
-            m = ((c[0][w] | c[1][w]) | (c[2][w] | c[3][w])) & ((r[0][w] | r[1][w]) | (r[2][w] | r[3][w]));
+            m = c[w] & r[w];
             dm = dirWords[w];
         }
         // block-wide exclusive prefix sum of the popcounts: word order == light order
@@ -376,24 +372,26 @@ __device__ __forceinline__ void test_candidates(const TileCtx& t, const float4* 
 #define WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
 
 template <bool BRUTE>
-__global__ __launch_bounds__(1024) void k1_tile_cull(const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType, int N, int words,
-                                                     const float4* __restrict__ tileInfo, int Tx, int bandRows,
-                                                     const unsigned long long* __restrict__ masks,
-                                                     const uint32_t* __restrict__ groupCount, const uint32_t* __restrict__ groupList, int groupsX,
-                                                     uint32_t* __restrict__ tileNum, uint32_t* __restrict__ tileList)
+__global__ __launch_bounds__(256) void k1_tile_cull(const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType, int N, int words,
+                                                    const float4* __restrict__ tileInfo, int Tx, int bandRows,
+                                                    const unsigned long long* __restrict__ masks,
+                                                    const uint32_t* __restrict__ groupCount, const uint32_t* __restrict__ groupList, int groupsX,
+                                                    uint32_t* __restrict__ tileNum, uint32_t* __restrict__ tileList)
 {
-    // One 1024-thread block per 4x4-tile group, one wave per tile.  The group's candidate light records are gathered
-    // from global memory ONCE, by all 16 waves together, into LDS; every tile then streams them out of LDS.  (A
-    // per-tile gather measured 42 us of the 70 us kernel at 4K / 65 536 lights: 16x the scattered 16-byte requests.)
-    __shared__ float4 sLV[CAPG];                                    // 32 KB: candidate (view pos, radius)
-    __shared__ uint32_t sE[CAPG];                                   //  8 KB: candidate light index | directional << 31
-    __shared__ uint32_t sIdxAll[16][CAND];
-    __shared__ __attribute__((aligned(16))) float sImpAll[16][CAND];
-    const int g = blockIdx.x;
+    // One 256-thread block per 2x2 QUARTER of a 4x4-tile group, one wave per tile.  The group's candidate records are
+    // staged in LDS, CHUNK at a time, by the four waves together (list entries first, then the dependent 16-byte
+    // gathers, four of each in flight per thread), and every tile streams them out of LDS.  Four blocks per group, not
+    // one of sixteen waves: a cluster group (2048 candidates, four 196 -> 128 selections per SIMD) used to keep ONE CU
+    // busy for ~40 us while the rest of the chip idled -- the kernel's tail -- and at 26 KB of LDS six blocks fit a CU.
+    __shared__ float4 sLV[CHUNK];                                   // 16 KB: candidate (view pos, radius)
+    __shared__ uint32_t sE[CHUNK];                                  //  4 KB: candidate light index | directional << 31
+    __shared__ uint32_t sIdxAll[4][CAND];
+    __shared__ __attribute__((aligned(16))) float sImpAll[4][CAND];
+    const int g = blockIdx.x >> 2, quarter = blockIdx.x & 3;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* sIdx = sIdxAll[wave];
     float* sImp = sImpAll[wave];
-    const int tx = (g % groupsX) * GROUP + (wave & 3), tyLocal = (g / groupsX) * GROUP + (wave >> 2);
+    const int tx = (g % groupsX) * GROUP + (quarter & 1) * 2 + (wave & 1), tyLocal = (g / groupsX) * GROUP + (quarter >> 1) * 2 + (wave >> 1);
     const bool active = tx < Tx && tyLocal < bandRows;
     const int bandTile = tyLocal * Tx + tx;
     TileCtx t;
@@ -417,31 +415,40 @@ __global__ __launch_bounds__(1024) void k1_tile_cull(const float4* __restrict__ 
         const uint32_t gn = groupCount[g];
         if (gn != GROUP_OVERFLOW) {
             const uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
-            for (uint32_t i = threadIdx.x; i < gn; i += 1024u) {
-                const uint32_t e = list[i];
-                sE[i] = e;
-                sLV[i] = lightView[e & 0x7FFFFFFFu];
-            }
-            __syncthreads();
-            if (!active) return;
-            for (uint32_t base = 0; base < gn && count < CAND; base += 64u) {
-                const uint32_t i = base + (uint32_t)lane;
-                bool pass = false;
-                float impact = 0.0f;
-                uint32_t e = 0u;
-                if (i < gn) {
-                    e = sE[i];
-                    if (e & 0x80000000u) pass = true; // directional: always a candidate, impact 0 (:153-162)
-                    else pass = tile_test(t, sLV[i], impact);
+            for (uint32_t c0 = 0; c0 < gn; c0 += CHUNK) {
+                const uint32_t cn = min((uint32_t)CHUNK, gn - c0);
+                if (c0) __syncthreads(); // every wave is done with the previous chunk
+                uint32_t e[CHUNK / 256];
+                float4 lv[CHUNK / 256];
+#pragma unroll
+                for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; e[k] = i < cn ? list[c0 + i] : 0u; }
+#pragma unroll
+                for (int k = 0; k < CHUNK / 256; k++) lv[k] = lightView[e[k] & 0x7FFFFFFFu]; // (entry 0 for the unused slots: a valid address)
+#pragma unroll
+                for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; if (i < cn) { sE[i] = e[k]; sLV[i] = lv[k]; } }
+                __syncthreads();
+                if (active) {
+                    for (uint32_t base = 0; base < cn && count < CAND; base += 64u) {
+                        const uint32_t i = base + (uint32_t)lane;
+                        bool pass = false;
+                        float impact = 0.0f;
+                        uint32_t ee = 0u;
+                        if (i < cn) {
+                            ee = sE[i];
+                            if (ee & 0x80000000u) pass = true; // directional: always a candidate, impact 0 (:153-162)
+                            else pass = tile_test(t, sLV[i], impact);
+                        }
+                        wave_append(pass, ee & 0x7FFFFFFFu, impact, count, sIdx, sImp);
+                    }
                 }
-                wave_append(pass, e & 0x7FFFFFFFu, impact, count, sIdx, sImp);
             }
+            if (!active) return;
         } else {
         // overflowed group (very dense region / lights around the eye): every tile walks its own two masks
         if (!active) return;
         uint32_t* sQ = reinterpret_cast<uint32_t*>(sLV) + wave * QCAP; // sLV is unused on this path
-        const unsigned long long* __restrict__ col = masks + (size_t)tx * words;
-        const unsigned long long* __restrict__ row = masks + (size_t)(Tx + tyLocal) * words;
+        const unsigned long long* __restrict__ col = masks + (size_t)(g % groupsX) * words;
+        const unsigned long long* __restrict__ row = masks + (size_t)(groupsX + g / groupsX) * words;
         uint32_t qHead = 0, qTail = 0; // ring buffer indices (wave-uniform)
         unsigned long long next = (lane < words) ? (col[lane] & row[lane]) : 0ull;
         for (int w0 = 0; w0 < words && count < CAND; w0 += 64) {
@@ -659,7 +666,7 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
     const int bandBlocks = brute ? 0 : (L.numBands + 255) / 256;
     if (lightBlocks + bandBlocks > 0) {
         hipLaunchKernelGGL(k0_light_view, dim3(lightBlocks + bandBlocks), dim3(256), 0, s, view, dLights, N, lightBlocks, lightView, lightType,
-                           invProj, frame->viewportSize[0], frame->viewportSize[1], L.Tx, L.Ty, band->tileRowBegin, L.numBands, bandPlanes);
+                           invProj, frame->viewportSize[0], frame->viewportSize[1], L.Tx, L.Ty, band->tileRowBegin, L.bandRows, L.groupsX, L.numBands, bandPlanes);
         SAILOR_CHECK_LAUNCH(ctx, "k0_light_view");
     }
     const int stripsPerRow = (L.Tx + 15) / 16;
@@ -669,7 +676,7 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
     SAILOR_CHECK_LAUNCH(ctx, "k1_tile_setup");
 
     if (brute) {
-        hipLaunchKernelGGL(k1_tile_cull<true>, dim3(L.numGroups), dim3(1024), 0, s, lightView, lightType, N, L.words, tileInfo, L.Tx, L.bandRows, masks,
+        hipLaunchKernelGGL(k1_tile_cull<true>, dim3(L.numGroups * 4), dim3(256), 0, s, lightView, lightType, N, L.words, tileInfo, L.Tx, L.bandRows, masks,
                            groupCount, groupList, L.groupsX, tileNum, tileList);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull<brute>");
     } else {
@@ -680,7 +687,7 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
         SAILOR_CHECK_LAUNCH(ctx, "k1_band_masks");
         hipLaunchKernelGGL(k1_group_lists, dim3(L.numGroups), dim3(256), 0, s, masks, dirWords, L.words, L.Tx, L.bandRows, L.groupsX, groupCount, groupList);
         SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
-        hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.numGroups), dim3(1024), 0, s, lightView, lightType, N, L.words, tileInfo, L.Tx, L.bandRows, masks,
+        hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.numGroups * 4), dim3(256), 0, s, lightView, lightType, N, L.words, tileInfo, L.Tx, L.bandRows, masks,
                            groupCount, groupList, L.groupsX, tileNum, tileList);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
     }
@@ -713,7 +720,7 @@ int sailor_hip_light_cull_diagnostics(SailorHipContext* ctx, int32_t width, int3
     for (size_t i = 0; i < masks.size(); i++) {
         const uint64_t c = (uint64_t)__builtin_popcountll(masks[i]);
         bits += c;
-        if (i < (size_t)L.Tx * L.words) colBits += c;
+        if (i < (size_t)L.groupsX * L.words) colBits += c;
     }
     for (uint32_t c : counts) {
         if (c == GROUP_OVERFLOW) { over++; continue; }
