@@ -400,7 +400,7 @@ def main():
                 "frac_of_measured_copy_peak": shade_gbs / HBM_COPY_GBS,
                 "valu_sidebar": {"pixel_light_evals": evals, "gevals_per_s": evals / (shade_ms[0] * 1e-3) / 1e9,
                                  "note": "~110 fp32 ops per (pixel,light): VALU-bound once mean list length exceeds ~10 (SURVEY.md 7, hard part 2)"},
-                "cull": {"kernels": "k0_light_view+k1_*", "avg_ms": cull_ms[0], "median_ms": cull_ms[1], "bytes": b_cull,
+                "cull": {"kernels": "k01_prepare+k1_*", "avg_ms": cull_ms[0], "median_ms": cull_ms[1], "bytes": b_cull,
                          "achieved_gbs": b_cull / (cull_ms[0] * 1e-3) / 1e9, "frac": b_cull / (cull_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
     exchange_info = None

@@ -6,6 +6,7 @@
 // re-reads and re-transforms every light, appends with LDS atomics, bubble-sorts on one thread and allocates
 // output space with a global atomic.  Here:
 //
+//   (k01_prepare runs the next two in one launch: they are independent)
 //   k0_light_view      once per light: view-space position + radius into a float4 SoA (same fp32 op sequence as
 //                      ComputeLightCulling.shader:164-169, so bits are identical), light type into a u32 SoA
 //   k1_tile_setup      streaming pass over the linear-depth image (the only large HBM stream of the cull):
@@ -126,13 +127,13 @@ __device__ void frustum_from_rect(const Mat4& invProj, float x0, float y0, float
 // K0: ComputeLightCulling.shader:164-169 hoisted out of the per-tile loop (it does not depend on the tile).
 // The tail blocks of the same launch build the conservative band planes (one thread per column / row of tile groups).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k0_light_view(Mat4 view, const SailorLightShaderData* __restrict__ lights, int N, int lightBlocks,
-                                                      float4* __restrict__ lightView, uint32_t* __restrict__ lightType,
-                                                      Mat4 invProj, int vpW, int vpH, int Tx, int Ty, int tileRow0, int bandRows, int groupsX, int numBands,
-                                                      float4* __restrict__ bandPlanes)
+__device__ __forceinline__ void k0_light_view(int block, const Mat4& view, const SailorLightShaderData* __restrict__ lights, int N, int lightBlocks,
+                                              float4* __restrict__ lightView, uint32_t* __restrict__ lightType,
+                                              const Mat4& invProj, int vpW, int vpH, int Tx, int Ty, int tileRow0, int bandRows, int groupsX, int numBands,
+                                              float4* __restrict__ bandPlanes)
 {
-    if ((int)blockIdx.x >= lightBlocks) {
-        const int b = ((int)blockIdx.x - lightBlocks) * 256 + threadIdx.x;
+    if (block >= lightBlocks) {
+        const int b = (block - lightBlocks) * 256 + threadIdx.x;
         if (b >= numBands) return;
         Frustum4 f;
         if (b < groupsX) { // group column b (tile columns 4b .. 4b+3): planes through the eye and the screen lines x = 64 b, x = 64 (b + 1)
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void k0_light_view(Mat4 view, const SailorLigh
         }
         return;
     }
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = block * 256 + threadIdx.x;
     if (j >= N) return;
     const SailorLightShaderData* L = lights + j;
     const float x = L->worldPosition[0], y = L->worldPosition[1], z = L->worldPosition[2];
@@ -172,12 +173,12 @@ __device__ __forceinline__ uint32_t depth_bits(const float* __restrict__ depth, 
     return __float_as_uint(depth[(size_t)(row - bandRow0) * W + col]);
 }
 
-__global__ __launch_bounds__(256) void k1_tile_setup(Mat4 invProj, int vpW, int vpH, const float* __restrict__ depth, int W, int H,
-                                                      int Tx, int tileRow0, int bandRow0, int stripsPerRow, int vecOK, float4* __restrict__ tileInfo)
+__device__ __forceinline__ void k1_tile_setup(int block, const Mat4& invProj, int vpW, int vpH, const float* __restrict__ depth, int W, int H,
+                                              int Tx, int tileRow0, int bandRow0, int stripsPerRow, int vecOK, float4* __restrict__ tileInfo)
 {
     __shared__ uint32_t sMin[4][16], sMax[4][16];
-    const int strip = blockIdx.x % stripsPerRow;
-    const int tyLocal = blockIdx.x / stripsPerRow;
+    const int strip = block % stripsPerRow;
+    const int tyLocal = block / stripsPerRow;
     const int ty = tileRow0 + tyLocal;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gx0 = strip * 256 + lane * 4; // 4 pixels per lane, 4 lanes per tile
@@ -226,6 +227,26 @@ __global__ __launch_bounds__(256) void k1_tile_setup(Mat4 invProj, int vpW, int 
             o[3] = make_float4(f.n[3][0], f.n[3][1], f.n[3][2], zFar);
         }
     }
+}
+
+// One launch for the two independent preparation passes: blocks [0, setupBlocks) stream the depth image (K1a, the long
+// pole: they are dispatched first), the rest transform the lights and build the band planes (K0).
+struct PrepareArgs {
+    Mat4 view, invProj;
+    const SailorLightShaderData* lights;
+    const float* depth;
+    float4* lightView; uint32_t* lightType; float4* tileInfo; float4* bandPlanes;
+    int N, lightBlocks, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands, stripsPerRow, vecOK;
+};
+
+__global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
+{
+    const int b = (int)blockIdx.x;
+    if (b < a.setupBlocks)
+        k1_tile_setup(b, a.invProj, a.vpW, a.vpH, a.depth, a.W, a.H, a.Tx, a.tileRow0, a.bandRow0, a.stripsPerRow, a.vecOK, a.tileInfo);
+    else
+        k0_light_view(b - a.setupBlocks, a.view, a.lights, a.N, a.lightBlocks, a.lightView, a.lightType, a.invProj, a.vpW, a.vpH, a.Tx, a.Ty, a.tileRow0,
+                      a.bandRows, a.groupsX, a.numBands, a.bandPlanes);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -664,16 +685,18 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
 
     const int lightBlocks = (N + 255) / 256;
     const int bandBlocks = brute ? 0 : (L.numBands + 255) / 256;
-    if (lightBlocks + bandBlocks > 0) {
-        hipLaunchKernelGGL(k0_light_view, dim3(lightBlocks + bandBlocks), dim3(256), 0, s, view, dLights, N, lightBlocks, lightView, lightType,
-                           invProj, frame->viewportSize[0], frame->viewportSize[1], L.Tx, L.Ty, band->tileRowBegin, L.bandRows, L.groupsX, L.numBands, bandPlanes);
-        SAILOR_CHECK_LAUNCH(ctx, "k0_light_view");
-    }
     const int stripsPerRow = (L.Tx + 15) / 16;
-    const int vecOK = (((uintptr_t)dLinearDepth & 15) == 0 && (W & 3) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(k1_tile_setup, dim3(stripsPerRow * L.bandRows), dim3(256), 0, s, invProj, frame->viewportSize[0], frame->viewportSize[1],
-                       dLinearDepth, W, H, L.Tx, band->tileRowBegin, band->fbRowBegin, stripsPerRow, vecOK, tileInfo);
-    SAILOR_CHECK_LAUNCH(ctx, "k1_tile_setup");
+    PrepareArgs pa;
+    pa.view = view; pa.invProj = invProj;
+    pa.lights = dLights; pa.depth = dLinearDepth;
+    pa.lightView = lightView; pa.lightType = lightType; pa.tileInfo = tileInfo; pa.bandPlanes = bandPlanes;
+    pa.N = N; pa.lightBlocks = lightBlocks; pa.setupBlocks = stripsPerRow * L.bandRows;
+    pa.vpW = frame->viewportSize[0]; pa.vpH = frame->viewportSize[1]; pa.W = W; pa.H = H; pa.Tx = L.Tx; pa.Ty = L.Ty;
+    pa.tileRow0 = band->tileRowBegin; pa.bandRow0 = band->fbRowBegin; pa.bandRows = L.bandRows; pa.groupsX = L.groupsX; pa.numBands = L.numBands;
+    pa.stripsPerRow = stripsPerRow;
+    pa.vecOK = (((uintptr_t)dLinearDepth & 15) == 0 && (W & 3) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k01_prepare, dim3(pa.setupBlocks + lightBlocks + bandBlocks), dim3(256), 0, s, pa);
+    SAILOR_CHECK_LAUNCH(ctx, "k01_prepare");
 
     if (brute) {
         hipLaunchKernelGGL(k1_tile_cull<true>, dim3(L.numGroups * 4), dim3(256), 0, s, lightView, lightType, N, L.words, tileInfo, L.Tx, L.bandRows, masks,
