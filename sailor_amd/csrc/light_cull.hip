@@ -354,38 +354,45 @@ struct TileCtx {
 };
 
 // Math.glsl:224-239 SphereFrustumOverlaps + ComputeLightCulling.shader:187 impact
-__device__ __forceinline__ bool tile_test(const TileCtx& t, const float4 lv, float& impact)
+__device__ __forceinline__ bool tile_test(const TileCtx& t, const float4 lv)
 {
     const float r = lv.w;
     if (lv.z - r > t.zNear || lv.z + r < t.zFar) return false;
 #pragma unroll
     for (int k = 0; k < 4; k++)
         if (dot3f(t.n[k][0], t.n[k][1], t.n[k][2], lv.x, lv.y, lv.z) < -r) return false;
-    const float dx = lv.x - t.cx, dy = lv.y - t.cy, dz = lv.z - t.cz;
-    impact = sqrtf(dot3f(dx, dy, dz, dx, dy, dz));
     return true;
 }
 
-__device__ __forceinline__ void wave_append(bool pass, uint32_t j, float impact, uint32_t& count, uint32_t* sIdx, float* sImp)
+// ComputeLightCulling.shader:187 impact = distance(light, frustum centre).  Only the 196 -> 128 selection reads it, so it
+// is computed afterwards, for the <= 196 candidates of the few tiles that need a selection, not for every tested light.
+__device__ __forceinline__ float tile_impact(const TileCtx& t, const float4 lv)
+{
+    const float dx = lv.x - t.cx, dy = lv.y - t.cy, dz = lv.z - t.cz;
+    return sqrtf(dot3f(dx, dy, dz, dx, dy, dz));
+}
+
+// j carries the light index, bit 31 = directional (impact 0, :153-162)
+__device__ __forceinline__ void wave_append(bool pass, uint32_t j, uint32_t& count, uint32_t* sIdx)
 {
     const uint64_t mask = __ballot(pass);
     const uint32_t pos = count + (uint32_t)__popcll(mask & lanemask_lt());
-    if (pass && pos < CAND) { sIdx[pos] = j; sImp[pos] = impact; }
+    if (pass && pos < CAND) sIdx[pos] = j;
     count += (uint32_t)__popcll(mask);
 }
 
 // exact test of one candidate per lane (ascending light index across lanes), ordered append
 __device__ __forceinline__ void test_candidates(const TileCtx& t, const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType,
-                                                bool have, uint32_t j, uint32_t& count, uint32_t* sIdx, float* sImp)
+                                                bool have, uint32_t j, uint32_t& count, uint32_t* sIdx)
 {
     bool pass = false;
-    float impact = 0.0f;
+    uint32_t dir = 0u;
     if (have) {
         const float4 lv = lightView[j];
-        if (lightType[j] == 0u) pass = true; // directional: always a candidate, impact 0 (:153-162)
-        else pass = tile_test(t, lv, impact);
+        if (lightType[j] == 0u) { pass = true; dir = 0x80000000u; } // directional: always a candidate, impact 0 (:153-162)
+        else pass = tile_test(t, lv);
     }
-    wave_append(pass, j, impact, count, sIdx, sImp);
+    wave_append(pass, j | dir, count, sIdx);
 }
 
 // LDS hand-off between the lanes of ONE wave: the wave's DS operations execute in order, so only the compiler has to be
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const float4* __restrict__ l
         if (!active) return;
         for (int base = 0; base < N && count < CAND; base += 64) {
             const int j = base + lane;
-            test_candidates(t, lightView, lightType, j < N, (uint32_t)j, count, sIdx, sImp);
+            test_candidates(t, lightView, lightType, j < N, (uint32_t)j, count, sIdx);
         }
     } else {
         const uint32_t gn = groupCount[g];
@@ -452,14 +459,13 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const float4* __restrict__ l
                     for (uint32_t base = 0; base < cn && count < CAND; base += 64u) {
                         const uint32_t i = base + (uint32_t)lane;
                         bool pass = false;
-                        float impact = 0.0f;
                         uint32_t ee = 0u;
                         if (i < cn) {
                             ee = sE[i];
                             if (ee & 0x80000000u) pass = true; // directional: always a candidate, impact 0 (:153-162)
-                            else pass = tile_test(t, sLV[i], impact);
+                            else pass = tile_test(t, sLV[i]);
                         }
-                        wave_append(pass, ee & 0x7FFFFFFFu, impact, count, sIdx, sImp);
+                        wave_append(pass, ee, count, sIdx);
                     }
                 }
             }
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const float4* __restrict__ l
                 if (qTail - qHead >= 64u) { // a full wave of candidates is waiting: exact-test them
                     WAVE_SYNC();
                     const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
-                    test_candidates(t, lightView, lightType, true, j, count, sIdx, sImp);
+                    test_candidates(t, lightView, lightType, true, j, count, sIdx);
                     qHead += 64u;
                     WAVE_SYNC();
                 }
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const float4* __restrict__ l
         if (qTail != qHead && count < CAND) { // final partial round (< 64 pending)
             const uint32_t n = qTail - qHead;
             const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
-            test_candidates(t, lightView, lightType, (uint32_t)lane < n, j, count, sIdx, sImp);
+            test_candidates(t, lightView, lightType, (uint32_t)lane < n, j, count, sIdx);
         }
         }
     }
@@ -511,8 +517,12 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const float4* __restrict__ l
     uint32_t* out = tileList + (size_t)bandTile * KEEP;
     if (n <= KEEP) {
         // :235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]
-        for (uint32_t i = lane; i < num; i += 64) out[i] = sIdx[n - 1 - i];
+        for (uint32_t i = lane; i < num; i += 64) out[i] = sIdx[n - 1 - i] & 0x7FFFFFFFu;
     } else {
+        for (uint32_t k = lane; k < n; k += 64) {
+            const uint32_t e = sIdx[k];
+            sImp[k] = (e & 0x80000000u) ? 0.0f : tile_impact(t, lightView[e]);
+        }
         // :198-225 partial bubble sort == rank under (impact ascending, candidate position descending); keep rank < 128
         // each lane ranks up to 4 candidates (k = lane + 64 i) against all n, 4 impacts per LDS read.  Candidates q of
         // an earlier 64-block all have q < k (count g < f), of a later block all have q > k (count g <= f); only the
@@ -548,7 +558,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const float4* __restrict__ l
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t k = lane + 64u * i;
-            if (k < n && rank[i] < KEEP) out[rank[i]] = sIdx[k];
+            if (k < n && rank[i] < KEEP) out[rank[i]] = sIdx[k] & 0x7FFFFFFFu;
         }
     }
     if (lane == 0) tileNum[bandTile] = num;
