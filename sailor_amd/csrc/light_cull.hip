@@ -40,7 +40,7 @@
 #define GROUP 4              // k1_group_lists: tiles per group edge (4x4 tiles share one candidate list)
 #define CAPG 2048            // entries per group list; a denser group falls back to walking the masks per tile
 #define GROUP_OVERFLOW 0xFFFFFFFFu
-#define CHUNK 1024           // group candidates staged in LDS per step of k1_tile_cull
+#define CHUNK 512            // group candidates staged in LDS per step of k1_tile_cull (16 KB of LDS per block: 8 blocks per CU)
 
 struct CullLayout {
     int Tx, Ty, bandRows, bandTiles, numBands, words, sumBlocks, groupsX, groupsY, numGroups;
@@ -440,18 +440,25 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const float4* __restrict__ l
             test_candidates(t, lightView, lightType, j < N, (uint32_t)j, count, sIdx);
         }
     } else {
+        // The kernel is bound by the latency of its dependent loads (a block has ~1 us of work behind 2-3 round trips to
+        // L2 / HBM), so the first chunk's list entries are requested together with the group's count, not after it:
+        // slots past the count hold stale entries of an earlier frame or nothing at all, hence the clamp to N - 1.
+        const uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
+        uint32_t e[CHUNK / 256];
+#pragma unroll
+        for (int k = 0; k < CHUNK / 256; k++) e[k] = list[threadIdx.x + 256u * k];
         const uint32_t gn = groupCount[g];
         if (gn != GROUP_OVERFLOW) {
-            const uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
             for (uint32_t c0 = 0; c0 < gn; c0 += CHUNK) {
                 const uint32_t cn = min((uint32_t)CHUNK, gn - c0);
-                if (c0) __syncthreads(); // every wave is done with the previous chunk
-                uint32_t e[CHUNK / 256];
+                if (c0) {
+                    __syncthreads(); // every wave is done with the previous chunk
+#pragma unroll
+                    for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; e[k] = i < cn ? list[c0 + i] : 0u; }
+                }
                 float4 lv[CHUNK / 256];
 #pragma unroll
-                for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; e[k] = i < cn ? list[c0 + i] : 0u; }
-#pragma unroll
-                for (int k = 0; k < CHUNK / 256; k++) lv[k] = lightView[e[k] & 0x7FFFFFFFu]; // (entry 0 for the unused slots: a valid address)
+                for (int k = 0; k < CHUNK / 256; k++) lv[k] = lightView[min(e[k] & 0x7FFFFFFFu, (uint32_t)(N - 1))];
 #pragma unroll
                 for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; if (i < cn) { sE[i] = e[k]; sLV[i] = lv[k]; } }
                 __syncthreads();
