@@ -169,6 +169,31 @@ def ecs_baseline(ctx, count: int, steps: int):
             "cpu_allcores_mentities_per_s": count / tn / 1e6, "cpu_sse_cull_only_mboxes_per_s_1thread": n4 / t_sse / 1e6, "cpu_cores": cores, "cpu_model": _cpu_model(), "kind": "port"}
 
 
+def linearize_block(ctx, frame, fp, d_lights, steps: int):
+    """the LinearizeDepth pass in front of K1, standalone (8 algorithmic bytes per pixel) and folded into
+    the cull's depth pass (SAILOR_CULL_RAW_DEPTH: no extra pass, no extra bytes), next to the oracle on one host core."""
+    from oracle import oracle
+    from sailor_amd import _lib as L
+    from sailor_amd.forward_plus import linearize_depth
+    cam, W, H, N = frame.cam, frame.cam.width, frame.cam.height, len(frame.lights)
+    zn = cam.frame.cameraZNearZFar[0]
+    raw = synth.make_raw_depth(frame.depth, zn)
+    d_raw = torch.from_numpy(raw).to(ctx.device)
+    d_lin = torch.empty_like(d_raw)
+    for _ in range(3):
+        linearize_depth(ctx, cam.frame, d_raw, d_lin)
+    lin_ms = event_ms(lambda: linearize_depth(ctx, cam.frame, d_raw, d_lin), steps)
+    two = event_ms(lambda: (linearize_depth(ctx, cam.frame, d_raw, d_lin), fp.cull(cam.frame, d_lights, N, d_lin)), steps)
+    fused = event_ms(lambda: fp.cull(cam.frame, d_lights, N, d_raw, L.CULL_RAW_DEPTH), steps)
+    t0 = time.perf_counter()
+    oracle.linearize_depth(zn, raw)
+    t_cpu = time.perf_counter() - t0
+    b = 8 * W * H
+    return {"pixels": W * H, "gpu_ms": lin_ms[1], "gpu_hbm_gbs": b / lin_ms[1] / 1e6, "gpu_hbm_frac": b / lin_ms[1] / 1e6 / HBM_PEAK_GBS,
+            "linearize_then_cull_ms": two[1], "cull_on_raw_depth_ms": fused[1],
+            "cpu_1thread_mpixels_per_s": W * H / t_cpu / 1e6, "kind": "port"}
+
+
 def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev):
     """Single-GPU estimate of the G-way split: per-band step time (hipGraph replay), equal vs cost-balanced bands."""
     from sailor_amd import dist as sdist
@@ -429,6 +454,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frame, args.cpu_sample_tile_rows)
             out["ecs_sweep"] = ecs_baseline(ctx, 1 << 20, 20)
+            out["linearize_depth"] = linearize_block(ctx, frame, fp, d_lights, 30)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

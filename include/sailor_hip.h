@@ -205,6 +205,10 @@ SAILOR_HIP_API int sailor_hip_band_for_rank(int32_t width, int32_t height, int32
  */
 #define SAILOR_CULL_DEFAULT 0u
 #define SAILOR_CULL_BRUTE_FORCE 1u /* skip the conservative macro-tile pre-filter (same results, for validation) */
+#define SAILOR_CULL_RAW_DEPTH 2u   /* dLinearDepth holds the RAW reversed-Z depth attachment: the depth pass linearises it on
+                                      the fly (sailor_hip_linearize_depth's arithmetic, same bits) -- the LinearizeDepth node's
+                                      full-screen pass and its 8 bytes per pixel disappear.  x -> zNear / x is monotone, so
+                                      the tile's min / max are taken on the raw bits and only two values per tile are divided */
 
 SAILOR_HIP_API size_t sailor_hip_light_cull_workspace_size(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band);
 SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
@@ -213,6 +217,18 @@ SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
                                          SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity,
                                          void* dWorkspace, size_t workspaceBytes,
                                          const SailorBand* band, uint32_t flags);
+
+/* ---- LinearizeDepth: the pass immediately before K1 ---------------------------------------
+ * Replaces: the full-screen draw of LinearizeDepthNode::Process (FrameGraph/LinearizeDepthNode.cpp:22-109) with the
+ * fragment shader Content/Shaders/LinearizeDepth.shader:61-73 under its REVERSE_Z_INF_FAR_PLANE define (:6):
+ *   linearDepth = -frame.cameraZNearZFar.x / depth;  outColor = vec4(-linearDepth)
+ * i.e. out = zNear / raw with one IEEE division (both negations are exact).  The quad's flipped texcoord (:49) and the
+ * driver's flipped viewport (GraphicsDriver/Vulkan/VulkanDevice.cpp:681) cancel: output row r reads depth row r.
+ *   dRawDepth / dLinearDepth : device, float32, `rows` x `width`, row-major (any contiguous run of framebuffer rows)
+ * raw = 0 (nothing drawn, far plane at infinity) gives +inf, as in the reference.
+ */
+SAILOR_HIP_API int sailor_hip_linearize_depth(SailorHipContext* ctx, const SailorUboFrameData* frame,
+                                              const float* dRawDepth, float* dLinearDepth, int32_t width, int32_t rows);
 
 /* Tuning diagnostics (synchronises): out8 = {numBands, mask bits set, numGroups, sum of group list lengths, overflowed
  * groups, longest group list, 64-bit words per band, bits set in the column masks} for the intermediate pre-filter state

@@ -38,6 +38,7 @@ def lib() -> C.CDLL:
         L.oracle_perspective_rh_reversed_z.argtypes = [C.c_float] * 4 + [C.c_void_p]
         L.oracle_extract_frustum_planes.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.oracle_csm_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.oracle_linearize_depth.argtypes = [C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
         _lib = L
     return _lib
 
@@ -123,6 +124,14 @@ def ecs_sweep(trs: np.ndarray, parent: np.ndarray, local_aabb: np.ndarray, plane
     visibility = np.zeros((n + 63) // 64, np.uint64) if visibility is None else visibility
     lib().oracle_ecs_sweep(C.c_uint32(begin), C.c_uint32(end), _p(trs), _p(parent), _p(local_aabb), _p(planes), _p(world), _p(world_aabb), _p(visibility))
     return world, world_aabb, visibility
+
+
+def linearize_depth(z_near: float, raw: np.ndarray) -> np.ndarray:
+    """LinearizeDepth.shader:61-73 (REVERSE_Z_INF_FAR_PLANE) over a raw reversed-Z depth image; same shape back."""
+    raw = np.ascontiguousarray(raw, np.float32)
+    out = np.empty_like(raw)
+    lib().oracle_linearize_depth(C.c_float(z_near), _p(raw), C.c_size_t(raw.size), _p(out))
+    return out
 
 
 def mesh_frustum_cull(frame, instances: np.ndarray) -> np.ndarray:

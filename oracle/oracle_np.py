@@ -105,7 +105,20 @@ def light_cull(frame_bytes, W: int, H: int, lights: np.ndarray, depth: np.ndarra
                 impact = np.sqrt((dx * dx + dy * dy) + dz * dz).astype(F)
                 impact[ltype[cand] == 0] = F(0.0)
             k = len(cand)
-            if k > KEEP:
+            if k > KEEP and np.isnan(impact).any():
+                # no total order (sky tile: depth +inf -> NaN centre): the shader's partial bubble sort literally,
+                # ComputeLightCulling.shader:198-225 -- a compare next to a NaN is false, so NaNs never move
+                cand = cand.copy(); imp = impact.copy()
+                left = KEEP
+                for i in range(k - 1):
+                    for j in range(k - i - 1):
+                        if imp[j] < imp[j + 1]:
+                            imp[j], imp[j + 1] = imp[j + 1], imp[j]
+                            cand[j], cand[j + 1] = cand[j + 1], cand[j]
+                    left -= 1
+                    if left == 0:
+                        break
+            elif k > KEEP:
                 order = np.argsort(-impact, kind="stable")   # descending impact, ties keep original order
                 cand = cand[order]
             num = min(k, KEEP)

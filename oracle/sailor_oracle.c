@@ -398,7 +398,12 @@ ORACLE_API void oracle_select_emit(const uint32_t* candIdx, const float* candImp
     uint32_t idx[CAND]; float imp[CAND];
     memcpy(idx, candIdx, n * 4); memcpy(imp, candImpact, n * 4);
     uint32_t num = n < KEEP ? n : KEEP;
-    if (n > KEEP && !literal) {
+    int anyNaN = 0;
+    for (uint32_t k = 0; k < n; k++) anyNaN |= (imp[k] != imp[k]);
+    /* The closed form presumes a total order.  A NaN impact (a tile with nothing drawn: depth +inf -> frustum centre NaN;
+     * or a non-finite light) has none -- the shader's compare at :207 is false next to it -- so such tiles always take
+     * the literal sort. */
+    if (n > KEEP && !literal && !anyNaN) {
         select_closed_form(idx, imp, n, outList);
     } else {
         if (n > KEEP) select_literal_bubble(idx, imp, n);
@@ -924,6 +929,19 @@ static inline int overlaps_aabb(const float* planes, const float* aabb)
     return inside;
 }
 ORACLE_API int oracle_overlaps_aabb(const float* planes, const float* aabb) { return overlaps_aabb(planes, aabb); }
+
+/* Content/Shaders/LinearizeDepth.shader:61-73 with REVERSE_Z_INF_FAR_PLANE (:6), drawn by
+ * FrameGraph/LinearizeDepthNode.cpp:22-109 over the whole target: the texcoord flip of the quad (:49) and the flipped
+ * viewport (GraphicsDriver/Vulkan/VulkanDevice.cpp:681) cancel, so texel (x, r) of the target reads texel (x, r) of
+ * the depth attachment.  `invVss` / `zvs` (:65-67) are dead code. */
+ORACLE_API void oracle_linearize_depth(float zNear, const float* raw, size_t count, float* out)
+{
+    for (size_t i = 0; i < count; i++) {
+        const float depth = raw[i];
+        const float linearDepth = -zNear / depth; /* :70 */
+        out[i] = -linearDepth;                    /* :74 outColor = vec4(-linearDepth) */
+    }
+}
 
 /* Math/Bounds.cpp:211-243 Frustum::OverlapsSphere / ContainsSphere (scalar) */
 ORACLE_API int oracle_overlaps_sphere(const float* planes, const float* sphere)

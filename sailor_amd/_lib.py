@@ -22,6 +22,7 @@ NUM_CASCADES = 4     # Constants.glsl:23
 CTX_OWN_STREAM = 1
 CULL_DEFAULT = 0
 CULL_BRUTE_FORCE = 1
+CULL_RAW_DEPTH = 2
 
 SHADOWMAP_R16F = 0
 SHADOWMAP_RGBA32F = 1
@@ -92,6 +93,7 @@ SIGNATURES = {
     "sailor_hip_light_cull_workspace_size": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band)]),
     "sailor_hip_light_cull": (C.c_int, [_P, C.POINTER(UboFrameData), C.POINTER(LightCullPushConstants), _P, _P, _P, _P, C.c_size_t,
                                         _P, C.c_size_t, C.POINTER(Band), C.c_uint32]),
+    "sailor_hip_linearize_depth": (C.c_int, [_P, C.POINTER(UboFrameData), _P, _P, C.c_int32, C.c_int32]),
     "sailor_hip_light_cull_diagnostics": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band), _P, C.POINTER(C.c_uint64)]),
     "sailor_hip_light_grid_rebase": (C.c_int, [_P, _P, C.c_int32, C.c_uint32]),
     "sailor_hip_shade": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_size_t, _P, C.c_int32, _P, _P, C.POINTER(CsmDesc), _P, C.POINTER(Band)]),

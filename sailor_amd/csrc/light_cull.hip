@@ -174,7 +174,8 @@ __device__ __forceinline__ uint32_t depth_bits(const float* __restrict__ depth, 
 }
 
 __device__ __forceinline__ void k1_tile_setup(int block, const Mat4& invProj, int vpW, int vpH, const float* __restrict__ depth, int W, int H,
-                                              int Tx, int tileRow0, int bandRow0, int stripsPerRow, int vecOK, float4* __restrict__ tileInfo)
+                                              int Tx, int tileRow0, int bandRow0, int stripsPerRow, int vecOK, int rawDepth, float zNearCam,
+                                              float4* __restrict__ tileInfo)
 {
     __shared__ uint32_t sMin[4][16], sMax[4][16];
     const int strip = block % stripsPerRow;
@@ -215,6 +216,13 @@ __device__ __forceinline__ void k1_tile_setup(int block, const Mat4& invProj, in
             const uint32_t bmn = min(min(sMin[0][i], sMin[1][i]), min(sMin[2][i], sMin[3][i]));
             const uint32_t bmx = max(max(sMax[0][i], sMax[1][i]), max(sMax[2][i], sMax[3][i]));
             float zFar = __uint_as_float(bmx), zNear = __uint_as_float(bmn);
+            if (rawDepth) {
+                // SAILOR_CULL_RAW_DEPTH: the image holds the reversed-Z attachment.  x -> fl(zNear / x) is monotone
+                // non-increasing on x >= 0, so the largest linear depth of the tile is the linearised smallest raw value
+                // and vice versa -- bit for bit what min / max over the linearised texels give (LinearizeDepth.shader:70,74).
+                const float lo = -(-zNearCam / zFar), hi = -(-zNearCam / zNear);
+                zNear = lo; zFar = hi;
+            }
             const float diff = zFar - zNear; // "Add extra bounds" (:174-177): swaps near and far in fp32
             zFar -= diff;
             zNear += diff;
@@ -236,14 +244,15 @@ struct PrepareArgs {
     const SailorLightShaderData* lights;
     const float* depth;
     float4* lightView; uint32_t* lightType; float4* tileInfo; float4* bandPlanes;
-    int N, lightBlocks, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands, stripsPerRow, vecOK;
+    int N, lightBlocks, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands, stripsPerRow, vecOK, rawDepth;
+    float zNearCam;
 };
 
 __global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
 {
     const int b = (int)blockIdx.x;
     if (b < a.setupBlocks)
-        k1_tile_setup(b, a.invProj, a.vpW, a.vpH, a.depth, a.W, a.H, a.Tx, a.tileRow0, a.bandRow0, a.stripsPerRow, a.vecOK, a.tileInfo);
+        k1_tile_setup(b, a.invProj, a.vpW, a.vpH, a.depth, a.W, a.H, a.Tx, a.tileRow0, a.bandRow0, a.stripsPerRow, a.vecOK, a.rawDepth, a.zNearCam, a.tileInfo);
     else
         k0_light_view(b - a.setupBlocks, a.view, a.lights, a.N, a.lightBlocks, a.lightView, a.lightType, a.invProj, a.vpW, a.vpH, a.Tx, a.Ty, a.tileRow0,
                       a.bandRows, a.groupsX, a.numBands, a.bandPlanes);
@@ -526,9 +535,40 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const float4* __restrict__ l
         // :235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]
         for (uint32_t i = lane; i < num; i += 64) out[i] = sIdx[n - 1 - i] & 0x7FFFFFFFu;
     } else {
+        bool nanHere = false;
         for (uint32_t k = lane; k < n; k += 64) {
             const uint32_t e = sIdx[k];
-            sImp[k] = (e & 0x80000000u) ? 0.0f : tile_impact(t, lightView[e]);
+            const float imp = (e & 0x80000000u) ? 0.0f : tile_impact(t, lightView[e]);
+            sImp[k] = imp;
+            nanHere = nanHere || imp != imp;
+        }
+        if (__ballot(nanHere) != 0ull) {
+            // A NaN impact (tile with nothing drawn: depth +inf makes the frustum centre NaN; or a non-finite light) has no
+            // rank: the shader's compare-and-swap (:207) is simply false next to it.  Literal semantics then: if no adjacent
+            // pair can swap at all -- the sky-tile case, every impact NaN or a directional 0 -- the bubble sort is a no-op;
+            // otherwise one lane replays it (NaNs act as walls; rare and slow, but the reference's answer).
+            WAVE_SYNC();
+            bool swapHere = false;
+            for (uint32_t k = lane; k + 1 < n; k += 64) swapHere = swapHere || sImp[k] < sImp[k + 1];
+            if (__ballot(swapHere) != 0ull) {
+                if (lane == 0) {
+                    uint32_t numSorted = KEEP;
+                    for (uint32_t i = 0; i + 1 < n; i++) {
+                        for (uint32_t j = 0; j < n - i - 1; j++) {
+                            const float a = sImp[j], b = sImp[j + 1];
+                            if (a < b) {
+                                sImp[j] = b; sImp[j + 1] = a;
+                                const uint32_t x = sIdx[j]; sIdx[j] = sIdx[j + 1]; sIdx[j + 1] = x;
+                            }
+                        }
+                        if (--numSorted == 0) break;
+                    }
+                }
+                WAVE_SYNC();
+            }
+            for (uint32_t i = lane; i < num; i += 64) out[i] = sIdx[n - 1 - i] & 0x7FFFFFFFu; // :235-238
+            if (lane == 0) tileNum[bandTile] = num;
+            return;
         }
         // :198-225 partial bubble sort == rank under (impact ascending, candidate position descending); keep rank < 128
         // each lane ranks up to 4 candidates (k = lane + 64 i) against all n, 4 impacts per LDS read.  Candidates q of
@@ -712,6 +752,8 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
     pa.tileRow0 = band->tileRowBegin; pa.bandRow0 = band->fbRowBegin; pa.bandRows = L.bandRows; pa.groupsX = L.groupsX; pa.numBands = L.numBands;
     pa.stripsPerRow = stripsPerRow;
     pa.vecOK = (((uintptr_t)dLinearDepth & 15) == 0 && (W & 3) == 0) ? 1 : 0;
+    pa.rawDepth = (flags & SAILOR_CULL_RAW_DEPTH) ? 1 : 0;
+    pa.zNearCam = frame->cameraZNearZFar[0];
     hipLaunchKernelGGL(k01_prepare, dim3(pa.setupBlocks + lightBlocks + bandBlocks), dim3(256), 0, s, pa);
     SAILOR_CHECK_LAUNCH(ctx, "k01_prepare");
 
@@ -736,6 +778,42 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
     hipLaunchKernelGGL(k1_pack, dim3((L.bandTiles + 3) / 4), dim3(256), 0, s, tileNum, tilePrefix, blockSums, L.sumBlocks, tileList, L.bandTiles, dLightsGrid,
                        dCulledLights, (uint32_t)(culledCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : culledCapacity));
     SAILOR_CHECK_LAUNCH(ctx, "k1_pack");
+    return SAILOR_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LinearizeDepth: Content/Shaders/LinearizeDepth.shader:61-73 under REVERSE_Z_INF_FAR_PLANE, as
+// drawn by FrameGraph/LinearizeDepthNode.cpp:22-109.  Pure stream: 4 bytes in, 4 bytes out per texel, float4 per lane.
+// (K1 does not need this pass at all -- see SAILOR_CULL_RAW_DEPTH -- it exists for the node's other consumers.)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_linearize_depth(const float* __restrict__ raw, float* __restrict__ out, size_t count, float zNear, int vec)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    if (vec) {
+        const size_t n4 = count / 4;
+        const float4* __restrict__ r4 = reinterpret_cast<const float4*>(raw);
+        float4* __restrict__ o4 = reinterpret_cast<float4*>(out);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            const float4 d = r4[i];
+            o4[i] = make_float4(-(-zNear / d.x), -(-zNear / d.y), -(-zNear / d.z), -(-zNear / d.w));
+        }
+        for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) out[i] = -(-zNear / raw[i]);
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) out[i] = -(-zNear / raw[i]);
+    }
+}
+
+int sailor_hip_linearize_depth(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dRawDepth, float* dLinearDepth, int32_t width, int32_t rows)
+{
+    if (!ctx || !frame || !dRawDepth || !dLinearDepth || width <= 0 || rows < 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const size_t count = (size_t)width * (size_t)rows;
+    if (count == 0) return SAILOR_HIP_OK;
+    const int vec = ((((uintptr_t)dRawDepth | (uintptr_t)dLinearDepth) & 15) == 0) ? 1 : 0;
+    size_t blocks = (count / 4 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32; // 32 blocks per CU, grid-stride beyond
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_linearize_depth, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, dRawDepth, dLinearDepth, count, frame->cameraZNearZFar[0], vec);
+    SAILOR_CHECK_LAUNCH(ctx, "k_linearize_depth");
     return SAILOR_HIP_OK;
 }
 

@@ -53,6 +53,16 @@ class HipContext:
             pass
 
 
+def linearize_depth(ctx: "HipContext", frame: UboFrameData, raw: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """LinearizeDepthNode (FrameGraph/LinearizeDepthNode.cpp:22): raw reversed-Z depth rows -> positive view distance."""
+    assert raw.dtype == torch.float32 and raw.dim() == 2 and raw.is_contiguous()
+    if out is None:
+        out = torch.empty_like(raw)
+    _lib.check(ctx._lib.sailor_hip_linearize_depth(ctx.handle, C.byref(frame), _ptr(raw), _ptr(out), raw.shape[1], raw.shape[0]),
+               "sailor_hip_linearize_depth", ctx.handle)
+    return out
+
+
 class ForwardPlus:
     """Cull + shade for one band of a W x H frame on one GPU."""
 

@@ -30,6 +30,7 @@ bool FrameGraphBuilder::IsRegistered(const std::string& nodeName) { return Regis
 // force the registration objects of the path's nodes into the library
 template class Sailor::Framegraph::TFrameGraphNode<LightCullingNode>;
 template class Sailor::Framegraph::TFrameGraphNode<RenderSceneNode>;
+template class Sailor::Framegraph::TFrameGraphNode<LinearizeDepthNode>;
 
 // ---- RHIFrameGraph ----------------------------------------------------------------------------------------------------------
 UboFrameData RHIFrameGraph::FillFrameData(RHICommandListPtr transferCmdList, RHISceneViewSnapshot& snapshot, float deltaTime, float worldTime) const
@@ -61,6 +62,46 @@ void RHIFrameGraph::Clear()
     for (auto& node : m_graph) node->Clear();
     m_graph.clear();
     m_renderTargets.clear();
+}
+
+// ---- LinearizeDepthNode (FrameGraph/LinearizeDepthNode.cpp:18-109) -------------------------------------------------------------
+const char* LinearizeDepthNode::m_name = "LinearizeDepth";
+
+void LinearizeDepthNode::Process(RHIFrameGraphPtr frameGraph, RHICommandListPtr, RHICommandListPtr commandList, const RHISceneViewSnapshot& sceneView)
+{
+    auto driver = Renderer::GetDriver();
+    auto commands = Renderer::GetDriverCommands();
+    commands->BeginDebugRegion(commandList, GetName());
+
+    auto depthAttachment = GetRHIResource("depthStencil").DynamicCast<RHITexture>(); // (:29-37)
+    if (!depthAttachment) depthAttachment = frameGraph->GetRenderTarget("DepthBuffer");
+    if (!m_pLinearizeDepthShader) m_pLinearizeDepthShader = driver->CreateShader("Shaders/LinearizeDepth.shader"); // (:39-43)
+    auto target = GetRHIResource("target").DynamicCast<RHITexture>();                                                // (:45)
+    if (!m_pLinearizeDepthShader || !target || !depthAttachment) { // (:47-50) silent early return
+        commands->EndDebugRegion(commandList);
+        return;
+    }
+    if (!m_linearizeDepth) { // (:52-56)
+        m_linearizeDepth = driver->CreateShaderBindings();
+        driver->AddSamplerToShaderBindings(m_linearizeDepth, "depthSampler", depthAttachment, 0);
+    }
+    if (!m_postEffectMaterial) m_postEffectMaterial = driver->CreateMaterial(m_pLinearizeDepthShader); // (:58-63)
+
+    commands->ImageMemoryBarrier(commandList, depthAttachment, EImageLayout::ShaderReadOnlyOptimal); // (:79)
+    commands->ImageMemoryBarrier(commandList, target, EImageLayout::ColorAttachmentOptimal);          // (:80)
+    commands->BeginRenderPass(commandList, TVector<RHITexturePtr> { target }, RHITexturePtr());       // (:84-92)
+    commands->BindMaterial(commandList, m_postEffectMaterial);                                         // (:94)
+    commands->BindShaderBindings(commandList, m_postEffectMaterial, { sceneView.m_frameBindings, m_linearizeDepth }); // (:98)
+    commands->DrawIndexed(commandList, 6, 1, 0, 0, 0);                                                 // (:105) the full-screen NDC quad
+    commands->EndRenderPass(commandList);                                                              // (:106)
+    commands->EndDebugRegion(commandList);
+}
+
+void LinearizeDepthNode::Clear()
+{
+    m_linearizeDepth.Clear();
+    m_postEffectMaterial.Clear();
+    m_pLinearizeDepthShader.Clear();
 }
 
 // ---- LightCullingNode (FrameGraph/LightCullingNode.cpp:17-87) ------------------------------------------------------------------

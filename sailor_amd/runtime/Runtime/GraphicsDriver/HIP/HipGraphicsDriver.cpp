@@ -100,6 +100,8 @@ void HipGraphicsDriver::SubmitCommandList(RHICommandListPtr commandList)
     commandList->m_hip.m_commands.clear();
 }
 
+RHIMaterialPtr HipGraphicsDriver::CreateMaterial(RHIShaderPtr shader) { return RHIMaterialPtr::Make(std::move(shader)); }
+
 RHIShaderBindingSetPtr HipGraphicsDriver::CreateShaderBindings() { return RHIShaderBindingSetPtr::Make(); }
 
 RHIShaderBindingPtr HipGraphicsDriver::AddSsboToShaderBindings(RHIShaderBindingSetPtr& set, const std::string& name, size_t elementSize,
@@ -253,6 +255,55 @@ int HipGraphicsDriver::RecordShade(const TVector<RHIShaderBindingSetPtr>& bindin
                             (const SailorLightShaderData*)buffer_of(bindings[1], "light"), lightsNum,
                             (const SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (const uint32_t*)buffer_of(bindings[1], "culledLights"),
                             hasCsm ? &csm : nullptr, (float*)buffer_of(bindings[2], "radiance"), nullptr);
+}
+
+// ---- the render-pass subset: state is kept on the command list, a 6-index draw of a known full-screen material becomes a
+// kernel launch at submit time (record-then-submit, like Dispatch) ---------------------------------------------------------------
+void HipGraphicsDriver::BeginRenderPass(RHICommandListPtr cmd, const TVector<RHITexturePtr>& colorAttachments, RHITexturePtr)
+{
+    cmd->m_colorAttachments = colorAttachments;
+}
+
+void HipGraphicsDriver::EndRenderPass(RHICommandListPtr cmd)
+{
+    cmd->m_colorAttachments.clear();
+    cmd->m_boundMaterial.Clear();
+    cmd->m_boundBindings.clear();
+}
+
+void HipGraphicsDriver::BindMaterial(RHICommandListPtr cmd, RHIMaterialPtr material) { cmd->m_boundMaterial = material; }
+
+void HipGraphicsDriver::BindShaderBindings(RHICommandListPtr cmd, RHIMaterialPtr, const TVector<RHIShaderBindingSetPtr>& bindings)
+{
+    cmd->m_boundBindings = bindings;
+}
+
+void HipGraphicsDriver::DrawIndexed(RHICommandListPtr cmd, uint32_t indexCount, uint32_t instanceCount, uint32_t, uint32_t, uint32_t)
+{
+    const std::string name = (cmd->m_boundMaterial && cmd->m_boundMaterial->m_shader) ? cmd->m_boundMaterial->m_shader->m_name : std::string();
+    RHITexturePtr target = cmd->m_colorAttachments.empty() ? RHITexturePtr() : cmd->m_colorAttachments[0];
+    auto bindings = cmd->m_boundBindings;
+    const bool fullScreenQuad = indexCount == 6 && instanceCount == 1; // RHIFrameGraph.cpp:106-125 GetFullscreenNdcQuad
+    cmd->m_hip.m_commands.push_back([this, name, bindings, target, fullScreenQuad]() {
+        if (fullScreenQuad && name == "Shaders/LinearizeDepth.shader") return RecordLinearizeDepth(bindings, target);
+        return (int)SAILOR_HIP_ERR_UNSUPPORTED;
+    });
+}
+
+int HipGraphicsDriver::RecordLinearizeDepth(const TVector<RHIShaderBindingSetPtr>& bindings, const RHITexturePtr& target)
+{
+    // LinearizeDepthNode.cpp:89: { sceneView.m_frameBindings, m_linearizeDepth }; LinearizeDepth.shader:15-28 (set 0 frame), :58 (set 1 depthSampler)
+    if (bindings.size() != 2 || !target || !target->m_buffer) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    auto frameB = bindings[0]->Find("frameData");
+    auto depthB = bindings[1]->Find("depthSampler");
+    if (!frameB || frameB->m_hostCopy.size() < sizeof(SailorUboFrameData) || !depthB || depthB->m_textures.empty() || !depthB->m_textures[0]->m_buffer)
+        return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const auto& src = depthB->m_textures[0];
+    if (src->GetExtent().x != target->GetExtent().x || src->GetExtent().y != target->GetExtent().y) return SAILOR_HIP_ERR_UNSUPPORTED; // 1:1 texel fetch only
+    SailorUboFrameData frame;
+    memcpy(&frame, frameB->m_hostCopy.data(), sizeof frame);
+    return sailor_hip_linearize_depth(m_ctx, &frame, (const float*)src->m_buffer->m_hip.m_devicePtr, (float*)target->m_buffer->m_hip.m_devicePtr,
+                                      target->GetExtent().x, target->GetExtent().y);
 }
 
 int HipGraphicsDriver::RecordMeshCulling(const TVector<RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pcBytes)

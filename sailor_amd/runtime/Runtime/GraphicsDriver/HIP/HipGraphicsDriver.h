@@ -5,6 +5,8 @@
 //   "Shaders/ComputeLightCulling.shader" -> sailor_hip_light_cull        (binding contract: ComputeLightCulling.shader:20-47)
 //   "Shaders/Standard.shader"            -> sailor_hip_shade             (binding contract: Standard.shader:180-251)
 //   "Shaders/ComputeMeshCulling.shader"  -> sailor_hip_mesh_frustum_cull (binding contract: ComputeMeshCulling.shader:37-58)
+// and the one full-screen DRAW in front of the path (6 indices with the material of)
+//   "Shaders/LinearizeDepth.shader"      -> sailor_hip_linearize_depth   (binding contract: LinearizeDepth.shader:15-59)
 #pragma once
 #include "../../RHI/GraphicsDriver.h"
 
@@ -25,6 +27,7 @@ public:
     RHI::RHIShaderPtr CreateShader(const std::string& assetPath) override;
     RHI::RHITexturePtr CreateTexture(const void* pData, size_t size, RHI::ivec2 extent, RHI::EFormat format) override;
     void SubmitCommandList(RHI::RHICommandListPtr commandList) override;
+    RHI::RHIMaterialPtr CreateMaterial(RHI::RHIShaderPtr shader) override;
     RHI::RHIShaderBindingSetPtr CreateShaderBindings() override;
     RHI::RHIShaderBindingPtr AddSsboToShaderBindings(RHI::RHIShaderBindingSetPtr& set, const std::string& name, size_t elementSize, size_t numElements,
                                                      uint32_t shaderBinding, bool bBindSsboWithOffset = false) override;
@@ -46,6 +49,12 @@ public:
     void ImageMemoryBarrier(RHI::RHICommandListPtr cmd, RHI::RHITexturePtr image, RHI::EImageLayout newLayout) override;
     void UpdateShaderBinding(RHI::RHICommandListPtr cmd, RHI::RHIShaderBindingPtr binding, const void* data, size_t size, size_t variableOffset = 0) override;
     void UpdateBuffer(RHI::RHICommandListPtr cmd, RHI::RHIBufferPtr buffer, const void* data, size_t size, size_t offset = 0) override;
+    void BeginRenderPass(RHI::RHICommandListPtr cmd, const TVector<RHI::RHITexturePtr>& colorAttachments, RHI::RHITexturePtr depthStencilAttachment) override;
+    void EndRenderPass(RHI::RHICommandListPtr cmd) override;
+    void BindMaterial(RHI::RHICommandListPtr cmd, RHI::RHIMaterialPtr material) override;
+    void BindShaderBindings(RHI::RHICommandListPtr cmd, RHI::RHIMaterialPtr material, const TVector<RHI::RHIShaderBindingSetPtr>& bindings) override;
+    void DrawIndexed(RHI::RHICommandListPtr cmd, uint32_t indexCount, uint32_t instanceCount, uint32_t firstIndex, uint32_t vertexOffset,
+                     uint32_t firstInstance) override;
     void Dispatch(RHI::RHICommandListPtr cmd, RHI::RHIShaderPtr computeShader, uint32_t groupSizeX, uint32_t groupSizeY, uint32_t groupSizeZ,
                   const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const void* pPushConstantsData = nullptr,
                   uint32_t sizePushConstantsData = 0) override;
@@ -54,6 +63,7 @@ private:
     int RecordLightCulling(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pc);
     int RecordShade(const TVector<RHI::RHIShaderBindingSetPtr>& bindings);
     int RecordMeshCulling(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pc);
+    int RecordLinearizeDepth(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const RHI::RHITexturePtr& target);
 
     SailorHipContext* m_ctx = nullptr;
     int m_status = 0;

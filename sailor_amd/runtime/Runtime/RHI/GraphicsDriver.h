@@ -1,6 +1,7 @@
 // The two interfaces every FrameGraph node talks to -- the subset the Forward+ path calls.
 // Mirrors Runtime/RHI/GraphicsDriver.h:59-224 (IGraphicsDriver) and :226-346 (IGraphicsDriverCommands): same method names,
-// argument order and meaning; methods the path never calls (swapchain, materials, render passes, ...) are omitted.
+// argument order and meaning; methods the path never calls (swapchain, vertex buffers, ...) are omitted.  The render-pass
+// subset exists for the one full-screen draw in front of the path, LinearizeDepthNode (FrameGraph/LinearizeDepthNode.cpp:22-109).
 #pragma once
 #include "Types.h"
 
@@ -15,6 +16,7 @@ public:
     virtual RHIShaderPtr CreateShader(const std::string& assetPath) = 0;                                   // :97 (SPIR-V there, a kernel name here)
     virtual RHITexturePtr CreateTexture(const void* pData, size_t size, ivec2 extent, EFormat format) = 0; // :98-108
     virtual void SubmitCommandList(RHICommandListPtr commandList) = 0;                                     // :149
+    virtual RHIMaterialPtr CreateMaterial(RHIShaderPtr shader) = 0;                                        // :138-141 (vertex layout / topology / render state dropped)
     virtual RHIShaderBindingSetPtr CreateShaderBindings() = 0;                                             // :152
     virtual RHIShaderBindingPtr AddSsboToShaderBindings(RHIShaderBindingSetPtr& pShaderBindings, const std::string& name, size_t elementSize,
                                                         size_t numElements, uint32_t shaderBinding, bool bBindSsboWithOffset = false) = 0; // :154
@@ -36,6 +38,12 @@ public:
     virtual void ImageMemoryBarrier(RHICommandListPtr cmd, RHITexturePtr image, EImageLayout newLayout) = 0; // :290
     virtual void UpdateShaderBinding(RHICommandListPtr cmd, RHIShaderBindingPtr binding, const void* data, size_t size, size_t variableOffset = 0) = 0; // :303
     virtual void UpdateBuffer(RHICommandListPtr cmd, RHIBufferPtr buffer, const void* data, size_t size, size_t offset = 0) = 0;                       // :304
+    virtual void BeginRenderPass(RHICommandListPtr cmd, const TVector<RHITexturePtr>& colorAttachments, RHITexturePtr depthStencilAttachment) = 0; // :246-255 (area, clear values dropped)
+    virtual void EndRenderPass(RHICommandListPtr cmd) = 0;                                                                                          // :273
+    virtual void BindMaterial(RHICommandListPtr cmd, RHIMaterialPtr material) = 0;                                                                  // :276
+    virtual void BindShaderBindings(RHICommandListPtr cmd, RHIMaterialPtr material, const TVector<RHIShaderBindingSetPtr>& bindings) = 0;           // :282
+    virtual void DrawIndexed(RHICommandListPtr cmd, uint32_t indexCount, uint32_t instanceCount, uint32_t firstIndex, uint32_t vertexOffset,
+                             uint32_t firstInstance) = 0;                                                                                           // :285
     virtual void Dispatch(RHICommandListPtr cmd, RHIShaderPtr computeShader, uint32_t groupSizeX, uint32_t groupSizeY, uint32_t groupSizeZ,
                           const TVector<RHIShaderBindingSetPtr>& bindings, const void* pPushConstantsData = nullptr,
                           uint32_t sizePushConstantsData = 0) = 0;                                                                                       // :310-314

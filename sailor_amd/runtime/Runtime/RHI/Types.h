@@ -70,7 +70,7 @@ public:
 using RHIBufferPtr = TRefPtr<RHIBuffer>;
 
 enum class EFormat { R32_SFLOAT, R16_SFLOAT, R32G32B32A32_SFLOAT };
-enum class EImageLayout { Undefined, ShaderReadOnlyOptimal, General };
+enum class EImageLayout { Undefined, ShaderReadOnlyOptimal, General, ColorAttachmentOptimal };
 
 // RHI/Texture.h: here a linear row-major image in device memory (row 0 = top)
 class RHITexture : public RHIResource {
@@ -125,11 +125,24 @@ public:
 };
 using RHIShaderPtr = TRefPtr<RHIShader>;
 
+// RHI/Material.h: for this path a material is its shader (render state, vertex layout and topology have no meaning for a
+// full-screen pass executed as a compute kernel)
+class RHIMaterial : public RHIResource {
+public:
+    explicit RHIMaterial(RHIShaderPtr shader) : m_shader(std::move(shader)) {}
+    RHIShaderPtr m_shader;
+};
+using RHIMaterialPtr = TRefPtr<RHIMaterial>;
+
 // RHI/CommandList.h: recorded work, executed at SubmitCommandList (record-then-submit, RHI/GraphicsDriver.h:149)
 class RHICommandList : public RHIResource {
 public:
     struct { TVector<std::function<int()>> m_commands; } m_hip;
     TVector<std::string> m_debugRegions; // names seen by BeginDebugRegion, for tests
+    // state of the render pass being recorded (BeginRenderPass .. EndRenderPass)
+    TVector<TRefPtr<class RHITexture>> m_colorAttachments;
+    TRefPtr<class RHIMaterial> m_boundMaterial;
+    TVector<TRefPtr<class RHIShaderBindingSet>> m_boundBindings;
 };
 using RHICommandListPtr = TRefPtr<RHICommandList>;
 

@@ -19,8 +19,8 @@ struct SailorRuntime {
     std::unique_ptr<LightingECS> lighting;
     RHIFrameGraph graph;
     RHISceneViewSnapshot snapshot;
-    FrameGraphNodePtr lightCulling, renderScene;
-    RHITexturePtr depth;
+    FrameGraphNodePtr lightCulling, renderScene, linearizeDepth;
+    RHITexturePtr depth, rawDepth;
     RHIBufferPtr surface, radiance;
     std::unique_ptr<EcsSweepSystem> sweep;
     int frames = 0;
@@ -44,7 +44,7 @@ RT_API void sailor_rt_destroy(SailorRuntime* rt)
     rt->sweep.reset();
     rt->lighting.reset();
     rt->depth.Clear(); rt->surface.Clear(); rt->radiance.Clear();
-    rt->lightCulling.Clear(); rt->renderScene.Clear();
+    rt->lightCulling.Clear(); rt->renderScene.Clear(); rt->linearizeDepth.Clear(); rt->rawDepth.Clear();
     rt->snapshot = RHISceneViewSnapshot();
     delete rt;
 }
@@ -58,6 +58,7 @@ RT_API int sailor_rt_build_graph(SailorRuntime* rt, const char** nodeNames, int 
         auto node = FrameGraphBuilder::CreateNode(nodeNames[i]);
         if (!node) return -1;
         if (std::string(nodeNames[i]) == "LightCulling") rt->lightCulling = node;
+        if (std::string(nodeNames[i]) == "LinearizeDepth") rt->linearizeDepth = node;
         if (std::string(nodeNames[i]) == "RenderScene") { node->SetString("Tag", "Opaque"); rt->renderScene = node; }
         rt->graph.AddNode(node);
     }
@@ -106,6 +107,18 @@ RT_API void sailor_rt_set_depth(SailorRuntime* rt, void* devicePtr, int width, i
     auto* hip = static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver());
     rt->depth = hip->WrapTexture(devicePtr, { width, height }, EFormat::R32_SFLOAT);
     if (rt->lightCulling) rt->lightCulling->SetRHIResource("depthStencil", rt->depth);
+}
+
+// the raw reversed-Z depth attachment (caller's device memory) in front of a "LinearizeDepth" node whose target is the
+// LinearDepth render target set with sailor_rt_set_depth (DefaultRenderer.renderer: LinearizeDepth -> LightCulling)
+RT_API void sailor_rt_set_raw_depth(SailorRuntime* rt, void* devicePtr, int width, int height)
+{
+    auto* hip = static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver());
+    rt->rawDepth = hip->WrapTexture(devicePtr, { width, height }, EFormat::R32_SFLOAT);
+    if (rt->linearizeDepth) {
+        rt->linearizeDepth->SetRHIResource("depthStencil", rt->rawDepth);
+        if (rt->depth) rt->linearizeDepth->SetRHIResource("target", rt->depth);
+    }
 }
 
 RT_API void sailor_rt_set_surface(SailorRuntime* rt, void* surfaceDevicePtr, void* radianceDevicePtr, int width, int height)

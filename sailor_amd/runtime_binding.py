@@ -34,6 +34,7 @@ def load() -> C.CDLL:
         rt.sailor_rt_add_light.argtypes = [P, C.c_uint32, C.c_uint32, P, P, P, P, P]
         rt.sailor_rt_tick_lights.argtypes = [P]
         rt.sailor_rt_set_depth.argtypes = [P, P, C.c_int, C.c_int]
+        rt.sailor_rt_set_raw_depth.argtypes = [P, P, C.c_int, C.c_int]
         rt.sailor_rt_set_surface.argtypes = [P, P, P, C.c_int, C.c_int]
         rt.sailor_rt_set_shadow_maps.argtypes = [P, P, P, P, P]
         rt.sailor_rt_process_frame.argtypes = [P]
@@ -73,6 +74,10 @@ class Runtime:
 
     def set_depth(self, depth_tensor):
         self.rt.sailor_rt_set_depth(self.h, depth_tensor.data_ptr(), depth_tensor.shape[1], depth_tensor.shape[0])
+
+    def set_raw_depth(self, raw_tensor):
+        """after set_depth: the LinearizeDepth node reads this and writes the tensor given to set_depth"""
+        self.rt.sailor_rt_set_raw_depth(self.h, raw_tensor.data_ptr(), raw_tensor.shape[1], raw_tensor.shape[0])
 
     def set_surface(self, surface_tensor, radiance_tensor):
         self.rt.sailor_rt_set_surface(self.h, surface_tensor.data_ptr(), radiance_tensor.data_ptr(), surface_tensor.shape[2], surface_tensor.shape[1])

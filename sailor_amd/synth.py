@@ -101,6 +101,19 @@ def make_linear_depth(width: int, height: int, seed: int = SEED, d_min: float = 
     return np.ascontiguousarray(depth.astype(np.float32))
 
 
+def make_raw_depth(linear: np.ndarray, z_near: float = 1.0, sky_fraction: float = 0.0, seed: int = SEED) -> np.ndarray:
+    """A reversed-Z, infinite-far-plane depth attachment that LinearizeDepth.shader:70 maps back to (about) `linear`:
+    raw = zNear / linear in float32 (so linearising it is a rounding away from `linear`, not the identity).  With
+    `sky_fraction` > 0 that share of 16x16 blocks is cleared to 0.0 = nothing drawn (linear depth +inf)."""
+    raw = (np.float32(z_near) / linear.astype(np.float32)).astype(np.float32)
+    if sky_fraction > 0.0:
+        H, W = linear.shape
+        bw, bh = (W + 15) // 16, (H + 15) // 16
+        pick = uniforms(STREAM_DEPTH, bw * bh, 1 << 22, seed).reshape(bh, bw) < sky_fraction
+        raw = np.where(pick[np.ix_(np.arange(H) // 16, np.arange(W) // 16)], np.float32(0.0), raw)
+    return np.ascontiguousarray(raw, np.float32)
+
+
 def pixel_rays(cam: Camera) -> tuple[np.ndarray, np.ndarray]:
     """Appendix D: pixel (px, py) (py = 0 top) has NDC (2(px+.5)/W - 1, 1 - 2(py+.5)/H); view ray (ndc.x/P00, ndc.y/P11, -1)."""
     proj = np.frombuffer(bytes(cam.frame.projection), np.float32)

@@ -38,6 +38,18 @@ def make(name: str) -> None:
           f"tiles >128 candidates {(cnt > 128).sum()}, >196 {(cnt > 196).sum()}, lit pixels {(rad[..., :3].sum(-1) > 0).mean():.3f}")
 
 
+def make_depth() -> None:
+    """LinearizeDepth: raw reversed-Z attachment of the tiny frame (6 % sky blocks, plus hand-picked
+    edge values in the first row) and the oracle's linearisation of it."""
+    f = synth.make_frame("tiny", with_surface=False)
+    raw = synth.make_raw_depth(f.depth, 1.0, sky_fraction=0.06)
+    raw[0, :8] = np.array([1.0, 0.5, 1e-4, 3.0e-39, 0.0, 0.99999994, 1.1754944e-38, 2.5e-5], np.float32)
+    lin = oracle.linearize_depth(1.0, raw)
+    np.savez_compressed(OUT / "tiny_depth.npz", z_near=np.float32(1.0), raw=raw, linear=lin)
+    print(f"tiny_depth: {raw.shape[1]}x{raw.shape[0]}, {(raw == 0).mean():.3f} sky, linear range [{lin[np.isfinite(lin)].min():.3f}, {lin[np.isfinite(lin)].max():.3e}]")
+
+
 if __name__ == "__main__":
     for n in ("tiny", "tiny_csm"):
         make(n)
+    make_depth()

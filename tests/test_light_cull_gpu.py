@@ -172,3 +172,28 @@ def test_c3_4k_65536_lights_default_equals_brute_force_and_invariants(ctx):
     np.testing.assert_array_equal(g[t0:t0 + 720, 1], og[:, 1])
     for t in range(720):
         np.testing.assert_array_equal(idx[g[t0 + t, 0]: g[t0 + t, 0] + g[t0 + t, 1]], oi[og[t, 0]: og[t, 0] + og[t, 1]])
+
+
+@pytest.mark.parametrize("flags", [_lib.CULL_DEFAULT, _lib.CULL_BRUTE_FORCE])
+def test_nan_impacts_follow_the_literal_bubble_sort(ctx, flags):
+    """Tiles with nothing drawn (linear depth +inf) get a NaN frustum centre, i.e. NaN impacts: no total order, the shader's
+    compare-and-swap (ComputeLightCulling.shader:207) is false next to a NaN.  (a) sky tiles: every impact is NaN or a
+    directional 0 -> the sort is a no-op; (b) lights with a NaN position among finite ones -> NaNs act as walls, finite runs
+    are bubbled between them.  Both must equal the oracle, whose closed form defers to the literal sort when a NaN is present."""
+    f = synth.make_frame("tiny", with_surface=False)
+    W, H = f.cam.width, f.cam.height
+    depth = f.depth.copy()
+    sky = synth.make_raw_depth(depth, 1.0, sky_fraction=0.5) == 0
+    depth[sky] = np.inf
+    ref_g, ref_i, cnt = oracle.light_cull(f.cam.frame, W, H, f.lights, depth, want_counts=True)
+    sky_tiles = sky.reshape(H // 16, 16, W // 16, 16).any(axis=(1, 3)).reshape(-1)
+    assert ((cnt > oracle.KEEP) & sky_tiles).any(), "need a sky tile that runs the selection"
+    assert_lists_equal(gpu_cull(ctx, f.cam, f.lights, depth, flags), ref_g, ref_i)
+
+    lights = f.lights.copy()
+    lights["worldPosition"][::7] = np.nan
+    ref_g, ref_i, cnt = oracle.light_cull(f.cam.frame, W, H, lights, f.depth, want_counts=True)
+    assert (cnt > oracle.KEEP).any()
+    lit_g, lit_i, _ = oracle.light_cull(f.cam.frame, W, H, lights, f.depth, literal_select=True)
+    np.testing.assert_array_equal(ref_i[: 1 + int(ref_i[0])], lit_i[: 1 + int(lit_i[0])])
+    assert_lists_equal(gpu_cull(ctx, f.cam, lights, f.depth, flags), ref_g, ref_i)

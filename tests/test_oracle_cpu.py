@@ -194,3 +194,41 @@ def test_golden_fixture(name):
         csm, _keep = oracle.make_csm(f.shadows.lights_matrices, f.shadows.maps)
     rad = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, g, idx, csm)
     np.testing.assert_allclose(rad, z["radiance"], rtol=2e-6, atol=1e-6)  # libm powf may differ by an ulp across hosts
+
+
+def test_linearize_depth_golden_and_numpy():
+    """LinearizeDepth.shader:70,74: the C restatement against the committed fixture and against the
+    same two IEEE operations in NumPy float32; raw 0 (nothing drawn) -> +inf, denormal raw -> finite or +inf, never NaN."""
+    g = np.load(GOLDEN / "tiny_depth.npz")
+    zn = np.float32(g["z_near"])
+    lin = oracle.linearize_depth(float(zn), g["raw"])
+    np.testing.assert_array_equal(lin.view(np.uint32), g["linear"].view(np.uint32))
+    with np.errstate(divide="ignore", over="ignore"):
+        ref = -((-zn) / g["raw"].astype(np.float32))
+    np.testing.assert_array_equal(lin.view(np.uint32), ref.astype(np.float32).view(np.uint32))
+    assert not np.isnan(lin).any() and np.isposinf(lin[g["raw"] == 0]).all()
+    # regenerating the fixture's input from the frozen generator gives the same bytes
+    f = synth.make_frame("tiny", with_surface=False)
+    raw = synth.make_raw_depth(f.depth, 1.0, sky_fraction=0.06)
+    np.testing.assert_array_equal(raw[1:], g["raw"][1:])
+
+
+def test_nan_impacts_c_numpy_and_literal_agree():
+    """Sky tiles (linear depth +inf -> NaN frustum centre -> NaN impacts) and NaN light positions: the closed-form selection
+    has no meaning there; the C oracle defers to the literal bubble sort, the NumPy restatement replays it independently."""
+    f = synth.make_frame("tiny", with_surface=False)
+    W, H = f.cam.width, f.cam.height
+    depth = f.depth.copy()
+    depth[synth.make_raw_depth(depth, 1.0, sky_fraction=0.5) == 0] = np.inf
+    lights = f.lights.copy()
+    lights["worldPosition"][::7] = np.nan
+    fb = np.frombuffer(bytes(f.cam.frame), np.uint8)
+    for L, D in ((f.lights, depth), (lights, f.depth)):
+        g, i, cnt = oracle.light_cull(f.cam.frame, W, H, L, D, want_counts=True)
+        assert (cnt > oracle.KEEP).any()
+        g2, i2, _ = oracle.light_cull(f.cam.frame, W, H, L, D, literal_select=True)
+        with np.errstate(invalid="ignore"):
+            g3, i3 = oracle_np.light_cull(fb, W, H, L, D)
+        n = 1 + int(i[0])
+        np.testing.assert_array_equal(g, g2); np.testing.assert_array_equal(i[:n], i2[:n])
+        np.testing.assert_array_equal(g, g3); np.testing.assert_array_equal(i[:n], i3[:n])

@@ -69,3 +69,36 @@ def test_frame_graph_nodes_drive_the_hip_path(name):
         assert (err <= 1e-4 * np.abs(ref) + 1e-5).all(), err.max()
     finally:
         rt.close()
+
+
+def test_linearize_depth_node_feeds_the_cull():
+    """Graph LinearizeDepth -> LightCulling from node names: the node records the reference's full-screen draw
+    (BeginRenderPass / BindMaterial / BindShaderBindings / DrawIndexed(6) / EndRenderPass, LinearizeDepthNode.cpp:79-106), the HIP
+    backend turns it into sailor_hip_linearize_depth; the LinearDepth target and the lists equal the oracle's."""
+    f = synth.make_frame("tiny", with_surface=False)
+    W, H = f.cam.width, f.cam.height
+    zn = f.cam.frame.cameraZNearZFar[0]
+    raw = synth.make_raw_depth(f.depth, zn, sky_fraction=0.05)
+    lin_ref = oracle.linearize_depth(zn, raw)
+    rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        assert rt.rt.sailor_rt_node_registered(b"LinearizeDepth") == 1
+        rt.build_graph(["LinearizeDepth", "LightCulling"])
+        rt.set_camera(f.cam)
+        rt.set_lights(f.lights)
+        linear = torch.zeros((H, W), dtype=torch.float32, device="cuda")
+        d_raw = torch.from_numpy(raw).cuda()
+        rt.set_depth(linear)
+        rt.set_raw_depth(d_raw)
+        assert rt.process_frame() == 0
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(linear.cpu().numpy().view(np.uint32), lin_ref.view(np.uint32))
+        og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, lin_ref)
+        gp, _gb = rt.buffer("lightsGrid")
+        cp, _cb = rt.buffer("culledLights")
+        Tx, Ty = host.num_tiles(W, H)
+        np.testing.assert_array_equal(read_u32(gp, Tx * Ty * 8).reshape(-1, 2), og)
+        np.testing.assert_array_equal(read_u32(cp, 4 * (1 + int(oi[0]))), oi[: 1 + int(oi[0])])
+    finally:
+        rt.close()
