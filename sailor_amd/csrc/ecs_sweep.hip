@@ -59,69 +59,167 @@ __device__ __forceinline__ void transform_matrix(const float4 pos, const float4 
 
 struct Planes6 { float p[24]; };
 
+// AABB::Apply (Bounds.cpp:479-492, corner order of Bounds.h:119-130) + Frustum::OverlapsAABB (Bounds.cpp:245-260)
+__device__ __forceinline__ bool ecs_bounds_vis(const float* W, const float* la, const Planes6& planes, float* omin, float* omax)
+{
+    const float mnx = la[0], mny = la[1], mnz = la[2], mxx = la[3], mxy = la[4], mxz = la[5];
+    const float px[8] = { mnx, mxx, mnx, mxx, mxx, mxx, mnx, mnx };
+    const float py[8] = { mny, mxy, mxy, mny, mxy, mny, mxy, mny };
+    const float pz[8] = { mnz, mxz, mxz, mxz, mnz, mnz, mnz, mxz };
+    omin[0] = omin[1] = omin[2] = FLT_MAX;
+    omax[0] = omax[1] = omax[2] = FLT_MIN;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float t = (W[0 + c] * px[k] + W[4 + c] * py[k]) + (W[8 + c] * pz[k] + W[12 + c] * 1.0f);
+            omin[c] = (omin[c] < t) ? omin[c] : t;
+            omax[c] = (t < omax[c]) ? omax[c] : t;
+        }
+    }
+    bool vis = true;
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+        const float ax = omin[0] * planes.p[4 * p + 0], bx = omax[0] * planes.p[4 * p + 0];
+        const float ay = omin[1] * planes.p[4 * p + 1], by = omax[1] * planes.p[4 * p + 1];
+        const float az = omin[2] * planes.p[4 * p + 2], bz = omax[2] * planes.p[4 * p + 2];
+        const float d = (ax < bx ? bx : ax) + (ay < by ? by : ay) + (az < bz ? bz : az) + planes.p[4 * p + 3];
+        vis = vis && (d > 0.0f);
+    }
+    return vis;
+}
+
+// world = parentWorld * relative (TransformECS.cpp:201) or relative for a root (:192-195)
+__device__ __forceinline__ void ecs_world(const float4 pos, const float4 rot, const float4 scl, bool hasParent, const float4* __restrict__ parentWorld, float* W)
+{
+    float rel[16];
+    transform_matrix(pos, rot, scl, rel);
+    if (!hasParent) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) W[k] = rel[k];
+    } else {
+        const float4 c0 = parentWorld[0], c1 = parentWorld[1], c2 = parentWorld[2], c3 = parentWorld[3];
+        const float P[16] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w };
+        mat_mul(P, rel, W);
+    }
+}
+
+// FUSED levels: the world matrix of an entity of level d is the left-to-right product rel(root) * rel(..) * rel(self), every
+// factor recomputed from that ancestor's 48-byte TRS exactly as its own lane computes it -- so the bits are those of the
+// level-by-level sweep, but no lane waits for another launch.  Up to ECS_FUSED_LEVELS levels (the hierarchy of the 1 M-entity
+// workload has 3): one launch instead of one per level; the short dependent launches of the child levels ran at a third of the
+// root level's bandwidth.
+#define ECS_FUSED_LEVELS 4
+__device__ __forceinline__ void ecs_world_fused(const float4* __restrict__ trs, const uint32_t* __restrict__ parent, const float4 pos, const float4 rot,
+                                                const float4 scl, uint32_t par, float* W)
+{
+    uint32_t anc[ECS_FUSED_LEVELS - 1];
+    int depth = 0;
+#pragma unroll
+    for (int k = 0; k < ECS_FUSED_LEVELS - 1; k++) {
+        anc[k] = par;
+        if (par != 0xFFFFFFFFu) { depth = k + 1; par = parent[par]; }
+    }
+    float rel[16];
+    bool started = false;
+#pragma unroll
+    for (int k = ECS_FUSED_LEVELS - 2; k >= 0; k--) { // from the root down
+        if (k < depth) {
+            const float4* t = trs + (size_t)anc[k] * 3;
+            transform_matrix(t[0], t[1], t[2], rel);
+            if (!started) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) W[q] = rel[q];
+                started = true;
+            } else {
+                float T[16];
+                mat_mul(W, rel, T);
+#pragma unroll
+                for (int q = 0; q < 16; q++) W[q] = T[q];
+            }
+        }
+    }
+    transform_matrix(pos, rot, scl, rel);
+    if (!started) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) W[q] = rel[q];
+    } else {
+        float T[16];
+        mat_mul(W, rel, T);
+#pragma unroll
+        for (int q = 0; q < 16; q++) W[q] = T[q];
+    }
+}
+
+#define ECS_WAVE_F4 352 // float4 slots of LDS per wave: max(TRS 192 + box 96, world 256 + box 96)
+
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k4_ecs_level(uint32_t lo, uint32_t hi, const float4* __restrict__ trs, const uint32_t* __restrict__ parent,
-                                                     const float* __restrict__ localAabb, Planes6 planes,
+                                                     const float* __restrict__ localAabb, Planes6 planes, int boxVec,
                                                      float4* __restrict__ world, float* __restrict__ worldAabb, unsigned long long* __restrict__ visibility)
 {
-    // one wave owns one 64-entity visibility word; entities outside [lo, hi) of the word are masked
-    const uint32_t word = (lo >> 6) + blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t i = word * 64 + (threadIdx.x & 63);
+    // One wave owns one 64-entity visibility word.  The records are AoS (48 B TRS, 24 B box in; 64 B matrix, 24 B box out), so a
+    // lane-per-entity access is a 16-byte (or 4-byte) request every 48 / 64 / 24 bytes -- four to six partial-line requests
+    // per line.  A wave whose 64 entities all belong to this level therefore moves its records through LDS: every global
+    // request is a full 1 KiB of consecutive float4s, the stride is paid in LDS.  Words that straddle a level boundary
+    // (at most two per launch) and unaligned box arrays take the direct path.
+    __shared__ float4 sStage[4][ECS_WAVE_F4];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // fused: deepest level first -- its waves are latency-bound (dependent ancestor gathers), the roots behind them are
+    // bandwidth-bound, so the two overlap instead of the slow waves forming the tail of the launch
+    const uint32_t blk = FUSED ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x;
+    const uint32_t word = (lo >> 6) + blk * 4 + wave;
+    const uint32_t base = word * 64, i = base + lane;
     const bool active = i >= lo && i < hi;
+    const unsigned long long amask = __ballot(active);
     bool vis = false;
-    if (active) {
-        const float4 pos = trs[(size_t)i * 3 + 0], rot = trs[(size_t)i * 3 + 1], scl = trs[(size_t)i * 3 + 2];
-        float rel[16], W[16];
-        transform_matrix(pos, rot, scl, rel);
+    float W[16], omin[3], omax[3];
+    if (amask == ~0ull && boxVec) {
+        float4* S = sStage[wave];
+        const float4* gT = trs + (size_t)base * 3;
+        const float4* gB = reinterpret_cast<const float4*>(localAabb + (size_t)base * 6);
         const uint32_t par = parent[i];
-        if (par == 0xFFFFFFFFu) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) W[k] = rel[k]; // TransformECS.cpp:192-195
-        } else {
-            float P[16];
-            const float4* pw = world + (size_t)par * 4;
-            const float4 c0 = pw[0], c1 = pw[1], c2 = pw[2], c3 = pw[3];
-            P[0] = c0.x; P[1] = c0.y; P[2] = c0.z; P[3] = c0.w; P[4] = c1.x; P[5] = c1.y; P[6] = c1.z; P[7] = c1.w;
-            P[8] = c2.x; P[9] = c2.y; P[10] = c2.z; P[11] = c2.w; P[12] = c3.x; P[13] = c3.y; P[14] = c3.z; P[15] = c3.w;
-            mat_mul(P, rel, W); // TransformECS.cpp:201
-        }
+        S[lane] = gT[lane]; S[64 + lane] = gT[64 + lane]; S[128 + lane] = gT[128 + lane];
+        S[192 + lane] = gB[lane];
+        if (lane < 32) S[256 + lane] = gB[64 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const float4 pos = S[lane * 3 + 0], rot = S[lane * 3 + 1], scl = S[lane * 3 + 2];
+        const float* sb = reinterpret_cast<const float*>(S + 192) + lane * 6;
+        const float la[6] = { sb[0], sb[1], sb[2], sb[3], sb[4], sb[5] };
+        if (FUSED) ecs_world_fused(trs, parent, pos, rot, scl, par, W);
+        else ecs_world(pos, rot, scl, par != 0xFFFFFFFFu, world + (size_t)(par != 0xFFFFFFFFu ? par : 0u) * 4, W);
+        vis = ecs_bounds_vis(W, la, planes, omin, omax);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // every lane has read its inputs: the slots are reused for the outputs
+        S[lane * 4 + 0] = make_float4(W[0], W[1], W[2], W[3]);
+        S[lane * 4 + 1] = make_float4(W[4], W[5], W[6], W[7]);
+        S[lane * 4 + 2] = make_float4(W[8], W[9], W[10], W[11]);
+        S[lane * 4 + 3] = make_float4(W[12], W[13], W[14], W[15]);
+        float* so = reinterpret_cast<float*>(S + 256) + lane * 6;
+        so[0] = omin[0]; so[1] = omin[1]; so[2] = omin[2]; so[3] = omax[0]; so[4] = omax[1]; so[5] = omax[2];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float4* oW = world + (size_t)base * 4;
+        oW[lane] = S[lane]; oW[64 + lane] = S[64 + lane]; oW[128 + lane] = S[128 + lane]; oW[192 + lane] = S[192 + lane];
+        float4* oB = reinterpret_cast<float4*>(worldAabb + (size_t)base * 6);
+        oB[lane] = S[256 + lane];
+        if (lane < 32) oB[64 + lane] = S[320 + lane];
+    } else if (active) {
+        const float4 pos = trs[(size_t)i * 3 + 0], rot = trs[(size_t)i * 3 + 1], scl = trs[(size_t)i * 3 + 2];
+        const uint32_t par = parent[i];
+        const float* gl = localAabb + (size_t)i * 6;
+        const float la[6] = { gl[0], gl[1], gl[2], gl[3], gl[4], gl[5] };
+        if (FUSED) ecs_world_fused(trs, parent, pos, rot, scl, par, W);
+        else ecs_world(pos, rot, scl, par != 0xFFFFFFFFu, world + (size_t)(par != 0xFFFFFFFFu ? par : 0u) * 4, W);
+        vis = ecs_bounds_vis(W, la, planes, omin, omax);
         float4* ow = world + (size_t)i * 4;
         ow[0] = make_float4(W[0], W[1], W[2], W[3]);
         ow[1] = make_float4(W[4], W[5], W[6], W[7]);
         ow[2] = make_float4(W[8], W[9], W[10], W[11]);
         ow[3] = make_float4(W[12], W[13], W[14], W[15]);
-
-        // AABB::Apply (Bounds.cpp:479-492), corner order of Bounds.h:119-130
-        const float* la = localAabb + (size_t)i * 6;
-        const float mnx = la[0], mny = la[1], mnz = la[2], mxx = la[3], mxy = la[4], mxz = la[5];
-        const float px[8] = { mnx, mxx, mnx, mxx, mxx, mxx, mnx, mnx };
-        const float py[8] = { mny, mxy, mxy, mny, mxy, mny, mxy, mny };
-        const float pz[8] = { mnz, mxz, mxz, mxz, mnz, mnz, mnz, mxz };
-        float omin[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, omax[3] = { FLT_MIN, FLT_MIN, FLT_MIN };
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float t = (W[0 + c] * px[k] + W[4 + c] * py[k]) + (W[8 + c] * pz[k] + W[12 + c] * 1.0f);
-                omin[c] = (omin[c] < t) ? omin[c] : t;
-                omax[c] = (t < omax[c]) ? omax[c] : t;
-            }
-        }
         float* oa = worldAabb + (size_t)i * 6;
         oa[0] = omin[0]; oa[1] = omin[1]; oa[2] = omin[2]; oa[3] = omax[0]; oa[4] = omax[1]; oa[5] = omax[2];
-
-        // Frustum::OverlapsAABB (Bounds.cpp:245-260)
-        vis = true;
-#pragma unroll
-        for (int p = 0; p < 6; p++) {
-            const float ax = omin[0] * planes.p[4 * p + 0], bx = omax[0] * planes.p[4 * p + 0];
-            const float ay = omin[1] * planes.p[4 * p + 1], by = omax[1] * planes.p[4 * p + 1];
-            const float az = omin[2] * planes.p[4 * p + 2], bz = omax[2] * planes.p[4 * p + 2];
-            const float d = (ax < bx ? bx : ax) + (ay < by ? by : ay) + (az < bz ? bz : az) + planes.p[4 * p + 3];
-            vis = vis && (d > 0.0f);
-        }
     }
-    const unsigned long long vmask = __ballot(vis), amask = __ballot(active);
-    if ((threadIdx.x & 63) == 0 && amask) {
+    const unsigned long long vmask = __ballot(vis);
+    if (lane == 0 && amask) {
         // a word straddling two levels is completed by two stream-ordered launches: keep the other launch's bits
         const unsigned long long old = (amask == ~0ull) ? 0ull : visibility[word];
         visibility[word] = (old & ~amask) | (vmask & amask);
@@ -196,13 +294,22 @@ int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntities, const Sail
     if (((uintptr_t)dTransforms & 15) || ((uintptr_t)dWorld & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     Planes6 P;
     memcpy(P.p, planes, sizeof P.p);
+    const int boxVec = ((((uintptr_t)dLocalAabb | (uintptr_t)dWorldAabb) & 15) == 0) ? 1 : 0; // 64 boxes = 1536 B: float4-addressable per word
+    for (uint32_t l = 0; l < numLevels; l++)
+        if (levelOffsets[l + 1] < levelOffsets[l] || levelOffsets[l + 1] > numEntities) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (numLevels <= ECS_FUSED_LEVELS) { // shallow hierarchy: every level in one launch (ancestors' relative matrices are recomputed)
+        const uint32_t words = (numEntities + 63) >> 6;
+        hipLaunchKernelGGL(k4_ecs_level<true>, dim3((words + 3) / 4), dim3(256), 0, ctx->stream, 0u, numEntities, (const float4*)dTransforms, dParent,
+                           (const float*)dLocalAabb, P, boxVec, (float4*)dWorld, (float*)dWorldAabb, (unsigned long long*)dVisibility);
+        SAILOR_CHECK_LAUNCH(ctx, "k4_ecs_level<fused>");
+        return SAILOR_HIP_OK;
+    }
     for (uint32_t l = 0; l < numLevels; l++) {
         const uint32_t lo = levelOffsets[l], hi = levelOffsets[l + 1];
-        if (hi < lo || hi > numEntities) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
         if (hi == lo) continue;
         const uint32_t words = ((hi + 63) >> 6) - (lo >> 6);
-        hipLaunchKernelGGL(k4_ecs_level, dim3((words + 3) / 4), dim3(256), 0, ctx->stream, lo, hi, (const float4*)dTransforms, dParent,
-                           (const float*)dLocalAabb, P, (float4*)dWorld, (float*)dWorldAabb, (unsigned long long*)dVisibility);
+        hipLaunchKernelGGL(k4_ecs_level<false>, dim3((words + 3) / 4), dim3(256), 0, ctx->stream, lo, hi, (const float4*)dTransforms, dParent,
+                           (const float*)dLocalAabb, P, boxVec, (float4*)dWorld, (float*)dWorldAabb, (unsigned long long*)dVisibility);
         SAILOR_CHECK_LAUNCH(ctx, "k4_ecs_level");
     }
     return SAILOR_HIP_OK;

@@ -36,6 +36,35 @@ def test_sweep_bit_exact(ctx, count):
         assert 0 < nvis < count
 
 
+@pytest.mark.parametrize("levels", [4, 5, 9])
+def test_deep_hierarchy(ctx, levels):
+    """<= 4 levels run as ONE launch (ancestors' relative matrices recomputed, same left-to-right product); deeper trees take
+    one launch per level with level boundaries inside 64-entity words.  Both must give the oracle's bits."""
+    per, n = 37 + 64 * 3, 0
+    ents = synth.make_entities(per * levels, editor_world=False)
+    offs = [0]
+    for lvl in range(levels):
+        n += per + 5 * lvl  # uneven level sizes
+        offs.append(min(n, per * levels))
+    offs[-1] = per * levels
+    ents.level_offsets = np.array(offs, np.uint32)
+    ents.parent[:] = 0xFFFFFFFF
+    u = synth.uniforms(synth.STREAM_ENTITIES, per * levels, 1 << 26)
+    for lvl in range(1, levels):
+        lo, hi, plo, phi = offs[lvl], offs[lvl + 1], offs[lvl - 1], offs[lvl]
+        ents.parent[lo:hi] = (plo + np.floor(u[lo:hi] * (phi - plo))).astype(np.uint32)
+        ents.transforms[lo:hi, 0:3] *= np.float32(0.05)
+        ents.transforms[lo:hi, 8:11] = np.float32(0.9) + np.float32(0.2) * ents.transforms[lo:hi, 8:11] / np.float32(4.0)  # keep the scale chain bounded
+    cam = synth.make_camera(1920, 1080)
+    planes = camera_planes(cam)
+    world, aabb, vis = EcsSweep(ctx, ents).run(planes)
+    ctx.synchronize()
+    ow, oa, ov = oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes)
+    np.testing.assert_array_equal(world.cpu().numpy().view(np.uint32), ow.view(np.uint32))
+    np.testing.assert_array_equal(aabb.cpu().numpy().view(np.uint32), oa.view(np.uint32))
+    np.testing.assert_array_equal(vis.cpu().numpy().view(np.uint64), ov)
+
+
 def test_flt_min_quirk_all_negative_box(ctx):
     """Math/Bounds.cpp:484: max is seeded with the smallest POSITIVE float, so an all-negative box keeps max ~ 1.18e-38."""
     ents = synth.make_entities(64, editor_world=False)
