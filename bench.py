@@ -194,6 +194,24 @@ def linearize_block(ctx, frame, fp, d_lights, steps: int):
             "cpu_1thread_mpixels_per_s": W * H / t_cpu / 1e6, "kind": "port"}
 
 
+def ambient_block(ctx, frame, fp, d_lights, d_surface, steps: int):
+    """the shade pass with Standard.shader's ambient / IBL term (irradiance cube 16^2, pre-filtered environment
+    cube 64^2 with 7 levels, 64x64 BRDF table computed on the GPU, AO target): extra algorithmic bytes = 4 per pixel (AO) + the
+    textures once (0.7 MB)."""
+    from sailor_amd.forward_plus import compute_brdf_lut, upload_ibl
+    cam, W, H, N = frame.cam, frame.cam.width, frame.cam.height, len(frame.lights)
+    lut_ms = event_ms(lambda: compute_brdf_lut(ctx, 256, 256), 5)
+    lut = compute_brdf_lut(ctx, 64, 64).cpu().numpy()
+    ibl = synth.make_ibl_set(W, H, lut)
+    desc, keep = upload_ibl(ibl, ctx.device)
+    for _ in range(3):
+        fp.shade(cam.frame, d_surface, d_lights, N, None, ibl=desc)
+    with_ibl = event_ms(lambda: fp.shade(cam.frame, d_surface, d_lights, N, None, ibl=desc), steps)
+    without = event_ms(lambda: fp.shade(cam.frame, d_surface, d_lights, N, None), steps)
+    return {"shade_with_ambient_ms": with_ibl[1], "shade_without_ms": without[1], "extra_bytes_per_pixel": 4,
+            "brdf_lut_256x256_ms": lut_ms[1], "kernel": "k2_shade_ibl"}
+
+
 def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev):
     """Single-GPU estimate of the G-way split: per-band step time (hipGraph replay), equal vs cost-balanced bands."""
     from sailor_amd import dist as sdist
@@ -455,6 +473,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(frame, args.cpu_sample_tile_rows)
             out["ecs_sweep"] = ecs_baseline(ctx, 1 << 20, 20)
             out["linearize_depth"] = linearize_block(ctx, frame, fp, d_lights, 30)
+            if csm is None:
+                out["ambient_ibl"] = ambient_block(ctx, frame, fp, d_lights, d_surface, 30)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

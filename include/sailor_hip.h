@@ -132,6 +132,23 @@ typedef struct SailorCsmDesc {
     int32_t format[SAILOR_NUM_CSM_CASCADES];
 } SailorCsmDesc;
 
+/* The image-based-lighting inputs of Standard.shader's AmbientLighting (:343-372): binding 3 `g_irradianceCubemap`, binding 4
+ * `g_brdfSampler`, binding 5 `g_envCubemap`, binding 9 `g_aoSampler` (:219-221,234).  All device pointers, fp32 texels (the
+ * reference keeps RGBA16F / RG16F images).  Canonical sampler (identical in the oracle): cube face and (s, t) by the Vulkan
+ * major-axis table (ties z over y over x), bilinear inside the face with clamp-to-edge, linear between the two nearest mip
+ * levels with lod clamped to [0, levels - 1]; 2-D: bilinear, clamp-to-edge. */
+typedef struct SailorIblDesc {
+    const float* irradiance; /* 6 faces (+X,-X,+Y,-Y,+Z,-Z) x irrSize^2 float4, face-major, row t = 0 first */
+    int32_t irrSize;
+    const float* env;        /* mip chain, level-major: level l = 6 faces x max(1, envSize >> l)^2 float4 */
+    int32_t envSize;
+    int32_t envLevels;       /* textureQueryLevels(g_envCubemap) (:361) */
+    const float* brdfLut;    /* lutH x lutW float2 (DFG1, DFG2), u = cosLo, v = roughness (ComputeBrdfLut.shader) */
+    int32_t lutW;
+    int32_t lutH;
+    const float* ao;         /* band rows x width floats: the g_aoSampler target at this pixel (:386); NULL = 1.0 */
+} SailorIblDesc;
+
 /*
  * A horizontal band of the frame: tile rows [tileRowBegin, tileRowEnd) of the light grid.  Tile row t covers
  * framebuffer rows H-1-16t-15 .. H-1-16t, so the band's pixels are framebuffer rows
@@ -258,6 +275,19 @@ SAILOR_HIP_API int sailor_hip_shade(SailorHipContext* ctx, const SailorUboFrameD
                                     const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
                                     const SailorCsmDesc* csm, float* dRadiance,
                                     const SailorBand* band);
+
+/* As sailor_hip_shade, plus the ambient term: outColor.rgb = AmbientLighting(...) + sum over lights
+ * (Standard.shader:425).  ibl == NULL is sailor_hip_shade. */
+SAILOR_HIP_API int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFrameData* frame,
+                                       const float* dSurface, size_t surfacePlaneStride,
+                                       const SailorLightShaderData* dLights, int32_t lightsNum,
+                                       const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
+                                       const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance,
+                                       const SailorBand* band);
+
+/* The split-sum BRDF look-up table sampled by AmbientLighting: Content/Shaders/ComputeBrdfLut.shader:26-71 (1 024 Hammersley /
+ * GGX samples per texel), dispatched once at start-up.  dLut: device, height x width float2 (the reference image is RG16F). */
+SAILOR_HIP_API int sailor_hip_compute_brdf_lut(SailorHipContext* ctx, float* dLut, int32_t width, int32_t height);
 
 /* ---- K4: ECS transform + bounds + frustum-cull sweep -------------------------------------------------------
  * Replaces: TransformECS::Tick full-sweep branch + CalculateMatrices (ECS/TransformECS.cpp:144-212),

@@ -83,6 +83,50 @@ def make_csm(lights_matrices: np.ndarray, maps: list) -> tuple[OracleCsm, list]:
     return d, keep
 
 
+class OracleIbl(C.Structure):
+    _fields_ = [("irradiance", C.c_void_p), ("irrSize", C.c_int32), ("env", C.c_void_p), ("envSize", C.c_int32), ("envLevels", C.c_int32),
+                ("brdfLut", C.c_void_p), ("lutW", C.c_int32), ("lutH", C.c_int32), ("ao", C.c_void_p)]
+
+
+def make_ibl(irradiance: np.ndarray, env_chain: np.ndarray, env_size: int, env_levels: int, brdf_lut: np.ndarray, ao: np.ndarray | None):
+    """irradiance float32[6,S,S,4]; env_chain float32 flat mip chain (level-major, each level [6,s,s,4]); brdf_lut float32[H,W,2];
+    ao float32[H,W] or None.  -> (OracleIbl, keep-alive list)"""
+    irr = np.ascontiguousarray(irradiance, np.float32); env = np.ascontiguousarray(env_chain, np.float32).reshape(-1)
+    lut = np.ascontiguousarray(brdf_lut, np.float32)
+    assert irr.ndim == 4 and irr.shape[0] == 6 and irr.shape[1] == irr.shape[2] and irr.shape[3] == 4 and lut.ndim == 3 and lut.shape[2] == 2
+    assert env.size == sum(6 * max(1, env_size >> l) ** 2 * 4 for l in range(env_levels))
+    d = OracleIbl()
+    d.irradiance, d.irrSize = irr.ctypes.data, irr.shape[1]
+    d.env, d.envSize, d.envLevels = env.ctypes.data, env_size, env_levels
+    d.brdfLut, d.lutW, d.lutH = lut.ctypes.data, lut.shape[1], lut.shape[0]
+    keep = [irr, env, lut]
+    if ao is not None:
+        a = np.ascontiguousarray(ao, np.float32)
+        d.ao = a.ctypes.data
+        keep.append(a)
+    return d, keep
+
+
+def compute_brdf_lut(w: int, h: int) -> np.ndarray:
+    """ComputeBrdfLut.shader:26-71 -> float32[h, w, 2] (DFG1, DFG2)"""
+    out = np.zeros((h, w, 2), np.float32)
+    lib().oracle_compute_brdf_lut(w, h, _p(out))
+    return out
+
+
+def cube_sample_lod(cube_chain: np.ndarray, size0: int, levels: int, direction, lod: float) -> np.ndarray:
+    c = np.ascontiguousarray(cube_chain, np.float32).reshape(-1); d = np.ascontiguousarray(direction, np.float32)
+    out = np.zeros(4, np.float32)
+    lib().oracle_cube_sample_lod(_p(c), size0, levels, _p(d), C.c_float(lod), _p(out))
+    return out
+
+
+def cube_face_st(direction):
+    d = np.ascontiguousarray(direction, np.float32); face = C.c_int(0); st = np.zeros(2, np.float32)
+    lib().oracle_cube_face_st(_p(d), C.byref(face), _p(st))
+    return face.value, st
+
+
 def light_cull(frame, W: int, H: int, lights: np.ndarray, depth: np.ndarray, tile_rows=None, literal_select: bool = False, want_counts: bool = False):
     """-> (grid uint32[T,2], indices uint32[1+T*128], counts uint32[T] | None) for the band of tile rows."""
     Tx, Ty = num_tiles(W, H)
@@ -99,7 +143,7 @@ def light_cull(frame, W: int, H: int, lights: np.ndarray, depth: np.ndarray, til
     return grid[:T], indices, (counts[:T] if want_counts else None)
 
 
-def shade(frame, W: int, H: int, surface: np.ndarray, lights: np.ndarray, grid: np.ndarray, indices: np.ndarray, csm=None, rows=None) -> np.ndarray:
+def shade(frame, W: int, H: int, surface: np.ndarray, lights: np.ndarray, grid: np.ndarray, indices: np.ndarray, csm=None, rows=None, ibl=None) -> np.ndarray:
     """surface float32[3,H,W,4]; grid/indices in the global canonical layout -> radiance float32[H,W,4] (rows outside `rows` are 0)."""
     fb = _frame_bytes(frame)
     surface = np.ascontiguousarray(surface, np.float32)
@@ -109,7 +153,11 @@ def shade(frame, W: int, H: int, surface: np.ndarray, lights: np.ndarray, grid: 
     lights = np.ascontiguousarray(lights)
     grid = np.ascontiguousarray(grid, np.uint32)
     indices = np.ascontiguousarray(indices, np.uint32)
-    lib().oracle_shade(_p(fb), W, H, _p(surface), _p(lights), _p(grid), _p(indices), C.byref(csm) if csm is not None else None, _p(out), r0, r1)
+    if ibl is not None:
+        lib().oracle_shade_ibl(_p(fb), W, H, _p(surface), _p(lights), _p(grid), _p(indices), C.byref(csm) if csm is not None else None,
+                               C.byref(ibl), _p(out), r0, r1)
+    else:
+        lib().oracle_shade(_p(fb), W, H, _p(surface), _p(lights), _p(grid), _p(indices), C.byref(csm) if csm is not None else None, _p(out), r0, r1)
     return out
 
 

@@ -738,15 +738,170 @@ static void calculate_lighting(const UboFrameData* ubo, const LightData* L, cons
     }
 }
 
+/* ------------------------------------------------------------------------------------------- */
+/* Ambient / image-based lighting: Standard.shader:343-372 AmbientLighting  */
+/* ------------------------------------------------------------------------------------------- */
+/* The reference samples three textures through Vulkan samplers (linear filtering, driver-defined precision).  The
+ * canonical sampler restated here -- and implemented identically on the GPU -- is:
+ *   cube face + (s, t) by the Vulkan spec's major-axis table (ties: z over y over x), bilinear INSIDE the face with
+ *   clamp-to-edge (no filtering across face seams), level-of-detail by linear interpolation between the two nearest
+ *   mip levels, lod clamped to [0, levels - 1]; 2-D textures: bilinear, clamp-to-edge, texel centres at (i + 0.5) / size.
+ * Texels are float4 (cubes) / float2 (LUT) in fp32; the reference stores RGBA16F / RG16F images. */
+typedef struct {
+    const float* irradiance; int irrSize;         /* 6 faces (+X,-X,+Y,-Y,+Z,-Z) x irrSize^2 float4, face-major, row t = 0 first */
+    const float* env; int envSize; int envLevels; /* mip chain, level-major: level l = 6 faces x max(1, envSize >> l)^2 float4 */
+    const float* brdfLut; int lutW, lutH;         /* float2 (DFG1, DFG2), row-major: u = cosLo, v = roughness */
+    const float* ao;                              /* optional W*H floats (the g_aoSampler target), NULL = 1.0 */
+} OracleIbl;
+
+static void cube_face_st(const float* r, int* face, float* s, float* t)
+{
+    const float ax = fabsf(r[0]), ay = fabsf(r[1]), az = fabsf(r[2]);
+    float sc, tc, ma;
+    if (az >= ax && az >= ay) { *face = r[2] < 0.0f ? 5 : 4; sc = r[2] < 0.0f ? -r[0] : r[0]; tc = -r[1]; ma = az; }
+    else if (ay >= ax)        { *face = r[1] < 0.0f ? 3 : 2; sc = r[0]; tc = r[1] < 0.0f ? -r[2] : r[2]; ma = ay; }
+    else                      { *face = r[0] < 0.0f ? 1 : 0; sc = r[0] < 0.0f ? r[2] : -r[2]; tc = -r[1]; ma = ax; }
+    *s = 0.5f * (sc / ma + 1.0f);
+    *t = 0.5f * (tc / ma + 1.0f);
+}
+
+static void bilinear4(const float* tex, int size, float s, float t, float* out) /* tex = one face, float4 texels */
+{
+    const float x = s * (float)size - 0.5f, y = t * (float)size - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float ax = x - fx, ay = y - fy;
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? 0 : (x0 > size - 1 ? size - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > size - 1 ? size - 1 : x1);
+    y0 = y0 < 0 ? 0 : (y0 > size - 1 ? size - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > size - 1 ? size - 1 : y1);
+    for (int c = 0; c < 4; c++) {
+        const float t00 = tex[((size_t)y0 * size + x0) * 4 + c], t10 = tex[((size_t)y0 * size + x1) * 4 + c];
+        const float t01 = tex[((size_t)y1 * size + x0) * 4 + c], t11 = tex[((size_t)y1 * size + x1) * 4 + c];
+        const float top = t00 * (1.0f - ax) + t10 * ax, bot = t01 * (1.0f - ax) + t11 * ax;
+        out[c] = top * (1.0f - ay) + bot * ay;
+    }
+}
+
+static void cube_sample_level(const float* cube, int size0, int level, const float* dir, float* out)
+{
+    size_t off = 0;
+    for (int l = 0; l < level; l++) { const int sz = (size0 >> l) > 1 ? (size0 >> l) : 1; off += (size_t)6 * sz * sz * 4; }
+    const int size = (size0 >> level) > 1 ? (size0 >> level) : 1;
+    int face; float s, t;
+    cube_face_st(dir, &face, &s, &t);
+    bilinear4(cube + off + (size_t)face * size * size * 4, size, s, t, out);
+}
+
+static void cube_sample_lod(const float* cube, int size0, int levels, const float* dir, float lod, float* out)
+{
+    const float maxLod = (float)(levels - 1);
+    lod = lod < 0.0f ? 0.0f : (lod > maxLod ? maxLod : lod);
+    const float fl = floorf(lod);
+    const int l0 = (int)fl, l1 = l0 + 1 > levels - 1 ? levels - 1 : l0 + 1;
+    const float f = lod - fl;
+    float a[4], b[4];
+    cube_sample_level(cube, size0, l0, dir, a);
+    cube_sample_level(cube, size0, l1, dir, b);
+    for (int c = 0; c < 4; c++) out[c] = a[c] * (1.0f - f) + b[c] * f;
+}
+
+static void lut_sample(const float* lut, int W, int H, float u, float v, float* outRG)
+{
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float ax = x - fx, ay = y - fy;
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1);
+    y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+    for (int c = 0; c < 2; c++) {
+        const float t00 = lut[((size_t)y0 * W + x0) * 2 + c], t10 = lut[((size_t)y0 * W + x1) * 2 + c];
+        const float t01 = lut[((size_t)y1 * W + x0) * 2 + c], t11 = lut[((size_t)y1 * W + x1) * 2 + c];
+        const float top = t00 * (1.0f - ax) + t10 * ax, bot = t01 * (1.0f - ax) + t11 * ax;
+        outRG[c] = top * (1.0f - ay) + bot * ay;
+    }
+}
+
+ORACLE_API void oracle_cube_sample_lod(const float* cube, int size0, int levels, const float* dir, float lod, float* out4)
+{
+    cube_sample_lod(cube, size0, levels, dir, lod, out4);
+}
+ORACLE_API void oracle_cube_face_st(const float* dir, int* face, float* st) { cube_face_st(dir, face, &st[0], &st[1]); }
+
+/* Standard.shader:343-372 */
+static void ambient_lighting(const OracleIbl* ibl, const float* albedo, float metallic, float roughness, float ao,
+                             const float* F0, const float* Lr, const float* normal, float cosLo, float* out)
+{
+    float irr[4], spec[4], brdf[2];
+    cube_sample_lod(ibl->irradiance, ibl->irrSize, 1, normal, 0.0f, irr);              /* :346 */
+    const float x = 1.0f - cosLo, x2 = x * x, f5 = x2 * x2 * x;                         /* :352 pow(1 - cosLo, 5) */
+    cube_sample_lod(ibl->env, ibl->envSize, ibl->envLevels, Lr, roughness * (float)ibl->envLevels, spec); /* :361-362 */
+    lut_sample(ibl->brdfLut, ibl->lutW, ibl->lutH, cosLo, roughness, brdf);             /* :365 */
+    for (int c = 0; c < 3; c++) {
+        const float F = F0[c] + (1.0f - F0[c]) * f5;
+        const float kd = (1.0f - F) * (1.0f - metallic) + 0.0f * metallic;             /* :355 mix(1 - F, 0, metallic) */
+        const float diffuseIBL = kd * albedo[c] * irr[c];                              /* :358 */
+        const float specularIBL = (F0[c] * brdf[0] + brdf[1]) * spec[c];               /* :368 */
+        out[c] = ao * (diffuseIBL + specularIBL);                                      /* :371 */
+    }
+}
+
+/* ComputeBrdfLut.shader:26-71 (Lighting.glsl:27-37 SampleGGX, :65-70 GeometrySchlickGGX_IBL, Math.glsl:285-293).
+ * outRG = w*h float2; pow(x, 5) as x^2 * x^2 * x (x in [0, 1]); the reference stores RG16F. */
+static float radical_inverse_vdc(uint32_t bits)
+{
+    bits = (bits << 16u) | (bits >> 16u);
+    bits = ((bits & 0x55555555u) << 1u) | ((bits & 0xAAAAAAAAu) >> 1u);
+    bits = ((bits & 0x33333333u) << 2u) | ((bits & 0xCCCCCCCCu) >> 2u);
+    bits = ((bits & 0x0F0F0F0Fu) << 4u) | ((bits & 0xF0F0F0F0u) >> 4u);
+    bits = ((bits & 0x00FF00FFu) << 8u) | ((bits & 0xFF00FF00u) >> 8u);
+    return (float)bits * 2.3283064365386963e-10f;
+}
+
+ORACLE_API void oracle_compute_brdf_lut(int w, int h, float* outRG)
+{
+    const float TwoPI = 6.283185307179586f;
+    const uint32_t NumSamples = 1024;
+    const float InvNumSamples = 1.0f / (float)NumSamples;
+    for (int gy = 0; gy < h; gy++) {
+        for (int gx = 0; gx < w; gx++) {
+            float cosLo = (float)gx / (float)w;
+            const float roughness = (float)gy / (float)h;
+            cosLo = fmaxf(cosLo, 0.001f);
+            const float Lo[3] = { sqrtf(1.0f - cosLo * cosLo), 0.0f, cosLo };
+            float DFG1 = 0.0f, DFG2 = 0.0f;
+            for (uint32_t i = 0; i < NumSamples; i++) {
+                const float u1 = (float)i * InvNumSamples, u2 = radical_inverse_vdc(i);
+                const float alpha = roughness * roughness;
+                const float cosTheta = sqrtf((1.0f - u2) / (1.0f + (alpha * alpha - 1.0f) * u2));
+                const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+                const float phi = TwoPI * u1;
+                const float Lh[3] = { sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta };
+                const float d = dot3(Lo, Lh);
+                const float Li[3] = { 2.0f * d * Lh[0] - Lo[0], 2.0f * d * Lh[1] - Lo[1], 2.0f * d * Lh[2] - Lo[2] };
+                const float cosLi = Li[2], cosLh = Lh[2], cosLoLh = fmaxf(d, 0.0f);
+                if (cosLi > 0.0f) {
+                    const float k = (roughness * roughness) / 2.0f;
+                    const float G = geometry_schlick_g1(cosLi, k) * geometry_schlick_g1(cosLo, k);
+                    const float Gv = G * cosLoLh / (cosLh * cosLo);
+                    const float x = 1.0f - cosLoLh, x2 = x * x, Fc = x2 * x2 * x;
+                    DFG1 += (1.0f - Fc) * Gv;
+                    DFG2 += Fc * Gv;
+                }
+            }
+            outRG[((size_t)gy * w + gx) * 2 + 0] = DFG1 * InvNumSamples;
+            outRG[((size_t)gy * w + gx) * 2 + 1] = DFG2 * InvNumSamples;
+        }
+    }
+}
+
 /*
  * Shade framebuffer rows [fbRowBegin, fbRowEnd).  surface = 3 planes of W*H float4 (plane-major):
  *   P0 = (worldPos.xyz, albedo.a)  P1 = (normal.xyz, roughness)  P2 = (albedo.rgb, metallic)   
  * out = W*H float4 (rgb = sum of lights, ambient == 0; a = albedo.a -- Standard.shader:425-438).
  * grid/indices are in the GLOBAL canonical layout (tile index = ty*Tx + tx).
  */
-ORACLE_API void oracle_shade(const void* ubo_, int W, int H, const float* surface, const void* lights_,
-                             const uint32_t* grid, const uint32_t* indices, const void* csm_, float* out,
-                             int fbRowBegin, int fbRowEnd)
+static void shade_impl(const void* ubo_, int W, int H, const float* surface, const void* lights_,
+                       const uint32_t* grid, const uint32_t* indices, const void* csm_, const OracleIbl* ibl, float* out,
+                       int fbRowBegin, int fbRowEnd)
 {
     const UboFrameData* ubo = (const UboFrameData*)ubo_;
     const LightData* lights = (const LightData*)lights_;
@@ -779,6 +934,11 @@ ORACLE_API void oracle_shade(const void* ubo_, int W, int H, const float* surfac
             const uint32_t offset = grid[2 * tileIndex + 0];
             const uint32_t numLights = grid[2 * tileIndex + 1];
             float acc[3] = { 0.0f, 0.0f, 0.0f };
+            if (ibl) { /* Standard.shader:396 Lr = 2 cosLo n + viewDirection; :425 outColor = AmbientLighting(...) */
+                const float Lr[3] = { 2.0f * cosLo * normal[0] + viewDir[0], 2.0f * cosLo * normal[1] + viewDir[1], 2.0f * cosLo * normal[2] + viewDir[2] };
+                const float ao = ibl->ao ? ibl->ao[(size_t)py * W + px] : 1.0f; /* :386 texel (px, py) of the AO target */
+                ambient_lighting(ibl, albedo, metallic, roughness, ao, F0, Lr, normal, cosLo, acc);
+            }
             for (uint32_t i = 0; i < numLights; i++) {
                 uint32_t index = indices[offset + i];
                 if (index == 0xFFFFFFFFu) break;
@@ -789,6 +949,21 @@ ORACLE_API void oracle_shade(const void* ubo_, int W, int H, const float* surfac
             out[pix + 0] = acc[0]; out[pix + 1] = acc[1]; out[pix + 2] = acc[2]; out[pix + 3] = P0[3];
         }
     }
+}
+
+ORACLE_API void oracle_shade(const void* ubo_, int W, int H, const float* surface, const void* lights_,
+                             const uint32_t* grid, const uint32_t* indices, const void* csm_, float* out,
+                             int fbRowBegin, int fbRowEnd)
+{
+    shade_impl(ubo_, W, H, surface, lights_, grid, indices, csm_, NULL, out, fbRowBegin, fbRowEnd);
+}
+
+/* as oracle_shade, with the ambient term of Standard.shader:425 (ibl = OracleIbl*) */
+ORACLE_API void oracle_shade_ibl(const void* ubo_, int W, int H, const float* surface, const void* lights_,
+                                 const uint32_t* grid, const uint32_t* indices, const void* csm_, const void* ibl_, float* out,
+                                 int fbRowBegin, int fbRowEnd)
+{
+    shade_impl(ubo_, W, H, surface, lights_, grid, indices, csm_, (const OracleIbl*)ibl_, out, fbRowBegin, fbRowEnd);
 }
 
 /* ------------------------------------------------------------------------------------------- */

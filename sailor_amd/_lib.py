@@ -68,6 +68,11 @@ class CsmDesc(C.Structure):
                 ("width", C.c_int32 * NUM_CASCADES), ("height", C.c_int32 * NUM_CASCADES), ("format", C.c_int32 * NUM_CASCADES)]
 
 
+class IblDesc(C.Structure):  # include/sailor_hip.h SailorIblDesc (Standard.shader bindings 3, 4, 5, 9)
+    _fields_ = [("irradiance", C.c_void_p), ("irrSize", C.c_int32), ("env", C.c_void_p), ("envSize", C.c_int32), ("envLevels", C.c_int32),
+                ("brdfLut", C.c_void_p), ("lutW", C.c_int32), ("lutH", C.c_int32), ("ao", C.c_void_p)]
+
+
 assert C.sizeof(UboFrameData) == 232 and C.sizeof(LightCullPushConstants) == 88 and C.sizeof(LightShaderData) == 112
 
 _P = C.c_void_p
@@ -97,6 +102,9 @@ SIGNATURES = {
     "sailor_hip_light_cull_diagnostics": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band), _P, C.POINTER(C.c_uint64)]),
     "sailor_hip_light_grid_rebase": (C.c_int, [_P, _P, C.c_int32, C.c_uint32]),
     "sailor_hip_shade": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_size_t, _P, C.c_int32, _P, _P, C.POINTER(CsmDesc), _P, C.POINTER(Band)]),
+    "sailor_hip_shade_ex": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_size_t, _P, C.c_int32, _P, _P, C.POINTER(CsmDesc), C.POINTER(IblDesc), _P,
+                                      C.POINTER(Band)]),
+    "sailor_hip_compute_brdf_lut": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     "sailor_hip_ecs_sweep": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_uint32), C.c_uint32, _P, C.POINTER(C.c_float), _P, _P, _P]),
     "sailor_hip_mesh_frustum_cull": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_uint32, C.c_uint32]),
     "sailor_hip_allgather_u32": (C.c_int, [_P, _P, _P, _P, C.c_size_t]),

@@ -35,6 +35,11 @@ struct CsmArgs {
     int format[SAILOR_NUM_CSM_CASCADES];
 };
 
+struct IblArgs { // SailorIblDesc by value
+    const float4* irradiance; const float4* env; const float2* brdfLut; const float* ao;
+    int irrSize, envSize, envLevels, lutW, lutH;
+};
+
 struct ShadeArgs {
     Mat4 view;
     float camX, camY, camZ;
@@ -197,6 +202,56 @@ __device__ float directional_shadow(const ShadeArgs& A, const CsmArgs& C, uint32
     return shadow_pcf(map, C.format[cascade], C.width[cascade], C.height[cascade], lp, bias);
 }
 
+// ---- ambient / IBL term (Standard.shader:343-372), canonical samplers == oracle/sailor_oracle.c (tolerance-checked) ----
+__device__ __forceinline__ void cube_face_st(float rx, float ry, float rz, int& face, float& s, float& t)
+{
+    const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
+    float sc, tc, ma;
+    if (az >= ax && az >= ay) { face = rz < 0.0f ? 5 : 4; sc = rz < 0.0f ? -rx : rx; tc = -ry; ma = az; }
+    else if (ay >= ax)        { face = ry < 0.0f ? 3 : 2; sc = rx; tc = ry < 0.0f ? -rz : rz; ma = ay; }
+    else                      { face = rx < 0.0f ? 1 : 0; sc = rx < 0.0f ? rz : -rz; tc = -ry; ma = ax; }
+    s = 0.5f * (sc / ma + 1.0f);
+    t = 0.5f * (tc / ma + 1.0f);
+}
+
+__device__ __forceinline__ float4 bilinear_f4(const float4* __restrict__ tex, int size, float s, float t)
+{
+    const BilinearTaps b = bilinear_taps(size, size, s, t);
+    const float4 a = tex[(size_t)b.y0 * size + b.x0], c = tex[(size_t)b.y0 * size + b.x1];
+    const float4 d = tex[(size_t)b.y1 * size + b.x0], e = tex[(size_t)b.y1 * size + b.x1];
+    return make_float4(lerp2(a.x, c.x, d.x, e.x, b.ax, b.ay), lerp2(a.y, c.y, d.y, e.y, b.ax, b.ay),
+                       lerp2(a.z, c.z, d.z, e.z, b.ax, b.ay), lerp2(a.w, c.w, d.w, e.w, b.ax, b.ay));
+}
+
+__device__ __forceinline__ float4 cube_sample_level(const float4* __restrict__ cube, int size0, int level, int face, float s, float t)
+{
+    size_t off = 0;
+    for (int l = 0; l < level; l++) { const int sz = max(size0 >> l, 1); off += (size_t)6 * sz * sz; }
+    const int size = max(size0 >> level, 1);
+    return bilinear_f4(cube + off + (size_t)face * size * size, size, s, t);
+}
+
+__device__ __forceinline__ float4 cube_sample_lod(const float4* __restrict__ cube, int size0, int levels, float rx, float ry, float rz, float lod)
+{
+    int face; float s, t;
+    cube_face_st(rx, ry, rz, face, s, t);
+    const float maxLod = (float)(levels - 1);
+    lod = lod < 0.0f ? 0.0f : (lod > maxLod ? maxLod : lod);
+    const float fl = floorf(lod);
+    const int l0 = (int)fl, l1 = min(l0 + 1, levels - 1);
+    const float f = lod - fl;
+    const float4 a = cube_sample_level(cube, size0, l0, face, s, t), b = cube_sample_level(cube, size0, l1, face, s, t);
+    return make_float4(a.x * (1.0f - f) + b.x * f, a.y * (1.0f - f) + b.y * f, a.z * (1.0f - f) + b.z * f, a.w * (1.0f - f) + b.w * f);
+}
+
+__device__ __forceinline__ float2 lut_sample(const float2* __restrict__ lut, int W, int H, float u, float v)
+{
+    const BilinearTaps b = bilinear_taps(W, H, u, v);
+    const float2 a = lut[(size_t)b.y0 * W + b.x0], c = lut[(size_t)b.y0 * W + b.x1];
+    const float2 d = lut[(size_t)b.y1 * W + b.x0], e = lut[(size_t)b.y1 * W + b.x1];
+    return make_float2(lerp2(a.x, c.x, d.x, e.x, b.ax, b.ay), lerp2(a.y, c.y, d.y, e.y, b.ax, b.ay));
+}
+
 // ---- K2 ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
@@ -244,8 +299,8 @@ __device__ __forceinline__ void wave_minmax6(int& a, int& b, int& c, int& d, int
 // below is about vector instructions per (wave, light) step: light type, finiteness and "survived the box test" are
 // wave-uniform 64-bit masks (scalar registers, scalar branches), the reach test feeds s_cbranch_vccz directly, and most
 // steps end after ~10 vector instructions.
-template <bool HAS_CSM>
-__device__ __forceinline__ void k2_shade_body(const ShadeArgs& A, const CsmArgs& C, const float4* __restrict__ surface, size_t planeStride,
+template <bool HAS_CSM, bool HAS_IBL>
+__device__ __forceinline__ void k2_shade_body(const ShadeArgs& A, const CsmArgs& C, const IblArgs& I, const float4* __restrict__ surface, size_t planeStride,
                                                  const SailorLightShaderData* __restrict__ lights,
                                                  const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled,
                                                  float4* __restrict__ radiance)
@@ -317,6 +372,7 @@ __device__ __forceinline__ void k2_shade_body(const ShadeArgs& A, const CsmArgs&
     const float vinv = 1.0f / sqrtf(dot3f(vx, vy, vz, vx, vy, vz));          // exact chain (see header)
     const float Lox = -(vx * vinv), Loy = -(vy * vinv), Loz = -(vz * vinv);  // Lo = -viewDirection
     const float cosLo = fmaxf(0.0f, dot3f(nx, ny, nz, Lox, Loy, Loz));
+    float accX = 0.0f, accY = 0.0f, accZ = 0.0f;
     const float oneMinusMetal = 1.0f - metallic;
     const float F0x = fmaf(P2.x, metallic, 0.04f * oneMinusMetal);
     const float F0y = fmaf(P2.y, metallic, 0.04f * oneMinusMetal);
@@ -373,7 +429,6 @@ __device__ __forceinline__ void k2_shade_body(const ShadeArgs& A, const CsmArgs&
     // (ds_add_f32 is serialised per lane on this LDS: ~170 cycles per wave instruction, scripts/microbench/lds_ops.hip).
     uint16_t* Q = sQ + wave * QMAX;
     float* res = sRes + threadIdx.x - lane; // this wave's [3 colours][PENDK][64 pixels] slots, 256 floats apart
-    float accX = 0.0f, accY = 0.0f, accZ = 0.0f;
     for (;;) {
         uint32_t cnt = 0u;      // queued pairs (wave-uniform)
         uint32_t pc = 0u;       // this pixel's queued pairs
@@ -466,7 +521,9 @@ __device__ __forceinline__ void k2_shade_body(const ShadeArgs& A, const CsmArgs&
             {
                 const float pnx = PULL(nx), pny = PULL(ny), pnz = PULL(nz);
                 const float pLox = PULL(Lox), pLoy = PULL(Loy), pLoz = PULL(Loz);
-                const float pcosLo = PULL(cosLo), pg1Lo = PULL(g1Lo), palphaSq = PULL(alphaSq), pk = PULL(k);
+                const float pcosLo = PULL(cosLo), pg1Lo = PULL(g1Lo), palphaSq = PULL(alphaSq);
+                const float pkr = HAS_IBL ? PULL(roughness) : PULL(k); // the ambient term at the end needs the roughness itself: pull it, derive k
+                const float pk = HAS_IBL ? ((pkr + 1.0f) * (pkr + 1.0f)) * 0.125f : pkr;
                 if (valid) {
                     if (HAS_CSM) {
                         const uint32_t bits = __float_as_uint(R[1].w);
@@ -520,29 +577,125 @@ __device__ __forceinline__ void k2_shade_body(const ShadeArgs& A, const CsmArgs&
         if (!overflow) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    if (HAS_IBL) {
+        float ambX, ambY, ambZ;
+        // outColor.xyz = AmbientLighting(material, F0, Lr, normal, cosLo) (Standard.shader:425, :343-372); Lr = 2 cosLo n + viewDirection (:396)
+        const float Lrx = fmaf(2.0f * cosLo, nx, -Lox), Lry = fmaf(2.0f * cosLo, ny, -Loy), Lrz = fmaf(2.0f * cosLo, nz, -Loz);
+        // Evaluated LAST, when only the pixel's invariants and the three sums are live, and one texture at a time (scheduling
+        // barriers): the pair pass sits exactly at 64 VGPRs, and three more live values across it -- or sixteen float4 gathers
+        // in flight here -- push the kernel to ~100 VGPRs = half the occupancy (measured: 0.40 instead of 0.19 ms).
+        const float x1 = 1.0f - cosLo, x2 = x1 * x1, x5 = x2 * x2 * x1;                                               // :352 FresnelSchlick(F0, cosLo)
+        const float Fx = fmaf(1.0f - F0x, x5, F0x), Fy = fmaf(1.0f - F0y, x5, F0y), Fz = fmaf(1.0f - F0z, x5, F0z);
+        {
+            int face; float cs, ct;
+            cube_face_st(nx, ny, nz, face, cs, ct);
+            const float4 irr = cube_sample_level(I.irradiance, I.irrSize, 0, face, cs, ct);                           // :346
+            ambX = (1.0f - Fx) * kdAx * irr.x; ambY = (1.0f - Fy) * kdAy * irr.y; ambZ = (1.0f - Fz) * kdAz * irr.z;  // :358 kd albedo irradiance
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float2 dfg = lut_sample(I.brdfLut, I.lutW, I.lutH, cosLo, roughness);                                    // :365
+        const float sx = fmaf(F0x, dfg.x, dfg.y), sy = fmaf(F0y, dfg.x, dfg.y), sz = fmaf(F0z, dfg.x, dfg.y);         // :368 F0 A + B
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            int face; float cs, ct;
+            cube_face_st(Lrx, Lry, Lrz, face, cs, ct);
+            const float maxLod = (float)(I.envLevels - 1);
+            float lod = roughness * (float)I.envLevels;                                                               // :361-362
+            lod = lod < 0.0f ? 0.0f : (lod > maxLod ? maxLod : lod);
+            const float fl = floorf(lod), f = lod - fl;
+            const int l0 = (int)fl, l1 = min(l0 + 1, I.envLevels - 1);
+            const float4 a = cube_sample_level(I.env, I.envSize, l0, face, cs, ct);
+            ambX = fmaf(sx * (1.0f - f), a.x, ambX); ambY = fmaf(sy * (1.0f - f), a.y, ambY); ambZ = fmaf(sz * (1.0f - f), a.z, ambZ);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 b = cube_sample_level(I.env, I.envSize, l1, face, cs, ct);
+            ambX = fmaf(sx * f, b.x, ambX); ambY = fmaf(sy * f, b.y, ambY); ambZ = fmaf(sz * f, b.z, ambZ);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float ao = I.ao ? I.ao[pix] : 1.0f;                                                                     // :386
+        accX = fmaf(ambX, ao, accX); accY = fmaf(ambY, ao, accY); accZ = fmaf(ambZ, ao, accZ);                              // :371, :425 ambient + sum over lights
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if (active) radiance[(size_t)(py - A.fbRow0) * A.W + gx] = make_float4(accX, accY, accZ, P0.w); // outColor.a = material.albedo.a (:438)
 }
 
-// Two entry points: without shadow maps the pair pass fits 64 VGPRs, and the register allocator is told to stay there
-// (8 waves per SIMD); with the 16-tap PCF inlined it does not, and forcing it would spill.
+// Entry points: without shadow maps the pair pass fits 64 VGPRs, and the register allocator is told to stay there
+// (8 waves per SIMD); with the 16-tap PCF inlined it does not, and forcing it would spill.  The ambient term adds a third.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k2_shade(ShadeArgs A, CsmArgs C, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
               const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
 {
-    k2_shade_body<false>(A, C, surface, planeStride, lights, grid, culled, radiance);
+    k2_shade_body<false, false>(A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance);
 }
 
 __global__ __launch_bounds__(256)
 void k2_shade_csm(ShadeArgs A, CsmArgs C, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
                   const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
 {
-    k2_shade_body<true>(A, C, surface, planeStride, lights, grid, culled, radiance);
+    k2_shade_body<true, false>(A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance);
 }
 
-extern "C" int sailor_hip_shade(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
-                                const SailorLightShaderData* dLights, int32_t lightsNum,
-                                const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
-                                const SailorCsmDesc* csm, float* dRadiance, const SailorBand* band)
+__global__ __launch_bounds__(256)
+void k2_shade_ibl(ShadeArgs A, CsmArgs C, IblArgs I, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
+                  const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
+{
+    k2_shade_body<false, true>(A, C, I, surface, planeStride, lights, grid, culled, radiance);
+}
+
+__global__ __launch_bounds__(256)
+void k2_shade_csm_ibl(ShadeArgs A, CsmArgs C, IblArgs I, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
+                      const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
+{
+    k2_shade_body<true, true>(A, C, I, surface, planeStride, lights, grid, culled, radiance);
+}
+
+// ---- ComputeBrdfLut.shader:26-71 (Lighting.glsl:27-37 SampleGGX, :65-70 GeometrySchlickGGX_IBL, Math.glsl:285-293) ----
+// One lane per texel, 1 024 samples each, the sums in sample order (as the shader's loop).
+__global__ __launch_bounds__(256) void k_brdf_lut(float2* __restrict__ lut, int W, int H)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= W * H) return;
+    const int gx = i % W, gy = i / W;
+    const float TwoPI = 6.283185307179586f;
+    const float InvNumSamples = 1.0f / 1024.0f;
+    float cosLo = (float)gx / (float)W;
+    const float roughness = (float)gy / (float)H;
+    cosLo = fmaxf(cosLo, 0.001f);
+    const float Lox = sqrtf(1.0f - cosLo * cosLo), Loz = cosLo;
+    const float alpha = roughness * roughness, k = (roughness * roughness) / 2.0f;
+    const float g1Lo = cosLo / (cosLo * (1.0f - k) + k);
+    float DFG1 = 0.0f, DFG2 = 0.0f;
+    for (uint32_t n = 0; n < 1024u; n++) {
+        const float u1 = (float)n * InvNumSamples;
+        const float u2 = (float)__brev(n) * 2.3283064365386963e-10f; // RadicalInverse_VdC == 32-bit reversal
+        const float cosTheta = sqrtf((1.0f - u2) / (1.0f + (alpha * alpha - 1.0f) * u2));
+        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        const float phi = TwoPI * u1;
+        const float Lhx = sinTheta * cosf(phi), Lhz = cosTheta; // Lh.y only enters Li.y, which is not used
+        const float d = (Lox * Lhx + 0.0f * (sinTheta * sinf(phi))) + Loz * Lhz;
+        const float cosLi = 2.0f * d * Lhz - Loz, cosLoLh = fmaxf(d, 0.0f);
+        if (cosLi > 0.0f) {
+            const float G = (cosLi / (cosLi * (1.0f - k) + k)) * g1Lo;
+            const float Gv = G * cosLoLh / (Lhz * cosLo);
+            const float x = 1.0f - cosLoLh, x2 = x * x, Fc = x2 * x2 * x;
+            DFG1 += (1.0f - Fc) * Gv;
+            DFG2 += Fc * Gv;
+        }
+    }
+    lut[i] = make_float2(DFG1 * InvNumSamples, DFG2 * InvNumSamples);
+}
+
+extern "C" int sailor_hip_compute_brdf_lut(SailorHipContext* ctx, float* dLut, int32_t width, int32_t height)
+{
+    if (!ctx || !dLut || width <= 0 || height <= 0 || ((uintptr_t)dLut & 7)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(k_brdf_lut, dim3((unsigned)(((size_t)width * height + 255) / 256)), dim3(256), 0, ctx->stream, (float2*)dLut, width, height);
+    SAILOR_CHECK_LAUNCH(ctx, "k_brdf_lut");
+    return SAILOR_HIP_OK;
+}
+
+extern "C" int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
+                                   const SailorLightShaderData* dLights, int32_t lightsNum,
+                                   const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
+                                   const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance, const SailorBand* band)
 {
     if (!ctx || !frame || !dSurface || !dLightsGrid || !dCulledLights || !dRadiance) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (lightsNum < 0 || (lightsNum > 0 && !dLights)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
@@ -584,6 +737,23 @@ extern "C" int sailor_hip_shade(SailorHipContext* ctx, const SailorUboFrameData*
         }
     }
     const dim3 grid((unsigned)A.Tx, (unsigned)(band->tileRowEnd - band->tileRowBegin));
+    if (ibl) {
+        if (!ibl->irradiance || !ibl->env || !ibl->brdfLut || ibl->irrSize <= 0 || ibl->envSize <= 0 || ibl->envLevels <= 0 || ibl->envLevels > 16 ||
+            ibl->lutW <= 0 || ibl->lutH <= 0)
+            return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+        if (((uintptr_t)ibl->irradiance & 15) || ((uintptr_t)ibl->env & 15) || ((uintptr_t)ibl->brdfLut & 7)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+        IblArgs I;
+        I.irradiance = (const float4*)ibl->irradiance; I.env = (const float4*)ibl->env; I.brdfLut = (const float2*)ibl->brdfLut; I.ao = ibl->ao;
+        I.irrSize = ibl->irrSize; I.envSize = ibl->envSize; I.envLevels = ibl->envLevels; I.lutW = ibl->lutW; I.lutH = ibl->lutH;
+        if (hasCsm)
+            hipLaunchKernelGGL(k2_shade_csm_ibl, grid, dim3(256), 0, ctx->stream, A, C, I, (const float4*)dSurface, surfacePlaneStride,
+                               dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
+        else
+            hipLaunchKernelGGL(k2_shade_ibl, grid, dim3(256), 0, ctx->stream, A, C, I, (const float4*)dSurface, surfacePlaneStride,
+                               dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
+        SAILOR_CHECK_LAUNCH(ctx, "k2_shade_ibl");
+        return SAILOR_HIP_OK;
+    }
     if (hasCsm)
         hipLaunchKernelGGL(k2_shade_csm, grid, dim3(256), 0, ctx->stream, A, C, (const float4*)dSurface, surfacePlaneStride,
                            dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
@@ -592,4 +762,12 @@ extern "C" int sailor_hip_shade(SailorHipContext* ctx, const SailorUboFrameData*
                            dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
     SAILOR_CHECK_LAUNCH(ctx, "k2_shade");
     return SAILOR_HIP_OK;
+}
+
+extern "C" int sailor_hip_shade(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
+                                const SailorLightShaderData* dLights, int32_t lightsNum,
+                                const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
+                                const SailorCsmDesc* csm, float* dRadiance, const SailorBand* band)
+{
+    return sailor_hip_shade_ex(ctx, frame, dSurface, surfacePlaneStride, dLights, lightsNum, dLightsGrid, dCulledLights, csm, nullptr, dRadiance, band);
 }

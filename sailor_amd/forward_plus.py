@@ -99,8 +99,9 @@ class ForwardPlus:
 
     # -- K2 + K3 --------------------------------------------------------------------------------------------------
     def shade(self, frame: UboFrameData, surface: torch.Tensor, lights: torch.Tensor, lights_num: int, csm: CsmDesc | None = None,
-              out: torch.Tensor | None = None) -> torch.Tensor:
-        """surface: float32 [3, band rows, W, 4]; returns radiance float32 [band rows, W, 4]."""
+              out: torch.Tensor | None = None, ibl: "_lib.IblDesc | None" = None) -> torch.Tensor:
+        """surface: float32 [3, band rows, W, 4]; returns radiance float32 [band rows, W, 4].  ibl: ambient term (its `ao`
+        pointer, if any, holds the band's rows)."""
         rows = self.band.fbRowCount
         assert surface.dtype == torch.float32 and surface.is_contiguous() and surface.shape == (3, rows, self.W, 4), surface.shape
         if out is None:
@@ -108,6 +109,11 @@ class ForwardPlus:
                 self.radiance = torch.empty((rows, self.W, 4), dtype=torch.float32, device=self.ctx.device)
             out = self.radiance
         lib = self.ctx._lib
+        if ibl is not None:
+            _lib.check(lib.sailor_hip_shade_ex(self.ctx.handle, C.byref(frame), _ptr(surface), rows * self.W, _ptr(lights), lights_num, _ptr(self.grid),
+                                               _ptr(self.culled), C.byref(csm) if csm is not None else None, C.byref(ibl), _ptr(out), C.byref(self.band)),
+                       "sailor_hip_shade_ex", self.ctx.handle)
+            return out
         _lib.check(lib.sailor_hip_shade(self.ctx.handle, C.byref(frame), _ptr(surface), rows * self.W, _ptr(lights), lights_num, _ptr(self.grid),
                                         _ptr(self.culled), C.byref(csm) if csm is not None else None, _ptr(out), C.byref(self.band)),
                    "sailor_hip_shade", self.ctx.handle)
@@ -146,6 +152,31 @@ def upload_shadow_maps(shadows, device) -> tuple[CsmDesc, list]:
         fmt = _lib.SHADOWMAP_R16F if m.dtype == np.float16 else (_lib.SHADOWMAP_RGBA32F if m.ndim == 3 else _lib.SHADOWMAP_R32F)
         maps.append((t.data_ptr(), m.shape[1], m.shape[0], fmt))
     return host.make_csm_desc(shadows.lights_matrices, maps), keep
+
+
+def upload_ibl(ibl_set, device, ao_rows: tuple[int, int] | None = None) -> tuple["_lib.IblDesc", list]:
+    """synth.IblSet -> (IblDesc with device pointers, tensors to keep alive); ao_rows = framebuffer rows of the band."""
+    irr = torch.from_numpy(np.ascontiguousarray(ibl_set.irradiance)).to(device)
+    env = torch.from_numpy(np.ascontiguousarray(ibl_set.env_chain)).to(device)
+    lut = torch.from_numpy(np.ascontiguousarray(ibl_set.brdf_lut)).to(device)
+    keep = [irr, env, lut]
+    d = _lib.IblDesc()
+    d.irradiance, d.irrSize = irr.data_ptr(), ibl_set.irradiance.shape[1]
+    d.env, d.envSize, d.envLevels = env.data_ptr(), ibl_set.env_size, ibl_set.env_levels
+    d.brdfLut, d.lutW, d.lutH = lut.data_ptr(), ibl_set.brdf_lut.shape[1], ibl_set.brdf_lut.shape[0]
+    if ibl_set.ao is not None:
+        a = ibl_set.ao if ao_rows is None else ibl_set.ao[ao_rows[0]:ao_rows[1]]
+        ao = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        keep.append(ao)
+        d.ao = ao.data_ptr()
+    return d, keep
+
+
+def compute_brdf_lut(ctx: "HipContext", width: int, height: int) -> torch.Tensor:
+    """ComputeBrdfLut.shader on the GPU -> float32 [height, width, 2]"""
+    out = torch.empty((height, width, 2), dtype=torch.float32, device=ctx.device)
+    _lib.check(ctx._lib.sailor_hip_compute_brdf_lut(ctx.handle, _ptr(out), width, height), "sailor_hip_compute_brdf_lut", ctx.handle)
+    return out
 
 
 class EcsSweep:

@@ -51,6 +51,17 @@ void RHIFrameGraph::Process(RHISceneViewSnapshot& snapshot)
     auto transferCmdList = driver->CreateCommandList();
     auto cmdList = driver->CreateCommandList();
     FillFrameData(transferCmdList, snapshot, snapshot.m_deltaTime, snapshot.m_currentTime);
+    if (snapshot.m_rhiLightsData) { // RHIFrameGraph.cpp:128-163: the IBL samplers and the AO target join the lights set (bindings 3, 4, 5, 9)
+        struct { const char* name; RHITexturePtr tex; uint32_t binding; } ibl[] = {
+            { "g_irradianceCubemap", GetSampler("g_irradianceCubemap"), 3 }, { "g_brdfSampler", GetSampler("g_brdfSampler"), 4 },
+            { "g_envCubemap", GetSampler("g_envCubemap"), 5 }, { "g_aoSampler", GetRenderTarget("g_AO"), 9 } };
+        for (auto& e : ibl) {
+            if (!e.tex) continue;
+            auto b = snapshot.m_rhiLightsData->Find(e.name);
+            if (!b || b->m_textures.empty() || b->m_textures[0].GetRawPtr() != e.tex.GetRawPtr())
+                driver->AddSamplerToShaderBindings(snapshot.m_rhiLightsData, e.name, e.tex, e.binding);
+        }
+    }
     for (auto& node : m_graph) node->Prepare(this, snapshot);
     for (auto& node : m_graph) node->Process(this, transferCmdList, cmdList, snapshot); // RHIFrameGraph.cpp:250-252
     driver->SubmitCommandList(transferCmdList);

@@ -20,6 +20,13 @@ public:
         auto it = m_renderTargets.find(name);
         return it == m_renderTargets.end() ? RHI::RHITexturePtr() : it->second;
     }
+    // named samplers published by nodes (EnvironmentNode.cpp:79,169-170 SetSampler("g_brdfSampler" / "g_envCubemap" / "g_irradianceCubemap"))
+    void SetSampler(const std::string& name, RHI::RHITexturePtr tex) { m_samplers[name] = tex; }
+    RHI::RHITexturePtr GetSampler(const std::string& name) const
+    {
+        auto it = m_samplers.find(name);
+        return it == m_samplers.end() ? RHI::RHITexturePtr() : it->second;
+    }
     void SetViewport(int32_t width, int32_t height) { m_viewport = { width, height }; } // App::GetMainWindow()->GetRenderArea()
 
     RHI::UboFrameData FillFrameData(RHI::RHICommandListPtr transferCmdList, RHI::RHISceneViewSnapshot& snapshot, float deltaTime, float worldTime) const;
@@ -30,6 +37,7 @@ public:
 private:
     std::vector<FrameGraphNodePtr> m_graph;
     std::map<std::string, RHI::RHITexturePtr> m_renderTargets;
+    std::map<std::string, RHI::RHITexturePtr> m_samplers;
     RHI::ivec2 m_viewport;
 };
 

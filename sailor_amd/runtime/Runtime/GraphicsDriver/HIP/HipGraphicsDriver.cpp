@@ -67,7 +67,7 @@ RHIBufferPtr HipGraphicsDriver::WrapBuffer(void* devicePtr, size_t size)
 
 RHIShaderPtr HipGraphicsDriver::CreateShader(const std::string& assetPath) { return RHIShaderPtr::Make(assetPath); }
 
-static size_t texel_size(EFormat f) { return f == EFormat::R16_SFLOAT ? 2 : (f == EFormat::R32_SFLOAT ? 4 : 16); }
+static size_t texel_size(EFormat f) { return f == EFormat::R16_SFLOAT ? 2 : (f == EFormat::R32_SFLOAT ? 4 : (f == EFormat::R32G32_SFLOAT ? 8 : 16)); }
 
 RHITexturePtr HipGraphicsDriver::CreateTexture(const void* pData, size_t size, ivec2 extent, EFormat format)
 {
@@ -250,11 +250,28 @@ int HipGraphicsDriver::RecordShade(const TVector<RHIShaderBindingSetPtr>& bindin
             hasCsm = true;
         }
     }
+    // Standard.shader:219-221,234: bindings 3 g_irradianceCubemap, 4 g_brdfSampler, 5 g_envCubemap, 9 g_aoSampler -> the ambient term
+    SailorIblDesc ibl {};
+    bool hasIbl = false;
+    {
+        auto tex = [&](const char* name) -> RHITexturePtr {
+            auto b = bindings[1]->Find(name);
+            return (b && !b->m_textures.empty() && b->m_textures[0] && b->m_textures[0]->m_buffer) ? b->m_textures[0] : RHITexturePtr();
+        };
+        auto irr = tex("g_irradianceCubemap"), lut = tex("g_brdfSampler"), env = tex("g_envCubemap"), ao = tex("g_aoSampler");
+        if (irr && lut && env) {
+            ibl.irradiance = (const float*)irr->m_buffer->m_hip.m_devicePtr; ibl.irrSize = irr->m_extent.x;
+            ibl.env = (const float*)env->m_buffer->m_hip.m_devicePtr; ibl.envSize = env->m_extent.x; ibl.envLevels = (int32_t)env->m_mipLevels;
+            ibl.brdfLut = (const float*)lut->m_buffer->m_hip.m_devicePtr; ibl.lutW = lut->m_extent.x; ibl.lutH = lut->m_extent.y;
+            ibl.ao = (ao && ao->m_extent.x == W && ao->m_extent.y == H) ? (const float*)ao->m_buffer->m_hip.m_devicePtr : nullptr;
+            hasIbl = true;
+        }
+    }
     const int32_t lightsNum = (int32_t)(countB->m_buffer->m_size / sizeof(SailorLightShaderData));
-    return sailor_hip_shade(m_ctx, &frame, (const float*)surfaceB->m_buffer->m_hip.m_devicePtr, (size_t)W * H,
-                            (const SailorLightShaderData*)buffer_of(bindings[1], "light"), lightsNum,
-                            (const SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (const uint32_t*)buffer_of(bindings[1], "culledLights"),
-                            hasCsm ? &csm : nullptr, (float*)buffer_of(bindings[2], "radiance"), nullptr);
+    return sailor_hip_shade_ex(m_ctx, &frame, (const float*)surfaceB->m_buffer->m_hip.m_devicePtr, (size_t)W * H,
+                               (const SailorLightShaderData*)buffer_of(bindings[1], "light"), lightsNum,
+                               (const SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (const uint32_t*)buffer_of(bindings[1], "culledLights"),
+                               hasCsm ? &csm : nullptr, hasIbl ? &ibl : nullptr, (float*)buffer_of(bindings[2], "radiance"), nullptr);
 }
 
 // ---- the render-pass subset: state is kept on the command list, a 6-index draw of a known full-screen material becomes a

@@ -69,7 +69,7 @@ public:
 };
 using RHIBufferPtr = TRefPtr<RHIBuffer>;
 
-enum class EFormat { R32_SFLOAT, R16_SFLOAT, R32G32B32A32_SFLOAT };
+enum class EFormat { R32_SFLOAT, R16_SFLOAT, R32G32B32A32_SFLOAT, R32G32_SFLOAT };
 enum class EImageLayout { Undefined, ShaderReadOnlyOptimal, General, ColorAttachmentOptimal };
 
 // RHI/Texture.h: here a linear row-major image in device memory (row 0 = top)
@@ -78,6 +78,7 @@ public:
     RHIBufferPtr m_buffer;
     ivec2 m_extent;
     EFormat m_format = EFormat::R32_SFLOAT;
+    uint32_t m_mipLevels = 1; // a cubemap is 6 faces x m_extent.x^2 texels per level, level-major (include/sailor_hip.h SailorIblDesc)
     ivec2 GetExtent() const { return m_extent; }
 };
 using RHITexturePtr = TRefPtr<RHITexture>;

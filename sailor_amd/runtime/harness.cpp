@@ -140,6 +140,25 @@ RT_API void sailor_rt_set_shadow_maps(SailorRuntime* rt, void* const* mapDeviceP
     rt->lighting->SetShadowMaps(maps, lightsMatrices64);
 }
 
+// the image-based-lighting inputs: published to the frame graph the way EnvironmentNode does (SetSampler, EnvironmentNode.cpp:79,169-170),
+// the AO target as render target "g_AO" (RHIFrameGraph.cpp:155)
+RT_API void sailor_rt_set_ibl(SailorRuntime* rt, void* irradiance, int irrSize, void* env, int envSize, int envLevels, void* lut, int lutW, int lutH,
+                              void* ao, int width, int height)
+{
+    auto* hip = static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver());
+    auto irr = hip->WrapTexture(irradiance, { irrSize, irrSize * 6 }, EFormat::R32G32B32A32_SFLOAT);
+    size_t envTexels = 0;
+    for (int l = 0; l < envLevels; l++) { const int s = (envSize >> l) > 1 ? (envSize >> l) : 1; envTexels += (size_t)6 * s * s; }
+    auto e = hip->WrapTexture(env, { 1, (int32_t)envTexels }, EFormat::R32G32B32A32_SFLOAT);
+    e->m_extent = { envSize, envSize };
+    e->m_mipLevels = (uint32_t)envLevels;
+    irr->m_extent = { irrSize, irrSize };
+    rt->graph.SetSampler("g_irradianceCubemap", irr);
+    rt->graph.SetSampler("g_envCubemap", e);
+    rt->graph.SetSampler("g_brdfSampler", hip->WrapTexture(lut, { lutW, lutH }, EFormat::R32G32_SFLOAT));
+    if (ao) rt->graph.SetRenderTarget("g_AO", hip->WrapTexture(ao, { width, height }, EFormat::R32_SFLOAT));
+}
+
 RT_API int sailor_rt_process_frame(SailorRuntime* rt)
 {
     rt->graph.Process(rt->snapshot);

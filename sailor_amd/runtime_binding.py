@@ -37,6 +37,7 @@ def load() -> C.CDLL:
         rt.sailor_rt_set_raw_depth.argtypes = [P, P, C.c_int, C.c_int]
         rt.sailor_rt_set_surface.argtypes = [P, P, P, C.c_int, C.c_int]
         rt.sailor_rt_set_shadow_maps.argtypes = [P, P, P, P, P]
+        rt.sailor_rt_set_ibl.argtypes = [P, P, C.c_int, P, C.c_int, C.c_int, P, C.c_int, C.c_int, P, C.c_int, C.c_int]
         rt.sailor_rt_process_frame.argtypes = [P]
         rt.sailor_rt_wait_idle.argtypes = [P]
         rt.sailor_rt_buffer.restype = P
@@ -78,6 +79,12 @@ class Runtime:
     def set_raw_depth(self, raw_tensor):
         """after set_depth: the LinearizeDepth node reads this and writes the tensor given to set_depth"""
         self.rt.sailor_rt_set_raw_depth(self.h, raw_tensor.data_ptr(), raw_tensor.shape[1], raw_tensor.shape[0])
+
+    def set_ibl(self, irradiance, env_chain, env_size, env_levels, lut, ao):
+        """device tensors: irradiance [6,S,S,4], env mip chain (flat), lut [H,W,2], ao [H,W] or None"""
+        self.rt.sailor_rt_set_ibl(self.h, irradiance.data_ptr(), irradiance.shape[1], env_chain.data_ptr(), env_size, env_levels,
+                                  lut.data_ptr(), lut.shape[1], lut.shape[0], ao.data_ptr() if ao is not None else None,
+                                  ao.shape[1] if ao is not None else 0, ao.shape[0] if ao is not None else 0)
 
     def set_surface(self, surface_tensor, radiance_tensor):
         self.rt.sailor_rt_set_surface(self.h, surface_tensor.data_ptr(), radiance_tensor.data_ptr(), surface_tensor.shape[2], surface_tensor.shape[1])

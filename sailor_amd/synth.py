@@ -253,6 +253,61 @@ def directional_forward(q) -> np.ndarray:
 
 
 @dataclass
+class IblSet:
+    irradiance: np.ndarray     # float32[6, S, S, 4]   g_irradianceCubemap (one level)
+    env_chain: np.ndarray      # float32 flat mip chain of g_envCubemap, level-major, each level [6, s, s, 4]
+    env_size: int
+    env_levels: int
+    brdf_lut: np.ndarray       # float32[H, W, 2]      g_brdfSampler (ComputeBrdfLut.shader)
+    ao: np.ndarray | None      # float32[H, W]         g_aoSampler target, or None
+
+
+def _cube_dirs(size: int) -> np.ndarray:
+    """unit direction of every texel centre, [6, size, size, 3], face / (s, t) convention of the Vulkan major-axis table"""
+    c = (np.arange(size, dtype=np.float64) + 0.5) / size * 2.0 - 1.0
+    sc, tc = np.meshgrid(c, c)  # tc varies along rows
+    one = np.ones_like(sc)
+    faces = [(one, -tc, -sc), (-one, -tc, sc), (sc, one, tc), (sc, -one, -tc), (sc, -tc, one), (-sc, -tc, -one)]
+    d = np.stack([np.stack(f, -1) for f in faces], 0)
+    return d / np.linalg.norm(d, axis=-1, keepdims=True)
+
+
+def make_ibl_set(width: int, height: int, lut, env_size: int = 64, irr_size: int = 16, seed: int = SEED, with_ao: bool = True) -> IblSet:
+    """Analytic sky: a sun lobe + horizon gradient + a few coloured blobs, evaluated at texel centres; mips by 2x2 box filter;
+    'irradiance' = a low-frequency version of the same sky (a stand-in for ComputeIrradianceMap.shader's output).  `lut` is the
+    BRDF look-up table (float32[H, W, 2]) -- pass oracle.compute_brdf_lut(...) or the GPU's.  AO = value noise in [0.3, 1]."""
+    u = uniforms(STREAM_SHADOW, 64, 1 << 27, seed).astype(np.float64)
+
+    def sky(d, sharp):
+        sun = np.array([0.3, 0.8, 0.52]); sun /= np.linalg.norm(sun)
+        out = np.zeros(d.shape[:-1] + (4,), np.float64)
+        up = d[..., 1] * 0.5 + 0.5
+        out[..., 0] = 0.25 + 0.5 * up; out[..., 1] = 0.35 + 0.5 * up; out[..., 2] = 0.55 + 0.4 * up
+        lobe = np.clip((d * sun).sum(-1), 0, 1) ** sharp
+        out[..., :3] += lobe[..., None] * np.array([6.0, 5.0, 3.5])
+        for k in range(6):
+            c = u[k * 6:k * 6 + 3] * 2 - 1; c /= np.linalg.norm(c)
+            col = u[k * 6 + 3:k * 6 + 6] * 2.0
+            out[..., :3] += (np.clip((d * c).sum(-1), 0, 1) ** (sharp * 0.5))[..., None] * col
+        out[..., 3] = 1.0
+        return out
+
+    levels = int(np.log2(env_size)) + 1
+    chain = [sky(_cube_dirs(env_size), 64.0)]
+    for _l in range(1, levels):
+        p = chain[-1]
+        s2 = p.shape[1] // 2
+        chain.append(p.reshape(6, s2, 2, s2, 2, 4).mean(axis=(2, 4)))
+    env_chain = np.concatenate([c.astype(np.float32).reshape(-1) for c in chain])
+    irr = sky(_cube_dirs(irr_size), 2.0).astype(np.float32) * np.float32(0.35)
+    ao = None
+    if with_ao:
+        ao = (0.3 + 0.7 * _value_noise(width, height, 32, STREAM_SURFACE, 1 << 25, seed)).astype(np.float32)
+    return IblSet(irradiance=np.ascontiguousarray(irr), env_chain=np.ascontiguousarray(env_chain), env_size=env_size, env_levels=levels,
+                  brdf_lut=np.ascontiguousarray(lut, np.float32), ao=ao)
+
+
+@dataclass
 class ShadowSet:
     lights_matrices: np.ndarray                 # float32[4,16]
     maps: list = field(default_factory=list)    # 4 numpy arrays: [0] float32[S,S,4], [1..3] float16[S,S]

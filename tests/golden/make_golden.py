@@ -49,7 +49,23 @@ def make_depth() -> None:
     print(f"tiny_depth: {raw.shape[1]}x{raw.shape[0]}, {(raw == 0).mean():.3f} sky, linear range [{lin[np.isfinite(lin)].min():.3f}, {lin[np.isfinite(lin)].max():.3e}]")
 
 
+def make_ibl() -> None:
+    """Ambient term: the oracle's ComputeBrdfLut table (32x32) and the tiny frame shaded with the synthetic
+    IBL set (the cubemaps / AO regenerate from the frozen generator, so only the table and the result are stored)."""
+    f = synth.make_frame("tiny")
+    W, H = f.cam.width, f.cam.height
+    lut = oracle.compute_brdf_lut(32, 32)
+    ibl = synth.make_ibl_set(W, H, lut)
+    g, idx, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth)
+    oibl, _keep = oracle.make_ibl(ibl.irradiance, ibl.env_chain, ibl.env_size, ibl.env_levels, ibl.brdf_lut, ibl.ao)
+    rad = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, g, idx, ibl=oibl)
+    np.savez_compressed(OUT / "tiny_ibl.npz", brdf_lut=lut, radiance=rad, env_checksum=np.float64(ibl.env_chain.astype(np.float64).sum()),
+                        irr_checksum=np.float64(ibl.irradiance.astype(np.float64).sum()), ao_checksum=np.float64(ibl.ao.astype(np.float64).sum()))
+    print(f"tiny_ibl: lut range [{lut.min():.4f}, {lut.max():.4f}], mean radiance {rad[..., :3].mean():.3f}")
+
+
 if __name__ == "__main__":
     for n in ("tiny", "tiny_csm"):
         make(n)
     make_depth()
+    make_ibl()

@@ -1,0 +1,76 @@
+"""Ambient / image-based lighting term on the GPU: Standard.shader's AmbientLighting (:343-372) added to
+the shaded radiance, and the ComputeBrdfLut.shader table it samples -- through the C-ABI, against the CPU oracle.
+Tolerance as for K2: |gpu - ref| <= 1e-4*|ref| + 1e-5 (the samplers are bilinear fp32 on both sides)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from sailor_amd import host, synth
+from sailor_amd.forward_plus import ForwardPlus, compute_brdf_lut, upload_ibl, upload_lights, upload_shadow_maps
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def close(got, ref):
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    bad = err > RTOL * np.abs(ref.astype(np.float64)) + ATOL
+    assert np.isfinite(got).all() and not bad.any(), f"{bad.sum()} of {bad.size} out of tolerance, worst abs {err.max():.3e}"
+
+
+def test_brdf_lut_matches_the_oracle(ctx):
+    for w, h in ((32, 32), (48, 20)):
+        got = compute_brdf_lut(ctx, w, h).cpu().numpy()
+        ref = oracle.compute_brdf_lut(w, h)
+        # 1 024-term sums of cos / sin / sqrt expressions: libm vs device trigonometry differ in the last ulp per term
+        assert np.abs(got - ref).max() < 2e-6, np.abs(got - ref).max()
+        assert 0.0 <= got.min() and got.max() <= 1.0 + 1e-6
+        assert got[0, 0, 1] > 0.99 and got[h - 1, w - 1, 0] < 0.5  # grazing + smooth: all Fresnel; normal + rough: darkened
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_csm"])
+@pytest.mark.parametrize("with_ao", [True, False])
+def test_ambient_plus_lights(ctx, name, with_ao):
+    f = synth.make_frame(name)
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    ibl = synth.make_ibl_set(W, H, oracle.compute_brdf_lut(32, 32), with_ao=with_ao)
+    g, idx, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth)
+    ocsm = None
+    if f.shadows is not None:
+        ocsm, _k = oracle.make_csm(f.shadows.lights_matrices, f.shadows.maps)
+    oibl, _k2 = oracle.make_ibl(ibl.irradiance, ibl.env_chain, ibl.env_size, ibl.env_levels, ibl.brdf_lut, ibl.ao)
+    ref = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, g, idx, ocsm, ibl=oibl)
+    direct = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, g, idx, ocsm)
+    assert (ref[..., :3] - direct[..., :3]).min() > 0.0, "the ambient term is strictly positive on this sky"
+
+    fp = ForwardPlus(ctx, W, H, N)
+    lights = upload_lights(f.lights, ctx.device)
+    fp.cull(f.cam.frame, lights, N, torch.from_numpy(f.depth).to(ctx.device))
+    csm, keep = upload_shadow_maps(f.shadows, ctx.device) if f.shadows is not None else (None, None)
+    desc, keep2 = upload_ibl(ibl, ctx.device)
+    got = fp.shade(f.cam.frame, torch.from_numpy(f.surface).to(ctx.device), lights, N, csm, ibl=desc).cpu().numpy()
+    close(got, ref)
+    np.testing.assert_array_equal(got[..., 3], ref[..., 3])
+
+
+def test_ambient_on_bands_and_ragged_viewport(ctx):
+    """AO rows follow the band; 131x77 has partial tiles."""
+    w, h = 131, 77
+    cam = synth.make_camera(w, h)
+    depth = synth.make_linear_depth(w, h, 5)
+    lights = synth.make_lights(cam, depth, synth.LightSetConfig(count=300, radius_scale=5.0, spot_fraction=0.3), 5)
+    surface = synth.make_surface(cam, depth, 5)
+    ibl = synth.make_ibl_set(w, h, oracle.compute_brdf_lut(16, 16), env_size=32, irr_size=8, seed=5)
+    g, idx, _ = oracle.light_cull(cam.frame, w, h, lights, depth)
+    oibl, _k = oracle.make_ibl(ibl.irradiance, ibl.env_chain, ibl.env_size, ibl.env_levels, ibl.brdf_lut, ibl.ao)
+    ref = oracle.shade(cam.frame, w, h, surface, lights, g, idx, ibl=oibl)
+    d_lights = upload_lights(lights, ctx.device)
+    for r in range(2):
+        band = host.band_for_rank(w, h, r, 2)
+        rows = slice(band.fbRowBegin, band.fbRowBegin + band.fbRowCount)
+        fp = ForwardPlus(ctx, w, h, len(lights), band=band)
+        fp.cull(cam.frame, d_lights, len(lights), torch.from_numpy(np.ascontiguousarray(depth[rows])).to(ctx.device))
+        desc, keep = upload_ibl(ibl, ctx.device, ao_rows=(rows.start, rows.stop))
+        got = fp.shade(cam.frame, torch.from_numpy(np.ascontiguousarray(surface[:, rows])).to(ctx.device), d_lights, len(lights), None, ibl=desc).cpu().numpy()
+        close(got, ref[rows])

@@ -232,3 +232,33 @@ def test_nan_impacts_c_numpy_and_literal_agree():
         n = 1 + int(i[0])
         np.testing.assert_array_equal(g, g2); np.testing.assert_array_equal(i[:n], i2[:n])
         np.testing.assert_array_equal(g, g3); np.testing.assert_array_equal(i[:n], i3[:n])
+
+
+def test_ambient_term_golden_and_sampler_conventions():
+    """SURVEY.md 8f rank 2.  (a) the BRDF table and the ambient-lit tiny frame against the committed fixture; (b) the canonical cube
+    sampler: face / (s, t) by the Vulkan major-axis table, texel centres reproduce the texel, lod interpolates between levels."""
+    g = np.load(GOLDEN / "tiny_ibl.npz")
+    lut = oracle.compute_brdf_lut(32, 32)
+    np.testing.assert_allclose(lut, g["brdf_lut"], rtol=0, atol=1e-7)
+    f = synth.make_frame("tiny")
+    W, H = f.cam.width, f.cam.height
+    ibl = synth.make_ibl_set(W, H, lut)
+    assert abs(ibl.env_chain.astype(np.float64).sum() - float(g["env_checksum"])) < 1e-6 * float(g["env_checksum"])
+    assert abs(ibl.ao.astype(np.float64).sum() - float(g["ao_checksum"])) < 1e-6 * float(g["ao_checksum"])
+    gr, idx, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth)
+    oibl, _k = oracle.make_ibl(ibl.irradiance, ibl.env_chain, ibl.env_size, ibl.env_levels, ibl.brdf_lut, ibl.ao)
+    rad = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, gr, idx, ibl=oibl)
+    np.testing.assert_allclose(rad, g["radiance"], rtol=1e-6, atol=1e-6)
+    # (b)
+    for d, face in (([1, .2, .3], 0), ([-1, .2, .3], 1), ([.1, 1, .3], 2), ([.1, -1, .3], 3), ([.1, .2, 1], 4), ([.1, .2, -1], 5), ([1, 1, 1], 4), ([1, 1, -1], 5)):
+        assert oracle.cube_face_st(d)[0] == face
+    dirs = synth._cube_dirs(ibl.env_size)
+    lvl0 = ibl.env_chain[: 6 * ibl.env_size ** 2 * 4].reshape(6, ibl.env_size, ibl.env_size, 4)
+    for fc, y, x in ((0, 3, 5), (1, 0, 0), (2, 63, 63), (3, 10, 40), (4, 31, 32), (5, 7, 7)):
+        np.testing.assert_allclose(oracle.cube_sample_lod(ibl.env_chain, ibl.env_size, ibl.env_levels, dirs[fc, y, x], 0.0), lvl0[fc, y, x], rtol=2e-5)
+    a = oracle.cube_sample_lod(ibl.env_chain, ibl.env_size, ibl.env_levels, [0.2, 0.9, -0.1], 2.0)
+    b = oracle.cube_sample_lod(ibl.env_chain, ibl.env_size, ibl.env_levels, [0.2, 0.9, -0.1], 3.0)
+    m = oracle.cube_sample_lod(ibl.env_chain, ibl.env_size, ibl.env_levels, [0.2, 0.9, -0.1], 2.25)
+    np.testing.assert_allclose(m, 0.75 * a + 0.25 * b, rtol=1e-6)
+    top = oracle.cube_sample_lod(ibl.env_chain, ibl.env_size, ibl.env_levels, [0.2, 0.9, -0.1], 99.0)  # clamped to the 1x1 level
+    np.testing.assert_allclose(top, ibl.env_chain[-6 * 4:].reshape(6, 4)[2], rtol=1e-6)

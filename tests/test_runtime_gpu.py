@@ -102,3 +102,33 @@ def test_linearize_depth_node_feeds_the_cull():
         np.testing.assert_array_equal(read_u32(cp, 4 * (1 + int(oi[0]))), oi[: 1 + int(oi[0])])
     finally:
         rt.close()
+
+
+def test_ambient_term_through_the_frame_graph():
+    """IBL samplers published to the frame graph (EnvironmentNode's SetSampler) + the g_AO render target are bound into the lights
+    set at bindings 3, 4, 5, 9 by RHIFrameGraph::Process (RHIFrameGraph.cpp:128-163); RenderScene then shades with the ambient term."""
+    f = synth.make_frame("tiny")
+    W, H = f.cam.width, f.cam.height
+    ibl = synth.make_ibl_set(W, H, oracle.compute_brdf_lut(32, 32))
+    rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        rt.build_graph(["LightCulling", "RenderScene"])
+        rt.set_camera(f.cam)
+        rt.set_lights(f.lights)
+        depth = torch.from_numpy(f.depth).cuda()
+        surface = torch.from_numpy(f.surface).cuda()
+        radiance = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        rt.set_depth(depth)
+        rt.set_surface(surface, radiance)
+        keep = [torch.from_numpy(a).cuda() for a in (ibl.irradiance, ibl.env_chain, ibl.brdf_lut, ibl.ao)]
+        rt.set_ibl(keep[0], keep[1], ibl.env_size, ibl.env_levels, keep[2], keep[3])
+        assert rt.process_frame() == 0
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth)
+        oibl, _k = oracle.make_ibl(ibl.irradiance, ibl.env_chain, ibl.env_size, ibl.env_levels, ibl.brdf_lut, ibl.ao)
+        ref = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, og, oi, ibl=oibl)
+        err = np.abs(radiance.cpu().numpy().astype(np.float64) - ref)
+        assert (err <= 1e-4 * np.abs(ref) + 1e-5).all(), err.max()
+    finally:
+        rt.close()
