@@ -212,6 +212,26 @@ def ambient_block(ctx, frame, fp, d_lights, d_surface, steps: int):
             "brdf_lut_256x256_ms": lut_ms[1], "kernel": "k2_shade_ibl"}
 
 
+def blur_block(ctx, steps: int):
+    """ShadowPrepassNode's EVSM blur of the cascade-0 moments map (4096^2 RGBA32F, radii (2, 5) =
+    ShadowCascadeBlur[0]): two passes, 32 algorithmic bytes per texel and pass."""
+    from oracle import oracle
+    from sailor_amd.forward_plus import evsm_blur
+    S = 4096
+    m = torch.rand((S, S, 4), dtype=torch.float32, device=ctx.device)
+    tmp = torch.empty_like(m)
+    for _ in range(2):
+        evsm_blur(ctx, m, 2, 5, tmp)
+    ms = event_ms(lambda: evsm_blur(ctx, m, 2, 5, tmp), steps)
+    b = 2 * 32 * S * S
+    sample = np.random.default_rng(0).random((512, 512, 4)).astype(np.float32)
+    t0 = time.perf_counter()
+    oracle.evsm_blur(sample, 2, 5)
+    t_cpu = time.perf_counter() - t0
+    return {"texels": S * S, "gpu_ms": ms[1], "gpu_hbm_gbs": b / ms[1] / 1e6, "gpu_hbm_frac": b / ms[1] / 1e6 / HBM_PEAK_GBS,
+            "cpu_1thread_mtexels_per_s": 512 * 512 / t_cpu / 1e6, "kind": "port"}
+
+
 def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev):
     """Single-GPU estimate of the G-way split: per-band step time (hipGraph replay), equal vs cost-balanced bands."""
     from sailor_amd import dist as sdist
@@ -475,6 +495,7 @@ def main():
             out["linearize_depth"] = linearize_block(ctx, frame, fp, d_lights, 30)
             if csm is None:
                 out["ambient_ibl"] = ambient_block(ctx, frame, fp, d_lights, d_surface, 30)
+            out["evsm_blur"] = blur_block(ctx, 10)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

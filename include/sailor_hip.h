@@ -289,6 +289,20 @@ SAILOR_HIP_API int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFra
  * GGX samples per texel), dispatched once at start-up.  dLut: device, height x width float2 (the reference image is RG16F). */
 SAILOR_HIP_API int sailor_hip_compute_brdf_lut(SailorHipContext* ctx, float* dLut, int32_t width, int32_t height);
 
+/* ---- EVSM shadow-map blur ---------------------------------------------------------------
+ * Replaces: the two full-screen draws "Blur Horizontal" / "Blur Vertical" of ShadowPrepassNode::Process
+ * (FrameGraph/ShadowPrepassNode.cpp:283-356) with Content/Shaders/Blur.shader (defines EVSM + HORIZONTAL | VERTICAL, :66-98) ->
+ * GaussianBlur_Evsm (Lighting.glsl:83-127) over the cascade-0 moments map (RGBA32F): .zw blurred with the umbra radius, .xy with
+ * the penumbra radius (RHI/SceneView.h:60; ECS/LightingECS.h:68 ShadowCascadeBlur = (2, 5) for cascade 0), radii capped at 12.
+ *   dMap  : device, height x width float4, blurred IN PLACE (the node renders into a temporary target and back)
+ *   dTemp : device scratch of the same size (the node's blurAttachment)
+ * Taps sit on texel centres: the texel itself, clamp-to-edge.  Same sums in the same order as the shader: bit-exact vs the oracle. */
+SAILOR_HIP_API int sailor_hip_evsm_blur(SailorHipContext* ctx, float* dMap, float* dTemp, int32_t width, int32_t height,
+                                        int32_t radiusUmbra, int32_t radiusPenumbra);
+/* one of the two draws: vertical == 0 is Blur.shader with HORIZONTAL (texelSize.y = 0, :72-74), else VERTICAL (:68-70) */
+SAILOR_HIP_API int sailor_hip_evsm_blur_pass(SailorHipContext* ctx, const float* dSrc, float* dDst, int32_t width, int32_t height,
+                                             int32_t radiusUmbra, int32_t radiusPenumbra, int32_t vertical);
+
 /* ---- K4: ECS transform + bounds + frustum-cull sweep -------------------------------------------------------
  * Replaces: TransformECS::Tick full-sweep branch + CalculateMatrices (ECS/TransformECS.cpp:144-212),
  * Transform::Matrix (Math/Transform.cpp:39-42), the AABB::Apply of StaticMeshRendererECS::Tick

@@ -38,6 +38,7 @@ def lib() -> C.CDLL:
         L.oracle_perspective_rh_reversed_z.argtypes = [C.c_float] * 4 + [C.c_void_p]
         L.oracle_extract_frustum_planes.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.oracle_csm_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.oracle_const_evsm_blur_weight.restype = C.c_float
         L.oracle_linearize_depth.argtypes = [C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
         _lib = L
     return _lib
@@ -179,6 +180,16 @@ def linearize_depth(z_near: float, raw: np.ndarray) -> np.ndarray:
     raw = np.ascontiguousarray(raw, np.float32)
     out = np.empty_like(raw)
     lib().oracle_linearize_depth(C.c_float(z_near), _p(raw), C.c_size_t(raw.size), _p(out))
+    return out
+
+
+def evsm_blur(image: np.ndarray, radius_umbra: int, radius_penumbra: int) -> np.ndarray:
+    """ShadowPrepassNode.cpp:283-356: horizontal then vertical GaussianBlur_Evsm pass over a float32[H, W, 4] moments map."""
+    img = np.ascontiguousarray(image, np.float32)
+    H, W = img.shape[:2]
+    tmp = np.empty_like(img); out = np.empty_like(img)
+    lib().oracle_evsm_blur_pass(_p(img), _p(tmp), W, H, radius_umbra, radius_penumbra, 0)
+    lib().oracle_evsm_blur_pass(_p(tmp), _p(out), W, H, radius_umbra, radius_penumbra, 1)
     return out
 
 

@@ -739,6 +739,60 @@ static void calculate_lighting(const UboFrameData* ubo, const LightData* L, cons
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* EVSM shadow-map blur: Lighting.glsl:83-127 GaussianBlur_Evsm as drawn by  */
+/* Blur.shader:66-98 (defines EVSM + HORIZONTAL | VERTICAL) from ShadowPrepassNode.cpp:283-356     */
+/* ------------------------------------------------------------------------------------------- */
+static const float kEvsmBlurWeights[12][12] = { /* Lighting.glsl:87-99 */
+    { 0.5f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 },
+    { 0.281088f, 0.218912f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 },
+    { 0.197159f, 0.176426f, 0.126415f, 0, 0, 0, 0, 0, 0, 0, 0, 0 },
+    { 0.152068f, 0.142855f, 0.118431f, 0.0866459f, 0, 0, 0, 0, 0, 0, 0, 0 },
+    { 0.123827f, 0.118971f, 0.105518f, 0.0863909f, 0.0652929f, 0, 0, 0, 0, 0, 0, 0 },
+    { 0.104454f, 0.101593f, 0.0934699f, 0.0813492f, 0.0669741f, 0.0521595f, 0, 0, 0, 0, 0, 0 },
+    { 0.0903332f, 0.0885083f, 0.083252f, 0.0751759f, 0.0651684f, 0.0542336f, 0.0433285f, 0, 0, 0, 0, 0 },
+    { 0.07958f, 0.0783462f, 0.0747585f, 0.0691403f, 0.061977f, 0.0538465f, 0.0453433f, 0.0370081f, 0, 0, 0, 0 },
+    { 0.0711171f, 0.0702445f, 0.0676904f, 0.0636383f, 0.0583697f, 0.0522315f, 0.0455989f, 0.0388376f, 0.0322721f, 0, 0, 0 },
+    { 0.0642825f, 0.0636429f, 0.0617619f, 0.0587498f, 0.0547779f, 0.0500633f, 0.0448484f, 0.0393811f, 0.0338957f, 0.0285966f, 0, 0 },
+    { 0.0586472f, 0.0581645f, 0.0567402f, 0.0544433f, 0.0513831f, 0.0476999f, 0.0435548f, 0.039118f, 0.0345572f, 0.0300277f, 0.0256641f, 0 },
+    { 0.0539209f, 0.0535478f, 0.0524437f, 0.050654f, 0.0482506f, 0.0453272f, 0.0419936f, 0.0383686f, 0.034573f, 0.0307232f, 0.0269255f, 0.0232718f } };
+ORACLE_API float oracle_const_evsm_blur_weight(int row, int i) { return kEvsmBlurWeights[row][i]; }
+
+/* One pass over a W x H RGBA32F image.  radius = ivec2(data.blurRadius.xy) = (umbra -> .zw, penumbra -> .xy)
+ * (Blur.shader:94, RHI/SceneView.h:60).  The taps uv +- i * texelSize sit on texel centres: canonical = the texel itself,
+ * clamp-to-edge.  vertical != 0: texelSize.x = 0 (Blur.shader:68-70), else texelSize.y = 0 (:72-74). */
+ORACLE_API void oracle_evsm_blur_pass(const float* src, float* dst, int W, int H, int radiusX, int radiusY, int vertical)
+{
+    const int stepCount = 12;
+    const int mx = radiusX > radiusY ? radiusX : radiusY;
+    const int blurRadius = mx < stepCount ? mx : stepCount;
+    const int blurRadius1 = radiusX < stepCount ? radiusX : stepCount, blurRadius2 = radiusY < stepCount ? radiusY : stepCount;
+    for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+            float sum[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            for (int i = 0; i < blurRadius; i++) {
+                int xa = x, xb = x, ya = y, yb = y;
+                if (vertical) { ya = y + i > H - 1 ? H - 1 : y + i; yb = y - i < 0 ? 0 : y - i; }
+                else          { xa = x + i > W - 1 ? W - 1 : x + i; xb = x - i < 0 ? 0 : x - i; }
+                const float* a = src + ((size_t)ya * W + xa) * 4;
+                const float* b = src + ((size_t)yb * W + xb) * 4;
+                if (i < radiusX) { /* :113-117 umbra.zw; the .xy of the vec4 sum receive + 0 * w */
+                    const float w = kEvsmBlurWeights[blurRadius1 - 1][i];
+                    sum[0] += 0.0f * w; sum[1] += 0.0f * w;
+                    sum[2] += (a[2] + b[2]) * w; sum[3] += (a[3] + b[3]) * w;
+                }
+                if (i < radiusY) { /* :119-123 penumbra.xy */
+                    const float w = kEvsmBlurWeights[blurRadius2 - 1][i];
+                    sum[0] += (a[0] + b[0]) * w; sum[1] += (a[1] + b[1]) * w;
+                    sum[2] += 0.0f * w; sum[3] += 0.0f * w;
+                }
+            }
+            float* o = dst + ((size_t)y * W + x) * 4;
+            o[0] = sum[0]; o[1] = sum[1]; o[2] = sum[2]; o[3] = sum[3];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
 /* Ambient / image-based lighting: Standard.shader:343-372 AmbientLighting  */
 /* ------------------------------------------------------------------------------------------- */
 /* The reference samples three textures through Vulkan samplers (linear filtering, driver-defined precision).  The

@@ -172,6 +172,16 @@ def upload_ibl(ibl_set, device, ao_rows: tuple[int, int] | None = None) -> tuple
     return d, keep
 
 
+def evsm_blur(ctx: "HipContext", moments: torch.Tensor, radius_umbra: int, radius_penumbra: int, temp: torch.Tensor | None = None) -> torch.Tensor:
+    """ShadowPrepassNode's blur of the cascade-0 EVSM map, in place; moments float32 [H, W, 4]."""
+    assert moments.dtype == torch.float32 and moments.dim() == 3 and moments.shape[2] == 4 and moments.is_contiguous()
+    if temp is None:
+        temp = torch.empty_like(moments)
+    _lib.check(ctx._lib.sailor_hip_evsm_blur(ctx.handle, _ptr(moments), _ptr(temp), moments.shape[1], moments.shape[0], radius_umbra, radius_penumbra),
+               "sailor_hip_evsm_blur", ctx.handle)
+    return moments
+
+
 def compute_brdf_lut(ctx: "HipContext", width: int, height: int) -> torch.Tensor:
     """ComputeBrdfLut.shader on the GPU -> float32 [height, width, 2]"""
     out = torch.empty((height, width, 2), dtype=torch.float32, device=ctx.device)

@@ -65,7 +65,7 @@ RHIBufferPtr HipGraphicsDriver::WrapBuffer(void* devicePtr, size_t size)
     return b;
 }
 
-RHIShaderPtr HipGraphicsDriver::CreateShader(const std::string& assetPath) { return RHIShaderPtr::Make(assetPath); }
+RHIShaderPtr HipGraphicsDriver::CreateShader(const std::string& assetPath, const TVector<std::string>& defines) { return RHIShaderPtr::Make(assetPath, defines); }
 
 static size_t texel_size(EFormat f) { return f == EFormat::R16_SFLOAT ? 2 : (f == EFormat::R32_SFLOAT ? 4 : (f == EFormat::R32G32_SFLOAT ? 8 : 16)); }
 
@@ -299,10 +299,24 @@ void HipGraphicsDriver::DrawIndexed(RHICommandListPtr cmd, uint32_t indexCount, 
 {
     const std::string name = (cmd->m_boundMaterial && cmd->m_boundMaterial->m_shader) ? cmd->m_boundMaterial->m_shader->m_name : std::string();
     RHITexturePtr target = cmd->m_colorAttachments.empty() ? RHITexturePtr() : cmd->m_colorAttachments[0];
-    auto bindings = cmd->m_boundBindings;
+    // A draw sees the binding sets as they are NOW: ShadowPrepassNode re-points `colorSampler` of one and the same set between its two
+    // blur draws (ShadowPrepassNode.cpp:292,329), so the sets are snapshotted at record time (textures / buffers by reference, UBO bytes by value).
+    TVector<RHIShaderBindingSetPtr> bindings;
+    for (auto& set : cmd->m_boundBindings) {
+        auto copy = RHIShaderBindingSetPtr::Make();
+        for (auto& kv : set->m_bindings) {
+            auto b = copy->GetOrAddShaderBinding(kv.first);
+            b->m_type = kv.second->m_type; b->m_binding = kv.second->m_binding; b->m_buffer = kv.second->m_buffer;
+            b->m_textures = kv.second->m_textures; b->m_hostCopy = kv.second->m_hostCopy;
+        }
+        bindings.push_back(copy);
+    }
     const bool fullScreenQuad = indexCount == 6 && instanceCount == 1; // RHIFrameGraph.cpp:106-125 GetFullscreenNdcQuad
-    cmd->m_hip.m_commands.push_back([this, name, bindings, target, fullScreenQuad]() {
+    RHIShaderPtr shader = cmd->m_boundMaterial ? cmd->m_boundMaterial->m_shader : RHIShaderPtr();
+    const bool evsm = shader && shader->HasDefine("EVSM"), vertical = shader && shader->HasDefine("VERTICAL"), horizontal = shader && shader->HasDefine("HORIZONTAL");
+    cmd->m_hip.m_commands.push_back([this, name, bindings, target, fullScreenQuad, evsm, vertical, horizontal]() {
         if (fullScreenQuad && name == "Shaders/LinearizeDepth.shader") return RecordLinearizeDepth(bindings, target);
+        if (fullScreenQuad && name == "Shaders/Blur.shader" && evsm && vertical != horizontal) return RecordEvsmBlur(bindings, target, vertical);
         return (int)SAILOR_HIP_ERR_UNSUPPORTED;
     });
 }
@@ -321,6 +335,24 @@ int HipGraphicsDriver::RecordLinearizeDepth(const TVector<RHIShaderBindingSetPtr
     memcpy(&frame, frameB->m_hostCopy.data(), sizeof frame);
     return sailor_hip_linearize_depth(m_ctx, &frame, (const float*)src->m_buffer->m_hip.m_devicePtr, (float*)target->m_buffer->m_hip.m_devicePtr,
                                       target->GetExtent().x, target->GetExtent().y);
+}
+
+int HipGraphicsDriver::RecordEvsmBlur(const TVector<RHIShaderBindingSetPtr>& bindings, const RHITexturePtr& target, bool vertical)
+{
+    // ShadowPrepassNode.cpp:309,343: { sceneView.m_frameBindings, m_pBlurShaderBindings }; Blur.shader:53-61: set 1 binding 0 `data` (blurRadius.xy =
+    // [umbra, penumbra], uploaded at :286), binding 1 `colorSampler`
+    if (bindings.size() != 2 || !target || !target->m_buffer) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    auto dataB = bindings[1]->Find("data");
+    auto srcB = bindings[1]->Find("colorSampler");
+    if (!dataB || dataB->m_hostCopy.size() < 8 || !srcB || srcB->m_textures.empty() || !srcB->m_textures[0] || !srcB->m_textures[0]->m_buffer)
+        return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const auto& src = srcB->m_textures[0];
+    if (src->m_format != EFormat::R32G32B32A32_SFLOAT || target->m_format != EFormat::R32G32B32A32_SFLOAT) return SAILOR_HIP_ERR_UNSUPPORTED;
+    if (src->GetExtent().x != target->GetExtent().x || src->GetExtent().y != target->GetExtent().y) return SAILOR_HIP_ERR_UNSUPPORTED;
+    float radius[2];
+    memcpy(radius, dataB->m_hostCopy.data(), 8);
+    return sailor_hip_evsm_blur_pass(m_ctx, (const float*)src->m_buffer->m_hip.m_devicePtr, (float*)target->m_buffer->m_hip.m_devicePtr,
+                                     target->GetExtent().x, target->GetExtent().y, (int32_t)radius[0], (int32_t)radius[1], vertical ? 1 : 0); // ivec2(data.blurRadius.xy) (Blur.shader:94)
 }
 
 int HipGraphicsDriver::RecordMeshCulling(const TVector<RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pcBytes)

@@ -7,6 +7,7 @@
 //   "Shaders/ComputeMeshCulling.shader"  -> sailor_hip_mesh_frustum_cull (binding contract: ComputeMeshCulling.shader:37-58)
 // and the one full-screen DRAW in front of the path (6 indices with the material of)
 //   "Shaders/LinearizeDepth.shader"      -> sailor_hip_linearize_depth   (binding contract: LinearizeDepth.shader:15-59)
+//   "Shaders/Blur.shader" {EVSM, HORIZONTAL | VERTICAL} -> sailor_hip_evsm_blur_pass (binding contract: Blur.shader:53-61)
 #pragma once
 #include "../../RHI/GraphicsDriver.h"
 
@@ -24,7 +25,7 @@ public:
     void WaitIdle() override;
     RHI::RHICommandListPtr CreateCommandList(bool bIsSecondary = false) override;
     RHI::RHIBufferPtr CreateBuffer(size_t size) override;
-    RHI::RHIShaderPtr CreateShader(const std::string& assetPath) override;
+    RHI::RHIShaderPtr CreateShader(const std::string& assetPath, const TVector<std::string>& defines = {}) override;
     RHI::RHITexturePtr CreateTexture(const void* pData, size_t size, RHI::ivec2 extent, RHI::EFormat format) override;
     void SubmitCommandList(RHI::RHICommandListPtr commandList) override;
     RHI::RHIMaterialPtr CreateMaterial(RHI::RHIShaderPtr shader) override;
@@ -64,6 +65,7 @@ private:
     int RecordShade(const TVector<RHI::RHIShaderBindingSetPtr>& bindings);
     int RecordMeshCulling(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pc);
     int RecordLinearizeDepth(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const RHI::RHITexturePtr& target);
+    int RecordEvsmBlur(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const RHI::RHITexturePtr& target, bool vertical);
 
     SailorHipContext* m_ctx = nullptr;
     int m_status = 0;

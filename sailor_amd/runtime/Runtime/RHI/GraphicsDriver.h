@@ -13,7 +13,7 @@ public:
     virtual void WaitIdle() = 0;                                                                           // :83
     virtual RHICommandListPtr CreateCommandList(bool bIsSecondary = false) = 0;                            // :88
     virtual RHIBufferPtr CreateBuffer(size_t size) = 0;                                                    // :89
-    virtual RHIShaderPtr CreateShader(const std::string& assetPath) = 0;                                   // :97 (SPIR-V there, a kernel name here)
+    virtual RHIShaderPtr CreateShader(const std::string& assetPath, const TVector<std::string>& defines = {}) = 0; // :97 (SPIR-V there; here the asset path + permutation)
     virtual RHITexturePtr CreateTexture(const void* pData, size_t size, ivec2 extent, EFormat format) = 0; // :98-108
     virtual void SubmitCommandList(RHICommandListPtr commandList) = 0;                                     // :149
     virtual RHIMaterialPtr CreateMaterial(RHIShaderPtr shader) = 0;                                        // :138-141 (vertex layout / topology / render state dropped)

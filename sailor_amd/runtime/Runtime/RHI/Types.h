@@ -121,8 +121,10 @@ using RHIShaderBindingSetPtr = TRefPtr<RHIShaderBindingSet>;
 // RHI/Shader.h: identified by the asset path the reference loads it from (e.g. "Shaders/ComputeLightCulling.shader")
 class RHIShader : public RHIResource {
 public:
-    explicit RHIShader(std::string name) : m_name(std::move(name)) {}
+    explicit RHIShader(std::string name, std::vector<std::string> defines = {}) : m_name(std::move(name)), m_defines(std::move(defines)) {}
     std::string m_name;
+    std::vector<std::string> m_defines; // the permutation (ShaderCompiler::LoadShader_Immediate(fileId, shader, { "VERTICAL", "EVSM" }), ShadowPrepassNode.cpp:60)
+    bool HasDefine(const std::string& d) const { for (auto& x : m_defines) if (x == d) return true; return false; }
 };
 using RHIShaderPtr = TRefPtr<RHIShader>;
 

@@ -159,6 +159,48 @@ RT_API void sailor_rt_set_ibl(SailorRuntime* rt, void* irradiance, int irrSize, 
     if (ao) rt->graph.SetRenderTarget("g_AO", hip->WrapTexture(ao, { width, height }, EFormat::R32_SFLOAT));
 }
 
+// The blur section of ShadowPrepassNode::Process (FrameGraph/ShadowPrepassNode.cpp:283-356) for one EVSM cascade, command for command: the
+// radius upload (:286), "Blur Horizontal" (shadow map -> temporary target) and "Blur Vertical" (temporary target -> shadow map).  (The caster draws
+// in front of it need a rasteriser and are not part of this path.)
+RT_API int sailor_rt_blur_shadow_map(SailorRuntime* rt, void* mapDevicePtr, void* tempDevicePtr, int size, float radiusUmbra, float radiusPenumbra)
+{
+    auto* hip = static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver());
+    auto driver = Renderer::GetDriver();
+    auto commands = Renderer::GetDriverCommands();
+    auto shadowMap = hip->WrapTexture(mapDevicePtr, { size, size }, EFormat::R32G32B32A32_SFLOAT);
+    auto blurAttachment = hip->WrapTexture(tempDevicePtr, { size, size }, EFormat::R32G32B32A32_SFLOAT); // GetOrAddTemporaryRenderTarget (:285)
+    auto vertical = driver->CreateMaterial(driver->CreateShader("Shaders/Blur.shader", { "VERTICAL", "EVSM" }));     // :60-62
+    auto horizontal = driver->CreateMaterial(driver->CreateShader("Shaders/Blur.shader", { "HORIZONTAL", "EVSM" })); // :65-67
+    auto blurBindings = driver->CreateShaderBindings();                                                             // :70
+    auto blurData = driver->AddBufferToShaderBindings(blurBindings, "data", 48, 0, EShaderBindingType::UniformBuffer); // :73 (3 x vec4)
+    auto frameBindings = driver->CreateShaderBindings();
+    auto cmd = driver->CreateCommandList();
+    const float blurRadius[2] = { radiusUmbra, radiusPenumbra };
+    if (radiusUmbra * radiusUmbra + radiusPenumbra * radiusPenumbra > 0.01f) { // m_blurRadius.length() > 0.1f (:283)
+        commands->UpdateShaderBinding(cmd, blurData, blurRadius, sizeof blurRadius); // :286
+        commands->BeginDebugRegion(cmd, "Blur Horizontal");
+        driver->AddSamplerToShaderBindings(blurBindings, "colorSampler", shadowMap, 1); // :292
+        commands->ImageMemoryBarrier(cmd, shadowMap, EImageLayout::ShaderReadOnlyOptimal);
+        commands->ImageMemoryBarrier(cmd, blurAttachment, EImageLayout::ColorAttachmentOptimal);
+        commands->BeginRenderPass(cmd, TVector<RHITexturePtr> { blurAttachment }, RHITexturePtr());
+        commands->BindMaterial(cmd, horizontal);
+        commands->BindShaderBindings(cmd, horizontal, { frameBindings, blurBindings });
+        commands->DrawIndexed(cmd, 6, 1, 0, 0, 0);
+        commands->EndRenderPass(cmd);
+        commands->EndDebugRegion(cmd);
+        commands->BeginDebugRegion(cmd, "Blur Vertical");
+        driver->AddSamplerToShaderBindings(blurBindings, "colorSampler", blurAttachment, 1); // :329
+        commands->BeginRenderPass(cmd, TVector<RHITexturePtr> { shadowMap }, RHITexturePtr());
+        commands->BindMaterial(cmd, vertical);
+        commands->BindShaderBindings(cmd, vertical, { frameBindings, blurBindings });
+        commands->DrawIndexed(cmd, 6, 1, 0, 0, 0);
+        commands->EndRenderPass(cmd);
+        commands->EndDebugRegion(cmd);
+    }
+    driver->SubmitCommandList(cmd);
+    return hip->GetLastDispatchStatus();
+}
+
 RT_API int sailor_rt_process_frame(SailorRuntime* rt)
 {
     rt->graph.Process(rt->snapshot);

@@ -38,6 +38,7 @@ def load() -> C.CDLL:
         rt.sailor_rt_set_surface.argtypes = [P, P, P, C.c_int, C.c_int]
         rt.sailor_rt_set_shadow_maps.argtypes = [P, P, P, P, P]
         rt.sailor_rt_set_ibl.argtypes = [P, P, C.c_int, P, C.c_int, C.c_int, P, C.c_int, C.c_int, P, C.c_int, C.c_int]
+        rt.sailor_rt_blur_shadow_map.argtypes = [P, P, P, C.c_int, C.c_float, C.c_float]
         rt.sailor_rt_process_frame.argtypes = [P]
         rt.sailor_rt_wait_idle.argtypes = [P]
         rt.sailor_rt_buffer.restype = P
@@ -85,6 +86,10 @@ class Runtime:
         self.rt.sailor_rt_set_ibl(self.h, irradiance.data_ptr(), irradiance.shape[1], env_chain.data_ptr(), env_size, env_levels,
                                   lut.data_ptr(), lut.shape[1], lut.shape[0], ao.data_ptr() if ao is not None else None,
                                   ao.shape[1] if ao is not None else 0, ao.shape[0] if ao is not None else 0)
+
+    def blur_shadow_map(self, moments, temp, radius_umbra, radius_penumbra):
+        """the blur section of ShadowPrepassNode::Process over a float32 [S, S, 4] device tensor, in place"""
+        return self.rt.sailor_rt_blur_shadow_map(self.h, moments.data_ptr(), temp.data_ptr(), moments.shape[0], radius_umbra, radius_penumbra)
 
     def set_surface(self, surface_tensor, radiance_tensor):
         self.rt.sailor_rt_set_surface(self.h, surface_tensor.data_ptr(), radiance_tensor.data_ptr(), surface_tensor.shape[2], surface_tensor.shape[1])

@@ -64,8 +64,17 @@ def make_ibl() -> None:
     print(f"tiny_ibl: lut range [{lut.min():.4f}, {lut.max():.4f}], mean radiance {rad[..., :3].mean():.3f}")
 
 
+def make_blur() -> None:
+    """EVSM blur: cascade 0 of the tiny_csm shadow set (64x64 RGBA32F) blurred with ShadowCascadeBlur[0] = (2, 5)."""
+    f = synth.make_frame("tiny_csm", with_surface=False)
+    m = np.ascontiguousarray(f.shadows.maps[0])
+    np.savez_compressed(OUT / "tiny_blur.npz", radii=np.array([2, 5], np.int32), blurred=oracle.evsm_blur(m, 2, 5))
+    print(f"tiny_blur: {m.shape}")
+
+
 if __name__ == "__main__":
     for n in ("tiny", "tiny_csm"):
         make(n)
     make_depth()
     make_ibl()
+    make_blur()

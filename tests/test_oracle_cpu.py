@@ -262,3 +262,34 @@ def test_ambient_term_golden_and_sampler_conventions():
     np.testing.assert_allclose(m, 0.75 * a + 0.25 * b, rtol=1e-6)
     top = oracle.cube_sample_lod(ibl.env_chain, ibl.env_size, ibl.env_levels, [0.2, 0.9, -0.1], 99.0)  # clamped to the 1x1 level
     np.testing.assert_allclose(top, ibl.env_chain[-6 * 4:].reshape(6, 4)[2], rtol=1e-6)
+
+
+def test_evsm_blur_weights_golden_and_numpy():
+    """SURVEY.md 8f rank 3.  Lighting.glsl:87-99: every weight row sums to 0.5 (centre tap counted twice -> 1); the blurred cascade-0 map of the
+    tiny_csm fixture; and an independent NumPy restatement of the two passes (same op order) bit for bit."""
+    L = oracle.lib()
+    W = np.array([[L.oracle_const_evsm_blur_weight(r, i) for i in range(12)] for r in range(12)], np.float64)
+    assert np.abs(W.sum(1) - 0.5).max() < 2e-6 and (np.triu(W, 1) == 0).all() and (np.diff(W, axis=1)[np.tril_indices(12, -1)] <= 0).all() is not None
+    g = np.load(GOLDEN / "tiny_blur.npz")
+    f = synth.make_frame("tiny_csm", with_surface=False)
+    m = np.ascontiguousarray(f.shadows.maps[0])
+    out = oracle.evsm_blur(m, int(g["radii"][0]), int(g["radii"][1]))
+    np.testing.assert_array_equal(out.view(np.uint32), g["blurred"].view(np.uint32))
+
+    def np_pass(img, rx, ry, vertical):
+        H, Wd = img.shape[:2]
+        acc = np.zeros_like(img)
+        w1 = W[min(rx, 12) - 1].astype(np.float32) if rx > 0 else None
+        w2 = W[min(ry, 12) - 1].astype(np.float32) if ry > 0 else None
+        idx = np.arange(H if vertical else Wd)
+        for i in range(min(max(rx, ry), 12)):
+            hi, lo = np.minimum(idx + i, idx[-1]), np.maximum(idx - i, 0)
+            a, b = (img[hi], img[lo]) if vertical else (img[:, hi], img[:, lo])
+            if i < rx:
+                acc[..., 2:] = acc[..., 2:] + (a[..., 2:] + b[..., 2:]) * w1[i]
+            if i < ry:
+                acc[..., :2] = acc[..., :2] + (a[..., :2] + b[..., :2]) * w2[i]
+        return acc
+
+    ref = np_pass(np_pass(m, 2, 5, False), 2, 5, True)
+    np.testing.assert_array_equal(out.view(np.uint32), ref.astype(np.float32).view(np.uint32))

@@ -132,3 +132,25 @@ def test_ambient_term_through_the_frame_graph():
         assert (err <= 1e-4 * np.abs(ref) + 1e-5).all(), err.max()
     finally:
         rt.close()
+
+
+def test_shadow_prepass_blur_draws_become_the_blur_kernel():
+    """ShadowPrepassNode.cpp:283-356 recorded against the HIP backend: two 6-index draws with the Blur.shader {EVSM, HORIZONTAL | VERTICAL}
+    materials -> sailor_hip_evsm_blur_pass twice; the shadow map ends up blurred in place exactly as the oracle blurs it.  The two binding updates
+    of `colorSampler` between the draws must each be captured at record time."""
+    cam = synth.make_camera(256, 144)
+    m = np.ascontiguousarray(synth.make_shadow_set(cam, 128).maps[0])
+    rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        d = torch.from_numpy(m.copy()).cuda()
+        tmp = torch.zeros_like(d)
+        assert rt.blur_shadow_map(d, tmp, 2.0, 5.0) == 0   # ShadowCascadeBlur[0] (ECS/LightingECS.h:68)
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), oracle.evsm_blur(m, 2, 5).view(np.uint32))
+        d2 = torch.from_numpy(m.copy()).cuda()
+        assert rt.blur_shadow_map(d2, tmp, 0.0, 0.05) == 0  # |radius| <= 0.1: the node skips the blur
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(d2.cpu().numpy(), m)
+    finally:
+        rt.close()
