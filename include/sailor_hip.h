@@ -235,6 +235,16 @@ SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
                                          void* dWorkspace, size_t workspaceBytes,
                                          const SailorBand* band, uint32_t flags);
 
+/* Shading-order hint.  sailor_hip_light_cull also leaves, in its workspace, the band's tiles ordered by list length class (>= 96, >= 40,
+ * rest; tile order inside a class), each as tileX | tileRowInBand << 16.  Handing this pointer to sailor_hip_shade_ex makes the shade
+ * launch start its long-running tiles first instead of wherever they fall in raster order (a tile in the middle of a light cluster keeps
+ * its block busy ~100x longer than an average one: started late it is the tail of the launch).  Pure scheduling: results do not depend on
+ * it.  Produced for split frames only (bands smaller than the frame: there a launch is a round or two of blocks and its longest tile
+ * is its duration; on the whole frame the hint measured no gain and is not produced): NULL for the whole-frame band and on bad arguments.
+ * Valid until the next sailor_hip_light_cull on the same workspace. */
+SAILOR_HIP_API const uint32_t* sailor_hip_light_cull_tile_order(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band,
+                                                                const void* dWorkspace);
+
 /* ---- LinearizeDepth: the pass immediately before K1 ---------------------------------------
  * Replaces: the full-screen draw of LinearizeDepthNode::Process (FrameGraph/LinearizeDepthNode.cpp:22-109) with the
  * fragment shader Content/Shaders/LinearizeDepth.shader:61-73 under its REVERSE_Z_INF_FAR_PLANE define (:6):
@@ -277,13 +287,13 @@ SAILOR_HIP_API int sailor_hip_shade(SailorHipContext* ctx, const SailorUboFrameD
                                     const SailorBand* band);
 
 /* As sailor_hip_shade, plus the ambient term: outColor.rgb = AmbientLighting(...) + sum over lights
- * (Standard.shader:425).  ibl == NULL is sailor_hip_shade. */
+ * (Standard.shader:425).  ibl == NULL and dTileOrder == NULL is sailor_hip_shade. */
 SAILOR_HIP_API int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFrameData* frame,
                                        const float* dSurface, size_t surfacePlaneStride,
                                        const SailorLightShaderData* dLights, int32_t lightsNum,
                                        const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
                                        const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance,
-                                       const SailorBand* band);
+                                       const SailorBand* band, const uint32_t* dTileOrder /* sailor_hip_light_cull_tile_order or NULL */);
 
 /* The split-sum BRDF look-up table sampled by AmbientLighting: Content/Shaders/ComputeBrdfLut.shader:26-71 (1 024 Hammersley /
  * GGX samples per texel), dispatched once at start-up.  dLut: device, height x width float2 (the reference image is RG16F). */

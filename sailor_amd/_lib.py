@@ -103,7 +103,8 @@ SIGNATURES = {
     "sailor_hip_light_grid_rebase": (C.c_int, [_P, _P, C.c_int32, C.c_uint32]),
     "sailor_hip_shade": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_size_t, _P, C.c_int32, _P, _P, C.POINTER(CsmDesc), _P, C.POINTER(Band)]),
     "sailor_hip_shade_ex": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_size_t, _P, C.c_int32, _P, _P, C.POINTER(CsmDesc), C.POINTER(IblDesc), _P,
-                                      C.POINTER(Band)]),
+                                      C.POINTER(Band), _P]),
+    "sailor_hip_light_cull_tile_order": (_P, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band), _P]),
     "sailor_hip_evsm_blur": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sailor_hip_evsm_blur_pass": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sailor_hip_compute_brdf_lut": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),

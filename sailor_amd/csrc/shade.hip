@@ -52,6 +52,7 @@ struct ShadeArgs {
     int fbRow0;       // band.fbRowBegin
     int fbRows;       // band.fbRowCount
     int lightsNum;
+    const uint32_t* order; // sailor_hip_light_cull_tile_order or null
 };
 
 // ---- K3: canonical-order helpers (must match oracle/sailor_oracle.c bit for bit) -----------------------------
@@ -310,8 +311,11 @@ __device__ __forceinline__ void k2_shade_body(const ShadeArgs& A, const CsmArgs&
     __shared__ uint16_t sQ[4 * QMAX];
     __shared__ uint32_t sNum;
 
-    const int tx = blockIdx.x, ty = A.tileRow0 + blockIdx.y; // grid = (tiles per row, tile rows of the band): no division
-    const int bandTile = blockIdx.y * A.Tx + blockIdx.x;
+    // grid = (tiles per row, tile rows of the band): no division.  With an order hint block i takes the i-th tile of that order.
+    int btx = blockIdx.x, bty = blockIdx.y;
+    if (A.order) { const uint32_t o = A.order[blockIdx.y * A.Tx + blockIdx.x]; btx = (int)(o & 0xFFFFu); bty = (int)(o >> 16); }
+    const int tx = btx, ty = A.tileRow0 + bty;
+    const int bandTile = bty * A.Tx + btx;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // each wave shades one 8x8 quadrant of the tile: the most compact 64-pixel footprint, so that "no pixel of the wave
     // is within reach of this light" holds as often as possible
@@ -695,7 +699,7 @@ extern "C" int sailor_hip_compute_brdf_lut(SailorHipContext* ctx, float* dLut, i
 extern "C" int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
                                    const SailorLightShaderData* dLights, int32_t lightsNum,
                                    const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
-                                   const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance, const SailorBand* band)
+                                   const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance, const SailorBand* band, const uint32_t* dTileOrder)
 {
     if (!ctx || !frame || !dSurface || !dLightsGrid || !dCulledLights || !dRadiance) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (lightsNum < 0 || (lightsNum > 0 && !dLights)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
@@ -719,6 +723,7 @@ extern "C" int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFrameDa
     A.fbRow0 = band->fbRowBegin;
     A.fbRows = band->fbRowCount;
     A.lightsNum = lightsNum;
+    A.order = dTileOrder;
     const int bandTiles = (band->tileRowEnd - band->tileRowBegin) * A.Tx;
     if (bandTiles == 0) return SAILOR_HIP_OK;
 
@@ -769,5 +774,5 @@ extern "C" int sailor_hip_shade(SailorHipContext* ctx, const SailorUboFrameData*
                                 const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
                                 const SailorCsmDesc* csm, float* dRadiance, const SailorBand* band)
 {
-    return sailor_hip_shade_ex(ctx, frame, dSurface, surfacePlaneStride, dLights, lightsNum, dLightsGrid, dCulledLights, csm, nullptr, dRadiance, band);
+    return sailor_hip_shade_ex(ctx, frame, dSurface, surfacePlaneStride, dLights, lightsNum, dLightsGrid, dCulledLights, csm, nullptr, dRadiance, band, nullptr);
 }

@@ -8,6 +8,7 @@ Mirrors the two reference passes that own these buffers:
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -81,6 +82,10 @@ class ForwardPlus:
         self.grid = torch.zeros(max(self.band_tiles, 1) * 2, dtype=torch.int32, device=dev)
         self.culled = torch.zeros(1 + max(self.band_tiles, 1) * LIGHTS_PER_TILE, dtype=torch.int32, device=dev)
         self.radiance = None
+        # the cull's shading-order hint (long lists first) lives in the workspace; None = raster order
+        self.tile_order = lib.sailor_hip_light_cull_tile_order(width, height, max_lights, C.byref(self.band), _ptr(self.workspace))
+        self.use_tile_order = os.environ.get("SAILOR_NO_TILE_ORDER") is None
+        self._culled_once = False
 
     # -- K0 + K1 --------------------------------------------------------------------------------------------------
     def cull(self, frame: UboFrameData, lights: torch.Tensor, lights_num: int, depth: torch.Tensor, flags: int = _lib.CULL_DEFAULT,
@@ -95,6 +100,7 @@ class ForwardPlus:
         _lib.check(lib.sailor_hip_light_cull(ctx.handle, C.byref(frame), C.byref(pc), _ptr(lights), _ptr(depth), _ptr(self.grid), _ptr(self.culled),
                                              self.culled.numel(), _ptr(self.workspace), self.workspace.numel(), C.byref(self.band), flags),
                    "sailor_hip_light_cull", ctx.handle)
+        self._culled_once = True
         return self.grid, self.culled
 
     # -- K2 + K3 --------------------------------------------------------------------------------------------------
@@ -109,9 +115,11 @@ class ForwardPlus:
                 self.radiance = torch.empty((rows, self.W, 4), dtype=torch.float32, device=self.ctx.device)
             out = self.radiance
         lib = self.ctx._lib
-        if ibl is not None:
+        order = self.tile_order if (self.use_tile_order and self._culled_once) else None  # only lists made by THIS object's cull have an order
+        if ibl is not None or order is not None:
             _lib.check(lib.sailor_hip_shade_ex(self.ctx.handle, C.byref(frame), _ptr(surface), rows * self.W, _ptr(lights), lights_num, _ptr(self.grid),
-                                               _ptr(self.culled), C.byref(csm) if csm is not None else None, C.byref(ibl), _ptr(out), C.byref(self.band)),
+                                               _ptr(self.culled), C.byref(csm) if csm is not None else None, C.byref(ibl) if ibl is not None else None,
+                                               _ptr(out), C.byref(self.band), order),
                        "sailor_hip_shade_ex", self.ctx.handle)
             return out
         _lib.check(lib.sailor_hip_shade(self.ctx.handle, C.byref(frame), _ptr(surface), rows * self.W, _ptr(lights), lights_num, _ptr(self.grid),

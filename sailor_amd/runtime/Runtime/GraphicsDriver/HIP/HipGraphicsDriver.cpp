@@ -216,6 +216,7 @@ int HipGraphicsDriver::RecordLightCulling(const TVector<RHIShaderBindingSetPtr>&
     const size_t need = sailor_hip_light_cull_workspace_size(pc.viewportSize[0], pc.viewportSize[1], pc.lightsNum, &band);
     if (!m_cullWorkspace || m_cullWorkspace->m_size < need) m_cullWorkspace = CreateBuffer(need);
     if (!m_cullWorkspace) return SAILOR_HIP_ERR_OUT_OF_MEMORY;
+    m_cullW = pc.viewportSize[0]; m_cullH = pc.viewportSize[1]; m_cullLights = pc.lightsNum; m_cullOrderValid = true; // the shade of this frame may use the order hint
     return sailor_hip_light_cull(m_ctx, &frame, &pc, (const SailorLightShaderData*)buffer_of(bindings[0], "light"),
                                  (const float*)depthB->m_textures[0]->m_buffer->m_hip.m_devicePtr,
                                  (SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (uint32_t*)buffer_of(bindings[1], "culledLights"),
@@ -271,7 +272,8 @@ int HipGraphicsDriver::RecordShade(const TVector<RHIShaderBindingSetPtr>& bindin
     return sailor_hip_shade_ex(m_ctx, &frame, (const float*)surfaceB->m_buffer->m_hip.m_devicePtr, (size_t)W * H,
                                (const SailorLightShaderData*)buffer_of(bindings[1], "light"), lightsNum,
                                (const SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (const uint32_t*)buffer_of(bindings[1], "culledLights"),
-                               hasCsm ? &csm : nullptr, hasIbl ? &ibl : nullptr, (float*)buffer_of(bindings[2], "radiance"), nullptr);
+                               hasCsm ? &csm : nullptr, hasIbl ? &ibl : nullptr, (float*)buffer_of(bindings[2], "radiance"), nullptr,
+                               m_cullOrderValid ? sailor_hip_light_cull_tile_order(m_cullW, m_cullH, m_cullLights, nullptr, m_cullWorkspace->m_hip.m_devicePtr) : nullptr);
 }
 
 // ---- the render-pass subset: state is kept on the command list, a 6-index draw of a known full-screen material becomes a

@@ -71,6 +71,8 @@ private:
     int m_status = 0;
     int m_lastDispatchStatus = 0;
     RHI::RHIBufferPtr m_cullWorkspace;
+    int32_t m_cullW = 0, m_cullH = 0, m_cullLights = 0; // geometry of the last light cull: locates its shading-order hint in the workspace
+    bool m_cullOrderValid = false;
 };
 
 } // namespace Sailor::GraphicsDriver::HIP

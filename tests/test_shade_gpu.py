@@ -150,3 +150,36 @@ def test_linearity_in_light_intensity_at_4k(ctx):
     r0, r1 = H - 16 * (tr0 + 3), H - 16 * tr0
     ref = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, grid, oi, None, rows=(r0, r1))
     assert_radiance_close(a[r0:r1], ref[r0:r1])
+
+
+def test_tile_order_hint_is_a_permutation_and_changes_nothing(ctx):
+    """sailor_hip_light_cull_tile_order (split frames only): every tile of the band exactly once, long lists first (>= 96, then >= 40, then
+    the rest, raster order inside a class); shading with the hint gives the same bits as shading without -- it is scheduling only."""
+    import ctypes as C
+    f = synth.make_frame("tiny")
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    whole = ForwardPlus(ctx, W, H, N)
+    assert not whole.tile_order, "no hint for the whole frame"
+    band = host.band_for_rank(W, H, 1, 2)
+    fp = ForwardPlus(ctx, W, H, N, band=band)
+    assert fp.tile_order
+    rows = slice(band.fbRowBegin, band.fbRowBegin + band.fbRowCount)
+    lights = upload_lights(f.lights, ctx.device)
+    fp.cull(f.cam.frame, lights, N, torch.from_numpy(np.ascontiguousarray(f.depth[rows])).to(ctx.device))
+    g, _ = fp.lists_to_host()
+    T = fp.band_tiles
+    order = np.empty(T, np.uint32)
+    lib = _lib.load()
+    _lib.check(lib.sailor_hip_buffer_download(ctx.handle, order.ctypes.data, C.c_void_p(fp.tile_order), 0, T * 4), "download", ctx.handle)
+    tiles = (order >> 16).astype(np.int64) * fp.Tx + (order & 0xFFFF)
+    assert sorted(tiles.tolist()) == list(range(T))
+    num = g[:, 1].astype(np.int64)
+    cls = np.where(num >= 96, 0, np.where(num >= 40, 1, 2))
+    assert (cls == 0).any() and (cls == 2).any()
+    expect = np.concatenate([np.nonzero(cls == c)[0] for c in (0, 1, 2)])
+    np.testing.assert_array_equal(tiles, expect)
+    s = torch.from_numpy(np.ascontiguousarray(f.surface[:, rows])).to(ctx.device)
+    with_hint = fp.shade(f.cam.frame, s, lights, N).clone()
+    fp.use_tile_order = False
+    without = fp.shade(f.cam.frame, s, lights, N)
+    assert torch.equal(with_hint, without)
