@@ -183,3 +183,50 @@ def test_tile_order_hint_is_a_permutation_and_changes_nothing(ctx):
     fp.use_tile_order = False
     without = fp.shade(f.cam.frame, s, lights, N)
     assert torch.equal(with_hint, without)
+
+
+def test_every_light_reaches_every_pixel(ctx):
+    """128 large lights over a small viewport: every tile list is full and every (pixel, light) is a lit pair -- 8 192 pairs per quadrant,
+    i.e. dozens of pair windows per wave, each closed by the 120-pair / 3-per-pixel limits of the queue."""
+    w, h = 64, 48
+    cam = synth.make_camera(w, h)
+    depth = synth.make_linear_depth(w, h, 9, d_min=40.0, d_max=60.0)
+    lights = synth.make_lights(cam, depth, synth.LightSetConfig(count=160, radius_scale=400.0, spot_fraction=0.2), 9)
+    surface = synth.make_surface(cam, depth, 9)
+    g, idx, cnt = oracle.light_cull(cam.frame, w, h, lights, depth, want_counts=True)
+    assert (g[:, 1] == 128).all() and (cnt > 128).all()
+    ref = oracle.shade(cam.frame, w, h, surface, lights, g, idx)
+    fp = ForwardPlus(ctx, w, h, len(lights))
+    l = upload_lights(lights, ctx.device)
+    fp.cull(cam.frame, l, len(lights), torch.from_numpy(depth).to(ctx.device))
+    got = fp.shade(cam.frame, torch.from_numpy(surface).to(ctx.device), l, len(lights)).cpu().numpy()
+    assert_radiance_close(got, ref)
+    assert (ref[..., :3] > 0).all()
+
+
+def test_non_finite_terms_propagate_like_the_reference(ctx):
+    """0 * inf must stay NaN: a zero window / facing factor only annihilates a FINITE product.  Pixels with roughness 0 (NdfGGX = 0/0) and
+    lights with an infinite or NaN intensity may not be skipped by any of the conservative tests; the NaN / inf pattern of the radiance must be
+    the oracle's, the finite rest within tolerance."""
+    f = synth.make_frame("tiny")
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    surface = f.surface.copy()
+    surface[1, ::7, ::5, 3] = 0.0           # roughness 0 on a lattice of pixels
+    lights = f.lights.copy()
+    lights["intensity"][3] = [np.inf, 1.0, 2.0]
+    lights["intensity"][40] = [np.nan, 5.0, 5.0]
+    lights["intensity"][77] = [-np.inf, 0.0, 1.0]
+    g, idx, _ = oracle.light_cull(f.cam.frame, W, H, lights, f.depth)
+    with np.errstate(all="ignore"):
+        ref = oracle.shade(f.cam.frame, W, H, surface, lights, g, idx)
+    assert np.isnan(ref).any() and np.isfinite(ref).any()
+    fp = ForwardPlus(ctx, W, H, N)
+    l = upload_lights(lights, ctx.device)
+    fp.cull(f.cam.frame, l, N, torch.from_numpy(f.depth).to(ctx.device))
+    got = fp.shade(f.cam.frame, torch.from_numpy(surface).to(ctx.device), l, N).cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_array_equal(np.isposinf(got), np.isposinf(ref))
+    np.testing.assert_array_equal(np.isneginf(got), np.isneginf(ref))
+    fin = np.isfinite(ref)
+    err = np.abs(got[fin].astype(np.float64) - ref[fin])
+    assert (err <= RTOL * np.abs(ref[fin]) + ATOL).all(), err.max()
