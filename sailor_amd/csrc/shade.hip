@@ -2,17 +2,18 @@
 //
 // Replaces the fragment work of Content/Shaders/Standard.shader (main :377-439, CalculateLighting :259-341) and
 // Lighting.glsl (BRDF :39-76, CSM :168-284) for the draws of RenderSceneNode::Process
-// (FrameGraph/RenderSceneNode.cpp:109), as compute over a surface buffer (ambient == 0).
+// (FrameGraph/RenderSceneNode.cpp:109), as compute over a surface buffer (ambient term optional, 8f rank 2).
 //
 // Shape: one 256-thread block per 16x16 tile -- the unit the light list is defined on -- so the tile's <=128
 // light records are fetched from HBM once, derived per-light constants (normalised spot axis, cone width, reach
-// thresholds) are computed once by 128 lanes, and the records sit in LDS (129 x 80 B = 10 KB) where every lane reads
-// the SAME address per step (LDS broadcast, conflict-free).  Each wave covers one 8x8 quadrant of the tile (eight
-// 128-byte row segments per float4 plane); radiance goes out as one float4 per lane.  The light type branch is
-// wave-uniform (all lanes walk the same list).  The tile list is conservative (sphere vs tile frustum) while the
-// surface is a thin sheet inside that frustum: on the 4K / 65 536-light frame only ~3 % of the (pixel, light) pairs are
-// actually lit.  So every step starts with a ~12-instruction conservative "can any of my 64 pixels be reached" test
-// and most steps end there; the exact falloff and the BRDF only run for lights that reach the quadrant.
+// thresholds) are computed once by 128 lanes, and the records sit in LDS (128 x 80 B = 10 KB).  Each wave owns one 8x8
+// quadrant of the tile (eight 128-byte row segments per float4 plane); radiance goes out as one float4 per lane.  The
+// tile list is conservative (sphere vs tile frustum) while the surface is a thin sheet inside that frustum: on the 4K /
+// 65 536-light frame only ~3 % of the (pixel, light) pairs are actually lit, and the kernel is bound by vector-instruction
+// issue.  So a wave (1) tests its list one LANE per LIGHT against the quadrant's bounding box, (2) tests the survivors one
+// LANE per PIXEL with a 6-instruction conservative reach test + the facing test and queues the (pixel, light) pairs that
+// pass, (3) runs the exact falloff and the BRDF one LANE per PAIR on full waves.  Details at k2_shade_body.  The ambient /
+// IBL term of Standard.shader (:343-372) and the BRDF look-up table it samples are the last two sections of this file.
 //
 // Numerics: the BRDF is tolerance-checked (1e-4 relative), so its well-conditioned parts use v_rcp and explicit
 // FMAs.  Two places are NOT well-conditioned and are evaluated in the oracle's exact fp32 order instead:
@@ -296,10 +297,10 @@ __device__ __forceinline__ void wave_minmax6(int& a, int& b, int& c, int& d, int
 //   rec3 = (Li = -direction.xyz, cutOff.y)
 //   rec4 = (intensity.xyz, -)
 //
-// The kernel is VALU-bound (rocprofv3: SQ_INSTS_VALU x 4 cycles on 1024 SIMDs == the kernel's duration), so the shape
-// below is about vector instructions per (wave, light) step: light type, finiteness and "survived the box test" are
-// wave-uniform 64-bit masks (scalar registers, scalar branches), the reach test feeds s_cbranch_vccz directly, and most
-// steps end after ~10 vector instructions.
+// The kernel is VALU-bound (rocprofv3: SQ_INSTS_VALU x 4 cycles on 1024 SIMDs == the duration of the loop-per-light version it
+// replaced), so the shape below is about vector instructions per wave: light kind, finiteness and "survived the box test" are
+// wave-uniform 64-bit masks (scalar registers, scalar branches, six static segments -- no per-light type branches), the reach
+// test feeds the scalar branch directly, and the ~130-instruction exact falloff + BRDF only ever runs on queued pairs.
 template <bool HAS_CSM, bool HAS_IBL>
 __device__ __forceinline__ void k2_shade_body(const ShadeArgs& A, const CsmArgs& C, const IblArgs& I, const float4* __restrict__ surface, size_t planeStride,
                                                  const SailorLightShaderData* __restrict__ lights,
