@@ -469,7 +469,7 @@ __device__ __forceinline__ void k2_shade_body(const ShadeArgs& A, const CsmArgs&
                         }
                     }
                     if (m != 0ull) {
-                        const bool mine = (m >> lane) & 1ull;
+                        const bool mine = __builtin_amdgcn_inverse_ballot_w64(m); // exec = m: no per-lane bit test
                         if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || __ballot(mine && pc >= (uint32_t)PENDK) != 0ull) { overflow = true; break; }
                         if (mine) {
                             const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
