@@ -143,7 +143,7 @@ __device__ float shadow_pcf(const void* __restrict__ map, int fmt, int W, int H,
     if (px > 1.0f || py > 1.0f || px < 0.0f || py < 0.0f || pz < 0.5f) return 1.0f;
     const float tsx = 1.0f / (float)W, tsy = 1.0f / (float)H;
     float shadow = 0.0f;
-#pragma unroll 4
+#pragma unroll 1
     for (int i = 0; i < 16; i++) {
         const float ox = kPoissonDisk[i][0] * 2.0f * tsx, oy = kPoissonDisk[i][1] * 2.0f * tsy;
         const float pcfDepth = sample_r(map, fmt, W, H, px + ox, py + oy) * 0.5f + 0.5f;
