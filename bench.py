@@ -169,6 +169,36 @@ def ecs_baseline(ctx, count: int, steps: int):
             "cpu_allcores_mentities_per_s": count / tn / 1e6, "cpu_sse_cull_only_mboxes_per_s_1thread": n4 / t_sse / 1e6, "cpu_cores": cores, "cpu_model": _cpu_model(), "kind": "port"}
 
 
+def mesh_cull_block(ctx, count: int, num_batches: int, steps: int):
+    """SURVEY.md 8f rank 4 (the half with defined semantics): ComputeMeshCulling.shader main() without OCCLUSION_CULLING = frustum
+    flags + per-draw stable compaction of the 96-byte instance records.  The buffers are compacted in place, so every timed call
+    starts from a fresh device copy (the copy is outside the events).  Algorithmic bytes: 84 read + 4 written per instance for
+    the flags; 96 read per instance + 96 written per moved record + 28 per batch for the compaction."""
+    from oracle import oracle
+    from sailor_amd.forward_plus import MeshCull
+    cam = synth.make_camera(3840, 2160)
+    s = synth.make_instance_set(count, num_batches)
+    mc = MeshCull(ctx, s.instances, s.batches)
+    inst0, batch0 = mc.instances.clone(), mc.batches.clone()
+    t = []
+    for _ in range(steps + 3):
+        mc.instances.copy_(inst0); mc.batches.copy_(batch0)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); mc.run(cam.frame); b.record()
+        torch.cuda.synchronize()
+        t.append(a.elapsed_time(b))
+    med = float(np.median(t[3:]))
+    t0 = time.perf_counter()
+    ref_i, ref_b = oracle.mesh_cull_compact(cam.frame, s.instances, count, 0, s.batches)
+    t1 = time.perf_counter() - t0
+    kept = int(ref_b[:, 1].sum())
+    moved = int((ref_i["materialInstance"] != np.arange(count, dtype=np.uint32)).sum())
+    algo = count * (84 + 4) + count * 96 + moved * 96 + num_batches * 28
+    return {"instances": count, "batches": num_batches, "kept": kept, "moved_records": moved, "gpu_ms": med,
+            "gpu_minstances_per_s": count / med / 1e3, "algorithmic_bytes": algo, "gpu_hbm_gbs": algo / med / 1e6,
+            "gpu_hbm_frac": algo / med / 1e6 / HBM_PEAK_GBS, "cpu_1thread_minstances_per_s": count / t1 / 1e6, "kind": "port"}
+
+
 def linearize_block(ctx, frame, fp, d_lights, steps: int):
     """the LinearizeDepth pass in front of K1, standalone (8 algorithmic bytes per pixel) and folded into
     the cull's depth pass (SAILOR_CULL_RAW_DEPTH: no extra pass, no extra bytes), next to the oracle on one host core."""
@@ -492,6 +522,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frame, args.cpu_sample_tile_rows)
             out["ecs_sweep"] = ecs_baseline(ctx, 1 << 20, 20)
+            out["mesh_cull_compact"] = mesh_cull_block(ctx, 1 << 20, 4096, 20)
             out["linearize_depth"] = linearize_block(ctx, frame, fp, d_lights, 30)
             if csm is None:
                 out["ambient_ibl"] = ambient_block(ctx, frame, fp, d_lights, d_surface, 30)

@@ -104,6 +104,15 @@ typedef struct SailorPerInstanceData {
     uint32_t _pad[2];
 } SailorPerInstanceData;
 
+/* RHI/Types.h DrawIndexedIndirectData == VkDrawIndexedIndirectCommand == ComputeMeshCulling.shader:28-35.  20 bytes. */
+typedef struct SailorDrawIndexedIndirectData {
+    uint32_t indexCount;
+    uint32_t instanceCount;
+    uint32_t firstIndex;
+    int32_t vertexOffset;
+    uint32_t firstInstance;
+} SailorDrawIndexedIndirectData;
+
 /* Math/Transform.h: {vec4 m_position; quat m_rotation (memory x,y,z,w); vec4 m_scale}.  48 bytes. */
 typedef struct SailorTransform {
     float position[4];
@@ -336,10 +345,26 @@ SAILOR_HIP_API int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntit
                                         float* dWorld, SailorAABB* dWorldAabb, uint64_t* dVisibility);
 
 /* Replaces: FrustumCulling of Content/Shaders/ComputeMeshCulling.shader:96-110 (+ CreateViewFrustum, Math.glsl:185-222)
- * for the Dispatch at RHI/Batch.hpp:188; writes PerInstanceData::isCulled in place.  Hi-Z occlusion and the
- * indirect-draw compaction of that shader are out of scope. */
+ * for the Dispatch at RHI/Batch.hpp:188; writes PerInstanceData::isCulled in place for the instances
+ * [firstInstanceIndex, firstInstanceIndex + numInstances).  Hi-Z occlusion (the shader's OCCLUSION_CULLING define) is out of
+ * scope. */
 SAILOR_HIP_API int sailor_hip_mesh_frustum_cull(SailorHipContext* ctx, const SailorUboFrameData* frame,
                                                 SailorPerInstanceData* dInstances, uint32_t numInstances, uint32_t firstInstanceIndex);
+
+/* Replaces: the whole main() of Content/Shaders/ComputeMeshCulling.shader:119-177 built without OCCLUSION_CULLING, for the same
+ * Dispatch (RHI/Batch.hpp:177-188; push constants numBatches / numInstances / firstInstanceIndex):
+ *   step 2 (:126-144)  isCulled over the instance window, as sailor_hip_mesh_frustum_cull;
+ *   step 3 (:146-177)  per indirect draw a stable in-place compaction of its instance records
+ *                      [firstInstance, firstInstance + instanceCount) by isCulled == 0, and instanceCount = number kept.
+ * Every flag is written before any batch is compacted (the canonical reading of the shader's cross-workgroup race).  The batches
+ * own disjoint instance ranges inside the buffer and their instanceCounts add up to at most numInstances (exactly numInstances at
+ * RHI/Batch.hpp:158-159,183).  Records behind a batch's kept prefix keep their old contents, as in the shader.
+ *   dBatches   : device in/out, numBatches x SailorDrawIndexedIndirectData ("drawIndexedIndirect", set 2 binding 0)
+ *   dWorkspace : device scratch, 256-byte aligned, sailor_hip_mesh_cull_workspace_bytes(numInstances, numBatches) bytes */
+SAILOR_HIP_API size_t sailor_hip_mesh_cull_workspace_bytes(uint32_t numInstances, uint32_t numBatches);
+SAILOR_HIP_API int sailor_hip_mesh_cull_compact(SailorHipContext* ctx, const SailorUboFrameData* frame, SailorPerInstanceData* dInstances,
+                                                uint32_t numInstances, uint32_t firstInstanceIndex, SailorDrawIndexedIndirectData* dBatches,
+                                                uint32_t numBatches, void* dWorkspace, size_t workspaceBytes);
 
 /* ---- RCCL exchange for split frames (only when the frame is split AND a consumer needs the global list) ----
  * `comm` is an ncclComm_t created by the host.  Collective 1: all-gather of one uint32 (band total) per rank.

@@ -193,12 +193,29 @@ def evsm_blur(image: np.ndarray, radius_umbra: int, radius_penumbra: int) -> np.
     return out
 
 
+def _copy_records(a: np.ndarray) -> np.ndarray:
+    """byte-exact copy of a structured array (ndarray.copy() does not carry the padding bytes of the 96-byte records)."""
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint8).reshape(-1).copy().view(a.dtype)
+
+
 def mesh_frustum_cull(frame, instances: np.ndarray) -> np.ndarray:
     fb = _frame_bytes(frame)
-    inst = np.ascontiguousarray(instances).copy()
+    inst = _copy_records(instances)
     assert inst.dtype.itemsize == 96
     lib().oracle_mesh_frustum_cull(_p(fb), _p(inst), C.c_uint32(len(inst)))
     return inst
+
+
+def mesh_cull_compact(frame, instances: np.ndarray, num_instances: int, first_instance: int, batches: np.ndarray):
+    """ComputeMeshCulling.shader main(): frustum flags over [first, first + num), then per-batch stable compaction.
+    `batches` is uint32 [numBatches, 5] (indexCount, instanceCount, firstIndex, vertexOffset, firstInstance)."""
+    fb = _frame_bytes(frame)
+    inst = _copy_records(instances)
+    bt = np.ascontiguousarray(batches, np.uint32).copy()
+    assert inst.dtype.itemsize == 96 and bt.ndim == 2 and bt.shape[1] == 5
+    lib().oracle_mesh_cull_compact(_p(fb), _p(inst), C.c_uint32(num_instances), C.c_uint32(first_instance), _p(bt), C.c_uint32(len(bt)))
+    return inst, bt
 
 
 def extract_frustum_planes(world_matrix, aspect, fov_y, z_near, z_far):

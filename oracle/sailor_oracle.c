@@ -1282,6 +1282,33 @@ ORACLE_API void oracle_mesh_frustum_cull(const void* ubo_, void* instances, uint
     }
 }
 
+/* Content/Shaders/ComputeMeshCulling.shader:119-177 main() without the OCCLUSION_CULLING define: step 2 = FrustumCulling over
+ * the instance window (as above), barrier, step 3 = "remove empty draw calls": per DrawIndexedIndirectData (20 B: indexCount,
+ * instanceCount, firstIndex, vertexOffset, firstInstance -- :28-35) a stable in-place compaction of the batch's instance records
+ * (:154-174) and instanceCount = number kept (:176).  Canonical reading of the shader's cross-workgroup race (SURVEY.md
+ * Appendix C): every flag of step 2 is written before any batch of step 3 is compacted; batches own disjoint instance ranges. */
+ORACLE_API void oracle_mesh_cull_compact(const void* ubo_, void* instances, uint32_t numInstances, uint32_t firstInstanceIndex,
+                                         void* batches, uint32_t numBatches)
+{
+    uint8_t* inst = (uint8_t*)instances;
+    oracle_mesh_frustum_cull(ubo_, inst + 96 * (size_t)firstInstanceIndex, numInstances);
+    for (uint32_t b = 0; b < numBatches; b++) {
+        uint32_t* batch = (uint32_t*)((uint8_t*)batches + 20 * (size_t)b);
+        const uint32_t first = batch[4], count = batch[1];
+        uint32_t readIndex = first, writeIndex = first;
+        for (uint32_t i = 0; i < count; i++) {
+            uint32_t culled;
+            memcpy(&culled, inst + 96 * (size_t)readIndex + 84, 4);
+            if (culled == 0) {
+                if (readIndex != writeIndex) memcpy(inst + 96 * (size_t)writeIndex, inst + 96 * (size_t)readIndex, 96);
+                writeIndex++;
+            }
+            readIndex++;
+        }
+        batch[1] = writeIndex - first;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* CSM matrix set-up (S9): FrameGraph/ShadowPrepassNode.cpp:378-404 ; Math/Bounds.cpp:78-109 ;  */
 /* ECS/LightingECS.cpp:276-298                                                                  */

@@ -1,0 +1,241 @@
+// Step 3 of ComputeMeshCulling.shader main() (:146-177, "remove empty draw calls") for gfx950: per indirect draw a stable
+// in-place compaction of its PerInstanceData records by isCulled, and instanceCount = number kept.
+//
+// The shader gives one thread a whole batch and moves 96-byte records one by one.  Here a batch is cut into chunks of 256
+// records; a persistent grid of 256-thread blocks walks the chunks in batch order:
+//   load    the chunk's 24 KiB of records into LDS with linear float4 requests (fully coalesced),
+//   count   the kept records (ballot + popcount), publish the count,
+//   offset  of the chunk inside its batch by decoupled look-back over the preceding chunks' published counts (one wave looks
+//           at 64 predecessors per step),
+//   store   the kept records from LDS to their destination, again as one linear float4 stream.
+// In-place safety: a chunk's destination never lies behind its own source, so it can only overlap the sources of chunks at or
+// before it in the same batch.  A chunk publishes only after its records are in LDS, and a chunk that holds a complete
+// look-back has seen a publication of every predecessor -- so every overlapped source has been read before the first store.
+// Records that stay where they are (nothing culled in front of them) are not rewritten, as in the shader (:164).
+#include "common.h"
+
+#define DC_CHUNK 256          // records per chunk = threads per block
+#define DC_REC4 6             // float4 per 96-byte record
+#define DC_MAX_BLOCKS 1536    // persistent grid: 6 blocks per CU are co-resident (25.1 KB LDS, 256 threads each)
+
+#define DC_FLAG_AGGREGATE 1ull
+#define DC_FLAG_PREFIX 2ull
+
+struct DrawPlan {              // workspace layout, all offsets in bytes
+    size_t offFirst, offCount, offItemOffset, offItems, offStatus, total;
+    uint32_t maxItems;
+};
+
+static DrawPlan draw_plan_layout(uint32_t numInstances, uint32_t numBatches)
+{
+    DrawPlan L;
+    size_t o = 0;
+    L.offFirst = o; o = align_up(o + 4ull * numBatches, 256);
+    L.offCount = o; o = align_up(o + 4ull * numBatches, 256);
+    L.offItemOffset = o; o = align_up(o + 4ull * (numBatches + 1ull), 256);
+    // sum over batches of ceil(count / 256) <= numInstances / 256 + numBatches when the batches' counts add up to numInstances
+    // (RHI/Batch.hpp:158-159,183); larger sums are still handled, by the grid-stride walk, but need the status slots:
+    L.maxItems = numInstances / DC_CHUNK + numBatches + 1;
+    L.offItems = o; o = align_up(o + 16ull * L.maxItems, 256);
+    L.offStatus = o; o = align_up(o + 8ull * L.maxItems, 256);
+    L.total = o;
+    return L;
+}
+
+// one block: copies (firstInstance, instanceCount) of every batch out of the indirect buffer (step 3 rewrites instanceCount
+// while other chunks of the batch still need the old one) and lays the chunks of all batches out as one item sequence
+__global__ __launch_bounds__(1024) void k4_draw_plan(const uint32_t* __restrict__ batches, uint32_t numBatches, uint32_t* __restrict__ planFirst,
+                                                      uint32_t* __restrict__ planCount, uint32_t* __restrict__ itemOffset, uint32_t maxItems)
+{
+    __shared__ uint32_t sWave[16];
+    __shared__ uint32_t sCarry;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sCarry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < numBatches; base += 1024) {
+        const uint32_t b = base + threadIdx.x;
+        uint32_t items = 0;
+        if (b < numBatches) {
+            const uint32_t count = batches[5 * b + 1], first = batches[5 * b + 4];
+            planFirst[b] = first;
+            planCount[b] = count;
+            items = (count + DC_CHUNK - 1) / DC_CHUNK;
+        }
+        uint32_t incl = items; // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= (uint32_t)d) incl += up;
+        }
+        if (lane == 63) sWave[wave] = incl;
+        __syncthreads();
+        uint32_t before = sCarry;
+        for (uint32_t w = 0; w < wave; w++) before += sWave[w];
+        if (b < numBatches) itemOffset[b] = before + incl - items;
+        __syncthreads();
+        if (threadIdx.x == 1023) sCarry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) itemOffset[numBatches] = sCarry < maxItems ? sCarry : maxItems; // never more items than status slots
+}
+
+// one thread per item: its batch (last b with itemOffset[b] <= item; empty batches share their successor's offset and are
+// skipped) and its record range -- so that the compaction blocks start with one 16-byte load instead of a dependent search
+__global__ __launch_bounds__(256) void k4_draw_items(uint32_t numBatches, const uint32_t* __restrict__ planFirst, const uint32_t* __restrict__ planCount,
+                                                      const uint32_t* __restrict__ itemOffset, uint4* __restrict__ items,
+                                                      unsigned long long* __restrict__ status, uint32_t maxItems)
+{
+    const uint32_t item = blockIdx.x * 256 + threadIdx.x;
+    if (item < maxItems) status[item] = 0ull; // "nothing published yet"
+    if (item >= itemOffset[numBatches]) return;
+    uint32_t lo = 0, hi = numBatches;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (itemOffset[mid] <= item) lo = mid; else hi = mid;
+    }
+    const uint32_t chunk = item - itemOffset[lo];
+    const uint32_t count = planCount[lo], srcRec = chunk * DC_CHUNK;
+    const uint32_t len = min((uint32_t)DC_CHUNK, count - srcRec);
+    // x: first record of the batch, y: chunk index inside the batch, z: records in the chunk | last-chunk bit, w: batch
+    items[item] = make_uint4(planFirst[lo], chunk, len | (srcRec + len == count ? 0x80000000u : 0u), lo);
+}
+
+// Status words: relaxed agent-scope atomics (served coherently across the eight XCD L2s).  No release / acquire: on gfx950 those
+// write back / invalidate the whole XCD L2 per publication (measured: 357 us for 8 192 chunks), and nothing needs them -- the
+// only ordering the scheme relies on is "records in LDS, then publish" and "look-back complete, then store", both of which
+// are separated by a workgroup barrier in program order.
+__device__ __forceinline__ unsigned long long dc_load(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void dc_store(unsigned long long* p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(DC_CHUNK) void k4_draw_compact(float4* __restrict__ inst, uint32_t* __restrict__ batches, uint32_t numBatches,
+                                                            const uint32_t* __restrict__ itemOffset, const uint4* __restrict__ items,
+                                                            unsigned long long* __restrict__ status)
+{
+    __shared__ float4 sRec[DC_CHUNK * DC_REC4];
+    __shared__ uint16_t sMap[DC_CHUNK];
+    __shared__ uint32_t sWaveKept[4];
+    __shared__ uint32_t sExcl;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t totalItems = itemOffset[numBatches];
+
+    for (uint32_t item = blockIdx.x; item < totalItems; item += gridDim.x) {
+        const uint4 desc = items[item];
+        const uint32_t first = desc.x, chunk = desc.y, len = desc.z & 0x7FFFFFFFu, b = desc.w;
+        const bool lastChunk = (desc.z >> 31) != 0u;
+        const uint32_t itemLo = item - chunk;
+        const uint32_t srcRec = chunk * DC_CHUNK;                           // record index inside the batch
+        const float4* src = inst + ((size_t)first + srcRec) * DC_REC4;
+
+        const uint32_t n4 = len * DC_REC4;
+#pragma unroll
+        for (int k = 0; k < DC_REC4; k++) {
+            const uint32_t q = tid + DC_CHUNK * k;
+            if (q < n4) sRec[q] = src[q];
+        }
+        __syncthreads();
+        // PerInstanceData::isCulled at byte 84 = component y of the record's sixth float4
+        const bool keep = tid < len && __float_as_uint(sRec[tid * DC_REC4 + 5].y) == 0u;
+        const unsigned long long mask = __ballot(keep);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (lane == 0) sWaveKept[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t waveBase = 0;
+        for (uint32_t w = 0; w < wave; w++) waveBase += sWaveKept[w];
+        const uint32_t kept = sWaveKept[0] + sWaveKept[1] + sWaveKept[2] + sWaveKept[3];
+        if (keep) sMap[waveBase + rank] = (uint16_t)tid;
+
+        if (wave == 0) { // publish, then look back (the records are in LDS: see the barrier above)
+            uint32_t excl = 0;
+            if (chunk == 0) {
+                if (lane == 0) dc_store(status + item, (DC_FLAG_PREFIX << 32) | kept);
+            } else {
+                if (lane == 0) dc_store(status + item, (DC_FLAG_AGGREGATE << 32) | kept);
+                int64_t p = (int64_t)item - 1;
+                for (;;) {
+                    const int64_t idx = p - (int64_t)lane;
+                    const bool valid = idx >= (int64_t)itemLo;
+                    unsigned long long s;
+                    do {
+                        s = valid ? dc_load(status + idx) : (DC_FLAG_PREFIX << 32);
+                    } while (__any((s >> 32) == 0ull));
+                    const unsigned long long pref = __ballot((s >> 32) == DC_FLAG_PREFIX);
+                    const uint32_t stop = pref ? (uint32_t)__builtin_ctzll(pref) : 63u; // nearest predecessor holding a prefix
+                    uint32_t v = lane <= stop ? (uint32_t)s : 0u;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+                    excl += v;
+                    if (pref) break;
+                    p -= 64;
+                }
+                if (lane == 0) dc_store(status + item, (DC_FLAG_PREFIX << 32) | (excl + kept));
+            }
+            if (lane == 0) {
+                sExcl = excl;
+                if (lastChunk) batches[5 * b + 1] = excl + kept; // :176 instanceCount = writeIndex - firstInstance
+            }
+        }
+        __syncthreads();
+        const uint32_t excl = sExcl;
+        if (excl != srcRec || kept != len) { // otherwise every kept record already sits at its destination
+            float4* dst = inst + ((size_t)first + excl) * DC_REC4;
+            const uint32_t out4 = kept * DC_REC4;
+#pragma unroll
+            for (int k = 0; k < DC_REC4; k++) {
+                const uint32_t q = tid + DC_CHUNK * k;
+                if (q < out4) {
+                    const uint32_t r = q / DC_REC4, part = q - r * DC_REC4;
+                    const uint32_t s = sMap[r];
+                    if (excl + r != srcRec + s) dst[q] = sRec[s * DC_REC4 + part]; // :164 readIndex != writeIndex
+                }
+            }
+        }
+        __syncthreads(); // sRec / sMap / sExcl are reused by the next item
+    }
+}
+
+extern "C" {
+
+size_t sailor_hip_mesh_cull_workspace_bytes(uint32_t numInstances, uint32_t numBatches)
+{
+    return draw_plan_layout(numInstances, numBatches).total;
+}
+
+int sailor_hip_mesh_cull_compact(SailorHipContext* ctx, const SailorUboFrameData* frame, SailorPerInstanceData* dInstances, uint32_t numInstances,
+                                 uint32_t firstInstanceIndex, SailorDrawIndexedIndirectData* dBatches, uint32_t numBatches, void* dWorkspace,
+                                 size_t workspaceBytes)
+{
+    if (!ctx || !frame) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const DrawPlan L = draw_plan_layout(numInstances, numBatches);
+    if (numBatches != 0) {
+        if (!dInstances || !dBatches || !dWorkspace || ((uintptr_t)dInstances & 15) || ((uintptr_t)dBatches & 3)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+        if (workspaceBytes < L.total || ((uintptr_t)dWorkspace & 255)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    }
+    // step 2: flags over the instance window
+    const int rc = sailor_hip_mesh_frustum_cull(ctx, frame, dInstances ? dInstances + firstInstanceIndex : nullptr, numInstances, 0);
+    if (rc != SAILOR_HIP_OK || numBatches == 0) return rc;
+    uint8_t* ws = (uint8_t*)dWorkspace;
+    uint32_t* planFirst = (uint32_t*)(ws + L.offFirst);
+    uint32_t* planCount = (uint32_t*)(ws + L.offCount);
+    uint32_t* itemOffset = (uint32_t*)(ws + L.offItemOffset);
+    uint4* items = (uint4*)(ws + L.offItems);
+    unsigned long long* status = (unsigned long long*)(ws + L.offStatus);
+    hipLaunchKernelGGL(k4_draw_plan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)dBatches, numBatches, planFirst, planCount, itemOffset,
+                       L.maxItems);
+    SAILOR_CHECK_LAUNCH(ctx, "k4_draw_plan");
+    hipLaunchKernelGGL(k4_draw_items, dim3((L.maxItems + 255) / 256), dim3(256), 0, ctx->stream, numBatches, planFirst, planCount, itemOffset, items,
+                       status, L.maxItems);
+    SAILOR_CHECK_LAUNCH(ctx, "k4_draw_items");
+    const uint32_t blocks = L.maxItems < DC_MAX_BLOCKS ? L.maxItems : DC_MAX_BLOCKS;
+    hipLaunchKernelGGL(k4_draw_compact, dim3(blocks), dim3(DC_CHUNK), 0, ctx->stream, (float4*)dInstances, (uint32_t*)dBatches, numBatches, itemOffset,
+                       items, status);
+    SAILOR_CHECK_LAUNCH(ctx, "k4_draw_compact");
+    return SAILOR_HIP_OK;
+}
+
+} // extern "C"

@@ -243,42 +243,50 @@ __device__ __forceinline__ void msc_plane(const float* p1, const float* p2, floa
     n[0] = cx / len; n[1] = cy / len; n[2] = cz / len;
 }
 
+#define MSC_PER_BLOCK 1024 // instances per 256-thread block: the frustum set-up below is paid once per 1024 instances
+
 __global__ __launch_bounds__(256) void k4_mesh_frustum_cull(Mat4 view, Mat4 invProj, int vpW, int vpH, float zNearArg, float zFarArg,
                                                              SailorPerInstanceData* __restrict__ inst, uint32_t first, uint32_t count)
 {
+    __shared__ float sV[4][3];
     __shared__ float sN[4][3];
-    if (threadIdx.x == 0) { // Math.glsl:185-222 CreateViewFrustum(frame.viewportSize, frame.invProjection)
-        float vs[4][3];
+    // Math.glsl:185-222 CreateViewFrustum(frame.viewportSize, frame.invProjection): one lane per corner, then one per plane
+    if (threadIdx.x < 4) {
         const float fw = (float)vpW, fh = (float)vpH;
-        msc_screen_to_view(invProj, 0.0f, 0.0f, fw, fh, vs[0]);
-        msc_screen_to_view(invProj, fw, 0.0f, fw, fh, vs[1]);
-        msc_screen_to_view(invProj, 0.0f, fh, fw, fh, vs[2]);
-        msc_screen_to_view(invProj, fw, fh, fw, fh, vs[3]);
-        msc_plane(vs[2], vs[0], sN[0]);
-        msc_plane(vs[1], vs[3], sN[1]);
-        msc_plane(vs[0], vs[1], sN[2]);
-        msc_plane(vs[3], vs[2], sN[3]);
+        msc_screen_to_view(invProj, (threadIdx.x & 1) ? fw : 0.0f, (threadIdx.x & 2) ? fh : 0.0f, fw, fh, sV[threadIdx.x]);
     }
     __syncthreads();
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= count) return;
-    SailorPerInstanceData* I = inst + first + k;
-    const float4* m4 = reinterpret_cast<const float4*>(I);
-    Mat4 model;
-    const float4 c0 = m4[0], c1 = m4[1], c2 = m4[2], c3 = m4[3], sb = m4[4];
-    model.m[0] = c0.x; model.m[1] = c0.y; model.m[2] = c0.z; model.m[3] = c0.w; model.m[4] = c1.x; model.m[5] = c1.y; model.m[6] = c1.z; model.m[7] = c1.w;
-    model.m[8] = c2.x; model.m[9] = c2.y; model.m[10] = c2.z; model.m[11] = c2.w; model.m[12] = c3.x; model.m[13] = c3.y; model.m[14] = c3.z; model.m[15] = c3.w;
-    const float4 wc = glsl_mul(model, sb.x, sb.y, sb.z, 1.0f);
-    const float4 vc = glsl_mul(view, wc.x, wc.y, wc.z, wc.w);
-    const float cx = vc.x / vc.w, cy = vc.y / vc.w, cz = (vc.z / vc.w) * -1.0f;
-    const float lossyScale = sqrtf(dot3f(c0.x, c0.y, c0.z, c0.x, c0.y, c0.z));
-    const float radius = sb.w * lossyScale;
-    // SphereFrustumOverlaps(center, radius, frustum, zNear = frame.cameraZNearZFar.y, zFar = frame.cameraZNearZFar.x) (:107)
-    bool overlaps = !(cz - radius > zNearArg || cz + radius < zFarArg);
+    if (threadIdx.x < 4) {
+        // planes (2,0) (1,3) (0,1) (3,2): left, right, top, bottom
+        const int pa = threadIdx.x == 0 ? 2 : threadIdx.x == 1 ? 1 : threadIdx.x == 2 ? 0 : 3;
+        const int pb = threadIdx.x == 0 ? 0 : threadIdx.x == 1 ? 3 : threadIdx.x == 2 ? 1 : 2;
+        float p1[3] = { sV[pa][0], sV[pa][1], sV[pa][2] }, p2[3] = { sV[pb][0], sV[pb][1], sV[pb][2] }, n[3];
+        msc_plane(p1, p2, n);
+        sN[threadIdx.x][0] = n[0]; sN[threadIdx.x][1] = n[1]; sN[threadIdx.x][2] = n[2];
+    }
+    __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 4; p++)
-        if (dot3f(sN[p][0], sN[p][1], sN[p][2], cx, cy, cz) < -radius) overlaps = false;
-    I->isCulled = overlaps ? 0u : 1u;
+    for (int it = 0; it < MSC_PER_BLOCK / 256; it++) {
+        const uint32_t k = blockIdx.x * MSC_PER_BLOCK + it * 256 + threadIdx.x;
+        if (k >= count) break;
+        SailorPerInstanceData* I = inst + first + k;
+        const float4* m4 = reinterpret_cast<const float4*>(I);
+        Mat4 model;
+        const float4 c0 = m4[0], c1 = m4[1], c2 = m4[2], c3 = m4[3], sb = m4[4];
+        model.m[0] = c0.x; model.m[1] = c0.y; model.m[2] = c0.z; model.m[3] = c0.w; model.m[4] = c1.x; model.m[5] = c1.y; model.m[6] = c1.z; model.m[7] = c1.w;
+        model.m[8] = c2.x; model.m[9] = c2.y; model.m[10] = c2.z; model.m[11] = c2.w; model.m[12] = c3.x; model.m[13] = c3.y; model.m[14] = c3.z; model.m[15] = c3.w;
+        const float4 wc = glsl_mul(model, sb.x, sb.y, sb.z, 1.0f);
+        const float4 vc = glsl_mul(view, wc.x, wc.y, wc.z, wc.w);
+        const float cx = vc.x / vc.w, cy = vc.y / vc.w, cz = (vc.z / vc.w) * -1.0f;
+        const float lossyScale = sqrtf(dot3f(c0.x, c0.y, c0.z, c0.x, c0.y, c0.z));
+        const float radius = sb.w * lossyScale;
+        // SphereFrustumOverlaps(center, radius, frustum, zNear = frame.cameraZNearZFar.y, zFar = frame.cameraZNearZFar.x) (:107)
+        bool overlaps = !(cz - radius > zNearArg || cz + radius < zFarArg);
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+            if (dot3f(sN[p][0], sN[p][1], sN[p][2], cx, cy, cz) < -radius) overlaps = false;
+        I->isCulled = overlaps ? 0u : 1u;
+    }
 }
 
 extern "C" {
@@ -324,7 +332,7 @@ int sailor_hip_mesh_frustum_cull(SailorHipContext* ctx, const SailorUboFrameData
     Mat4 view, invProj;
     memcpy(view.m, frame->view, 64);
     memcpy(invProj.m, frame->invProjection, 64);
-    hipLaunchKernelGGL(k4_mesh_frustum_cull, dim3((numInstances + 255) / 256), dim3(256), 0, ctx->stream, view, invProj,
+    hipLaunchKernelGGL(k4_mesh_frustum_cull, dim3((numInstances + MSC_PER_BLOCK - 1) / MSC_PER_BLOCK), dim3(256), 0, ctx->stream, view, invProj,
                        frame->viewportSize[0], frame->viewportSize[1], frame->cameraZNearZFar[1], frame->cameraZNearZFar[0],
                        dInstances, firstInstanceIndex, numInstances);
     SAILOR_CHECK_LAUNCH(ctx, "k4_mesh_frustum_cull");

@@ -221,3 +221,31 @@ class EcsSweep:
                                             _ptr(self.world), _ptr(self.world_aabb), _ptr(self.visibility)),
                    "sailor_hip_ecs_sweep", self.ctx.handle)
         return self.world, self.world_aabb, self.visibility
+
+
+class MeshCull:
+    """ComputeMeshCulling.shader main() (frustum flags + indirect-draw compaction) over resident instance / indirect buffers."""
+
+    def __init__(self, ctx: HipContext, instances: np.ndarray, batches: np.ndarray):
+        assert instances.dtype.itemsize == 96
+        self.ctx = ctx
+        self.n = len(instances)
+        self.num_batches = len(batches)
+        self.instances = torch.from_numpy(instances.view(np.uint8).reshape(-1).copy()).to(ctx.device)
+        self.batches = torch.from_numpy(np.ascontiguousarray(batches, np.uint32).view(np.int32).copy()).to(ctx.device)
+        self._dtype = instances.dtype
+        self._ws_bytes = int(ctx._lib.sailor_hip_mesh_cull_workspace_bytes(self.n, self.num_batches))
+        self.workspace = torch.empty(max(self._ws_bytes, 256), dtype=torch.uint8, device=ctx.device)
+
+    def run(self, frame, num_instances=None, first_instance=0):
+        n = self.n - first_instance if num_instances is None else num_instances
+        _lib.check(self.ctx._lib.sailor_hip_mesh_cull_compact(self.ctx.handle, C.byref(frame), _ptr(self.instances), n, first_instance,
+                                                               _ptr(self.batches), self.num_batches, _ptr(self.workspace), self._ws_bytes),
+                   "sailor_hip_mesh_cull_compact", self.ctx.handle)
+        return self.instances, self.batches
+
+    def download(self):
+        self.ctx.synchronize()
+        # no ndarray.copy() of the record view: it would not carry the records' padding bytes
+        return (self.instances.cpu().numpy().view(self._dtype),
+                self.batches.cpu().numpy().view(np.uint32).reshape(-1, 5).copy())

@@ -38,6 +38,7 @@ HipGraphicsDriver::HipGraphicsDriver(int deviceOrdinal, void* stream, bool ownSt
 HipGraphicsDriver::~HipGraphicsDriver()
 {
     m_cullWorkspace.Clear();
+    m_meshCullWorkspace.Clear();
     if (m_ctx) sailor_hip_context_destroy(m_ctx);
 }
 
@@ -359,13 +360,28 @@ int HipGraphicsDriver::RecordEvsmBlur(const TVector<RHIShaderBindingSetPtr>& bin
 
 int HipGraphicsDriver::RecordMeshCulling(const TVector<RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pcBytes)
 {
-    // ComputeMeshCulling.shader:13-18 push constants {numBatches, numInstances, firstInstanceIndex}; set 1 `data`, set 3 frame
+    // ComputeMeshCulling.shader:13-18 push constants {numBatches, numInstances, firstInstanceIndex}; the Dispatch binds
+    // { depthHighZ, data, drawIndexedIndirect, frame } (RenderSceneNode.cpp:265,335; DepthPrepassNode.cpp:290) -- looked up by name,
+    // the Hi-Z set is not used (frustum-only build of the shader)
     if (bindings.size() < 2 || pcBytes.size() < 12) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     uint32_t pc[3];
     memcpy(pc, pcBytes.data(), 12);
-    auto frameB = bindings.back()->Find("frameData");
+    RHIShaderBindingPtr frameB;
+    void* data = nullptr;
+    void* batches = nullptr;
+    for (const auto& set : bindings) {
+        if (!set) continue;
+        if (auto f = set->Find("frameData")) frameB = f;
+        if (void* d = buffer_of(set, "data")) data = d;
+        if (void* d = buffer_of(set, "drawIndexedIndirect")) batches = d;
+    }
     if (!frameB || frameB->m_hostCopy.size() < sizeof(SailorUboFrameData)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     SailorUboFrameData frame;
     memcpy(&frame, frameB->m_hostCopy.data(), sizeof frame);
-    return sailor_hip_mesh_frustum_cull(m_ctx, &frame, (SailorPerInstanceData*)buffer_of(bindings[0], "data"), pc[1], pc[2]);
+    if (!batches || pc[0] == 0) return sailor_hip_mesh_frustum_cull(m_ctx, &frame, (SailorPerInstanceData*)data, pc[1], pc[2]);
+    const size_t need = sailor_hip_mesh_cull_workspace_bytes(pc[1], pc[0]);
+    if (!m_meshCullWorkspace || m_meshCullWorkspace->m_size < need) m_meshCullWorkspace = CreateBuffer(need);
+    if (!m_meshCullWorkspace) return SAILOR_HIP_ERR_OUT_OF_MEMORY;
+    return sailor_hip_mesh_cull_compact(m_ctx, &frame, (SailorPerInstanceData*)data, pc[1], pc[2], (SailorDrawIndexedIndirectData*)batches, pc[0],
+                                        m_meshCullWorkspace->m_hip.m_devicePtr, m_meshCullWorkspace->m_size);
 }

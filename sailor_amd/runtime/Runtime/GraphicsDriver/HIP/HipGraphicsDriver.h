@@ -4,7 +4,8 @@
 // translates recorded Dispatches of the path's shaders into calls of the C-ABI (include/sailor_hip.h):
 //   "Shaders/ComputeLightCulling.shader" -> sailor_hip_light_cull        (binding contract: ComputeLightCulling.shader:20-47)
 //   "Shaders/Standard.shader"            -> sailor_hip_shade             (binding contract: Standard.shader:180-251)
-//   "Shaders/ComputeMeshCulling.shader"  -> sailor_hip_mesh_frustum_cull (binding contract: ComputeMeshCulling.shader:37-58)
+//   "Shaders/ComputeMeshCulling.shader"  -> sailor_hip_mesh_cull_compact (binding contract: ComputeMeshCulling.shader:37-58;
+//                                           sailor_hip_mesh_frustum_cull when no indirect buffer is bound)
 // and the one full-screen DRAW in front of the path (6 indices with the material of)
 //   "Shaders/LinearizeDepth.shader"      -> sailor_hip_linearize_depth   (binding contract: LinearizeDepth.shader:15-59)
 //   "Shaders/Blur.shader" {EVSM, HORIZONTAL | VERTICAL} -> sailor_hip_evsm_blur_pass (binding contract: Blur.shader:53-61)
@@ -71,6 +72,7 @@ private:
     int m_status = 0;
     int m_lastDispatchStatus = 0;
     RHI::RHIBufferPtr m_cullWorkspace;
+    RHI::RHIBufferPtr m_meshCullWorkspace;
     int32_t m_cullW = 0, m_cullH = 0, m_cullLights = 0; // geometry of the last light cull: locates its shading-order hint in the workspace
     bool m_cullOrderValid = false;
 };

@@ -201,6 +201,37 @@ RT_API int sailor_rt_blur_shadow_map(SailorRuntime* rt, void* mapDevicePtr, void
     return hip->GetLastDispatchStatus();
 }
 
+// The "GPU Culling" section of RHIRecordDrawCallGPUCulling (RHI/Batch.hpp:146-188) over resident buffers: the indirect buffer is bound as
+// "drawIndexedIndirect" (:86-89), the push constants are { numBatches, numInstances, firstInstanceIndex } (:176-184) and the Dispatch binds
+// { computeMeshCullingBindings (depthHighZ), perInstanceData, indirect buffer, frame } (RenderSceneNode.cpp:335).  The frame UBO is the one
+// RHIFrameGraph::FillFrameData uploads for the current camera / viewport.
+RT_API int sailor_rt_gpu_culling(SailorRuntime* rt, void* instancesDevicePtr, uint32_t numInstances, uint32_t firstInstanceIndex, void* batchesDevicePtr,
+                                 uint32_t numBatches)
+{
+    auto* hip = static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver());
+    auto driver = Renderer::GetDriver();
+    auto commands = Renderer::GetDriverCommands();
+    auto transferCmdList = driver->CreateCommandList();
+    rt->graph.FillFrameData(transferCmdList, rt->snapshot, rt->snapshot.m_deltaTime, rt->snapshot.m_currentTime);
+    auto computeCullingShader = driver->CreateShader("Shaders/ComputeMeshCulling.shader");
+    auto computeMeshCullingBindings = driver->CreateShaderBindings(); // would hold the Hi-Z pyramid: not used by the frustum-only build
+    auto perInstanceData = driver->CreateShaderBindings();
+    perInstanceData->GetOrAddShaderBinding("data")->m_buffer = hip->WrapBuffer(instancesDevicePtr, (size_t)(firstInstanceIndex + numInstances) * sizeof(SailorPerInstanceData));
+    auto indirectCommandBufferBinding = driver->CreateShaderBindings();
+    if (batchesDevicePtr)
+        indirectCommandBufferBinding->GetOrAddShaderBinding("drawIndexedIndirect")->m_buffer = hip->WrapBuffer(batchesDevicePtr, (size_t)numBatches * sizeof(SailorDrawIndexedIndirectData));
+    struct PushConstants { uint32_t m_numBatches = 0, m_numInstances = 0, m_firstInstanceIndex = 0; } constants;
+    constants.m_numBatches = numBatches;
+    constants.m_numInstances = numInstances;
+    constants.m_firstInstanceIndex = firstInstanceIndex;
+    commands->BeginDebugRegion(transferCmdList, "GPU Culling");
+    commands->Dispatch(transferCmdList, computeCullingShader, 256, 1, 1,
+                       { computeMeshCullingBindings, perInstanceData, indirectCommandBufferBinding, rt->snapshot.m_frameBindings }, &constants, sizeof constants);
+    commands->EndDebugRegion(transferCmdList);
+    driver->SubmitCommandList(transferCmdList);
+    return hip->GetLastDispatchStatus();
+}
+
 RT_API int sailor_rt_process_frame(SailorRuntime* rt)
 {
     rt->graph.Process(rt->snapshot);

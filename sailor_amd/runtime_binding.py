@@ -39,6 +39,7 @@ def load() -> C.CDLL:
         rt.sailor_rt_set_shadow_maps.argtypes = [P, P, P, P, P]
         rt.sailor_rt_set_ibl.argtypes = [P, P, C.c_int, P, C.c_int, C.c_int, P, C.c_int, C.c_int, P, C.c_int, C.c_int]
         rt.sailor_rt_blur_shadow_map.argtypes = [P, P, P, C.c_int, C.c_float, C.c_float]
+        rt.sailor_rt_gpu_culling.argtypes = [P, P, C.c_uint32, C.c_uint32, P, C.c_uint32]
         rt.sailor_rt_process_frame.argtypes = [P]
         rt.sailor_rt_wait_idle.argtypes = [P]
         rt.sailor_rt_buffer.restype = P
@@ -90,6 +91,11 @@ class Runtime:
     def blur_shadow_map(self, moments, temp, radius_umbra, radius_penumbra):
         """the blur section of ShadowPrepassNode::Process over a float32 [S, S, 4] device tensor, in place"""
         return self.rt.sailor_rt_blur_shadow_map(self.h, moments.data_ptr(), temp.data_ptr(), moments.shape[0], radius_umbra, radius_penumbra)
+
+    def gpu_culling(self, instances, num_instances, first_instance, batches, num_batches):
+        """the "GPU Culling" Dispatch of RHIRecordDrawCallGPUCulling over uint8 / int32 device tensors, in place"""
+        return self.rt.sailor_rt_gpu_culling(self.h, instances.data_ptr(), num_instances, first_instance,
+                                             batches.data_ptr() if batches is not None else None, num_batches)
 
     def set_surface(self, surface_tensor, radiance_tensor):
         self.rt.sailor_rt_set_surface(self.h, surface_tensor.data_ptr(), radiance_tensor.data_ptr(), surface_tensor.shape[2], surface_tensor.shape[1])

@@ -424,3 +424,45 @@ def make_frame(name: str, with_surface: bool = True, seed: int = SEED, **overrid
     surface = make_surface(cam, depth, seed) if with_surface else None
     shadows = make_shadow_set(cam, cfg["shadow_size"], seed) if cfg.get("shadow_size") else None
     return Frame(name=name, cam=cam, depth=depth, lights=lights, surface=surface, shadows=shadows)
+
+
+@dataclass
+class InstanceSet:
+    instances: np.ndarray   # host.INSTANCE_DTYPE [count]
+    batches: np.ndarray     # uint32 [numBatches, 5]: indexCount, instanceCount, firstIndex, vertexOffset, firstInstance
+
+
+def make_instance_set(count: int, num_batches: int, seed: int = SEED, first_instance: int = 0, spread: float = 3000.0) -> InstanceSet:
+    """The per-instance SSBO + indirect buffer of one RHIRecordDrawCallGPUCulling call (RHI/Batch.hpp:146-159): `count` instances
+    in `num_batches` contiguous batches of ragged size (a few empty, a few long), in front of `first_instance` untouched records.
+    model = translate(U[-spread, spread]^3) * scale(U[0.5, 4]); sphere centre U[-5,5]^3, radius U[1,61]; materialInstance = the
+    record's original index (so a moved record can be recognised)."""
+    total = first_instance + count
+    u = uniforms(STREAM_ENTITIES, total * 8, 1 << 26, seed).reshape(total, 8)
+    inst = np.zeros(total, host.INSTANCE_DTYPE)
+    sc = (np.float32(0.5) + np.float32(3.5) * u[:, 0]).astype(np.float32)
+    model = np.zeros((total, 16), np.float32)
+    model[:, 0] = sc; model[:, 5] = sc; model[:, 10] = sc; model[:, 15] = 1.0
+    model[:, 12:15] = ((u[:, 1:4] * 2 - 1) * np.float32(spread)).astype(np.float32)
+    model[:, 14] -= np.float32(0.5 * spread)  # most of the cloud in front of the camera (it looks down -z)
+    inst["model"] = model
+    inst["sphereBounds"][:, :3] = (u[:, 4:7] - np.float32(0.5)) * np.float32(10)
+    inst["sphereBounds"][:, 3] = np.float32(1) + np.float32(60) * u[:, 7]
+    inst["materialInstance"] = np.arange(total, dtype=np.uint32)
+    inst["isCulled"] = 7
+    # ragged batch sizes: cut points from the stream, every 16th batch empty, every 64th takes a large share
+    w = uniforms(STREAM_ENTITIES, num_batches, (1 << 26) + (1 << 25), seed).astype(np.float64) + 0.05
+    w[::16] = 0.0
+    w[5::64] *= 40.0
+    if w.sum() == 0.0:
+        w[:] = 1.0
+    sizes = np.floor(w / w.sum() * count).astype(np.int64)
+    sizes[np.argmax(w)] += count - int(sizes.sum())
+    first = first_instance + np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    batches = np.zeros((num_batches, 5), np.uint32)
+    batches[:, 0] = 36 + 3 * (np.arange(num_batches) % 100)
+    batches[:, 1] = sizes
+    batches[:, 2] = 1000 * np.arange(num_batches)
+    batches[:, 3] = np.arange(num_batches)
+    batches[:, 4] = first
+    return InstanceSet(instances=inst, batches=batches)

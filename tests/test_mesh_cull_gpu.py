@@ -1,0 +1,100 @@
+"""ComputeMeshCulling.shader main() without OCCLUSION_CULLING (frustum flags + indirect-draw compaction) through the C-ABI:
+every byte of the instance buffer and of the indirect buffer equals the oracle's (oracle_mesh_cull_compact)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from sailor_amd import _lib, host, synth
+from sailor_amd.forward_plus import MeshCull
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, cam, inst, batches, n, first):
+    mc = MeshCull(ctx, inst, batches)
+    mc.run(cam.frame, n, first)
+    got_i, got_b = mc.download()
+    ref_i, ref_b = oracle.mesh_cull_compact(cam.frame, inst, n, first, batches)
+    np.testing.assert_array_equal(got_b, ref_b)
+    np.testing.assert_array_equal(got_i.view(np.uint32).reshape(-1, 24), ref_i.view(np.uint32).reshape(-1, 24))
+    return mc, ref_i, ref_b
+
+
+def test_ragged_batches_with_untouched_head(ctx):
+    cam = synth.make_camera(1920, 1080)
+    s = synth.make_instance_set(20000, 100, first_instance=37)
+    _, ref_i, ref_b = _check(ctx, cam, s.instances, s.batches, 20000, 37)
+    assert (ref_i["isCulled"][:37] == 7).all()
+    assert (s.batches[:, 1] == 0).sum() > 0 and 0 < int(ref_b[:, 1].sum()) < 20000
+    assert (ref_b[:, [0, 2, 3, 4]] == s.batches[:, [0, 2, 3, 4]]).all()
+
+
+def test_one_long_batch_spans_more_chunks_than_blocks(ctx):
+    """300 000 records in one draw: 1 172 chunks on the 1 024-block persistent grid, look-back over > 64 predecessors."""
+    cam = synth.make_camera(3840, 2160)
+    s = synth.make_instance_set(300000, 1)
+    assert s.batches[0, 1] == 300000
+    _check(ctx, cam, s.instances, s.batches, 300000, 0)
+
+
+def test_nothing_culled_and_everything_culled(ctx):
+    cam = synth.make_camera(1920, 1080)
+    s = synth.make_instance_set(5000, 7)
+    near = oracle._copy_records(s.instances)
+    near["model"][:, 12:15] = np.float32([0.0, 150.0, -500.0])  # in front of the camera: all visible
+    mc, ref_i, ref_b = _check(ctx, cam, near, s.batches, 5000, 0)
+    np.testing.assert_array_equal(ref_b, s.batches)
+    assert (ref_i["materialInstance"] == np.arange(5000)).all()
+    behind = oracle._copy_records(s.instances)
+    behind["model"][:, 12:15] = np.float32([0.0, 150.0, 5000.0])  # behind it: all culled
+    _, ref_i, ref_b = _check(ctx, cam, behind, s.batches, 5000, 0)
+    assert (ref_b[:, 1] == 0).all() and (ref_i["materialInstance"] == np.arange(5000)).all()
+
+
+def test_many_tiny_batches_and_no_batches(ctx):
+    cam = synth.make_camera(1920, 1080)
+    s = synth.make_instance_set(6000, 5000)
+    _check(ctx, cam, s.instances, s.batches, 6000, 0)
+    # numBatches = 0: only the flags
+    mc = MeshCull(ctx, s.instances, s.batches[:0])
+    mc.run(cam.frame)
+    got_i, _ = mc.download()
+    np.testing.assert_array_equal(got_i["isCulled"], oracle.mesh_frustum_cull(cam.frame, s.instances)["isCulled"])
+    np.testing.assert_array_equal(got_i["materialInstance"], np.arange(6000))
+
+
+def test_second_frame_over_the_compacted_buffers(ctx):
+    """The buffers persist across frames in the reference (Batch.hpp re-uploads them only when the draw list changes)."""
+    cam = synth.make_camera(1920, 1080)
+    s = synth.make_instance_set(30000, 64)
+    mc = MeshCull(ctx, s.instances, s.batches)
+    mc.run(cam.frame)
+    i1, b1 = oracle.mesh_cull_compact(cam.frame, s.instances, 30000, 0, s.batches)
+    cam2 = synth.make_camera(1280, 720, fov=50.0)
+    mc.run(cam2.frame)
+    i2, b2 = oracle.mesh_cull_compact(cam2.frame, i1, 30000, 0, b1)
+    got_i, got_b = mc.download()
+    np.testing.assert_array_equal(got_b, b2)
+    np.testing.assert_array_equal(got_i.view(np.uint32).reshape(-1, 24), i2.view(np.uint32).reshape(-1, 24))
+    assert int(b2[:, 1].sum()) < int(b1[:, 1].sum())
+
+
+def test_1m_instances_4096_batches(ctx):
+    cam = synth.make_camera(7680, 4320)
+    s = synth.make_instance_set(1 << 20, 4096)
+    _check(ctx, cam, s.instances, s.batches, 1 << 20, 0)
+
+
+def test_argument_errors(ctx):
+    lib = _lib.load()
+    cam = synth.make_camera(640, 480)
+    s = synth.make_instance_set(100, 3)
+    mc = MeshCull(ctx, s.instances, s.batches)
+    rc = lib.sailor_hip_mesh_cull_compact(ctx.handle, C.byref(cam.frame), mc.instances.data_ptr(), 100, 0, mc.batches.data_ptr(), 3,
+                                          mc.workspace.data_ptr(), 16)
+    assert rc == -1
+    rc = lib.sailor_hip_mesh_cull_compact(ctx.handle, C.byref(cam.frame), mc.instances.data_ptr(), 100, 0, None, 3,
+                                          mc.workspace.data_ptr(), mc._ws_bytes)
+    assert rc == -1

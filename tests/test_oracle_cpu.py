@@ -293,3 +293,24 @@ def test_evsm_blur_weights_golden_and_numpy():
 
     ref = np_pass(np_pass(m, 2, 5, False), 2, 5, True)
     np.testing.assert_array_equal(out.view(np.uint32), ref.astype(np.float32).view(np.uint32))
+
+
+def test_mesh_cull_compaction_is_a_stable_per_batch_partition():
+    """oracle_mesh_cull_compact (ComputeMeshCulling.shader:146-177 restated literally) against an independent NumPy statement: per batch the
+    kept records in order at the front, instanceCount = their number, everything behind the kept prefix untouched except for the flag."""
+    cam = synth.make_camera(1920, 1080)
+    s = synth.make_instance_set(20000, 100, first_instance=37)
+    inst, bt = oracle.mesh_cull_compact(cam.frame, s.instances, 20000, 37, s.batches)
+    flags = oracle.mesh_frustum_cull(cam.frame, s.instances[37:])["isCulled"]
+    expect = s.instances.view(np.uint32).reshape(-1, 24).copy()
+    expect[37:, 21] = flags
+    after_flags = expect.copy()
+    for b in range(100):
+        f, c = int(s.batches[b, 4]), int(s.batches[b, 1])
+        keep = np.nonzero(after_flags[f:f + c, 21] == 0)[0] + f
+        expect[f:f + len(keep)] = after_flags[keep]
+        assert bt[b, 1] == len(keep)
+    np.testing.assert_array_equal(inst.view(np.uint32).reshape(-1, 24), expect)
+    assert (bt[:, [0, 2, 3, 4]] == s.batches[:, [0, 2, 3, 4]]).all()
+    assert (s.batches[:, 1] == 0).sum() > 0 and 0 < int(bt[:, 1].sum()) < 20000
+    assert (inst["isCulled"][:37] == 7).all()

@@ -154,3 +154,35 @@ def test_shadow_prepass_blur_draws_become_the_blur_kernel():
         np.testing.assert_array_equal(d2.cpu().numpy(), m)
     finally:
         rt.close()
+
+
+def test_gpu_culling_dispatch_compacts_the_indirect_draws():
+    """RHIRecordDrawCallGPUCulling's Dispatch (RHI/Batch.hpp:177-188) recorded against the HIP backend: push constants {numBatches, numInstances,
+    firstInstanceIndex}, sets {depthHighZ, data, drawIndexedIndirect, frame} -> sailor_hip_mesh_cull_compact; without an indirect buffer only the
+    flags (sailor_hip_mesh_frustum_cull)."""
+    cam = synth.make_camera(1280, 720)
+    s = synth.make_instance_set(9000, 40, first_instance=11)
+    raw = s.instances.view(np.uint8).reshape(-1)
+    rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        rt.set_camera(cam)
+        inst = torch.from_numpy(raw.copy()).cuda()
+        batches = torch.from_numpy(s.batches.view(np.int32).copy()).cuda()
+        assert rt.gpu_culling(inst, 9000, 11, batches, 40) == 0
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        ref_i, ref_b = oracle.mesh_cull_compact(cam.frame, s.instances, 9000, 11, s.batches)
+        np.testing.assert_array_equal(batches.cpu().numpy().view(np.uint32), ref_b)
+        np.testing.assert_array_equal(inst.cpu().numpy().view(np.uint32).reshape(-1, 24), ref_i.view(np.uint32).reshape(-1, 24))
+        assert 0 < int(ref_b[:, 1].sum()) < 9000
+        inst2 = torch.from_numpy(raw.copy()).cuda()
+        assert rt.gpu_culling(inst2, 9000, 11, None, 0) == 0
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        got = inst2.cpu().numpy().view(np.uint32).reshape(-1, 24)
+        flags = oracle.mesh_frustum_cull(cam.frame, s.instances[11:])["isCulled"]
+        np.testing.assert_array_equal(got[11:, 21], flags)
+        assert (got[:11, 21] == 7).all()
+        np.testing.assert_array_equal(got[:, 20], np.arange(9011))
+    finally:
+        rt.close()
