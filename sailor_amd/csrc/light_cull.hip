@@ -80,7 +80,7 @@ static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
     L.offGroupList = o; o = align_up(o + groups * CAPG * 4, 256);
     L.offClassPrefix = o; o = align_up(o + tiles * 4, 256);
     L.offClassSums = o; o = align_up(o + (size_t)L.sumBlocks * 4, 256);
-    L.offTileOrder = o; o = align_up(o + tiles * 4, 256);
+    L.offTileOrder = o; o = align_up(o + (tiles + 1) * 4, 256); // + the number of class A and B tiles
     L.total = o;
     return L;
 }
@@ -699,6 +699,7 @@ __global__ __launch_bounds__(256) void k1_pack(const uint32_t* __restrict__ tile
         const uint32_t cls = tile_class_bits(num);
         const uint32_t pos = cls == 1u ? aBefore : (cls ? aT + bBefore : aT + bT + ((uint32_t)tile - aBefore - bBefore));
         tileOrder[pos] = (uint32_t)(tile % Tx) | ((uint32_t)(tile / Tx) << 16);
+        if (tile == 0) tileOrder[T] = aT + bT; // how many entries of the order hold >= CLASS_B lights (the shade's split blocks)
     }
     const uint32_t* src = tileList + (size_t)tile * KEEP;
     for (uint32_t i = lane; i < num; i += 64)

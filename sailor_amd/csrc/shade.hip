@@ -301,45 +301,75 @@ __device__ __forceinline__ void wave_minmax6(int& a, int& b, int& c, int& d, int
 // replaced), so the shape below is about vector instructions per wave: light kind, finiteness and "survived the box test" are
 // wave-uniform 64-bit masks (scalar registers, scalar branches, six static segments -- no per-light type branches), the reach
 // test feeds the scalar branch directly, and the ~130-instruction exact falloff + BRDF only ever runs on queued pairs.
-template <bool HAS_CSM, bool HAS_IBL>
-__device__ __forceinline__ void k2_shade_body(const ShadeArgs& A, const CsmArgs& C, const IblArgs& I, const float4* __restrict__ surface, size_t planeStride,
+//
+// BAND (split frames: sailor_hip_shade_ex on a sub-band with the cull's tile-order hint): a band of a split frame has too few
+// tiles to hide its longest one -- a tile in the middle of a light cluster (128 lights reaching all 256 pixels = 128 pair passes
+// per wave) kept its block busy for ~65 us while the rest of a 1/8 band took 25.  The hint lists the band's tiles by list-length
+// class, long lists first, and ends with the number of tiles holding >= SPLIT_MIN lights.  Those tiles are taken by "split"
+// blocks, one per (tile, 8x8 quadrant): the block's four waves take every fourth list slot each over the SAME 64 pixels and add
+// their partial sums up through LDS (wave 0 + 1 + 2 + 3, a fixed order).  The grid is 1-D: SPLIT_BLOCKS split blocks first (they
+// walk the long tiles with a grid stride, so the long tiles start first), then one ordinary block per tile, which returns at
+// once if the tile belongs to the split blocks.
+#define SPLIT_MIN 40      // == CLASS_B of light_cull.hip: the hint's first two classes
+#define SPLIT_BLOCKS 2048 // one round of resident blocks (8 per CU)
+struct ShadeLds {
+    float4 sL[KEEP * LREC];
+    float sRes[3 * PENDK * 256];
+    uint16_t sQ[4 * QMAX];
+    uint32_t sNum;
+};
+#define ROLE_TILE 0       // one block per tile, grid (tiles per row, tile rows)
+#define ROLE_BAND_TILE 1  // the same inside k2_shade_band: returns at once on a tile of the split blocks
+#define ROLE_BAND_SPLIT 2 // one block per (long tile, quadrant)
+template <bool HAS_CSM, bool HAS_IBL, int ROLE = ROLE_TILE>
+__device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, const IblArgs& I, const float4* __restrict__ surface, size_t planeStride,
                                                  const SailorLightShaderData* __restrict__ lights,
                                                  const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled,
-                                                 float4* __restrict__ radiance)
+                                                 float4* __restrict__ radiance, int selTx = 0, int selTy = 0, int selQuad = 0)
 {
-    __shared__ float4 sL[KEEP * LREC];
-    __shared__ float sRes[3 * PENDK * 256];
-    __shared__ uint16_t sQ[4 * QMAX];
-    __shared__ uint32_t sNum;
+    float4* const sL = lds.sL;
+    float* const sRes = lds.sRes;
+    uint16_t* const sQ = lds.sQ;
+    uint32_t& sNum = lds.sNum;
+    constexpr bool BAND = ROLE != ROLE_TILE;
+    constexpr bool splitRole = ROLE == ROLE_BAND_SPLIT;
+    int tid = threadIdx.x;
+    // (a split block walks several tiles: keep everything derived from the lane id inside the loop body -- hoisted out of the
+    // loop those values stay live across the whole body and the 64-register budget spills)
+    if (splitRole) asm volatile("" : "+v"(tid));
 
     // grid = (tiles per row, tile rows of the band): no division.  With an order hint block i takes the i-th tile of that order.
     int btx = blockIdx.x, bty = blockIdx.y;
-    if (A.order) { const uint32_t o = A.order[blockIdx.y * A.Tx + blockIdx.x]; btx = (int)(o & 0xFFFFu); bty = (int)(o >> 16); }
+    const int lane = tid & 63, wave = tid >> 6;
+    int quad = wave;
+    if (BAND) { btx = selTx; bty = selTy; if (splitRole) quad = selQuad; }
+    else if (A.order) { const uint32_t o = A.order[blockIdx.y * A.Tx + blockIdx.x]; btx = (int)(o & 0xFFFFu); bty = (int)(o >> 16); }
     const int tx = btx, ty = A.tileRow0 + bty;
     const int bandTile = bty * A.Tx + btx;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // each wave shades one 8x8 quadrant of the tile: the most compact 64-pixel footprint, so that "no pixel of the wave
     // is within reach of this light" holds as often as possible
-    const int gx = tx * TILE + (wave & 1) * 8 + (lane & 7);
-    const int gy = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const int gx = tx * TILE + (quad & 1) * 8 + (lane & 7);
+    const int gy = ty * TILE + (quad >> 1) * 8 + (lane >> 3);
     const int py = A.H - 1 - gy;            // framebuffer row (Standard.shader:414: screenUv.y = H - fragY)
     const bool active = gx < A.W && py >= 0;
     const size_t pix = active ? ((size_t)(py - A.fbRow0) * A.W + gx) : 0;
 
+    SailorLightsGrid g;
     // issue the surface loads first -- unconditionally (lanes outside the frame read pixel 0 of the band and are masked
     // out of every ballot and of the store), so that nothing waits on them before the list staging below is under way
     const float4 P0 = surface[pix];
     const float4 P1 = surface[planeStride + pix];
     const float4 P2 = surface[2 * planeStride + pix];
 
-    const SailorLightsGrid g = grid[bandTile]; // Standard.shader:422-423
+    g = grid[bandTile]; // Standard.shader:422-423
+    if (BAND && !splitRole && g.num >= (uint32_t)SPLIT_MIN) return; // a tile of the split blocks
     const uint32_t listNum = g.num < (uint32_t)KEEP ? g.num : (uint32_t)KEEP;
-    if (threadIdx.x == 0) sNum = listNum;
+    if (tid == 0) sNum = listNum;
     __syncthreads();
-    if (threadIdx.x < listNum) {
-        const uint32_t index = culled[g.offset + threadIdx.x];
+    if (tid < listNum) {
+        const uint32_t index = culled[g.offset + tid];
         if (index >= (uint32_t)A.lightsNum) {
-            atomicMin(&sNum, threadIdx.x); // Standard.shader:430-433 "index == uint(-1) -> break" (and out-of-range guard)
+            atomicMin(&sNum, tid); // Standard.shader:430-433 "index == uint(-1) -> break" (and out-of-range guard)
         } else {
             const float4* L = reinterpret_cast<const float4*>(lights + index);
             const float4 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3], q4 = L[4], q5 = L[5], q6 = L[6];
@@ -357,7 +387,7 @@ __device__ __forceinline__ void k2_shade_body(const ShadeArgs& A, const CsmArgs&
             if (type == 1u) { if (finite && r > 0.0f) a = (r * r) * 1.00001f; }
             else { if (finite) a = -(q5.y - 1e-5f); b = q5.x - q5.y; }
             const uint32_t bits = (type < 255u ? type : 255u) | ((shadowType < 255u ? shadowType : 255u) << 8) | (finite ? 0x10000u : 0u);
-            float4* o = sL + threadIdx.x * LREC;
+            float4* o = sL + tid * LREC;
             o[0] = make_float4(q1.x, q1.y, q1.z, a);
             o[1] = make_float4(ndx * linv, ndy * linv, ndz * linv, __uint_as_float(bits));
             o[2] = make_float4(q4.x, q4.y, q4.z, b);
@@ -427,13 +457,19 @@ __device__ __forceinline__ void k2_shade_body(const ShadeArgs& A, const CsmArgs&
         seg[4 + h] = all & ~(seg[h] | seg[2 + h]);
     }
 
+    if (BAND && splitRole) { // this wave's share of the list: every fourth slot
+        const unsigned long long share = 0x1111111111111111ull << __builtin_amdgcn_readfirstlane(wave); // (scalar: the masks stay in SGPRs)
+#pragma unroll
+        for (int q = 0; q < 6; q++) seg[q] &= share;
+    }
+
     // ---- 2 + 3. queue the (pixel, light) pairs that can be lit, then shade them one LANE per PAIR ----
     // Window = up to QMAX queued pairs, at most PENDK per pixel; a light whose pairs do not fit ends the window (it is
     // tested again in the next one -- rare: a quadrant of the 4K frame queues ~50 pairs).  A pair's result goes to slot
     // [its ordinal among the pixel's queued pairs][pixel], which the pixel's own lane adds up afterwards: no atomics
     // (ds_add_f32 is serialised per lane on this LDS: ~170 cycles per wave instruction, scripts/microbench/lds_ops.hip).
     uint16_t* Q = sQ + wave * QMAX;
-    float* res = sRes + threadIdx.x - lane; // this wave's [3 colours][PENDK][64 pixels] slots, 256 floats apart
+    float* res = sRes + tid - lane; // this wave's [3 colours][PENDK][64 pixels] slots, 256 floats apart
     for (;;) {
         uint32_t cnt = 0u;      // queued pairs (wave-uniform)
         uint32_t pc = 0u;       // this pixel's queued pairs
@@ -582,6 +618,16 @@ __device__ __forceinline__ void k2_shade_body(const ShadeArgs& A, const CsmArgs&
         if (!overflow) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    if (BAND && splitRole) { // the four partial sums of each pixel: wave 0 + 1 + 2 + 3
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        res[lane] = accX; res[PENDK * 256 + lane] = accY; res[2 * PENDK * 256 + lane] = accZ;
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 1; w < 4; w++) {
+            accX += sRes[w * 64 + lane]; accY += sRes[PENDK * 256 + w * 64 + lane]; accZ += sRes[2 * PENDK * 256 + w * 64 + lane];
+        }
+    }
     if (HAS_IBL) {
         float ambX, ambY, ambZ;
         // outColor.xyz = AmbientLighting(material, F0, Lr, normal, cosLo) (Standard.shader:425, :343-372); Lr = 2 cosLo n + viewDirection (:396)
@@ -629,28 +675,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k2_shade(ShadeArgs A, CsmArgs C, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
               const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
 {
-    k2_shade_body<false, false>(A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance);
+    __shared__ ShadeLds lds;
+    k2_shade_body<false, false>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k2_shade_band(ShadeArgs A, CsmArgs C, int bandTiles, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
+                   const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
+{
+    __shared__ ShadeLds lds;
+    if (blockIdx.x >= (unsigned)SPLIT_BLOCKS) {
+        const int t = (int)blockIdx.x - SPLIT_BLOCKS, ty = t / A.Tx;
+        k2_shade_body<false, false, ROLE_BAND_TILE>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, t - ty * A.Tx, ty, 0);
+        return;
+    }
+    const uint32_t limit = 4u * A.order[bandTiles];
+    for (uint32_t idx = blockIdx.x; idx < limit; idx += (uint32_t)SPLIT_BLOCKS) {
+        const uint32_t o = A.order[idx >> 2];
+        k2_shade_body<false, false, ROLE_BAND_SPLIT>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, (int)(o & 0xFFFFu), (int)(o >> 16),
+                                                     (int)(idx & 3u));
+        __syncthreads(); // the LDS arrays are reused by the block's next tile
+    }
 }
 
 __global__ __launch_bounds__(256)
 void k2_shade_csm(ShadeArgs A, CsmArgs C, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
                   const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
 {
-    k2_shade_body<true, false>(A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance);
+    __shared__ ShadeLds lds;
+    k2_shade_body<true, false>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance);
 }
 
 __global__ __launch_bounds__(256)
 void k2_shade_ibl(ShadeArgs A, CsmArgs C, IblArgs I, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
                   const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
 {
-    k2_shade_body<false, true>(A, C, I, surface, planeStride, lights, grid, culled, radiance);
+    __shared__ ShadeLds lds;
+    k2_shade_body<false, true>(lds, A, C, I, surface, planeStride, lights, grid, culled, radiance);
 }
 
 __global__ __launch_bounds__(256)
 void k2_shade_csm_ibl(ShadeArgs A, CsmArgs C, IblArgs I, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
                       const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
 {
-    k2_shade_body<true, true>(A, C, I, surface, planeStride, lights, grid, culled, radiance);
+    __shared__ ShadeLds lds;
+    k2_shade_body<true, true>(lds, A, C, I, surface, planeStride, lights, grid, culled, radiance);
 }
 
 // ---- ComputeBrdfLut.shader:26-71 (Lighting.glsl:27-37 SampleGGX, :65-70 GeometrySchlickGGX_IBL, Math.glsl:285-293) ----
@@ -763,6 +832,9 @@ extern "C" int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFrameDa
     if (hasCsm)
         hipLaunchKernelGGL(k2_shade_csm, grid, dim3(256), 0, ctx->stream, A, C, (const float4*)dSurface, surfacePlaneStride,
                            dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
+    else if (dTileOrder && band->tileRowEnd - band->tileRowBegin < Ty) // a band of a split frame: long tiles are split across four blocks
+        hipLaunchKernelGGL(k2_shade_band, dim3((unsigned)SPLIT_BLOCKS + (unsigned)bandTiles), dim3(256), 0, ctx->stream, A, C, bandTiles,
+                           (const float4*)dSurface, surfacePlaneStride, dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
     else
         hipLaunchKernelGGL(k2_shade, grid, dim3(256), 0, ctx->stream, A, C, (const float4*)dSurface, surfacePlaneStride,
                            dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);

@@ -152,9 +152,11 @@ def test_linearity_in_light_intensity_at_4k(ctx):
     assert_radiance_close(a[r0:r1], ref[r0:r1])
 
 
-def test_tile_order_hint_is_a_permutation_and_changes_nothing(ctx):
+def test_tile_order_hint_is_a_permutation_and_long_tiles_are_split(ctx):
     """sailor_hip_light_cull_tile_order (split frames only): every tile of the band exactly once, long lists first (>= 96, then >= 40, then
-    the rest, raster order inside a class); shading with the hint gives the same bits as shading without -- it is scheduling only."""
+    the rest, raster order inside a class), followed by the number of tiles in the first two classes.  Shading a band with the hint hands
+    those tiles to the split blocks (four waves share one quadrant's list): tiles below 40 lights keep their bits, the split ones differ from
+    the one-block form by the order of four partial sums only -- both within the radiance tolerance of the oracle."""
     import ctypes as C
     f = synth.make_frame("tiny")
     W, H, N = f.cam.width, f.cam.height, len(f.lights)
@@ -168,21 +170,66 @@ def test_tile_order_hint_is_a_permutation_and_changes_nothing(ctx):
     fp.cull(f.cam.frame, lights, N, torch.from_numpy(np.ascontiguousarray(f.depth[rows])).to(ctx.device))
     g, _ = fp.lists_to_host()
     T = fp.band_tiles
-    order = np.empty(T, np.uint32)
+    order = np.empty(T + 1, np.uint32)
     lib = _lib.load()
-    _lib.check(lib.sailor_hip_buffer_download(ctx.handle, order.ctypes.data, C.c_void_p(fp.tile_order), 0, T * 4), "download", ctx.handle)
-    tiles = (order >> 16).astype(np.int64) * fp.Tx + (order & 0xFFFF)
+    _lib.check(lib.sailor_hip_buffer_download(ctx.handle, order.ctypes.data, C.c_void_p(fp.tile_order), 0, (T + 1) * 4), "download", ctx.handle)
+    tiles = (order[:T] >> 16).astype(np.int64) * fp.Tx + (order[:T] & 0xFFFF)
     assert sorted(tiles.tolist()) == list(range(T))
     num = g[:, 1].astype(np.int64)
     cls = np.where(num >= 96, 0, np.where(num >= 40, 1, 2))
     assert (cls == 0).any() and (cls == 2).any()
     expect = np.concatenate([np.nonzero(cls == c)[0] for c in (0, 1, 2)])
     np.testing.assert_array_equal(tiles, expect)
+    assert order[T] == (cls < 2).sum()
     s = torch.from_numpy(np.ascontiguousarray(f.surface[:, rows])).to(ctx.device)
-    with_hint = fp.shade(f.cam.frame, s, lights, N).clone()
+    with_hint = fp.shade(f.cam.frame, s, lights, N).cpu().numpy()
     fp.use_tile_order = False
-    without = fp.shade(f.cam.frame, s, lights, N)
-    assert torch.equal(with_hint, without)
+    without = fp.shade(f.cam.frame, s, lights, N).cpu().numpy()
+    ref = oracle_frame(f)[rows]
+    assert_radiance_close(with_hint, ref)
+    assert_radiance_close(without, ref)
+    # per tile: identical bits unless the tile went to the split blocks
+    Hb = band.fbRowCount
+    for t in range(T):
+        ty, tx = divmod(t, fp.Tx)
+        gy0 = (band.tileRowBegin + ty) * 16   # shader rows count from the bottom of the frame
+        r1, r0 = H - gy0 - band.fbRowBegin, max(H - gy0 - 16, band.fbRowBegin) - band.fbRowBegin
+        a, b = with_hint[r0:r1, tx * 16:tx * 16 + 16], without[r0:r1, tx * 16:tx * 16 + 16]
+        if num[t] < 40:
+            np.testing.assert_array_equal(a, b)
+    assert np.abs(with_hint - without).max() > 0, "the long tiles took the split path"
+
+
+def test_split_tiles_on_a_band_of_the_4k_frame(ctx):
+    """configs[2], band 3 of 8 (it crosses a light cluster: hundreds of tiles with 40..128 lights go to the split blocks): the split form and
+    the one-block-per-tile form agree to twice the oracle tolerance everywhere, bit for bit on the short tiles, and an oracle-checked strip
+    of the band is within tolerance."""
+    f = synth.make_frame("C3")
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    band = host.band_for_rank(W, H, 3, 8)
+    fp = ForwardPlus(ctx, W, H, N, band=band)
+    rows = slice(band.fbRowBegin, band.fbRowBegin + band.fbRowCount)
+    lights = upload_lights(f.lights, ctx.device)
+    fp.cull(f.cam.frame, lights, N, torch.from_numpy(np.ascontiguousarray(f.depth[rows])).to(ctx.device))
+    g, idx = fp.lists_to_host()
+    s = torch.from_numpy(np.ascontiguousarray(f.surface[:, rows])).to(ctx.device)
+    split = fp.shade(f.cam.frame, s, lights, N).cpu().numpy()
+    fp.use_tile_order = False
+    plain = fp.shade(f.cam.frame, s, lights, N).cpu().numpy()
+    num = g[:, 1].reshape(-1, fp.Tx)
+    assert (num >= 40).sum() > 100 and (num == 128).any()
+    err = np.abs(split.astype(np.float64) - plain)
+    assert (err <= 2 * RTOL * np.abs(plain) + 2 * ATOL).all()
+    long_px = np.repeat(np.repeat(num[::-1] >= 40, 16, 0), 16, 1)[-band.fbRowCount:, :W]  # tile row 0 of the band = its bottom rows
+    assert (split[~long_px] == plain[~long_px]).all() and err[long_px].max() > 0
+    # the oracle on the band's first tile row (16 framebuffer rows)
+    tr0 = band.tileRowBegin
+    og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(tr0, tr0 + 1))
+    grid = np.zeros((240 * 135, 2), np.uint32); grid[:, 0] = 1
+    grid[tr0 * 240:(tr0 + 1) * 240] = og
+    r0, r1 = H - 16 * (tr0 + 1), H - 16 * tr0
+    ref = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, grid, oi, None, rows=(r0, r1))
+    assert_radiance_close(split[r0 - band.fbRowBegin:r1 - band.fbRowBegin], ref[r0:r1])
 
 
 def test_every_light_reaches_every_pixel(ctx):
