@@ -29,6 +29,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
+from ctypes import c_float as C_float
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -197,6 +198,34 @@ def mesh_cull_block(ctx, count: int, num_batches: int, steps: int):
     return {"instances": count, "batches": num_batches, "kept": kept, "moved_records": moved, "gpu_ms": med,
             "gpu_minstances_per_s": count / med / 1e3, "algorithmic_bytes": algo, "gpu_hbm_gbs": algo / med / 1e6,
             "gpu_hbm_frac": algo / med / 1e6 / HBM_PEAK_GBS, "cpu_1thread_minstances_per_s": count / t1 / 1e6, "kind": "port"}
+
+
+def ibl_prefilter_block(ctx, steps: int):
+    """SURVEY.md 8f rank 2, the one-off half: EnvironmentNode's cubemap pre-filters at the reference's sizes (EnvironmentNode.h:16-20:
+    512 x 512 x 6 environment cube with 10 mips, 32 x 32 x 6 irradiance cube).  Sample counts are the shaders' constants: 1 024 GGX samples per
+    env texel (8 texel gathers each), 65 536 hemisphere samples per irradiance texel (4 gathers each).  CPU: the oracle on a bounded
+    sample (one mip level / a 2 x 2 x 6 irradiance cube), scaled per sample."""
+    from oracle import oracle
+    from sailor_amd.forward_plus import compute_irradiance_map, prefilter_env_map
+    ibl = synth.make_ibl_set(16, 16, np.zeros((2, 2, 2), np.float32), env_size=512, with_ao=False)
+    raw = torch.from_numpy(ibl.env_chain).to(ctx.device)
+    env = prefilter_env_map(ctx, raw, 512, ibl.env_levels)
+    _, pre_ms, _, _ = event_ms(lambda: prefilter_env_map(ctx, raw, 512, ibl.env_levels), steps)
+    _, irr_ms, _, _ = event_ms(lambda: compute_irradiance_map(ctx, env, 512, ibl.env_levels, 32), steps)
+    env_samples = sum(6 * max(512 >> l, 1) ** 2 for l in range(1, ibl.env_levels)) * 1024
+    irr_samples = 6 * 32 * 32 * 65536
+    small = synth.make_ibl_set(16, 16, np.zeros((2, 2, 2), np.float32), env_size=64, with_ao=False)
+    t0 = time.perf_counter()
+    out = np.zeros_like(small.env_chain)
+    oracle.lib().oracle_prefilter_env_level(oracle._p(small.env_chain), 64, small.env_levels, oracle._p(out), 1, C_float(1.0 / (small.env_levels - 1)))
+    t_env = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle.compute_irradiance_map(small.env_chain, 64, small.env_levels, 2)
+    t_irr = time.perf_counter() - t0
+    return {"env_prefilter_ms": pre_ms, "env_gsamples_per_s": env_samples / pre_ms / 1e6, "irradiance_ms": irr_ms,
+            "irradiance_gsamples_per_s": irr_samples / irr_ms / 1e6, "env_samples": env_samples, "irradiance_samples": irr_samples,
+            "cpu_1thread_env_msamples_per_s": 6 * 32 * 32 * 1024 / t_env / 1e6, "cpu_1thread_irradiance_msamples_per_s": 6 * 2 * 2 * 65536 / t_irr / 1e6,
+            "kind": "port"}
 
 
 def linearize_block(ctx, frame, fp, d_lights, steps: int):
@@ -527,6 +556,7 @@ def main():
             if csm is None:
                 out["ambient_ibl"] = ambient_block(ctx, frame, fp, d_lights, d_surface, 30)
             out["evsm_blur"] = blur_block(ctx, 10)
+            out["ibl_prefilter"] = ibl_prefilter_block(ctx, 3)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -202,6 +202,8 @@ SAILOR_HIP_API int sailor_hip_buffer_free(SailorHipContext* ctx, void* devicePtr
 SAILOR_HIP_API int sailor_hip_buffer_upload(SailorHipContext* ctx, void* dstDevice, size_t dstOffset, const void* src, size_t bytes);
 /* synchronous device->host copy (waits for the stream) */
 SAILOR_HIP_API int sailor_hip_buffer_download(SailorHipContext* ctx, void* dstHost, const void* srcDevice, size_t srcOffset, size_t bytes);
+/* device-to-device copy on the context's stream (the BlitImage of equally sized images, e.g. EnvironmentNode.cpp:200-203) */
+SAILOR_HIP_API int sailor_hip_buffer_copy(SailorHipContext* ctx, void* dstDevice, size_t dstOffset, const void* srcDevice, size_t srcOffset, size_t bytes);
 SAILOR_HIP_API int sailor_hip_buffer_fill_u32(SailorHipContext* ctx, void* dstDevice, size_t dstOffset, uint32_t value, size_t count);
 
 /* ---- bands ---------------------------------------------------------------------------------------------- */
@@ -307,6 +309,23 @@ SAILOR_HIP_API int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFra
 /* The split-sum BRDF look-up table sampled by AmbientLighting: Content/Shaders/ComputeBrdfLut.shader:26-71 (1 024 Hammersley /
  * GGX samples per texel), dispatched once at start-up.  dLut: device, height x width float2 (the reference image is RG16F). */
 SAILOR_HIP_API int sailor_hip_compute_brdf_lut(SailorHipContext* ctx, float* dLut, int32_t width, int32_t height);
+
+/* Replaces: Content/Shaders/ComputeIrradianceMap.shader:78-101 for the Dispatch at FrameGraph/EnvironmentNode.cpp:264-269
+ * (IrradianceMapSize / 32 groups squared x 6): 65 536 uniform hemisphere samples per texel of the environment cube at lod 0.
+ *   dEnv        : device in, RGBA32F cube mip chain ("envMap"): level-major, then face (+X -X +Y -Y +Z -Z), then rows of texels
+ *   dIrradiance : device out, 6 x size x size RGBA32F ("irradianceMap"; the reference image is RGBA16F), alpha = 1 */
+SAILOR_HIP_API int sailor_hip_compute_irradiance_map(SailorHipContext* ctx, const float* dEnv, int32_t envSize, int32_t envLevels,
+                                                     float* dIrradiance, int32_t size);
+
+/* Replaces: the "pre-filter the mip chain" section of FrameGraph/EnvironmentNode.cpp:196-233 -- level 0 copied from the raw cube (:200-203),
+ * level l = 1 .. levels-1 by Content/Shaders/ComputeEnvMap_IBL.shader:76-136 with push constants { level - 1, roughness = l / (levels - 1) }:
+ * 1 024 GGX importance samples per texel, mip-filtered lookups into all levels of the raw cube.
+ *   dRawEnv : device in, RGBA32F cube mip chain ("rawEnvMap", size x size x 6, `levels` levels, layout as above)
+ *   dEnv    : device out, the same layout ("envMap[]"); must not alias dRawEnv */
+SAILOR_HIP_API int sailor_hip_prefilter_env_map(SailorHipContext* ctx, const float* dRawEnv, float* dEnv, int32_t size, int32_t levels);
+/* One Dispatch of that loop (EnvironmentNode.cpp:223-231): output mip `level` (the shader's push constant is level - 1) at `roughness`. */
+SAILOR_HIP_API int sailor_hip_prefilter_env_level(SailorHipContext* ctx, const float* dRawEnv, float* dEnv, int32_t size, int32_t levels,
+                                                  int32_t level, float roughness);
 
 /* ---- EVSM shadow-map blur ---------------------------------------------------------------
  * Replaces: the two full-screen draws "Blur Horizontal" / "Blur Vertical" of ShadowPrepassNode::Process

@@ -108,6 +108,38 @@ def make_ibl(irradiance: np.ndarray, env_chain: np.ndarray, env_size: int, env_l
     return d, keep
 
 
+def cube_level_offsets(size0: int, levels: int):
+    """float offsets of the mip levels of a cube in the level-major / face / row / texel RGBA32F layout (+ the total)"""
+    offs, o = [], 0
+    for l in range(levels):
+        offs.append(o)
+        sz = max(size0 >> l, 1)
+        o += 6 * sz * sz * 4
+    return offs, o
+
+
+def compute_irradiance_map(env: np.ndarray, env_size: int, env_levels: int, size: int) -> np.ndarray:
+    """ComputeIrradianceMap.shader: [6, size, size, 4] float32 from the cube `env` (flat RGBA32F mip chain)"""
+    env = np.ascontiguousarray(env, np.float32).reshape(-1)
+    assert env.size == cube_level_offsets(env_size, env_levels)[1]
+    out = np.zeros((6, size, size, 4), np.float32)
+    lib().oracle_compute_irradiance_map(_p(env), C.c_int(env_size), C.c_int(env_levels), _p(out), C.c_int(size))
+    return out
+
+
+def prefilter_env_map(raw: np.ndarray, size0: int, levels: int) -> np.ndarray:
+    """EnvironmentNode.cpp:196-233: level 0 copied, level l = ComputeEnvMap_IBL.shader at roughness l / (levels - 1)"""
+    raw = np.ascontiguousarray(raw, np.float32).reshape(-1)
+    offs, total = cube_level_offsets(size0, levels)
+    assert raw.size == total
+    out = np.zeros(total, np.float32)
+    out[:offs[1] if levels > 1 else total] = raw[:offs[1] if levels > 1 else total]
+    delta = np.float32(1.0) / np.float32(max(levels - 1, 1))
+    for level in range(1, levels):
+        lib().oracle_prefilter_env_level(_p(raw), C.c_int(size0), C.c_int(levels), _p(out), C.c_int(level), C.c_float(np.float32(level) * delta))
+    return out
+
+
 def compute_brdf_lut(w: int, h: int) -> np.ndarray:
     """ComputeBrdfLut.shader:26-71 -> float32[h, w, 2] (DFG1, DFG2)"""
     out = np.zeros((h, w, 2), np.float32)

@@ -898,18 +898,136 @@ static void ambient_lighting(const OracleIbl* ibl, const float* albedo, float me
     }
 }
 
-/* ComputeBrdfLut.shader:26-71 (Lighting.glsl:27-37 SampleGGX, :65-70 GeometrySchlickGGX_IBL, Math.glsl:285-293).
- * outRG = w*h float2; pow(x, 5) as x^2 * x^2 * x (x in [0, 1]); the reference stores RG16F. */
-static float radical_inverse_vdc(uint32_t bits)
+
+/* ---- the cubemap pre-filters of the ambient term (one-off work of FrameGraph/EnvironmentNode.cpp:196-273) ------------------
+ * Content/Shaders/ComputeIrradianceMap.shader and ComputeEnvMap_IBL.shader share these helpers (:22-77 / :31-73).  Cube layout as
+ * everywhere here: level-major, then face, then size x size RGBA32F texels; textureLod = the canonical sampler above. */
+static float radical_inverse_vdc(uint32_t bits) /* Math.glsl:285-293 */
 {
-    bits = (bits << 16u) | (bits >> 16u);
-    bits = ((bits & 0x55555555u) << 1u) | ((bits & 0xAAAAAAAAu) >> 1u);
-    bits = ((bits & 0x33333333u) << 2u) | ((bits & 0xCCCCCCCCu) >> 2u);
-    bits = ((bits & 0x0F0F0F0Fu) << 4u) | ((bits & 0xF0F0F0F0u) >> 4u);
-    bits = ((bits & 0x00FF00FFu) << 8u) | ((bits & 0xFF00FF00u) >> 8u);
+    bits = (bits << 16) | (bits >> 16);
+    bits = ((bits & 0x55555555u) << 1) | ((bits & 0xAAAAAAAAu) >> 1);
+    bits = ((bits & 0x33333333u) << 2) | ((bits & 0xCCCCCCCCu) >> 2);
+    bits = ((bits & 0x0F0F0F0Fu) << 4) | ((bits & 0xF0F0F0F0u) >> 4);
+    bits = ((bits & 0x00FF00FFu) << 8) | ((bits & 0xFF00FF00u) >> 8);
     return (float)bits * 2.3283064365386963e-10f;
 }
 
+static void prefilter_normalize(float* v)
+{
+    const float inv = 1.0f / sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    v[0] *= inv; v[1] *= inv; v[2] *= inv;
+}
+
+/* GetSamplingVector (ComputeIrradianceMap.shader:43-58): the direction of texel (x, y) of face z, from its CORNER (no + 0.5) */
+static void prefilter_sampling_vector(int x, int y, int face, int size, float* N)
+{
+    const float stx = (float)x / (float)size, sty = (float)y / (float)size;
+    const float ux = 2.0f * stx - 1.0f, uy = 2.0f * (1.0f - sty) - 1.0f;
+    switch (face) {
+    case 0: N[0] = 1.0f; N[1] = uy; N[2] = -ux; break;
+    case 1: N[0] = -1.0f; N[1] = uy; N[2] = ux; break;
+    case 2: N[0] = ux; N[1] = 1.0f; N[2] = -uy; break;
+    case 3: N[0] = ux; N[1] = -1.0f; N[2] = uy; break;
+    case 4: N[0] = ux; N[1] = uy; N[2] = 1.0f; break;
+    default: N[0] = -ux; N[1] = uy; N[2] = -1.0f; break;
+    }
+    prefilter_normalize(N);
+}
+
+/* ComputeBasisVectors (:61-69): T = cross(N, +Y), or cross(N, +X) when that is degenerate; S = normalize(cross(N, T)) */
+static void prefilter_basis(const float* N, float* S, float* T)
+{
+    T[0] = N[1] * 0.0f - N[2] * 1.0f; T[1] = N[2] * 0.0f - N[0] * 0.0f; T[2] = N[0] * 1.0f - N[1] * 0.0f;
+    if ((T[0] * T[0] + T[1] * T[1]) + T[2] * T[2] < 0.00001f) { /* step(Epsilon, dot(T, T)) == 0 */
+        T[0] = N[1] * 0.0f - N[2] * 0.0f; T[1] = N[2] * 1.0f - N[0] * 0.0f; T[2] = N[0] * 0.0f - N[1] * 1.0f;
+    }
+    prefilter_normalize(T);
+    S[0] = N[1] * T[2] - N[2] * T[1]; S[1] = N[2] * T[0] - N[0] * T[2]; S[2] = N[0] * T[1] - N[1] * T[0];
+    prefilter_normalize(S);
+}
+
+static void tangent_to_world(const float* v, const float* N, const float* S, const float* T, float* out) /* (:72-75) */
+{
+    for (int c = 0; c < 3; c++) out[c] = (S[c] * v[0] + T[c] * v[1]) + N[c] * v[2];
+}
+
+/* ComputeIrradianceMap.shader:78-101: 65 536 uniformly distributed hemisphere samples per texel, summed in sample order.
+ * env: the (pre-filtered) environment cube, sampled at lod 0; out: 6 x size x size RGBA32F. */
+ORACLE_API void oracle_compute_irradiance_map(const float* env, int envSize, int envLevels, float* out, int size)
+{
+    const uint32_t NumSamples = 64u * 1024u;
+    const float InvNumSamples = 1.0f / (float)NumSamples, TwoPI = 6.283185307179586f;
+    for (int face = 0; face < 6; face++)
+        for (int y = 0; y < size; y++)
+            for (int x = 0; x < size; x++) {
+                float N[3], S[3], T[3], irr[3] = { 0.0f, 0.0f, 0.0f };
+                prefilter_sampling_vector(x, y, face, size, N);
+                prefilter_basis(N, S, T);
+                for (uint32_t i = 0; i < NumSamples; i++) {
+                    const float u1 = (float)i * InvNumSamples, u2 = radical_inverse_vdc(i);
+                    const float u1p = sqrtf(fmaxf(0.0f, 1.0f - u1 * u1));
+                    const float h[3] = { cosf(TwoPI * u2) * u1p, sinf(TwoPI * u2) * u1p, u1 }; /* SampleHemisphere (:32-36) */
+                    float Li[3], texel[4];
+                    tangent_to_world(h, N, S, T, Li);
+                    const float cosTheta = fmaxf(0.0f, (Li[0] * N[0] + Li[1] * N[1]) + Li[2] * N[2]);
+                    cube_sample_lod(env, envSize, envLevels, Li, 0.0f, texel);
+                    for (int c = 0; c < 3; c++) irr[c] += (2.0f * texel[c]) * cosTheta;
+                }
+                float* o = out + (((size_t)face * size + y) * size + x) * 4;
+                for (int c = 0; c < 3; c++) o[c] = irr[c] / (float)NumSamples;
+                o[3] = 1.0f;
+            }
+}
+
+/* ComputeEnvMap_IBL.shader:76-136 for one output mip `level` (>= 1) of the pre-filtered cube: 1 024 GGX importance samples per
+ * texel with mip-filtered lookups into the raw cube (all its levels).  EnvironmentNode.cpp:219-233 runs it for level 1..L-1 with
+ * roughness = level / (L - 1); level 0 is a copy of the raw level 0 (:200-203).  out = the same mip-chain layout as raw. */
+ORACLE_API void oracle_prefilter_env_level(const float* raw, int size0, int levels, float* out, int level, float roughness)
+{
+    const uint32_t NumSamples = 1024u;
+    const float InvNumSamples = 1.0f / (float)NumSamples, TwoPI = 6.283185307179586f, PI = 3.14159265359f;
+    size_t off = 0;
+    for (int l = 0; l < level; l++) { const int sz = (size0 >> l) > 1 ? (size0 >> l) : 1; off += (size_t)6 * sz * sz * 4; }
+    const int size = (size0 >> level) > 1 ? (size0 >> level) : 1;
+    const float wt = 4.0f * PI / (6.0f * (float)size0 * (float)size0);
+    const float alpha = roughness * roughness, alphaSq = alpha * alpha;
+    for (int face = 0; face < 6; face++)
+        for (int y = 0; y < size; y++)
+            for (int x = 0; x < size; x++) {
+                float N[3], S[3], T[3], color[3] = { 0.0f, 0.0f, 0.0f }, weight = 0.0f;
+                prefilter_sampling_vector(x, y, face, size, N);
+                prefilter_basis(N, S, T);
+                for (uint32_t i = 0; i < NumSamples; i++) {
+                    const float u1 = (float)i * InvNumSamples, u2 = radical_inverse_vdc(i);
+                    /* SampleGGX (Lighting.glsl:27-37) */
+                    const float cosT = sqrtf((1.0f - u2) / (1.0f + (alpha * alpha - 1.0f) * u2));
+                    const float sinT = sqrtf(1.0f - cosT * cosT), phi = TwoPI * u1;
+                    const float h[3] = { sinT * cosf(phi), sinT * sinf(phi), cosT };
+                    float Lh[3], Li[3];
+                    tangent_to_world(h, N, S, T, Lh);
+                    const float d = (N[0] * Lh[0] + N[1] * Lh[1]) + N[2] * Lh[2]; /* Lo = N */
+                    for (int c = 0; c < 3; c++) Li[c] = (2.0f * d) * Lh[c] - N[c];
+                    const float cosLi = (N[0] * Li[0] + N[1] * Li[1]) + N[2] * Li[2];
+                    if (cosLi > 0.0f) {
+                        const float cosLh = fmaxf(d, 0.0f);
+                        const float denom = (cosLh * cosLh) * (alphaSq - 1.0f) + 1.0f;
+                        const float pdf = (alphaSq / (PI * denom * denom)) * 0.25f;  /* NdfGGX * 0.25 */
+                        const float ws = 1.0f / ((float)NumSamples * pdf);
+                        const float mip = fmaxf(0.5f * log2f(ws / wt) + 1.0f, 0.0f);
+                        float texel[4];
+                        cube_sample_lod(raw, size0, levels, Li, mip, texel);
+                        for (int c = 0; c < 3; c++) color[c] += texel[c] * cosLi;
+                        weight += cosLi;
+                    }
+                }
+                float* o = out + off + (((size_t)face * size + y) * size + x) * 4;
+                for (int c = 0; c < 3; c++) o[c] = color[c] / weight;
+                o[3] = 1.0f;
+            }
+}
+
+/* ComputeBrdfLut.shader:26-71 (Lighting.glsl:27-37 SampleGGX, :65-70 GeometrySchlickGGX_IBL, Math.glsl:285-293).
+ * outRG = w*h float2; pow(x, 5) as x^2 * x^2 * x (x in [0, 1]); the reference stores RG16F. */
 ORACLE_API void oracle_compute_brdf_lut(int w, int h, float* outRG)
 {
     const float TwoPI = 6.283185307179586f;

@@ -108,6 +108,10 @@ SIGNATURES = {
     "sailor_hip_evsm_blur": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sailor_hip_evsm_blur_pass": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sailor_hip_compute_brdf_lut": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    "sailor_hip_compute_irradiance_map": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32]),
+    "sailor_hip_prefilter_env_map": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
+    "sailor_hip_prefilter_env_level": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float]),
+    "sailor_hip_buffer_copy": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t]),
     "sailor_hip_ecs_sweep": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_uint32), C.c_uint32, _P, C.POINTER(C.c_float), _P, _P, _P]),
     "sailor_hip_mesh_frustum_cull": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_uint32, C.c_uint32]),
     "sailor_hip_mesh_cull_workspace_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),

@@ -124,6 +124,14 @@ __global__ void k_fill_u32(uint32_t* dst, uint32_t value, size_t count)
     for (; i < count; i += stride) dst[i] = value;
 }
 
+int sailor_hip_buffer_copy(SailorHipContext* ctx, void* dstDevice, size_t dstOffset, const void* srcDevice, size_t srcOffset, size_t bytes)
+{
+    if (!ctx || (bytes && (!dstDevice || !srcDevice))) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (bytes == 0) return SAILOR_HIP_OK;
+    SAILOR_TRY_HIP(ctx, hipMemcpyAsync((char*)dstDevice + dstOffset, (const char*)srcDevice + srcOffset, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return SAILOR_HIP_OK;
+}
+
 int sailor_hip_buffer_fill_u32(SailorHipContext* ctx, void* dstDevice, size_t dstOffset, uint32_t value, size_t count)
 {
     if (!ctx || !dstDevice || (dstOffset & 3)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;

@@ -1,0 +1,186 @@
+// The two cubemap pre-filters behind the ambient term (FrameGraph/EnvironmentNode.cpp:196-273), for gfx950:
+//   ComputeIrradianceMap.shader  65 536 uniform hemisphere samples per texel of the 32 x 32 x 6 irradiance cube,
+//   ComputeEnvMap_IBL.shader     1 024 GGX importance samples per texel of every mip of the 512 x 512 x 6 environment cube,
+//                                with mip-filtered lookups into the raw cube.
+// The shaders run one invocation per output texel (32 x 32 groups) and loop over the samples.  The irradiance cube has only
+// 6 144 texels -- 96 wavefronts for 400 M samples -- so here the SAMPLES are spread over lanes: one 256-thread block per
+// irradiance texel (lane j takes samples j, j + 256, ... in order), one wavefront per environment texel (16 samples per lane),
+// and the partial sums are added up in a fixed tree.  The sums therefore differ from the shader's sequential order in the last
+// bits (the oracle follows the shader); everything else -- Hammersley points, basis vectors, GGX sampling, pdf -> mip level,
+// the canonical cube sampler -- is the oracle's arithmetic.  Tolerance-checked like the rest of the shading path.
+#include "common.h"
+#include "sampling.h"
+
+#define PF_TWO_PI 6.283185307179586f
+#define PF_PI 3.14159265359f
+
+__device__ __forceinline__ float pf_radical_inverse(uint32_t i) { return (float)__brev(i) * 2.3283064365386963e-10f; } // Math.glsl:285-293
+
+__device__ __forceinline__ void pf_normalize(float& x, float& y, float& z)
+{
+    const float inv = 1.0f / sqrtf((x * x + y * y) + z * z);
+    x *= inv; y *= inv; z *= inv;
+}
+
+struct PfFrame { float Nx, Ny, Nz, Sx, Sy, Sz, Tx, Ty, Tz; };
+
+// GetSamplingVector + ComputeBasisVectors (ComputeIrradianceMap.shader:43-69): texel (x, y) of `face`, from the texel's corner
+__device__ __forceinline__ PfFrame pf_frame(int x, int y, int face, int size)
+{
+    const float stx = (float)x / (float)size, sty = (float)y / (float)size;
+    const float ux = 2.0f * stx - 1.0f, uy = 2.0f * (1.0f - sty) - 1.0f;
+    PfFrame f;
+    switch (face) {
+    case 0: f.Nx = 1.0f; f.Ny = uy; f.Nz = -ux; break;
+    case 1: f.Nx = -1.0f; f.Ny = uy; f.Nz = ux; break;
+    case 2: f.Nx = ux; f.Ny = 1.0f; f.Nz = -uy; break;
+    case 3: f.Nx = ux; f.Ny = -1.0f; f.Nz = uy; break;
+    case 4: f.Nx = ux; f.Ny = uy; f.Nz = 1.0f; break;
+    default: f.Nx = -ux; f.Ny = uy; f.Nz = -1.0f; break;
+    }
+    pf_normalize(f.Nx, f.Ny, f.Nz);
+    f.Tx = f.Ny * 0.0f - f.Nz * 1.0f; f.Ty = f.Nz * 0.0f - f.Nx * 0.0f; f.Tz = f.Nx * 1.0f - f.Ny * 0.0f; // cross(N, +Y)
+    if ((f.Tx * f.Tx + f.Ty * f.Ty) + f.Tz * f.Tz < 0.00001f) {                                             // degenerate: cross(N, +X)
+        f.Tx = f.Ny * 0.0f - f.Nz * 0.0f; f.Ty = f.Nz * 1.0f - f.Nx * 0.0f; f.Tz = f.Nx * 0.0f - f.Ny * 1.0f;
+    }
+    pf_normalize(f.Tx, f.Ty, f.Tz);
+    f.Sx = f.Ny * f.Tz - f.Nz * f.Ty; f.Sy = f.Nz * f.Tx - f.Nx * f.Tz; f.Sz = f.Nx * f.Ty - f.Ny * f.Tx;
+    pf_normalize(f.Sx, f.Sy, f.Sz);
+    return f;
+}
+
+__device__ __forceinline__ void pf_to_world(const PfFrame& f, float hx, float hy, float hz, float& ox, float& oy, float& oz) // (:72-75)
+{
+    ox = (f.Sx * hx + f.Tx * hy) + f.Nx * hz;
+    oy = (f.Sy * hx + f.Ty * hy) + f.Ny * hz;
+    oz = (f.Sz * hx + f.Tz * hy) + f.Nz * hz;
+}
+
+__device__ __forceinline__ float pf_wave_sum(float v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ---- ComputeIrradianceMap.shader:78-101 ----
+#define IRR_SAMPLES (64u * 1024u)
+__global__ __launch_bounds__(256) void k_irradiance_map(const float4* __restrict__ env, int envSize, int envLevels, float4* __restrict__ out, int size)
+{
+    __shared__ float sPart[3][4];
+    const int texel = blockIdx.x; // (face, y, x)
+    const int x = texel % size, y = (texel / size) % size, face = texel / (size * size);
+    const PfFrame f = pf_frame(x, y, face, size);
+    const float InvNumSamples = 1.0f / (float)IRR_SAMPLES;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    for (uint32_t i = threadIdx.x; i < IRR_SAMPLES; i += 256u) {
+        const float u1 = (float)i * InvNumSamples, u2 = pf_radical_inverse(i);
+        const float u1p = sqrtf(fmaxf(0.0f, 1.0f - u1 * u1));
+        float sn, cs;
+        sincosf(PF_TWO_PI * u2, &sn, &cs);
+        float lx, ly, lz;
+        pf_to_world(f, cs * u1p, sn * u1p, u1, lx, ly, lz); // SampleHemisphere (:32-36)
+        const float cosTheta = fmaxf(0.0f, (lx * f.Nx + ly * f.Ny) + lz * f.Nz);
+        // textureLod(envMap, Li, 0): level 0 only (the canonical sampler's second level has weight exactly 0 there)
+        int sface; float ss, st;
+        cube_face_st(lx, ly, lz, sface, ss, st);
+        const float4 t = cube_sample_level(env, envSize, 0, sface, ss, st);
+        r += (2.0f * t.x) * cosTheta; g += (2.0f * t.y) * cosTheta; b += (2.0f * t.z) * cosTheta;
+    }
+    r = pf_wave_sum(r); g = pf_wave_sum(g); b = pf_wave_sum(b);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sPart[0][wave] = r; sPart[1][wave] = g; sPart[2][wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float n = (float)IRR_SAMPLES;
+        out[texel] = make_float4((((sPart[0][0] + sPart[0][1]) + sPart[0][2]) + sPart[0][3]) / n, (((sPart[1][0] + sPart[1][1]) + sPart[1][2]) + sPart[1][3]) / n,
+                                 (((sPart[2][0] + sPart[2][1]) + sPart[2][2]) + sPart[2][3]) / n, 1.0f);
+    }
+}
+
+// ---- ComputeEnvMap_IBL.shader:76-136, one output mip level per launch ----
+#define ENV_SAMPLES 1024u
+__global__ __launch_bounds__(256) void k_prefilter_env(const float4* __restrict__ raw, int size0, int levels, float4* __restrict__ outLevel, int size, float roughness)
+{
+    const int texel = blockIdx.x * 4 + (threadIdx.x >> 6); // one wavefront per (face, y, x)
+    if (texel >= 6 * size * size) return;
+    const int lane = threadIdx.x & 63;
+    const int x = texel % size, y = (texel / size) % size, face = texel / (size * size);
+    const PfFrame f = pf_frame(x, y, face, size);
+    const float InvNumSamples = 1.0f / (float)ENV_SAMPLES;
+    const float wt = 4.0f * PF_PI / (6.0f * (float)size0 * (float)size0); // solid angle of a texel of the raw cube's level 0 (:86-87)
+    const float alpha = roughness * roughness, alphaSq = alpha * alpha;
+    float r = 0.0f, g = 0.0f, b = 0.0f, weight = 0.0f;
+    for (uint32_t i = lane; i < ENV_SAMPLES; i += 64u) {
+        const float u1 = (float)i * InvNumSamples, u2 = pf_radical_inverse(i);
+        // SampleGGX (Lighting.glsl:27-37)
+        const float cosT = sqrtf((1.0f - u2) / (1.0f + (alpha * alpha - 1.0f) * u2));
+        const float sinT = sqrtf(1.0f - cosT * cosT);
+        float sn, cs;
+        sincosf(PF_TWO_PI * u1, &sn, &cs);
+        float hx, hy, hz;
+        pf_to_world(f, sinT * cs, sinT * sn, cosT, hx, hy, hz);
+        const float d = (f.Nx * hx + f.Ny * hy) + f.Nz * hz; // dot(Lo, Lh), Lo = N (:92)
+        const float lx = (2.0f * d) * hx - f.Nx, ly = (2.0f * d) * hy - f.Ny, lz = (2.0f * d) * hz - f.Nz;
+        const float cosLi = (f.Nx * lx + f.Ny * ly) + f.Nz * lz;
+        if (cosLi > 0.0f) {
+            const float cosLh = fmaxf(d, 0.0f);
+            const float denom = (cosLh * cosLh) * (alphaSq - 1.0f) + 1.0f;
+            const float pdf = (alphaSq / (PF_PI * denom * denom)) * 0.25f; // NdfGGX * 0.25 (:121)
+            const float ws = 1.0f / ((float)ENV_SAMPLES * pdf);
+            const float mip = fmaxf(0.5f * log2f(ws / wt) + 1.0f, 0.0f);    // (:127)
+            const float4 t = cube_sample_lod(raw, size0, levels, lx, ly, lz, mip);
+            r += t.x * cosLi; g += t.y * cosLi; b += t.z * cosLi;
+            weight += cosLi;
+        }
+    }
+    r = pf_wave_sum(r); g = pf_wave_sum(g); b = pf_wave_sum(b); weight = pf_wave_sum(weight);
+    if (lane == 0) outLevel[texel] = make_float4(r / weight, g / weight, b / weight, 1.0f);
+}
+
+extern "C" {
+
+int sailor_hip_compute_irradiance_map(SailorHipContext* ctx, const float* dEnv, int32_t envSize, int32_t envLevels, float* dIrradiance, int32_t size)
+{
+    if (!ctx || !dEnv || !dIrradiance || envSize <= 0 || envLevels <= 0 || envLevels > 16 || size <= 0 || size > 4096) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (((uintptr_t)dEnv & 15) || ((uintptr_t)dIrradiance & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(k_irradiance_map, dim3(6u * (unsigned)size * (unsigned)size), dim3(256), 0, ctx->stream, (const float4*)dEnv, envSize, envLevels,
+                       (float4*)dIrradiance, size);
+    SAILOR_CHECK_LAUNCH(ctx, "k_irradiance_map");
+    return SAILOR_HIP_OK;
+}
+
+static size_t pf_level_offset(int size, int level) // float4 texels in front of `level`
+{
+    size_t off = 0;
+    for (int l = 0; l < level; l++) { const int sz = (size >> l) > 1 ? (size >> l) : 1; off += (size_t)6 * sz * sz; }
+    return off;
+}
+
+int sailor_hip_prefilter_env_level(SailorHipContext* ctx, const float* dRawEnv, float* dEnv, int32_t size, int32_t levels, int32_t level, float roughness)
+{
+    if (!ctx || !dRawEnv || !dEnv || size <= 0 || size > 8192 || levels <= 0 || levels > 16 || level < 0 || level >= levels) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (((uintptr_t)dRawEnv & 15) || ((uintptr_t)dEnv & 15) || dRawEnv == dEnv) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const int sz = (size >> level) > 1 ? (size >> level) : 1;
+    const unsigned texels = 6u * (unsigned)sz * (unsigned)sz;
+    hipLaunchKernelGGL(k_prefilter_env, dim3((texels + 3) / 4), dim3(256), 0, ctx->stream, (const float4*)dRawEnv, size, levels,
+                       (float4*)dEnv + pf_level_offset(size, level), sz, roughness);
+    SAILOR_CHECK_LAUNCH(ctx, "k_prefilter_env");
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_prefilter_env_map(SailorHipContext* ctx, const float* dRawEnv, float* dEnv, int32_t size, int32_t levels)
+{
+    if (!ctx || !dRawEnv || !dEnv || size <= 0 || size > 8192 || levels <= 0 || levels > 16) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (((uintptr_t)dRawEnv & 15) || ((uintptr_t)dEnv & 15) || dRawEnv == dEnv) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    // level 0 is copied (the BlitImage at EnvironmentNode.cpp:200-203), the mip tail is pre-filtered level by level (:219-233)
+    SAILOR_TRY_HIP(ctx, hipMemcpyAsync(dEnv, dRawEnv, (size_t)6 * size * size * 16, hipMemcpyDeviceToDevice, ctx->stream));
+    const float deltaRoughness = 1.0f / (levels - 1 > 1 ? (float)(levels - 1) : 1.0f);
+    for (int level = 1; level < levels; level++) {
+        const int rc = sailor_hip_prefilter_env_level(ctx, dRawEnv, dEnv, size, levels, level, (float)level * deltaRoughness);
+        if (rc != SAILOR_HIP_OK) return rc;
+    }
+    return SAILOR_HIP_OK;
+}
+
+} // extern "C"

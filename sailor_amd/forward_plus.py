@@ -197,6 +197,21 @@ def compute_brdf_lut(ctx: "HipContext", width: int, height: int) -> torch.Tensor
     return out
 
 
+def compute_irradiance_map(ctx: "HipContext", env_chain: torch.Tensor, env_size: int, env_levels: int, size: int) -> torch.Tensor:
+    """ComputeIrradianceMap.shader on the GPU: flat RGBA32F cube mip chain -> float32 [6, size, size, 4]"""
+    out = torch.empty((6, size, size, 4), dtype=torch.float32, device=ctx.device)
+    _lib.check(ctx._lib.sailor_hip_compute_irradiance_map(ctx.handle, _ptr(env_chain), env_size, env_levels, _ptr(out), size),
+               "sailor_hip_compute_irradiance_map", ctx.handle)
+    return out
+
+
+def prefilter_env_map(ctx: "HipContext", raw_chain: torch.Tensor, size: int, levels: int) -> torch.Tensor:
+    """EnvironmentNode's specular pre-filter (ComputeEnvMap_IBL.shader per mip) on the GPU: flat chain -> flat chain"""
+    out = torch.empty_like(raw_chain)
+    _lib.check(ctx._lib.sailor_hip_prefilter_env_map(ctx.handle, _ptr(raw_chain), _ptr(out), size, levels), "sailor_hip_prefilter_env_map", ctx.handle)
+    return out
+
+
 class EcsSweep:
     """K4 on one GPU over level-sorted entities."""
 

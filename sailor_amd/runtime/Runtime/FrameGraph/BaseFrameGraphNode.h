@@ -39,6 +39,14 @@ public:
         return true;
     }
 
+    bool TryGetFloat(const std::string& name, float& out) const
+    {
+        auto it = m_floatParams.find(name);
+        if (it == m_floatParams.end()) return false;
+        out = it->second;
+        return true;
+    }
+
     virtual void Prepare(RHIFrameGraphPtr, const RHI::RHISceneViewSnapshot&) {}
     virtual void Process(RHIFrameGraphPtr frameGraph, RHI::RHICommandListPtr transferCommandList, RHI::RHICommandListPtr commandList,
                          const RHI::RHISceneViewSnapshot& sceneView) = 0;

@@ -31,6 +31,7 @@ bool FrameGraphBuilder::IsRegistered(const std::string& nodeName) { return Regis
 template class Sailor::Framegraph::TFrameGraphNode<LightCullingNode>;
 template class Sailor::Framegraph::TFrameGraphNode<RenderSceneNode>;
 template class Sailor::Framegraph::TFrameGraphNode<LinearizeDepthNode>;
+template class Sailor::Framegraph::TFrameGraphNode<EnvironmentNode>;
 
 // ---- RHIFrameGraph ----------------------------------------------------------------------------------------------------------
 UboFrameData RHIFrameGraph::FillFrameData(RHICommandListPtr transferCmdList, RHISceneViewSnapshot& snapshot, float deltaTime, float worldTime) const
@@ -73,6 +74,97 @@ void RHIFrameGraph::Clear()
     for (auto& node : m_graph) node->Clear();
     m_graph.clear();
     m_renderTargets.clear();
+}
+
+// ---- EnvironmentNode (FrameGraph/EnvironmentNode.cpp:19-281) --------------------------------------------------------------------
+const char* EnvironmentNode::m_name = "Environment";
+
+void EnvironmentNode::Process(RHIFrameGraphPtr frameGraph, RHICommandListPtr, RHICommandListPtr commandList, const RHISceneViewSnapshot&)
+{
+    auto driver = Renderer::GetDriver();
+    auto commands = Renderer::GetDriverCommands();
+    commands->BeginDebugRegion(commandList, GetName());
+    if (!m_pComputeBrdfShader) { m_pComputeBrdfShader = driver->CreateShader("Shaders/ComputeBrdfLut.shader"); m_computeBrdfBindings = driver->CreateShaderBindings(); }                 // (:31-39)
+    if (!m_pComputeSpecularShader) { m_pComputeSpecularShader = driver->CreateShader("Shaders/ComputeEnvMap_IBL.shader"); m_computeSpecularBindings = driver->CreateShaderBindings(); } // (:41-49)
+    if (!m_pComputeIrradianceShader) { m_pComputeIrradianceShader = driver->CreateShader("Shaders/ComputeIrradianceMap.shader"); m_computeIrradianceBindings = driver->CreateShaderBindings(); } // (:51-59)
+
+    if (!m_brdfSampler) { // (:69-98)
+        m_brdfSampler = driver->CreateRenderTarget({ (int32_t)BrdfLutSize, (int32_t)BrdfLutSize }, 1, EFormat::R32G32_SFLOAT);
+        commands->ImageMemoryBarrier(commandList, m_brdfSampler, EImageLayout::ShaderReadOnlyOptimal);
+        frameGraph->SetSampler("g_brdfSampler", m_brdfSampler);
+        commands->BeginDebugRegion(commandList, "Generate Cook-Torrance BRDF 2D LUT for split-sum approximation");
+        driver->AddStorageImageToShaderBindings(m_computeBrdfBindings, "dst", m_brdfSampler, 0);
+        commands->ImageMemoryBarrier(commandList, m_brdfSampler, EImageLayout::ComputeWrite);
+        commands->Dispatch(commandList, m_pComputeBrdfShader, (uint32_t)(m_brdfSampler->GetExtent().x / 32.0f), (uint32_t)(m_brdfSampler->GetExtent().y / 32.0f), 6u,
+                           { m_computeBrdfBindings }, nullptr, 0);
+        commands->ImageMemoryBarrier(commandList, m_brdfSampler, EImageLayout::ShaderReadOnlyOptimal);
+        commands->EndDebugRegion(commandList);
+    }
+
+    if (m_bIsDirty) { // (:100-276)
+        RHICubemapPtr rawEnvCubemap = frameGraph->GetSampler("g_skyCubemap"); // (:139-142)
+        if (!rawEnvCubemap || !rawEnvCubemap->m_bCubemap) { commands->EndDebugRegion(commandList); return; } // (:143-146)
+        const int32_t EnvMapSize = rawEnvCubemap->GetExtent().x;
+        const uint32_t EnvMapLevels = rawEnvCubemap->GetMipLevels();
+        const bool bShouldUpdateEnvCubemap = !m_envCubemap, bShouldUpdateIrradianceCubemap = !m_irradianceCubemap; // (:162-163)
+        if (!bShouldUpdateEnvCubemap && !bShouldUpdateIrradianceCubemap) { // (:165-173)
+            frameGraph->SetSampler("g_envCubemap", m_envCubemap);
+            frameGraph->SetSampler("g_irradianceCubemap", m_irradianceCubemap);
+            m_bIsDirty = false;
+            commands->EndDebugRegion(commandList);
+            return;
+        }
+        if (bShouldUpdateEnvCubemap) { // (:176-236)
+            m_envCubemap = driver->CreateCubemap({ EnvMapSize, EnvMapSize }, EnvMapLevels, EFormat::R32G32B32A32_SFLOAT);
+            frameGraph->SetSampler("g_envCubemap", m_envCubemap);
+            commands->ImageMemoryBarrier(commandList, m_envCubemap, EImageLayout::General);
+            commands->BeginDebugRegion(commandList, "Compute pre-filtered specular environment map");
+            struct PushConstants { int32_t level {}; float roughness {}; };
+            const uint32_t NumMipTailLevels = EnvMapLevels - 1;
+            commands->ImageMemoryBarrier(commandList, rawEnvCubemap, EImageLayout::TransferSrcOptimal);
+            commands->ImageMemoryBarrier(commandList, m_envCubemap, EImageLayout::TransferDstOptimal);
+            commands->BlitImage(commandList, rawEnvCubemap, m_envCubemap, { 0, 0, EnvMapSize, EnvMapSize }, { 0, 0, EnvMapSize, EnvMapSize }); // (:200-203) mip 0
+            commands->ImageMemoryBarrier(commandList, rawEnvCubemap, EImageLayout::ShaderReadOnlyOptimal);
+            commands->ImageMemoryBarrier(commandList, m_envCubemap, EImageLayout::ComputeWrite);
+            TVector<RHITexturePtr> envMapMips; // the mip tail (:208-212)
+            for (uint32_t level = 1; level < EnvMapLevels; ++level) envMapMips.push_back(m_envCubemap->GetMipLevel(level));
+            driver->AddSamplerToShaderBindings(m_computeSpecularBindings, "rawEnvMap", rawEnvCubemap, 0);
+            driver->AddStorageImageToShaderBindings(m_computeSpecularBindings, "envMap", envMapMips, 1);
+            const float deltaRoughness = 1.0f / std::max(float(NumMipTailLevels), 1.0f);
+            for (uint32_t level = 1, size = (uint32_t)EnvMapSize / 2; level < EnvMapLevels; ++level, size /= 2) { // (:220-233)
+                const uint32_t numGroups = std::max<uint32_t>(1u, size / 32u);
+                const PushConstants pushConstants = { (int32_t)(level - 1u), level * deltaRoughness };
+                commands->Dispatch(commandList, m_pComputeSpecularShader, numGroups, numGroups, 6u, { m_computeSpecularBindings }, &pushConstants, sizeof(PushConstants));
+            }
+            commands->EndDebugRegion(commandList);
+        }
+        if (bShouldUpdateIrradianceCubemap) { // (:238-273)
+            int32_t irradianceSize = (int32_t)IrradianceMapSize;
+            float overrideSize = 0.0f;
+            if (TryGetFloat("IrradianceMapSize", overrideSize) && overrideSize >= 1.0f) irradianceSize = (int32_t)overrideSize; // test knob (65 536 samples per texel)
+            m_irradianceCubemap = driver->CreateCubemap({ irradianceSize, irradianceSize }, 1, EFormat::R32G32B32A32_SFLOAT);
+            commands->ImageMemoryBarrier(commandList, m_irradianceCubemap, EImageLayout::ShaderReadOnlyOptimal);
+            frameGraph->SetSampler("g_irradianceCubemap", m_irradianceCubemap);
+            commands->ImageMemoryBarrier(commandList, m_irradianceCubemap, EImageLayout::General);
+            commands->BeginDebugRegion(commandList, "Compute diffuse irradiance cubemap");
+            commands->ImageMemoryBarrier(commandList, m_envCubemap, EImageLayout::ShaderReadOnlyOptimal);
+            commands->ImageMemoryBarrier(commandList, m_irradianceCubemap, EImageLayout::ComputeWrite);
+            driver->AddSamplerToShaderBindings(m_computeIrradianceBindings, "envMap", m_envCubemap, 0);
+            driver->AddStorageImageToShaderBindings(m_computeIrradianceBindings, "irradianceMap", m_irradianceCubemap, 1);
+            commands->Dispatch(commandList, m_pComputeIrradianceShader, std::max(1u, (uint32_t)irradianceSize / 32u), std::max(1u, (uint32_t)irradianceSize / 32u), 6u,
+                               { m_computeIrradianceBindings });
+            commands->EndDebugRegion(commandList);
+        }
+        m_bIsDirty = false;
+    }
+    commands->EndDebugRegion(commandList);
+}
+
+void EnvironmentNode::Clear()
+{
+    m_pComputeIrradianceShader.Clear(); m_pComputeSpecularShader.Clear(); m_pComputeBrdfShader.Clear();
+    m_computeIrradianceBindings.Clear(); m_computeSpecularBindings.Clear(); m_computeBrdfBindings.Clear();
+    m_envCubemap.Clear(); m_irradianceCubemap.Clear(); m_brdfSampler.Clear();
 }
 
 // ---- LinearizeDepthNode (FrameGraph/LinearizeDepthNode.cpp:18-109) -------------------------------------------------------------

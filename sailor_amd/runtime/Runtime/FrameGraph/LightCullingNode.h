@@ -57,4 +57,27 @@ protected:
     RHI::RHIShaderBindingSetPtr m_surfaceBindings;
 };
 
+// The one-off image-based-lighting bake: Runtime/FrameGraph/EnvironmentNode.h.  Raw environment = the frame graph's sampler
+// "g_skyCubemap" (EnvironmentNode.cpp:139-142; the equirect-file branch needs the asset pipeline and is not mirrored); results are
+// published as samplers "g_brdfSampler", "g_envCubemap", "g_irradianceCubemap" (:79, :187, :247), which RHIFrameGraph::Process binds
+// into the lights set for Standard.shader's ambient term.
+class EnvironmentNode : public TFrameGraphNode<EnvironmentNode> {
+public:
+    static constexpr uint32_t IrradianceMapSize = 32; // EnvironmentNode.h:19
+    static constexpr uint32_t BrdfLutSize = 256;      // EnvironmentNode.h:20 (EnvMapSize / EnvMapLevels (:16-17) are taken from the raw cubemap here)
+    static const char* GetName() { return m_name; }
+    void Process(RHIFrameGraphPtr frameGraph, RHI::RHICommandListPtr transferCommandList, RHI::RHICommandListPtr commandList,
+                 const RHI::RHISceneViewSnapshot& sceneView) override;
+    void Clear() override;
+    void MarkDirty() { m_bIsDirty = true; } // EnvironmentNode.h:28
+
+protected:
+    static const char* m_name;
+    RHI::RHIShaderPtr m_pComputeIrradianceShader, m_pComputeSpecularShader, m_pComputeBrdfShader;
+    RHI::RHIShaderBindingSetPtr m_computeIrradianceBindings, m_computeSpecularBindings, m_computeBrdfBindings;
+    RHI::RHICubemapPtr m_envCubemap, m_irradianceCubemap; // (keyed by the sky parameters in the reference: one sky here)
+    RHI::RHITexturePtr m_brdfSampler;
+    bool m_bIsDirty = false;
+};
+
 } // namespace Sailor::Framegraph

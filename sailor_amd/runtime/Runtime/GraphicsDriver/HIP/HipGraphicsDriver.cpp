@@ -82,6 +82,42 @@ RHITexturePtr HipGraphicsDriver::CreateTexture(const void* pData, size_t size, i
     return t;
 }
 
+static size_t cube_chain_texels(int size, uint32_t levels)
+{
+    size_t n = 0;
+    for (uint32_t l = 0; l < levels; l++) { const int sz = (size >> l) > 1 ? (size >> l) : 1; n += (size_t)6 * sz * sz; }
+    return n;
+}
+
+RHITexturePtr RHI::RHITexture::GetMipLevel(uint32_t mipLevel) const
+{
+    auto v = RHITexturePtr::Make();
+    v->m_buffer = m_buffer; v->m_format = m_format; v->m_bCubemap = m_bCubemap; v->m_mipLevels = 1;
+    const int sz = (m_extent.x >> mipLevel) > 1 ? (m_extent.x >> mipLevel) : 1;
+    v->m_extent = { sz, sz };
+    v->m_viewLevel = mipLevel;
+    v->m_parent = RHITexturePtr(const_cast<RHI::RHITexture*>(this));
+    return v;
+}
+
+RHITexturePtr HipGraphicsDriver::CreateRenderTarget(ivec2 extent, uint32_t, EFormat format) { return CreateTexture(nullptr, 0, extent, format); }
+
+RHICubemapPtr HipGraphicsDriver::CreateCubemap(ivec2 extent, uint32_t mipLevels, EFormat format)
+{
+    auto t = RHITexturePtr::Make();
+    t->m_extent = extent; t->m_format = format; t->m_mipLevels = mipLevels; t->m_bCubemap = true;
+    t->m_buffer = CreateBuffer(cube_chain_texels(extent.x, mipLevels) * texel_size(format));
+    return t->m_buffer ? t : RHITexturePtr();
+}
+
+RHICubemapPtr HipGraphicsDriver::WrapCubemap(void* devicePtr, int size, uint32_t mipLevels, EFormat format)
+{
+    auto t = RHITexturePtr::Make();
+    t->m_extent = { size, size }; t->m_format = format; t->m_mipLevels = mipLevels; t->m_bCubemap = true;
+    t->m_buffer = WrapBuffer(devicePtr, cube_chain_texels(size, mipLevels) * texel_size(format));
+    return t;
+}
+
 RHITexturePtr HipGraphicsDriver::WrapTexture(void* devicePtr, ivec2 extent, EFormat format)
 {
     auto t = RHITexturePtr::Make();
@@ -126,6 +162,21 @@ RHIShaderBindingPtr HipGraphicsDriver::AddBufferToShaderBindings(RHIShaderBindin
     return b;
 }
 
+RHIShaderBindingPtr HipGraphicsDriver::AddStorageImageToShaderBindings(RHIShaderBindingSetPtr& set, const std::string& name, RHITexturePtr texture, uint32_t shaderBinding)
+{
+    return AddStorageImageToShaderBindings(set, name, TVector<RHITexturePtr> { texture }, shaderBinding);
+}
+
+RHIShaderBindingPtr HipGraphicsDriver::AddStorageImageToShaderBindings(RHIShaderBindingSetPtr& set, const std::string& name, const TVector<RHITexturePtr>& array,
+                                                                       uint32_t shaderBinding)
+{
+    auto b = set->GetOrAddShaderBinding(name);
+    b->m_type = EShaderBindingType::StorageImage;
+    b->m_binding = shaderBinding;
+    b->m_textures = array;
+    return b;
+}
+
 RHIShaderBindingPtr HipGraphicsDriver::AddSamplerToShaderBindings(RHIShaderBindingSetPtr& set, const std::string& name, RHITexturePtr texture, uint32_t shaderBinding)
 {
     auto b = set->GetOrAddShaderBinding(name);
@@ -160,6 +211,21 @@ void HipGraphicsDriver::BeginDebugRegion(RHICommandListPtr cmdList, const std::s
 void HipGraphicsDriver::EndDebugRegion(RHICommandListPtr) {}
 void HipGraphicsDriver::ImageMemoryBarrier(RHICommandListPtr, RHITexturePtr, EImageLayout) {} // one in-order stream: nothing to do
 
+bool HipGraphicsDriver::BlitImage(RHICommandListPtr cmd, RHITexturePtr src, RHITexturePtr dst, ivec4 srcRegionRect, ivec4 dstRegionRect)
+{
+    // the path's only blit copies level 0 of one cubemap to another of the same size and format (EnvironmentNode.cpp:200-203): a device copy
+    if (!src || !dst || src->m_format != dst->m_format || src->GetExtent().x != dst->GetExtent().x || src->GetExtent().y != dst->GetExtent().y ||
+        srcRegionRect.x != 0 || srcRegionRect.y != 0 || dstRegionRect.x != 0 || dstRegionRect.y != 0 || srcRegionRect.z != dstRegionRect.z ||
+        srcRegionRect.w != dstRegionRect.w || srcRegionRect.z != src->GetExtent().x || srcRegionRect.w != src->GetExtent().y)
+        return false;
+    const size_t bytes = (size_t)(src->m_bCubemap ? 6 : 1) * src->GetExtent().x * src->GetExtent().y * texel_size(src->m_format);
+    SailorHipContext* ctx = m_ctx;
+    cmd->m_hip.m_commands.push_back([ctx, src, dst, bytes]() {
+        return sailor_hip_buffer_copy(ctx, dst->m_buffer->m_hip.m_devicePtr, 0, src->m_buffer->m_hip.m_devicePtr, 0, bytes);
+    });
+    return true;
+}
+
 void HipGraphicsDriver::UpdateShaderBinding(RHICommandListPtr cmd, RHIShaderBindingPtr binding, const void* data, size_t size, size_t variableOffset)
 {
     if (binding->m_type == EShaderBindingType::UniformBuffer) {
@@ -190,6 +256,9 @@ void HipGraphicsDriver::Dispatch(RHICommandListPtr cmd, RHIShaderPtr computeShad
         if (name == "Shaders/ComputeLightCulling.shader") return RecordLightCulling(bindings, pc);
         if (name == "Shaders/Standard.shader") return RecordShade(bindings);
         if (name == "Shaders/ComputeMeshCulling.shader") return RecordMeshCulling(bindings, pc);
+        if (name == "Shaders/ComputeBrdfLut.shader") return RecordBrdfLut(bindings);
+        if (name == "Shaders/ComputeIrradianceMap.shader") return RecordIrradianceMap(bindings);
+        if (name == "Shaders/ComputeEnvMap_IBL.shader") return RecordEnvPrefilter(bindings, pc);
         return (int)SAILOR_HIP_ERR_UNSUPPORTED;
     });
 }
@@ -356,6 +425,45 @@ int HipGraphicsDriver::RecordEvsmBlur(const TVector<RHIShaderBindingSetPtr>& bin
     memcpy(radius, dataB->m_hostCopy.data(), 8);
     return sailor_hip_evsm_blur_pass(m_ctx, (const float*)src->m_buffer->m_hip.m_devicePtr, (float*)target->m_buffer->m_hip.m_devicePtr,
                                      target->GetExtent().x, target->GetExtent().y, (int32_t)radius[0], (int32_t)radius[1], vertical ? 1 : 0); // ivec2(data.blurRadius.xy) (Blur.shader:94)
+}
+
+// ---- EnvironmentNode's one-off Dispatches (FrameGraph/EnvironmentNode.cpp:86-91, :223-231, :264-269) ------------------------------------------
+static RHITexturePtr texture_of(const TVector<RHIShaderBindingSetPtr>& bindings, const char* name, size_t index = 0)
+{
+    for (const auto& set : bindings)
+        if (set) if (auto b = set->Find(name)) if (b->m_textures.size() > index) return b->m_textures[index];
+    return RHITexturePtr();
+}
+
+int HipGraphicsDriver::RecordBrdfLut(const TVector<RHIShaderBindingSetPtr>& bindings)
+{
+    auto dst = texture_of(bindings, "dst"); // ComputeBrdfLut.shader:24 (rg16f there; two fp32 channels here)
+    if (!dst || dst->m_format != EFormat::R32G32_SFLOAT) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    return sailor_hip_compute_brdf_lut(m_ctx, (float*)dst->m_buffer->m_hip.m_devicePtr, dst->GetExtent().x, dst->GetExtent().y);
+}
+
+int HipGraphicsDriver::RecordIrradianceMap(const TVector<RHIShaderBindingSetPtr>& bindings)
+{
+    auto env = texture_of(bindings, "envMap"), irr = texture_of(bindings, "irradianceMap"); // ComputeIrradianceMap.shader:19-20
+    if (!env || !irr || !env->m_bCubemap || !irr->m_bCubemap || env->m_format != EFormat::R32G32B32A32_SFLOAT || irr->m_format != EFormat::R32G32B32A32_SFLOAT)
+        return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    return sailor_hip_compute_irradiance_map(m_ctx, (const float*)env->m_buffer->m_hip.m_devicePtr, env->GetExtent().x, (int32_t)env->m_mipLevels,
+                                             (float*)irr->m_buffer->m_hip.m_devicePtr, irr->GetExtent().x);
+}
+
+int HipGraphicsDriver::RecordEnvPrefilter(const TVector<RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pcBytes)
+{
+    // ComputeEnvMap_IBL.shader:20-29: rawEnvMap, envMap[NumMipLevels] = the mip TAIL views (EnvironmentNode.cpp:208-215), push constants { level, roughness }
+    if (pcBytes.size() < 8) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    int32_t level; float roughness;
+    memcpy(&level, pcBytes.data(), 4); memcpy(&roughness, pcBytes.data() + 4, 4);
+    auto raw = texture_of(bindings, "rawEnvMap");
+    auto view = level >= 0 ? texture_of(bindings, "envMap", (size_t)level) : RHITexturePtr();
+    if (!raw || !view || !view->m_parent || !raw->m_bCubemap || raw->m_format != EFormat::R32G32B32A32_SFLOAT) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const auto& env = view->m_parent;
+    if (env->GetExtent().x != raw->GetExtent().x || env->m_mipLevels != raw->m_mipLevels || env->m_format != raw->m_format) return SAILOR_HIP_ERR_UNSUPPORTED;
+    return sailor_hip_prefilter_env_level(m_ctx, (const float*)raw->m_buffer->m_hip.m_devicePtr, (float*)env->m_buffer->m_hip.m_devicePtr, raw->GetExtent().x,
+                                          (int32_t)raw->m_mipLevels, (int32_t)view->m_viewLevel, roughness);
 }
 
 int HipGraphicsDriver::RecordMeshCulling(const TVector<RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pcBytes)

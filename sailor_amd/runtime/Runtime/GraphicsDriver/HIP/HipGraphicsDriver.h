@@ -6,6 +6,8 @@
 //   "Shaders/Standard.shader"            -> sailor_hip_shade             (binding contract: Standard.shader:180-251)
 //   "Shaders/ComputeMeshCulling.shader"  -> sailor_hip_mesh_cull_compact (binding contract: ComputeMeshCulling.shader:37-58;
 //                                           sailor_hip_mesh_frustum_cull when no indirect buffer is bound)
+//   "Shaders/ComputeBrdfLut.shader" / "ComputeIrradianceMap.shader" / "ComputeEnvMap_IBL.shader" (EnvironmentNode's one-off Dispatches)
+//                                        -> sailor_hip_compute_brdf_lut / _compute_irradiance_map / _prefilter_env_level
 // and the one full-screen DRAW in front of the path (6 indices with the material of)
 //   "Shaders/LinearizeDepth.shader"      -> sailor_hip_linearize_depth   (binding contract: LinearizeDepth.shader:15-59)
 //   "Shaders/Blur.shader" {EVSM, HORIZONTAL | VERTICAL} -> sailor_hip_evsm_blur_pass (binding contract: Blur.shader:53-61)
@@ -28,6 +30,8 @@ public:
     RHI::RHIBufferPtr CreateBuffer(size_t size) override;
     RHI::RHIShaderPtr CreateShader(const std::string& assetPath, const TVector<std::string>& defines = {}) override;
     RHI::RHITexturePtr CreateTexture(const void* pData, size_t size, RHI::ivec2 extent, RHI::EFormat format) override;
+    RHI::RHITexturePtr CreateRenderTarget(RHI::ivec2 extent, uint32_t mipLevels, RHI::EFormat format) override;
+    RHI::RHICubemapPtr CreateCubemap(RHI::ivec2 extent, uint32_t mipLevels, RHI::EFormat format) override;
     void SubmitCommandList(RHI::RHICommandListPtr commandList) override;
     RHI::RHIMaterialPtr CreateMaterial(RHI::RHIShaderPtr shader) override;
     RHI::RHIShaderBindingSetPtr CreateShaderBindings() override;
@@ -39,16 +43,22 @@ public:
                                                         uint32_t shaderBinding) override;
     RHI::RHIShaderBindingPtr AddSamplerToShaderBindings(RHI::RHIShaderBindingSetPtr& set, const std::string& name,
                                                         const TVector<RHI::RHITexturePtr>& array, uint32_t shaderBinding) override;
+    RHI::RHIShaderBindingPtr AddStorageImageToShaderBindings(RHI::RHIShaderBindingSetPtr& set, const std::string& name, RHI::RHITexturePtr texture,
+                                                             uint32_t shaderBinding) override;
+    RHI::RHIShaderBindingPtr AddStorageImageToShaderBindings(RHI::RHIShaderBindingSetPtr& set, const std::string& name,
+                                                             const TVector<RHI::RHITexturePtr>& array, uint32_t shaderBinding) override;
     RHI::RHIShaderBindingPtr AddShaderBinding(RHI::RHIShaderBindingSetPtr& set, const RHI::RHIShaderBindingPtr& binding, const std::string& name,
                                               uint32_t shaderBinding) override;
     // wrap memory owned by someone else (a torch tensor in the tests, an engine heap in the real thing)
     RHI::RHIBufferPtr WrapBuffer(void* devicePtr, size_t size);
     RHI::RHITexturePtr WrapTexture(void* devicePtr, RHI::ivec2 extent, RHI::EFormat format);
+    RHI::RHICubemapPtr WrapCubemap(void* devicePtr, int size, uint32_t mipLevels, RHI::EFormat format);
 
     // IGraphicsDriverCommands
     void BeginDebugRegion(RHI::RHICommandListPtr cmdList, const std::string& title) override;
     void EndDebugRegion(RHI::RHICommandListPtr cmdList) override;
     void ImageMemoryBarrier(RHI::RHICommandListPtr cmd, RHI::RHITexturePtr image, RHI::EImageLayout newLayout) override;
+    bool BlitImage(RHI::RHICommandListPtr cmd, RHI::RHITexturePtr src, RHI::RHITexturePtr dst, RHI::ivec4 srcRegionRect, RHI::ivec4 dstRegionRect) override;
     void UpdateShaderBinding(RHI::RHICommandListPtr cmd, RHI::RHIShaderBindingPtr binding, const void* data, size_t size, size_t variableOffset = 0) override;
     void UpdateBuffer(RHI::RHICommandListPtr cmd, RHI::RHIBufferPtr buffer, const void* data, size_t size, size_t offset = 0) override;
     void BeginRenderPass(RHI::RHICommandListPtr cmd, const TVector<RHI::RHITexturePtr>& colorAttachments, RHI::RHITexturePtr depthStencilAttachment) override;
@@ -64,6 +74,9 @@ public:
 private:
     int RecordLightCulling(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pc);
     int RecordShade(const TVector<RHI::RHIShaderBindingSetPtr>& bindings);
+    int RecordBrdfLut(const TVector<RHI::RHIShaderBindingSetPtr>& bindings);
+    int RecordIrradianceMap(const TVector<RHI::RHIShaderBindingSetPtr>& bindings);
+    int RecordEnvPrefilter(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pc);
     int RecordMeshCulling(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pc);
     int RecordLinearizeDepth(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const RHI::RHITexturePtr& target);
     int RecordEvsmBlur(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const RHI::RHITexturePtr& target, bool vertical);

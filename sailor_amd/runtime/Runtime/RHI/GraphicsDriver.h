@@ -15,6 +15,8 @@ public:
     virtual RHIBufferPtr CreateBuffer(size_t size) = 0;                                                    // :89
     virtual RHIShaderPtr CreateShader(const std::string& assetPath, const TVector<std::string>& defines = {}) = 0; // :97 (SPIR-V there; here the asset path + permutation)
     virtual RHITexturePtr CreateTexture(const void* pData, size_t size, ivec2 extent, EFormat format) = 0; // :98-108
+    virtual RHITexturePtr CreateRenderTarget(ivec2 extent, uint32_t mipLevels, EFormat format) = 0;        // :110-117 (filtration, clamping, usage dropped)
+    virtual RHICubemapPtr CreateCubemap(ivec2 extent, uint32_t mipLevels, EFormat format) = 0;             // :137-143
     virtual void SubmitCommandList(RHICommandListPtr commandList) = 0;                                     // :149
     virtual RHIMaterialPtr CreateMaterial(RHIShaderPtr shader) = 0;                                        // :138-141 (vertex layout / topology / render state dropped)
     virtual RHIShaderBindingSetPtr CreateShaderBindings() = 0;                                             // :152
@@ -26,6 +28,10 @@ public:
                                                            uint32_t shaderBinding) = 0;                                                     // :156
     virtual RHIShaderBindingPtr AddSamplerToShaderBindings(RHIShaderBindingSetPtr& pShaderBindings, const std::string& name,
                                                            const TVector<RHITexturePtr>& array, uint32_t shaderBinding) = 0;               // :157
+    virtual RHIShaderBindingPtr AddStorageImageToShaderBindings(RHIShaderBindingSetPtr& pShaderBindings, const std::string& name, RHITexturePtr texture,
+                                                                uint32_t shaderBinding) = 0;                                                // :158
+    virtual RHIShaderBindingPtr AddStorageImageToShaderBindings(RHIShaderBindingSetPtr& pShaderBindings, const std::string& name,
+                                                                const TVector<RHITexturePtr>& array, uint32_t shaderBinding) = 0;          // :159
     virtual RHIShaderBindingPtr AddShaderBinding(RHIShaderBindingSetPtr& pShaderBindings, const RHIShaderBindingPtr& binding, const std::string& name,
                                                  uint32_t shaderBinding) = 0;                                                               // :160
 };
@@ -36,6 +42,7 @@ public:
     virtual void BeginDebugRegion(RHICommandListPtr cmdList, const std::string& title) = 0; // :238
     virtual void EndDebugRegion(RHICommandListPtr cmdList) = 0;                              // :239
     virtual void ImageMemoryBarrier(RHICommandListPtr cmd, RHITexturePtr image, EImageLayout newLayout) = 0; // :290
+    virtual bool BlitImage(RHICommandListPtr cmd, RHITexturePtr src, RHITexturePtr dst, ivec4 srcRegionRect, ivec4 dstRegionRect) = 0;                 // :293 (equal regions only: a copy)
     virtual void UpdateShaderBinding(RHICommandListPtr cmd, RHIShaderBindingPtr binding, const void* data, size_t size, size_t variableOffset = 0) = 0; // :303
     virtual void UpdateBuffer(RHICommandListPtr cmd, RHIBufferPtr buffer, const void* data, size_t size, size_t offset = 0) = 0;                       // :304
     virtual void BeginRenderPass(RHICommandListPtr cmd, const TVector<RHITexturePtr>& colorAttachments, RHITexturePtr depthStencilAttachment) = 0; // :246-255 (area, clear values dropped)

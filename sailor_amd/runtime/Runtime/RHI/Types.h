@@ -56,6 +56,7 @@ class RHIResource : public TRefBase {};
 using RHIResourcePtr = TRefPtr<RHIResource>;
 
 struct ivec2 { int32_t x = 0, y = 0; };
+struct ivec4 { int32_t x = 0, y = 0, z = 0, w = 0; };
 
 using UboFrameData = SailorUboFrameData; // RHI/Types.h:751-761
 
@@ -70,7 +71,7 @@ public:
 using RHIBufferPtr = TRefPtr<RHIBuffer>;
 
 enum class EFormat { R32_SFLOAT, R16_SFLOAT, R32G32B32A32_SFLOAT, R32G32_SFLOAT };
-enum class EImageLayout { Undefined, ShaderReadOnlyOptimal, General, ColorAttachmentOptimal };
+enum class EImageLayout { Undefined, ShaderReadOnlyOptimal, General, ColorAttachmentOptimal, ComputeWrite, TransferSrcOptimal, TransferDstOptimal };
 
 // RHI/Texture.h: here a linear row-major image in device memory (row 0 = top)
 class RHITexture : public RHIResource {
@@ -79,11 +80,18 @@ public:
     ivec2 m_extent;
     EFormat m_format = EFormat::R32_SFLOAT;
     uint32_t m_mipLevels = 1; // a cubemap is 6 faces x m_extent.x^2 texels per level, level-major (include/sailor_hip.h SailorIblDesc)
+    bool m_bCubemap = false;
+    // a mip-level view of a cubemap (RHI/Cubemap.h:24 GetMipLevel): shares m_buffer with its parent
+    TRefPtr<RHITexture> m_parent;
+    uint32_t m_viewLevel = 0;
     ivec2 GetExtent() const { return m_extent; }
+    uint32_t GetMipLevels() const { return m_mipLevels; }
+    TRefPtr<RHITexture> GetMipLevel(uint32_t mipLevel) const;
 };
 using RHITexturePtr = TRefPtr<RHITexture>;
+using RHICubemapPtr = RHITexturePtr; // RHI/Cubemap.h:15: class RHICubemap : public RHITexture
 
-enum class EShaderBindingType { UniformBuffer, StorageBuffer, CombinedImageSampler };
+enum class EShaderBindingType { UniformBuffer, StorageBuffer, CombinedImageSampler, StorageImage };
 
 // RHI/ShaderBinding.h: one named resource at one binding slot
 class RHIShaderBinding : public RHIResource {

@@ -19,7 +19,7 @@ struct SailorRuntime {
     std::unique_ptr<LightingECS> lighting;
     RHIFrameGraph graph;
     RHISceneViewSnapshot snapshot;
-    FrameGraphNodePtr lightCulling, renderScene, linearizeDepth;
+    FrameGraphNodePtr lightCulling, renderScene, linearizeDepth, environment;
     RHITexturePtr depth, rawDepth;
     RHIBufferPtr surface, radiance;
     std::unique_ptr<EcsSweepSystem> sweep;
@@ -44,7 +44,7 @@ RT_API void sailor_rt_destroy(SailorRuntime* rt)
     rt->sweep.reset();
     rt->lighting.reset();
     rt->depth.Clear(); rt->surface.Clear(); rt->radiance.Clear();
-    rt->lightCulling.Clear(); rt->renderScene.Clear(); rt->linearizeDepth.Clear(); rt->rawDepth.Clear();
+    rt->lightCulling.Clear(); rt->renderScene.Clear(); rt->linearizeDepth.Clear(); rt->environment.Clear(); rt->rawDepth.Clear();
     rt->snapshot = RHISceneViewSnapshot();
     delete rt;
 }
@@ -59,6 +59,7 @@ RT_API int sailor_rt_build_graph(SailorRuntime* rt, const char** nodeNames, int 
         if (!node) return -1;
         if (std::string(nodeNames[i]) == "LightCulling") rt->lightCulling = node;
         if (std::string(nodeNames[i]) == "LinearizeDepth") rt->linearizeDepth = node;
+        if (std::string(nodeNames[i]) == "Environment") rt->environment = node;
         if (std::string(nodeNames[i]) == "RenderScene") { node->SetString("Tag", "Opaque"); rt->renderScene = node; }
         rt->graph.AddNode(node);
     }
@@ -157,6 +158,30 @@ RT_API void sailor_rt_set_ibl(SailorRuntime* rt, void* irradiance, int irrSize, 
     rt->graph.SetSampler("g_envCubemap", e);
     rt->graph.SetSampler("g_brdfSampler", hip->WrapTexture(lut, { lutW, lutH }, EFormat::R32G32_SFLOAT));
     if (ao) rt->graph.SetRenderTarget("g_AO", hip->WrapTexture(ao, { width, height }, EFormat::R32_SFLOAT));
+}
+
+// The raw environment the Environment node bakes from: published as the sampler "g_skyCubemap" the way SkyNode does, and the node is marked dirty
+// (SkyNode::MarkDirty -> EnvironmentNode::MarkDirty).  irradianceSize > 0 overrides the node's 32 x 32 x 6 output (a test knob).
+RT_API int sailor_rt_set_sky_cubemap(SailorRuntime* rt, void* cubeChain, int size, int levels, int irradianceSize, void* ao, int width, int height)
+{
+    auto* hip = static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver());
+    if (!rt->environment) return -1;
+    rt->graph.SetSampler("g_skyCubemap", hip->WrapCubemap(cubeChain, size, (uint32_t)levels, EFormat::R32G32B32A32_SFLOAT));
+    if (irradianceSize > 0) rt->environment->SetFloat("IrradianceMapSize", (float)irradianceSize);
+    static_cast<EnvironmentNode*>(rt->environment.GetRawPtr())->MarkDirty();
+    if (ao) rt->graph.SetRenderTarget("g_AO", hip->WrapTexture(ao, { width, height }, EFormat::R32_SFLOAT));
+    return 0;
+}
+
+// device pointer + geometry of a sampler the graph's nodes published (g_brdfSampler, g_envCubemap, g_irradianceCubemap, ...)
+RT_API void* sailor_rt_sampler(SailorRuntime* rt, const char* name, int* outWidth, int* outHeight, int* outLevels)
+{
+    auto t = rt->graph.GetSampler(name);
+    if (!t || !t->m_buffer) return nullptr;
+    if (outWidth) *outWidth = t->GetExtent().x;
+    if (outHeight) *outHeight = t->GetExtent().y;
+    if (outLevels) *outLevels = (int)t->GetMipLevels();
+    return t->m_buffer->m_hip.m_devicePtr;
 }
 
 // The blur section of ShadowPrepassNode::Process (FrameGraph/ShadowPrepassNode.cpp:283-356) for one EVSM cascade, command for command: the

@@ -39,6 +39,9 @@ def load() -> C.CDLL:
         rt.sailor_rt_set_shadow_maps.argtypes = [P, P, P, P, P]
         rt.sailor_rt_set_ibl.argtypes = [P, P, C.c_int, P, C.c_int, C.c_int, P, C.c_int, C.c_int, P, C.c_int, C.c_int]
         rt.sailor_rt_blur_shadow_map.argtypes = [P, P, P, C.c_int, C.c_float, C.c_float]
+        rt.sailor_rt_set_sky_cubemap.argtypes = [P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, C.c_int]
+        rt.sailor_rt_sampler.restype = P
+        rt.sailor_rt_sampler.argtypes = [P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         rt.sailor_rt_gpu_culling.argtypes = [P, P, C.c_uint32, C.c_uint32, P, C.c_uint32]
         rt.sailor_rt_process_frame.argtypes = [P]
         rt.sailor_rt_wait_idle.argtypes = [P]
@@ -91,6 +94,17 @@ class Runtime:
     def blur_shadow_map(self, moments, temp, radius_umbra, radius_penumbra):
         """the blur section of ShadowPrepassNode::Process over a float32 [S, S, 4] device tensor, in place"""
         return self.rt.sailor_rt_blur_shadow_map(self.h, moments.data_ptr(), temp.data_ptr(), moments.shape[0], radius_umbra, radius_penumbra)
+
+    def set_sky_cubemap(self, chain, size, levels, irradiance_size=0, ao=None):
+        """publish the raw environment cube (flat RGBA32F mip chain, device tensor) as "g_skyCubemap" and mark the Environment node dirty"""
+        return self.rt.sailor_rt_set_sky_cubemap(self.h, chain.data_ptr(), size, levels, irradiance_size, ao.data_ptr() if ao is not None else None,
+                                                 ao.shape[1] if ao is not None else 0, ao.shape[0] if ao is not None else 0)
+
+    def sampler(self, name: str):
+        """(device pointer, width, height, mip levels) of a sampler published by the graph's nodes"""
+        w, h, l = C.c_int(0), C.c_int(0), C.c_int(0)
+        p = self.rt.sailor_rt_sampler(self.h, name.encode(), C.byref(w), C.byref(h), C.byref(l))
+        return p, w.value, h.value, l.value
 
     def gpu_culling(self, instances, num_instances, first_instance, batches, num_batches):
         """the "GPU Culling" Dispatch of RHIRecordDrawCallGPUCulling over uint8 / int32 device tensors, in place"""

@@ -314,3 +314,34 @@ def test_mesh_cull_compaction_is_a_stable_per_batch_partition():
     assert (bt[:, [0, 2, 3, 4]] == s.batches[:, [0, 2, 3, 4]]).all()
     assert (s.batches[:, 1] == 0).sum() > 0 and 0 < int(bt[:, 1].sum()) < 20000
     assert (inst["isCulled"][:37] == 7).all()
+
+
+def test_ibl_prefilters_of_a_constant_sky():
+    """ComputeIrradianceMap / ComputeEnvMap_IBL restated: a constant sky stays the constant (irradiance: 2 L mean(cos) over the uniform
+    hemisphere set; env: a cosine-weighted mean of constant texels, at any mip level), alpha = 1, level 0 copied."""
+    levels = 4
+    offs, total = oracle.cube_level_offsets(8, levels)
+    sky = np.tile(np.float32([0.5, 1.25, 2.0, 1.0]), total // 4)
+    irr = oracle.compute_irradiance_map(sky, 8, levels, 2)
+    np.testing.assert_allclose(irr[..., :3], np.broadcast_to(np.float32([0.5, 1.25, 2.0]), irr[..., :3].shape), rtol=2e-4)
+    assert (irr[..., 3] == 1.0).all()
+    env = oracle.prefilter_env_map(sky, 8, levels)
+    np.testing.assert_allclose(env.reshape(-1, 4)[:, :3], np.broadcast_to(np.float32([0.5, 1.25, 2.0]), (total // 4, 3)), rtol=1e-5)
+    np.testing.assert_array_equal(env[:offs[1]], sky[:offs[1]])
+
+
+def test_env_prefilter_mip_selection_and_sampling_vector():
+    """The texel direction comes from the texel CORNER (ComputeEnvMap_IBL.shader:42-43 has no + 0.5): texel (0, 0) of the 1 x 1 top mip of
+    face +X looks along normalize(1, 1, 1)-ish (1, uv.y = 1, -uv.x = 1); and a sharper sky loses contrast level by level."""
+    ibl = synth.make_ibl_set(16, 16, np.zeros((2, 2, 2), np.float32), env_size=16, with_ao=False)
+    env = oracle.prefilter_env_map(ibl.env_chain, 16, ibl.env_levels)
+    offs, total = oracle.cube_level_offsets(16, ibl.env_levels)
+    top = env[offs[-1]:].reshape(6, 4)
+    # roughness 1 at the 1 x 1 level: nearly the cosine-weighted hemisphere mean around (1, 1, 1) / sqrt(3) for face 0
+    d = np.float32([1.0, 1.0, 1.0]) / np.sqrt(np.float32(3.0))
+    out = np.zeros(4, np.float32)
+    oracle.lib().oracle_cube_sample_lod(oracle._p(np.ascontiguousarray(ibl.env_chain)), 16, ibl.env_levels, oracle._p(np.ascontiguousarray(d)),
+                                        C.c_float(ibl.env_levels - 1.0), oracle._p(out))
+    assert np.all(np.abs(top[0, :3] - out[:3]) < 0.5 * np.abs(out[:3]) + 0.2)
+    spread = [np.ptp(env[offs[l]:offs[l + 1]].reshape(-1, 4)[:, 0]) for l in range(1, ibl.env_levels - 1)]
+    assert all(a >= b for a, b in zip(spread, spread[1:]))

@@ -186,3 +186,56 @@ def test_gpu_culling_dispatch_compacts_the_indirect_draws():
         np.testing.assert_array_equal(got[:, 20], np.arange(9011))
     finally:
         rt.close()
+
+
+def test_environment_node_bakes_the_ibl_inputs_of_the_ambient_term():
+    """EnvironmentNode::Process recorded against the HIP backend: the BRDF table, the pre-filtered environment cube (BlitImage of mip 0 + one
+    ComputeEnvMap_IBL Dispatch per mip, push constants {level - 1, roughness}) and the irradiance cube come out of sailor_hip_compute_brdf_lut /
+    _prefilter_env_level / _compute_irradiance_map, are published as samplers, bound into the lights set by the next RHIFrameGraph::Process, and
+    RenderScene shades with them -- the same chain on the oracle gives the same picture."""
+    f = synth.make_frame("tiny")
+    W, H = f.cam.width, f.cam.height
+    sky = synth.make_ibl_set(W, H, np.zeros((2, 2, 2), np.float32), env_size=16)
+    rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        rt.build_graph(["Environment", "LightCulling", "RenderScene"])
+        rt.set_camera(f.cam)
+        rt.set_lights(f.lights)
+        depth = torch.from_numpy(f.depth).cuda()
+        surface = torch.from_numpy(f.surface).cuda()
+        radiance = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        rt.set_depth(depth)
+        rt.set_surface(surface, radiance)
+        raw = torch.from_numpy(sky.env_chain).cuda()
+        ao = torch.from_numpy(sky.ao).cuda()
+        assert rt.set_sky_cubemap(raw, 16, sky.env_levels, irradiance_size=2, ao=ao) == 0
+        assert rt.process_frame() == 0   # bakes; the samplers reach the lights set at the start of the next frame (RHIFrameGraph.cpp:128-163)
+        assert rt.process_frame() == 0
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        # the baked textures
+        ref_env = oracle.prefilter_env_map(sky.env_chain, 16, sky.env_levels)
+        ref_irr = oracle.compute_irradiance_map(ref_env, 16, sky.env_levels, 2)
+        ref_lut = oracle.compute_brdf_lut(256, 256)
+        p, w, h, levels = rt.sampler("g_envCubemap")
+        assert (w, h, levels) == (16, 16, sky.env_levels)
+        env = read_u32(p, ref_env.size * 4).view(np.float32)
+        np.testing.assert_allclose(env, ref_env, rtol=1e-4, atol=1e-5)
+        p, w, h, levels = rt.sampler("g_irradianceCubemap")
+        assert (w, h, levels) == (2, 2, 1)
+        irr = read_u32(p, ref_irr.size * 4).view(np.float32).reshape(ref_irr.shape)
+        np.testing.assert_allclose(irr, ref_irr, rtol=2e-4, atol=1e-5)
+        p, w, h, levels = rt.sampler("g_brdfSampler")
+        assert (w, h) == (256, 256)
+        lut = read_u32(p, 256 * 256 * 8).view(np.float32).reshape(256, 256, 2)
+        np.testing.assert_allclose(lut, ref_lut, rtol=0, atol=4e-6)
+        # the picture
+        og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth)
+        oibl, _k = oracle.make_ibl(ref_irr, ref_env, 16, sky.env_levels, ref_lut, sky.ao)
+        ref = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, og, oi, ibl=oibl)
+        no_ambient = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, og, oi)
+        assert np.abs(ref - no_ambient).max() > 0.05
+        err = np.abs(radiance.cpu().numpy().astype(np.float64) - ref)
+        assert (err <= 3e-4 * np.abs(ref) + 1e-5).all(), err.max()  # the ambient inputs themselves carry 1e-4 (summation order of the bake)
+    finally:
+        rt.close()
