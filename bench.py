@@ -195,7 +195,27 @@ def mesh_cull_block(ctx, count: int, num_batches: int, steps: int):
     kept = int(ref_b[:, 1].sum())
     moved = int((ref_i["materialInstance"] != np.arange(count, dtype=np.uint32)).sum())
     algo = count * (84 + 4) + count * 96 + moved * 96 + num_batches * 28
+    # the shader as shipped (OCCLUSION_CULLING): Hi-Z pyramid of the half-resolution raw depth (DefaultRenderer.renderer: ViewportWidth/2 squared,
+    # 8 B per output texel and level) + frustum || occlusion + compaction
+    from sailor_amd.forward_plus import hiz_build
+    hw, hh, levels = cam.width // 2, cam.height // 2, 11
+    raw = torch.from_numpy(synth.make_raw_depth(synth.make_linear_depth(hw, hh, 9, d_min=200.0, d_max=2500.0), cam.frame.cameraZNearZFar[0])).to(ctx.device)
+    pyr = hiz_build(ctx, raw, hw, hw, levels)
+    _, hiz_ms, _, _ = event_ms(lambda: hiz_build(ctx, raw, hw, hw, levels), steps)
+    t = []
+    for _ in range(steps + 3):
+        mc.instances.copy_(inst0); mc.batches.copy_(batch0)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); mc.run(cam.frame, hiz=(pyr, hw, hw, levels)); b.record()
+        torch.cuda.synchronize()
+        t.append(a.elapsed_time(b))
+    occ_ms = float(np.median(t[3:]))
+    _, occ_b = mc.download()
+    lv = [max(hw >> l, 1) ** 2 for l in range(levels)]
+    hiz_bytes = 4 * (hw * hh + sum(lv[:-1]) + sum(lv))  # every level read once and written once, the depth read once
     return {"instances": count, "batches": num_batches, "kept": kept, "moved_records": moved, "gpu_ms": med,
+            "with_occlusion": {"hiz_pyramid": f"{hw}x{hw}, {levels} mips from {hw}x{hh} depth", "hiz_build_ms": hiz_ms, "hiz_gbs": hiz_bytes / hiz_ms / 1e6,
+                               "cull_compact_ms": occ_ms, "kept": int(occ_b[:, 1].sum())},
             "gpu_minstances_per_s": count / med / 1e3, "algorithmic_bytes": algo, "gpu_hbm_gbs": algo / med / 1e6,
             "gpu_hbm_frac": algo / med / 1e6 / HBM_PEAK_GBS, "cpu_1thread_minstances_per_s": count / t1 / 1e6, "kind": "port"}
 

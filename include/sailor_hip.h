@@ -380,7 +380,29 @@ SAILOR_HIP_API int sailor_hip_mesh_frustum_cull(SailorHipContext* ctx, const Sai
  * RHI/Batch.hpp:158-159,183).  Records behind a batch's kept prefix keep their old contents, as in the shader.
  *   dBatches   : device in/out, numBatches x SailorDrawIndexedIndirectData ("drawIndexedIndirect", set 2 binding 0)
  *   dWorkspace : device scratch, 256-byte aligned, sailor_hip_mesh_cull_workspace_bytes(numInstances, numBatches) bytes */
+/* The Hi-Z pyramid ("depthHighZ", set 0 binding 0 of ComputeMeshCulling.shader; render target DepthHighZ of Content/DefaultRenderer.renderer:51-57:
+ * R32_SFLOAT, mips, sampler reduction Min): level-major, level l = max(height >> l, 1) rows of max(width >> l, 1) floats of raw reversed-Z depth. */
+typedef struct SailorHiZDesc {
+    const float* pyramid;
+    int32_t width, height, levels;
+} SailorHiZDesc;
+
+/* Replaces: Content/Shaders/ComputeDepthHighZ.shader:22-30 for one Dispatch of FrameGraph/DepthHighZNode.cpp:90-95 -- out(pos) = the minimum
+ * over the bilinear footprint of the source at (pos + 0.5) / outputSize (texels with non-zero weight, clamp-to-edge). */
+SAILOR_HIP_API int sailor_hip_hiz_downscale(SailorHipContext* ctx, const float* dSrc, int32_t srcWidth, int32_t srcHeight, float* dDst,
+                                            int32_t dstWidth, int32_t dstHeight);
+/* The node's whole loop (DepthHighZNode.cpp:78-96): mip 0 from the depth attachment "src", mip i + 1 from mip i. */
+SAILOR_HIP_API int sailor_hip_hiz_build(SailorHipContext* ctx, const float* dDepth, int32_t depthWidth, int32_t depthHeight, float* dPyramid,
+                                        int32_t width, int32_t height, int32_t levels);
+/* sailor_hip_mesh_frustum_cull with the shader's OCCLUSION_CULLING define when `hiz` is given: isCulled = FrustumCulling || OcclusionCulling
+ * (ComputeMeshCulling.shader:62-94,136-140; ProjectSphere Math.glsl:296-315; floor(log2()) of the mip selection taken from the exponent field). */
+SAILOR_HIP_API int sailor_hip_mesh_cull_flags(SailorHipContext* ctx, const SailorUboFrameData* frame, SailorPerInstanceData* dInstances,
+                                              uint32_t numInstances, uint32_t firstInstanceIndex, const SailorHiZDesc* hiz);
 SAILOR_HIP_API size_t sailor_hip_mesh_cull_workspace_bytes(uint32_t numInstances, uint32_t numBatches);
+/* sailor_hip_mesh_cull_compact (below) with the Hi-Z pyramid: the shader as shipped (`defines: - OCCLUSION_CULLING`); hiz == NULL = frustum only */
+SAILOR_HIP_API int sailor_hip_mesh_cull_compact_ex(SailorHipContext* ctx, const SailorUboFrameData* frame, SailorPerInstanceData* dInstances,
+                                                   uint32_t numInstances, uint32_t firstInstanceIndex, SailorDrawIndexedIndirectData* dBatches,
+                                                   uint32_t numBatches, void* dWorkspace, size_t workspaceBytes, const SailorHiZDesc* hiz);
 SAILOR_HIP_API int sailor_hip_mesh_cull_compact(SailorHipContext* ctx, const SailorUboFrameData* frame, SailorPerInstanceData* dInstances,
                                                 uint32_t numInstances, uint32_t firstInstanceIndex, SailorDrawIndexedIndirectData* dBatches,
                                                 uint32_t numBatches, void* dWorkspace, size_t workspaceBytes);

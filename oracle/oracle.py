@@ -239,14 +239,44 @@ def mesh_frustum_cull(frame, instances: np.ndarray) -> np.ndarray:
     return inst
 
 
-def mesh_cull_compact(frame, instances: np.ndarray, num_instances: int, first_instance: int, batches: np.ndarray):
+def hiz_level_offsets(width: int, height: int, levels: int):
+    offs, o = [], 0
+    for l in range(levels):
+        offs.append(o)
+        o += max(width >> l, 1) * max(height >> l, 1)
+    return offs, o
+
+
+def hiz_build(depth: np.ndarray, width: int, height: int, levels: int) -> np.ndarray:
+    """DepthHighZNode's loop over ComputeDepthHighZ.shader: flat float32 pyramid (level-major) from a raw depth image [H, W]"""
+    depth = np.ascontiguousarray(depth, np.float32)
+    out = np.zeros(hiz_level_offsets(width, height, levels)[1], np.float32)
+    lib().oracle_hiz_build(_p(depth), C.c_int(depth.shape[1]), C.c_int(depth.shape[0]), _p(out), C.c_int(width), C.c_int(height), C.c_int(levels))
+    return out
+
+
+def mesh_cull_occlusion(frame, instances: np.ndarray, pyramid: np.ndarray, width: int, height: int, levels: int) -> np.ndarray:
+    """ComputeMeshCulling.shader step 2 with OCCLUSION_CULLING: isCulled = FrustumCulling || OcclusionCulling"""
+    fb = _frame_bytes(frame)
+    inst = _copy_records(instances)
+    pyr = np.ascontiguousarray(pyramid, np.float32)
+    lib().oracle_mesh_cull_occlusion(_p(fb), _p(inst), C.c_uint32(len(inst)), _p(pyr), C.c_int32(width), C.c_int32(height), C.c_int32(levels))
+    return inst
+
+
+def mesh_cull_compact(frame, instances: np.ndarray, num_instances: int, first_instance: int, batches: np.ndarray, hiz=None):
     """ComputeMeshCulling.shader main(): frustum flags over [first, first + num), then per-batch stable compaction.
     `batches` is uint32 [numBatches, 5] (indexCount, instanceCount, firstIndex, vertexOffset, firstInstance)."""
     fb = _frame_bytes(frame)
     inst = _copy_records(instances)
     bt = np.ascontiguousarray(batches, np.uint32).copy()
     assert inst.dtype.itemsize == 96 and bt.ndim == 2 and bt.shape[1] == 5
-    lib().oracle_mesh_cull_compact(_p(fb), _p(inst), C.c_uint32(num_instances), C.c_uint32(first_instance), _p(bt), C.c_uint32(len(bt)))
+    if hiz is None:
+        lib().oracle_mesh_cull_compact(_p(fb), _p(inst), C.c_uint32(num_instances), C.c_uint32(first_instance), _p(bt), C.c_uint32(len(bt)))
+    else:  # hiz = (flat pyramid, width, height, levels): the shader's OCCLUSION_CULLING build
+        pyr = np.ascontiguousarray(hiz[0], np.float32)
+        lib().oracle_mesh_cull_compact_hiz(_p(fb), _p(inst), C.c_uint32(num_instances), C.c_uint32(first_instance), _p(bt), C.c_uint32(len(bt)),
+                                           _p(pyr), C.c_int32(hiz[1]), C.c_int32(hiz[2]), C.c_int32(hiz[3]))
     return inst, bt
 
 

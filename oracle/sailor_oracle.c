@@ -1374,12 +1374,111 @@ ORACLE_API void oracle_ecs_sweep(uint32_t begin, uint32_t end, const float* trs,
     }
 }
 
-/* Content/Shaders/ComputeMeshCulling.shader:96-110 FrustumCulling over PerInstanceData (96 B: mat4 model@0,
- * vec4 sphereBounds@64, u32 materialInstance@80, u32 isCulled@84 -- FrameGraph/RenderSceneNode.h:16-33).
- * Writes isCulled in place (1 = culled). */
-ORACLE_API void oracle_mesh_frustum_cull(const void* ubo_, void* instances, uint32_t numInstances)
+/* ---- Hi-Z pyramid (FrameGraph/DepthHighZNode.cpp:74-96, Content/Shaders/ComputeDepthHighZ.shader) ----------------------------
+ * The pyramid's sampler is created with `reduction: Min` (Content/DefaultRenderer.renderer:51-57): a texture() fetch returns the
+ * minimum over the bilinear footprint instead of the weighted mean.  Canonical form (Vulkan: "the texels of the footprint with
+ * non-zero weights"): x = u * W - 0.5, i0 = floor(x), i1 = i0 + 1, weights (1 - frac, frac), clamp-to-edge; likewise y; the
+ * minimum over the up to four texels whose weight is not zero.  Pyramid layout: level-major, level l = max(H >> l, 1) rows of
+ * max(W >> l, 1) floats (R32_SFLOAT, raw reversed-Z depth: the minimum is the FARTHEST depth of the footprint). */
+static int hiz_coord(float x, int size) /* floor to a texel index, clamp-to-edge; NaN -> 0 */
 {
-    const UboFrameData* ubo = (const UboFrameData*)ubo_;
+    if (!(x == x)) return 0;
+    if (x < -1.0f) x = -1.0f;
+    if (x > (float)size) x = (float)size;
+    const int i = (int)floorf(x);
+    return i < 0 ? 0 : (i > size - 1 ? size - 1 : i);
+}
+
+static float hiz_fetch_min(const float* tex, int W, int H, float u, float v)
+{
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    const float fx = x - floorf(x), fy = y - floorf(y);
+    const int x0 = hiz_coord(x, W), x1 = hiz_coord(x + 1.0f, W), y0 = hiz_coord(y, H), y1 = hiz_coord(y + 1.0f, H);
+    /* weights (1-fx)(1-fy), fx(1-fy), (1-fx)fy, fx fy: 1 - frac is never 0 (frac < 1); frac may be 0 (or NaN: then both columns count) */
+    const int useX1 = !(fx == 0.0f), useY1 = !(fy == 0.0f);
+    float m = tex[(size_t)y0 * W + x0];
+    if (useX1) { const float t = tex[(size_t)y0 * W + x1]; m = t < m ? t : m; }
+    if (useY1) {
+        const float t = tex[(size_t)y1 * W + x0]; m = t < m ? t : m;
+        if (useX1) { const float t2 = tex[(size_t)y1 * W + x1]; m = t2 < m ? t2 : m; }
+    }
+    return m;
+}
+
+/* ComputeDepthHighZ.shader:22-30: out(pos) = texture(inputDepth, (pos + 0.5) / outputSize).x with the min-reduction sampler */
+ORACLE_API void oracle_hiz_downscale(const float* src, int srcW, int srcH, float* dst, int dstW, int dstH)
+{
+    for (int y = 0; y < dstH; y++)
+        for (int x = 0; x < dstW; x++)
+            dst[(size_t)y * dstW + x] = hiz_fetch_min(src, srcW, srcH, ((float)x + 0.5f) / (float)dstW, ((float)y + 0.5f) / (float)dstH);
+}
+
+/* DepthHighZNode.cpp:78-95: mip 0 from the depth attachment ("src"), mip i + 1 from mip i */
+ORACLE_API void oracle_hiz_build(const float* depth, int depthW, int depthH, float* pyramid, int W, int H, int levels)
+{
+    const float* src = depth;
+    int sw = depthW, sh = depthH;
+    float* dst = pyramid;
+    for (int l = 0; l < levels; l++) {
+        const int w = (W >> l) > 1 ? (W >> l) : 1, h = (H >> l) > 1 ? (H >> l) : 1;
+        oracle_hiz_downscale(src, sw, sh, dst, w, h);
+        src = dst; sw = w; sh = h;
+        dst += (size_t)w * h;
+    }
+}
+
+/* Math.glsl:296-315 ProjectSphere (2D Polyhedral Bounds of a Clipped, Perspective-Projected 3D Sphere, Mara & McGuire 2013) */
+static int project_sphere(const float* C, float r, float znear, float P00, float P11, float* aabb)
+{
+    if (C[2] < r + znear) return 0;
+    const float cx[2] = { -C[0], -C[2] };
+    const float vx[2] = { sqrtf((cx[0] * cx[0] + cx[1] * cx[1]) - r * r), r };
+    const float minx[2] = { vx[0] * cx[0] + (-vx[1]) * cx[1], vx[1] * cx[0] + vx[0] * cx[1] }; /* mat2(vx.x, vx.y, -vx.y, vx.x) * cx */
+    const float maxx[2] = { vx[0] * cx[0] + vx[1] * cx[1], (-vx[1]) * cx[0] + vx[0] * cx[1] }; /* mat2(vx.x, -vx.y, vx.y, vx.x) * cx */
+    const float cy[2] = { -C[1], -C[2] };
+    const float vy[2] = { sqrtf((cy[0] * cy[0] + cy[1] * cy[1]) - r * r), r };
+    const float miny[2] = { vy[0] * cy[0] + (-vy[1]) * cy[1], vy[1] * cy[0] + vy[0] * cy[1] };
+    const float maxy[2] = { vy[0] * cy[0] + vy[1] * cy[1], (-vy[1]) * cy[0] + vy[0] * cy[1] };
+    const float a[4] = { minx[0] / minx[1] * P00, miny[0] / miny[1] * P11, maxx[0] / maxx[1] * P00, maxy[0] / maxy[1] * P11 };
+    /* aabb = aabb.xwzy * vec4(0.5, -0.5, 0.5, -0.5) + vec4(0.5) */
+    aabb[0] = a[0] * 0.5f + 0.5f; aabb[1] = a[3] * -0.5f + 0.5f; aabb[2] = a[2] * 0.5f + 0.5f; aabb[3] = a[1] * -0.5f + 0.5f;
+    return 1;
+}
+
+/* floor(log2(m)) of the shader (:82), as the exponent field -- exact for every positive float; textureLod clamps the level to the
+ * pyramid (m <= 0, NaN -> level 0) */
+static int hiz_level(float m, int levels)
+{
+    if (!(m > 0.0f)) return 0;
+    uint32_t bits;
+    memcpy(&bits, &m, 4);
+    const int e = (int)((bits >> 23) & 0xFFu) - 127;
+    return e < 0 ? 0 : (e > levels - 1 ? levels - 1 : e);
+}
+
+typedef struct { const float* pyramid; int32_t width, height, levels; } OracleHiZ;
+
+/* ComputeMeshCulling.shader:62-94 OcclusionCulling: 1 = occluded */
+static int occlusion_culling(const UboFrameData* ubo, const float* center, float radius, const OracleHiZ* hz)
+{
+    float aabb[4];
+    if (!project_sphere(center, radius, ubo->cameraZNearZFar[0], ubo->projection[0], ubo->projection[5], aabb)) return 0;
+    const float width = (aabb[2] - aabb[0]) * (float)hz->width, height = (aabb[3] - aabb[1]) * (float)hz->height;
+    const int level = hiz_level(width < height ? height : width, hz->levels); /* max(width, height) (:82) */
+    const float u = (aabb[0] + aabb[2]) * 0.5f, v = (aabb[1] + aabb[3]) * 0.5f;
+    const float* tex = hz->pyramid;
+    for (int l = 0; l < level; l++) tex += (size_t)((hz->width >> l) > 1 ? (hz->width >> l) : 1) * ((hz->height >> l) > 1 ? (hz->height >> l) : 1);
+    const int w = (hz->width >> level) > 1 ? (hz->width >> level) : 1, h = (hz->height >> level) > 1 ? (hz->height >> level) : 1;
+    const float depth = hiz_fetch_min(tex, w, h, u, v);
+    const float depthSphere = ubo->cameraZNearZFar[0] / (center[2] - radius);
+    return depthSphere < depth;
+}
+
+/* Content/Shaders/ComputeMeshCulling.shader:96-110 FrustumCulling over PerInstanceData (96 B: mat4 model@0,
+ * vec4 sphereBounds@64, u32 materialInstance@80, u32 isCulled@84 -- FrameGraph/RenderSceneNode.h:16-33), and with `hiz`
+ * (OracleHiZ*, the OCCLUSION_CULLING build) `|| OcclusionCulling` (:139).  Writes isCulled in place (1 = culled). */
+static void mesh_cull_flags(const UboFrameData* ubo, void* instances, uint32_t numInstances, const OracleHiZ* hz)
+{
     ViewFrustum fr;
     /* Math.glsl:185-222 CreateViewFrustum(viewportSize, invProjection) */
     create_frustum_rect(0.0f, 0.0f, (float)ubo->viewportSize[0], (float)ubo->viewportSize[1], ubo->viewportSize[0], ubo->viewportSize[1], ubo->invProjection, &fr);
@@ -1396,8 +1495,21 @@ ORACLE_API void oracle_mesh_frustum_cull(const void* ubo_, void* instances, uint
         const float radius = sb[3] * lossyScale;
         const int overlaps = sphere_frustum_overlaps(center, radius, &fr, ubo->cameraZNearZFar[1], ubo->cameraZNearZFar[0]);
         uint32_t culled = overlaps ? 0u : 1u;
+        if (!culled && hz && hz->pyramid) culled = occlusion_culling(ubo, center, radius, hz) ? 1u : 0u;
         memcpy(inst + 84, &culled, 4);
     }
+}
+
+ORACLE_API void oracle_mesh_frustum_cull(const void* ubo_, void* instances, uint32_t numInstances)
+{
+    mesh_cull_flags((const UboFrameData*)ubo_, instances, numInstances, NULL);
+}
+
+ORACLE_API void oracle_mesh_cull_occlusion(const void* ubo_, void* instances, uint32_t numInstances, const float* pyramid, int32_t width, int32_t height,
+                                           int32_t levels)
+{
+    const OracleHiZ hz = { pyramid, width, height, levels };
+    mesh_cull_flags((const UboFrameData*)ubo_, instances, numInstances, &hz);
 }
 
 /* Content/Shaders/ComputeMeshCulling.shader:119-177 main() without the OCCLUSION_CULLING define: step 2 = FrustumCulling over
@@ -1405,11 +1517,11 @@ ORACLE_API void oracle_mesh_frustum_cull(const void* ubo_, void* instances, uint
  * instanceCount, firstIndex, vertexOffset, firstInstance -- :28-35) a stable in-place compaction of the batch's instance records
  * (:154-174) and instanceCount = number kept (:176).  Canonical reading of the shader's cross-workgroup race (SURVEY.md
  * Appendix C): every flag of step 2 is written before any batch of step 3 is compacted; batches own disjoint instance ranges. */
-ORACLE_API void oracle_mesh_cull_compact(const void* ubo_, void* instances, uint32_t numInstances, uint32_t firstInstanceIndex,
-                                         void* batches, uint32_t numBatches)
+static void mesh_cull_compact_impl(const void* ubo_, void* instances, uint32_t numInstances, uint32_t firstInstanceIndex, void* batches, uint32_t numBatches,
+                                   const OracleHiZ* hz)
 {
     uint8_t* inst = (uint8_t*)instances;
-    oracle_mesh_frustum_cull(ubo_, inst + 96 * (size_t)firstInstanceIndex, numInstances);
+    mesh_cull_flags((const UboFrameData*)ubo_, inst + 96 * (size_t)firstInstanceIndex, numInstances, hz);
     for (uint32_t b = 0; b < numBatches; b++) {
         uint32_t* batch = (uint32_t*)((uint8_t*)batches + 20 * (size_t)b);
         const uint32_t first = batch[4], count = batch[1];
@@ -1425,6 +1537,20 @@ ORACLE_API void oracle_mesh_cull_compact(const void* ubo_, void* instances, uint
         }
         batch[1] = writeIndex - first;
     }
+}
+
+ORACLE_API void oracle_mesh_cull_compact(const void* ubo_, void* instances, uint32_t numInstances, uint32_t firstInstanceIndex,
+                                         void* batches, uint32_t numBatches)
+{
+    mesh_cull_compact_impl(ubo_, instances, numInstances, firstInstanceIndex, batches, numBatches, NULL);
+}
+
+/* the shader as shipped (defines: OCCLUSION_CULLING): frustum || occlusion against the Hi-Z pyramid, then the compaction */
+ORACLE_API void oracle_mesh_cull_compact_hiz(const void* ubo_, void* instances, uint32_t numInstances, uint32_t firstInstanceIndex, void* batches,
+                                             uint32_t numBatches, const float* pyramid, int32_t width, int32_t height, int32_t levels)
+{
+    const OracleHiZ hz = { pyramid, width, height, levels };
+    mesh_cull_compact_impl(ubo_, instances, numInstances, firstInstanceIndex, batches, numBatches, &hz);
 }
 
 /* ------------------------------------------------------------------------------------------- */

@@ -68,6 +68,10 @@ class CsmDesc(C.Structure):
                 ("width", C.c_int32 * NUM_CASCADES), ("height", C.c_int32 * NUM_CASCADES), ("format", C.c_int32 * NUM_CASCADES)]
 
 
+class HiZDesc(C.Structure):
+    _fields_ = [("pyramid", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("levels", C.c_int32)]
+
+
 class IblDesc(C.Structure):  # include/sailor_hip.h SailorIblDesc (Standard.shader bindings 3, 4, 5, 9)
     _fields_ = [("irradiance", C.c_void_p), ("irrSize", C.c_int32), ("env", C.c_void_p), ("envSize", C.c_int32), ("envLevels", C.c_int32),
                 ("brdfLut", C.c_void_p), ("lutW", C.c_int32), ("lutH", C.c_int32), ("ao", C.c_void_p)]
@@ -114,6 +118,10 @@ SIGNATURES = {
     "sailor_hip_buffer_copy": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t]),
     "sailor_hip_ecs_sweep": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_uint32), C.c_uint32, _P, C.POINTER(C.c_float), _P, _P, _P]),
     "sailor_hip_mesh_frustum_cull": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_uint32, C.c_uint32]),
+    "sailor_hip_hiz_downscale": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32]),
+    "sailor_hip_hiz_build": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32]),
+    "sailor_hip_mesh_cull_flags": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_uint32, C.c_uint32, C.POINTER(HiZDesc)]),
+    "sailor_hip_mesh_cull_compact_ex": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P, C.c_size_t, C.POINTER(HiZDesc)]),
     "sailor_hip_mesh_cull_workspace_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "sailor_hip_mesh_cull_compact": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P, C.c_size_t]),
     "sailor_hip_allgather_u32": (C.c_int, [_P, _P, _P, _P, C.c_size_t]),

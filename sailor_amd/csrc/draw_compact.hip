@@ -206,9 +206,9 @@ size_t sailor_hip_mesh_cull_workspace_bytes(uint32_t numInstances, uint32_t numB
     return draw_plan_layout(numInstances, numBatches).total;
 }
 
-int sailor_hip_mesh_cull_compact(SailorHipContext* ctx, const SailorUboFrameData* frame, SailorPerInstanceData* dInstances, uint32_t numInstances,
-                                 uint32_t firstInstanceIndex, SailorDrawIndexedIndirectData* dBatches, uint32_t numBatches, void* dWorkspace,
-                                 size_t workspaceBytes)
+int sailor_hip_mesh_cull_compact_ex(SailorHipContext* ctx, const SailorUboFrameData* frame, SailorPerInstanceData* dInstances, uint32_t numInstances,
+                                    uint32_t firstInstanceIndex, SailorDrawIndexedIndirectData* dBatches, uint32_t numBatches, void* dWorkspace,
+                                    size_t workspaceBytes, const SailorHiZDesc* hiz)
 {
     if (!ctx || !frame) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     const DrawPlan L = draw_plan_layout(numInstances, numBatches);
@@ -217,7 +217,7 @@ int sailor_hip_mesh_cull_compact(SailorHipContext* ctx, const SailorUboFrameData
         if (workspaceBytes < L.total || ((uintptr_t)dWorkspace & 255)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     }
     // step 2: flags over the instance window
-    const int rc = sailor_hip_mesh_frustum_cull(ctx, frame, dInstances ? dInstances + firstInstanceIndex : nullptr, numInstances, 0);
+    const int rc = sailor_hip_mesh_cull_flags(ctx, frame, dInstances ? dInstances + firstInstanceIndex : nullptr, numInstances, 0, hiz);
     if (rc != SAILOR_HIP_OK || numBatches == 0) return rc;
     uint8_t* ws = (uint8_t*)dWorkspace;
     uint32_t* planFirst = (uint32_t*)(ws + L.offFirst);
@@ -236,6 +236,13 @@ int sailor_hip_mesh_cull_compact(SailorHipContext* ctx, const SailorUboFrameData
                        items, status);
     SAILOR_CHECK_LAUNCH(ctx, "k4_draw_compact");
     return SAILOR_HIP_OK;
+}
+
+int sailor_hip_mesh_cull_compact(SailorHipContext* ctx, const SailorUboFrameData* frame, SailorPerInstanceData* dInstances, uint32_t numInstances,
+                                 uint32_t firstInstanceIndex, SailorDrawIndexedIndirectData* dBatches, uint32_t numBatches, void* dWorkspace,
+                                 size_t workspaceBytes)
+{
+    return sailor_hip_mesh_cull_compact_ex(ctx, frame, dInstances, numInstances, firstInstanceIndex, dBatches, numBatches, dWorkspace, workspaceBytes, nullptr);
 }
 
 } // extern "C"

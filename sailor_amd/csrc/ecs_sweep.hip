@@ -243,10 +243,84 @@ __device__ __forceinline__ void msc_plane(const float* p1, const float* p2, floa
     n[0] = cx / len; n[1] = cy / len; n[2] = cz / len;
 }
 
+// ---- Hi-Z pyramid (DepthHighZNode.cpp:74-96, ComputeDepthHighZ.shader) and OcclusionCulling (ComputeMeshCulling.shader:62-94) ----
+// The pyramid's sampler has `reduction: Min` (DefaultRenderer.renderer:51-57).  Canonical fetch == oracle/sailor_oracle.c hiz_fetch_min:
+// bilinear footprint (x = u W - 0.5, clamp-to-edge), minimum over the texels whose weight is not zero.
+struct HiZArgs { const float* pyramid; int width, height, levels; };
+
+__device__ __forceinline__ int hiz_coord(float x, int size)
+{
+    if (!(x == x)) return 0;
+    if (x < -1.0f) x = -1.0f;
+    if (x > (float)size) x = (float)size;
+    const int i = (int)floorf(x);
+    return i < 0 ? 0 : (i > size - 1 ? size - 1 : i);
+}
+
+__device__ __forceinline__ float hiz_fetch_min(const float* __restrict__ tex, int W, int H, float u, float v)
+{
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    const float fx = x - floorf(x), fy = y - floorf(y);
+    const int x0 = hiz_coord(x, W), x1 = hiz_coord(x + 1.0f, W), y0 = hiz_coord(y, H), y1 = hiz_coord(y + 1.0f, H);
+    const bool useX1 = !(fx == 0.0f), useY1 = !(fy == 0.0f);
+    float m = tex[(size_t)y0 * W + x0];
+    if (useX1) { const float t = tex[(size_t)y0 * W + x1]; m = t < m ? t : m; }
+    if (useY1) {
+        const float t = tex[(size_t)y1 * W + x0]; m = t < m ? t : m;
+        if (useX1) { const float t2 = tex[(size_t)y1 * W + x1]; m = t2 < m ? t2 : m; }
+    }
+    return m;
+}
+
+// ComputeDepthHighZ.shader:22-30, one thread per output texel
+__global__ __launch_bounds__(256) void k_hiz_downscale(const float* __restrict__ src, int srcW, int srcH, float* __restrict__ dst, int dstW, int dstH)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= dstW || y >= dstH) return;
+    dst[(size_t)y * dstW + x] = hiz_fetch_min(src, srcW, srcH, ((float)x + 0.5f) / (float)dstW, ((float)y + 0.5f) / (float)dstH);
+}
+
+// Math.glsl:296-315 ProjectSphere, op for op as the oracle's project_sphere
+__device__ __forceinline__ bool msc_project_sphere(float Cx, float Cy, float Cz, float r, float znear, float P00, float P11, float* aabb)
+{
+    if (Cz < r + znear) return false;
+    const float cx0 = -Cx, cx1 = -Cz;
+    const float vx0 = sqrtf((cx0 * cx0 + cx1 * cx1) - r * r), vx1 = r;
+    const float minx0 = vx0 * cx0 + (-vx1) * cx1, minx1 = vx1 * cx0 + vx0 * cx1;
+    const float maxx0 = vx0 * cx0 + vx1 * cx1, maxx1 = (-vx1) * cx0 + vx0 * cx1;
+    const float cy0 = -Cy, cy1 = -Cz;
+    const float vy0 = sqrtf((cy0 * cy0 + cy1 * cy1) - r * r), vy1 = r;
+    const float miny0 = vy0 * cy0 + (-vy1) * cy1, miny1 = vy1 * cy0 + vy0 * cy1;
+    const float maxy0 = vy0 * cy0 + vy1 * cy1, maxy1 = (-vy1) * cy0 + vy0 * cy1;
+    const float a0 = minx0 / minx1 * P00, a1 = miny0 / miny1 * P11, a2 = maxx0 / maxx1 * P00, a3 = maxy0 / maxy1 * P11;
+    aabb[0] = a0 * 0.5f + 0.5f; aabb[1] = a3 * -0.5f + 0.5f; aabb[2] = a2 * 0.5f + 0.5f; aabb[3] = a1 * -0.5f + 0.5f;
+    return true;
+}
+
+__device__ __forceinline__ bool msc_occluded(const HiZArgs& hz, float cx, float cy, float cz, float radius, float znear, float P00, float P11)
+{
+    float aabb[4];
+    if (!msc_project_sphere(cx, cy, cz, radius, znear, P00, P11, aabb)) return false;
+    const float width = (aabb[2] - aabb[0]) * (float)hz.width, height = (aabb[3] - aabb[1]) * (float)hz.height;
+    const float m = width < height ? height : width;
+    int level = 0; // floor(log2(m)) = the exponent field; textureLod clamps it to the pyramid
+    if (m > 0.0f) {
+        const int e = (int)((__float_as_uint(m) >> 23) & 0xFFu) - 127;
+        level = e < 0 ? 0 : (e > hz.levels - 1 ? hz.levels - 1 : e);
+    }
+    const float u = (aabb[0] + aabb[2]) * 0.5f, v = (aabb[1] + aabb[3]) * 0.5f;
+    const float* tex = hz.pyramid;
+    for (int l = 0; l < level; l++) tex += (size_t)max(hz.width >> l, 1) * max(hz.height >> l, 1);
+    const float depth = hiz_fetch_min(tex, max(hz.width >> level, 1), max(hz.height >> level, 1), u, v);
+    const float depthSphere = znear / (cz - radius);
+    return depthSphere < depth;
+}
+
 #define MSC_PER_BLOCK 1024 // instances per 256-thread block: the frustum set-up below is paid once per 1024 instances
 
+template <bool OCCLUSION>
 __global__ __launch_bounds__(256) void k4_mesh_frustum_cull(Mat4 view, Mat4 invProj, int vpW, int vpH, float zNearArg, float zFarArg,
-                                                             SailorPerInstanceData* __restrict__ inst, uint32_t first, uint32_t count)
+                                                             SailorPerInstanceData* __restrict__ inst, uint32_t first, uint32_t count, HiZArgs hz, float P00, float P11)
 {
     __shared__ float sV[4][3];
     __shared__ float sN[4][3];
@@ -285,7 +359,9 @@ __global__ __launch_bounds__(256) void k4_mesh_frustum_cull(Mat4 view, Mat4 invP
 #pragma unroll
         for (int p = 0; p < 4; p++)
             if (dot3f(sN[p][0], sN[p][1], sN[p][2], cx, cy, cz) < -radius) overlaps = false;
-        I->isCulled = overlaps ? 0u : 1u;
+        bool culled = !overlaps;
+        if (OCCLUSION && !culled) culled = msc_occluded(hz, cx, cy, cz, radius, zFarArg /* = frame.cameraZNearZFar.x */, P00, P11); // FrustumCulling || OcclusionCulling (:139)
+        I->isCulled = culled ? 1u : 0u;
     }
 }
 
@@ -323,19 +399,59 @@ int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntities, const Sail
     return SAILOR_HIP_OK;
 }
 
-int sailor_hip_mesh_frustum_cull(SailorHipContext* ctx, const SailorUboFrameData* frame, SailorPerInstanceData* dInstances,
-                                 uint32_t numInstances, uint32_t firstInstanceIndex)
+int sailor_hip_mesh_cull_flags(SailorHipContext* ctx, const SailorUboFrameData* frame, SailorPerInstanceData* dInstances, uint32_t numInstances,
+                               uint32_t firstInstanceIndex, const SailorHiZDesc* hiz)
 {
     if (!ctx || !frame) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (hiz && (!hiz->pyramid || hiz->width <= 0 || hiz->height <= 0 || hiz->levels <= 0 || hiz->levels > 16)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (numInstances == 0) return SAILOR_HIP_OK;
     if (!dInstances || ((uintptr_t)dInstances & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     Mat4 view, invProj;
     memcpy(view.m, frame->view, 64);
     memcpy(invProj.m, frame->invProjection, 64);
-    hipLaunchKernelGGL(k4_mesh_frustum_cull, dim3((numInstances + MSC_PER_BLOCK - 1) / MSC_PER_BLOCK), dim3(256), 0, ctx->stream, view, invProj,
-                       frame->viewportSize[0], frame->viewportSize[1], frame->cameraZNearZFar[1], frame->cameraZNearZFar[0],
-                       dInstances, firstInstanceIndex, numInstances);
+    HiZArgs hz = { nullptr, 1, 1, 1 };
+    if (hiz) { hz.pyramid = hiz->pyramid; hz.width = hiz->width; hz.height = hiz->height; hz.levels = hiz->levels; }
+    const dim3 grid((numInstances + MSC_PER_BLOCK - 1) / MSC_PER_BLOCK);
+    if (hiz)
+        hipLaunchKernelGGL(k4_mesh_frustum_cull<true>, grid, dim3(256), 0, ctx->stream, view, invProj, frame->viewportSize[0], frame->viewportSize[1],
+                           frame->cameraZNearZFar[1], frame->cameraZNearZFar[0], dInstances, firstInstanceIndex, numInstances, hz, frame->projection[0],
+                           frame->projection[5]);
+    else
+        hipLaunchKernelGGL(k4_mesh_frustum_cull<false>, grid, dim3(256), 0, ctx->stream, view, invProj, frame->viewportSize[0], frame->viewportSize[1],
+                           frame->cameraZNearZFar[1], frame->cameraZNearZFar[0], dInstances, firstInstanceIndex, numInstances, hz, 0.0f, 0.0f);
     SAILOR_CHECK_LAUNCH(ctx, "k4_mesh_frustum_cull");
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_mesh_frustum_cull(SailorHipContext* ctx, const SailorUboFrameData* frame, SailorPerInstanceData* dInstances,
+                                 uint32_t numInstances, uint32_t firstInstanceIndex)
+{
+    return sailor_hip_mesh_cull_flags(ctx, frame, dInstances, numInstances, firstInstanceIndex, nullptr);
+}
+
+int sailor_hip_hiz_downscale(SailorHipContext* ctx, const float* dSrc, int32_t srcWidth, int32_t srcHeight, float* dDst, int32_t dstWidth, int32_t dstHeight)
+{
+    if (!ctx || !dSrc || !dDst || srcWidth <= 0 || srcHeight <= 0 || dstWidth <= 0 || dstHeight <= 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(k_hiz_downscale, dim3((dstWidth + 31) / 32, (dstHeight + 7) / 8), dim3(256), 0, ctx->stream, dSrc, srcWidth, srcHeight, dDst, dstWidth,
+                       dstHeight);
+    SAILOR_CHECK_LAUNCH(ctx, "k_hiz_downscale");
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_hiz_build(SailorHipContext* ctx, const float* dDepth, int32_t depthWidth, int32_t depthHeight, float* dPyramid, int32_t width, int32_t height,
+                         int32_t levels)
+{
+    if (!ctx || levels <= 0 || levels > 16 || width <= 0 || height <= 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const float* src = dDepth;
+    int sw = depthWidth, sh = depthHeight;
+    float* dst = dPyramid;
+    for (int l = 0; l < levels; l++) { // DepthHighZNode.cpp:78-95: mip 0 from the depth attachment, mip i + 1 from mip i
+        const int w = (width >> l) > 1 ? (width >> l) : 1, h = (height >> l) > 1 ? (height >> l) : 1;
+        const int rc = sailor_hip_hiz_downscale(ctx, src, sw, sh, dst, w, h);
+        if (rc != SAILOR_HIP_OK) return rc;
+        src = dst; sw = w; sh = h;
+        dst += (size_t)w * h;
+    }
     return SAILOR_HIP_OK;
 }
 

@@ -238,6 +238,15 @@ class EcsSweep:
         return self.world, self.world_aabb, self.visibility
 
 
+def hiz_build(ctx: "HipContext", depth: torch.Tensor, width: int, height: int, levels: int) -> torch.Tensor:
+    """DepthHighZNode's loop on the GPU: raw depth [H, W] float32 -> flat level-major min pyramid"""
+    total = sum(max(width >> l, 1) * max(height >> l, 1) for l in range(levels))
+    out = torch.empty(total, dtype=torch.float32, device=ctx.device)
+    _lib.check(ctx._lib.sailor_hip_hiz_build(ctx.handle, _ptr(depth), depth.shape[1], depth.shape[0], _ptr(out), width, height, levels),
+               "sailor_hip_hiz_build", ctx.handle)
+    return out
+
+
 class MeshCull:
     """ComputeMeshCulling.shader main() (frustum flags + indirect-draw compaction) over resident instance / indirect buffers."""
 
@@ -252,11 +261,16 @@ class MeshCull:
         self._ws_bytes = int(ctx._lib.sailor_hip_mesh_cull_workspace_bytes(self.n, self.num_batches))
         self.workspace = torch.empty(max(self._ws_bytes, 256), dtype=torch.uint8, device=ctx.device)
 
-    def run(self, frame, num_instances=None, first_instance=0):
+    def run(self, frame, num_instances=None, first_instance=0, hiz=None):
+        """hiz = (pyramid tensor, width, height, levels) switches the shader's OCCLUSION_CULLING define on"""
         n = self.n - first_instance if num_instances is None else num_instances
-        _lib.check(self.ctx._lib.sailor_hip_mesh_cull_compact(self.ctx.handle, C.byref(frame), _ptr(self.instances), n, first_instance,
-                                                               _ptr(self.batches), self.num_batches, _ptr(self.workspace), self._ws_bytes),
-                   "sailor_hip_mesh_cull_compact", self.ctx.handle)
+        desc = None
+        if hiz is not None:
+            desc = _lib.HiZDesc(hiz[0].data_ptr(), hiz[1], hiz[2], hiz[3])
+        _lib.check(self.ctx._lib.sailor_hip_mesh_cull_compact_ex(self.ctx.handle, C.byref(frame), _ptr(self.instances), n, first_instance,
+                                                                  _ptr(self.batches), self.num_batches, _ptr(self.workspace), self._ws_bytes,
+                                                                  C.byref(desc) if desc is not None else None),
+                   "sailor_hip_mesh_cull_compact_ex", self.ctx.handle)
         return self.instances, self.batches
 
     def download(self):

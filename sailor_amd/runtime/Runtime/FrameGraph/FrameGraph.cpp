@@ -1,3 +1,4 @@
+#include <cmath>
 #include "FrameGraphNode.h"
 #include "LightCullingNode.h"
 #include "RHIFrameGraph.h"
@@ -32,6 +33,7 @@ template class Sailor::Framegraph::TFrameGraphNode<LightCullingNode>;
 template class Sailor::Framegraph::TFrameGraphNode<RenderSceneNode>;
 template class Sailor::Framegraph::TFrameGraphNode<LinearizeDepthNode>;
 template class Sailor::Framegraph::TFrameGraphNode<EnvironmentNode>;
+template class Sailor::Framegraph::TFrameGraphNode<DepthHighZNode>;
 
 // ---- RHIFrameGraph ----------------------------------------------------------------------------------------------------------
 UboFrameData RHIFrameGraph::FillFrameData(RHICommandListPtr transferCmdList, RHISceneViewSnapshot& snapshot, float deltaTime, float worldTime) const
@@ -165,6 +167,53 @@ void EnvironmentNode::Clear()
     m_pComputeIrradianceShader.Clear(); m_pComputeSpecularShader.Clear(); m_pComputeBrdfShader.Clear();
     m_computeIrradianceBindings.Clear(); m_computeSpecularBindings.Clear(); m_computeBrdfBindings.Clear();
     m_envCubemap.Clear(); m_irradianceCubemap.Clear(); m_brdfSampler.Clear();
+}
+
+// ---- DepthHighZNode (FrameGraph/DepthHighZNode.cpp:17-103) -----------------------------------------------------------------------
+const char* DepthHighZNode::m_name = "DepthHighZ";
+
+void DepthHighZNode::Process(RHIFrameGraphPtr frameGraph, RHICommandListPtr, RHICommandListPtr commandList, const RHISceneViewSnapshot&)
+{
+    auto driver = Renderer::GetDriver();
+    auto commands = Renderer::GetDriverCommands();
+    auto depthAttachment = GetRHIResource("src").DynamicCast<RHITexture>(); // (:28-32)
+    if (!depthAttachment) depthAttachment = frameGraph->GetRenderTarget("DepthBuffer");
+    auto highZRenderTarget = GetRHIResource("dst").DynamicCast<RHITexture>(); // (:34)
+    if (!depthAttachment || !highZRenderTarget) return;
+    if (!m_pComputeDepthHighZShader) m_pComputeDepthHighZShader = driver->CreateShader("Shaders/ComputeDepthHighZ.shader"); // (:38-44)
+    if (m_computeDepthHighZBindings.empty()) { // (:51-67)
+        m_computeDepthHighZBindings.resize(highZRenderTarget->GetMipLevels() - 1);
+        for (uint32_t i = 0; i < highZRenderTarget->GetMipLevels() - 1; ++i) {
+            auto readMipLevel = highZRenderTarget->GetMipLevel(i), writeMipLevel = highZRenderTarget->GetMipLevel(i + 1); // GetMipLayer
+            m_computeDepthHighZBindings[i] = driver->CreateShaderBindings();
+            driver->AddSamplerToShaderBindings(m_computeDepthHighZBindings[i], "inputDepth", readMipLevel, 0);
+            driver->AddStorageImageToShaderBindings(m_computeDepthHighZBindings[i], "outputDepth", writeMipLevel, 1);
+        }
+        m_computePrepassDepthHighZBindings = driver->CreateShaderBindings();
+        driver->AddSamplerToShaderBindings(m_computePrepassDepthHighZBindings, "inputDepth", depthAttachment, 0);
+        driver->AddStorageImageToShaderBindings(m_computePrepassDepthHighZBindings, "outputDepth", highZRenderTarget->GetMipLevel(0), 1);
+    }
+    commands->BeginDebugRegion(commandList, GetName());
+    commands->ImageMemoryBarrier(commandList, highZRenderTarget, EImageLayout::General);
+    for (int32_t i = -1; i < (int32_t)highZRenderTarget->GetMipLevels() - 1; ++i) { // Depth Downscale (:78-96)
+        const bool bFirst = i == -1;
+        auto readMipLevel = bFirst ? depthAttachment : highZRenderTarget->GetMipLevel((uint32_t)i);
+        auto writeMipLevel = highZRenderTarget->GetMipLevel((uint32_t)(i + 1));
+        PushConstantsDownscale params {};
+        params.m_outputSize[0] = (float)writeMipLevel->GetExtent().x; params.m_outputSize[1] = (float)writeMipLevel->GetExtent().y;
+        commands->ImageMemoryBarrier(commandList, readMipLevel, EImageLayout::ShaderReadOnlyOptimal);
+        commands->ImageMemoryBarrier(commandList, writeMipLevel, EImageLayout::ComputeWrite);
+        commands->Dispatch(commandList, m_pComputeDepthHighZShader, (uint32_t)std::ceil(params.m_outputSize[0] / 8), (uint32_t)std::ceil(params.m_outputSize[1] / 8), 1u,
+                           { bFirst ? m_computePrepassDepthHighZBindings : m_computeDepthHighZBindings[(size_t)i] }, &params, sizeof(PushConstantsDownscale));
+    }
+    commands->EndDebugRegion(commandList);
+}
+
+void DepthHighZNode::Clear()
+{
+    m_pComputeDepthHighZShader.Clear();
+    m_computeDepthHighZBindings.clear();
+    m_computePrepassDepthHighZBindings.Clear();
 }
 
 // ---- LinearizeDepthNode (FrameGraph/LinearizeDepthNode.cpp:18-109) -------------------------------------------------------------

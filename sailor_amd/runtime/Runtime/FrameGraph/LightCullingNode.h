@@ -80,4 +80,21 @@ protected:
     bool m_bIsDirty = false;
 };
 
+// The Hi-Z pyramid builder: Runtime/FrameGraph/DepthHighZNode.h.  Resources: "src" = the (half-resolution) depth target, "dst" = the
+// DepthHighZ render target with its mip chain (DefaultRenderer.renderer:51-57, :213-217).
+class DepthHighZNode : public TFrameGraphNode<DepthHighZNode> {
+public:
+    static const char* GetName() { return m_name; }
+    void Process(RHIFrameGraphPtr frameGraph, RHI::RHICommandListPtr transferCommandList, RHI::RHICommandListPtr commandList,
+                 const RHI::RHISceneViewSnapshot& sceneView) override;
+    void Clear() override;
+
+protected:
+    struct PushConstantsDownscale { float m_outputSize[2]; }; // DepthHighZNode.h
+    static const char* m_name;
+    RHI::RHIShaderPtr m_pComputeDepthHighZShader;
+    TVector<RHI::RHIShaderBindingSetPtr> m_computeDepthHighZBindings;
+    RHI::RHIShaderBindingSetPtr m_computePrepassDepthHighZBindings;
+};
+
 } // namespace Sailor::Framegraph

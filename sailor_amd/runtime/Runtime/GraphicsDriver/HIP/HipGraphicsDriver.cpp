@@ -93,14 +93,35 @@ RHITexturePtr RHI::RHITexture::GetMipLevel(uint32_t mipLevel) const
 {
     auto v = RHITexturePtr::Make();
     v->m_buffer = m_buffer; v->m_format = m_format; v->m_bCubemap = m_bCubemap; v->m_mipLevels = 1;
-    const int sz = (m_extent.x >> mipLevel) > 1 ? (m_extent.x >> mipLevel) : 1;
-    v->m_extent = { sz, sz };
+    v->m_extent = { (m_extent.x >> mipLevel) > 1 ? (m_extent.x >> mipLevel) : 1, (m_extent.y >> mipLevel) > 1 ? (m_extent.y >> mipLevel) : 1 };
     v->m_viewLevel = mipLevel;
     v->m_parent = RHITexturePtr(const_cast<RHI::RHITexture*>(this));
     return v;
 }
 
-RHITexturePtr HipGraphicsDriver::CreateRenderTarget(ivec2 extent, uint32_t, EFormat format) { return CreateTexture(nullptr, 0, extent, format); }
+RHITexturePtr HipGraphicsDriver::CreateRenderTarget(ivec2 extent, uint32_t mipLevels, EFormat format)
+{
+    if (mipLevels <= 1) return CreateTexture(nullptr, 0, extent, format);
+    auto t = RHITexturePtr::Make(); // a mip chain: level-major, like the cubemaps
+    t->m_extent = extent; t->m_format = format; t->m_mipLevels = mipLevels;
+    size_t texels = 0;
+    for (uint32_t l = 0; l < mipLevels; l++) texels += (size_t)((extent.x >> l) > 1 ? (extent.x >> l) : 1) * ((extent.y >> l) > 1 ? (extent.y >> l) : 1);
+    t->m_buffer = CreateBuffer(texels * texel_size(format));
+    return t->m_buffer ? t : RHITexturePtr();
+}
+
+// device address of a texture or of a mip-level view (RHITexture::GetMipLevel)
+static void* texels_of(const RHITexturePtr& t)
+{
+    if (!t || !t->m_buffer) return nullptr;
+    char* base = (char*)t->m_buffer->m_hip.m_devicePtr;
+    if (!t->m_parent) return base;
+    const auto& p = t->m_parent;
+    size_t texels = 0;
+    for (uint32_t l = 0; l < t->m_viewLevel; l++)
+        texels += (size_t)(p->m_bCubemap ? 6 : 1) * ((p->m_extent.x >> l) > 1 ? (p->m_extent.x >> l) : 1) * ((p->m_extent.y >> l) > 1 ? (p->m_extent.y >> l) : 1);
+    return base + texels * texel_size(p->m_format);
+}
 
 RHICubemapPtr HipGraphicsDriver::CreateCubemap(ivec2 extent, uint32_t mipLevels, EFormat format)
 {
@@ -252,10 +273,12 @@ void HipGraphicsDriver::Dispatch(RHICommandListPtr cmd, RHIShaderPtr computeShad
     const std::string name = computeShader->m_name;
     // The workgroup grid of the reference dispatch (numTiles.x, numTiles.y, 1) is implied by the push constants; the HIP
     // kernels choose their own launch geometry.
-    cmd->m_hip.m_commands.push_back([this, name, bindings, pc = std::move(pc)]() {
+    const bool occlusion = computeShader->HasDefine("OCCLUSION_CULLING"); // RenderSceneNode.cpp:130 loads the culling shader with it
+    cmd->m_hip.m_commands.push_back([this, name, bindings, occlusion, pc = std::move(pc)]() {
         if (name == "Shaders/ComputeLightCulling.shader") return RecordLightCulling(bindings, pc);
         if (name == "Shaders/Standard.shader") return RecordShade(bindings);
-        if (name == "Shaders/ComputeMeshCulling.shader") return RecordMeshCulling(bindings, pc);
+        if (name == "Shaders/ComputeMeshCulling.shader") return RecordMeshCulling(bindings, pc, occlusion);
+        if (name == "Shaders/ComputeDepthHighZ.shader") return RecordDepthHighZ(bindings);
         if (name == "Shaders/ComputeBrdfLut.shader") return RecordBrdfLut(bindings);
         if (name == "Shaders/ComputeIrradianceMap.shader") return RecordIrradianceMap(bindings);
         if (name == "Shaders/ComputeEnvMap_IBL.shader") return RecordEnvPrefilter(bindings, pc);
@@ -466,11 +489,20 @@ int HipGraphicsDriver::RecordEnvPrefilter(const TVector<RHIShaderBindingSetPtr>&
                                           (int32_t)raw->m_mipLevels, (int32_t)view->m_viewLevel, roughness);
 }
 
-int HipGraphicsDriver::RecordMeshCulling(const TVector<RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pcBytes)
+int HipGraphicsDriver::RecordDepthHighZ(const TVector<RHIShaderBindingSetPtr>& bindings)
+{
+    // ComputeDepthHighZ.shader:11-17: inputDepth (sampler, reduction Min), outputDepth (storage image), push constant outputSize = the output extent
+    auto src = texture_of(bindings, "inputDepth"), dst = texture_of(bindings, "outputDepth");
+    if (!src || !dst || src->m_format != EFormat::R32_SFLOAT || dst->m_format != EFormat::R32_SFLOAT) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    return sailor_hip_hiz_downscale(m_ctx, (const float*)texels_of(src), src->GetExtent().x, src->GetExtent().y, (float*)texels_of(dst), dst->GetExtent().x,
+                                    dst->GetExtent().y);
+}
+
+int HipGraphicsDriver::RecordMeshCulling(const TVector<RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pcBytes, bool occlusion)
 {
     // ComputeMeshCulling.shader:13-18 push constants {numBatches, numInstances, firstInstanceIndex}; the Dispatch binds
-    // { depthHighZ, data, drawIndexedIndirect, frame } (RenderSceneNode.cpp:265,335; DepthPrepassNode.cpp:290) -- looked up by name,
-    // the Hi-Z set is not used (frustum-only build of the shader)
+    // { depthHighZ, data, drawIndexedIndirect, frame } (RenderSceneNode.cpp:265,335; DepthPrepassNode.cpp:290) -- looked up by name.
+    // The Hi-Z set is used when the shader was created with its OCCLUSION_CULLING define (RenderSceneNode.cpp:130).
     if (bindings.size() < 2 || pcBytes.size() < 12) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     uint32_t pc[3];
     memcpy(pc, pcBytes.data(), 12);
@@ -486,10 +518,19 @@ int HipGraphicsDriver::RecordMeshCulling(const TVector<RHIShaderBindingSetPtr>& 
     if (!frameB || frameB->m_hostCopy.size() < sizeof(SailorUboFrameData)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     SailorUboFrameData frame;
     memcpy(&frame, frameB->m_hostCopy.data(), sizeof frame);
-    if (!batches || pc[0] == 0) return sailor_hip_mesh_frustum_cull(m_ctx, &frame, (SailorPerInstanceData*)data, pc[1], pc[2]);
+    SailorHiZDesc hiz {};
+    const SailorHiZDesc* pHiz = nullptr;
+    if (occlusion) {
+        auto pyramid = texture_of(bindings, "depthHighZ");
+        if (!pyramid || pyramid->m_format != EFormat::R32_SFLOAT || pyramid->m_parent) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+        hiz.pyramid = (const float*)pyramid->m_buffer->m_hip.m_devicePtr;
+        hiz.width = pyramid->GetExtent().x; hiz.height = pyramid->GetExtent().y; hiz.levels = (int32_t)pyramid->GetMipLevels();
+        pHiz = &hiz;
+    }
+    if (!batches || pc[0] == 0) return sailor_hip_mesh_cull_flags(m_ctx, &frame, (SailorPerInstanceData*)data, pc[1], pc[2], pHiz);
     const size_t need = sailor_hip_mesh_cull_workspace_bytes(pc[1], pc[0]);
     if (!m_meshCullWorkspace || m_meshCullWorkspace->m_size < need) m_meshCullWorkspace = CreateBuffer(need);
     if (!m_meshCullWorkspace) return SAILOR_HIP_ERR_OUT_OF_MEMORY;
-    return sailor_hip_mesh_cull_compact(m_ctx, &frame, (SailorPerInstanceData*)data, pc[1], pc[2], (SailorDrawIndexedIndirectData*)batches, pc[0],
-                                        m_meshCullWorkspace->m_hip.m_devicePtr, m_meshCullWorkspace->m_size);
+    return sailor_hip_mesh_cull_compact_ex(m_ctx, &frame, (SailorPerInstanceData*)data, pc[1], pc[2], (SailorDrawIndexedIndirectData*)batches, pc[0],
+                                           m_meshCullWorkspace->m_hip.m_devicePtr, m_meshCullWorkspace->m_size, pHiz);
 }

@@ -6,6 +6,7 @@
 //   "Shaders/Standard.shader"            -> sailor_hip_shade             (binding contract: Standard.shader:180-251)
 //   "Shaders/ComputeMeshCulling.shader"  -> sailor_hip_mesh_cull_compact (binding contract: ComputeMeshCulling.shader:37-58;
 //                                           sailor_hip_mesh_frustum_cull when no indirect buffer is bound)
+//   "Shaders/ComputeDepthHighZ.shader"   -> sailor_hip_hiz_downscale     (binding contract: ComputeDepthHighZ.shader:11-17)
 //   "Shaders/ComputeBrdfLut.shader" / "ComputeIrradianceMap.shader" / "ComputeEnvMap_IBL.shader" (EnvironmentNode's one-off Dispatches)
 //                                        -> sailor_hip_compute_brdf_lut / _compute_irradiance_map / _prefilter_env_level
 // and the one full-screen DRAW in front of the path (6 indices with the material of)
@@ -77,7 +78,8 @@ private:
     int RecordBrdfLut(const TVector<RHI::RHIShaderBindingSetPtr>& bindings);
     int RecordIrradianceMap(const TVector<RHI::RHIShaderBindingSetPtr>& bindings);
     int RecordEnvPrefilter(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pc);
-    int RecordMeshCulling(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pc);
+    int RecordMeshCulling(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const TVector<uint8_t>& pc, bool occlusion);
+    int RecordDepthHighZ(const TVector<RHI::RHIShaderBindingSetPtr>& bindings);
     int RecordLinearizeDepth(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const RHI::RHITexturePtr& target);
     int RecordEvsmBlur(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const RHI::RHITexturePtr& target, bool vertical);
 

@@ -20,6 +20,7 @@ struct SailorRuntime {
     RHIFrameGraph graph;
     RHISceneViewSnapshot snapshot;
     FrameGraphNodePtr lightCulling, renderScene, linearizeDepth, environment;
+    RHITexturePtr depthHighZ;
     RHITexturePtr depth, rawDepth;
     RHIBufferPtr surface, radiance;
     std::unique_ptr<EcsSweepSystem> sweep;
@@ -43,7 +44,7 @@ RT_API void sailor_rt_destroy(SailorRuntime* rt)
     rt->graph.Clear();
     rt->sweep.reset();
     rt->lighting.reset();
-    rt->depth.Clear(); rt->surface.Clear(); rt->radiance.Clear();
+    rt->depth.Clear(); rt->surface.Clear(); rt->radiance.Clear(); rt->depthHighZ.Clear();
     rt->lightCulling.Clear(); rt->renderScene.Clear(); rt->linearizeDepth.Clear(); rt->environment.Clear(); rt->rawDepth.Clear();
     rt->snapshot = RHISceneViewSnapshot();
     delete rt;
@@ -238,8 +239,12 @@ RT_API int sailor_rt_gpu_culling(SailorRuntime* rt, void* instancesDevicePtr, ui
     auto commands = Renderer::GetDriverCommands();
     auto transferCmdList = driver->CreateCommandList();
     rt->graph.FillFrameData(transferCmdList, rt->snapshot, rt->snapshot.m_deltaTime, rt->snapshot.m_currentTime);
-    auto computeCullingShader = driver->CreateShader("Shaders/ComputeMeshCulling.shader");
-    auto computeMeshCullingBindings = driver->CreateShaderBindings(); // would hold the Hi-Z pyramid: not used by the frustum-only build
+    // RenderSceneNode.cpp:126-139: the shader is loaded with its OCCLUSION_CULLING define and the node's "depthHighZ" attachment is bound as a sampler
+    // (here: when sailor_rt_build_depth_highz has produced a pyramid; otherwise the frustum-only build)
+    auto computeCullingShader = rt->depthHighZ ? driver->CreateShader("Shaders/ComputeMeshCulling.shader", { "OCCLUSION_CULLING" })
+                                               : driver->CreateShader("Shaders/ComputeMeshCulling.shader");
+    auto computeMeshCullingBindings = driver->CreateShaderBindings();
+    if (rt->depthHighZ) driver->AddSamplerToShaderBindings(computeMeshCullingBindings, "depthHighZ", rt->depthHighZ, 0);
     auto perInstanceData = driver->CreateShaderBindings();
     perInstanceData->GetOrAddShaderBinding("data")->m_buffer = hip->WrapBuffer(instancesDevicePtr, (size_t)(firstInstanceIndex + numInstances) * sizeof(SailorPerInstanceData));
     auto indirectCommandBufferBinding = driver->CreateShaderBindings();
@@ -254,6 +259,27 @@ RT_API int sailor_rt_gpu_culling(SailorRuntime* rt, void* instancesDevicePtr, ui
                        { computeMeshCullingBindings, perInstanceData, indirectCommandBufferBinding, rt->snapshot.m_frameBindings }, &constants, sizeof constants);
     commands->EndDebugRegion(transferCmdList);
     driver->SubmitCommandList(transferCmdList);
+    return hip->GetLastDispatchStatus();
+}
+
+// DefaultRenderer.renderer's DepthHighZ target (R32_SFLOAT, mips, reduction Min) + one run of the DepthHighZ node over a wrapped depth image.
+// The pyramid stays bound for the following sailor_rt_gpu_culling calls; levels <= 0 drops it again.
+RT_API int sailor_rt_build_depth_highz(SailorRuntime* rt, void* depthDevicePtr, int depthWidth, int depthHeight, int width, int height, int levels, void** outPyramid)
+{
+    auto* hip = static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver());
+    auto driver = Renderer::GetDriver();
+    if (levels <= 0) { rt->depthHighZ.Clear(); return 0; }
+    auto node = FrameGraphBuilder::CreateNode("DepthHighZ");
+    if (!node) return -1;
+    rt->depthHighZ = driver->CreateRenderTarget({ width, height }, (uint32_t)levels, EFormat::R32_SFLOAT);
+    if (!rt->depthHighZ) return -1;
+    node->SetRHIResource("src", hip->WrapTexture(depthDevicePtr, { depthWidth, depthHeight }, EFormat::R32_SFLOAT));
+    node->SetRHIResource("dst", rt->depthHighZ);
+    auto cmd = driver->CreateCommandList();
+    node->Process(&rt->graph, cmd, cmd, rt->snapshot);
+    driver->SubmitCommandList(cmd);
+    node->Clear();
+    if (outPyramid) *outPyramid = rt->depthHighZ->m_buffer->m_hip.m_devicePtr;
     return hip->GetLastDispatchStatus();
 }
 

@@ -42,6 +42,7 @@ def load() -> C.CDLL:
         rt.sailor_rt_set_sky_cubemap.argtypes = [P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, C.c_int]
         rt.sailor_rt_sampler.restype = P
         rt.sailor_rt_sampler.argtypes = [P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        rt.sailor_rt_build_depth_highz.argtypes = [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(P)]
         rt.sailor_rt_gpu_culling.argtypes = [P, P, C.c_uint32, C.c_uint32, P, C.c_uint32]
         rt.sailor_rt_process_frame.argtypes = [P]
         rt.sailor_rt_wait_idle.argtypes = [P]
@@ -105,6 +106,13 @@ class Runtime:
         w, h, l = C.c_int(0), C.c_int(0), C.c_int(0)
         p = self.rt.sailor_rt_sampler(self.h, name.encode(), C.byref(w), C.byref(h), C.byref(l))
         return p, w.value, h.value, l.value
+
+    def build_depth_highz(self, depth, width, height, levels):
+        """run the DepthHighZ node over a float32 [h, w] device tensor; returns (status, device pointer of the level-major pyramid)"""
+        p = C.c_void_p()
+        st = self.rt.sailor_rt_build_depth_highz(self.h, depth.data_ptr() if depth is not None else None, depth.shape[1] if depth is not None else 0,
+                                                 depth.shape[0] if depth is not None else 0, width, height, levels, C.byref(p))
+        return st, p.value
 
     def gpu_culling(self, instances, num_instances, first_instance, batches, num_batches):
         """the "GPU Culling" Dispatch of RHIRecordDrawCallGPUCulling over uint8 / int32 device tensors, in place"""

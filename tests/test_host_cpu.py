@@ -201,6 +201,7 @@ def test_cpp_runtime_registers_the_reference_node_names_and_refuses_to_run_witho
     assert rt.sailor_rt_node_registered(b"RenderScene") == 1    # FrameGraph/RenderSceneNode.cpp:19
     assert rt.sailor_rt_node_registered(b"LinearizeDepth") == 1  # FrameGraph/LinearizeDepthNode.cpp:19
     assert rt.sailor_rt_node_registered(b"Environment") == 1     # FrameGraph/EnvironmentNode.cpp:19
+    assert rt.sailor_rt_node_registered(b"DepthHighZ") == 1      # FrameGraph/DepthHighZNode.cpp:18
     assert rt.sailor_rt_node_registered(b"Bloom") == 0          # out of scope
     if not torch.cuda.is_available():
         with pytest.raises(_lib.SailorHipError):

@@ -4,6 +4,7 @@ import ctypes as C
 
 import numpy as np
 import pytest
+import torch
 
 from sailor_amd import _lib, host, synth
 from sailor_amd.forward_plus import MeshCull
@@ -98,3 +99,58 @@ def test_argument_errors(ctx):
     rc = lib.sailor_hip_mesh_cull_compact(ctx.handle, C.byref(cam.frame), mc.instances.data_ptr(), 100, 0, None, 3,
                                           mc.workspace.data_ptr(), mc._ws_bytes)
     assert rc == -1
+
+
+# ---- the shader as shipped: OCCLUSION_CULLING against the Hi-Z pyramid ------------------------------------------------------------
+def _depth_and_pyramid(cam, w, h, levels, seed=5):
+    lin = synth.make_linear_depth(w, h, seed, d_min=200.0, d_max=2500.0)
+    raw = synth.make_raw_depth(lin, cam.frame.cameraZNearZFar[0])
+    return raw
+
+
+@pytest.mark.parametrize("shape", [((540, 960), 960, 960, 10), ((67, 131), 131, 131, 8), ((300, 500), 250, 250, 8), ((64, 64), 64, 64, 7)])
+def test_hiz_pyramid_matches_the_oracle_bit_for_bit(ctx, shape):
+    """DepthHighZNode's loop: mip 0 from the half-resolution depth (DefaultRenderer.renderer: DepthHighZ is ViewportWidth/2 squared, so the first
+    step is not 2:1), every further mip from the previous; ragged sizes exercise the zero-weight and clamp rules of the min sampler."""
+    from sailor_amd.forward_plus import hiz_build
+    (dh, dw), w, h, levels = shape
+    cam = synth.make_camera(1920, 1080)
+    raw = _depth_and_pyramid(cam, dw, dh, levels)
+    got = hiz_build(ctx, torch.from_numpy(raw).to(ctx.device), w, h, levels).cpu().numpy()
+    ref = oracle.hiz_build(raw, w, h, levels)
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_occlusion_flags_and_compaction_with_the_pyramid(ctx):
+    from sailor_amd.forward_plus import hiz_build
+    W, H, levels = 1920, 1080, 10
+    cam = synth.make_camera(W, H)
+    raw = _depth_and_pyramid(cam, W // 2, H // 2, levels)
+    pyr = hiz_build(ctx, torch.from_numpy(raw).to(ctx.device), W // 2, W // 2, levels)
+    ref_pyr = oracle.hiz_build(raw, W // 2, W // 2, levels)
+    s = synth.make_instance_set(50000, 300, first_instance=5)
+    mc = MeshCull(ctx, s.instances, s.batches)
+    mc.run(cam.frame, 50000, 5, hiz=(pyr, W // 2, W // 2, levels))
+    got_i, got_b = mc.download()
+    ref_i, ref_b = oracle.mesh_cull_compact(cam.frame, s.instances, 50000, 5, s.batches, hiz=(ref_pyr, W // 2, W // 2, levels))
+    np.testing.assert_array_equal(got_b, ref_b)
+    np.testing.assert_array_equal(got_i.view(np.uint32).reshape(-1, 24), ref_i.view(np.uint32).reshape(-1, 24))
+    frustum_only = oracle.mesh_frustum_cull(cam.frame, s.instances[5:])["isCulled"]
+    with_hiz = oracle.mesh_cull_occlusion(cam.frame, s.instances[5:], ref_pyr, W // 2, W // 2, levels)["isCulled"]
+    assert ((frustum_only == 1) <= (with_hiz == 1)).all() and int(with_hiz.sum()) > int(frustum_only.sum()) + 1000
+    assert 0 < int(ref_b[:, 1].sum()) < 50000 - int(frustum_only.sum())
+
+
+def test_occlusion_1m_instances(ctx):
+    from sailor_amd.forward_plus import hiz_build
+    W, H, levels = 3840, 2160, 11
+    cam = synth.make_camera(W, H)
+    raw = _depth_and_pyramid(cam, W // 2, H // 2, levels, seed=9)
+    pyr = hiz_build(ctx, torch.from_numpy(raw).to(ctx.device), W // 2, W // 2, levels)
+    s = synth.make_instance_set(1 << 20, 4096)
+    mc = MeshCull(ctx, s.instances, s.batches)
+    mc.run(cam.frame, hiz=(pyr, W // 2, W // 2, levels))
+    got_i, got_b = mc.download()
+    ref_i, ref_b = oracle.mesh_cull_compact(cam.frame, s.instances, 1 << 20, 0, s.batches, hiz=(pyr.cpu().numpy(), W // 2, W // 2, levels))
+    np.testing.assert_array_equal(got_b, ref_b)
+    np.testing.assert_array_equal(got_i.view(np.uint32).reshape(-1, 24), ref_i.view(np.uint32).reshape(-1, 24))

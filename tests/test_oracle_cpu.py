@@ -345,3 +345,29 @@ def test_env_prefilter_mip_selection_and_sampling_vector():
     assert np.all(np.abs(top[0, :3] - out[:3]) < 0.5 * np.abs(out[:3]) + 0.2)
     spread = [np.ptp(env[offs[l]:offs[l + 1]].reshape(-1, 4)[:, 0]) for l in range(1, ibl.env_levels - 1)]
     assert all(a >= b for a, b in zip(spread, spread[1:]))
+
+
+def test_hiz_min_pyramid_and_occlusion_semantics():
+    """ComputeDepthHighZ with the min-reduction sampler: 2:1 steps are the min of each 2 x 2 quad, every level's minimum is the image's; a texel
+    centre hit (weight exactly 0 on the neighbours) returns that texel alone; OcclusionCulling only ever adds to the frustum result, and a
+    pyramid of zeros (nothing drawn: reversed-Z far plane) occludes nothing."""
+    rng = np.random.default_rng(3)
+    img = rng.random((64, 64), dtype=np.float32) + np.float32(0.1)
+    pyr = oracle.hiz_build(img, 64, 64, 7)
+    offs, total = oracle.hiz_level_offsets(64, 64, 7)
+    assert total == sum((64 >> l) ** 2 for l in range(7))
+    np.testing.assert_array_equal(pyr[:64 * 64].reshape(64, 64), img)  # same size: every sample sits on a texel centre
+    l1 = pyr[offs[1]:offs[2]].reshape(32, 32)
+    np.testing.assert_array_equal(l1, img.reshape(32, 2, 32, 2).min(axis=(1, 3)))
+    for l in range(7):
+        assert pyr[offs[l]:(offs[l + 1] if l < 6 else total)].min() == img.min()
+    # upsampling step (the reference's first step: W/2 x H/2 depth into a W/2 x W/2 target)
+    tall = oracle.hiz_build(img[:32], 64, 64, 1).reshape(64, 64)
+    assert tall.min() == img[:32].min() and tall.max() <= img[:32].max()
+    cam = synth.make_camera(1280, 720)
+    s = synth.make_instance_set(5000, 10)
+    frustum = oracle.mesh_frustum_cull(cam.frame, s.instances)["isCulled"]
+    zeros = oracle.mesh_cull_occlusion(cam.frame, s.instances, np.zeros(total, np.float32), 64, 64, 7)["isCulled"]
+    np.testing.assert_array_equal(zeros, frustum)
+    near = oracle.mesh_cull_occlusion(cam.frame, s.instances, np.full(total, 1.0, np.float32), 64, 64, 7)["isCulled"]  # an occluder on the near plane
+    assert ((frustum == 1) <= (near == 1)).all() and near.sum() > frustum.sum()

@@ -239,3 +239,42 @@ def test_environment_node_bakes_the_ibl_inputs_of_the_ambient_term():
         assert (err <= 3e-4 * np.abs(ref) + 1e-5).all(), err.max()  # the ambient inputs themselves carry 1e-4 (summation order of the bake)
     finally:
         rt.close()
+
+
+def test_depth_highz_node_and_the_shipped_culling_shader():
+    """DepthHighZNode::Process (one ComputeDepthHighZ Dispatch per mip, bindings inputDepth / outputDepth on mip views) builds the pyramid bit for
+    bit as the oracle; the culling Dispatch with the OCCLUSION_CULLING define and the "depthHighZ" sampler then gives FrustumCulling ||
+    OcclusionCulling + the compaction (RenderSceneNode.cpp:126-139, Batch.hpp:177-188)."""
+    W, H, levels = 1280, 720, 9
+    cam = synth.make_camera(W, H)
+    lin = synth.make_linear_depth(W // 2, H // 2, 5, d_min=200.0, d_max=2500.0)
+    raw = synth.make_raw_depth(lin, cam.frame.cameraZNearZFar[0])
+    s = synth.make_instance_set(12000, 50)
+    rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        rt.set_camera(cam)
+        depth = torch.from_numpy(raw).cuda()
+        st, ptr = rt.build_depth_highz(depth, W // 2, W // 2, levels)
+        assert st == 0 and ptr
+        rt.wait_idle()
+        ref_pyr = oracle.hiz_build(raw, W // 2, W // 2, levels)
+        np.testing.assert_array_equal(read_u32(ptr, ref_pyr.size * 4), ref_pyr.view(np.uint32))
+        inst = torch.from_numpy(s.instances.view(np.uint8).reshape(-1).copy()).cuda()
+        batches = torch.from_numpy(s.batches.view(np.int32).copy()).cuda()
+        assert rt.gpu_culling(inst, 12000, 0, batches, 50) == 0
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        ref_i, ref_b = oracle.mesh_cull_compact(cam.frame, s.instances, 12000, 0, s.batches, hiz=(ref_pyr, W // 2, W // 2, levels))
+        np.testing.assert_array_equal(batches.cpu().numpy().view(np.uint32), ref_b)
+        np.testing.assert_array_equal(inst.cpu().numpy().view(np.uint32).reshape(-1, 24), ref_i.view(np.uint32).reshape(-1, 24))
+        _, frustum_b = oracle.mesh_cull_compact(cam.frame, s.instances, 12000, 0, s.batches)
+        assert int(ref_b[:, 1].sum()) < int(frustum_b[:, 1].sum())
+        assert rt.build_depth_highz(None, 0, 0, 0)[0] == 0  # drop the pyramid: frustum-only build again
+        inst2 = torch.from_numpy(s.instances.view(np.uint8).reshape(-1).copy()).cuda()
+        batches2 = torch.from_numpy(s.batches.view(np.int32).copy()).cuda()
+        assert rt.gpu_culling(inst2, 12000, 0, batches2, 50) == 0
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(batches2.cpu().numpy().view(np.uint32), frustum_b)
+    finally:
+        rt.close()
