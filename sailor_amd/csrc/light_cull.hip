@@ -668,6 +668,12 @@ __global__ __launch_bounds__(256) void k1_pack(const uint32_t* __restrict__ tile
     if (tile >= T) return;
     const int lane = threadIdx.x & 63;
     const int blk = tile / SCAN_BLOCK;
+    // everything this wave reads is addressed by the tile index alone: issue it all up front (the staging list speculatively, both halves
+    // of its KEEP slots), so that the only dependent step is the store at the tile's offset
+    const uint32_t* src = tileList + (size_t)tile * KEEP;
+    const uint32_t e0 = src[lane], e1 = src[lane + 64];
+    const uint32_t num = tileNum[tile];
+    const uint32_t prefixInBlock = tilePrefix[tile];
     const bool classes = classPrefix != nullptr;
     uint32_t s = 0, tot = 0, aB = 0, aT = 0, bB = 0, bT = 0; // sums over earlier blocks / all blocks: entries, class A tiles, class B tiles
     for (int i = lane; i < sumBlocks; i += 64) {
@@ -688,8 +694,7 @@ __global__ __launch_bounds__(256) void k1_pack(const uint32_t* __restrict__ tile
             bB += (uint32_t)__shfl_xor((int)bB, d); bT += (uint32_t)__shfl_xor((int)bT, d);
         }
     }
-    const uint32_t offset = s + tilePrefix[tile] + 1u;
-    const uint32_t num = tileNum[tile];
+    const uint32_t offset = s + prefixInBlock + 1u;
     if (lane == 0) { grid[tile].offset = offset; grid[tile].num = num; }
     if (classes && lane == 0) {
         // the order hint: long lists first (their blocks run longest; started last they are the tail of the shade launch), each class in
@@ -701,9 +706,8 @@ __global__ __launch_bounds__(256) void k1_pack(const uint32_t* __restrict__ tile
         tileOrder[pos] = (uint32_t)(tile % Tx) | ((uint32_t)(tile / Tx) << 16);
         if (tile == 0) tileOrder[T] = aT + bT; // how many entries of the order hold >= CLASS_B lights (the shade's split blocks)
     }
-    const uint32_t* src = tileList + (size_t)tile * KEEP;
-    for (uint32_t i = lane; i < num; i += 64)
-        if (offset + i < capacity) culled[offset + i] = src[i];
+    if ((uint32_t)lane < num && offset + lane < capacity) culled[offset + lane] = e0;
+    if ((uint32_t)lane + 64u < num && offset + lane + 64u < capacity) culled[offset + lane + 64u] = e1;
     if (tile == 0 && lane == 0) culled[0] = tot;
 }
 

@@ -370,7 +370,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const unsigned long long forceMask = __ballot(active && !brdfFinite); // such pixels must see every light (0 * NaN)
     // survivors by kind: [0,1] finite point lights, [2,3] finite spot lights, [4,5] the rest (directional, unknown type,
     // non-finite intensity: every pixel is a pair) -- for list slots 0..63 and 64..127
-    unsigned long long seg[6] = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull };
+    unsigned long long seg[8] = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull }; // [6,7]: directional lights (type 0), see the loop behind the queue
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         if ((uint32_t)(h * 64) >= numLights) break;
@@ -393,13 +393,14 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         const unsigned long long all = __ballot(keep);
         seg[h] = __ballot(keep && fin && (bits & 0xFFu) == 1u);
         seg[2 + h] = __ballot(keep && fin && (bits & 0xFFu) == 2u);
-        seg[4 + h] = all & ~(seg[h] | seg[2 + h]);
+        seg[6 + h] = __ballot(li < numLights && (bits & 0xFFu) == 0u);
+        seg[4 + h] = all & ~(seg[h] | seg[2 + h] | seg[6 + h]);
     }
 
     if (BAND && splitRole) { // this wave's share of the list: every fourth slot
         const unsigned long long share = 0x1111111111111111ull << __builtin_amdgcn_readfirstlane(wave); // (scalar: the masks stay in SGPRs)
 #pragma unroll
-        for (int q = 0; q < 6; q++) seg[q] &= share;
+        for (int q = 0; q < 8; q++) seg[q] &= share;
     }
 
     // ---- 2 + 3. queue the (pixel, light) pairs that can be lit, then shade them one LANE per PAIR ----
@@ -469,7 +470,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
             const uint32_t s = (e >> 6) & (uint32_t)(KEEP - 1);
             const float4* R = sL + s * LREC;
 #define PULL(x) __int_as_float(__builtin_amdgcn_ds_bpermute(pa, __float_as_int(x)))
-            float falloff = 1.0f, shadow = 1.0f;
+            float falloff = 1.0f;
             const float4 r3 = R[3];
             const float pwx = PULL(wx), pwy = PULL(wy), pwz = PULL(wz);
             if (valid) {
@@ -505,11 +506,6 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                 const float pkr = HAS_IBL ? PULL(roughness) : PULL(k); // the ambient term at the end needs the roughness itself: pull it, derive k
                 const float pk = HAS_IBL ? ((pkr + 1.0f) * (pkr + 1.0f)) * 0.125f : pkr;
                 if (valid) {
-                    if (HAS_CSM) {
-                        const uint32_t bits = __float_as_uint(R[1].w);
-                        if ((bits & 0xFFu) == 0u)
-                            shadow = directional_shadow(A, C, (bits >> 8) & 0xFFu, -r3.x, -r3.y, -r3.z, pnx, pny, pnz, pwx, pwy, pwz);
-                    }
                     // ---- Cook-Torrance (Standard.shader:309-340) ----
                     const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
                     float hx = Lix + pLox, hy = Liy + pLoy, hz = Liz + pLoz;
@@ -524,7 +520,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                     const float D = palphaSq * rcp_fast(3.14159265359f * dn * dn);              // NdfGGX
                     const float G = cosLi * rcp_fast(fmaf(cosLi, 1.0f - pk, pk)) * pg1Lo;      // GeometrySchlickGGX
                     spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * pcosLo));
-                    scale = shadow * cosLi * falloff;
+                    scale = cosLi * falloff; // (shadow = 1: only directional lights are shadowed, and they do not come through the queue)
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -556,6 +552,45 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         }
         if (!overflow) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // ---- directional lights (type 0): every pixel is a pair, so they are shaded one LANE per PIXEL from the pixel's own registers -- no
+    // queue, no pulls -- in list order, nothing skipped (cosLi = 0 and non-finite intensities take their natural course).  K3, their
+    // shadow factor (Standard.shader:266-283), is looked up here: a quadrant's pixels mostly share a cascade, so a wave rarely runs both
+    // the EVSM and the 16-tap PCF path.  (Measured at C4: lookups in the pair pass 0.523 ms, here 0.448 ms; as a pass of their own that
+    // leaves the factors for a 64-register shade kernel, 0.32 + 0.22 ms -- the lookups are bound by the scattered 16-byte texel reads of
+    // the 268 MB moments map, not by the registers around them.)
+    if ((seg[6] | seg[7]) != 0ull) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            unsigned long long todo = seg[6 + h];
+            while (todo) {
+                const int bit = __builtin_ctzll(todo);
+                const float4* R = sL + (uint32_t)(h * 64 + bit) * LREC;
+                const float4 r3 = R[3], r4 = R[4];
+                float shadow = 1.0f;
+                if (HAS_CSM)
+                    shadow = directional_shadow(A, C, (__float_as_uint(R[1].w) >> 8) & 0xFFu, -r3.x, -r3.y, -r3.z, nx, ny, nz, wx, wy, wz);
+                // ---- Cook-Torrance (Standard.shader:309-340), as in the pair pass ----
+                const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
+                float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;
+                const float hinv = 1.0f / sqrtf(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
+                hx *= hinv; hy *= hinv; hz *= hinv;
+                const float cosLi = fmaxf(0.0f, dot3f(nx, ny, nz, Lix, Liy, Liz));
+                const float cosLh = fmaxf(0.0f, dot3f(nx, ny, nz, hx, hy, hz));
+                const float x1 = 1.0f - fmaxf(0.0f, dot3f(hx, hy, hz, Lox, Loy, Loz));
+                const float x2 = x1 * x1, x5 = x2 * x2 * x1;
+                const float dn = (cosLh * cosLh) * (alphaSq - 1.0f) + 1.0f;
+                const float D = alphaSq * rcp_fast(3.14159265359f * dn * dn);
+                const float G = cosLi * rcp_fast(fmaf(cosLi, oneMinusK, k)) * g1Lo;
+                const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * cosLo));
+                const float scale = shadow * cosLi; // falloff = 1 (:287)
+                const float Fx = fmaf(1.0f - F0x, x5, F0x), Fy = fmaf(1.0f - F0y, x5, F0y), Fz = fmaf(1.0f - F0z, x5, F0z);
+                accX += (fmaf(1.0f - Fx, kdAx, Fx * spec) * r4.x) * scale;
+                accY += (fmaf(1.0f - Fy, kdAy, Fy * spec) * r4.y) * scale;
+                accZ += (fmaf(1.0f - Fz, kdAz, Fz * spec) * r4.z) * scale;
+                todo &= todo - 1ull;
+            }
+        }
     }
     if (BAND && splitRole) { // the four partial sums of each pixel: wave 0 + 1 + 2 + 3
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -608,15 +643,21 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     if (active) radiance[(size_t)(py - A.fbRow0) * A.W + gx] = make_float4(accX, accY, accZ, P0.w); // outColor.a = material.albedo.a (:438)
 }
 
-// Entry points: without shadow maps the pair pass fits 64 VGPRs, and the register allocator is told to stay there
+// Entry points: without shadow lookups in it the kernel fits 64 VGPRs, and the register allocator is told to stay there
 // (8 waves per SIMD); with the 16-tap PCF inlined it does not, and forcing it would spill.  The ambient term adds a third.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k2_shade(ShadeArgs A, CsmArgs C, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
-              const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
-{
-    __shared__ ShadeLds lds;
-    k2_shade_body<false, false>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance);
-}
+#define SHADE_ENTRY(NAME, ATTR, CSM, IBL)                                                                                                          \
+    __global__ __launch_bounds__(256) ATTR void NAME(ShadeArgs A, CsmArgs C, IblArgs I, const float4* __restrict__ surface, size_t planeStride,    \
+                                                     const SailorLightShaderData* __restrict__ lights, const SailorLightsGrid* __restrict__ grid, \
+                                                     const uint32_t* __restrict__ culled, float4* __restrict__ radiance)                          \
+    {                                                                                                                                              \
+        __shared__ ShadeLds lds;                                                                                                                   \
+        k2_shade_body<CSM, IBL>(lds, A, C, I, surface, planeStride, lights, grid, culled, radiance);                                               \
+    }
+#define FORCE_64_VGPRS __attribute__((amdgpu_waves_per_eu(8, 8)))
+SHADE_ENTRY(k2_shade, FORCE_64_VGPRS, false, false)
+SHADE_ENTRY(k2_shade_csm, , true, false)
+SHADE_ENTRY(k2_shade_ibl, , false, true)
+SHADE_ENTRY(k2_shade_csm_ibl, , true, true)
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k2_shade_band(ShadeArgs A, CsmArgs C, int bandTiles, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
@@ -632,33 +673,9 @@ void k2_shade_band(ShadeArgs A, CsmArgs C, int bandTiles, const float4* __restri
     for (uint32_t idx = blockIdx.x; idx < limit; idx += (uint32_t)SPLIT_BLOCKS) {
         const uint32_t o = A.order[idx >> 2];
         k2_shade_body<false, false, ROLE_BAND_SPLIT>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, (int)(o & 0xFFFFu), (int)(o >> 16),
-                                                     (int)(idx & 3u));
+                                                           (int)(idx & 3u));
         __syncthreads(); // the LDS arrays are reused by the block's next tile
     }
-}
-
-__global__ __launch_bounds__(256)
-void k2_shade_csm(ShadeArgs A, CsmArgs C, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
-                  const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
-{
-    __shared__ ShadeLds lds;
-    k2_shade_body<true, false>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance);
-}
-
-__global__ __launch_bounds__(256)
-void k2_shade_ibl(ShadeArgs A, CsmArgs C, IblArgs I, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
-                  const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
-{
-    __shared__ ShadeLds lds;
-    k2_shade_body<false, true>(lds, A, C, I, surface, planeStride, lights, grid, culled, radiance);
-}
-
-__global__ __launch_bounds__(256)
-void k2_shade_csm_ibl(ShadeArgs A, CsmArgs C, IblArgs I, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
-                      const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
-{
-    __shared__ ShadeLds lds;
-    k2_shade_body<true, true>(lds, A, C, I, surface, planeStride, lights, grid, culled, radiance);
 }
 
 // ---- ComputeBrdfLut.shader:26-71 (Lighting.glsl:27-37 SampleGGX, :65-70 GeometrySchlickGGX_IBL, Math.glsl:285-293) ----
@@ -751,32 +768,26 @@ extern "C" int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFrameDa
         }
     }
     const dim3 grid((unsigned)A.Tx, (unsigned)(band->tileRowEnd - band->tileRowBegin));
+    IblArgs I {};
     if (ibl) {
         if (!ibl->irradiance || !ibl->env || !ibl->brdfLut || ibl->irrSize <= 0 || ibl->envSize <= 0 || ibl->envLevels <= 0 || ibl->envLevels > 16 ||
             ibl->lutW <= 0 || ibl->lutH <= 0)
             return SAILOR_HIP_ERR_INVALID_ARGUMENT;
         if (((uintptr_t)ibl->irradiance & 15) || ((uintptr_t)ibl->env & 15) || ((uintptr_t)ibl->brdfLut & 7)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-        IblArgs I;
         I.irradiance = (const float4*)ibl->irradiance; I.env = (const float4*)ibl->env; I.brdfLut = (const float2*)ibl->brdfLut; I.ao = ibl->ao;
         I.irrSize = ibl->irrSize; I.envSize = ibl->envSize; I.envLevels = ibl->envLevels; I.lutW = ibl->lutW; I.lutH = ibl->lutH;
-        if (hasCsm)
-            hipLaunchKernelGGL(k2_shade_csm_ibl, grid, dim3(256), 0, ctx->stream, A, C, I, (const float4*)dSurface, surfacePlaneStride,
-                               dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
-        else
-            hipLaunchKernelGGL(k2_shade_ibl, grid, dim3(256), 0, ctx->stream, A, C, I, (const float4*)dSurface, surfacePlaneStride,
-                               dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
-        SAILOR_CHECK_LAUNCH(ctx, "k2_shade_ibl");
-        return SAILOR_HIP_OK;
     }
-    if (hasCsm)
-        hipLaunchKernelGGL(k2_shade_csm, grid, dim3(256), 0, ctx->stream, A, C, (const float4*)dSurface, surfacePlaneStride,
-                           dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
+    const float4* S = (const float4*)dSurface;
+    float4* Rd = (float4*)dRadiance;
+#define LAUNCH_SHADE(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, ctx->stream, A, C, I, S, surfacePlaneStride, dLights, dLightsGrid, dCulledLights, Rd)
+    if (hasCsm && ibl) LAUNCH_SHADE(k2_shade_csm_ibl);
+    else if (hasCsm) LAUNCH_SHADE(k2_shade_csm);
+    else if (ibl) LAUNCH_SHADE(k2_shade_ibl);
     else if (dTileOrder && band->tileRowEnd - band->tileRowBegin < Ty) // a band of a split frame: long tiles are split across four blocks
-        hipLaunchKernelGGL(k2_shade_band, dim3((unsigned)SPLIT_BLOCKS + (unsigned)bandTiles), dim3(256), 0, ctx->stream, A, C, bandTiles,
-                           (const float4*)dSurface, surfacePlaneStride, dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
-    else
-        hipLaunchKernelGGL(k2_shade, grid, dim3(256), 0, ctx->stream, A, C, (const float4*)dSurface, surfacePlaneStride,
-                           dLights, dLightsGrid, dCulledLights, (float4*)dRadiance);
+        hipLaunchKernelGGL(k2_shade_band, dim3((unsigned)SPLIT_BLOCKS + (unsigned)bandTiles), dim3(256), 0, ctx->stream, A, C, bandTiles, S, surfacePlaneStride,
+                           dLights, dLightsGrid, dCulledLights, Rd);
+    else LAUNCH_SHADE(k2_shade);
+#undef LAUNCH_SHADE
     SAILOR_CHECK_LAUNCH(ctx, "k2_shade");
     return SAILOR_HIP_OK;
 }
