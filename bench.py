@@ -56,6 +56,7 @@ def parse():
                     help="2 (the reference's MaxFramesInQueue, RHI/Renderer.h:34): frame k+1's cull is recorded on a second stream beside frame k's shade")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--equal-bands", action="store_true", help="N > 1: equal tile-row bands instead of cost-balanced ones")
+    ap.add_argument("--no-afr", action="store_true", help="N > 1: skip the supplementary alternate-frame-rendering measurement")
     ap.add_argument("--simulate-split", type=int, default=0, help="G: time each band of a cost-balanced G-way split one after the other on this GPU and print the predicted speed-up; diagnostic")
     ap.add_argument("--simulate-band", default=None, help="R/G: time only band R of a G-way split in this single process (no collectives); diagnostic")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the list exchange even with one rank")
@@ -537,13 +538,61 @@ def main():
     b_cull = 20 * N + 4 * band_pixels + 8 * fp.band_tiles + 4 * sum_nt + 4
     evals = int((g[:, 1].astype(np.int64) * 256).sum())
     shade_gbs = b_shade / (shade_ms[0] * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k2_shade", "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
+    shade_kernel = "k2_shade_csm" if csm is not None else ("k2_shade_band" if fp.tile_order and fp.use_tile_order else "k2_shade")
+    roofline = {"bound": "hbm", "kernel": shade_kernel, "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
                 "traffic": measured_traffic("k2_shade" if csm is None else "k2_shade_csm", args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_ms[0], "median_launch_ms": shade_ms[1],
                 "frac_of_measured_copy_peak": shade_gbs / HBM_COPY_GBS,
                 "valu_sidebar": {"pixel_light_evals": evals, "gevals_per_s": evals / (shade_ms[0] * 1e-3) / 1e9,
                                  "note": "~110 fp32 ops per (pixel,light): VALU-bound once mean list length exceeds ~10 (SURVEY.md 7, hard part 2)"},
                 "cull": {"kernels": "k01_prepare+k1_*", "avg_ms": cull_ms[0], "median_ms": cull_ms[1], "bytes": b_cull,
                          "achieved_gbs": b_cull / (cull_ms[0] * 1e-3) / 1e9, "frac": b_cull / (cull_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+
+    # ---- supplementary, N > 1 only: alternate-frame rendering.  The split frame above is latency-bound (a 0.25 ms frame leaves ~30 us
+    # per GPU); the reference keeps two frames in flight (RHI/Renderer.h:34), and whole frames are independent, so a node can also give
+    # every GPU its own frame.  Same step (one cull + one shade of the whole frame) on every rank, K steps, max over ranks; reported next
+    # to `value`, never instead of it.  Every rank takes part in the collectives below whether or not its own set-up succeeded.
+    afr = None
+    if dist is not None and not args.no_afr:
+        ok = 1
+        try:
+            wf = ForwardPlus(ctx, W, H, N)
+            wd = torch.from_numpy(np.ascontiguousarray(frame.depth)).to(dev)
+            ws = torch.from_numpy(frame.surface_rows(0, H)).to(dev)
+
+            def wstep():
+                wf.cull(cam.frame, d_lights, N, wd)
+                wf.shade(cam.frame, ws, d_lights, N, csm)
+            wstep(); torch.cuda.synchronize()
+            wgraph = None
+            if not args.no_graph:
+                try:
+                    wgraph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(wgraph, stream=side):
+                        wstep()
+                except Exception:
+                    wgraph = None
+                    torch.cuda.synchronize()
+        except Exception as e:
+            ok = 0
+            print(f"[bench] rank {rank}: alternate-frame set-up failed ({type(e).__name__}: {e})", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            run = (wgraph.replay if wgraph is not None else wstep)
+            for _ in range(args.warmup):
+                run()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                run()
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            afr_elapsed = float(t.item())
+            afr = {"what": "every GPU renders whole frames of its own (frames are independent; one frame in flight per GPU)", "scaling": "weak",
+                   "value": world * W * H * args.steps / afr_elapsed / 1e6, "unit": "Mpixels/s", "ms_per_frame_per_gpu": afr_elapsed / args.steps * 1e3}
+        else:
+            afr = {"error": "set-up failed on some rank"}
 
     exchange_info = None
     if dist is not None:
@@ -568,6 +617,8 @@ def main():
         }
         if exchange_info:
             out["exchange"] = exchange_info
+        if afr:
+            out["alternate_frame_rendering"] = afr
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frame, args.cpu_sample_tile_rows)
             out["ecs_sweep"] = ecs_baseline(ctx, 1 << 20, 20)
