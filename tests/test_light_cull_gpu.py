@@ -197,3 +197,25 @@ def test_nan_impacts_follow_the_literal_bubble_sort(ctx, flags):
     lit_g, lit_i, _ = oracle.light_cull(f.cam.frame, W, H, lights, f.depth, literal_select=True)
     np.testing.assert_array_equal(ref_i[: 1 + int(ref_i[0])], lit_i[: 1 + int(lit_i[0])])
     assert_lists_equal(gpu_cull(ctx, f.cam, lights, f.depth, flags), ref_g, ref_i)
+
+
+def test_c5_8k_1m_lights_invariants_and_an_oracle_tile_row(ctx):
+    """BASELINE.json configs[4] at full size (7680 x 4320, 1 048 576 lights -- sixteen times the reference's 65 535-light cap): list
+    invariants over all 129 600 tiles and one tile row (480 tiles x 1 M lights) against the oracle."""
+    f = synth.make_frame("C5", with_surface=False)
+    W, H, N = 7680, 4320, 1 << 20
+    g, idx = gpu_cull(ctx, f.cam, f.lights, f.depth, _lib.CULL_DEFAULT)
+    assert g.shape == (480 * 270, 2)
+    num = g[:, 1].astype(np.int64)
+    assert num.max() <= 128 and int(idx[0]) == num.sum() and num.sum() > 0
+    np.testing.assert_array_equal(g[:, 0].astype(np.int64), 1 + np.concatenate([[0], np.cumsum(num)[:-1]]))
+    assert idx[1:1 + int(idx[0])].max() < N
+    for t in np.random.default_rng(1).choice(len(g), 500, replace=False):
+        seg = idx[g[t, 0]: g[t, 0] + g[t, 1]]
+        assert len(np.unique(seg)) == len(seg)
+    r0 = 131
+    og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(r0, r0 + 1), want_counts=True)
+    t0 = r0 * 480
+    np.testing.assert_array_equal(g[t0:t0 + 480, 1], og[:, 1])
+    for t in range(480):
+        np.testing.assert_array_equal(idx[g[t0 + t, 0]: g[t0 + t, 0] + g[t0 + t, 1]], oi[og[t, 0]: og[t, 0] + og[t, 1]])

@@ -152,6 +152,29 @@ def test_linearity_in_light_intensity_at_4k(ctx):
     assert_radiance_close(a[r0:r1], ref[r0:r1])
 
 
+def test_c4_4k_with_cascaded_shadow_maps(ctx):
+    """BASELINE.json configs[3] at full size (C3 + a directional EVSM light over four 4096^2 cascades): shadowing only ever removes light
+    (factor in [0, 1], every term non-negative), two bands reproduce the whole frame bit for bit (the split of configs[3]), and an
+    oracle-checked strip of 16 rows is within tolerance."""
+    f = synth.make_frame("C4")
+    W, H = f.cam.width, f.cam.height
+    whole, fp = gpu_frame(ctx, f)
+    unshadowed, _ = gpu_frame(ctx, f, csm=False)
+    assert np.isfinite(whole).all()
+    assert (whole[..., :3] <= unshadowed[..., :3] * (1 + 1e-5) + 1e-6).all()
+    assert (whole[..., :3] < unshadowed[..., :3] * 0.99).mean() > 0.01, "the directional light is shadowed somewhere"
+    parts = [gpu_frame(ctx, f, band=host.band_for_rank(W, H, r, 2))[0] for r in (1, 0)]  # band 0 = bottom rows
+    np.testing.assert_array_equal(np.concatenate(parts, 0), whole)
+    tr0 = 77
+    og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(tr0, tr0 + 1))
+    grid = np.zeros((240 * 135, 2), np.uint32); grid[:, 0] = 1
+    grid[tr0 * 240:(tr0 + 1) * 240] = og
+    r0, r1 = H - 16 * (tr0 + 1), H - 16 * tr0
+    desc, keep = oracle.make_csm(f.shadows.lights_matrices, f.shadows.maps)
+    ref = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, grid, oi, desc, rows=(r0, r1))
+    assert_radiance_close(whole[r0:r1], ref[r0:r1])
+
+
 def test_tile_order_hint_is_a_permutation_and_long_tiles_are_split(ctx):
     """sailor_hip_light_cull_tile_order (split frames only): every tile of the band exactly once, long lists first (>= 96, then >= 40, then
     the rest, raster order inside a class), followed by the number of tiles in the first two classes.  Shading a band with the hint hands
