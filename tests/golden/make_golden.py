@@ -72,9 +72,37 @@ def make_blur() -> None:
     print(f"tiny_blur: {m.shape}")
 
 
+def make_mesh_cull() -> None:
+    """GPU-culling Dispatch: 3 000 instances in 24 draws behind 9 untouched records, a 96 x 54 raw depth image and its 96 x 96
+    min pyramid; the oracle's pyramid, the instance / indirect buffers after frustum-only and after frustum + occlusion culling with compaction.
+    Inputs regenerate from the frozen generator; outputs are stored (instances as their 24 uint32 words)."""
+    cam = synth.make_camera(640, 360)
+    s = synth.make_instance_set(3000, 24, first_instance=9)
+    lin = synth.make_linear_depth(96, 54, 5, d_min=200.0, d_max=2500.0)
+    raw = synth.make_raw_depth(lin, cam.frame.cameraZNearZFar[0])
+    pyr = oracle.hiz_build(raw, 96, 96, 7)
+    fi, fb = oracle.mesh_cull_compact(cam.frame, s.instances, 3000, 9, s.batches)
+    oi, ob = oracle.mesh_cull_compact(cam.frame, s.instances, 3000, 9, s.batches, hiz=(pyr, 96, 96, 7))
+    np.savez_compressed(OUT / "tiny_mesh_cull.npz", pyramid=pyr, frustum_instances=fi.view(np.uint32).reshape(-1, 24), frustum_batches=fb,
+                        occlusion_instances=oi.view(np.uint32).reshape(-1, 24), occlusion_batches=ob)
+    print(f"tiny_mesh_cull: kept {int(fb[:, 1].sum())} of 3000 after the frustum test, {int(ob[:, 1].sum())} with occlusion")
+
+
+def make_prefilter() -> None:
+    """IBL bake: the synthetic 16 x 16 x 6 sky with 5 mips -> pre-filtered environment cube (every mip) and a 2 x 2 x 6
+    irradiance cube, by the oracle."""
+    sky = synth.make_ibl_set(16, 16, np.zeros((2, 2, 2), np.float32), env_size=16, with_ao=False)
+    env = oracle.prefilter_env_map(sky.env_chain, 16, sky.env_levels)
+    irr = oracle.compute_irradiance_map(env, 16, sky.env_levels, 2)
+    np.savez_compressed(OUT / "tiny_prefilter.npz", env=env, irradiance=irr, raw_checksum=np.float64(sky.env_chain.astype(np.float64).sum()))
+    print(f"tiny_prefilter: env {env.size // 4} texels, irradiance mean {irr[..., :3].mean():.4f}")
+
+
 if __name__ == "__main__":
     for n in ("tiny", "tiny_csm"):
         make(n)
     make_depth()
     make_ibl()
     make_blur()
+    make_mesh_cull()
+    make_prefilter()

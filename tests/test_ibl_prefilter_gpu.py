@@ -67,3 +67,14 @@ def test_prefiltered_cube_feeds_the_ambient_term(ctx):
     _close(env.cpu().numpy(), ref_env)
     err = np.abs(irr.astype(np.float64) - ref_irr)
     assert (err <= 2 * RTOL * np.abs(ref_irr) + ATOL).all()  # second stage: its input already differs by 1e-4
+
+
+def test_golden_fixture_through_the_c_abi(ctx):
+    """tests/golden/tiny_prefilter.npz: the bake of the 16 x 16 x 6 sky against the committed oracle outputs."""
+    from pathlib import Path
+    p = np.load(Path(__file__).resolve().parent / "golden" / "tiny_prefilter.npz")
+    sky = _sky(16)
+    env = prefilter_env_map(ctx, torch.from_numpy(sky.env_chain).to(ctx.device), 16, sky.env_levels)
+    _close(env.cpu().numpy(), p["env"].astype(np.float64))
+    irr = compute_irradiance_map(ctx, torch.from_numpy(p["env"]).to(ctx.device), 16, sky.env_levels, 2).cpu().numpy()
+    _close(irr, p["irradiance"].astype(np.float64))

@@ -154,3 +154,25 @@ def test_occlusion_1m_instances(ctx):
     ref_i, ref_b = oracle.mesh_cull_compact(cam.frame, s.instances, 1 << 20, 0, s.batches, hiz=(pyr.cpu().numpy(), W // 2, W // 2, levels))
     np.testing.assert_array_equal(got_b, ref_b)
     np.testing.assert_array_equal(got_i.view(np.uint32).reshape(-1, 24), ref_i.view(np.uint32).reshape(-1, 24))
+
+
+def test_golden_fixture_through_the_c_abi(ctx):
+    """tests/golden/tiny_mesh_cull.npz: pyramid, frustum-only and occlusion results of the GPU equal the committed vectors."""
+    from pathlib import Path
+    from sailor_amd.forward_plus import hiz_build
+    g = np.load(Path(__file__).resolve().parent / "golden" / "tiny_mesh_cull.npz")
+    cam = synth.make_camera(640, 360)
+    s = synth.make_instance_set(3000, 24, first_instance=9)
+    raw = synth.make_raw_depth(synth.make_linear_depth(96, 54, 5, d_min=200.0, d_max=2500.0), cam.frame.cameraZNearZFar[0])
+    pyr = hiz_build(ctx, torch.from_numpy(raw).to(ctx.device), 96, 96, 7)
+    np.testing.assert_array_equal(pyr.cpu().numpy().view(np.uint32), g["pyramid"].view(np.uint32))
+    mc = MeshCull(ctx, s.instances, s.batches)
+    mc.run(cam.frame, 3000, 9)
+    gi, gb = mc.download()
+    np.testing.assert_array_equal(gi.view(np.uint32).reshape(-1, 24), g["frustum_instances"])
+    np.testing.assert_array_equal(gb, g["frustum_batches"])
+    mc = MeshCull(ctx, s.instances, s.batches)
+    mc.run(cam.frame, 3000, 9, hiz=(pyr, 96, 96, 7))
+    gi, gb = mc.download()
+    np.testing.assert_array_equal(gi.view(np.uint32).reshape(-1, 24), g["occlusion_instances"])
+    np.testing.assert_array_equal(gb, g["occlusion_batches"])

@@ -371,3 +371,25 @@ def test_hiz_min_pyramid_and_occlusion_semantics():
     np.testing.assert_array_equal(zeros, frustum)
     near = oracle.mesh_cull_occlusion(cam.frame, s.instances, np.full(total, 1.0, np.float32), 64, 64, 7)["isCulled"]  # an occluder on the near plane
     assert ((frustum == 1) <= (near == 1)).all() and near.sum() > frustum.sum()
+
+
+def test_mesh_cull_and_prefilter_goldens():
+    """tests/golden/tiny_mesh_cull.npz, tiny_prefilter.npz: the oracle reproduces its committed outputs from the regenerated inputs."""
+    g = np.load(GOLDEN / "tiny_mesh_cull.npz")
+    cam = synth.make_camera(640, 360)
+    s = synth.make_instance_set(3000, 24, first_instance=9)
+    raw = synth.make_raw_depth(synth.make_linear_depth(96, 54, 5, d_min=200.0, d_max=2500.0), cam.frame.cameraZNearZFar[0])
+    pyr = oracle.hiz_build(raw, 96, 96, 7)
+    np.testing.assert_array_equal(pyr.view(np.uint32), g["pyramid"].view(np.uint32))
+    fi, fb = oracle.mesh_cull_compact(cam.frame, s.instances, 3000, 9, s.batches)
+    np.testing.assert_array_equal(fi.view(np.uint32).reshape(-1, 24), g["frustum_instances"])
+    np.testing.assert_array_equal(fb, g["frustum_batches"])
+    oi, ob = oracle.mesh_cull_compact(cam.frame, s.instances, 3000, 9, s.batches, hiz=(pyr, 96, 96, 7))
+    np.testing.assert_array_equal(oi.view(np.uint32).reshape(-1, 24), g["occlusion_instances"])
+    np.testing.assert_array_equal(ob, g["occlusion_batches"])
+    p = np.load(GOLDEN / "tiny_prefilter.npz")
+    sky = synth.make_ibl_set(16, 16, np.zeros((2, 2, 2), np.float32), env_size=16, with_ao=False)
+    assert float(sky.env_chain.astype(np.float64).sum()) == float(p["raw_checksum"])
+    env = oracle.prefilter_env_map(sky.env_chain, 16, sky.env_levels)
+    np.testing.assert_allclose(env, p["env"], rtol=2e-6, atol=1e-7)   # libm's cosf / sinf / log2f may differ in the last bit between hosts
+    np.testing.assert_allclose(oracle.compute_irradiance_map(env, 16, sky.env_levels, 2), p["irradiance"], rtol=2e-6, atol=1e-7)
