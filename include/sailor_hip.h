@@ -247,12 +247,15 @@ SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
                                          const SailorBand* band, uint32_t flags);
 
 /* Shading-order hint.  sailor_hip_light_cull also leaves, in its workspace, the band's tiles ordered by list length class (>= 96, >= 40,
- * rest; tile order inside a class), each as tileX | tileRowInBand << 16.  Handing this pointer to sailor_hip_shade_ex makes the shade
- * launch start its long-running tiles first instead of wherever they fall in raster order (a tile in the middle of a light cluster keeps
- * its block busy ~100x longer than an average one: started late it is the tail of the launch).  Pure scheduling: results do not depend on
- * it.  Produced for split frames only (bands smaller than the frame: there a launch is a round or two of blocks and its longest tile
- * is its duration; on the whole frame the hint measured no gain and is not produced): NULL for the whole-frame band and on bad arguments.
- * Valid until the next sailor_hip_light_cull on the same workspace. */
+ * rest; tile order inside a class), each as tileX | tileRowInBand << 16, followed by one more word: the number of tiles in the first two
+ * classes.  A band of a split frame is a round or two of blocks, so its longest tile is its duration, and a tile in the middle of a light
+ * cluster keeps one block busy ~100x longer than an average one.  Handing this pointer to sailor_hip_shade_ex (band smaller than the
+ * frame, no shadow maps, no ambient term) makes the launch give the tiles of the first two classes to "split" blocks -- one per (tile,
+ * 8x8 quadrant), four waves sharing the quadrant's list -- at the front of the grid.  Lists and every tile with < 40 lights keep their
+ * bits; a split tile's radiance differs from the one-block form by the order of four partial sums per pixel (within the shade tolerance).
+ * With shadow maps or the ambient term the hint only reorders the launch.  Produced for split frames only (on the whole frame neither
+ * the order nor the split measured a gain): NULL for the whole-frame band and on bad arguments.  Valid until the next
+ * sailor_hip_light_cull on the same workspace. */
 SAILOR_HIP_API const uint32_t* sailor_hip_light_cull_tile_order(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band,
                                                                 const void* dWorkspace);
 
