@@ -22,6 +22,9 @@ public:
     void SetVec4(const std::string& name, const vec4& value) { m_vectorParams[name] = value; }
     void SetFloat(const std::string& name, float value) { m_floatParams[name] = value; }
     void SetRHIResource(const std::string& name, RHI::RHIResourcePtr value) { m_resourceParams[name] = value; }
+    // BaseFrameGraphNode.h SetRHIResource_Unresolved: per-frame targets (DepthBuffer, BackBuffer, ...) are looked up by name when the node runs
+    void SetRHIResource_Unresolved(const std::string& name, const std::string& renderTargetName) { m_unresolvedResourceParams[name] = renderTargetName; }
+    const std::map<std::string, std::string>& GetUnresolvedResources() const { return m_unresolvedResourceParams; }
 
     RHI::RHIResourcePtr GetRHIResource(const std::string& name) const
     {
@@ -61,6 +64,7 @@ protected:
     std::map<std::string, vec4> m_vectorParams;
     std::map<std::string, float> m_floatParams;
     std::map<std::string, RHI::RHIResourcePtr> m_resourceParams;
+    std::map<std::string, std::string> m_unresolvedResourceParams;
     std::string m_tag;
 };
 

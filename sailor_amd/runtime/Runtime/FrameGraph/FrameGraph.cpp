@@ -226,6 +226,8 @@ void LinearizeDepthNode::Process(RHIFrameGraphPtr frameGraph, RHICommandListPtr,
     commands->BeginDebugRegion(commandList, GetName());
 
     auto depthAttachment = GetRHIResource("depthStencil").DynamicCast<RHITexture>(); // (:29-37)
+    for (const auto& r : m_unresolvedResourceParams)
+        if (r.first == "depthStencil") { depthAttachment = frameGraph->GetRenderTarget(r.second); break; }
     if (!depthAttachment) depthAttachment = frameGraph->GetRenderTarget("DepthBuffer");
     if (!m_pLinearizeDepthShader) m_pLinearizeDepthShader = driver->CreateShader("Shaders/LinearizeDepth.shader"); // (:39-43)
     auto target = GetRHIResource("target").DynamicCast<RHITexture>();                                                // (:45)

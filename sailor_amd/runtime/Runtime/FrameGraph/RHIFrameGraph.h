@@ -27,7 +27,10 @@ public:
         auto it = m_samplers.find(name);
         return it == m_samplers.end() ? RHI::RHITexturePtr() : it->second;
     }
+    void SetValue(const std::string& name, float v) { m_values[name] = v; } // RHIFrameGraph.h SetValue (FrameGraphParser.cpp:130)
+    float GetValue(const std::string& name, float fallback = 0.0f) const { auto it = m_values.find(name); return it == m_values.end() ? fallback : it->second; }
     void SetViewport(int32_t width, int32_t height) { m_viewport = { width, height }; } // App::GetMainWindow()->GetRenderArea()
+    RHI::ivec2 GetViewport() const { return m_viewport; }
 
     RHI::UboFrameData FillFrameData(RHI::RHICommandListPtr transferCmdList, RHI::RHISceneViewSnapshot& snapshot, float deltaTime, float worldTime) const;
     // One frame: FillFrameData, then node->Process in graph order, then submit (record-then-submit)
@@ -38,6 +41,7 @@ private:
     std::vector<FrameGraphNodePtr> m_graph;
     std::map<std::string, RHI::RHITexturePtr> m_renderTargets;
     std::map<std::string, RHI::RHITexturePtr> m_samplers;
+    std::map<std::string, float> m_values;
     RHI::ivec2 m_viewport;
 };
 

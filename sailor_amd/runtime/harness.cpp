@@ -7,6 +7,8 @@
 #include "Runtime/FrameGraph/RHIFrameGraph.h"
 #include "Runtime/GraphicsDriver/HIP/HipGraphicsDriver.h"
 #include "Runtime/RHI/Renderer.h"
+#include "Runtime/AssetRegistry/FrameGraph/FrameGraphParser.h"
+#include <cstdio>
 
 using namespace Sailor;
 using namespace Sailor::RHI;
@@ -65,6 +67,84 @@ RT_API int sailor_rt_build_graph(SailorRuntime* rt, const char** nodeNames, int 
         rt->graph.AddNode(node);
     }
     return 0;
+}
+
+// FrameGraphAsset::Deserialize alone (no device): a one-line summary of what a `.renderer` text declares, for the CPU tests:
+//   "targets=Name:WxH:format:mips,...;nodes=Name[tag]{string k=v;float k=v;vec4 k=x y z w;rt k=v},...;values=k=v,...;samplers=a,b"
+RT_API int sailor_rt_parse_renderer(const char* yamlText, int viewportWidth, int viewportHeight, char* out, int outSize)
+{
+    FrameGraphAsset asset;
+    std::string err;
+    if (!asset.Deserialize(yamlText ? yamlText : "", viewportWidth, viewportHeight, &err)) {
+        if (out && outSize > 0) snprintf(out, (size_t)outSize, "error: %s", err.c_str());
+        return -1;
+    }
+    std::string s = "targets=";
+    for (size_t i = 0; i < asset.m_renderTargets.size(); i++) {
+        const auto& t = asset.m_renderTargets[i];
+        const uint32_t maxExtent = t.m_width > t.m_height ? t.m_width : t.m_height;
+        uint32_t mips = 1;
+        if (t.m_bGenerateMips) { mips = 0; for (uint32_t e = maxExtent; e; e >>= 1) mips++; }
+        if (mips > t.m_maxMipLevel) mips = t.m_maxMipLevel;
+        s += (i ? "," : "") + t.m_name + ":" + std::to_string(t.m_width) + "x" + std::to_string(t.m_height) + ":" + t.m_format + ":" + std::to_string(mips) +
+             (t.m_reduction != "Average" ? ":" + t.m_reduction : "");
+    }
+    s += ";nodes=";
+    for (size_t i = 0; i < asset.m_nodes.size(); i++) {
+        const auto& n = asset.m_nodes[i];
+        s += (i ? "," : "") + n.m_name + "[" + n.m_tag + "]{";
+        for (const auto& p : n.m_strings) s += "string " + p.first + "=" + p.second + ";";
+        for (const auto& p : n.m_floats) { char b[64]; snprintf(b, sizeof b, "%g", p.second); s += "float " + p.first + "=" + b + ";"; }
+        for (const auto& p : n.m_vectors) { char b[128]; snprintf(b, sizeof b, "%g %g %g %g", p.second.x, p.second.y, p.second.z, p.second.w); s += "vec4 " + p.first + "=" + b + ";"; }
+        for (const auto& p : n.m_renderTargets) s += "rt " + p.first + "=" + p.second + ";";
+        s += "}";
+    }
+    s += ";values=";
+    { bool first = true; for (const auto& v : asset.m_values) { char b[64]; snprintf(b, sizeof b, "%g", v.second); s += (first ? "" : ",") + v.first + "=" + b; first = false; } }
+    s += ";samplers=";
+    for (size_t i = 0; i < asset.m_samplers.size(); i++) s += (i ? "," : "") + asset.m_samplers[i];
+    if (out && outSize > 0) snprintf(out, (size_t)outSize, "%s", s.c_str());
+    return (int)asset.m_nodes.size();
+}
+
+// FrameGraphImporter: build the runtime's frame graph from a `.renderer` text -- render targets, values, one node per `frame` entry that has a
+// node class here (the others are reported, as the reference logs them).  Returns the number of nodes created, < 0 on a parse error.
+RT_API int sailor_rt_load_renderer(SailorRuntime* rt, const char* yamlText, int* outNotImplemented, int* outRenderTargets)
+{
+    FrameGraphAsset asset;
+    if (!asset.Deserialize(yamlText ? yamlText : "", rt->graph.GetViewport().x, rt->graph.GetViewport().y)) return -1;
+    rt->graph.Clear();
+    rt->lightCulling.Clear(); rt->renderScene.Clear(); rt->linearizeDepth.Clear(); rt->environment.Clear();
+    const FrameGraphBuildReport report = FrameGraphImporter::BuildFrameGraph(asset, rt->graph);
+    for (const auto& node : rt->graph.GetGraph()) { // the harness' setters address these nodes directly
+        const std::string name = node->GetDebugName();
+        if (name == "LightCulling") rt->lightCulling = node;
+        if (name == "LinearizeDepth") rt->linearizeDepth = node;
+        if (name == "Environment") rt->environment = node;
+        if (name == "RenderScene" && !rt->renderScene) rt->renderScene = node;
+    }
+    if (rt->renderScene && rt->surface) { rt->renderScene->SetRHIResource("surface", rt->surface); rt->renderScene->SetRHIResource("radiance", rt->radiance); }
+    if (outNotImplemented) *outNotImplemented = report.m_nodesNotImplemented;
+    if (outRenderTargets) *outRenderTargets = report.m_renderTargets;
+    return report.m_nodesCreated;
+}
+
+// a render target of the loaded graph, by the name the `.renderer` text gives it
+RT_API void* sailor_rt_render_target(SailorRuntime* rt, const char* name, int* outWidth, int* outHeight, int* outLevels)
+{
+    auto t = rt->graph.GetRenderTarget(name);
+    if (!t || !t->m_buffer) return nullptr;
+    if (outWidth) *outWidth = t->GetExtent().x;
+    if (outHeight) *outHeight = t->GetExtent().y;
+    if (outLevels) *outLevels = (int)t->GetMipLevels();
+    return t->m_buffer->m_hip.m_devicePtr;
+}
+
+// publish a wrapped device image as a named render target of the graph (the per-frame targets a `.renderer` file leaves unresolved: DepthBuffer, ...)
+RT_API void sailor_rt_set_render_target(SailorRuntime* rt, const char* name, void* devicePtr, int width, int height)
+{
+    auto* hip = static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver());
+    rt->graph.SetRenderTarget(name, hip->WrapTexture(devicePtr, { width, height }, EFormat::R32_SFLOAT));
 }
 
 RT_API void sailor_rt_set_camera(SailorRuntime* rt, const float* world16, float fov, float aspect, float zNear, float zFar, int width, int height)

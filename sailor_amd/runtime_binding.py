@@ -43,6 +43,11 @@ def load() -> C.CDLL:
         rt.sailor_rt_sampler.restype = P
         rt.sailor_rt_sampler.argtypes = [P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         rt.sailor_rt_build_depth_highz.argtypes = [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(P)]
+        rt.sailor_rt_parse_renderer.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        rt.sailor_rt_load_renderer.argtypes = [P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        rt.sailor_rt_render_target.restype = P
+        rt.sailor_rt_render_target.argtypes = [P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        rt.sailor_rt_set_render_target.argtypes = [P, C.c_char_p, P, C.c_int, C.c_int]
         rt.sailor_rt_gpu_culling.argtypes = [P, P, C.c_uint32, C.c_uint32, P, C.c_uint32]
         rt.sailor_rt_process_frame.argtypes = [P]
         rt.sailor_rt_wait_idle.argtypes = [P]
@@ -51,6 +56,16 @@ def load() -> C.CDLL:
         rt.sailor_rt_ecs_sweep.argtypes = [P, P, P, P, C.c_uint32, P, C.c_uint32, C.POINTER(P), C.POINTER(P), C.POINTER(P)]
         _rt = rt
     return _rt
+
+
+def parse_renderer(text: str, viewport_width: int, viewport_height: int):
+    """FrameGraphAsset::Deserialize of a `.renderer` text (no device needed): (number of frame nodes, summary string); raises on a parse error"""
+    rt = load()
+    buf = C.create_string_buffer(1 << 16)
+    n = rt.sailor_rt_parse_renderer(text.encode(), viewport_width, viewport_height, buf, len(buf))
+    if n < 0:
+        raise ValueError(buf.value.decode())
+    return n, buf.value.decode()
 
 
 class Runtime:
@@ -113,6 +128,23 @@ class Runtime:
         st = self.rt.sailor_rt_build_depth_highz(self.h, depth.data_ptr() if depth is not None else None, depth.shape[1] if depth is not None else 0,
                                                  depth.shape[0] if depth is not None else 0, width, height, levels, C.byref(p))
         return st, p.value
+
+    def load_renderer(self, text: str):
+        """FrameGraphImporter::BuildFrameGraph from a `.renderer` text: (nodes created, nodes without a class here, render targets created)"""
+        skipped, targets = C.c_int(0), C.c_int(0)
+        n = self.rt.sailor_rt_load_renderer(self.h, text.encode(), C.byref(skipped), C.byref(targets))
+        if n < 0:
+            raise ValueError("the .renderer text does not parse")
+        return n, skipped.value, targets.value
+
+    def render_target(self, name: str):
+        w, h, l = C.c_int(0), C.c_int(0), C.c_int(0)
+        p = self.rt.sailor_rt_render_target(self.h, name.encode(), C.byref(w), C.byref(h), C.byref(l))
+        return p, w.value, h.value, l.value
+
+    def set_render_target(self, name: str, tensor):
+        """publish a float32 [h, w] device tensor as a named render target (DepthBuffer, ...)"""
+        self.rt.sailor_rt_set_render_target(self.h, name.encode(), tensor.data_ptr(), tensor.shape[1], tensor.shape[0])
 
     def gpu_culling(self, instances, num_instances, first_instance, batches, num_batches):
         """the "GPU Culling" Dispatch of RHIRecordDrawCallGPUCulling over uint8 / int32 device tensors, in place"""

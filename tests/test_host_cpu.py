@@ -226,3 +226,119 @@ def test_cost_balanced_tile_rows():
     assert (band.tileRowBegin, band.tileRowEnd, band.fbRowBegin, band.fbRowCount) == (17, 34, 2160 - 16 * 34, 16 * 17)
     with pytest.raises(_lib.SailorHipError):
         host.band_from_tile_rows(3840, 2160, 100, 136)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the `.renderer` frame-graph description (FrameGraphAsset::Deserialize mirror)
+# ---------------------------------------------------------------------------------------------------------------
+RENDERER_TEXT = """---
+samplers:
+- name: g_noiseSampler
+  fileId: ''
+  path: Textures/Noise.png
+
+float:
+- PI: 3.1415926
+
+############################
+renderTargets:
+- name: LinearDepth
+  format: R32_SFLOAT
+  filtration: Nearest
+  width: ViewportWidth
+  height: ViewportHeight
+  bIsSurface: false
+
+- name: DepthHighZ   # the pyramid of the occlusion test
+  format: R32_SFLOAT
+  width: ViewportWidth/2
+  height: ViewportWidth/2
+  bIsCompatibleWithComputeShaders: true
+  bGenerateMips: true
+  reduction: Min
+
+- name: Main
+  format: R16G16B16A16_SFLOAT
+  width: 320
+  height: 200
+  bGenerateMips: true
+  maxMipLevel: 4
+
+############################
+frame:
+############################
+- name: Clear
+  float:
+  - clearDepth: 0
+  vec4:
+  - clearColor: [0.1, 0.2, 0.3, 1]
+  renderTargets:
+  - target: DepthBuffer
+
+- name: LinearizeDepth
+  renderTargets:
+  - depthStencil: DepthBuffer
+  - target: LinearDepth
+
+############################
+- name: LightCulling
+############################
+  renderTargets:
+  - depthStencil: LinearDepth
+
+- name: Environment
+
+- name: RenderScene
+  string:
+  - Tag: Opaque
+  - GPUCulling: true
+  renderTargets:
+  - color: Main
+  - depthStencil: DepthBuffer
+  - depthHighZ: DepthHighZ
+
+- name: Bloom
+  tag: PostFx
+  string:
+  - defines: ~
+  float:
+  - data.threshold: 1.5
+"""
+
+
+def test_renderer_description_parses_like_the_reference_importer():
+    """FrameGraphParser.h:64-213 / FrameGraphParser.cpp:23-78 restated: sections, `ViewportWidth/2`, mip counts (min(maxMipLevel,
+    floor(log2(max extent)) + 1)), node dictionaries, `~`, comments."""
+    from sailor_amd import runtime_binding
+    n, summary = runtime_binding.parse_renderer(RENDERER_TEXT, 1280, 720)
+    assert n == 6
+    parts = dict(p.split("=", 1) for p in summary.split(";") if "=" in p and p.split("=", 1)[0] in ("targets", "values", "samplers"))
+    assert parts["targets"] == "LinearDepth:1280x720:R32_SFLOAT:1,DepthHighZ:640x640:R32_SFLOAT:10:Min,Main:320x200:R16G16B16A16_SFLOAT:4"
+    assert parts["values"].startswith("PI=3.14159") and parts["samplers"] == "g_noiseSampler"
+    nodes = summary[summary.index("nodes="):summary.index(";values=")]
+    assert "Clear[]{float clearDepth=0;vec4 clearColor=0.1 0.2 0.3 1;rt target=DepthBuffer;}" in nodes
+    assert "LinearizeDepth[]{rt depthStencil=DepthBuffer;rt target=LinearDepth;}" in nodes
+    assert "LightCulling[]{rt depthStencil=LinearDepth;}" in nodes and "Environment[]{}" in nodes
+    assert "RenderScene[]{string GPUCulling=true;string Tag=Opaque;rt color=Main;rt depthStencil=DepthBuffer;rt depthHighZ=DepthHighZ;}" in nodes
+    assert "Bloom[PostFx]{string defines=;float data.threshold=1.5;}" in nodes
+    with pytest.raises(ValueError):
+        runtime_binding.parse_renderer("frame:\n\t- name: Clear\n", 16, 16)
+
+
+def test_the_reference_renderer_file_parses_when_mounted():
+    """Content/DefaultRenderer.renderer itself (read only when /root/reference is mounted): every node of the path is found in frame order, the
+    pyramid target carries `reduction: Min` and a full mip chain."""
+    from pathlib import Path
+    from sailor_amd import runtime_binding
+    f = Path("/root/reference/Content/DefaultRenderer.renderer")
+    if not f.exists():
+        pytest.skip("reference not mounted")
+    n, summary = runtime_binding.parse_renderer(f.read_text(), 3840, 2160)
+    assert n > 20
+    nodes = summary[summary.index("nodes="):summary.index(";values=")]
+    order = [nodes.index(k) for k in ("LinearizeDepth[", "LightCulling[", "Environment[", "DepthHighZ[", "RenderScene[")]
+    assert order == sorted(order)
+    assert "LightCulling[]{rt depthStencil=LinearDepth;}" in nodes
+    assert "DepthHighZ[]{rt src=HalfDepth;rt dst=DepthHighZ;}" in nodes
+    assert "DepthHighZ:1920x1920:R32_SFLOAT:11:Min" in summary
+    assert "LinearDepth:3840x2160:R32_SFLOAT:1" in summary

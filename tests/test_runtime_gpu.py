@@ -278,3 +278,48 @@ def test_depth_highz_node_and_the_shipped_culling_shader():
         np.testing.assert_array_equal(batches2.cpu().numpy().view(np.uint32), frustum_b)
     finally:
         rt.close()
+
+
+def test_frame_graph_built_from_a_renderer_description():
+    """FrameGraphImporter::BuildFrameGraph from `.renderer` text: render targets created by name and size expression, nodes chained through them
+    (LinearizeDepth: DepthBuffer -> LinearDepth, LightCulling reads LinearDepth), nodes without a class here reported and skipped, and the frame the
+    graph renders equals the oracle's linearise -> cull -> bake -> shade chain."""
+    from test_host_cpu import RENDERER_TEXT
+    f = synth.make_frame("tiny")
+    W, H = f.cam.width, f.cam.height
+    zn = f.cam.frame.cameraZNearZFar[0]
+    raw = synth.make_raw_depth(f.depth, zn)
+    sky = synth.make_ibl_set(W, H, np.zeros((2, 2, 2), np.float32), env_size=16)
+    rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        rt.set_camera(f.cam)
+        created, skipped, targets = rt.load_renderer(RENDERER_TEXT)
+        assert (created, skipped, targets) == (4, 2, 3)   # Clear and Bloom have no node class here
+        p, w, h, levels = rt.render_target("DepthHighZ")
+        assert p and (w, h, levels) == (W // 2, W // 2, int(np.floor(np.log2(W // 2))) + 1)
+        p, w, h, levels = rt.render_target("LinearDepth")
+        assert p and (w, h, levels) == (W, H, 1)
+        rt.set_lights(f.lights)
+        d_raw = torch.from_numpy(raw).cuda()
+        rt.set_render_target("DepthBuffer", d_raw)            # the per-frame target the file leaves unresolved
+        surface = torch.from_numpy(f.surface).cuda()
+        radiance = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        rt.set_surface(surface, radiance)
+        raw_sky = torch.from_numpy(sky.env_chain).cuda()
+        ao = torch.from_numpy(sky.ao).cuda()
+        assert rt.set_sky_cubemap(raw_sky, 16, sky.env_levels, irradiance_size=2, ao=ao) == 0
+        assert rt.process_frame() == 0
+        assert rt.process_frame() == 0
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        lin = oracle.linearize_depth(zn, raw)
+        np.testing.assert_array_equal(read_u32(p, W * H * 4), lin.view(np.uint32).reshape(-1))
+        og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, lin)
+        ref_env = oracle.prefilter_env_map(sky.env_chain, 16, sky.env_levels)
+        ref_irr = oracle.compute_irradiance_map(ref_env, 16, sky.env_levels, 2)
+        oibl, _k = oracle.make_ibl(ref_irr, ref_env, 16, sky.env_levels, oracle.compute_brdf_lut(256, 256), sky.ao)
+        ref = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, og, oi, ibl=oibl)
+        err = np.abs(radiance.cpu().numpy().astype(np.float64) - ref)
+        assert (err <= 3e-4 * np.abs(ref) + 1e-5).all(), err.max()
+    finally:
+        rt.close()
