@@ -16,7 +16,7 @@
 
 #define DC_CHUNK 256          // records per chunk = threads per block
 #define DC_REC4 6             // float4 per 96-byte record
-#define DC_MAX_BLOCKS 1536    // persistent grid: 6 blocks per CU are co-resident (25.1 KB LDS, 256 threads each)
+#define DC_BLOCKS_PER_CU 6    // persistent grid: 6 blocks per CU are co-resident (25.1 KB LDS, 256 threads each) -- the look-back spins on them
 
 #define DC_FLAG_AGGREGATE 1ull
 #define DC_FLAG_PREFIX 2ull
@@ -231,7 +231,8 @@ int sailor_hip_mesh_cull_compact_ex(SailorHipContext* ctx, const SailorUboFrameD
     hipLaunchKernelGGL(k4_draw_items, dim3((L.maxItems + 255) / 256), dim3(256), 0, ctx->stream, numBatches, planFirst, planCount, itemOffset, items,
                        status, L.maxItems);
     SAILOR_CHECK_LAUNCH(ctx, "k4_draw_items");
-    const uint32_t blocks = L.maxItems < DC_MAX_BLOCKS ? L.maxItems : DC_MAX_BLOCKS;
+    const uint32_t resident = (uint32_t)(ctx->numCUs > 0 ? ctx->numCUs : 1) * DC_BLOCKS_PER_CU; // (a partitioned GPU exposes fewer CUs)
+    const uint32_t blocks = L.maxItems < resident ? L.maxItems : resident;
     hipLaunchKernelGGL(k4_draw_compact, dim3(blocks), dim3(DC_CHUNK), 0, ctx->stream, (float4*)dInstances, (uint32_t*)dBatches, numBatches, itemOffset,
                        items, status);
     SAILOR_CHECK_LAUNCH(ctx, "k4_draw_compact");
