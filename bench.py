@@ -165,8 +165,13 @@ def ecs_baseline(ctx, count: int, steps: int):
     t0 = time.perf_counter()
     L.oracle_overlaps_aabb_sse(pl.ctypes.data_as(C.c_void_p), al.ctypes.data_as(C.c_void_p), C.c_uint32(n4), res.ctypes.data_as(C.c_void_p))
     t_sse = time.perf_counter() - t0
+    # shadow-pass planning on the sweep's world boxes: four cascade frusta (LightingECS.cpp:287-296) x all entities -> four bitmasks
+    from sailor_amd.forward_plus import csm_caster_masks
+    sh = synth.make_shadow_set(cam, 16)
+    cplanes = np.stack([host.extract_frustum_planes_matrix(sh.lights_matrices[k])[0] for k in range(4)])
+    _, casc_ms, _, _ = event_ms(lambda: csm_caster_masks(ctx, sweep.world_aabb, cplanes), steps)
     bytes_per_entity = 164.125
-    return {"entities": count, "gpu_ms": med, "gpu_mentities_per_s": count / med / 1e3, "gpu_hbm_gbs": count * bytes_per_entity / med / 1e6,
+    return {"entities": count, "gpu_ms": med, "csm_caster_masks_ms": casc_ms, "csm_caster_masks_gbs": count * 24.5 / casc_ms / 1e6, "gpu_mentities_per_s": count / med / 1e3, "gpu_hbm_gbs": count * bytes_per_entity / med / 1e6,
             "gpu_hbm_frac": count * bytes_per_entity / med / 1e6 / HBM_PEAK_GBS,
             "cpu_1thread_mentities_per_s": count / t1 / 1e6, "cpu_ns_per_entity_1thread": t1 / count * 1e9,
             "cpu_allcores_mentities_per_s": count / tn / 1e6, "cpu_sse_cull_only_mboxes_per_s_1thread": n4 / t_sse / 1e6, "cpu_cores": cores, "cpu_model": _cpu_model(), "kind": "port"}

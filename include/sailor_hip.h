@@ -366,6 +366,15 @@ SAILOR_HIP_API int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntit
                                         const SailorAABB* dLocalAabb, const float* planes,
                                         float* dWorld, SailorAABB* dWorldAabb, uint64_t* dVisibility);
 
+/* The cascade mesh lists of LightingECS::PrepareCSMPasses (ECS/LightingECS.cpp:287-296: `cascade.m_meshList = sceneView->TraceScene(frustums[k], true)`)
+ * as bitmasks over the entities of sailor_hip_ecs_sweep: bit i of mask k = dWorldAabb[i] overlaps the frustum of cascade k (Math/Bounds.cpp:245-260).
+ *   cascadePlanes : host, numCascades x 6 x vec4 from sailor_host_extract_frustum_planes_matrix(lightCascadesMatrices[k] * lightMatrix) (:287-292)
+ *   dMasks        : device out, numCascades x ceil(numEntities / 64) words, LSB first
+ * The removal of meshes already drawn by an earlier cascade of the same kind (:310-327) and the change tracking (:334-366, CSMLightState::Equals :14-38)
+ * stay on the host, on these sets. */
+SAILOR_HIP_API int sailor_hip_csm_caster_masks(SailorHipContext* ctx, uint32_t numEntities, const SailorAABB* dWorldAabb, const float* cascadePlanes,
+                                               uint32_t numCascades, uint64_t* dMasks);
+
 /* Replaces: FrustumCulling of Content/Shaders/ComputeMeshCulling.shader:96-110 (+ CreateViewFrustum, Math.glsl:185-222)
  * for the Dispatch at RHI/Batch.hpp:188; writes PerInstanceData::isCulled in place for the instances
  * [firstInstanceIndex, firstInstanceIndex + numInstances).  Hi-Z occlusion (the shader's OCCLUSION_CULLING define) is out of
@@ -431,6 +440,8 @@ SAILOR_HIP_API int sailor_host_fill_frame_data(const float* cameraWorld, float f
 SAILOR_HIP_API int sailor_host_extract_frustum_planes(const float* worldMatrix, float aspect, float fovYDegrees, float zNear, float zFar,
                                                       float* outPlanes24, float* outCorners24);
 /* FrameGraph/ShadowPrepassNode.cpp:387-404 + Math/Bounds.cpp:78-109 + ECS/LightingECS.cpp:292: the 4 lightsMatrices */
+/* Math/Bounds.cpp:20-67 Frustum::ExtractFrustumPlanes(projectionViewMatrix) (+ CalculateCorners :110-140, reversed Z): planes L R T B N F, 8 corners */
+SAILOR_HIP_API int sailor_host_extract_frustum_planes_matrix(const float* projectionViewMatrix, float* outPlanes24, float* outCorners24);
 SAILOR_HIP_API int sailor_host_csm_matrices(const float* lightView, const float* cameraWorld, float aspect, float fovYDegrees,
                                             float cameraNear, float cameraFar, float* outMatrices64);
 /* ECS/LightingECS.cpp:163-172: pack one light (cutOff in degrees -> cosines) */

@@ -287,6 +287,23 @@ def extract_frustum_planes(world_matrix, aspect, fov_y, z_near, z_far):
     return planes.reshape(6, 4), corners.reshape(8, 3)
 
 
+def extract_frustum_planes_matrix(matrix):
+    """Frustum::ExtractFrustumPlanes(projectionViewMatrix): (planes [6, 4], corners [8, 3])"""
+    m = np.ascontiguousarray(matrix, np.float32).reshape(16)
+    planes = np.zeros(24, np.float32); corners = np.zeros(24, np.float32)
+    lib().oracle_extract_frustum_planes_matrix(_p(m), _p(planes), _p(corners))
+    return planes.reshape(6, 4), corners.reshape(8, 3)
+
+
+def csm_caster_masks(world_aabb: np.ndarray, planes: np.ndarray) -> np.ndarray:
+    """per cascade, the entities whose world AABB overlaps its frustum: uint64 [numCascades, ceil(n / 64)]"""
+    aabb = np.ascontiguousarray(world_aabb, np.float32).reshape(-1, 6)
+    pl = np.ascontiguousarray(planes, np.float32).reshape(-1, 24)
+    out = np.zeros((len(pl), (len(aabb) + 63) // 64), np.uint64)
+    lib().oracle_csm_caster_masks(C.c_uint32(len(aabb)), _p(aabb), _p(pl), C.c_uint32(len(pl)), _p(out))
+    return out
+
+
 def csm_matrices(light_view, camera_world, aspect, fov_y, near, far):
     lv = np.ascontiguousarray(light_view, np.float32).reshape(16); cw = np.ascontiguousarray(camera_world, np.float32).reshape(16)
     out = np.zeros(64, np.float32)

@@ -1215,6 +1215,48 @@ static void plane_normalize(float* plane)
     plane[0] /= mag; plane[1] /= mag; plane[2] /= mag; plane[3] /= mag;
 }
 
+/* Math/Bounds.cpp:20-67 Frustum::ExtractFrustumPlanes(projectionViewMatrix, bNormalizePlanes = true) with :110-140 CalculateCorners(matrix,
+ * bReverseZ = true): the eight corners are inverse(matrix) * (+-1, +-1, -+1, 1) / w, the planes are built from corner differences.  Used for the
+ * cascade frusta of the shadow passes (ECS/LightingECS.cpp:287-292: frustums[k].ExtractFrustumPlanes(lightCascadesMatrices[k] * lightMatrix)). */
+ORACLE_API void oracle_extract_frustum_planes_matrix(const float* matrix, float* outPlanes, float* outCorners)
+{
+    float inv[16], corners[8][3];
+    oracle_mat4_inverse(matrix, inv);
+    const float sgn[4][2] = { { 1.0f, 1.0f }, { -1.0f, 1.0f }, { -1.0f, -1.0f }, { 1.0f, -1.0f } };
+    for (int k = 0; k < 8; k++) {
+        const float reverseZ = -1.0f;
+        const float v[4] = { sgn[k & 3][0], sgn[k & 3][1], k < 4 ? reverseZ * 1.0f : reverseZ * -1.0f, 1.0f };
+        float pt[4];
+        glm_mat4_mul_vec4(inv, v, pt);
+        for (int c = 0; c < 3; c++) corners[k][c] = pt[c] / pt[3];
+    }
+    float right[3], up[3], forward[3], t[3], c3[3], n[3];
+    for (int c = 0; c < 3; c++) t[c] = corners[0][c] - corners[1][c];
+    normalize3_glm(t, right);
+    for (int c = 0; c < 3; c++) t[c] = corners[0][c] - corners[3][c];
+    normalize3_glm(t, up);
+    for (int c = 0; c < 3; c++) t[c] = corners[0][c] - corners[4][c];
+    normalize3_glm(t, forward);
+    float centerFar[3], centerNear[3], centerBottom[3], centerTop[3], centerLeft[3], centerRight[3], negForward[3];
+    for (int c = 0; c < 3; c++) {
+        centerFar[c] = 0.5f * (corners[0][c] + corners[2][c]);
+        centerNear[c] = 0.5f * (corners[4][c] + corners[6][c]);
+        centerBottom[c] = 0.5f * (corners[2][c] + corners[7][c]);
+        centerTop[c] = 0.5f * (corners[0][c] + corners[5][c]);
+        centerLeft[c] = 0.5f * (corners[1][c] + corners[6][c]);
+        centerRight[c] = 0.5f * (corners[0][c] + corners[7][c]);
+        negForward[c] = -forward[c];
+    }
+    plane_from_normal_point(forward, centerNear, outPlanes + 4 * 4);
+    plane_from_normal_point(negForward, centerFar, outPlanes + 5 * 4);
+    cross3(forward, up, c3); normalize3_glm(c3, n); plane_from_normal_point(n, centerLeft, outPlanes + 0 * 4);
+    cross3(up, forward, c3); normalize3_glm(c3, n); plane_from_normal_point(n, centerRight, outPlanes + 1 * 4);
+    cross3(forward, right, c3); normalize3_glm(c3, n); plane_from_normal_point(n, centerTop, outPlanes + 2 * 4);
+    cross3(right, forward, c3); normalize3_glm(c3, n); plane_from_normal_point(n, centerBottom, outPlanes + 3 * 4);
+    for (int i = 0; i < 6; i++) plane_normalize(outPlanes + 4 * i);
+    if (outCorners) memcpy(outCorners, corners, sizeof corners);
+}
+
 /* Math/Bounds.cpp:142-193 Frustum::ExtractFrustumPlanes(worldMatrix, aspect, fovY[deg], zNear, zFar).
  * outPlanes: 6 x vec4 (L,R,T,B,N,F), outCorners: 8 x vec3 (may be NULL). */
 ORACLE_API void oracle_extract_frustum_planes(const float* worldMatrix, float aspect, float fovY, float zNear, float zFar, float* outPlanes, float* outCorners)
@@ -1274,6 +1316,19 @@ static inline int overlaps_aabb(const float* planes, const float* aabb)
         inside &= d > 0;
     }
     return inside;
+}
+
+/* The cascade mesh lists of LightingECS::PrepareCSMPasses (ECS/LightingECS.cpp:287-296) as bitmasks: bit i of mask k = the world AABB of entity i
+ * overlaps the frustum of cascade k (Frustum::OverlapsAABB, Math/Bounds.cpp:245-260).  planes = numCascades x 6 x vec4; masks = numCascades x
+ * ceil(n / 64) words, LSB first.  (The octree walk of RHISceneView::TraceScene visits the same elements; the removal of meshes already covered
+ * by an earlier cascade (:310-327) and the change tracking (:334-366) work on these sets on the host.) */
+ORACLE_API void oracle_csm_caster_masks(uint32_t numEntities, const float* worldAabb, const float* planes, uint32_t numCascades, uint64_t* masks)
+{
+    const uint32_t words = (numEntities + 63) / 64;
+    memset(masks, 0, (size_t)numCascades * words * 8);
+    for (uint32_t k = 0; k < numCascades; k++)
+        for (uint32_t i = 0; i < numEntities; i++)
+            if (overlaps_aabb(planes + 24 * k, worldAabb + 6 * (size_t)i)) masks[(size_t)k * words + (i >> 6)] |= 1ull << (i & 63);
 }
 ORACLE_API int oracle_overlaps_aabb(const float* planes, const float* aabb) { return overlaps_aabb(planes, aabb); }
 

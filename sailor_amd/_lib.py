@@ -118,6 +118,7 @@ SIGNATURES = {
     "sailor_hip_buffer_copy": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t]),
     "sailor_hip_ecs_sweep": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_uint32), C.c_uint32, _P, C.POINTER(C.c_float), _P, _P, _P]),
     "sailor_hip_mesh_frustum_cull": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_uint32, C.c_uint32]),
+    "sailor_hip_csm_caster_masks": (C.c_int, [_P, C.c_uint32, _P, C.POINTER(C.c_float), C.c_uint32, _P]),
     "sailor_hip_hiz_downscale": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32]),
     "sailor_hip_hiz_build": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32]),
     "sailor_hip_mesh_cull_flags": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_uint32, C.c_uint32, C.POINTER(HiZDesc)]),
@@ -133,6 +134,7 @@ SIGNATURES = {
                                               C.c_float, C.c_float, C.POINTER(UboFrameData)]),
     "sailor_host_extract_frustum_planes": (C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float,
                                                      C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sailor_host_extract_frustum_planes_matrix": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sailor_host_csm_matrices": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float,
                                            C.POINTER(C.c_float)]),
     "sailor_host_pack_light": (C.c_int, [C.c_uint32, C.c_uint32] + [C.POINTER(C.c_float)] * 6 + [C.POINTER(LightShaderData)]),

@@ -243,6 +243,48 @@ __device__ __forceinline__ void msc_plane(const float* p1, const float* p2, floa
     n[0] = cx / len; n[1] = cy / len; n[2] = cz / len;
 }
 
+// ---- cascade caster sets (ECS/LightingECS.cpp:287-296): which entities does each shadow cascade have to draw? ----------------------
+// One lane per entity, its world AABB (K4's output) against the six planes of up to four cascade frusta (Frustum::OverlapsAABB,
+// Math/Bounds.cpp:245-260, the same expression as the camera test above); one ballot word per cascade and 64 entities.
+struct CascadePlanes { float p[SAILOR_NUM_CSM_CASCADES][24]; };
+
+__global__ __launch_bounds__(256) void k4_csm_caster_masks(uint32_t n, const float* __restrict__ worldAabb, CascadePlanes P, int numCascades,
+                                                            unsigned long long* __restrict__ masks, uint32_t words)
+{
+    __shared__ float sBox[4][384]; // a wave's 64 boxes = 1 536 contiguous bytes: moved as 96 float4s, then read back one box per lane
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t first = blockIdx.x * 256 + wave * 64;      // the wave's first entity
+    float mn[3] = { 0.0f, 0.0f, 0.0f }, mx[3] = { 0.0f, 0.0f, 0.0f };
+    if (first + 64 <= n && (((uintptr_t)worldAabb) & 15) == 0) {
+        const float4* src = reinterpret_cast<const float4*>(worldAabb + 6 * (size_t)first);
+        float4* dst = reinterpret_cast<float4*>(sBox[wave]);
+        dst[lane] = src[lane];
+        if (lane < 32) dst[64 + lane] = src[64 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const float* b = sBox[wave] + 6 * lane;
+        mn[0] = b[0]; mn[1] = b[1]; mn[2] = b[2]; mx[0] = b[3]; mx[1] = b[4]; mx[2] = b[5];
+    } else if (i < n) {
+        const float* b = worldAabb + 6 * (size_t)i;
+        mn[0] = b[0]; mn[1] = b[1]; mn[2] = b[2]; mx[0] = b[3]; mx[1] = b[4]; mx[2] = b[5];
+    }
+#pragma unroll
+    for (int k = 0; k < SAILOR_NUM_CSM_CASCADES; k++) {
+        if (k >= numCascades) break;
+        bool inside = i < n;
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+            const float ax = mn[0] * P.p[k][4 * p + 0], bx = mx[0] * P.p[k][4 * p + 0];
+            const float ay = mn[1] * P.p[k][4 * p + 1], by = mx[1] * P.p[k][4 * p + 1];
+            const float az = mn[2] * P.p[k][4 * p + 2], bz = mx[2] * P.p[k][4 * p + 2];
+            const float d = (ax < bx ? bx : ax) + (ay < by ? by : ay) + (az < bz ? bz : az) + P.p[k][4 * p + 3];
+            inside = inside && (d > 0.0f);
+        }
+        const unsigned long long m = __ballot(inside);
+        if ((threadIdx.x & 63) == 0 && (i >> 6) < words) masks[(size_t)k * words + (i >> 6)] = m;
+    }
+}
+
 // ---- Hi-Z pyramid (DepthHighZNode.cpp:74-96, ComputeDepthHighZ.shader) and OcclusionCulling (ComputeMeshCulling.shader:62-94) ----
 // The pyramid's sampler has `reduction: Min` (DefaultRenderer.renderer:51-57).  Canonical fetch == oracle/sailor_oracle.c hiz_fetch_min:
 // bilinear footprint (x = u W - 0.5, clamp-to-edge), minimum over the texels whose weight is not zero.
@@ -427,6 +469,22 @@ int sailor_hip_mesh_frustum_cull(SailorHipContext* ctx, const SailorUboFrameData
                                  uint32_t numInstances, uint32_t firstInstanceIndex)
 {
     return sailor_hip_mesh_cull_flags(ctx, frame, dInstances, numInstances, firstInstanceIndex, nullptr);
+}
+
+int sailor_hip_csm_caster_masks(SailorHipContext* ctx, uint32_t numEntities, const SailorAABB* dWorldAabb, const float* cascadePlanes, uint32_t numCascades,
+                                uint64_t* dMasks)
+{
+    if (!ctx || !cascadePlanes || numCascades == 0 || numCascades > SAILOR_NUM_CSM_CASCADES) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (numEntities == 0) return SAILOR_HIP_OK;
+    if (!dWorldAabb || !dMasks) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    CascadePlanes P;
+    memset(&P, 0, sizeof P);
+    memcpy(P.p, cascadePlanes, (size_t)numCascades * 24 * sizeof(float));
+    const uint32_t words = (numEntities + 63) / 64;
+    hipLaunchKernelGGL(k4_csm_caster_masks, dim3((numEntities + 255) / 256), dim3(256), 0, ctx->stream, numEntities, (const float*)dWorldAabb, P, (int)numCascades,
+                       (unsigned long long*)dMasks, words);
+    SAILOR_CHECK_LAUNCH(ctx, "k4_csm_caster_masks");
+    return SAILOR_HIP_OK;
 }
 
 int sailor_hip_hiz_downscale(SailorHipContext* ctx, const float* dSrc, int32_t srcWidth, int32_t srcHeight, float* dDst, int32_t dstWidth, int32_t dstHeight)

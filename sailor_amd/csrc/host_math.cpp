@@ -182,6 +182,28 @@ struct Frustum {
         corners[6] = xf(start - sx - sy);
         corners[7] = xf(start + sx - sy);
     }
+    // Bounds.cpp:20-67 ExtractFrustumPlanes(projectionViewMatrix) with :110-140 CalculateCorners(matrix, bReverseZ = true)
+    void extract(const M4& projectionView)
+    {
+        const M4 inv = inverse(projectionView);
+        const float sgn[4][2] = { { 1.0f, 1.0f }, { -1.0f, 1.0f }, { -1.0f, -1.0f }, { 1.0f, -1.0f } };
+        for (int k = 0; k < 8; k++) {
+            const float reverseZ = -1.0f;
+            const V4 pt = mul(inv, V4 { sgn[k & 3][0], sgn[k & 3][1], k < 4 ? reverseZ * 1.0f : reverseZ * -1.0f, 1.0f });
+            corners[k] = V3 { pt.x / pt.w, pt.y / pt.w, pt.z / pt.w };
+        }
+        const V3 right = normalize(corners[0] - corners[1]), up = normalize(corners[0] - corners[3]), forward = normalize(corners[0] - corners[4]);
+        const V3 centerFar = 0.5f * (corners[0] + corners[2]), centerNear = 0.5f * (corners[4] + corners[6]);
+        const V3 centerBottom = 0.5f * (corners[2] + corners[7]), centerTop = 0.5f * (corners[0] + corners[5]);
+        const V3 centerLeft = 0.5f * (corners[1] + corners[6]), centerRight = 0.5f * (corners[0] + corners[7]);
+        planes[4] = Plane(forward, centerNear);
+        planes[5] = Plane(-forward, centerFar);
+        planes[0] = Plane(normalize(cross(forward, up)), centerLeft);
+        planes[1] = Plane(normalize(cross(up, forward)), centerRight);
+        planes[2] = Plane(normalize(cross(forward, right)), centerTop);
+        planes[3] = Plane(normalize(cross(right, forward)), centerBottom);
+        for (auto& p : planes) p.normalize();
+    }
     // Bounds.cpp:78-109
     M4 ortho_by_view(const M4& view, float zMult) const
     {
@@ -258,6 +280,16 @@ int sailor_host_extract_frustum_planes(const float* worldMatrix, float aspect, f
     if (!worldMatrix || !outPlanes24) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     Frustum f;
     f.extract(load(worldMatrix), aspect, fovYDegrees, zNear, zFar);
+    for (int i = 0; i < 6; i++) std::memcpy(outPlanes24 + 4 * i, &f.planes[i].abcd, 16);
+    if (outCorners24) std::memcpy(outCorners24, f.corners, sizeof f.corners);
+    return SAILOR_HIP_OK;
+}
+
+int sailor_host_extract_frustum_planes_matrix(const float* projectionViewMatrix, float* outPlanes24, float* outCorners24)
+{
+    if (!projectionViewMatrix || !outPlanes24) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    Frustum f;
+    f.extract(load(projectionViewMatrix));
     for (int i = 0; i < 6; i++) std::memcpy(outPlanes24 + 4 * i, &f.planes[i].abcd, 16);
     if (outCorners24) std::memcpy(outCorners24, f.corners, sizeof f.corners);
     return SAILOR_HIP_OK;

@@ -238,6 +238,16 @@ class EcsSweep:
         return self.world, self.world_aabb, self.visibility
 
 
+def csm_caster_masks(ctx: "HipContext", world_aabb: torch.Tensor, cascade_planes: np.ndarray) -> torch.Tensor:
+    """sailor_hip_csm_caster_masks: world AABBs [n, 6] (the ECS sweep's output) x cascade frusta [k, 6, 4] -> int64 [k, ceil(n / 64)] bitmasks"""
+    pl = np.ascontiguousarray(cascade_planes, np.float32).reshape(-1, 24)
+    n = world_aabb.shape[0]
+    out = torch.empty((len(pl), (n + 63) // 64), dtype=torch.int64, device=ctx.device)  # every word is written
+    _lib.check(ctx._lib.sailor_hip_csm_caster_masks(ctx.handle, n, _ptr(world_aabb), pl.ctypes.data_as(C.POINTER(C.c_float)), len(pl), _ptr(out)),
+               "sailor_hip_csm_caster_masks", ctx.handle)
+    return out
+
+
 def hiz_build(ctx: "HipContext", depth: torch.Tensor, width: int, height: int, levels: int) -> torch.Tensor:
     """DepthHighZNode's loop on the GPU: raw depth [H, W] float32 -> flat level-major min pyramid"""
     total = sum(max(width >> l, 1) * max(height >> l, 1) for l in range(levels))

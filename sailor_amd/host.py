@@ -120,6 +120,42 @@ def extract_frustum_planes(world_matrix, aspect: float, fov_y_degrees: float, z_
     return planes.reshape(6, 4), corners.reshape(8, 3)
 
 
+def extract_frustum_planes_matrix(projection_view_matrix):
+    """Math/Bounds.cpp:20-67 Frustum::ExtractFrustumPlanes(projectionViewMatrix) -> (planes float32[6,4] L,R,T,B,N,F, corners float32[8,3])."""
+    m = _f32(projection_view_matrix, 16)
+    planes = np.empty(24, np.float32)
+    corners = np.empty(24, np.float32)
+    _lib.check(_lib.load().sailor_host_extract_frustum_planes_matrix(_fp(m), _fp(planes), _fp(corners)), "extract_frustum_planes_matrix")
+    return planes.reshape(6, 4), corners.reshape(8, 3)
+
+
+def plan_csm_passes(overlap_masks: np.ndarray, shadow_types, last_changed_frame: np.ndarray, previous):
+    """The bookkeeping of LightingECS::PrepareCSMPasses (ECS/LightingECS.cpp:299-366) for one directional light, on the cascade overlap sets
+    of sailor_hip_csm_caster_masks (uint64 [cascades, words]):
+      * cascade k > 0 drops every mesh that an EARLIER cascade of the same shadow type, re-rendered this frame, already overlaps (:310-327);
+      * a cascade is re-rendered iff its mesh list, as (mesh index, frame the mesh last changed) pairs, differs from last frame's snapshot
+        (CSMLightState::Equals :14-38; the camera / light transform thresholds of that comparison are the caller's `previous is None`).
+    Returns (list of cascades to render, their final uint64 masks [cascades, words], the new snapshots)."""
+    masks = np.array(overlap_masks, np.uint64, copy=True)
+    n_casc = masks.shape[0]
+    added = [None] * n_casc                      # bCascadeAdded[z]: the shadow type of a cascade that is rendered this frame
+    snapshots, render = [], []
+    frames = np.asarray(last_changed_frame)
+    for k in range(n_casc):
+        for z in range(k):
+            if added[z] is not None and added[z] == shadow_types[k]:
+                masks[k] &= ~np.asarray(overlap_masks[z], np.uint64)
+        bits = np.unpackbits(masks[k].view(np.uint8), bitorder="little")[: len(frames)].astype(bool)
+        idx = np.nonzero(bits)[0]
+        snap = (idx.copy(), frames[idx].copy())
+        same = previous is not None and k < len(previous) and np.array_equal(previous[k][0], snap[0]) and np.array_equal(previous[k][1], snap[1])
+        snapshots.append(snap)
+        if not same:
+            added[k] = shadow_types[k]
+            render.append(k)
+    return render, masks, snapshots
+
+
 def csm_matrices(light_view, camera_world, aspect: float, fov_y_degrees: float, camera_near: float, camera_far: float) -> np.ndarray:
     """The 4 `lightsMatrices` (FrameGraph/ShadowPrepassNode.cpp:387-404, ECS/LightingECS.cpp:292) as float32[4,16]."""
     lv, cw = _f32(light_view, 16), _f32(camera_world, 16)

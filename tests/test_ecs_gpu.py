@@ -124,3 +124,25 @@ def test_sweep_1m_entities_visibility_checksum(ctx):
     np.testing.assert_array_equal(vis.cpu().numpy().view(np.uint64), ov)
     np.testing.assert_array_equal(aabb.cpu().numpy().view(np.uint32), oa.view(np.uint32))
     np.testing.assert_array_equal(world.cpu().numpy().view(np.uint32), ow.view(np.uint32))
+
+
+def test_cascade_caster_sets_from_the_sweeps_world_boxes(ctx):
+    """sailor_hip_csm_caster_masks over the world AABBs the sweep just produced (1 048 576 entities, four cascade frusta extracted from the
+    light matrices as LightingECS.cpp:287-292 does): every mask word equals the oracle's."""
+    from sailor_amd.forward_plus import csm_caster_masks
+    ents = synth.make_entities(1 << 20)
+    cam = synth.make_camera(3840, 2160)
+    sweep = EcsSweep(ctx, ents)
+    _, aabb, _ = sweep.run(camera_planes(cam))
+    sh = synth.make_shadow_set(cam, 16)
+    planes = np.stack([host.extract_frustum_planes_matrix(sh.lights_matrices[k])[0] for k in range(4)])
+    got = csm_caster_masks(ctx, aabb, planes)
+    ctx.synchronize()
+    ref = oracle.csm_caster_masks(aabb.cpu().numpy(), planes)
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint64), ref)
+    counts = [int(np.unpackbits(m.view(np.uint8)).sum()) for m in ref]
+    assert 0 < counts[0] < counts[3] < (1 << 20)
+    # ragged count, fewer cascades
+    got = csm_caster_masks(ctx, aabb[:1000], planes[:2])
+    ctx.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint64), oracle.csm_caster_masks(aabb[:1000].cpu().numpy(), planes[:2]))

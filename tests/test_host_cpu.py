@@ -342,3 +342,68 @@ def test_the_reference_renderer_file_parses_when_mounted():
     assert "DepthHighZ[]{rt src=HalfDepth;rt dst=DepthHighZ;}" in nodes
     assert "DepthHighZ:1920x1920:R32_SFLOAT:11:Min" in summary
     assert "LinearDepth:3840x2160:R32_SFLOAT:1" in summary
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# shadow-pass planning (ECS/LightingECS.cpp:264-366): cascade frusta from matrices, cascade sets, change tracking
+# ---------------------------------------------------------------------------------------------------------------
+def camera_planes_for(cam):
+    planes, _ = host.extract_frustum_planes(cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+    return planes
+
+
+def _cascade_planes(cam):
+    """the four cascade frusta of a directional light, as PrepareCSMPasses builds them (:272-292)"""
+    sh = synth.make_shadow_set(cam, 16)
+    planes = [host.extract_frustum_planes_matrix(sh.lights_matrices[k])[0] for k in range(4)]
+    return sh, np.stack(planes)
+
+
+def test_frustum_from_matrix_host_equals_oracle_and_contains_its_own_corners():
+    cam = synth.make_camera(1280, 720)
+    sh, planes = _cascade_planes(cam)
+    for k in range(4):
+        op, oc = oracle.extract_frustum_planes_matrix(sh.lights_matrices[k])
+        hp, hc = host.extract_frustum_planes_matrix(sh.lights_matrices[k])
+        np.testing.assert_array_equal(hp.view(np.uint32), op.view(np.uint32))
+        np.testing.assert_array_equal(hc.view(np.uint32), oc.view(np.uint32))
+        np.testing.assert_allclose(np.linalg.norm(hp[:, :3], axis=1), 1.0, rtol=1e-6)
+        centre = hc.mean(0)
+        assert (hp[:, :3] @ centre + hp[:, 3] > 0).all(), "the planes face inwards"
+        # the clip-space cube maps back onto the corners
+        m = np.asarray(sh.lights_matrices[k], np.float64).reshape(4, 4).T
+        clip = (m @ np.c_[hc.astype(np.float64), np.ones(8)].T).T
+        np.testing.assert_allclose(np.abs(clip[:, :3] / clip[:, 3:4]), 1.0, rtol=2e-3, atol=2e-3)
+
+
+def test_csm_pass_planning_on_cascade_sets():
+    """oracle_csm_caster_masks + the host bookkeeping, literally as the reference does it: cascades of one shadow type that are rendered in the same
+    frame do not draw a mesh twice; an unchanged scene settles to "nothing to render" after two more frames; a moved mesh re-renders its cascade."""
+    cam = synth.make_camera(1280, 720)
+    ents = synth.make_entities(20000)
+    world, aabb, _ = oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, camera_planes_for(cam))
+    _, planes = _cascade_planes(cam)
+    masks = oracle.csm_caster_masks(aabb, planes)
+    counts = [int(np.unpackbits(m.view(np.uint8)).sum()) for m in masks]
+    assert all(c > 0 for c in counts) and counts[0] < counts[3]
+    types = [host.SHADOW_EVSM, host.SHADOW_PCF, host.SHADOW_PCF, host.SHADOW_PCF]   # "for EVSM only the 1st cascade is EVSM" (:297)
+    frames = np.zeros(20000, np.int64)
+    render, final, snaps = host.plan_csm_passes(masks, types, frames, None)
+    assert render == [0, 1, 2, 3]
+    assert (final[0] == masks[0]).all() and (final[1] == masks[1]).all()          # cascade 1 is PCF, cascade 0 EVSM: nothing removed
+    assert (final[2] & masks[1]).sum() == 0 and (final[3] & (masks[1] | masks[2])).sum() == 0
+    # The removal only looks at earlier cascades that are re-rendered THIS frame (bCascadeAdded stays None for an unchanged cascade, :306-314),
+    # so an unchanged scene settles over the next frames: cascade 2 comes back with its full set, then cascade 3, then nothing.
+    render2, final2, snaps2 = host.plan_csm_passes(masks, types, frames, snaps)
+    assert render2 == [2] and (final2[2] == masks[2]).all()
+    render3, final3, snaps3 = host.plan_csm_passes(masks, types, frames, snaps2)
+    assert render3 == [3] and (final3[3] == masks[3]).all()
+    render4, _, snaps4 = host.plan_csm_passes(masks, types, frames, snaps3)
+    assert render4 == []
+    moved = int(np.nonzero(np.unpackbits(masks[2].view(np.uint8), bitorder="little"))[0][0])
+    frames2 = frames.copy(); frames2[moved] = 7
+    render5, _, _ = host.plan_csm_passes(masks, types, frames2, snaps4)
+    holds = [bool((int(masks[k][moved >> 6]) >> (moved & 63)) & 1) for k in range(4)]
+    assert render5 and min(render5) == holds.index(True)   # the first cascade that holds the moved mesh is re-rendered ...
+    for k in render5:                                       # ... and every other one either holds it or follows a re-rendered cascade of its type
+        assert holds[k] or any(z in render5 and types[z] == types[k] for z in range(k))
