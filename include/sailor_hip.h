@@ -366,6 +366,20 @@ SAILOR_HIP_API int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntit
                                         const SailorAABB* dLocalAabb, const float* planes,
                                         float* dWorld, SailorAABB* dWorldAabb, uint64_t* dVisibility);
 
+/* Replaces: the caster draws of one shadow pass, FrameGraph/ShadowPrepassNode.cpp:219-262 with Content/Shaders/ShadowCaster.shader:46-59 (vertex stage:
+ * gl_Position = lightMatrix * instance.model * vec4(inPosition, 1)) -- depth only; the rasterisation rules are those of the oracle (1/256-pixel
+ * snapping, top-left rule, both windings, unfused fp32 depth interpolation, reversed Z: GREATER against a buffer cleared to 0, viewport (0, H, W, -H)).
+ *   lightMatrix  : host, mat4 (the pass' push constant, RHIUpdateShadowMapCommand::m_lightMatrix)
+ *   dPositions   : device, vec3 per vertex (VertexP3N3T3B3UV2C4::m_position); dIndices: device, 3 x numTriangles
+ *   dModels      : device, mat4 per instance (PerInstanceData.model); dInstanceIds: device, numDrawn instance indices, or NULL for 0 .. numDrawn-1
+ *   dDepth       : device in/out, width x height floats; `clear` != 0 clears it to 0 first (a dependent pass, :250-261, draws on top with clear == 0) */
+SAILOR_HIP_API int sailor_hip_raster_depth(SailorHipContext* ctx, const float* lightMatrix, const float* dPositions, const uint32_t* dIndices,
+                                           uint32_t numTriangles, const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn,
+                                           int32_t width, int32_t height, float* dDepth, int32_t clear);
+/* The fragment stage of ShadowCaster.shader:66-78 on the winning depth of every texel: EVSM moments (format RGBA32F: exp(40 z), its square,
+ * -exp(-40 z), its square), or the depth itself (R16F / R32F); texels nothing was drawn to keep the cleared colour 0. */
+SAILOR_HIP_API int sailor_hip_shadow_resolve(SailorHipContext* ctx, const float* dDepth, int32_t width, int32_t height, int32_t format, void* dShadowMap);
+
 /* The cascade mesh lists of LightingECS::PrepareCSMPasses (ECS/LightingECS.cpp:287-296: `cascade.m_meshList = sceneView->TraceScene(frustums[k], true)`)
  * as bitmasks over the entities of sailor_hip_ecs_sweep: bit i of mask k = dWorldAabb[i] overlaps the frustum of cascade k (Math/Bounds.cpp:245-260).
  *   cascadePlanes : host, numCascades x 6 x vec4 from sailor_host_extract_frustum_planes_matrix(lightCascadesMatrices[k] * lightMatrix) (:287-292)

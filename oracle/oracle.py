@@ -327,3 +327,24 @@ def transform_matrix(trs12):
     t = np.ascontiguousarray(trs12, np.float32).reshape(12); out = np.zeros(16, np.float32)
     lib().oracle_transform_matrix(_p(t), _p(out))
     return out
+
+
+def raster_depth(light_matrix, positions, indices, models, width: int, height: int, instance_ids=None, depth=None) -> np.ndarray:
+    """The canonical depth rasteriser (ShadowPrepassNode's caster draws): float32 [H, W] depth, GREATER test, 0 = nothing drawn."""
+    lm = np.ascontiguousarray(light_matrix, np.float32).reshape(16)
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
+    mdl = np.ascontiguousarray(models, np.float32).reshape(-1, 16)
+    out = np.zeros((height, width), np.float32) if depth is None else np.ascontiguousarray(depth, np.float32).copy()
+    ids = None if instance_ids is None else np.ascontiguousarray(instance_ids, np.uint32)
+    n = len(mdl) if ids is None else len(ids)
+    lib().oracle_raster_depth(_p(lm), _p(pos), _p(idx), C.c_uint32(len(idx)), _p(mdl), _p(ids) if ids is not None else None, C.c_uint32(n),
+                              C.c_int32(width), C.c_int32(height), _p(out))
+    return out
+
+
+def shadow_resolve_evsm(depth: np.ndarray) -> np.ndarray:
+    d = np.ascontiguousarray(depth, np.float32)
+    out = np.zeros(d.shape + (4,), np.float32)
+    lib().oracle_shadow_resolve_evsm(_p(d), C.c_int32(d.shape[1]), C.c_int32(d.shape[0]), _p(out))
+    return out

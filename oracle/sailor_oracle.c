@@ -1643,3 +1643,109 @@ ORACLE_API void oracle_csm_matrices(const float* lightView, const float* cameraW
         glm_mat4_mul_mat4(ortho, lightView, out + 16 * k);
     }
 }
+
+
+/* ------------------------------------------------------------------------------------------- */
+/* Depth rasterisation: the shadow-map producer (FrameGraph/ShadowPrepassNode.cpp:219-262,     */
+/* Content/Shaders/ShadowCaster.shader:46-79).                                                 */
+/* ------------------------------------------------------------------------------------------- */
+/* The reference draws instanced meshes with the light matrix as a push constant, depth attachment cleared to 0, reversed Z (the
+ * ortho matrices of Bounds.cpp:78-109 swap near and far), viewport (0, H, W, -H).  What a rasteriser does between the vertex
+ * shader and gl_FragCoord is fixed here as follows (Vulkan's rules with the freedoms pinned):
+ *   clip   = (lightMatrix * model) * vec4(position, 1)            GLSL order, mat * mat column by column, ((c0 x + c1 y) + c2 z) + c3 w
+ *   window = x: (ndc.x + 1) * (W / 2), y: (ndc.y + 1) * (-H / 2) + H, z: ndc.z   (triangles with a vertex at w <= 0 are dropped)
+ *   snap   = x, y to 1/256 pixel (round to nearest even), 64-bit integer edge functions, both windings, top-left fill rule
+ *   z      = (z0 + (z1 - z0) * w1) + (z2 - z0) * w2, w_k = float(edge_k) / float(2 * area), no fused operations
+ *   test   = fragments with z outside [0, 1] are clipped; GREATER against the stored depth (0 = cleared) */
+static void glsl_mat4_mul_mat4(const float* a, const float* b, float* o)
+{
+    for (int j = 0; j < 4; j++) glsl_mat4_mul_vec4(a, b + 4 * j, o + 4 * j);
+}
+
+typedef struct { int64_t x, y; float z; } RasterVertex;
+
+static int raster_setup(const float* LM, const float* positions, const uint32_t* tri, int W, int H, RasterVertex* v)
+{
+    for (int k = 0; k < 3; k++) {
+        const float* p = positions + 3 * (size_t)tri[k];
+        const float pos[4] = { p[0], p[1], p[2], 1.0f };
+        float clip[4];
+        glsl_mat4_mul_vec4(LM, pos, clip);
+        if (!(clip[3] > 0.0f)) return 0;
+        const float nx = clip[0] / clip[3], ny = clip[1] / clip[3], nz = clip[2] / clip[3];
+        const float xf = (nx + 1.0f) * ((float)W * 0.5f);
+        const float yf = (ny + 1.0f) * ((float)H * -0.5f) + (float)H;
+        const float sx = xf * 256.0f, sy = yf * 256.0f;
+        if (!(fabsf(sx) < 1.0e9f) || !(fabsf(sy) < 1.0e9f)) return 0; /* far outside the guard band (or NaN) */
+        v[k].x = (int64_t)rintf(sx); v[k].y = (int64_t)rintf(sy); v[k].z = nz;
+    }
+    int64_t area2 = (v[1].x - v[0].x) * (v[2].y - v[0].y) - (v[2].x - v[0].x) * (v[1].y - v[0].y);
+    if (area2 == 0) return 0;
+    if (area2 < 0) { const RasterVertex t = v[1]; v[1] = v[2]; v[2] = t; }
+    return 1;
+}
+
+static inline int64_t raster_edge(const RasterVertex* a, const RasterVertex* b, int64_t px, int64_t py)
+{
+    return (b->x - a->x) * (py - a->y) - (b->y - a->y) * (px - a->x);
+}
+static inline int raster_top_left(const RasterVertex* a, const RasterVertex* b)
+{
+    const int64_t dx = b->x - a->x, dy = b->y - a->y;
+    return (dy == 0 && dx > 0) || dy < 0;
+}
+static inline int64_t floor_div256(int64_t a) { return a >= 0 ? a / 256 : -((-a + 255) / 256); }
+
+/* depth: W x H floats, read and written (GREATER); instanceIds == NULL draws instances 0 .. numDrawn-1 */
+ORACLE_API void oracle_raster_depth(const float* lightMatrix, const float* positions, const uint32_t* indices, uint32_t numTriangles, const float* models,
+                                    const uint32_t* instanceIds, uint32_t numDrawn, int32_t W, int32_t H, float* depth)
+{
+    for (uint32_t d = 0; d < numDrawn; d++) {
+        const uint32_t inst = instanceIds ? instanceIds[d] : d;
+        float LM[16];
+        glsl_mat4_mul_mat4(lightMatrix, models + 16 * (size_t)inst, LM);
+        for (uint32_t t = 0; t < numTriangles; t++) {
+            RasterVertex v[3];
+            if (!raster_setup(LM, positions, indices + 3 * (size_t)t, W, H, v)) continue;
+            int64_t minx = v[0].x, maxx = v[0].x, miny = v[0].y, maxy = v[0].y;
+            for (int k = 1; k < 3; k++) {
+                minx = v[k].x < minx ? v[k].x : minx; maxx = v[k].x > maxx ? v[k].x : maxx;
+                miny = v[k].y < miny ? v[k].y : miny; maxy = v[k].y > maxy ? v[k].y : maxy;
+            }
+            /* pixel (i, j) has its centre at (256 i + 128, 256 j + 128) */
+            int64_t i0 = floor_div256(minx - 128 + 255), i1 = floor_div256(maxx - 128), j0 = floor_div256(miny - 128 + 255), j1 = floor_div256(maxy - 128);
+            if (i0 < 0) i0 = 0;
+            if (j0 < 0) j0 = 0;
+            if (i1 > W - 1) i1 = W - 1;
+            if (j1 > H - 1) j1 = H - 1;
+            const float area = (float)raster_edge(&v[0], &v[1], v[2].x, v[2].y);
+            const int tl0 = raster_top_left(&v[1], &v[2]), tl1 = raster_top_left(&v[2], &v[0]), tl2 = raster_top_left(&v[0], &v[1]);
+            for (int64_t j = j0; j <= j1; j++)
+                for (int64_t i = i0; i <= i1; i++) {
+                    const int64_t px = 256 * i + 128, py = 256 * j + 128;
+                    const int64_t e0 = raster_edge(&v[1], &v[2], px, py), e1 = raster_edge(&v[2], &v[0], px, py), e2 = raster_edge(&v[0], &v[1], px, py);
+                    if (e0 < 0 || e1 < 0 || e2 < 0) continue;
+                    if ((e0 == 0 && !tl0) || (e1 == 0 && !tl1) || (e2 == 0 && !tl2)) continue;
+                    const float w1 = (float)e1 / area, w2 = (float)e2 / area;
+                    const float z = (v[0].z + (v[1].z - v[0].z) * w1) + (v[2].z - v[0].z) * w2;
+                    if (!(z >= 0.0f && z <= 1.0f)) continue;
+                    float* o = depth + (size_t)j * W + i;
+                    if (z > *o) *o = z;
+                }
+        }
+    }
+}
+
+/* ShadowCaster.shader:66-78 on the winning fragment of every texel: EVSM moments (RGBA32F) or the depth itself; texels nothing was drawn
+ * to keep the cleared colour 0 (ShadowPrepassNode.cpp:239-248: clear colour vec4(0), clear depth 0). */
+ORACLE_API void oracle_shadow_resolve_evsm(const float* depth, int32_t W, int32_t H, float* outRGBA)
+{
+    for (size_t i = 0; i < (size_t)W * H; i++) {
+        const float z = depth[i];
+        float* o = outRGBA + 4 * i;
+        if (z > 0.0f) {
+            o[0] = canonical_expf(40.0f * z); o[1] = o[0] * o[0];
+            o[2] = -canonical_expf(-40.0f * z); o[3] = o[2] * o[2];
+        } else { o[0] = o[1] = o[2] = o[3] = 0.0f; }
+    }
+}

@@ -1,0 +1,205 @@
+// The shadow-map producer: ShadowPrepassNode's caster draws (FrameGraph/ShadowPrepassNode.cpp:219-262, Content/Shaders/ShadowCaster.shader) as a
+// compute rasteriser for gfx950.  Semantics = oracle/sailor_oracle.c oracle_raster_depth (Vulkan's rasterisation rules with the freedoms pinned:
+// 1/256-pixel snapping, 64-bit integer edge functions, both windings, top-left rule, unfused fp32 depth interpolation, GREATER against a depth
+// buffer cleared to 0 -- reversed Z).  The winning depth of a texel does not depend on the order the fragments arrive in, so the depth buffer is
+// a plain atomicMax over float bits (depths are > 0) and the result is bit-exact against the sequential oracle.
+//
+// Work distribution: one LANE per (instance, triangle) sets its triangle up.  Triangles whose pixel box is small are filled by their own lane;
+// the others are handed round the wave one after the other (the set-up travels by lane broadcast) and all 64 lanes walk the box together --
+// caster geometry mixes boxes of a few texels with boxes of a few hundred, and one lane alone would keep its wave waiting for it.
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+#define RASTER_SMALL_BOX 64 // pixels a lane fills on its own
+
+struct RasterTri { long long x0, y0, x1, y1, x2, y2; float z0, z1, z2; int i0, i1, j0, j1; bool valid; };
+
+// clip = (lightMatrix * model) * vec4(p, 1): GLSL order
+__device__ __forceinline__ Mat4 raster_mul(const Mat4& a, const float* __restrict__ b)
+{
+    Mat4 o;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float4 c = glsl_mul(a, b[4 * j + 0], b[4 * j + 1], b[4 * j + 2], b[4 * j + 3]);
+        o.m[4 * j + 0] = c.x; o.m[4 * j + 1] = c.y; o.m[4 * j + 2] = c.z; o.m[4 * j + 3] = c.w;
+    }
+    return o;
+}
+
+__device__ __forceinline__ long long raster_floor_div256(long long a) { return a >= 0 ? a / 256 : -((-a + 255) / 256); }
+
+__device__ __forceinline__ RasterTri raster_setup(const Mat4& LM, const float* __restrict__ positions, const uint32_t* __restrict__ tri, int W, int H)
+{
+    RasterTri t;
+    t.valid = false;
+    long long X[3], Y[3];
+    float Z[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float* p = positions + 3 * (size_t)tri[k];
+        const float4 clip = glsl_mul(LM, p[0], p[1], p[2], 1.0f);
+        if (!(clip.w > 0.0f)) return t;
+        const float nx = clip.x / clip.w, ny = clip.y / clip.w, nz = clip.z / clip.w;
+        const float xf = (nx + 1.0f) * ((float)W * 0.5f);
+        const float yf = (ny + 1.0f) * ((float)H * -0.5f) + (float)H;
+        const float sx = xf * 256.0f, sy = yf * 256.0f;
+        if (!(fabsf(sx) < 1.0e9f) || !(fabsf(sy) < 1.0e9f)) return t;
+        X[k] = (long long)rintf(sx); Y[k] = (long long)rintf(sy); Z[k] = nz;
+    }
+    const long long area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (X[2] - X[0]) * (Y[1] - Y[0]);
+    if (area2 == 0) return t;
+    if (area2 < 0) { long long s = X[1]; X[1] = X[2]; X[2] = s; s = Y[1]; Y[1] = Y[2]; Y[2] = s; const float z = Z[1]; Z[1] = Z[2]; Z[2] = z; }
+    t.x0 = X[0]; t.y0 = Y[0]; t.x1 = X[1]; t.y1 = Y[1]; t.x2 = X[2]; t.y2 = Y[2];
+    t.z0 = Z[0]; t.z1 = Z[1]; t.z2 = Z[2];
+    const long long minx = min(X[0], min(X[1], X[2])), maxx = max(X[0], max(X[1], X[2]));
+    const long long miny = min(Y[0], min(Y[1], Y[2])), maxy = max(Y[0], max(Y[1], Y[2]));
+    long long i0 = raster_floor_div256(minx - 128 + 255), i1 = raster_floor_div256(maxx - 128);
+    long long j0 = raster_floor_div256(miny - 128 + 255), j1 = raster_floor_div256(maxy - 128);
+    if (i0 < 0) i0 = 0;
+    if (j0 < 0) j0 = 0;
+    if (i1 > W - 1) i1 = W - 1;
+    if (j1 > H - 1) j1 = H - 1;
+    if (i1 < i0 || j1 < j0) return t;
+    t.i0 = (int)i0; t.i1 = (int)i1; t.j0 = (int)j0; t.j1 = (int)j1;
+    t.valid = true;
+    return t;
+}
+
+__device__ __forceinline__ long long raster_edge(long long ax, long long ay, long long bx, long long by, long long px, long long py)
+{
+    return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+}
+__device__ __forceinline__ bool raster_top_left(long long ax, long long ay, long long bx, long long by)
+{
+    const long long dx = bx - ax, dy = by - ay;
+    return (dy == 0 && dx > 0) || dy < 0;
+}
+
+__device__ __forceinline__ void raster_pixel(const RasterTri& t, float area, bool tl0, bool tl1, bool tl2, int i, int j, int W, unsigned int* __restrict__ depthBits)
+{
+    const long long px = 256ll * i + 128, py = 256ll * j + 128;
+    const long long e0 = raster_edge(t.x1, t.y1, t.x2, t.y2, px, py), e1 = raster_edge(t.x2, t.y2, t.x0, t.y0, px, py), e2 = raster_edge(t.x0, t.y0, t.x1, t.y1, px, py);
+    if (e0 < 0 || e1 < 0 || e2 < 0) return;
+    if ((e0 == 0 && !tl0) || (e1 == 0 && !tl1) || (e2 == 0 && !tl2)) return;
+    const float w1 = (float)e1 / area, w2 = (float)e2 / area;
+    const float z = (t.z0 + (t.z1 - t.z0) * w1) + (t.z2 - t.z0) * w2;
+    if (!(z > 0.0f && z <= 1.0f)) return; // z == 0 never passes GREATER against the cleared 0 either
+    atomicMax(depthBits + (size_t)j * W + i, __float_as_uint(z)); // positive floats order like their bits
+}
+
+__device__ __forceinline__ long long bcast64(long long v, int src)
+{
+    const int lo = __shfl((int)(unsigned int)(unsigned long long)v, src, 64), hi = __shfl((int)((unsigned long long)v >> 32), src, 64);
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
+}
+
+__global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, const float* __restrict__ positions, const uint32_t* __restrict__ indices, uint32_t numTriangles,
+                                                       const float* __restrict__ models, const uint32_t* __restrict__ instanceIds, uint32_t numDrawn, int W, int H,
+                                                       unsigned int* __restrict__ depthBits)
+{
+    const unsigned long long total = (unsigned long long)numDrawn * numTriangles;
+    const unsigned long long id = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    RasterTri t;
+    t.valid = false;
+    if (id < total) {
+        const uint32_t d = (uint32_t)(id / numTriangles), tri = (uint32_t)(id - (unsigned long long)d * numTriangles);
+        const uint32_t inst = instanceIds ? instanceIds[d] : d;
+        const Mat4 LM = raster_mul(L, models + 16 * (size_t)inst);
+        t = raster_setup(LM, positions, indices + 3 * (size_t)tri, W, H);
+    }
+    const bool small = t.valid && (long long)(t.i1 - t.i0 + 1) * (t.j1 - t.j0 + 1) <= RASTER_SMALL_BOX;
+    if (small) {
+        const float area = (float)raster_edge(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2);
+        const bool tl0 = raster_top_left(t.x1, t.y1, t.x2, t.y2), tl1 = raster_top_left(t.x2, t.y2, t.x0, t.y0), tl2 = raster_top_left(t.x0, t.y0, t.x1, t.y1);
+        for (int j = t.j0; j <= t.j1; j++)
+            for (int i = t.i0; i <= t.i1; i++) raster_pixel(t, area, tl0, tl1, tl2, i, j, W, depthBits);
+    }
+    // the large ones: the whole wave on one triangle at a time
+    unsigned long long todo = __ballot(t.valid && !small);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        RasterTri b;
+        b.x0 = bcast64(t.x0, src); b.y0 = bcast64(t.y0, src); b.x1 = bcast64(t.x1, src); b.y1 = bcast64(t.y1, src); b.x2 = bcast64(t.x2, src); b.y2 = bcast64(t.y2, src);
+        b.z0 = __shfl(t.z0, src, 64); b.z1 = __shfl(t.z1, src, 64); b.z2 = __shfl(t.z2, src, 64);
+        b.i0 = __shfl(t.i0, src, 64); b.i1 = __shfl(t.i1, src, 64); b.j0 = __shfl(t.j0, src, 64); b.j1 = __shfl(t.j1, src, 64);
+        const float area = (float)raster_edge(b.x0, b.y0, b.x1, b.y1, b.x2, b.y2);
+        const bool tl0 = raster_top_left(b.x1, b.y1, b.x2, b.y2), tl1 = raster_top_left(b.x2, b.y2, b.x0, b.y0), tl2 = raster_top_left(b.x0, b.y0, b.x1, b.y1);
+        const int bw = b.i1 - b.i0 + 1;
+        const long long count = (long long)bw * (b.j1 - b.j0 + 1);
+        // 8 x 8 pixel blocks across lanes would be friendlier to the atomics' cache lines; a row-major walk keeps the index arithmetic trivial
+        for (long long p = lane; p < count; p += 64) {
+            const int jj = (int)(p / bw), ii = (int)(p - (long long)jj * bw);
+            raster_pixel(b, area, tl0, tl1, tl2, b.i0 + ii, b.j0 + jj, W, depthBits);
+        }
+    }
+}
+
+// ShadowCaster.shader:66-78 on the winning depth; canonical exp == shade.hip / the oracle (polynomial, no fused operations)
+__device__ __forceinline__ float raster_expf(float x)
+{
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) x = -87.0f;
+    const float n = floorf(x * 1.44269504088896341f + 0.5f);
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    const float y = (p * z + r) + 1.0f;
+    return ldexpf(y, (int)n);
+}
+
+__global__ __launch_bounds__(256) void k_shadow_resolve(const float* __restrict__ depth, size_t texels, int format, void* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= texels) return;
+    const float z = depth[i];
+    if (format == SAILOR_SHADOWMAP_R32G32B32A32_SFLOAT) {
+        float4 m = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (z > 0.0f) {
+            m.x = raster_expf(40.0f * z); m.y = m.x * m.x;
+            m.z = -raster_expf(-40.0f * z); m.w = m.z * m.z;
+        }
+        reinterpret_cast<float4*>(out)[i] = m;
+    } else if (format == SAILOR_SHADOWMAP_R16_SFLOAT) {
+        reinterpret_cast<__half*>(out)[i] = __float2half_rn(z);
+    } else {
+        reinterpret_cast<float*>(out)[i] = z;
+    }
+}
+
+extern "C" {
+
+int sailor_hip_raster_depth(SailorHipContext* ctx, const float* lightMatrix, const float* dPositions, const uint32_t* dIndices, uint32_t numTriangles,
+                            const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn, int32_t width, int32_t height, float* dDepth, int32_t clear)
+{
+    if (!ctx || !lightMatrix || !dDepth || width <= 0 || height <= 0 || width > 32768 || height > 32768) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (clear) SAILOR_TRY_HIP(ctx, hipMemsetAsync(dDepth, 0, (size_t)width * height * 4, ctx->stream));
+    if (numTriangles == 0 || numDrawn == 0) return SAILOR_HIP_OK;
+    if (!dPositions || !dIndices || !dModels) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    Mat4 L;
+    memcpy(L.m, lightMatrix, 64);
+    const unsigned long long total = (unsigned long long)numDrawn * numTriangles;
+    if ((total + 255) / 256 > 0x7FFFFFFFull) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(k_raster_depth, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, L, dPositions, dIndices, numTriangles, dModels, dInstanceIds,
+                       numDrawn, width, height, (unsigned int*)dDepth);
+    SAILOR_CHECK_LAUNCH(ctx, "k_raster_depth");
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_shadow_resolve(SailorHipContext* ctx, const float* dDepth, int32_t width, int32_t height, int32_t format, void* dShadowMap)
+{
+    if (!ctx || !dDepth || !dShadowMap || width <= 0 || height <= 0 || format < 0 || format > 2) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const size_t texels = (size_t)width * height;
+    hipLaunchKernelGGL(k_shadow_resolve, dim3((unsigned)((texels + 255) / 256)), dim3(256), 0, ctx->stream, dDepth, texels, format, dShadowMap);
+    SAILOR_CHECK_LAUNCH(ctx, "k_shadow_resolve");
+    return SAILOR_HIP_OK;
+}
+
+} // extern "C"

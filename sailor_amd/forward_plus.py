@@ -238,6 +238,32 @@ class EcsSweep:
         return self.world, self.world_aabb, self.visibility
 
 
+def raster_depth(ctx: "HipContext", light_matrix, positions: torch.Tensor, indices: torch.Tensor, models: torch.Tensor, width: int, height: int,
+                 instance_ids: torch.Tensor | None = None, depth: torch.Tensor | None = None) -> torch.Tensor:
+    """sailor_hip_raster_depth: the caster draws of one shadow pass -> float32 [height, width] depth (reversed Z, 0 = nothing drawn).
+    `depth` given = draw on top of it (a dependent pass); otherwise a cleared buffer is used."""
+    lm = np.ascontiguousarray(light_matrix, np.float32).reshape(16)
+    out = depth if depth is not None else torch.empty((height, width), dtype=torch.float32, device=ctx.device)
+    n = models.shape[0] if instance_ids is None else instance_ids.numel()
+    _lib.check(ctx._lib.sailor_hip_raster_depth(ctx.handle, lm.ctypes.data_as(C.POINTER(C.c_float)), _ptr(positions), _ptr(indices), indices.numel() // 3,
+                                                _ptr(models), _ptr(instance_ids) if instance_ids is not None else None, n, width, height, _ptr(out),
+                                                0 if depth is not None else 1), "sailor_hip_raster_depth", ctx.handle)
+    return out
+
+
+def shadow_resolve(ctx: "HipContext", depth: torch.Tensor, fmt: int) -> torch.Tensor:
+    """ShadowCaster.shader's fragment stage on the winning depths: RGBA32F EVSM moments, R16F or R32F depth"""
+    h, w = depth.shape
+    if fmt == _lib.SHADOWMAP_RGBA32F:
+        out = torch.empty((h, w, 4), dtype=torch.float32, device=ctx.device)
+    elif fmt == _lib.SHADOWMAP_R16F:
+        out = torch.empty((h, w), dtype=torch.float16, device=ctx.device)
+    else:
+        out = torch.empty((h, w), dtype=torch.float32, device=ctx.device)
+    _lib.check(ctx._lib.sailor_hip_shadow_resolve(ctx.handle, _ptr(depth), w, h, fmt, _ptr(out)), "sailor_hip_shadow_resolve", ctx.handle)
+    return out
+
+
 def csm_caster_masks(ctx: "HipContext", world_aabb: torch.Tensor, cascade_planes: np.ndarray) -> torch.Tensor:
     """sailor_hip_csm_caster_masks: world AABBs [n, 6] (the ECS sweep's output) x cascade frusta [k, 6, 4] -> int64 [k, ceil(n / 64)] bitmasks"""
     pl = np.ascontiguousarray(cascade_planes, np.float32).reshape(-1, 24)

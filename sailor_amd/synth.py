@@ -466,3 +466,24 @@ def make_instance_set(count: int, num_batches: int, seed: int = SEED, first_inst
     batches[:, 3] = np.arange(num_batches)
     batches[:, 4] = first
     return InstanceSet(instances=inst, batches=batches)
+
+
+def unit_cube_mesh():
+    """positions float32[8, 3] of the cube [-1, 1]^3 and its 12 outward-facing triangles uint32[12, 3] (the casters' stand-in mesh: every entity
+    is drawn as its local bounding box)"""
+    p = np.float32([[x, y, z] for z in (-1, 1) for y in (-1, 1) for x in (-1, 1)])
+    quads = [(0, 2, 3, 1), (4, 5, 7, 6), (0, 1, 5, 4), (2, 6, 7, 3), (0, 4, 6, 2), (1, 3, 7, 5)]
+    tris = np.uint32([t for a, b, c, d in quads for t in ((a, b, c), (a, c, d))])
+    return p, tris
+
+
+def caster_models(world: np.ndarray, local_aabb: np.ndarray) -> np.ndarray:
+    """PerInstanceData.model of the box casters: world matrix x translate(box centre) x scale(box half extents), float32[N, 16] column-major
+    (float64 product rounded once: these are inputs)"""
+    w = np.asarray(world, np.float64).reshape(-1, 4, 4).transpose(0, 2, 1)          # -> row-major 4x4
+    box = np.asarray(local_aabb, np.float64).reshape(-1, 6)
+    centre, half = 0.5 * (box[:, :3] + box[:, 3:]), 0.5 * (box[:, 3:] - box[:, :3])
+    local = np.zeros((len(box), 4, 4))
+    local[:, 0, 0] = half[:, 0]; local[:, 1, 1] = half[:, 1]; local[:, 2, 2] = half[:, 2]; local[:, 3, 3] = 1.0
+    local[:, :3, 3] = centre
+    return np.ascontiguousarray((w @ local).transpose(0, 2, 1).reshape(-1, 16).astype(np.float32))

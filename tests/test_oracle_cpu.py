@@ -393,3 +393,27 @@ def test_mesh_cull_and_prefilter_goldens():
     env = oracle.prefilter_env_map(sky.env_chain, 16, sky.env_levels)
     np.testing.assert_allclose(env, p["env"], rtol=2e-6, atol=1e-7)   # libm's cosf / sinf / log2f may differ in the last bit between hosts
     np.testing.assert_allclose(oracle.compute_irradiance_map(env, 16, sky.env_levels, 2), p["irradiance"], rtol=2e-6, atol=1e-7)
+
+
+def test_depth_rasteriser_rules():
+    """The canonical rasteriser of the shadow casters: a quad of two triangles covers its 8 x 8 texels exactly once each (top-left rule), the map's
+    row 0 is clip-space +y, the larger (nearer, reversed-Z) depth wins, depths outside [0, 1] are clipped, a box seen along an axis is a square."""
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    quad = np.float32([[-0.5, -0.5, 0.3], [0.5, -0.5, 0.3], [0.5, 0.5, 0.3], [-0.5, 0.5, 0.3]])
+    idx = np.uint32([[0, 1, 2], [0, 2, 3]])
+    one = ident.reshape(1, 16)
+    d = oracle.raster_depth(ident, quad, idx, one, 16, 16)
+    assert (d > 0).sum() == 64 and (d[4:12, 4:12] == np.float32(0.3)).all()
+    a, b = oracle.raster_depth(ident, quad, idx[:1], one, 16, 16), oracle.raster_depth(ident, quad, idx[1:, ::-1], one, 16, 16)
+    assert ((a > 0) & (b > 0)).sum() == 0 and ((a > 0) | (b > 0)).sum() == 64
+    top = oracle.raster_depth(ident, np.float32([[-1, 0.5, 0.2], [1, 0.5, 0.2], [0, 1.0, 0.2]]), np.uint32([[0, 1, 2]]), one, 16, 16)
+    assert top[:4].max() > 0 and top[4:].max() == 0
+    pos, tris = synth.unit_cube_mesh()
+    scale = np.diag(np.float32([0.5, 0.25, 0.1, 1.0])).T.reshape(1, 16)
+    scale[0, 14] = 0.5                                           # centre at z = 0.5: the box spans z in [0.4, 0.6]
+    box = oracle.raster_depth(ident, pos, tris, scale, 32, 32)
+    assert (box > 0).sum() == 16 * 8 and np.allclose(box[box > 0], 0.6)
+    far = scale.copy(); far[0, 14] = 1.2                         # spans [1.1, 1.3]: clipped away
+    assert oracle.raster_depth(ident, pos, tris, far, 32, 32).max() == 0
+    m = oracle.shadow_resolve_evsm(box)
+    assert (m[box == 0] == 0).all() and np.allclose(m[box > 0][:, 0], np.exp(40 * 0.6), rtol=1e-5)

@@ -1,0 +1,78 @@
+"""The shadow-map producer (compute rasteriser for ShadowPrepassNode's caster draws + ShadowCaster.shader's fragment stage) through the C-ABI:
+depth buffers and resolved shadow maps equal the oracle's bit for bit -- the winning depth of a texel does not depend on fragment order."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from sailor_amd import _lib, host, synth
+from sailor_amd.forward_plus import EcsSweep, csm_caster_masks, raster_depth, shadow_resolve
+
+pytestmark = pytest.mark.gpu
+IDENTITY = np.eye(4, dtype=np.float32).reshape(16)
+
+
+def _gpu(ctx, lm, pos, idx, models, w, h, ids=None, depth=None):
+    d = raster_depth(ctx, lm, torch.from_numpy(np.ascontiguousarray(pos, np.float32)).to(ctx.device),
+                     torch.from_numpy(np.ascontiguousarray(idx, np.uint32).view(np.int32)).to(ctx.device),
+                     torch.from_numpy(np.ascontiguousarray(models, np.float32)).to(ctx.device), w, h,
+                     None if ids is None else torch.from_numpy(np.ascontiguousarray(ids, np.uint32).view(np.int32)).to(ctx.device), depth)
+    ctx.synchronize()
+    return d
+
+
+def test_fill_rule_viewport_flip_depth_test_and_clipping(ctx):
+    W = H = 16
+    quad = np.float32([[-0.5, -0.5, 0.3], [0.5, -0.5, 0.3], [0.5, 0.5, 0.3], [-0.5, 0.5, 0.3]])
+    idx = np.uint32([[0, 1, 2], [0, 2, 3]])
+    one = IDENTITY.reshape(1, 16)
+    d = _gpu(ctx, IDENTITY, quad, idx, one, W, H).cpu().numpy()
+    np.testing.assert_array_equal(d, oracle.raster_depth(IDENTITY, quad, idx, one, W, H))
+    assert (d > 0).sum() == 64 and (d[4:12, 4:12] == np.float32(0.3)).all()
+    # the two triangles share the diagonal: no texel belongs to both, none is missed (top-left rule); either winding is drawn
+    a = _gpu(ctx, IDENTITY, quad, idx[:1], one, W, H).cpu().numpy()
+    b = _gpu(ctx, IDENTITY, quad, idx[1:, ::-1], one, W, H).cpu().numpy()
+    assert ((a > 0) & (b > 0)).sum() == 0 and ((a > 0) | (b > 0)).sum() == 64
+    # viewport (0, H, W, -H): +y of clip space is the TOP of the map; reversed Z: the larger depth wins; z outside [0, 1] is clipped
+    tri = np.float32([[-1, 0.5, 0.2], [1, 0.5, 0.2], [0, 1.0, 0.2], [-1, -1, 0.6], [1, -1, 0.6], [0, 1, 0.6], [-1, -1, 1.5], [1, -1, 1.5], [0, 1, 1.5]])
+    idx3 = np.uint32([[0, 1, 2], [3, 4, 5], [6, 7, 8]])
+    d = _gpu(ctx, IDENTITY, tri, idx3, one, W, H).cpu().numpy()
+    np.testing.assert_array_equal(d, oracle.raster_depth(IDENTITY, tri, idx3, one, W, H))
+    assert d[:4].max() > 0 and d.max() == np.float32(0.6) and set(np.unique(d)) == {np.float32(0.0), np.float32(0.2), np.float32(0.6)}
+    assert (d[:3][d[:3] > 0] >= np.float32(0.2)).all() and d[12, 8] == np.float32(0.6)
+    # a sloped triangle: interpolated depths, drawn on top of an existing buffer (a dependent pass)
+    slope = np.float32([[-0.9, -0.8, 0.1], [0.8, -0.6, 0.9], [-0.2, 0.9, 0.5]])
+    base = _gpu(ctx, IDENTITY, quad, idx, one, W, H)
+    d = _gpu(ctx, IDENTITY, slope, np.uint32([[0, 1, 2]]), one, W, H, depth=base).cpu().numpy()
+    ref = oracle.raster_depth(IDENTITY, slope, np.uint32([[0, 1, 2]]), one, W, H, depth=oracle.raster_depth(IDENTITY, quad, idx, one, W, H))
+    np.testing.assert_array_equal(d.view(np.uint32), ref.view(np.uint32))
+    assert len(np.unique(d)) > 20
+
+
+@pytest.mark.parametrize("cascade,size", [(0, 512), (1, 256), (3, 256)])
+def test_box_casters_of_a_cascade_and_the_resolved_maps(ctx, cascade, size):
+    """3 000 entities drawn as their bounding boxes into a cascade of the directional light (the light matrices of LightingECS.cpp:276-298), only the
+    entities the cascade's frustum overlaps (sailor_hip_csm_caster_masks); then ShadowCaster's fragment stage in all three map formats."""
+    cam = synth.make_camera(1280, 720)
+    ents = synth.make_entities(3000)
+    sweep = EcsSweep(ctx, ents)
+    planes, _ = host.extract_frustum_planes(cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+    world, aabb, _ = sweep.run(planes)
+    sh = synth.make_shadow_set(cam, 16)
+    cplanes = np.stack([host.extract_frustum_planes_matrix(sh.lights_matrices[k])[0] for k in range(4)])
+    masks = csm_caster_masks(ctx, aabb, cplanes).cpu().numpy().view(np.uint64)
+    ids = np.nonzero(np.unpackbits(masks[cascade].view(np.uint8), bitorder="little")[:3000])[0].astype(np.uint32)
+    assert len(ids) > 10
+    pos, tris = synth.unit_cube_mesh()
+    models = synth.caster_models(world.cpu().numpy(), ents.local_aabb)
+    lm = sh.lights_matrices[cascade]
+    d = _gpu(ctx, lm, pos, tris, models, size, size, ids=ids)
+    ref = oracle.raster_depth(lm, pos, tris, models, size, size, instance_ids=ids)
+    np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    cover = float((ref > 0).mean())
+    assert 0.001 < cover < 1.0, cover
+    evsm = shadow_resolve(ctx, d, _lib.SHADOWMAP_RGBA32F).cpu().numpy()
+    np.testing.assert_array_equal(evsm.view(np.uint32), oracle.shadow_resolve_evsm(ref).view(np.uint32))
+    assert (evsm[ref == 0] == 0).all() and (evsm[ref > 0][:, 0] >= 1.0).all()
+    np.testing.assert_array_equal(shadow_resolve(ctx, d, _lib.SHADOWMAP_R16F).cpu().numpy().view(np.uint16), ref.astype(np.float16).view(np.uint16))
+    np.testing.assert_array_equal(shadow_resolve(ctx, d, _lib.SHADOWMAP_R32F).cpu().numpy(), ref)
