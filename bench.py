@@ -30,6 +30,9 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np
 import torch
 from ctypes import c_float as C_float
+import ctypes as _C
+C_float_p = _C.POINTER(_C.c_float)
+L_R16F, L_RGBA32F = 0, 1
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -253,6 +256,56 @@ def ibl_prefilter_block(ctx, steps: int):
             "irradiance_gsamples_per_s": irr_samples / irr_ms / 1e6, "env_samples": env_samples, "irradiance_samples": irr_samples,
             "cpu_1thread_env_msamples_per_s": 6 * 32 * 32 * 1024 / t_env / 1e6, "cpu_1thread_irradiance_msamples_per_s": 6 * 2 * 2 * 65536 / t_irr / 1e6,
             "kind": "port"}
+
+
+def shadow_pass_block(ctx, count: int, size: int, steps: int, use_coarse: bool = True):
+    """SURVEY.md 8f rank 3, the producer: the shadow passes of one directional light over `count` entities drawn as their bounding boxes (12
+    triangles each) -- cascade sets from the sweep's world boxes, the caster draws of the four cascades into size x size depth buffers (compute
+    rasteriser), ShadowCaster's fragment stage (cascade 0: EVSM moments, 1-3: R16F) and the EVSM blur of cascade 0.  CPU: the oracle rasteriser
+    on a bounded sample of the instances of cascade 3."""
+    from oracle import oracle
+    from sailor_amd.forward_plus import csm_caster_masks, evsm_blur, raster_depth, shadow_resolve
+    cam = synth.make_camera(3840, 2160)
+    ents = synth.make_entities(count)
+    sweep = EcsSweep(ctx, ents)
+    planes, _ = host.extract_frustum_planes(cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+    world, aabb, _ = sweep.run(planes)
+    sh = synth.make_shadow_set(cam, 16)
+    cplanes = np.stack([host.extract_frustum_planes_matrix(sh.lights_matrices[k])[0] for k in range(4)])
+    masks = csm_caster_masks(ctx, aabb, cplanes).cpu().numpy().view(np.uint64)
+    pos_h, tris_h = synth.unit_cube_mesh()
+    models_h = synth.caster_models(world.cpu().numpy(), ents.local_aabb)
+    pos = torch.from_numpy(pos_h).to(ctx.device); tris = torch.from_numpy(tris_h.view(np.int32)).to(ctx.device)
+    models = torch.from_numpy(models_h).to(ctx.device)
+    ids_h = [np.nonzero(np.unpackbits(masks[k].view(np.uint8), bitorder="little")[:count])[0].astype(np.uint32) for k in range(4)]
+    ids = [torch.from_numpy(i.view(np.int32)).to(ctx.device) for i in ids_h]
+    depth = [torch.empty((size, size), dtype=torch.float32, device=ctx.device) for _ in range(4)]
+    coarse = torch.empty(((size + 7) // 8, (size + 7) // 8), dtype=torch.int32, device=ctx.device) if use_coarse else None
+    out = {"entities": count, "map_size": size, "cascades": []}
+    total = 0.0
+    for k in range(4):
+        def draw(k=k):
+            ctx._lib.sailor_hip_raster_depth(ctx.handle, np.ascontiguousarray(sh.lights_matrices[k], np.float32).ctypes.data_as(C_float_p), pos.data_ptr(), tris.data_ptr(), 12,
+                                             models.data_ptr(), ids[k].data_ptr(), len(ids_h[k]), size, size, depth[k].data_ptr(), 1, coarse.data_ptr() if coarse is not None else None)
+        _, ms, _, _ = event_ms(draw, steps)
+        _, rs, _, _ = event_ms(lambda k=k: shadow_resolve(ctx, depth[k], L_RGBA32F if k == 0 else L_R16F), steps)
+        cover = float((depth[k] > 0).float().mean().item())
+        out["cascades"].append({"instances": int(len(ids_h[k])), "triangles": int(len(ids_h[k])) * 12, "raster_ms": ms, "resolve_ms": rs, "covered": cover,
+                                "mtriangles_per_s": len(ids_h[k]) * 12 / ms / 1e3})
+        total += ms + rs
+    moments = shadow_resolve(ctx, depth[0], L_RGBA32F)
+    tmp = torch.empty_like(moments)
+    _, bs, _, _ = event_ms(lambda: evsm_blur(ctx, moments, 2, 5, tmp), steps)
+    out["blur_cascade0_ms"] = bs
+    out["all_passes_ms"] = total + bs
+    sample = ids_h[3][:: max(1, len(ids_h[3]) // 20000)]
+    t0 = time.perf_counter()
+    oracle.raster_depth(sh.lights_matrices[3], pos_h, tris_h, models_h, size, size, instance_ids=sample)
+    t1 = time.perf_counter() - t0
+    out["cpu_1thread_mtriangles_per_s"] = len(sample) * 12 / t1 / 1e6
+    out["cpu_sample"] = f"{len(sample)} instances of cascade 3"
+    out["kind"] = "port"
+    return out
 
 
 def linearize_block(ctx, frame, fp, d_lights, steps: int):
@@ -644,6 +697,7 @@ def main():
                 out["ambient_ibl"] = ambient_block(ctx, frame, fp, d_lights, d_surface, 30)
             out["evsm_blur"] = blur_block(ctx, 10)
             out["ibl_prefilter"] = ibl_prefilter_block(ctx, 3)
+            out["shadow_passes"] = shadow_pass_block(ctx, 1 << 20, 4096, 5)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -5,8 +5,14 @@
 // a plain atomicMax over float bits (depths are > 0) and the result is bit-exact against the sequential oracle.
 //
 // Work distribution: one LANE per (instance, triangle) sets its triangle up.  Triangles whose pixel box is small are filled by their own lane;
-// the others are handed round the wave one after the other (the set-up travels by lane broadcast) and all 64 lanes walk the box together --
-// caster geometry mixes boxes of a few texels with boxes of a few hundred, and one lane alone would keep its wave waiting for it.
+// the others are handed round the wave one after the other (the set-up travels by lane broadcast): the wave first looks at the box as 8 x 8-texel
+// BLOCKS, one per lane -- a block entirely outside an edge is dropped, and so is a block whose coarse depth says nothing of this triangle can
+// still win there -- and then fills the surviving blocks with one lane per texel.
+//
+// Coarse depth (optional workspace, one word per 8 x 8 block): a LOWER BOUND of every depth stored in the block.  A triangle that covers a whole
+// block raises it to the smallest depth it wrote there; a triangle (or a block of one) whose largest possible depth does not exceed it is
+// skipped.  Bounds only -- stale values are merely less effective -- so the depth buffer is the same with and without it; shadow casters overdraw
+// each texel hundreds of times (every box along the light direction lands on it), and this is what makes the passes finish.
 #include "common.h"
 #include <hip/hip_fp16.h>
 
@@ -93,13 +99,24 @@ __device__ __forceinline__ long long bcast64(long long v, int src)
     return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
 }
 
+#define RASTER_Z_MARGIN 1.0e-6f // covers the rounding of the per-texel interpolation when a bound is derived from other points of the same plane
+
+// z of the triangle's plane at texel (i, j), the per-texel formula (edge functions need not be non-negative here)
+__device__ __forceinline__ float raster_plane_z(const RasterTri& t, float area, int i, int j)
+{
+    const long long px = 256ll * i + 128, py = 256ll * j + 128;
+    const long long e1 = raster_edge(t.x2, t.y2, t.x0, t.y0, px, py), e2 = raster_edge(t.x0, t.y0, t.x1, t.y1, px, py);
+    return (t.z0 + (t.z1 - t.z0) * ((float)e1 / area)) + (t.z2 - t.z0) * ((float)e2 / area);
+}
+
 __global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, const float* __restrict__ positions, const uint32_t* __restrict__ indices, uint32_t numTriangles,
                                                        const float* __restrict__ models, const uint32_t* __restrict__ instanceIds, uint32_t numDrawn, int W, int H,
-                                                       unsigned int* __restrict__ depthBits)
+                                                       unsigned int* __restrict__ depthBits, unsigned int* __restrict__ coarse)
 {
     const unsigned long long total = (unsigned long long)numDrawn * numTriangles;
     const unsigned long long id = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    const int CW = (W + 7) >> 3;
     RasterTri t;
     t.valid = false;
     if (id < total) {
@@ -108,12 +125,19 @@ __global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, const float* __res
         const Mat4 LM = raster_mul(L, models + 16 * (size_t)inst);
         t = raster_setup(LM, positions, indices + 3 * (size_t)tri, W, H);
     }
+    const float zmaxTri = fmaxf(t.z0, fmaxf(t.z1, t.z2)) + RASTER_Z_MARGIN; // inside the triangle z is a convex combination of the vertices'
+    if (t.valid && !(zmaxTri > 0.0f)) t.valid = false;                        // nothing of it can pass z > 0
     const bool small = t.valid && (long long)(t.i1 - t.i0 + 1) * (t.j1 - t.j0 + 1) <= RASTER_SMALL_BOX;
     if (small) {
-        const float area = (float)raster_edge(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2);
-        const bool tl0 = raster_top_left(t.x1, t.y1, t.x2, t.y2), tl1 = raster_top_left(t.x2, t.y2, t.x0, t.y0), tl2 = raster_top_left(t.x0, t.y0, t.x1, t.y1);
-        for (int j = t.j0; j <= t.j1; j++)
-            for (int i = t.i0; i <= t.i1; i++) raster_pixel(t, area, tl0, tl1, tl2, i, j, W, depthBits);
+        bool hidden = false;
+        if (coarse && (t.i0 >> 3) == (t.i1 >> 3) && (t.j0 >> 3) == (t.j1 >> 3))
+            hidden = zmaxTri <= __uint_as_float(coarse[(size_t)(t.j0 >> 3) * CW + (t.i0 >> 3)]);
+        if (!hidden) {
+            const float area = (float)raster_edge(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2);
+            const bool tl0 = raster_top_left(t.x1, t.y1, t.x2, t.y2), tl1 = raster_top_left(t.x2, t.y2, t.x0, t.y0), tl2 = raster_top_left(t.x0, t.y0, t.x1, t.y1);
+            for (int j = t.j0; j <= t.j1; j++)
+                for (int i = t.i0; i <= t.i1; i++) raster_pixel(t, area, tl0, tl1, tl2, i, j, W, depthBits);
+        }
     }
     // the large ones: the whole wave on one triangle at a time
     unsigned long long todo = __ballot(t.valid && !small);
@@ -124,14 +148,67 @@ __global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, const float* __res
         b.x0 = bcast64(t.x0, src); b.y0 = bcast64(t.y0, src); b.x1 = bcast64(t.x1, src); b.y1 = bcast64(t.y1, src); b.x2 = bcast64(t.x2, src); b.y2 = bcast64(t.y2, src);
         b.z0 = __shfl(t.z0, src, 64); b.z1 = __shfl(t.z1, src, 64); b.z2 = __shfl(t.z2, src, 64);
         b.i0 = __shfl(t.i0, src, 64); b.i1 = __shfl(t.i1, src, 64); b.j0 = __shfl(t.j0, src, 64); b.j1 = __shfl(t.j1, src, 64);
+        const float zmaxB = __shfl(zmaxTri, src, 64);
         const float area = (float)raster_edge(b.x0, b.y0, b.x1, b.y1, b.x2, b.y2);
         const bool tl0 = raster_top_left(b.x1, b.y1, b.x2, b.y2), tl1 = raster_top_left(b.x2, b.y2, b.x0, b.y0), tl2 = raster_top_left(b.x0, b.y0, b.x1, b.y1);
-        const int bw = b.i1 - b.i0 + 1;
-        const long long count = (long long)bw * (b.j1 - b.j0 + 1);
-        // 8 x 8 pixel blocks across lanes would be friendlier to the atomics' cache lines; a row-major walk keeps the index arithmetic trivial
-        for (long long p = lane; p < count; p += 64) {
-            const int jj = (int)(p / bw), ii = (int)(p - (long long)jj * bw);
-            raster_pixel(b, area, tl0, tl1, tl2, b.i0 + ii, b.j0 + jj, W, depthBits);
+        const int bi0 = b.i0 >> 3, bj0 = b.j0 >> 3, bw = (b.i1 >> 3) - bi0 + 1, bh = (b.j1 >> 3) - bj0 + 1;
+        const int nb = bw * bh;
+        for (int base = 0; base < nb; base += 64) {
+            // ---- one lane per 8 x 8 block: can anything of this triangle land in it, and can it still win? ----
+            const int blk = base + lane;
+            bool alive = blk < nb;
+            int bi = 0, bj = 0;
+            if (alive) {
+                bj = blk / bw; bi = blk - bj * bw;
+                bi += bi0; bj += bj0;
+                const int xa = bi * 8, xb = bi * 8 + 7, ya = bj * 8, yb = bj * 8 + 7; // the block's corner texels
+                // an edge function is affine: its maximum over the block is at a corner texel
+                long long m0 = -1, m1 = -1, m2 = -1;
+                float zc = -1.0f;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int cx = (c & 1) ? xb : xa, cy = (c & 2) ? yb : ya;
+                    const long long px = 256ll * cx + 128, py = 256ll * cy + 128;
+                    m0 = max(m0, raster_edge(b.x1, b.y1, b.x2, b.y2, px, py));
+                    m1 = max(m1, raster_edge(b.x2, b.y2, b.x0, b.y0, px, py));
+                    m2 = max(m2, raster_edge(b.x0, b.y0, b.x1, b.y1, px, py));
+                    zc = fmaxf(zc, raster_plane_z(b, area, cx, cy));
+                }
+                alive = m0 >= 0 && m1 >= 0 && m2 >= 0;
+                if (alive && coarse) {
+                    const float zbound = fminf(zmaxB, zc + RASTER_Z_MARGIN); // the plane over the block, and the triangle as a whole
+                    alive = zbound > __uint_as_float(coarse[(size_t)bj * CW + bi]);
+                }
+            }
+            unsigned long long live = __ballot(alive);
+            // ---- the surviving blocks, one lane per texel ----
+            while (live) {
+                const int s2 = __builtin_ctzll(live);
+                live &= live - 1ull;
+                const int cbi = __shfl(bi, s2, 64), cbj = __shfl(bj, s2, 64);
+                const int i = cbi * 8 + (lane & 7), j = cbj * 8 + (lane >> 3);
+                bool wrote = false;
+                float z = 2.0f;
+                if (i >= b.i0 && i <= b.i1 && j >= b.j0 && j <= b.j1) {
+                    const long long px = 256ll * i + 128, py = 256ll * j + 128;
+                    const long long e0 = raster_edge(b.x1, b.y1, b.x2, b.y2, px, py), e1 = raster_edge(b.x2, b.y2, b.x0, b.y0, px, py),
+                                    e2 = raster_edge(b.x0, b.y0, b.x1, b.y1, px, py);
+                    const bool in = !(e0 < 0 || e1 < 0 || e2 < 0) && !((e0 == 0 && !tl0) || (e1 == 0 && !tl1) || (e2 == 0 && !tl2));
+                    if (in) {
+                        z = (b.z0 + (b.z1 - b.z0) * ((float)e1 / area)) + (b.z2 - b.z0) * ((float)e2 / area);
+                        if (z > 0.0f && z <= 1.0f) {
+                            atomicMax(depthBits + (size_t)j * W + i, __float_as_uint(z));
+                            wrote = true;
+                        }
+                    }
+                }
+                if (coarse && __ballot(wrote) == ~0ull) { // the whole block now holds depths >= the smallest one written here
+                    float zmin = z;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) zmin = fminf(zmin, __shfl_xor(zmin, d, 64));
+                    if (lane == 0) atomicMax(coarse + (size_t)cbj * CW + cbi, __float_as_uint(zmin));
+                }
+            }
         }
     }
 }
@@ -177,10 +254,14 @@ __global__ __launch_bounds__(256) void k_shadow_resolve(const float* __restrict_
 extern "C" {
 
 int sailor_hip_raster_depth(SailorHipContext* ctx, const float* lightMatrix, const float* dPositions, const uint32_t* dIndices, uint32_t numTriangles,
-                            const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn, int32_t width, int32_t height, float* dDepth, int32_t clear)
+                            const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn, int32_t width, int32_t height, float* dDepth, int32_t clear,
+                            uint32_t* dCoarseDepth)
 {
     if (!ctx || !lightMatrix || !dDepth || width <= 0 || height <= 0 || width > 32768 || height > 32768) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-    if (clear) SAILOR_TRY_HIP(ctx, hipMemsetAsync(dDepth, 0, (size_t)width * height * 4, ctx->stream));
+    if (clear) {
+        SAILOR_TRY_HIP(ctx, hipMemsetAsync(dDepth, 0, (size_t)width * height * 4, ctx->stream));
+        if (dCoarseDepth) SAILOR_TRY_HIP(ctx, hipMemsetAsync(dCoarseDepth, 0, (size_t)((width + 7) / 8) * ((height + 7) / 8) * 4, ctx->stream));
+    }
     if (numTriangles == 0 || numDrawn == 0) return SAILOR_HIP_OK;
     if (!dPositions || !dIndices || !dModels) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     Mat4 L;
@@ -188,7 +269,7 @@ int sailor_hip_raster_depth(SailorHipContext* ctx, const float* lightMatrix, con
     const unsigned long long total = (unsigned long long)numDrawn * numTriangles;
     if ((total + 255) / 256 > 0x7FFFFFFFull) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(k_raster_depth, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, L, dPositions, dIndices, numTriangles, dModels, dInstanceIds,
-                       numDrawn, width, height, (unsigned int*)dDepth);
+                       numDrawn, width, height, (unsigned int*)dDepth, (unsigned int*)dCoarseDepth);
     SAILOR_CHECK_LAUNCH(ctx, "k_raster_depth");
     return SAILOR_HIP_OK;
 }

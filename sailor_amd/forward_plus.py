@@ -239,15 +239,16 @@ class EcsSweep:
 
 
 def raster_depth(ctx: "HipContext", light_matrix, positions: torch.Tensor, indices: torch.Tensor, models: torch.Tensor, width: int, height: int,
-                 instance_ids: torch.Tensor | None = None, depth: torch.Tensor | None = None) -> torch.Tensor:
+                 instance_ids: torch.Tensor | None = None, depth: torch.Tensor | None = None, coarse: torch.Tensor | None = None) -> torch.Tensor:
     """sailor_hip_raster_depth: the caster draws of one shadow pass -> float32 [height, width] depth (reversed Z, 0 = nothing drawn).
-    `depth` given = draw on top of it (a dependent pass); otherwise a cleared buffer is used."""
+    `depth` given = draw on top of it (a dependent pass); otherwise a cleared buffer is used.  `coarse`: int32 [ceil(h / 8), ceil(w / 8)] scratch that
+    belongs to the depth buffer (hierarchical depth; same result, much less fill)."""
     lm = np.ascontiguousarray(light_matrix, np.float32).reshape(16)
     out = depth if depth is not None else torch.empty((height, width), dtype=torch.float32, device=ctx.device)
     n = models.shape[0] if instance_ids is None else instance_ids.numel()
     _lib.check(ctx._lib.sailor_hip_raster_depth(ctx.handle, lm.ctypes.data_as(C.POINTER(C.c_float)), _ptr(positions), _ptr(indices), indices.numel() // 3,
                                                 _ptr(models), _ptr(instance_ids) if instance_ids is not None else None, n, width, height, _ptr(out),
-                                                0 if depth is not None else 1), "sailor_hip_raster_depth", ctx.handle)
+                                                0 if depth is not None else 1, _ptr(coarse)), "sailor_hip_raster_depth", ctx.handle)
     return out
 
 

@@ -69,6 +69,14 @@ def test_box_casters_of_a_cascade_and_the_resolved_maps(ctx, cascade, size):
     d = _gpu(ctx, lm, pos, tris, models, size, size, ids=ids)
     ref = oracle.raster_depth(lm, pos, tris, models, size, size, instance_ids=ids)
     np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # with the coarse-depth workspace: fewer texels touched, the same buffer; every coarse word is a lower bound of its block
+    coarse = torch.empty(((size + 7) // 8, (size + 7) // 8), dtype=torch.int32, device=ctx.device)
+    dc = raster_depth(ctx, lm, torch.from_numpy(pos).to(ctx.device), torch.from_numpy(tris.view(np.int32)).to(ctx.device), torch.from_numpy(models).to(ctx.device),
+                      size, size, torch.from_numpy(ids.view(np.int32)).to(ctx.device), coarse=coarse)
+    ctx.synchronize()
+    np.testing.assert_array_equal(dc.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    lower = coarse.cpu().numpy().view(np.float32)
+    assert (lower <= ref.reshape(size // 8, 8, size // 8, 8).min(axis=(1, 3))).all() and (lower > 0).any()
     cover = float((ref > 0).mean())
     assert 0.001 < cover < 1.0, cover
     evsm = shadow_resolve(ctx, d, _lib.SHADOWMAP_RGBA32F).cpu().numpy()
@@ -76,3 +84,53 @@ def test_box_casters_of_a_cascade_and_the_resolved_maps(ctx, cascade, size):
     assert (evsm[ref == 0] == 0).all() and (evsm[ref > 0][:, 0] >= 1.0).all()
     np.testing.assert_array_equal(shadow_resolve(ctx, d, _lib.SHADOWMAP_R16F).cpu().numpy().view(np.uint16), ref.astype(np.float16).view(np.uint16))
     np.testing.assert_array_equal(shadow_resolve(ctx, d, _lib.SHADOWMAP_R32F).cpu().numpy(), ref)
+
+
+def test_entities_to_shadow_maps_to_shaded_frame(ctx):
+    """The whole producer chain in front of K3, on the GPU and on the oracle: ECS sweep -> cascade caster sets -> caster draws of the four cascades
+    -> ShadowCaster's fragment stage (EVSM moments for cascade 0, R16F depth for 1-3) -> EVSM blur of cascade 0 -> the frame shaded with THESE maps.
+    Every stage up to the maps is bit-exact, so both shaders see the same maps; the radiance agrees to the shade tolerance."""
+    from sailor_amd.forward_plus import ForwardPlus, evsm_blur, upload_lights, upload_shadow_maps
+    f = synth.make_frame("tiny_csm")
+    cam, W, H, S = f.cam, f.cam.width, f.cam.height, 128
+    ents = synth.make_entities(4000)
+    ents.transforms[:, 0:3] *= np.float32(0.05)           # pull the cloud into the first cascades so that the boxes shadow the visible surface
+    planes, _ = host.extract_frustum_planes(cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+    world, aabb, _ = EcsSweep(ctx, ents).run(planes)
+    lms = f.shadows.lights_matrices
+    cplanes = np.stack([host.extract_frustum_planes_matrix(lms[k])[0] for k in range(4)])
+    masks = csm_caster_masks(ctx, aabb, cplanes).cpu().numpy().view(np.uint64)
+    pos, tris = synth.unit_cube_mesh()
+    models = synth.caster_models(world.cpu().numpy(), ents.local_aabb)
+    d_pos, d_tris, d_models = (torch.from_numpy(pos).to(ctx.device), torch.from_numpy(tris.view(np.int32)).to(ctx.device), torch.from_numpy(models).to(ctx.device))
+    # oracle side of the same chain
+    ow, oaabb, _ = oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes)
+    np.testing.assert_array_equal(masks, oracle.csm_caster_masks(oaabb, cplanes))
+    gpu_maps, ref_maps = [], []
+    for k in range(4):
+        ids = np.nonzero(np.unpackbits(masks[k].view(np.uint8), bitorder="little")[:4000])[0].astype(np.uint32)
+        d = raster_depth(ctx, lms[k], d_pos, d_tris, d_models, S, S, torch.from_numpy(ids.view(np.int32)).to(ctx.device))
+        ref = oracle.raster_depth(lms[k], pos, tris, models, S, S, instance_ids=ids)
+        if k == 0:
+            m = evsm_blur(ctx, shadow_resolve(ctx, d, _lib.SHADOWMAP_RGBA32F), 2, 5)
+            gpu_maps.append(m.cpu().numpy())
+            ref_maps.append(oracle.evsm_blur(oracle.shadow_resolve_evsm(ref), 2, 5))
+        else:
+            gpu_maps.append(shadow_resolve(ctx, d, _lib.SHADOWMAP_R16F).cpu().numpy())
+            ref_maps.append(ref.astype(np.float16))
+        np.testing.assert_array_equal(gpu_maps[k].view(np.uint8), ref_maps[k].view(np.uint8))
+    assert sum(float((m != 0).mean()) for m in ref_maps) > 0.05
+    # shade with the produced maps
+    shadows = synth.ShadowSet(lights_matrices=lms, maps=gpu_maps, size=S)
+    fp = ForwardPlus(ctx, W, H, len(f.lights))
+    lights = upload_lights(f.lights, ctx.device)
+    fp.cull(cam.frame, lights, len(f.lights), torch.from_numpy(f.depth).to(ctx.device))
+    desc, keep = upload_shadow_maps(shadows, ctx.device)
+    got = fp.shade(cam.frame, torch.from_numpy(f.surface).to(ctx.device), lights, len(f.lights), desc).cpu().numpy()
+    g, idx, _ = oracle.light_cull(cam.frame, W, H, f.lights, f.depth)
+    odesc, okeep = oracle.make_csm(lms, ref_maps)
+    ref = oracle.shade(cam.frame, W, H, f.surface, f.lights, g, idx, odesc)
+    unshadowed = oracle.shade(cam.frame, W, H, f.surface, f.lights, g, idx, None)
+    assert np.abs(ref - unshadowed).max() > 0.5, "the boxes cast shadows on the visible surface"
+    err = np.abs(got.astype(np.float64) - ref)
+    assert (err <= 1e-4 * np.abs(ref) + 1e-5).all(), err.max()
