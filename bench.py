@@ -258,7 +258,7 @@ def ibl_prefilter_block(ctx, steps: int):
             "kind": "port"}
 
 
-def shadow_pass_block(ctx, count: int, size: int, steps: int, use_coarse: bool = True):
+def shadow_pass_block(ctx, count: int, size: int, steps: int, use_coarse: bool = True, front_to_back: bool = True):
     """SURVEY.md 8f rank 3, the producer: the shadow passes of one directional light over `count` entities drawn as their bounding boxes (12
     triangles each) -- cascade sets from the sweep's world boxes, the caster draws of the four cascades into size x size depth buffers (compute
     rasteriser), ShadowCaster's fragment stage (cascade 0: EVSM moments, 1-3: R16F) and the EVSM blur of cascade 0.  CPU: the oracle rasteriser
@@ -278,10 +278,16 @@ def shadow_pass_block(ctx, count: int, size: int, steps: int, use_coarse: bool =
     pos = torch.from_numpy(pos_h).to(ctx.device); tris = torch.from_numpy(tris_h.view(np.int32)).to(ctx.device)
     models = torch.from_numpy(models_h).to(ctx.device)
     ids_h = [np.nonzero(np.unpackbits(masks[k].view(np.uint8), bitorder="little")[:count])[0].astype(np.uint32) for k in range(4)]
+    if front_to_back:  # nearest to the light first (reversed Z: largest clip z): the coarse depth is tight after the first few boxes
+        for k in range(4):
+            lm = np.asarray(sh.lights_matrices[k], np.float64).reshape(4, 4).T
+            centre = models_h[ids_h[k]].reshape(-1, 4, 4)[:, 3, :3].astype(np.float64)
+            z = centre @ lm[2, :3] + lm[2, 3]
+            ids_h[k] = np.ascontiguousarray(ids_h[k][np.argsort(-z, kind="stable")])
     ids = [torch.from_numpy(i.view(np.int32)).to(ctx.device) for i in ids_h]
     depth = [torch.empty((size, size), dtype=torch.float32, device=ctx.device) for _ in range(4)]
-    coarse = torch.empty(((size + 7) // 8, (size + 7) // 8), dtype=torch.int32, device=ctx.device) if use_coarse else None
-    out = {"entities": count, "map_size": size, "cascades": []}
+    coarse = torch.empty(int(ctx._lib.sailor_hip_raster_coarse_words(size, size)), dtype=torch.int32, device=ctx.device) if use_coarse else None
+    out = {"entities": count, "map_size": size, "coarse_depth": use_coarse, "front_to_back": front_to_back, "cascades": []}
     total = 0.0
     for k in range(4):
         def draw(k=k):

@@ -373,8 +373,9 @@ SAILOR_HIP_API int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntit
  *   dPositions   : device, vec3 per vertex (VertexP3N3T3B3UV2C4::m_position); dIndices: device, 3 x numTriangles
  *   dModels      : device, mat4 per instance (PerInstanceData.model); dInstanceIds: device, numDrawn instance indices, or NULL for 0 .. numDrawn-1
  *   dDepth       : device in/out, width x height floats; `clear` != 0 clears it to 0 first (a dependent pass, :250-261, draws on top with clear == 0)
- *   dCoarseDepth : device scratch or NULL, ceil(width / 8) x ceil(height / 8) words belonging to dDepth (cleared with it): a lower bound of the depths
- *                  stored in each 8 x 8 block, used to skip triangles that cannot win any more.  The result does not depend on it. */
+ *   dCoarseDepth : device scratch or NULL, sailor_hip_raster_coarse_words(width, height) words belonging to dDepth (cleared with it): lower bounds of the
+ *                  depths stored in each 8 x 8 block and each 64 x 64 superblock, used to skip what cannot win any more.  The result does not depend on it. */
+SAILOR_HIP_API size_t sailor_hip_raster_coarse_words(int32_t width, int32_t height);
 SAILOR_HIP_API int sailor_hip_raster_depth(SailorHipContext* ctx, const float* lightMatrix, const float* dPositions, const uint32_t* dIndices,
                                            uint32_t numTriangles, const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn,
                                            int32_t width, int32_t height, float* dDepth, int32_t clear, uint32_t* dCoarseDepth);

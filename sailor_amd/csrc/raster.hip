@@ -5,11 +5,11 @@
 // a plain atomicMax over float bits (depths are > 0) and the result is bit-exact against the sequential oracle.
 //
 // Work distribution: one LANE per (instance, triangle) sets its triangle up.  Triangles whose pixel box is small are filled by their own lane;
-// the others are handed round the wave one after the other (the set-up travels by lane broadcast): the wave first looks at the box as 8 x 8-texel
-// BLOCKS, one per lane -- a block entirely outside an edge is dropped, and so is a block whose coarse depth says nothing of this triangle can
-// still win there -- and then fills the surviving blocks with one lane per texel.
+// the others are handed round the wave one after the other (the set-up travels by lane broadcast): the wave looks at the box as 64 x 64-texel
+// superblocks, one per lane, then at the 8 x 8-texel BLOCKS of each surviving superblock, one per lane -- a (super)block entirely outside an edge is
+// dropped, and so is one whose coarse depth says nothing of this triangle can still win there -- and fills the surviving blocks one lane per texel.
 //
-// Coarse depth (optional workspace, one word per 8 x 8 block): a LOWER BOUND of every depth stored in the block.  A triangle that covers a whole
+// Coarse depth (optional workspace, one word per 8 x 8 block and, behind those, one per 64 x 64 superblock): a LOWER BOUND of every depth stored there.  A triangle that covers a whole
 // block raises it to the smallest depth it wrote there; a triangle (or a block of one) whose largest possible depth does not exceed it is
 // skipped.  Bounds only -- stale values are merely less effective -- so the depth buffer is the same with and without it; shadow casters overdraw
 // each texel hundreds of times (every box along the light direction lands on it), and this is what makes the passes finish.
@@ -17,6 +17,12 @@
 #include <hip/hip_fp16.h>
 
 #define RASTER_SMALL_BOX 64 // pixels a lane fills on its own
+#ifdef RASTER_STATS
+__device__ unsigned long long gStats[8];
+#define STAT(i, v) atomicAdd(&gStats[i], (unsigned long long)(v))
+#else
+#define STAT(i, v)
+#endif
 
 struct RasterTri { long long x0, y0, x1, y1, x2, y2; float z0, z1, z2; int i0, i1, j0, j1; bool valid; };
 
@@ -109,6 +115,25 @@ __device__ __forceinline__ float raster_plane_z(const RasterTri& t, float area, 
     return (t.z0 + (t.z1 - t.z0) * ((float)e1 / area)) + (t.z2 - t.z0) * ((float)e2 / area);
 }
 
+// Bounds over the texel rectangle [xa, xb] x [ya, yb]: an edge function and the depth plane are affine, so their extremes sit at corner texels.
+// m* = largest value of each edge function (all >= 0 <=> the rectangle may touch the triangle), n* = smallest (all > 0 <=> it lies inside it).
+__device__ __forceinline__ void raster_box_bounds(const RasterTri& t, float area, int xa, int ya, int xb, int yb, long long& m0, long long& m1, long long& m2,
+                                                  long long& n0, long long& n1, long long& n2, float& zhi, float& zlo)
+{
+    m0 = m1 = m2 = -0x7FFFFFFFFFFFFFFFll; n0 = n1 = n2 = 0x7FFFFFFFFFFFFFFFll;
+    zhi = -3.0e38f; zlo = 3.0e38f;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int cx = (c & 1) ? xb : xa, cy = (c & 2) ? yb : ya;
+        const long long px = 256ll * cx + 128, py = 256ll * cy + 128;
+        const long long e0 = raster_edge(t.x1, t.y1, t.x2, t.y2, px, py), e1 = raster_edge(t.x2, t.y2, t.x0, t.y0, px, py), e2 = raster_edge(t.x0, t.y0, t.x1, t.y1, px, py);
+        m0 = max(m0, e0); m1 = max(m1, e1); m2 = max(m2, e2);
+        n0 = min(n0, e0); n1 = min(n1, e1); n2 = min(n2, e2);
+        const float z = (t.z0 + (t.z1 - t.z0) * ((float)e1 / area)) + (t.z2 - t.z0) * ((float)e2 / area);
+        zhi = fmaxf(zhi, z); zlo = fminf(zlo, z);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, const float* __restrict__ positions, const uint32_t* __restrict__ indices, uint32_t numTriangles,
                                                        const float* __restrict__ models, const uint32_t* __restrict__ instanceIds, uint32_t numDrawn, int W, int H,
                                                        unsigned int* __restrict__ depthBits, unsigned int* __restrict__ coarse)
@@ -116,7 +141,8 @@ __global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, const float* __res
     const unsigned long long total = (unsigned long long)numDrawn * numTriangles;
     const unsigned long long id = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const int CW = (W + 7) >> 3;
+    const int CW = (W + 7) >> 3, SW = (W + 63) >> 6;
+    unsigned int* coarse2 = coarse ? coarse + (size_t)CW * ((H + 7) >> 3) : nullptr; // level 2 behind level 1 in the same workspace
     RasterTri t;
     t.valid = false;
     if (id < total) {
@@ -127,6 +153,7 @@ __global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, const float* __res
     }
     const float zmaxTri = fmaxf(t.z0, fmaxf(t.z1, t.z2)) + RASTER_Z_MARGIN; // inside the triangle z is a convex combination of the vertices'
     if (t.valid && !(zmaxTri > 0.0f)) t.valid = false;                        // nothing of it can pass z > 0
+    if (t.valid && fminf(t.z0, fminf(t.z1, t.z2)) - RASTER_Z_MARGIN > 1.0f) t.valid = false; // ... or z <= 1
     const bool small = t.valid && (long long)(t.i1 - t.i0 + 1) * (t.j1 - t.j0 + 1) <= RASTER_SMALL_BOX;
     if (small) {
         bool hidden = false;
@@ -151,62 +178,83 @@ __global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, const float* __res
         const float zmaxB = __shfl(zmaxTri, src, 64);
         const float area = (float)raster_edge(b.x0, b.y0, b.x1, b.y1, b.x2, b.y2);
         const bool tl0 = raster_top_left(b.x1, b.y1, b.x2, b.y2), tl1 = raster_top_left(b.x2, b.y2, b.x0, b.y0), tl2 = raster_top_left(b.x0, b.y0, b.x1, b.y1);
-        const int bi0 = b.i0 >> 3, bj0 = b.j0 >> 3, bw = (b.i1 >> 3) - bi0 + 1, bh = (b.j1 >> 3) - bj0 + 1;
-        const int nb = bw * bh;
-        for (int base = 0; base < nb; base += 64) {
-            // ---- one lane per 8 x 8 block: can anything of this triangle land in it, and can it still win? ----
-            const int blk = base + lane;
-            bool alive = blk < nb;
-            int bi = 0, bj = 0;
-            if (alive) {
-                bj = blk / bw; bi = blk - bj * bw;
-                bi += bi0; bj += bj0;
-                const int xa = bi * 8, xb = bi * 8 + 7, ya = bj * 8, yb = bj * 8 + 7; // the block's corner texels
-                // an edge function is affine: its maximum over the block is at a corner texel
-                long long m0 = -1, m1 = -1, m2 = -1;
-                float zc = -1.0f;
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int cx = (c & 1) ? xb : xa, cy = (c & 2) ? yb : ya;
-                    const long long px = 256ll * cx + 128, py = 256ll * cy + 128;
-                    m0 = max(m0, raster_edge(b.x1, b.y1, b.x2, b.y2, px, py));
-                    m1 = max(m1, raster_edge(b.x2, b.y2, b.x0, b.y0, px, py));
-                    m2 = max(m2, raster_edge(b.x0, b.y0, b.x1, b.y1, px, py));
-                    zc = fmaxf(zc, raster_plane_z(b, area, cx, cy));
-                }
-                alive = m0 >= 0 && m1 >= 0 && m2 >= 0;
-                if (alive && coarse) {
-                    const float zbound = fminf(zmaxB, zc + RASTER_Z_MARGIN); // the plane over the block, and the triangle as a whole
-                    alive = zbound > __uint_as_float(coarse[(size_t)bj * CW + bi]);
+        // ---- level 2: 64 x 64-texel superblocks, one per lane ----
+        const int si0 = b.i0 >> 6, sj0 = b.j0 >> 6, sw = (b.i1 >> 6) - si0 + 1, sh = (b.j1 >> 6) - sj0 + 1;
+        const int ns = sw * sh;
+        for (int sbase = 0; sbase < ns; sbase += 64) {
+            const int sblk = sbase + lane;
+            bool salive = sblk < ns;
+            int si = 0, sj = 0;
+            if (salive) {
+                sj = sblk / sw; si = sblk - sj * sw;
+                si += si0; sj += sj0;
+                long long m0, m1, m2, n0, n1, n2;
+                float zhi, zlo;
+                raster_box_bounds(b, area, si * 64, sj * 64, si * 64 + 63, sj * 64 + 63, m0, m1, m2, n0, n1, n2, zhi, zlo);
+                salive = m0 >= 0 && m1 >= 0 && m2 >= 0 && zhi + RASTER_Z_MARGIN > 0.0f && !(zlo - RASTER_Z_MARGIN > 1.0f); // ... and not clipped away as a whole
+                if (salive && coarse2) {
+                    unsigned int* c2 = coarse2 + (size_t)sj * SW + si;
+                    salive = fminf(zmaxB, zhi + RASTER_Z_MARGIN) > __uint_as_float(*c2);
+                    // the triangle covers the whole superblock (every corner texel strictly inside every edge) with depths in (0, 1]: once its
+                    // texels are written, nothing below the smallest of them can win anywhere in the superblock
+                    if (salive && n0 > 0 && n1 > 0 && n2 > 0 && zlo - RASTER_Z_MARGIN > 0.0f && zhi + RASTER_Z_MARGIN <= 1.0f && si * 64 + 63 < W && sj * 64 + 63 < H)
+                        atomicMax(c2, __float_as_uint(zlo - RASTER_Z_MARGIN));
                 }
             }
-            unsigned long long live = __ballot(alive);
-            // ---- the surviving blocks, one lane per texel ----
-            while (live) {
-                const int s2 = __builtin_ctzll(live);
-                live &= live - 1ull;
-                const int cbi = __shfl(bi, s2, 64), cbj = __shfl(bj, s2, 64);
-                const int i = cbi * 8 + (lane & 7), j = cbj * 8 + (lane >> 3);
-                bool wrote = false;
-                float z = 2.0f;
-                if (i >= b.i0 && i <= b.i1 && j >= b.j0 && j <= b.j1) {
-                    const long long px = 256ll * i + 128, py = 256ll * j + 128;
-                    const long long e0 = raster_edge(b.x1, b.y1, b.x2, b.y2, px, py), e1 = raster_edge(b.x2, b.y2, b.x0, b.y0, px, py),
-                                    e2 = raster_edge(b.x0, b.y0, b.x1, b.y1, px, py);
-                    const bool in = !(e0 < 0 || e1 < 0 || e2 < 0) && !((e0 == 0 && !tl0) || (e1 == 0 && !tl1) || (e2 == 0 && !tl2));
-                    if (in) {
-                        z = (b.z0 + (b.z1 - b.z0) * ((float)e1 / area)) + (b.z2 - b.z0) * ((float)e2 / area);
-                        if (z > 0.0f && z <= 1.0f) {
-                            atomicMax(depthBits + (size_t)j * W + i, __float_as_uint(z));
-                            wrote = true;
+            unsigned long long slive = __ballot(salive);
+            if (lane == 0) { STAT(0, min(64, ns - sbase)); STAT(1, __popcll(slive)); }
+            while (slive) {
+                const int s1 = __builtin_ctzll(slive);
+                slive &= slive - 1ull;
+                const int csi = __shfl(si, s1, 64), csj = __shfl(sj, s1, 64);
+                // ---- level 1: the superblock's 8 x 8 blocks, one per lane ----
+                const int bi = csi * 8 + (lane & 7), bj = csj * 8 + (lane >> 3);
+                bool alive = bi >= (b.i0 >> 3) && bi <= (b.i1 >> 3) && bj >= (b.j0 >> 3) && bj <= (b.j1 >> 3);
+                float c1 = 3.0e38f; // this block's coarse depth (blocks beyond the map do not exist)
+                if (coarse && bi < CW && bj < ((H + 7) >> 3)) c1 = __uint_as_float(coarse[(size_t)bj * CW + bi]);
+                if (alive) {
+                    long long m0, m1, m2, n0, n1, n2;
+                    float zhi, zlo;
+                    raster_box_bounds(b, area, bi * 8, bj * 8, bi * 8 + 7, bj * 8 + 7, m0, m1, m2, n0, n1, n2, zhi, zlo);
+                    alive = m0 >= 0 && m1 >= 0 && m2 >= 0 && zhi + RASTER_Z_MARGIN > 0.0f && !(zlo - RASTER_Z_MARGIN > 1.0f);
+                    if (alive && coarse) alive = fminf(zmaxB, zhi + RASTER_Z_MARGIN) > c1;
+                }
+                if (coarse2) { // the smallest of the 64 block bounds is a bound for the superblock: keeps level 2 as tight as level 1 has become
+                    float cmin = c1;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, d, 64));
+                    if (lane == 0 && cmin > 0.0f && cmin < 3.0e38f) atomicMax(coarse2 + (size_t)csj * SW + csi, __float_as_uint(cmin));
+                }
+                unsigned long long live = __ballot(alive);
+                if (lane == 0) { STAT(2, 64); STAT(3, __popcll(live)); }
+                // ---- the surviving blocks, one lane per texel ----
+                while (live) {
+                    const int s2 = __builtin_ctzll(live);
+                    live &= live - 1ull;
+                    const int cbi = csi * 8 + (s2 & 7), cbj = csj * 8 + (s2 >> 3);
+                    const int i = cbi * 8 + (lane & 7), j = cbj * 8 + (lane >> 3);
+                    bool wrote = false;
+                    float z = 2.0f;
+                    if (i >= b.i0 && i <= b.i1 && j >= b.j0 && j <= b.j1) {
+                        const long long px = 256ll * i + 128, py = 256ll * j + 128;
+                        const long long e0 = raster_edge(b.x1, b.y1, b.x2, b.y2, px, py), e1 = raster_edge(b.x2, b.y2, b.x0, b.y0, px, py),
+                                        e2 = raster_edge(b.x0, b.y0, b.x1, b.y1, px, py);
+                        const bool in = !(e0 < 0 || e1 < 0 || e2 < 0) && !((e0 == 0 && !tl0) || (e1 == 0 && !tl1) || (e2 == 0 && !tl2));
+                        if (in) {
+                            z = (b.z0 + (b.z1 - b.z0) * ((float)e1 / area)) + (b.z2 - b.z0) * ((float)e2 / area);
+                            if (z > 0.0f && z <= 1.0f) {
+                                atomicMax(depthBits + (size_t)j * W + i, __float_as_uint(z)); // positive floats order like their bits
+                                wrote = true;
+                            }
                         }
                     }
-                }
-                if (coarse && __ballot(wrote) == ~0ull) { // the whole block now holds depths >= the smallest one written here
-                    float zmin = z;
+                    { const unsigned long long wb = __ballot(wrote), ib = __ballot(z < 2.0f); if (lane == 0) { STAT(4, __popcll(ib)); STAT(5, __popcll(wb)); STAT(6, wb == ~0ull); } }
+                    if (coarse && __ballot(wrote) == ~0ull) { // the whole block now holds depths >= the smallest one written here
+                        float zmin = z;
 #pragma unroll
-                    for (int d = 32; d > 0; d >>= 1) zmin = fminf(zmin, __shfl_xor(zmin, d, 64));
-                    if (lane == 0) atomicMax(coarse + (size_t)cbj * CW + cbi, __float_as_uint(zmin));
+                        for (int d = 32; d > 0; d >>= 1) zmin = fminf(zmin, __shfl_xor(zmin, d, 64));
+                        if (lane == 0) atomicMax(coarse + (size_t)cbj * CW + cbi, __float_as_uint(zmin));
+                    }
                 }
             }
         }
@@ -253,6 +301,20 @@ __global__ __launch_bounds__(256) void k_shadow_resolve(const float* __restrict_
 
 extern "C" {
 
+#ifdef RASTER_STATS
+__attribute__((visibility("default"))) void sailor_hip_raster_stats(unsigned long long* out, int reset)
+{
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(gStats), 64);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(gStats), z, 64); }
+}
+#endif
+
+size_t sailor_hip_raster_coarse_words(int32_t width, int32_t height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    return (size_t)((width + 7) / 8) * ((height + 7) / 8) + (size_t)((width + 63) / 64) * ((height + 63) / 64);
+}
+
 int sailor_hip_raster_depth(SailorHipContext* ctx, const float* lightMatrix, const float* dPositions, const uint32_t* dIndices, uint32_t numTriangles,
                             const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn, int32_t width, int32_t height, float* dDepth, int32_t clear,
                             uint32_t* dCoarseDepth)
@@ -260,7 +322,8 @@ int sailor_hip_raster_depth(SailorHipContext* ctx, const float* lightMatrix, con
     if (!ctx || !lightMatrix || !dDepth || width <= 0 || height <= 0 || width > 32768 || height > 32768) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (clear) {
         SAILOR_TRY_HIP(ctx, hipMemsetAsync(dDepth, 0, (size_t)width * height * 4, ctx->stream));
-        if (dCoarseDepth) SAILOR_TRY_HIP(ctx, hipMemsetAsync(dCoarseDepth, 0, (size_t)((width + 7) / 8) * ((height + 7) / 8) * 4, ctx->stream));
+        if (dCoarseDepth)
+            SAILOR_TRY_HIP(ctx, hipMemsetAsync(dCoarseDepth, 0, ((size_t)((width + 7) / 8) * ((height + 7) / 8) + (size_t)((width + 63) / 64) * ((height + 63) / 64)) * 4, ctx->stream));
     }
     if (numTriangles == 0 || numDrawn == 0) return SAILOR_HIP_OK;
     if (!dPositions || !dIndices || !dModels) return SAILOR_HIP_ERR_INVALID_ARGUMENT;

@@ -241,7 +241,7 @@ class EcsSweep:
 def raster_depth(ctx: "HipContext", light_matrix, positions: torch.Tensor, indices: torch.Tensor, models: torch.Tensor, width: int, height: int,
                  instance_ids: torch.Tensor | None = None, depth: torch.Tensor | None = None, coarse: torch.Tensor | None = None) -> torch.Tensor:
     """sailor_hip_raster_depth: the caster draws of one shadow pass -> float32 [height, width] depth (reversed Z, 0 = nothing drawn).
-    `depth` given = draw on top of it (a dependent pass); otherwise a cleared buffer is used.  `coarse`: int32 [ceil(h / 8), ceil(w / 8)] scratch that
+    `depth` given = draw on top of it (a dependent pass); otherwise a cleared buffer is used.  `coarse`: int32 [sailor_hip_raster_coarse_words(w, h)] scratch that
     belongs to the depth buffer (hierarchical depth; same result, much less fill)."""
     lm = np.ascontiguousarray(light_matrix, np.float32).reshape(16)
     out = depth if depth is not None else torch.empty((height, width), dtype=torch.float32, device=ctx.device)

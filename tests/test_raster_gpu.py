@@ -70,13 +70,15 @@ def test_box_casters_of_a_cascade_and_the_resolved_maps(ctx, cascade, size):
     ref = oracle.raster_depth(lm, pos, tris, models, size, size, instance_ids=ids)
     np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), ref.view(np.uint32))
     # with the coarse-depth workspace: fewer texels touched, the same buffer; every coarse word is a lower bound of its block
-    coarse = torch.empty(((size + 7) // 8, (size + 7) // 8), dtype=torch.int32, device=ctx.device)
+    coarse = torch.empty(int(_lib.load().sailor_hip_raster_coarse_words(size, size)), dtype=torch.int32, device=ctx.device)
     dc = raster_depth(ctx, lm, torch.from_numpy(pos).to(ctx.device), torch.from_numpy(tris.view(np.int32)).to(ctx.device), torch.from_numpy(models).to(ctx.device),
                       size, size, torch.from_numpy(ids.view(np.int32)).to(ctx.device), coarse=coarse)
     ctx.synchronize()
     np.testing.assert_array_equal(dc.cpu().numpy().view(np.uint32), ref.view(np.uint32))
-    lower = coarse.cpu().numpy().view(np.float32)
+    words = coarse.cpu().numpy().view(np.float32)
+    lower, lower2 = words[:(size // 8) ** 2].reshape(size // 8, size // 8), words[(size // 8) ** 2:].reshape(size // 64, size // 64)
     assert (lower <= ref.reshape(size // 8, 8, size // 8, 8).min(axis=(1, 3))).all() and (lower > 0).any()
+    assert (lower2 <= ref.reshape(size // 64, 64, size // 64, 64).min(axis=(1, 3))).all()
     cover = float((ref > 0).mean())
     assert 0.001 < cover < 1.0, cover
     evsm = shadow_resolve(ctx, d, _lib.SHADOWMAP_RGBA32F).cpu().numpy()
