@@ -379,6 +379,13 @@ SAILOR_HIP_API size_t sailor_hip_raster_coarse_words(int32_t width, int32_t heig
 SAILOR_HIP_API int sailor_hip_raster_depth(SailorHipContext* ctx, const float* lightMatrix, const float* dPositions, const uint32_t* dIndices,
                                            uint32_t numTriangles, const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn,
                                            int32_t width, int32_t height, float* dDepth, int32_t clear, uint32_t* dCoarseDepth);
+/* Replaces: the draws of the depth prepass, FrameGraph/DepthPrepassNode.cpp:283-297 with Content/Shaders/DepthOnly.shader:51
+ * (gl_Position = frame.projection * (frame.view * (model * position))): the same rasteriser, the camera's matrices from the frame UBO; the reversed-Z
+ * projection makes it GREATER against the cleared 0 again.  dDepth is the raw depth attachment LinearizeDepth / SAILOR_CULL_RAW_DEPTH consume.
+ * Triangles with a vertex at w <= 0 are dropped (no near-plane clipping). */
+SAILOR_HIP_API int sailor_hip_raster_depth_camera(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dPositions, const uint32_t* dIndices,
+                                                  uint32_t numTriangles, const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn,
+                                                  int32_t width, int32_t height, float* dDepth, int32_t clear, uint32_t* dCoarseDepth);
 /* The fragment stage of ShadowCaster.shader:66-78 on the winning depth of every texel: EVSM moments (format RGBA32F: exp(40 z), its square,
  * -exp(-40 z), its square), or the depth itself (R16F / R32F); texels nothing was drawn to keep the cleared colour 0. */
 SAILOR_HIP_API int sailor_hip_shadow_resolve(SailorHipContext* ctx, const float* dDepth, int32_t width, int32_t height, int32_t format, void* dShadowMap);

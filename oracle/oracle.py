@@ -329,7 +329,7 @@ def transform_matrix(trs12):
     return out
 
 
-def raster_depth(light_matrix, positions, indices, models, width: int, height: int, instance_ids=None, depth=None) -> np.ndarray:
+def raster_depth(light_matrix, positions, indices, models, width: int, height: int, instance_ids=None, depth=None, view=None) -> np.ndarray:
     """The canonical depth rasteriser (ShadowPrepassNode's caster draws): float32 [H, W] depth, GREATER test, 0 = nothing drawn."""
     lm = np.ascontiguousarray(light_matrix, np.float32).reshape(16)
     pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
@@ -338,8 +338,13 @@ def raster_depth(light_matrix, positions, indices, models, width: int, height: i
     out = np.zeros((height, width), np.float32) if depth is None else np.ascontiguousarray(depth, np.float32).copy()
     ids = None if instance_ids is None else np.ascontiguousarray(instance_ids, np.uint32)
     n = len(mdl) if ids is None else len(ids)
-    lib().oracle_raster_depth(_p(lm), _p(pos), _p(idx), C.c_uint32(len(idx)), _p(mdl), _p(ids) if ids is not None else None, C.c_uint32(n),
-                              C.c_int32(width), C.c_int32(height), _p(out))
+    if view is None:
+        lib().oracle_raster_depth(_p(lm), _p(pos), _p(idx), C.c_uint32(len(idx)), _p(mdl), _p(ids) if ids is not None else None, C.c_uint32(n),
+                                  C.c_int32(width), C.c_int32(height), _p(out))
+    else:  # the depth prepass: light_matrix is the camera projection, view its view matrix
+        vm = np.ascontiguousarray(view, np.float32).reshape(16)
+        lib().oracle_raster_depth_camera(_p(lm), _p(vm), _p(pos), _p(idx), C.c_uint32(len(idx)), _p(mdl), _p(ids) if ids is not None else None, C.c_uint32(n),
+                                         C.c_int32(width), C.c_int32(height), _p(out))
     return out
 
 

@@ -1664,13 +1664,20 @@ static void glsl_mat4_mul_mat4(const float* a, const float* b, float* o)
 
 typedef struct { int64_t x, y; float z; } RasterVertex;
 
-static int raster_setup(const float* LM, const float* positions, const uint32_t* tri, int W, int H, RasterVertex* v)
+/* view == NULL: clip = LM * position with LM = lightMatrix * model (ShadowCaster.shader:58);
+ * view != NULL: clip = projection * (view * (model * position)) (DepthOnly.shader:51), LM = projection here */
+static int raster_setup(const float* LM, const float* view, const float* model, const float* positions, const uint32_t* tri, int W, int H, RasterVertex* v)
 {
     for (int k = 0; k < 3; k++) {
         const float* p = positions + 3 * (size_t)tri[k];
         const float pos[4] = { p[0], p[1], p[2], 1.0f };
         float clip[4];
-        glsl_mat4_mul_vec4(LM, pos, clip);
+        if (view) {
+            float a[4], b[4];
+            glsl_mat4_mul_vec4(model, pos, a);
+            glsl_mat4_mul_vec4(view, a, b);
+            glsl_mat4_mul_vec4(LM, b, clip);
+        } else glsl_mat4_mul_vec4(LM, pos, clip);
         if (!(clip[3] > 0.0f)) return 0;
         const float nx = clip[0] / clip[3], ny = clip[1] / clip[3], nz = clip[2] / clip[3];
         const float xf = (nx + 1.0f) * ((float)W * 0.5f);
@@ -1697,16 +1704,17 @@ static inline int raster_top_left(const RasterVertex* a, const RasterVertex* b)
 static inline int64_t floor_div256(int64_t a) { return a >= 0 ? a / 256 : -((-a + 255) / 256); }
 
 /* depth: W x H floats, read and written (GREATER); instanceIds == NULL draws instances 0 .. numDrawn-1 */
-ORACLE_API void oracle_raster_depth(const float* lightMatrix, const float* positions, const uint32_t* indices, uint32_t numTriangles, const float* models,
-                                    const uint32_t* instanceIds, uint32_t numDrawn, int32_t W, int32_t H, float* depth)
+static void raster_depth_impl(const float* lightMatrix, const float* view, const float* positions, const uint32_t* indices, uint32_t numTriangles,
+                              const float* models, const uint32_t* instanceIds, uint32_t numDrawn, int32_t W, int32_t H, float* depth)
 {
     for (uint32_t d = 0; d < numDrawn; d++) {
         const uint32_t inst = instanceIds ? instanceIds[d] : d;
         float LM[16];
-        glsl_mat4_mul_mat4(lightMatrix, models + 16 * (size_t)inst, LM);
+        if (view) memcpy(LM, lightMatrix, sizeof LM);
+        else glsl_mat4_mul_mat4(lightMatrix, models + 16 * (size_t)inst, LM);
         for (uint32_t t = 0; t < numTriangles; t++) {
             RasterVertex v[3];
-            if (!raster_setup(LM, positions, indices + 3 * (size_t)t, W, H, v)) continue;
+            if (!raster_setup(LM, view, models + 16 * (size_t)inst, positions, indices + 3 * (size_t)t, W, H, v)) continue;
             int64_t minx = v[0].x, maxx = v[0].x, miny = v[0].y, maxy = v[0].y;
             for (int k = 1; k < 3; k++) {
                 minx = v[k].x < minx ? v[k].x : minx; maxx = v[k].x > maxx ? v[k].x : maxx;
@@ -1734,6 +1742,20 @@ ORACLE_API void oracle_raster_depth(const float* lightMatrix, const float* posit
                 }
         }
     }
+}
+
+ORACLE_API void oracle_raster_depth(const float* lightMatrix, const float* positions, const uint32_t* indices, uint32_t numTriangles, const float* models,
+                                    const uint32_t* instanceIds, uint32_t numDrawn, int32_t W, int32_t H, float* depth)
+{
+    raster_depth_impl(lightMatrix, NULL, positions, indices, numTriangles, models, instanceIds, numDrawn, W, H, depth);
+}
+
+/* The depth prepass (FrameGraph/DepthPrepassNode.cpp:283-297, Content/Shaders/DepthOnly.shader:51): the same rasteriser with the camera's matrices,
+ * gl_Position = projection * (view * (model * position)); reversed-Z projection, so GREATER against the cleared 0 again. */
+ORACLE_API void oracle_raster_depth_camera(const float* projection, const float* view, const float* positions, const uint32_t* indices, uint32_t numTriangles,
+                                           const float* models, const uint32_t* instanceIds, uint32_t numDrawn, int32_t W, int32_t H, float* depth)
+{
+    raster_depth_impl(projection, view, positions, indices, numTriangles, models, instanceIds, numDrawn, W, H, depth);
 }
 
 /* ShadowCaster.shader:66-78 on the winning fragment of every texel: EVSM moments (RGBA32F) or the depth itself; texels nothing was drawn

@@ -40,7 +40,9 @@ __device__ __forceinline__ Mat4 raster_mul(const Mat4& a, const float* __restric
 
 __device__ __forceinline__ long long raster_floor_div256(long long a) { return a >= 0 ? a / 256 : -((-a + 255) / 256); }
 
-__device__ __forceinline__ RasterTri raster_setup(const Mat4& LM, const float* __restrict__ positions, const uint32_t* __restrict__ tri, int W, int H)
+// hasView: clip = projection * (view * (model * position)) (DepthOnly.shader:51, LM = projection); else clip = (lightMatrix * model) * position
+__device__ __forceinline__ RasterTri raster_setup(const Mat4& LM, bool hasView, const Mat4& V, const float* __restrict__ model, const float* __restrict__ positions,
+                                                   const uint32_t* __restrict__ tri, int W, int H)
 {
     RasterTri t;
     t.valid = false;
@@ -49,7 +51,15 @@ __device__ __forceinline__ RasterTri raster_setup(const Mat4& LM, const float* _
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float* p = positions + 3 * (size_t)tri[k];
-        const float4 clip = glsl_mul(LM, p[0], p[1], p[2], 1.0f);
+        float4 clip;
+        if (hasView) {
+            Mat4 M;
+#pragma unroll
+            for (int q = 0; q < 16; q++) M.m[q] = model[q];
+            const float4 a = glsl_mul(M, p[0], p[1], p[2], 1.0f);
+            const float4 bq = glsl_mul(V, a.x, a.y, a.z, a.w);
+            clip = glsl_mul(LM, bq.x, bq.y, bq.z, bq.w);
+        } else clip = glsl_mul(LM, p[0], p[1], p[2], 1.0f);
         if (!(clip.w > 0.0f)) return t;
         const float nx = clip.x / clip.w, ny = clip.y / clip.w, nz = clip.z / clip.w;
         const float xf = (nx + 1.0f) * ((float)W * 0.5f);
@@ -134,7 +144,7 @@ __device__ __forceinline__ void raster_box_bounds(const RasterTri& t, float area
     }
 }
 
-__global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, const float* __restrict__ positions, const uint32_t* __restrict__ indices, uint32_t numTriangles,
+__global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, Mat4 V, int hasView, const float* __restrict__ positions, const uint32_t* __restrict__ indices, uint32_t numTriangles,
                                                        const float* __restrict__ models, const uint32_t* __restrict__ instanceIds, uint32_t numDrawn, int W, int H,
                                                        unsigned int* __restrict__ depthBits, unsigned int* __restrict__ coarse)
 {
@@ -148,8 +158,8 @@ __global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, const float* __res
     if (id < total) {
         const uint32_t d = (uint32_t)(id / numTriangles), tri = (uint32_t)(id - (unsigned long long)d * numTriangles);
         const uint32_t inst = instanceIds ? instanceIds[d] : d;
-        const Mat4 LM = raster_mul(L, models + 16 * (size_t)inst);
-        t = raster_setup(LM, positions, indices + 3 * (size_t)tri, W, H);
+        const Mat4 LM = hasView ? L : raster_mul(L, models + 16 * (size_t)inst);
+        t = raster_setup(LM, hasView != 0, V, models + 16 * (size_t)inst, positions, indices + 3 * (size_t)tri, W, H);
     }
     const float zmaxTri = fmaxf(t.z0, fmaxf(t.z1, t.z2)) + RASTER_Z_MARGIN; // inside the triangle z is a convex combination of the vertices'
     if (t.valid && !(zmaxTri > 0.0f)) t.valid = false;                        // nothing of it can pass z > 0
@@ -315,9 +325,9 @@ size_t sailor_hip_raster_coarse_words(int32_t width, int32_t height)
     return (size_t)((width + 7) / 8) * ((height + 7) / 8) + (size_t)((width + 63) / 64) * ((height + 63) / 64);
 }
 
-int sailor_hip_raster_depth(SailorHipContext* ctx, const float* lightMatrix, const float* dPositions, const uint32_t* dIndices, uint32_t numTriangles,
-                            const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn, int32_t width, int32_t height, float* dDepth, int32_t clear,
-                            uint32_t* dCoarseDepth)
+static int raster_depth_launch(SailorHipContext* ctx, const float* lightMatrix, const float* viewMatrix, const float* dPositions, const uint32_t* dIndices,
+                               uint32_t numTriangles, const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn, int32_t width, int32_t height, float* dDepth,
+                               int32_t clear, uint32_t* dCoarseDepth)
 {
     if (!ctx || !lightMatrix || !dDepth || width <= 0 || height <= 0 || width > 32768 || height > 32768) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (clear) {
@@ -327,14 +337,32 @@ int sailor_hip_raster_depth(SailorHipContext* ctx, const float* lightMatrix, con
     }
     if (numTriangles == 0 || numDrawn == 0) return SAILOR_HIP_OK;
     if (!dPositions || !dIndices || !dModels) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-    Mat4 L;
+    Mat4 L, V;
     memcpy(L.m, lightMatrix, 64);
+    memset(V.m, 0, 64);
+    if (viewMatrix) memcpy(V.m, viewMatrix, 64);
     const unsigned long long total = (unsigned long long)numDrawn * numTriangles;
     if ((total + 255) / 256 > 0x7FFFFFFFull) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(k_raster_depth, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, L, dPositions, dIndices, numTriangles, dModels, dInstanceIds,
+    hipLaunchKernelGGL(k_raster_depth, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, L, V, viewMatrix ? 1 : 0, dPositions, dIndices, numTriangles, dModels, dInstanceIds,
                        numDrawn, width, height, (unsigned int*)dDepth, (unsigned int*)dCoarseDepth);
     SAILOR_CHECK_LAUNCH(ctx, "k_raster_depth");
     return SAILOR_HIP_OK;
+}
+
+int sailor_hip_raster_depth(SailorHipContext* ctx, const float* lightMatrix, const float* dPositions, const uint32_t* dIndices, uint32_t numTriangles,
+                            const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn, int32_t width, int32_t height, float* dDepth, int32_t clear,
+                            uint32_t* dCoarseDepth)
+{
+    return raster_depth_launch(ctx, lightMatrix, nullptr, dPositions, dIndices, numTriangles, dModels, dInstanceIds, numDrawn, width, height, dDepth, clear, dCoarseDepth);
+}
+
+int sailor_hip_raster_depth_camera(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dPositions, const uint32_t* dIndices, uint32_t numTriangles,
+                                   const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn, int32_t width, int32_t height, float* dDepth, int32_t clear,
+                                   uint32_t* dCoarseDepth)
+{
+    if (!frame) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    return raster_depth_launch(ctx, frame->projection, frame->view, dPositions, dIndices, numTriangles, dModels, dInstanceIds, numDrawn, width, height, dDepth, clear,
+                               dCoarseDepth);
 }
 
 int sailor_hip_shadow_resolve(SailorHipContext* ctx, const float* dDepth, int32_t width, int32_t height, int32_t format, void* dShadowMap)

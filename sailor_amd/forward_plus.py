@@ -252,6 +252,17 @@ def raster_depth(ctx: "HipContext", light_matrix, positions: torch.Tensor, indic
     return out
 
 
+def raster_depth_camera(ctx: "HipContext", frame, positions: torch.Tensor, indices: torch.Tensor, models: torch.Tensor, width: int, height: int,
+                        instance_ids: torch.Tensor | None = None, coarse: torch.Tensor | None = None) -> torch.Tensor:
+    """sailor_hip_raster_depth_camera: the depth prepass -> raw reversed-Z depth float32 [height, width] (0 = nothing drawn)"""
+    out = torch.empty((height, width), dtype=torch.float32, device=ctx.device)
+    n = models.shape[0] if instance_ids is None else instance_ids.numel()
+    _lib.check(ctx._lib.sailor_hip_raster_depth_camera(ctx.handle, C.byref(frame), _ptr(positions), _ptr(indices), indices.numel() // 3, _ptr(models),
+                                                       _ptr(instance_ids) if instance_ids is not None else None, n, width, height, _ptr(out), 1, _ptr(coarse)),
+               "sailor_hip_raster_depth_camera", ctx.handle)
+    return out
+
+
 def shadow_resolve(ctx: "HipContext", depth: torch.Tensor, fmt: int) -> torch.Tensor:
     """ShadowCaster.shader's fragment stage on the winning depths: RGBA32F EVSM moments, R16F or R32F depth"""
     h, w = depth.shape

@@ -136,3 +136,37 @@ def test_entities_to_shadow_maps_to_shaded_frame(ctx):
     assert np.abs(ref - unshadowed).max() > 0.5, "the boxes cast shadows on the visible surface"
     err = np.abs(got.astype(np.float64) - ref)
     assert (err <= 1e-4 * np.abs(ref) + 1e-5).all(), err.max()
+
+
+def test_depth_prepass_feeds_linearize_and_the_light_cull(ctx):
+    """The depth producer in front of the path: the visible entities' boxes drawn with the camera's matrices
+    (DepthOnly.shader: projection * (view * (model * position))) give the raw reversed-Z attachment; linearised it drives the tile light cull --
+    depth, linear depth and per-tile lists all equal the oracle's."""
+    from sailor_amd.forward_plus import ForwardPlus, linearize_depth, raster_depth_camera, upload_lights
+    f = synth.make_frame("tiny", with_surface=False)
+    cam, W, H = f.cam, f.cam.width, f.cam.height
+    ents = synth.make_entities(500)
+    ents.transforms[:, 0:3] *= np.float32(0.12)
+    planes, _ = host.extract_frustum_planes(cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+    world, aabb, vis = EcsSweep(ctx, ents).run(planes)
+    ids = np.nonzero(np.unpackbits(vis.cpu().numpy().view(np.uint8), bitorder="little")[:500])[0].astype(np.uint32)
+    pos, tris = synth.unit_cube_mesh()
+    models = synth.caster_models(world.cpu().numpy(), ents.local_aabb)
+    coarse = torch.empty(int(_lib.load().sailor_hip_raster_coarse_words(W, H)), dtype=torch.int32, device=ctx.device)
+    raw = raster_depth_camera(ctx, cam.frame, torch.from_numpy(pos).to(ctx.device), torch.from_numpy(tris.view(np.int32)).to(ctx.device),
+                              torch.from_numpy(models).to(ctx.device), W, H, torch.from_numpy(ids.view(np.int32)).to(ctx.device), coarse)
+    ctx.synchronize()
+    fb = np.frombuffer(bytes(cam.frame), np.float32)
+    ref_raw = oracle.raster_depth(fb[16:32], pos, tris, models, W, H, instance_ids=ids, view=fb[0:16])
+    np.testing.assert_array_equal(raw.cpu().numpy().view(np.uint32), ref_raw.view(np.uint32))
+    assert float((ref_raw > 0).mean()) > 0.05 and len(np.unique(ref_raw)) > 1000
+    zn = cam.frame.cameraZNearZFar[0]
+    lin = linearize_depth(ctx, cam.frame, raw)
+    ref_lin = oracle.linearize_depth(zn, ref_raw)
+    np.testing.assert_array_equal(lin.cpu().numpy().view(np.uint32), ref_lin.view(np.uint32))
+    fp = ForwardPlus(ctx, W, H, len(f.lights))
+    fp.cull(cam.frame, upload_lights(f.lights, ctx.device), len(f.lights), raw, _lib.CULL_RAW_DEPTH)
+    g, idx = fp.lists_to_host()
+    og, oi, _ = oracle.light_cull(cam.frame, W, H, f.lights, ref_lin)
+    np.testing.assert_array_equal(g, og)
+    np.testing.assert_array_equal(idx[:1 + int(idx[0])], oi[:1 + int(oi[0])])
