@@ -170,3 +170,35 @@ def test_depth_prepass_feeds_linearize_and_the_light_cull(ctx):
     og, oi, _ = oracle.light_cull(cam.frame, W, H, f.lights, ref_lin)
     np.testing.assert_array_equal(g, og)
     np.testing.assert_array_equal(idx[:1 + int(idx[0])], oi[:1 + int(oi[0])])
+
+
+@pytest.mark.parametrize("size", [(64, 64), (200, 120), (517, 333)])
+def test_random_triangle_soup(ctx, size):
+    """6 000 random triangles -- slivers, degenerate ones, sub-texel ones, ones larger than the map, partly or wholly outside it and outside the depth
+    range, with and without the coarse-depth workspace, in two batches (the second drawn on top of the first): identical to the sequential oracle."""
+    W, H = size
+    rng = np.random.default_rng(W * 1000 + H)
+    n = 6000
+    centre = rng.uniform(-1.3, 1.3, (n, 1, 3)).astype(np.float32)
+    centre[..., 2] = rng.uniform(-0.2, 1.2, (n, 1)).astype(np.float32)
+    extent = (10.0 ** rng.uniform(-3.0, 0.6, (n, 1, 1))).astype(np.float32)
+    verts = centre + rng.uniform(-1, 1, (n, 3, 3)).astype(np.float32) * extent * np.float32([1, 1, 0.3])
+    verts[::97, 1] = verts[::97, 0]                                   # degenerate: two equal vertices
+    verts[5::89, :, 1] = np.float32(0.25)                             # degenerate: zero height
+    snap = rng.integers(-W, W, (n // 50, 3, 2)).astype(np.float32)    # vertices exactly on texel centres / edges (fill-rule ties)
+    verts[3::50][: len(snap), :, 0] = (snap[: len(verts[3::50]), :, 0] + 0.5) / W * 2 - 1
+    pos = np.ascontiguousarray(verts.reshape(-1, 3))
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    one = IDENTITY.reshape(1, 16)
+    half = n // 2
+    ref = oracle.raster_depth(IDENTITY, pos, idx[:half], one, W, H)
+    ref = oracle.raster_depth(IDENTITY, pos, idx[half:], one, W, H, depth=ref)
+    assert 0.3 < float((ref > 0).mean()) and len(np.unique(ref)) > 500
+    for use_coarse in (False, True):
+        coarse = torch.empty(int(_lib.load().sailor_hip_raster_coarse_words(W, H)), dtype=torch.int32, device=ctx.device) if use_coarse else None
+        d_pos = torch.from_numpy(pos).to(ctx.device)
+        d_one = torch.from_numpy(one.copy()).to(ctx.device)
+        d = raster_depth(ctx, IDENTITY, d_pos, torch.from_numpy(idx[:half].view(np.int32).copy()).to(ctx.device), d_one, W, H, coarse=coarse)
+        d = raster_depth(ctx, IDENTITY, d_pos, torch.from_numpy(idx[half:].view(np.int32).copy()).to(ctx.device), d_one, W, H, depth=d, coarse=coarse)
+        ctx.synchronize()
+        np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), ref.view(np.uint32))
