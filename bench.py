@@ -292,7 +292,7 @@ def shadow_pass_block(ctx, count: int, size: int, steps: int, use_coarse: bool =
     for k in range(4):
         def draw(k=k):
             ctx._lib.sailor_hip_raster_depth(ctx.handle, np.ascontiguousarray(sh.lights_matrices[k], np.float32).ctypes.data_as(C_float_p), pos.data_ptr(), tris.data_ptr(), 12,
-                                             models.data_ptr(), ids[k].data_ptr(), len(ids_h[k]), size, size, depth[k].data_ptr(), 1, coarse.data_ptr() if coarse is not None else None)
+                                             models.data_ptr(), ids[k].data_ptr(), len(ids_h[k]), size, size, depth[k].data_ptr(), 3, coarse.data_ptr() if coarse is not None else None)  # flags: CLEAR | CULL_BACK (the shadow material, ShadowPrepassNode.cpp:39)
         _, ms, _, _ = event_ms(draw, steps)
         _, rs, _, _ = event_ms(lambda k=k: shadow_resolve(ctx, depth[k], L_RGBA32F if k == 0 else L_R16F), steps)
         cover = float((depth[k] > 0).float().mean().item())

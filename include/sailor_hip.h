@@ -366,26 +366,30 @@ SAILOR_HIP_API int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntit
                                         const SailorAABB* dLocalAabb, const float* planes,
                                         float* dWorld, SailorAABB* dWorldAabb, uint64_t* dVisibility);
 
+#define SAILOR_RASTER_CLEAR 1u
+#define SAILOR_RASTER_CULL_BACK 2u
 /* Replaces: the caster draws of one shadow pass, FrameGraph/ShadowPrepassNode.cpp:219-262 with Content/Shaders/ShadowCaster.shader:46-59 (vertex stage:
  * gl_Position = lightMatrix * instance.model * vec4(inPosition, 1)) -- depth only; the rasterisation rules are those of the oracle (1/256-pixel
- * snapping, top-left rule, both windings, unfused fp32 depth interpolation, reversed Z: GREATER against a buffer cleared to 0, viewport (0, H, W, -H)).
+ * snapping, top-left rule, unfused fp32 depth interpolation, reversed Z: GREATER against a buffer cleared to 0, viewport (0, H, W, -H)).
  *   lightMatrix  : host, mat4 (the pass' push constant, RHIUpdateShadowMapCommand::m_lightMatrix)
  *   dPositions   : device, vec3 per vertex (VertexP3N3T3B3UV2C4::m_position); dIndices: device, 3 x numTriangles
  *   dModels      : device, mat4 per instance (PerInstanceData.model); dInstanceIds: device, numDrawn instance indices, or NULL for 0 .. numDrawn-1
- *   dDepth       : device in/out, width x height floats; `clear` != 0 clears it to 0 first (a dependent pass, :250-261, draws on top with clear == 0)
+ *   dDepth       : device in/out, width x height floats
+ *   flags        : SAILOR_RASTER_CLEAR clears dDepth (and the coarse depth) to 0 first -- a dependent pass (:250-261) draws on top without it;
+ *                  SAILOR_RASTER_CULL_BACK discards back faces as the reference's materials do (ECullMode::Back, frontFace counter-clockwise)
  *   dCoarseDepth : device scratch or NULL, sailor_hip_raster_coarse_words(width, height) words belonging to dDepth (cleared with it): lower bounds of the
  *                  depths stored in each 8 x 8 block and each 64 x 64 superblock, used to skip what cannot win any more.  The result does not depend on it. */
 SAILOR_HIP_API size_t sailor_hip_raster_coarse_words(int32_t width, int32_t height);
 SAILOR_HIP_API int sailor_hip_raster_depth(SailorHipContext* ctx, const float* lightMatrix, const float* dPositions, const uint32_t* dIndices,
                                            uint32_t numTriangles, const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn,
-                                           int32_t width, int32_t height, float* dDepth, int32_t clear, uint32_t* dCoarseDepth);
+                                           int32_t width, int32_t height, float* dDepth, uint32_t flags, uint32_t* dCoarseDepth);
 /* Replaces: the draws of the depth prepass, FrameGraph/DepthPrepassNode.cpp:283-297 with Content/Shaders/DepthOnly.shader:51
  * (gl_Position = frame.projection * (frame.view * (model * position))): the same rasteriser, the camera's matrices from the frame UBO; the reversed-Z
  * projection makes it GREATER against the cleared 0 again.  dDepth is the raw depth attachment LinearizeDepth / SAILOR_CULL_RAW_DEPTH consume.
  * Triangles with a vertex at w <= 0 are dropped (no near-plane clipping). */
 SAILOR_HIP_API int sailor_hip_raster_depth_camera(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dPositions, const uint32_t* dIndices,
                                                   uint32_t numTriangles, const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn,
-                                                  int32_t width, int32_t height, float* dDepth, int32_t clear, uint32_t* dCoarseDepth);
+                                                  int32_t width, int32_t height, float* dDepth, uint32_t flags, uint32_t* dCoarseDepth);
 /* The fragment stage of ShadowCaster.shader:66-78 on the winning depth of every texel: EVSM moments (format RGBA32F: exp(40 z), its square,
  * -exp(-40 z), its square), or the depth itself (R16F / R32F); texels nothing was drawn to keep the cleared colour 0. */
 SAILOR_HIP_API int sailor_hip_shadow_resolve(SailorHipContext* ctx, const float* dDepth, int32_t width, int32_t height, int32_t format, void* dShadowMap);

@@ -329,7 +329,7 @@ def transform_matrix(trs12):
     return out
 
 
-def raster_depth(light_matrix, positions, indices, models, width: int, height: int, instance_ids=None, depth=None, view=None) -> np.ndarray:
+def raster_depth(light_matrix, positions, indices, models, width: int, height: int, instance_ids=None, depth=None, view=None, cull_back=False) -> np.ndarray:
     """The canonical depth rasteriser (ShadowPrepassNode's caster draws): float32 [H, W] depth, GREATER test, 0 = nothing drawn."""
     lm = np.ascontiguousarray(light_matrix, np.float32).reshape(16)
     pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
@@ -340,11 +340,11 @@ def raster_depth(light_matrix, positions, indices, models, width: int, height: i
     n = len(mdl) if ids is None else len(ids)
     if view is None:
         lib().oracle_raster_depth(_p(lm), _p(pos), _p(idx), C.c_uint32(len(idx)), _p(mdl), _p(ids) if ids is not None else None, C.c_uint32(n),
-                                  C.c_int32(width), C.c_int32(height), _p(out))
+                                  C.c_int32(width), C.c_int32(height), _p(out), C.c_int32(1 if cull_back else 0))
     else:  # the depth prepass: light_matrix is the camera projection, view its view matrix
         vm = np.ascontiguousarray(view, np.float32).reshape(16)
         lib().oracle_raster_depth_camera(_p(lm), _p(vm), _p(pos), _p(idx), C.c_uint32(len(idx)), _p(mdl), _p(ids) if ids is not None else None, C.c_uint32(n),
-                                         C.c_int32(width), C.c_int32(height), _p(out))
+                                         C.c_int32(width), C.c_int32(height), _p(out), C.c_int32(1 if cull_back else 0))
     return out
 
 

@@ -1656,7 +1656,10 @@ ORACLE_API void oracle_csm_matrices(const float* lightView, const float* cameraW
  *   window = x: (ndc.x + 1) * (W / 2), y: (ndc.y + 1) * (-H / 2) + H, z: ndc.z   (triangles with a vertex at w <= 0 are dropped)
  *   snap   = x, y to 1/256 pixel (round to nearest even), 64-bit integer edge functions, both windings, top-left fill rule
  *   z      = (z0 + (z1 - z0) * w1) + (z2 - z0) * w2, w_k = float(edge_k) / float(2 * area), no fused operations
- *   test   = fragments with z outside [0, 1] are clipped; GREATER against the stored depth (0 = cleared) */
+ *   test   = fragments with z outside [0, 1] are clipped; GREATER against the stored depth (0 = cleared).  (The reference's materials compare
+ *            GreaterOrEqual, RHI/Types.h:537: the stored depth is the same maximum; the one difference -- a fragment at exactly z = 0 would pass against
+ *            the cleared 0 and write its colour -- is not reproduced: depth 0 means "nothing drawn" here.)
+ *   cull   = optional: back faces (Vulkan's signed area with frontFace COUNTER_CLOCKWISE) are discarded, as ECullMode::Back does */
 static void glsl_mat4_mul_mat4(const float* a, const float* b, float* o)
 {
     for (int j = 0; j < 4; j++) glsl_mat4_mul_vec4(a, b + 4 * j, o + 4 * j);
@@ -1666,7 +1669,8 @@ typedef struct { int64_t x, y; float z; } RasterVertex;
 
 /* view == NULL: clip = LM * position with LM = lightMatrix * model (ShadowCaster.shader:58);
  * view != NULL: clip = projection * (view * (model * position)) (DepthOnly.shader:51), LM = projection here */
-static int raster_setup(const float* LM, const float* view, const float* model, const float* positions, const uint32_t* tri, int W, int H, RasterVertex* v)
+static int raster_setup(const float* LM, const float* view, const float* model, const float* positions, const uint32_t* tri, int W, int H, int cullBack,
+                        RasterVertex* v)
 {
     for (int k = 0; k < 3; k++) {
         const float* p = positions + 3 * (size_t)tri[k];
@@ -1688,6 +1692,9 @@ static int raster_setup(const float* LM, const float* view, const float* model, 
     }
     int64_t area2 = (v[1].x - v[0].x) * (v[2].y - v[0].y) - (v[2].x - v[0].x) * (v[1].y - v[0].y);
     if (area2 == 0) return 0;
+    /* Vulkan: a = -1/2 sum(x_i y_j - x_j y_i) in framebuffer coordinates = -area2 / 2; frontFace is COUNTER_CLOCKWISE (VulkanPipileneStates.cpp:128), i.e.
+     * a > 0 is front-facing; ECullMode::Back (the shadow and depth materials, ShadowPrepassNode.cpp:39) discards the others */
+    if (cullBack && area2 > 0) return 0;
     if (area2 < 0) { const RasterVertex t = v[1]; v[1] = v[2]; v[2] = t; }
     return 1;
 }
@@ -1705,7 +1712,7 @@ static inline int64_t floor_div256(int64_t a) { return a >= 0 ? a / 256 : -((-a 
 
 /* depth: W x H floats, read and written (GREATER); instanceIds == NULL draws instances 0 .. numDrawn-1 */
 static void raster_depth_impl(const float* lightMatrix, const float* view, const float* positions, const uint32_t* indices, uint32_t numTriangles,
-                              const float* models, const uint32_t* instanceIds, uint32_t numDrawn, int32_t W, int32_t H, float* depth)
+                              const float* models, const uint32_t* instanceIds, uint32_t numDrawn, int32_t W, int32_t H, float* depth, int cullBack)
 {
     for (uint32_t d = 0; d < numDrawn; d++) {
         const uint32_t inst = instanceIds ? instanceIds[d] : d;
@@ -1714,7 +1721,7 @@ static void raster_depth_impl(const float* lightMatrix, const float* view, const
         else glsl_mat4_mul_mat4(lightMatrix, models + 16 * (size_t)inst, LM);
         for (uint32_t t = 0; t < numTriangles; t++) {
             RasterVertex v[3];
-            if (!raster_setup(LM, view, models + 16 * (size_t)inst, positions, indices + 3 * (size_t)t, W, H, v)) continue;
+            if (!raster_setup(LM, view, models + 16 * (size_t)inst, positions, indices + 3 * (size_t)t, W, H, cullBack, v)) continue;
             int64_t minx = v[0].x, maxx = v[0].x, miny = v[0].y, maxy = v[0].y;
             for (int k = 1; k < 3; k++) {
                 minx = v[k].x < minx ? v[k].x : minx; maxx = v[k].x > maxx ? v[k].x : maxx;
@@ -1745,17 +1752,17 @@ static void raster_depth_impl(const float* lightMatrix, const float* view, const
 }
 
 ORACLE_API void oracle_raster_depth(const float* lightMatrix, const float* positions, const uint32_t* indices, uint32_t numTriangles, const float* models,
-                                    const uint32_t* instanceIds, uint32_t numDrawn, int32_t W, int32_t H, float* depth)
+                                    const uint32_t* instanceIds, uint32_t numDrawn, int32_t W, int32_t H, float* depth, int32_t cullBack)
 {
-    raster_depth_impl(lightMatrix, NULL, positions, indices, numTriangles, models, instanceIds, numDrawn, W, H, depth);
+    raster_depth_impl(lightMatrix, NULL, positions, indices, numTriangles, models, instanceIds, numDrawn, W, H, depth, cullBack);
 }
 
 /* The depth prepass (FrameGraph/DepthPrepassNode.cpp:283-297, Content/Shaders/DepthOnly.shader:51): the same rasteriser with the camera's matrices,
  * gl_Position = projection * (view * (model * position)); reversed-Z projection, so GREATER against the cleared 0 again. */
 ORACLE_API void oracle_raster_depth_camera(const float* projection, const float* view, const float* positions, const uint32_t* indices, uint32_t numTriangles,
-                                           const float* models, const uint32_t* instanceIds, uint32_t numDrawn, int32_t W, int32_t H, float* depth)
+                                           const float* models, const uint32_t* instanceIds, uint32_t numDrawn, int32_t W, int32_t H, float* depth, int32_t cullBack)
 {
-    raster_depth_impl(projection, view, positions, indices, numTriangles, models, instanceIds, numDrawn, W, H, depth);
+    raster_depth_impl(projection, view, positions, indices, numTriangles, models, instanceIds, numDrawn, W, H, depth, cullBack);
 }
 
 /* ShadowCaster.shader:66-78 on the winning fragment of every texel: EVSM moments (RGBA32F) or the depth itself; texels nothing was drawn

@@ -24,6 +24,7 @@ CULL_DEFAULT = 0
 CULL_BRUTE_FORCE = 1
 CULL_RAW_DEPTH = 2
 
+RASTER_CLEAR, RASTER_CULL_BACK = 1, 2
 SHADOWMAP_R16F = 0
 SHADOWMAP_RGBA32F = 1
 SHADOWMAP_R32F = 2
@@ -119,8 +120,8 @@ SIGNATURES = {
     "sailor_hip_ecs_sweep": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_uint32), C.c_uint32, _P, C.POINTER(C.c_float), _P, _P, _P]),
     "sailor_hip_mesh_frustum_cull": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_uint32, C.c_uint32]),
     "sailor_hip_raster_coarse_words": (C.c_size_t, [C.c_int32, C.c_int32]),
-    "sailor_hip_raster_depth": (C.c_int, [_P, C.POINTER(C.c_float), _P, _P, C.c_uint32, _P, _P, C.c_uint32, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
-    "sailor_hip_raster_depth_camera": (C.c_int, [_P, C.POINTER(UboFrameData), _P, _P, C.c_uint32, _P, _P, C.c_uint32, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
+    "sailor_hip_raster_depth": (C.c_int, [_P, C.POINTER(C.c_float), _P, _P, C.c_uint32, _P, _P, C.c_uint32, C.c_int32, C.c_int32, _P, C.c_uint32, _P]),
+    "sailor_hip_raster_depth_camera": (C.c_int, [_P, C.POINTER(UboFrameData), _P, _P, C.c_uint32, _P, _P, C.c_uint32, C.c_int32, C.c_int32, _P, C.c_uint32, _P]),
     "sailor_hip_shadow_resolve": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "sailor_hip_csm_caster_masks": (C.c_int, [_P, C.c_uint32, _P, C.POINTER(C.c_float), C.c_uint32, _P]),
     "sailor_hip_hiz_downscale": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32]),

@@ -42,7 +42,7 @@ __device__ __forceinline__ long long raster_floor_div256(long long a) { return a
 
 // hasView: clip = projection * (view * (model * position)) (DepthOnly.shader:51, LM = projection); else clip = (lightMatrix * model) * position
 __device__ __forceinline__ RasterTri raster_setup(const Mat4& LM, bool hasView, const Mat4& V, const float* __restrict__ model, const float* __restrict__ positions,
-                                                   const uint32_t* __restrict__ tri, int W, int H)
+                                                   const uint32_t* __restrict__ tri, int W, int H, bool cullBack)
 {
     RasterTri t;
     t.valid = false;
@@ -70,6 +70,7 @@ __device__ __forceinline__ RasterTri raster_setup(const Mat4& LM, bool hasView, 
     }
     const long long area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (X[2] - X[0]) * (Y[1] - Y[0]);
     if (area2 == 0) return t;
+    if (cullBack && area2 > 0) return t; // Vulkan's signed area is -area2 / 2, front = counter-clockwise = positive (see the oracle)
     if (area2 < 0) { long long s = X[1]; X[1] = X[2]; X[2] = s; s = Y[1]; Y[1] = Y[2]; Y[2] = s; const float z = Z[1]; Z[1] = Z[2]; Z[2] = z; }
     t.x0 = X[0]; t.y0 = Y[0]; t.x1 = X[1]; t.y1 = Y[1]; t.x2 = X[2]; t.y2 = Y[2];
     t.z0 = Z[0]; t.z1 = Z[1]; t.z2 = Z[2];
@@ -144,7 +145,7 @@ __device__ __forceinline__ void raster_box_bounds(const RasterTri& t, float area
     }
 }
 
-__global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, Mat4 V, int hasView, const float* __restrict__ positions, const uint32_t* __restrict__ indices, uint32_t numTriangles,
+__global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, Mat4 V, int hasView, int cullBack, const float* __restrict__ positions, const uint32_t* __restrict__ indices, uint32_t numTriangles,
                                                        const float* __restrict__ models, const uint32_t* __restrict__ instanceIds, uint32_t numDrawn, int W, int H,
                                                        unsigned int* __restrict__ depthBits, unsigned int* __restrict__ coarse)
 {
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, Mat4 V, int hasVie
         const uint32_t d = (uint32_t)(id / numTriangles), tri = (uint32_t)(id - (unsigned long long)d * numTriangles);
         const uint32_t inst = instanceIds ? instanceIds[d] : d;
         const Mat4 LM = hasView ? L : raster_mul(L, models + 16 * (size_t)inst);
-        t = raster_setup(LM, hasView != 0, V, models + 16 * (size_t)inst, positions, indices + 3 * (size_t)tri, W, H);
+        t = raster_setup(LM, hasView != 0, V, models + 16 * (size_t)inst, positions, indices + 3 * (size_t)tri, W, H, cullBack != 0);
     }
     const float zmaxTri = fmaxf(t.z0, fmaxf(t.z1, t.z2)) + RASTER_Z_MARGIN; // inside the triangle z is a convex combination of the vertices'
     if (t.valid && !(zmaxTri > 0.0f)) t.valid = false;                        // nothing of it can pass z > 0
@@ -327,8 +328,9 @@ size_t sailor_hip_raster_coarse_words(int32_t width, int32_t height)
 
 static int raster_depth_launch(SailorHipContext* ctx, const float* lightMatrix, const float* viewMatrix, const float* dPositions, const uint32_t* dIndices,
                                uint32_t numTriangles, const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn, int32_t width, int32_t height, float* dDepth,
-                               int32_t clear, uint32_t* dCoarseDepth)
+                               uint32_t flags, uint32_t* dCoarseDepth)
 {
+    const bool clear = (flags & SAILOR_RASTER_CLEAR) != 0;
     if (!ctx || !lightMatrix || !dDepth || width <= 0 || height <= 0 || width > 32768 || height > 32768) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (clear) {
         SAILOR_TRY_HIP(ctx, hipMemsetAsync(dDepth, 0, (size_t)width * height * 4, ctx->stream));
@@ -343,25 +345,25 @@ static int raster_depth_launch(SailorHipContext* ctx, const float* lightMatrix, 
     if (viewMatrix) memcpy(V.m, viewMatrix, 64);
     const unsigned long long total = (unsigned long long)numDrawn * numTriangles;
     if ((total + 255) / 256 > 0x7FFFFFFFull) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(k_raster_depth, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, L, V, viewMatrix ? 1 : 0, dPositions, dIndices, numTriangles, dModels, dInstanceIds,
+    hipLaunchKernelGGL(k_raster_depth, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, L, V, viewMatrix ? 1 : 0, (flags & SAILOR_RASTER_CULL_BACK) ? 1 : 0, dPositions, dIndices, numTriangles, dModels, dInstanceIds,
                        numDrawn, width, height, (unsigned int*)dDepth, (unsigned int*)dCoarseDepth);
     SAILOR_CHECK_LAUNCH(ctx, "k_raster_depth");
     return SAILOR_HIP_OK;
 }
 
 int sailor_hip_raster_depth(SailorHipContext* ctx, const float* lightMatrix, const float* dPositions, const uint32_t* dIndices, uint32_t numTriangles,
-                            const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn, int32_t width, int32_t height, float* dDepth, int32_t clear,
+                            const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn, int32_t width, int32_t height, float* dDepth, uint32_t flags,
                             uint32_t* dCoarseDepth)
 {
-    return raster_depth_launch(ctx, lightMatrix, nullptr, dPositions, dIndices, numTriangles, dModels, dInstanceIds, numDrawn, width, height, dDepth, clear, dCoarseDepth);
+    return raster_depth_launch(ctx, lightMatrix, nullptr, dPositions, dIndices, numTriangles, dModels, dInstanceIds, numDrawn, width, height, dDepth, flags, dCoarseDepth);
 }
 
 int sailor_hip_raster_depth_camera(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dPositions, const uint32_t* dIndices, uint32_t numTriangles,
-                                   const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn, int32_t width, int32_t height, float* dDepth, int32_t clear,
+                                   const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn, int32_t width, int32_t height, float* dDepth, uint32_t flags,
                                    uint32_t* dCoarseDepth)
 {
     if (!frame) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-    return raster_depth_launch(ctx, frame->projection, frame->view, dPositions, dIndices, numTriangles, dModels, dInstanceIds, numDrawn, width, height, dDepth, clear,
+    return raster_depth_launch(ctx, frame->projection, frame->view, dPositions, dIndices, numTriangles, dModels, dInstanceIds, numDrawn, width, height, dDepth, flags,
                                dCoarseDepth);
 }
 

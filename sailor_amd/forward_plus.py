@@ -239,7 +239,8 @@ class EcsSweep:
 
 
 def raster_depth(ctx: "HipContext", light_matrix, positions: torch.Tensor, indices: torch.Tensor, models: torch.Tensor, width: int, height: int,
-                 instance_ids: torch.Tensor | None = None, depth: torch.Tensor | None = None, coarse: torch.Tensor | None = None) -> torch.Tensor:
+                 instance_ids: torch.Tensor | None = None, depth: torch.Tensor | None = None, coarse: torch.Tensor | None = None,
+                 cull_back: bool = False) -> torch.Tensor:
     """sailor_hip_raster_depth: the caster draws of one shadow pass -> float32 [height, width] depth (reversed Z, 0 = nothing drawn).
     `depth` given = draw on top of it (a dependent pass); otherwise a cleared buffer is used.  `coarse`: int32 [sailor_hip_raster_coarse_words(w, h)] scratch that
     belongs to the depth buffer (hierarchical depth; same result, much less fill)."""
@@ -248,17 +249,19 @@ def raster_depth(ctx: "HipContext", light_matrix, positions: torch.Tensor, indic
     n = models.shape[0] if instance_ids is None else instance_ids.numel()
     _lib.check(ctx._lib.sailor_hip_raster_depth(ctx.handle, lm.ctypes.data_as(C.POINTER(C.c_float)), _ptr(positions), _ptr(indices), indices.numel() // 3,
                                                 _ptr(models), _ptr(instance_ids) if instance_ids is not None else None, n, width, height, _ptr(out),
-                                                0 if depth is not None else 1, _ptr(coarse)), "sailor_hip_raster_depth", ctx.handle)
+                                                (0 if depth is not None else _lib.RASTER_CLEAR) | (_lib.RASTER_CULL_BACK if cull_back else 0), _ptr(coarse)),
+               "sailor_hip_raster_depth", ctx.handle)
     return out
 
 
 def raster_depth_camera(ctx: "HipContext", frame, positions: torch.Tensor, indices: torch.Tensor, models: torch.Tensor, width: int, height: int,
-                        instance_ids: torch.Tensor | None = None, coarse: torch.Tensor | None = None) -> torch.Tensor:
+                        instance_ids: torch.Tensor | None = None, coarse: torch.Tensor | None = None, cull_back: bool = False) -> torch.Tensor:
     """sailor_hip_raster_depth_camera: the depth prepass -> raw reversed-Z depth float32 [height, width] (0 = nothing drawn)"""
     out = torch.empty((height, width), dtype=torch.float32, device=ctx.device)
     n = models.shape[0] if instance_ids is None else instance_ids.numel()
     _lib.check(ctx._lib.sailor_hip_raster_depth_camera(ctx.handle, C.byref(frame), _ptr(positions), _ptr(indices), indices.numel() // 3, _ptr(models),
-                                                       _ptr(instance_ids) if instance_ids is not None else None, n, width, height, _ptr(out), 1, _ptr(coarse)),
+                                                       _ptr(instance_ids) if instance_ids is not None else None, n, width, height, _ptr(out),
+                                                       _lib.RASTER_CLEAR | (_lib.RASTER_CULL_BACK if cull_back else 0), _ptr(coarse)),
                "sailor_hip_raster_depth_camera", ctx.handle)
     return out
 

@@ -413,6 +413,10 @@ def test_depth_rasteriser_rules():
     scale[0, 14] = 0.5                                           # centre at z = 0.5: the box spans z in [0.4, 0.6]
     box = oracle.raster_depth(ident, pos, tris, scale, 32, 32)
     assert (box > 0).sum() == 16 * 8 and np.allclose(box[box > 0], 0.6)
+    # back-face culling (frontFace counter-clockwise in Vulkan's framebuffer convention): the cube's outward faces are the front faces
+    np.testing.assert_array_equal(oracle.raster_depth(ident, pos, tris, scale, 32, 32, cull_back=True), box)
+    inside_out = oracle.raster_depth(ident, pos, tris[:, ::-1], scale, 32, 32, cull_back=True)
+    assert (inside_out > 0).sum() == 16 * 8 and np.allclose(inside_out[inside_out > 0], 0.4)   # only the far faces survive
     far = scale.copy(); far[0, 14] = 1.2                         # spans [1.1, 1.3]: clipped away
     assert oracle.raster_depth(ident, pos, tris, far, 32, 32).max() == 0
     m = oracle.shadow_resolve_evsm(box)

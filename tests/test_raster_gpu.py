@@ -69,6 +69,11 @@ def test_box_casters_of_a_cascade_and_the_resolved_maps(ctx, cascade, size):
     d = _gpu(ctx, lm, pos, tris, models, size, size, ids=ids)
     ref = oracle.raster_depth(lm, pos, tris, models, size, size, instance_ids=ids)
     np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # ECullMode::Back, as the reference's shadow material: closed boxes inside the depth slab show the same front faces; in general the oracle decides
+    dcull = raster_depth(ctx, lm, torch.from_numpy(pos).to(ctx.device), torch.from_numpy(tris.view(np.int32)).to(ctx.device), torch.from_numpy(models).to(ctx.device),
+                         size, size, torch.from_numpy(ids.view(np.int32)).to(ctx.device), cull_back=True)
+    ctx.synchronize()
+    np.testing.assert_array_equal(dcull.cpu().numpy().view(np.uint32), oracle.raster_depth(lm, pos, tris, models, size, size, instance_ids=ids, cull_back=True).view(np.uint32))
     # with the coarse-depth workspace: fewer texels touched, the same buffer; every coarse word is a lower bound of its block
     coarse = torch.empty(int(_lib.load().sailor_hip_raster_coarse_words(size, size)), dtype=torch.int32, device=ctx.device)
     dc = raster_depth(ctx, lm, torch.from_numpy(pos).to(ctx.device), torch.from_numpy(tris.view(np.int32)).to(ctx.device), torch.from_numpy(models).to(ctx.device),
@@ -194,6 +199,12 @@ def test_random_triangle_soup(ctx, size):
     ref = oracle.raster_depth(IDENTITY, pos, idx[:half], one, W, H)
     ref = oracle.raster_depth(IDENTITY, pos, idx[half:], one, W, H, depth=ref)
     assert 0.3 < float((ref > 0).mean()) and len(np.unique(ref)) > 500
+    culled = oracle.raster_depth(IDENTITY, pos, idx, one, W, H, cull_back=True)
+    got = raster_depth(ctx, IDENTITY, torch.from_numpy(pos).to(ctx.device), torch.from_numpy(idx.view(np.int32).copy()).to(ctx.device),
+                       torch.from_numpy(one.copy()).to(ctx.device), W, H, cull_back=True)
+    ctx.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), culled.view(np.uint32))
+    assert (culled != ref).any(), "half of the random triangles face away"
     for use_coarse in (False, True):
         coarse = torch.empty(int(_lib.load().sailor_hip_raster_coarse_words(W, H)), dtype=torch.int32, device=ctx.device) if use_coarse else None
         d_pos = torch.from_numpy(pos).to(ctx.device)
