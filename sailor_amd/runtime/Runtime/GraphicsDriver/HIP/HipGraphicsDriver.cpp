@@ -371,13 +371,35 @@ int HipGraphicsDriver::RecordShade(const TVector<RHIShaderBindingSetPtr>& bindin
 
 // ---- the render-pass subset: state is kept on the command list, a 6-index draw of a known full-screen material becomes a
 // kernel launch at submit time (record-then-submit, like Dispatch) ---------------------------------------------------------------
-void HipGraphicsDriver::BeginRenderPass(RHICommandListPtr cmd, const TVector<RHITexturePtr>& colorAttachments, RHITexturePtr)
+void HipGraphicsDriver::BeginRenderPass(RHICommandListPtr cmd, const TVector<RHITexturePtr>& colorAttachments, RHITexturePtr depthStencilAttachment)
 {
     cmd->m_colorAttachments = colorAttachments;
+    cmd->m_depthAttachment = depthStencilAttachment;
+    cmd->m_casterDraws = 0;
+}
+
+void HipGraphicsDriver::BindVertexBuffer(RHICommandListPtr cmd, RHIBufferPtr vertexBuffer, uint32_t) { cmd->m_vertexBuffer = vertexBuffer; }
+void HipGraphicsDriver::BindIndexBuffer(RHICommandListPtr cmd, RHIBufferPtr indexBuffer, uint32_t, bool) { cmd->m_indexBuffer = indexBuffer; }
+void HipGraphicsDriver::PushConstants(RHICommandListPtr cmd, RHIMaterialPtr, size_t size, const void* ptr)
+{
+    cmd->m_pushConstants.assign((const uint8_t*)ptr, (const uint8_t*)ptr + size); // captured at record time (vkCmdPushConstants)
 }
 
 void HipGraphicsDriver::EndRenderPass(RHICommandListPtr cmd)
 {
+    if (cmd->m_casterDraws > 0 && !cmd->m_colorAttachments.empty() && cmd->m_depthAttachment) {
+        // the fragment stage of ShadowCaster.shader wrote one colour per winning fragment; as compute it is one pass over the depth attachment
+        RHITexturePtr color = cmd->m_colorAttachments[0], depth = cmd->m_depthAttachment;
+        SailorHipContext* ctx = m_ctx;
+        cmd->m_hip.m_commands.push_back([ctx, color, depth]() {
+            const int fmt = color->m_format == EFormat::R32G32B32A32_SFLOAT ? SAILOR_SHADOWMAP_R32G32B32A32_SFLOAT
+                                                                              : (color->m_format == EFormat::R16_SFLOAT ? SAILOR_SHADOWMAP_R16_SFLOAT : SAILOR_SHADOWMAP_R32_SFLOAT);
+            return sailor_hip_shadow_resolve(ctx, (const float*)depth->m_buffer->m_hip.m_devicePtr, depth->GetExtent().x, depth->GetExtent().y, fmt,
+                                             color->m_buffer->m_hip.m_devicePtr);
+        });
+    }
+    cmd->m_depthAttachment.Clear();
+    cmd->m_casterDraws = 0;
     cmd->m_colorAttachments.clear();
     cmd->m_boundMaterial.Clear();
     cmd->m_boundBindings.clear();
@@ -390,9 +412,30 @@ void HipGraphicsDriver::BindShaderBindings(RHICommandListPtr cmd, RHIMaterialPtr
     cmd->m_boundBindings = bindings;
 }
 
-void HipGraphicsDriver::DrawIndexed(RHICommandListPtr cmd, uint32_t indexCount, uint32_t instanceCount, uint32_t, uint32_t, uint32_t)
+void HipGraphicsDriver::DrawIndexed(RHICommandListPtr cmd, uint32_t indexCount, uint32_t instanceCount, uint32_t firstIndex, uint32_t vertexOffset, uint32_t firstInstance)
 {
     const std::string name = (cmd->m_boundMaterial && cmd->m_boundMaterial->m_shader) ? cmd->m_boundMaterial->m_shader->m_name : std::string();
+    if (name == "Shaders/ShadowCaster.shader") { // a caster draw of a shadow pass (ShadowPrepassNode.cpp:251-261 via RHIRecordDrawCall, RHI/Batch.hpp)
+        RHITexturePtr depth = cmd->m_depthAttachment;
+        RHIBufferPtr vb = cmd->m_vertexBuffer, ib = cmd->m_indexBuffer, instances;
+        for (auto& set : cmd->m_boundBindings)
+            if (set) if (auto b = set->Find("data")) if (b->m_buffer) instances = b->m_buffer; // ShadowCaster.shader:51-54 PerInstanceDataSSBO { mat4 model; }
+        const bool first = cmd->m_casterDraws++ == 0;
+        TVector<uint8_t> pc = cmd->m_pushConstants;
+        SailorHipContext* ctx = m_ctx;
+        cmd->m_hip.m_commands.push_back([ctx, depth, vb, ib, instances, pc, first, indexCount, instanceCount, firstIndex, vertexOffset, firstInstance]() {
+            if (!depth || !vb || !ib || !instances || pc.size() < 64 || depth->m_format != EFormat::R32_SFLOAT) return (int)SAILOR_HIP_ERR_INVALID_ARGUMENT;
+            float lightMatrix[16];
+            memcpy(lightMatrix, pc.data(), 64);
+            // the render pass clears the depth attachment (ShadowPrepassNode.cpp:239-248); the material culls back faces (:39)
+            return sailor_hip_raster_depth(ctx, lightMatrix, (const float*)vb->m_hip.m_devicePtr + 3 * (size_t)vertexOffset,
+                                           (const uint32_t*)ib->m_hip.m_devicePtr + firstIndex, indexCount / 3,
+                                           (const float*)instances->m_hip.m_devicePtr + 16 * (size_t)firstInstance, nullptr, instanceCount, depth->GetExtent().x,
+                                           depth->GetExtent().y, (float*)depth->m_buffer->m_hip.m_devicePtr, (first ? SAILOR_RASTER_CLEAR : 0u) | SAILOR_RASTER_CULL_BACK,
+                                           nullptr);
+        });
+        return;
+    }
     RHITexturePtr target = cmd->m_colorAttachments.empty() ? RHITexturePtr() : cmd->m_colorAttachments[0];
     // A draw sees the binding sets as they are NOW: ShadowPrepassNode re-points `colorSampler` of one and the same set between its two
     // blur draws (ShadowPrepassNode.cpp:292,329), so the sets are snapshotted at record time (textures / buffers by reference, UBO bytes by value).

@@ -12,6 +12,9 @@
 // and the one full-screen DRAW in front of the path (6 indices with the material of)
 //   "Shaders/LinearizeDepth.shader"      -> sailor_hip_linearize_depth   (binding contract: LinearizeDepth.shader:15-59)
 //   "Shaders/Blur.shader" {EVSM, HORIZONTAL | VERTICAL} -> sailor_hip_evsm_blur_pass (binding contract: Blur.shader:53-61)
+// and the depth-only instanced draws of the shadow passes (material of)
+//   "Shaders/ShadowCaster.shader" [EVSM]  -> sailor_hip_raster_depth into the pass' depth attachment, and at EndRenderPass sailor_hip_shadow_resolve
+//                                            into its colour attachment (push constant lightMatrix, set 1 `data`, vertex positions, 32-bit indices)
 #pragma once
 #include "../../RHI/GraphicsDriver.h"
 
@@ -63,6 +66,9 @@ public:
     void UpdateShaderBinding(RHI::RHICommandListPtr cmd, RHI::RHIShaderBindingPtr binding, const void* data, size_t size, size_t variableOffset = 0) override;
     void UpdateBuffer(RHI::RHICommandListPtr cmd, RHI::RHIBufferPtr buffer, const void* data, size_t size, size_t offset = 0) override;
     void BeginRenderPass(RHI::RHICommandListPtr cmd, const TVector<RHI::RHITexturePtr>& colorAttachments, RHI::RHITexturePtr depthStencilAttachment) override;
+    void BindVertexBuffer(RHI::RHICommandListPtr cmd, RHI::RHIBufferPtr vertexBuffer, uint32_t offset) override;
+    void BindIndexBuffer(RHI::RHICommandListPtr cmd, RHI::RHIBufferPtr indexBuffer, uint32_t offset, bool bUint16InsteadOfUint32 = false) override;
+    void PushConstants(RHI::RHICommandListPtr cmd, RHI::RHIMaterialPtr material, size_t size, const void* ptr) override;
     void EndRenderPass(RHI::RHICommandListPtr cmd) override;
     void BindMaterial(RHI::RHICommandListPtr cmd, RHI::RHIMaterialPtr material) override;
     void BindShaderBindings(RHI::RHICommandListPtr cmd, RHI::RHIMaterialPtr material, const TVector<RHI::RHIShaderBindingSetPtr>& bindings) override;

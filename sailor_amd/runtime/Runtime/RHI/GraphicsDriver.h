@@ -46,6 +46,9 @@ public:
     virtual void UpdateShaderBinding(RHICommandListPtr cmd, RHIShaderBindingPtr binding, const void* data, size_t size, size_t variableOffset = 0) = 0; // :303
     virtual void UpdateBuffer(RHICommandListPtr cmd, RHIBufferPtr buffer, const void* data, size_t size, size_t offset = 0) = 0;                       // :304
     virtual void BeginRenderPass(RHICommandListPtr cmd, const TVector<RHITexturePtr>& colorAttachments, RHITexturePtr depthStencilAttachment) = 0; // :246-255 (area, clear values dropped)
+    virtual void BindVertexBuffer(RHICommandListPtr cmd, RHIBufferPtr vertexBuffer, uint32_t offset) = 0;                                           // :316
+    virtual void BindIndexBuffer(RHICommandListPtr cmd, RHIBufferPtr indexBuffer, uint32_t offset, bool bUint16InsteadOfUint32 = false) = 0;          // :317
+    virtual void PushConstants(RHICommandListPtr cmd, RHIMaterialPtr material, size_t size, const void* ptr) = 0;                                      // :324
     virtual void EndRenderPass(RHICommandListPtr cmd) = 0;                                                                                          // :273
     virtual void BindMaterial(RHICommandListPtr cmd, RHIMaterialPtr material) = 0;                                                                  // :276
     virtual void BindShaderBindings(RHICommandListPtr cmd, RHIMaterialPtr material, const TVector<RHIShaderBindingSetPtr>& bindings) = 0;           // :282

@@ -152,6 +152,10 @@ public:
     TVector<std::string> m_debugRegions; // names seen by BeginDebugRegion, for tests
     // state of the render pass being recorded (BeginRenderPass .. EndRenderPass)
     TVector<TRefPtr<class RHITexture>> m_colorAttachments;
+    TRefPtr<class RHITexture> m_depthAttachment;
+    TRefPtr<class RHIBuffer> m_vertexBuffer, m_indexBuffer;   // BindVertexBuffer / BindIndexBuffer
+    TVector<uint8_t> m_pushConstants;                          // PushConstants(material, size, ptr)
+    uint32_t m_casterDraws = 0;                                // depth-only draws recorded in the current pass (the first one clears)
     TRefPtr<class RHIMaterial> m_boundMaterial;
     TVector<TRefPtr<class RHIShaderBindingSet>> m_boundBindings;
 };

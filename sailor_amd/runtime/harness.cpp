@@ -363,6 +363,44 @@ RT_API int sailor_rt_build_depth_highz(SailorRuntime* rt, void* depthDevicePtr, 
     return hip->GetLastDispatchStatus();
 }
 
+// One shadow pass of ShadowPrepassNode::Process (FrameGraph/ShadowPrepassNode.cpp:219-365), command for command: barriers, BeginRenderPass(shadow map, temporary
+// depth attachment, clear), the light matrix as push constant (:249), the caster draw (vertex / index buffer, per-instance SSBO `data`, instanced DrawIndexed --
+// what RHIRecordDrawCall records per batch), EndRenderPass, then for an EVSM pass with a blur radius the two blur draws (:283-356).
+RT_API int sailor_rt_shadow_pass(SailorRuntime* rt, const float* lightMatrix, void* positions, uint32_t numVertices, void* indices, uint32_t numIndices, void* models,
+                                 uint32_t firstInstance, uint32_t instanceCount, void* shadowMapDevicePtr, int size, int evsm, float radiusUmbra, float radiusPenumbra)
+{
+    auto* hip = static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver());
+    auto driver = Renderer::GetDriver();
+    auto commands = Renderer::GetDriverCommands();
+    auto shadowMap = hip->WrapTexture(shadowMapDevicePtr, { size, size }, evsm ? EFormat::R32G32B32A32_SFLOAT : EFormat::R16_SFLOAT);
+    auto depthAttachment = driver->CreateRenderTarget({ size, size }, 1, EFormat::R32_SFLOAT); // GetOrAddTemporaryRenderTarget(depth format, extent) (:229)
+    auto material = evsm ? driver->CreateMaterial(driver->CreateShader("Shaders/ShadowCaster.shader", { "EVSM" }))
+                         : driver->CreateMaterial(driver->CreateShader("Shaders/ShadowCaster.shader")); // GetOrAddShadowMaterial (:20-45)
+    auto perInstanceData = driver->CreateShaderBindings();
+    perInstanceData->GetOrAddShaderBinding("data")->m_buffer = hip->WrapBuffer(models, (size_t)(firstInstance + instanceCount) * 64);
+    auto cmd = driver->CreateCommandList();
+    commands->BeginDebugRegion(cmd, "Record Shadow Map Pass 0");
+    commands->ImageMemoryBarrier(cmd, shadowMap, EImageLayout::ColorAttachmentOptimal);
+    commands->ImageMemoryBarrier(cmd, depthAttachment, EImageLayout::General);
+    commands->BeginRenderPass(cmd, TVector<RHITexturePtr> { shadowMap }, depthAttachment);
+    commands->PushConstants(cmd, material, 64, lightMatrix);
+    commands->BindMaterial(cmd, material);
+    commands->BindShaderBindings(cmd, material, { rt->snapshot.m_frameBindings ? rt->snapshot.m_frameBindings : driver->CreateShaderBindings(), perInstanceData });
+    commands->BindVertexBuffer(cmd, hip->WrapBuffer(positions, (size_t)numVertices * 12), 0);
+    commands->BindIndexBuffer(cmd, hip->WrapBuffer(indices, (size_t)numIndices * 4), 0);
+    commands->DrawIndexed(cmd, numIndices, instanceCount, 0, 0, firstInstance);
+    commands->EndRenderPass(cmd);
+    commands->EndDebugRegion(cmd);
+    driver->SubmitCommandList(cmd);
+    int st = hip->GetLastDispatchStatus();
+    if (st == 0 && evsm && radiusUmbra * radiusUmbra + radiusPenumbra * radiusPenumbra > 0.01f) {
+        auto temp = driver->CreateRenderTarget({ size, size }, 1, EFormat::R32G32B32A32_SFLOAT);
+        st = sailor_rt_blur_shadow_map(rt, shadowMapDevicePtr, temp->m_buffer->m_hip.m_devicePtr, size, radiusUmbra, radiusPenumbra);
+        driver->WaitIdle(); // `temp` is released on return
+    }
+    return st;
+}
+
 RT_API int sailor_rt_process_frame(SailorRuntime* rt)
 {
     rt->graph.Process(rt->snapshot);

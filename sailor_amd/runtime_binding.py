@@ -48,6 +48,7 @@ def load() -> C.CDLL:
         rt.sailor_rt_render_target.restype = P
         rt.sailor_rt_render_target.argtypes = [P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         rt.sailor_rt_set_render_target.argtypes = [P, C.c_char_p, P, C.c_int, C.c_int]
+        rt.sailor_rt_shadow_pass.argtypes = [P, C.POINTER(C.c_float), P, C.c_uint32, P, C.c_uint32, P, C.c_uint32, C.c_uint32, P, C.c_int, C.c_int, C.c_float, C.c_float]
         rt.sailor_rt_gpu_culling.argtypes = [P, P, C.c_uint32, C.c_uint32, P, C.c_uint32]
         rt.sailor_rt_process_frame.argtypes = [P]
         rt.sailor_rt_wait_idle.argtypes = [P]
@@ -145,6 +146,13 @@ class Runtime:
     def set_render_target(self, name: str, tensor):
         """publish a float32 [h, w] device tensor as a named render target (DepthBuffer, ...)"""
         self.rt.sailor_rt_set_render_target(self.h, name.encode(), tensor.data_ptr(), tensor.shape[1], tensor.shape[0])
+
+    def shadow_pass(self, light_matrix, positions, indices, models, first_instance, instance_count, shadow_map, evsm, radius_umbra=0.0, radius_penumbra=0.0):
+        """one shadow pass of ShadowPrepassNode (caster draw + fragment stage + blur) over device tensors; the map is float32 [S, S, 4] (EVSM) or float16 [S, S]"""
+        lm = np.ascontiguousarray(light_matrix, np.float32).reshape(16)
+        return self.rt.sailor_rt_shadow_pass(self.h, lm.ctypes.data_as(C.POINTER(C.c_float)), positions.data_ptr(), positions.shape[0], indices.data_ptr(),
+                                             indices.numel(), models.data_ptr(), first_instance, instance_count, shadow_map.data_ptr(), shadow_map.shape[0],
+                                             1 if evsm else 0, radius_umbra, radius_penumbra)
 
     def gpu_culling(self, instances, num_instances, first_instance, batches, num_batches):
         """the "GPU Culling" Dispatch of RHIRecordDrawCallGPUCulling over uint8 / int32 device tensors, in place"""

@@ -323,3 +323,36 @@ def test_frame_graph_built_from_a_renderer_description():
         assert (err <= 3e-4 * np.abs(ref) + 1e-5).all(), err.max()
     finally:
         rt.close()
+
+
+@pytest.mark.parametrize("evsm", [True, False])
+def test_shadow_pass_recorded_against_the_hip_backend(evsm):
+    """ShadowPrepassNode's command sequence for one pass -- BeginRenderPass(shadow map, depth attachment), PushConstants(lightMatrix), vertex / index buffers,
+    the per-instance SSBO, an instanced DrawIndexed with the ShadowCaster material, EndRenderPass, the two blur draws -- becomes sailor_hip_raster_depth,
+    sailor_hip_shadow_resolve and sailor_hip_evsm_blur_pass; the map equals the oracle's rasterise (back faces culled) -> fragment stage -> blur."""
+    cam = synth.make_camera(1280, 720)
+    ents = synth.make_entities(1500)
+    planes, _ = host.extract_frustum_planes(cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+    ow, _, _ = oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes)
+    models = synth.caster_models(ow, ents.local_aabb)
+    pos, tris = synth.unit_cube_mesh()
+    sh = synth.make_shadow_set(cam, 16)
+    k, S, first, count = (0, 192, 100, 1200) if evsm else (2, 160, 0, 1500)
+    lm = sh.lights_matrices[k]
+    rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        rt.set_camera(cam)
+        d_pos, d_idx, d_models = torch.from_numpy(pos).cuda(), torch.from_numpy(tris.view(np.int32).copy()).cuda(), torch.from_numpy(models).cuda()
+        smap = torch.full((S, S, 4), 7.0, dtype=torch.float32, device="cuda") if evsm else torch.full((S, S), 7.0, dtype=torch.float16, device="cuda")
+        assert rt.shadow_pass(lm, d_pos, d_idx, d_models, first, count, smap, evsm, 2.0, 5.0) == 0   # ShadowCascadeBlur[0] (ECS/LightingECS.h:68)
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        depth = oracle.raster_depth(lm, pos, tris, models, S, S, instance_ids=np.arange(first, first + count, dtype=np.uint32), cull_back=True)
+        assert 0.01 < float((depth > 0).mean())
+        if evsm:
+            ref = oracle.evsm_blur(oracle.shadow_resolve_evsm(depth), 2, 5)
+            np.testing.assert_array_equal(smap.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+        else:
+            np.testing.assert_array_equal(smap.cpu().numpy().view(np.uint16), depth.astype(np.float16).view(np.uint16))
+    finally:
+        rt.close()
