@@ -179,9 +179,9 @@ __device__ __forceinline__ uint32_t depth_bits(const float* __restrict__ depth, 
 
 __device__ __forceinline__ void k1_tile_setup(int block, const Mat4& invProj, int vpW, int vpH, const float* __restrict__ depth, int W, int H,
                                               int Tx, int tileRow0, int bandRow0, int stripsPerRow, int vecOK, int rawDepth, float zNearCam,
-                                              float4* __restrict__ tileInfo)
+                                              float4* __restrict__ tileInfo, unsigned char* __restrict__ lds)
 {
-    __shared__ uint32_t sMin[4][16], sMax[4][16];
+    uint32_t (*sMin)[16] = reinterpret_cast<uint32_t (*)[16]>(lds), (*sMax)[16] = reinterpret_cast<uint32_t (*)[16]>(lds + 256); // [4][16] each
     const int strip = block % stripsPerRow;
     const int tyLocal = block / stripsPerRow;
     const int ty = tileRow0 + tyLocal;
@@ -252,14 +252,21 @@ struct PrepareArgs {
     float zNearCam;
 };
 
-__global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
+// Every stage below is a device function over (block index, LDS) plus a thin __global__ wrapper: the same bodies run inside the fused
+// "shade slice of frame k + cull stage of frame k+1" launches at the end of this file.
+#define LDS_K01_PREPARE 512
+__device__ __forceinline__ void k01_prepare_body(const int b, unsigned char* __restrict__ lds, const PrepareArgs& a)
 {
-    const int b = (int)blockIdx.x;
     if (b < a.setupBlocks)
-        k1_tile_setup(b, a.invProj, a.vpW, a.vpH, a.depth, a.W, a.H, a.Tx, a.tileRow0, a.bandRow0, a.stripsPerRow, a.vecOK, a.rawDepth, a.zNearCam, a.tileInfo);
+        k1_tile_setup(b, a.invProj, a.vpW, a.vpH, a.depth, a.W, a.H, a.Tx, a.tileRow0, a.bandRow0, a.stripsPerRow, a.vecOK, a.rawDepth, a.zNearCam, a.tileInfo, lds);
     else
         k0_light_view(b - a.setupBlocks, a.view, a.lights, a.N, a.lightBlocks, a.lightView, a.lightType, a.invProj, a.vpW, a.vpH, a.Tx, a.Ty, a.tileRow0,
                       a.bandRows, a.groupsX, a.numBands, a.bandPlanes);
+}
+__global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K01_PREPARE];
+    k01_prepare_body((int)blockIdx.x, lds, a);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -267,16 +274,17 @@ __global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
 // A light is dropped from a band only if its sphere is entirely in front of the eye AND entirely outside one of the
 // band's two planes by more than the margin; directional lights and everything doubtful stay in.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k1_band_masks(const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType, int N, int words,
-                                                      const float4* __restrict__ bandPlanes, int numBands, float planeMargin,
-                                                      unsigned long long* __restrict__ masks, unsigned long long* __restrict__ dirWords)
+#define LDS_K1_BAND_MASKS (2 * BANDS_PER_GROUP * 16)
+__device__ __forceinline__ void k1_band_masks_body(const unsigned bx, const unsigned by, unsigned char* __restrict__ lds, const float4* __restrict__ lightView,
+                                                   const uint32_t* __restrict__ lightType, int N, int words, const float4* __restrict__ bandPlanes, int numBands,
+                                                   float planeMargin, unsigned long long* __restrict__ masks, unsigned long long* __restrict__ dirWords)
 {
-    __shared__ float4 sPl[2 * BANDS_PER_GROUP];
-    const int b0 = blockIdx.y * BANDS_PER_GROUP;
+    float4* sPl = reinterpret_cast<float4*>(lds); // [2 * BANDS_PER_GROUP]
+    const int b0 = by * BANDS_PER_GROUP;
     const int nb = min(BANDS_PER_GROUP, numBands - b0);
     if ((int)threadIdx.x < 2 * nb) sPl[threadIdx.x] = bandPlanes[2 * b0 + threadIdx.x]; // this block's planes, read once
     __syncthreads();
-    const int word = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int word = bx * 4 + (threadIdx.x >> 6);
     if (word >= words) return;
     const int lane = threadIdx.x & 63;
     const int j = word * 64 + lane;
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256) void k1_band_masks(const float4* __restrict__ 
     const bool inFront = (lv.z - r) > m; // false for NaN => never plane-culled
     const float thr = -(r + m);
     const bool keepAlways = valid && (type == 0u || !inFront);
-    if (blockIdx.y == 0) { // one bit per light: "directional" (rides along into the group lists, saves a gather per candidate)
+    if (by == 0) { // one bit per light: "directional" (rides along into the group lists, saves a gather per candidate)
         const unsigned long long dm = __ballot(valid && type == 0u);
         if (lane == 0) dirWords[word] = dm;
     }
@@ -299,6 +307,13 @@ __global__ __launch_bounds__(256) void k1_band_masks(const float4* __restrict__ 
         const unsigned long long mask = __ballot(keepAlways || (valid && !out));
         if (lane == 0) masks[(size_t)(b0 + b) * words + word] = mask;
     }
+}
+__global__ __launch_bounds__(256) void k1_band_masks(const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType, int N, int words,
+                                                      const float4* __restrict__ bandPlanes, int numBands, float planeMargin,
+                                                      unsigned long long* __restrict__ masks, unsigned long long* __restrict__ dirWords)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K1_BAND_MASKS];
+    k1_band_masks_body(blockIdx.x, blockIdx.y, lds, lightView, lightType, N, words, bandPlanes, numBands, planeMargin, masks, dirWords);
 }
 
 __device__ __forceinline__ uint64_t lanemask_lt()
@@ -314,12 +329,13 @@ __device__ __forceinline__ uint64_t lanemask_lt()
 // sparse-bits -> dense-list conversion is fully parallel.  Done once per 16 tiles, not per tile (profiles/r01: the
 // per-tile scalar version saturated the CUs' scalar ALUs; a per-group scalar version was tail-bound by cluster groups).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ dirWords,
-                                                       int words, int Tx, int bandRows, int groupsX,
-                                                       uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList)
+#define LDS_K1_GROUP_LISTS 16
+__device__ __forceinline__ void k1_group_lists_body(const unsigned bx, unsigned char* __restrict__ lds, const unsigned long long* __restrict__ masks,
+                                                    const unsigned long long* __restrict__ dirWords, int words, int Tx, int bandRows, int groupsX,
+                                                    uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList)
 {
-    __shared__ uint32_t sW[4];
-    const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* sW = reinterpret_cast<uint32_t*>(lds); // [4]
+    const int g = bx, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long* __restrict__ c = masks + (size_t)(g % groupsX) * words;
     const unsigned long long* __restrict__ r = masks + (size_t)(groupsX + g / groupsX) * words;
     uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
@@ -356,6 +372,13 @@ __global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* 
         __syncthreads();
     }
     if (threadIdx.x == 0) groupCount[g] = base > CAPG ? GROUP_OVERFLOW : base;
+}
+__global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ dirWords,
+                                                       int words, int Tx, int bandRows, int groupsX,
+                                                       uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K1_GROUP_LISTS];
+    k1_group_lists_body(blockIdx.x, lds, masks, dirWords, words, Tx, bandRows, groupsX, groupCount, groupList);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -412,23 +435,23 @@ __device__ __forceinline__ void test_candidates(const TileCtx& t, const float4* 
 // told not to move accesses across this point (and to wait for outstanding DS results).
 #define WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
 
+#define LDS_K1_TILE_CULL (CHUNK * 16 + CHUNK * 4 + 4 * CAND * 4 + 4 * CAND * 4)
 template <bool BRUTE>
-__global__ __launch_bounds__(256) void k1_tile_cull(const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType, int N, int words,
-                                                    const float4* __restrict__ tileInfo, int Tx, int bandRows,
-                                                    const unsigned long long* __restrict__ masks,
-                                                    const uint32_t* __restrict__ groupCount, const uint32_t* __restrict__ groupList, int groupsX,
-                                                    uint32_t* __restrict__ tileNum, uint32_t* __restrict__ tileList)
+__device__ __forceinline__ void k1_tile_cull_body(const unsigned bx, unsigned char* __restrict__ lds, const float4* __restrict__ lightView,
+                                                  const uint32_t* __restrict__ lightType, int N, int words, const float4* __restrict__ tileInfo, int Tx, int bandRows,
+                                                  const unsigned long long* __restrict__ masks, const uint32_t* __restrict__ groupCount,
+                                                  const uint32_t* __restrict__ groupList, int groupsX, uint32_t* __restrict__ tileNum, uint32_t* __restrict__ tileList)
 {
     // One 256-thread block per 2x2 QUARTER of a 4x4-tile group, one wave per tile.  The group's candidate records are
     // staged in LDS, CHUNK at a time, by the four waves together (list entries first, then the dependent 16-byte
     // gathers, four of each in flight per thread), and every tile streams them out of LDS.  Four blocks per group, not
     // one of sixteen waves: a cluster group (2048 candidates, four 196 -> 128 selections per SIMD) used to keep ONE CU
     // busy for ~40 us while the rest of the chip idled -- the kernel's tail -- and at 26 KB of LDS six blocks fit a CU.
-    __shared__ float4 sLV[CHUNK];                                   // 16 KB: candidate (view pos, radius)
-    __shared__ uint32_t sE[CHUNK];                                  //  4 KB: candidate light index | directional << 31
-    __shared__ uint32_t sIdxAll[4][CAND];
-    __shared__ __attribute__((aligned(16))) float sImpAll[4][CAND];
-    const int g = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+    float4* sLV = reinterpret_cast<float4*>(lds);                                                         // [CHUNK] candidate (view pos, radius)
+    uint32_t* sE = reinterpret_cast<uint32_t*>(lds + CHUNK * 16);                                         // [CHUNK] candidate light index | directional << 31
+    uint32_t (*sIdxAll)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds + CHUNK * 20);                   // [4][CAND]
+    float (*sImpAll)[CAND] = reinterpret_cast<float (*)[CAND]>(lds + CHUNK * 20 + 4 * CAND * 4);          // [4][CAND], 16-byte aligned (CAND * 4 = 784)
+    const int g = bx >> 2, quarter = bx & 3;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* sIdx = sIdxAll[wave];
     float* sImp = sImpAll[wave];
@@ -614,6 +637,16 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const float4* __restrict__ l
     }
     if (lane == 0) tileNum[bandTile] = num;
 }
+template <bool BRUTE>
+__global__ __launch_bounds__(256) void k1_tile_cull(const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType, int N, int words,
+                                                    const float4* __restrict__ tileInfo, int Tx, int bandRows,
+                                                    const unsigned long long* __restrict__ masks,
+                                                    const uint32_t* __restrict__ groupCount, const uint32_t* __restrict__ groupList, int groupsX,
+                                                    uint32_t* __restrict__ tileNum, uint32_t* __restrict__ tileList)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K1_TILE_CULL];
+    k1_tile_cull_body<BRUTE>(blockIdx.x, lds, lightView, lightType, N, words, tileInfo, Tx, bandRows, masks, groupCount, groupList, groupsX, tileNum, tileList);
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // K1d: canonical offsets (Appendix A step 6) and compaction: per-1024-tile block sums, then every tile's wave
@@ -658,13 +691,12 @@ __global__ __launch_bounds__(1024) void k1_block_sums(const uint32_t* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k1_pack(const uint32_t* __restrict__ tileNum, const uint32_t* __restrict__ tilePrefix,
-                                                const uint32_t* __restrict__ blockSums, int sumBlocks,
-                                                const uint32_t* __restrict__ tileList, int T, SailorLightsGrid* __restrict__ grid,
-                                                uint32_t* __restrict__ culled, uint32_t capacity,
-                                                const uint32_t* __restrict__ classPrefix, const uint32_t* __restrict__ classSums, int Tx, uint32_t* __restrict__ tileOrder)
+__device__ __forceinline__ void k1_pack_body(const unsigned bx, const uint32_t* __restrict__ tileNum, const uint32_t* __restrict__ tilePrefix,
+                                             const uint32_t* __restrict__ blockSums, int sumBlocks, const uint32_t* __restrict__ tileList, int T,
+                                             SailorLightsGrid* __restrict__ grid, uint32_t* __restrict__ culled, uint32_t capacity,
+                                             const uint32_t* __restrict__ classPrefix, const uint32_t* __restrict__ classSums, int Tx, uint32_t* __restrict__ tileOrder)
 {
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tile = bx * 4 + (threadIdx.x >> 6);
     if (tile >= T) return;
     const int lane = threadIdx.x & 63;
     const int blk = tile / SCAN_BLOCK;
@@ -709,6 +741,14 @@ __global__ __launch_bounds__(256) void k1_pack(const uint32_t* __restrict__ tile
     if ((uint32_t)lane < num && offset + lane < capacity) culled[offset + lane] = e0;
     if ((uint32_t)lane + 64u < num && offset + lane + 64u < capacity) culled[offset + lane + 64u] = e1;
     if (tile == 0 && lane == 0) culled[0] = tot;
+}
+__global__ __launch_bounds__(256) void k1_pack(const uint32_t* __restrict__ tileNum, const uint32_t* __restrict__ tilePrefix,
+                                                const uint32_t* __restrict__ blockSums, int sumBlocks,
+                                                const uint32_t* __restrict__ tileList, int T, SailorLightsGrid* __restrict__ grid,
+                                                uint32_t* __restrict__ culled, uint32_t capacity,
+                                                const uint32_t* __restrict__ classPrefix, const uint32_t* __restrict__ classSums, int Tx, uint32_t* __restrict__ tileOrder)
+{
+    k1_pack_body(blockIdx.x, tileNum, tilePrefix, blockSums, sumBlocks, tileList, T, grid, culled, capacity, classPrefix, classSums, Tx, tileOrder);
 }
 
 __global__ void k_grid_rebase(SailorLightsGrid* grid, int T, uint32_t base)

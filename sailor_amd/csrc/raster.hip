@@ -259,7 +259,9 @@ __global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, Mat4 V, int hasVie
                             }
                         }
                     }
+#ifdef RASTER_STATS
                     { const unsigned long long wb = __ballot(wrote), ib = __ballot(z < 2.0f); if (lane == 0) { STAT(4, __popcll(ib)); STAT(5, __popcll(wb)); STAT(6, wb == ~0ull); } }
+#endif
                     if (coarse && __ballot(wrote) == ~0ull) { // the whole block now holds depths >= the smallest one written here
                         float zmin = z;
 #pragma unroll

@@ -1,0 +1,622 @@
+// The device side of K2 + K3 (and the ambient / IBL term): argument structs, the canonical shadow-map helpers, and k2_shade_body -- one 16 x 16 tile
+// per 256-thread block.  In a header so that shade.hip (one kernel per variant) and pipeline.hip (shade slices fused with the next frame's cull
+// stages) instantiate the same code.  Design notes: shade.hip.
+#pragma once
+#include "common.h"
+#include "sampling.h"
+#include <hip/hip_fp16.h>
+
+struct CsmArgs {
+    Mat4 lightsMatrices[SAILOR_NUM_CSM_CASCADES];
+    const void* maps[SAILOR_NUM_CSM_CASCADES];
+    int width[SAILOR_NUM_CSM_CASCADES];
+    int height[SAILOR_NUM_CSM_CASCADES];
+    int format[SAILOR_NUM_CSM_CASCADES];
+};
+
+struct IblArgs { // SailorIblDesc by value
+    const float4* irradiance; const float4* env; const float2* brdfLut; const float* ao;
+    int irrSize, envSize, envLevels, lutW, lutH;
+};
+
+struct ShadeArgs {
+    Mat4 view;
+    float camX, camY, camZ;
+    float zFar;
+    int vpW, vpH;     // frame.viewportSize
+    int W;            // surface width in pixels
+    int H;            // full frame height
+    int Tx;
+    int tileRow0;     // band.tileRowBegin
+    int fbRow0;       // band.fbRowBegin
+    int fbRows;       // band.fbRowCount
+    int lightsNum;
+    const uint32_t* order; // sailor_hip_light_cull_tile_order or null
+};
+
+// ---- K3: canonical-order helpers (must match oracle/sailor_oracle.c bit for bit) -----------------------------
+__device__ __forceinline__ float texel_r(const void* __restrict__ map, int fmt, int W, int x, int y)
+{
+    const size_t i = (size_t)y * W + x;
+    if (fmt == SAILOR_SHADOWMAP_R16_SFLOAT) return __half2float(reinterpret_cast<const __half*>(map)[i]);
+    if (fmt == SAILOR_SHADOWMAP_R32_SFLOAT) return reinterpret_cast<const float*>(map)[i];
+    return reinterpret_cast<const float*>(map)[i * 4];
+}
+
+__device__ __forceinline__ float sample_r(const void* __restrict__ map, int fmt, int W, int H, float u, float v)
+{
+    const BilinearTaps t = bilinear_taps(W, H, u, v);
+    return lerp2(texel_r(map, fmt, W, t.x0, t.y0), texel_r(map, fmt, W, t.x1, t.y0),
+                 texel_r(map, fmt, W, t.x0, t.y1), texel_r(map, fmt, W, t.x1, t.y1), t.ax, t.ay);
+}
+
+__device__ __forceinline__ float4 sample_rgba(const void* __restrict__ map, int fmt, int W, int H, float u, float v)
+{
+    const BilinearTaps t = bilinear_taps(W, H, u, v);
+    if (fmt != SAILOR_SHADOWMAP_R32G32B32A32_SFLOAT) {
+        const float r = lerp2(texel_r(map, fmt, W, t.x0, t.y0), texel_r(map, fmt, W, t.x1, t.y0),
+                              texel_r(map, fmt, W, t.x0, t.y1), texel_r(map, fmt, W, t.x1, t.y1), t.ax, t.ay);
+        return make_float4(r, 0.0f, 0.0f, 1.0f);
+    }
+    const float4* m = reinterpret_cast<const float4*>(map);
+    const float4 a = m[(size_t)t.y0 * W + t.x0], b = m[(size_t)t.y0 * W + t.x1];
+    const float4 c = m[(size_t)t.y1 * W + t.x0], d = m[(size_t)t.y1 * W + t.x1];
+    return make_float4(lerp2(a.x, b.x, c.x, d.x, t.ax, t.ay), lerp2(a.y, b.y, c.y, d.y, t.ax, t.ay),
+                       lerp2(a.z, b.z, c.z, d.z, t.ax, t.ay), lerp2(a.w, b.w, c.w, d.w, t.ax, t.ay));
+}
+
+// The one exp() of the path (Lighting.glsl:277-278): fixed fp32 algorithm shared with the oracle.
+__device__ __forceinline__ float canonical_expf(float x)
+{
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) x = -87.0f;
+    const float n = floorf(x * 1.44269504088896341f + 0.5f);
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    const float y = (p * z + r) + 1.0f;
+    return ldexpf(y, (int)n);
+}
+
+__constant__ float kPoissonDisk[16][2] = { // Lighting.glsl:176-185
+    { -0.94201624f, -0.39906216f }, { 0.94558609f, -0.76890725f }, { -0.094184101f, -0.92938870f }, { 0.34495938f, 0.29387760f },
+    { -0.91588581f, 0.45771432f }, { -0.81544232f, -0.87912464f }, { -0.38277543f, 0.27676845f }, { 0.97484398f, 0.75648379f },
+    { 0.44323325f, -0.97511554f }, { 0.53742981f, -0.47373420f }, { -0.26496911f, -0.41893023f }, { 0.79197514f, 0.19090188f },
+    { -0.24188840f, 0.99706507f }, { -0.81409955f, 0.91437590f }, { 0.19984126f, 0.78641367f }, { 0.14383161f, -0.14100790f }
+};
+
+// Lighting.glsl:242-261 ShadowCalculation_Pcf + :168-197 ManualPCF
+__device__ float shadow_pcf(const void* __restrict__ map, int fmt, int W, int H, float4 lp, float bias)
+{
+    float px = lp.x / lp.w, py = lp.y / lp.w, pz = lp.z / lp.w;
+    px = px * 0.5f + 0.5f; py = py * 0.5f + 0.5f; pz = pz * 0.5f + 0.5f;
+    py = 1.0f - py;
+    if (px > 1.0f || py > 1.0f || px < 0.0f || py < 0.0f || pz < 0.5f) return 1.0f;
+    const float tsx = 1.0f / (float)W, tsy = 1.0f / (float)H;
+    float shadow = 0.0f;
+#pragma unroll 1
+    for (int i = 0; i < 16; i++) {
+        const float ox = kPoissonDisk[i][0] * 2.0f * tsx, oy = kPoissonDisk[i][1] * 2.0f * tsy;
+        const float pcfDepth = sample_r(map, fmt, W, H, px + ox, py + oy) * 0.5f + 0.5f;
+        shadow += (pz + bias > pcfDepth) ? 1.0f : 0.0f;
+    }
+    return shadow / 16.0f;
+}
+
+// Lighting.glsl:218-240
+__device__ __forceinline__ float chebyshev(float m0, float m1, float currentDepth, float minVariance, float lin)
+{
+    const float d = currentDepth - m0;
+    if (d < 0.0f) return 1.0f;
+    const float variance = fmaxf(minVariance, m1 - m0 * m0);
+    const float pmax = variance / (variance + d * d);
+    return fminf(fmaxf((pmax - lin) / (1.0f - lin), 0.0f), 1.0f);
+}
+
+// Lighting.glsl:263-284 ShadowCalculation_Evsm
+__device__ float shadow_evsm(const void* __restrict__ map, int fmt, int W, int H, float4 lp, float bias, int cascade)
+{
+    float px = lp.x / lp.w, py = lp.y / lp.w;
+    const float pz = lp.z / lp.w;
+    px = px * 0.5f + 0.5f; py = py * 0.5f + 0.5f;
+    py = 1.0f - py;
+    if (px > 1.0f || py > 1.0f || px < 0.0f || py < 0.0f || pz < 0.0f) return 1.0f;
+    const float4 s = sample_rgba(map, fmt, W, H, px, py);
+    float p05 = 1.0f;
+    for (int i = 0; i < cascade; i++) p05 = p05 * 0.5f;
+    const float currentDepth = canonical_expf(40.0f * (pz + 0.003f * bias * p05));
+    const float negCurrentDepth = -canonical_expf(-40.0f * (pz + 0.0001f * bias));
+    const float posValue = chebyshev(s.x, s.y, currentDepth, 0.01f, 0.0f);
+    const float negValue = chebyshev(s.z, s.w, negCurrentDepth, 0.0f, 0.0f) * (cascade > 2 ? 0.0f : 1.0f);
+    return fminf(fmaxf(1.0f - fmaxf(posValue, negValue), 0.0f), 1.0f);
+}
+
+// Standard.shader:266-283 + Lighting.glsl:200-216 SelectCascade
+__device__ float directional_shadow(const ShadeArgs& A, const CsmArgs& C, uint32_t shadowType,
+                                    float dirX, float dirY, float dirZ, float nx, float ny, float nz, float wx, float wy, float wz)
+{
+    const float4 pv = glsl_mul(A.view, wx, wy, wz, 1.0f);
+    const float depthValue = fabsf(pv.z / pv.w);
+    int cascade = SAILOR_NUM_CSM_CASCADES;
+    const float levels[4] = { 0.05f, 0.1f, 0.333333f, 0.5f }; // Constants.glsl:24
+#pragma unroll
+    for (int i = SAILOR_NUM_CSM_CASCADES - 1; i >= 0; i--)
+        if (depthValue < A.zFar * levels[i]) cascade = i;
+    cascade = min(cascade, SAILOR_NUM_CSM_CASCADES - 1);
+    const void* map = C.maps[cascade];
+    if (!map) return 1.0f;
+    const float4 lp = glsl_mul(C.lightsMatrices[cascade], wx, wy, wz, 1.0f);
+    const float ndl = dot3f(nx, ny, nz, dirX, dirY, dirZ);
+    if (shadowType == 2u && cascade == 0) {
+        const float bias = (1.0f - ndl) * (float)(1 + cascade);
+        return shadow_evsm(map, C.format[cascade], C.width[cascade], C.height[cascade], lp, bias, cascade);
+    }
+    const float bias = fmaxf(0.000075f * (1.0f - ndl), 0.000005f);
+    return shadow_pcf(map, C.format[cascade], C.width[cascade], C.height[cascade], lp, bias);
+}
+
+// ---- ambient / IBL term (Standard.shader:343-372), canonical samplers == oracle/sailor_oracle.c (tolerance-checked) ----
+__device__ __forceinline__ float2 lut_sample(const float2* __restrict__ lut, int W, int H, float u, float v)
+{
+    const BilinearTaps b = bilinear_taps(W, H, u, v);
+    const float2 a = lut[(size_t)b.y0 * W + b.x0], c = lut[(size_t)b.y0 * W + b.x1];
+    const float2 d = lut[(size_t)b.y1 * W + b.x0], e = lut[(size_t)b.y1 * W + b.x1];
+    return make_float2(lerp2(a.x, c.x, d.x, e.x, b.ax, b.ay), lerp2(a.y, c.y, d.y, e.y, b.ax, b.ay));
+}
+
+// ---- K2 ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
+
+#define LREC 5 // float4 per staged light
+#define PENDK 3  // queued pairs per pixel in one window
+#define QMAX 120 // queued pairs per wave in one window (120: the block stays within 20 KB of LDS, 8 blocks per CU)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Order-preserving float <-> int32 map (an involution), so that the wave-wide bounding box can be reduced with
+// v_min_i32 / v_max_i32 DPP steps: one instruction per step and value, no NaN canonicalisation, no LDS round trips.
+__device__ __forceinline__ int f2key(float f) { const int b = __float_as_int(f); return b ^ ((b >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float key2f(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+
+#define DPP6_STEP(ctrl)                                                                                               \
+    asm volatile("v_min_i32_dpp %0, %0, %0 " ctrl "\n\tv_min_i32_dpp %1, %1, %1 " ctrl "\n\tv_min_i32_dpp %2, %2, %2 " ctrl \
+                 "\n\tv_max_i32_dpp %3, %3, %3 " ctrl "\n\tv_max_i32_dpp %4, %4, %4 " ctrl "\n\tv_max_i32_dpp %5, %5, %5 " ctrl \
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f))
+
+// min of a, b, c and max of d, e, f over the 64 lanes; every lane of row 3 (lanes 48..63) ends up with the result.
+// (xor-1, xor-2, mirror within 8, mirror within 16, then the gfx9 row broadcasts 15 -> row+1 and 31 -> rows 2,3.)
+__device__ __forceinline__ void wave_minmax6(int& a, int& b, int& c, int& d, int& e, int& f)
+{
+    asm volatile("s_nop 1" ::: "memory"); // a DPP read of a VGPR needs 2 wait states after the VALU write
+    DPP6_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    DPP6_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    DPP6_STEP("row_half_mirror row_mask:0xf bank_mask:0xf");
+    DPP6_STEP("row_mirror row_mask:0xf bank_mask:0xf");
+    DPP6_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    DPP6_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+    asm volatile("s_nop 1" ::: "memory");
+}
+
+// Staged light record (LDS, 5 float4):
+//   rec0 = (worldPosition.xyz, A)   the conservative reach test of both types is  !(v > A):
+//                                     point: v = d^2,    A = r^2 (1 + 1e-5)      (out of reach => exact-zero radius window)
+//                                     spot : v ~ -theta, A = -(cutOff.y - 1e-5)  (outside the cone => falloff exactly 0)
+//                                     A = +inf: never reject
+//   rec1 = (normalize(-direction).xyz, bits: type | shadowType << 8 | finite << 16)
+//   rec2 = (attenuation.xyz, B)     B = point: bounds.x          spot: epsilon = cutOff.x - cutOff.y (:297)
+//   rec3 = (Li = -direction.xyz, cutOff.y)
+//   rec4 = (intensity.xyz, -)
+//
+// The kernel is VALU-bound (rocprofv3: SQ_INSTS_VALU x 4 cycles on 1024 SIMDs == the duration of the loop-per-light version it
+// replaced), so the shape below is about vector instructions per wave: light kind, finiteness and "survived the box test" are
+// wave-uniform 64-bit masks (scalar registers, scalar branches, six static segments -- no per-light type branches), the reach
+// test feeds the scalar branch directly, and the ~130-instruction exact falloff + BRDF only ever runs on queued pairs.
+//
+// BAND (split frames: sailor_hip_shade_ex on a sub-band with the cull's tile-order hint): a band of a split frame has too few
+// tiles to hide its longest one -- a tile in the middle of a light cluster (128 lights reaching all 256 pixels = 128 pair passes
+// per wave) kept its block busy for ~65 us while the rest of a 1/8 band took 25.  The hint lists the band's tiles by list-length
+// class, long lists first, and ends with the number of tiles holding >= SPLIT_MIN lights.  Those tiles are taken by "split"
+// blocks, one per (tile, 8x8 quadrant): the block's four waves take every fourth list slot each over the SAME 64 pixels and add
+// their partial sums up through LDS (wave 0 + 1 + 2 + 3, a fixed order).  The grid is 1-D: SPLIT_BLOCKS split blocks first (they
+// walk the long tiles with a grid stride, so the long tiles start first), then one ordinary block per tile, which returns at
+// once if the tile belongs to the split blocks.
+#define SPLIT_MIN 40      // == CLASS_B of light_cull.hip: the hint's first two classes
+#define SPLIT_BLOCKS 2048 // one round of resident blocks (8 per CU)
+struct ShadeLds {
+    float4 sL[KEEP * LREC];
+    float sRes[3 * PENDK * 256];
+    uint16_t sQ[4 * QMAX];
+    uint32_t sNum;
+};
+#define ROLE_TILE 0       // one block per tile, grid (tiles per row, tile rows)
+#define ROLE_BAND_TILE 1  // the same inside k2_shade_band: returns at once on a tile of the split blocks
+#define ROLE_BAND_SPLIT 2 // one block per (long tile, quadrant)
+template <bool HAS_CSM, bool HAS_IBL, int ROLE = ROLE_TILE>
+__device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, const IblArgs& I, const float4* __restrict__ surface, size_t planeStride,
+                                                 const SailorLightShaderData* __restrict__ lights,
+                                                 const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled,
+                                                 float4* __restrict__ radiance, int selTx = 0, int selTy = 0, int selQuad = 0)
+{
+    float4* const sL = lds.sL;
+    float* const sRes = lds.sRes;
+    uint16_t* const sQ = lds.sQ;
+    uint32_t& sNum = lds.sNum;
+    constexpr bool BAND = ROLE != ROLE_TILE;
+    constexpr bool splitRole = ROLE == ROLE_BAND_SPLIT;
+    int tid = threadIdx.x;
+    // (a split block walks several tiles: keep everything derived from the lane id inside the loop body -- hoisted out of the
+    // loop those values stay live across the whole body and the 64-register budget spills)
+    if (splitRole) asm volatile("" : "+v"(tid));
+
+    // grid = (tiles per row, tile rows of the band): no division.  With an order hint block i takes the i-th tile of that order.
+    int btx = blockIdx.x, bty = blockIdx.y;
+    const int lane = tid & 63, wave = tid >> 6;
+    int quad = wave;
+    if (BAND) { btx = selTx; bty = selTy; if (splitRole) quad = selQuad; }
+    else if (A.order) { const uint32_t o = A.order[blockIdx.y * A.Tx + blockIdx.x]; btx = (int)(o & 0xFFFFu); bty = (int)(o >> 16); }
+    const int tx = btx, ty = A.tileRow0 + bty;
+    const int bandTile = bty * A.Tx + btx;
+    // each wave shades one 8x8 quadrant of the tile: the most compact 64-pixel footprint, so that "no pixel of the wave
+    // is within reach of this light" holds as often as possible
+    const int gx = tx * TILE + (quad & 1) * 8 + (lane & 7);
+    const int gy = ty * TILE + (quad >> 1) * 8 + (lane >> 3);
+    const int py = A.H - 1 - gy;            // framebuffer row (Standard.shader:414: screenUv.y = H - fragY)
+    const bool active = gx < A.W && py >= 0;
+    const size_t pix = active ? ((size_t)(py - A.fbRow0) * A.W + gx) : 0;
+
+    SailorLightsGrid g;
+    // issue the surface loads first -- unconditionally (lanes outside the frame read pixel 0 of the band and are masked
+    // out of every ballot and of the store), so that nothing waits on them before the list staging below is under way
+    const float4 P0 = surface[pix];
+    const float4 P1 = surface[planeStride + pix];
+    const float4 P2 = surface[2 * planeStride + pix];
+
+    g = grid[bandTile]; // Standard.shader:422-423
+    if (BAND && !splitRole && g.num >= (uint32_t)SPLIT_MIN) return; // a tile of the split blocks
+    const uint32_t listNum = g.num < (uint32_t)KEEP ? g.num : (uint32_t)KEEP;
+    if (tid == 0) sNum = listNum;
+    __syncthreads();
+    if (tid < listNum) {
+        const uint32_t index = culled[g.offset + tid];
+        if (index >= (uint32_t)A.lightsNum) {
+            atomicMin(&sNum, tid); // Standard.shader:430-433 "index == uint(-1) -> break" (and out-of-range guard)
+        } else {
+            const float4* L = reinterpret_cast<const float4*>(lights + index);
+            const float4 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3], q4 = L[4], q5 = L[5], q6 = L[6];
+            const uint32_t type = __float_as_uint(q0.x), shadowType = __float_as_uint(q0.y);
+            const float ndx = -q2.x, ndy = -q2.y, ndz = -q2.z;            // Li = -light.direction (:309)
+            const float len = sqrtf(dot3f(ndx, ndy, ndz, ndx, ndy, ndz)); // normalize(-light.direction) (:298)
+            const float linv = 1.0f / len;
+            // A zero factor only annihilates a FINITE product (inf * 0 = NaN in the reference): lights with a non-finite
+            // intensity are never skipped.
+            const bool finite = fabsf(q3.x) < __builtin_inff() && fabsf(q3.y) < __builtin_inff() && fabsf(q3.z) < __builtin_inff();
+            // Conservative "out of reach" threshold of a point light: d^2 > r^2 (1 + 1e-5) => fl(dist / r) >= 1 => the radius
+            // window (:290) is exactly 0.  Only for r > 0 (a negative radius clamps to the FULL window in the reference).
+            const float r = q6.x;
+            float a = __builtin_inff(), b = r;
+            if (type == 1u) { if (finite && r > 0.0f) a = (r * r) * 1.00001f; }
+            else { if (finite) a = -(q5.y - 1e-5f); b = q5.x - q5.y; }
+            const uint32_t bits = (type < 255u ? type : 255u) | ((shadowType < 255u ? shadowType : 255u) << 8) | (finite ? 0x10000u : 0u);
+            float4* o = sL + tid * LREC;
+            o[0] = make_float4(q1.x, q1.y, q1.z, a);
+            o[1] = make_float4(ndx * linv, ndy * linv, ndz * linv, __uint_as_float(bits));
+            o[2] = make_float4(q4.x, q4.y, q4.z, b);
+            o[3] = make_float4(ndx, ndy, ndz, q5.y);
+            o[4] = make_float4(q3.x, q3.y, q3.z, 0.0f);
+        }
+    }
+    __syncthreads();
+    const uint32_t numLights = sNum;
+
+    // ---- per-pixel invariants (Standard.shader:379-401) ----
+    const float wx = P0.x, wy = P0.y, wz = P0.z;
+    const v2f wxy = { wx, wy };
+    const float nx = P1.x, ny = P1.y, nz = P1.z, roughness = P1.w;
+    const float metallic = P2.w;
+    const float vx = wx - A.camX, vy = wy - A.camY, vz = wz - A.camZ;
+    const float vinv = 1.0f / sqrtf(dot3f(vx, vy, vz, vx, vy, vz));          // exact chain (see header)
+    const float Lox = -(vx * vinv), Loy = -(vy * vinv), Loz = -(vz * vinv);  // Lo = -viewDirection
+    const float cosLo = fmaxf(0.0f, dot3f(nx, ny, nz, Lox, Loy, Loz));
+    float accX = 0.0f, accY = 0.0f, accZ = 0.0f;
+    const float oneMinusMetal = 1.0f - metallic;
+    const float F0x = fmaf(P2.x, metallic, 0.04f * oneMinusMetal);
+    const float F0y = fmaf(P2.y, metallic, 0.04f * oneMinusMetal);
+    const float F0z = fmaf(P2.z, metallic, 0.04f * oneMinusMetal);
+    const float kdAx = oneMinusMetal * P2.x, kdAy = oneMinusMetal * P2.y, kdAz = oneMinusMetal * P2.z; // kd = (1 - F)(1 - metallic)
+    const float alpha = roughness * roughness, alphaSq = alpha * alpha;
+    const float rr = roughness + 1.0f, k = (rr * rr) * 0.125f, oneMinusK = 1.0f - k;
+    const float g1Lo = cosLo * rcp_fast(fmaf(cosLo, oneMinusK, k)); // GeometrySchlickG1(cosLo, k)
+    const bool brdfFinite = alphaSq > 0.0f;                       // roughness 0 makes NdfGGX 0/0 in the reference
+
+    // ---- which lights can reach this quadrant at all?  One LANE per LIGHT: sphere (centre, r sqrt(1 + 1e-4)) against the
+    // world-space bounding box of the quadrant's 64 surface points.  Two ballots cover the whole <= 128-entry list, and
+    // the per-pixel loop below then visits only the surviving lights.  (Conservative: a point light whose sphere misses
+    // the box has d^2 > r^2 (1 + 1e-5) for every pixel, i.e. an exact-zero radius window -- see rec0.w.)
+    int k0 = f2key(active ? wx : __builtin_inff()), k1 = f2key(active ? wy : __builtin_inff()), k2 = f2key(active ? wz : __builtin_inff());
+    int k3 = f2key(active ? wx : -__builtin_inff()), k4 = f2key(active ? wy : -__builtin_inff()), k5 = f2key(active ? wz : -__builtin_inff());
+    wave_minmax6(k0, k1, k2, k3, k4, k5);
+    const float bminx = key2f(__builtin_amdgcn_readlane(k0, 63)), bminy = key2f(__builtin_amdgcn_readlane(k1, 63)), bminz = key2f(__builtin_amdgcn_readlane(k2, 63));
+    const float bmaxx = key2f(__builtin_amdgcn_readlane(k3, 63)), bmaxy = key2f(__builtin_amdgcn_readlane(k4, 63)), bmaxz = key2f(__builtin_amdgcn_readlane(k5, 63));
+    const unsigned long long activeMask = __ballot(active);
+    const unsigned long long forceMask = __ballot(active && !brdfFinite); // such pixels must see every light (0 * NaN)
+    // survivors by kind: [0,1] finite point lights, [2,3] finite spot lights, [4,5] the rest (directional, unknown type,
+    // non-finite intensity: every pixel is a pair) -- for list slots 0..63 and 64..127
+    unsigned long long seg[8] = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull }; // [6,7]: directional lights (type 0), see the loop behind the queue
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if ((uint32_t)(h * 64) >= numLights) break;
+        const uint32_t li = (uint32_t)(h * 64 + lane);
+        bool keep = false;
+        uint32_t bits = 0x10000u;
+        if (li < numLights) {
+            const float4 c0 = sL[li * LREC + 0];
+            bits = __float_as_uint(sL[li * LREC + 1].w);
+            keep = true;
+            if ((bits & 0xFFu) == 1u && forceMask == 0ull) {
+                const float ex = fmaxf(fmaxf(bminx - c0.x, c0.x - bmaxx), 0.0f);
+                const float ey = fmaxf(fmaxf(bminy - c0.y, c0.y - bmaxy), 0.0f);
+                const float ez = fmaxf(fmaxf(bminz - c0.z, c0.z - bmaxz), 0.0f);
+                // c0.w = r^2 (1 + 1e-5) (+inf: never reject); another 1e-4 covers the rounding of this estimate
+                keep = !(fmaf(ex, ex, fmaf(ey, ey, ez * ez)) > c0.w * 1.0001f);
+            }
+        }
+        const bool fin = (bits & 0x10000u) != 0u;
+        const unsigned long long all = __ballot(keep);
+        seg[h] = __ballot(keep && fin && (bits & 0xFFu) == 1u);
+        seg[2 + h] = __ballot(keep && fin && (bits & 0xFFu) == 2u);
+        seg[6 + h] = __ballot(li < numLights && (bits & 0xFFu) == 0u);
+        seg[4 + h] = all & ~(seg[h] | seg[2 + h] | seg[6 + h]);
+    }
+
+    if (BAND && splitRole) { // this wave's share of the list: every fourth slot
+        const unsigned long long share = 0x1111111111111111ull << __builtin_amdgcn_readfirstlane(wave); // (scalar: the masks stay in SGPRs)
+#pragma unroll
+        for (int q = 0; q < 8; q++) seg[q] &= share;
+    }
+
+    // ---- 2 + 3. queue the (pixel, light) pairs that can be lit, then shade them one LANE per PAIR ----
+    // Window = up to QMAX queued pairs, at most PENDK per pixel; a light whose pairs do not fit ends the window (it is
+    // tested again in the next one -- rare: a quadrant of the 4K frame queues ~50 pairs).  A pair's result goes to slot
+    // [its ordinal among the pixel's queued pairs][pixel], which the pixel's own lane adds up afterwards: no atomics
+    // (ds_add_f32 is serialised per lane on this LDS: ~170 cycles per wave instruction, scripts/microbench/lds_ops.hip).
+    uint16_t* Q = sQ + wave * QMAX;
+    float* res = sRes + tid - lane; // this wave's [3 colours][PENDK][64 pixels] slots, 256 floats apart
+    for (;;) {
+        uint32_t cnt = 0u;      // queued pairs (wave-uniform)
+        uint32_t pc = 0u;       // this pixel's queued pairs
+        bool overflow = false;
+#pragma unroll
+        for (int kind = 0; kind < 3 && !overflow; kind++) {
+#pragma unroll
+            for (int h = 0; h < 2 && !overflow; h++) {
+                unsigned long long todo = seg[kind * 2 + h];
+                while (todo) {
+                    const int bit = __builtin_ctzll(todo);
+                    const uint32_t s = (uint32_t)(h * 64 + bit);
+                    unsigned long long m = activeMask; // "the rest": every pixel is a pair
+                    if (kind < 2) {
+                        const float4* R = sL + s * LREC;
+                        const float4 r0 = R[0];
+                        const v2f dxy = v2f{ r0.x, r0.y } - wxy;
+                        const float dz = r0.z - wz;
+                        const float d2 = fmaf(dxy.x, dxy.x, fmaf(dxy.y, dxy.y, dz * dz));
+                        float v = d2;
+                        if (kind == 1) {
+                            // spot: falloff is exactly 0 iff theta < cutOff.y (:303-306); theta ~ dot(d, axis) / |d| to a few ulp
+                            const float4 r1 = R[1];
+                            v = -(fmaf(dxy.x, r1.x, fmaf(dxy.y, r1.y, dz * r1.z)) * rsq_fast(d2));
+                        }
+                        const unsigned long long reach = __ballot(!(v > r0.w));
+                        m = 0ull;
+                        if (((reach | forceMask) & activeMask) != 0ull) {
+                            // ... and facing it?  cosLi = max(0, n . Li) = 0 zeroes both the specular G term and the final product.
+                            const float4 r3 = R[3];
+                            const unsigned long long facing = __ballot(dot3f(nx, ny, nz, r3.x, r3.y, r3.z) > 0.0f);
+                            m = ((reach & facing) | forceMask) & activeMask;
+                        }
+                    }
+                    if (m != 0ull) {
+                        const bool mine = __builtin_amdgcn_inverse_ballot_w64(m); // exec = m: no per-lane bit test
+                        if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || __ballot(mine && pc >= (uint32_t)PENDK) != 0ull) { overflow = true; break; }
+                        if (mine) {
+                            const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            Q[pos] = (uint16_t)((uint32_t)lane | (s << 6) | (pc << 13));
+                            pc++;
+                        }
+                        cnt += (uint32_t)__popcll(m);
+                    }
+                    todo &= todo - 1ull;
+                }
+                seg[kind * 2 + h] = todo; // what the next window still has to look at
+            }
+        }
+        if (cnt == 0u) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t base = 0u; base < cnt; base += 64u) {
+            // one LANE per PAIR.  The pixel's invariants are pulled from its lane's registers (ds_bpermute: the LDS crossbar,
+            // no LDS memory), the light record from LDS.  All 64 lanes execute the pulls (a disabled source lane returns 0).
+            const uint32_t e = Q[base + (uint32_t)lane];
+            const bool valid = base + (uint32_t)lane < cnt;
+            const int pa = (int)((e & 63u) << 2);
+            const uint32_t s = (e >> 6) & (uint32_t)(KEEP - 1);
+            const float4* R = sL + s * LREC;
+#define PULL(x) __int_as_float(__builtin_amdgcn_ds_bpermute(pa, __float_as_int(x)))
+            float falloff = 1.0f;
+            const float4 r3 = R[3];
+            const float pwx = PULL(wx), pwy = PULL(wy), pwz = PULL(wz);
+            if (valid) {
+                const float4 r0 = R[0], r1 = R[1];
+                const uint32_t type = __float_as_uint(r1.w) & 0xFFu;
+                if (type == 1u || type == 2u) {
+                    // exact falloff (the oracle's op order where it is ill-conditioned)
+                    const float4 r2 = R[2];
+                    const float dx = r0.x - pwx, dy = r0.y - pwy, dz = r0.z - pwz;
+                    const float d2 = dot3f(dx, dy, dz, dx, dy, dz);
+                    const float dist = sqrtf(d2);                                       // exact: feeds 1 - (dist / bounds.x)^2
+                    const float att = rcp_fast(fmaf(r2.z, d2, fmaf(r2.y, dist, r2.x))); // 1/(a.x + a.y d + a.z d^2) (:289,:300)
+                    const bool isPoint = type == 1u;
+                    // one IEEE division serves both types: point dist / bounds.x (:290), spot 1 / dist (normalize, :298)
+                    const float x = (isPoint ? dist : 1.0f) / (isPoint ? r2.w : dist);
+                    if (isPoint) {
+                        const float q = fminf(fmaxf(x, 0.0f), 1.0f);
+                        falloff = att * (1.0f - q * q);                                  // (:290)
+                    } else {
+                        const float theta = dot3f(dx * x, dy * x, dz * x, r1.x, r1.y, r1.z); // dot(normalize(pos - wp), normalize(-dir))
+                        const float cutY = r3.w;
+                        falloff = att * fminf(fmaxf((theta - cutY) / r2.w, 0.0f), 1.0f);     // (:301); exact: cancels at the cone edge
+                        if (theta < cutY) falloff = 0.0f;                                     // (:303-306)
+                    }
+                }
+            }
+            // (the pulls are spread out so that at most ten pulled values are live at a time: 64 VGPRs = 8 waves per SIMD)
+            float spec = 0.0f, x5 = 0.0f, scale = 0.0f;
+            {
+                const float pnx = PULL(nx), pny = PULL(ny), pnz = PULL(nz);
+                const float pLox = PULL(Lox), pLoy = PULL(Loy), pLoz = PULL(Loz);
+                const float pcosLo = PULL(cosLo), pg1Lo = PULL(g1Lo), palphaSq = PULL(alphaSq);
+                const float pkr = HAS_IBL ? PULL(roughness) : PULL(k); // the ambient term at the end needs the roughness itself: pull it, derive k
+                const float pk = HAS_IBL ? ((pkr + 1.0f) * (pkr + 1.0f)) * 0.125f : pkr;
+                if (valid) {
+                    // ---- Cook-Torrance (Standard.shader:309-340) ----
+                    const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
+                    float hx = Lix + pLox, hy = Liy + pLoy, hz = Liz + pLoz;
+                    const float hinv = 1.0f / sqrtf(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
+                    hx *= hinv; hy *= hinv; hz *= hinv;
+                    const float cosLi = fmaxf(0.0f, dot3f(pnx, pny, pnz, Lix, Liy, Liz));
+                    const float cosLh = fmaxf(0.0f, dot3f(pnx, pny, pnz, hx, hy, hz));
+                    const float x1 = 1.0f - fmaxf(0.0f, dot3f(hx, hy, hz, pLox, pLoy, pLoz));
+                    const float x2 = x1 * x1;
+                    x5 = x2 * x2 * x1;                                                        // pow(1 - cosTheta, 5)
+                    const float dn = (cosLh * cosLh) * (palphaSq - 1.0f) + 1.0f;                // exact: the cancelling denominator
+                    const float D = palphaSq * rcp_fast(3.14159265359f * dn * dn);              // NdfGGX
+                    const float G = cosLi * rcp_fast(fmaf(cosLi, 1.0f - pk, pk)) * pg1Lo;      // GeometrySchlickGGX
+                    spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * pcosLo));
+                    scale = cosLi * falloff; // (shadow = 1: only directional lights are shadowed, and they do not come through the queue)
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float pF0x = PULL(F0x), pF0y = PULL(F0y), pF0z = PULL(F0z);
+                const float pkdAx = PULL(kdAx), pkdAy = PULL(kdAy), pkdAz = PULL(kdAz);
+                if (valid) {
+                    const float Fx = fmaf(1.0f - pF0x, x5, pF0x), Fy = fmaf(1.0f - pF0y, x5, pF0y), Fz = fmaf(1.0f - pF0z, x5, pF0z);
+                    const float4 r4 = R[4];
+                    // shadow * ((kd*albedo + F*D*G/denom) * Lradiance * cosLi) * falloff ; kd = mix(1 - F, 0, metallic)
+                    float* o = res + ((e >> 13) * 256u + (e & 63u));
+                    o[0] = (fmaf(1.0f - Fx, pkdAx, Fx * spec) * r4.x) * scale;
+                    o[PENDK * 256] = (fmaf(1.0f - Fy, pkdAy, Fy * spec) * r4.y) * scale;
+                    o[2 * PENDK * 256] = (fmaf(1.0f - Fz, pkdAz, Fz * spec) * r4.z) * scale;
+                }
+            }
+#undef PULL
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // each pixel adds up the results of its own pairs, in the order they were queued
+#pragma unroll
+        for (uint32_t j = 0; j < (uint32_t)PENDK; j++) {
+            if (__ballot(pc > j) == 0ull) break;
+            if (pc > j) {
+                accX += res[j * 256u + lane];
+                accY += res[(PENDK + j) * 256u + lane];
+                accZ += res[(2 * PENDK + j) * 256u + lane];
+            }
+        }
+        if (!overflow) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // ---- directional lights (type 0): every pixel is a pair, so they are shaded one LANE per PIXEL from the pixel's own registers -- no
+    // queue, no pulls -- in list order, nothing skipped (cosLi = 0 and non-finite intensities take their natural course).  K3, their
+    // shadow factor (Standard.shader:266-283), is looked up here: a quadrant's pixels mostly share a cascade, so a wave rarely runs both
+    // the EVSM and the 16-tap PCF path.  (Measured at C4: lookups in the pair pass 0.523 ms, here 0.448 ms; as a pass of their own that
+    // leaves the factors for a 64-register shade kernel, 0.32 + 0.22 ms -- the lookups are bound by the scattered 16-byte texel reads of
+    // the 268 MB moments map, not by the registers around them.)
+    if ((seg[6] | seg[7]) != 0ull) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            unsigned long long todo = seg[6 + h];
+            while (todo) {
+                const int bit = __builtin_ctzll(todo);
+                const float4* R = sL + (uint32_t)(h * 64 + bit) * LREC;
+                const float4 r3 = R[3], r4 = R[4];
+                float shadow = 1.0f;
+                if (HAS_CSM)
+                    shadow = directional_shadow(A, C, (__float_as_uint(R[1].w) >> 8) & 0xFFu, -r3.x, -r3.y, -r3.z, nx, ny, nz, wx, wy, wz);
+                // ---- Cook-Torrance (Standard.shader:309-340), as in the pair pass ----
+                const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
+                float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;
+                const float hinv = 1.0f / sqrtf(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
+                hx *= hinv; hy *= hinv; hz *= hinv;
+                const float cosLi = fmaxf(0.0f, dot3f(nx, ny, nz, Lix, Liy, Liz));
+                const float cosLh = fmaxf(0.0f, dot3f(nx, ny, nz, hx, hy, hz));
+                const float x1 = 1.0f - fmaxf(0.0f, dot3f(hx, hy, hz, Lox, Loy, Loz));
+                const float x2 = x1 * x1, x5 = x2 * x2 * x1;
+                const float dn = (cosLh * cosLh) * (alphaSq - 1.0f) + 1.0f;
+                const float D = alphaSq * rcp_fast(3.14159265359f * dn * dn);
+                const float G = cosLi * rcp_fast(fmaf(cosLi, oneMinusK, k)) * g1Lo;
+                const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * cosLo));
+                const float scale = shadow * cosLi; // falloff = 1 (:287)
+                const float Fx = fmaf(1.0f - F0x, x5, F0x), Fy = fmaf(1.0f - F0y, x5, F0y), Fz = fmaf(1.0f - F0z, x5, F0z);
+                accX += (fmaf(1.0f - Fx, kdAx, Fx * spec) * r4.x) * scale;
+                accY += (fmaf(1.0f - Fy, kdAy, Fy * spec) * r4.y) * scale;
+                accZ += (fmaf(1.0f - Fz, kdAz, Fz * spec) * r4.z) * scale;
+                todo &= todo - 1ull;
+            }
+        }
+    }
+    if (BAND && splitRole) { // the four partial sums of each pixel: wave 0 + 1 + 2 + 3
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        res[lane] = accX; res[PENDK * 256 + lane] = accY; res[2 * PENDK * 256 + lane] = accZ;
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 1; w < 4; w++) {
+            accX += sRes[w * 64 + lane]; accY += sRes[PENDK * 256 + w * 64 + lane]; accZ += sRes[2 * PENDK * 256 + w * 64 + lane];
+        }
+    }
+    if (HAS_IBL) {
+        float ambX, ambY, ambZ;
+        // outColor.xyz = AmbientLighting(material, F0, Lr, normal, cosLo) (Standard.shader:425, :343-372); Lr = 2 cosLo n + viewDirection (:396)
+        const float Lrx = fmaf(2.0f * cosLo, nx, -Lox), Lry = fmaf(2.0f * cosLo, ny, -Loy), Lrz = fmaf(2.0f * cosLo, nz, -Loz);
+        // Evaluated LAST, when only the pixel's invariants and the three sums are live, and one texture at a time (scheduling
+        // barriers): the pair pass sits exactly at 64 VGPRs, and three more live values across it -- or sixteen float4 gathers
+        // in flight here -- push the kernel to ~100 VGPRs = half the occupancy (measured: 0.40 instead of 0.19 ms).
+        const float x1 = 1.0f - cosLo, x2 = x1 * x1, x5 = x2 * x2 * x1;                                               // :352 FresnelSchlick(F0, cosLo)
+        const float Fx = fmaf(1.0f - F0x, x5, F0x), Fy = fmaf(1.0f - F0y, x5, F0y), Fz = fmaf(1.0f - F0z, x5, F0z);
+        {
+            int face; float cs, ct;
+            cube_face_st(nx, ny, nz, face, cs, ct);
+            const float4 irr = cube_sample_level(I.irradiance, I.irrSize, 0, face, cs, ct);                           // :346
+            ambX = (1.0f - Fx) * kdAx * irr.x; ambY = (1.0f - Fy) * kdAy * irr.y; ambZ = (1.0f - Fz) * kdAz * irr.z;  // :358 kd albedo irradiance
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float2 dfg = lut_sample(I.brdfLut, I.lutW, I.lutH, cosLo, roughness);                                    // :365
+        const float sx = fmaf(F0x, dfg.x, dfg.y), sy = fmaf(F0y, dfg.x, dfg.y), sz = fmaf(F0z, dfg.x, dfg.y);         // :368 F0 A + B
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            int face; float cs, ct;
+            cube_face_st(Lrx, Lry, Lrz, face, cs, ct);
+            const float maxLod = (float)(I.envLevels - 1);
+            float lod = roughness * (float)I.envLevels;                                                               // :361-362
+            lod = lod < 0.0f ? 0.0f : (lod > maxLod ? maxLod : lod);
+            const float fl = floorf(lod), f = lod - fl;
+            const int l0 = (int)fl, l1 = min(l0 + 1, I.envLevels - 1);
+            const float4 a = cube_sample_level(I.env, I.envSize, l0, face, cs, ct);
+            ambX = fmaf(sx * (1.0f - f), a.x, ambX); ambY = fmaf(sy * (1.0f - f), a.y, ambY); ambZ = fmaf(sz * (1.0f - f), a.z, ambZ);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 b = cube_sample_level(I.env, I.envSize, l1, face, cs, ct);
+            ambX = fmaf(sx * f, b.x, ambX); ambY = fmaf(sy * f, b.y, ambY); ambZ = fmaf(sz * f, b.z, ambZ);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float ao = I.ao ? I.ao[pix] : 1.0f;                                                                     // :386
+        accX = fmaf(ambX, ao, accX); accY = fmaf(ambY, ao, accY); accZ = fmaf(ambZ, ao, accZ);                              // :371, :425 ambient + sum over lights
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (active) radiance[(size_t)(py - A.fbRow0) * A.W + gx] = make_float4(accX, accY, accZ, P0.w); // outColor.a = material.albedo.a (:438)
+}
+
