@@ -447,21 +447,6 @@ SAILOR_HIP_API int sailor_hip_mesh_cull_compact(SailorHipContext* ctx, const Sai
                                                 uint32_t numInstances, uint32_t firstInstanceIndex, SailorDrawIndexedIndirectData* dBatches,
                                                 uint32_t numBatches, void* dWorkspace, size_t workspaceBytes);
 
-/* Two frames in flight in ONE call (the reference keeps MaxFramesInQueue = 2, RHI/Renderer.h:34): the light cull of the NEXT frame and the shade of
- * THIS frame, recorded as five launches in which every cull stage runs together with a slice of the shade's tile rows (plus the short scan between
- * tile cull and pack on its own).  Results are exactly those of sailor_hip_light_cull(next...) and sailor_hip_shade_ex(this..., csm = NULL, ibl = NULL,
- * dTileOrder) called one after the other -- the same device code -- but the cull's latency-bound stages are hidden behind the shade's arithmetic:
- * two streams or two hipGraph branches do not overlap kernels on this GPU, blocks of one launch do.  The two frames must not share output buffers
- * (dNextGrid / dNextCulled / dNextWorkspace belong to the next frame, dGrid / dCulled -- and dTileOrder, which lives in THIS frame's cull workspace --
- * to this one); `band` applies to both.  Falls back to the two plain calls when the cull takes its brute-force path. */
-SAILOR_HIP_API int sailor_hip_frame_pipelined(SailorHipContext* ctx,
-                                              const SailorUboFrameData* nextFrame, const SailorLightCullPushConstants* pc, const SailorLightShaderData* dNextLights,
-                                              const float* dNextDepth, SailorLightsGrid* dNextGrid, uint32_t* dNextCulled, size_t culledCapacity,
-                                              void* dNextWorkspace, size_t workspaceBytes, uint32_t flags,
-                                              const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
-                                              const SailorLightShaderData* dLights, int32_t lightsNum, const SailorLightsGrid* dGrid, const uint32_t* dCulled,
-                                              float* dRadiance, const SailorBand* band, const uint32_t* dTileOrder);
-
 /* ---- RCCL exchange for split frames (only when the frame is split AND a consumer needs the global list) ----
  * `comm` is an ncclComm_t created by the host.  Collective 1: all-gather of one uint32 (band total) per rank.
  * Collective 2: all-gather of the padded band index segments (each rank contributes `segmentCapacity` uints). */

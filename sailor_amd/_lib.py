@@ -103,8 +103,6 @@ SIGNATURES = {
     "sailor_hip_light_cull_workspace_size": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band)]),
     "sailor_hip_light_cull": (C.c_int, [_P, C.POINTER(UboFrameData), C.POINTER(LightCullPushConstants), _P, _P, _P, _P, C.c_size_t,
                                         _P, C.c_size_t, C.POINTER(Band), C.c_uint32]),
-    "sailor_hip_frame_pipelined": (C.c_int, [_P, C.POINTER(UboFrameData), C.POINTER(LightCullPushConstants), _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, C.c_uint32,
-                                             C.POINTER(UboFrameData), _P, C.c_size_t, _P, C.c_int32, _P, _P, _P, C.POINTER(Band), _P]),
     "sailor_hip_linearize_depth": (C.c_int, [_P, C.POINTER(UboFrameData), _P, _P, C.c_int32, C.c_int32]),
     "sailor_hip_light_cull_diagnostics": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band), _P, C.POINTER(C.c_uint64)]),
     "sailor_hip_light_grid_rebase": (C.c_int, [_P, _P, C.c_int32, C.c_uint32]),

@@ -32,7 +32,6 @@
 //
 // No MFMA: sphere/plane tests and compaction, not a contraction.  Compiled with -ffp-contract=off.
 #include "common.h"
-#include "shade_body.h"
 #include <vector>
 
 #define BANDS_PER_GROUP 24   // group columns / rows handled per k1_band_masks wave (grid.y = ceil(bands / 24))
@@ -784,25 +783,10 @@ size_t sailor_hip_light_cull_workspace_size(int32_t width, int32_t height, int32
     return make_layout(width, height, lightsCapacity, *band).total;
 }
 
-// Everything one cull needs, worked out on the host: the validated geometry, the workspace carved into its arrays, the arguments of every stage.
-// sailor_hip_light_cull launches the stages one after the other; sailor_hip_frame_pipelined (end of this file) launches them with slices of the
-// previous frame's shade riding along.
-struct CullPlan {
-    CullLayout L;
-    PrepareArgs pa;
-    bool empty = false, brute = false, splitFrame = false;
-    int prepBlocks = 0, bmGridX = 0, bmGridY = 0;
-    float planeMargin = 1e-3f;
-    int N = 0;
-    float4* lightView; uint32_t* lightType; float4* tileInfo; float4* bandPlanes;
-    unsigned long long* masks; unsigned long long* dirWords;
-    uint32_t *tileNum, *tilePrefix, *tileList, *blockSums, *groupCount, *groupList, *classPrefix, *classSums, *tileOrder;
-    SailorLightsGrid* grid; uint32_t* culled; uint32_t capacity;
-};
-
-static int cull_plan(SailorHipContext* ctx, const SailorUboFrameData* frame, const SailorLightCullPushConstants* pc, const SailorLightShaderData* dLights,
-                     const float* dLinearDepth, SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity, void* dWorkspace,
-                     size_t workspaceBytes, const SailorBand* band, uint32_t flags, CullPlan& P)
+int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame, const SailorLightCullPushConstants* pc,
+                          const SailorLightShaderData* dLights, const float* dLinearDepth,
+                          SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity,
+                          void* dWorkspace, size_t workspaceBytes, const SailorBand* band, uint32_t flags)
 {
     if (!ctx || !frame || !pc || !dLinearDepth || !dLightsGrid || !dCulledLights || !dWorkspace) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     const int W = pc->viewportSize[0], H = pc->viewportSize[1], N = pc->lightsNum;
@@ -813,31 +797,31 @@ static int cull_plan(SailorHipContext* ctx, const SailorUboFrameData* frame, con
     SailorBand whole;
     if (!band) { sailor_hip_band_whole_frame(W, H, &whole); band = &whole; }
     if (!band_valid(W, H, band)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-    P.L = make_layout(W, H, N, *band);
-    const CullLayout& L = P.L;
+    const CullLayout L = make_layout(W, H, N, *band);
     if (pc->numTiles[0] != L.Tx || pc->numTiles[1] != L.Ty) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (workspaceBytes < L.total) return SAILOR_HIP_ERR_WORKSPACE_TOO_SMALL;
     if (culledCapacity < 1) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (((uintptr_t)dWorkspace & 255) != 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
 
+    hipStream_t s = ctx->stream;
     char* ws = (char*)dWorkspace;
-    P.lightView = (float4*)(ws + L.offLightView);
-    P.lightType = (uint32_t*)(ws + L.offLightType);
-    P.tileInfo = (float4*)(ws + L.offTileInfo);
-    P.bandPlanes = (float4*)(ws + L.offBandPlanes);
-    P.masks = (unsigned long long*)(ws + L.offMasks);
-    P.dirWords = (unsigned long long*)(ws + L.offDirWords);
-    P.tileNum = (uint32_t*)(ws + L.offTileNum);
-    P.tilePrefix = (uint32_t*)(ws + L.offTilePrefix);
-    P.tileList = (uint32_t*)(ws + L.offTileList);
-    P.blockSums = (uint32_t*)(ws + L.offBlockSums);
-    P.groupCount = (uint32_t*)(ws + L.offGroupCount);
-    P.groupList = (uint32_t*)(ws + L.offGroupList);
-    P.grid = dLightsGrid; P.culled = dCulledLights;
-    P.capacity = (uint32_t)(culledCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : culledCapacity);
-    P.N = N;
-    P.empty = L.bandTiles == 0;
-    if (P.empty) return SAILOR_HIP_OK;
+    float4* lightView = (float4*)(ws + L.offLightView);
+    uint32_t* lightType = (uint32_t*)(ws + L.offLightType);
+    float4* tileInfo = (float4*)(ws + L.offTileInfo);
+    float4* bandPlanes = (float4*)(ws + L.offBandPlanes);
+    unsigned long long* masks = (unsigned long long*)(ws + L.offMasks);
+    unsigned long long* dirWords = (unsigned long long*)(ws + L.offDirWords);
+    uint32_t* tileNum = (uint32_t*)(ws + L.offTileNum);
+    uint32_t* tilePrefix = (uint32_t*)(ws + L.offTilePrefix);
+    uint32_t* tileList = (uint32_t*)(ws + L.offTileList);
+    uint32_t* blockSums = (uint32_t*)(ws + L.offBlockSums);
+    uint32_t* groupCount = (uint32_t*)(ws + L.offGroupCount);
+    uint32_t* groupList = (uint32_t*)(ws + L.offGroupList);
+
+    if (L.bandTiles == 0) {
+        SAILOR_TRY_HIP(ctx, hipMemsetAsync(dCulledLights, 0, 4, s));
+        return SAILOR_HIP_OK;
+    }
 
     Mat4 view, invProj;
     memcpy(view.m, frame->view, 64);
@@ -846,15 +830,15 @@ static int cull_plan(SailorHipContext* ctx, const SailorUboFrameData* frame, con
     // The side-plane margin argument needs a sane perspective; tiny light counts are cheaper brute force.
     const float p00 = fabsf(frame->projection[0]), p11 = fabsf(frame->projection[5]);
     const bool sane = p00 > 1e-2f && p11 > 1e-2f && p00 < 1e4f && p11 < 1e4f;
-    P.brute = (flags & SAILOR_CULL_BRUTE_FORCE) || !sane || N < 512;
+    const bool brute = (flags & SAILOR_CULL_BRUTE_FORCE) || !sane || N < 512;
 
     const int lightBlocks = (N + 255) / 256;
-    const int bandBlocks = P.brute ? 0 : (L.numBands + 255) / 256;
+    const int bandBlocks = brute ? 0 : (L.numBands + 255) / 256;
     const int stripsPerRow = (L.Tx + 15) / 16;
-    PrepareArgs& pa = P.pa;
+    PrepareArgs pa;
     pa.view = view; pa.invProj = invProj;
     pa.lights = dLights; pa.depth = dLinearDepth;
-    pa.lightView = P.lightView; pa.lightType = P.lightType; pa.tileInfo = P.tileInfo; pa.bandPlanes = P.bandPlanes;
+    pa.lightView = lightView; pa.lightType = lightType; pa.tileInfo = tileInfo; pa.bandPlanes = bandPlanes;
     pa.N = N; pa.lightBlocks = lightBlocks; pa.setupBlocks = stripsPerRow * L.bandRows;
     pa.vpW = frame->viewportSize[0]; pa.vpH = frame->viewportSize[1]; pa.W = W; pa.H = H; pa.Tx = L.Tx; pa.Ty = L.Ty;
     pa.tileRow0 = band->tileRowBegin; pa.bandRow0 = band->fbRowBegin; pa.bandRows = L.bandRows; pa.groupsX = L.groupsX; pa.numBands = L.numBands;
@@ -862,53 +846,36 @@ static int cull_plan(SailorHipContext* ctx, const SailorUboFrameData* frame, con
     pa.vecOK = (((uintptr_t)dLinearDepth & 15) == 0 && (W & 3) == 0) ? 1 : 0;
     pa.rawDepth = (flags & SAILOR_CULL_RAW_DEPTH) ? 1 : 0;
     pa.zNearCam = frame->cameraZNearZFar[0];
-    P.prepBlocks = pa.setupBlocks + lightBlocks + bandBlocks;
-    P.bmGridX = (L.words + 3) / 4;
-    P.bmGridY = (L.numBands + BANDS_PER_GROUP - 1) / BANDS_PER_GROUP;
+    hipLaunchKernelGGL(k01_prepare, dim3(pa.setupBlocks + lightBlocks + bandBlocks), dim3(256), 0, s, pa);
+    SAILOR_CHECK_LAUNCH(ctx, "k01_prepare");
+
+    if (brute) {
+        hipLaunchKernelGGL(k1_tile_cull<true>, dim3(L.numGroups * 4), dim3(256), 0, s, lightView, lightType, N, L.words, tileInfo, L.Tx, L.bandRows, masks,
+                           groupCount, groupList, L.groupsX, tileNum, tileList);
+        SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull<brute>");
+    } else {
+        const float planeMargin = 1e-3f;
+        const int groups = (L.numBands + BANDS_PER_GROUP - 1) / BANDS_PER_GROUP;
+        hipLaunchKernelGGL(k1_band_masks, dim3((L.words + 3) / 4, groups), dim3(256), 0, s, lightView, lightType, N, L.words, bandPlanes, L.numBands,
+                           planeMargin, masks, dirWords);
+        SAILOR_CHECK_LAUNCH(ctx, "k1_band_masks");
+        hipLaunchKernelGGL(k1_group_lists, dim3(L.numGroups), dim3(256), 0, s, masks, dirWords, L.words, L.Tx, L.bandRows, L.groupsX, groupCount, groupList);
+        SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
+        hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.numGroups * 4), dim3(256), 0, s, lightView, lightType, N, L.words, tileInfo, L.Tx, L.bandRows, masks,
+                           groupCount, groupList, L.groupsX, tileNum, tileList);
+        SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
+    }
     // The order hint pays for itself on split frames (a band's shade launch is bounded by its longest tile; starting those first took
     // 14 us off the slowest band of an 8-way split); on the whole frame it only costs (the scan grows by 5 us, the shade does not
     // get faster: 16 rounds of blocks hide the tail), so it is not produced there.
-    P.splitFrame = L.bandRows < L.Ty;
-    P.classPrefix = P.splitFrame ? (uint32_t*)(ws + L.offClassPrefix) : nullptr;
-    P.classSums = (uint32_t*)(ws + L.offClassSums);
-    P.tileOrder = (uint32_t*)(ws + L.offTileOrder);
-    return SAILOR_HIP_OK;
-}
-
-int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame, const SailorLightCullPushConstants* pc,
-                          const SailorLightShaderData* dLights, const float* dLinearDepth,
-                          SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity,
-                          void* dWorkspace, size_t workspaceBytes, const SailorBand* band, uint32_t flags)
-{
-    CullPlan P;
-    const int rc = cull_plan(ctx, frame, pc, dLights, dLinearDepth, dLightsGrid, dCulledLights, culledCapacity, dWorkspace, workspaceBytes, band, flags, P);
-    if (rc != SAILOR_HIP_OK) return rc;
-    hipStream_t s = ctx->stream;
-    const CullLayout& L = P.L;
-    if (P.empty) {
-        SAILOR_TRY_HIP(ctx, hipMemsetAsync(dCulledLights, 0, 4, s));
-        return SAILOR_HIP_OK;
-    }
-    hipLaunchKernelGGL(k01_prepare, dim3(P.prepBlocks), dim3(256), 0, s, P.pa);
-    SAILOR_CHECK_LAUNCH(ctx, "k01_prepare");
-    if (P.brute) {
-        hipLaunchKernelGGL(k1_tile_cull<true>, dim3(L.numGroups * 4), dim3(256), 0, s, P.lightView, P.lightType, P.N, L.words, P.tileInfo, L.Tx, L.bandRows, P.masks,
-                           P.groupCount, P.groupList, L.groupsX, P.tileNum, P.tileList);
-        SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull<brute>");
-    } else {
-        hipLaunchKernelGGL(k1_band_masks, dim3(P.bmGridX, P.bmGridY), dim3(256), 0, s, P.lightView, P.lightType, P.N, L.words, P.bandPlanes, L.numBands,
-                           P.planeMargin, P.masks, P.dirWords);
-        SAILOR_CHECK_LAUNCH(ctx, "k1_band_masks");
-        hipLaunchKernelGGL(k1_group_lists, dim3(L.numGroups), dim3(256), 0, s, P.masks, P.dirWords, L.words, L.Tx, L.bandRows, L.groupsX, P.groupCount, P.groupList);
-        SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
-        hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.numGroups * 4), dim3(256), 0, s, P.lightView, P.lightType, P.N, L.words, P.tileInfo, L.Tx, L.bandRows, P.masks,
-                           P.groupCount, P.groupList, L.groupsX, P.tileNum, P.tileList);
-        SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
-    }
-    hipLaunchKernelGGL(k1_block_sums, dim3(L.sumBlocks), dim3(SCAN_BLOCK), 0, s, P.tileNum, L.bandTiles, P.tilePrefix, P.blockSums, P.classPrefix, P.classSums);
+    const bool splitFrame = L.bandRows < L.Ty;
+    uint32_t* classPrefix = splitFrame ? (uint32_t*)(ws + L.offClassPrefix) : nullptr;
+    uint32_t* classSums = (uint32_t*)(ws + L.offClassSums);
+    uint32_t* tileOrder = (uint32_t*)(ws + L.offTileOrder);
+    hipLaunchKernelGGL(k1_block_sums, dim3(L.sumBlocks), dim3(SCAN_BLOCK), 0, s, tileNum, L.bandTiles, tilePrefix, blockSums, classPrefix, classSums);
     SAILOR_CHECK_LAUNCH(ctx, "k1_block_sums");
-    hipLaunchKernelGGL(k1_pack, dim3((L.bandTiles + 3) / 4), dim3(256), 0, s, P.tileNum, P.tilePrefix, P.blockSums, L.sumBlocks, P.tileList, L.bandTiles, P.grid,
-                       P.culled, P.capacity, P.classPrefix, P.classSums, L.Tx, P.tileOrder);
+    hipLaunchKernelGGL(k1_pack, dim3((L.bandTiles + 3) / 4), dim3(256), 0, s, tileNum, tilePrefix, blockSums, L.sumBlocks, tileList, L.bandTiles, dLightsGrid,
+                       dCulledLights, (uint32_t)(culledCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : culledCapacity), classPrefix, classSums, L.Tx, tileOrder);
     SAILOR_CHECK_LAUNCH(ctx, "k1_pack");
     return SAILOR_HIP_OK;
 }
@@ -1003,150 +970,3 @@ int sailor_hip_light_grid_rebase(SailorHipContext* ctx, SailorLightsGrid* dLight
 }
 
 } // extern "C"
-
-// ------------------------------------------------------------------------------------------------------------
-// Frame pipeline: the cull of frame k+1 hidden behind the shade of frame k.
-// ------------------------------------------------------------------------------------------------------------
-// The reference keeps two frames in flight (RHI/Renderer.h:34).  On this GPU two streams -- or two branches of a hipGraph -- do not overlap
-// kernels in practice (400 tiny kernels on two graph branches take three times as long as 200 on one), and inside ONE launch a dependent
-// pipeline would need every stage's output written back across the eight XCD L2s per block.  What does overlap is independent work inside one
-// launch: so every cull stage of frame k+1 is launched together with a SLICE of frame k's shade -- cull blocks first in the grid, the slice's
-// tiles behind them.  The stage boundaries of the cull stay kernel boundaries; the cull's latency-bound blocks run in the shadow of the shade's
-// issue-bound ones.  Slices are sized by the stages' stand-alone durations.  On a band of a split frame the long tiles' split blocks
-// (shade_body.h) ride with the tile-cull stage, the longest one there.
-struct FusedStageArgs {
-    PrepareArgs pa;
-    const float4* lightView; const uint32_t* lightType; const float4* tileInfo; const float4* bandPlanes;
-    unsigned long long* masks; unsigned long long* dirWords;
-    uint32_t *tileNum, *tilePrefix, *tileList, *blockSums, *groupCount, *groupList, *classPrefix, *classSums, *tileOrder;
-    SailorLightsGrid* grid; uint32_t* culled; uint32_t capacity;
-    int N, words, numBands, Tx, bandRows, groupsX, sumBlocks, bandTiles, bmGridX;
-    float planeMargin;
-    unsigned cullBlocks, cullRows; // blocks of this launch's cull stage; grid rows (of Tx blocks) they occupy in front of the shade slice
-};
-
-struct FusedShadeArgs {
-    ShadeArgs A;
-    const float4* surface; size_t planeStride; const SailorLightShaderData* lights; const SailorLightsGrid* grid; const uint32_t* culled; float4* radiance;
-    int sliceRow0, sliceRows;  // tile rows of the band shaded by this launch
-    int splitRows;             // > 0: grid rows (behind the slice) whose blocks walk the band's long tiles as split blocks; needs A.order
-    int bandTiles;
-};
-
-template <int STAGE, bool BANDED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_frame_stage(FusedStageArgs c, FusedShadeArgs h)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char lds[sizeof(ShadeLds) > LDS_K1_TILE_CULL ? sizeof(ShadeLds) : LDS_K1_TILE_CULL];
-    const unsigned row = blockIdx.y;
-    if (row < c.cullRows) { // ---- a block of the next frame's cull stage ----
-        const unsigned b = row * gridDim.x + blockIdx.x;
-        if (b >= c.cullBlocks) return;
-        if (STAGE == 0) k01_prepare_body((int)b, lds, c.pa);
-        if (STAGE == 1) k1_band_masks_body(b % (unsigned)c.bmGridX, b / (unsigned)c.bmGridX, lds, c.lightView, c.lightType, c.N, c.words, c.bandPlanes, c.numBands,
-                                           c.planeMargin, c.masks, c.dirWords);
-        if (STAGE == 2) k1_group_lists_body(b, lds, c.masks, c.dirWords, c.words, c.Tx, c.bandRows, c.groupsX, c.groupCount, c.groupList);
-        if (STAGE == 3) k1_tile_cull_body<false>(b, lds, c.lightView, c.lightType, c.N, c.words, c.tileInfo, c.Tx, c.bandRows, c.masks, c.groupCount, c.groupList,
-                                                 c.groupsX, c.tileNum, c.tileList);
-        if (STAGE == 4) k1_pack_body(b, c.tileNum, c.tilePrefix, c.blockSums, c.sumBlocks, c.tileList, c.bandTiles, c.grid, c.culled, c.capacity, c.classPrefix,
-                                     c.classSums, c.Tx, c.tileOrder);
-        return;
-    }
-    // ---- a tile of this frame's shade slice ----
-    ShadeLds& sl = *reinterpret_cast<ShadeLds*>(lds);
-    const unsigned srow = row - c.cullRows;
-    const CsmArgs noCsm {};
-    if (srow < (unsigned)h.sliceRows) {
-        if ((int)blockIdx.x >= h.A.Tx) return;
-        k2_shade_body<false, false, BANDED ? ROLE_BAND_TILE : ROLE_SLICE>(sl, h.A, noCsm, IblArgs(), h.surface, h.planeStride, h.lights, h.grid, h.culled, h.radiance,
-                                                                          (int)blockIdx.x, h.sliceRow0 + (int)srow, 0);
-        return;
-    }
-    if (BANDED && STAGE == 3) { // the band's long tiles, one block per (tile, quadrant), walked with a grid stride
-        const uint32_t first = (srow - (unsigned)h.sliceRows) * gridDim.x + blockIdx.x, stride = (unsigned)h.splitRows * gridDim.x;
-        const uint32_t limit = 4u * h.A.order[h.bandTiles];
-        for (uint32_t idx = first; idx < limit; idx += stride) {
-            const uint32_t o = h.A.order[idx >> 2];
-            k2_shade_body<false, false, ROLE_BAND_SPLIT>(sl, h.A, noCsm, IblArgs(), h.surface, h.planeStride, h.lights, h.grid, h.culled, h.radiance, (int)(o & 0xFFFFu),
-                                                         (int)(o >> 16), (int)(idx & 3u));
-            __syncthreads();
-        }
-    }
-}
-
-extern "C" int sailor_hip_frame_pipelined(SailorHipContext* ctx,
-                                          /* cull of the NEXT frame: exactly the arguments of sailor_hip_light_cull */
-                                          const SailorUboFrameData* nextFrame, const SailorLightCullPushConstants* pc, const SailorLightShaderData* dNextLights,
-                                          const float* dNextDepth, SailorLightsGrid* dNextGrid, uint32_t* dNextCulled, size_t culledCapacity, void* dNextWorkspace,
-                                          size_t workspaceBytes, uint32_t flags,
-                                          /* shade of THIS frame: the arguments of sailor_hip_shade_ex (no shadow maps, no ambient term) */
-                                          const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride, const SailorLightShaderData* dLights,
-                                          int32_t lightsNum, const SailorLightsGrid* dGrid, const uint32_t* dCulled, float* dRadiance, const SailorBand* band,
-                                          const uint32_t* dTileOrder)
-{
-    CullPlan P;
-    int rc = cull_plan(ctx, nextFrame, pc, dNextLights, dNextDepth, dNextGrid, dNextCulled, culledCapacity, dNextWorkspace, workspaceBytes, band, flags, P);
-    if (rc != SAILOR_HIP_OK) return rc;
-    if (!frame || !dSurface || !dGrid || !dCulled || !dRadiance || lightsNum < 0 || (lightsNum > 0 && !dLights)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-    if (frame->viewportSize[0] != pc->viewportSize[0] || frame->viewportSize[1] != pc->viewportSize[1]) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-    SailorBand whole;
-    if (!band) { sailor_hip_band_whole_frame(pc->viewportSize[0], pc->viewportSize[1], &whole); band = &whole; }
-    if (P.empty || P.brute) { // nothing to overlap / the brute-force walk has no stages: one after the other
-        rc = sailor_hip_light_cull(ctx, nextFrame, pc, dNextLights, dNextDepth, dNextGrid, dNextCulled, culledCapacity, dNextWorkspace, workspaceBytes, band, flags);
-        if (rc != SAILOR_HIP_OK) return rc;
-        return sailor_hip_shade_ex(ctx, frame, dSurface, surfacePlaneStride, dLights, lightsNum, dGrid, dCulled, nullptr, nullptr, dRadiance, band, dTileOrder);
-    }
-    if (surfacePlaneStride < (size_t)band->fbRowCount * frame->viewportSize[0]) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-    if (((uintptr_t)dSurface & 15) || ((uintptr_t)dRadiance & 15) || ((uintptr_t)dLights & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-    const CullLayout& L = P.L;
-    hipStream_t s = ctx->stream;
-
-    FusedStageArgs c;
-    c.pa = P.pa;
-    c.lightView = P.lightView; c.lightType = P.lightType; c.tileInfo = P.tileInfo; c.bandPlanes = P.bandPlanes; c.masks = P.masks; c.dirWords = P.dirWords;
-    c.tileNum = P.tileNum; c.tilePrefix = P.tilePrefix; c.tileList = P.tileList; c.blockSums = P.blockSums; c.groupCount = P.groupCount; c.groupList = P.groupList;
-    c.classPrefix = P.classPrefix; c.classSums = P.classSums; c.tileOrder = P.tileOrder; c.grid = P.grid; c.culled = P.culled; c.capacity = P.capacity;
-    c.N = P.N; c.words = L.words; c.numBands = L.numBands; c.Tx = L.Tx; c.bandRows = L.bandRows; c.groupsX = L.groupsX; c.sumBlocks = L.sumBlocks;
-    c.bandTiles = L.bandTiles; c.bmGridX = P.bmGridX; c.planeMargin = P.planeMargin;
-    const unsigned stageBlocks[5] = { (unsigned)P.prepBlocks, (unsigned)(P.bmGridX * P.bmGridY), (unsigned)L.numGroups, (unsigned)(L.numGroups * 4),
-                                      (unsigned)((L.bandTiles + 3) / 4) };
-
-    FusedShadeArgs h;
-    shade_args_fill(frame, band, lightsNum, dTileOrder, h.A);
-    h.surface = (const float4*)dSurface; h.planeStride = surfacePlaneStride; h.lights = dLights; h.grid = dGrid; h.culled = dCulled; h.radiance = (float4*)dRadiance;
-    h.bandTiles = L.bandTiles;
-    const bool banded = dTileOrder != nullptr && P.splitFrame; // long tiles go to split blocks (they ride with the tile-cull stage)
-
-    // tile rows per stage, by the stages' stand-alone durations at 4K / 65 536 lights (profiles/r01: 10.5, 6.9, 8.1, 33.2, 8.5 us)
-    const int weights[5] = { 16, 10, 12, 49, 13 };
-    int rows[5], given = 0;
-    for (int i = 0; i < 5; i++) { rows[i] = L.bandRows * weights[i] / 100; given += rows[i]; }
-    rows[3] += L.bandRows - given;
-    int row0 = 0;
-    for (int stage = 0; stage < 5; stage++) {
-        if (stage == 4) { // the scan between the tile cull and the pack has 1 024-thread blocks: on its own
-            hipLaunchKernelGGL(k1_block_sums, dim3(L.sumBlocks), dim3(SCAN_BLOCK), 0, s, P.tileNum, L.bandTiles, P.tilePrefix, P.blockSums, P.classPrefix, P.classSums);
-            SAILOR_CHECK_LAUNCH(ctx, "k1_block_sums");
-        }
-        c.cullBlocks = stageBlocks[stage];
-        c.cullRows = (c.cullBlocks + (unsigned)L.Tx - 1) / (unsigned)L.Tx;
-        h.sliceRow0 = row0; h.sliceRows = rows[stage];
-        h.splitRows = (banded && stage == 3) ? (SPLIT_BLOCKS + L.Tx - 1) / L.Tx : 0;
-        row0 += rows[stage];
-        const dim3 grid((unsigned)L.Tx, c.cullRows + (unsigned)h.sliceRows + (unsigned)h.splitRows);
-#define LAUNCH_STAGE(ST)                                                                                          \
-    do {                                                                                                          \
-        if (banded) hipLaunchKernelGGL((k_frame_stage<ST, true>), grid, dim3(256), 0, s, c, h);                   \
-        else hipLaunchKernelGGL((k_frame_stage<ST, false>), grid, dim3(256), 0, s, c, h);                         \
-    } while (0)
-        switch (stage) {
-        case 0: LAUNCH_STAGE(0); break;
-        case 1: LAUNCH_STAGE(1); break;
-        case 2: LAUNCH_STAGE(2); break;
-        case 3: LAUNCH_STAGE(3); break;
-        default: LAUNCH_STAGE(4); break;
-        }
-#undef LAUNCH_STAGE
-        SAILOR_CHECK_LAUNCH(ctx, "k_frame_stage");
-    }
-    return SAILOR_HIP_OK;
-}

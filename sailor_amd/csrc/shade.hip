@@ -124,7 +124,17 @@ extern "C" int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFrameDa
     if (((uintptr_t)dSurface & 15) || ((uintptr_t)dRadiance & 15) || ((uintptr_t)dLights & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
 
     ShadeArgs A;
-    shade_args_fill(frame, band, lightsNum, dTileOrder, A);
+    memcpy(A.view.m, frame->view, 64);
+    A.camX = frame->cameraPosition[0]; A.camY = frame->cameraPosition[1]; A.camZ = frame->cameraPosition[2];
+    A.zFar = frame->cameraZNearZFar[1];
+    A.vpW = W; A.vpH = H; A.W = W; A.H = H;
+    // Standard.shader:413-420: numTiles.x + padding.x == LightCullingNode's numTiles.x
+    A.Tx = W / TILE + ((W % TILE) ? 1 : 0);
+    A.tileRow0 = band->tileRowBegin;
+    A.fbRow0 = band->fbRowBegin;
+    A.fbRows = band->fbRowCount;
+    A.lightsNum = lightsNum;
+    A.order = dTileOrder;
     const int bandTiles = (band->tileRowEnd - band->tileRowBegin) * A.Tx;
     if (bandTiles == 0) return SAILOR_HIP_OK;
 

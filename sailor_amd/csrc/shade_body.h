@@ -84,7 +84,7 @@ __device__ __forceinline__ float canonical_expf(float x)
     return ldexpf(y, (int)n);
 }
 
-static __constant__ float kPoissonDisk[16][2] = { // Lighting.glsl:176-185
+__constant__ float kPoissonDisk[16][2] = { // Lighting.glsl:176-185
     { -0.94201624f, -0.39906216f }, { 0.94558609f, -0.76890725f }, { -0.094184101f, -0.92938870f }, { 0.34495938f, 0.29387760f },
     { -0.91588581f, 0.45771432f }, { -0.81544232f, -0.87912464f }, { -0.38277543f, 0.27676845f }, { 0.97484398f, 0.75648379f },
     { 0.44323325f, -0.97511554f }, { 0.53742981f, -0.47373420f }, { -0.26496911f, -0.41893023f }, { 0.79197514f, 0.19090188f },
@@ -237,7 +237,6 @@ struct ShadeLds {
 #define ROLE_TILE 0       // one block per tile, grid (tiles per row, tile rows)
 #define ROLE_BAND_TILE 1  // the same inside k2_shade_band: returns at once on a tile of the split blocks
 #define ROLE_BAND_SPLIT 2 // one block per (long tile, quadrant)
-#define ROLE_SLICE 3      // ROLE_TILE with the tile given by the caller (a slice of the band's tile rows inside a fused launch)
 template <bool HAS_CSM, bool HAS_IBL, int ROLE = ROLE_TILE>
 __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, const IblArgs& I, const float4* __restrict__ surface, size_t planeStride,
                                                  const SailorLightShaderData* __restrict__ lights,
@@ -248,7 +247,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     float* const sRes = lds.sRes;
     uint16_t* const sQ = lds.sQ;
     uint32_t& sNum = lds.sNum;
-    constexpr bool BAND = ROLE == ROLE_BAND_TILE || ROLE == ROLE_BAND_SPLIT;
+    constexpr bool BAND = ROLE != ROLE_TILE;
     constexpr bool splitRole = ROLE == ROLE_BAND_SPLIT;
     int tid = threadIdx.x;
     // (a split block walks several tiles: keep everything derived from the lane id inside the loop body -- hoisted out of the
@@ -259,7 +258,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     int btx = blockIdx.x, bty = blockIdx.y;
     const int lane = tid & 63, wave = tid >> 6;
     int quad = wave;
-    if (BAND || ROLE == ROLE_SLICE) { btx = selTx; bty = selTy; if (splitRole) quad = selQuad; }
+    if (BAND) { btx = selTx; bty = selTy; if (splitRole) quad = selQuad; }
     else if (A.order) { const uint32_t o = A.order[blockIdx.y * A.Tx + blockIdx.x]; btx = (int)(o & 0xFFFFu); bty = (int)(o >> 16); }
     const int tx = btx, ty = A.tileRow0 + bty;
     const int bandTile = bty * A.Tx + btx;
@@ -621,18 +620,3 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     if (active) radiance[(size_t)(py - A.fbRow0) * A.W + gx] = make_float4(accX, accY, accZ, P0.w); // outColor.a = material.albedo.a (:438)
 }
 
-// host: the per-launch constants of a shade (shared by sailor_hip_shade_ex and sailor_hip_frame_pipelined)
-static inline void shade_args_fill(const SailorUboFrameData* frame, const SailorBand* band, int32_t lightsNum, const uint32_t* order, ShadeArgs& A)
-{
-    const int W = frame->viewportSize[0], H = frame->viewportSize[1];
-    memcpy(A.view.m, frame->view, 64);
-    A.camX = frame->cameraPosition[0]; A.camY = frame->cameraPosition[1]; A.camZ = frame->cameraPosition[2];
-    A.zFar = frame->cameraZNearZFar[1];
-    A.vpW = W; A.vpH = H; A.W = W; A.H = H;
-    A.Tx = W / TILE + ((W % TILE) ? 1 : 0); // Standard.shader:413-420: numTiles.x + padding.x == LightCullingNode's numTiles.x
-    A.tileRow0 = band->tileRowBegin;
-    A.fbRow0 = band->fbRowBegin;
-    A.fbRows = band->fbRowCount;
-    A.lightsNum = lightsNum;
-    A.order = order;
-}

@@ -127,30 +127,6 @@ class ForwardPlus:
                    "sailor_hip_shade", self.ctx.handle)
         return out
 
-    # -- two frames in flight ------------------------------------------------------------------------------------------
-    def shade_while_culling(self, nxt: "ForwardPlus", next_frame: UboFrameData, next_lights: torch.Tensor, next_lights_num: int, next_depth: torch.Tensor,
-                            frame: UboFrameData, surface: torch.Tensor, lights: torch.Tensor, lights_num: int, flags: int = _lib.CULL_DEFAULT,
-                            out: torch.Tensor | None = None) -> torch.Tensor:
-        """sailor_hip_frame_pipelined: shade THIS object's lists (frame k) while `nxt` -- a second ForwardPlus of the same geometry, with its own list
-        buffers and workspace -- culls frame k+1.  Same results as nxt.cull(...) followed by self.shade(...)."""
-        rows = self.band.fbRowCount
-        assert nxt is not self and (nxt.W, nxt.H) == (self.W, self.H) and nxt.band.tileRowBegin == self.band.tileRowBegin and nxt.band.tileRowEnd == self.band.tileRowEnd
-        assert surface.dtype == torch.float32 and surface.is_contiguous() and surface.shape == (3, rows, self.W, 4), surface.shape
-        assert next_depth.dtype == torch.float32 and next_depth.is_contiguous() and next_depth.shape == (rows, self.W)
-        if out is None:
-            if self.radiance is None:
-                self.radiance = torch.empty((rows, self.W, 4), dtype=torch.float32, device=self.ctx.device)
-            out = self.radiance
-        pc = host.push_constants(next_frame, self.W, self.H, next_lights_num)
-        order = self.tile_order if (self.use_tile_order and self._culled_once) else None
-        _lib.check(self.ctx._lib.sailor_hip_frame_pipelined(self.ctx.handle, C.byref(next_frame), C.byref(pc), _ptr(next_lights), _ptr(next_depth), _ptr(nxt.grid),
-                                                            _ptr(nxt.culled), nxt.culled.numel(), _ptr(nxt.workspace), nxt.workspace.numel(), flags,
-                                                            C.byref(frame), _ptr(surface), rows * self.W, _ptr(lights), lights_num, _ptr(self.grid), _ptr(self.culled),
-                                                            _ptr(out), C.byref(self.band), order),
-                   "sailor_hip_frame_pipelined", self.ctx.handle)
-        nxt._culled_once = True
-        return out
-
     # -- helpers ----------------------------------------------------------------------------------------------------
     def cull_diagnostics(self, lights_num: int) -> dict:
         out = (C.c_uint64 * 8)()
