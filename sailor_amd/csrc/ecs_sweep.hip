@@ -322,6 +322,26 @@ __global__ __launch_bounds__(256) void k_hiz_downscale(const float* __restrict__
     dst[(size_t)y * dstW + x] = hiz_fetch_min(src, srcW, srcH, ((float)x + 0.5f) / (float)dstW, ((float)y + 0.5f) / (float)dstH);
 }
 
+// The tail of the pyramid in ONE launch: from a level of at most 64 x 64 texels down to 1 x 1, one 256-thread block, a barrier between levels
+// (the levels are a dependent chain of launches otherwise, ~3 us each for a handful of texels).  Same fetches, same values.
+__global__ __launch_bounds__(256) void k_hiz_tail(float* __restrict__ pyramid, int srcW, int srcH, size_t srcOffset, int levels)
+{
+    const float* src = pyramid + srcOffset;
+    float* dst = pyramid + srcOffset + (size_t)srcW * srcH;
+    int sw = srcW, sh = srcH;
+    for (int l = 0; l < levels; l++) {
+        const int w = max(sw >> 1, 1), h = max(sh >> 1, 1);
+        for (int i = threadIdx.x; i < w * h; i += 256) {
+            const int x = i % w, y = i / w;
+            dst[i] = hiz_fetch_min(src, sw, sh, ((float)x + 0.5f) / (float)w, ((float)y + 0.5f) / (float)h);
+        }
+        __threadfence_block();
+        __syncthreads();
+        src = dst; sw = w; sh = h;
+        dst += (size_t)w * h;
+    }
+}
+
 // Math.glsl:296-315 ProjectSphere, op for op as the oracle's project_sphere
 __device__ __forceinline__ bool msc_project_sphere(float Cx, float Cy, float Cz, float r, float znear, float P00, float P11, float* aabb)
 {
@@ -503,8 +523,15 @@ int sailor_hip_hiz_build(SailorHipContext* ctx, const float* dDepth, int32_t dep
     const float* src = dDepth;
     int sw = depthWidth, sh = depthHeight;
     float* dst = dPyramid;
+    if (!dDepth || !dPyramid) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     for (int l = 0; l < levels; l++) { // DepthHighZNode.cpp:78-95: mip 0 from the depth attachment, mip i + 1 from mip i
         const int w = (width >> l) > 1 ? (width >> l) : 1, h = (height >> l) > 1 ? (height >> l) : 1;
+        // mip sizes follow max(size >> level, 1), and (size >> l) >> 1 == size >> (l + 1): once a level fits one block, the rest is one launch
+        if (l > 0 && sw <= 64 && sh <= 64 && src != dDepth) {
+            hipLaunchKernelGGL(k_hiz_tail, dim3(1), dim3(256), 0, ctx->stream, dPyramid, sw, sh, (size_t)(src - dPyramid), levels - l);
+            SAILOR_CHECK_LAUNCH(ctx, "k_hiz_tail");
+            return SAILOR_HIP_OK;
+        }
         const int rc = sailor_hip_hiz_downscale(ctx, src, sw, sh, dst, w, h);
         if (rc != SAILOR_HIP_OK) return rc;
         src = dst; sw = w; sh = h;
