@@ -252,7 +252,22 @@ def ibl_prefilter_block(ctx, steps: int):
     t0 = time.perf_counter()
     oracle.compute_irradiance_map(small.env_chain, 64, small.env_levels, 2)
     t_irr = time.perf_counter() - t0
-    return {"env_prefilter_ms": pre_ms, "env_gsamples_per_s": env_samples / pre_ms / 1e6, "irradiance_ms": irr_ms,
+    # the raw cube in front of them (EnvironmentNode.cpp:116-138): a 2048 x 1024 RGBA32F panorama -> 512 x 512 x 6, then the 2:1 blit chain.
+    # Algorithmic bytes: the panorama read once + level 0 written (conversion); level 0 read + 1/3 of it written (mips).
+    from sailor_amd.forward_plus import raw_env_cubemap
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    pano = (torch.rand((1024, 2048, 4), generator=gen, dtype=torch.float32) * 4.0).to(ctx.device)
+    raw_env_cubemap(ctx, pano, 512, 10)
+    _, raw_ms, _, _ = event_ms(lambda: raw_env_cubemap(ctx, pano, 512, 10), steps)
+    chain_floats = sum(6 * max(512 >> l, 1) ** 2 * 4 for l in range(10))
+    zero_ms = event_ms(lambda: torch.zeros(chain_floats, dtype=torch.float32, device=ctx.device), steps)[1]  # the wrapper's allocation + clear, not the path's
+    raw_bytes = 2048 * 1024 * 16 + 2 * 6 * 512 * 512 * 16 + (6 * 512 * 512 * 16) // 3
+    t0 = time.perf_counter()
+    oracle.equirect_to_cube(pano.cpu().numpy(), 512)
+    t_raw = time.perf_counter() - t0
+    raw = {"raw_cube_ms": raw_ms - zero_ms, "raw_cube_gbs": raw_bytes / ((raw_ms - zero_ms) * 1e-3) / 1e9, "raw_cube_bytes": raw_bytes,
+           "cpu_1thread_equirect_mtexels_per_s": 6 * 512 * 512 / t_raw / 1e6, "gpu_equirect_plus_mips_mtexels_per_s": 6 * 512 * 512 / ((raw_ms - zero_ms) * 1e-3) / 1e6}
+    return {**raw, "env_prefilter_ms": pre_ms, "env_gsamples_per_s": env_samples / pre_ms / 1e6, "irradiance_ms": irr_ms,
             "irradiance_gsamples_per_s": irr_samples / irr_ms / 1e6, "env_samples": env_samples, "irradiance_samples": irr_samples,
             "cpu_1thread_env_msamples_per_s": 6 * 32 * 32 * 1024 / t_env / 1e6, "cpu_1thread_irradiance_msamples_per_s": 6 * 2 * 2 * 65536 / t_irr / 1e6,
             "kind": "port"}

@@ -313,6 +313,20 @@ SAILOR_HIP_API int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFra
  * GGX samples per texel), dispatched once at start-up.  dLut: device, height x width float2 (the reference image is RG16F). */
 SAILOR_HIP_API int sailor_hip_compute_brdf_lut(SailorHipContext* ctx, float* dLut, int32_t width, int32_t height);
 
+/* Replaces: IGraphicsDriverCommands::ConvertEquirect2Cubemap (GraphicsDriver/Vulkan/VulkanGraphicsDriver.cpp:1662-1686) =
+ * Content/Shaders/ComputeEquirect2Cube.shader:20-58, the first step of the raw environment cube (FrameGraph/EnvironmentNode.cpp:131-135).
+ *   dEquirect : device in, eqWidth x eqHeight RGBA32F ("src"), rows top to bottom; `repeat` != 0 = the texture's sampler wraps
+ *               (TextureAssetInfo.h:30 default), 0 = clamp-to-edge
+ *   dCube     : device out, 6 x size x size RGBA32F = level 0 of the cube chain ("dst"; the reference image is RGBA16F)
+ *   coverWidth / coverHeight : the reference dispatches equirectExtent / 32 groups (not cubeSize / 32), so only texels with
+ *               x < coverWidth and y < coverHeight are written; pass `size` twice for the whole cube */
+SAILOR_HIP_API int sailor_hip_equirect_to_cube(SailorHipContext* ctx, const float* dEquirect, int32_t eqWidth, int32_t eqHeight, int32_t repeat,
+                                               float* dCube, int32_t size, int32_t coverWidth, int32_t coverHeight);
+/* Replaces: IGraphicsDriverCommands::GenerateMipMaps on a cubemap (GraphicsDriver/Vulkan/VulkanCommandBuffer.cpp:814-907; called at
+ * EnvironmentNode.cpp:137): level i = a 2:1 VK_FILTER_LINEAR blit of level i - 1, face by face = the mean of 2 x 2 texels.
+ *   dCube : device in/out, the level-major RGBA32F chain; level 0 is read, levels 1 .. levels-1 are written */
+SAILOR_HIP_API int sailor_hip_generate_mipmaps_cube(SailorHipContext* ctx, float* dCube, int32_t size, int32_t levels);
+
 /* Replaces: Content/Shaders/ComputeIrradianceMap.shader:78-101 for the Dispatch at FrameGraph/EnvironmentNode.cpp:264-269
  * (IrradianceMapSize / 32 groups squared x 6): 65 536 uniform hemisphere samples per texel of the environment cube at lod 0.
  *   dEnv        : device in, RGBA32F cube mip chain ("envMap"): level-major, then face (+X -X +Y -Y +Z -Z), then rows of texels

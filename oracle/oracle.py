@@ -140,6 +140,25 @@ def prefilter_env_map(raw: np.ndarray, size0: int, levels: int) -> np.ndarray:
     return out
 
 
+def equirect_to_cube(equirect: np.ndarray, size: int, repeat: bool = True, cover=None, out: np.ndarray | None = None) -> np.ndarray:
+    """ComputeEquirect2Cube.shader: [6, size, size, 4] float32 from the [H, W, 4] equirect image; `cover` = (w, h) written extent"""
+    equirect = np.ascontiguousarray(equirect, np.float32)
+    h, w = equirect.shape[:2]
+    out = np.zeros((6, size, size, 4), np.float32) if out is None else out
+    cw, ch = (size, size) if cover is None else cover
+    lib().oracle_equirect_to_cube(_p(equirect), C.c_int(w), C.c_int(h), C.c_int(1 if repeat else 0), _p(out), C.c_int(size), C.c_int(cw), C.c_int(ch))
+    return out
+
+
+def generate_mipmaps_cube(level0: np.ndarray, size0: int, levels: int) -> np.ndarray:
+    """VulkanCommandBuffer::GenerateMipMaps on a cube: the flat level-major RGBA32F chain whose level 0 is `level0`"""
+    offs, total = cube_level_offsets(size0, levels)
+    chain = np.zeros(total, np.float32)
+    chain[:6 * size0 * size0 * 4] = np.ascontiguousarray(level0, np.float32).reshape(-1)
+    lib().oracle_generate_mipmaps_cube(_p(chain), C.c_int(size0), C.c_int(levels))
+    return chain
+
+
 def compute_brdf_lut(w: int, h: int) -> np.ndarray:
     """ComputeBrdfLut.shader:26-71 -> float32[h, w, 2] (DFG1, DFG2)"""
     out = np.zeros((h, w, 2), np.float32)

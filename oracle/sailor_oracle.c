@@ -1026,6 +1026,87 @@ ORACLE_API void oracle_prefilter_env_level(const float* raw, int size0, int leve
             }
 }
 
+/* ---- the raw environment cube (FrameGraph/EnvironmentNode.cpp:116-140): equirect -> cube level 0, then the mip chain ------------
+ * Content/Shaders/ComputeEquirect2Cube.shader:20-58.  One invocation per (x, y, face): st = xy / size (NO half-texel offset, as the
+ * shader), the direction by the face table at :27-33, normalize = v / length(v), phi = atan(v.z, v.x), theta = acos(v.y),
+ * texture(src, (phi / TwoPI, theta / PI)) with the shader's own PI = 3.141592.  A compute shader has no derivatives: level 0 of
+ * the equirect texture, bilinear; its sampler wraps (TextureAssetInfo.h:30 m_clamping = Repeat) or clamps, per `repeat`.
+ * VulkanGraphicsDriver.cpp:1680-1683 dispatches equirectExtent / 32 groups of 32 x 32, not cubeSize / 32: texels at
+ * x >= coverW or y >= coverH are never written (imageStore outside the image is discarded) -- they keep their old value.
+ * atan2f / acosf are the platform's; GPU and CPU differ in the last ulp, the parity test carries the tolerance.
+ * Texels are float4 in fp32 (the reference stores RGBA16F). */
+static void equirect_sample(const float* tex, int W, int H, int repeat, float u, float v, float* out)
+{
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float ax = x - fx, ay = y - fy;
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    if (repeat) {
+        x0 = ((x0 % W) + W) % W; x1 = ((x1 % W) + W) % W;
+        y0 = ((y0 % H) + H) % H; y1 = ((y1 % H) + H) % H;
+    } else {
+        x0 = x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1);
+        y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+    }
+    for (int c = 0; c < 4; c++) {
+        const float t00 = tex[((size_t)y0 * W + x0) * 4 + c], t10 = tex[((size_t)y0 * W + x1) * 4 + c];
+        const float t01 = tex[((size_t)y1 * W + x0) * 4 + c], t11 = tex[((size_t)y1 * W + x1) * 4 + c];
+        const float top = t00 * (1.0f - ax) + t10 * ax, bot = t01 * (1.0f - ax) + t11 * ax;
+        out[c] = top * (1.0f - ay) + bot * ay;
+    }
+}
+
+ORACLE_API void oracle_equirect_to_cube(const float* equirect, int eqW, int eqH, int repeat, float* cube, int size, int coverW, int coverH)
+{
+    const float PI = 3.141592f, TwoPI = 2.0f * PI; /* ComputeEquirect2Cube.shader:11-12 */
+    for (int face = 0; face < 6; face++)
+        for (int y = 0; y < size && y < coverH; y++)
+            for (int x = 0; x < size && x < coverW; x++) {
+                const float stx = (float)x / (float)size, sty = (float)y / (float)size;
+                const float ux = 2.0f * stx - 1.0f, uy = 2.0f * (1.0f - sty) - 1.0f; /* :22-23 */
+                float r[3];
+                switch (face) { /* :27-33 */
+                case 0: r[0] = 1.0f;  r[1] = uy;    r[2] = -ux;  break;
+                case 1: r[0] = -1.0f; r[1] = uy;    r[2] = ux;   break;
+                case 2: r[0] = ux;    r[1] = 1.0f;  r[2] = -uy;  break;
+                case 3: r[0] = ux;    r[1] = -1.0f; r[2] = uy;   break;
+                case 4: r[0] = ux;    r[1] = uy;    r[2] = 1.0f; break;
+                default: r[0] = -ux;  r[1] = uy;    r[2] = -1.0f; break;
+                }
+                float v[3];
+                normalize3_glsl(r, v);
+                const float phi = atan2f(v[2], v[0]), theta = acosf(v[1]); /* :44-45 */
+                equirect_sample(equirect, eqW, eqH, repeat, phi / TwoPI, theta / PI, cube + (((size_t)face * size + y) * size + x) * 4);
+            }
+}
+
+/* VulkanCommandBuffer.cpp:814-907 GenerateMipMaps: level i = vkCmdBlitImage(level i - 1, VK_FILTER_LINEAR) at exactly half the
+ * extent (or 1), every array layer (cube face) on its own.  A 2:1 linear blit puts each destination texel centre on the corner
+ * shared by four source texels: weights 1/4 each -- ((a + b) + (c + d)) * 0.25; along an axis that is already 1 wide the two
+ * taps coincide.  `cube` is the level-major chain; level 0 is the input. */
+ORACLE_API void oracle_generate_mipmaps_cube(float* cube, int size0, int levels)
+{
+    size_t srcOff = 0;
+    for (int l = 1; l < levels; l++) {
+        const int ss = (size0 >> (l - 1)) > 1 ? (size0 >> (l - 1)) : 1, ds = ss > 1 ? ss / 2 : 1;
+        const size_t dstOff = srcOff + (size_t)6 * ss * ss * 4;
+        for (int face = 0; face < 6; face++) {
+            const float* src = cube + srcOff + (size_t)face * ss * ss * 4;
+            float* dst = cube + dstOff + (size_t)face * ds * ds * 4;
+            for (int y = 0; y < ds; y++)
+                for (int x = 0; x < ds; x++) {
+                    const int x0 = ss > 1 ? 2 * x : 0, x1 = ss > 1 ? 2 * x + 1 : 0, y0 = ss > 1 ? 2 * y : 0, y1 = ss > 1 ? 2 * y + 1 : 0;
+                    for (int c = 0; c < 4; c++) {
+                        const float a = src[((size_t)y0 * ss + x0) * 4 + c], b = src[((size_t)y0 * ss + x1) * 4 + c];
+                        const float d = src[((size_t)y1 * ss + x0) * 4 + c], e = src[((size_t)y1 * ss + x1) * 4 + c];
+                        dst[((size_t)y * ds + x) * 4 + c] = ((a + b) + (d + e)) * 0.25f;
+                    }
+                }
+        }
+        srcOff = dstOff;
+    }
+}
+
 /* ComputeBrdfLut.shader:26-71 (Lighting.glsl:27-37 SampleGGX, :65-70 GeometrySchlickGGX_IBL, Math.glsl:285-293).
  * outRG = w*h float2; pow(x, 5) as x^2 * x^2 * x (x in [0, 1]); the reference stores RG16F. */
 ORACLE_API void oracle_compute_brdf_lut(int w, int h, float* outRG)

@@ -115,6 +115,8 @@ SIGNATURES = {
     "sailor_hip_compute_brdf_lut": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     "sailor_hip_compute_irradiance_map": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32]),
     "sailor_hip_prefilter_env_map": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
+    "sailor_hip_equirect_to_cube": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32]),
+    "sailor_hip_generate_mipmaps_cube": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     "sailor_hip_prefilter_env_level": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float]),
     "sailor_hip_buffer_copy": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t]),
     "sailor_hip_ecs_sweep": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_uint32), C.c_uint32, _P, C.POINTER(C.c_float), _P, _P, _P]),

@@ -138,7 +138,79 @@ __global__ __launch_bounds__(256) void k_prefilter_env(const float4* __restrict_
     if (lane == 0) outLevel[texel] = make_float4(r / weight, g / weight, b / weight, 1.0f);
 }
 
+// ---- the raw environment cube: ComputeEquirect2Cube.shader + GenerateMipMaps (EnvironmentNode.cpp:116-140) ----------------------
+// One lane per cube texel, x fastest: a wavefront walks 64 neighbouring directions, so its four-tap footprints in the equirect
+// image are neighbouring float4s.  HBM-bound: 16 B written per texel, the equirect image read about once.
+__global__ __launch_bounds__(256) void k_equirect_to_cube(const float4* __restrict__ equirect, int eqW, int eqH, int repeat,
+                                                          float4* __restrict__ cube, int size, int coverW, int coverH)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), face = blockIdx.z;
+    if (x >= size || y >= size || x >= coverW || y >= coverH) return;
+    const float PI = 3.141592f, TwoPI = 2.0f * PI;
+    const PfFrame f = pf_frame(x, y, face, size); // the same face table (ComputeEquirect2Cube.shader:27-33), before normalisation
+    const float len = sqrtf(f.Nx * f.Nx + f.Ny * f.Ny + f.Nz * f.Nz);
+    const float vx = f.Nx / len, vy = f.Ny / len, vz = f.Nz / len;
+    const float u = atan2f(vz, vx) / TwoPI, v = acosf(vy) / PI;
+    const float px = u * (float)eqW - 0.5f, py = v * (float)eqH - 0.5f;
+    const float fx = floorf(px), fy = floorf(py);
+    const float ax = px - fx, ay = py - fy;
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    if (repeat) {
+        x0 = ((x0 % eqW) + eqW) % eqW; x1 = ((x1 % eqW) + eqW) % eqW;
+        y0 = ((y0 % eqH) + eqH) % eqH; y1 = ((y1 % eqH) + eqH) % eqH;
+    } else {
+        x0 = min(max(x0, 0), eqW - 1); x1 = min(max(x1, 0), eqW - 1);
+        y0 = min(max(y0, 0), eqH - 1); y1 = min(max(y1, 0), eqH - 1);
+    }
+    const float4 a = equirect[(size_t)y0 * eqW + x0], b = equirect[(size_t)y0 * eqW + x1];
+    const float4 c = equirect[(size_t)y1 * eqW + x0], d = equirect[(size_t)y1 * eqW + x1];
+    cube[((size_t)face * size + y) * size + x] = make_float4(lerp2(a.x, b.x, c.x, d.x, ax, ay), lerp2(a.y, b.y, c.y, d.y, ax, ay),
+                                                             lerp2(a.z, b.z, c.z, d.z, ax, ay), lerp2(a.w, b.w, c.w, d.w, ax, ay));
+}
+
+// One level of the 2:1 linear blit chain, all six faces: a lane per destination texel, two float4 pairs in.
+__global__ __launch_bounds__(256) void k_cube_mip_level(const float4* __restrict__ src, int ss, float4* __restrict__ dst, int ds)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 6 * ds * ds) return;
+    const int face = i / (ds * ds), r = i - face * ds * ds, y = r / ds, x = r - y * ds;
+    const int x0 = ss > 1 ? 2 * x : 0, x1 = ss > 1 ? 2 * x + 1 : 0, y0 = ss > 1 ? 2 * y : 0, y1 = ss > 1 ? 2 * y + 1 : 0;
+    const float4* s = src + (size_t)face * ss * ss;
+    const float4 a = s[(size_t)y0 * ss + x0], b = s[(size_t)y0 * ss + x1], c = s[(size_t)y1 * ss + x0], d = s[(size_t)y1 * ss + x1];
+    dst[i] = make_float4(((a.x + b.x) + (c.x + d.x)) * 0.25f, ((a.y + b.y) + (c.y + d.y)) * 0.25f,
+                         ((a.z + b.z) + (c.z + d.z)) * 0.25f, ((a.w + b.w) + (c.w + d.w)) * 0.25f);
+}
+
 extern "C" {
+
+int sailor_hip_equirect_to_cube(SailorHipContext* ctx, const float* dEquirect, int32_t eqWidth, int32_t eqHeight, int32_t repeat,
+                                float* dCube, int32_t size, int32_t coverWidth, int32_t coverHeight)
+{
+    if (!ctx || !dEquirect || !dCube || eqWidth <= 0 || eqHeight <= 0 || eqWidth > 32768 || eqHeight > 32768 || size <= 0 || size > 8192)
+        return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (((uintptr_t)dEquirect & 15) || ((uintptr_t)dCube & 15) || coverWidth < 0 || coverHeight < 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const int cw = coverWidth < size ? coverWidth : size, ch = coverHeight < size ? coverHeight : size;
+    if (cw == 0 || ch == 0) return SAILOR_HIP_OK;
+    hipLaunchKernelGGL(k_equirect_to_cube, dim3((cw + 63) / 64, (ch + 3) / 4, 6), dim3(256), 0, ctx->stream,
+                       (const float4*)dEquirect, eqWidth, eqHeight, repeat ? 1 : 0, (float4*)dCube, size, cw, ch);
+    SAILOR_CHECK_LAUNCH(ctx, "k_equirect_to_cube");
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_generate_mipmaps_cube(SailorHipContext* ctx, float* dCube, int32_t size, int32_t levels)
+{
+    if (!ctx || !dCube || size <= 0 || size > 8192 || levels <= 0 || levels > 16 || ((uintptr_t)dCube & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    float4* src = (float4*)dCube;
+    for (int l = 1; l < levels; l++) {
+        const int ss = (size >> (l - 1)) > 1 ? (size >> (l - 1)) : 1, ds = ss > 1 ? ss / 2 : 1;
+        float4* dst = src + (size_t)6 * ss * ss;
+        hipLaunchKernelGGL(k_cube_mip_level, dim3((6 * ds * ds + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)src, ss, dst, ds);
+        SAILOR_CHECK_LAUNCH(ctx, "k_cube_mip_level");
+        src = dst;
+    }
+    return SAILOR_HIP_OK;
+}
+
 
 int sailor_hip_compute_irradiance_map(SailorHipContext* ctx, const float* dEnv, int32_t envSize, int32_t envLevels, float* dIrradiance, int32_t size)
 {

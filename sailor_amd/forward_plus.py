@@ -212,6 +212,19 @@ def prefilter_env_map(ctx: "HipContext", raw_chain: torch.Tensor, size: int, lev
     return out
 
 
+def raw_env_cubemap(ctx: "HipContext", equirect: torch.Tensor, size: int, levels: int, repeat: bool = True, cover=None) -> torch.Tensor:
+    """EnvironmentNode.cpp:116-140: ConvertEquirect2Cubemap + GenerateMipMaps -> the flat RGBA32F chain of `rawEnvCubemap`.
+    `equirect` is float32 [H, W, 4]; `cover` = (w, h) mirrors the reference's equirectExtent / 32 dispatch (default: the whole cube)."""
+    assert equirect.dtype == torch.float32 and equirect.dim() == 3 and equirect.shape[2] == 4 and equirect.is_contiguous()
+    total = sum(6 * max(size >> l, 1) ** 2 * 4 for l in range(levels))
+    chain = torch.zeros(total, dtype=torch.float32, device=ctx.device)
+    cw, ch = (size, size) if cover is None else cover
+    _lib.check(ctx._lib.sailor_hip_equirect_to_cube(ctx.handle, _ptr(equirect), equirect.shape[1], equirect.shape[0], 1 if repeat else 0,
+                                                    _ptr(chain), size, cw, ch), "sailor_hip_equirect_to_cube", ctx.handle)
+    _lib.check(ctx._lib.sailor_hip_generate_mipmaps_cube(ctx.handle, _ptr(chain), size, levels), "sailor_hip_generate_mipmaps_cube", ctx.handle)
+    return chain
+
+
 class EcsSweep:
     """K4 on one GPU over level-sorted entities."""
 

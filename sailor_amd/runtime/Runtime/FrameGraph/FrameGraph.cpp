@@ -104,7 +104,20 @@ void EnvironmentNode::Process(RHIFrameGraphPtr frameGraph, RHICommandListPtr, RH
     }
 
     if (m_bIsDirty) { // (:100-276)
-        RHICubemapPtr rawEnvCubemap = frameGraph->GetSampler("g_skyCubemap"); // (:139-142)
+        RHICubemapPtr rawEnvCubemap;
+        if (m_envMapTexture) { // (:116-138) the panorama -> the raw cube and its mip chain
+            rawEnvCubemap = driver->CreateCubemap({ (int32_t)EnvMapSize, (int32_t)EnvMapSize }, EnvMapLevels, EFormat::R32G32B32A32_SFLOAT);
+            commands->ImageMemoryBarrier(commandList, rawEnvCubemap, EImageLayout::ShaderReadOnlyOptimal);
+            commands->BeginDebugRegion(commandList, "Generate Raw Env Cubemap from Equirect");
+            commands->ImageMemoryBarrier(commandList, rawEnvCubemap, EImageLayout::ComputeWrite);
+            commands->ConvertEquirect2Cubemap(commandList, m_envMapTexture, rawEnvCubemap);
+            commands->ImageMemoryBarrier(commandList, rawEnvCubemap, EImageLayout::TransferDstOptimal);
+            commands->GenerateMipMaps(commandList, rawEnvCubemap);
+            commands->EndDebugRegion(commandList);
+            frameGraph->SetSampler("g_rawEnvCubemap", rawEnvCubemap); // not in the reference: lets the harness read the intermediate back
+        } else {
+            rawEnvCubemap = frameGraph->GetSampler("g_skyCubemap"); // (:139-142)
+        }
         if (!rawEnvCubemap || !rawEnvCubemap->m_bCubemap) { commands->EndDebugRegion(commandList); return; } // (:143-146)
         const int32_t EnvMapSize = rawEnvCubemap->GetExtent().x;
         const uint32_t EnvMapLevels = rawEnvCubemap->GetMipLevels();
@@ -166,7 +179,7 @@ void EnvironmentNode::Clear()
 {
     m_pComputeIrradianceShader.Clear(); m_pComputeSpecularShader.Clear(); m_pComputeBrdfShader.Clear();
     m_computeIrradianceBindings.Clear(); m_computeSpecularBindings.Clear(); m_computeBrdfBindings.Clear();
-    m_envCubemap.Clear(); m_irradianceCubemap.Clear(); m_brdfSampler.Clear();
+    m_envCubemap.Clear(); m_irradianceCubemap.Clear(); m_brdfSampler.Clear(); m_envMapTexture.Clear();
 }
 
 // ---- DepthHighZNode (FrameGraph/DepthHighZNode.cpp:17-103) -----------------------------------------------------------------------

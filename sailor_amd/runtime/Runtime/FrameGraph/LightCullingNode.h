@@ -63,6 +63,8 @@ protected:
 // into the lights set for Standard.shader's ambient term.
 class EnvironmentNode : public TFrameGraphNode<EnvironmentNode> {
 public:
+    static constexpr uint32_t EnvMapSize = 512;       // EnvironmentNode.h:16 } the raw cube made from an equirect panorama; a sky cubemap
+    static constexpr uint32_t EnvMapLevels = 10;      // EnvironmentNode.h:17 } published as g_skyCubemap brings its own size
     static constexpr uint32_t IrradianceMapSize = 32; // EnvironmentNode.h:19
     static constexpr uint32_t BrdfLutSize = 256;      // EnvironmentNode.h:20 (EnvMapSize / EnvMapLevels (:16-17) are taken from the raw cubemap here)
     static const char* GetName() { return m_name; }
@@ -70,6 +72,8 @@ public:
                  const RHI::RHISceneViewSnapshot& sceneView) override;
     void Clear() override;
     void MarkDirty() { m_bIsDirty = true; } // EnvironmentNode.h:28
+    // EnvironmentNode.cpp:100-111 loads the "EnvironmentMap" asset through the TextureImporter (out of scope): the loaded texture is handed in
+    void SetEnvironmentMap(RHI::RHITexturePtr equirect) { m_envMapTexture = equirect; m_envCubemap.Clear(); m_irradianceCubemap.Clear(); m_bIsDirty = true; }
 
 protected:
     static const char* m_name;
@@ -77,6 +81,7 @@ protected:
     RHI::RHIShaderBindingSetPtr m_computeIrradianceBindings, m_computeSpecularBindings, m_computeBrdfBindings;
     RHI::RHICubemapPtr m_envCubemap, m_irradianceCubemap; // (keyed by the sky parameters in the reference: one sky here)
     RHI::RHITexturePtr m_brdfSampler;
+    RHI::RHITexturePtr m_envMapTexture; // EnvironmentNode.h:43
     bool m_bIsDirty = false;
 };
 

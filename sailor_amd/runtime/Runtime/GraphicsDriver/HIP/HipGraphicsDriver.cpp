@@ -247,6 +247,31 @@ bool HipGraphicsDriver::BlitImage(RHICommandListPtr cmd, RHITexturePtr src, RHIT
     return true;
 }
 
+// VulkanGraphicsDriver.cpp:1642-1653 -> VulkanCommandBuffer::GenerateMipMaps: the linear 2:1 blit chain.  The path calls it on the raw
+// environment cube only (EnvironmentNode.cpp:137).
+void HipGraphicsDriver::GenerateMipMaps(RHICommandListPtr cmd, RHITexturePtr target)
+{
+    SailorHipContext* ctx = m_ctx;
+    cmd->m_hip.m_commands.push_back([ctx, target]() {
+        if (!target || !target->m_bCubemap || target->m_format != EFormat::R32G32B32A32_SFLOAT) return (int)SAILOR_HIP_ERR_INVALID_ARGUMENT;
+        return sailor_hip_generate_mipmaps_cube(ctx, (float*)target->m_buffer->m_hip.m_devicePtr, target->GetExtent().x, (int32_t)target->GetMipLevels());
+    });
+}
+
+// VulkanGraphicsDriver.cpp:1662-1686: ComputeEquirect2Cube.shader over equirectExtent / 32 groups of 32 x 32 (x 6 faces) -- the covered corner
+// of each face is groups * 32 texels, whatever the cube's size.
+void HipGraphicsDriver::ConvertEquirect2Cubemap(RHICommandListPtr cmd, RHITexturePtr equirect, RHICubemapPtr cubemap)
+{
+    SailorHipContext* ctx = m_ctx;
+    cmd->m_hip.m_commands.push_back([ctx, equirect, cubemap]() {
+        if (!equirect || !cubemap || !cubemap->m_bCubemap || equirect->m_format != EFormat::R32G32B32A32_SFLOAT || cubemap->m_format != EFormat::R32G32B32A32_SFLOAT)
+            return (int)SAILOR_HIP_ERR_INVALID_ARGUMENT;
+        const int32_t coverW = (int32_t)((uint32_t)(equirect->GetExtent().x / 32.0f) * 32u), coverH = (int32_t)((uint32_t)(equirect->GetExtent().y / 32.0f) * 32u);
+        return sailor_hip_equirect_to_cube(ctx, (const float*)equirect->m_buffer->m_hip.m_devicePtr, equirect->GetExtent().x, equirect->GetExtent().y,
+                                           equirect->m_bRepeat ? 1 : 0, (float*)cubemap->m_buffer->m_hip.m_devicePtr, cubemap->GetExtent().x, coverW, coverH);
+    });
+}
+
 void HipGraphicsDriver::UpdateShaderBinding(RHICommandListPtr cmd, RHIShaderBindingPtr binding, const void* data, size_t size, size_t variableOffset)
 {
     if (binding->m_type == EShaderBindingType::UniformBuffer) {

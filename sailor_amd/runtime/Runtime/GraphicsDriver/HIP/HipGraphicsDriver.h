@@ -63,6 +63,8 @@ public:
     void EndDebugRegion(RHI::RHICommandListPtr cmdList) override;
     void ImageMemoryBarrier(RHI::RHICommandListPtr cmd, RHI::RHITexturePtr image, RHI::EImageLayout newLayout) override;
     bool BlitImage(RHI::RHICommandListPtr cmd, RHI::RHITexturePtr src, RHI::RHITexturePtr dst, RHI::ivec4 srcRegionRect, RHI::ivec4 dstRegionRect) override;
+    void GenerateMipMaps(RHI::RHICommandListPtr cmd, RHI::RHITexturePtr target) override;
+    void ConvertEquirect2Cubemap(RHI::RHICommandListPtr cmd, RHI::RHITexturePtr equirect, RHI::RHICubemapPtr cubemap) override;
     void UpdateShaderBinding(RHI::RHICommandListPtr cmd, RHI::RHIShaderBindingPtr binding, const void* data, size_t size, size_t variableOffset = 0) override;
     void UpdateBuffer(RHI::RHICommandListPtr cmd, RHI::RHIBufferPtr buffer, const void* data, size_t size, size_t offset = 0) override;
     void BeginRenderPass(RHI::RHICommandListPtr cmd, const TVector<RHI::RHITexturePtr>& colorAttachments, RHI::RHITexturePtr depthStencilAttachment) override;

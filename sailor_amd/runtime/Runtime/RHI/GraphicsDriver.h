@@ -43,6 +43,8 @@ public:
     virtual void EndDebugRegion(RHICommandListPtr cmdList) = 0;                              // :239
     virtual void ImageMemoryBarrier(RHICommandListPtr cmd, RHITexturePtr image, EImageLayout newLayout) = 0; // :290
     virtual bool BlitImage(RHICommandListPtr cmd, RHITexturePtr src, RHITexturePtr dst, ivec4 srcRegionRect, ivec4 dstRegionRect) = 0;                 // :293 (equal regions only: a copy)
+    virtual void GenerateMipMaps(RHICommandListPtr cmd, RHITexturePtr target) = 0;                                                                  // :296 (cubemaps)
+    virtual void ConvertEquirect2Cubemap(RHICommandListPtr cmd, RHITexturePtr equirect, RHICubemapPtr cubemap) = 0;                                 // :297
     virtual void UpdateShaderBinding(RHICommandListPtr cmd, RHIShaderBindingPtr binding, const void* data, size_t size, size_t variableOffset = 0) = 0; // :303
     virtual void UpdateBuffer(RHICommandListPtr cmd, RHIBufferPtr buffer, const void* data, size_t size, size_t offset = 0) = 0;                       // :304
     virtual void BeginRenderPass(RHICommandListPtr cmd, const TVector<RHITexturePtr>& colorAttachments, RHITexturePtr depthStencilAttachment) = 0; // :246-255 (area, clear values dropped)

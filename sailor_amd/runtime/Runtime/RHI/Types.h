@@ -81,6 +81,7 @@ public:
     EFormat m_format = EFormat::R32_SFLOAT;
     uint32_t m_mipLevels = 1; // a cubemap is 6 faces x m_extent.x^2 texels per level, level-major (include/sailor_hip.h SailorIblDesc)
     bool m_bCubemap = false;
+    bool m_bRepeat = true;    // ETextureClamping::Repeat (the TextureAssetInfo default) vs Clamp: read by ConvertEquirect2Cubemap's sampler
     // a mip-level view of a cubemap (RHI/Cubemap.h:24 GetMipLevel): shares m_buffer with its parent
     TRefPtr<RHITexture> m_parent;
     uint32_t m_viewLevel = 0;

@@ -254,6 +254,19 @@ RT_API int sailor_rt_set_sky_cubemap(SailorRuntime* rt, void* cubeChain, int siz
     return 0;
 }
 
+// The other source of the raw environment: an equirect panorama (the node's "EnvironmentMap" texture, EnvironmentNode.cpp:100-138).  The harness
+// hands over the loaded RGBA32F texture; the node converts it to a 512 x 512 x 6 cube with 10 mips and bakes from that.
+RT_API int sailor_rt_set_environment_map(SailorRuntime* rt, void* equirect, int width, int height, int repeat, int irradianceSize)
+{
+    auto* hip = static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver());
+    if (!rt->environment || !equirect) return -1;
+    auto tex = hip->WrapTexture(equirect, { width, height }, EFormat::R32G32B32A32_SFLOAT);
+    tex->m_bRepeat = repeat != 0;
+    if (irradianceSize > 0) rt->environment->SetFloat("IrradianceMapSize", (float)irradianceSize);
+    static_cast<EnvironmentNode*>(rt->environment.GetRawPtr())->SetEnvironmentMap(tex);
+    return 0;
+}
+
 // device pointer + geometry of a sampler the graph's nodes published (g_brdfSampler, g_envCubemap, g_irradianceCubemap, ...)
 RT_API void* sailor_rt_sampler(SailorRuntime* rt, const char* name, int* outWidth, int* outHeight, int* outLevels)
 {

@@ -40,6 +40,7 @@ def load() -> C.CDLL:
         rt.sailor_rt_set_ibl.argtypes = [P, P, C.c_int, P, C.c_int, C.c_int, P, C.c_int, C.c_int, P, C.c_int, C.c_int]
         rt.sailor_rt_blur_shadow_map.argtypes = [P, P, P, C.c_int, C.c_float, C.c_float]
         rt.sailor_rt_set_sky_cubemap.argtypes = [P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, C.c_int]
+        rt.sailor_rt_set_environment_map.argtypes = [P, P, C.c_int, C.c_int, C.c_int, C.c_int]
         rt.sailor_rt_sampler.restype = P
         rt.sailor_rt_sampler.argtypes = [P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         rt.sailor_rt_build_depth_highz.argtypes = [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(P)]
@@ -116,6 +117,10 @@ class Runtime:
         """publish the raw environment cube (flat RGBA32F mip chain, device tensor) as "g_skyCubemap" and mark the Environment node dirty"""
         return self.rt.sailor_rt_set_sky_cubemap(self.h, chain.data_ptr(), size, levels, irradiance_size, ao.data_ptr() if ao is not None else None,
                                                  ao.shape[1] if ao is not None else 0, ao.shape[0] if ao is not None else 0)
+
+    def set_environment_map(self, equirect, repeat=True, irradiance_size=0):
+        """hand the Environment node its "EnvironmentMap" panorama (float32 [H, W, 4] device tensor): it converts it to the raw 512 x 512 x 6 cube"""
+        return self.rt.sailor_rt_set_environment_map(self.h, equirect.data_ptr(), equirect.shape[1], equirect.shape[0], 1 if repeat else 0, irradiance_size)
 
     def sampler(self, name: str):
         """(device pointer, width, height, mip levels) of a sampler published by the graph's nodes"""

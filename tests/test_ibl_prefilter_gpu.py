@@ -78,3 +78,60 @@ def test_golden_fixture_through_the_c_abi(ctx):
     _close(env.cpu().numpy(), p["env"].astype(np.float64))
     irr = compute_irradiance_map(ctx, torch.from_numpy(p["env"]).to(ctx.device), 16, sky.env_levels, 2).cpu().numpy()
     _close(irr, p["irradiance"].astype(np.float64))
+
+
+def _equirect(w, h, seed=3):
+    """A smooth HDR panorama with a bright sun lobe, float32 [h, w, 4]"""
+    rng = np.random.default_rng(seed)
+    u = (np.arange(w, dtype=np.float32) + 0.5) / w
+    v = (np.arange(h, dtype=np.float32) + 0.5) / h
+    uu, vv = np.meshgrid(u, v)
+    img = np.empty((h, w, 4), np.float32)
+    for c in range(3):
+        a, b, k = rng.uniform(0.2, 1.0), rng.uniform(0.1, 0.5), rng.integers(1, 4)
+        img[..., c] = a + b * np.sin(2 * np.pi * k * uu + c) * np.sin(np.pi * vv) + 20.0 * np.exp(-((uu - 0.3) ** 2 + (vv - 0.25) ** 2) * 400.0)
+    img[..., 3] = 1.0
+    return img
+
+
+@pytest.mark.parametrize("repeat", [True, False])
+def test_equirect_to_cube_matches_the_oracle(ctx, repeat):
+    from sailor_amd.forward_plus import raw_env_cubemap
+    eq = _equirect(256, 128)
+    size, levels = 64, 7
+    got = raw_env_cubemap(ctx, torch.from_numpy(eq).to(ctx.device), size, levels, repeat=repeat).cpu().numpy()
+    ref0 = oracle.equirect_to_cube(eq, size, repeat=repeat)
+    n0 = 6 * size * size * 4
+    _close(got[:n0].reshape(ref0.shape), ref0)
+    assert np.ptp(ref0[..., 0]) > 1.0
+    # the mip chain is exact arithmetic on whatever level 0 holds: bit for bit against the oracle run on the GPU's own level 0
+    np.testing.assert_array_equal(got, oracle.generate_mipmaps_cube(got[:n0], size, levels))
+    assert got.size == oracle.cube_level_offsets(size, levels)[1]
+
+
+def test_equirect_dispatch_covers_only_the_equirect_extent(ctx):
+    """VulkanGraphicsDriver.cpp:1680-1683 dispatches equirectExtent / 32 groups: a 64 x 32 panorama writes only a 64 x 32 corner of each
+    128 x 128 face; everything else keeps what the image held (zeros here)."""
+    from sailor_amd.forward_plus import raw_env_cubemap
+    eq = _equirect(64, 32)
+    got = raw_env_cubemap(ctx, torch.from_numpy(eq).to(ctx.device), 128, 1, cover=(64, 32)).cpu().numpy().reshape(6, 128, 128, 4)
+    ref = oracle.equirect_to_cube(eq, 128, cover=(64, 32))
+    _close(got, ref)
+    assert (got[:, 32:, :, :] == 0).all() and (got[:, :, 64:, :] == 0).all() and (got[:, :32, :64, 3] == 1.0).all()
+
+
+def test_raw_cube_at_the_reference_sizes_feeds_the_prefilter(ctx):
+    """EnvMapSize 512 x 512 x 6 from a 2048 x 1024 panorama, full mip chain; properties that need no oracle at this size: every level's
+    mean equals level 0's mean (2 x 2 box means), alpha stays 1, and the +Y face looks at the panorama's top rows."""
+    from sailor_amd.forward_plus import raw_env_cubemap
+    eq = _equirect(2048, 1024)
+    size, levels = 512, 10
+    chain = raw_env_cubemap(ctx, torch.from_numpy(eq).to(ctx.device), size, levels).cpu().numpy()
+    offs, total = oracle.cube_level_offsets(size, levels)
+    m0 = chain[:offs[1]].reshape(-1, 4).astype(np.float64).mean(axis=0)
+    for l in range(1, levels):
+        lv = chain[offs[l]:(offs[l + 1] if l + 1 < levels else total)].reshape(-1, 4).astype(np.float64)
+        np.testing.assert_allclose(lv.mean(axis=0), m0, rtol=1e-5)
+    np.testing.assert_array_equal(chain.reshape(-1, 4)[:, 3], 1.0)
+    top = chain[:offs[1]].reshape(6, size, size, 4)[2, size // 2, size // 2, :3]
+    np.testing.assert_allclose(top, eq[0, :, :3].mean(axis=0), rtol=0.05)

@@ -421,3 +421,50 @@ def test_depth_rasteriser_rules():
     assert oracle.raster_depth(ident, pos, tris, far, 32, 32).max() == 0
     m = oracle.shadow_resolve_evsm(box)
     assert (m[box == 0] == 0).all() and np.allclose(m[box > 0][:, 0], np.exp(40 * 0.6), rtol=1e-5)
+
+
+def test_equirect_to_cube_looks_where_the_direction_points():
+    """ComputeEquirect2Cube.shader: a panorama whose colour IS its own (u, v) must come out as (phi / TwoPI, theta / PI) of each texel's
+    direction; phi < 0 wraps with the Repeat sampler and sticks to column 0 with Clamp."""
+    w, h, size = 512, 256, 16
+    u = (np.arange(w, dtype=np.float32) + 0.5) / w
+    v = (np.arange(h, dtype=np.float32) + 0.5) / h
+    eq = np.zeros((h, w, 4), np.float32)
+    eq[..., 0], eq[..., 1] = np.meshgrid(u, v)
+    eq[..., 3] = 1.0
+    cube = oracle.equirect_to_cube(eq, size, repeat=True)
+    # face 4 (+Z): ret = (uv.x, uv.y, 1); texel (x, y) from its corner
+    x, y = 11, 5
+    d = np.array([2 * x / size - 1, 2 * (1 - y / size) - 1, 1.0])
+    d /= np.linalg.norm(d)
+    phi, theta = np.arctan2(d[2], d[0]), np.arccos(d[1])
+    np.testing.assert_allclose(cube[4, y, x, :2], [phi / (2 * 3.141592), theta / 3.141592], atol=2e-3)
+    # face 5 (-Z): phi < 0 -> u in (-0.5, 0): Repeat reads column u + 1, Clamp reads column 0
+    d = np.array([-(2 * x / size - 1), 2 * (1 - y / size) - 1, -1.0])
+    d /= np.linalg.norm(d)
+    phi = np.arctan2(d[2], d[0])
+    assert phi < 0
+    np.testing.assert_allclose(cube[5, y, x, 0], phi / (2 * 3.141592) + 1.0, atol=2e-3)
+    clamp = oracle.equirect_to_cube(eq, size, repeat=False)
+    np.testing.assert_allclose(clamp[5, y, x, 0], u[0], atol=1e-6)
+    # partial dispatch: untouched texels keep their contents
+    part = oracle.equirect_to_cube(eq, size, cover=(8, 4), out=np.full((6, size, size, 4), 7.0, np.float32))
+    assert (part[:, 4:, :, :] == 7.0).all() and (part[:, :, 8:, :] == 7.0).all()
+    np.testing.assert_array_equal(part[:, :4, :8], cube[:, :4, :8])
+
+
+def test_generate_mipmaps_is_a_chain_of_2x2_means():
+    rng = np.random.default_rng(9)
+    size, levels = 8, 4
+    l0 = rng.uniform(0, 4, (6, size, size, 4)).astype(np.float32)
+    chain = oracle.generate_mipmaps_cube(l0, size, levels)
+    offs, total = oracle.cube_level_offsets(size, levels)
+    np.testing.assert_array_equal(chain[:offs[1]], l0.reshape(-1))
+    l1 = chain[offs[1]:offs[2]].reshape(6, 4, 4, 4)
+    want = ((l0[:, 0::2, 0::2] + l0[:, 0::2, 1::2]) + (l0[:, 1::2, 0::2] + l0[:, 1::2, 1::2])) * np.float32(0.25)
+    np.testing.assert_array_equal(l1, want)
+    l3 = chain[offs[3]:].reshape(6, 1, 1, 4)
+    np.testing.assert_allclose(l3[:, 0, 0], l0.reshape(6, -1, 4).mean(axis=1), rtol=1e-6)
+    # a chain longer than log2(size) + 1 repeats the 1 x 1 level (mip extents stop at 1)
+    longer = oracle.generate_mipmaps_cube(l0, size, 6)
+    np.testing.assert_array_equal(longer[-24:], longer[-48:-24])

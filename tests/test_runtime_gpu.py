@@ -356,3 +356,46 @@ def test_shadow_pass_recorded_against_the_hip_backend(evsm):
             np.testing.assert_array_equal(smap.cpu().numpy().view(np.uint16), depth.astype(np.float16).view(np.uint16))
     finally:
         rt.close()
+
+
+def test_environment_node_converts_an_equirect_panorama():
+    """The other branch of EnvironmentNode::Process (EnvironmentNode.cpp:116-138): an "EnvironmentMap" panorama -> ConvertEquirect2Cubemap
+    (dispatched over equirectExtent / 32 groups, VulkanGraphicsDriver.cpp:1680-1683) + GenerateMipMaps -> the raw 512 x 512 x 6 / 10-mip cube the
+    pre-filters then read.  Level 0 against the oracle, the mip chain bit for bit on the GPU's own level 0, the pre-filtered cube's level 0 = the copy."""
+    w, h = 1024, 512
+    u = (np.arange(w, dtype=np.float32) + 0.5) / w
+    v = (np.arange(h, dtype=np.float32) + 0.5) / h
+    uu, vv = np.meshgrid(u, v)
+    eq = np.empty((h, w, 4), np.float32)
+    eq[..., 0] = 0.6 + 0.4 * np.sin(2 * np.pi * uu) * np.sin(np.pi * vv)
+    eq[..., 1] = 0.5 + 0.3 * np.cos(4 * np.pi * uu)
+    eq[..., 2] = 0.2 + vv + 8.0 * np.exp(-((uu - 0.7) ** 2 + (vv - 0.3) ** 2) * 300.0)
+    eq[..., 3] = 1.0
+    rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        rt.build_graph(["Environment"])
+        pano = torch.from_numpy(eq).cuda()
+        assert rt.set_environment_map(pano, repeat=True, irradiance_size=2) == 0
+        assert rt.process_frame() == 0
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        p, cw, ch, levels = rt.sampler("g_rawEnvCubemap")
+        assert (cw, ch, levels) == (512, 512, 10)
+        offs, total = oracle.cube_level_offsets(512, 10)
+        raw = read_u32(p, total * 4).view(np.float32)
+        ref0 = oracle.equirect_to_cube(eq, 512, repeat=True)
+        np.testing.assert_allclose(raw[:offs[1]], ref0.reshape(-1), rtol=1e-4, atol=1e-5)
+        np.testing.assert_array_equal(raw, oracle.generate_mipmaps_cube(raw[:offs[1]], 512, 10))
+        p, cw, ch, levels = rt.sampler("g_envCubemap")
+        assert (cw, ch, levels) == (512, 512, 10)
+        env = read_u32(p, total * 4).view(np.float32)
+        np.testing.assert_array_equal(env[:offs[1]], raw[:offs[1]])
+        assert np.isfinite(env).all() and (env.reshape(-1, 4)[:, 3] == 1.0).all()
+        # rougher mips of the pre-filtered cube keep the sky's overall level (importance-sampled means of the raw cube)
+        for l in (3, 6, 9):
+            lv = env[offs[l]:(offs[l + 1] if l + 1 < 10 else total)].reshape(-1, 4)[:, :2]
+            np.testing.assert_allclose(lv.mean(axis=0), raw[:offs[1]].reshape(-1, 4)[:, :2].mean(axis=0), rtol=0.1)
+        p, cw, ch, levels = rt.sampler("g_irradianceCubemap")
+        assert (cw, ch, levels) == (2, 2, 1)
+    finally:
+        rt.close()
