@@ -400,7 +400,7 @@ SAILOR_HIP_API int sailor_hip_raster_depth(SailorHipContext* ctx, const float* l
 /* Replaces: the draws of the depth prepass, FrameGraph/DepthPrepassNode.cpp:283-297 with Content/Shaders/DepthOnly.shader:51
  * (gl_Position = frame.projection * (frame.view * (model * position))): the same rasteriser, the camera's matrices from the frame UBO; the reversed-Z
  * projection makes it GREATER against the cleared 0 again.  dDepth is the raw depth attachment LinearizeDepth / SAILOR_CULL_RAW_DEPTH consume.
- * Triangles with a vertex at w <= 0 are dropped (no near-plane clipping). */
+ * Triangles that cross the near plane (z_clip > w_clip, which includes vertices behind the eye) are cut against it in clip space, as in the oracle. */
 SAILOR_HIP_API int sailor_hip_raster_depth_camera(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dPositions, const uint32_t* dIndices,
                                                   uint32_t numTriangles, const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn,
                                                   int32_t width, int32_t height, float* dDepth, uint32_t flags, uint32_t* dCoarseDepth);

@@ -1734,7 +1734,8 @@ ORACLE_API void oracle_csm_matrices(const float* lightView, const float* cameraW
  * ortho matrices of Bounds.cpp:78-109 swap near and far), viewport (0, H, W, -H).  What a rasteriser does between the vertex
  * shader and gl_FragCoord is fixed here as follows (Vulkan's rules with the freedoms pinned):
  *   clip   = (lightMatrix * model) * vec4(position, 1)            GLSL order, mat * mat column by column, ((c0 x + c1 y) + c2 z) + c3 w
- *   window = x: (ndc.x + 1) * (W / 2), y: (ndc.y + 1) * (-H / 2) + H, z: ndc.z   (triangles with a vertex at w <= 0 are dropped)
+ *   clip   : triangles with a vertex beyond the near plane (z_clip > w_clip) are cut against it first -- raster_near_clip below
+ *   window = x: (ndc.x + 1) * (W / 2), y: (ndc.y + 1) * (-H / 2) + H, z: ndc.z   (beyond +-2^22 pixels: dropped)
  *   snap   = x, y to 1/256 pixel (round to nearest even), 64-bit integer edge functions, both windings, top-left fill rule
  *   z      = (z0 + (z1 - z0) * w1) + (z2 - z0) * w2, w_k = float(edge_k) / float(2 * area), no fused operations
  *   test   = fragments with z outside [0, 1] are clipped; GREATER against the stored depth (0 = cleared).  (The reference's materials compare
@@ -1750,19 +1751,63 @@ typedef struct { int64_t x, y; float z; } RasterVertex;
 
 /* view == NULL: clip = LM * position with LM = lightMatrix * model (ShadowCaster.shader:58);
  * view != NULL: clip = projection * (view * (model * position)) (DepthOnly.shader:51), LM = projection here */
-static int raster_setup(const float* LM, const float* view, const float* model, const float* positions, const uint32_t* tri, int W, int H, int cullBack,
-                        RasterVertex* v)
+static void raster_clip_vertices(const float* LM, const float* view, const float* model, const float* positions, const uint32_t* tri, float clip[3][4])
 {
     for (int k = 0; k < 3; k++) {
         const float* p = positions + 3 * (size_t)tri[k];
         const float pos[4] = { p[0], p[1], p[2], 1.0f };
-        float clip[4];
         if (view) {
             float a[4], b[4];
             glsl_mat4_mul_vec4(model, pos, a);
             glsl_mat4_mul_vec4(view, a, b);
-            glsl_mat4_mul_vec4(LM, b, clip);
-        } else glsl_mat4_mul_vec4(LM, pos, clip);
+            glsl_mat4_mul_vec4(LM, b, clip[k]);
+        } else glsl_mat4_mul_vec4(LM, pos, clip[k]);
+    }
+}
+
+static void raster_cut(const float* I, float dI, const float* O, float dO, float* P)
+{
+    const float t = dI / (dI - dO);
+    for (int c = 0; c < 4; c++) P[c] = I[c] + (O[c] - I[c]) * t;
+}
+
+/* Near-plane clipping.  With the reversed depth range the near plane is z_clip = w_clip (ndc z = 1); a vertex beyond it -- which includes
+ * every vertex behind the eye -- cannot be projected.  Vulkan clips primitives against the plane geometrically; the arithmetic is pinned as:
+ * d = w - z per vertex, inside = d >= 0.  All inside: the triangle as it is (fragments beyond the plane fail z <= 1).  None: dropped.
+ * Otherwise the new vertex on an edge is computed from its INSIDE end, P = I + (O - I) * (dI / (dI - dO)); with one vertex inside (A; B, C
+ * follow it in the triangle's own order) the result is (A, AB, AC); with two inside (A, B; C outside follows them) the quad A, B, BC, AC is
+ * drawn as (A, B, BC) and (A, BC, AC).  Returns the number of triangles written to out (0, 1 or 2). */
+static int raster_near_clip(float clip[3][4], float out[2][3][4])
+{
+    float d[3];
+    int mask = 0;
+    for (int k = 0; k < 3; k++) { d[k] = clip[k][3] - clip[k][2]; if (d[k] >= 0.0f) mask |= 1 << k; }
+    if (mask == 0) return 0;
+    if (mask == 7) { memcpy(out[0], clip, sizeof(float) * 12); return 1; }
+    const int one = (mask & (mask - 1)) == 0;
+    int r;
+    if (one) r = mask == 1 ? 0 : (mask == 2 ? 1 : 2);
+    else r = mask == 6 ? 1 : (mask == 5 ? 2 : 0); /* the vertex after the outside one */
+    const float *A = clip[r], *B = clip[(r + 1) % 3], *C = clip[(r + 2) % 3];
+    const float dA = d[r], dB = d[(r + 1) % 3], dC = d[(r + 2) % 3];
+    if (one) {
+        memcpy(out[0][0], A, 16);
+        raster_cut(A, dA, B, dB, out[0][1]);
+        raster_cut(A, dA, C, dC, out[0][2]);
+        return 1;
+    }
+    float BC[4], AC[4];
+    raster_cut(B, dB, C, dC, BC);
+    raster_cut(A, dA, C, dC, AC);
+    memcpy(out[0][0], A, 16); memcpy(out[0][1], B, 16); memcpy(out[0][2], BC, 16);
+    memcpy(out[1][0], A, 16); memcpy(out[1][1], BC, 16); memcpy(out[1][2], AC, 16);
+    return 2;
+}
+
+static int raster_setup(float clipTri[3][4], int W, int H, int cullBack, RasterVertex* v)
+{
+    for (int k = 0; k < 3; k++) {
+        const float* clip = clipTri[k];
         if (!(clip[3] > 0.0f)) return 0;
         const float nx = clip[0] / clip[3], ny = clip[1] / clip[3], nz = clip[2] / clip[3];
         const float xf = (nx + 1.0f) * ((float)W * 0.5f);
@@ -1800,9 +1845,12 @@ static void raster_depth_impl(const float* lightMatrix, const float* view, const
         float LM[16];
         if (view) memcpy(LM, lightMatrix, sizeof LM);
         else glsl_mat4_mul_mat4(lightMatrix, models + 16 * (size_t)inst, LM);
-        for (uint32_t t = 0; t < numTriangles; t++) {
+        for (uint32_t t = 0; t < 2 * numTriangles; t++) { /* (triangle, part): a triangle cut by the near plane can leave two */
             RasterVertex v[3];
-            if (!raster_setup(LM, view, models + 16 * (size_t)inst, positions, indices + 3 * (size_t)t, W, H, cullBack, v)) continue;
+            float clip[3][4], parts[2][3][4];
+            raster_clip_vertices(LM, view, models + 16 * (size_t)inst, positions, indices + 3 * (size_t)(t >> 1), clip);
+            if ((int)(t & 1) >= raster_near_clip(clip, parts)) continue;
+            if (!raster_setup(parts[t & 1], W, H, cullBack, v)) continue;
             int64_t minx = v[0].x, maxx = v[0].x, miny = v[0].y, maxy = v[0].y;
             for (int k = 1; k < 3; k++) {
                 minx = v[k].x < minx ? v[k].x : minx; maxx = v[k].x > maxx ? v[k].x : maxx;

@@ -40,26 +40,61 @@ __device__ __forceinline__ Mat4 raster_mul(const Mat4& a, const float* __restric
 
 __device__ __forceinline__ long long raster_floor_div256(long long a) { return a >= 0 ? a / 256 : -((-a + 255) / 256); }
 
+// A vertex beyond the near plane of the reversed depth range (z_clip > w_clip, which includes everything behind the eye) cannot be projected:
+// such a triangle is cut against w - z = 0 in clip space first.  The new vertex on an edge is always computed from its inside end,
+// P = I + (O - I) * (dI / (dI - dO)) with d = w - z, one rounding per operation.  One vertex inside (A; B, C follow it in the triangle's
+// own order): the triangle (A, AB, AC).  Two inside (A, B; C outside follows them): the quad A, B, BC, AC as the triangles
+// (A, B, BC) = part 0 and (A, BC, AC) = part 1.  Triangles wholly inside are untouched (their fragments beyond the plane fail z <= 1).
+__device__ __forceinline__ float4 raster_cut(const float4& I, float dI, const float4& O, float dO)
+{
+    const float t = dI / (dI - dO);
+    return make_float4(I.x + (O.x - I.x) * t, I.y + (O.y - I.y) * t, I.z + (O.z - I.z) * t, I.w + (O.w - I.w) * t);
+}
+
 // hasView: clip = projection * (view * (model * position)) (DepthOnly.shader:51, LM = projection); else clip = (lightMatrix * model) * position
 __device__ __forceinline__ RasterTri raster_setup(const Mat4& LM, bool hasView, const Mat4& V, const float* __restrict__ model, const float* __restrict__ positions,
-                                                   const uint32_t* __restrict__ tri, int W, int H, bool cullBack)
+                                                   const uint32_t* __restrict__ tri, int W, int H, bool cullBack, int part, bool& hasSecond)
 {
     RasterTri t;
     t.valid = false;
-    long long X[3], Y[3];
-    float Z[3];
+    hasSecond = false;
+    float4 c[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float* p = positions + 3 * (size_t)tri[k];
-        float4 clip;
         if (hasView) {
             Mat4 M;
 #pragma unroll
             for (int q = 0; q < 16; q++) M.m[q] = model[q];
             const float4 a = glsl_mul(M, p[0], p[1], p[2], 1.0f);
             const float4 bq = glsl_mul(V, a.x, a.y, a.z, a.w);
-            clip = glsl_mul(LM, bq.x, bq.y, bq.z, bq.w);
-        } else clip = glsl_mul(LM, p[0], p[1], p[2], 1.0f);
+            c[k] = glsl_mul(LM, bq.x, bq.y, bq.z, bq.w);
+        } else c[k] = glsl_mul(LM, p[0], p[1], p[2], 1.0f);
+    }
+    const float d0 = c[0].w - c[0].z, d1 = c[1].w - c[1].z, d2 = c[2].w - c[2].z;
+    const int mask = (d0 >= 0.0f ? 1 : 0) | (d1 >= 0.0f ? 2 : 0) | (d2 >= 0.0f ? 4 : 0);
+    if (mask == 0) return t;
+    if (mask != 7) {
+        const bool one = (mask & (mask - 1)) == 0;
+        const int r = one ? (mask == 1 ? 0 : (mask == 2 ? 1 : 2)) : (mask == 6 ? 1 : (mask == 5 ? 2 : 0)); // the rotation that brings A to the front
+        const float4 A = r == 0 ? c[0] : (r == 1 ? c[1] : c[2]), B = r == 0 ? c[1] : (r == 1 ? c[2] : c[0]), C = r == 0 ? c[2] : (r == 1 ? c[0] : c[1]);
+        const float dA = r == 0 ? d0 : (r == 1 ? d1 : d2), dB = r == 0 ? d1 : (r == 1 ? d2 : d0), dC = r == 0 ? d2 : (r == 1 ? d0 : d1);
+        if (one) {
+            if (part) return t;
+            c[0] = A; c[1] = raster_cut(A, dA, B, dB); c[2] = raster_cut(A, dA, C, dC);
+        } else {
+            const float4 BC = raster_cut(B, dB, C, dC);
+            hasSecond = true;
+            c[0] = A;
+            if (part == 0) { c[1] = B; c[2] = BC; }
+            else { c[1] = BC; c[2] = raster_cut(A, dA, C, dC); }
+        }
+    } else if (part) return t;
+    long long X[3], Y[3];
+    float Z[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float4 clip = c[k];
         if (!(clip.w > 0.0f)) return t;
         const float nx = clip.x / clip.w, ny = clip.y / clip.w, nz = clip.z / clip.w;
         const float xf = (nx + 1.0f) * ((float)W * 0.5f);
@@ -145,7 +180,7 @@ __device__ __forceinline__ void raster_box_bounds(const RasterTri& t, float area
     }
 }
 
-__global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, Mat4 V, int hasView, int cullBack, const float* __restrict__ positions, const uint32_t* __restrict__ indices, uint32_t numTriangles,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_raster_depth(Mat4 L, Mat4 V, int hasView, int cullBack, const float* __restrict__ positions, const uint32_t* __restrict__ indices, uint32_t numTriangles,
                                                        const float* __restrict__ models, const uint32_t* __restrict__ instanceIds, uint32_t numDrawn, int W, int H,
                                                        unsigned int* __restrict__ depthBits, unsigned int* __restrict__ coarse)
 {
@@ -154,123 +189,130 @@ __global__ __launch_bounds__(256) void k_raster_depth(Mat4 L, Mat4 V, int hasVie
     const int lane = threadIdx.x & 63;
     const int CW = (W + 7) >> 3, SW = (W + 63) >> 6;
     unsigned int* coarse2 = coarse ? coarse + (size_t)CW * ((H + 7) >> 3) : nullptr; // level 2 behind level 1 in the same workspace
-    RasterTri t;
-    t.valid = false;
-    if (id < total) {
-        const uint32_t d = (uint32_t)(id / numTriangles), tri = (uint32_t)(id - (unsigned long long)d * numTriangles);
-        const uint32_t inst = instanceIds ? instanceIds[d] : d;
-        const Mat4 LM = hasView ? L : raster_mul(L, models + 16 * (size_t)inst);
-        t = raster_setup(LM, hasView != 0, V, models + 16 * (size_t)inst, positions, indices + 3 * (size_t)tri, W, H, cullBack != 0);
-    }
-    const float zmaxTri = fmaxf(t.z0, fmaxf(t.z1, t.z2)) + RASTER_Z_MARGIN; // inside the triangle z is a convex combination of the vertices'
-    if (t.valid && !(zmaxTri > 0.0f)) t.valid = false;                        // nothing of it can pass z > 0
-    if (t.valid && fminf(t.z0, fminf(t.z1, t.z2)) - RASTER_Z_MARGIN > 1.0f) t.valid = false; // ... or z <= 1
-    const bool small = t.valid && (long long)(t.i1 - t.i0 + 1) * (t.j1 - t.j0 + 1) <= RASTER_SMALL_BOX;
-    if (small) {
-        bool hidden = false;
-        if (coarse && (t.i0 >> 3) == (t.i1 >> 3) && (t.j0 >> 3) == (t.j1 >> 3))
-            hidden = zmaxTri <= __uint_as_float(coarse[(size_t)(t.j0 >> 3) * CW + (t.i0 >> 3)]);
-        if (!hidden) {
-            const float area = (float)raster_edge(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2);
-            const bool tl0 = raster_top_left(t.x1, t.y1, t.x2, t.y2), tl1 = raster_top_left(t.x2, t.y2, t.x0, t.y0), tl2 = raster_top_left(t.x0, t.y0, t.x1, t.y1);
-            for (int j = t.j0; j <= t.j1; j++)
-                for (int i = t.i0; i <= t.i1; i++) raster_pixel(t, area, tl0, tl1, tl2, i, j, W, depthBits);
+    // a triangle cut by the near plane can leave a quad: its second half is a second trip through the same code, taken only by waves that hold one
+    bool again = false;
+    for (int part = 0; part < 2; part++) {
+        if (part && !__any(again)) break;
+        RasterTri t;
+        t.valid = false;
+        bool second = false;
+        if (id < total) {
+            const uint32_t d = (uint32_t)(id / numTriangles), tri = (uint32_t)(id - (unsigned long long)d * numTriangles);
+            const uint32_t inst = instanceIds ? instanceIds[d] : d;
+            const Mat4 LM = hasView ? L : raster_mul(L, models + 16 * (size_t)inst);
+            t = raster_setup(LM, hasView != 0, V, models + 16 * (size_t)inst, positions, indices + 3 * (size_t)tri, W, H, cullBack != 0, part, second);
         }
-    }
-    // the large ones: the whole wave on one triangle at a time
-    unsigned long long todo = __ballot(t.valid && !small);
-    while (todo) {
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        RasterTri b;
-        b.x0 = bcast64(t.x0, src); b.y0 = bcast64(t.y0, src); b.x1 = bcast64(t.x1, src); b.y1 = bcast64(t.y1, src); b.x2 = bcast64(t.x2, src); b.y2 = bcast64(t.y2, src);
-        b.z0 = __shfl(t.z0, src, 64); b.z1 = __shfl(t.z1, src, 64); b.z2 = __shfl(t.z2, src, 64);
-        b.i0 = __shfl(t.i0, src, 64); b.i1 = __shfl(t.i1, src, 64); b.j0 = __shfl(t.j0, src, 64); b.j1 = __shfl(t.j1, src, 64);
-        const float zmaxB = __shfl(zmaxTri, src, 64);
-        const float area = (float)raster_edge(b.x0, b.y0, b.x1, b.y1, b.x2, b.y2);
-        const bool tl0 = raster_top_left(b.x1, b.y1, b.x2, b.y2), tl1 = raster_top_left(b.x2, b.y2, b.x0, b.y0), tl2 = raster_top_left(b.x0, b.y0, b.x1, b.y1);
-        // ---- level 2: 64 x 64-texel superblocks, one per lane ----
-        const int si0 = b.i0 >> 6, sj0 = b.j0 >> 6, sw = (b.i1 >> 6) - si0 + 1, sh = (b.j1 >> 6) - sj0 + 1;
-        const int ns = sw * sh;
-        for (int sbase = 0; sbase < ns; sbase += 64) {
-            const int sblk = sbase + lane;
-            bool salive = sblk < ns;
-            int si = 0, sj = 0;
-            if (salive) {
-                sj = sblk / sw; si = sblk - sj * sw;
-                si += si0; sj += sj0;
-                long long m0, m1, m2, n0, n1, n2;
-                float zhi, zlo;
-                raster_box_bounds(b, area, si * 64, sj * 64, si * 64 + 63, sj * 64 + 63, m0, m1, m2, n0, n1, n2, zhi, zlo);
-                salive = m0 >= 0 && m1 >= 0 && m2 >= 0 && zhi + RASTER_Z_MARGIN > 0.0f && !(zlo - RASTER_Z_MARGIN > 1.0f); // ... and not clipped away as a whole
-                if (salive && coarse2) {
-                    unsigned int* c2 = coarse2 + (size_t)sj * SW + si;
-                    salive = fminf(zmaxB, zhi + RASTER_Z_MARGIN) > __uint_as_float(*c2);
-                    // the triangle covers the whole superblock (every corner texel strictly inside every edge) with depths in (0, 1]: once its
-                    // texels are written, nothing below the smallest of them can win anywhere in the superblock
-                    if (salive && n0 > 0 && n1 > 0 && n2 > 0 && zlo - RASTER_Z_MARGIN > 0.0f && zhi + RASTER_Z_MARGIN <= 1.0f && si * 64 + 63 < W && sj * 64 + 63 < H)
-                        atomicMax(c2, __float_as_uint(zlo - RASTER_Z_MARGIN));
-                }
+        const float zmaxTri = fmaxf(t.z0, fmaxf(t.z1, t.z2)) + RASTER_Z_MARGIN; // inside the triangle z is a convex combination of the vertices'
+        if (t.valid && !(zmaxTri > 0.0f)) t.valid = false;                        // nothing of it can pass z > 0
+        if (t.valid && fminf(t.z0, fminf(t.z1, t.z2)) - RASTER_Z_MARGIN > 1.0f) t.valid = false; // ... or z <= 1
+        const bool small = t.valid && (long long)(t.i1 - t.i0 + 1) * (t.j1 - t.j0 + 1) <= RASTER_SMALL_BOX;
+        if (small) {
+            bool hidden = false;
+            if (coarse && (t.i0 >> 3) == (t.i1 >> 3) && (t.j0 >> 3) == (t.j1 >> 3))
+                hidden = zmaxTri <= __uint_as_float(coarse[(size_t)(t.j0 >> 3) * CW + (t.i0 >> 3)]);
+            if (!hidden) {
+                const float area = (float)raster_edge(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2);
+                const bool tl0 = raster_top_left(t.x1, t.y1, t.x2, t.y2), tl1 = raster_top_left(t.x2, t.y2, t.x0, t.y0), tl2 = raster_top_left(t.x0, t.y0, t.x1, t.y1);
+                for (int j = t.j0; j <= t.j1; j++)
+                    for (int i = t.i0; i <= t.i1; i++) raster_pixel(t, area, tl0, tl1, tl2, i, j, W, depthBits);
             }
-            unsigned long long slive = __ballot(salive);
-            if (lane == 0) { STAT(0, min(64, ns - sbase)); STAT(1, __popcll(slive)); }
-            while (slive) {
-                const int s1 = __builtin_ctzll(slive);
-                slive &= slive - 1ull;
-                const int csi = __shfl(si, s1, 64), csj = __shfl(sj, s1, 64);
-                // ---- level 1: the superblock's 8 x 8 blocks, one per lane ----
-                const int bi = csi * 8 + (lane & 7), bj = csj * 8 + (lane >> 3);
-                bool alive = bi >= (b.i0 >> 3) && bi <= (b.i1 >> 3) && bj >= (b.j0 >> 3) && bj <= (b.j1 >> 3);
-                float c1 = 3.0e38f; // this block's coarse depth (blocks beyond the map do not exist)
-                if (coarse && bi < CW && bj < ((H + 7) >> 3)) c1 = __uint_as_float(coarse[(size_t)bj * CW + bi]);
-                if (alive) {
+        }
+        // the large ones: the whole wave on one triangle at a time
+        unsigned long long todo = __ballot(t.valid && !small);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            RasterTri b;
+            b.x0 = bcast64(t.x0, src); b.y0 = bcast64(t.y0, src); b.x1 = bcast64(t.x1, src); b.y1 = bcast64(t.y1, src); b.x2 = bcast64(t.x2, src); b.y2 = bcast64(t.y2, src);
+            b.z0 = __shfl(t.z0, src, 64); b.z1 = __shfl(t.z1, src, 64); b.z2 = __shfl(t.z2, src, 64);
+            b.i0 = __shfl(t.i0, src, 64); b.i1 = __shfl(t.i1, src, 64); b.j0 = __shfl(t.j0, src, 64); b.j1 = __shfl(t.j1, src, 64);
+            const float zmaxB = __shfl(zmaxTri, src, 64);
+            const float area = (float)raster_edge(b.x0, b.y0, b.x1, b.y1, b.x2, b.y2);
+            const bool tl0 = raster_top_left(b.x1, b.y1, b.x2, b.y2), tl1 = raster_top_left(b.x2, b.y2, b.x0, b.y0), tl2 = raster_top_left(b.x0, b.y0, b.x1, b.y1);
+            // ---- level 2: 64 x 64-texel superblocks, one per lane ----
+            const int si0 = b.i0 >> 6, sj0 = b.j0 >> 6, sw = (b.i1 >> 6) - si0 + 1, sh = (b.j1 >> 6) - sj0 + 1;
+            const int ns = sw * sh;
+            for (int sbase = 0; sbase < ns; sbase += 64) {
+                const int sblk = sbase + lane;
+                bool salive = sblk < ns;
+                int si = 0, sj = 0;
+                if (salive) {
+                    sj = sblk / sw; si = sblk - sj * sw;
+                    si += si0; sj += sj0;
                     long long m0, m1, m2, n0, n1, n2;
                     float zhi, zlo;
-                    raster_box_bounds(b, area, bi * 8, bj * 8, bi * 8 + 7, bj * 8 + 7, m0, m1, m2, n0, n1, n2, zhi, zlo);
-                    alive = m0 >= 0 && m1 >= 0 && m2 >= 0 && zhi + RASTER_Z_MARGIN > 0.0f && !(zlo - RASTER_Z_MARGIN > 1.0f);
-                    if (alive && coarse) alive = fminf(zmaxB, zhi + RASTER_Z_MARGIN) > c1;
+                    raster_box_bounds(b, area, si * 64, sj * 64, si * 64 + 63, sj * 64 + 63, m0, m1, m2, n0, n1, n2, zhi, zlo);
+                    salive = m0 >= 0 && m1 >= 0 && m2 >= 0 && zhi + RASTER_Z_MARGIN > 0.0f && !(zlo - RASTER_Z_MARGIN > 1.0f); // ... and not clipped away as a whole
+                    if (salive && coarse2) {
+                        unsigned int* c2 = coarse2 + (size_t)sj * SW + si;
+                        salive = fminf(zmaxB, zhi + RASTER_Z_MARGIN) > __uint_as_float(*c2);
+                        // the triangle covers the whole superblock (every corner texel strictly inside every edge) with depths in (0, 1]: once its
+                        // texels are written, nothing below the smallest of them can win anywhere in the superblock
+                        if (salive && n0 > 0 && n1 > 0 && n2 > 0 && zlo - RASTER_Z_MARGIN > 0.0f && zhi + RASTER_Z_MARGIN <= 1.0f && si * 64 + 63 < W && sj * 64 + 63 < H)
+                            atomicMax(c2, __float_as_uint(zlo - RASTER_Z_MARGIN));
+                    }
                 }
-                if (coarse2) { // the smallest of the 64 block bounds is a bound for the superblock: keeps level 2 as tight as level 1 has become
-                    float cmin = c1;
-#pragma unroll
-                    for (int d = 32; d > 0; d >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, d, 64));
-                    if (lane == 0 && cmin > 0.0f && cmin < 3.0e38f) atomicMax(coarse2 + (size_t)csj * SW + csi, __float_as_uint(cmin));
-                }
-                unsigned long long live = __ballot(alive);
-                if (lane == 0) { STAT(2, 64); STAT(3, __popcll(live)); }
-                // ---- the surviving blocks, one lane per texel ----
-                while (live) {
-                    const int s2 = __builtin_ctzll(live);
-                    live &= live - 1ull;
-                    const int cbi = csi * 8 + (s2 & 7), cbj = csj * 8 + (s2 >> 3);
-                    const int i = cbi * 8 + (lane & 7), j = cbj * 8 + (lane >> 3);
-                    bool wrote = false;
-                    float z = 2.0f;
-                    if (i >= b.i0 && i <= b.i1 && j >= b.j0 && j <= b.j1) {
-                        const long long px = 256ll * i + 128, py = 256ll * j + 128;
-                        const long long e0 = raster_edge(b.x1, b.y1, b.x2, b.y2, px, py), e1 = raster_edge(b.x2, b.y2, b.x0, b.y0, px, py),
-                                        e2 = raster_edge(b.x0, b.y0, b.x1, b.y1, px, py);
-                        const bool in = !(e0 < 0 || e1 < 0 || e2 < 0) && !((e0 == 0 && !tl0) || (e1 == 0 && !tl1) || (e2 == 0 && !tl2));
-                        if (in) {
-                            z = (b.z0 + (b.z1 - b.z0) * ((float)e1 / area)) + (b.z2 - b.z0) * ((float)e2 / area);
-                            if (z > 0.0f && z <= 1.0f) {
-                                atomicMax(depthBits + (size_t)j * W + i, __float_as_uint(z)); // positive floats order like their bits
-                                wrote = true;
+                unsigned long long slive = __ballot(salive);
+                if (lane == 0) { STAT(0, min(64, ns - sbase)); STAT(1, __popcll(slive)); }
+                while (slive) {
+                    const int s1 = __builtin_ctzll(slive);
+                    slive &= slive - 1ull;
+                    const int csi = __shfl(si, s1, 64), csj = __shfl(sj, s1, 64);
+                    // ---- level 1: the superblock's 8 x 8 blocks, one per lane ----
+                    const int bi = csi * 8 + (lane & 7), bj = csj * 8 + (lane >> 3);
+                    bool alive = bi >= (b.i0 >> 3) && bi <= (b.i1 >> 3) && bj >= (b.j0 >> 3) && bj <= (b.j1 >> 3);
+                    float c1 = 3.0e38f; // this block's coarse depth (blocks beyond the map do not exist)
+                    if (coarse && bi < CW && bj < ((H + 7) >> 3)) c1 = __uint_as_float(coarse[(size_t)bj * CW + bi]);
+                    if (alive) {
+                        long long m0, m1, m2, n0, n1, n2;
+                        float zhi, zlo;
+                        raster_box_bounds(b, area, bi * 8, bj * 8, bi * 8 + 7, bj * 8 + 7, m0, m1, m2, n0, n1, n2, zhi, zlo);
+                        alive = m0 >= 0 && m1 >= 0 && m2 >= 0 && zhi + RASTER_Z_MARGIN > 0.0f && !(zlo - RASTER_Z_MARGIN > 1.0f);
+                        if (alive && coarse) alive = fminf(zmaxB, zhi + RASTER_Z_MARGIN) > c1;
+                    }
+                    if (coarse2) { // the smallest of the 64 block bounds is a bound for the superblock: keeps level 2 as tight as level 1 has become
+                        float cmin = c1;
+    #pragma unroll
+                        for (int d = 32; d > 0; d >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, d, 64));
+                        if (lane == 0 && cmin > 0.0f && cmin < 3.0e38f) atomicMax(coarse2 + (size_t)csj * SW + csi, __float_as_uint(cmin));
+                    }
+                    unsigned long long live = __ballot(alive);
+                    if (lane == 0) { STAT(2, 64); STAT(3, __popcll(live)); }
+                    // ---- the surviving blocks, one lane per texel ----
+                    while (live) {
+                        const int s2 = __builtin_ctzll(live);
+                        live &= live - 1ull;
+                        const int cbi = csi * 8 + (s2 & 7), cbj = csj * 8 + (s2 >> 3);
+                        const int i = cbi * 8 + (lane & 7), j = cbj * 8 + (lane >> 3);
+                        bool wrote = false;
+                        float z = 2.0f;
+                        if (i >= b.i0 && i <= b.i1 && j >= b.j0 && j <= b.j1) {
+                            const long long px = 256ll * i + 128, py = 256ll * j + 128;
+                            const long long e0 = raster_edge(b.x1, b.y1, b.x2, b.y2, px, py), e1 = raster_edge(b.x2, b.y2, b.x0, b.y0, px, py),
+                                            e2 = raster_edge(b.x0, b.y0, b.x1, b.y1, px, py);
+                            const bool in = !(e0 < 0 || e1 < 0 || e2 < 0) && !((e0 == 0 && !tl0) || (e1 == 0 && !tl1) || (e2 == 0 && !tl2));
+                            if (in) {
+                                z = (b.z0 + (b.z1 - b.z0) * ((float)e1 / area)) + (b.z2 - b.z0) * ((float)e2 / area);
+                                if (z > 0.0f && z <= 1.0f) {
+                                    atomicMax(depthBits + (size_t)j * W + i, __float_as_uint(z)); // positive floats order like their bits
+                                    wrote = true;
+                                }
                             }
                         }
-                    }
-#ifdef RASTER_STATS
-                    { const unsigned long long wb = __ballot(wrote), ib = __ballot(z < 2.0f); if (lane == 0) { STAT(4, __popcll(ib)); STAT(5, __popcll(wb)); STAT(6, wb == ~0ull); } }
-#endif
-                    if (coarse && __ballot(wrote) == ~0ull) { // the whole block now holds depths >= the smallest one written here
-                        float zmin = z;
-#pragma unroll
-                        for (int d = 32; d > 0; d >>= 1) zmin = fminf(zmin, __shfl_xor(zmin, d, 64));
-                        if (lane == 0) atomicMax(coarse + (size_t)cbj * CW + cbi, __float_as_uint(zmin));
+    #ifdef RASTER_STATS
+                        { const unsigned long long wb = __ballot(wrote), ib = __ballot(z < 2.0f); if (lane == 0) { STAT(4, __popcll(ib)); STAT(5, __popcll(wb)); STAT(6, wb == ~0ull); } }
+    #endif
+                        if (coarse && __ballot(wrote) == ~0ull) { // the whole block now holds depths >= the smallest one written here
+                            float zmin = z;
+    #pragma unroll
+                            for (int d = 32; d > 0; d >>= 1) zmin = fminf(zmin, __shfl_xor(zmin, d, 64));
+                            if (lane == 0) atomicMax(coarse + (size_t)cbj * CW + cbi, __float_as_uint(zmin));
+                        }
                     }
                 }
             }
         }
+        if (part == 0) again = second;
     }
 }
 

@@ -468,3 +468,37 @@ def test_generate_mipmaps_is_a_chain_of_2x2_means():
     # a chain longer than log2(size) + 1 repeats the 1 x 1 level (mip extents stop at 1)
     longer = oracle.generate_mipmaps_cube(l0, size, 6)
     np.testing.assert_array_equal(longer[-24:], longer[-48:-24])
+
+
+def test_rasteriser_cuts_triangles_at_the_near_plane():
+    """A floor that runs from far in front of the eye to far behind it (two triangles, both with vertices at w <= 0): every pixel below the horizon
+    that looks at the floor gets the analytic depth near / distance -- no holes where whole triangles used to be dropped; a floor so close that part
+    of it is nearer than the near plane is cut there (ndc z > 1 is clipped)."""
+    W, H, near = 160, 120, np.float32(0.1)
+    P = np.zeros(16, np.float32)
+    P[0], P[5], P[2 * 4 + 3], P[3 * 4 + 2] = H / W, 1.0, -1.0, near    # reversed Z, infinite far, looking down -Z
+    one = np.eye(4, dtype=np.float32).reshape(1, 16)
+    idx = np.uint32([[0, 1, 2], [0, 2, 3]])
+    ny = 1.0 - 2.0 * (np.arange(H) + 0.5) / H
+    nx = 2.0 * (np.arange(W) + 0.5) / W - 1.0
+    for y_floor, x_half in ((-1.0, 40.0), (-0.05, 40.0)):
+        pos = np.float32([[-x_half, y_floor, -200.0], [x_half, y_floor, -200.0], [x_half, y_floor, 30.0], [-x_half, y_floor, 30.0]])
+        for flip in (False, True):
+            tri = idx[:, ::-1] if flip else idx
+            depth = oracle.raster_depth(P, pos, tri, one, W, H)
+            with np.errstate(divide="ignore"):
+                dist = np.where(ny < 0, y_floor / ny, np.inf)            # -z of the floor point a pixel row looks at
+            want = np.where(np.isfinite(dist), near / dist, 0.0)
+            x_at = nx[None, :] * dist[:, None] * (W / H)
+            seen = (dist[:, None] < 199.0) & (np.abs(x_at) < x_half - 1e-3) & (want[:, None] < 0.999)
+            gone = (want[:, None] > 1.001) | (ny[:, None] > 0) | (dist[:, None] > 201.0)
+            assert seen.sum() > 1000
+            np.testing.assert_allclose(depth[seen], np.broadcast_to(want[:, None], depth.shape)[seen], rtol=2e-4, atol=1e-4)  # vertices snap to 1/256 pixel: up to (depth gradient per pixel) / 256
+            assert (depth[gone & np.ones_like(seen)] == 0).all()
+        if y_floor == -0.05:
+            assert (want > 1.001).sum() > 10, "part of the near floor is nearer than the near plane"
+    # winding survives the cut: the floor seen from above is front- or back-facing as a whole
+    a = oracle.raster_depth(P, pos, idx, one, W, H, cull_back=True)
+    b = oracle.raster_depth(P, pos, idx[:, ::-1], one, W, H, cull_back=True)
+    assert ((a > 0).sum() == 0) != ((b > 0).sum() == 0)
+    np.testing.assert_array_equal(np.maximum(a, b), depth)

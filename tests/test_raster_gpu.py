@@ -213,3 +213,57 @@ def test_random_triangle_soup(ctx, size):
         d = raster_depth(ctx, IDENTITY, d_pos, torch.from_numpy(idx[half:].view(np.int32).copy()).to(ctx.device), d_one, W, H, depth=d, coarse=coarse)
         ctx.synchronize()
         np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def _perspective(width, height, near=0.1, f=1.0):
+    """reversed-Z, infinite far plane, looking down -Z: w = -z, ndc z = near / -z (1 at the near plane, 0 at infinity); column-major"""
+    m = np.zeros(16, np.float32)
+    m[0] = f * height / width
+    m[5] = f
+    m[2 * 4 + 3] = -1.0
+    m[3 * 4 + 2] = near
+    return m
+
+
+@pytest.mark.parametrize("size", [(96, 64), (333, 200)])
+def test_triangles_through_the_near_plane_and_behind_the_eye(ctx, size):
+    """Perspective soup around the eye: several hundred triangles cross the near plane (z_clip > w_clip), many reach behind the eye (w <= 0) -- cut
+    in clip space into one or two triangles, on the GPU exactly as in the oracle; with and without back-face culling and the coarse-depth workspace,
+    through the light-matrix entry point and the camera (projection, view) one."""
+    from sailor_amd.forward_plus import raster_depth_camera
+    W, H = size
+    rng = np.random.default_rng(77 + W)
+    n = 4000
+    centre = rng.uniform(-3, 3, (n, 1, 3)).astype(np.float32)
+    centre[..., 2] = rng.uniform(-8.0, 1.5, (n, 1)).astype(np.float32)
+    extent = (10.0 ** rng.uniform(-2.0, 0.7, (n, 1, 1))).astype(np.float32)
+    verts = centre + rng.uniform(-1, 1, (n, 3, 3)).astype(np.float32) * extent
+    verts[::41, :, 2] = np.float32(-0.1)       # exactly on the near plane: d = w - z = 0 counts as inside
+    verts[7::53, 0, 2] = np.float32(0.0)       # a vertex at w = 0
+    pos = np.ascontiguousarray(verts.reshape(-1, 3))
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    one = IDENTITY.reshape(1, 16)
+    P = _perspective(W, H)
+    d = verts[..., 2] * -1.0 - 0.1             # w - z_clip per vertex
+    crossing = ((d >= 0).any(axis=1) & (d < 0).any(axis=1)).mean()
+    assert crossing > 0.05 and (verts[..., 2] > 0).any(axis=1).mean() > 0.1
+    d_pos, d_idx, d_one = torch.from_numpy(pos).to(ctx.device), torch.from_numpy(idx.view(np.int32).copy()).to(ctx.device), torch.from_numpy(one.copy()).to(ctx.device)
+    for cull in (False, True):
+        ref = oracle.raster_depth(P, pos, idx, one, W, H, cull_back=cull)
+        assert float((ref > 0).mean()) > 0.5 and float(ref.max()) <= 1.0
+        for use_coarse in (False, True):
+            coarse = torch.empty(int(_lib.load().sailor_hip_raster_coarse_words(W, H)), dtype=torch.int32, device=ctx.device) if use_coarse else None
+            got = raster_depth(ctx, P, d_pos, d_idx, d_one, W, H, coarse=coarse, cull_back=cull)
+            ctx.synchronize()
+            np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # the same soup through DepthOnly's projection * (view * (model * position)): the tiny frame's camera, the soup moved in front of it
+    f = synth.make_frame("tiny", with_surface=False)
+    cam = f.cam
+    fb = np.frombuffer(bytes(cam.frame), np.float32)
+    inv_view = np.linalg.inv(fb[0:16].reshape(4, 4).T.astype(np.float64))
+    world = (np.c_[pos.astype(np.float64), np.ones(len(pos))] @ inv_view.T)[:, :3].astype(np.float32)
+    ref = oracle.raster_depth(fb[16:32], world, idx, one, cam.width, cam.height, view=fb[0:16])
+    assert float((ref > 0).mean()) > 0.3
+    got = raster_depth_camera(ctx, cam.frame, torch.from_numpy(world).to(ctx.device), d_idx, d_one, cam.width, cam.height)
+    ctx.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32))
