@@ -8,6 +8,7 @@
 #include "Runtime/GraphicsDriver/HIP/HipGraphicsDriver.h"
 #include "Runtime/RHI/Renderer.h"
 #include "Runtime/AssetRegistry/FrameGraph/FrameGraphParser.h"
+#include "Runtime/AssetRegistry/World/WorldPrefabImporter.h"
 #include <cstdio>
 
 using namespace Sailor;
@@ -71,6 +72,78 @@ RT_API int sailor_rt_build_graph(SailorRuntime* rt, const char** nodeNames, int 
 
 // FrameGraphAsset::Deserialize alone (no device): a one-line summary of what a `.renderer` text declares, for the CPU tests:
 //   "targets=Name:WxH:format:mips,...;nodes=Name[tag]{string k=v;float k=v;vec4 k=x y z w;rt k=v},...;values=k=v,...;samplers=a,b"
+// WorldPrefab::Deserialize + World::Instantiate of a `.world` text (no device needed): a one-line summary for the tests, -1 + message on an error
+static std::string world_summary(const WorldScene& scene)
+{
+    char b[768];
+    std::string s = "name=" + scene.m_name + ";objects=" + std::to_string(scene.m_gameObjects.size()) + ";";
+    for (const auto& go : scene.m_gameObjects) {
+        snprintf(b, sizeof b, "%s[parent=%d pos=%g %g %g rot=%.9g %.9g %.9g %.9g scale=%g %g %g comps=", go.m_name.c_str(), (int)go.m_parent, go.m_transform.position[0],
+                 go.m_transform.position[1], go.m_transform.position[2], go.m_transform.rotation[0], go.m_transform.rotation[1], go.m_transform.rotation[2],
+                 go.m_transform.rotation[3], go.m_transform.scale[0], go.m_transform.scale[1], go.m_transform.scale[2]);
+        s += b;
+        for (size_t i = 0; i < go.m_componentTypes.size(); i++) s += (i ? "," : "") + go.m_componentTypes[i];
+        s += "];";
+    }
+    for (const auto& c : scene.m_cameras) {
+        snprintf(b, sizeof b, "camera{owner=%u fov=%g zNear=%g zFar=%g};", c.m_owner, c.m_fov, c.m_zNear, c.m_zFar);
+        s += b;
+    }
+    for (const auto& l : scene.m_lights) {
+        snprintf(b, sizeof b, "light{owner=%u type=%u intensity=%g %g %g attenuation=%.9g %.9g %.9g bounds=%g %g %g cutOff=%g %g dir=%.9g %.9g %.9g pos=%g %g %g};", l.m_owner,
+                 (unsigned)l.m_data.m_type, l.m_data.m_intensity[0], l.m_data.m_intensity[1], l.m_data.m_intensity[2], l.m_data.m_attenuation[0], l.m_data.m_attenuation[1],
+                 l.m_data.m_attenuation[2], l.m_data.m_bounds[0], l.m_data.m_bounds[1], l.m_data.m_bounds[2], l.m_data.m_cutOff[0], l.m_data.m_cutOff[1], l.m_data.m_direction[0],
+                 l.m_data.m_direction[1], l.m_data.m_direction[2], l.m_data.m_worldPosition[0], l.m_data.m_worldPosition[1], l.m_data.m_worldPosition[2]);
+        s += b;
+    }
+    for (const auto& m : scene.m_meshRenderers) s += "mesh{owner=" + std::to_string(m.m_owner) + " model=" + m.m_modelFileId + "};";
+    s += "other=" + std::to_string(scene.m_otherComponents);
+    return s;
+}
+
+RT_API int sailor_rt_parse_world(const char* yamlText, char* out, int outSize)
+{
+    WorldPrefab prefab;
+    WorldScene scene;
+    std::string err;
+    if (!prefab.Deserialize(yamlText ? yamlText : "", &err) || !scene.Instantiate(prefab, &err)) {
+        if (out && outSize > 0) snprintf(out, (size_t)outSize, "error: %s", err.c_str());
+        return -1;
+    }
+    if (out && outSize > 0) snprintf(out, (size_t)outSize, "%s", world_summary(scene).c_str());
+    return (int)scene.m_gameObjects.size();
+}
+
+// Loads a `.world` into the runtime the way Sailor.cpp:185-190 + World::Instantiate do for the parts the path reads: the first camera becomes the scene view's
+// camera (aspect from the viewport), every LightComponent registers with the lighting system and is packed by LightingECS::Tick, and the game objects' transforms /
+// parent indices come back flat for the ECS sweep (outTransforms: 12 floats each, outParents; up to maxObjects).  Returns the number of game objects.
+RT_API int sailor_rt_load_world(SailorRuntime* rt, const char* yamlText, int width, int height, float* outTransforms, uint32_t* outParents, int maxObjects, int* outLights,
+                                int* outMeshes)
+{
+    WorldPrefab prefab;
+    WorldScene scene;
+    if (!prefab.Deserialize(yamlText ? yamlText : "") || !scene.Instantiate(prefab)) return -1;
+    if (!scene.m_cameras.empty()) {
+        const auto& c = scene.m_cameras[0];
+        memcpy(rt->snapshot.m_camera.m_world, scene.m_gameObjects[c.m_owner].m_world, 64);
+        rt->snapshot.m_camera.m_fov = c.m_fov; rt->snapshot.m_camera.m_aspect = (float)width / (float)height;
+        rt->snapshot.m_camera.m_zNear = c.m_zNear; rt->snapshot.m_camera.m_zFar = c.m_zFar;
+    }
+    rt->graph.SetViewport(width, height);
+    for (const auto& l : scene.m_lights) rt->lighting->RegisterComponent(l.m_data);
+    auto cmd = Renderer::GetDriver()->CreateCommandList();
+    rt->lighting->Tick(cmd);
+    Renderer::GetDriver()->SubmitCommandList(cmd);
+    rt->lighting->FillLightingData(rt->snapshot);
+    for (int i = 0; i < (int)scene.m_gameObjects.size() && i < maxObjects; i++) {
+        if (outTransforms) memcpy(outTransforms + 12 * i, &scene.m_gameObjects[i].m_transform, 48);
+        if (outParents) outParents[i] = scene.m_gameObjects[i].m_parent;
+    }
+    if (outLights) *outLights = (int)scene.m_lights.size();
+    if (outMeshes) *outMeshes = (int)scene.m_meshRenderers.size();
+    return (int)scene.m_gameObjects.size();
+}
+
 RT_API int sailor_rt_parse_renderer(const char* yamlText, int viewportWidth, int viewportHeight, char* out, int outSize)
 {
     FrameGraphAsset asset;

@@ -45,6 +45,8 @@ def load() -> C.CDLL:
         rt.sailor_rt_sampler.argtypes = [P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         rt.sailor_rt_build_depth_highz.argtypes = [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(P)]
         rt.sailor_rt_parse_renderer.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        rt.sailor_rt_parse_world.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        rt.sailor_rt_load_world.argtypes = [P, C.c_char_p, C.c_int, C.c_int, P, P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         rt.sailor_rt_load_renderer.argtypes = [P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         rt.sailor_rt_render_target.restype = P
         rt.sailor_rt_render_target.argtypes = [P, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -58,6 +60,16 @@ def load() -> C.CDLL:
         rt.sailor_rt_ecs_sweep.argtypes = [P, P, P, P, C.c_uint32, P, C.c_uint32, C.POINTER(P), C.POINTER(P), C.POINTER(P)]
         _rt = rt
     return _rt
+
+
+def parse_world(text: str):
+    """WorldPrefab::Deserialize + World::Instantiate of a `.world` text (no device needed): (number of game objects, summary string)"""
+    rt = load()
+    buf = C.create_string_buffer(1 << 16)
+    n = rt.sailor_rt_parse_world(text.encode(), buf, len(buf))
+    if n < 0:
+        raise ValueError(buf.value.decode())
+    return n, buf.value.decode()
 
 
 def parse_renderer(text: str, viewport_width: int, viewport_height: int):
@@ -134,6 +146,18 @@ class Runtime:
         st = self.rt.sailor_rt_build_depth_highz(self.h, depth.data_ptr() if depth is not None else None, depth.shape[1] if depth is not None else 0,
                                                  depth.shape[0] if depth is not None else 0, width, height, levels, C.byref(p))
         return st, p.value
+
+    def load_world(self, text: str, width: int, height: int, max_objects: int = 4096):
+        """load a `.world`: camera -> scene view, LightComponents -> LightingECS (packed by Tick); returns (transforms float32 [n, 12], parents uint32 [n],
+        number of lights, number of mesh renderers) for the ECS sweep"""
+        import numpy as np
+        tr = np.zeros((max_objects, 12), np.float32)
+        par = np.zeros(max_objects, np.uint32)
+        nl, nm = C.c_int(0), C.c_int(0)
+        n = self.rt.sailor_rt_load_world(self.h, text.encode(), width, height, tr.ctypes.data, par.ctypes.data, max_objects, C.byref(nl), C.byref(nm))
+        if n < 0:
+            raise ValueError("the .world text does not parse")
+        return tr[:n], par[:n], nl.value, nm.value
 
     def load_renderer(self, text: str):
         """FrameGraphImporter::BuildFrameGraph from a `.renderer` text: (nodes created, nodes without a class here, render targets created)"""

@@ -487,3 +487,44 @@ def caster_models(world: np.ndarray, local_aabb: np.ndarray) -> np.ndarray:
     local[:, 0, 0] = half[:, 0]; local[:, 1, 1] = half[:, 1]; local[:, 2, 2] = half[:, 2]; local[:, 3, 3] = 1.0
     local[:, :3, 3] = centre
     return np.ascontiguousarray((w @ local).transpose(0, 2, 1).reshape(-1, 16).astype(np.float32))
+
+
+# ---- `.world` text (Content/Editor.world): what WorldPrefab::Serialize writes (WorldPrefabImporter.cpp:18-32, PrefabImporter.cpp:17-50) ----
+def _yaml_seq(values, indent: int) -> str:
+    pad = " " * indent
+    return "".join(f"{pad}- {float(np.float32(v))!r}\n" if not float(np.float32(v)).is_integer() else f"{pad}- {int(v)}\n" for v in values)
+
+
+def make_world_text(name: str, prefabs: list) -> str:
+    """prefabs: a list of prefabs, each a list of game objects {name, position[4], rotation[4] (x, y, z, w), scale[4], parent (index inside the
+    prefab or None), components: [{typename, properties: {key: scalar | sequence | dict}}]}.  Numbers are written with enough digits to read
+    back as the same float32 (the reference writes %.9g-style floats)."""
+    out = [f"name: {name}\n", "prefabs:\n"]
+    for objects in prefabs:
+        comps = []
+        out.append("  - gameObjects:\n")
+        for k, go in enumerate(objects):
+            out.append(f"      - name: {go['name']}\n")
+            for key in ("position", "rotation", "scale"):
+                out.append(f"        {key}:\n" + _yaml_seq(go[key], 10))
+            parent = go.get("parent")
+            out.append(f"        parentIndex: {4294967295 if parent is None else parent}\n")
+            out.append(f"        instanceId: {1000 + k}\n")
+            out.append("        components:\n")
+            for c in go.get("components", []):
+                out.append(f"          - {len(comps)}\n")
+                comps.append(c)
+            if not go.get("components"):
+                out[-1] = "        components: []\n"
+        out.append("    components:\n" if comps else "    components: []\n")
+        for c in comps:
+            out.append(f"      - typename: {c['typename']}\n        overrideProperties:\n")
+            for key, val in c.get("properties", {}).items():
+                if isinstance(val, dict):
+                    out.append(f"          {key}:\n" + "".join(f"            {k2}: {v2}\n" for k2, v2 in val.items()))
+                elif isinstance(val, (list, tuple, np.ndarray)):
+                    out.append(f"          {key}:\n" + _yaml_seq(val, 12))
+                else:
+                    out.append(f"          {key}: {val}\n")
+            out.append("          fileId: NullFileId\n")
+    return "".join(out)

@@ -407,3 +407,87 @@ def test_csm_pass_planning_on_cascade_sets():
     assert render5 and min(render5) == holds.index(True)   # the first cascade that holds the moved mesh is re-rendered ...
     for k in render5:                                       # ... and every other one either holds it or follows a re-rendered cascade of its type
         assert holds[k] or any(z in render5 and types[z] == types[k] for z in range(k))
+
+
+# ---- the `.world` scene description -------------------------------------------------------------------------------
+def _summary_fields(summary, prefix):
+    return [e for e in summary.split(";") if e.startswith(prefix)]
+
+
+def _world_objects():
+    cam = {"name": "Camera", "position": [0, 150, 0, 1], "rotation": [0, 0, 0, 0], "scale": [1, 1, 1, 1],
+           "components": [{"typename": "Sailor::CameraComponent", "properties": {"fov": 75, "zNear": 0.5, "zFar": 9000}},
+                          {"typename": "Sailor::EditorComponent", "properties": {}}]}
+    rig = [{"name": "Rig", "position": [10, 20, 30, 1], "rotation": [0, 0.38268343, 0, 0.92387953], "scale": [2, 2, 2, 1], "components": []},
+           {"name": "Arm", "position": [1.5, 2.25, -3.1, 1], "rotation": [0.1, 0.2, 0.3, 0.9273618], "scale": [1, 0.5, 1, 1], "parent": 0,
+            "components": [{"typename": "Sailor::MeshRendererComponent", "properties": {"model": {"fileId": '"{0123-AB}"', "instanceId": "NullInstanceId"}}}]},
+           {"name": "Lamp", "position": [0, 4, 0, 1], "rotation": [0.70710677, 0, 0, 0.70710677], "scale": [1, 1, 1, 1], "parent": 1,
+            "components": [{"typename": "Sailor::LightComponent",
+                            "properties": {"intensity": [255, 128, 7], "lightType": "Spot", "bounds": [12, 12, 12], "cutOff": [20, 35]}}]}]
+    sun = {"name": "Sun", "position": [0, 0, 0, 0], "rotation": [0.0918623805, 0.858316064, 0.477002949, 0.477002949], "scale": [1, 1, 1, 1],
+           "components": [{"typename": "Sailor::LightComponent", "properties": {"intensity": [17, 17, 17], "lightType": "Directional"}}]}
+    return [[cam], rig, [sun]]
+
+
+def test_world_description_instantiates_like_the_reference():
+    """WorldPrefab::Deserialize + the game-object half of World::Instantiate: objects in file order, parents by index inside their prefab, world
+    matrices through the parent chain, the camera's properties, LightComponents -> LightData with LightingECS's direction / position rule
+    (world * (0, 0, -1, 0), world[3]); a zero quaternion (as Editor.world stores for unrotated objects) is the identity rotation."""
+    from sailor_amd import runtime_binding, synth
+    prefabs = _world_objects()
+    text = synth.make_world_text("WorldEditor", prefabs)
+    n, summary = runtime_binding.parse_world("# written by a test\n" + text)
+    assert n == 5 and summary.startswith("name=WorldEditor;objects=5;")
+    assert "Arm[parent=1 " in summary and "Lamp[parent=2 " in summary and "Rig[parent=-1 " in summary and "Sun[parent=-1 " in summary
+    assert _summary_fields(summary, "camera{") == ["camera{owner=0 fov=75 zNear=0.5 zFar=9000}"]
+    assert _summary_fields(summary, "mesh{") == ["mesh{owner=2 model={0123-AB}}"] and summary.endswith("other=1")
+    # the lamp hangs two levels down: its world matrix is Rig * Arm * Lamp
+    rig, arm, lamp = prefabs[1]
+    world = host.mat4_mul(host.mat4_mul(host.transform_matrix(rig["position"], rig["rotation"], rig["scale"]),
+                                        host.transform_matrix(arm["position"], arm["rotation"], arm["scale"])),
+                          host.transform_matrix(lamp["position"], lamp["rotation"], lamp["scale"]))
+    lights = _summary_fields(summary, "light{")
+    assert len(lights) == 2 and lights[0].startswith("light{owner=3 type=2 intensity=255 128 7 attenuation=1 0.0219999999 0.00190000003 bounds=12 12 12 cutOff=20 35 ")
+    got_dir = np.float32(lights[0].split("dir=")[1].split(" pos=")[0].split())
+    got_pos = np.float32(lights[0].split("pos=")[1].rstrip("}").split())
+    np.testing.assert_array_equal(got_dir, -world[8:11])
+    np.testing.assert_allclose(got_pos, world[12:15], rtol=1e-5)
+    # the directional light keeps LightData's defaults for what the file leaves out (ECS/LightingECS.h:23-28) and the file's unnormalised quaternion
+    assert lights[1].startswith("light{owner=4 type=0 intensity=17 17 17 attenuation=1 0.0219999999 0.00190000003 bounds=100 100 100 cutOff=30 45 ")
+    sun_world = host.transform_matrix([0, 0, 0, 0], prefabs[2][0]["rotation"], [1, 1, 1, 1])
+    np.testing.assert_array_equal(np.float32(lights[1].split("dir=")[1].split(" pos=")[0].split()), -sun_world[8:11])
+    # the camera's zero quaternion: the identity rotation, like glm::mat4_cast
+    np.testing.assert_array_equal(host.transform_matrix([0, 150, 0, 1], [0, 0, 0, 0], [1, 1, 1, 1]), host.transform_matrix([0, 150, 0, 1], [0, 0, 0, 1], [1, 1, 1, 1]))
+
+
+def test_world_description_rejects_what_it_cannot_read():
+    from sailor_amd import runtime_binding, synth
+    text = synth.make_world_text("W", _world_objects())
+    with pytest.raises(ValueError, match="parentIndex out of range"):
+        runtime_binding.parse_world(text.replace("parentIndex: 1\n", "parentIndex: 7\n"))
+    with pytest.raises(ValueError, match="component index out of range"):
+        runtime_binding.parse_world(text.replace("          - 1\n    components:", "          - 9\n    components:", 1))
+    with pytest.raises(ValueError, match="not a sequence"):
+        runtime_binding.parse_world("name: W\nprefabs: none\n")
+    with pytest.raises(ValueError, match="line 3"):
+        runtime_binding.parse_world("name: W\nprefabs:\n\t- gameObjects:\n")
+    with pytest.raises(ValueError, match="indentation"):
+        runtime_binding.parse_world("name: W\nprefabs:\n  - gameObjects:\n      - name: A\n       position: 3\n")
+    assert runtime_binding.parse_world("name: Empty\nprefabs: []\n") == (0, "name=Empty;objects=0;other=0")
+
+
+def test_the_reference_world_file_parses_when_mounted():
+    """Content/Editor.world itself (read only when /root/reference is mounted): the four objects, the camera the synthetic frames copy
+    (position (0, 150, 0), fov 90, zNear 1, zFar 20 000 -- SURVEY.md 8c), the directional light's intensity 17 and the two mesh renderers."""
+    from sailor_amd import runtime_binding
+    f = Path("/root/reference/Content/Editor.world")
+    if not f.exists():
+        pytest.skip("reference not mounted")
+    n, summary = runtime_binding.parse_world(f.read_text())
+    assert n == 4 and summary.startswith("name=WorldEditor;objects=4;Camera[parent=-1 pos=0 150 0 ")
+    assert _summary_fields(summary, "camera{") == ["camera{owner=0 fov=90 zNear=1 zFar=20000}"]
+    lights = _summary_fields(summary, "light{")
+    assert len(lights) == 1 and lights[0].startswith("light{owner=3 type=0 intensity=17 17 17 attenuation=1 0.0219999999 0.00190000003 bounds=100 100 100 cutOff=30 45 ")
+    assert len(_summary_fields(summary, "mesh{")) == 2 and summary.endswith("other=2")
+    cam = synth_camera = __import__("sailor_amd.synth", fromlist=["make_camera"]).make_camera(64, 64)
+    assert (cam.fov, cam.z_near, cam.z_far) == (90.0, 1.0, 20000.0) and tuple(cam.world[12:15]) == (0.0, 150.0, 0.0)

@@ -399,3 +399,78 @@ def test_environment_node_converts_an_equirect_panorama():
         assert (cw, ch, levels) == (2, 2, 1)
     finally:
         rt.close()
+
+
+def test_world_description_drives_the_lighting_path():
+    """A `.world` text (WorldPrefab::Deserialize + World::Instantiate, SURVEY.md 8f rank 4) carrying the tiny frame's camera and its lights as LightComponents
+    on game objects -- a third of them hanging under a moved, rotated parent -- loaded into the runtime: the camera becomes the scene view's, LightingECS packs the
+    components (direction = world * forward, position = world[3], cut-off cosines), LightCulling + RenderScene then give the oracle's lists and radiance for the
+    same records packed on the host."""
+    f = synth.make_frame("tiny")
+    W, H = f.cam.width, f.cam.height
+    rng = np.random.default_rng(11)
+    n = len(f.lights)
+    rig = {"name": "Rig", "position": [30.0, -12.5, 8.0, 1], "rotation": [0, 0.38268343, 0, 0.92387953], "scale": [1, 1, 1, 1], "components": []}
+    rig_world = host.transform_matrix(rig["position"], rig["rotation"], rig["scale"])
+    rig_inv = host.mat4_inverse(rig_world).reshape(4, 4).T.astype(np.float64)
+    roots, children, expected = [], [rig], np.zeros(n, host.LIGHT_DTYPE)
+    for i in range(n):
+        q = rng.normal(size=4)
+        q = (q / np.linalg.norm(q)).astype(np.float32)
+        kind = {host.LIGHT_POINT: "Point", host.LIGHT_SPOT: "Spot", host.LIGHT_DIRECTIONAL: "Directional"}[int(f.lights["type"][i])]
+        cut = [float(rng.integers(10, 30)), float(rng.integers(31, 60))]
+        comp = {"typename": "Sailor::LightComponent", "properties": {"intensity": f.lights["intensity"][i], "lightType": kind, "bounds": f.lights["bounds"][i], "cutOff": cut}}
+        pos = np.r_[f.lights["worldPosition"][i].astype(np.float64), 1.0]
+        under_rig = i % 3 == 0
+        local = (rig_inv @ pos) if under_rig else pos
+        go = {"name": f"Light{i}", "position": np.float32(local), "rotation": q, "scale": [1, 1, 1, 1], "components": [comp]}
+        if under_rig:
+            go["parent"] = 0
+            children.append(go)
+        else:
+            roots.append([go])
+        m = host.transform_matrix(go["position"], q, go["scale"])
+        world = host.mat4_mul(rig_world, m) if under_rig else m
+        go["_world"], go["_cut"], go["_src"] = world, cut, i
+    cam = {"name": "Camera", "position": [0, 150, 0, 1], "rotation": [0, 0, 0, 0], "scale": [1, 1, 1, 1],
+           "components": [{"typename": "Sailor::CameraComponent", "properties": {"fov": 90, "zNear": 1, "zFar": 20000}}]}
+    prefabs = [[cam], children] + roots
+    order = [go for prefab in prefabs for go in prefab if "_world" in go]
+    for k, go in enumerate(order):  # LightingECS registers components in instantiation order
+        i, world = go["_src"], go["_world"]
+        expected[k]["type"] = f.lights["type"][i]
+        expected[k]["shadowType"] = host.SHADOW_PCF                      # ECS/LightingECS.h:28 default
+        expected[k]["worldPosition"] = world[12:15]
+        expected[k]["direction"] = -world[8:11]
+        expected[k]["intensity"] = f.lights["intensity"][i]
+        expected[k]["attenuation"] = np.float32([1.0, 0.022, 0.0019])     # ECS/LightingECS.h:24 default
+        expected[k]["cutOff"] = host.cutoff_cosines(*go["_cut"])
+        expected[k]["bounds"] = f.lights["bounds"][i]
+    text = synth.make_world_text("Tiny", [[{k: v for k, v in go.items() if not k.startswith("_")} for go in prefab] for prefab in prefabs])
+    rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        rt.build_graph(["LightCulling", "RenderScene"])
+        transforms, parents, num_lights, num_meshes = rt.load_world(text, W, H)
+        assert (len(transforms), num_lights, num_meshes) == (n + 2, n, 0)
+        assert parents[0] == 0xFFFFFFFF and parents[1] == 0xFFFFFFFF and (parents[2:len(children) + 1] == 1).all() and (parents[len(children) + 1:] == 0xFFFFFFFF).all()
+        np.testing.assert_array_equal(transforms[1], np.float32(rig["position"] + rig["rotation"] + rig["scale"]))
+        depth = torch.from_numpy(f.depth).cuda()
+        surface = torch.from_numpy(f.surface).cuda()
+        radiance = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        rt.set_depth(depth)
+        rt.set_surface(surface, radiance)
+        assert rt.process_frame() == 0
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        og, oi, _ = oracle.light_cull(f.cam.frame, W, H, expected, f.depth)
+        assert int(oi[0]) > 100
+        Tx, Ty = host.num_tiles(W, H)
+        gp, _ = rt.buffer("lightsGrid")
+        cp, _ = rt.buffer("culledLights")
+        np.testing.assert_array_equal(read_u32(gp, Tx * Ty * 8).reshape(-1, 2), og)
+        np.testing.assert_array_equal(read_u32(cp, 4 * (1 + int(oi[0]))), oi[: 1 + int(oi[0])])
+        ref = oracle.shade(f.cam.frame, W, H, f.surface, expected, og, oi, None)
+        err = np.abs(radiance.cpu().numpy().astype(np.float64) - ref)
+        assert (err <= 1e-4 * np.abs(ref) + 1e-5).all(), err.max()
+    finally:
+        rt.close()
