@@ -129,12 +129,45 @@ def extract_frustum_planes_matrix(projection_view_matrix):
     return planes.reshape(6, 4), corners.reshape(8, 3)
 
 
-def plan_csm_passes(overlap_masks: np.ndarray, shadow_types, last_changed_frame: np.ndarray, previous):
+def quat_rotate(q_xyzw, v) -> np.ndarray:
+    """glm::rotate(quat, vec3) = v + ((cross(q.xyz, v) * q.w) + cross(q.xyz, cross(q.xyz, v))) * 2, in float32 (Math/Transform.cpp:74 GetForward)"""
+    q = np.asarray(q_xyzw, np.float32)
+    v = np.asarray(v, np.float32)
+    uv = np.cross(q[:3], v).astype(np.float32)
+    uuv = np.cross(q[:3], uv).astype(np.float32)
+    return (v + (uv * q[3] + uuv) * np.float32(2.0)).astype(np.float32)
+
+
+CSM_CAMERA_POS_DELTA = np.float32(15.0)        # ECS/LightingECS.cpp:16
+CSM_CAMERA_ROTATION_DELTA = np.float32(0.9995)  # ECS/LightingECS.cpp:17
+
+
+def csm_view_unchanged(prev_view, view) -> bool:
+    """The transform half of CSMLightState::Equals (ECS/LightingECS.cpp:14-24).  A view is (component index, camera position[4], camera rotation xyzw,
+    light position[4], light rotation xyzw): unchanged iff same light component, the camera moved at most 15 units and its forward vector keeps a
+    dot product of at least 0.9995 with the old one, and the light's position and rotation are exactly equal."""
+    if prev_view is None or view is None:
+        return prev_view is None and view is None
+    (ci0, cp0, cr0, lp0, lr0), (ci1, cp1, cr1, lp1, lr1) = prev_view, view
+    if ci0 != ci1:
+        return False
+    d = np.asarray(cp0, np.float32) - np.asarray(cp1, np.float32)
+    if np.sqrt(np.float32(np.dot(d, d)), dtype=np.float32) > CSM_CAMERA_POS_DELTA:
+        return False
+    f0, f1 = quat_rotate(cr0, [0, 0, -1]), quat_rotate(cr1, [0, 0, -1])
+    if np.float32(np.dot(f0, f1)) < CSM_CAMERA_ROTATION_DELTA:
+        return False
+    return bool(np.array_equal(np.asarray(lp0, np.float32), np.asarray(lp1, np.float32)) and np.array_equal(np.asarray(lr0, np.float32), np.asarray(lr1, np.float32)))
+
+
+def plan_csm_passes(overlap_masks: np.ndarray, shadow_types, last_changed_frame: np.ndarray, previous, view=None):
     """The bookkeeping of LightingECS::PrepareCSMPasses (ECS/LightingECS.cpp:299-366) for one directional light, on the cascade overlap sets
     of sailor_hip_csm_caster_masks (uint64 [cascades, words]):
       * cascade k > 0 drops every mesh that an EARLIER cascade of the same shadow type, re-rendered this frame, already overlaps (:310-327);
       * a cascade is re-rendered iff its mesh list, as (mesh index, frame the mesh last changed) pairs, differs from last frame's snapshot
-        (CSMLightState::Equals :14-38; the camera / light transform thresholds of that comparison are the caller's `previous is None`).
+        or -- with `view` = (light component index, camera position, camera rotation, light position, light rotation) -- the camera moved more than 15
+        units / turned past dot 0.9995 / the light moved at all since that snapshot was taken (CSMLightState::Equals :14-38, csm_view_unchanged).
+        A cascade that is NOT re-rendered keeps its old snapshot, camera included (:353-357): slow camera drift accumulates until it crosses the threshold.
     Returns (list of cascades to render, their final uint64 masks [cascades, words], the new snapshots)."""
     masks = np.array(overlap_masks, np.uint64, copy=True)
     n_casc = masks.shape[0]
@@ -147,9 +180,11 @@ def plan_csm_passes(overlap_masks: np.ndarray, shadow_types, last_changed_frame:
                 masks[k] &= ~np.asarray(overlap_masks[z], np.uint64)
         bits = np.unpackbits(masks[k].view(np.uint8), bitorder="little")[: len(frames)].astype(bool)
         idx = np.nonzero(bits)[0]
-        snap = (idx.copy(), frames[idx].copy())
+        snap = (idx.copy(), frames[idx].copy(), view)
         same = previous is not None and k < len(previous) and np.array_equal(previous[k][0], snap[0]) and np.array_equal(previous[k][1], snap[1])
-        snapshots.append(snap)
+        if same and (view is not None or (len(previous[k]) > 2 and previous[k][2] is not None)):
+            same = csm_view_unchanged(previous[k][2] if len(previous[k]) > 2 else None, view)
+        snapshots.append(previous[k] if same else snap)  # an equal snapshot is kept as it is (:353-357)
         if not same:
             added[k] = shadow_types[k]
             render.append(k)
