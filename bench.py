@@ -79,6 +79,20 @@ def event_ms(fn, steps):
     return float(t.mean()), float(np.median(t)), float(np.percentile(t, 10)), float(np.percentile(t, 90))
 
 
+def event_batch_ms(fn, steps):
+    """average duration of fn() in ms from ONE HIP event pair around `steps` back-to-back calls on the launch stream: what a launch costs inside a
+    running pipeline (the next launch ramps up while the previous one drains), which is also what rocprofv3's kernel trace reports -- its per-kernel
+    durations add up to the wall time of the step.  An event pair around every single launch (event_ms) drains the GPU on both sides of the kernel and
+    reads 10-15 % longer for a 0.2 ms kernel."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / steps
+
+
 def measured_traffic(kernel: str, config: str, world: int):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01/traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes).
@@ -620,6 +634,9 @@ def main():
     # ---- per-kernel timing on the launch stream (HIP events) + algorithmic bytes ----
     cull_ms = event_ms(cull, args.steps)
     shade_ms = event_ms(shade, args.steps)
+    cull_batch_ms = event_batch_ms(cull, args.steps)
+    shade_batch_ms = event_batch_ms(shade, args.steps)
+    pipeline_ms = event_batch_ms(lambda: (cull(), shade()), args.steps)   # eager cull + shade chains back to back: the step without graphs or overlap
     g, idx = fp.lists_to_host()
     sum_nt = int(idx[0])
     distinct = int(len(np.unique(idx[1:]))) if sum_nt else 0
@@ -627,15 +644,20 @@ def main():
     b_shade = 64 * band_pixels + 8 * fp.band_tiles + 4 * sum_nt + 112 * distinct
     b_cull = 20 * N + 4 * band_pixels + 8 * fp.band_tiles + 4 * sum_nt + 4
     evals = int((g[:, 1].astype(np.int64) * 256).sum())
-    shade_gbs = b_shade / (shade_ms[0] * 1e-3) / 1e9
+    shade_gbs = b_shade / (shade_batch_ms * 1e-3) / 1e9
     shade_kernel = "k2_shade_csm" if csm is not None else ("k2_shade_band" if fp.tile_order and fp.use_tile_order else "k2_shade")
     roofline = {"bound": "hbm", "kernel": shade_kernel, "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
-                "traffic": measured_traffic("k2_shade" if csm is None else "k2_shade_csm", args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_ms[0], "median_launch_ms": shade_ms[1],
+                "traffic": measured_traffic("k2_shade" if csm is None else "k2_shade_csm", args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_batch_ms,
+                "timing": "one HIP event pair around %d back-to-back launches on the launch stream (agrees with rocprofv3 --kernel-trace --stats); "
+                          "isolated_* = an event pair around every single launch (pipeline drained on both sides)" % args.steps,
+                "isolated_avg_launch_ms": shade_ms[0], "isolated_median_launch_ms": shade_ms[1],
+                "in_pipeline_launch_ms": pipeline_ms - cull_batch_ms,  # eager (cull + shade) x K minus (cull) x K: the kernel between its real neighbours
+                "eager_step_ms": pipeline_ms,
                 "frac_of_measured_copy_peak": shade_gbs / HBM_COPY_GBS,
-                "valu_sidebar": {"pixel_light_evals": evals, "gevals_per_s": evals / (shade_ms[0] * 1e-3) / 1e9,
+                "valu_sidebar": {"pixel_light_evals": evals, "gevals_per_s": evals / (shade_batch_ms * 1e-3) / 1e9,
                                  "note": "~110 fp32 ops per (pixel,light): VALU-bound once mean list length exceeds ~10 (SURVEY.md 7, hard part 2)"},
-                "cull": {"kernels": "k01_prepare+k1_*", "avg_ms": cull_ms[0], "median_ms": cull_ms[1], "bytes": b_cull,
-                         "achieved_gbs": b_cull / (cull_ms[0] * 1e-3) / 1e9, "frac": b_cull / (cull_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                "cull": {"kernels": "k01_prepare+k1_*", "avg_ms": cull_batch_ms, "isolated_avg_ms": cull_ms[0], "isolated_median_ms": cull_ms[1], "bytes": b_cull,
+                         "achieved_gbs": b_cull / (cull_batch_ms * 1e-3) / 1e9, "frac": b_cull / (cull_batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
     # ---- supplementary, N > 1 only: alternate-frame rendering.  The split frame above is latency-bound (a 0.25 ms frame leaves ~30 us
     # per GPU); the reference keeps two frames in flight (RHI/Renderer.h:34), and whole frames are independent, so a node can also give
@@ -701,8 +723,8 @@ def main():
                        "width": W, "height": H, "lights": N, "parallelism": f"tile-row bands x{world}", "partition": partition,
                        "mean_list_length": sum_nt / max(fp.band_tiles, 1), "sum_num_rank0_band": sum_nt, "distinct_lights_rank0_band": distinct,
                        "generator": {"seed": synth.SEED, "radius_scale": frame.cfg["lights"].radius_scale}},
-            "mlights_culled_per_s": N / (cull_ms[1] * 1e-3) / 1e6,
-            "cull_ms": cull_ms[1], "shade_ms": shade_ms[1],
+            "mlights_culled_per_s": N / (cull_batch_ms * 1e-3) / 1e6,
+            "cull_ms": cull_batch_ms, "shade_ms": shade_batch_ms,
             "roofline": roofline,
         }
         if exchange_info:
