@@ -93,6 +93,12 @@ def event_batch_ms(fn, steps):
     return a.elapsed_time(b) / steps
 
 
+def side_ms(fn, steps):
+    """the side blocks' timing: event_batch_ms in event_ms's (mean, median, p10, p90) shape -- one figure, the in-pipeline cost of a launch"""
+    b = event_batch_ms(fn, steps)
+    return b, b, b, b
+
+
 def measured_traffic(kernel: str, config: str, world: int):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01/traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes).
@@ -155,7 +161,7 @@ def ecs_baseline(ctx, count: int, steps: int):
     sweep = EcsSweep(ctx, ents)
     for _ in range(3):
         sweep.run(planes)
-    mean, med, _, _ = event_ms(lambda: sweep.run(planes), steps)
+    mean, med, _, _ = side_ms(lambda: sweep.run(planes), steps)
     world = np.zeros((count, 16), np.float32); aabb = np.zeros((count, 6), np.float32); vis = np.zeros((count + 63) // 64, np.uint64)
     t0 = time.perf_counter()
     oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes, world=world, world_aabb=aabb, visibility=vis)
@@ -186,7 +192,7 @@ def ecs_baseline(ctx, count: int, steps: int):
     from sailor_amd.forward_plus import csm_caster_masks
     sh = synth.make_shadow_set(cam, 16)
     cplanes = np.stack([host.extract_frustum_planes_matrix(sh.lights_matrices[k])[0] for k in range(4)])
-    _, casc_ms, _, _ = event_ms(lambda: csm_caster_masks(ctx, sweep.world_aabb, cplanes), steps)
+    _, casc_ms, _, _ = side_ms(lambda: csm_caster_masks(ctx, sweep.world_aabb, cplanes), steps)
     bytes_per_entity = 164.125
     return {"entities": count, "gpu_ms": med, "csm_caster_masks_ms": casc_ms, "csm_caster_masks_gbs": count * 24.5 / casc_ms / 1e6, "gpu_mentities_per_s": count / med / 1e3, "gpu_hbm_gbs": count * bytes_per_entity / med / 1e6,
             "gpu_hbm_frac": count * bytes_per_entity / med / 1e6 / HBM_PEAK_GBS,
@@ -225,7 +231,7 @@ def mesh_cull_block(ctx, count: int, num_batches: int, steps: int):
     hw, hh, levels = cam.width // 2, cam.height // 2, 11
     raw = torch.from_numpy(synth.make_raw_depth(synth.make_linear_depth(hw, hh, 9, d_min=200.0, d_max=2500.0), cam.frame.cameraZNearZFar[0])).to(ctx.device)
     pyr = hiz_build(ctx, raw, hw, hw, levels)
-    _, hiz_ms, _, _ = event_ms(lambda: hiz_build(ctx, raw, hw, hw, levels), steps)
+    _, hiz_ms, _, _ = side_ms(lambda: hiz_build(ctx, raw, hw, hw, levels), steps)
     t = []
     for _ in range(steps + 3):
         mc.instances.copy_(inst0); mc.batches.copy_(batch0)
@@ -254,8 +260,8 @@ def ibl_prefilter_block(ctx, steps: int):
     ibl = synth.make_ibl_set(16, 16, np.zeros((2, 2, 2), np.float32), env_size=512, with_ao=False)
     raw = torch.from_numpy(ibl.env_chain).to(ctx.device)
     env = prefilter_env_map(ctx, raw, 512, ibl.env_levels)
-    _, pre_ms, _, _ = event_ms(lambda: prefilter_env_map(ctx, raw, 512, ibl.env_levels), steps)
-    _, irr_ms, _, _ = event_ms(lambda: compute_irradiance_map(ctx, env, 512, ibl.env_levels, 32), steps)
+    _, pre_ms, _, _ = side_ms(lambda: prefilter_env_map(ctx, raw, 512, ibl.env_levels), steps)
+    _, irr_ms, _, _ = side_ms(lambda: compute_irradiance_map(ctx, env, 512, ibl.env_levels, 32), steps)
     env_samples = sum(6 * max(512 >> l, 1) ** 2 for l in range(1, ibl.env_levels)) * 1024
     irr_samples = 6 * 32 * 32 * 65536
     small = synth.make_ibl_set(16, 16, np.zeros((2, 2, 2), np.float32), env_size=64, with_ao=False)
@@ -272,9 +278,9 @@ def ibl_prefilter_block(ctx, steps: int):
     gen = torch.Generator(device="cpu").manual_seed(5)
     pano = (torch.rand((1024, 2048, 4), generator=gen, dtype=torch.float32) * 4.0).to(ctx.device)
     raw_env_cubemap(ctx, pano, 512, 10)
-    _, raw_ms, _, _ = event_ms(lambda: raw_env_cubemap(ctx, pano, 512, 10), steps)
+    _, raw_ms, _, _ = side_ms(lambda: raw_env_cubemap(ctx, pano, 512, 10), steps)
     chain_floats = sum(6 * max(512 >> l, 1) ** 2 * 4 for l in range(10))
-    zero_ms = event_ms(lambda: torch.zeros(chain_floats, dtype=torch.float32, device=ctx.device), steps)[1]  # the wrapper's allocation + clear, not the path's
+    zero_ms = side_ms(lambda: torch.zeros(chain_floats, dtype=torch.float32, device=ctx.device), steps)[1]  # the wrapper's allocation + clear, not the path's
     raw_bytes = 2048 * 1024 * 16 + 2 * 6 * 512 * 512 * 16 + (6 * 512 * 512 * 16) // 3
     t0 = time.perf_counter()
     oracle.equirect_to_cube(pano.cpu().numpy(), 512)
@@ -322,15 +328,15 @@ def shadow_pass_block(ctx, count: int, size: int, steps: int, use_coarse: bool =
         def draw(k=k):
             ctx._lib.sailor_hip_raster_depth(ctx.handle, np.ascontiguousarray(sh.lights_matrices[k], np.float32).ctypes.data_as(C_float_p), pos.data_ptr(), tris.data_ptr(), 12,
                                              models.data_ptr(), ids[k].data_ptr(), len(ids_h[k]), size, size, depth[k].data_ptr(), 3, coarse.data_ptr() if coarse is not None else None)  # flags: CLEAR | CULL_BACK (the shadow material, ShadowPrepassNode.cpp:39)
-        _, ms, _, _ = event_ms(draw, steps)
-        _, rs, _, _ = event_ms(lambda k=k: shadow_resolve(ctx, depth[k], L_RGBA32F if k == 0 else L_R16F), steps)
+        _, ms, _, _ = side_ms(draw, steps)
+        _, rs, _, _ = side_ms(lambda k=k: shadow_resolve(ctx, depth[k], L_RGBA32F if k == 0 else L_R16F), steps)
         cover = float((depth[k] > 0).float().mean().item())
         out["cascades"].append({"instances": int(len(ids_h[k])), "triangles": int(len(ids_h[k])) * 12, "raster_ms": ms, "resolve_ms": rs, "covered": cover,
                                 "mtriangles_per_s": len(ids_h[k]) * 12 / ms / 1e3})
         total += ms + rs
     moments = shadow_resolve(ctx, depth[0], L_RGBA32F)
     tmp = torch.empty_like(moments)
-    _, bs, _, _ = event_ms(lambda: evsm_blur(ctx, moments, 2, 5, tmp), steps)
+    _, bs, _, _ = side_ms(lambda: evsm_blur(ctx, moments, 2, 5, tmp), steps)
     out["blur_cascade0_ms"] = bs
     out["all_passes_ms"] = total + bs
     sample = ids_h[3][:: max(1, len(ids_h[3]) // 20000)]
@@ -356,9 +362,9 @@ def linearize_block(ctx, frame, fp, d_lights, steps: int):
     d_lin = torch.empty_like(d_raw)
     for _ in range(3):
         linearize_depth(ctx, cam.frame, d_raw, d_lin)
-    lin_ms = event_ms(lambda: linearize_depth(ctx, cam.frame, d_raw, d_lin), steps)
-    two = event_ms(lambda: (linearize_depth(ctx, cam.frame, d_raw, d_lin), fp.cull(cam.frame, d_lights, N, d_lin)), steps)
-    fused = event_ms(lambda: fp.cull(cam.frame, d_lights, N, d_raw, L.CULL_RAW_DEPTH), steps)
+    lin_ms = side_ms(lambda: linearize_depth(ctx, cam.frame, d_raw, d_lin), steps)
+    two = side_ms(lambda: (linearize_depth(ctx, cam.frame, d_raw, d_lin), fp.cull(cam.frame, d_lights, N, d_lin)), steps)
+    fused = side_ms(lambda: fp.cull(cam.frame, d_lights, N, d_raw, L.CULL_RAW_DEPTH), steps)
     t0 = time.perf_counter()
     oracle.linearize_depth(zn, raw)
     t_cpu = time.perf_counter() - t0
@@ -374,14 +380,14 @@ def ambient_block(ctx, frame, fp, d_lights, d_surface, steps: int):
     textures once (0.7 MB)."""
     from sailor_amd.forward_plus import compute_brdf_lut, upload_ibl
     cam, W, H, N = frame.cam, frame.cam.width, frame.cam.height, len(frame.lights)
-    lut_ms = event_ms(lambda: compute_brdf_lut(ctx, 256, 256), 5)
+    lut_ms = side_ms(lambda: compute_brdf_lut(ctx, 256, 256), 5)
     lut = compute_brdf_lut(ctx, 64, 64).cpu().numpy()
     ibl = synth.make_ibl_set(W, H, lut)
     desc, keep = upload_ibl(ibl, ctx.device)
     for _ in range(3):
         fp.shade(cam.frame, d_surface, d_lights, N, None, ibl=desc)
-    with_ibl = event_ms(lambda: fp.shade(cam.frame, d_surface, d_lights, N, None, ibl=desc), steps)
-    without = event_ms(lambda: fp.shade(cam.frame, d_surface, d_lights, N, None), steps)
+    with_ibl = side_ms(lambda: fp.shade(cam.frame, d_surface, d_lights, N, None, ibl=desc), steps)
+    without = side_ms(lambda: fp.shade(cam.frame, d_surface, d_lights, N, None), steps)
     return {"shade_with_ambient_ms": with_ibl[1], "shade_without_ms": without[1], "extra_bytes_per_pixel": 4,
             "brdf_lut_256x256_ms": lut_ms[1], "kernel": "k2_shade_ibl"}
 
@@ -396,7 +402,7 @@ def blur_block(ctx, steps: int):
     tmp = torch.empty_like(m)
     for _ in range(2):
         evsm_blur(ctx, m, 2, 5, tmp)
-    ms = event_ms(lambda: evsm_blur(ctx, m, 2, 5, tmp), steps)
+    ms = side_ms(lambda: evsm_blur(ctx, m, 2, 5, tmp), steps)
     b = 2 * 32 * S * S
     sample = np.random.default_rng(0).random((512, 512, 4)).astype(np.float32)
     t0 = time.perf_counter()
