@@ -522,6 +522,7 @@ def main():
     if args.simulate_band:
         r_, g_ = (int(v) for v in args.simulate_band.split("/"))
         band = host.band_for_rank(W, H, r_, g_)
+        partition = f"diagnostic: band {r_} of an equal {g_}-way tile-row split, alone on this GPU"
     rows = slice(band.fbRowBegin, band.fbRowBegin + band.fbRowCount)
     fp, d_depth = resident(band)
     d_surface = torch.from_numpy(frame.surface_rows(rows.start, rows.stop)).to(dev)
