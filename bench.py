@@ -7,14 +7,17 @@
 
 One step = one pass of the hot path over one synthetic frame: K0 light view transform + K1 tile light cull + K2 PBR shade
 over the per-tile lists (BASELINE.json configs[2]: 4K, 65 536 point+spot lights, synthetic G-buffer/surface tiles), with
-every input already resident in HBM.  With N > 1 the SAME frame is split into N contiguous tile-row bands, one per rank
-(strong scaling: total work is fixed); cull + shade need no collective on a band partition, so none is in
-the timed region; after timing, the band lists are exchanged once over RCCL (count all-gather + index all-gather) and
-the stitched global buffers are checked against a checksum so the distributed path is exercised end to end.
+every input already resident in HBM.  With N > 1 every rank runs that same step on a whole frame of its own (frames, and the
+tiles inside them, are independent units: per-GPU work is fixed -- weak scaling, no collective on the data path), and
+`value` = N*W*H*K / max-over-ranks(time).  The same invocation then measures the other way of using N GPUs and reports it
+as `split_frame`: ONE frame cut into N cost-balanced tile-row bands (strong scaling); cull + shade need no
+collective there either; after its timed steps the band lists are exchanged once over RCCL (count all-gather + index
+all-gather) and the stitched global buffers are summarised by a checksum, so the distributed path is exercised end to end.
+`--split-frame` swaps the roles (the split frame becomes `value`, a frame per GPU is reported as `alternate_frame_rendering`).
 
-Rank 0 prints ONE JSON line.  `value` = W*H*K / max-over-ranks(time) in Mpixels/s.  `roofline` is for the dominant
-kernel (k2_shade): algorithmic bytes per launch / its average launch duration measured with HIP events
-on the launch stream.  `cpu_baseline` = the CPU oracle (a port: the reference cannot be built here) timed on a bounded
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k2_shade): algorithmic bytes per launch
+/ its launch duration from one HIP event pair around K back-to-back launches on the launch stream.  `cpu_baseline` = the
+CPU oracle (a port: the reference cannot be built here) timed on a bounded
 sample of the same workload on this box's host cores.
 """
 from __future__ import annotations
@@ -60,7 +63,10 @@ def parse():
                     help="2 (the reference's MaxFramesInQueue, RHI/Renderer.h:34): frame k+1's cull is recorded on a second stream beside frame k's shade")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--equal-bands", action="store_true", help="N > 1: equal tile-row bands instead of cost-balanced ones")
-    ap.add_argument("--no-afr", action="store_true", help="N > 1: skip the supplementary alternate-frame-rendering measurement")
+    ap.add_argument("--split-frame", action="store_true",
+                    help="N > 1: make ONE frame split into tile-row bands (strong scaling, latency-bound) the primary measurement; by default every GPU "
+                         "renders whole frames of its own (weak scaling, no data-path collective) and the split frame is reported next to it")
+    ap.add_argument("--no-afr", action="store_true", help="N > 1: skip the supplementary measurement (the other of the two multi-GPU modes)")
     ap.add_argument("--simulate-split", type=int, default=0, help="G: time each band of a cost-balanced G-way split one after the other on this GPU and print the predicted speed-up; diagnostic")
     ap.add_argument("--simulate-band", default=None, help="R/G: time only band R of a G-way split in this single process (no collectives); diagnostic")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the list exchange even with one rank")
@@ -505,7 +511,13 @@ def main():
 
     band = host.band_for_rank(W, H, rank, world)
     partition = "whole frame"
-    if world > 1 and not args.equal_bands:
+    # N > 1, default: the units of the path -- frames, and the tiles inside them -- are independent, so every GPU takes a whole frame per step
+    # (per-GPU work fixed: weak scaling, no collective on the data path).  --split-frame: one frame cut into bands (strong scaling).
+    weak = not args.split_frame
+    if world > 1 and weak:
+        band = host.band_whole_frame(W, H)
+        partition = "one whole frame per GPU and step (frames are independent; no data-path collective)"
+    elif world > 1 and not args.equal_bands:
         # Cost-balanced bands (sailor_amd/dist.py:balanced_tile_rows): one calibration cull on equal bands, all ranks learn
         # every tile row's list volume (a renderer would use the previous frame's), and re-split.  Not in the timed region.
         from sailor_amd import dist as sdist
@@ -636,7 +648,8 @@ def main():
         elapsed = float(t.item())
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = W * H * args.steps / elapsed / 1e6
+    frames_per_step = world if (weak and world > 1) else 1
+    value = frames_per_step * W * H * args.steps / elapsed / 1e6
 
     # ---- per-kernel timing on the launch stream (HIP events) + algorithmic bytes ----
     cull_ms = event_ms(cull, args.steps)
@@ -671,7 +684,7 @@ def main():
     # every GPU its own frame.  Same step (one cull + one shade of the whole frame) on every rank, K steps, max over ranks; reported next
     # to `value`, never instead of it.  Every rank takes part in the collectives below whether or not its own set-up succeeded.
     afr = None
-    if dist is not None and not args.no_afr:
+    if dist is not None and not args.no_afr and not weak:
         ok = 1
         try:
             wf = ForwardPlus(ctx, W, H, N)
@@ -713,8 +726,79 @@ def main():
         else:
             afr = {"error": "set-up failed on some rank"}
 
+    # ---- supplementary in the default (weak) mode: ONE frame split into cost-balanced tile-row bands, one band per GPU -- the strong-scaling reading,
+    # with the RCCL exchange that rebuilds the reference's global lists.  Set-up failures are agreed on by all ranks before any further collective.
+    split = None
+    if dist is not None and not args.no_afr and weak:
+        from sailor_amd import dist as sdist
+
+        def all_ok(flag_value):
+            fl = torch.tensor([flag_value], dtype=torch.int32, device=dev)
+            dist.all_reduce(fl, op=dist.ReduceOp.MIN)
+            return int(fl.item()) == 1
+
+        ok, f0 = 1, None
+        try:
+            b0 = host.band_for_rank(W, H, rank, world)
+            f0, d0 = resident(b0)
+            f0.cull(cam.frame, d_lights, N, d0)
+            torch.cuda.synchronize()
+        except Exception as e:
+            ok = 0
+            print(f"[bench] rank {rank}: split-frame calibration failed ({type(e).__name__}: {e})", file=sys.stderr)
+        if not all_ok(ok):
+            split = {"error": "calibration failed on some rank"}
+        else:
+            rows_entries = sdist.gather_row_entries(f0.grid[: f0.band_tiles * 2], Tx, b0.tileRowEnd - b0.tileRowBegin, Ty, b0.tileRowBegin)
+            bounds = sdist.balanced_tile_rows(rows_entries, Tx, world)
+            del f0, d0
+            ok, bgraph = 1, None
+            try:
+                bb = host.band_from_tile_rows(W, H, bounds[rank], bounds[rank + 1])
+                bf, bd = resident(bb)
+                bs = torch.from_numpy(frame.surface_rows(bb.fbRowBegin, bb.fbRowBegin + bb.fbRowCount)).to(dev)
+
+                def bstep():
+                    bf.cull(cam.frame, d_lights, N, bd)
+                    bf.shade(cam.frame, bs, d_lights, N, csm)
+                bstep(); torch.cuda.synchronize()
+                if not args.no_graph:
+                    try:
+                        bgraph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(bgraph, stream=side):
+                            bstep()
+                    except Exception:
+                        bgraph = None
+                        torch.cuda.synchronize()
+            except Exception as e:
+                ok = 0
+                print(f"[bench] rank {rank}: split-frame set-up failed ({type(e).__name__}: {e})", file=sys.stderr)
+            if not all_ok(ok):
+                split = {"error": "set-up failed on some rank"}
+            else:
+                brun = bgraph.replay if bgraph is not None else bstep
+                for _ in range(max(args.warmup, 20)):
+                    brun()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    brun()
+                barrier()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                split_elapsed = float(t.item())
+                gg, gi = sdist.exchange_lists(bf.grid[: bf.band_tiles * 2], bf.culled)
+                torch.cuda.synchronize()
+                tot = int(gi[0].item())
+                split = {"what": "ONE frame split into cost-balanced tile-row bands, one band per GPU; cull and shade need no collective, an RCCL all-gather "
+                                 "rebuilds the reference's global lists for consumers that want them (outside the timed steps)",
+                         "scaling": "strong", "value": W * H * args.steps / split_elapsed / 1e6, "unit": "Mpixels/s",
+                         "ms_per_step": split_elapsed / args.steps * 1e3, "speedup_vs_one_gpu_whole_frame": ms_per_step / (split_elapsed / args.steps * 1e3),
+                         "tile_row_bounds": [int(b) for b in bounds],
+                         "exchange": {"global_sum_num": tot, "checksum": int(gi[1:1 + tot].to(torch.int64).sum().item()), "tiles": int(gg.numel() // 2)}}
+
     exchange_info = None
-    if dist is not None:
+    if dist is not None and not weak:
         gg, gi = exchange()
         torch.cuda.synchronize()
         tot = int(gi[0].item())
@@ -724,10 +808,10 @@ def main():
         out = {
             "metric": "lit Mpixels/s (K0+K1 tile light cull + K2 PBR shade over per-tile lists)", "value": value, "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_ms": args.spinup_ms, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "launch": "hipGraph replay, 2 frames in flight" if pipelined else ("hipGraph replay" if graph is not None else "eager"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if weak else "strong", "launch": "hipGraph replay, 2 frames in flight" if pipelined else ("hipGraph replay" if graph is not None else "eager"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H}, {N} point+spot lights, 16x16 tiles ({fp.Tx}x{fp.Ty}), cull + PBR shade"
                                    + (" + 4-cascade CSM" if csm is not None else ""),
-                       "width": W, "height": H, "lights": N, "parallelism": f"tile-row bands x{world}", "partition": partition,
+                       "width": W, "height": H, "lights": N, "parallelism": (f"dp{world}: a whole frame per GPU" if weak else f"tile-row bands x{world}"), "partition": partition,
                        "mean_list_length": sum_nt / max(fp.band_tiles, 1), "sum_num_rank0_band": sum_nt, "distinct_lights_rank0_band": distinct,
                        "generator": {"seed": synth.SEED, "radius_scale": frame.cfg["lights"].radius_scale}},
             "mlights_culled_per_s": N / (cull_batch_ms * 1e-3) / 1e6,
@@ -738,6 +822,8 @@ def main():
             out["exchange"] = exchange_info
         if afr:
             out["alternate_frame_rendering"] = afr
+        if split:
+            out["split_frame"] = split
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frame, args.cpu_sample_tile_rows)
             out["ecs_sweep"] = ecs_baseline(ctx, 1 << 20, 20)
