@@ -1,0 +1,51 @@
+"""bench.py's output contract on a real device: one JSON line with the driver's keys, the `roofline` and `cpu_baseline` objects, and -- with a one-rank
+RCCL process group -- both multi-GPU modes (a frame per GPU as `value`, the split frame + list exchange next to it)."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _run(cmd, env=None):
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line"
+    return json.loads(lines[0])
+
+
+def test_default_line_carries_the_contract():
+    d = _run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--spinup-ms", "50", "--cpu-sample-tile-rows", "4"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in d, key
+    assert d["unit"] == "Mpixels/s" and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and d["scaling"] in ("weak", "strong")
+    assert d["config"]["workload"].startswith("C3: 3840x2160, 65536 ") and "model" not in d["config"]
+    assert abs(d["value"] - 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k2_shade"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.05 < r["frac"] < 1.0
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] > 0.9 * r["bytes_per_launch"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Mpixels/s" and c["value"] > 0 and "tile rows" in c["sample"]
+    for block in ("ecs_sweep", "mesh_cull_compact", "linearize_depth", "ambient_ibl", "evsm_blur", "ibl_prefilter", "shadow_passes"):
+        assert block in d, block
+
+
+@pytest.mark.parametrize("split_primary", [False, True])
+def test_one_rank_process_group_runs_both_multi_gpu_modes(split_primary):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--steps", "5", "--warmup", "2", "--spinup-ms", "50", "--no-cpu-baseline"]
+    d = _run(cmd + (["--split-frame"] if split_primary else []), env)
+    assert d["scaling"] == ("strong" if split_primary else "weak")
+    other = d["alternate_frame_rendering"] if split_primary else d["split_frame"]
+    assert other["scaling"] == ("weak" if split_primary else "strong") and other["value"] > 0 and "error" not in other
+    ex = d["exchange"] if split_primary else d["split_frame"]["exchange"]
+    assert ex["tiles"] == 240 * 135 and ex["global_sum_num"] == d["config"]["sum_num_rank0_band"] and ex["checksum"] > 0
