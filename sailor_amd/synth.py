@@ -528,3 +528,22 @@ def make_world_text(name: str, prefabs: list) -> str:
                     out.append(f"          {key}: {val}\n")
             out.append("          fileId: NullFileId\n")
     return "".join(out)
+
+
+def make_triangle_soup(count: int, seed: int = SEED):
+    """A deterministic triangle soup around an eye at the origin looking down -Z (positions float32 [3 * count, 3], indices uint32 [count, 3]): sizes over
+    three decades, a part of it across the near plane z = -0.1 and behind the eye, some vertices exactly on the plane / at w = 0 -- the rasteriser's clip cases."""
+    u = uniforms(STREAM_ENTITIES, count * 16, 7, seed).reshape(count, 16).astype(np.float64)
+    centre = np.stack([6 * u[:, 0] - 3, 6 * u[:, 1] - 3, 9.5 * u[:, 2] - 8.0], axis=1)[:, None, :]
+    extent = (10.0 ** (2.7 * u[:, 3] - 2.0))[:, None, None]
+    verts = (centre + (2 * u[:, 4:13].reshape(count, 3, 3) - 1) * extent).astype(np.float32)
+    verts[::41, :, 2] = np.float32(-0.1)
+    verts[7::53, 0, 2] = np.float32(0.0)
+    return np.ascontiguousarray(verts.reshape(-1, 3)), np.arange(3 * count, dtype=np.uint32).reshape(count, 3)
+
+
+def perspective_reversed_z(width: int, height: int, near: float = 0.1, f: float = 1.0) -> np.ndarray:
+    """column-major float32[16]: reversed Z, infinite far plane, looking down -Z (w = -z, ndc z = near / -z)"""
+    m = np.zeros(16, np.float32)
+    m[0], m[5], m[2 * 4 + 3], m[3 * 4 + 2] = f * height / width, f, -1.0, near
+    return m

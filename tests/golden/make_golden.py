@@ -98,6 +98,18 @@ def make_prefilter() -> None:
     print(f"tiny_prefilter: env {env.size // 4} texels, irradiance mean {irr[..., :3].mean():.4f}")
 
 
+def make_raster() -> None:
+    """The canonical depth rasteriser: 1 500 triangles around the eye through a reversed-Z perspective matrix -- near-plane
+    cuts, back-face culling on and off -- at 96 x 64."""
+    pos, idx = synth.make_triangle_soup(1500)
+    P = synth.perspective_reversed_z(96, 64)
+    one = np.eye(4, dtype=np.float32).reshape(1, 16)
+    both = oracle.raster_depth(P, pos, idx, one, 96, 64)
+    front = oracle.raster_depth(P, pos, idx, one, 96, 64, cull_back=True)
+    np.savez_compressed(OUT / "tiny_raster.npz", both=both, front=front, soup_checksum=np.float64(pos.astype(np.float64).sum()))
+    print(f"tiny_raster: covered {float((both > 0).mean()):.3f} / {float((front > 0).mean()):.3f} (front faces only)")
+
+
 if __name__ == "__main__":
     for n in ("tiny", "tiny_csm"):
         make(n)
@@ -106,3 +118,4 @@ if __name__ == "__main__":
     make_blur()
     make_mesh_cull()
     make_prefilter()
+    make_raster()

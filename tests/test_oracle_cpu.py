@@ -502,3 +502,18 @@ def test_rasteriser_cuts_triangles_at_the_near_plane():
     b = oracle.raster_depth(P, pos, idx[:, ::-1], one, W, H, cull_back=True)
     assert ((a > 0).sum() == 0) != ((b > 0).sum() == 0)
     np.testing.assert_array_equal(np.maximum(a, b), depth)
+
+
+def test_raster_golden():
+    """tests/golden/tiny_raster.npz: the canonical rasteriser (fill rule, snapping, near-plane cut, back-face rule) reproduces its committed depth images
+    from the regenerated soup -- bit for bit: every operation on the way is a single correctly rounded fp32 / integer operation."""
+    g = np.load(GOLDEN / "tiny_raster.npz")
+    pos, idx = synth.make_triangle_soup(1500)
+    assert float(pos.astype(np.float64).sum()) == float(g["soup_checksum"])
+    d = pos.reshape(-1, 3, 3)[..., 2] * -1.0 - 0.1
+    assert ((d >= 0).any(axis=1) & (d < 0).any(axis=1)).sum() > 50, "triangles across the near plane"
+    P = synth.perspective_reversed_z(96, 64)
+    one = np.eye(4, dtype=np.float32).reshape(1, 16)
+    np.testing.assert_array_equal(oracle.raster_depth(P, pos, idx, one, 96, 64).view(np.uint32), g["both"].view(np.uint32))
+    np.testing.assert_array_equal(oracle.raster_depth(P, pos, idx, one, 96, 64, cull_back=True).view(np.uint32), g["front"].view(np.uint32))
+    assert (g["both"] != g["front"]).any() and float((g["both"] > 0).mean()) > 0.5

@@ -267,3 +267,17 @@ def test_triangles_through_the_near_plane_and_behind_the_eye(ctx, size):
     got = raster_depth_camera(ctx, cam.frame, torch.from_numpy(world).to(ctx.device), d_idx, d_one, cam.width, cam.height)
     ctx.synchronize()
     np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_golden_fixture_through_the_c_abi(ctx):
+    """tests/golden/tiny_raster.npz: the committed oracle depth images of the near-plane soup, from the GPU, bit for bit."""
+    from pathlib import Path
+    g = np.load(Path(__file__).resolve().parent / "golden" / "tiny_raster.npz")
+    pos, idx = synth.make_triangle_soup(1500)
+    P = synth.perspective_reversed_z(96, 64)
+    d_pos, d_idx = torch.from_numpy(pos).to(ctx.device), torch.from_numpy(idx.view(np.int32).copy()).to(ctx.device)
+    d_one = torch.from_numpy(IDENTITY.reshape(1, 16).copy()).to(ctx.device)
+    for key, cull in (("both", False), ("front", True)):
+        got = raster_depth(ctx, P, d_pos, d_idx, d_one, 96, 64, cull_back=cull)
+        ctx.synchronize()
+        np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), g[key].view(np.uint32))
