@@ -330,6 +330,7 @@ __device__ __forceinline__ uint64_t lanemask_lt()
 // per-tile scalar version saturated the CUs' scalar ALUs; a per-group scalar version was tail-bound by cluster groups).
 // ------------------------------------------------------------------------------------------------------------
 #define LDS_K1_GROUP_LISTS 16
+#define GL_WPT 4 // words per thread and round in k1_group_lists
 __device__ __forceinline__ void k1_group_lists_body(const unsigned bx, unsigned char* __restrict__ lds, const unsigned long long* __restrict__ masks,
                                                     const unsigned long long* __restrict__ dirWords, int words, int Tx, int bandRows, int groupsX,
                                                     uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList)
@@ -340,15 +341,33 @@ __device__ __forceinline__ void k1_group_lists_body(const unsigned bx, unsigned 
     const unsigned long long* __restrict__ r = masks + (size_t)(groupsX + g / groupsX) * words;
     uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
     uint32_t base = 0; // entries written by earlier chunks (block-uniform)
-    for (int w0 = 0; w0 < words; w0 += 256) {
-        const int w = w0 + threadIdx.x;
-        unsigned long long m = 0ull, dm = 0ull;
-        if (w < words) {
-            m = c[w] & r[w];
-            dm = dirWords[w];
+    // GL_WPT consecutive words per thread and round: one block-wide scan (and its two barriers) per 256 * GL_WPT words -- at 1 M lights a group walks
+    // 16 384 words, and the scan, not the 24 bytes per word, was what a round cost
+    for (int w0 = 0; w0 < words; w0 += 256 * GL_WPT) {
+        const int wFirst = w0 + (int)threadIdx.x * GL_WPT;
+        unsigned long long m[GL_WPT], dm[GL_WPT];
+        uint32_t cnt = 0;
+        if (wFirst + GL_WPT <= words && (words & 3) == 0) { // 32 contiguous bytes per thread and array: two 16-byte loads each, coalesced across the wave
+            const ulonglong2* c2 = reinterpret_cast<const ulonglong2*>(c + wFirst);
+            const ulonglong2* r2 = reinterpret_cast<const ulonglong2*>(r + wFirst);
+            const ulonglong2* d2 = reinterpret_cast<const ulonglong2*>(dirWords + wFirst);
+            const ulonglong2 ca = c2[0], cb = c2[1], ra = r2[0], rb = r2[1], da = d2[0], db = d2[1];
+            m[0] = ca.x & ra.x; m[1] = ca.y & ra.y; m[2] = cb.x & rb.x; m[3] = cb.y & rb.y;
+            dm[0] = da.x; dm[1] = da.y; dm[2] = db.x; dm[3] = db.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < GL_WPT; j++) {
+                const int w = wFirst + j;
+                m[j] = 0ull; dm[j] = 0ull;
+                if (w < words) {
+                    m[j] = c[w] & r[w];
+                    dm[j] = dirWords[w];
+                }
+            }
         }
+#pragma unroll
+        for (int j = 0; j < GL_WPT; j++) cnt += (uint32_t)__popcll(m[j]);
         // block-wide exclusive prefix sum of the popcounts: word order == light order
-        const uint32_t cnt = (uint32_t)__popcll(m);
         uint32_t incl = cnt;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -361,12 +380,17 @@ __device__ __forceinline__ void k1_group_lists_body(const unsigned bx, unsigned 
 #pragma unroll
         for (int k = 0; k < 4; k++) { const uint32_t v = sW[k]; before += (k < wave) ? v : 0u; total += v; }
         uint32_t pos = base + before + incl - cnt;
-        const uint32_t first = (uint32_t)w * 64u;
-        while (m != 0ull) { // this word's set bits, ascending
-            const int bit = __builtin_ctzll(m);
-            m &= m - 1ull;
-            if (pos < CAPG) list[pos] = (first + (uint32_t)bit) | (uint32_t)((dm >> bit) & 1ull) << 31; // bit 31 = directional
-            pos++;
+#pragma unroll
+        for (int j = 0; j < GL_WPT; j++) {
+            const uint32_t first = (uint32_t)(wFirst + j) * 64u;
+            unsigned long long mm = m[j];
+            const unsigned long long dd = dm[j];
+            while (mm != 0ull) { // this word's set bits, ascending
+                const int bit = __builtin_ctzll(mm);
+                mm &= mm - 1ull;
+                if (pos < CAPG) list[pos] = (first + (uint32_t)bit) | (uint32_t)((dd >> bit) & 1ull) << 31; // bit 31 = directional
+                pos++;
+            }
         }
         base += total;
         __syncthreads();
