@@ -347,13 +347,16 @@ __device__ __forceinline__ void k1_group_lists_body(const unsigned bx, unsigned 
         const int wFirst = w0 + (int)threadIdx.x * GL_WPT;
         unsigned long long m[GL_WPT], dm[GL_WPT];
         uint32_t cnt = 0;
-        if (wFirst + GL_WPT <= words && (words & 3) == 0) { // 32 contiguous bytes per thread and array: two 16-byte loads each, coalesced across the wave
+        if (wFirst + GL_WPT <= words && (words & (GL_WPT - 1)) == 0) { // 8 * GL_WPT contiguous bytes per thread and array as 16-byte loads, coalesced across the wave
             const ulonglong2* c2 = reinterpret_cast<const ulonglong2*>(c + wFirst);
             const ulonglong2* r2 = reinterpret_cast<const ulonglong2*>(r + wFirst);
             const ulonglong2* d2 = reinterpret_cast<const ulonglong2*>(dirWords + wFirst);
-            const ulonglong2 ca = c2[0], cb = c2[1], ra = r2[0], rb = r2[1], da = d2[0], db = d2[1];
-            m[0] = ca.x & ra.x; m[1] = ca.y & ra.y; m[2] = cb.x & rb.x; m[3] = cb.y & rb.y;
-            dm[0] = da.x; dm[1] = da.y; dm[2] = db.x; dm[3] = db.y;
+#pragma unroll
+            for (int j = 0; j < GL_WPT / 2; j++) {
+                const ulonglong2 cv = c2[j], rv = r2[j], dv = d2[j];
+                m[2 * j] = cv.x & rv.x; m[2 * j + 1] = cv.y & rv.y;
+                dm[2 * j] = dv.x; dm[2 * j + 1] = dv.y;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < GL_WPT; j++) {
