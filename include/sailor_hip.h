@@ -213,6 +213,9 @@ SAILOR_HIP_API int sailor_hip_band_whole_frame(int32_t width, int32_t height, Sa
 SAILOR_HIP_API int sailor_hip_band_from_tile_rows(int32_t width, int32_t height, int32_t tileRowBegin, int32_t tileRowEnd, SailorBand* outBand);
 /* contiguous tile-row bands: rank g of G gets rows [floor(g*Ty/G), floor((g+1)*Ty/G)) */
 SAILOR_HIP_API int sailor_hip_band_for_rank(int32_t width, int32_t height, int32_t rank, int32_t worldSize, SailorBand* outBand);
+/* 1 if `band` is a run of whole tile rows of a width x height frame with the matching framebuffer rows (what the three helpers above
+ * produce), else 0.  Every band entry point refuses anything else. */
+SAILOR_HIP_API int sailor_hip_band_is_valid(int32_t width, int32_t height, const SailorBand* band);
 
 /* ---- K0 + K1: tile light cull ---------------------------------------------------------------------------
  * Replaces: the Dispatch recorded by LightCullingNode::Process (FrameGraph/LightCullingNode.cpp:74-77) and the
@@ -225,8 +228,10 @@ SAILOR_HIP_API int sailor_hip_band_for_rank(int32_t width, int32_t height, int32
  *   dLightsGrid    : device out, one SailorLightsGrid per tile OF THE BAND (band-local tile index
  *                    (ty - tileRowBegin)*Tx + tx); offset is band-local: 1 + sum of num over earlier band tiles
  *   dCulledLights  : device out, uint32: [0] = sum of num over the band, [offset+i] = i-th light of the tile;
- *                    capacity culledCapacity uints, needs 1 + bandTiles*128 (the reference allocates one short,
- *                    LightCullingNode.cpp:64)
+ *                    capacity culledCapacity uints: 1 + bandTiles*128 holds every possible result.  The reference allocates
+ *                    bandTiles*128 (one short, LightCullingNode.cpp:64): that size is accepted, and a list that does not
+ *                    fit is cut -- lightsGrid[tile].num and [0] then say what was written, so a consumer never reads past
+ *                    the buffer; anything smaller is SAILOR_HIP_ERR_INVALID_ARGUMENT
  *   dWorkspace     : device scratch of at least sailor_hip_light_cull_workspace_size(...) bytes
  *   flags          : SAILOR_CULL_* bits
  * For the whole-frame band the outputs ARE the reference's `lightsGrid` / `culledLights` buffers.
@@ -246,16 +251,16 @@ SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
                                          void* dWorkspace, size_t workspaceBytes,
                                          const SailorBand* band, uint32_t flags);
 
-/* Shading-order hint.  sailor_hip_light_cull also leaves, in its workspace, the band's tiles ordered by list length class (>= 96, >= 40,
- * rest; tile order inside a class), each as tileX | tileRowInBand << 16, followed by one more word: the number of tiles in the first two
- * classes.  A band of a split frame is a round or two of blocks, so its longest tile is its duration, and a tile in the middle of a light
- * cluster keeps one block busy ~100x longer than an average one.  Handing this pointer to sailor_hip_shade_ex (band smaller than the
- * frame, no shadow maps, no ambient term) makes the launch give the tiles of the first two classes to "split" blocks -- one per (tile,
- * 8x8 quadrant), four waves sharing the quadrant's list -- at the front of the grid.  Lists and every tile with < 40 lights keep their
- * bits; a split tile's radiance differs from the one-block form by the order of four partial sums per pixel (within the shade tolerance).
- * With shadow maps or the ambient term the hint only reorders the launch.  Produced for split frames only (on the whole frame neither
- * the order nor the split measured a gain): NULL for the whole-frame band and on bad arguments.  Valid until the next
- * sailor_hip_light_cull on the same workspace. */
+/* Shading hint.  sailor_hip_light_cull also leaves, in its workspace, the band's LONG tiles as an array of T + 2 words (T = tiles of the
+ * band), each tile as tileX | tileRowInBand << 16: the nA tiles with >= 96 lights at [0, nA), the nB tiles with 40..95 lights at
+ * [T-1], [T-2], ... (both in tile order), then [T] = nA and [T+1] = nB.  A band of a split frame is a round or two of blocks, so its longest
+ * tile is its duration, and a tile in the middle of a light cluster keeps one block busy ~100x longer than an average one.  Handing this
+ * pointer to sailor_hip_shade_ex (band smaller than the frame, no shadow maps, no ambient term) makes the launch give those tiles to
+ * "split" blocks -- one per (tile, 8x8 quadrant), four waves sharing the quadrant's list -- at the front of the grid.  Lists and every
+ * tile with < 40 lights keep their bits; a split tile's radiance differs from the one-block form by the order of four partial sums per
+ * pixel (within the shade tolerance).  With shadow maps or the ambient term the hint is ignored.  Produced for split frames only (on the
+ * whole frame the split measured no gain): NULL for the whole-frame band, for bands of more than 65 535 tiles and on bad arguments.
+ * Valid until the next sailor_hip_light_cull on the same workspace. */
 SAILOR_HIP_API const uint32_t* sailor_hip_light_cull_tile_order(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band,
                                                                 const void* dWorkspace);
 

@@ -100,6 +100,7 @@ SIGNATURES = {
     "sailor_hip_band_whole_frame": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(Band)]),
     "sailor_hip_band_from_tile_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band)]),
     "sailor_hip_band_for_rank": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band)]),
+    "sailor_hip_band_is_valid": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(Band)]),
     "sailor_hip_light_cull_workspace_size": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band)]),
     "sailor_hip_light_cull": (C.c_int, [_P, C.POINTER(UboFrameData), C.POINTER(LightCullPushConstants), _P, _P, _P, _P, C.c_size_t,
                                         _P, C.c_size_t, C.POINTER(Band), C.c_uint32]),

@@ -4,24 +4,31 @@
 // LightCullingNode::Process (FrameGraph/LightCullingNode.cpp:74-77), under the canonical sequential semantics of
 // SURVEY.md Appendix A.  Not a translation of the GLSL: the reference runs one 16x16 workgroup per tile that
 // re-reads and re-transforms every light, appends with LDS atomics, bubble-sorts on one thread and allocates
-// output space with a global atomic.  Here:
+// output space with a global atomic.  Here, four launches:
 //
-//   (k01_prepare runs the next two in one launch: they are independent)
-//   k0_light_view      once per light: view-space position + radius into a float4 SoA (same fp32 op sequence as
-//                      ComputeLightCulling.shader:164-169, so bits are identical), light type into a u32 SoA
-//   k1_tile_setup      streaming pass over the linear-depth image (the only large HBM stream of the cull):
-//                      16 tiles per 256-thread block, 1 KiB coalesced float4 row segments, wave shuffles + a
-//                      4-entry LDS combine for min/max, then 16 lanes build the 16 tile frusta
-//   k1_band_masks      conservative pre-filter as BITMASKS: one 64-bit ballot per (64 lights, column of 4x4-tile groups)
-//                      and per (64 lights, row of groups): "this light's sphere may reach this 64-pixel band".  Pure
-//                      streaming, no atomics, no compaction, no inter-block order: 3 MB of masks at 4K / 65 536 lights
+//   k01_prepare        two independent roles in one launch.
+//                      lights : once per light, view-space position + radius into a float4 SoA (same fp32 op sequence as
+//                               ComputeLightCulling.shader:164-169, so bits are identical), then -- same wave, the record
+//                               still in registers -- the conservative pre-filter as BITMASKS: one 64-bit ballot per
+//                               (64 lights, column of 4x4-tile groups) and per (64 lights, row of groups): "this light's
+//                               sphere may reach this 64-pixel band".  No atomics, no compaction, no inter-block order.
+//                      tiles  : streaming pass over the linear-depth image (the only large HBM stream of the cull):
+//                               16 tiles per 256-thread block, 1 KiB coalesced float4 row segments, wave shuffles + a
+//                               4-entry LDS combine for min/max; 16 lanes build the 16 tile frusta while the loads fly
 //   k1_group_lists     one block per 4x4-tile group: (its column's mask) AND (its row's mask), 16 384 lights per
 //                      step; the few surviving bits become an ordered, contiguous candidate list (ballot, readlane, mbcnt)
-//   k1_tile_cull       one 256-thread block per 2x2 quarter of a group, one wave per tile: the group's candidate records
-//                      are staged in LDS 1024 at a time, each wave streams them through the exact test, 64 per step;
-//                      ballot/popcount ordered append; rank-based nearest-128 selection
-//                      (groups denser than 2048 candidates fall back to walking the two masks of the tile itself)
-//   k1_block_sums / k1_pack  canonical offsets = prefix sum over tiles in tile-index order, then compaction
+//   k1_tile_cull       one 256-thread block per run of four tiles of a tile row (= one row of a group), one wave per tile:
+//                      the group's candidate records are staged in LDS 512 at a time, each wave streams them through the
+//                      exact test, 64 per step; ballot/popcount ordered append; rank-based nearest-128 selection
+//                      (groups denser than 2048 candidates fall back to walking the two masks of the tile itself).
+//                      Blocks are numbered in TILE-INDEX order and leave their four lists back to back in a 512-entry
+//                      staging slot, plus one word of totals per block
+//   k1_pack            canonical offsets (Appendix A step 6: prefix sum of the list lengths in tile order) and compaction
+//                      in ONE streaming launch without a scan chain: a pack block owns 16 consecutive staging slots and
+//                      simply adds up the totals of every slot before them (16 KB of L2 reads on average at 4K), then
+//                      copies its slots to their final place as contiguous runs.  (Tried first: a decoupled look-back inside
+//                      k1_tile_cull -- bit-exact, but every block then sits behind 1-2 more memory-side round trips and
+//                      waits, holding its CU slot, for the slowest block before it: 95 us instead of 33.)
 //
 // Bit-exactness: the pre-filter only ever removes lights that every tile of the column (row) would reject by its own
 // left/right (top/bottom) plane: the band's planes are the same planes through the eye (screen x = const, resp.
@@ -34,18 +41,22 @@
 #include "common.h"
 #include <vector>
 
-#define BANDS_PER_GROUP 24   // group columns / rows handled per k1_band_masks wave (grid.y = ceil(bands / 24))
-#define QCAP 128             // LDS candidate queue of k1_tile_cull (ring buffer: < 64 pending + <= 64 new)
-#define SCAN_BLOCK 1024      // tiles per k1_block_sums block
+#define BANDS_PER_BLOCK 24   // group columns / rows whose masks one light block of k01_prepare builds
+#define QCAP 128             // LDS candidate queue of the overflow path of k1_tile_cull (ring buffer: < 64 pending + <= 64 new)
 #define GROUP 4              // k1_group_lists: tiles per group edge (4x4 tiles share one candidate list)
 #define CAPG 2048            // entries per group list; a denser group falls back to walking the masks per tile
 #define GROUP_OVERFLOW 0xFFFFFFFFu
 #define CHUNK 512            // group candidates staged in LDS per step of k1_tile_cull (16 KB of LDS per block: 8 blocks per CU)
 
+#define SLOT 512             // staging entries per k1_tile_cull block (4 tiles x KEEP)
+#define PACK_BLOCKS 16       // staging slots per k1_pack block
+
+// Totals of one k1_tile_cull block: list entries (uint32) and, for the shading hint, class A tiles << 16 | class B tiles (uint32)
+#define CLS_MAX_TILES 65535
+
 struct CullLayout {
-    int Tx, Ty, bandRows, bandTiles, numBands, words, sumBlocks, groupsX, groupsY, numGroups;
-    size_t offLightView, offLightType, offTileInfo, offBandPlanes, offMasks, offDirWords, offTileNum, offTilePrefix, offTileList, offBlockSums, offGroupCount, offGroupList,
-        offClassPrefix, offClassSums, offTileOrder, total;
+    int Tx, Ty, bandRows, bandTiles, numBands, words, groupsX, groupsY, numGroups, cullBlocks, packBlocks;
+    size_t offLightView, offLightType, offTileInfo, offMasks, offDirWords, offGroupCount, offGroupList, offTotals, offClsTotals, offTileNum, offStaging, offTileOrder, total;
 };
 
 static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
@@ -59,28 +70,27 @@ static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
     if (L.words < 1) L.words = 1;
     const size_t n = (size_t)(N > 0 ? N : 1);
     const size_t tiles = (size_t)(L.bandTiles > 0 ? L.bandTiles : 1);
-    L.sumBlocks = (int)((tiles + SCAN_BLOCK - 1) / SCAN_BLOCK);
     L.groupsX = (L.Tx + GROUP - 1) / GROUP;
     L.groupsY = (L.bandRows + GROUP - 1) / GROUP;
     L.numGroups = L.groupsX * L.groupsY;
     L.numBands = L.groupsX + L.groupsY;      // group columns first, then the band's group rows (4 tiles wide / high)
+    L.cullBlocks = L.groupsX * L.bandRows;   // one k1_tile_cull block per (group column, tile row)
+    L.packBlocks = (L.cullBlocks + PACK_BLOCKS - 1) / PACK_BLOCKS;
     const size_t groups = (size_t)(L.numGroups > 0 ? L.numGroups : 1);
     size_t o = 0;
     L.offLightView = o; o = align_up(o + n * 16, 256);
     L.offLightType = o; o = align_up(o + n * 4, 256);
     L.offTileInfo = o; o = align_up(o + tiles * 64, 256);
-    L.offBandPlanes = o; o = align_up(o + (size_t)(L.numBands > 0 ? L.numBands : 1) * 32, 256);
     L.offMasks = o; o = align_up(o + (size_t)(L.numBands > 0 ? L.numBands : 1) * L.words * 8, 256);
     L.offDirWords = o; o = align_up(o + (size_t)L.words * 8, 256);
-    L.offTileNum = o; o = align_up(o + tiles * 4, 256);
-    L.offTilePrefix = o; o = align_up(o + tiles * 4, 256);
-    L.offTileList = o; o = align_up(o + tiles * KEEP * 4, 256);
-    L.offBlockSums = o; o = align_up(o + (size_t)L.sumBlocks * 4, 256);
     L.offGroupCount = o; o = align_up(o + groups * 4, 256);
     L.offGroupList = o; o = align_up(o + groups * CAPG * 4, 256);
-    L.offClassPrefix = o; o = align_up(o + tiles * 4, 256);
-    L.offClassSums = o; o = align_up(o + (size_t)L.sumBlocks * 4, 256);
-    L.offTileOrder = o; o = align_up(o + (tiles + 1) * 4, 256); // + the number of class A and B tiles
+    const size_t cb = (size_t)(L.cullBlocks > 0 ? L.cullBlocks : 1);
+    L.offTotals = o; o = align_up(o + (cb + PACK_BLOCKS) * 4, 256);
+    L.offClsTotals = o; o = align_up(o + (cb + PACK_BLOCKS) * 4, 256);
+    L.offTileNum = o; o = align_up(o + tiles * 4, 256);
+    L.offStaging = o; o = align_up(o + cb * SLOT * 4, 256);
+    L.offTileOrder = o; o = align_up(o + (tiles + 2) * 4, 256); // long tiles (A from the front, B from the back) + their two counts
     L.total = o;
     return L;
 }
@@ -127,46 +137,87 @@ __device__ void frustum_from_rect(const Mat4& invProj, float x0, float y0, float
     f.cy = vs[4][1];
 }
 
+// One launch for the two independent preparation passes: blocks [0, lightRoleBlocks) transform the lights and build the band
+// masks (K0 + K1b: latency / ALU work, dispatched first so that it runs beside the stream), the rest stream the depth image (K1a).
+struct PrepareArgs {
+    Mat4 view, invProj;
+    const SailorLightShaderData* lights;
+    const float* depth;
+    float4* lightView; uint32_t* lightType; float4* tileInfo;
+    unsigned long long* masks; unsigned long long* dirWords;
+    int N, words, lightBlocks, lightRoleBlocks, bandsPerBlock, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands,
+        stripsPerRow, vecOK, rawDepth;
+    float zNearCam, planeMargin;
+};
+
 // ------------------------------------------------------------------------------------------------------------
-// K0: ComputeLightCulling.shader:164-169 hoisted out of the per-tile loop (it does not depend on the tile).
-// The tail blocks of the same launch build the conservative band planes (one thread per column / row of tile groups).
+// K0: ComputeLightCulling.shader:164-169 hoisted out of the per-tile loop (it does not depend on the tile), and
+// K1b: the band masks.  masks[b][word] bit k = "light 64*word + k may reach group column / group row b".
+// A light is dropped from a band only if its sphere is entirely in front of the eye AND entirely outside one of the
+// band's two planes by more than the margin; directional lights and everything doubtful stay in.
+// The block first builds the planes of its <= BANDS_PER_BLOCK bands (one thread per band; planes through the eye and the
+// screen lines x = 64 b, x = 64 (b + 1), resp. y): ~1 us, hidden behind the depth stream of the other role.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void k0_light_view(int block, const Mat4& view, const SailorLightShaderData* __restrict__ lights, int N, int lightBlocks,
-                                              float4* __restrict__ lightView, uint32_t* __restrict__ lightType,
-                                              const Mat4& invProj, int vpW, int vpH, int Tx, int Ty, int tileRow0, int bandRows, int groupsX, int numBands,
-                                              float4* __restrict__ bandPlanes)
+__device__ __forceinline__ void k0_lights(const int lb, unsigned char* __restrict__ lds, const PrepareArgs& a)
 {
-    if (block >= lightBlocks) {
-        const int b = (block - lightBlocks) * 256 + threadIdx.x;
-        if (b >= numBands) return;
+    float4* sPl = reinterpret_cast<float4*>(lds); // [2 * BANDS_PER_BLOCK]
+    const int wordBlock = lb % a.lightBlocks, split = lb / a.lightBlocks;
+    const int b0 = split * a.bandsPerBlock;
+    const int nb = min(a.bandsPerBlock, a.numBands - b0); // <= 0: no pre-filter (brute-force walk)
+    if ((int)threadIdx.x < nb) {
+        const int b = b0 + (int)threadIdx.x;
         Frustum4 f;
-        if (b < groupsX) { // group column b (tile columns 4b .. 4b+3): planes through the eye and the screen lines x = 64 b, x = 64 (b + 1)
-            frustum_from_rect(invProj, (float)(b * GROUP * TILE), 0.0f, (float)(min((b + 1) * GROUP, Tx) * TILE), (float)(Ty * TILE), vpW, vpH, f);
-            bandPlanes[2 * b + 0] = make_float4(f.n[0][0], f.n[0][1], f.n[0][2], 0.0f);
-            bandPlanes[2 * b + 1] = make_float4(f.n[1][0], f.n[1][1], f.n[1][2], 0.0f);
-        } else {           // group row: the band's tile rows 4 gy .. 4 gy + 3
-            const int gy = b - groupsX;
-            const int ty = tileRow0 + gy * GROUP, tyEnd = tileRow0 + min((gy + 1) * GROUP, bandRows);
-            frustum_from_rect(invProj, 0.0f, (float)(ty * TILE), (float)(Tx * TILE), (float)(tyEnd * TILE), vpW, vpH, f);
-            bandPlanes[2 * b + 0] = make_float4(f.n[2][0], f.n[2][1], f.n[2][2], 0.0f);
-            bandPlanes[2 * b + 1] = make_float4(f.n[3][0], f.n[3][1], f.n[3][2], 0.0f);
+        if (b < a.groupsX) { // group column b (tile columns 4b .. 4b+3)
+            frustum_from_rect(a.invProj, (float)(b * GROUP * TILE), 0.0f, (float)(min((b + 1) * GROUP, a.Tx) * TILE), (float)(a.Ty * TILE), a.vpW, a.vpH, f);
+            sPl[2 * threadIdx.x + 0] = make_float4(f.n[0][0], f.n[0][1], f.n[0][2], 0.0f);
+            sPl[2 * threadIdx.x + 1] = make_float4(f.n[1][0], f.n[1][1], f.n[1][2], 0.0f);
+        } else {             // group row: the band's tile rows 4 gy .. 4 gy + 3
+            const int gy = b - a.groupsX;
+            const int ty = a.tileRow0 + gy * GROUP, tyEnd = a.tileRow0 + min((gy + 1) * GROUP, a.bandRows);
+            frustum_from_rect(a.invProj, 0.0f, (float)(ty * TILE), (float)(a.Tx * TILE), (float)(tyEnd * TILE), a.vpW, a.vpH, f);
+            sPl[2 * threadIdx.x + 0] = make_float4(f.n[2][0], f.n[2][1], f.n[2][2], 0.0f);
+            sPl[2 * threadIdx.x + 1] = make_float4(f.n[3][0], f.n[3][1], f.n[3][2], 0.0f);
         }
-        return;
     }
-    const int j = block * 256 + threadIdx.x;
-    if (j >= N) return;
-    const SailorLightShaderData* L = lights + j;
-    const float x = L->worldPosition[0], y = L->worldPosition[1], z = L->worldPosition[2];
-    float4 p = glsl_mul(view, x, y, z, 1.0f);
-    const float w = p.w;
-    p.x = p.x / w; p.y = p.y / w; p.z = p.z / w;
-    p.z = p.z * -1.0f; // "Reverse Z"
-    lightView[j] = make_float4(p.x, p.y, p.z, L->bounds[0]);
-    lightType[j] = L->type;
+    const int word = wordBlock * 4 + (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = word * 64 + lane;
+    const bool valid = j < a.N;
+    float4 lv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t type = 1u;
+    if (valid) {
+        const SailorLightShaderData* L = a.lights + j;
+        const float x = L->worldPosition[0], y = L->worldPosition[1], z = L->worldPosition[2];
+        float4 p = glsl_mul(a.view, x, y, z, 1.0f);
+        const float w = p.w;
+        p.x = p.x / w; p.y = p.y / w; p.z = p.z / w;
+        p.z = p.z * -1.0f; // "Reverse Z"
+        lv = make_float4(p.x, p.y, p.z, L->bounds[0]);
+        type = L->type;
+        if (split == 0) { a.lightView[j] = lv; a.lightType[j] = type; }
+    }
+    __syncthreads(); // the planes are in LDS
+    if (nb <= 0 || word >= a.words) return;
+    const float r = lv.w;
+    const float m = a.planeMargin * ((fabsf(lv.x) + fabsf(lv.y)) + (fabsf(lv.z) + fabsf(r)));
+    const bool inFront = (lv.z - r) > m; // false for NaN => never plane-culled
+    const float thr = -(r + m);
+    const bool keepAlways = valid && (type == 0u || !inFront);
+    if (split == 0) { // one bit per light: "directional" (rides along into the group lists, saves a gather per candidate)
+        const unsigned long long dm = __ballot(valid && type == 0u);
+        if (lane == 0) a.dirWords[word] = dm;
+    }
+#pragma unroll 4
+    for (int b = 0; b < nb; b++) {
+        const float4 nA = sPl[2 * b + 0], nB = sPl[2 * b + 1]; // LDS broadcast reads
+        const bool out = dot3f(nA.x, nA.y, nA.z, lv.x, lv.y, lv.z) < thr || dot3f(nB.x, nB.y, nB.z, lv.x, lv.y, lv.z) < thr;
+        const unsigned long long mask = __ballot(keepAlways || (valid && !out));
+        if (lane == 0) a.masks[(size_t)(b0 + b) * a.words + word] = mask;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1a: depth bounds (ComputeLightCulling.shader:119-128) + tile frustum, 16 tiles per block.
+// K1a: depth bounds (ComputeLightCulling.shader:119-128) + tile frustum, 32 tiles per block.
 // tileInfo[t] = { (n0, cx), (n1, cy), (n2, zNear'), (n3, zFar') } with the near/far swap of :171-177 applied.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t depth_bits(const float* __restrict__ depth, int W, int H, int bandRow0, int gx, int gy)
@@ -177,143 +228,95 @@ __device__ __forceinline__ uint32_t depth_bits(const float* __restrict__ depth, 
     return __float_as_uint(depth[(size_t)(row - bandRow0) * W + col]);
 }
 
-__device__ __forceinline__ void k1_tile_setup(int block, const Mat4& invProj, int vpW, int vpH, const float* __restrict__ depth, int W, int H,
-                                              int Tx, int tileRow0, int bandRow0, int stripsPerRow, int vecOK, int rawDepth, float zNearCam,
-                                              float4* __restrict__ tileInfo, unsigned char* __restrict__ lds)
+#define SETUP_STRIPS 2 // 16-tile strips per block: the whole role is one round of resident blocks at 4K, 8 float4 loads in flight per lane
+__device__ __forceinline__ void k1_tile_setup(const int block, unsigned char* __restrict__ lds, const PrepareArgs& a)
 {
-    uint32_t (*sMin)[16] = reinterpret_cast<uint32_t (*)[16]>(lds), (*sMax)[16] = reinterpret_cast<uint32_t (*)[16]>(lds + 256); // [4][16] each
-    const int strip = block % stripsPerRow;
-    const int tyLocal = block / stripsPerRow;
-    const int ty = tileRow0 + tyLocal;
+    uint32_t (*sMin)[16 * SETUP_STRIPS] = reinterpret_cast<uint32_t (*)[16 * SETUP_STRIPS]>(lds);                       // [4][32]
+    uint32_t (*sMax)[16 * SETUP_STRIPS] = reinterpret_cast<uint32_t (*)[16 * SETUP_STRIPS]>(lds + 256 * SETUP_STRIPS); // [4][32]
+    const int strip0 = (block % a.stripsPerRow) * SETUP_STRIPS;
+    const int tyLocal = block / a.stripsPerRow;
+    const int ty = a.tileRow0 + tyLocal;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gx0 = strip * 256 + lane * 4; // 4 pixels per lane, 4 lanes per tile
-    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-    const bool vec = vecOK && (gx0 + 3 < W);
+    const int W = a.W, H = a.H;
+    float4 d[SETUP_STRIPS][4];
+    bool vec[SETUP_STRIPS];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int gy = ty * TILE + wave * 4 + k;
-        if (vec) {
-            int row = H - 1 - gy;
-            row = row < 0 ? 0 : row;
-            const float4 d = *reinterpret_cast<const float4*>(depth + (size_t)(row - bandRow0) * W + gx0);
-            const uint32_t a = __float_as_uint(d.x), b = __float_as_uint(d.y), c = __float_as_uint(d.z), e = __float_as_uint(d.w);
-            mn = min(min(mn, a), min(b, min(c, e)));
-            mx = max(max(mx, a), max(b, max(c, e)));
-        } else {
+    for (int s = 0; s < SETUP_STRIPS; s++) {
+        const int gx0 = (strip0 + s) * 256 + lane * 4; // 4 pixels per lane, 4 lanes per tile
+        vec[s] = a.vecOK && (gx0 + 3 < W);
+        if (vec[s]) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t a = depth_bits(depth, W, H, bandRow0, gx0 + q, gy);
-                mn = min(mn, a);
-                mx = max(mx, a);
+            for (int k = 0; k < 4; k++) {
+                int row = H - 1 - (ty * TILE + wave * 4 + k);
+                row = row < 0 ? 0 : row;
+                d[s][k] = *reinterpret_cast<const float4*>(a.depth + (size_t)(row - a.bandRow0) * W + gx0);
             }
         }
     }
-    // 4 lanes share a tile
-    mn = min(mn, (uint32_t)__shfl_xor((int)mn, 1)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, 1));
-    mn = min(mn, (uint32_t)__shfl_xor((int)mn, 2)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, 2));
-    if ((lane & 3) == 0) { sMin[wave][lane >> 2] = mn; sMax[wave][lane >> 2] = mx; }
+    // the frusta do not depend on the depth: built while the loads above are in flight
+    const int tx = strip0 * 16 + (int)threadIdx.x;
+    const bool owner = threadIdx.x < 16 * SETUP_STRIPS && tx < a.Tx;
+    Frustum4 f;
+    if (owner) frustum_from_rect(a.invProj, (float)(tx * TILE), (float)(ty * TILE), (float)((tx + 1) * TILE), (float)((ty + 1) * TILE), a.vpW, a.vpH, f);
+#pragma unroll
+    for (int s = 0; s < SETUP_STRIPS; s++) {
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+        if (vec[s]) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t p = __float_as_uint(d[s][k].x), q = __float_as_uint(d[s][k].y), r = __float_as_uint(d[s][k].z), w = __float_as_uint(d[s][k].w);
+                mn = min(min(mn, p), min(q, min(r, w)));
+                mx = max(max(mx, p), max(q, max(r, w)));
+            }
+        } else if ((strip0 + s) * 16 < a.Tx) {
+            const int gx0 = (strip0 + s) * 256 + lane * 4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int gy = ty * TILE + wave * 4 + k;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t v = depth_bits(a.depth, W, H, a.bandRow0, gx0 + q, gy);
+                    mn = min(mn, v);
+                    mx = max(mx, v);
+                }
+            }
+        }
+        // 4 lanes share a tile
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, 1)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, 1));
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, 2)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, 2));
+        if ((lane & 3) == 0) { sMin[wave][s * 16 + (lane >> 2)] = mn; sMax[wave][s * 16 + (lane >> 2)] = mx; }
+    }
     __syncthreads();
-    if (threadIdx.x < 16) {
-        const int tx = strip * 16 + threadIdx.x;
-        if (tx < Tx) {
-            const int i = threadIdx.x;
-            const uint32_t bmn = min(min(sMin[0][i], sMin[1][i]), min(sMin[2][i], sMin[3][i]));
-            const uint32_t bmx = max(max(sMax[0][i], sMax[1][i]), max(sMax[2][i], sMax[3][i]));
-            float zFar = __uint_as_float(bmx), zNear = __uint_as_float(bmn);
-            if (rawDepth) {
-                // SAILOR_CULL_RAW_DEPTH: the image holds the reversed-Z attachment.  x -> fl(zNear / x) is monotone
-                // non-increasing on x >= 0, so the largest linear depth of the tile is the linearised smallest raw value
-                // and vice versa -- bit for bit what min / max over the linearised texels give (LinearizeDepth.shader:70,74).
-                const float lo = -(-zNearCam / zFar), hi = -(-zNearCam / zNear);
-                zNear = lo; zFar = hi;
-            }
-            const float diff = zFar - zNear; // "Add extra bounds" (:174-177): swaps near and far in fp32
-            zFar -= diff;
-            zNear += diff;
-            Frustum4 f;
-            frustum_from_rect(invProj, (float)(tx * TILE), (float)(ty * TILE), (float)((tx + 1) * TILE), (float)((ty + 1) * TILE), vpW, vpH, f);
-            float4* o = tileInfo + (size_t)(tyLocal * Tx + tx) * 4;
-            o[0] = make_float4(f.n[0][0], f.n[0][1], f.n[0][2], f.cx);
-            o[1] = make_float4(f.n[1][0], f.n[1][1], f.n[1][2], f.cy);
-            o[2] = make_float4(f.n[2][0], f.n[2][1], f.n[2][2], zNear);
-            o[3] = make_float4(f.n[3][0], f.n[3][1], f.n[3][2], zFar);
+    if (owner) {
+        const int i = threadIdx.x;
+        const uint32_t bmn = min(min(sMin[0][i], sMin[1][i]), min(sMin[2][i], sMin[3][i]));
+        const uint32_t bmx = max(max(sMax[0][i], sMax[1][i]), max(sMax[2][i], sMax[3][i]));
+        float zFar = __uint_as_float(bmx), zNear = __uint_as_float(bmn);
+        if (a.rawDepth) {
+            // SAILOR_CULL_RAW_DEPTH: the image holds the reversed-Z attachment.  x -> fl(zNear / x) is monotone
+            // non-increasing on x >= 0, so the largest linear depth of the tile is the linearised smallest raw value
+            // and vice versa -- bit for bit what min / max over the linearised texels give (LinearizeDepth.shader:70,74).
+            const float lo = -(-a.zNearCam / zFar), hi = -(-a.zNearCam / zNear);
+            zNear = lo; zFar = hi;
         }
+        const float diff = zFar - zNear; // "Add extra bounds" (:174-177): swaps near and far in fp32
+        zFar -= diff;
+        zNear += diff;
+        float4* o = a.tileInfo + (size_t)(tyLocal * a.Tx + tx) * 4;
+        o[0] = make_float4(f.n[0][0], f.n[0][1], f.n[0][2], f.cx);
+        o[1] = make_float4(f.n[1][0], f.n[1][1], f.n[1][2], f.cy);
+        o[2] = make_float4(f.n[2][0], f.n[2][1], f.n[2][2], zNear);
+        o[3] = make_float4(f.n[3][0], f.n[3][1], f.n[3][2], zFar);
     }
 }
 
-// One launch for the two independent preparation passes: blocks [0, setupBlocks) stream the depth image (K1a, the long
-// pole: they are dispatched first), the rest transform the lights and build the band planes (K0).
-struct PrepareArgs {
-    Mat4 view, invProj;
-    const SailorLightShaderData* lights;
-    const float* depth;
-    float4* lightView; uint32_t* lightType; float4* tileInfo; float4* bandPlanes;
-    int N, lightBlocks, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands, stripsPerRow, vecOK, rawDepth;
-    float zNearCam;
-};
-
-// Every stage below is a device function over (block index, LDS) plus a thin __global__ wrapper: the same bodies run inside the fused
-// "shade slice of frame k + cull stage of frame k+1" launches at the end of this file.
-#define LDS_K01_PREPARE 512
-__device__ __forceinline__ void k01_prepare_body(const int b, unsigned char* __restrict__ lds, const PrepareArgs& a)
-{
-    if (b < a.setupBlocks)
-        k1_tile_setup(b, a.invProj, a.vpW, a.vpH, a.depth, a.W, a.H, a.Tx, a.tileRow0, a.bandRow0, a.stripsPerRow, a.vecOK, a.rawDepth, a.zNearCam, a.tileInfo, lds);
-    else
-        k0_light_view(b - a.setupBlocks, a.view, a.lights, a.N, a.lightBlocks, a.lightView, a.lightType, a.invProj, a.vpW, a.vpH, a.Tx, a.Ty, a.tileRow0,
-                      a.bandRows, a.groupsX, a.numBands, a.bandPlanes);
-}
+#define LDS_K01_PREPARE (2 * BANDS_PER_BLOCK * 16)
 __global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K01_PREPARE];
-    k01_prepare_body((int)blockIdx.x, lds, a);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// K1b: band masks.  masks[b][word] bit k = "light 64*word + k may reach group column / group row b".
-// A light is dropped from a band only if its sphere is entirely in front of the eye AND entirely outside one of the
-// band's two planes by more than the margin; directional lights and everything doubtful stay in.
-// ------------------------------------------------------------------------------------------------------------
-#define LDS_K1_BAND_MASKS (2 * BANDS_PER_GROUP * 16)
-__device__ __forceinline__ void k1_band_masks_body(const unsigned bx, const unsigned by, unsigned char* __restrict__ lds, const float4* __restrict__ lightView,
-                                                   const uint32_t* __restrict__ lightType, int N, int words, const float4* __restrict__ bandPlanes, int numBands,
-                                                   float planeMargin, unsigned long long* __restrict__ masks, unsigned long long* __restrict__ dirWords)
-{
-    float4* sPl = reinterpret_cast<float4*>(lds); // [2 * BANDS_PER_GROUP]
-    const int b0 = by * BANDS_PER_GROUP;
-    const int nb = min(BANDS_PER_GROUP, numBands - b0);
-    if ((int)threadIdx.x < 2 * nb) sPl[threadIdx.x] = bandPlanes[2 * b0 + threadIdx.x]; // this block's planes, read once
-    __syncthreads();
-    const int word = bx * 4 + (threadIdx.x >> 6);
-    if (word >= words) return;
-    const int lane = threadIdx.x & 63;
-    const int j = word * 64 + lane;
-    const bool valid = j < N;
-    float4 lv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t type = 1u;
-    if (valid) { lv = lightView[j]; type = lightType[j]; }
-    const float r = lv.w;
-    const float m = planeMargin * ((fabsf(lv.x) + fabsf(lv.y)) + (fabsf(lv.z) + fabsf(r)));
-    const bool inFront = (lv.z - r) > m; // false for NaN => never plane-culled
-    const float thr = -(r + m);
-    const bool keepAlways = valid && (type == 0u || !inFront);
-    if (by == 0) { // one bit per light: "directional" (rides along into the group lists, saves a gather per candidate)
-        const unsigned long long dm = __ballot(valid && type == 0u);
-        if (lane == 0) dirWords[word] = dm;
-    }
-    for (int b = 0; b < nb; b++) {
-        const float4 nA = sPl[2 * b + 0], nB = sPl[2 * b + 1]; // LDS broadcast reads
-        const bool out = dot3f(nA.x, nA.y, nA.z, lv.x, lv.y, lv.z) < thr || dot3f(nB.x, nB.y, nB.z, lv.x, lv.y, lv.z) < thr;
-        const unsigned long long mask = __ballot(keepAlways || (valid && !out));
-        if (lane == 0) masks[(size_t)(b0 + b) * words + word] = mask;
-    }
-}
-__global__ __launch_bounds__(256) void k1_band_masks(const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType, int N, int words,
-                                                      const float4* __restrict__ bandPlanes, int numBands, float planeMargin,
-                                                      unsigned long long* __restrict__ masks, unsigned long long* __restrict__ dirWords)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K1_BAND_MASKS];
-    k1_band_masks_body(blockIdx.x, blockIdx.y, lds, lightView, lightType, N, words, bandPlanes, numBands, planeMargin, masks, dirWords);
+    const int b = (int)blockIdx.x;
+    if (b < a.lightRoleBlocks) k0_lights(b, lds, a);
+    else k1_tile_setup(b - a.lightRoleBlocks, lds, a);
 }
 
 __device__ __forceinline__ uint64_t lanemask_lt()
@@ -329,14 +332,12 @@ __device__ __forceinline__ uint64_t lanemask_lt()
 // sparse-bits -> dense-list conversion is fully parallel.  Done once per 16 tiles, not per tile (profiles/r01: the
 // per-tile scalar version saturated the CUs' scalar ALUs; a per-group scalar version was tail-bound by cluster groups).
 // ------------------------------------------------------------------------------------------------------------
-#define LDS_K1_GROUP_LISTS 16
 #define GL_WPT 4 // words per thread and round in k1_group_lists
-__device__ __forceinline__ void k1_group_lists_body(const unsigned bx, unsigned char* __restrict__ lds, const unsigned long long* __restrict__ masks,
-                                                    const unsigned long long* __restrict__ dirWords, int words, int Tx, int bandRows, int groupsX,
-                                                    uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList)
+__global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ dirWords,
+                                                       int words, int groupsX, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList)
 {
-    uint32_t* sW = reinterpret_cast<uint32_t*>(lds); // [4]
-    const int g = bx, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint32_t sW[4];
+    const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long* __restrict__ c = masks + (size_t)(g % groupsX) * words;
     const unsigned long long* __restrict__ r = masks + (size_t)(groupsX + g / groupsX) * words;
     uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
@@ -400,16 +401,9 @@ __device__ __forceinline__ void k1_group_lists_body(const unsigned bx, unsigned 
     }
     if (threadIdx.x == 0) groupCount[g] = base > CAPG ? GROUP_OVERFLOW : base;
 }
-__global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ dirWords,
-                                                       int words, int Tx, int bandRows, int groupsX,
-                                                       uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K1_GROUP_LISTS];
-    k1_group_lists_body(blockIdx.x, lds, masks, dirWords, words, Tx, bandRows, groupsX, groupCount, groupList);
-}
 
 // ------------------------------------------------------------------------------------------------------------
-// K1c: exact per-tile cull, one wave per tile.
+// K1c: exact per-tile cull, one wave per tile, canonical offsets by decoupled look-back, lists written in place.
 // ------------------------------------------------------------------------------------------------------------
 struct TileCtx {
     float n[4][3];
@@ -462,55 +456,72 @@ __device__ __forceinline__ void test_candidates(const TileCtx& t, const float4* 
 // told not to move accesses across this point (and to wait for outstanding DS results).
 #define WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
 
+// Tile classes for the shading hint (sailor_hip_light_cull_tile_order): A = lists of >= CLASS_A entries, B = >= CLASS_B.
+#define CLASS_A 96u
+#define CLASS_B 40u
+__device__ __forceinline__ uint32_t tile_class_word(uint32_t num) { return num >= CLASS_A ? 0x10000u : (num >= CLASS_B ? 1u : 0u); }
+
+struct CullArgs {
+    const float4* lightView; const uint32_t* lightType; const float4* tileInfo;
+    const unsigned long long* masks; const uint32_t* groupCount; const uint32_t* groupList;
+    uint32_t* totals; uint32_t* clsTotals; uint32_t* tileNum; uint32_t* staging;
+    int N, words, Tx, groupsX, classes;
+};
+
 #define LDS_K1_TILE_CULL (CHUNK * 16 + CHUNK * 4 + 4 * CAND * 4 + 4 * CAND * 4)
 template <bool BRUTE>
-__device__ __forceinline__ void k1_tile_cull_body(const unsigned bx, unsigned char* __restrict__ lds, const float4* __restrict__ lightView,
-                                                  const uint32_t* __restrict__ lightType, int N, int words, const float4* __restrict__ tileInfo, int Tx, int bandRows,
-                                                  const unsigned long long* __restrict__ masks, const uint32_t* __restrict__ groupCount,
-                                                  const uint32_t* __restrict__ groupList, int groupsX, uint32_t* __restrict__ tileNum, uint32_t* __restrict__ tileList)
+__global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
 {
-    // One 256-thread block per 2x2 QUARTER of a 4x4-tile group, one wave per tile.  The group's candidate records are
-    // staged in LDS, CHUNK at a time, by the four waves together (list entries first, then the dependent 16-byte
+    // One 256-thread block per run of four tiles (a group's four columns in one tile row), one wave per tile.  The group's candidate
+    // records are staged in LDS, CHUNK at a time, by the four waves together (list entries first, then the dependent 16-byte
     // gathers, four of each in flight per thread), and every tile streams them out of LDS.  Four blocks per group, not
     // one of sixteen waves: a cluster group (2048 candidates, four 196 -> 128 selections per SIMD) used to keep ONE CU
-    // busy for ~40 us while the rest of the chip idled -- the kernel's tail -- and at 26 KB of LDS six blocks fit a CU.
+    // busy for ~40 us while the rest of the chip idled -- the kernel's tail -- and at 22 KB of LDS seven blocks fit a CU.
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K1_TILE_CULL];
+    __shared__ uint32_t sNum[4];
     float4* sLV = reinterpret_cast<float4*>(lds);                                                         // [CHUNK] candidate (view pos, radius)
     uint32_t* sE = reinterpret_cast<uint32_t*>(lds + CHUNK * 16);                                         // [CHUNK] candidate light index | directional << 31
     uint32_t (*sIdxAll)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds + CHUNK * 20);                   // [4][CAND]
     float (*sImpAll)[CAND] = reinterpret_cast<float (*)[CAND]>(lds + CHUNK * 20 + 4 * CAND * 4);          // [4][CAND], 16-byte aligned (CAND * 4 = 784)
-    const int g = bx >> 2, quarter = bx & 3;
+    const float4* __restrict__ lightView = a.lightView;
+    const uint32_t* __restrict__ lightType = a.lightType;
+    const int N = a.N, Tx = a.Tx, groupsX = a.groupsX;
+    const int b = (int)blockIdx.x;                       // == tile-index order: (tile row, group column)
+    const int gx = b % groupsX, tyLocal = b / groupsX;
+    const int g = (tyLocal / GROUP) * groupsX + gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* sIdx = sIdxAll[wave];
     float* sImp = sImpAll[wave];
-    const int tx = (g % groupsX) * GROUP + (quarter & 1) * 2 + (wave & 1), tyLocal = (g / groupsX) * GROUP + (quarter >> 1) * 2 + (wave >> 1);
-    const bool active = tx < Tx && tyLocal < bandRows;
+    const int tx = gx * GROUP + wave;
+    const bool active = tx < Tx;
     const int bandTile = tyLocal * Tx + tx;
     TileCtx t;
     if (active) {
-        const float4* ti = tileInfo + (size_t)bandTile * 4;
-        const float4 a = ti[0], b = ti[1], c = ti[2], d = ti[3];
-        t.n[0][0] = a.x; t.n[0][1] = a.y; t.n[0][2] = a.z; t.cx = a.w;
-        t.n[1][0] = b.x; t.n[1][1] = b.y; t.n[1][2] = b.z; t.cy = b.w;
-        t.n[2][0] = c.x; t.n[2][1] = c.y; t.n[2][2] = c.z; t.zNear = c.w;
-        t.n[3][0] = d.x; t.n[3][1] = d.y; t.n[3][2] = d.z; t.zFar = d.w;
+        const float4* ti = a.tileInfo + (size_t)bandTile * 4;
+        const float4 q0 = ti[0], q1 = ti[1], q2 = ti[2], q3 = ti[3];
+        t.n[0][0] = q0.x; t.n[0][1] = q0.y; t.n[0][2] = q0.z; t.cx = q0.w;
+        t.n[1][0] = q1.x; t.n[1][1] = q1.y; t.n[1][2] = q1.z; t.cy = q1.w;
+        t.n[2][0] = q2.x; t.n[2][1] = q2.y; t.n[2][2] = q2.z; t.zNear = q2.w;
+        t.n[3][0] = q3.x; t.n[3][1] = q3.y; t.n[3][2] = q3.z; t.zFar = q3.w;
         t.cz = (t.zFar + t.zNear) * 0.5f;
     }
     uint32_t count = 0;
     if (BRUTE) {
-        if (!active) return;
-        for (int base = 0; base < N && count < CAND; base += 64) {
-            const int j = base + lane;
-            test_candidates(t, lightView, lightType, j < N, (uint32_t)j, count, sIdx);
+        if (active) {
+            for (int base = 0; base < N && count < CAND; base += 64) {
+                const int j = base + lane;
+                test_candidates(t, lightView, lightType, j < N, (uint32_t)j, count, sIdx);
+            }
         }
     } else {
         // The kernel is bound by the latency of its dependent loads (a block has ~1 us of work behind 2-3 round trips to
         // L2 / HBM), so the first chunk's list entries are requested together with the group's count, not after it:
         // slots past the count hold stale entries of an earlier frame or nothing at all, hence the clamp to N - 1.
-        const uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
+        const uint32_t* __restrict__ list = a.groupList + (size_t)g * CAPG;
         uint32_t e[CHUNK / 256];
 #pragma unroll
         for (int k = 0; k < CHUNK / 256; k++) e[k] = list[threadIdx.x + 256u * k];
-        const uint32_t gn = groupCount[g];
+        const uint32_t gn = a.groupCount[g];
         if (gn != GROUP_OVERFLOW) {
             for (uint32_t c0 = 0; c0 < gn; c0 += CHUNK) {
                 const uint32_t cn = min((uint32_t)CHUNK, gn - c0);
@@ -539,243 +550,273 @@ __device__ __forceinline__ void k1_tile_cull_body(const unsigned bx, unsigned ch
                     }
                 }
             }
-            if (!active) return;
-        } else {
-        // overflowed group (very dense region / lights around the eye): every tile walks its own two masks
-        if (!active) return;
-        uint32_t* sQ = reinterpret_cast<uint32_t*>(sLV) + wave * QCAP; // sLV is unused on this path
-        const unsigned long long* __restrict__ col = masks + (size_t)(g % groupsX) * words;
-        const unsigned long long* __restrict__ row = masks + (size_t)(groupsX + g / groupsX) * words;
-        uint32_t qHead = 0, qTail = 0; // ring buffer indices (wave-uniform)
-        unsigned long long next = (lane < words) ? (col[lane] & row[lane]) : 0ull;
-        for (int w0 = 0; w0 < words && count < CAND; w0 += 64) {
-            const unsigned long long m = next;
-            const int wn = w0 + 64 + lane;
-            next = (wn < words) ? (col[wn] & row[wn]) : 0ull; // prefetch the next 4096 lights' masks
-            // Scalar walk over the non-empty words of this step, in ascending order.  Each word's set bits go to the
-            // ordered queue with one mbcnt (bit k of word L = light 64 (w0 + L) + k lands behind the k' < k bits).
-            unsigned long long nz = __ballot(m != 0ull);
-            while (nz != 0ull && count < CAND) {
-                const int L = __builtin_ctzll(nz);
-                nz &= nz - 1ull;
-                const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)m, L);
-                const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(m >> 32), L);
-                const unsigned long long mk = ((unsigned long long)hi << 32) | lo;
-                if ((mk >> lane) & 1ull)
-                    sQ[(qTail + (uint32_t)__popcll(mk & lanemask_lt())) & (QCAP - 1)] = (uint32_t)(w0 + L) * 64u + (uint32_t)lane;
-                qTail += (uint32_t)__popcll(mk);
-                if (qTail - qHead >= 64u) { // a full wave of candidates is waiting: exact-test them
-                    WAVE_SYNC();
-                    const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
-                    test_candidates(t, lightView, lightType, true, j, count, sIdx);
-                    qHead += 64u;
-                    WAVE_SYNC();
+        } else if (active) {
+            // overflowed group (very dense region / lights around the eye): every tile walks its own two masks
+            uint32_t* sQ = reinterpret_cast<uint32_t*>(sLV) + wave * QCAP; // sLV is unused on this path
+            const unsigned long long* __restrict__ col = a.masks + (size_t)gx * a.words;
+            const unsigned long long* __restrict__ row = a.masks + (size_t)(groupsX + tyLocal / GROUP) * a.words;
+            const int words = a.words;
+            uint32_t qHead = 0, qTail = 0; // ring buffer indices (wave-uniform)
+            unsigned long long next = (lane < words) ? (col[lane] & row[lane]) : 0ull;
+            for (int w0 = 0; w0 < words && count < CAND; w0 += 64) {
+                const unsigned long long m = next;
+                const int wn = w0 + 64 + lane;
+                next = (wn < words) ? (col[wn] & row[wn]) : 0ull; // prefetch the next 4096 lights' masks
+                // Scalar walk over the non-empty words of this step, in ascending order.  Each word's set bits go to the
+                // ordered queue with one mbcnt (bit k of word L = light 64 (w0 + L) + k lands behind the k' < k bits).
+                unsigned long long nz = __ballot(m != 0ull);
+                while (nz != 0ull && count < CAND) {
+                    const int L = __builtin_ctzll(nz);
+                    nz &= nz - 1ull;
+                    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)m, L);
+                    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(m >> 32), L);
+                    const unsigned long long mk = ((unsigned long long)hi << 32) | lo;
+                    if ((mk >> lane) & 1ull)
+                        sQ[(qTail + (uint32_t)__popcll(mk & lanemask_lt())) & (QCAP - 1)] = (uint32_t)(w0 + L) * 64u + (uint32_t)lane;
+                    qTail += (uint32_t)__popcll(mk);
+                    if (qTail - qHead >= 64u) { // a full wave of candidates is waiting: exact-test them
+                        WAVE_SYNC();
+                        const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
+                        test_candidates(t, lightView, lightType, true, j, count, sIdx);
+                        qHead += 64u;
+                        WAVE_SYNC();
+                    }
                 }
             }
-        }
-        WAVE_SYNC();
-        if (qTail != qHead && count < CAND) { // final partial round (< 64 pending)
-            const uint32_t n = qTail - qHead;
-            const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
-            test_candidates(t, lightView, lightType, (uint32_t)lane < n, j, count, sIdx);
-        }
+            WAVE_SYNC();
+            if (qTail != qHead && count < CAND) { // final partial round (< 64 pending)
+                const uint32_t n = qTail - qHead;
+                const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
+                test_candidates(t, lightView, lightType, (uint32_t)lane < n, j, count, sIdx);
+            }
         }
     }
-    const uint32_t n = count < CAND ? count : CAND;
+    const uint32_t n = count < CAND ? count : CAND;   // 0 for a wave beyond the last tile column
     const uint32_t num = n < KEEP ? n : KEEP;
+    if (lane == 0) sNum[wave] = num;
+    __syncthreads(); // every wave's candidates are in LDS, the four list lengths are known
+    uint32_t before = 0u, total = 0u, cls = 0u; // entries of the block's earlier tiles / of the whole block; its class A << 16 | class B tiles
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t v = sNum[w];
+        if (w < wave) before += v;
+        total += v;
+        cls += tile_class_word(v);
+    }
+    if (threadIdx.x == 0) {
+        a.totals[b] = total;
+        if (a.classes) a.clsTotals[b] = cls;
+    }
+    if (!active) return;
+    if (lane == 0) a.tileNum[bandTile] = num;
+    // the block's four lists back to back in its staging slot: k1_pack moves the slot as one contiguous run
+    uint32_t* __restrict__ out = a.staging + (size_t)b * SLOT + before;
     WAVE_SYNC(); // orders the wave's LDS writes above with the reads below
-    uint32_t* out = tileList + (size_t)bandTile * KEEP;
     if (n <= KEEP) {
         // :235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]
         for (uint32_t i = lane; i < num; i += 64) out[i] = sIdx[n - 1 - i] & 0x7FFFFFFFu;
-    } else {
-        bool nanHere = false;
-        for (uint32_t k = lane; k < n; k += 64) {
-            const uint32_t e = sIdx[k];
-            const float imp = (e & 0x80000000u) ? 0.0f : tile_impact(t, lightView[e]);
-            sImp[k] = imp;
-            nanHere = nanHere || imp != imp;
-        }
-        if (__ballot(nanHere) != 0ull) {
-            // A NaN impact (tile with nothing drawn: depth +inf makes the frustum centre NaN; or a non-finite light) has no
-            // rank: the shader's compare-and-swap (:207) is simply false next to it.  Literal semantics then: if no adjacent
-            // pair can swap at all -- the sky-tile case, every impact NaN or a directional 0 -- the bubble sort is a no-op;
-            // otherwise one lane replays it (NaNs act as walls; rare and slow, but the reference's answer).
-            WAVE_SYNC();
-            bool swapHere = false;
-            for (uint32_t k = lane; k + 1 < n; k += 64) swapHere = swapHere || sImp[k] < sImp[k + 1];
-            if (__ballot(swapHere) != 0ull) {
-                if (lane == 0) {
-                    uint32_t numSorted = KEEP;
-                    for (uint32_t i = 0; i + 1 < n; i++) {
-                        for (uint32_t j = 0; j < n - i - 1; j++) {
-                            const float a = sImp[j], b = sImp[j + 1];
-                            if (a < b) {
-                                sImp[j] = b; sImp[j + 1] = a;
-                                const uint32_t x = sIdx[j]; sIdx[j] = sIdx[j + 1]; sIdx[j + 1] = x;
-                            }
-                        }
-                        if (--numSorted == 0) break;
-                    }
-                }
-                WAVE_SYNC();
-            }
-            for (uint32_t i = lane; i < num; i += 64) out[i] = sIdx[n - 1 - i] & 0x7FFFFFFFu; // :235-238
-            if (lane == 0) tileNum[bandTile] = num;
-            return;
-        }
-        // :198-225 partial bubble sort == rank under (impact ascending, candidate position descending); keep rank < 128
-        // each lane ranks up to 4 candidates (k = lane + 64 i) against all n, 4 impacts per LDS read.  Candidates q of
-        // an earlier 64-block all have q < k (count g < f), of a later block all have q > k (count g <= f); only the
-        // lane's own block needs the position tie-break.  Slots past n are padded with +inf and never counted.
-        if (lane < 4 && (n & ~3u) + lane >= n && (n & ~3u) + lane < (uint32_t)CAND) sImp[(n & ~3u) + lane] = __builtin_inff();
+        return;
+    }
+    // ---- 196 -> 128 selection (ComputeLightCulling.shader:198-225)
+    bool nanHere = false;
+    for (uint32_t k = lane; k < n; k += 64) {
+        const uint32_t e = sIdx[k];
+        const float imp = (e & 0x80000000u) ? 0.0f : tile_impact(t, lightView[e]);
+        sImp[k] = imp;
+        nanHere = nanHere || imp != imp;
+    }
+    if (__ballot(nanHere) != 0ull) {
+        // A NaN impact (tile with nothing drawn: depth +inf makes the frustum centre NaN; or a non-finite light) has no
+        // rank: the shader's compare-and-swap (:207) is simply false next to it.  Literal semantics then: if no adjacent
+        // pair can swap at all -- the sky-tile case, every impact NaN or a directional 0 -- the bubble sort is a no-op;
+        // otherwise one lane replays it (NaNs act as walls; rare and slow, but the reference's answer).
         WAVE_SYNC();
-        float f[4];
-        uint32_t rank[4] = { 0u, 0u, 0u, 0u };
-#pragma unroll
-        for (int i = 0; i < 4; i++) { const uint32_t k = lane + 64u * i; f[i] = (k < n) ? sImp[k] : -1.0f; }
-        const float4* sImp4 = reinterpret_cast<const float4*>(sImp);
-        const uint32_t n4 = (n + 3u) / 4u;
-#pragma unroll
-        for (int jb = 0; jb < 4; jb++) {
-            const uint32_t qEnd = min(n4, (uint32_t)(jb + 1) * 16u);
-            for (uint32_t q4 = (uint32_t)jb * 16u; q4 < qEnd; q4++) {
-                const float4 gv = sImp4[q4];
-                const float g[4] = { gv.x, gv.y, gv.z, gv.w };
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        if (jb < i) rank[i] += (g[e] < f[i]) ? 1u : 0u;
-                        else if (jb > i) rank[i] += (g[e] <= f[i]) ? 1u : 0u;
-                        else {
-                            const uint32_t q = q4 * 4u + e, k = lane + 64u * i;
-                            rank[i] += (g[e] < f[i] || (g[e] == f[i] && q > k)) ? 1u : 0u;
+        bool swapHere = false;
+        for (uint32_t k = lane; k + 1 < n; k += 64) swapHere = swapHere || sImp[k] < sImp[k + 1];
+        if (__ballot(swapHere) != 0ull) {
+            if (lane == 0) {
+                uint32_t numSorted = KEEP;
+                for (uint32_t i = 0; i + 1 < n; i++) {
+                    for (uint32_t j = 0; j < n - i - 1; j++) {
+                        const float x = sImp[j], y = sImp[j + 1];
+                        if (x < y) {
+                            sImp[j] = y; sImp[j + 1] = x;
+                            const uint32_t q = sIdx[j]; sIdx[j] = sIdx[j + 1]; sIdx[j + 1] = q;
                         }
+                    }
+                    if (--numSorted == 0) break;
+                }
+            }
+            WAVE_SYNC();
+        }
+        for (uint32_t i = lane; i < num; i += 64) out[i] = sIdx[n - 1 - i] & 0x7FFFFFFFu; // :235-238
+        return;
+    }
+    // :198-225 partial bubble sort == rank under (impact ascending, candidate position descending); keep rank < 128
+    // each lane ranks up to 4 candidates (k = lane + 64 i) against all n, 4 impacts per LDS read.  Candidates q of
+    // an earlier 64-block all have q < k (count g < f), of a later block all have q > k (count g <= f); only the
+    // lane's own block needs the position tie-break.  Slots past n are padded with +inf and never counted.
+    if (lane < 4 && (n & ~3u) + lane >= n && (n & ~3u) + lane < (uint32_t)CAND) sImp[(n & ~3u) + lane] = __builtin_inff();
+    WAVE_SYNC();
+    float f[4];
+    uint32_t rank[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const uint32_t k = lane + 64u * i; f[i] = (k < n) ? sImp[k] : -1.0f; }
+    const float4* sImp4 = reinterpret_cast<const float4*>(sImp);
+    const uint32_t n4 = (n + 3u) / 4u;
+#pragma unroll
+    for (int jb = 0; jb < 4; jb++) {
+        const uint32_t qEnd = min(n4, (uint32_t)(jb + 1) * 16u);
+        for (uint32_t q4 = (uint32_t)jb * 16u; q4 < qEnd; q4++) {
+            const float4 gv = sImp4[q4];
+            const float gq[4] = { gv.x, gv.y, gv.z, gv.w };
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (jb < i) rank[i] += (gq[e] < f[i]) ? 1u : 0u;
+                    else if (jb > i) rank[i] += (gq[e] <= f[i]) ? 1u : 0u;
+                    else {
+                        const uint32_t q = q4 * 4u + e, k = lane + 64u * i;
+                        rank[i] += (gq[e] < f[i] || (gq[e] == f[i] && q > k)) ? 1u : 0u;
                     }
                 }
             }
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t k = lane + 64u * i;
-            if (k < n && rank[i] < KEEP) out[rank[i]] = sIdx[k] & 0x7FFFFFFFu;
-        }
     }
-    if (lane == 0) tileNum[bandTile] = num;
-}
-template <bool BRUTE>
-__global__ __launch_bounds__(256) void k1_tile_cull(const float4* __restrict__ lightView, const uint32_t* __restrict__ lightType, int N, int words,
-                                                    const float4* __restrict__ tileInfo, int Tx, int bandRows,
-                                                    const unsigned long long* __restrict__ masks,
-                                                    const uint32_t* __restrict__ groupCount, const uint32_t* __restrict__ groupList, int groupsX,
-                                                    uint32_t* __restrict__ tileNum, uint32_t* __restrict__ tileList)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K1_TILE_CULL];
-    k1_tile_cull_body<BRUTE>(blockIdx.x, lds, lightView, lightType, N, words, tileInfo, Tx, bandRows, masks, groupCount, groupList, groupsX, tileNum, tileList);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t k = lane + 64u * i;
+        if (k < n && rank[i] < KEEP) out[rank[i]] = sIdx[k] & 0x7FFFFFFFu;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1d: canonical offsets (Appendix A step 6) and compaction: per-1024-tile block sums, then every tile's wave
-// rebuilds its own exclusive prefix (block sums before its block + tiles before it inside the block).
+// K1d: canonical offsets (Appendix A step 6) and compaction.  Block p owns the staging slots (= k1_tile_cull blocks, = runs of
+// four tiles in tile-index order) [16 p, 16 p + 16).  Its base is the sum of the totals of all slots before them -- read and added
+// up by the block itself, 4 bytes per slot, from L2: no scan kernel, no look-back chain, no atomics (one atomic add per
+// k1_tile_cull block into per-pack-block sums was tried: +3 us on k1_tile_cull).  Then: one wave
+// turns the 64 tiles' list lengths into offsets (lightsGrid), and the 16 slots move to culledLights as contiguous runs.
 // ------------------------------------------------------------------------------------------------------------
-// Tile classes for the shading ORDER hint (sailor_hip_light_cull_tile_order): A = lists of >= CLASS_A entries, B = >= CLASS_B, C = the rest.
-// Their counts ride through the same scan, packed A | B << 16 (<= 1024 tiles per block: no carry).
-#define CLASS_A 96u
-#define CLASS_B 40u
-__device__ __forceinline__ uint32_t tile_class_bits(uint32_t num) { return num >= CLASS_A ? 1u : (num >= CLASS_B ? 0x10000u : 0u); }
+struct PackArgs {
+    const uint32_t* totals; const uint32_t* clsTotals; const uint32_t* tileNum; const uint32_t* staging;
+    SailorLightsGrid* grid; uint32_t* culled; uint32_t* tileOrder;
+    int Tx, groupsX, bandRows, cullBlocks, classes;
+    uint32_t capacity;
+};
 
-__global__ __launch_bounds__(1024) void k1_block_sums(const uint32_t* __restrict__ tileNum, int T, uint32_t* __restrict__ tilePrefix,
-                                                       uint32_t* __restrict__ blockSums, uint32_t* __restrict__ classPrefix, uint32_t* __restrict__ classSums)
+__device__ __forceinline__ uint32_t sum_u32_prefix(const uint32_t* __restrict__ v, const int count4)
 {
-    __shared__ uint32_t sW[16], sC[16];
-    const int t = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    // sum of v[0 .. 4 count4): 16 bytes per load, four loads in flight per thread
+    const uint4* __restrict__ v4 = reinterpret_cast<const uint4*>(v);
+    uint32_t acc = 0u;
+    for (int i = threadIdx.x; i < count4; i += 1024) {
+        uint4 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[k] = i + 256 * k < count4 ? v4[i + 256 * k] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc += (q[k].x + q[k].y) + (q[k].z + q[k].w);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k1_pack(const PackArgs a)
+{
+    __shared__ uint32_t sPart[4], sPartC[4];
+    __shared__ uint32_t sLen[PACK_BLOCKS], sDst[PACK_BLOCKS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t v = (t < T) ? tileNum[t] : 0u;
-    const bool classes = classPrefix != nullptr; // the order hint is only produced for split frames (see the host side)
-    const uint32_t c = (classes && t < T) ? tile_class_bits(v) : 0u;
-    uint32_t incl = v, cincl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += u;
-        if (classes) { const uint32_t uc = (uint32_t)__shfl_up((int)cincl, d); if (lane >= d) cincl += uc; }
+    const int first = (int)blockIdx.x * PACK_BLOCKS;
+    // this block's 64 tiles: requested now, used after the base is known
+    uint32_t num = 0u;
+    int tile = -1, tx = 0, tyLocal = 0;
+    if (wave == 0) {
+        const int cb = first + (lane >> 2);
+        if (cb < a.cullBlocks) {
+            tyLocal = cb / a.groupsX;
+            tx = (cb - tyLocal * a.groupsX) * GROUP + (lane & 3);
+            if (tx < a.Tx) { tile = tyLocal * a.Tx + tx; num = a.tileNum[tile]; }
+        }
     }
-    if (lane == 63) { sW[wave] = incl; sC[wave] = cincl; }
+    uint32_t own = 0u;
+    if (threadIdx.x < PACK_BLOCKS && first + (int)threadIdx.x < a.cullBlocks) own = a.totals[first + threadIdx.x];
+    // totals of every slot before this block's (`first` is a multiple of 16)
+    uint32_t acc = sum_u32_prefix(a.totals, first / 4), accC = a.classes ? sum_u32_prefix(a.clsTotals, first / 4) : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { acc += (uint32_t)__shfl_xor((int)acc, d, 64); accC += (uint32_t)__shfl_xor((int)accC, d, 64); }
+    if (lane == 0) { sPart[wave] = acc; sPartC[wave] = accC; }
     __syncthreads();
-    uint32_t before = 0, total = 0, cbefore = 0, ctotal = 0;
+    const uint32_t baseSum = (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]);
+    const uint32_t baseCls = (sPartC[0] + sPartC[1]) + (sPartC[2] + sPartC[3]);
+    if (wave == 0) {
+        // the 16 slots: length and destination (inclusive scan over lanes 0..15)
+        const uint32_t len = own;
+        uint32_t incl = len;
 #pragma unroll
-    for (int w = 0; w < 16; w++) {
-        const uint32_t x = sW[w], y = sC[w];
-        before += (w < wave) ? x : 0u; total += x;
-        cbefore += (w < wave) ? y : 0u; ctotal += y;
+        for (int d = 1; d < PACK_BLOCKS; d <<= 1) {
+            const uint32_t u = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += u;
+        }
+        if (lane < PACK_BLOCKS) { sLen[lane] = len; sDst[lane] = 1u + baseSum + incl - len; }
+        // the 64 tiles: offset = 1 + entries of all earlier tiles
+        uint32_t tincl = num;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t u = (uint32_t)__shfl_up((int)tincl, d);
+            if (lane >= d) tincl += u;
+        }
+        const uint32_t offset = 1u + baseSum + tincl - num;
+        if (tile >= 0) {
+            // A list that does not fit the caller's buffer is cut, and the grid says so: the shade never reads past `capacity`.
+            const uint32_t fit = offset >= a.capacity ? 0u : min(num, a.capacity - offset);
+            a.grid[tile].offset = offset;
+            a.grid[tile].num = fit;
+        }
+        if (a.classes) {
+            // the shading hint: class A tiles from the front of the array, class B tiles from its back, both in tile order
+            const uint32_t mine = tile_class_word(num);
+            uint32_t c = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t uc = (uint32_t)__shfl_up((int)c, d);
+                if (lane >= d) c += uc;
+            }
+            const uint32_t cb = baseCls + c - mine; // class counts of all earlier tiles
+            const uint32_t aBefore = cb >> 16, bBefore = cb & 0xFFFFu;
+            const uint32_t T = (uint32_t)(a.bandRows * a.Tx);
+            if (tile >= 0 && num >= CLASS_B) a.tileOrder[num >= CLASS_A ? aBefore : T - 1u - bBefore] = (uint32_t)tx | ((uint32_t)tyLocal << 16);
+            if (first + PACK_BLOCKS >= a.cullBlocks && lane == 63) { // the last block: the two counts
+                const uint32_t all = cb + mine;
+                a.tileOrder[T] = all >> 16;
+                a.tileOrder[T + 1u] = all & 0xFFFFu;
+            }
+        }
+        if (first + PACK_BLOCKS >= a.cullBlocks && lane == 63) { // Appendix A step 6: indices[0] = sum of num
+            const uint32_t tot = baseSum + tincl;
+            a.culled[0] = a.capacity ? min(tot, a.capacity - 1u) : 0u;
+        }
     }
-    if (t < T) tilePrefix[t] = before + incl - v; // exclusive prefix inside the 1024-tile block
-    if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
-    if (classes) {
-        if (t < T) classPrefix[t] = cbefore + cincl - c;
-        if (threadIdx.x == 0) classSums[blockIdx.x] = ctotal;
-    }
-}
-
-__device__ __forceinline__ void k1_pack_body(const unsigned bx, const uint32_t* __restrict__ tileNum, const uint32_t* __restrict__ tilePrefix,
-                                             const uint32_t* __restrict__ blockSums, int sumBlocks, const uint32_t* __restrict__ tileList, int T,
-                                             SailorLightsGrid* __restrict__ grid, uint32_t* __restrict__ culled, uint32_t capacity,
-                                             const uint32_t* __restrict__ classPrefix, const uint32_t* __restrict__ classSums, int Tx, uint32_t* __restrict__ tileOrder)
-{
-    const int tile = bx * 4 + (threadIdx.x >> 6);
-    if (tile >= T) return;
-    const int lane = threadIdx.x & 63;
-    const int blk = tile / SCAN_BLOCK;
-    // everything this wave reads is addressed by the tile index alone: issue it all up front (the staging list speculatively, both halves
-    // of its KEEP slots), so that the only dependent step is the store at the tile's offset
-    const uint32_t* src = tileList + (size_t)tile * KEEP;
-    const uint32_t e0 = src[lane], e1 = src[lane + 64];
-    const uint32_t num = tileNum[tile];
-    const uint32_t prefixInBlock = tilePrefix[tile];
-    const bool classes = classPrefix != nullptr;
-    uint32_t s = 0, tot = 0, aB = 0, aT = 0, bB = 0, bT = 0; // sums over earlier blocks / all blocks: entries, class A tiles, class B tiles
-    for (int i = lane; i < sumBlocks; i += 64) {
-        const uint32_t b = blockSums[i];
-        tot += b; s += (i < blk) ? b : 0u;
-        if (classes) {
-            const uint32_t c = classSums[i];
-            aT += c & 0xFFFFu; bT += c >> 16;
-            if (i < blk) { aB += c & 0xFFFFu; bB += c >> 16; }
+    __syncthreads();
+    // all loads first (two per slot and thread: a slot holds <= 512 entries), then the stores: one round trip for the block's 32 KB
+    uint32_t v[PACK_BLOCKS][2];
+#pragma unroll
+    for (int j = 0; j < PACK_BLOCKS; j++) {
+        const uint32_t len = sLen[j];
+        const uint32_t* __restrict__ src = a.staging + (size_t)(first + j) * SLOT;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t e = threadIdx.x + 256u * h;
+            v[j][h] = e < len ? src[e] : 0u;
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { s += (uint32_t)__shfl_xor((int)s, d); tot += (uint32_t)__shfl_xor((int)tot, d); }
-    if (classes) {
+    for (int j = 0; j < PACK_BLOCKS; j++) {
+        const uint32_t len = sLen[j], dst = sDst[j];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            aB += (uint32_t)__shfl_xor((int)aB, d); aT += (uint32_t)__shfl_xor((int)aT, d);
-            bB += (uint32_t)__shfl_xor((int)bB, d); bT += (uint32_t)__shfl_xor((int)bT, d);
+        for (int h = 0; h < 2; h++) {
+            const uint32_t e = threadIdx.x + 256u * h;
+            if (e < len && dst + e < a.capacity) a.culled[dst + e] = v[j][h];
         }
     }
-    const uint32_t offset = s + prefixInBlock + 1u;
-    if (lane == 0) { grid[tile].offset = offset; grid[tile].num = num; }
-    if (classes && lane == 0) {
-        // the order hint: long lists first (their blocks run longest; started last they are the tail of the shade launch), each class in
-        // tile order (neighbouring tiles share light records in L2)
-        const uint32_t cp = classPrefix[tile];
-        const uint32_t aBefore = aB + (cp & 0xFFFFu), bBefore = bB + (cp >> 16);
-        const uint32_t cls = tile_class_bits(num);
-        const uint32_t pos = cls == 1u ? aBefore : (cls ? aT + bBefore : aT + bT + ((uint32_t)tile - aBefore - bBefore));
-        tileOrder[pos] = (uint32_t)(tile % Tx) | ((uint32_t)(tile / Tx) << 16);
-        if (tile == 0) tileOrder[T] = aT + bT; // how many entries of the order hold >= CLASS_B lights (the shade's split blocks)
-    }
-    if ((uint32_t)lane < num && offset + lane < capacity) culled[offset + lane] = e0;
-    if ((uint32_t)lane + 64u < num && offset + lane + 64u < capacity) culled[offset + lane + 64u] = e1;
-    if (tile == 0 && lane == 0) culled[0] = tot;
-}
-__global__ __launch_bounds__(256) void k1_pack(const uint32_t* __restrict__ tileNum, const uint32_t* __restrict__ tilePrefix,
-                                                const uint32_t* __restrict__ blockSums, int sumBlocks,
-                                                const uint32_t* __restrict__ tileList, int T, SailorLightsGrid* __restrict__ grid,
-                                                uint32_t* __restrict__ culled, uint32_t capacity,
-                                                const uint32_t* __restrict__ classPrefix, const uint32_t* __restrict__ classSums, int Tx, uint32_t* __restrict__ tileOrder)
-{
-    k1_pack_body(blockIdx.x, tileNum, tilePrefix, blockSums, sumBlocks, tileList, T, grid, culled, capacity, classPrefix, classSums, Tx, tileOrder);
 }
 
 __global__ void k_grid_rebase(SailorLightsGrid* grid, int T, uint32_t base)
@@ -799,7 +840,15 @@ static bool band_valid(int W, int H, const SailorBand* b)
     return b->fbRowBegin == lo && b->fbRowCount == hi - lo;
 }
 
+// the tile-order hint is produced for split frames whose class counts fit 16 bits each
+static bool layout_has_hint(const CullLayout& L) { return L.bandRows < L.Ty && L.bandTiles > 0 && L.bandTiles <= CLS_MAX_TILES; }
+
 extern "C" {
+
+int sailor_hip_band_is_valid(int32_t width, int32_t height, const SailorBand* band)
+{
+    return (width > 0 && height > 0 && band_valid(width, height, band)) ? 1 : 0;
+}
 
 size_t sailor_hip_light_cull_workspace_size(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band)
 {
@@ -827,82 +876,73 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
     const CullLayout L = make_layout(W, H, N, *band);
     if (pc->numTiles[0] != L.Tx || pc->numTiles[1] != L.Ty) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (workspaceBytes < L.total) return SAILOR_HIP_ERR_WORKSPACE_TOO_SMALL;
-    if (culledCapacity < 1) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    // The reference allocates numTiles * 128 uints (LightCullingNode.cpp:64: one short of the worst case); anything smaller than
+    // that cannot hold a band of full lists and is refused up front.  A buffer of exactly that size is accepted: a list that does
+    // not fit is cut and lightsGrid[tile].num / culledLights[0] say what was written.
+    if (culledCapacity < 1 || culledCapacity < (size_t)L.bandTiles * KEEP) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if ((unsigned long long)L.bandTiles * KEEP > 0x7FFFFFFFull) return SAILOR_HIP_ERR_UNSUPPORTED;
     if (((uintptr_t)dWorkspace & 255) != 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
 
     hipStream_t s = ctx->stream;
     char* ws = (char*)dWorkspace;
-    float4* lightView = (float4*)(ws + L.offLightView);
-    uint32_t* lightType = (uint32_t*)(ws + L.offLightType);
-    float4* tileInfo = (float4*)(ws + L.offTileInfo);
-    float4* bandPlanes = (float4*)(ws + L.offBandPlanes);
-    unsigned long long* masks = (unsigned long long*)(ws + L.offMasks);
-    unsigned long long* dirWords = (unsigned long long*)(ws + L.offDirWords);
-    uint32_t* tileNum = (uint32_t*)(ws + L.offTileNum);
-    uint32_t* tilePrefix = (uint32_t*)(ws + L.offTilePrefix);
-    uint32_t* tileList = (uint32_t*)(ws + L.offTileList);
-    uint32_t* blockSums = (uint32_t*)(ws + L.offBlockSums);
-    uint32_t* groupCount = (uint32_t*)(ws + L.offGroupCount);
-    uint32_t* groupList = (uint32_t*)(ws + L.offGroupList);
 
     if (L.bandTiles == 0) {
         SAILOR_TRY_HIP(ctx, hipMemsetAsync(dCulledLights, 0, 4, s));
         return SAILOR_HIP_OK;
     }
 
-    Mat4 view, invProj;
-    memcpy(view.m, frame->view, 64);
-    memcpy(invProj.m, frame->invProjection, 64);
-
     // The side-plane margin argument needs a sane perspective; tiny light counts are cheaper brute force.
     const float p00 = fabsf(frame->projection[0]), p11 = fabsf(frame->projection[5]);
     const bool sane = p00 > 1e-2f && p11 > 1e-2f && p00 < 1e4f && p11 < 1e4f;
     const bool brute = (flags & SAILOR_CULL_BRUTE_FORCE) || !sane || N < 512;
 
-    const int lightBlocks = (N + 255) / 256;
-    const int bandBlocks = brute ? 0 : (L.numBands + 255) / 256;
-    const int stripsPerRow = (L.Tx + 15) / 16;
     PrepareArgs pa;
-    pa.view = view; pa.invProj = invProj;
+    memcpy(pa.view.m, frame->view, 64);
+    memcpy(pa.invProj.m, frame->invProjection, 64);
     pa.lights = dLights; pa.depth = dLinearDepth;
-    pa.lightView = lightView; pa.lightType = lightType; pa.tileInfo = tileInfo; pa.bandPlanes = bandPlanes;
-    pa.N = N; pa.lightBlocks = lightBlocks; pa.setupBlocks = stripsPerRow * L.bandRows;
+    pa.lightView = (float4*)(ws + L.offLightView); pa.lightType = (uint32_t*)(ws + L.offLightType); pa.tileInfo = (float4*)(ws + L.offTileInfo);
+    pa.masks = (unsigned long long*)(ws + L.offMasks); pa.dirWords = (unsigned long long*)(ws + L.offDirWords);
+    pa.N = N; pa.words = L.words;
+    pa.lightBlocks = (N + 255) / 256;
+    pa.numBands = brute ? 0 : L.numBands;
+    const int splits = brute ? 1 : (L.numBands + BANDS_PER_BLOCK - 1) / BANDS_PER_BLOCK;
+    pa.bandsPerBlock = brute ? 0 : (L.numBands + splits - 1) / splits; // the bands spread evenly over the splits
+    pa.lightRoleBlocks = pa.lightBlocks * splits;
+    pa.stripsPerRow = (L.Tx + 16 * SETUP_STRIPS - 1) / (16 * SETUP_STRIPS);
+    pa.setupBlocks = pa.stripsPerRow * L.bandRows;
     pa.vpW = frame->viewportSize[0]; pa.vpH = frame->viewportSize[1]; pa.W = W; pa.H = H; pa.Tx = L.Tx; pa.Ty = L.Ty;
-    pa.tileRow0 = band->tileRowBegin; pa.bandRow0 = band->fbRowBegin; pa.bandRows = L.bandRows; pa.groupsX = L.groupsX; pa.numBands = L.numBands;
-    pa.stripsPerRow = stripsPerRow;
+    pa.tileRow0 = band->tileRowBegin; pa.bandRow0 = band->fbRowBegin; pa.bandRows = L.bandRows; pa.groupsX = L.groupsX;
     pa.vecOK = (((uintptr_t)dLinearDepth & 15) == 0 && (W & 3) == 0) ? 1 : 0;
     pa.rawDepth = (flags & SAILOR_CULL_RAW_DEPTH) ? 1 : 0;
     pa.zNearCam = frame->cameraZNearZFar[0];
-    hipLaunchKernelGGL(k01_prepare, dim3(pa.setupBlocks + lightBlocks + bandBlocks), dim3(256), 0, s, pa);
+    pa.planeMargin = 1e-3f;
+    hipLaunchKernelGGL(k01_prepare, dim3(pa.lightRoleBlocks + pa.setupBlocks), dim3(256), 0, s, pa);
     SAILOR_CHECK_LAUNCH(ctx, "k01_prepare");
 
+    CullArgs ca;
+    ca.lightView = pa.lightView; ca.lightType = pa.lightType; ca.tileInfo = pa.tileInfo; ca.masks = pa.masks;
+    ca.groupCount = (const uint32_t*)(ws + L.offGroupCount); ca.groupList = (const uint32_t*)(ws + L.offGroupList);
+    ca.totals = (uint32_t*)(ws + L.offTotals); ca.clsTotals = (uint32_t*)(ws + L.offClsTotals); ca.tileNum = (uint32_t*)(ws + L.offTileNum); ca.staging = (uint32_t*)(ws + L.offStaging);
+    ca.N = N; ca.words = L.words; ca.Tx = L.Tx; ca.groupsX = L.groupsX;
+    // The hint pays for itself on split frames (a band's shade launch is bounded by its longest tile); on the whole frame it measured nothing.
+    ca.classes = layout_has_hint(L) ? 1 : 0;
     if (brute) {
-        hipLaunchKernelGGL(k1_tile_cull<true>, dim3(L.numGroups * 4), dim3(256), 0, s, lightView, lightType, N, L.words, tileInfo, L.Tx, L.bandRows, masks,
-                           groupCount, groupList, L.groupsX, tileNum, tileList);
+        hipLaunchKernelGGL(k1_tile_cull<true>, dim3(L.cullBlocks), dim3(256), 0, s, ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull<brute>");
     } else {
-        const float planeMargin = 1e-3f;
-        const int groups = (L.numBands + BANDS_PER_GROUP - 1) / BANDS_PER_GROUP;
-        hipLaunchKernelGGL(k1_band_masks, dim3((L.words + 3) / 4, groups), dim3(256), 0, s, lightView, lightType, N, L.words, bandPlanes, L.numBands,
-                           planeMargin, masks, dirWords);
-        SAILOR_CHECK_LAUNCH(ctx, "k1_band_masks");
-        hipLaunchKernelGGL(k1_group_lists, dim3(L.numGroups), dim3(256), 0, s, masks, dirWords, L.words, L.Tx, L.bandRows, L.groupsX, groupCount, groupList);
+        hipLaunchKernelGGL(k1_group_lists, dim3(L.numGroups), dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
+                           (uint32_t*)(ws + L.offGroupList));
         SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
-        hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.numGroups * 4), dim3(256), 0, s, lightView, lightType, N, L.words, tileInfo, L.Tx, L.bandRows, masks,
-                           groupCount, groupList, L.groupsX, tileNum, tileList);
+        hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.cullBlocks), dim3(256), 0, s, ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
     }
-    // The order hint pays for itself on split frames (a band's shade launch is bounded by its longest tile; starting those first took
-    // 14 us off the slowest band of an 8-way split); on the whole frame it only costs (the scan grows by 5 us, the shade does not
-    // get faster: 16 rounds of blocks hide the tail), so it is not produced there.
-    const bool splitFrame = L.bandRows < L.Ty;
-    uint32_t* classPrefix = splitFrame ? (uint32_t*)(ws + L.offClassPrefix) : nullptr;
-    uint32_t* classSums = (uint32_t*)(ws + L.offClassSums);
-    uint32_t* tileOrder = (uint32_t*)(ws + L.offTileOrder);
-    hipLaunchKernelGGL(k1_block_sums, dim3(L.sumBlocks), dim3(SCAN_BLOCK), 0, s, tileNum, L.bandTiles, tilePrefix, blockSums, classPrefix, classSums);
-    SAILOR_CHECK_LAUNCH(ctx, "k1_block_sums");
-    hipLaunchKernelGGL(k1_pack, dim3((L.bandTiles + 3) / 4), dim3(256), 0, s, tileNum, tilePrefix, blockSums, L.sumBlocks, tileList, L.bandTiles, dLightsGrid,
-                       dCulledLights, (uint32_t)(culledCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : culledCapacity), classPrefix, classSums, L.Tx, tileOrder);
+    PackArgs ka;
+    ka.totals = ca.totals; ka.clsTotals = ca.clsTotals; ka.tileNum = ca.tileNum; ka.staging = ca.staging;
+    ka.grid = dLightsGrid; ka.culled = dCulledLights; ka.tileOrder = (uint32_t*)(ws + L.offTileOrder);
+    ka.Tx = L.Tx; ka.groupsX = L.groupsX; ka.bandRows = L.bandRows; ka.cullBlocks = L.cullBlocks; ka.classes = ca.classes;
+    ka.capacity = (uint32_t)(culledCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : culledCapacity);
+    hipLaunchKernelGGL(k1_pack, dim3(L.packBlocks), dim3(256), 0, s, ka);
     SAILOR_CHECK_LAUNCH(ctx, "k1_pack");
     return SAILOR_HIP_OK;
 }
@@ -934,6 +974,7 @@ int sailor_hip_linearize_depth(SailorHipContext* ctx, const SailorUboFrameData* 
     if (!ctx || !frame || !dRawDepth || !dLinearDepth || width <= 0 || rows < 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     const size_t count = (size_t)width * (size_t)rows;
     if (count == 0) return SAILOR_HIP_OK;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
     const int vec = ((((uintptr_t)dRawDepth | (uintptr_t)dLinearDepth) & 15) == 0) ? 1 : 0;
     size_t blocks = (count / 4 + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32; // 32 blocks per CU, grid-stride beyond
@@ -950,8 +991,9 @@ const uint32_t* sailor_hip_light_cull_tile_order(int32_t width, int32_t height, 
     if (!band) { sailor_hip_band_whole_frame(width, height, &whole); band = &whole; }
     if (!band_valid(width, height, band)) return nullptr;
     if (width > 16 * 65535 || height > 16 * 65535) return nullptr; // packed as two 16-bit tile coordinates
-    if (band->tileRowEnd - band->tileRowBegin >= (height - 1) / TILE + 1) return nullptr; // whole frame: no hint is produced (raster order)
-    return (const uint32_t*)((const char*)dWorkspace + make_layout(width, height, lightsCapacity, *band).offTileOrder);
+    const CullLayout L = make_layout(width, height, lightsCapacity, *band);
+    if (!layout_has_hint(L)) return nullptr; // whole frame: no hint is produced (raster order)
+    return (const uint32_t*)((const char*)dWorkspace + L.offTileOrder);
 }
 
 // Diagnostics for benchmarks / tuning (synchronises): density of the band masks and of the group candidate lists left in
@@ -991,6 +1033,7 @@ int sailor_hip_light_grid_rebase(SailorHipContext* ctx, SailorLightsGrid* dLight
 {
     if (!ctx || !dLightsGrid || numTiles < 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (numTiles == 0 || globalBase == 0) return SAILOR_HIP_OK;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_grid_rebase, dim3((numTiles + 255) / 256), dim3(256), 0, ctx->stream, dLightsGrid, numTiles, globalBase);
     SAILOR_CHECK_LAUNCH(ctx, "k_grid_rebase");
     return SAILOR_HIP_OK;

@@ -54,9 +54,11 @@ void k2_shade_band(ShadeArgs A, CsmArgs C, int bandTiles, const float4* __restri
         k2_shade_body<false, false, ROLE_BAND_TILE>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, t - ty * A.Tx, ty, 0);
         return;
     }
-    const uint32_t limit = 4u * A.order[bandTiles];
+    // the cull's hint: order[0 .. nA) = the tiles with >= 96 lights, order[T-1], order[T-2] .. = the nB tiles with 40..95, order[T] = nA, order[T+1] = nB
+    const uint32_t nA = A.order[bandTiles], limit = 4u * (nA + A.order[bandTiles + 1]);
     for (uint32_t idx = blockIdx.x; idx < limit; idx += (uint32_t)SPLIT_BLOCKS) {
-        const uint32_t o = A.order[idx >> 2];
+        const uint32_t li = idx >> 2;
+        const uint32_t o = A.order[li < nA ? li : (uint32_t)bandTiles - 1u - (li - nA)];
         k2_shade_body<false, false, ROLE_BAND_SPLIT>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, (int)(o & 0xFFFFu), (int)(o >> 16),
                                                            (int)(idx & 3u));
         __syncthreads(); // the LDS arrays are reused by the block's next tile
@@ -119,10 +121,11 @@ extern "C" int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFrameDa
     SailorBand whole;
     if (!band) { sailor_hip_band_whole_frame(W, H, &whole); band = &whole; }
     const int Ty = (H - 1) / TILE + 1;
-    if (band->tileRowBegin < 0 || band->tileRowEnd > Ty || band->tileRowBegin > band->tileRowEnd) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (!sailor_hip_band_is_valid(W, H, band)) return SAILOR_HIP_ERR_INVALID_ARGUMENT; // tile rows AND their framebuffer rows, as the cull checks them
     if (surfacePlaneStride < (size_t)band->fbRowCount * W) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (((uintptr_t)dSurface & 15) || ((uintptr_t)dRadiance & 15) || ((uintptr_t)dLights & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
 
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
     ShadeArgs A;
     memcpy(A.view.m, frame->view, 64);
     A.camX = frame->cameraPosition[0]; A.camY = frame->cameraPosition[1]; A.camZ = frame->cameraPosition[2];

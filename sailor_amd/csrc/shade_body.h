@@ -221,7 +221,7 @@ __device__ __forceinline__ void wave_minmax6(int& a, int& b, int& c, int& d, int
 // BAND (split frames: sailor_hip_shade_ex on a sub-band with the cull's tile-order hint): a band of a split frame has too few
 // tiles to hide its longest one -- a tile in the middle of a light cluster (128 lights reaching all 256 pixels = 128 pair passes
 // per wave) kept its block busy for ~65 us while the rest of a 1/8 band took 25.  The hint lists the band's tiles by list-length
-// class, long lists first, and ends with the number of tiles holding >= SPLIT_MIN lights.  Those tiles are taken by "split"
+// class (>= 96 lights from the front of the array, >= SPLIT_MIN from its back, then the two counts).  Those tiles are taken by "split"
 // blocks, one per (tile, 8x8 quadrant): the block's four waves take every fourth list slot each over the SAME 64 pixels and add
 // their partial sums up through LDS (wave 0 + 1 + 2 + 3, a fixed order).  The grid is 1-D: SPLIT_BLOCKS split blocks first (they
 // walk the long tiles with a grid stride, so the long tiles start first), then one ordinary block per tile, which returns at
@@ -254,12 +254,11 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     // loop those values stay live across the whole body and the 64-register budget spills)
     if (splitRole) asm volatile("" : "+v"(tid));
 
-    // grid = (tiles per row, tile rows of the band): no division.  With an order hint block i takes the i-th tile of that order.
+    // grid = (tiles per row, tile rows of the band): no division.
     int btx = blockIdx.x, bty = blockIdx.y;
     const int lane = tid & 63, wave = tid >> 6;
     int quad = wave;
     if (BAND) { btx = selTx; bty = selTy; if (splitRole) quad = selQuad; }
-    else if (A.order) { const uint32_t o = A.order[blockIdx.y * A.Tx + blockIdx.x]; btx = (int)(o & 0xFFFFu); bty = (int)(o >> 16); }
     const int tx = btx, ty = A.tileRow0 + bty;
     const int bandTile = bty * A.Tx + btx;
     // each wave shades one 8x8 quadrant of the tile: the most compact 64-pixel footprint, so that "no pixel of the wave
