@@ -7,13 +7,13 @@
 
 One step = one pass of the hot path over one synthetic frame: K0 light view transform + K1 tile light cull + K2 PBR shade
 over the per-tile lists (BASELINE.json configs[2]: 4K, 65 536 point+spot lights, synthetic G-buffer/surface tiles), with
-every input already resident in HBM.  With N > 1 every rank runs that same step on a whole frame of its own (frames, and the
-tiles inside them, are independent units: per-GPU work is fixed -- weak scaling, no collective on the data path), and
-`value` = N*W*H*K / max-over-ranks(time).  The same invocation then measures the other way of using N GPUs and reports it
-as `split_frame`: ONE frame cut into N cost-balanced tile-row bands (strong scaling); cull + shade need no
-collective there either; after its timed steps the band lists are exchanged once over RCCL (count all-gather + index
-all-gather) and the stitched global buffers are summarised by a checksum, so the distributed path is exercised end to end.
-`--split-frame` swaps the roles (the split frame becomes `value`, a frame per GPU is reported as `alternate_frame_rendering`).
+every input already resident in HBM.  With N > 1 the step is ONE frame cut into N cost-balanced tile-row bands, one band per
+rank (BASELINE.json's multi-GPU metric, SURVEY.md 8e: strong scaling; cull + shade need no collective), and
+`value` = W*H*K / max-over-ranks(time); after the timed steps the band lists are exchanged once over RCCL (count all-gather +
+index all-gather) and the stitched global buffers are summarised by a checksum, so the distributed path is exercised end to
+end (`--exchange-every-step` puts the exchange inside the timed region).  The same invocation also measures the other way of
+using N GPUs -- every rank renders whole frames of its own -- and reports it as `alternate_frame_rendering`, together with
+`speedup_vs_one_gpu_whole_frame` = that whole-frame step time / the split step time.  `--frame-per-gpu` swaps the roles.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k2_shade): algorithmic bytes per launch
 / its launch duration from one HIP event pair around K back-to-back launches on the launch stream.  `cpu_baseline` = the
@@ -63,9 +63,10 @@ def parse():
                     help="2 (the reference's MaxFramesInQueue, RHI/Renderer.h:34): frame k+1's cull is recorded on a second stream beside frame k's shade")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--equal-bands", action="store_true", help="N > 1: equal tile-row bands instead of cost-balanced ones")
-    ap.add_argument("--split-frame", action="store_true",
-                    help="N > 1: make ONE frame split into tile-row bands (strong scaling, latency-bound) the primary measurement; by default every GPU "
-                         "renders whole frames of its own (weak scaling, no data-path collective) and the split frame is reported next to it")
+    ap.add_argument("--split-frame", action="store_true", help="N > 1: ONE frame split into tile-row bands is `value` (the default; kept for old command lines)")
+    ap.add_argument("--frame-per-gpu", action="store_true",
+                    help="N > 1: make a whole frame per GPU (weak scaling, no data-path collective) the primary measurement; by default ONE frame is "
+                         "split into tile-row bands (strong scaling, BASELINE.json's metric) and the frame-per-GPU reading is reported next to it")
     ap.add_argument("--no-afr", action="store_true", help="N > 1: skip the supplementary measurement (the other of the two multi-GPU modes)")
     ap.add_argument("--simulate-split", type=int, default=0, help="G: time each band of a cost-balanced G-way split one after the other on this GPU and print the predicted speed-up; diagnostic")
     ap.add_argument("--simulate-band", default=None, help="R/G: time only band R of a G-way split in this single process (no collectives); diagnostic")
@@ -511,9 +512,9 @@ def main():
 
     band = host.band_for_rank(W, H, rank, world)
     partition = "whole frame"
-    # N > 1, default: the units of the path -- frames, and the tiles inside them -- are independent, so every GPU takes a whole frame per step
-    # (per-GPU work fixed: weak scaling, no collective on the data path).  --split-frame: one frame cut into bands (strong scaling).
-    weak = not args.split_frame
+    # N > 1, default: ONE frame cut into tile-row bands, one per GPU (BASELINE.json's metric: strong scaling).  --frame-per-gpu: every GPU
+    # takes a whole frame per step (per-GPU work fixed: weak scaling, no collective on the data path).
+    weak = args.frame_per_gpu
     if world > 1 and weak:
         band = host.band_whole_frame(W, H)
         partition = "one whole frame per GPU and step (frames are independent; no data-path collective)"
@@ -649,6 +650,19 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     frames_per_step = world if (weak and world > 1) else 1
+    # per-step distribution (median, p10 / p90): a second pass of K steps with one HIP event per step on the launch stream --
+    # outside the timed region above, which stays free of event records
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    evs[0].record(side)
+    for i in range(args.steps):
+        run_step()
+        evs[i + 1].record(side)
+    torch.cuda.synchronize()
+    per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)])
+    step_stats = {"median": float(np.median(per_step)), "p10": float(np.percentile(per_step, 10)), "p90": float(np.percentile(per_step, 90)),
+                  "how": "HIP events between consecutive steps on the launch stream, a separate pass of K steps (this rank)"}
+    if args.steps & 1 and pipelined:
+        run_step()  # keep the two-frames-in-flight parity
     value = frames_per_step * W * H * args.steps / elapsed / 1e6
 
     # ---- per-kernel timing on the launch stream (HIP events) + algorithmic bytes ----
@@ -814,6 +828,7 @@ def main():
                        "width": W, "height": H, "lights": N, "parallelism": (f"dp{world}: a whole frame per GPU" if weak else f"tile-row bands x{world}"), "partition": partition,
                        "mean_list_length": sum_nt / max(fp.band_tiles, 1), "sum_num_rank0_band": sum_nt, "distinct_lights_rank0_band": distinct,
                        "generator": {"seed": synth.SEED, "radius_scale": frame.cfg["lights"].radius_scale}},
+            "step_ms": step_stats,
             "mlights_culled_per_s": N / (cull_batch_ms * 1e-3) / 1e6,
             "cull_ms": cull_batch_ms, "shade_ms": shade_batch_ms,
             "roofline": roofline,
@@ -822,6 +837,8 @@ def main():
             out["exchange"] = exchange_info
         if afr:
             out["alternate_frame_rendering"] = afr
+            if "ms_per_frame_per_gpu" in afr:
+                out["speedup_vs_one_gpu_whole_frame"] = afr["ms_per_frame_per_gpu"] / ms_per_step
         if split:
             out["split_frame"] = split
         if world == 1 and not args.no_cpu_baseline:

@@ -6,15 +6,16 @@
 // re-reads and re-transforms every light, appends with LDS atomics, bubble-sorts on one thread and allocates
 // output space with a global atomic.  Here, four launches:
 //
-//   k01_prepare        two independent roles in one launch.
+//   k01_prepare        three independent roles in one launch.
 //                      lights : once per light, view-space position + radius into a float4 SoA (same fp32 op sequence as
 //                               ComputeLightCulling.shader:164-169, so bits are identical), then -- same wave, the record
 //                               still in registers -- the conservative pre-filter as BITMASKS: one 64-bit ballot per
 //                               (64 lights, column of 4x4-tile groups) and per (64 lights, row of groups): "this light's
 //                               sphere may reach this 64-pixel band".  No atomics, no compaction, no inter-block order.
-//                      tiles  : streaming pass over the linear-depth image (the only large HBM stream of the cull):
-//                               16 tiles per 256-thread block, 1 KiB coalesced float4 row segments, wave shuffles + a
-//                               4-entry LDS combine for min/max; 16 lanes build the 16 tile frusta while the loads fly
+//                      frusta : one lane per tile: the four side planes + centre (they do not depend on the depth)
+//                      depth  : streaming pass over the linear-depth image (the only large HBM stream of the cull):
+//                               32 tiles per 256-thread block, 1 KiB coalesced float4 row segments, wave shuffles + a
+//                               4-entry LDS combine for min/max
 //   k1_group_lists     one block per 4x4-tile group: (its column's mask) AND (its row's mask), 16 384 lights per
 //                      step; the few surviving bits become an ordered, contiguous candidate list (ballot, readlane, mbcnt)
 //   k1_tile_cull       one 256-thread block per run of four tiles of a tile row (= one row of a group), one wave per tile:
@@ -137,15 +138,16 @@ __device__ void frustum_from_rect(const Mat4& invProj, float x0, float y0, float
     f.cy = vs[4][1];
 }
 
-// One launch for the two independent preparation passes: blocks [0, lightRoleBlocks) transform the lights and build the band
-// masks (K0 + K1b: latency / ALU work, dispatched first so that it runs beside the stream), the rest stream the depth image (K1a).
+// One launch for the three independent preparation passes: blocks [0, lightRoleBlocks) transform the lights and build the band
+// masks (K0 + K1b), the next few build the tile frusta (latency / ALU work, dispatched first so that it runs beside the stream), the
+// rest stream the depth image (K1a).
 struct PrepareArgs {
     Mat4 view, invProj;
     const SailorLightShaderData* lights;
     const float* depth;
     float4* lightView; uint32_t* lightType; float4* tileInfo;
     unsigned long long* masks; unsigned long long* dirWords;
-    int N, words, lightBlocks, lightRoleBlocks, bandsPerBlock, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands,
+    int N, words, lightBlocks, lightRoleBlocks, frustumBlocks, bandsPerBlock, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands,
         stripsPerRow, vecOK, rawDepth;
     float zNearCam, planeMargin;
 };
@@ -253,11 +255,8 @@ __device__ __forceinline__ void k1_tile_setup(const int block, unsigned char* __
             }
         }
     }
-    // the frusta do not depend on the depth: built while the loads above are in flight
     const int tx = strip0 * 16 + (int)threadIdx.x;
     const bool owner = threadIdx.x < 16 * SETUP_STRIPS && tx < a.Tx;
-    Frustum4 f;
-    if (owner) frustum_from_rect(a.invProj, (float)(tx * TILE), (float)(ty * TILE), (float)((tx + 1) * TILE), (float)((ty + 1) * TILE), a.vpW, a.vpH, f);
 #pragma unroll
     for (int s = 0; s < SETUP_STRIPS; s++) {
         uint32_t mn = 0xFFFFFFFFu, mx = 0u;
@@ -302,12 +301,27 @@ __device__ __forceinline__ void k1_tile_setup(const int block, unsigned char* __
         const float diff = zFar - zNear; // "Add extra bounds" (:174-177): swaps near and far in fp32
         zFar -= diff;
         zNear += diff;
-        float4* o = a.tileInfo + (size_t)(tyLocal * a.Tx + tx) * 4;
-        o[0] = make_float4(f.n[0][0], f.n[0][1], f.n[0][2], f.cx);
-        o[1] = make_float4(f.n[1][0], f.n[1][1], f.n[1][2], f.cy);
-        o[2] = make_float4(f.n[2][0], f.n[2][1], f.n[2][2], zNear);
-        o[3] = make_float4(f.n[3][0], f.n[3][1], f.n[3][2], zFar);
+        float* o = reinterpret_cast<float*>(a.tileInfo + (size_t)(tyLocal * a.Tx + tx) * 4);
+        o[11] = zNear; // the .w of the record's last two float4s; the frustum role writes the other fourteen floats
+        o[15] = zFar;
     }
+}
+
+// K1a': the tile frusta (ComputeLightCulling.shader:57-95), one LANE per tile.  They do not depend on the depth image, so they are not
+// computed by 16 lanes of a streaming block while its other 240 wait at a barrier: full waves in blocks of their own, beside the stream.
+__device__ __forceinline__ void k1_tile_frusta(const int block, const PrepareArgs& a)
+{
+    const int i = block * 256 + (int)threadIdx.x;
+    if (i >= a.bandRows * a.Tx) return;
+    const int tyLocal = i / a.Tx, tx = i - tyLocal * a.Tx, ty = a.tileRow0 + tyLocal;
+    Frustum4 f;
+    frustum_from_rect(a.invProj, (float)(tx * TILE), (float)(ty * TILE), (float)((tx + 1) * TILE), (float)((ty + 1) * TILE), a.vpW, a.vpH, f);
+    float4* o = a.tileInfo + (size_t)i * 4;
+    o[0] = make_float4(f.n[0][0], f.n[0][1], f.n[0][2], f.cx);
+    o[1] = make_float4(f.n[1][0], f.n[1][1], f.n[1][2], f.cy);
+    float* o2 = reinterpret_cast<float*>(o + 2);
+    o2[0] = f.n[2][0]; o2[1] = f.n[2][1]; o2[2] = f.n[2][2];
+    o2[4] = f.n[3][0]; o2[5] = f.n[3][1]; o2[6] = f.n[3][2];
 }
 
 #define LDS_K01_PREPARE (2 * BANDS_PER_BLOCK * 16)
@@ -316,7 +330,8 @@ __global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K01_PREPARE];
     const int b = (int)blockIdx.x;
     if (b < a.lightRoleBlocks) k0_lights(b, lds, a);
-    else k1_tile_setup(b - a.lightRoleBlocks, lds, a);
+    else if (b < a.lightRoleBlocks + a.frustumBlocks) k1_tile_frusta(b - a.lightRoleBlocks, a);
+    else k1_tile_setup(b - a.lightRoleBlocks - a.frustumBlocks, lds, a);
 }
 
 __device__ __forceinline__ uint64_t lanemask_lt()
@@ -465,153 +480,16 @@ struct CullArgs {
     const float4* lightView; const uint32_t* lightType; const float4* tileInfo;
     const unsigned long long* masks; const uint32_t* groupCount; const uint32_t* groupList;
     uint32_t* totals; uint32_t* clsTotals; uint32_t* tileNum; uint32_t* staging;
-    int N, words, Tx, groupsX, classes;
+    int N, words, Tx, groupsX, bandRows, classes;
 };
 
-#define LDS_K1_TILE_CULL (CHUNK * 16 + CHUNK * 4 + 4 * CAND * 4 + 4 * CAND * 4)
-template <bool BRUTE>
-__global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
+// The <= 196 candidates of a tile (sIdx, ascending light index) -> its list at `out` (Appendix A steps 4 + 5).  One wave.
+__device__ __forceinline__ void emit_list(const TileCtx& t, const uint32_t n, uint32_t* sIdx, float* sImp, const float4* __restrict__ lightView,
+                                          uint32_t* __restrict__ out)
 {
-    // One 256-thread block per run of four tiles (a group's four columns in one tile row), one wave per tile.  The group's candidate
-    // records are staged in LDS, CHUNK at a time, by the four waves together (list entries first, then the dependent 16-byte
-    // gathers, four of each in flight per thread), and every tile streams them out of LDS.  Four blocks per group, not
-    // one of sixteen waves: a cluster group (2048 candidates, four 196 -> 128 selections per SIMD) used to keep ONE CU
-    // busy for ~40 us while the rest of the chip idled -- the kernel's tail -- and at 22 KB of LDS seven blocks fit a CU.
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K1_TILE_CULL];
-    __shared__ uint32_t sNum[4];
-    float4* sLV = reinterpret_cast<float4*>(lds);                                                         // [CHUNK] candidate (view pos, radius)
-    uint32_t* sE = reinterpret_cast<uint32_t*>(lds + CHUNK * 16);                                         // [CHUNK] candidate light index | directional << 31
-    uint32_t (*sIdxAll)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds + CHUNK * 20);                   // [4][CAND]
-    float (*sImpAll)[CAND] = reinterpret_cast<float (*)[CAND]>(lds + CHUNK * 20 + 4 * CAND * 4);          // [4][CAND], 16-byte aligned (CAND * 4 = 784)
-    const float4* __restrict__ lightView = a.lightView;
-    const uint32_t* __restrict__ lightType = a.lightType;
-    const int N = a.N, Tx = a.Tx, groupsX = a.groupsX;
-    const int b = (int)blockIdx.x;                       // == tile-index order: (tile row, group column)
-    const int gx = b % groupsX, tyLocal = b / groupsX;
-    const int g = (tyLocal / GROUP) * groupsX + gx;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t* sIdx = sIdxAll[wave];
-    float* sImp = sImpAll[wave];
-    const int tx = gx * GROUP + wave;
-    const bool active = tx < Tx;
-    const int bandTile = tyLocal * Tx + tx;
-    TileCtx t;
-    if (active) {
-        const float4* ti = a.tileInfo + (size_t)bandTile * 4;
-        const float4 q0 = ti[0], q1 = ti[1], q2 = ti[2], q3 = ti[3];
-        t.n[0][0] = q0.x; t.n[0][1] = q0.y; t.n[0][2] = q0.z; t.cx = q0.w;
-        t.n[1][0] = q1.x; t.n[1][1] = q1.y; t.n[1][2] = q1.z; t.cy = q1.w;
-        t.n[2][0] = q2.x; t.n[2][1] = q2.y; t.n[2][2] = q2.z; t.zNear = q2.w;
-        t.n[3][0] = q3.x; t.n[3][1] = q3.y; t.n[3][2] = q3.z; t.zFar = q3.w;
-        t.cz = (t.zFar + t.zNear) * 0.5f;
-    }
-    uint32_t count = 0;
-    if (BRUTE) {
-        if (active) {
-            for (int base = 0; base < N && count < CAND; base += 64) {
-                const int j = base + lane;
-                test_candidates(t, lightView, lightType, j < N, (uint32_t)j, count, sIdx);
-            }
-        }
-    } else {
-        // The kernel is bound by the latency of its dependent loads (a block has ~1 us of work behind 2-3 round trips to
-        // L2 / HBM), so the first chunk's list entries are requested together with the group's count, not after it:
-        // slots past the count hold stale entries of an earlier frame or nothing at all, hence the clamp to N - 1.
-        const uint32_t* __restrict__ list = a.groupList + (size_t)g * CAPG;
-        uint32_t e[CHUNK / 256];
-#pragma unroll
-        for (int k = 0; k < CHUNK / 256; k++) e[k] = list[threadIdx.x + 256u * k];
-        const uint32_t gn = a.groupCount[g];
-        if (gn != GROUP_OVERFLOW) {
-            for (uint32_t c0 = 0; c0 < gn; c0 += CHUNK) {
-                const uint32_t cn = min((uint32_t)CHUNK, gn - c0);
-                if (c0) {
-                    __syncthreads(); // every wave is done with the previous chunk
-#pragma unroll
-                    for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; e[k] = i < cn ? list[c0 + i] : 0u; }
-                }
-                float4 lv[CHUNK / 256];
-#pragma unroll
-                for (int k = 0; k < CHUNK / 256; k++) lv[k] = lightView[min(e[k] & 0x7FFFFFFFu, (uint32_t)(N - 1))];
-#pragma unroll
-                for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; if (i < cn) { sE[i] = e[k]; sLV[i] = lv[k]; } }
-                __syncthreads();
-                if (active) {
-                    for (uint32_t base = 0; base < cn && count < CAND; base += 64u) {
-                        const uint32_t i = base + (uint32_t)lane;
-                        bool pass = false;
-                        uint32_t ee = 0u;
-                        if (i < cn) {
-                            ee = sE[i];
-                            if (ee & 0x80000000u) pass = true; // directional: always a candidate, impact 0 (:153-162)
-                            else pass = tile_test(t, sLV[i]);
-                        }
-                        wave_append(pass, ee, count, sIdx);
-                    }
-                }
-            }
-        } else if (active) {
-            // overflowed group (very dense region / lights around the eye): every tile walks its own two masks
-            uint32_t* sQ = reinterpret_cast<uint32_t*>(sLV) + wave * QCAP; // sLV is unused on this path
-            const unsigned long long* __restrict__ col = a.masks + (size_t)gx * a.words;
-            const unsigned long long* __restrict__ row = a.masks + (size_t)(groupsX + tyLocal / GROUP) * a.words;
-            const int words = a.words;
-            uint32_t qHead = 0, qTail = 0; // ring buffer indices (wave-uniform)
-            unsigned long long next = (lane < words) ? (col[lane] & row[lane]) : 0ull;
-            for (int w0 = 0; w0 < words && count < CAND; w0 += 64) {
-                const unsigned long long m = next;
-                const int wn = w0 + 64 + lane;
-                next = (wn < words) ? (col[wn] & row[wn]) : 0ull; // prefetch the next 4096 lights' masks
-                // Scalar walk over the non-empty words of this step, in ascending order.  Each word's set bits go to the
-                // ordered queue with one mbcnt (bit k of word L = light 64 (w0 + L) + k lands behind the k' < k bits).
-                unsigned long long nz = __ballot(m != 0ull);
-                while (nz != 0ull && count < CAND) {
-                    const int L = __builtin_ctzll(nz);
-                    nz &= nz - 1ull;
-                    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)m, L);
-                    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(m >> 32), L);
-                    const unsigned long long mk = ((unsigned long long)hi << 32) | lo;
-                    if ((mk >> lane) & 1ull)
-                        sQ[(qTail + (uint32_t)__popcll(mk & lanemask_lt())) & (QCAP - 1)] = (uint32_t)(w0 + L) * 64u + (uint32_t)lane;
-                    qTail += (uint32_t)__popcll(mk);
-                    if (qTail - qHead >= 64u) { // a full wave of candidates is waiting: exact-test them
-                        WAVE_SYNC();
-                        const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
-                        test_candidates(t, lightView, lightType, true, j, count, sIdx);
-                        qHead += 64u;
-                        WAVE_SYNC();
-                    }
-                }
-            }
-            WAVE_SYNC();
-            if (qTail != qHead && count < CAND) { // final partial round (< 64 pending)
-                const uint32_t n = qTail - qHead;
-                const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
-                test_candidates(t, lightView, lightType, (uint32_t)lane < n, j, count, sIdx);
-            }
-        }
-    }
-    const uint32_t n = count < CAND ? count : CAND;   // 0 for a wave beyond the last tile column
+    const int lane = threadIdx.x & 63;
     const uint32_t num = n < KEEP ? n : KEEP;
-    if (lane == 0) sNum[wave] = num;
-    __syncthreads(); // every wave's candidates are in LDS, the four list lengths are known
-    uint32_t before = 0u, total = 0u, cls = 0u; // entries of the block's earlier tiles / of the whole block; its class A << 16 | class B tiles
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const uint32_t v = sNum[w];
-        if (w < wave) before += v;
-        total += v;
-        cls += tile_class_word(v);
-    }
-    if (threadIdx.x == 0) {
-        a.totals[b] = total;
-        if (a.classes) a.clsTotals[b] = cls;
-    }
-    if (!active) return;
-    if (lane == 0) a.tileNum[bandTile] = num;
-    // the block's four lists back to back in its staging slot: k1_pack moves the slot as one contiguous run
-    uint32_t* __restrict__ out = a.staging + (size_t)b * SLOT + before;
-    WAVE_SYNC(); // orders the wave's LDS writes above with the reads below
+    WAVE_SYNC(); // orders the wave's LDS writes (the appends) with the reads below
     if (n <= KEEP) {
         // :235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]
         for (uint32_t i = lane; i < num; i += 64) out[i] = sIdx[n - 1 - i] & 0x7FFFFFFFu;
@@ -689,6 +567,162 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
         const uint32_t k = lane + 64u * i;
         if (k < n && rank[i] < KEEP) out[rank[i]] = sIdx[k] & 0x7FFFFFFFu;
     }
+}
+
+// the `cn` candidates staged in LDS through one tile's exact test, 64 per step, ordered append
+__device__ __forceinline__ void test_staged(const TileCtx& t, const uint32_t cn, const uint32_t* sE, const float4* sLV, uint32_t& count, uint32_t* sIdx)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t base = 0; base < cn && count < CAND; base += 64u) {
+        const uint32_t i = base + lane;
+        bool pass = false;
+        uint32_t ee = 0u;
+        if (i < cn) {
+            ee = sE[i];
+            if (ee & 0x80000000u) pass = true; // directional: always a candidate, impact 0 (:153-162)
+            else pass = tile_test(t, sLV[i]);
+        }
+        wave_append(pass, ee, count, sIdx);
+    }
+}
+
+#define LDS_K1_TILE_CULL (CHUNK * 16 + CHUNK * 4 + 4 * CAND * 4 + 4 * CAND * 4)
+template <bool BRUTE>
+__global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
+{
+    // One 256-thread block per run of four tiles (a group's four columns in one tile row), numbered in tile-index order, one wave per
+    // tile; every block owns one staging slot.  The group's candidate records are staged in LDS, CHUNK at a time, by the four waves
+    // together (list entries first, then the dependent 16-byte gathers, four of each in flight per thread), and every tile streams
+    // them out of LDS.  Four blocks per group, not one of sixteen waves: a cluster group (2048 candidates, four 196 -> 128
+    // selections per SIMD) used to keep ONE CU busy for ~40 us while the rest of the chip idled -- the kernel's tail.  (Also measured:
+    // the block of a group's first row doing all four rows of a single-chunk group, wave w = row w, the other three blocks leaving at
+    // once -- one staging per group instead of four, but four tiles in sequence per wave: 38.8 us against 32.4.)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K1_TILE_CULL];
+    __shared__ uint32_t sNum[4];
+    float4* sLV = reinterpret_cast<float4*>(lds);                                                         // [CHUNK] candidate (view pos, radius)
+    uint32_t* sE = reinterpret_cast<uint32_t*>(lds + CHUNK * 16);                                         // [CHUNK] candidate light index | directional << 31
+    uint32_t (*sIdxAll)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds + CHUNK * 20);                   // [4][CAND]
+    float (*sImpAll)[CAND] = reinterpret_cast<float (*)[CAND]>(lds + CHUNK * 20 + 4 * CAND * 4);          // [4][CAND], 16-byte aligned (CAND * 4 = 784)
+    const float4* __restrict__ lightView = a.lightView;
+    const uint32_t* __restrict__ lightType = a.lightType;
+    const int N = a.N, Tx = a.Tx, groupsX = a.groupsX;
+    const int b = (int)blockIdx.x;                       // == tile-index order: (tile row, group column)
+    const int gx = b % groupsX, tyLocal = b / groupsX;
+    const int g = (tyLocal / GROUP) * groupsX + gx;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* sIdx = sIdxAll[wave];
+    float* sImp = sImpAll[wave];
+
+    uint32_t e[CHUNK / 256];
+    uint32_t gn = 0u;
+    if (!BRUTE) {
+        // The kernel is bound by the latency of its dependent loads (a block has ~1 us of work behind 2-3 round trips to
+        // L2 / HBM), so the first chunk's list entries are requested together with the group's count, not after it:
+        // slots past the count hold stale entries of an earlier frame or nothing at all, hence the clamp to N - 1.
+        const uint32_t* __restrict__ list = a.groupList + (size_t)g * CAPG;
+#pragma unroll
+        for (int k = 0; k < CHUNK / 256; k++) e[k] = list[threadIdx.x + 256u * k];
+        gn = a.groupCount[g];
+    }
+
+    const int tx = gx * GROUP + wave;
+    const bool active = tx < Tx;
+    const int bandTile = tyLocal * Tx + tx;
+    TileCtx t;
+    if (active) {
+        const float4* ti = a.tileInfo + (size_t)bandTile * 4;
+        const float4 q0 = ti[0], q1 = ti[1], q2 = ti[2], q3 = ti[3];
+        t.n[0][0] = q0.x; t.n[0][1] = q0.y; t.n[0][2] = q0.z; t.cx = q0.w;
+        t.n[1][0] = q1.x; t.n[1][1] = q1.y; t.n[1][2] = q1.z; t.cy = q1.w;
+        t.n[2][0] = q2.x; t.n[2][1] = q2.y; t.n[2][2] = q2.z; t.zNear = q2.w;
+        t.n[3][0] = q3.x; t.n[3][1] = q3.y; t.n[3][2] = q3.z; t.zFar = q3.w;
+        t.cz = (t.zFar + t.zNear) * 0.5f;
+    }
+    uint32_t count = 0;
+    if (BRUTE) {
+        if (active) {
+            for (int base = 0; base < N && count < CAND; base += 64) {
+                const int j = base + lane;
+                test_candidates(t, lightView, lightType, j < N, (uint32_t)j, count, sIdx);
+            }
+        }
+    } else if (gn != GROUP_OVERFLOW) {
+        const uint32_t* __restrict__ list = a.groupList + (size_t)g * CAPG;
+        for (uint32_t c0 = 0; c0 < gn; c0 += CHUNK) {
+            const uint32_t cn = min((uint32_t)CHUNK, gn - c0);
+            if (c0) {
+                __syncthreads(); // every wave is done with the previous chunk
+#pragma unroll
+                for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; e[k] = i < cn ? list[c0 + i] : 0u; }
+            }
+            float4 lv[CHUNK / 256];
+#pragma unroll
+            for (int k = 0; k < CHUNK / 256; k++) lv[k] = lightView[min(e[k] & 0x7FFFFFFFu, (uint32_t)(N - 1))];
+#pragma unroll
+            for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; if (i < cn) { sE[i] = e[k]; sLV[i] = lv[k]; } }
+            __syncthreads();
+            if (active) test_staged(t, cn, sE, sLV, count, sIdx);
+        }
+    } else if (active) {
+        // overflowed group (very dense region / lights around the eye): every tile walks its own two masks
+        uint32_t* sQ = reinterpret_cast<uint32_t*>(sLV) + wave * QCAP; // sLV is unused on this path
+        const unsigned long long* __restrict__ col = a.masks + (size_t)gx * a.words;
+        const unsigned long long* __restrict__ row = a.masks + (size_t)(groupsX + tyLocal / GROUP) * a.words;
+        const int words = a.words;
+        uint32_t qHead = 0, qTail = 0; // ring buffer indices (wave-uniform)
+        unsigned long long next = (lane < words) ? (col[lane] & row[lane]) : 0ull;
+        for (int w0 = 0; w0 < words && count < CAND; w0 += 64) {
+            const unsigned long long m = next;
+            const int wn = w0 + 64 + lane;
+            next = (wn < words) ? (col[wn] & row[wn]) : 0ull; // prefetch the next 4096 lights' masks
+            // Scalar walk over the non-empty words of this step, in ascending order.  Each word's set bits go to the
+            // ordered queue with one mbcnt (bit k of word L = light 64 (w0 + L) + k lands behind the k' < k bits).
+            unsigned long long nz = __ballot(m != 0ull);
+            while (nz != 0ull && count < CAND) {
+                const int L = __builtin_ctzll(nz);
+                nz &= nz - 1ull;
+                const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)m, L);
+                const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(m >> 32), L);
+                const unsigned long long mk = ((unsigned long long)hi << 32) | lo;
+                if ((mk >> lane) & 1ull)
+                    sQ[(qTail + (uint32_t)__popcll(mk & lanemask_lt())) & (QCAP - 1)] = (uint32_t)(w0 + L) * 64u + (uint32_t)lane;
+                qTail += (uint32_t)__popcll(mk);
+                if (qTail - qHead >= 64u) { // a full wave of candidates is waiting: exact-test them
+                    WAVE_SYNC();
+                    const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
+                    test_candidates(t, lightView, lightType, true, j, count, sIdx);
+                    qHead += 64u;
+                    WAVE_SYNC();
+                }
+            }
+        }
+        WAVE_SYNC();
+        if (qTail != qHead && count < CAND) { // final partial round (< 64 pending)
+            const uint32_t n = qTail - qHead;
+            const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
+            test_candidates(t, lightView, lightType, (uint32_t)lane < n, j, count, sIdx);
+        }
+    }
+    const uint32_t n = count < CAND ? count : CAND;   // 0 for a wave beyond the last tile column
+    const uint32_t num = n < KEEP ? n : KEEP;
+    if (lane == 0) sNum[wave] = num;
+    __syncthreads(); // every wave's candidates are in LDS, the four list lengths are known
+    uint32_t before = 0u, total = 0u, cls = 0u; // entries of the block's earlier tiles / of the whole block; its class A << 16 | class B tiles
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t v = sNum[w];
+        if (w < wave) before += v;
+        total += v;
+        cls += tile_class_word(v);
+    }
+    if (threadIdx.x == 0) {
+        a.totals[b] = total;
+        if (a.classes) a.clsTotals[b] = cls;
+    }
+    if (!active) return;
+    if (lane == 0) a.tileNum[bandTile] = num;
+    // the block's four lists back to back in its staging slot: k1_pack moves the slot as one contiguous run
+    emit_list(t, n, sIdx, sImp, lightView, a.staging + (size_t)b * SLOT + before);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -911,20 +945,21 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
     pa.lightRoleBlocks = pa.lightBlocks * splits;
     pa.stripsPerRow = (L.Tx + 16 * SETUP_STRIPS - 1) / (16 * SETUP_STRIPS);
     pa.setupBlocks = pa.stripsPerRow * L.bandRows;
+    pa.frustumBlocks = (L.bandTiles + 255) / 256;
     pa.vpW = frame->viewportSize[0]; pa.vpH = frame->viewportSize[1]; pa.W = W; pa.H = H; pa.Tx = L.Tx; pa.Ty = L.Ty;
     pa.tileRow0 = band->tileRowBegin; pa.bandRow0 = band->fbRowBegin; pa.bandRows = L.bandRows; pa.groupsX = L.groupsX;
     pa.vecOK = (((uintptr_t)dLinearDepth & 15) == 0 && (W & 3) == 0) ? 1 : 0;
     pa.rawDepth = (flags & SAILOR_CULL_RAW_DEPTH) ? 1 : 0;
     pa.zNearCam = frame->cameraZNearZFar[0];
     pa.planeMargin = 1e-3f;
-    hipLaunchKernelGGL(k01_prepare, dim3(pa.lightRoleBlocks + pa.setupBlocks), dim3(256), 0, s, pa);
+    hipLaunchKernelGGL(k01_prepare, dim3(pa.lightRoleBlocks + pa.frustumBlocks + pa.setupBlocks), dim3(256), 0, s, pa);
     SAILOR_CHECK_LAUNCH(ctx, "k01_prepare");
 
     CullArgs ca;
     ca.lightView = pa.lightView; ca.lightType = pa.lightType; ca.tileInfo = pa.tileInfo; ca.masks = pa.masks;
     ca.groupCount = (const uint32_t*)(ws + L.offGroupCount); ca.groupList = (const uint32_t*)(ws + L.offGroupList);
     ca.totals = (uint32_t*)(ws + L.offTotals); ca.clsTotals = (uint32_t*)(ws + L.offClsTotals); ca.tileNum = (uint32_t*)(ws + L.offTileNum); ca.staging = (uint32_t*)(ws + L.offStaging);
-    ca.N = N; ca.words = L.words; ca.Tx = L.Tx; ca.groupsX = L.groupsX;
+    ca.N = N; ca.words = L.words; ca.Tx = L.Tx; ca.groupsX = L.groupsX; ca.bandRows = L.bandRows;
     // The hint pays for itself on split frames (a band's shade launch is bounded by its longest tile); on the whole frame it measured nothing.
     ca.classes = layout_has_hint(L) ? 1 : 0;
     if (brute) {

@@ -1,5 +1,5 @@
 """bench.py's output contract on a real device: one JSON line with the driver's keys, the `roofline` and `cpu_baseline` objects, and -- with a one-rank
-RCCL process group -- both multi-GPU modes (a frame per GPU as `value`, the split frame + list exchange next to it)."""
+RCCL process group -- both multi-GPU modes (the split frame + list exchange as `value`, a frame per GPU next to it; `--frame-per-gpu` swaps them)."""
 import json
 import os
 import subprocess
@@ -39,13 +39,16 @@ def test_default_line_carries_the_contract():
         assert block in d, block
 
 
-@pytest.mark.parametrize("split_primary", [False, True])
+@pytest.mark.parametrize("split_primary", [True, False])
 def test_one_rank_process_group_runs_both_multi_gpu_modes(split_primary):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--steps", "5", "--warmup", "2", "--spinup-ms", "50", "--no-cpu-baseline"]
-    d = _run(cmd + (["--split-frame"] if split_primary else []), env)
-    assert d["scaling"] == ("strong" if split_primary else "weak")
+    d = _run(cmd + ([] if split_primary else ["--frame-per-gpu"]), env)
+    assert d["scaling"] == ("strong" if split_primary else "weak")  # the default headline is the split frame (BASELINE.json's metric)
     other = d["alternate_frame_rendering"] if split_primary else d["split_frame"]
     assert other["scaling"] == ("weak" if split_primary else "strong") and other["value"] > 0 and "error" not in other
     ex = d["exchange"] if split_primary else d["split_frame"]["exchange"]
     assert ex["tiles"] == 240 * 135 and ex["global_sum_num"] == d["config"]["sum_num_rank0_band"] and ex["checksum"] > 0
+    if split_primary:
+        assert d["speedup_vs_one_gpu_whole_frame"] > 0
+    assert d["step_ms"]["p10"] <= d["step_ms"]["median"] <= d["step_ms"]["p90"]
