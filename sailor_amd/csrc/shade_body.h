@@ -179,28 +179,26 @@ __device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsq
 #define QMAX 120 // queued pairs per wave in one window (120: the block stays within 20 KB of LDS, 8 blocks per CU)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// Order-preserving float <-> int32 map (an involution), so that the wave-wide bounding box can be reduced with
-// v_min_i32 / v_max_i32 DPP steps: one instruction per step and value, no NaN canonicalisation, no LDS round trips.
-__device__ __forceinline__ int f2key(float f) { const int b = __float_as_int(f); return b ^ ((b >> 31) & 0x7fffffff); }
-__device__ __forceinline__ float key2f(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
-
-#define DPP6_STEP(ctrl)                                                                                               \
-    asm volatile("v_min_i32_dpp %0, %0, %0 " ctrl "\n\tv_min_i32_dpp %1, %1, %1 " ctrl "\n\tv_min_i32_dpp %2, %2, %2 " ctrl \
-                 "\n\tv_max_i32_dpp %3, %3, %3 " ctrl "\n\tv_max_i32_dpp %4, %4, %4 " ctrl "\n\tv_max_i32_dpp %5, %5, %5 " ctrl \
-                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f))
-
-// min of a, b, c and max of d, e, f over the 64 lanes; every lane of row 3 (lanes 48..63) ends up with the result.
-// (xor-1, xor-2, mirror within 8, mirror within 16, then the gfx9 row broadcasts 15 -> row+1 and 31 -> rows 2,3.)
-__device__ __forceinline__ void wave_minmax6(int& a, int& b, int& c, int& d, int& e, int& f)
+// max of a non-negative (or NaN) float's bits over the wave as unsigned integers; the value of lane 63 (which holds the result) is returned.
+// (xor-1, xor-2, mirror within 8, mirror within 16, then the gfx9 row broadcasts 15 -> row+1 and 31 -> rows 2,3; a DPP read of a VGPR
+// needs 2 wait states after the VALU write.)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-    asm volatile("s_nop 1" ::: "memory"); // a DPP read of a VGPR needs 2 wait states after the VALU write
-    DPP6_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
-    DPP6_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-    DPP6_STEP("row_half_mirror row_mask:0xf bank_mask:0xf");
-    DPP6_STEP("row_mirror row_mask:0xf bank_mask:0xf");
-    DPP6_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
-    DPP6_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
-    asm volatile("s_nop 1" ::: "memory");
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // Staged light record (LDS, 5 float4):
@@ -333,15 +331,21 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const float g1Lo = cosLo * rcp_fast(fmaf(cosLo, oneMinusK, k)); // GeometrySchlickG1(cosLo, k)
     const bool brdfFinite = alphaSq > 0.0f;                       // roughness 0 makes NdfGGX 0/0 in the reference
 
-    // ---- which lights can reach this quadrant at all?  One LANE per LIGHT: sphere (centre, r sqrt(1 + 1e-4)) against the
-    // world-space bounding box of the quadrant's 64 surface points.  Two ballots cover the whole <= 128-entry list, and
-    // the per-pixel loop below then visits only the surviving lights.  (Conservative: a point light whose sphere misses
-    // the box has d^2 > r^2 (1 + 1e-5) for every pixel, i.e. an exact-zero radius window -- see rec0.w.)
-    int k0 = f2key(active ? wx : __builtin_inff()), k1 = f2key(active ? wy : __builtin_inff()), k2 = f2key(active ? wz : __builtin_inff());
-    int k3 = f2key(active ? wx : -__builtin_inff()), k4 = f2key(active ? wy : -__builtin_inff()), k5 = f2key(active ? wz : -__builtin_inff());
-    wave_minmax6(k0, k1, k2, k3, k4, k5);
-    const float bminx = key2f(__builtin_amdgcn_readlane(k0, 63)), bminy = key2f(__builtin_amdgcn_readlane(k1, 63)), bminz = key2f(__builtin_amdgcn_readlane(k2, 63));
-    const float bmaxx = key2f(__builtin_amdgcn_readlane(k3, 63)), bmaxy = key2f(__builtin_amdgcn_readlane(k4, 63)), bmaxz = key2f(__builtin_amdgcn_readlane(k5, 63));
+    // ---- which lights can reach this quadrant at all?  One LANE per LIGHT against the bounding SPHERE of the quadrant's 64 surface
+    // points: centre = the pixel in its middle (lane 27), radius^2 = the largest squared distance to it (one max-reduction over the
+    // bits: a non-negative float orders like its bits, and a NaN wins and keeps every light).  |L - c| > sqrt(A) + R  =>  every pixel
+    // has d^2 > A = r^2 (1 + 1e-5), i.e. fails the reach test of the per-pixel loop below, i.e. an exact-zero radius window.  (Was: the
+    // quadrant's bounding box by six min / max reductions -- 12.1 instead of 13.3 surviving lights per quadrant on the 4K frame
+    // (scripts/analysis/shade_trips.py), for three times the instructions.)
+    const float scx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx), 27));
+    const float scy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy), 27));
+    const float scz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wz), 27));
+    float sphereR;
+    {
+        const float ex = wx - scx, ey = wy - scy, ez = wz - scz;
+        const float d2c = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
+        sphereR = __builtin_amdgcn_sqrtf(__uint_as_float(wave_max_u32(active ? __float_as_uint(d2c) : 0u))) * 1.0001f;
+    }
     const unsigned long long activeMask = __ballot(active);
     const unsigned long long forceMask = __ballot(active && !brdfFinite); // such pixels must see every light (0 * NaN)
     // survivors by kind: [0,1] finite point lights, [2,3] finite spot lights, [4,5] the rest (directional, unknown type,
@@ -358,11 +362,9 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
             bits = __float_as_uint(sL[li * LREC + 1].w);
             keep = true;
             if ((bits & 0xFFu) == 1u && forceMask == 0ull) {
-                const float ex = fmaxf(fmaxf(bminx - c0.x, c0.x - bmaxx), 0.0f);
-                const float ey = fmaxf(fmaxf(bminy - c0.y, c0.y - bmaxy), 0.0f);
-                const float ez = fmaxf(fmaxf(bminz - c0.z, c0.z - bmaxz), 0.0f);
-                // c0.w = r^2 (1 + 1e-5) (+inf: never reject); another 1e-4 covers the rounding of this estimate
-                keep = !(fmaf(ex, ex, fmaf(ey, ey, ez * ez)) > c0.w * 1.0001f);
+                const float ex = c0.x - scx, ey = c0.y - scy, ez = c0.z - scz;
+                const float t = __builtin_amdgcn_sqrtf(c0.w) * 1.0001f + sphereR; // c0.w = r^2 (1 + 1e-5) (+inf: never reject)
+                keep = !(fmaf(ex, ex, fmaf(ey, ey, ez * ez)) > t * t);
             }
         }
         const bool fin = (bits & 0x10000u) != 0u;
