@@ -34,3 +34,17 @@ def ctx():
     c = HipContext("cuda:0")
     yield c
     c.close()
+
+
+def daily_tile_row(num_rows: int, fixed: int, span: int = 1) -> int:
+    """A tile row for the oracle-sampled part of a full-size test that changes from day to day (seeded by the date, so a run is
+    reproducible on its day and prints what it used): the fixed row of the test stays, this one widens the coverage over time."""
+    import datetime
+    import random
+    d = datetime.date.today()
+    rng = random.Random(d.year * 10000 + d.month * 100 + d.day)
+    r = rng.randrange(0, num_rows - span + 1)
+    if abs(r - fixed) < span:
+        r = (fixed + span + 7) % (num_rows - span + 1)
+    print(f"[daily oracle row] {d.isoformat()}: tile rows {r}..{r + span - 1} of {num_rows}")
+    return r

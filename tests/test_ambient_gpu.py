@@ -1,6 +1,6 @@
 """Ambient / image-based lighting term on the GPU: Standard.shader's AmbientLighting (:343-372) added to
 the shaded radiance, and the ComputeBrdfLut.shader table it samples -- through the C-ABI, against the CPU oracle.
-Tolerance as for K2: |gpu - ref| <= 1e-4*|ref| + 1e-5 (the samplers are bilinear fp32 on both sides)."""
+Tolerance as for K2: |gpu - ref| <= 1e-4*|ref|, no absolute floor (the samplers are bilinear fp32 on both sides)."""
 import numpy as np
 import pytest
 import torch
@@ -10,7 +10,7 @@ from sailor_amd import host, synth
 from sailor_amd.forward_plus import ForwardPlus, compute_brdf_lut, upload_ibl, upload_lights, upload_shadow_maps
 
 pytestmark = pytest.mark.gpu
-RTOL, ATOL = 1e-4, 1e-5
+RTOL, ATOL = 1e-4, 0.0
 
 
 def close(got, ref):

@@ -7,6 +7,7 @@ import torch
 from oracle import oracle
 from sailor_amd import _lib, host, synth
 from sailor_amd.forward_plus import ForwardPlus, upload_lights
+from conftest import daily_tile_row
 
 pytestmark = pytest.mark.gpu
 
@@ -146,7 +147,7 @@ def test_tile_row_bands_stitch_to_the_whole_frame(ctx, world_size):
 def test_c3_4k_65536_lights_default_equals_brute_force_and_invariants(ctx):
     """BASELINE.json configs[2] at full size: too big for the scalar oracle in seconds, so the hierarchical path is checked
     against the brute-force HIP walk (itself oracle-checked above) plus size-independent invariants, and a sampled band
-    of tile rows against the oracle."""
+    of tile rows against the oracle (three fixed rows, two that change with the date)."""
     f = synth.make_frame("C3", with_surface=False)
     W, H, N = 3840, 2160, 65536
     a = gpu_cull(ctx, f.cam, f.lights, f.depth, _lib.CULL_DEFAULT)
@@ -165,13 +166,13 @@ def test_c3_4k_65536_lights_default_equals_brute_force_and_invariants(ctx):
         assert len(np.unique(seg)) == len(seg)
     mean = num.mean()
     assert 16 <= mean <= 32, f"frozen generator: mean list length {mean}"
-    # oracle on 3 tile rows (3 x 240 tiles x 65 536 lights)
-    r0 = 60
-    og, oi, cnt = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(r0, r0 + 3), want_counts=True)
-    t0 = r0 * 240
-    np.testing.assert_array_equal(g[t0:t0 + 720, 1], og[:, 1])
-    for t in range(720):
-        np.testing.assert_array_equal(idx[g[t0 + t, 0]: g[t0 + t, 0] + g[t0 + t, 1]], oi[og[t, 0]: og[t, 0] + og[t, 1]])
+    # oracle on 3 fixed tile rows (3 x 240 tiles x 65 536 lights) and on 2 that change with the date
+    for r0, rows in ((60, 3), (daily_tile_row(135, 60, 2), 2)):
+        og, oi, cnt = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(r0, r0 + rows), want_counts=True)
+        t0 = r0 * 240
+        np.testing.assert_array_equal(g[t0:t0 + rows * 240, 1], og[:, 1])
+        for t in range(rows * 240):
+            np.testing.assert_array_equal(idx[g[t0 + t, 0]: g[t0 + t, 0] + g[t0 + t, 1]], oi[og[t, 0]: og[t, 0] + og[t, 1]])
 
 
 @pytest.mark.parametrize("flags", [_lib.CULL_DEFAULT, _lib.CULL_BRUTE_FORCE])
@@ -213,9 +214,9 @@ def test_c5_8k_1m_lights_invariants_and_an_oracle_tile_row(ctx):
     for t in np.random.default_rng(1).choice(len(g), 500, replace=False):
         seg = idx[g[t, 0]: g[t, 0] + g[t, 1]]
         assert len(np.unique(seg)) == len(seg)
-    r0 = 131
-    og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(r0, r0 + 1), want_counts=True)
-    t0 = r0 * 480
-    np.testing.assert_array_equal(g[t0:t0 + 480, 1], og[:, 1])
-    for t in range(480):
-        np.testing.assert_array_equal(idx[g[t0 + t, 0]: g[t0 + t, 0] + g[t0 + t, 1]], oi[og[t, 0]: og[t, 0] + og[t, 1]])
+    for r0 in (131, daily_tile_row(270, 131)):
+        og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(r0, r0 + 1), want_counts=True)
+        t0 = r0 * 480
+        np.testing.assert_array_equal(g[t0:t0 + 480, 1], og[:, 1])
+        for t in range(480):
+            np.testing.assert_array_equal(idx[g[t0 + t, 0]: g[t0 + t, 0] + g[t0 + t, 1]], oi[og[t, 0]: og[t, 0] + og[t, 1]])

@@ -140,7 +140,7 @@ def test_entities_to_shadow_maps_to_shaded_frame(ctx):
     unshadowed = oracle.shade(cam.frame, W, H, f.surface, f.lights, g, idx, None)
     assert np.abs(ref - unshadowed).max() > 0.5, "the boxes cast shadows on the visible surface"
     err = np.abs(got.astype(np.float64) - ref)
-    assert (err <= 1e-4 * np.abs(ref) + 1e-5).all(), err.max()
+    assert (err <= 1e-4 * np.abs(ref)).all(), err.max()
 
 
 def test_depth_prepass_feeds_linearize_and_the_light_cull(ctx):

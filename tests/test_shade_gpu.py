@@ -1,15 +1,21 @@
 """K2+K3 parity (GPU): PBR shade over per-tile lists with CSM sampling, through the C-ABI, against the CPU oracle.
-Tolerance (BASELINE.json north_star): radiance within 1e-4 relative fp32; here |gpu - ref| <= 1e-4*|ref| + 1e-5."""
+Tolerance (BASELINE.json north_star): radiance within 1e-4 relative fp32 -- here exactly that, |gpu - ref| <= 1e-4*|ref| with NO absolute
+floor: exact zeros must be exact zeros and a dim pixel is held to the same relative bound as a bright one (measured: 6e-7 on the fixtures)."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import oracle
 from sailor_amd import _lib, host, synth
+from conftest import daily_tile_row
 from sailor_amd.forward_plus import ForwardPlus, upload_lights, upload_shadow_maps
 
 pytestmark = pytest.mark.gpu
-RTOL, ATOL = 1e-4, 1e-5
+RTOL = 1e-4
+
+
+def atol_of(ref):
+    return 0.0
 
 
 def gpu_frame(ctx, f, band=None, csm=True, flags=_lib.CULL_DEFAULT):
@@ -40,7 +46,7 @@ def assert_radiance_close(got, ref):
     assert got.shape == ref.shape
     assert np.isfinite(got).all()
     err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
-    tol = RTOL * np.abs(ref.astype(np.float64)) + ATOL
+    tol = RTOL * np.abs(ref.astype(np.float64)) + atol_of(ref[..., :3])
     bad = err > tol
     assert not bad.any(), f"{bad.sum()} of {bad.size} values out of tolerance; worst rel {np.max(err / (np.abs(ref) + 1e-30)):.3e} abs {err.max():.3e}"
     np.testing.assert_array_equal(got[..., 3], ref[..., 3])  # outColor.a = albedo.a, passed through
@@ -141,15 +147,15 @@ def test_linearity_in_light_intensity_at_4k(ctx):
     f2.lights["intensity"] *= 2.0
     b, _ = gpu_frame(ctx, f2)
     np.testing.assert_array_equal(b[..., :3], 2.0 * a[..., :3])
-    # oracle on 48 framebuffer rows = 3 tile rows
+    # oracle on 48 framebuffer rows = 3 fixed tile rows, and on one tile row that changes with the date
     W, H = 3840, 2160
-    tr0 = 40
-    og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(tr0, tr0 + 3))
-    grid = np.zeros((240 * 135, 2), np.uint32); grid[:, 0] = 1
-    grid[tr0 * 240:(tr0 + 3) * 240] = og
-    r0, r1 = H - 16 * (tr0 + 3), H - 16 * tr0
-    ref = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, grid, oi, None, rows=(r0, r1))
-    assert_radiance_close(a[r0:r1], ref[r0:r1])
+    for tr0, n in ((40, 3), (daily_tile_row(135, 40), 1)):
+        og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(tr0, tr0 + n))
+        grid = np.zeros((240 * 135, 2), np.uint32); grid[:, 0] = 1
+        grid[tr0 * 240:(tr0 + n) * 240] = og
+        r0, r1 = H - 16 * (tr0 + n), H - 16 * tr0
+        ref = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, grid, oi, None, rows=(r0, r1))
+        assert_radiance_close(a[r0:r1], ref[r0:r1])
 
 
 def test_c4_4k_with_cascaded_shadow_maps(ctx):
@@ -242,7 +248,7 @@ def test_split_tiles_on_a_band_of_the_4k_frame(ctx):
     num = g[:, 1].reshape(-1, fp.Tx)
     assert (num >= 40).sum() > 100 and (num == 128).any()
     err = np.abs(split.astype(np.float64) - plain)
-    assert (err <= 2 * RTOL * np.abs(plain) + 2 * ATOL).all()
+    assert (err <= 2 * RTOL * np.abs(plain) + 2 * atol_of(plain[..., :3])).all()
     long_px = np.repeat(np.repeat(num[::-1] >= 40, 16, 0), 16, 1)[-band.fbRowCount:, :W]  # tile row 0 of the band = its bottom rows
     assert (split[~long_px] == plain[~long_px]).all() and err[long_px].max() > 0
     # the oracle on the band's first tile row (16 framebuffer rows)
@@ -299,4 +305,4 @@ def test_non_finite_terms_propagate_like_the_reference(ctx):
     np.testing.assert_array_equal(np.isneginf(got), np.isneginf(ref))
     fin = np.isfinite(ref)
     err = np.abs(got[fin].astype(np.float64) - ref[fin])
-    assert (err <= RTOL * np.abs(ref[fin]) + ATOL).all(), err.max()
+    assert (err <= RTOL * np.abs(ref[fin]) + atol_of(ref[..., :3])).all(), err.max()
