@@ -160,7 +160,6 @@ def _cpu_model():
 
 def ecs_baseline(ctx, count: int, steps: int):
     """K4 next to the reference's CPU ECS/frustum-cull loop: oracle port, 1 thread and all host cores."""
-    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
     ents = synth.make_entities(count)
     cam = synth.make_camera(3840, 2160)
@@ -174,13 +173,9 @@ def ecs_baseline(ctx, count: int, steps: int):
     oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes, world=world, world_aabb=aabb, visibility=vis)
     t1 = time.perf_counter() - t0
     cores = os.cpu_count() or 1
-    offs = [int(v) for v in ents.level_offsets]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as pool:
-        for lo, hi in zip(offs[:-1], offs[1:]):  # levels in order; 1024-entity chunks like StaticMeshRendererECS.cpp:19
-            chunks = [(b, min(b + 1024, hi)) for b in range(lo, hi, 1024)]
-            list(pool.map(lambda c: oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes, c[0], c[1], world, aabb, vis), chunks))
-    tn = time.perf_counter() - t0
+    # all host cores: the reference's own parallel form -- 1 024-entity chunks on worker threads (ECS/StaticMeshRendererECS.cpp:19), one hierarchy
+    # level after the other -- inside the C oracle (pthreads; the seconds are taken between the start barrier and the last level's barrier)
+    tn = min(oracle.ecs_sweep_threads(ents.transforms, ents.parent, ents.local_aabb, planes, ents.level_offsets, cores, world, aabb, vis)[3] for _ in range(3))
     # the cull loop alone, scalar (Math/Bounds.cpp:245-260) and the reference's SSE batch form (:264-325, restated literally --
     # including its layout bug -- purely as a cost proxy): 16-byte aligned input, n % 4 == 0
     import ctypes as C
@@ -204,7 +199,8 @@ def ecs_baseline(ctx, count: int, steps: int):
     return {"entities": count, "gpu_ms": med, "csm_caster_masks_ms": casc_ms, "csm_caster_masks_gbs": count * 24.5 / casc_ms / 1e6, "gpu_mentities_per_s": count / med / 1e3, "gpu_hbm_gbs": count * bytes_per_entity / med / 1e6,
             "gpu_hbm_frac": count * bytes_per_entity / med / 1e6 / HBM_PEAK_GBS,
             "cpu_1thread_mentities_per_s": count / t1 / 1e6, "cpu_ns_per_entity_1thread": t1 / count * 1e9,
-            "cpu_allcores_mentities_per_s": count / tn / 1e6, "cpu_sse_cull_only_mboxes_per_s_1thread": n4 / t_sse / 1e6, "cpu_cores": cores, "cpu_model": _cpu_model(), "kind": "port"}
+            "cpu_allcores_mentities_per_s": count / tn / 1e6, "cpu_allcores_speedup_vs_1thread": t1 / tn,
+            "cpu_allcores_gbs": count * bytes_per_entity / tn / 1e9, "cpu_sse_cull_only_mboxes_per_s_1thread": n4 / t_sse / 1e6, "cpu_cores": cores, "cpu_model": _cpu_model(), "kind": "port"}
 
 
 def mesh_cull_block(ctx, count: int, num_batches: int, steps: int):

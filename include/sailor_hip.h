@@ -496,6 +496,45 @@ SAILOR_HIP_API int sailor_host_pack_light(uint32_t type, uint32_t shadowType, co
                                           const float* intensity, const float* attenuation, const float* cutOffDegrees, const float* bounds,
                                           SailorLightShaderData* outLight);
 
+
+/* Math/Bounds.cpp:211-243 Frustum::OverlapsSphere / ContainsSphere (scalar): sphere4 = (centre.xyz, radius); 1 / 0, negative = bad argument.
+ * OverlapsSphere: no plane has the whole sphere behind it.  ContainsSphere: the sphere lies in front of all six planes by at least its radius. */
+SAILOR_HIP_API int sailor_host_overlaps_sphere(const float* planes24, const float* sphere4);
+SAILOR_HIP_API int sailor_host_contains_sphere(const float* planes24, const float* sphere4);
+/* ECS/LightingECS.cpp:209-260 LightingECS::GetLightsInFrustum over flat component arrays (type, shadowType, active flag or NULL = all active,
+ * owner position, bounds): shadow-casting directional lights in component order; point and spot lights whose sphere (radius = largest bound)
+ * is contained in the frustum, sorted by distance to the camera with the reference's lower_bound insertion (equal distances: the later
+ * component goes in front).  Every output array needs room for numLights entries. */
+SAILOR_HIP_API int sailor_host_lights_in_frustum(const float* planes24, const float* cameraPosition3, uint32_t numLights, const uint32_t* types,
+                                                 const uint32_t* shadowTypes, const uint8_t* active, const float* positions3, const float* bounds3,
+                                                 uint32_t* outDirectional, uint32_t* outNumDirectional,
+                                                 uint32_t* outPoint, float* outPointDistance, uint32_t* outNumPoint,
+                                                 uint32_t* outSpot, float* outSpotDistance, uint32_t* outNumSpot);
+
+/* The change tracking of LightingECS::PrepareCSMPasses (ECS/LightingECS.cpp:299-366) on the cascade overlap sets that
+ * sailor_hip_csm_caster_masks produces.  SailorCsmSnapshots is LightingECS::m_csmSnapshots; SailorCsmView the transform half of a
+ * CSMLightState (:14-38): light component index, camera position / rotation (xyzw), light position / rotation. */
+typedef struct SailorCsmView {
+    uint32_t componentIndex;
+    float cameraPosition[4], cameraRotation[4], lightPosition[4], lightRotation[4];
+} SailorCsmView;
+typedef struct SailorCsmSnapshots SailorCsmSnapshots; /* opaque */
+SAILOR_HIP_API SailorCsmSnapshots* sailor_host_csm_snapshots_create(void);
+SAILOR_HIP_API SailorCsmSnapshots* sailor_host_csm_snapshots_clone(const SailorCsmSnapshots* snapshots);
+SAILOR_HIP_API void sailor_host_csm_snapshots_destroy(SailorCsmSnapshots* snapshots);
+SAILOR_HIP_API uint32_t sailor_host_csm_snapshots_count(const SailorCsmSnapshots* snapshots);
+SAILOR_HIP_API int sailor_host_csm_snapshot_get(const SailorCsmSnapshots* snapshots, uint32_t index, uint32_t capacity, uint32_t* outCount, uint32_t* outMeshes,
+                                                uint64_t* outFrames, int32_t* outHasView, SailorCsmView* outView);
+/* One directional light: for cascade k = 0 .. numCascades-1 (snapshot slots firstSnapshot + k)
+ *   * drop from its overlap set every mesh that an EARLIER cascade of the same shadow type, re-rendered this frame, overlaps (:310-327);
+ *   * re-render it iff its (mesh, frame the mesh last changed) list differs from the stored snapshot, or -- with `view` -- the camera moved more
+ *     than 15 units / turned past dot(forward, forward') = 0.9995 / the light moved at all since that snapshot was TAKEN (a kept snapshot keeps
+ *     its old camera, :353-357).
+ * overlapMasks / outMasks: numCascades x ceil(numEntities / 64) words; outRender: numCascades flags; lastChangedFrame: one per entity. */
+SAILOR_HIP_API int sailor_host_csm_plan_passes(SailorCsmSnapshots* snapshots, uint32_t firstSnapshot, uint32_t numCascades, uint32_t numEntities,
+                                               const uint64_t* overlapMasks, const uint32_t* shadowTypes, const uint64_t* lastChangedFrame,
+                                               const SailorCsmView* view, uint32_t* outRender, uint64_t* outMasks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,13 +6,14 @@ bench.py's cpu_baseline leg; never from the sailor_amd package.  PARITY UNPINNED
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
 import numpy as np
 
 _DIR = Path(__file__).resolve().parent
-LIB_PATH = _DIR / "liboracle.so"
+LIB_PATH = Path(os.environ.get("SAILOR_ORACLE_LIB", _DIR / "liboracle.so"))  # (the sanitizer run of the CPU suite points this at liboracle_asan.so)
 TILE, CAND, KEEP = 16, 196, 128
 _lib = None
 
@@ -224,6 +225,25 @@ def ecs_sweep(trs: np.ndarray, parent: np.ndarray, local_aabb: np.ndarray, plane
     visibility = np.zeros((n + 63) // 64, np.uint64) if visibility is None else visibility
     lib().oracle_ecs_sweep(C.c_uint32(begin), C.c_uint32(end), _p(trs), _p(parent), _p(local_aabb), _p(planes), _p(world), _p(world_aabb), _p(visibility))
     return world, world_aabb, visibility
+
+
+def ecs_sweep_threads(trs: np.ndarray, parent: np.ndarray, local_aabb: np.ndarray, planes: np.ndarray, level_offsets: np.ndarray, num_threads: int,
+                      world=None, world_aabb=None, visibility=None):
+    """The sweep on `num_threads` host threads (1 024-entity chunks, level by level) -> (world, world_aabb, visibility, seconds inside the sweep)."""
+    n = len(parent)
+    trs = np.ascontiguousarray(trs, np.float32); parent = np.ascontiguousarray(parent, np.uint32)
+    local_aabb = np.ascontiguousarray(local_aabb, np.float32); planes = np.ascontiguousarray(planes, np.float32).reshape(24)
+    offs = np.ascontiguousarray(level_offsets, np.uint32)
+    world = np.zeros((n, 16), np.float32) if world is None else world
+    world_aabb = np.zeros((n, 6), np.float32) if world_aabb is None else world_aabb
+    visibility = np.zeros((n + 63) // 64, np.uint64) if visibility is None else visibility
+    fn = lib().oracle_ecs_sweep_threads
+    fn.restype = C.c_double
+    secs = fn(C.c_uint32(len(offs) - 1), _p(offs), _p(trs), _p(parent), _p(local_aabb), _p(planes), _p(world), _p(world_aabb), _p(visibility),
+              C.c_uint32(num_threads))
+    if secs < 0:
+        raise RuntimeError("oracle_ecs_sweep_threads: could not start the worker threads")
+    return world, world_aabb, visibility, float(secs)
 
 
 def linearize_depth(z_near: float, raw: np.ndarray) -> np.ndarray:

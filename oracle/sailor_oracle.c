@@ -1443,12 +1443,15 @@ ORACLE_API int oracle_contains_sphere(const float* planes, const float* sphere)
 }
 
 /* Math/Bounds.cpp:264-325 Frustum::OverlapsAABB(AABB*, n, int32*) -- the SSE batch form, restated LITERALLY.
- * NOTE (reference behaviour, reproduced): the code loads 4 consecutive 24-byte AABBs as six __m128 rows at float
- * offsets 0,4,8,12,16,20 and transposes them as if each row were one box's (x,y,z,_) -- it was adapted from a
- * {vec4 min, vec4 max} layout -- and _MM_TRANSPOSE4_PS overwrites the `zero` register that is later used as the
- * comparison operand.  Its lane results therefore do NOT correspond to boxes i..i+3; no caller uses it.
- * It is kept as the reference's "most optimized" cost proxy for the CPU baseline; outputs: 0x80000000 where any
- * plane compare was true, 0 otherwise.  Requires 16-byte aligned input and numObjects % 4 == 0. */
+ * NOTE (reference behaviour, reproduced): the code loads six __m128 rows at float offsets 0,4,8 / 12,16,20, advances by 24 floats
+ * and transposes (row0, row1, row2, zero).  With the reference's own 24-byte AABB {vec3 min, vec3 max} the rows straddle boxes, so
+ * the lane results do not correspond to boxes i..i+3, and _MM_TRANSPOSE4_PS overwrites the `zero` register that is later the
+ * comparison operand with the rows' fourth components.  The arithmetic is only meaningful for input laid out as THREE boxes per
+ * 24 floats -- vec4 min0, min1, min2, vec4 max0, max1, max2 with zero .w padding: lanes 0..2 are then those boxes (lane 3 a box
+ * of zeros) and `zero` stays zero.  tests/test_oracle_cpu.py checks exactly that against the scalar form; no caller in the
+ * reference uses the function.  It is kept as the reference's "most optimized" cost proxy for the CPU baseline.
+ * Outputs: 0x80000000 where any plane compare (distance <= 0) was true, i.e. CULLED, 0 otherwise (inverted w.r.t. the scalar form).
+ * Requires 16-byte aligned input and numObjects % 4 == 0. */
 ORACLE_API void oracle_overlaps_aabb_sse(const float* planes, const float* aabbs, uint32_t numObjects, int32_t* outResults)
 {
     const float* pAabbData = aabbs;
@@ -1508,6 +1511,73 @@ ORACLE_API void oracle_ecs_sweep(uint32_t begin, uint32_t end, const float* trs,
         if (vis) __atomic_fetch_or(&visibility[i >> 6], bit, __ATOMIC_RELAXED);
         else __atomic_fetch_and(&visibility[i >> 6], ~bit, __ATOMIC_RELAXED);
     }
+}
+
+/*
+ * The same sweep on `numThreads` host threads, the way the reference parallelises its per-entity loops: chunks of 1 024 entities
+ * handed to worker threads (ECS/StaticMeshRendererECS.cpp:19 `const size_t numThreads = ...; 1024 per task`, Tasks/Scheduler.cpp:150-152),
+ * one hierarchy level after the other (a child needs its parent's world matrix).  Workers pull chunks from a shared counter; a barrier
+ * separates the levels.  Returns the seconds spent between the start barrier and the last level's barrier (thread creation excluded,
+ * as the reference's scheduler threads exist before the frame starts).  CPU baseline only (bench.py).
+ */
+#include <pthread.h>
+#include <time.h>
+typedef struct {
+    const float* trs; const uint32_t* parent; const float* localAabb; const float* planes;
+    float* world; float* worldAabb; uint64_t* visibility;
+    const uint32_t* levelOffsets; uint32_t numLevels;
+    uint32_t* nextChunk; /* one counter per level */
+    pthread_barrier_t* bar;
+} SweepJob;
+
+static void* sweep_worker(void* arg)
+{
+    const SweepJob* j = (const SweepJob*)arg;
+    pthread_barrier_wait(j->bar); /* start */
+    for (uint32_t l = 0; l < j->numLevels; l++) {
+        const uint32_t lo = j->levelOffsets[l], hi = j->levelOffsets[l + 1];
+        for (;;) {
+            const uint32_t c = __atomic_fetch_add(&j->nextChunk[l], 1u, __ATOMIC_RELAXED);
+            const uint64_t b = (uint64_t)lo + (uint64_t)c * 1024u;
+            if (b >= hi) break;
+            const uint32_t e = (uint32_t)(b + 1024u < hi ? b + 1024u : hi);
+            oracle_ecs_sweep((uint32_t)b, e, j->trs, j->parent, j->localAabb, j->planes, j->world, j->worldAabb, j->visibility);
+        }
+        pthread_barrier_wait(j->bar); /* the level is complete */
+    }
+    return NULL;
+}
+
+ORACLE_API double oracle_ecs_sweep_threads(uint32_t numLevels, const uint32_t* levelOffsets, const float* trs, const uint32_t* parent,
+                                           const float* localAabb, const float* planes, float* world, float* worldAabb, uint64_t* visibility,
+                                           uint32_t numThreads)
+{
+    if (numThreads < 1) numThreads = 1;
+    if (numThreads > 1024) numThreads = 1024;
+    pthread_t tid[1024];
+    uint32_t counters[64];
+    if (numLevels > 64) return -1.0;
+    memset(counters, 0, sizeof counters);
+    pthread_barrier_t bar;
+    if (pthread_barrier_init(&bar, NULL, numThreads + 1) != 0) return -1.0;
+    SweepJob job = { trs, parent, localAabb, planes, world, worldAabb, visibility, levelOffsets, numLevels, counters, &bar };
+    uint32_t started = 0;
+    for (; started < numThreads; started++)
+        if (pthread_create(&tid[started], NULL, sweep_worker, &job) != 0) break;
+    if (started != numThreads) { /* cannot release a barrier sized for more threads: give up cleanly */
+        for (uint32_t i = 0; i < started; i++) pthread_cancel(tid[i]);
+        for (uint32_t i = 0; i < started; i++) pthread_join(tid[i], NULL);
+        pthread_barrier_destroy(&bar);
+        return -1.0;
+    }
+    struct timespec t0, t1;
+    pthread_barrier_wait(&bar);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t l = 0; l < numLevels; l++) pthread_barrier_wait(&bar);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (uint32_t i = 0; i < numThreads; i++) pthread_join(tid[i], NULL);
+    pthread_barrier_destroy(&bar);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
 /* ---- Hi-Z pyramid (FrameGraph/DepthHighZNode.cpp:74-96, Content/Shaders/ComputeDepthHighZ.shader) ----------------------------

@@ -69,6 +69,11 @@ class CsmDesc(C.Structure):
                 ("width", C.c_int32 * NUM_CASCADES), ("height", C.c_int32 * NUM_CASCADES), ("format", C.c_int32 * NUM_CASCADES)]
 
 
+class CsmView(C.Structure):  # include/sailor_hip.h SailorCsmView (the transform half of CSMLightState, ECS/LightingECS.cpp:14-38)
+    _fields_ = [("componentIndex", C.c_uint32), ("cameraPosition", C.c_float * 4), ("cameraRotation", C.c_float * 4),
+                ("lightPosition", C.c_float * 4), ("lightRotation", C.c_float * 4)]
+
+
 class HiZDesc(C.Structure):
     _fields_ = [("pyramid", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("levels", C.c_int32)]
 
@@ -145,6 +150,16 @@ SIGNATURES = {
     "sailor_host_extract_frustum_planes_matrix": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sailor_host_csm_matrices": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float,
                                            C.POINTER(C.c_float)]),
+    "sailor_host_overlaps_sphere": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sailor_host_contains_sphere": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "sailor_host_lights_in_frustum": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_uint32),
+                                                _P, _P, C.POINTER(C.c_uint32), _P, _P, C.POINTER(C.c_uint32)]),
+    "sailor_host_csm_snapshots_create": (_P, []),
+    "sailor_host_csm_snapshots_clone": (_P, [_P]),
+    "sailor_host_csm_snapshots_destroy": (None, [_P]),
+    "sailor_host_csm_snapshots_count": (C.c_uint32, [_P]),
+    "sailor_host_csm_snapshot_get": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), _P, _P, C.POINTER(C.c_int32), C.POINTER(CsmView)]),
+    "sailor_host_csm_plan_passes": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P, C.POINTER(CsmView), _P, _P]),
     "sailor_host_pack_light": (C.c_int, [C.c_uint32, C.c_uint32] + [C.POINTER(C.c_float)] * 6 + [C.POINTER(LightShaderData)]),
 }
 

@@ -15,6 +15,9 @@
 #include "../../include/sailor_hip.h"
 #include <cmath>
 #include <cstring>
+#include <vector>
+#include <new>
+#include <algorithm>
 #include <limits>
 
 namespace {
@@ -328,6 +331,155 @@ int sailor_host_pack_light(uint32_t type, uint32_t shadowType, const float* worl
     // LightingECS.cpp:171: vec2(cos(radians(cutOff.x)), cos(radians(cutOff.y)))
     outLight->cutOff[0] = std::cos(cutOffDegrees[0] * 0.01745329251994329576923690768489f);
     outLight->cutOff[1] = std::cos(cutOffDegrees[1] * 0.01745329251994329576923690768489f);
+    return SAILOR_HIP_OK;
+}
+
+// ---- Math/Bounds.cpp:211-243: the scalar sphere tests; their only caller is LightingECS::GetLightsInFrustum (ContainsSphere, :237) ----
+int sailor_host_overlaps_sphere(const float* planes24, const float* sphere4)
+{
+    if (!planes24 || !sphere4) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    int res = 1;
+    for (int p = 0; p < 6; p++)
+        if (planes24[4 * p + 0] * sphere4[0] + planes24[4 * p + 1] * sphere4[1] + planes24[4 * p + 2] * sphere4[2] + planes24[4 * p + 3] < -sphere4[3]) res = 0;
+    return res;
+}
+
+int sailor_host_contains_sphere(const float* planes24, const float* sphere4)
+{
+    if (!planes24 || !sphere4) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    int res = 1;
+    for (int p = 0; p < 6; p++)
+        if (planes24[4 * p + 0] * sphere4[0] + planes24[4 * p + 1] * sphere4[1] + planes24[4 * p + 2] * sphere4[2] + planes24[4 * p + 3] < sphere4[3]) res = 0;
+    return res;
+}
+
+// ---- ECS/LightingECS.cpp:209-260 GetLightsInFrustum: the shadow-casting lights of a view.  Directional lights in component order; point
+// and spot lights whose bounding sphere (radius = the largest bound) lies INSIDE the frustum, each list sorted by distance to the camera
+// through the reference's own insertion: position = std::lower_bound(list, proxy) under operator< on the distance, i.e. a light goes
+// in FRONT of the lights already there at the same distance.
+int sailor_host_lights_in_frustum(const float* planes24, const float* cameraPosition3, uint32_t numLights, const uint32_t* types, const uint32_t* shadowTypes,
+                                  const uint8_t* active, const float* positions3, const float* bounds3,
+                                  uint32_t* outDirectional, uint32_t* outNumDirectional,
+                                  uint32_t* outPoint, float* outPointDistance, uint32_t* outNumPoint,
+                                  uint32_t* outSpot, float* outSpotDistance, uint32_t* outNumSpot)
+{
+    if (!planes24 || !cameraPosition3 || (numLights && (!types || !shadowTypes || !positions3 || !bounds3)) || !outDirectional || !outNumDirectional || !outPoint ||
+        !outPointDistance || !outNumPoint || !outSpot || !outSpotDistance || !outNumSpot)
+        return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    uint32_t nd = 0, np = 0, ns = 0;
+    auto insert = [](uint32_t* idx, float* dist, uint32_t& n, uint32_t index, float d) {
+        uint32_t lo = 0, hi = n; // lower_bound: first element that is not < d
+        while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (dist[mid] < d) lo = mid + 1; else hi = mid; }
+        for (uint32_t k = n; k > lo; k--) { idx[k] = idx[k - 1]; dist[k] = dist[k - 1]; }
+        idx[lo] = index; dist[lo] = d; n++;
+    };
+    for (uint32_t i = 0; i < numLights; i++) {
+        if (shadowTypes[i] == 0u /* EShadowType::None */ || (active && !active[i])) continue; // :222
+        if (types[i] == 0u /* Directional */) { outDirectional[nd++] = i; continue; }           // :255
+        const float* b = bounds3 + 3 * (size_t)i;
+        const float* p = positions3 + 3 * (size_t)i;
+        const float sphere[4] = { p[0], p[1], p[2], std::max(std::max(b[0], b[1]), b[2]) };     // :235
+        if (!sailor_host_contains_sphere(planes24, sphere)) continue;                            // :237
+        const float dx = p[0] - cameraPosition3[0], dy = p[1] - cameraPosition3[1], dz = p[2] - cameraPosition3[2];
+        const float d = std::sqrt((dx * dx + dy * dy) + dz * dz);                                // :240 glm::length
+        if (types[i] == 2u /* Spot */) insert(outSpot, outSpotDistance, ns, i, d);
+        else insert(outPoint, outPointDistance, np, i, d);
+    }
+    *outNumDirectional = nd; *outNumPoint = np; *outNumSpot = ns;
+    return SAILOR_HIP_OK;
+}
+
+} // extern "C"
+
+// ---- ECS/LightingECS.cpp:14-38 CSMLightState + :299-366, the change tracking of LightingECS::PrepareCSMPasses -------------------------
+namespace {
+struct CsmLightState {
+    bool hasView = false;
+    SailorCsmView view {};
+    std::vector<uint32_t> meshes;  // m_snapshot: (static mesh index, frame the mesh last changed)
+    std::vector<uint64_t> frames;
+};
+static void quat_rotate(const float* q, const float* v, float* o) // glm: v + ((cross(q.xyz, v) * q.w) + cross(q.xyz, cross(q.xyz, v))) * 2 (Transform::GetForward)
+{
+    const float uv[3] = { q[1] * v[2] - v[1] * q[2], q[2] * v[0] - v[2] * q[0], q[0] * v[1] - v[0] * q[1] };
+    const float uuv[3] = { q[1] * uv[2] - uv[1] * q[2], q[2] * uv[0] - uv[2] * q[0], q[0] * uv[1] - uv[0] * q[1] };
+    for (int i = 0; i < 3; i++) o[i] = v[i] + ((uv[i] * q[3]) + uuv[i]) * 2.0f;
+}
+// the transform half of CSMLightState::Equals (:19-24)
+static bool view_unchanged(bool hasA, const SailorCsmView& a, bool hasB, const SailorCsmView& b)
+{
+    if (!hasA || !hasB) return !hasA && !hasB;
+    if (a.componentIndex != b.componentIndex) return false;
+    float d2 = 0.0f;
+    for (int i = 0; i < 4; i++) { const float d = a.cameraPosition[i] - b.cameraPosition[i]; d2 += d * d; }
+    if (std::sqrt(d2) > 15.0f) return false;                         // CameraPosDelta
+    const float fwd[3] = { 0.0f, 0.0f, -1.0f };
+    float fa[3], fb[3];
+    quat_rotate(a.cameraRotation, fwd, fa); quat_rotate(b.cameraRotation, fwd, fb);
+    if ((fa[0] * fb[0] + fa[1] * fb[1]) + fa[2] * fb[2] < 0.9995f) return false; // CameraRotationDelta
+    for (int i = 0; i < 4; i++)
+        if (a.lightPosition[i] != b.lightPosition[i] || a.lightRotation[i] != b.lightRotation[i]) return false;
+    return true;
+}
+} // namespace
+
+struct SailorCsmSnapshots { std::vector<CsmLightState> states; }; // LightingECS::m_csmSnapshots
+
+extern "C" {
+
+SailorCsmSnapshots* sailor_host_csm_snapshots_create(void) { return new (std::nothrow) SailorCsmSnapshots(); }
+SailorCsmSnapshots* sailor_host_csm_snapshots_clone(const SailorCsmSnapshots* s) { return s ? new (std::nothrow) SailorCsmSnapshots(*s) : nullptr; }
+void sailor_host_csm_snapshots_destroy(SailorCsmSnapshots* s) { delete s; }
+uint32_t sailor_host_csm_snapshots_count(const SailorCsmSnapshots* s) { return s ? (uint32_t)s->states.size() : 0u; }
+
+int sailor_host_csm_snapshot_get(const SailorCsmSnapshots* s, uint32_t k, uint32_t capacity, uint32_t* outCount, uint32_t* outMeshes, uint64_t* outFrames,
+                                 int32_t* outHasView, SailorCsmView* outView)
+{
+    if (!s || k >= s->states.size() || !outCount) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const CsmLightState& st = s->states[k];
+    *outCount = (uint32_t)st.meshes.size();
+    for (uint32_t i = 0; i < st.meshes.size() && i < capacity; i++) {
+        if (outMeshes) outMeshes[i] = st.meshes[i];
+        if (outFrames) outFrames[i] = st.frames[i];
+    }
+    if (outHasView) *outHasView = st.hasView ? 1 : 0;
+    if (outView) *outView = st.view;
+    return SAILOR_HIP_OK;
+}
+
+int sailor_host_csm_plan_passes(SailorCsmSnapshots* state, uint32_t firstSnapshot, uint32_t numCascades, uint32_t numEntities, const uint64_t* overlapMasks,
+                                const uint32_t* shadowTypes, const uint64_t* lastChangedFrame, const SailorCsmView* view, uint32_t* outRender, uint64_t* outMasks)
+{
+    if (!state || !overlapMasks || !shadowTypes || (numEntities && !lastChangedFrame) || !outRender || !outMasks || numCascades > 16) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const size_t words = ((size_t)numEntities + 63) / 64;
+    uint32_t added[16];                       // bCascadeAdded[z]: the shadow type of a cascade that is rendered this frame, 0 = None
+    uint32_t snapshotIndex = firstSnapshot;
+    for (uint32_t k = 0; k < numCascades; k++) {
+        added[k] = 0u;
+        uint64_t* m = outMasks + (size_t)k * words;
+        std::memcpy(m, overlapMasks + (size_t)k * words, words * 8);
+        for (uint32_t z = 0; z < k; z++)       // :310-327 "don't duplicate data for higher cascades"
+            if (added[z] != 0u && added[z] == shadowTypes[k])
+                for (size_t w = 0; w < words; w++) m[w] &= ~overlapMasks[(size_t)z * words + w];
+        CsmLightState snap;                    // :334-347
+        snap.hasView = view != nullptr;
+        if (view) snap.view = *view;
+        for (uint32_t i = 0; i < numEntities; i++)
+            if ((m[i >> 6] >> (i & 63)) & 1ull) { snap.meshes.push_back(i); snap.frames.push_back(lastChangedFrame[i]); }
+        bool same = false;
+        if (snapshotIndex < state->states.size()) {
+            const CsmLightState& old = state->states[snapshotIndex];
+            same = old.meshes == snap.meshes && old.frames == snap.frames;
+            if (same && (snap.hasView || old.hasView)) same = view_unchanged(old.hasView, old.view, snap.hasView, snap.view);
+            if (!same) state->states[snapshotIndex] = std::move(snap); // :358
+        } else {
+            state->states.resize(snapshotIndex);  // (a gap can only come from a caller that skips indices: filled with empty states)
+            state->states.push_back(std::move(snap)); // :363
+        }
+        outRender[k] = same ? 0u : 1u;         // an equal snapshot is kept as it is, camera included (:353-357)
+        if (!same) added[k] = shadowTypes[k];
+        snapshotIndex++;
+    }
     return SAILOR_HIP_OK;
 }
 

@@ -160,35 +160,105 @@ def csm_view_unchanged(prev_view, view) -> bool:
     return bool(np.array_equal(np.asarray(lp0, np.float32), np.asarray(lp1, np.float32)) and np.array_equal(np.asarray(lr0, np.float32), np.asarray(lr1, np.float32)))
 
 
+class CsmSnapshots:
+    """LightingECS::m_csmSnapshots behind the C-ABI (sailor_host_csm_snapshots_*): `snaps[k]` = (mesh indices, their last-changed frames, the view the
+    snapshot was taken with or None)."""
+
+    def __init__(self, handle=None):
+        lib = _lib.load()
+        self._lib = lib
+        self.handle = handle if handle is not None else lib.sailor_host_csm_snapshots_create()
+        if not self.handle:
+            raise MemoryError("sailor_host_csm_snapshots_create")
+
+    def clone(self) -> "CsmSnapshots":
+        return CsmSnapshots(self._lib.sailor_host_csm_snapshots_clone(self.handle))
+
+    def __len__(self):
+        return int(self._lib.sailor_host_csm_snapshots_count(self.handle))
+
+    def __getitem__(self, k: int):
+        n = C.c_uint32()
+        _lib.check(self._lib.sailor_host_csm_snapshot_get(self.handle, k, 0, C.byref(n), None, None, None, None), "csm_snapshot_get")
+        idx = np.zeros(max(n.value, 1), np.uint32); frames = np.zeros(max(n.value, 1), np.uint64)
+        has = C.c_int32(); v = _lib.CsmView()
+        _lib.check(self._lib.sailor_host_csm_snapshot_get(self.handle, k, n.value, C.byref(n), idx.ctypes.data_as(C.c_void_p), frames.ctypes.data_as(C.c_void_p),
+                                                          C.byref(has), C.byref(v)), "csm_snapshot_get")
+        view = (int(v.componentIndex), np.float32(list(v.cameraPosition)), np.float32(list(v.cameraRotation)), np.float32(list(v.lightPosition)),
+                np.float32(list(v.lightRotation))) if has.value else None
+        return idx[: n.value], frames[: n.value], view
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.sailor_host_csm_snapshots_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def _csm_view_struct(view):
+    v = _lib.CsmView()
+    v.componentIndex = int(view[0])
+    for name, vals in zip(("cameraPosition", "cameraRotation", "lightPosition", "lightRotation"), view[1:]):
+        a = np.asarray(vals, np.float32)
+        for i in range(4):
+            getattr(v, name)[i] = float(a[i])
+    return v
+
+
 def plan_csm_passes(overlap_masks: np.ndarray, shadow_types, last_changed_frame: np.ndarray, previous, view=None):
-    """The bookkeeping of LightingECS::PrepareCSMPasses (ECS/LightingECS.cpp:299-366) for one directional light, on the cascade overlap sets
-    of sailor_hip_csm_caster_masks (uint64 [cascades, words]):
+    """The bookkeeping of LightingECS::PrepareCSMPasses (ECS/LightingECS.cpp:299-366) for one directional light -- sailor_host_csm_plan_passes
+    (host_math.cpp) -- on the cascade overlap sets of sailor_hip_csm_caster_masks (uint64 [cascades, words]):
       * cascade k > 0 drops every mesh that an EARLIER cascade of the same shadow type, re-rendered this frame, already overlaps (:310-327);
       * a cascade is re-rendered iff its mesh list, as (mesh index, frame the mesh last changed) pairs, differs from last frame's snapshot
         or -- with `view` = (light component index, camera position, camera rotation, light position, light rotation) -- the camera moved more than 15
         units / turned past dot 0.9995 / the light moved at all since that snapshot was taken (CSMLightState::Equals :14-38, csm_view_unchanged).
         A cascade that is NOT re-rendered keeps its old snapshot, camera included (:353-357): slow camera drift accumulates until it crosses the threshold.
-    Returns (list of cascades to render, their final uint64 masks [cascades, words], the new snapshots)."""
-    masks = np.array(overlap_masks, np.uint64, copy=True)
-    n_casc = masks.shape[0]
-    added = [None] * n_casc                      # bCascadeAdded[z]: the shadow type of a cascade that is rendered this frame
-    snapshots, render = [], []
-    frames = np.asarray(last_changed_frame)
-    for k in range(n_casc):
-        for z in range(k):
-            if added[z] is not None and added[z] == shadow_types[k]:
-                masks[k] &= ~np.asarray(overlap_masks[z], np.uint64)
-        bits = np.unpackbits(masks[k].view(np.uint8), bitorder="little")[: len(frames)].astype(bool)
-        idx = np.nonzero(bits)[0]
-        snap = (idx.copy(), frames[idx].copy(), view)
-        same = previous is not None and k < len(previous) and np.array_equal(previous[k][0], snap[0]) and np.array_equal(previous[k][1], snap[1])
-        if same and (view is not None or (len(previous[k]) > 2 and previous[k][2] is not None)):
-            same = csm_view_unchanged(previous[k][2] if len(previous[k]) > 2 else None, view)
-        snapshots.append(previous[k] if same else snap)  # an equal snapshot is kept as it is (:353-357)
-        if not same:
-            added[k] = shadow_types[k]
-            render.append(k)
-    return render, masks, snapshots
+    `previous`: the CsmSnapshots a former call returned, or None.  Returns (list of cascades to render, their final uint64 masks [cascades, words],
+    the new CsmSnapshots; `previous` is left as it was)."""
+    masks_in = np.ascontiguousarray(overlap_masks, np.uint64)
+    n_casc, words = masks_in.shape
+    frames = np.ascontiguousarray(last_changed_frame, np.uint64)
+    n = len(frames)
+    assert words == (n + 63) // 64
+    types = np.ascontiguousarray(shadow_types, np.uint32)
+    snaps = previous.clone() if previous is not None else CsmSnapshots()
+    render = np.zeros(n_casc, np.uint32)
+    out = np.zeros_like(masks_in)
+    vs = _csm_view_struct(view) if view is not None else None
+    _lib.check(_lib.load().sailor_host_csm_plan_passes(snaps.handle, 0, n_casc, n, masks_in.ctypes.data_as(C.c_void_p), types.ctypes.data_as(C.c_void_p),
+                                                       frames.ctypes.data_as(C.c_void_p), C.byref(vs) if vs is not None else None,
+                                                       render.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), "csm_plan_passes")
+    return [int(k) for k in np.nonzero(render)[0]], out, snaps
+
+
+def overlaps_sphere(planes, center, radius: float) -> bool:
+    """Math/Bounds.cpp:211-226 Frustum::OverlapsSphere"""
+    pl = _f32(planes, 24); sp = np.float32([center[0], center[1], center[2], radius])
+    return bool(_lib.load().sailor_host_overlaps_sphere(_fp(pl), _fp(sp)))
+
+
+def contains_sphere(planes, center, radius: float) -> bool:
+    """Math/Bounds.cpp:228-243 Frustum::ContainsSphere"""
+    pl = _f32(planes, 24); sp = np.float32([center[0], center[1], center[2], radius])
+    return bool(_lib.load().sailor_host_contains_sphere(_fp(pl), _fp(sp)))
+
+
+def lights_in_frustum(planes, camera_position, types, shadow_types, positions, bounds, active=None):
+    """LightingECS::GetLightsInFrustum (ECS/LightingECS.cpp:209-260) -> (directional indices, (point indices, distances), (spot indices, distances))"""
+    n = len(types)
+    pl = _f32(planes, 24); cp = np.float32(camera_position)[:3].copy()
+    t = np.ascontiguousarray(types, np.uint32); st = np.ascontiguousarray(shadow_types, np.uint32)
+    pos = np.ascontiguousarray(positions, np.float32).reshape(n, 3); bd = np.ascontiguousarray(bounds, np.float32).reshape(n, 3)
+    act = None if active is None else np.ascontiguousarray(active, np.uint8)
+    od, op, os_ = (np.zeros(max(n, 1), np.uint32) for _ in range(3))
+    dp, ds = np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.float32)
+    nd, npt, ns = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    _lib.check(_lib.load().sailor_host_lights_in_frustum(_fp(pl), _fp(cp), n, vp(t), vp(st), vp(act), vp(pos), vp(bd), vp(od), C.byref(nd), vp(op), vp(dp), C.byref(npt),
+                                                         vp(os_), vp(ds), C.byref(ns)), "lights_in_frustum")
+    return od[: nd.value].copy(), (op[: npt.value].copy(), dp[: npt.value].copy()), (os_[: ns.value].copy(), ds[: ns.value].copy())
 
 
 def csm_matrices(light_view, camera_world, aspect: float, fov_y_degrees: float, camera_near: float, camera_far: float) -> np.ndarray:

@@ -6,6 +6,8 @@
   * the committed golden fixtures under tests/golden/.
 """
 import ctypes as C
+import os
+import sys
 import re
 from pathlib import Path
 
@@ -17,6 +19,7 @@ from sailor_amd import host, synth
 
 REF = Path("/root/reference")
 GOLDEN = Path(__file__).resolve().parent / "golden"
+ROOT = Path(__file__).resolve().parents[1]
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -569,3 +572,143 @@ def test_c_oracle_ecs_sweep_agrees_with_the_float64_restatement():
     _, a, _, _ = oracle_f64.ecs_sweep(trs, np.array([0xFFFFFFFF], np.uint32), box, planes)
     _, a32, _ = oracle.ecs_sweep(trs, np.array([0xFFFFFFFF], np.uint32), box, planes)
     assert (a[0, 3:] > 0).all() and (a[0, 3:] < 1e-37).all() and np.array_equal(a32[0, 3:], a[0, 3:].astype(np.float32))
+
+
+def test_sse_batch_overlaps_aabb_against_the_scalar_form():
+    """SURVEY.md 8a E7: Frustum::OverlapsAABB(AABB*, n, int32*) (Math/Bounds.cpp:264-325), restated literally.  Its row loads (float offsets
+    0,4,8 / 12,16,20, 24 floats per step) and the (row0, row1, row2, zero) transposes only make sense for THREE boxes per step laid out as
+    vec4 min0, min1, min2, vec4 max0, max1, max2 with zero padding (then `zero`, which the transposes overwrite with the rows' fourth
+    components, stays zero).  On such input lanes 0..2 must say what the scalar form (:245-260) says, with the inverted output convention
+    (0x80000000 = culled); lane 3 is a box of zeros.  On the reference's own 24-byte {vec3 min, vec3 max} array the lanes do not correspond to
+    boxes -- checked too, as the documented reason why no caller uses the function."""
+    rng = np.random.default_rng(5)
+    cam = synth.make_camera(1280, 720)
+    planes, _ = host.extract_frustum_planes(cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+    pl = np.ascontiguousarray(planes, np.float32).reshape(24)
+    steps = 4096
+    centre = rng.uniform(-3000, 3000, (steps, 3, 3)).astype(np.float32); centre[..., 1] += 150
+    ext = rng.uniform(0.5, 400, (steps, 3, 3)).astype(np.float32)
+    mn, mx = centre - ext, centre + ext
+    buf = np.zeros(steps * 24 + 4, np.float32)
+    off = (-buf.ctypes.data % 16) // 4
+    data = buf[off:off + steps * 24].reshape(steps, 6, 4)
+    data[:, 0:3, :3] = mn; data[:, 3:6, :3] = mx           # .w padding stays 0
+    res = np.zeros(steps * 4, np.int32)
+    L = oracle.lib()
+    L.oracle_overlaps_aabb_sse(pl.ctypes.data_as(C.c_void_p), data.ctypes.data_as(C.c_void_p), C.c_uint32(steps * 4), res.ctypes.data_as(C.c_void_p))
+    res = res.reshape(steps, 4)
+    assert set(np.unique(res)) <= {0, -0x80000000}
+    # scalar form on the same boxes; the two add their four terms in a different order, so boxes within rounding of a plane are left out
+    boxes = np.concatenate([mn, mx], -1).reshape(-1, 6).astype(np.float32)
+    scalar = np.array([L.oracle_overlaps_aabb(pl.ctypes.data_as(C.c_void_p), np.ascontiguousarray(b).ctypes.data_as(C.c_void_p)) for b in boxes]).reshape(steps, 3)
+    p4 = planes.reshape(6, 4).astype(np.float64)
+    d = np.maximum(boxes[:, None, :3] * p4[None, :, :3], boxes[:, None, 3:] * p4[None, :, :3]).sum(-1) + p4[None, :, 3]
+    clear = (np.abs(d).min(1) > 1e-2).reshape(steps, 3)
+    assert clear.mean() > 0.99 and 0.05 < scalar.mean() < 0.95
+    np.testing.assert_array_equal((res[:, :3] == 0)[clear], scalar.astype(bool)[clear])
+    zero_box = (p4[:, 3] > 0).all()                          # lane 3: min = max = 0 -> distance = d of every plane
+    assert ((res[:, 3] == 0) == zero_box).all()
+    # the reference's own layout (24-byte boxes back to back): lane k is NOT box 4 i + k
+    packed = np.zeros(steps * 24 + 4, np.float32)
+    po = (-packed.ctypes.data % 16) // 4
+    pk = packed[po:po + steps * 24]
+    pk[:] = boxes[: steps * 4].reshape(-1)[: steps * 24] if boxes.shape[0] >= steps * 4 else np.resize(boxes.reshape(-1), steps * 24)
+    res2 = np.zeros(steps * 4, np.int32)
+    L.oracle_overlaps_aabb_sse(pl.ctypes.data_as(C.c_void_p), pk.ctypes.data_as(C.c_void_p), C.c_uint32(steps * 4), res2.ctypes.data_as(C.c_void_p))
+    flat = np.resize(boxes, (steps * 4, 6))
+    scalar2 = np.array([L.oracle_overlaps_aabb(pl.ctypes.data_as(C.c_void_p), np.ascontiguousarray(b).ctypes.data_as(C.c_void_p)) for b in flat])
+    assert ((res2 == 0) != scalar2.astype(bool)).mean() > 0.05
+
+
+def test_sphere_tests_and_the_light_pre_sort():
+    """SURVEY.md 8a E8: Frustum::OverlapsSphere / ContainsSphere (Math/Bounds.cpp:211-243) -- the product's host functions against the oracle's --
+    and LightingECS::GetLightsInFrustum (ECS/LightingECS.cpp:209-260): only shadow-casting, active lights; directional ones in component order;
+    point / spot lights whose sphere is CONTAINED, by distance, equal distances in reverse component order (std::lower_bound insertion)."""
+    rng = np.random.default_rng(9)
+    cam = synth.make_camera(1280, 720)
+    planes, _ = host.extract_frustum_planes(cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+    pl = np.ascontiguousarray(planes, np.float32).reshape(24)
+    L = oracle.lib()
+    n = 3000
+    pos = rng.uniform(-2500, 2500, (n, 3)).astype(np.float32); pos[:, 1] += 150; pos[:, 2] -= 1500
+    rad = rng.uniform(1, 600, n).astype(np.float32)
+    ov = ct = 0
+    for i in range(n):
+        sp = np.float32([*pos[i], rad[i]])
+        o_ref = L.oracle_overlaps_sphere(pl.ctypes.data_as(C.c_void_p), sp.ctypes.data_as(C.c_void_p))
+        c_ref = L.oracle_contains_sphere(pl.ctypes.data_as(C.c_void_p), sp.ctypes.data_as(C.c_void_p))
+        assert host.overlaps_sphere(pl, pos[i], float(rad[i])) == bool(o_ref) and host.contains_sphere(pl, pos[i], float(rad[i])) == bool(c_ref)
+        assert not c_ref or o_ref  # contained implies overlapping
+        ov += o_ref; ct += c_ref
+    assert 0 < ct < ov < n
+    # the pre-sort
+    types = rng.choice([0, 1, 2], n, p=[0.02, 0.6, 0.38]).astype(np.uint32)
+    shadow = rng.choice([0, 1, 2], n, p=[0.3, 0.5, 0.2]).astype(np.uint32)
+    active = (rng.uniform(size=n) > 0.1).astype(np.uint8)
+    bounds = np.stack([rad * rng.uniform(0.2, 1, n), rad, rad * rng.uniform(0.2, 1, n)], 1).astype(np.float32)
+    pos[10] = pos[20]; pos[30] = pos[20]; types[[10, 20, 30]] = 1; shadow[[10, 20, 30]] = 1; active[[10, 20, 30]] = 1; bounds[[10, 20, 30]] = 5.0
+    pos[[10, 20, 30]] = np.float32([0, 150, -500])            # three point lights at the same distance, inside the frustum
+    cam_pos = np.float32([0, 150, 0])
+    dirs, (pi, pd), (si, sd) = host.lights_in_frustum(pl, cam_pos, types, shadow, pos, bounds, active)
+    # reference semantics in plain Python
+    e_dir, e_pt, e_sp = [], [], []
+    for i in range(n):
+        if shadow[i] == 0 or not active[i]:
+            continue
+        if types[i] == 0:
+            e_dir.append(i); continue
+        sp = np.float32([*pos[i], bounds[i].max()])
+        if not L.oracle_contains_sphere(pl.ctypes.data_as(C.c_void_p), sp.ctypes.data_as(C.c_void_p)):
+            continue
+        dv = pos[i] - cam_pos
+        dist = np.sqrt(np.float32(np.float32(dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]), dtype=np.float32)
+        lst = e_sp if types[i] == 2 else e_pt
+        k = 0
+        while k < len(lst) and lst[k][1] < dist:             # std::lower_bound under operator< on the distance
+            k += 1
+        lst.insert(k, (i, dist))
+    np.testing.assert_array_equal(dirs, e_dir)
+    np.testing.assert_array_equal(pi, [i for i, _ in e_pt]); np.testing.assert_array_equal(pd, np.float32([d for _, d in e_pt]))
+    np.testing.assert_array_equal(si, [i for i, _ in e_sp]); np.testing.assert_array_equal(sd, np.float32([d for _, d in e_sp]))
+    assert len(e_dir) > 3 and len(e_pt) > 20 and len(e_sp) > 10 and (np.diff(pd) >= 0).all()
+    where = [int(np.nonzero(pi == k)[0][0]) for k in (30, 20, 10)]
+    assert where[1] == where[0] + 1 and where[2] == where[0] + 2  # ties: the later component in front
+    # all-active default, nothing to report
+    d0, (p0, _), (s0, _) = host.lights_in_frustum(pl, cam_pos, types[:0], shadow[:0], pos[:0], bounds[:0])
+    assert len(d0) == len(p0) == len(s0) == 0
+
+
+def test_cpu_suite_of_the_oracle_under_address_and_ub_sanitizers():
+    """a sanitizer pass over the C oracle on the CPU build (GPU sanitizers are not available on the pool): the tiny cull,
+    shade with shadow maps, the ECS sweep on one and on several threads, the SSE batch form -- in a child interpreter with libasan preloaded."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    asan = subprocess.run([gcc, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not Path(asan).exists():
+        pytest.skip("no libasan.so")
+    subprocess.run(["make", "-C", str(ROOT / "oracle"), "liboracle_asan.so"], check=True, capture_output=True)
+    code = r"""
+import numpy as np
+from oracle import oracle
+from sailor_amd import synth, host
+f = synth.make_frame("tiny_csm")
+W, H = f.cam.width, f.cam.height
+g, idx, cnt = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, want_counts=True)
+csm, keep = oracle.make_csm(f.shadows.lights_matrices, f.shadows.maps)
+rad = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, g, idx, csm)
+ents = synth.make_entities(5000)
+planes, _ = host.extract_frustum_planes(f.cam.world, f.cam.aspect, f.cam.fov, f.cam.z_near, f.cam.z_far)
+w, a, v = oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes)
+w2, a2, v2, _ = oracle.ecs_sweep_threads(ents.transforms, ents.parent, ents.local_aabb, planes, ents.level_offsets, 3)
+assert np.array_equal(w, w2) and np.array_equal(a, a2) and np.array_equal(v, v2)
+masks = oracle.csm_caster_masks(a, np.stack([planes] * 4))
+print("sanitized pass ok", int(idx[0]), float(rad.max()), int(np.unpackbits(v.view(np.uint8)).sum()))
+"""
+    env = dict(os.environ, LD_PRELOAD=asan, SAILOR_ORACLE_LIB=str(ROOT / "oracle" / "liboracle_asan.so"), ASAN_OPTIONS="detect_leaks=0:abort_on_error=0",
+               PYTHONPATH=str(ROOT))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert p.returncode == 0 and "sanitized pass ok" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]
