@@ -471,6 +471,25 @@ SAILOR_HIP_API int sailor_hip_mesh_cull_compact(SailorHipContext* ctx, const Sai
  * Collective 2: all-gather of the padded band index segments (each rank contributes `segmentCapacity` uints). */
 SAILOR_HIP_API int sailor_hip_allgather_u32(SailorHipContext* ctx, void* comm, const uint32_t* dSend, uint32_t* dRecv, size_t countPerRank);
 
+/* The whole exchange of a split frame (the reference's single Dispatch at FrameGraph/LightCullingNode.cpp:74-77 fills ONE pair of
+ * buffers, a split frame has one pair per band): every rank hands in the lists of its band (sailor_hip_band_for_rank(width, height, rank,
+ * worldSize), as sailor_hip_light_cull left them) and gets the reference's global `lightsGrid` (tiles x {offset, num}) and `culledLights`
+ * ([0] = sum of num, then the lists at the canonical offsets) -- three ncclAllGather of fixed-size slots on the context's stream (band total;
+ * index segment; grid) and one stitch kernel that takes each band's global base from the gathered totals on the device.  Nothing synchronises.
+ *   comm          : an ncclComm_t of `worldSize` ranks created by the host (RCCL over xGMI)
+ *   dGlobalCulled : globalCapacity uints, 1 + tiles * 128 holds every result
+ *   dWorkspace    : sailor_hip_exchange_workspace_size(width, height, worldSize) bytes, 256-byte aligned */
+#define SAILOR_MAX_SPLIT 64
+SAILOR_HIP_API size_t sailor_hip_exchange_workspace_size(int32_t width, int32_t height, int32_t worldSize);
+SAILOR_HIP_API int sailor_hip_exchange_light_lists(SailorHipContext* ctx, void* comm, int32_t rank, int32_t worldSize, int32_t width, int32_t height,
+                                                   const SailorLightsGrid* dBandGrid, const uint32_t* dBandCulled, SailorLightsGrid* dGlobalGrid,
+                                                   uint32_t* dGlobalCulled, size_t globalCapacity, void* dWorkspace, size_t workspaceBytes);
+/* The stitch alone, on gathered slots: dTotals[worldSize]; dSegments[worldSize][segmentCapacity] (band r's culledLights[1 ..]);
+ * dGrids[worldSize][gridCapacity] (band r's lightsGrid as uint32 pairs, band-local offsets). */
+SAILOR_HIP_API int sailor_hip_stitch_light_lists(SailorHipContext* ctx, int32_t width, int32_t height, int32_t worldSize, const uint32_t* dTotals,
+                                                 const uint32_t* dSegments, size_t segmentCapacity, const uint32_t* dGrids, size_t gridCapacity,
+                                                 SailorLightsGrid* dGlobalGrid, uint32_t* dGlobalCulled, size_t globalCapacity);
+
 /* ---- host-side math of the path (pure CPU, no device needed) ----------------------------------------------- */
 /* Math/Math.cpp:18-21 PerspectiveRH (reversed Z) */
 SAILOR_HIP_API int sailor_host_perspective_rh(float fovRadians, float aspect, float zNear, float zFar, float* outMat4);

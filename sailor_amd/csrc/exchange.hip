@@ -29,3 +29,116 @@ extern "C" int sailor_hip_allgather_u32(SailorHipContext* ctx, void* comm, const
     if (rc != 0) { ctx->lastError = "ncclAllGather failed"; return SAILOR_HIP_ERR_RCCL; }
     return SAILOR_HIP_OK;
 }
+
+// ---- the whole exchange of a split frame: band lists -> the reference's global lightsGrid / culledLights on every rank --------
+// Three all-gathers of fixed-size slots (band total; index segment padded to the largest band's worst case; grid padded to the largest
+// band) into the workspace, then ONE kernel per rank that turns the gathered slots into the canonical buffers: global offset of band r =
+// sum of the totals of the bands before it (read from the gathered totals on the device: no host round trip anywhere in the exchange).
+struct StitchArgs {
+    const uint32_t* totals;   // [world]
+    const uint32_t* segments; // [world][segCap]  (a band's culledLights[1 ..])
+    const uint32_t* grids;    // [world][gridCap] ({offset, num} pairs, band-local offsets)
+    uint32_t* outGrid; uint32_t* outCulled;
+    uint32_t world, segCap, gridCap, outCapacity;
+    uint32_t tiles[SAILOR_MAX_SPLIT + 1]; // prefix sums of the bands' tile counts
+};
+
+__global__ __launch_bounds__(256) void k_stitch_lists(const StitchArgs a)
+{
+    const uint32_t r = blockIdx.y; // band
+    uint32_t base = 0, all = 0;
+    for (uint32_t q = 0; q < a.world; q++) { const uint32_t t = a.totals[q]; if (q < r) base += t; all += t; }
+    const uint32_t total = a.totals[r] < a.segCap ? a.totals[r] : a.segCap;
+    const uint32_t stride = gridDim.x * 256u, first = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t i = first; i < total; i += stride)
+        if (1u + base + i < a.outCapacity) a.outCulled[1u + base + i] = a.segments[(size_t)r * a.segCap + i];
+    const uint32_t t0 = a.tiles[r], nt = a.tiles[r + 1] - t0;
+    for (uint32_t i = first; i < nt; i += stride) {
+        const uint32_t off = a.grids[(size_t)r * a.gridCap + 2u * i], num = a.grids[(size_t)r * a.gridCap + 2u * i + 1u];
+        a.outGrid[2u * (t0 + i)] = off + base; // Appendix A step 6: canonical global offsets
+        a.outGrid[2u * (t0 + i) + 1u] = num;
+    }
+    if (r == 0 && first == 0) a.outCulled[0] = all;
+}
+
+extern "C" size_t sailor_hip_exchange_workspace_size(int32_t width, int32_t height, int32_t worldSize)
+{
+    if (width <= 0 || height <= 0 || worldSize < 1 || worldSize > SAILOR_MAX_SPLIT) return 0;
+    int32_t Tx = 0, Ty = 0;
+    sailor_hip_num_tiles(width, height, &Tx, &Ty);
+    const size_t maxRows = ((size_t)Ty + worldSize - 1) / worldSize; // band_for_rank: floor((g+1) Ty / G) - floor(g Ty / G) <= ceil(Ty / G)
+    const size_t maxTiles = maxRows * Tx;
+    return align_up((size_t)worldSize * 4, 256) + align_up((size_t)worldSize * maxTiles * KEEP * 4, 256) + align_up((size_t)worldSize * maxTiles * 8, 256) +
+           align_up(maxTiles * KEEP * 4, 256) + align_up(maxTiles * 8, 256);
+}
+
+extern "C" int sailor_hip_stitch_light_lists(SailorHipContext* ctx, int32_t width, int32_t height, int32_t worldSize, const uint32_t* dTotals,
+                                             const uint32_t* dSegments, size_t segmentCapacity, const uint32_t* dGrids, size_t gridCapacity,
+                                             SailorLightsGrid* dGlobalGrid, uint32_t* dGlobalCulled, size_t globalCapacity)
+{
+    if (!ctx || !dTotals || !dSegments || !dGrids || !dGlobalGrid || !dGlobalCulled || width <= 0 || height <= 0 || worldSize < 1 || worldSize > SAILOR_MAX_SPLIT)
+        return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (globalCapacity < 1 || segmentCapacity > 0xFFFFFFFFull || gridCapacity > 0xFFFFFFFFull) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    StitchArgs a;
+    a.totals = dTotals; a.segments = dSegments; a.grids = dGrids; a.outGrid = (uint32_t*)dGlobalGrid; a.outCulled = dGlobalCulled;
+    a.world = (uint32_t)worldSize; a.segCap = (uint32_t)segmentCapacity; a.gridCap = (uint32_t)gridCapacity;
+    a.outCapacity = (uint32_t)(globalCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : globalCapacity);
+    a.tiles[0] = 0;
+    uint32_t maxTiles = 1;
+    for (int r = 0; r < worldSize; r++) {
+        SailorBand b;
+        sailor_hip_band_for_rank(width, height, r, worldSize, &b);
+        int32_t Tx = 0, Ty = 0;
+        sailor_hip_num_tiles(width, height, &Tx, &Ty);
+        const uint32_t nt = (uint32_t)((b.tileRowEnd - b.tileRowBegin) * Tx);
+        if ((size_t)nt * 2 > gridCapacity) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+        a.tiles[r + 1] = a.tiles[r] + nt;
+        if (nt > maxTiles) maxTiles = nt;
+    }
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned bx = (maxTiles * (unsigned)KEEP / 8 + 255) / 256;
+    if (bx > 256) bx = 256;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_stitch_lists, dim3(bx, (unsigned)worldSize), dim3(256), 0, ctx->stream, a);
+    SAILOR_CHECK_LAUNCH(ctx, "k_stitch_lists");
+    return SAILOR_HIP_OK;
+}
+
+__global__ void k_pad_copy(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint32_t* __restrict__ count, uint32_t fixedCount, uint32_t capacity)
+{
+    const uint32_t n = count ? (*count < capacity ? *count : capacity) : fixedCount;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[i];
+}
+
+extern "C" int sailor_hip_exchange_light_lists(SailorHipContext* ctx, void* comm, int32_t rank, int32_t worldSize, int32_t width, int32_t height,
+                                               const SailorLightsGrid* dBandGrid, const uint32_t* dBandCulled, SailorLightsGrid* dGlobalGrid,
+                                               uint32_t* dGlobalCulled, size_t globalCapacity, void* dWorkspace, size_t workspaceBytes)
+{
+    if (!ctx || !comm || !dBandGrid || !dBandCulled || !dGlobalGrid || !dGlobalCulled || !dWorkspace || rank < 0 || rank >= worldSize) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const size_t need = sailor_hip_exchange_workspace_size(width, height, worldSize);
+    if (need == 0 || ((uintptr_t)dWorkspace & 255)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (workspaceBytes < need) return SAILOR_HIP_ERR_WORKSPACE_TOO_SMALL;
+    int32_t Tx = 0, Ty = 0;
+    sailor_hip_num_tiles(width, height, &Tx, &Ty);
+    const size_t maxTiles = (((size_t)Ty + worldSize - 1) / worldSize) * Tx;
+    const size_t segCap = maxTiles * KEEP, gridCap = maxTiles * 2;
+    char* ws = (char*)dWorkspace;
+    uint32_t* totals = (uint32_t*)ws; ws += align_up((size_t)worldSize * 4, 256);
+    uint32_t* segments = (uint32_t*)ws; ws += align_up((size_t)worldSize * segCap * 4, 256);
+    uint32_t* grids = (uint32_t*)ws; ws += align_up((size_t)worldSize * gridCap * 4, 256);
+    uint32_t* sendSeg = (uint32_t*)ws; ws += align_up(segCap * 4, 256);
+    uint32_t* sendGrid = (uint32_t*)ws;
+    SailorBand band;
+    sailor_hip_band_for_rank(width, height, rank, worldSize, &band);
+    const uint32_t myTiles = (uint32_t)((band.tileRowEnd - band.tileRowBegin) * Tx);
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    // fixed-size send slots (what lies behind the valid part is never read by the stitch)
+    hipLaunchKernelGGL(k_pad_copy, dim3(256), dim3(256), 0, ctx->stream, dBandCulled + 1, sendSeg, dBandCulled, 0u, (uint32_t)segCap);
+    hipLaunchKernelGGL(k_pad_copy, dim3(64), dim3(256), 0, ctx->stream, (const uint32_t*)dBandGrid, sendGrid, (const uint32_t*)nullptr, myTiles * 2u, (uint32_t)gridCap);
+    SAILOR_CHECK_LAUNCH(ctx, "k_pad_copy");
+    int rc = sailor_hip_allgather_u32(ctx, comm, dBandCulled, totals, 1);             // collective 1: band totals
+    if (rc == SAILOR_HIP_OK) rc = sailor_hip_allgather_u32(ctx, comm, sendSeg, segments, segCap);   // collective 2: index segments
+    if (rc == SAILOR_HIP_OK) rc = sailor_hip_allgather_u32(ctx, comm, sendGrid, grids, gridCap);    // (the grids, 8 bytes per tile)
+    if (rc != SAILOR_HIP_OK) return rc;
+    return sailor_hip_stitch_light_lists(ctx, width, height, worldSize, totals, segments, segCap, grids, gridCap, dGlobalGrid, dGlobalCulled, globalCapacity);
+}

@@ -330,7 +330,18 @@ int HipGraphicsDriver::RecordLightCulling(const TVector<RHIShaderBindingSetPtr>&
     SailorUboFrameData frame;
     memcpy(&frame, frameB->m_hostCopy.data(), sizeof frame);
     SailorBand band;
-    sailor_hip_band_whole_frame(pc.viewportSize[0], pc.viewportSize[1], &band);
+    if (m_worldSize > 1) {
+        // Split frame: the node sized its push constants by the depth attachment it was given (LightCullingNode.cpp:55-57) -- the band's rows.
+        // The tile frusta live in the WHOLE frame (frame.viewportSize, RHIFrameGraph.cpp:67), so the push constants are rebuilt for it.
+        const int W = frame.viewportSize[0], H = frame.viewportSize[1];
+        if (sailor_hip_band_for_rank(W, H, m_rank, m_worldSize, &band) != SAILOR_HIP_OK) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+        if (pc.viewportSize[0] != W || pc.viewportSize[1] != band.fbRowCount) return SAILOR_HIP_ERR_INVALID_ARGUMENT; // the depth attachment must be the band's rows
+        pc.viewportSize[0] = W; pc.viewportSize[1] = H;
+        sailor_hip_num_tiles(W, H, &pc.numTiles[0], &pc.numTiles[1]);
+    } else {
+        sailor_hip_band_whole_frame(pc.viewportSize[0], pc.viewportSize[1], &band);
+    }
+    m_band = band; m_splitW = pc.viewportSize[0]; m_splitH = pc.viewportSize[1];
     const size_t need = sailor_hip_light_cull_workspace_size(pc.viewportSize[0], pc.viewportSize[1], pc.lightsNum, &band);
     if (!m_cullWorkspace || m_cullWorkspace->m_size < need) m_cullWorkspace = CreateBuffer(need);
     if (!m_cullWorkspace) return SAILOR_HIP_ERR_OUT_OF_MEMORY;
@@ -339,6 +350,26 @@ int HipGraphicsDriver::RecordLightCulling(const TVector<RHIShaderBindingSetPtr>&
                                  (const float*)depthB->m_textures[0]->m_buffer->m_hip.m_devicePtr,
                                  (SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (uint32_t*)buffer_of(bindings[1], "culledLights"),
                                  culledB->m_buffer->m_size / 4, m_cullWorkspace->m_hip.m_devicePtr, m_cullWorkspace->m_size, &band, SAILOR_CULL_DEFAULT);
+}
+
+int HipGraphicsDriver::SetFrameSplit(int rank, int worldSize, void* ncclComm)
+{
+    if (worldSize < 1 || worldSize > SAILOR_MAX_SPLIT || rank < 0 || rank >= worldSize) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    m_rank = rank; m_worldSize = worldSize; m_comm = ncclComm;
+    m_cullOrderValid = false;
+    return SAILOR_HIP_OK;
+}
+
+int HipGraphicsDriver::ExchangeLightLists(RHIBufferPtr bandGrid, RHIBufferPtr bandCulled, RHIBufferPtr globalGrid, RHIBufferPtr globalCulled)
+{
+    if (!bandGrid || !bandCulled || !globalGrid || !globalCulled || !m_comm || m_splitW <= 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const size_t need = sailor_hip_exchange_workspace_size(m_splitW, m_splitH, m_worldSize);
+    if (!m_exchangeWorkspace || m_exchangeWorkspace->m_size < need) m_exchangeWorkspace = CreateBuffer(need);
+    if (!m_exchangeWorkspace) return SAILOR_HIP_ERR_OUT_OF_MEMORY;
+    return sailor_hip_exchange_light_lists(m_ctx, m_comm, m_rank, m_worldSize, m_splitW, m_splitH, (const SailorLightsGrid*)bandGrid->m_hip.m_devicePtr,
+                                           (const uint32_t*)bandCulled->m_hip.m_devicePtr, (SailorLightsGrid*)globalGrid->m_hip.m_devicePtr,
+                                           (uint32_t*)globalCulled->m_hip.m_devicePtr, globalCulled->m_size / 4, m_exchangeWorkspace->m_hip.m_devicePtr,
+                                           m_exchangeWorkspace->m_size);
 }
 
 int HipGraphicsDriver::RecordShade(const TVector<RHIShaderBindingSetPtr>& bindings)
@@ -387,11 +418,14 @@ int HipGraphicsDriver::RecordShade(const TVector<RHIShaderBindingSetPtr>& bindin
         }
     }
     const int32_t lightsNum = (int32_t)(countB->m_buffer->m_size / sizeof(SailorLightShaderData));
-    return sailor_hip_shade_ex(m_ctx, &frame, (const float*)surfaceB->m_buffer->m_hip.m_devicePtr, (size_t)W * H,
+    const SailorBand* band = (m_worldSize > 1 && m_splitW == W && m_splitH == H) ? &m_band : nullptr; // the band of this frame's light cull
+    const size_t planeStride = band ? (size_t)W * band->fbRowCount : (size_t)W * H;
+    if (surfaceB->m_buffer->m_size < planeStride * 48) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    return sailor_hip_shade_ex(m_ctx, &frame, (const float*)surfaceB->m_buffer->m_hip.m_devicePtr, planeStride,
                                (const SailorLightShaderData*)buffer_of(bindings[1], "light"), lightsNum,
                                (const SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (const uint32_t*)buffer_of(bindings[1], "culledLights"),
-                               hasCsm ? &csm : nullptr, hasIbl ? &ibl : nullptr, (float*)buffer_of(bindings[2], "radiance"), nullptr,
-                               m_cullOrderValid ? sailor_hip_light_cull_tile_order(m_cullW, m_cullH, m_cullLights, nullptr, m_cullWorkspace->m_hip.m_devicePtr) : nullptr);
+                               hasCsm ? &csm : nullptr, hasIbl ? &ibl : nullptr, (float*)buffer_of(bindings[2], "radiance"), band,
+                               m_cullOrderValid ? sailor_hip_light_cull_tile_order(m_cullW, m_cullH, m_cullLights, band, m_cullWorkspace->m_hip.m_devicePtr) : nullptr);
 }
 
 // ---- the render-pass subset: state is kept on the command list, a 6-index draw of a known full-screen material becomes a

@@ -53,6 +53,14 @@ public:
                                                              const TVector<RHI::RHITexturePtr>& array, uint32_t shaderBinding) override;
     RHI::RHIShaderBindingPtr AddShaderBinding(RHI::RHIShaderBindingSetPtr& set, const RHI::RHIShaderBindingPtr& binding, const std::string& name,
                                               uint32_t shaderBinding) override;
+    // Split frame: this driver renders tile-row band `rank` of `worldSize` of every frame.  The per-pixel targets bound afterwards
+    // (sceneDepth, surface, radiance) hold the band's framebuffer rows only; `frame.viewportSize` stays the whole frame's.  `ncclComm` (an
+    // ncclComm_t of worldSize ranks, may be null until an exchange is wanted) is only used by ExchangeLightLists.
+    int SetFrameSplit(int rank, int worldSize, void* ncclComm);
+    const SailorBand* GetBand() const { return m_worldSize > 1 ? &m_band : nullptr; }
+    // The RCCL step of a split frame: the band's lightsGrid / culledLights of the last light cull -> the reference's global buffers (on every
+    // rank), recorded on the driver's stream (sailor_hip_exchange_light_lists).  Buffers: tiles x 8 bytes and (1 + tiles x 128) x 4 bytes.
+    int ExchangeLightLists(RHI::RHIBufferPtr bandGrid, RHI::RHIBufferPtr bandCulled, RHI::RHIBufferPtr globalGrid, RHI::RHIBufferPtr globalCulled);
     // wrap memory owned by someone else (a torch tensor in the tests, an engine heap in the real thing)
     RHI::RHIBufferPtr WrapBuffer(void* devicePtr, size_t size);
     RHI::RHITexturePtr WrapTexture(void* devicePtr, RHI::ivec2 extent, RHI::EFormat format);
@@ -98,6 +106,11 @@ private:
     RHI::RHIBufferPtr m_meshCullWorkspace;
     int32_t m_cullW = 0, m_cullH = 0, m_cullLights = 0; // geometry of the last light cull: locates its shading-order hint in the workspace
     bool m_cullOrderValid = false;
+    int m_rank = 0, m_worldSize = 1; // the frame split
+    void* m_comm = nullptr;
+    SailorBand m_band {};
+    int32_t m_splitW = 0, m_splitH = 0; // the frame size m_band was computed for
+    RHI::RHIBufferPtr m_exchangeWorkspace;
 };
 
 } // namespace Sailor::GraphicsDriver::HIP

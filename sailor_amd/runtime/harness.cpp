@@ -487,6 +487,24 @@ RT_API int sailor_rt_shadow_pass(SailorRuntime* rt, const float* lightMatrix, vo
     return st;
 }
 
+// split frame: this runtime renders tile-row band `rank` of `worldSize` (targets set afterwards hold the band's rows); `comm` = ncclComm_t or null
+RT_API int sailor_rt_set_frame_split(SailorRuntime* rt, int rank, int worldSize, void* comm)
+{
+    (void)rt;
+    return static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver())->SetFrameSplit(rank, worldSize, comm);
+}
+
+// the RCCL step: the band lists of the last frame -> the reference's global buffers, in caller-owned device memory
+RT_API int sailor_rt_exchange_light_lists(SailorRuntime* rt, void* globalGridDevicePtr, size_t gridBytes, void* globalCulledDevicePtr, size_t culledBytes)
+{
+    auto* hip = static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver());
+    auto node = rt->lightCulling.DynamicCast<LightCullingNode>();
+    if (!node || !node->GetCulledLights()) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    auto g = node->GetCulledLights()->Find("lightsGrid"), c = node->GetCulledLights()->Find("culledLights");
+    if (!g || !c || !g->m_buffer || !c->m_buffer) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    return hip->ExchangeLightLists(g->m_buffer, c->m_buffer, hip->WrapBuffer(globalGridDevicePtr, gridBytes), hip->WrapBuffer(globalCulledDevicePtr, culledBytes));
+}
+
 RT_API int sailor_rt_process_frame(SailorRuntime* rt)
 {
     rt->graph.Process(rt->snapshot);

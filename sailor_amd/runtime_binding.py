@@ -54,6 +54,8 @@ def load() -> C.CDLL:
         rt.sailor_rt_shadow_pass.argtypes = [P, C.POINTER(C.c_float), P, C.c_uint32, P, C.c_uint32, P, C.c_uint32, C.c_uint32, P, C.c_int, C.c_int, C.c_float, C.c_float]
         rt.sailor_rt_gpu_culling.argtypes = [P, P, C.c_uint32, C.c_uint32, P, C.c_uint32]
         rt.sailor_rt_process_frame.argtypes = [P]
+        rt.sailor_rt_set_frame_split.argtypes = [P, C.c_int, C.c_int, P]
+        rt.sailor_rt_exchange_light_lists.argtypes = [P, P, C.c_size_t, P, C.c_size_t]
         rt.sailor_rt_wait_idle.argtypes = [P]
         rt.sailor_rt_buffer.restype = P
         rt.sailor_rt_buffer.argtypes = [P, C.c_char_p, C.POINTER(C.c_size_t)]
@@ -197,6 +199,14 @@ class Runtime:
         fmts = (C.c_int * 4)(*formats)
         lm = np.ascontiguousarray(lights_matrices, np.float32).reshape(64)
         self.rt.sailor_rt_set_shadow_maps(self.h, ptrs, sizes, fmts, lm.ctypes.data)
+
+    def set_frame_split(self, rank: int, world_size: int, comm=None):
+        """this runtime renders tile-row band `rank` of `world_size`; per-pixel targets set afterwards hold the band's rows"""
+        _lib.check(self.rt.sailor_rt_set_frame_split(self.h, rank, world_size, C.c_void_p(comm) if comm else None), "sailor_rt_set_frame_split")
+
+    def exchange_light_lists(self, global_grid, global_culled):
+        _lib.check(self.rt.sailor_rt_exchange_light_lists(self.h, global_grid.data_ptr(), global_grid.numel() * global_grid.element_size(),
+                                                          global_culled.data_ptr(), global_culled.numel() * global_culled.element_size()), "sailor_rt_exchange_light_lists")
 
     def process_frame(self) -> int:
         return self.rt.sailor_rt_process_frame(self.h)

@@ -474,3 +474,131 @@ def test_world_description_drives_the_lighting_path():
         assert (err <= 1e-4 * np.abs(ref)).all(), err.max()
     finally:
         rt.close()
+
+
+# ---- split frame: the C++ driver records the band entry points, the exchange goes through the C-ABI over RCCL ------------------------------
+def _single_rank_comm():
+    """an ncclComm_t of ONE rank (the one GPU of the test box), created the way a host engine would: ncclGetUniqueId + ncclCommInitRank"""
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        rccl = C.CDLL("librccl.so")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    return rccl, comm
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_split_frame_bands_through_the_cpp_driver(world):
+    """HipGraphicsDriver::SetFrameSplit: every rank's runtime gets the band's rows of depth / surface and the whole frame's camera; the node-owned
+    SSBOs then hold the band's lists (band-local offsets) bit for bit, the radiance rows the band's pixels."""
+    f = synth.make_frame("tiny", width=320, height=208, lights=synth.LightSetConfig(count=3000, spot_fraction=0.3, radius_scale=5.0))
+    W, H = f.cam.width, f.cam.height
+    Tx, Ty = host.num_tiles(W, H)
+    og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth)
+    ref = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, og, oi, None)
+    rows_seen = 0
+    for rank in range(world):
+        band = host.band_for_rank(W, H, rank, world)
+        r0, r1 = band.fbRowBegin, band.fbRowBegin + band.fbRowCount
+        rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+        try:
+            rt.build_graph(["LightCulling", "RenderScene"])
+            rt.set_frame_split(rank, world)
+            rt.set_camera(f.cam)
+            rt.set_lights(f.lights)
+            depth = torch.from_numpy(np.ascontiguousarray(f.depth[r0:r1])).cuda()
+            surface = torch.from_numpy(np.ascontiguousarray(f.surface[:, r0:r1])).cuda()
+            radiance = torch.zeros((r1 - r0, W, 4), dtype=torch.float32, device="cuda")
+            rt.set_depth(depth)
+            rt.set_surface(surface, radiance)
+            assert rt.process_frame() == 0
+            rt.wait_idle(); torch.cuda.synchronize()
+            bg, bi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(band.tileRowBegin, band.tileRowEnd))
+            tiles = (band.tileRowEnd - band.tileRowBegin) * Tx
+            gp, _ = rt.buffer("lightsGrid"); cp, _ = rt.buffer("culledLights")
+            np.testing.assert_array_equal(read_u32(gp, tiles * 8).reshape(-1, 2), bg)
+            np.testing.assert_array_equal(read_u32(cp, 4 * (1 + int(bi[0]))), bi[: 1 + int(bi[0])])
+            got = radiance.cpu().numpy().astype(np.float64)
+            assert (np.abs(got - ref[r0:r1]) <= 1e-4 * np.abs(ref[r0:r1])).all()
+            rows_seen += r1 - r0
+        finally:
+            rt.close()
+    assert rows_seen == H
+
+
+def test_list_exchange_through_the_c_abi_over_rccl():
+    """sailor_hip_exchange_light_lists / sailor_hip_allgather_u32 / sailor_hip_stitch_light_lists with a real ncclComm_t.  The box has one GPU,
+    so (a) the whole exchange runs with a one-rank communicator through the C++ driver (HipGraphicsDriver::ExchangeLightLists): the global
+    buffers must equal the oracle's; (b) a two-band frame is stitched from two sequentially produced bands: each band's total / segment / grid
+    goes through ncclAllGather (one rank) into ITS slot of the gathered buffers -- what a two-rank all-gather leaves on every rank -- and the
+    stitch must give the oracle's whole-frame buffers bit for bit."""
+    from sailor_amd.forward_plus import ForwardPlus, HipContext, upload_lights
+    f = synth.make_frame("tiny", width=320, height=208, lights=synth.LightSetConfig(count=3000, spot_fraction=0.3, radius_scale=5.0))
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    Tx, Ty = host.num_tiles(W, H)
+    og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth)
+    rccl, comm = _single_rank_comm()
+    try:
+        # (a) C++ driver, one rank
+        rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+        try:
+            rt.build_graph(["LightCulling"])
+            rt.set_frame_split(0, 1, comm.value)
+            rt.set_camera(f.cam); rt.set_lights(f.lights)
+            depth = torch.from_numpy(f.depth).cuda()
+            rt.set_depth(depth)
+            assert rt.process_frame() == 0
+            ggrid = torch.zeros(Tx * Ty * 2, dtype=torch.int32, device="cuda")
+            gcul = torch.zeros(1 + Tx * Ty * 128, dtype=torch.int32, device="cuda")
+            rt.exchange_light_lists(ggrid, gcul)
+            rt.wait_idle(); torch.cuda.synchronize()
+            np.testing.assert_array_equal(ggrid.cpu().numpy().view(np.uint32).reshape(-1, 2), og)
+            np.testing.assert_array_equal(gcul.cpu().numpy().view(np.uint32)[: 1 + int(oi[0])], oi[: 1 + int(oi[0])])
+        finally:
+            rt.close()
+        # (b) two bands, gathered slot by slot over the one-rank communicator, stitched by the C-ABI
+        ctx = HipContext("cuda:0")
+        lib = ctx._lib
+        world = 2
+        max_tiles = ((Ty + world - 1) // world) * Tx
+        seg_cap, grid_cap = max_tiles * 128, max_tiles * 2
+        totals = torch.zeros(world, dtype=torch.int32, device="cuda")
+        segs = torch.zeros(world * seg_cap, dtype=torch.int32, device="cuda")
+        grids = torch.zeros(world * grid_cap, dtype=torch.int32, device="cuda")
+        lights = upload_lights(f.lights, ctx.device)
+        keep = []
+        for r in range(world):
+            band = host.band_for_rank(W, H, r, world)
+            fp = ForwardPlus(ctx, W, H, N, band=band)
+            d = torch.from_numpy(np.ascontiguousarray(f.depth[band.fbRowBegin:band.fbRowBegin + band.fbRowCount])).cuda()
+            fp.cull(f.cam.frame, lights, N, d)
+            seg = torch.zeros(seg_cap, dtype=torch.int32, device="cuda"); seg[: fp.culled.numel() - 1] = fp.culled[1:]
+            gpad = torch.zeros(grid_cap, dtype=torch.int32, device="cuda"); gpad[: fp.band_tiles * 2] = fp.grid[: fp.band_tiles * 2]
+            for src, dst, cnt in ((fp.culled, totals[r:], 1), (seg, segs[r * seg_cap:], seg_cap), (gpad, grids[r * grid_cap:], grid_cap)):
+                _lib.check(lib.sailor_hip_allgather_u32(ctx.handle, comm, src.data_ptr(), dst.data_ptr(), cnt), "sailor_hip_allgather_u32", ctx.handle)
+            keep.append((fp, d, seg, gpad))
+        out_grid = torch.zeros(Tx * Ty * 2, dtype=torch.int32, device="cuda")
+        out_cul = torch.zeros(1 + Tx * Ty * 128, dtype=torch.int32, device="cuda")
+        _lib.check(lib.sailor_hip_stitch_light_lists(ctx.handle, W, H, world, totals.data_ptr(), segs.data_ptr(), seg_cap, grids.data_ptr(), grid_cap,
+                                                     out_grid.data_ptr(), out_cul.data_ptr(), out_cul.numel()), "sailor_hip_stitch_light_lists", ctx.handle)
+        ctx.synchronize()
+        np.testing.assert_array_equal(out_grid.cpu().numpy().view(np.uint32).reshape(-1, 2), og)
+        np.testing.assert_array_equal(out_cul.cpu().numpy().view(np.uint32)[: 1 + int(oi[0])], oi[: 1 + int(oi[0])])
+        # the grid rebase helper gives the same offsets for band 1
+        fp1 = keep[1][0]
+        g1 = fp1.grid.clone()
+        _lib.check(lib.sailor_hip_light_grid_rebase(ctx.handle, g1.data_ptr(), fp1.band_tiles, int(totals[0].item())), "sailor_hip_light_grid_rebase", ctx.handle)
+        ctx.synchronize()
+        t0 = keep[0][0].band_tiles
+        np.testing.assert_array_equal(g1.cpu().numpy().view(np.uint32)[: fp1.band_tiles * 2].reshape(-1, 2), og[t0:])
+        ctx.close()
+    finally:
+        rccl.ncclCommDestroy(comm)
