@@ -102,6 +102,7 @@ int sailor_hip_buffer_free(SailorHipContext* ctx, void* devicePtr)
 int sailor_hip_buffer_upload(SailorHipContext* ctx, void* dstDevice, size_t dstOffset, const void* src, size_t bytes)
 {
     if (!ctx || !dstDevice || (!src && bytes)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     if (!bytes) return SAILOR_HIP_OK;
     // Pageable-source hipMemcpyAsync stages the bytes before returning, i.e. the payload is captured at record time.
     SAILOR_TRY_HIP(ctx, hipMemcpyAsync((char*)dstDevice + dstOffset, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -127,6 +128,7 @@ __global__ void k_fill_u32(uint32_t* dst, uint32_t value, size_t count)
 int sailor_hip_buffer_copy(SailorHipContext* ctx, void* dstDevice, size_t dstOffset, const void* srcDevice, size_t srcOffset, size_t bytes)
 {
     if (!ctx || (bytes && (!dstDevice || !srcDevice))) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     if (bytes == 0) return SAILOR_HIP_OK;
     SAILOR_TRY_HIP(ctx, hipMemcpyAsync((char*)dstDevice + dstOffset, (const char*)srcDevice + srcOffset, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return SAILOR_HIP_OK;
@@ -135,6 +137,7 @@ int sailor_hip_buffer_copy(SailorHipContext* ctx, void* dstDevice, size_t dstOff
 int sailor_hip_buffer_fill_u32(SailorHipContext* ctx, void* dstDevice, size_t dstOffset, uint32_t value, size_t count)
 {
     if (!ctx || !dstDevice || (dstOffset & 3)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     if (!count) return SAILOR_HIP_OK;
     size_t blocks = (count + 255) / 256;
     if (blocks > 2048) blocks = 2048;

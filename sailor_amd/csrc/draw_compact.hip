@@ -2,7 +2,7 @@
 // in-place compaction of its PerInstanceData records by isCulled, and instanceCount = number kept.
 //
 // The shader gives one thread a whole batch and moves 96-byte records one by one.  Here a batch is cut into chunks of 256
-// records; a persistent grid of 256-thread blocks walks the chunks in batch order:
+// records, one 256-thread block per chunk, blocks numbered in batch order:
 //   load    the chunk's 24 KiB of records into LDS with linear float4 requests (fully coalesced),
 //   count   the kept records (ballot + popcount), publish the count,
 //   offset  of the chunk inside its batch by decoupled look-back over the preceding chunks' published counts (one wave looks
@@ -11,12 +11,14 @@
 // In-place safety: a chunk's destination never lies behind its own source, so it can only overlap the sources of chunks at or
 // before it in the same batch.  A chunk publishes only after its records are in LDS, and a chunk that holds a complete
 // look-back has seen a publication of every predecessor -- so every overlapped source has been read before the first store.
+// Forward progress: a block waits only for blocks of a LOWER index, and the dispatcher starts the blocks of a grid in index order,
+// so whoever is waited for is running or done -- no assumption about how many blocks are co-resident (an earlier version walked
+// the chunks with a persistent grid sized from the CU count, which hangs when fewer blocks than assumed fit the device).
 // Records that stay where they are (nothing culled in front of them) are not rewritten, as in the shader (:164).
 #include "common.h"
 
 #define DC_CHUNK 256          // records per chunk = threads per block
 #define DC_REC4 6             // float4 per 96-byte record
-#define DC_BLOCKS_PER_CU 6    // persistent grid: 6 blocks per CU are co-resident (25.1 KB LDS, 256 threads each) -- the look-back spins on them
 
 #define DC_FLAG_AGGREGATE 1ull
 #define DC_FLAG_PREFIX 2ull
@@ -34,7 +36,7 @@ static DrawPlan draw_plan_layout(uint32_t numInstances, uint32_t numBatches)
     L.offCount = o; o = align_up(o + 4ull * numBatches, 256);
     L.offItemOffset = o; o = align_up(o + 4ull * (numBatches + 1ull), 256);
     // sum over batches of ceil(count / 256) <= numInstances / 256 + numBatches when the batches' counts add up to numInstances
-    // (RHI/Batch.hpp:158-159,183); larger sums are still handled, by the grid-stride walk, but need the status slots:
+    // (RHI/Batch.hpp:158-159,183); k4_draw_plan never produces more items than this:
     L.maxItems = numInstances / DC_CHUNK + numBatches + 1;
     L.offItems = o; o = align_up(o + 16ull * L.maxItems, 256);
     L.offStatus = o; o = align_up(o + 8ull * L.maxItems, 256);
@@ -124,7 +126,9 @@ __global__ __launch_bounds__(DC_CHUNK) void k4_draw_compact(float4* __restrict__
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t totalItems = itemOffset[numBatches];
 
-    for (uint32_t item = blockIdx.x; item < totalItems; item += gridDim.x) {
+    const uint32_t item = blockIdx.x;
+    if (item >= totalItems) return;
+    {
         const uint4 desc = items[item];
         const uint32_t first = desc.x, chunk = desc.y, len = desc.z & 0x7FFFFFFFu, b = desc.w;
         const bool lastChunk = (desc.z >> 31) != 0u;
@@ -195,7 +199,6 @@ __global__ __launch_bounds__(DC_CHUNK) void k4_draw_compact(float4* __restrict__
                 }
             }
         }
-        __syncthreads(); // sRec / sMap / sExcl are reused by the next item
     }
 }
 
@@ -211,6 +214,7 @@ int sailor_hip_mesh_cull_compact_ex(SailorHipContext* ctx, const SailorUboFrameD
                                     size_t workspaceBytes, const SailorHiZDesc* hiz)
 {
     if (!ctx || !frame) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     const DrawPlan L = draw_plan_layout(numInstances, numBatches);
     if (numBatches != 0) {
         if (!dInstances || !dBatches || !dWorkspace || ((uintptr_t)dInstances & 15) || ((uintptr_t)dBatches & 3)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
@@ -231,9 +235,7 @@ int sailor_hip_mesh_cull_compact_ex(SailorHipContext* ctx, const SailorUboFrameD
     hipLaunchKernelGGL(k4_draw_items, dim3((L.maxItems + 255) / 256), dim3(256), 0, ctx->stream, numBatches, planFirst, planCount, itemOffset, items,
                        status, L.maxItems);
     SAILOR_CHECK_LAUNCH(ctx, "k4_draw_items");
-    const uint32_t resident = (uint32_t)(ctx->numCUs > 0 ? ctx->numCUs : 1) * DC_BLOCKS_PER_CU; // (a partitioned GPU exposes fewer CUs)
-    const uint32_t blocks = L.maxItems < resident ? L.maxItems : resident;
-    hipLaunchKernelGGL(k4_draw_compact, dim3(blocks), dim3(DC_CHUNK), 0, ctx->stream, (float4*)dInstances, (uint32_t*)dBatches, numBatches, itemOffset,
+    hipLaunchKernelGGL(k4_draw_compact, dim3(L.maxItems), dim3(DC_CHUNK), 0, ctx->stream, (float4*)dInstances, (uint32_t*)dBatches, numBatches, itemOffset,
                        items, status);
     SAILOR_CHECK_LAUNCH(ctx, "k4_draw_compact");
     return SAILOR_HIP_OK;

@@ -434,6 +434,7 @@ int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntities, const Sail
                          float* dWorld, SailorAABB* dWorldAabb, uint64_t* dVisibility)
 {
     if (!ctx || !levelOffsets || !planes) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     if (numEntities == 0) return SAILOR_HIP_OK;
     if (!dTransforms || !dParent || !dLocalAabb || !dWorld || !dWorldAabb || !dVisibility) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (numLevels == 0 || levelOffsets[0] != 0 || levelOffsets[numLevels] != numEntities) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
@@ -465,6 +466,7 @@ int sailor_hip_mesh_cull_flags(SailorHipContext* ctx, const SailorUboFrameData* 
                                uint32_t firstInstanceIndex, const SailorHiZDesc* hiz)
 {
     if (!ctx || !frame) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     if (hiz && (!hiz->pyramid || hiz->width <= 0 || hiz->height <= 0 || hiz->levels <= 0 || hiz->levels > 16)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (numInstances == 0) return SAILOR_HIP_OK;
     if (!dInstances || ((uintptr_t)dInstances & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
@@ -495,6 +497,7 @@ int sailor_hip_csm_caster_masks(SailorHipContext* ctx, uint32_t numEntities, con
                                 uint64_t* dMasks)
 {
     if (!ctx || !cascadePlanes || numCascades == 0 || numCascades > SAILOR_NUM_CSM_CASCADES) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     if (numEntities == 0) return SAILOR_HIP_OK;
     if (!dWorldAabb || !dMasks) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     CascadePlanes P;
@@ -510,6 +513,7 @@ int sailor_hip_csm_caster_masks(SailorHipContext* ctx, uint32_t numEntities, con
 int sailor_hip_hiz_downscale(SailorHipContext* ctx, const float* dSrc, int32_t srcWidth, int32_t srcHeight, float* dDst, int32_t dstWidth, int32_t dstHeight)
 {
     if (!ctx || !dSrc || !dDst || srcWidth <= 0 || srcHeight <= 0 || dstWidth <= 0 || dstHeight <= 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     hipLaunchKernelGGL(k_hiz_downscale, dim3((dstWidth + 31) / 32, (dstHeight + 7) / 8), dim3(256), 0, ctx->stream, dSrc, srcWidth, srcHeight, dDst, dstWidth,
                        dstHeight);
     SAILOR_CHECK_LAUNCH(ctx, "k_hiz_downscale");

@@ -189,6 +189,7 @@ int sailor_hip_equirect_to_cube(SailorHipContext* ctx, const float* dEquirect, i
     if (!ctx || !dEquirect || !dCube || eqWidth <= 0 || eqHeight <= 0 || eqWidth > 32768 || eqHeight > 32768 || size <= 0 || size > 8192)
         return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (((uintptr_t)dEquirect & 15) || ((uintptr_t)dCube & 15) || coverWidth < 0 || coverHeight < 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     const int cw = coverWidth < size ? coverWidth : size, ch = coverHeight < size ? coverHeight : size;
     if (cw == 0 || ch == 0) return SAILOR_HIP_OK;
     hipLaunchKernelGGL(k_equirect_to_cube, dim3((cw + 63) / 64, (ch + 3) / 4, 6), dim3(256), 0, ctx->stream,
@@ -200,6 +201,7 @@ int sailor_hip_equirect_to_cube(SailorHipContext* ctx, const float* dEquirect, i
 int sailor_hip_generate_mipmaps_cube(SailorHipContext* ctx, float* dCube, int32_t size, int32_t levels)
 {
     if (!ctx || !dCube || size <= 0 || size > 8192 || levels <= 0 || levels > 16 || ((uintptr_t)dCube & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     float4* src = (float4*)dCube;
     for (int l = 1; l < levels; l++) {
         const int ss = (size >> (l - 1)) > 1 ? (size >> (l - 1)) : 1, ds = ss > 1 ? ss / 2 : 1;
@@ -215,6 +217,7 @@ int sailor_hip_generate_mipmaps_cube(SailorHipContext* ctx, float* dCube, int32_
 int sailor_hip_compute_irradiance_map(SailorHipContext* ctx, const float* dEnv, int32_t envSize, int32_t envLevels, float* dIrradiance, int32_t size)
 {
     if (!ctx || !dEnv || !dIrradiance || envSize <= 0 || envLevels <= 0 || envLevels > 16 || size <= 0 || size > 4096) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     if (((uintptr_t)dEnv & 15) || ((uintptr_t)dIrradiance & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(k_irradiance_map, dim3(6u * (unsigned)size * (unsigned)size), dim3(256), 0, ctx->stream, (const float4*)dEnv, envSize, envLevels,
                        (float4*)dIrradiance, size);
@@ -232,6 +235,7 @@ static size_t pf_level_offset(int size, int level) // float4 texels in front of 
 int sailor_hip_prefilter_env_level(SailorHipContext* ctx, const float* dRawEnv, float* dEnv, int32_t size, int32_t levels, int32_t level, float roughness)
 {
     if (!ctx || !dRawEnv || !dEnv || size <= 0 || size > 8192 || levels <= 0 || levels > 16 || level < 0 || level >= levels) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     if (((uintptr_t)dRawEnv & 15) || ((uintptr_t)dEnv & 15) || dRawEnv == dEnv) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     const int sz = (size >> level) > 1 ? (size >> level) : 1;
     const unsigned texels = 6u * (unsigned)sz * (unsigned)sz;

@@ -376,6 +376,7 @@ static int raster_depth_launch(SailorHipContext* ctx, const float* lightMatrix, 
 {
     const bool clear = (flags & SAILOR_RASTER_CLEAR) != 0;
     if (!ctx || !lightMatrix || !dDepth || width <= 0 || height <= 0 || width > 32768 || height > 32768) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     if (clear) {
         SAILOR_TRY_HIP(ctx, hipMemsetAsync(dDepth, 0, (size_t)width * height * 4, ctx->stream));
         if (dCoarseDepth)
@@ -414,6 +415,7 @@ int sailor_hip_raster_depth_camera(SailorHipContext* ctx, const SailorUboFrameDa
 int sailor_hip_shadow_resolve(SailorHipContext* ctx, const float* dDepth, int32_t width, int32_t height, int32_t format, void* dShadowMap)
 {
     if (!ctx || !dDepth || !dShadowMap || width <= 0 || height <= 0 || format < 0 || format > 2) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     const size_t texels = (size_t)width * height;
     hipLaunchKernelGGL(k_shadow_resolve, dim3((unsigned)((texels + 255) / 256)), dim3(256), 0, ctx->stream, dDepth, texels, format, dShadowMap);
     SAILOR_CHECK_LAUNCH(ctx, "k_shadow_resolve");

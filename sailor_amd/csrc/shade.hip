@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void k_brdf_lut(float2* __restrict__ lut, int 
 extern "C" int sailor_hip_compute_brdf_lut(SailorHipContext* ctx, float* dLut, int32_t width, int32_t height)
 {
     if (!ctx || !dLut || width <= 0 || height <= 0 || ((uintptr_t)dLut & 7)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     hipLaunchKernelGGL(k_brdf_lut, dim3((unsigned)(((size_t)width * height + 255) / 256)), dim3(256), 0, ctx->stream, (float2*)dLut, width, height);
     SAILOR_CHECK_LAUNCH(ctx, "k_brdf_lut");
     return SAILOR_HIP_OK;

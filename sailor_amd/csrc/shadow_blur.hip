@@ -98,6 +98,7 @@ extern "C" int sailor_hip_evsm_blur_pass(SailorHipContext* ctx, const float* dSr
                                          int32_t radiusPenumbra, int32_t vertical)
 {
     if (!ctx || !dSrc || !dDst || width <= 0 || height <= 0 || radiusUmbra < 0 || radiusPenumbra < 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
     if (((uintptr_t)dSrc & 15) || ((uintptr_t)dDst & 15) || dSrc == dDst) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     const int stepCount = 12;
     const int mx = radiusUmbra > radiusPenumbra ? radiusUmbra : radiusPenumbra;

@@ -27,19 +27,23 @@ Renderer::~Renderer()
 
 RHIBuffer::~RHIBuffer()
 {
-    if (m_hip.m_bOwned && m_hip.m_devicePtr && m_ctx) sailor_hip_buffer_free(m_ctx, m_hip.m_devicePtr);
+    if (m_hip.m_bOwned && m_hip.m_devicePtr && m_ctx) sailor_hip_buffer_free(m_ctx.get(), m_hip.m_devicePtr);
 }
 
 HipGraphicsDriver::HipGraphicsDriver(int deviceOrdinal, void* stream, bool ownStream)
 {
     m_status = sailor_hip_context_create(deviceOrdinal, stream, ownStream ? SAILOR_CTX_OWN_STREAM : 0u, &m_ctx);
+    if (m_ctx) m_ctxOwner = std::shared_ptr<SailorHipContext>(m_ctx, [](SailorHipContext* c) { sailor_hip_context_destroy(c); });
 }
 
 HipGraphicsDriver::~HipGraphicsDriver()
 {
     m_cullWorkspace.Clear();
     m_meshCullWorkspace.Clear();
-    if (m_ctx) sailor_hip_context_destroy(m_ctx);
+    m_exchangeWorkspace.Clear();
+    if (m_ctx) sailor_hip_context_synchronize(m_ctx);
+    m_ctx = nullptr;
+    m_ctxOwner.reset(); // the context itself goes with the last buffer that refers to it
 }
 
 void HipGraphicsDriver::WaitIdle() { if (m_ctx) sailor_hip_context_synchronize(m_ctx); }
@@ -49,7 +53,7 @@ RHICommandListPtr HipGraphicsDriver::CreateCommandList(bool) { return RHICommand
 RHIBufferPtr HipGraphicsDriver::CreateBuffer(size_t size)
 {
     auto b = RHIBufferPtr::Make();
-    b->m_ctx = m_ctx;
+    b->m_ctx = m_ctxOwner;
     b->m_size = size;
     if (!m_ctx || sailor_hip_buffer_create(m_ctx, size, &b->m_hip.m_devicePtr) != SAILOR_HIP_OK) return RHIBufferPtr();
     b->m_hip.m_bOwned = true;
@@ -59,7 +63,7 @@ RHIBufferPtr HipGraphicsDriver::CreateBuffer(size_t size)
 RHIBufferPtr HipGraphicsDriver::WrapBuffer(void* devicePtr, size_t size)
 {
     auto b = RHIBufferPtr::Make();
-    b->m_ctx = m_ctx;
+    b->m_ctx = m_ctxOwner;
     b->m_size = size;
     b->m_hip.m_devicePtr = devicePtr;
     b->m_hip.m_bOwned = false;

@@ -16,6 +16,7 @@
 //   "Shaders/ShadowCaster.shader" [EVSM]  -> sailor_hip_raster_depth into the pass' depth attachment, and at EndRenderPass sailor_hip_shadow_resolve
 //                                            into its colour attachment (push constant lightMatrix, set 1 `data`, vertex positions, 32-bit indices)
 #pragma once
+#include <memory>
 #include "../../RHI/GraphicsDriver.h"
 
 namespace Sailor::GraphicsDriver::HIP {
@@ -99,7 +100,8 @@ private:
     int RecordLinearizeDepth(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const RHI::RHITexturePtr& target);
     int RecordEvsmBlur(const TVector<RHI::RHIShaderBindingSetPtr>& bindings, const RHI::RHITexturePtr& target, bool vertical);
 
-    SailorHipContext* m_ctx = nullptr;
+    SailorHipContext* m_ctx = nullptr;              // == m_ctxOwner.get(): what the C-ABI calls take
+    std::shared_ptr<SailorHipContext> m_ctxOwner;   // destroyed with the last buffer that still refers to it
     int m_status = 0;
     int m_lastDispatchStatus = 0;
     RHI::RHIBufferPtr m_cullWorkspace;

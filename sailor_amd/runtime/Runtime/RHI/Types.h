@@ -3,6 +3,7 @@
 // UboFrameData), RHI/Buffer.h, RHI/Shader.h, RHI/CommandList.h -- with an `m_hip` member where the reference's classes
 // carry `m_vulkan` (RHI/Shader.h:17-27,71-76, RHI/Buffer.h:15-24, RHI/CommandList.h:15-20).
 #pragma once
+#include <memory>
 #include <atomic>
 #include <cstdint>
 #include <cstring>
@@ -66,7 +67,9 @@ public:
     struct { void* m_devicePtr = nullptr; bool m_bOwned = false; } m_hip;
     size_t m_size = 0;
     ~RHIBuffer() override;
-    SailorHipContext* m_ctx = nullptr;
+    // The context the allocation belongs to, shared with the driver that made it: a buffer (or a texture / binding holding one) may outlive
+    // the driver object, and the context is destroyed by whoever lets go of it last.
+    std::shared_ptr<SailorHipContext> m_ctx;
 };
 using RHIBufferPtr = TRefPtr<RHIBuffer>;
 
