@@ -107,18 +107,63 @@ def side_ms(fn, steps):
 
 
 def measured_traffic(kernel: str, config: str, world: int):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01/traffic.json: separate
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/<latest round>/traffic[_<config>].json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes).
     bench.py cannot sample PMC counters itself; None when no matching profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t.get("config") == config and world == 1:
-            return t["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    prof = os.path.join(ROOT, "profiles")
+    rounds = sorted((d for d in os.listdir(prof) if d.startswith("r") and d[1:].isdigit()), reverse=True) if os.path.isdir(prof) else []
+    for r in rounds:
+        for name in ("traffic.json", f"traffic_{config}.json"):
+            try:
+                with open(os.path.join(prof, r, name)) as f:
+                    t = json.load(f)
+                if t.get("config") == config and world == 1:
+                    return t["kernels"][kernel]["hbm_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
     return None
+
+
+def csm_distinct_texels(frame, shadows, surface_pos: np.ndarray, normals: np.ndarray):
+    """D_c of SURVEY.md 8(d): the number of DISTINCT texels that the K3 lookups of the frame's directional lights fetch in cascade c (EVSM: one
+    bilinear 2 x 2 footprint in cascade 0; PCF: sixteen of them) -- the algorithmic bytes of K3 are 256 + sum_c b_c D_c with b_0 = 16, b_1..3 = 2.
+    Vectorised restatement of the lookups' addressing only (Standard.shader:266-283, Lighting.glsl:168-216, 242-284), float32 like the kernel."""
+    fb = np.frombuffer(bytes(frame.cam.frame), np.uint8)
+    view = fb[:64].view(np.float32).reshape(4, 4).astype(np.float32)            # view[c][r]
+    z_far = float(fb[216:224].view(np.float32)[1])
+    levels = np.float32([0.05, 0.1, 0.333333, 0.5]) * np.float32(z_far)
+    poisson = np.float32([(-0.94201624, -0.39906216), (0.94558609, -0.76890725), (-0.094184101, -0.92938870), (0.34495938, 0.29387760),
+                          (-0.91588581, 0.45771432), (-0.81544232, -0.87912464), (-0.38277543, 0.27676845), (0.97484398, 0.75648379),
+                          (0.44323325, -0.97511554), (0.53742981, -0.47373420), (-0.26496911, -0.41893023), (0.79197514, 0.19090188),
+                          (-0.24188840, 0.99706507), (-0.81409955, 0.91437590), (0.19984126, 0.78641367), (0.14383161, -0.14100790)])
+    directional = [l for l in frame.lights if int(l["type"]) == 0]
+    sizes = [(m.shape[1], m.shape[0]) for m in shadows.maps]
+    seen = [np.zeros(h * w, bool) for (w, h) in sizes]
+    P = surface_pos.reshape(-1, 3).astype(np.float32)
+    for light in directional:
+        pz_view = (P @ view[:3, 2] + view[3, 2]) / (P @ view[:3, 3] + view[3, 3])
+        cascade = np.minimum(np.searchsorted(levels, np.abs(pz_view), side="right"), 3)
+        for c in range(4):
+            sel = np.nonzero(cascade == c)[0]
+            if sel.size == 0:
+                continue
+            M = shadows.lights_matrices[c].reshape(4, 4).astype(np.float32)        # M[col][row]
+            q = P[sel] @ M[:3, :] + M[3, :]
+            px = (q[:, 0] / q[:, 3]) * np.float32(0.5) + np.float32(0.5)
+            py = np.float32(1.0) - ((q[:, 1] / q[:, 3]) * np.float32(0.5) + np.float32(0.5))
+            pz = q[:, 2] / q[:, 3]
+            evsm = int(light["shadowType"]) == 2 and c == 0
+            inside = (px <= 1) & (py <= 1) & (px >= 0) & (py >= 0) & ((pz >= 0) if evsm else (pz * np.float32(0.5) + np.float32(0.5) >= 0.5))
+            px, py = px[inside], py[inside]
+            w, h = sizes[c]
+            taps = [(np.float32(0), np.float32(0))] if evsm else [(poisson[i, 0] * 2 / np.float32(w), poisson[i, 1] * 2 / np.float32(h)) for i in range(16)]
+            for ox, oy in taps:
+                x = (px + ox) * np.float32(w) - np.float32(0.5); y = (py + oy) * np.float32(h) - np.float32(0.5)
+                x0 = np.floor(x).astype(np.int64); y0 = np.floor(y).astype(np.int64)
+                for dx in (0, 1):
+                    for dy in (0, 1):
+                        seen[c][np.clip(y0 + dy, 0, h - 1) * w + np.clip(x0 + dx, 0, w - 1)] = True
+    return [int(m.sum()) for m in seen]
 
 
 def cpu_baseline(frame, sample_rows: int):
@@ -672,6 +717,14 @@ def main():
     distinct = int(len(np.unique(idx[1:]))) if sum_nt else 0
     band_pixels = band.fbRowCount * W
     b_shade = 64 * band_pixels + 8 * fp.band_tiles + 4 * sum_nt + 112 * distinct
+    csm_info = None
+    if csm is not None:   # K3 add-on: 256 B of matrices + b_c bytes per DISTINCT texel fetched in cascade c (b_0 = 16 RGBA32F, b_1..3 = 2 R16F)
+        surf_host = frame.surface_rows(rows.start, rows.stop)
+        d_c = csm_distinct_texels(frame, shadows, surf_host[0, :, :, :3], surf_host[1, :, :, :3])
+        b_csm = 256 + 16 * d_c[0] + 2 * (d_c[1] + d_c[2] + d_c[3])
+        b_shade += b_csm
+        csm_info = {"distinct_texels_per_cascade": d_c, "bytes": b_csm}
+        del surf_host
     b_cull = 20 * N + 4 * band_pixels + 8 * fp.band_tiles + 4 * sum_nt + 4
     evals = int((g[:, 1].astype(np.int64) * 256).sum())
     shade_gbs = b_shade / (shade_batch_ms * 1e-3) / 1e9
@@ -686,6 +739,7 @@ def main():
                 "frac_of_measured_copy_peak": shade_gbs / HBM_COPY_GBS,
                 "valu_sidebar": {"pixel_light_evals": evals, "gevals_per_s": evals / (shade_batch_ms * 1e-3) / 1e9,
                                  "note": "~110 fp32 ops per (pixel,light): VALU-bound once mean list length exceeds ~10 (SURVEY.md 7, hard part 2)"},
+                "csm": csm_info,
                 "cull": {"kernels": "k01_prepare+k1_*", "avg_ms": cull_batch_ms, "isolated_avg_ms": cull_ms[0], "isolated_median_ms": cull_ms[1], "bytes": b_cull,
                          "achieved_gbs": b_cull / (cull_batch_ms * 1e-3) / 1e9, "frac": b_cull / (cull_batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 

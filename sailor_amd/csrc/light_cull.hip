@@ -42,7 +42,8 @@
 #include "common.h"
 #include <vector>
 
-#define BANDS_PER_BLOCK 24   // group columns / rows whose masks one light block of k01_prepare builds
+#define BANDS_PER_BLOCK 24   // group columns / rows whose masks one light block of k01_prepare builds when the lights alone do not fill the chip
+#define MAX_BANDS_PER_BLOCK 256 // ... and at most (LDS for their planes); with >= 1024 light blocks a block builds all of its lights' masks
 #define QCAP 128             // LDS candidate queue of the overflow path of k1_tile_cull (ring buffer: < 64 pending + <= 64 new)
 #define GROUP 4              // k1_group_lists: tiles per group edge (4x4 tiles share one candidate list)
 #define CAPG 2048            // entries per group list; a denser group falls back to walking the masks per tile
@@ -162,7 +163,7 @@ struct PrepareArgs {
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void k0_lights(const int lb, unsigned char* __restrict__ lds, const PrepareArgs& a)
 {
-    float4* sPl = reinterpret_cast<float4*>(lds); // [2 * BANDS_PER_BLOCK]
+    float4* sPl = reinterpret_cast<float4*>(lds); // [2 * bandsPerBlock]
     const int wordBlock = lb % a.lightBlocks, split = lb / a.lightBlocks;
     const int b0 = split * a.bandsPerBlock;
     const int nb = min(a.bandsPerBlock, a.numBands - b0); // <= 0: no pre-filter (brute-force walk)
@@ -324,7 +325,7 @@ __device__ __forceinline__ void k1_tile_frusta(const int block, const PrepareArg
     o2[4] = f.n[3][0]; o2[5] = f.n[3][1]; o2[6] = f.n[3][2];
 }
 
-#define LDS_K01_PREPARE (2 * BANDS_PER_BLOCK * 16)
+#define LDS_K01_PREPARE (2 * MAX_BANDS_PER_BLOCK * 16)
 __global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K01_PREPARE];
@@ -940,7 +941,10 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
     pa.N = N; pa.words = L.words;
     pa.lightBlocks = (N + 255) / 256;
     pa.numBands = brute ? 0 : L.numBands;
-    const int splits = brute ? 1 : (L.numBands + BANDS_PER_BLOCK - 1) / BANDS_PER_BLOCK;
+    // Few lights: the bands are spread over several blocks per 256 lights (parallelism; every block repeats the cheap transform).  Many lights
+    // (the 1 M of configs[4]): the light blocks fill the chip by themselves, and repeating the 112-byte record reads per split is what costs.
+    const int perBlock = pa.lightBlocks >= 1024 ? MAX_BANDS_PER_BLOCK : BANDS_PER_BLOCK;
+    const int splits = brute ? 1 : (L.numBands + perBlock - 1) / perBlock;
     pa.bandsPerBlock = brute ? 0 : (L.numBands + splits - 1) / splits; // the bands spread evenly over the splits
     pa.lightRoleBlocks = pa.lightBlocks * splits;
     pa.stripsPerRow = (L.Tx + 16 * SETUP_STRIPS - 1) / (16 * SETUP_STRIPS);

@@ -91,6 +91,24 @@ __constant__ float kPoissonDisk[16][2] = { // Lighting.glsl:176-185
     { -0.24188840f, 0.99706507f }, { -0.81409955f, 0.91437590f }, { 0.19984126f, 0.78641367f }, { 0.14383161f, -0.14100790f }
 };
 
+// One bilinear footprint of an R16F map: the two texels of a footprint row are neighbours, so each row is ONE 4-byte request (x1 = x0 + 1
+// unless the footprint is clamped at the left / right edge; the pair is then read at the nearest in-row position and the halves are
+// selected).  Same texels, same lerp2 as sample_r: same bits.
+__device__ __forceinline__ float sample_r16_pairs(const __half* __restrict__ map, int W, int H, float u, float v)
+{
+    const BilinearTaps t = bilinear_taps(W, H, u, v);
+    const int base = min(t.x0, W - 2);
+    typedef uint32_t __attribute__((aligned(2))) u32_a2;
+    const uint32_t r0 = *reinterpret_cast<const u32_a2*>(map + (size_t)t.y0 * W + base);
+    const uint32_t r1 = *reinterpret_cast<const u32_a2*>(map + (size_t)t.y1 * W + base);
+    const bool lo0 = t.x0 == base, lo1 = t.x1 == base;
+    const float a00 = __half2float(__ushort_as_half((unsigned short)(lo0 ? r0 & 0xFFFFu : r0 >> 16)));
+    const float a10 = __half2float(__ushort_as_half((unsigned short)(lo1 ? r0 & 0xFFFFu : r0 >> 16)));
+    const float a01 = __half2float(__ushort_as_half((unsigned short)(lo0 ? r1 & 0xFFFFu : r1 >> 16)));
+    const float a11 = __half2float(__ushort_as_half((unsigned short)(lo1 ? r1 & 0xFFFFu : r1 >> 16)));
+    return lerp2(a00, a10, a01, a11, t.ax, t.ay);
+}
+
 // Lighting.glsl:242-261 ShadowCalculation_Pcf + :168-197 ManualPCF
 __device__ float shadow_pcf(const void* __restrict__ map, int fmt, int W, int H, float4 lp, float bias)
 {
@@ -100,6 +118,23 @@ __device__ float shadow_pcf(const void* __restrict__ map, int fmt, int W, int H,
     if (px > 1.0f || py > 1.0f || px < 0.0f || py < 0.0f || pz < 0.5f) return 1.0f;
     const float tsx = 1.0f / (float)W, tsy = 1.0f / (float)H;
     float shadow = 0.0f;
+    if (fmt == SAILOR_SHADOWMAP_R16_SFLOAT && W >= 2) {
+        // the cascades' own format (ECS/LightingECS.h:57-58): 2 requests per tap, 8 taps = 16 requests in flight (the wave is bound by the
+        // round trips of its scattered texel reads, not by arithmetic)
+        const __half* m16 = reinterpret_cast<const __half*>(map);
+#pragma unroll 1
+        for (int i0 = 0; i0 < 16; i0 += 8) {
+            float d[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float ox = kPoissonDisk[i0 + j][0] * 2.0f * tsx, oy = kPoissonDisk[i0 + j][1] * 2.0f * tsy;
+                d[j] = sample_r16_pairs(m16, W, H, px + ox, py + oy) * 0.5f + 0.5f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) shadow += (pz + bias > d[j]) ? 1.0f : 0.0f;
+        }
+        return shadow / 16.0f;
+    }
 #pragma unroll 1
     for (int i = 0; i < 16; i++) {
         const float ox = kPoissonDisk[i][0] * 2.0f * tsx, oy = kPoissonDisk[i][1] * 2.0f * tsy;

@@ -306,3 +306,31 @@ def test_non_finite_terms_propagate_like_the_reference(ctx):
     fin = np.isfinite(ref)
     err = np.abs(got[fin].astype(np.float64) - ref[fin])
     assert (err <= RTOL * np.abs(ref[fin]) + atol_of(ref[..., :3])).all(), err.max()
+
+
+def test_c5_shade_8k(ctx):
+    """BASELINE.json configs[4] on one GPU: 7680 x 4320, 1 048 576 lights.  Full-size properties -- finite everywhere, alpha passed through, exact
+    doubling under doubled intensities (power-of-two scaling commutes with every rounding) -- and one tile row (16 framebuffer rows x 7 680
+    pixels) against the oracle on the oracle's own lists, plus one that changes with the date."""
+    f = synth.make_frame("C5")
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    assert (W, H, N) == (7680, 4320, 1 << 20)
+    a, fp = gpu_frame(ctx, f)
+    assert np.isfinite(a).all()
+    np.testing.assert_array_equal(a[..., 3], f.surface[0, ..., 3])
+    g, idx = fp.lists_to_host()
+    lit = a[..., :3].max(-1) > 0
+    assert 0.2 < lit.mean() <= 1.0
+    f2 = synth.Frame(f.name, f.cam, f.depth, f.lights.copy(), f.surface, None)
+    f2.lights["intensity"] *= 2.0
+    b, _ = gpu_frame(ctx, f2)
+    np.testing.assert_array_equal(b[..., :3], 2.0 * a[..., :3])
+    del b, f2
+    for tr0 in (131, daily_tile_row(270, 131)):
+        og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(tr0, tr0 + 1))
+        np.testing.assert_array_equal(g[tr0 * 480:(tr0 + 1) * 480, 1], og[:, 1])
+        grid = np.zeros((480 * 270, 2), np.uint32); grid[:, 0] = 1
+        grid[tr0 * 480:(tr0 + 1) * 480] = og
+        r0, r1 = H - 16 * (tr0 + 1), H - 16 * tr0
+        ref = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, grid, oi, None, rows=(r0, r1))
+        assert_radiance_close(a[r0:r1], ref[r0:r1])
