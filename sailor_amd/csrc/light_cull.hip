@@ -607,7 +607,10 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     const float4* __restrict__ lightView = a.lightView;
     const uint32_t* __restrict__ lightType = a.lightType;
     const int N = a.N, Tx = a.Tx, groupsX = a.groupsX;
-    const int b = (int)blockIdx.x;                       // == tile-index order: (tile row, group column)
+    // slot == block index == tile-index order: (tile row, group column).  (Measured: handing every XCD -- block i runs on XCD i % 8 -- a contiguous
+    // eighth of the slots, so that a group's four row blocks share one L2 and an XCD's gathers stay inside the lights of its band: 44 us instead of
+    // 32 -- the cluster groups all land on one XCD.)
+    const int b = (int)blockIdx.x;
     const int gx = b % groupsX, tyLocal = b / groupsX;
     const int g = (tyLocal / GROUP) * groupsX + gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
