@@ -265,7 +265,7 @@ struct ShadeLds {
     float4 sL[KEEP * LREC];
     float sRes[3 * PENDK * 256];
     uint16_t sQ[4 * QMAX];
-    uint32_t sNum;
+    uint32_t sEnd[4];
 };
 #define ROLE_TILE 0       // one block per tile, grid (tiles per row, tile rows)
 #define ROLE_BAND_TILE 1  // the same inside k2_shade_band: returns at once on a tile of the split blocks
@@ -279,7 +279,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     float4* const sL = lds.sL;
     float* const sRes = lds.sRes;
     uint16_t* const sQ = lds.sQ;
-    uint32_t& sNum = lds.sNum;
+    uint32_t* const sEnd = lds.sEnd;
     constexpr bool BAND = ROLE != ROLE_TILE;
     constexpr bool splitRole = ROLE == ROLE_BAND_SPLIT;
     int tid = threadIdx.x;
@@ -302,49 +302,28 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const bool active = gx < A.W && py >= 0;
     const size_t pix = active ? ((size_t)(py - A.fbRow0) * A.W + gx) : 0;
 
-    SailorLightsGrid g;
-    // issue the surface loads first -- unconditionally (lanes outside the frame read pixel 0 of the band and are masked
-    // out of every ballot and of the store), so that nothing waits on them before the list staging below is under way
+    // Prologue, ordered by what waits for what.  The list is a chain of three dependent round trips (grid entry -> culledLights indices -> light
+    // records), the surface is one; a wave that sits through them one after the other spends a third of its life waiting.  So: the grid entry
+    // (a scalar load) and the surface loads go out together; the list indices follow as soon as the grid entry is there; the per-pixel
+    // invariants -- which wait for the surface only -- are computed while the light records are in flight; and the workgroup barrier that
+    // publishes the staged records waits for LDS only, not for outstanding global loads.
+    const SailorLightsGrid g = grid[bandTile]; // Standard.shader:422-423
+    // unconditional surface loads (lanes outside the frame read pixel 0 of the band and are masked out of every ballot and of the store)
     const float4 P0 = surface[pix];
     const float4 P1 = surface[planeStride + pix];
     const float4 P2 = surface[2 * planeStride + pix];
-
-    g = grid[bandTile]; // Standard.shader:422-423
-    if (BAND && !splitRole && g.num >= (uint32_t)SPLIT_MIN) return; // a tile of the split blocks
+    if (ROLE == ROLE_BAND_TILE && g.num >= (uint32_t)SPLIT_MIN) return; // a tile of the split blocks
     const uint32_t listNum = g.num < (uint32_t)KEEP ? g.num : (uint32_t)KEEP;
-    if (tid == 0) sNum = listNum;
-    __syncthreads();
-    if (tid < listNum) {
-        const uint32_t index = culled[g.offset + tid];
-        if (index >= (uint32_t)A.lightsNum) {
-            atomicMin(&sNum, tid); // Standard.shader:430-433 "index == uint(-1) -> break" (and out-of-range guard)
-        } else {
-            const float4* L = reinterpret_cast<const float4*>(lights + index);
-            const float4 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3], q4 = L[4], q5 = L[5], q6 = L[6];
-            const uint32_t type = __float_as_uint(q0.x), shadowType = __float_as_uint(q0.y);
-            const float ndx = -q2.x, ndy = -q2.y, ndz = -q2.z;            // Li = -light.direction (:309)
-            const float len = sqrtf(dot3f(ndx, ndy, ndz, ndx, ndy, ndz)); // normalize(-light.direction) (:298)
-            const float linv = 1.0f / len;
-            // A zero factor only annihilates a FINITE product (inf * 0 = NaN in the reference): lights with a non-finite
-            // intensity are never skipped.
-            const bool finite = fabsf(q3.x) < __builtin_inff() && fabsf(q3.y) < __builtin_inff() && fabsf(q3.z) < __builtin_inff();
-            // Conservative "out of reach" threshold of a point light: d^2 > r^2 (1 + 1e-5) => fl(dist / r) >= 1 => the radius
-            // window (:290) is exactly 0.  Only for r > 0 (a negative radius clamps to the FULL window in the reference).
-            const float r = q6.x;
-            float a = __builtin_inff(), b = r;
-            if (type == 1u) { if (finite && r > 0.0f) a = (r * r) * 1.00001f; }
-            else { if (finite) a = -(q5.y - 1e-5f); b = q5.x - q5.y; }
-            const uint32_t bits = (type < 255u ? type : 255u) | ((shadowType < 255u ? shadowType : 255u) << 8) | (finite ? 0x10000u : 0u);
-            float4* o = sL + tid * LREC;
-            o[0] = make_float4(q1.x, q1.y, q1.z, a);
-            o[1] = make_float4(ndx * linv, ndy * linv, ndz * linv, __uint_as_float(bits));
-            o[2] = make_float4(q4.x, q4.y, q4.z, b);
-            o[3] = make_float4(ndx, ndy, ndz, q5.y);
-            o[4] = make_float4(q3.x, q3.y, q3.z, 0.0f);
-        }
+    const bool haveLight = (uint32_t)tid < listNum;
+    uint32_t index = 0xFFFFFFFFu;
+    if (haveLight) index = culled[g.offset + tid];
+    // Standard.shader:430-433 "index == uint(-1) -> break" (and out-of-range guard): the list ends at the first such slot
+    const bool staged = haveLight && index < (uint32_t)A.lightsNum;
+    float4 q0, q1, q2, q3, q4, q5, q6;
+    if (staged) {
+        const float4* L = reinterpret_cast<const float4*>(lights + index);
+        q0 = L[0]; q1 = L[1]; q2 = L[2]; q3 = L[3]; q4 = L[4]; q5 = L[5]; q6 = L[6];
     }
-    __syncthreads();
-    const uint32_t numLights = sNum;
 
     // ---- per-pixel invariants (Standard.shader:379-401) ----
     const float wx = P0.x, wy = P0.y, wz = P0.z;
@@ -361,6 +340,34 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const float F0y = fmaf(P2.y, metallic, 0.04f * oneMinusMetal);
     const float F0z = fmaf(P2.z, metallic, 0.04f * oneMinusMetal);
     const float kdAx = oneMinusMetal * P2.x, kdAy = oneMinusMetal * P2.y, kdAz = oneMinusMetal * P2.z; // kd = (1 - F)(1 - metallic)
+    {
+        const unsigned long long bad = __ballot(haveLight && !staged);
+        if (lane == 0) sEnd[wave] = bad ? (uint32_t)(wave * 64 + __builtin_ctzll(bad)) : 0xFFFFFFFFu;
+    }
+    if (staged) {
+        const uint32_t type = __float_as_uint(q0.x), shadowType = __float_as_uint(q0.y);
+        const float ndx = -q2.x, ndy = -q2.y, ndz = -q2.z;            // Li = -light.direction (:309)
+        const float len = sqrtf(dot3f(ndx, ndy, ndz, ndx, ndy, ndz)); // normalize(-light.direction) (:298)
+        const float linv = 1.0f / len;
+        // A zero factor only annihilates a FINITE product (inf * 0 = NaN in the reference): lights with a non-finite
+        // intensity are never skipped.
+        const bool finite = fabsf(q3.x) < __builtin_inff() && fabsf(q3.y) < __builtin_inff() && fabsf(q3.z) < __builtin_inff();
+        // Conservative "out of reach" threshold of a point light: d^2 > r^2 (1 + 1e-5) => fl(dist / r) >= 1 => the radius
+        // window (:290) is exactly 0.  Only for r > 0 (a negative radius clamps to the FULL window in the reference).
+        const float r = q6.x;
+        float ra = __builtin_inff(), rb = r;
+        if (type == 1u) { if (finite && r > 0.0f) ra = (r * r) * 1.00001f; }
+        else { if (finite) ra = -(q5.y - 1e-5f); rb = q5.x - q5.y; }
+        const uint32_t bits = (type < 255u ? type : 255u) | ((shadowType < 255u ? shadowType : 255u) << 8) | (finite ? 0x10000u : 0u);
+        float4* o = sL + tid * LREC;
+        o[0] = make_float4(q1.x, q1.y, q1.z, ra);
+        o[1] = make_float4(ndx * linv, ndy * linv, ndz * linv, __uint_as_float(bits));
+        o[2] = make_float4(q4.x, q4.y, q4.z, rb);
+        o[3] = make_float4(ndx, ndy, ndz, q5.y);
+        o[4] = make_float4(q3.x, q3.y, q3.z, 0.0f);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the records are in LDS (global loads may stay in flight)
+    const uint32_t numLights = min(min(listNum, sEnd[0]), min(sEnd[1], min(sEnd[2], sEnd[3])));
     const float alpha = roughness * roughness, alphaSq = alpha * alpha;
     const float rr = roughness + 1.0f, k = (rr * rr) * 0.125f, oneMinusK = 1.0f - k;
     const float g1Lo = cosLo * rcp_fast(fmaf(cosLo, oneMinusK, k)); // GeometrySchlickG1(cosLo, k)
