@@ -1,4 +1,5 @@
 #include "HipGraphicsDriver.h"
+#include <dlfcn.h>
 #include "../../RHI/Renderer.h"
 
 #include <cstdio>
@@ -232,8 +233,33 @@ RHIShaderBindingPtr HipGraphicsDriver::AddShaderBinding(RHIShaderBindingSetPtr& 
     return b;
 }
 
-void HipGraphicsDriver::BeginDebugRegion(RHICommandListPtr cmdList, const std::string& title) { cmdList->m_debugRegions.push_back(title); }
-void HipGraphicsDriver::EndDebugRegion(RHICommandListPtr) {}
+// Debug regions (RHI/GraphicsDriver.h:238-239; the Vulkan backend turns them into vkCmdBeginDebugUtilsLabelEXT): here roctx ranges with the
+// reference's own region names ("LightCulling", LightCullingNode.cpp:37,80; "RenderScene QueueTag:..." ...), pushed / popped when the
+// command list is replayed, so that a rocprofv3 --marker-trace shows the kernels of a node inside the node's range.  libroctx64 is bound
+// lazily: without it the regions are only kept on the command list.
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        void* h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) { push = (int (*)(const char*))dlsym(h, "roctxRangePushA"); pop = (int (*)())dlsym(h, "roctxRangePop"); }
+    }
+};
+const Roctx& roctx() { static Roctx r; return r; }
+} // namespace
+
+void HipGraphicsDriver::BeginDebugRegion(RHICommandListPtr cmdList, const std::string& title)
+{
+    cmdList->m_debugRegions.push_back(title);
+    cmdList->m_hip.m_commands.push_back([title]() { if (roctx().push) roctx().push(title.c_str()); return (int)SAILOR_HIP_OK; });
+}
+void HipGraphicsDriver::EndDebugRegion(RHICommandListPtr cmdList)
+{
+    cmdList->m_hip.m_commands.push_back([]() { if (roctx().pop) roctx().pop(); return (int)SAILOR_HIP_OK; });
+}
 void HipGraphicsDriver::ImageMemoryBarrier(RHICommandListPtr, RHITexturePtr, EImageLayout) {} // one in-order stream: nothing to do
 
 bool HipGraphicsDriver::BlitImage(RHICommandListPtr cmd, RHITexturePtr src, RHITexturePtr dst, ivec4 srcRegionRect, ivec4 dstRegionRect)
