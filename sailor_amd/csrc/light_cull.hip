@@ -588,6 +588,17 @@ __device__ __forceinline__ void test_staged(const TileCtx& t, const uint32_t cn,
 }
 
 #define LDS_K1_TILE_CULL (CHUNK * 16 + CHUNK * 4 + 4 * CAND * 4 + 4 * CAND * 4)
+// make EXTRA=-DCULL_PROF + scripts/cull_prof.py: per-block phase times (s_memtime; comparable within a block only -- the counter is per XCD)
+#ifdef CULL_PROF
+__device__ unsigned long long g_cullProf[65536][4];
+extern "C" __attribute__((visibility("default"))) int sailor_hip_debug_read_cull_prof(void* dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_cullProf), bytes);
+}
+#define PROF_T(i) if (threadIdx.x == 0 && blockIdx.x < 65536) g_cullProf[blockIdx.x][i] = __builtin_amdgcn_s_memtime()
+#else
+#define PROF_T(i)
+#endif
 template <bool BRUTE>
 __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
 {
@@ -611,6 +622,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     // eighth of the slots, so that a group's four row blocks share one L2 and an XCD's gathers stay inside the lights of its band: 44 us instead of
     // 32 -- the cluster groups all land on one XCD.)
     const int b = (int)blockIdx.x;
+    PROF_T(0);
     const int gx = b % groupsX, tyLocal = b / groupsX;
     const int g = (tyLocal / GROUP) * groupsX + gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -710,7 +722,9 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     const uint32_t n = count < CAND ? count : CAND;   // 0 for a wave beyond the last tile column
     const uint32_t num = n < KEEP ? n : KEEP;
     if (lane == 0) sNum[wave] = num;
+    PROF_T(1);
     __syncthreads(); // every wave's candidates are in LDS, the four list lengths are known
+    PROF_T(2);
     uint32_t before = 0u, total = 0u, cls = 0u; // entries of the block's earlier tiles / of the whole block; its class A << 16 | class B tiles
 #pragma unroll
     for (int w = 0; w < 4; w++) {
@@ -727,6 +741,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     if (lane == 0) a.tileNum[bandTile] = num;
     // the block's four lists back to back in its staging slot: k1_pack moves the slot as one contiguous run
     emit_list(t, n, sIdx, sImp, lightView, a.staging + (size_t)b * SLOT + before);
+    PROF_T(3);
 }
 
 // ------------------------------------------------------------------------------------------------------------
