@@ -341,6 +341,10 @@ __device__ __forceinline__ uint64_t lanemask_lt()
     return lane == 0 ? 0ull : (~0ull >> (64 - lane));
 }
 
+// LDS hand-off between the lanes of ONE wave: the wave's DS operations execute in order, so only the compiler has to be
+// told not to move accesses across this point (and to wait for outstanding DS results).
+#define WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
+
 // ------------------------------------------------------------------------------------------------------------
 // K1b2: candidate lists of 4x4-tile groups.  One 256-thread block per group ANDs the masks of the group's column and
 // row (256 words = 16 384 lights per step) and writes the set bits -- ascending light index -- as a
@@ -418,6 +422,124 @@ __global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* 
     if (threadIdx.x == 0) groupCount[g] = base > CAPG ? GROUP_OVERFLOW : base;
 }
 
+// The same lists for LARGE light sets (>= 4 096 mask words: C5's million lights = 16 384 words per band, ~420 candidates per group, 97 % of the
+// AND's words empty).  The kernel above takes 152 us there and is bound by vector-instruction issue: every round of 1 024 words pays a block-wide
+// scan and, because a handful of its 256 threads do hold a candidate, the whole divergent bit loop (64-bit ctz / clear-lowest / shifts and the
+// store's address arithmetic: ~50 of the ~63 instructions a 128-word row costs a wave; measured with SQ counters on three rewrites that kept
+// that shape and all ran 152-167 us -- fewer bytes, prefetching and DPP scans changed nothing).  So the two halves are separated:
+//   * one wave per group walks all the words of its column's mask in rows of 128 (two words per lane, one coalesced 16-byte load per row),
+//     ANDs them with the row band's mask and only QUEUES the non-empty words -- word index + bits, in word order, by ballot + mbcnt -- in LDS;
+//   * whenever 64 words are queued, the wave turns to them one LANE per WORD: one DPP prefix sum over the 64 popcounts gives every word its
+//     output position, and the bit loop runs with all lanes busy (~8 such batches per group instead of 128 near-empty ones).
+// A block takes four column-adjacent groups of a group row, one wave each: the row band's mask -- the same for the four -- is fetched once per
+// block (each wave loads one row of every step of four) and handed round through LDS, 160 instead of 256 KB of L2 reads per group.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    // Hillis-Steele inside each row of 16 lanes (a shifted-in lane outside the row reads 0), then the row totals: lane 15 of rows 0 / 2 into rows
+    // 1 / 3, lane 31 into rows 2 and 3.  (A DPP read of a VGPR needs 2 wait states after the VALU write.)
+    asm volatile("s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return v;
+}
+
+#define GLW_ROWS 4  // rows of 128 words per step
+#define GLW_Q 256   // queued words per wave (ring; < 64 pending + <= 128 new per row)
+template <bool EXACT> // EXACT: words is a multiple of 128 * GLW_ROWS, no load needs a bounds check
+__global__ __launch_bounds__(256) void k1_group_lists_wide(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ dirWords,
+                                                            int words, int groupsX, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList)
+{
+    __shared__ __attribute__((aligned(16))) unsigned long long sRow[2][GLW_ROWS][128];
+    __shared__ unsigned long long sQBits[4][GLW_Q];
+    __shared__ uint32_t sQWord[4][GLW_Q];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blocksX = (groupsX + 3) / 4;
+    const int gy = (int)blockIdx.x / blocksX, gx = ((int)blockIdx.x % blocksX) * 4 + wave;
+    const bool mine = gx < groupsX; // (a wave beyond the last column still fetches its share of the row band's mask)
+    const int g = gy * groupsX + (mine ? gx : groupsX - 1);
+    const unsigned long long* __restrict__ c = masks + (size_t)(mine ? gx : groupsX - 1) * words;
+    const unsigned long long* __restrict__ r = masks + (size_t)(groupsX + gy) * words;
+    uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
+    unsigned long long* qBits = sQBits[wave];
+    uint32_t* qWord = sQWord[wave];
+    const int rows = (words + 127) / 128, steps = (rows + GLW_ROWS - 1) / GLW_ROWS;
+    const ulonglong2 zero2 = { 0ull, 0ull };
+    // (words is even on this path: 16-byte aligned pairs)
+    auto load2 = [&](const unsigned long long* __restrict__ m, int row) {
+        const int w = row * 128 + lane * 2;
+        if (EXACT) return *reinterpret_cast<const ulonglong2*>(m + (row < rows ? w : lane * 2)); // (the prefetch past the last step re-reads row 0; unused)
+        return w < words ? *reinterpret_cast<const ulonglong2*>(m + w) : zero2;
+    };
+    uint32_t base = 0;             // the group's entries so far (wave-uniform)
+    uint32_t qHead = 0, qTail = 0; // ring indices (wave-uniform)
+    // up to 64 queued words, one lane per word: positions by one prefix sum, then every lane writes its word's set bits (ascending)
+    auto drain = [&](uint32_t n) {
+        const uint32_t qi = (qHead + (uint32_t)lane) & (GLW_Q - 1);
+        const bool have = (uint32_t)lane < n;
+        unsigned long long mm = have ? qBits[qi] : 0ull;
+        const uint32_t w = have ? qWord[qi] : 0u;
+        const unsigned long long dd = have ? dirWords[w] : 0ull;
+        const uint32_t cnt = (uint32_t)__popcll(mm);
+        const uint32_t incl = wave_incl_scan_u32(cnt);
+        uint32_t pos = base + incl - cnt;
+        const uint32_t first = w * 64u;
+        while (mm != 0ull) {
+            const int bit = __builtin_ctzll(mm);
+            mm &= mm - 1ull;
+            if (pos < CAPG) list[pos] = (first + (uint32_t)bit) | (uint32_t)((dd >> bit) & 1ull) << 31; // bit 31 = directional
+            pos++;
+        }
+        base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        qHead += n;
+    };
+    ulonglong2 cNext[GLW_ROWS], rNext;
+#pragma unroll
+    for (int k = 0; k < GLW_ROWS; k++) cNext[k] = load2(c, k);
+    rNext = load2(r, wave);
+    for (int s = 0; s < steps; s++) {
+        ulonglong2 cv[GLW_ROWS];
+#pragma unroll
+        for (int k = 0; k < GLW_ROWS; k++) cv[k] = cNext[k];
+        *reinterpret_cast<ulonglong2*>(&sRow[s & 1][wave][lane * 2]) = rNext;
+        // the next step's words are requested before this step's work
+#pragma unroll
+        for (int k = 0; k < GLW_ROWS; k++) cNext[k] = load2(c, (s + 1) * GLW_ROWS + k);
+        rNext = load2(r, (s + 1) * GLW_ROWS + wave);
+        __syncthreads(); // this step's four rows of the row band's mask are in LDS (the buffer of step s - 1 is free: every wave has passed its reads)
+        if (!mine) continue;
+#pragma unroll
+        for (int k = 0; k < GLW_ROWS; k++) {
+            const ulonglong2 rv = *reinterpret_cast<const ulonglong2*>(&sRow[s & 1][k][lane * 2]);
+            const unsigned long long m0 = cv[k].x & rv.x, m1 = cv[k].y & rv.y;
+            const unsigned long long b0 = __ballot(m0 != 0ull), b1 = __ballot(m1 != 0ull);
+            if ((b0 | b1) == 0ull) continue; // (wave-uniform)
+            const unsigned long long lt = lanemask_lt();
+            const uint32_t i0 = qTail + (uint32_t)__popcll(b0 & lt) + (uint32_t)__popcll(b1 & lt);
+            const uint32_t w = (uint32_t)((s * GLW_ROWS + k) * 128 + lane * 2);
+            if (m0 != 0ull) { qBits[i0 & (GLW_Q - 1)] = m0; qWord[i0 & (GLW_Q - 1)] = w; }
+            const uint32_t i1 = i0 + (m0 != 0ull ? 1u : 0u);
+            if (m1 != 0ull) { qBits[i1 & (GLW_Q - 1)] = m1; qWord[i1 & (GLW_Q - 1)] = w + 1u; }
+            qTail += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
+            while (qTail - qHead >= 64u) { WAVE_SYNC(); drain(64u); WAVE_SYNC(); }
+        }
+    }
+    if (mine) {
+        if (qTail != qHead) { WAVE_SYNC(); drain(qTail - qHead); }
+        if (lane == 0) groupCount[g] = base > CAPG ? GROUP_OVERFLOW : base;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // K1c: exact per-tile cull, one wave per tile, canonical offsets by decoupled look-back, lists written in place.
 // ------------------------------------------------------------------------------------------------------------
@@ -468,9 +590,6 @@ __device__ __forceinline__ void test_candidates(const TileCtx& t, const float4* 
     wave_append(pass, j | dir, count, sIdx);
 }
 
-// LDS hand-off between the lanes of ONE wave: the wave's DS operations execute in order, so only the compiler has to be
-// told not to move accesses across this point (and to wait for outstanding DS results).
-#define WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
 
 // Tile classes for the shading hint (sailor_hip_light_cull_tile_order): A = lists of >= CLASS_A entries, B = >= CLASS_B.
 #define CLASS_A 96u
@@ -988,8 +1107,19 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
         hipLaunchKernelGGL(k1_tile_cull<true>, dim3(L.cullBlocks), dim3(256), 0, s, ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull<brute>");
     } else {
-        hipLaunchKernelGGL(k1_group_lists, dim3(L.numGroups), dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
-                           (uint32_t*)(ws + L.offGroupList));
+        if (L.words >= 4096 && (L.words & 1) == 0)
+        {
+            const dim3 wideGrid((unsigned)(((L.groupsX + 3) / 4) * L.groupsY));
+            if (L.words % (128 * GLW_ROWS) == 0)
+                hipLaunchKernelGGL(k1_group_lists_wide<true>, wideGrid, dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
+                                   (uint32_t*)(ws + L.offGroupList));
+            else
+                hipLaunchKernelGGL(k1_group_lists_wide<false>, wideGrid, dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
+                                   (uint32_t*)(ws + L.offGroupList));
+        }
+        else
+            hipLaunchKernelGGL(k1_group_lists, dim3(L.numGroups), dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
+                               (uint32_t*)(ws + L.offGroupList));
         SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
         hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.cullBlocks), dim3(256), 0, s, ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
