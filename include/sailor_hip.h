@@ -242,6 +242,8 @@ SAILOR_HIP_API int sailor_hip_band_is_valid(int32_t width, int32_t height, const
                                       the fly (sailor_hip_linearize_depth's arithmetic, same bits) -- the LinearizeDepth node's
                                       full-screen pass and its 8 bytes per pixel disappear.  x -> zNear / x is monotone, so
                                       the tile's min / max are taken on the raw bits and only two values per tile are divided */
+#define SAILOR_CULL_INTERVAL_MASKS 4u /* build the pre-filter masks from per-light band intervals (the default above 262 144 lights) also for small
+                                       * light sets with <= 256 bands: same lists, for validation */
 
 SAILOR_HIP_API size_t sailor_hip_light_cull_workspace_size(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band);
 SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,

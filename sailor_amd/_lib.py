@@ -23,6 +23,7 @@ CTX_OWN_STREAM = 1
 CULL_DEFAULT = 0
 CULL_BRUTE_FORCE = 1
 CULL_RAW_DEPTH = 2
+CULL_INTERVAL_MASKS = 4
 
 RASTER_CLEAR, RASTER_CULL_BACK = 1, 2
 SHADOWMAP_R16F = 0

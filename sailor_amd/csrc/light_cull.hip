@@ -149,7 +149,7 @@ struct PrepareArgs {
     float4* lightView; uint32_t* lightType; float4* tileInfo;
     unsigned long long* masks; unsigned long long* dirWords;
     int N, words, lightBlocks, lightRoleBlocks, frustumBlocks, bandsPerBlock, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands,
-        stripsPerRow, vecOK, rawDepth;
+        stripsPerRow, vecOK, rawDepth, intervals;
     float zNearCam, planeMargin;
 };
 
@@ -210,12 +210,70 @@ __device__ __forceinline__ void k0_lights(const int lb, unsigned char* __restric
         const unsigned long long dm = __ballot(valid && type == 0u);
         if (lane == 0) a.dirWords[word] = dm;
     }
+    if (a.intervals) {
+        // Large light sets (the block holds ALL bands): the 2 x numBands plane tests per light were the launch -- 188 bands x ~25 instructions per
+        // wave at C5, 115 of prepare's 134 us.  The bands a sphere in front of the eye can reach are an interval of group columns times an
+        // interval of group rows, so each lane bisects for its light's four interval ends on the SAME plane tests (per-lane LDS reads of the
+        // planes), and the masks are ballots of "band inside the lane's interval".  What makes dropping a band safe is unchanged: a band is only
+        // dropped on the strength of an evaluated test that put the sphere entirely beyond a plane between it and the band (beyond the far
+        // plane of band L => beyond every band up to L; the half-spaces of a family of planes through the eye and parallel screen lines nest
+        // for a sphere in front of the eye), so the bisection needs no monotonicity of the rounded test to stay conservative.
+        int lo[2] = { 0, 0 }, hi[2] = { 0, 0 };
+#pragma unroll
+        for (int axis = 0; axis < 2; axis++) {
+            const int first = axis == 0 ? 0 : a.groupsX, count = axis == 0 ? a.groupsX : nb - a.groupsX;
+            // "far" plane (right / bottom, sPl[2 b + 1]): the bands the sphere lies entirely beyond form a prefix 0 .. L
+            int L = -1, R = count;
+            while (R - L > 1) {
+                const int mid = (L + R) >> 1;
+                const float4 nB = sPl[2 * (first + mid) + 1];
+                if (dot3f(nB.x, nB.y, nB.z, lv.x, lv.y, lv.z) < thr) L = mid; else R = mid;
+            }
+            lo[axis] = L + 1;
+            // "near" plane (left / top, sPl[2 b]): the bands the sphere lies entirely in front of form a suffix R .. count - 1
+            L = lo[axis] - 1; R = count;
+            while (R - L > 1) {
+                const int mid = (L + R) >> 1;
+                const float4 nA = sPl[2 * (first + mid) + 0];
+                if (dot3f(nA.x, nA.y, nA.z, lv.x, lv.y, lv.z) < thr) R = mid; else L = mid;
+            }
+            hi[axis] = R - 1; // (lo > hi: no band of this axis)
+        }
+        // A band's mask word is one 64-bit ballot; sixty-four of them are parked in the lanes of a register pair and leave as ONE
+        // store instruction, lane k writing band k's word: 188 single-lane stores per wave were 16 cycles of the CU's memory pipeline each
+        // (3 M store instructions per launch at C5 -- most of the role's time once the plane tests were gone).
+        uint32_t accLo = 0u, accHi = 0u;
+        int pending = 0, firstPending = 0; // bands parked since the last store (wave-uniform)
+        auto flush = [&]() {
+            if (lane < pending) a.masks[(size_t)(b0 + firstPending + lane) * a.words + word] = ((unsigned long long)accHi << 32) | accLo;
+            firstPending += pending; pending = 0;
+        };
+#pragma unroll
+        for (int axis = 0; axis < 2; axis++) {
+            const int count = axis == 0 ? a.groupsX : nb - a.groupsX;
+            const uint32_t l = (uint32_t)lo[axis], span = (uint32_t)(hi[axis] - lo[axis]); // (an empty interval has hi - lo = -1 = 0xFFFFFFFF: masked by `some`)
+            const bool some = hi[axis] >= lo[axis];
+            for (int k = 0; k < count; k++) {
+                const unsigned long long mask = __ballot(keepAlways || (valid && some && (uint32_t)k - l <= span));
+                if (lane == pending) { accLo = (uint32_t)mask; accHi = (uint32_t)(mask >> 32); } // (a compare and two selects; v_writelane cannot take two scalar operands here)
+                if (++pending == 64) flush();
+            }
+        }
+        flush();
+        return;
+    }
+    // (the masks of up to 64 bands are parked in the lanes of a register pair and leave as one store instruction, as above)
+    uint32_t accLo = 0u, accHi = 0u;
+    for (int bb = 0; bb < nb; bb += 64) {
+        const int cnt = min(64, nb - bb);
 #pragma unroll 4
-    for (int b = 0; b < nb; b++) {
-        const float4 nA = sPl[2 * b + 0], nB = sPl[2 * b + 1]; // LDS broadcast reads
-        const bool out = dot3f(nA.x, nA.y, nA.z, lv.x, lv.y, lv.z) < thr || dot3f(nB.x, nB.y, nB.z, lv.x, lv.y, lv.z) < thr;
-        const unsigned long long mask = __ballot(keepAlways || (valid && !out));
-        if (lane == 0) a.masks[(size_t)(b0 + b) * a.words + word] = mask;
+        for (int k = 0; k < cnt; k++) {
+            const float4 nA = sPl[2 * (bb + k) + 0], nB = sPl[2 * (bb + k) + 1]; // LDS broadcast reads
+            const bool out = dot3f(nA.x, nA.y, nA.z, lv.x, lv.y, lv.z) < thr || dot3f(nB.x, nB.y, nB.z, lv.x, lv.y, lv.z) < thr;
+            const unsigned long long mask = __ballot(keepAlways || (valid && !out));
+            if (lane == k) { accLo = (uint32_t)mask; accHi = (uint32_t)(mask >> 32); }
+        }
+        if (lane < cnt) a.masks[(size_t)(b0 + bb + lane) * a.words + word] = ((unsigned long long)accHi << 32) | accLo;
     }
 }
 
@@ -1080,10 +1138,12 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
     pa.numBands = brute ? 0 : L.numBands;
     // Few lights: the bands are spread over several blocks per 256 lights (parallelism; every block repeats the cheap transform).  Many lights
     // (the 1 M of configs[4]): the light blocks fill the chip by themselves, and repeating the 112-byte record reads per split is what costs.
-    const int perBlock = pa.lightBlocks >= 1024 ? MAX_BANDS_PER_BLOCK : BANDS_PER_BLOCK;
+    const int perBlock = (pa.lightBlocks >= 1024 || (flags & SAILOR_CULL_INTERVAL_MASKS)) ? MAX_BANDS_PER_BLOCK : BANDS_PER_BLOCK;
     const int splits = brute ? 1 : (L.numBands + perBlock - 1) / perBlock;
     pa.bandsPerBlock = brute ? 0 : (L.numBands + splits - 1) / splits; // the bands spread evenly over the splits
     pa.lightRoleBlocks = pa.lightBlocks * splits;
+    // the masks by bisection for each light's band intervals instead of 2 x numBands plane tests: needs all bands in one block
+    pa.intervals = (!brute && splits == 1 && (pa.lightBlocks >= 1024 || (flags & SAILOR_CULL_INTERVAL_MASKS))) ? 1 : 0;
     pa.stripsPerRow = (L.Tx + 16 * SETUP_STRIPS - 1) / (16 * SETUP_STRIPS);
     pa.setupBlocks = pa.stripsPerRow * L.bandRows;
     pa.frustumBlocks = (L.bandTiles + 255) / 256;

@@ -28,6 +28,11 @@ def assert_lists_equal(got, ref_grid, ref_idx):
     np.testing.assert_array_equal(idx[: 1 + total], ref_idx[: 1 + total])
 
 
+# the three ways to the same lists: band masks by plane tests (default below 262 144 lights), no pre-filter at all, band masks from per-light
+# band intervals found by bisection (the default above; forced here on the small frames)
+ALL_PATHS = [_lib.CULL_DEFAULT, _lib.CULL_BRUTE_FORCE, _lib.CULL_INTERVAL_MASKS]
+
+
 def frame(width, height, n_lights, seed=synth.SEED, **kw):
     cam = synth.make_camera(width, height)
     depth = synth.make_linear_depth(width, height, seed)
@@ -35,7 +40,7 @@ def frame(width, height, n_lights, seed=synth.SEED, **kw):
     return cam, depth, lights
 
 
-@pytest.mark.parametrize("flags", [_lib.CULL_DEFAULT, _lib.CULL_BRUTE_FORCE])
+@pytest.mark.parametrize("flags", ALL_PATHS)
 def test_tiny_fixture_bit_exact(ctx, flags):
     f = synth.make_frame("tiny", with_surface=False)
     ref_g, ref_i, cnt = oracle.light_cull(f.cam.frame, f.cam.width, f.cam.height, f.lights, f.depth, want_counts=True)
@@ -43,7 +48,7 @@ def test_tiny_fixture_bit_exact(ctx, flags):
     assert_lists_equal(gpu_cull(ctx, f.cam, f.lights, f.depth, flags), ref_g, ref_i)
 
 
-@pytest.mark.parametrize("flags", [_lib.CULL_DEFAULT, _lib.CULL_BRUTE_FORCE])
+@pytest.mark.parametrize("flags", ALL_PATHS)
 def test_c2_1080p_4096_point_lights_bit_exact(ctx, flags):
     """BASELINE.json configs[1]: 1080p, 16x16 tiles (last tile row partial), 4 096 point lights."""
     f = synth.make_frame("C2", with_surface=False)
@@ -58,7 +63,7 @@ def test_ragged_viewports(ctx, size):
     w, h = size
     cam, depth, lights = frame(w, h, 1500, radius_scale=6.0, spot_fraction=0.3, seed=7)
     ref_g, ref_i, _ = oracle.light_cull(cam.frame, w, h, lights, depth)
-    for flags in (_lib.CULL_DEFAULT, _lib.CULL_BRUTE_FORCE):
+    for flags in ALL_PATHS:
         assert_lists_equal(gpu_cull(ctx, cam, lights, depth, flags), ref_g, ref_i)
 
 
@@ -90,7 +95,7 @@ def test_directional_lights_fill_every_tile(ctx):
     lights["type"][100:400] = host.LIGHT_DIRECTIONAL
     ref_g, ref_i, _ = oracle.light_cull(cam.frame, 128, 96, lights, depth)
     assert (ref_g[:, 1] == 128).all()
-    for flags in (_lib.CULL_DEFAULT, _lib.CULL_BRUTE_FORCE):
+    for flags in ALL_PATHS:
         assert_lists_equal(gpu_cull(ctx, cam, lights, depth, flags), ref_g, ref_i)
 
 
@@ -105,8 +110,8 @@ def test_lights_behind_and_around_the_camera(ctx):
     lights["bounds"][:k] = rng.uniform(5, 600, (k, 1)).astype(np.float32)
     del view
     ref_g, ref_i, _ = oracle.light_cull(cam.frame, 640, 360, lights, depth)
-    assert_lists_equal(gpu_cull(ctx, cam, lights, depth, _lib.CULL_DEFAULT), ref_g, ref_i)
-    assert_lists_equal(gpu_cull(ctx, cam, lights, depth, _lib.CULL_BRUTE_FORCE), ref_g, ref_i)
+    for flags in ALL_PATHS:
+        assert_lists_equal(gpu_cull(ctx, cam, lights, depth, flags), ref_g, ref_i)
 
 
 def test_deterministic_over_repeated_launches(ctx):
@@ -154,6 +159,9 @@ def test_c3_4k_65536_lights_default_equals_brute_force_and_invariants(ctx):
     b = gpu_cull(ctx, f.cam, f.lights, f.depth, _lib.CULL_BRUTE_FORCE)
     np.testing.assert_array_equal(a[0], b[0])
     np.testing.assert_array_equal(a[1], b[1])
+    c = gpu_cull(ctx, f.cam, f.lights, f.depth, _lib.CULL_INTERVAL_MASKS)  # 94 bands in one block: the large-set mask builder on the 4K frame
+    np.testing.assert_array_equal(a[0], c[0])
+    np.testing.assert_array_equal(a[1], c[1])
     g, idx = a
     assert g.shape == (240 * 135, 2)
     num = g[:, 1].astype(np.int64)
@@ -175,7 +183,7 @@ def test_c3_4k_65536_lights_default_equals_brute_force_and_invariants(ctx):
             np.testing.assert_array_equal(idx[g[t0 + t, 0]: g[t0 + t, 0] + g[t0 + t, 1]], oi[og[t, 0]: og[t, 0] + og[t, 1]])
 
 
-@pytest.mark.parametrize("flags", [_lib.CULL_DEFAULT, _lib.CULL_BRUTE_FORCE])
+@pytest.mark.parametrize("flags", ALL_PATHS)
 def test_nan_impacts_follow_the_literal_bubble_sort(ctx, flags):
     """Tiles with nothing drawn (linear depth +inf) get a NaN frustum centre, i.e. NaN impacts: no total order, the shader's
     compare-and-swap (ComputeLightCulling.shader:207) is false next to a NaN.  (a) sky tiles: every impact is NaN or a
