@@ -460,6 +460,37 @@ def blur_block(ctx, steps: int):
             "cpu_1thread_mtexels_per_s": 512 * 512 / t_cpu / 1e6, "kind": "port"}
 
 
+def capture_frame_pipeline(side, side2, unroll, shade_fns, cull_fns):
+    """One hipGraph holding `unroll` (even) steps of the two-frames-in-flight pipeline over two list sets: shade_fns[p]() records frame k's shade
+    from set p = k & 1 on `side`, cull_fns[p]() records frame k + 1's cull into set p on `side2`.  The only dependencies are the frames' own:
+    shade(k) waits for cull(k), cull(k + 1) for shade(k - 1) (it overwrites the set that frame read); one join at the end of the graph.  The
+    lists of frame 0 (set 0) must exist before the first replay."""
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        shade_done = [None, None]
+        cull_done = None
+        for k in range(unroll):
+            p = k & 1
+            if cull_done is not None:
+                side.wait_event(cull_done)
+            shade_fns[p]()
+            shade_done[p] = torch.cuda.Event(); shade_done[p].record(side)
+            if shade_done[1 - p] is not None:
+                side2.wait_event(shade_done[1 - p])
+            elif k == 0:
+                side2.wait_stream(side)  # fork
+            with torch.cuda.stream(side2):
+                cull_fns[1 - p]()
+                cull_done = torch.cuda.Event(); cull_done.record(side2)
+        side.wait_stream(side2)  # join
+    return g
+
+
+def pipeline_unroll(steps: int) -> int:
+    """Steps per pipeline graph: even (two list sets: a replay ends where it began) and a divisor of K (the timed region is exactly K steps); 0 = none."""
+    return next((u for u in (16, 14, 12, 10, 8, 6, 4, 2) if steps % u == 0), 0)
+
+
 def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev):
     """Single-GPU estimate of the G-way split: per-band step time (hipGraph replay), equal vs cost-balanced bands."""
     from sailor_amd import dist as sdist
@@ -470,26 +501,44 @@ def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev):
     row_entries = g[:, 1].astype(np.int64).reshape(Ty, Tx).sum(1)
     out = {"config": args.config, "split": G}
 
+    unroll = 0 if args.frames_in_flight == 1 else pipeline_unroll(args.steps)
+    side = torch.cuda.current_stream()
+    side2 = torch.cuda.Stream(device=dev)
+    ctx2 = HipContext(dev, stream=side2)
+
     def time_band(b):
-        f = ForwardPlus(ctx, W, H, N, band=b)
+        """ms per step of band b alone on this GPU, launched the way a rank of the split frame launches it (the main path's pipeline graph)"""
+        fs = [ForwardPlus(ctx, W, H, N, band=b) for _ in range(2 if unroll else 1)]
         dd = torch.from_numpy(np.ascontiguousarray(frame.depth[b.fbRowBegin:b.fbRowBegin + b.fbRowCount])).to(dev)
         ds = torch.from_numpy(frame.surface_rows(b.fbRowBegin, b.fbRowBegin + b.fbRowCount)).to(dev)
-
-        def step():
+        for f in fs:
             f.cull(cam.frame, d_lights, N, dd)
             f.shade(cam.frame, ds, d_lights, N, None)
-        step(); torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=torch.cuda.current_stream()):
-            step()
-        for _ in range(args.warmup):
+        torch.cuda.synchronize()
+        if unroll:
+            graph = capture_frame_pipeline(side, side2, unroll, [lambda f=f: f.shade(cam.frame, ds, d_lights, N, None) for f in fs],
+                                           [lambda f=f: f.cull(cam.frame, d_lights, N, dd, ctx=ctx2) for f in fs])
+            fs[0].cull(cam.frame, d_lights, N, dd)
+            per = unroll
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                fs[0].cull(cam.frame, d_lights, N, dd)
+                fs[0].shade(cam.frame, ds, d_lights, N, None)
+            per = 1
+        t_spin = time.perf_counter()   # the same clock spin-up as the main path (a band's K steps are over in 2-4 ms)
+        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+            for _ in range(8):
+                graph.replay()
+            torch.cuda.synchronize()
+        for _ in range((args.warmup + per - 1) // per):
             graph.replay()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.steps // per):
             graph.replay()
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / args.steps * 1e3
+        return (time.perf_counter() - t0) / (args.steps // per * per) * 1e3
 
     whole = time_band(host.band_whole_frame(W, H))
     for name, bounds in (("equal", [host.band_for_rank(W, H, r, G).tileRowBegin for r in range(G)] + [Ty]),
@@ -497,6 +546,7 @@ def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev):
         ms = [time_band(host.band_from_tile_rows(W, H, bounds[r], bounds[r + 1])) for r in range(G)]
         out[name] = {"bounds": [int(b) for b in bounds], "band_ms": ms, "max_ms": max(ms), "predicted_speedup": whole / max(ms)}
     out["whole_frame_ms"] = whole
+    out["launch"] = f"hipGraph replay ({unroll} steps of the frame pipeline per graph), 2 frames in flight" if unroll else "hipGraph replay, 1 frame in flight"
     print(json.dumps(out), flush=True)
 
 
@@ -618,6 +668,14 @@ def main():
     # a second stream.  Every step still performs exactly one cull and one shade of a frame.
     pipelined = args.frames_in_flight == 2 and not args.no_graph and not args.exchange_every_step
     graphs = []
+    # One replay = `unroll` steps of the software pipeline, with the dependencies of the frames themselves and nothing else: shade(k) waits for
+    # cull(k), cull(k + 1) for shade(k - 1) (it overwrites the list set that frame read).  One fork / join per STEP -- round 1's form, two graphs of
+    # one step each -- makes every step last as long as the longer of its two branches plus the join (0.2335 ms); without it the chain of cull
+    # kernels slides under the neighbouring shades (0.219 ms, measured first with eager launches on two streams: scripts/cu_mask_probe.py).
+    # unroll is even (two list sets: a replay must end where it began) and divides K, so the timed region is exactly K steps.
+    unroll = pipeline_unroll(args.steps)
+    if pipelined and unroll == 0:
+        pipelined = False  # an odd K: one frame in flight (the JSON line says so)
     if pipelined:
         try:
             side2 = torch.cuda.Stream(device=dev)
@@ -628,15 +686,10 @@ def main():
                 f.cull(cam.frame, d_lights, N, d_depth)
                 f.shade(cam.frame, d_surface, d_lights, N, csm)
             torch.cuda.synchronize()
-            for p in (0, 1):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    side2.wait_stream(side)                                  # fork
-                    with torch.cuda.stream(side2):
-                        fps[1 - p].cull(cam.frame, d_lights, N, d_depth, ctx=ctx2)   # frame k+1 -> the other buffer set
-                    fps[p].shade(cam.frame, d_surface, d_lights, N, csm)             # frame k
-                    side.wait_stream(side2)                                  # join
-                graphs.append(g)
+            g = capture_frame_pipeline(side, side2, unroll,
+                                       [lambda f=f: f.shade(cam.frame, d_surface, d_lights, N, csm) for f in fps],
+                                       [lambda f=f: f.cull(cam.frame, d_lights, N, d_depth, ctx=ctx2) for f in fps])
+            graphs.append(g)
             fps[0].cull(cam.frame, d_lights, N, d_depth)                     # prologue: frame 0's lists
             torch.cuda.synchronize()
         except Exception as e:
@@ -655,33 +708,31 @@ def main():
             graph = None
             torch.cuda.synchronize()
 
-    step_counter = [0]
+    # a "run" is `per_run` steps: the unrolled pipeline graph, or one step of the other forms
+    per_run = unroll if pipelined else 1
 
-    def run_step():
+    def run():
         if pipelined:
-            graphs[step_counter[0] & 1].replay()
-            step_counter[0] += 1
+            graphs[0].replay()
         elif graph is not None:
             graph.replay()
         else:
             step()
 
-    # Clock spin-up (untimed, before the W warm-up steps): K steps of a 0.26 ms frame are over in a few milliseconds, less than the GPU
+    # Clock spin-up (untimed, before the W warm-up steps): K steps of a 0.23 ms frame are over in a few milliseconds, less than the GPU
     # needs to leave its idle power state -- a renderer runs continuously, so the steady state is what the K timed steps should see.
     if args.spinup_ms > 0:
         t_spin = time.perf_counter()
         while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
-            for _ in range(32):
-                run_step()
+            for _ in range(max(1, 32 // per_run)):
+                run()
             torch.cuda.synchronize()
-        if step_counter[0] & 1:   # keep the two-frames-in-flight parity where the prologue left it
-            run_step()
-    for _ in range(args.warmup):
-        run_step()
+    for _ in range((args.warmup + per_run - 1) // per_run):   # at least W warm-up steps
+        run()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
+    for _ in range(args.steps // per_run):
+        run()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -693,17 +744,18 @@ def main():
     frames_per_step = world if (weak and world > 1) else 1
     # per-step distribution (median, p10 / p90): a second pass of K steps with one HIP event per step on the launch stream --
     # outside the timed region above, which stays free of event records
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    n_runs = args.steps // per_run
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_runs + 1)]
     evs[0].record(side)
-    for i in range(args.steps):
-        run_step()
+    for i in range(n_runs):
+        run()
         evs[i + 1].record(side)
     torch.cuda.synchronize()
-    per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)])
+    per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n_runs)]) / per_run
     step_stats = {"median": float(np.median(per_step)), "p10": float(np.percentile(per_step, 10)), "p90": float(np.percentile(per_step, 90)),
-                  "how": "HIP events between consecutive steps on the launch stream, a separate pass of K steps (this rank)"}
-    if args.steps & 1 and pipelined:
-        run_step()  # keep the two-frames-in-flight parity
+                  "how": ("HIP events between consecutive steps on the launch stream" if per_run == 1 else
+                          f"HIP events between consecutive replays of the {per_run}-step pipeline graph on the launch stream, divided by {per_run}") +
+                         ", a separate pass of K steps (this rank)"}
     value = frames_per_step * W * H * args.steps / elapsed / 1e6
 
     # ---- per-kernel timing on the launch stream (HIP events) + algorithmic bytes ----
@@ -872,7 +924,7 @@ def main():
         out = {
             "metric": "lit Mpixels/s (K0+K1 tile light cull + K2 PBR shade over per-tile lists)", "value": value, "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_ms": args.spinup_ms, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak" if weak else "strong", "launch": "hipGraph replay, 2 frames in flight" if pipelined else ("hipGraph replay" if graph is not None else "eager"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if weak else "strong", "launch": f"hipGraph replay ({unroll} steps of the frame pipeline per graph), 2 frames in flight" if pipelined else ("hipGraph replay" if graph is not None else "eager"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H}, {N} point+spot lights, 16x16 tiles ({fp.Tx}x{fp.Ty}), cull + PBR shade"
                                    + (" + 4-cascade CSM" if csm is not None else ""),
                        "width": W, "height": H, "lights": N, "parallelism": (f"dp{world}: a whole frame per GPU" if weak else f"tile-row bands x{world}"), "partition": partition,
