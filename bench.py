@@ -953,10 +953,16 @@ def main():
             out["evsm_blur"] = blur_block(ctx, 10)
             out["ibl_prefilter"] = ibl_prefilter_block(ctx, 3)
             out["shadow_passes"] = shadow_pass_block(ctx, 1 << 20, 4096, 5)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which would otherwise be flushed behind it at exit
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
