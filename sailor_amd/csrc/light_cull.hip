@@ -16,8 +16,12 @@
 //                      depth  : streaming pass over the linear-depth image (the only large HBM stream of the cull):
 //                               32 tiles per 256-thread block, 1 KiB coalesced float4 row segments, wave shuffles + a
 //                               4-entry LDS combine for min/max
+//                      Above 262 144 lights a block holds all bands and finds each light's band INTERVALS by bisection on the
+//                      same plane tests instead (k0_lights; SAILOR_CULL_INTERVAL_MASKS forces that form)
 //   k1_group_lists     one block per 4x4-tile group: (its column's mask) AND (its row's mask), 16 384 lights per
 //                      step; the few surviving bits become an ordered, contiguous candidate list (ballot, readlane, mbcnt)
+//   k1_group_lists_wide  the same lists for >= 4 096 mask words (a million lights): one wave per group queues the non-empty
+//                      words and drains them one lane per word; four groups per block share the row band's mask through LDS
 //   k1_tile_cull       one 256-thread block per run of four tiles of a tile row (= one row of a group), one wave per tile:
 //                      the group's candidate records are staged in LDS 512 at a time, each wave streams them through the
 //                      exact test, 64 per step; ballot/popcount ordered append; rank-based nearest-128 selection
