@@ -31,7 +31,7 @@ def _mul_glsl(M, x, y, z, w):
     return [((M[0][i] * x + M[1][i] * y) + M[2][i] * z) + M[3][i] * w for i in range(4)]
 
 
-def _screen_to_view(inv_proj, sx, sy, sz, sw, vp_w, vp_h):
+def _screen_to_view(inv_proj, sx, sy, sz, sw, vp_w, vp_h, F=F):
     tx = F(sx) / F(vp_w)
     ty = F(sy) / F(vp_h)
     cx = tx * F(2.0) - F(1.0)
@@ -41,7 +41,7 @@ def _screen_to_view(inv_proj, sx, sy, sz, sw, vp_w, vp_h):
     return np.array([v[0] / w, v[1] / w, (v[2] / w) * F(-1.0)], F)
 
 
-def _plane(p1, p2):
+def _plane(p1, p2, F=F):
     """ComputePlane(eye = 0, p1, p2) -> unit normal (plane.w = dot(n, 0) = +-0 never changes a comparison)."""
     v0 = p1 - F(0.0)
     v2 = p2 - F(0.0)
@@ -50,15 +50,57 @@ def _plane(p1, p2):
     return c / ln
 
 
-def tile_frustum(inv_proj, tx, ty, vp_w, vp_h):
+def tile_frustum(inv_proj, tx, ty, vp_w, vp_h, F=F):
     x0, y0, x1, y1 = F(tx * TILE), F(ty * TILE), F((tx + 1) * TILE), F((ty + 1) * TILE)
-    vs0 = _screen_to_view(inv_proj, x0, y0, -1.0, 1.0, vp_w, vp_h)
-    vs1 = _screen_to_view(inv_proj, x1, y0, -1.0, 1.0, vp_w, vp_h)
-    vs2 = _screen_to_view(inv_proj, x0, y1, -1.0, 1.0, vp_w, vp_h)
-    vs3 = _screen_to_view(inv_proj, x1, y1, -1.0, 1.0, vp_w, vp_h)
-    vs4 = _screen_to_view(inv_proj, (x0 + x1) * F(0.5), (y0 + y1) * F(0.5), (F(-1.0) + F(-1.0)) * F(0.5), (F(1.0) + F(1.0)) * F(0.5), vp_w, vp_h)
-    planes = [_plane(vs2, vs0), _plane(vs1, vs3), _plane(vs0, vs1), _plane(vs3, vs2)]
+    vs0 = _screen_to_view(inv_proj, x0, y0, -1.0, 1.0, vp_w, vp_h, F)
+    vs1 = _screen_to_view(inv_proj, x1, y0, -1.0, 1.0, vp_w, vp_h, F)
+    vs2 = _screen_to_view(inv_proj, x0, y1, -1.0, 1.0, vp_w, vp_h, F)
+    vs3 = _screen_to_view(inv_proj, x1, y1, -1.0, 1.0, vp_w, vp_h, F)
+    vs4 = _screen_to_view(inv_proj, (x0 + x1) * F(0.5), (y0 + y1) * F(0.5), (F(-1.0) + F(-1.0)) * F(0.5), (F(1.0) + F(1.0)) * F(0.5), vp_w, vp_h, F)
+    planes = [_plane(vs2, vs0, F), _plane(vs1, vs3, F), _plane(vs0, vs1, F), _plane(vs3, vs2, F)]
     return planes, vs4[0], vs4[1]
+
+
+def overlap_table(frame_bytes, W: int, H: int, lights: np.ndarray, depth: np.ndarray, dtype=np.float32):
+    """The per-(tile, light) decisions of Math.glsl:224-239 SphereFrustumOverlaps (+ the directional rule of :153-162) evaluated in `dtype`,
+    and how close each decision is to flipping: `slack[t, j]` = the smallest relative distance of any of the six comparisons from its
+    boundary.  With dtype = float64 this is the "truth" the float32 restatements are held against (tests/test_oracle_cpu.py): the two may
+    only disagree where float64 itself says the sphere touches a plane or a depth bound to within rounding."""
+    T = dtype
+    view32, inv32, vp_w, vp_h = _frame_fields(frame_bytes)
+    view, inv_proj = view32.astype(T), inv32.astype(T)
+    Tx, Ty = (W - 1) // TILE + 1, (H - 1) // TILE + 1
+    ltype = lights["type"].astype(np.uint32)
+    radius = lights["bounds"][:, 0].astype(T)
+    wp = lights["worldPosition"].astype(T)
+    p = _mul_glsl(view, wp[:, 0], wp[:, 1], wp[:, 2], T(1.0))
+    px, py, pz = p[0] / p[3], p[1] / p[3], (p[2] / p[3]) * T(-1.0)
+    depth_bits = np.ascontiguousarray(depth, np.float32).view(np.uint32)
+    ok = np.zeros((Ty * Tx, len(lights)), bool)
+    slack = np.full((Ty * Tx, len(lights)), np.inf)
+    lx = np.arange(TILE)
+    scale = np.abs(px) + np.abs(py) + np.abs(pz) + np.abs(radius)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for ty in range(Ty):
+            rows = np.clip(H - 1 - (TILE * ty + lx), 0, H - 1)
+            for tx in range(Tx):
+                cols = np.minimum(TILE * tx + lx, W - 1)
+                bits = depth_bits[np.ix_(rows, cols)]
+                z_far, z_near = T(bits.max().view(np.float32)), T(bits.min().view(np.float32))
+                diff = z_far - z_near
+                z_far, z_near = z_far - diff, z_near + diff
+                planes, _, _ = tile_frustum(inv_proj, tx, ty, vp_w, vp_h, T)
+                o = ~((pz - radius > z_near) | (pz + radius < z_far))
+                s = np.minimum(np.abs((pz - radius) - z_near), np.abs((pz + radius) - z_far)) / (scale + np.abs(z_near) + np.abs(z_far))
+                for pl in planes:
+                    d = (pl[0] * px + pl[1] * py) + pl[2] * pz
+                    o &= ~(d < -radius)
+                    s = np.minimum(s, np.abs(d + radius) / scale)
+                o |= ltype == 0
+                s = np.where(ltype == 0, np.inf, s)
+                ok[ty * Tx + tx] = o
+                slack[ty * Tx + tx] = s
+    return ok, slack
 
 
 def light_cull(frame_bytes, W: int, H: int, lights: np.ndarray, depth: np.ndarray, tile_rows=None):

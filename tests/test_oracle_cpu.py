@@ -112,6 +112,33 @@ def test_c_and_numpy_restatements_agree_bitwise(case):
     np.testing.assert_array_equal(ci, li)
 
 
+@pytest.mark.parametrize("case", [
+    dict(w=128, h=96, n=512, seed=synth.SEED, radius_scale=6.0, spot_fraction=0.25, cluster_lights=300),
+    dict(w=131, h=77, n=700, seed=5, radius_scale=8.0, spot_fraction=0.5),
+    dict(w=320, h=200, n=3000, seed=9, radius_scale=4.0, cluster_lights=500, cluster_count=2),
+])
+def test_fp32_overlap_decisions_against_float64(case):
+    """The oracle is unpinned by the reference, so the float32 sphere / tile-frustum decisions (Math.glsl:224-239) are held against the same
+    decisions in float64: of the ~10^5 .. 10^6 (tile, light) pairs of a frame the two may only differ where float64 itself puts the sphere within
+    rounding of a plane or a depth bound -- and the lists the C oracle emits are exactly the float32 table's (first 196 in index order)."""
+    w, h, n, seed = case.pop("w"), case.pop("h"), case.pop("n"), case.pop("seed")
+    cam, depth, lights = _frame(w, h, n, seed, **case)
+    lights["type"][7] = host.LIGHT_DIRECTIONAL
+    fb = bytes(cam.frame)
+    ok32, _ = oracle_np.overlap_table(fb, w, h, lights, depth, np.float32)
+    ok64, slack = oracle_np.overlap_table(fb, w, h, lights, depth, np.float64)
+    differ = ok32 != ok64
+    print(f"{w}x{h}, {n} lights: {ok64.sum()} overlaps of {ok64.size} pairs; float32 differs on {differ.sum()}, largest slack there "
+          f"{slack[differ].max() if differ.any() else 0.0:.2e}; smallest slack anywhere {slack.min():.2e}")
+    assert differ.sum() <= 1e-4 * ok64.size
+    assert (slack[differ] < 1e-5).all()
+    # the C oracle's lists are the float32 table: per tile, the first 196 set bits (before the nearest-128 selection reorders them)
+    g, idx, cnt = oracle.light_cull(cam.frame, w, h, lights, depth, want_counts=True)
+    np.testing.assert_array_equal(np.minimum(ok32.sum(1), oracle.CAND), np.minimum(cnt, oracle.CAND))
+    for t in np.nonzero(ok32.sum(1) <= oracle.KEEP)[0][:200]:
+        np.testing.assert_array_equal(np.sort(idx[g[t, 0]: g[t, 0] + g[t, 1]]), np.nonzero(ok32[t])[0])
+
+
 def test_bands_of_the_oracle_compose():
     cam, depth, lights = _frame(320, 200, 2000, 4, radius_scale=5.0, cluster_lights=300)
     g, idx, _ = oracle.light_cull(cam.frame, 320, 200, lights, depth)
