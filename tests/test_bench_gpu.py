@@ -52,3 +52,58 @@ def test_one_rank_process_group_runs_both_multi_gpu_modes(split_primary):
     if split_primary:
         assert d["speedup_vs_one_gpu_whole_frame"] > 0
     assert d["step_ms"]["p10"] <= d["step_ms"]["median"] <= d["step_ms"]["p90"]
+
+
+def test_even_step_counts_run_the_frame_pipeline_graph():
+    d = _run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2", "--spinup-ms", "50", "--no-cpu-baseline"])
+    assert "8 steps of the frame pipeline per graph" in d["launch"] and d["steps"] == 8
+    assert abs(d["value"] - 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    assert d["step_ms"]["p10"] <= d["step_ms"]["median"] <= d["step_ms"]["p90"]
+
+
+def test_the_frame_pipeline_graph_leaves_the_frames_results():
+    """The pipeline graph orders two streams by the frames' own dependencies only (shade(k) after cull(k), cull(k + 1) after shade(k - 1)).  Run it
+    with DIFFERENT light sets in the two list sets -- a missing dependency would shade a frame from the other frame's lists -- and compare what
+    every set holds afterwards with plain stream-ordered launches."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, str(ROOT))
+    import bench
+    from sailor_amd import synth
+    from sailor_amd.forward_plus import HipContext, ForwardPlus, upload_lights
+    dev = torch.device("cuda", 0)
+    f = synth.make_frame("C2")
+    cam, W, H, N = f.cam, f.cam.width, f.cam.height, len(f.lights)
+    side, side2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        ctx, ctx2 = HipContext(dev, stream=side), HipContext(dev, stream=side2)
+        d_depth = torch.from_numpy(np.ascontiguousarray(f.depth)).to(dev)
+        d_surface = torch.from_numpy(np.ascontiguousarray(f.surface)).to(dev)
+        lights_b = f.lights.copy()
+        lights_b["worldPosition"][:, 0] += 3.0   # the other frame: every light moved
+        d_l = [upload_lights(f.lights, dev), upload_lights(lights_b, dev)]
+        fps = [ForwardPlus(ctx, W, H, N) for _ in range(2)]
+        outs = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        ref = []
+        for p in range(2):   # reference: stream order, one frame after the other
+            fps[p].cull(cam.frame, d_l[p], N, d_depth)
+            fps[p].shade(cam.frame, d_surface, d_l[p], N, None, out=outs[p])
+            torch.cuda.synchronize()
+            g, idx = fps[p].lists_to_host()
+            ref.append((g, idx, outs[p].cpu().numpy().copy()))
+            outs[p].zero_()
+        assert not np.array_equal(ref[0][1], ref[1][1])
+        torch.cuda.synchronize()
+        graph = bench.capture_frame_pipeline(side, side2, 6,
+                                             [lambda p=p: fps[p].shade(cam.frame, d_surface, d_l[p], N, None, out=outs[p]) for p in range(2)],
+                                             [lambda p=p: fps[p].cull(cam.frame, d_l[p], N, d_depth, ctx=ctx2) for p in range(2)])
+        fps[0].cull(cam.frame, d_l[0], N, d_depth)   # the prologue: frame 0's lists
+        torch.cuda.synchronize()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        for p in range(2):
+            g, idx = fps[p].lists_to_host()
+            np.testing.assert_array_equal(g, ref[p][0])
+            np.testing.assert_array_equal(idx, ref[p][1])
+            np.testing.assert_array_equal(outs[p].cpu().numpy(), ref[p][2])
