@@ -309,9 +309,13 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     // publishes the staged records waits for LDS only, not for outstanding global loads.
     const SailorLightsGrid g = grid[bandTile]; // Standard.shader:422-423
     // unconditional surface loads (lanes outside the frame read pixel 0 of the band and are masked out of every ballot and of the store)
-    const float4 P0 = surface[pix];
-    const float4 P1 = surface[planeStride + pix];
-    const float4 P2 = surface[2 * planeStride + pix];
+    // (streamed once: non-temporal, so that what every tile reads again -- lists, light records, the next frame's depth and masks -- keeps its
+    // place in L2)
+#define NT_LOAD4(P) make_float4(__builtin_nontemporal_load(&(P).x), __builtin_nontemporal_load(&(P).y), __builtin_nontemporal_load(&(P).z), __builtin_nontemporal_load(&(P).w))
+    const float4 P0 = NT_LOAD4(surface[pix]);
+    const float4 P1 = NT_LOAD4(surface[planeStride + pix]);
+    const float4 P2 = NT_LOAD4(surface[2 * planeStride + pix]);
+#undef NT_LOAD4
     if (ROLE == ROLE_BAND_TILE && g.num >= (uint32_t)SPLIT_MIN) return; // a tile of the split blocks
     const uint32_t listNum = g.num < (uint32_t)KEEP ? g.num : (uint32_t)KEEP;
     const bool haveLight = (uint32_t)tid < listNum;
