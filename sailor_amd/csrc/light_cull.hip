@@ -62,7 +62,7 @@
 
 struct CullLayout {
     int Tx, Ty, bandRows, bandTiles, numBands, words, groupsX, groupsY, numGroups, cullBlocks, packBlocks;
-    size_t offLightView, offLightType, offTileInfo, offMasks, offDirWords, offGroupCount, offGroupList, offTotals, offClsTotals, offTileNum, offStaging, offTileOrder, total;
+    size_t offLightView, offLightType, offTileInfo, offMasks, offDirWords, offGroupCount, offGroupList, offTotals, offClsTotals, offTileNum, offStaging, offTileOrder, offDirFlag, total;
 };
 
 static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
@@ -90,6 +90,7 @@ static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
     L.offMasks = o; o = align_up(o + (size_t)(L.numBands > 0 ? L.numBands : 1) * L.words * 8, 256);
     L.offDirWords = o; o = align_up(o + (size_t)L.words * 8, 256);
     L.offGroupCount = o; o = align_up(o + groups * 4, 256);
+    L.offDirFlag = o; o = align_up(o + 4, 256);
     L.offGroupList = o; o = align_up(o + groups * CAPG * 4, 256);
     const size_t cb = (size_t)(L.cullBlocks > 0 ? L.cullBlocks : 1);
     L.offTotals = o; o = align_up(o + (cb + PACK_BLOCKS) * 4, 256);
@@ -152,10 +153,29 @@ struct PrepareArgs {
     const float* depth;
     float4* lightView; uint32_t* lightType; float4* tileInfo;
     unsigned long long* masks; unsigned long long* dirWords;
+    uint32_t* dirFlag; // "some light may be directional": set here, read by k1_group_lists_wide, cleared by k1_pack (unknown before the first cull: then merely conservative)
     int N, words, lightBlocks, lightRoleBlocks, frustumBlocks, bandsPerBlock, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands,
         stripsPerRow, vecOK, rawDepth, intervals;
     float zNearCam, planeMargin;
 };
+
+// 64 x 64 bit-matrix transpose across a wave: lane l holds row l, returns column l (bit i = bit l of lane i's row).  Recursive block swap:
+// at stage k the lanes l and l ^ k exchange the off-diagonal k x k blocks.
+__device__ __forceinline__ unsigned long long transpose_64x64(unsigned long long r)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long keep[6] = { 0x00000000FFFFFFFFull, 0x0000FFFF0000FFFFull, 0x00FF00FF00FF00FFull,
+                                         0x0F0F0F0F0F0F0F0Full, 0x3333333333333333ull, 0x5555555555555555ull }; // columns whose bit k is clear
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+        const int k = 32 >> s;
+        const uint32_t plo = (uint32_t)__shfl_xor((int)(uint32_t)r, k, 64), phi = (uint32_t)__shfl_xor((int)(uint32_t)(r >> 32), k, 64);
+        const unsigned long long p = ((unsigned long long)phi << 32) | plo;
+        const unsigned long long m = keep[s];
+        r = (lane & (uint32_t)k) ? ((r & ~m) | ((p & ~m) >> k)) : ((r & m) | ((p & m) << k));
+    }
+    return r;
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // K0: ComputeLightCulling.shader:164-169 hoisted out of the per-tile loop (it does not depend on the tile), and
@@ -212,7 +232,7 @@ __device__ __forceinline__ void k0_lights(const int lb, unsigned char* __restric
     const bool keepAlways = valid && (type == 0u || !inFront);
     if (split == 0) { // one bit per light: "directional" (rides along into the group lists, saves a gather per candidate)
         const unsigned long long dm = __ballot(valid && type == 0u);
-        if (lane == 0) a.dirWords[word] = dm;
+        if (lane == 0) { a.dirWords[word] = dm; if (dm != 0ull) atomicOr(a.dirFlag, 1u); }
     }
     if (a.intervals) {
         // Large light sets (the block holds ALL bands): the 2 x numBands plane tests per light were the launch -- 188 bands x ~25 instructions per
@@ -243,27 +263,27 @@ __device__ __forceinline__ void k0_lights(const int lb, unsigned char* __restric
             }
             hi[axis] = R - 1; // (lo > hi: no band of this axis)
         }
-        // A band's mask word is one 64-bit ballot; sixty-four of them are parked in the lanes of a register pair and leave as ONE
-        // store instruction, lane k writing band k's word: 188 single-lane stores per wave were 16 cycles of the CU's memory pipeline each
-        // (3 M store instructions per launch at C5 -- most of the role's time once the plane tests were gone).
-        uint32_t accLo = 0u, accHi = 0u;
-        int pending = 0, firstPending = 0; // bands parked since the last store (wave-uniform)
-        auto flush = [&]() {
-            if (lane < pending) a.masks[(size_t)(b0 + firstPending + lane) * a.words + word] = ((unsigned long long)accHi << 32) | accLo;
-            firstPending += pending; pending = 0;
-        };
+        // The mask words of 64 bands at a time.  A lane's interval IS its row of the (64 lights x 64 bands) bit matrix -- a run of ones, two
+        // shifts -- and the mask words are the matrix's columns: one 64 x 64 bit transpose across the wave (six butterfly stages) replaces 64
+        // ballots of "band inside the lane's interval" (and their 64 single-lane stores: lane j ends up holding band j's word and all
+        // sixty-four leave in ONE store instruction -- a single-lane store costs the CU's memory pipeline 16 cycles like any other, and
+        // 188 per wave, 3 M per launch at C5, were most of the role's time once the plane tests were gone).
 #pragma unroll
         for (int axis = 0; axis < 2; axis++) {
-            const int count = axis == 0 ? a.groupsX : nb - a.groupsX;
-            const uint32_t l = (uint32_t)lo[axis], span = (uint32_t)(hi[axis] - lo[axis]); // (an empty interval has hi - lo = -1 = 0xFFFFFFFF: masked by `some`)
-            const bool some = hi[axis] >= lo[axis];
-            for (int k = 0; k < count; k++) {
-                const unsigned long long mask = __ballot(keepAlways || (valid && some && (uint32_t)k - l <= span));
-                if (lane == pending) { accLo = (uint32_t)mask; accHi = (uint32_t)(mask >> 32); } // (a compare and two selects; v_writelane cannot take two scalar operands here)
-                if (++pending == 64) flush();
+            const int first = axis == 0 ? 0 : a.groupsX, count = axis == 0 ? a.groupsX : nb - a.groupsX;
+            for (int w0 = 0; w0 < count; w0 += 64) {
+                const int n = min(64, count - w0);                                     // bands in this window
+                const unsigned long long window = n == 64 ? ~0ull : ((1ull << n) - 1ull);
+                unsigned long long row = 0ull;
+                if (keepAlways) row = window;
+                else if (valid) {
+                    const int x = max(lo[axis], w0) - w0, y = min(hi[axis], w0 + 63) - w0; // the interval inside the window: bits x .. y
+                    if (x <= y) row = ((~0ull) >> (63 - (y - x))) << x;
+                }
+                const unsigned long long col = transpose_64x64(row) ;                 // lane j: bit i = light i of this wave reaches band w0 + j
+                if (lane < n) a.masks[(size_t)(b0 + first + w0 + lane) * a.words + word] = col;
             }
         }
-        flush();
         return;
     }
     // (the masks of up to 64 bands are parked in the lanes of a register pair and leave as one store instruction, as above)
@@ -520,9 +540,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 #define GLW_Q 256   // queued words per wave (ring; < 64 pending + <= 128 new per row)
 template <bool EXACT> // EXACT: words is a multiple of 128 * GLW_ROWS, no load needs a bounds check
 __global__ __launch_bounds__(256) void k1_group_lists_wide(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ dirWords,
-                                                            int words, int groupsX, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList)
+                                                            int words, int groupsX, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList,
+                                                            const uint32_t* __restrict__ dirFlag)
 {
     __shared__ __attribute__((aligned(16))) unsigned long long sRow[2][GLW_ROWS][128];
+    const bool anyDir = *dirFlag != 0u; // no directional light in the set (the usual case): the draining waves need not wait for their words of dirWords
     __shared__ unsigned long long sQBits[4][GLW_Q];
     __shared__ uint32_t sQWord[4][GLW_Q];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -551,7 +573,7 @@ __global__ __launch_bounds__(256) void k1_group_lists_wide(const unsigned long l
         const bool have = (uint32_t)lane < n;
         unsigned long long mm = have ? qBits[qi] : 0ull;
         const uint32_t w = have ? qWord[qi] : 0u;
-        const unsigned long long dd = have ? dirWords[w] : 0ull;
+        const unsigned long long dd = (have && anyDir) ? dirWords[w] : 0ull;
         const uint32_t cnt = (uint32_t)__popcll(mm);
         const uint32_t incl = wave_incl_scan_u32(cnt);
         uint32_t pos = base + incl - cnt;
@@ -934,7 +956,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
 // ------------------------------------------------------------------------------------------------------------
 struct PackArgs {
     const uint32_t* totals; const uint32_t* clsTotals; const uint32_t* tileNum; const uint32_t* staging;
-    SailorLightsGrid* grid; uint32_t* culled; uint32_t* tileOrder;
+    SailorLightsGrid* grid; uint32_t* culled; uint32_t* tileOrder; uint32_t* dirFlag;
     int Tx, groupsX, bandRows, cullBlocks, classes;
     uint32_t capacity;
 };
@@ -960,6 +982,7 @@ __global__ __launch_bounds__(256) void k1_pack(const PackArgs a)
     __shared__ uint32_t sLen[PACK_BLOCKS], sDst[PACK_BLOCKS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int first = (int)blockIdx.x * PACK_BLOCKS;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.dirFlag = 0u; // (the next cull's k01_prepare sets it again if a light is directional)
     // this block's 64 tiles: requested now, used after the base is known
     uint32_t num = 0u;
     int tile = -1, tx = 0, tyLocal = 0;
@@ -1157,6 +1180,7 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
     pa.rawDepth = (flags & SAILOR_CULL_RAW_DEPTH) ? 1 : 0;
     pa.zNearCam = frame->cameraZNearZFar[0];
     pa.planeMargin = 1e-3f;
+    pa.dirFlag = (uint32_t*)(ws + L.offDirFlag);
     hipLaunchKernelGGL(k01_prepare, dim3(pa.lightRoleBlocks + pa.frustumBlocks + pa.setupBlocks), dim3(256), 0, s, pa);
     SAILOR_CHECK_LAUNCH(ctx, "k01_prepare");
 
@@ -1176,10 +1200,10 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
             const dim3 wideGrid((unsigned)(((L.groupsX + 3) / 4) * L.groupsY));
             if (L.words % (128 * GLW_ROWS) == 0)
                 hipLaunchKernelGGL(k1_group_lists_wide<true>, wideGrid, dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
-                                   (uint32_t*)(ws + L.offGroupList));
+                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag));
             else
                 hipLaunchKernelGGL(k1_group_lists_wide<false>, wideGrid, dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
-                                   (uint32_t*)(ws + L.offGroupList));
+                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag));
         }
         else
             hipLaunchKernelGGL(k1_group_lists, dim3(L.numGroups), dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
@@ -1190,7 +1214,7 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
     }
     PackArgs ka;
     ka.totals = ca.totals; ka.clsTotals = ca.clsTotals; ka.tileNum = ca.tileNum; ka.staging = ca.staging;
-    ka.grid = dLightsGrid; ka.culled = dCulledLights; ka.tileOrder = (uint32_t*)(ws + L.offTileOrder);
+    ka.grid = dLightsGrid; ka.culled = dCulledLights; ka.tileOrder = (uint32_t*)(ws + L.offTileOrder); ka.dirFlag = (uint32_t*)(ws + L.offDirFlag);
     ka.Tx = L.Tx; ka.groupsX = L.groupsX; ka.bandRows = L.bandRows; ka.cullBlocks = L.cullBlocks; ka.classes = ca.classes;
     ka.capacity = (uint32_t)(culledCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : culledCapacity);
     hipLaunchKernelGGL(k1_pack, dim3(L.packBlocks), dim3(256), 0, s, ka);

@@ -228,3 +228,23 @@ def test_c5_8k_1m_lights_invariants_and_an_oracle_tile_row(ctx):
         np.testing.assert_array_equal(g[t0:t0 + 480, 1], og[:, 1])
         for t in range(480):
             np.testing.assert_array_equal(idx[g[t0 + t, 0]: g[t0 + t, 0] + g[t0 + t, 1]], oi[og[t, 0]: og[t, 0] + og[t, 1]])
+
+
+def test_large_light_set_with_directional_lights_on_a_small_frame(ctx):
+    """300 000 lights on a 640 x 360 frame: the kernels of the large-set path (band intervals + bit transpose in k01_prepare, k1_group_lists_wide
+    in its bounds-checked form: 4 688 mask words are not a multiple of 512) against the oracle over the WHOLE frame, with and without
+    directional lights on one workspace (the "some light is directional" flag that lets the list builder skip the directional words is set by
+    one cull and cleared at its end)."""
+    W, H, N = 640, 360, 300_000
+    cam, depth, lights = frame(W, H, N, radius_scale=0.35, spot_fraction=0.3, seed=11)
+    with_dir = lights.copy()
+    with_dir["type"][[5, 70_001, 299_999]] = host.LIGHT_DIRECTIONAL
+    fp = ForwardPlus(ctx, W, H, N)
+    d = torch.from_numpy(np.ascontiguousarray(depth)).to(ctx.device)
+    refs = {}
+    for name, ls in (("directional", with_dir), ("none", lights), ("directional", with_dir)):
+        if name not in refs:
+            refs[name] = oracle.light_cull(cam.frame, W, H, ls, depth)
+        fp.cull(cam.frame, upload_lights(ls, ctx.device), N, d)
+        assert_lists_equal(fp.lists_to_host(), refs[name][0], refs[name][1])
+    assert refs["directional"][0][:, 1].min() >= 3 and refs["none"][0][:, 1].mean() > 4
