@@ -828,7 +828,9 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     PROF_T(0);
     const int gx = b % groupsX, tyLocal = b / groupsX;
     const int g = (tyLocal / GROUP) * groupsX + gx;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (the wave index as a scalar: the tile's frustum -- the same 64 bytes for all lanes -- then arrives by scalar loads instead of four vector
+    // loads that occupy the CU's vector-memory pipeline for 64 lanes' worth of address processing each)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     uint32_t* sIdx = sIdxAll[wave];
     float* sImp = sImpAll[wave];
 
