@@ -498,7 +498,7 @@ def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev):
     Tx, Ty = host.num_tiles(W, H)
     fp_full.cull(cam.frame, d_lights, N, d_depth_full)
     g, _ = fp_full.lists_to_host()
-    row_entries = g[:, 1].astype(np.int64).reshape(Ty, Tx).sum(1)
+    row_entries = sdist.row_cost_entries(g[:, 1].astype(np.int64), Tx)
     out = {"config": args.config, "split": G}
 
     unroll = 0 if args.frames_in_flight == 1 else pipeline_unroll(args.steps)

@@ -25,6 +25,18 @@ def bands(width: int, height: int, world_size: int):
 # Relative cost of one tile (streaming its 256 pixels + fixed per-tile work) and of one light-list entry, from the single-GPU
 # profile of the 4K / 65 536-light frame (profiles/r01): ~4.1 ns per tile + ~0.28 ns per entry on an MI355X.
 TILE_COST, ENTRY_COST = 4.1, 0.28
+# A tile in a light cluster (>= LONG_TILE lights) costs its band far more than its entries: the cluster blocks of k1_tile_cull are the band's
+# whole cull time (24 against 6 us on an eighth of the 4K frame) and its shade goes through the split blocks.  Charged as LONG_TILE_ENTRIES
+# extra entries per such tile -- measured on the 8-way split of the 4K / 65 536-light frame (bench.py --simulate-split 8): the bands' steps
+# go from 0.059 .. 0.072 ms to 0.062 .. 0.068 ms, the predicted speed-up from 3.0x to 3.2x.
+LONG_TILE, LONG_TILE_ENTRIES = 96, 1000
+
+
+def row_cost_entries(num_per_tile, tiles_per_row: int):
+    """Per tile row: the sum of the list lengths plus the long-tile charge (what balanced_tile_rows takes as row_entries).  num_per_tile: a
+    torch or numpy integer array of rows * tiles_per_row list lengths."""
+    n = num_per_tile.reshape(-1, tiles_per_row)
+    return n.sum(1) + LONG_TILE_ENTRIES * (n >= LONG_TILE).sum(1)
 
 
 def balanced_tile_rows(row_entries, tiles_per_row: int, world_size: int):
@@ -51,8 +63,8 @@ def balanced_tile_rows(row_entries, tiles_per_row: int, world_size: int):
 
 
 def gather_row_entries(band_grid: torch.Tensor, tiles_per_row: int, band_rows: int, total_rows: int, row_begin: int, group=None):
-    """All-gather of the per-tile-row list-length sums of every rank's band -> float64 numpy [total_rows] on every rank."""
-    num = band_grid.reshape(-1, 2)[:, 1].to(torch.int64).reshape(band_rows, tiles_per_row).sum(1) if band_rows else torch.zeros(0, dtype=torch.int64, device=band_grid.device)
+    """All-gather of the per-tile-row costs (row_cost_entries) of every rank's band -> float64 numpy [total_rows] on every rank."""
+    num = row_cost_entries(band_grid.reshape(-1, 2)[:, 1].to(torch.int64), tiles_per_row) if band_rows else torch.zeros(0, dtype=torch.int64, device=band_grid.device)
     full = torch.zeros(total_rows, dtype=torch.int64, device=band_grid.device)
     full[row_begin:row_begin + band_rows] = num
     dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)

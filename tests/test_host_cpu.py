@@ -540,3 +540,19 @@ def test_csm_passes_follow_the_camera_and_light_thresholds():
         render, _, snaps = host.plan_csm_passes(masks, types, frames, snaps, view([20, 150, 0], cam_rot=yaw(2.0), light_rot=tiny))
     render, _, _ = host.plan_csm_passes(masks, types, frames, snaps, view([20, 150, 0], cam_rot=yaw(2.0), light_rot=tiny, index=3))
     assert render == [0, 1, 2, 3]
+
+
+def test_row_costs_charge_long_tiles():
+    """sailor_amd/dist.py:row_cost_entries -- a row's cost is its list volume plus LONG_TILE_ENTRIES per tile in a light cluster, in numpy and torch alike."""
+    import torch
+    from sailor_amd import dist as sdist
+    num = np.array([[3, 95, 0, 7], [96, 128, 1, 0], [0, 0, 0, 0]], np.int64)
+    want = np.array([105, 225 + 2 * sdist.LONG_TILE_ENTRIES, 0])
+    np.testing.assert_array_equal(sdist.row_cost_entries(num.reshape(-1), 4), want)
+    np.testing.assert_array_equal(sdist.row_cost_entries(torch.from_numpy(num.reshape(-1)), 4).numpy(), want)
+    # a cluster row pulls the boundary towards itself: the band that holds it gets fewer rows
+    flat = np.full((40, 10), 20, np.int64)
+    clustered = flat.copy(); clustered[5, :6] = 128
+    b0 = sdist.balanced_tile_rows(sdist.row_cost_entries(flat.reshape(-1), 10), 10, 4)
+    b1 = sdist.balanced_tile_rows(sdist.row_cost_entries(clustered.reshape(-1), 10), 10, 4)
+    assert b0 == [0, 10, 20, 30, 40] and b1[1] < b0[1]
