@@ -739,3 +739,95 @@ print("sanitized pass ok", int(idx[0]), float(rad.max()), int(np.unpackbits(v.vi
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert p.returncode == 0 and "sanitized pass ok" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
     assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]
+
+
+def _exact_coverage(tri, W, H):
+    """Which pixel centres does a triangle with vertices on the 1/256-pixel grid cover, in exact integer arithmetic, by the fill rule's DEFINITION
+    (Vulkan 1.3 spec 27.7.1 / the D3D top-left rule in a y-down framebuffer): strictly inside, or on an edge that is a top edge (horizontal, the
+    interior below it) or a left edge (not horizontal, the interior to its right) -- written orientation-free, from the third vertex's side, not
+    from a normalised winding as the oracle's raster_top_left does."""
+    cov = np.zeros((H, W), bool)
+    (ax, ay), (bx, by), (cx, cy) = tri
+    if (bx - ax) * (cy - ay) - (cx - ax) * (by - ay) == 0:
+        return cov
+    for j in range(H):
+        for i in range(W):
+            px, py = 256 * i + 128, 256 * j + 128
+            inside = True
+            for (x0, y0), (x1, y1), (x2, y2) in (((ax, ay), (bx, by), (cx, cy)), ((bx, by), (cx, cy), (ax, ay)), ((cx, cy), (ax, ay), (bx, by))):
+                side_p = (x1 - x0) * (py - y0) - (y1 - y0) * (px - x0)
+                side_c = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0)   # the interior's side of this edge
+                if side_p == 0:
+                    if y0 == y1:
+                        ok = y2 > y0                       # top edge: horizontal, interior below (larger y)
+                    else:
+                        # left edge: the interior lies towards larger x.  x of the edge line at the third vertex's height, compared exactly:
+                        # (x2 - x_edge(y2)) has the sign of ((x2 - x0) (y1 - y0) - (x1 - x0) (y2 - y0)) / (y1 - y0)
+                        num = (x2 - x0) * (y1 - y0) - (x1 - x0) * (y2 - y0)
+                        ok = (num > 0) == ((y1 - y0) > 0)
+                    if not ok:
+                        inside = False; break
+                elif (side_p > 0) != (side_c > 0):
+                    inside = False; break
+            cov[j, i] = inside
+    return cov
+
+
+def test_rasteriser_fill_rule_against_exact_arithmetic():
+    """The oracle's depth rasteriser (the thing the GPU's is bit-compared with) against the fill rule evaluated from its definition in exact integers:
+    vertices placed exactly on the 1/256-pixel grid through an identity light matrix, random and degenerate-prone triangles (axis-aligned edges
+    through pixel centres, shared edges, slivers), both windings.  Coverage must be identical; a mesh of two triangles sharing an edge covers every
+    pixel of the quad exactly once; the depth of a covered pixel is the plane's depth at its centre to float rounding."""
+    from fractions import Fraction
+    W = H = 32
+    rng = np.random.default_rng(17)
+    ident = np.eye(4, dtype=np.float32)
+
+    def to_position(X, Y, z):   # snapped window (X, Y) / 256 -> the ndc that the viewport transform maps back onto it, exactly in float32
+        return [X / (256.0 * W / 2) - 1.0, 1.0 - Y / (256.0 * H / 2), z]
+
+    def draw(tris, zs):
+        pos = np.array([to_position(X, Y, z) for tri, zz in zip(tris, zs) for (X, Y), z in zip(tri, zz)], np.float32)
+        idx = np.arange(len(pos), dtype=np.uint32).reshape(-1, 3)
+        return oracle.raster_depth(ident.T.copy(), pos, idx, ident[None].copy(), W, H)
+
+    cases = []
+    for _ in range(150):
+        kind = rng.integers(0, 4)
+        if kind == 0:    # anywhere on the fine grid
+            tri = [(int(rng.integers(0, 256 * W)), int(rng.integers(0, 256 * H))) for _ in range(3)]
+        elif kind == 1:  # vertices on pixel centres: edges run through many centres
+            tri = [(256 * int(rng.integers(0, W)) + 128, 256 * int(rng.integers(0, H)) + 128) for _ in range(3)]
+        elif kind == 2:  # an axis-aligned edge through pixel centres
+            y = 256 * int(rng.integers(1, H - 1)) + 128
+            tri = [(256 * int(rng.integers(0, W // 2)) + 128, y), (256 * int(rng.integers(W // 2, W)) + 128, y), (int(rng.integers(0, 256 * W)), int(rng.integers(0, 256 * H)))]
+        else:            # a vertical edge through pixel centres
+            x = 256 * int(rng.integers(1, W - 1)) + 128
+            tri = [(x, 256 * int(rng.integers(0, H // 2)) + 128), (x, 256 * int(rng.integers(H // 2, H)) + 128), (int(rng.integers(0, 256 * W)), int(rng.integers(0, 256 * H)))]
+        if rng.integers(0, 2):
+            tri = [tri[0], tri[2], tri[1]]
+        cases.append(tri)
+    for tri in cases:
+        zs = [float(v) for v in rng.integers(1, 255, 3) / 256.0]
+        got = draw([tri], [zs])
+        want = _exact_coverage(tri, W, H)
+        np.testing.assert_array_equal(got > 0, want, err_msg=str(tri))
+        # depth = the plane through the three vertices at the pixel centre (exact rational barycentrics), to float rounding
+        (ax, ay), (bx, by), (cx, cy) = tri
+        area = (bx - ax) * (cy - ay) - (cx - ax) * (by - ay)
+        for j, i in zip(*np.nonzero(want)):
+            px, py = 256 * int(i) + 128, 256 * int(j) + 128
+            w1 = Fraction((px - ax) * (cy - ay) - (py - ay) * (cx - ax), area)   # weight of vertex b: cross(p - a, c - a) / cross(b - a, c - a)
+            w2 = Fraction((bx - ax) * (py - ay) - (by - ay) * (px - ax), area)   # weight of vertex c: cross(b - a, p - a) / cross(b - a, c - a)
+            z = Fraction(zs[0]) + (Fraction(zs[1]) - Fraction(zs[0])) * w1 + (Fraction(zs[2]) - Fraction(zs[0])) * w2
+            assert abs(float(z) - float(got[j, i])) <= 4e-7 * max(1.0, abs(float(z))), (tri, i, j)
+    # two triangles sharing an edge: every pixel of the quad exactly once (drawn separately, coverage counted)
+    for _ in range(40):
+        q = [(int(rng.integers(0, 256 * W)), int(rng.integers(0, 256 * H))) for _ in range(4)]
+        a, b, c, d = q
+        if ((b[0] - a[0]) * (c[1] - a[1]) - (c[0] - a[0]) * (b[1] - a[1])) * ((c[0] - a[0]) * (d[1] - a[1]) - (d[0] - a[0]) * (c[1] - a[1])) <= 0:
+            continue   # not convex along the diagonal a-c: the halves would overlap or be degenerate
+        n1 = (draw([[a, b, c]], [[0.5] * 3]) > 0).astype(int)
+        n2 = (draw([[a, c, d]], [[0.5] * 3]) > 0).astype(int)
+        assert (n1 + n2).max() <= 1
+        np.testing.assert_array_equal(n1 + n2, (_exact_coverage([a, b, c], W, H) | _exact_coverage([a, c, d], W, H)).astype(int))
