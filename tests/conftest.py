@@ -42,9 +42,10 @@ def daily_tile_row(num_rows: int, fixed: int, span: int = 1) -> int:
     import datetime
     import random
     d = datetime.date.today()
-    rng = random.Random(d.year * 10000 + d.month * 100 + d.day)
+    seed = int(os.environ.get("SAILOR_DAILY_SEED", d.year * 10000 + d.month * 100 + d.day))  # (override: sweep other rows on demand)
+    rng = random.Random(seed)
     r = rng.randrange(0, num_rows - span + 1)
     if abs(r - fixed) < span:
         r = (fixed + span + 7) % (num_rows - span + 1)
-    print(f"[daily oracle row] {d.isoformat()}: tile rows {r}..{r + span - 1} of {num_rows}")
+    print(f"[daily oracle row] {d.isoformat()} (seed {seed}): tile rows {r}..{r + span - 1} of {num_rows}")
     return r
