@@ -353,9 +353,14 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         const float ndx = -q2.x, ndy = -q2.y, ndz = -q2.z;            // Li = -light.direction (:309)
         const float len = sqrtf(dot3f(ndx, ndy, ndz, ndx, ndy, ndz)); // normalize(-light.direction) (:298)
         const float linv = 1.0f / len;
-        // A zero factor only annihilates a FINITE product (inf * 0 = NaN in the reference): lights with a non-finite
-        // intensity are never skipped.
-        const bool finite = fabsf(q3.x) < __builtin_inff() && fabsf(q3.y) < __builtin_inff() && fabsf(q3.z) < __builtin_inff();
+        // A zero factor only annihilates a FINITE product (inf * 0 = NaN in the reference): a light with ANY non-finite parameter --
+        // intensity, but also position, direction, attenuation, cone or radius, which reach the product through the falloff -- is never
+        // skipped.
+#define NONFINITE(x) __builtin_amdgcn_classf((x), 0x207) /* sNaN | qNaN | -inf | +inf: one v_cmp_class each, the ORs are scalar */
+        const bool finite = !(NONFINITE(q3.x) || NONFINITE(q3.y) || NONFINITE(q3.z) || NONFINITE(q1.x) || NONFINITE(q1.y) || NONFINITE(q1.z) ||
+                              NONFINITE(q2.x) || NONFINITE(q2.y) || NONFINITE(q2.z) || NONFINITE(q4.x) || NONFINITE(q4.y) || NONFINITE(q4.z) ||
+                              NONFINITE(q5.x) || NONFINITE(q5.y) || NONFINITE(q6.x));
+#undef NONFINITE
         // Conservative "out of reach" threshold of a point light: d^2 > r^2 (1 + 1e-5) => fl(dist / r) >= 1 => the radius
         // window (:290) is exactly 0.  Only for r > 0 (a negative radius clamps to the FULL window in the reference).
         const float r = q6.x;

@@ -308,6 +308,34 @@ def test_non_finite_terms_propagate_like_the_reference(ctx):
     assert (err <= RTOL * np.abs(ref[fin]) + atol_of(ref[..., :3])).all(), err.max()
 
 
+@pytest.mark.parametrize("field", ["worldPosition", "direction", "attenuation", "cutOff", "bounds"])
+def test_non_finite_light_parameters_other_than_the_intensity(ctx, field):
+    """Found by scripts/fuzz_parity.py: a light whose POSITION is NaN makes every pixel of the tiles that list it NaN in the reference (the falloff
+    is NaN, and NaN times the zero facing factor stays NaN) -- the conservative skips may only be taken for lights that are finite in every
+    parameter that reaches the product, not just in the intensity."""
+    f = synth.make_frame("tiny")
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    lights = f.lights.copy()
+    point, spot = np.nonzero(lights["type"] == host.LIGHT_POINT)[0][:2], np.nonzero(lights["type"] == host.LIGHT_SPOT)[0][:2]
+    for k, bad in zip((point[0], spot[0], point[1], spot[1]), (np.nan, np.nan, np.inf, -np.inf)):
+        lights[field][k, 0] = bad
+    g, idx, _ = oracle.light_cull(f.cam.frame, W, H, lights, f.depth)
+    with np.errstate(all="ignore"):
+        ref = oracle.shade(f.cam.frame, W, H, f.surface, lights, g, idx)
+    fp = ForwardPlus(ctx, W, H, N)
+    l = upload_lights(lights, ctx.device)
+    fp.cull(f.cam.frame, l, N, torch.from_numpy(f.depth).to(ctx.device))
+    assert_lists = fp.lists_to_host()
+    np.testing.assert_array_equal(assert_lists[0], g)
+    got = fp.shade(f.cam.frame, torch.from_numpy(f.surface).to(ctx.device), l, N).cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_array_equal(np.isposinf(got), np.isposinf(ref))
+    np.testing.assert_array_equal(np.isneginf(got), np.isneginf(ref))
+    fin = np.isfinite(ref)
+    err = np.abs(got[fin].astype(np.float64) - ref[fin])
+    assert (err <= RTOL * np.abs(ref[fin])).all(), err.max()
+
+
 def test_c5_shade_8k(ctx):
     """BASELINE.json configs[4] on one GPU: 7680 x 4320, 1 048 576 lights.  Full-size properties -- finite everywhere, alpha passed through, exact
     doubling under doubled intensities (power-of-two scaling commutes with every rounding) -- and one tile row (16 framebuffer rows x 7 680
