@@ -486,9 +486,14 @@ def capture_frame_pipeline(side, side2, unroll, shade_fns, cull_fns):
     return g
 
 
-def pipeline_unroll(steps: int) -> int:
-    """Steps per pipeline graph: even (two list sets: a replay ends where it began) and a divisor of K (the timed region is exactly K steps); 0 = none."""
-    return next((u for u in (16, 14, 12, 10, 8, 6, 4, 2) if steps % u == 0), 0)
+def pipeline_unroll(steps: int):
+    """(U, r): the K timed steps are K // U replays of a U-step pipeline graph (U even: with two list sets a replay ends where it began) plus one
+    replay of an r-step graph for the rest, so that the timed region is exactly K steps whatever K is.  U = 0: only the tail graph (K = 1)."""
+    u = next((u for u in (16, 14, 12, 10, 8, 6, 4, 2) if steps % u == 0), 0)
+    if u:
+        return u, 0
+    u = 10 if steps >= 10 else (steps - 1 if steps >= 3 else 0)
+    return u, steps - (steps // u) * u if u else steps
 
 
 def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev):
@@ -501,7 +506,7 @@ def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev):
     row_entries = sdist.row_cost_entries(g[:, 1].astype(np.int64), Tx)
     out = {"config": args.config, "split": G}
 
-    unroll = 0 if args.frames_in_flight == 1 else pipeline_unroll(args.steps)
+    unroll = 0 if args.frames_in_flight == 1 else pipeline_unroll(args.steps)[0]
     side = torch.cuda.current_stream()
     side2 = torch.cuda.Stream(device=dev)
     ctx2 = HipContext(dev, stream=side2)
@@ -672,10 +677,9 @@ def main():
     # cull(k), cull(k + 1) for shade(k - 1) (it overwrites the list set that frame read).  One fork / join per STEP -- round 1's form, two graphs of
     # one step each -- makes every step last as long as the longer of its two branches plus the join (0.2335 ms); without it the chain of cull
     # kernels slides under the neighbouring shades (0.219 ms, measured first with eager launches on two streams: scripts/cu_mask_probe.py).
-    # unroll is even (two list sets: a replay must end where it began) and divides K, so the timed region is exactly K steps.
-    unroll = pipeline_unroll(args.steps)
-    if pipelined and unroll == 0:
-        pipelined = False  # an odd K: one frame in flight (the JSON line says so)
+    # The main graph's length is even (two list sets: a replay ends where it began); a K that no even length divides gets a second, shorter graph
+    # for the rest, so the timed region is exactly K steps (pipeline_unroll).
+    unroll, tail = pipeline_unroll(args.steps)
     if pipelined:
         try:
             side2 = torch.cuda.Stream(device=dev)
@@ -686,10 +690,10 @@ def main():
                 f.cull(cam.frame, d_lights, N, d_depth)
                 f.shade(cam.frame, d_surface, d_lights, N, csm)
             torch.cuda.synchronize()
-            g = capture_frame_pipeline(side, side2, unroll,
-                                       [lambda f=f: f.shade(cam.frame, d_surface, d_lights, N, csm) for f in fps],
-                                       [lambda f=f: f.cull(cam.frame, d_lights, N, d_depth, ctx=ctx2) for f in fps])
-            graphs.append(g)
+            for length in (unroll, tail):
+                graphs.append(capture_frame_pipeline(side, side2, length,
+                                                     [lambda f=f: f.shade(cam.frame, d_surface, d_lights, N, csm) for f in fps],
+                                                     [lambda f=f: f.cull(cam.frame, d_lights, N, d_depth, ctx=ctx2) for f in fps]) if length else None)
             fps[0].cull(cam.frame, d_lights, N, d_depth)                     # prologue: frame 0's lists
             torch.cuda.synchronize()
         except Exception as e:
@@ -708,18 +712,22 @@ def main():
             graph = None
             torch.cuda.synchronize()
 
-    # a "run" is `per_run` steps: the unrolled pipeline graph, or one step of the other forms
-    per_run = unroll if pipelined else 1
+    # a "run" is `per_run` steps: the main pipeline graph, or one step of the other forms; `finish()` is the pipeline's shorter graph for the rest of K
+    per_run = (unroll if unroll else tail) if pipelined else 1
 
     def run():
         if pipelined:
-            graphs[0].replay()
+            (graphs[0] if graphs[0] is not None else graphs[1]).replay()
         elif graph is not None:
             graph.replay()
         else:
             step()
 
-    # Clock spin-up (untimed, before the W warm-up steps): K steps of a 0.23 ms frame are over in a few milliseconds, less than the GPU
+    def finish():
+        if pipelined and graphs[0] is not None and graphs[1] is not None:
+            graphs[1].replay()
+
+    # Clock spin-up (untimed, before the W warm-up steps): K steps of a 0.22 ms frame are over in a few milliseconds, less than the GPU
     # needs to leave its idle power state -- a renderer runs continuously, so the steady state is what the K timed steps should see.
     if args.spinup_ms > 0:
         t_spin = time.perf_counter()
@@ -733,6 +741,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps // per_run):
         run()
+    finish()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -924,7 +933,7 @@ def main():
         out = {
             "metric": "lit Mpixels/s (K0+K1 tile light cull + K2 PBR shade over per-tile lists)", "value": value, "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_ms": args.spinup_ms, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak" if weak else "strong", "launch": f"hipGraph replay ({unroll} steps of the frame pipeline per graph), 2 frames in flight" if pipelined else ("hipGraph replay" if graph is not None else "eager"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if weak else "strong", "launch": f"hipGraph replay ({per_run} steps of the frame pipeline per graph" + (f", {tail} in the last" if unroll and tail else "") + "), 2 frames in flight" if pipelined else ("hipGraph replay" if graph is not None else "eager"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H}, {N} point+spot lights, 16x16 tiles ({fp.Tx}x{fp.Ty}), cull + PBR shade"
                                    + (" + 4-cascade CSM" if csm is not None else ""),
                        "width": W, "height": H, "lights": N, "parallelism": (f"dp{world}: a whole frame per GPU" if weak else f"tile-row bands x{world}"), "partition": partition,

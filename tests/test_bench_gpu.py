@@ -25,6 +25,7 @@ def test_default_line_carries_the_contract():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert key in d, key
     assert d["unit"] == "Mpixels/s" and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert "4 steps of the frame pipeline per graph, 1 in the last" in d["launch"]   # an odd K: exactly K steps all the same
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and d["scaling"] in ("weak", "strong")
     assert d["config"]["workload"].startswith("C3: 3840x2160, 65536 ") and "model" not in d["config"]
     assert abs(d["value"] - 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
