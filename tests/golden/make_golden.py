@@ -49,6 +49,12 @@ def make_depth() -> None:
     print(f"tiny_depth: {raw.shape[1]}x{raw.shape[0]}, {(raw == 0).mean():.3f} sky, linear range [{lin[np.isfinite(lin)].min():.3f}, {lin[np.isfinite(lin)].max():.3e}]")
 
 
+# what the stored radiance was sampled with -- NOT the reference's samplers ("what's weak" 11)
+SAMPLER_NOTE = ("canonical sampler of oracle/sailor_oracle.c, self-defined: fp32 texels, cube face and (s, t) by the Vulkan major-axis table (ties z over y over x), "
+                "bilinear inside the face with clamp-to-edge, linear between the two nearest mips, lod clamped to [0, levels - 1].  The reference samples RGBA16F "
+                "images through driver-defined Vulkan samplers; its cubemap bakes accumulate sequentially, the GPU's by a fixed tree (tolerance-checked).")
+
+
 def make_ibl() -> None:
     """Ambient term: the oracle's ComputeBrdfLut table (32x32) and the tiny frame shaded with the synthetic
     IBL set (the cubemaps / AO regenerate from the frozen generator, so only the table and the result are stored)."""
@@ -60,7 +66,8 @@ def make_ibl() -> None:
     oibl, _keep = oracle.make_ibl(ibl.irradiance, ibl.env_chain, ibl.env_size, ibl.env_levels, ibl.brdf_lut, ibl.ao)
     rad = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, g, idx, ibl=oibl)
     np.savez_compressed(OUT / "tiny_ibl.npz", brdf_lut=lut, radiance=rad, env_checksum=np.float64(ibl.env_chain.astype(np.float64).sum()),
-                        irr_checksum=np.float64(ibl.irradiance.astype(np.float64).sum()), ao_checksum=np.float64(ibl.ao.astype(np.float64).sum()))
+                        irr_checksum=np.float64(ibl.irradiance.astype(np.float64).sum()), ao_checksum=np.float64(ibl.ao.astype(np.float64).sum()),
+                        sampler=np.array(SAMPLER_NOTE))
     print(f"tiny_ibl: lut range [{lut.min():.4f}, {lut.max():.4f}], mean radiance {rad[..., :3].mean():.3f}")
 
 
