@@ -405,24 +405,23 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         if ((uint32_t)(h * 64) >= numLights) break;
+        // (every condition as a wave mask of ONE simple compare, the combinations as scalar mask arithmetic: a bool that is assigned in branches
+        // lives in a VGPR as 0 / 1 and costs a v_cndmask + v_cmp per use)
         const uint32_t li = (uint32_t)(h * 64 + lane);
-        bool keep = false;
-        uint32_t bits = 0x10000u;
-        if (li < numLights) {
-            const float4 c0 = sL[li * LREC + 0];
-            bits = __float_as_uint(sL[li * LREC + 1].w);
-            keep = true;
-            if ((bits & 0xFFu) == 1u && forceMask == 0ull) {
-                const float ex = c0.x - scx, ey = c0.y - scy, ez = c0.z - scz;
-                const float t = __builtin_amdgcn_sqrtf(c0.w) * 1.0001f + sphereR; // c0.w = r^2 (1 + 1e-5) (+inf: never reject)
-                keep = !(fmaf(ex, ex, fmaf(ey, ey, ez * ez)) > t * t);
-            }
-        }
-        const bool fin = (bits & 0x10000u) != 0u;
-        const unsigned long long all = __ballot(keep);
-        seg[h] = __ballot(keep && fin && (bits & 0xFFu) == 1u);
-        seg[2 + h] = __ballot(keep && fin && (bits & 0xFFu) == 2u);
-        seg[6 + h] = __ballot(li < numLights && (bits & 0xFFu) == 0u);
+        const uint32_t lc = li < numLights ? li : 0u; // (lanes past the list read slot 0 and are masked out)
+        const float4 c0 = sL[lc * LREC + 0];
+        const uint32_t bits = __float_as_uint(sL[lc * LREC + 1].w);
+        const unsigned long long mIn = __ballot(li < numLights);
+        const unsigned long long mFin = __ballot((bits & 0x10000u) != 0u);
+        const unsigned long long mPoint = __ballot((bits & 0xFFu) == 1u), mSpot = __ballot((bits & 0xFFu) == 2u), mDir = __ballot((bits & 0xFFu) == 0u);
+        const float ex = c0.x - scx, ey = c0.y - scy, ez = c0.z - scz;
+        const float t = __builtin_amdgcn_sqrtf(c0.w) * 1.0001f + sphereR; // c0.w = r^2 (1 + 1e-5) (+inf: never reject)
+        const unsigned long long mFar = __ballot(fmaf(ex, ex, fmaf(ey, ey, ez * ez)) > t * t); // only meaningful for finite point lights
+        const unsigned long long dropped = forceMask == 0ull ? (mPoint & mFin & mFar) : 0ull;
+        const unsigned long long all = mIn & ~dropped;
+        seg[h] = all & mFin & mPoint;
+        seg[2 + h] = all & mFin & mSpot;
+        seg[6 + h] = mIn & mDir;
         seg[4 + h] = all & ~(seg[h] | seg[2 + h] | seg[6 + h]);
     }
 
