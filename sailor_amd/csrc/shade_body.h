@@ -299,7 +299,8 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const int gx = tx * TILE + (quad & 1) * 8 + (lane & 7);
     const int gy = ty * TILE + (quad >> 1) * 8 + (lane >> 3);
     const int py = A.H - 1 - gy;            // framebuffer row (Standard.shader:414: screenUv.y = H - fragY)
-    const bool active = gx < A.W && py >= 0;
+    const unsigned long long activeMask = __ballot(gx < A.W && py >= 0); // (the mask first, the per-lane flag from it: the other way round costs a VGPR 0 / 1 per use)
+    const bool active = __builtin_amdgcn_inverse_ballot_w64(activeMask);
     const size_t pix = active ? ((size_t)(py - A.fbRow0) * A.W + gx) : 0;
 
     // Prologue, ordered by what waits for what.  The list is a chain of three dependent round trips (grid entry -> culledLights indices -> light
@@ -397,8 +398,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         const float d2c = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
         sphereR = __builtin_amdgcn_sqrtf(__uint_as_float(wave_max_u32(active ? __float_as_uint(d2c) : 0u))) * 1.0001f;
     }
-    const unsigned long long activeMask = __ballot(active);
-    const unsigned long long forceMask = __ballot(active && !brdfFinite); // such pixels must see every light (0 * NaN)
+    const unsigned long long forceMask = activeMask & __ballot(!(alphaSq > 0.0f)); // roughness 0: such pixels must see every light (0 * NaN)
     // survivors by kind: [0,1] finite point lights, [2,3] finite spot lights, [4,5] the rest (directional, unknown type,
     // non-finite intensity: every pixel is a pair) -- for list slots 0..63 and 64..127
     unsigned long long seg[8] = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull }; // [6,7]: directional lights (type 0), see the loop behind the queue
@@ -474,7 +474,8 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                     }
                     if (m != 0ull) {
                         const bool mine = __builtin_amdgcn_inverse_ballot_w64(m); // exec = m: no per-lane bit test
-                        if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || __ballot(mine && pc >= (uint32_t)PENDK) != 0ull) { overflow = true; break; }
+                        // (masks of single compares combined as scalars: a ballot of `mine && ...` goes through a VGPR 0 / 1 and back)
+                        if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= (uint32_t)PENDK)) != 0ull) { overflow = true; break; }
                         if (mine) {
                             const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                             Q[pos] = (uint16_t)((uint32_t)lane | (s << 6) | (pc << 13));
