@@ -440,7 +440,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     float* res = sRes + tid - lane; // this wave's [3 colours][PENDK][64 pixels] slots, 256 floats apart
     for (;;) {
         uint32_t cnt = 0u;      // queued pairs (wave-uniform)
-        uint32_t pc = 0u;       // this pixel's queued pairs
+        uint32_t pc = (uint32_t)lane; // this pixel's queued pairs, kept as (pairs << 13) | lane: the queue entry is one v_or3 with the light's slot
         bool overflow = false;
 #pragma unroll
         for (int kind = 0; kind < 3 && !overflow; kind++) {
@@ -475,11 +475,11 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                     if (m != 0ull) {
                         const bool mine = __builtin_amdgcn_inverse_ballot_w64(m); // exec = m: no per-lane bit test
                         // (masks of single compares combined as scalars: a ballot of `mine && ...` goes through a VGPR 0 / 1 and back)
-                        if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= (uint32_t)PENDK)) != 0ull) { overflow = true; break; }
+                        if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= ((uint32_t)PENDK << 13))) != 0ull) { overflow = true; break; }
                         if (mine) {
-                            const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            Q[pos] = (uint16_t)((uint32_t)lane | (s << 6) | (pc << 13));
-                            pc++;
+                            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, cnt)); // (the count so far rides in as mbcnt's addend)
+                            Q[pos] = (uint16_t)(pc | (s << 6));
+                            pc += 1u << 13;
                         }
                         cnt += (uint32_t)__popcll(m);
                     }
@@ -572,8 +572,8 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         // each pixel adds up the results of its own pairs, in the order they were queued
 #pragma unroll
         for (uint32_t j = 0; j < (uint32_t)PENDK; j++) {
-            if (__ballot(pc > j) == 0ull) break;
-            if (pc > j) {
+            if (__ballot(pc >= ((j + 1u) << 13)) == 0ull) break;
+            if (pc >= ((j + 1u) << 13)) {
                 accX += res[j * 256u + lane];
                 accY += res[(PENDK + j) * 256u + lane];
                 accZ += res[(2 * PENDK + j) * 256u + lane];
