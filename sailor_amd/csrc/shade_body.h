@@ -483,7 +483,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                         }
                         cnt += (uint32_t)__popcll(m);
                     }
-                    todo &= todo - 1ull;
+                    asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction instead of three
                 }
                 seg[kind * 2 + h] = todo; // what the next window still has to look at
             }
