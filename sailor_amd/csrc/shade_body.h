@@ -5,6 +5,7 @@
 #include "common.h"
 #include "sampling.h"
 #include <hip/hip_fp16.h>
+#include <type_traits>
 
 struct CsmArgs {
     Mat4 lightsMatrices[SAILOR_NUM_CSM_CASCADES];
@@ -441,53 +442,61 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     for (;;) {
         uint32_t cnt = 0u;      // queued pairs (wave-uniform)
         uint32_t pc = (uint32_t)lane; // this pixel's queued pairs, kept as (pairs << 13) | lane: the queue entry is one v_or3 with the light's slot
-        bool overflow = false;
+        // The wave is bound by instruction issue of every kind (a scalar instruction costs what a vector one costs: measured), and the loop
+        // around a light is mostly scalar mask arithmetic.  In the usual quadrant -- every pixel inside the frame, none with roughness 0 -- the
+        // "force" and "active" masks are the identity, so that case gets its own copy of the loops without them (PLAIN): m = reach & facing.
+        auto fill_window = [&](auto plainTag) -> bool {
+            constexpr bool PLAIN = decltype(plainTag)::value;
+            bool overflow = false;
 #pragma unroll
-        for (int kind = 0; kind < 3 && !overflow; kind++) {
+            for (int kind = 0; kind < 3 && !overflow; kind++) {
 #pragma unroll
-            for (int h = 0; h < 2 && !overflow; h++) {
-                unsigned long long todo = seg[kind * 2 + h];
-                while (todo) {
-                    const int bit = __builtin_ctzll(todo);
-                    const uint32_t s = (uint32_t)(h * 64 + bit);
-                    unsigned long long m = activeMask; // "the rest": every pixel is a pair
-                    if (kind < 2) {
-                        const float4* R = sL + s * LREC;
-                        const float4 r0 = R[0];
-                        const v2f dxy = v2f{ r0.x, r0.y } - wxy;
-                        const float dz = r0.z - wz;
-                        const float d2 = fmaf(dxy.x, dxy.x, fmaf(dxy.y, dxy.y, dz * dz));
-                        float v = d2;
-                        if (kind == 1) {
-                            // spot: falloff is exactly 0 iff theta < cutOff.y (:303-306); theta ~ dot(d, axis) / |d| to a few ulp
-                            const float4 r1 = R[1];
-                            v = -(fmaf(dxy.x, r1.x, fmaf(dxy.y, r1.y, dz * r1.z)) * rsq_fast(d2));
+                for (int h = 0; h < 2 && !overflow; h++) {
+                    unsigned long long todo = seg[kind * 2 + h];
+                    while (todo) {
+                        const int bit = __builtin_ctzll(todo);
+                        const uint32_t s = (uint32_t)(h * 64 + bit);
+                        unsigned long long m = activeMask; // "the rest": every pixel is a pair
+                        if (kind < 2) {
+                            const float4* R = sL + s * LREC;
+                            const float4 r0 = R[0];
+                            const v2f dxy = v2f{ r0.x, r0.y } - wxy;
+                            const float dz = r0.z - wz;
+                            const float d2 = fmaf(dxy.x, dxy.x, fmaf(dxy.y, dxy.y, dz * dz));
+                            float v = d2;
+                            if (kind == 1) {
+                                // spot: falloff is exactly 0 iff theta < cutOff.y (:303-306); theta ~ dot(d, axis) / |d| to a few ulp
+                                const float4 r1 = R[1];
+                                v = -(fmaf(dxy.x, r1.x, fmaf(dxy.y, r1.y, dz * r1.z)) * rsq_fast(d2));
+                            }
+                            const unsigned long long reach = __ballot(!(v > r0.w));
+                            m = 0ull;
+                            if ((PLAIN ? reach : ((reach | forceMask) & activeMask)) != 0ull) {
+                                // ... and facing it?  cosLi = max(0, n . Li) = 0 zeroes both the specular G term and the final product.
+                                const float4 r3 = R[3];
+                                const unsigned long long facing = __ballot(dot3f(nx, ny, nz, r3.x, r3.y, r3.z) > 0.0f);
+                                m = PLAIN ? (reach & facing) : (((reach & facing) | forceMask) & activeMask);
+                            }
                         }
-                        const unsigned long long reach = __ballot(!(v > r0.w));
-                        m = 0ull;
-                        if (((reach | forceMask) & activeMask) != 0ull) {
-                            // ... and facing it?  cosLi = max(0, n . Li) = 0 zeroes both the specular G term and the final product.
-                            const float4 r3 = R[3];
-                            const unsigned long long facing = __ballot(dot3f(nx, ny, nz, r3.x, r3.y, r3.z) > 0.0f);
-                            m = ((reach & facing) | forceMask) & activeMask;
+                        if (m != 0ull) {
+                            const bool mine = __builtin_amdgcn_inverse_ballot_w64(m); // exec = m: no per-lane bit test
+                            // (masks of single compares combined as scalars: a ballot of `mine && ...` goes through a VGPR 0 / 1 and back)
+                            if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= ((uint32_t)PENDK << 13))) != 0ull) { overflow = true; break; }
+                            if (mine) {
+                                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, cnt)); // (the count so far rides in as mbcnt's addend)
+                                Q[pos] = (uint16_t)(pc | (s << 6));
+                                pc += 1u << 13;
+                            }
+                            cnt += (uint32_t)__popcll(m);
                         }
+                        asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction instead of three
                     }
-                    if (m != 0ull) {
-                        const bool mine = __builtin_amdgcn_inverse_ballot_w64(m); // exec = m: no per-lane bit test
-                        // (masks of single compares combined as scalars: a ballot of `mine && ...` goes through a VGPR 0 / 1 and back)
-                        if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= ((uint32_t)PENDK << 13))) != 0ull) { overflow = true; break; }
-                        if (mine) {
-                            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, cnt)); // (the count so far rides in as mbcnt's addend)
-                            Q[pos] = (uint16_t)(pc | (s << 6));
-                            pc += 1u << 13;
-                        }
-                        cnt += (uint32_t)__popcll(m);
-                    }
-                    asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction instead of three
+                    seg[kind * 2 + h] = todo; // what the next window still has to look at
                 }
-                seg[kind * 2 + h] = todo; // what the next window still has to look at
             }
-        }
+            return overflow;
+        };
+        const bool overflow = (forceMask == 0ull && activeMask == ~0ull) ? fill_window(std::true_type{}) : fill_window(std::false_type{});
         if (cnt == 0u) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (uint32_t base = 0u; base < cnt; base += 64u) {
