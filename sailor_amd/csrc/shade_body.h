@@ -438,6 +438,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     // [its ordinal among the pixel's queued pairs][pixel], which the pixel's own lane adds up afterwards: no atomics
     // (ds_add_f32 is serialised per lane on this LDS: ~170 cycles per wave instruction, scripts/microbench/lds_ops.hip).
     uint16_t* Q = sQ + wave * QMAX;
+    const uint32_t qAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)Q; // its LDS byte address, for the hand-written append below
     float* res = sRes + tid - lane; // this wave's [3 colours][PENDK][64 pixels] slots, 256 floats apart
     for (;;) {
         uint32_t cnt = 0u;      // queued pairs (wave-uniform)
@@ -453,7 +454,10 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
 #pragma unroll
                 for (int h = 0; h < 2 && !overflow; h++) {
                     unsigned long long todo = seg[kind * 2 + h];
-                    while (todo) {
+                    // (one way out of the loop, at its bottom: with a `break` in the middle the loop is no single-exit region of its own, falls into
+                    // the region of the divergent pair pass below and is structurised along with it -- see the append)
+                    bool go = todo != 0ull;
+                    while (go) {
                         const int bit = __builtin_ctzll(todo);
                         const uint32_t s = (uint32_t)(h * 64 + bit);
                         unsigned long long m = activeMask; // "the rest": every pixel is a pair
@@ -479,17 +483,33 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                             }
                         }
                         if (m != 0ull) {
-                            const bool mine = __builtin_amdgcn_inverse_ballot_w64(m); // exec = m: no per-lane bit test
                             // (masks of single compares combined as scalars: a ballot of `mine && ...` goes through a VGPR 0 / 1 and back)
-                            if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= ((uint32_t)PENDK << 13))) != 0ull) { overflow = true; break; }
-                            if (mine) {
-                                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, cnt)); // (the count so far rides in as mbcnt's addend)
-                                Q[pos] = (uint16_t)(pc | (s << 6));
-                                pc += 1u << 13;
+                            overflow = cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= ((uint32_t)PENDK << 13))) != 0ull;
+                            if (!overflow) {
+                            // The lanes of m append (pc | s << 6) to the queue and count the pair.  Written out with the exec mask set by hand: as
+                            // `if (lane in m) { ... }` this is the only divergent branch of the loops around it, and with it the compiler
+                            // structurises them -- a state variable, three more branches and five more scalar instructions per light.  Every
+                            // lane is live here (the waves are full and nothing above has diverged), so exec goes back to all ones.
+                            {
+                                uint32_t t0, t1;
+                                asm volatile("s_mov_b64 exec, %[m]\n\t"
+                                             "v_mov_b32 %[t0], %[cnt]\n\t"
+                                             "v_mbcnt_lo_u32_b32 %[t0], %[mlo], %[t0]\n\t"
+                                             "v_mbcnt_hi_u32_b32 %[t0], %[mhi], %[t0]\n\t"   // the count so far rides in as mbcnt's addend
+                                             "v_lshl_add_u32 %[t0], %[t0], 1, %[q]\n\t"
+                                             "v_lshl_or_b32 %[t1], %[s], 6, %[pc]\n\t"
+                                             "ds_write_b16 %[t0], %[t1]\n\t"
+                                             "v_add_u32 %[pc], 0x2000, %[pc]\n\t"
+                                             "s_mov_b64 exec, -1"
+                                             : [t0] "=&v"(t0), [t1] "=&v"(t1), [pc] "+v"(pc)
+                                             : [m] "s"(m), [mlo] "s"((uint32_t)m), [mhi] "s"((uint32_t)(m >> 32)), [cnt] "s"(cnt), [s] "s"(s), [q] "v"(qAddr)
+                                             : "memory");
                             }
                             cnt += (uint32_t)__popcll(m);
+                            }
                         }
-                        asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction instead of three
+                        if (!overflow) asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction instead of three
+                        go = !overflow && todo != 0ull;
                     }
                     seg[kind * 2 + h] = todo; // what the next window still has to look at
                 }
