@@ -456,8 +456,8 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                     unsigned long long todo = seg[kind * 2 + h];
                     // (one way out of the loop, at its bottom: with a `break` in the middle the loop is no single-exit region of its own, falls into
                     // the region of the divergent pair pass below and is structurised along with it -- see the append)
-                    bool go = todo != 0ull;
-                    while (go) {
+                    unsigned long long rest = 0ull; // on overflow: what is left, this light included
+                    while (todo) {
                         const int bit = __builtin_ctzll(todo);
                         const uint32_t s = (uint32_t)(h * 64 + bit);
                         unsigned long long m = activeMask; // "the rest": every pixel is a pair
@@ -484,8 +484,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                         }
                         if (m != 0ull) {
                             // (masks of single compares combined as scalars: a ballot of `mine && ...` goes through a VGPR 0 / 1 and back)
-                            overflow = cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= ((uint32_t)PENDK << 13))) != 0ull;
-                            if (!overflow) {
+                            if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= ((uint32_t)PENDK << 13))) != 0ull) { rest = todo; todo = 0ull; continue; }
                             // The lanes of m append (pc | s << 6) to the queue and count the pair.  Written out with the exec mask set by hand: as
                             // `if (lane in m) { ... }` this is the only divergent branch of the loops around it, and with it the compiler
                             // structurises them -- a state variable, three more branches and five more scalar instructions per light.  Every
@@ -506,12 +505,11 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                                              : "memory");
                             }
                             cnt += (uint32_t)__popcll(m);
-                            }
                         }
-                        if (!overflow) asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction instead of three
-                        go = !overflow && todo != 0ull;
+                        asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction instead of three
                     }
-                    seg[kind * 2 + h] = todo; // what the next window still has to look at
+                    seg[kind * 2 + h] = rest; // what the next window still has to look at
+                    overflow = rest != 0ull;
                 }
             }
             return overflow;
