@@ -260,6 +260,85 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // their partial sums up through LDS (wave 0 + 1 + 2 + 3, a fixed order).  The grid is 1-D: SPLIT_BLOCKS split blocks first (they
 // walk the long tiles with a grid stride, so the long tiles start first), then one ordinary block per tile, which returns at
 // once if the tile belongs to the split blocks.
+// The loop over the point / spot lights of one list half that may reach a quadrant, for the usual quadrant (every pixel inside the frame, none
+// with roughness 0), by hand: the wave is bound by instruction issue -- a scalar instruction costs what a vector one costs -- and the
+// compiler's version of this loop spends more instructions on getting around it than on the tests.  Per light: the conservative reach test on
+// rec0 (and rec1 for a cone), out if no pixel passes; the facing test on rec3, out if no pixel passes both; the two overflow checks (queue,
+// pairs per pixel), which end the window with the light still in `rest`; the append of (pairs << 13 | slot << 6 | lane) for the lanes that
+// passed, exec set to them.  Registers v56-v62 hold rec0 and rec1 / rec3 (inline assembly cannot name the parts of a register tuple, so the
+// tuples are fixed ones); everything else is the compiler's choice.  Hazards (the compiler does not look inside): a v_pk result is not
+// read by the next instruction, a v_rsq result not by the next one either (s_nop).  The arithmetic is instruction for instruction what the
+// C++ loop beside it compiles to.
+#define SHADE_TEST_POINT \
+    "v_mul_f32 v58, v58, v58\n\t" \
+    "v_fmac_f32 v58, v57, v57\n\t" \
+    "v_fmac_f32 v58, v56, v56\n\t" \
+    "v_cmp_ngt_f32 vcc, v58, v59\n\t"
+#define SHADE_TEST_SPOT \
+    "v_mul_f32 %[t1], v58, v58\n\t" \
+    "v_mul_f32 v62, v58, v62\n\t" \
+    "v_fmac_f32 %[t1], v57, v57\n\t" \
+    "v_fmac_f32 v62, v57, v61\n\t" \
+    "v_fmac_f32 %[t1], v56, v56\n\t" \
+    "v_fmac_f32 v62, v56, v60\n\t" \
+    "v_rsq_f32 %[t1], %[t1]\n\t" \
+    "s_nop 0\n\t" \
+    "v_mul_f32_e64 v62, -v62, %[t1]\n\t" \
+    "v_cmp_ngt_f32 vcc, v62, v59\n\t"
+#define SHADE_LIGHT_LOOP(H_LINE, LOADS, TEST) \
+    asm volatile("s_mov_b64 %[ex], exec\n" \
+                 "0:\n\t" \
+                 "s_ff1_i32_b64 %[bit], %[todo]\n\t" \
+                 H_LINE \
+                 "v_mad_u32_u24 %[t0], %[bit], %[v80], %[base]\n\t" \
+                 "ds_read_b128 v[56:59], %[t0]\n\t" \
+                 LOADS \
+                 "s_waitcnt lgkmcnt(0)\n\t" \
+                 "v_pk_add_f32 v[56:57], v[56:57], %[wxy] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+                 "v_sub_f32 v58, v58, %[wz]\n\t" \
+                 TEST \
+                 "s_cbranch_vccz 2f\n\t" \
+                 "ds_read_b96 v[60:62], %[t0] offset:48\n\t" \
+                 "s_waitcnt lgkmcnt(0)\n\t" \
+                 "v_mul_f32 v60, %[nx], v60\n\t" \
+                 "v_mul_f32 v61, %[ny], v61\n\t" \
+                 "v_mul_f32 v62, %[nz], v62\n\t" \
+                 "v_add_f32 v60, v60, v61\n\t" \
+                 "v_add_f32 v60, v60, v62\n\t" \
+                 "v_cmp_lt_f32_e64 %[m], 0, v60\n\t" \
+                 "s_and_b64 vcc, %[m], vcc\n\t" \
+                 "s_cbranch_scc0 2f\n\t" \
+                 "s_bcnt1_i32_b64 %[n], vcc\n\t" \
+                 "s_add_i32 %[n], %[n], %[cnt]\n\t" \
+                 "s_cmp_gt_u32 %[n], %[qmax]\n\t" \
+                 "s_cbranch_scc1 1f\n\t" \
+                 "v_cmp_lt_u32_e64 %[m], %[lim], %[pc]\n\t" \
+                 "s_and_b64 %[m], %[m], vcc\n\t" \
+                 "s_cbranch_scc1 1f\n\t" \
+                 "s_mov_b64 exec, vcc\n\t" \
+                 "v_mov_b32 %[t0], %[cnt]\n\t" \
+                 "v_mbcnt_lo_u32_b32 %[t0], vcc_lo, %[t0]\n\t" \
+                 "v_mbcnt_hi_u32_b32 %[t0], vcc_hi, %[t0]\n\t" \
+                 "v_lshl_add_u32 %[t0], %[t0], 1, %[q]\n\t" \
+                 "v_lshl_or_b32 %[t1], %[bit], 6, %[pc]\n\t" \
+                 "ds_write_b16 %[t0], %[t1]\n\t" \
+                 "v_add_u32 %[pc], 0x2000, %[pc]\n\t" \
+                 "s_mov_b64 exec, %[ex]\n\t" \
+                 "s_mov_b32 %[cnt], %[n]\n" \
+                 "2:\n\t" \
+                 "s_bitset0_b64 %[todo], %[bit]\n\t" \
+                 "s_cmp_lg_u64 %[todo], 0\n\t" \
+                 "s_cbranch_scc1 0b\n\t" \
+                 "s_branch 3f\n" \
+                 "1:\n\t" \
+                 "s_mov_b64 %[rest], %[todo]\n" \
+                 "3:" \
+                 : [todo] "+s"(todo), [cnt] "+s"(cnt), [pc] "+v"(pc), [rest] "+s"(rest), [bit] "=&s"(bit), [n] "=&s"(n), [m] "=&s"(m), [ex] "=&s"(ex), \
+                   [t0] "=&v"(t0), [t1] "=&v"(t1) \
+                 : [wxy] "v"(wxy), [wz] "v"(wz), [nx] "v"(nx), [ny] "v"(ny), [nz] "v"(nz), [q] "v"(qAddr), [v80] "v"(recBytes), [base] "v"(sLAddr), \
+                   [lim] "s"(((uint32_t)PENDK << 13) - 1u), [qmax] "n"(QMAX) \
+                 : "v56", "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc", "memory")
+
 #define SPLIT_MIN 40      // == CLASS_B of light_cull.hip: the hint's first two classes
 #define SPLIT_BLOCKS 2048 // one round of resident blocks (8 per CU)
 struct ShadeLds {
@@ -439,6 +518,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     // (ds_add_f32 is serialised per lane on this LDS: ~170 cycles per wave instruction, scripts/microbench/lds_ops.hip).
     uint16_t* Q = sQ + wave * QMAX;
     const uint32_t qAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)Q; // its LDS byte address, for the hand-written append below
+    const uint32_t sLAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)sL, recBytes = LREC * 16u;
     float* res = sRes + tid - lane; // this wave's [3 colours][PENDK][64 pixels] slots, 256 floats apart
     for (;;) {
         uint32_t cnt = 0u;      // queued pairs (wave-uniform)
@@ -446,73 +526,82 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         // The wave is bound by instruction issue of every kind (a scalar instruction costs what a vector one costs: measured), and the loop
         // around a light is mostly scalar mask arithmetic.  In the usual quadrant -- every pixel inside the frame, none with roughness 0 -- the
         // "force" and "active" masks are the identity, so that case gets its own copy of the loops without them (PLAIN): m = reach & facing.
-        auto fill_window = [&](auto plainTag) -> bool {
+        auto light_loop = [&](auto plainTag, auto kindTag, auto hTag) -> bool {
             constexpr bool PLAIN = decltype(plainTag)::value;
-            bool overflow = false;
-#pragma unroll
-            for (int kind = 0; kind < 3 && !overflow; kind++) {
-#pragma unroll
-                for (int h = 0; h < 2 && !overflow; h++) {
-                    unsigned long long todo = seg[kind * 2 + h];
-                    // (one way out of the loop, at its bottom: with a `break` in the middle the loop is no single-exit region of its own, falls into
-                    // the region of the divergent pair pass below and is structurised along with it -- see the append)
-                    unsigned long long rest = 0ull; // on overflow: what is left, this light included
-                    while (todo) {
-                        const int bit = __builtin_ctzll(todo);
-                        const uint32_t s = (uint32_t)(h * 64 + bit);
-                        unsigned long long m = activeMask; // "the rest": every pixel is a pair
-                        if (kind < 2) {
-                            const float4* R = sL + s * LREC;
-                            const float4 r0 = R[0];
-                            const v2f dxy = v2f{ r0.x, r0.y } - wxy;
-                            const float dz = r0.z - wz;
-                            const float d2 = fmaf(dxy.x, dxy.x, fmaf(dxy.y, dxy.y, dz * dz));
-                            float v = d2;
-                            if (kind == 1) {
-                                // spot: falloff is exactly 0 iff theta < cutOff.y (:303-306); theta ~ dot(d, axis) / |d| to a few ulp
-                                const float4 r1 = R[1];
-                                v = -(fmaf(dxy.x, r1.x, fmaf(dxy.y, r1.y, dz * r1.z)) * rsq_fast(d2));
-                            }
-                            const unsigned long long reach = __ballot(!(v > r0.w));
-                            m = 0ull;
-                            if ((PLAIN ? reach : ((reach | forceMask) & activeMask)) != 0ull) {
-                                // ... and facing it?  cosLi = max(0, n . Li) = 0 zeroes both the specular G term and the final product.
-                                const float4 r3 = R[3];
-                                const unsigned long long facing = __ballot(dot3f(nx, ny, nz, r3.x, r3.y, r3.z) > 0.0f);
-                                m = PLAIN ? (reach & facing) : (((reach & facing) | forceMask) & activeMask);
-                            }
+            constexpr int kind = decltype(kindTag)::value, h = decltype(hTag)::value;
+            unsigned long long todo = seg[kind * 2 + h];
+            unsigned long long rest = 0ull; // on overflow: what is left, this light included
+            if constexpr (PLAIN && kind < 2) {
+                // The usual case by hand (see SHADE_LIGHT_LOOP above): the same tests, the same append, 15 instructions around a light out of
+                // reach where the compiler's control flow takes 21.
+                if (todo != 0ull) {
+                    uint32_t bit, n, t0, t1;
+                    unsigned long long m, ex;
+                    if constexpr (kind == 0 && h == 0) SHADE_LIGHT_LOOP("", "", SHADE_TEST_POINT);
+                    if constexpr (kind == 0 && h == 1) SHADE_LIGHT_LOOP("s_or_b32 %[bit], %[bit], 64\n\t", "", SHADE_TEST_POINT);
+                    if constexpr (kind == 1 && h == 0) SHADE_LIGHT_LOOP("", "ds_read_b96 v[60:62], %[t0] offset:16\n\t", SHADE_TEST_SPOT);
+                    if constexpr (kind == 1 && h == 1) SHADE_LIGHT_LOOP("s_or_b32 %[bit], %[bit], 64\n\t", "ds_read_b96 v[60:62], %[t0] offset:16\n\t", SHADE_TEST_SPOT);
+                }
+            } else {
+                // (one way out of the loop, through its condition: with a `break` in the middle the loop is no single-exit region of its own, falls
+                // into the region of the divergent pair pass below and is structurised along with it -- see the append)
+                while (todo) {
+                    const int bit = __builtin_ctzll(todo);
+                    const uint32_t s = (uint32_t)(h * 64 + bit);
+                    unsigned long long m = activeMask; // "the rest": every pixel is a pair
+                    if (kind < 2) {
+                        const float4* R = sL + s * LREC;
+                        const float4 r0 = R[0];
+                        const v2f dxy = v2f{ r0.x, r0.y } - wxy;
+                        const float dz = r0.z - wz;
+                        const float d2 = fmaf(dxy.x, dxy.x, fmaf(dxy.y, dxy.y, dz * dz));
+                        float v = d2;
+                        if (kind == 1) {
+                            // spot: falloff is exactly 0 iff theta < cutOff.y (:303-306); theta ~ dot(d, axis) / |d| to a few ulp
+                            const float4 r1 = R[1];
+                            v = -(fmaf(dxy.x, r1.x, fmaf(dxy.y, r1.y, dz * r1.z)) * rsq_fast(d2));
                         }
-                        if (m != 0ull) {
-                            // (masks of single compares combined as scalars: a ballot of `mine && ...` goes through a VGPR 0 / 1 and back)
-                            if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= ((uint32_t)PENDK << 13))) != 0ull) { rest = todo; todo = 0ull; continue; }
-                            // The lanes of m append (pc | s << 6) to the queue and count the pair.  Written out with the exec mask set by hand: as
-                            // `if (lane in m) { ... }` this is the only divergent branch of the loops around it, and with it the compiler
-                            // structurises them -- a state variable, three more branches and five more scalar instructions per light.  Every
-                            // lane is live here (the waves are full and nothing above has diverged), so exec goes back to all ones.
-                            {
-                                uint32_t t0, t1;
-                                asm volatile("s_mov_b64 exec, %[m]\n\t"
-                                             "v_mov_b32 %[t0], %[cnt]\n\t"
-                                             "v_mbcnt_lo_u32_b32 %[t0], %[mlo], %[t0]\n\t"
-                                             "v_mbcnt_hi_u32_b32 %[t0], %[mhi], %[t0]\n\t"   // the count so far rides in as mbcnt's addend
-                                             "v_lshl_add_u32 %[t0], %[t0], 1, %[q]\n\t"
-                                             "v_lshl_or_b32 %[t1], %[s], 6, %[pc]\n\t"
-                                             "ds_write_b16 %[t0], %[t1]\n\t"
-                                             "v_add_u32 %[pc], 0x2000, %[pc]\n\t"
-                                             "s_mov_b64 exec, -1"
-                                             : [t0] "=&v"(t0), [t1] "=&v"(t1), [pc] "+v"(pc)
-                                             : [m] "s"(m), [mlo] "s"((uint32_t)m), [mhi] "s"((uint32_t)(m >> 32)), [cnt] "s"(cnt), [s] "s"(s), [q] "v"(qAddr)
-                                             : "memory");
-                            }
-                            cnt += (uint32_t)__popcll(m);
+                        const unsigned long long reach = __ballot(!(v > r0.w));
+                        m = 0ull;
+                        if ((PLAIN ? reach : ((reach | forceMask) & activeMask)) != 0ull) {
+                            // ... and facing it?  cosLi = max(0, n . Li) = 0 zeroes both the specular G term and the final product.
+                            const float4 r3 = R[3];
+                            const unsigned long long facing = __ballot(dot3f(nx, ny, nz, r3.x, r3.y, r3.z) > 0.0f);
+                            m = PLAIN ? (reach & facing) : (((reach & facing) | forceMask) & activeMask);
                         }
-                        asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction instead of three
                     }
-                    seg[kind * 2 + h] = rest; // what the next window still has to look at
-                    overflow = rest != 0ull;
+                    if (m != 0ull) {
+                        // (masks of single compares combined as scalars: a ballot of `mine && ...` goes through a VGPR 0 / 1 and back)
+                        if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= ((uint32_t)PENDK << 13))) != 0ull) { rest = todo; todo = 0ull; continue; }
+                        // The lanes of m append (pc | s << 6) to the queue and count the pair.  Written out with the exec mask set by hand: as
+                        // `if (lane in m) { ... }` this is the only divergent branch of the loops around it, and with it the compiler
+                        // structurises them -- a state variable, three more branches and five more scalar instructions per light.  Every
+                        // lane is live here (the waves are full and nothing above has diverged), so exec goes back to all ones.
+                        uint32_t t0, t1;
+                        asm volatile("s_mov_b64 exec, %[m]\n\t"
+                                     "v_mov_b32 %[t0], %[cnt]\n\t"
+                                     "v_mbcnt_lo_u32_b32 %[t0], %[mlo], %[t0]\n\t"
+                                     "v_mbcnt_hi_u32_b32 %[t0], %[mhi], %[t0]\n\t"   // the count so far rides in as mbcnt's addend
+                                     "v_lshl_add_u32 %[t0], %[t0], 1, %[q]\n\t"
+                                     "v_lshl_or_b32 %[t1], %[s], 6, %[pc]\n\t"
+                                     "ds_write_b16 %[t0], %[t1]\n\t"
+                                     "v_add_u32 %[pc], 0x2000, %[pc]\n\t"
+                                     "s_mov_b64 exec, -1"
+                                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [pc] "+v"(pc)
+                                     : [m] "s"(m), [mlo] "s"((uint32_t)m), [mhi] "s"((uint32_t)(m >> 32)), [cnt] "s"(cnt), [s] "s"(s), [q] "v"(qAddr)
+                                     : "memory");
+                        cnt += (uint32_t)__popcll(m);
+                    }
+                    asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction instead of three
                 }
             }
-            return overflow;
+            seg[kind * 2 + h] = rest; // what the next window still has to look at
+            return rest != 0ull;
+        };
+        auto fill_window = [&](auto plainTag) -> bool {
+            using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+            return light_loop(plainTag, K0{}, K0{}) || light_loop(plainTag, K0{}, K1{}) || light_loop(plainTag, K1{}, K0{}) || light_loop(plainTag, K1{}, K1{}) ||
+                   light_loop(plainTag, K2{}, K0{}) || light_loop(plainTag, K2{}, K1{});
         };
         const bool overflow = (forceMask == 0ull && activeMask == ~0ull) ? fill_window(std::true_type{}) : fill_window(std::false_type{});
         if (cnt == 0u) break;
