@@ -209,6 +209,21 @@ __device__ __forceinline__ float2 lut_sample(const float2* __restrict__ lut, int
 // ---- K2 ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
+// sqrtf for the squared lengths of this file -- the same bits, fewer instructions.  The compiler's correctly rounded sqrtf is v_sqrt_f32 plus
+// two one-ulp corrections, wrapped in a 2^32 scaling for x < 2^-96 and a class check for 0 / inf: 21 instructions and four hazard nops, of
+// which the corrections are nine.  The corrections alone give sqrtf's bits for every input outside 0 < |x| < 2^-96 (all 2^32 patterns
+// compared on the chip: scripts/microbench/sqrt_exhaustive.hip), and a squared length that small does not occur in a scene -- so: the
+// corrections alone, behind a wave-uniform check that sends a wave with such a value to sqrtf itself.
+__device__ __forceinline__ float sqrt_exact(float x)
+{
+    if (__builtin_expect(__ballot(__float_as_uint(x) - 1u < 0x0F7FFFFFu) != 0ull, 0)) return sqrtf(x); // 0 < x < 2^-96 (x is never negative here)
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = fmaf(-sd, s, x), ru = fmaf(-su, s, x);
+    float r = (0.0f >= rd) ? sd : s;
+    r = (0.0f < ru) ? su : r;
+    return r;
+}
 
 #define LREC 5 // float4 per staged light
 #define PENDK 3  // queued pairs per pixel in one window
@@ -416,7 +431,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const float nx = P1.x, ny = P1.y, nz = P1.z, roughness = P1.w;
     const float metallic = P2.w;
     const float vx = wx - A.camX, vy = wy - A.camY, vz = wz - A.camZ;
-    const float vinv = 1.0f / sqrtf(dot3f(vx, vy, vz, vx, vy, vz));          // exact chain (see header)
+    const float vinv = 1.0f / sqrt_exact(dot3f(vx, vy, vz, vx, vy, vz));          // exact chain (see header)
     const float Lox = -(vx * vinv), Loy = -(vy * vinv), Loz = -(vz * vinv);  // Lo = -viewDirection
     const float cosLo = fmaxf(0.0f, dot3f(nx, ny, nz, Lox, Loy, Loz));
     float accX = 0.0f, accY = 0.0f, accZ = 0.0f;
@@ -432,7 +447,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     if (staged) {
         const uint32_t type = __float_as_uint(q0.x), shadowType = __float_as_uint(q0.y);
         const float ndx = -q2.x, ndy = -q2.y, ndz = -q2.z;            // Li = -light.direction (:309)
-        const float len = sqrtf(dot3f(ndx, ndy, ndz, ndx, ndy, ndz)); // normalize(-light.direction) (:298)
+        const float len = sqrt_exact(dot3f(ndx, ndy, ndz, ndx, ndy, ndz)); // normalize(-light.direction) (:298)
         const float linv = 1.0f / len;
         // A zero factor only annihilates a FINITE product (inf * 0 = NaN in the reference): a light with ANY non-finite parameter --
         // intensity, but also position, direction, attenuation, cone or radius, which reach the product through the falloff -- is never
@@ -626,7 +641,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                     const float4 r2 = R[2];
                     const float dx = r0.x - pwx, dy = r0.y - pwy, dz = r0.z - pwz;
                     const float d2 = dot3f(dx, dy, dz, dx, dy, dz);
-                    const float dist = sqrtf(d2);                                       // exact: feeds 1 - (dist / bounds.x)^2
+                    const float dist = sqrt_exact(d2);                                       // exact: feeds 1 - (dist / bounds.x)^2
                     const float att = rcp_fast(fmaf(r2.z, d2, fmaf(r2.y, dist, r2.x))); // 1/(a.x + a.y d + a.z d^2) (:289,:300)
                     const bool isPoint = type == 1u;
                     // one IEEE division serves both types: point dist / bounds.x (:290), spot 1 / dist (normalize, :298)
@@ -654,7 +669,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                     // ---- Cook-Torrance (Standard.shader:309-340) ----
                     const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
                     float hx = Lix + pLox, hy = Liy + pLoy, hz = Liz + pLoz;
-                    const float hinv = 1.0f / sqrtf(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
+                    const float hinv = 1.0f / sqrt_exact(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
                     hx *= hinv; hy *= hinv; hz *= hinv;
                     const float cosLi = fmaxf(0.0f, dot3f(pnx, pny, pnz, Lix, Liy, Liz));
                     const float cosLh = fmaxf(0.0f, dot3f(pnx, pny, pnz, hx, hy, hz));
@@ -718,7 +733,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                 // ---- Cook-Torrance (Standard.shader:309-340), as in the pair pass ----
                 const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
                 float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;
-                const float hinv = 1.0f / sqrtf(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
+                const float hinv = 1.0f / sqrt_exact(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
                 hx *= hinv; hy *= hinv; hz *= hinv;
                 const float cosLi = fmaxf(0.0f, dot3f(nx, ny, nz, Lix, Liy, Liz));
                 const float cosLh = fmaxf(0.0f, dot3f(nx, ny, nz, hx, hy, hz));
