@@ -226,8 +226,8 @@ __device__ __forceinline__ float sqrt_exact(float x)
 }
 
 #define LREC 5 // float4 per staged light
-#define PENDK 3  // queued pairs per pixel in one window
-#define QMAX 120 // queued pairs per wave in one window (120: the block stays within 20 KB of LDS, 8 blocks per CU)
+#define PENDK 4  // queued pairs per pixel in one window (their queue positions ride in one register, 7 bits each under a sentinel bit)
+#define QMAX 120 // queued pairs per wave in one window (< 128; 120: the block stays within 17 KB of LDS, 9 blocks per CU)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // max of a non-negative (or NaN) float's bits over the wave as unsigned integers; the value of lane 63 (which holds the result) is returned.
@@ -281,39 +281,43 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // rec0 (and rec1 for a cone), out if no pixel passes; the facing test on rec3, out if no pixel passes both; the two overflow checks (queue,
 // pairs per pixel), which end the window with the light still in `rest`; the append of (pairs << 13 | slot << 6 | lane) for the lanes that
 // passed, exec set to them.  Registers v56-v62 hold rec0 and rec1 / rec3 (inline assembly cannot name the parts of a register tuple, so the
-// tuples are fixed ones); everything else is the compiler's choice.  Hazards (the compiler does not look inside): a v_pk result is not
+// tuples are fixed ones, and they double as the loop's temporaries); everything else is the compiler's choice.  Hazards (the compiler does not look inside): a v_pk result is not
 // read by the next instruction, a v_rsq result not by the next one either (s_nop).  The arithmetic is instruction for instruction what the
-// C++ loop beside it compiles to.
+// C++ loop beside it compiles to.  (The in / out operands are early-clobber: an input that happens to hold the same value -- the
+// records' base address and the count are both 0 at the first light -- would otherwise share the register.)
 #define SHADE_TEST_POINT \
     "v_mul_f32 v58, v58, v58\n\t" \
     "v_fmac_f32 v58, v57, v57\n\t" \
     "v_fmac_f32 v58, v56, v56\n\t" \
     "v_cmp_ngt_f32 vcc, v58, v59\n\t"
 #define SHADE_TEST_SPOT \
-    "v_mul_f32 %[t1], v58, v58\n\t" \
     "v_mul_f32 v62, v58, v62\n\t" \
-    "v_fmac_f32 %[t1], v57, v57\n\t" \
     "v_fmac_f32 v62, v57, v61\n\t" \
-    "v_fmac_f32 %[t1], v56, v56\n\t" \
     "v_fmac_f32 v62, v56, v60\n\t" \
-    "v_rsq_f32 %[t1], %[t1]\n\t" \
+    "v_mul_f32 v60, v58, v58\n\t" \
+    "v_fmac_f32 v60, v57, v57\n\t" \
+    "v_fmac_f32 v60, v56, v56\n\t" \
+    "v_rsq_f32 v60, v60\n\t" \
     "s_nop 0\n\t" \
-    "v_mul_f32_e64 v62, -v62, %[t1]\n\t" \
+    "v_mul_f32_e64 v62, -v62, v60\n\t" \
     "v_cmp_ngt_f32 vcc, v62, v59\n\t"
 #define SHADE_LIGHT_LOOP(H_LINE, LOADS, TEST) \
     asm volatile("s_mov_b64 %[ex], exec\n" \
                  "0:\n\t" \
                  "s_ff1_i32_b64 %[bit], %[todo]\n\t" \
                  H_LINE \
-                 "v_mad_u32_u24 %[t0], %[bit], %[v80], %[base]\n\t" \
-                 "ds_read_b128 v[56:59], %[t0]\n\t" \
+                 "s_lshl2_add_u32 %[n], %[bit], %[bit]\n\t"        /* 5 bit */ \
+                 "s_lshl4_add_u32 %[n], %[n], %[base]\n\t"         /* the record's LDS address: 80 bit + base (LREC * 16 = 80) */ \
+                 "v_mov_b32 v62, %[n]\n\t" \
+                 "ds_read_b128 v[56:59], v62\n\t" \
                  LOADS \
                  "s_waitcnt lgkmcnt(0)\n\t" \
                  "v_pk_add_f32 v[56:57], v[56:57], %[wxy] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
                  "v_sub_f32 v58, v58, %[wz]\n\t" \
                  TEST \
                  "s_cbranch_vccz 2f\n\t" \
-                 "ds_read_b96 v[60:62], %[t0] offset:48\n\t" \
+                 "v_mov_b32 v60, %[n]\n\t" \
+                 "ds_read_b96 v[60:62], v60 offset:48\n\t" \
                  "s_waitcnt lgkmcnt(0)\n\t" \
                  "v_mul_f32 v60, %[nx], v60\n\t" \
                  "v_mul_f32 v61, %[ny], v61\n\t" \
@@ -331,13 +335,13 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
                  "s_and_b64 %[m], %[m], vcc\n\t" \
                  "s_cbranch_scc1 1f\n\t" \
                  "s_mov_b64 exec, vcc\n\t" \
-                 "v_mov_b32 %[t0], %[cnt]\n\t" \
-                 "v_mbcnt_lo_u32_b32 %[t0], vcc_lo, %[t0]\n\t" \
-                 "v_mbcnt_hi_u32_b32 %[t0], vcc_hi, %[t0]\n\t" \
-                 "v_lshl_add_u32 %[t0], %[t0], 1, %[q]\n\t" \
-                 "v_lshl_or_b32 %[t1], %[bit], 6, %[pc]\n\t" \
-                 "ds_write_b16 %[t0], %[t1]\n\t" \
-                 "v_add_u32 %[pc], 0x2000, %[pc]\n\t" \
+                 "v_mov_b32 v56, %[cnt]\n\t" \
+                 "v_mbcnt_lo_u32_b32 v56, vcc_lo, v56\n\t" \
+                 "v_mbcnt_hi_u32_b32 v56, vcc_hi, v56\n\t" \
+                 "v_lshl_or_b32 %[pc], %[pc], 7, v56\n\t" \
+                 "v_lshl_add_u32 v56, v56, 1, %[q]\n\t" \
+                 "v_lshl_or_b32 v57, %[bit], 6, %[lane]\n\t" \
+                 "ds_write_b16 v56, v57\n\t" \
                  "s_mov_b64 exec, %[ex]\n\t" \
                  "s_mov_b32 %[cnt], %[n]\n" \
                  "2:\n\t" \
@@ -348,17 +352,17 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
                  "1:\n\t" \
                  "s_mov_b64 %[rest], %[todo]\n" \
                  "3:" \
-                 : [todo] "+s"(todo), [cnt] "+s"(cnt), [pc] "+v"(pc), [rest] "+s"(rest), [bit] "=&s"(bit), [n] "=&s"(n), [m] "=&s"(m), [ex] "=&s"(ex), \
-                   [t0] "=&v"(t0), [t1] "=&v"(t1) \
-                 : [wxy] "v"(wxy), [wz] "v"(wz), [nx] "v"(nx), [ny] "v"(ny), [nz] "v"(nz), [q] "v"(qAddr), [v80] "v"(recBytes), [base] "v"(sLAddr), \
-                   [lim] "s"(((uint32_t)PENDK << 13) - 1u), [qmax] "n"(QMAX) \
+                 : [todo] "+&s"(todo), [cnt] "+&s"(cnt), [pc] "+&v"(pc), [rest] "+&s"(rest), [bit] "=&s"(bit), [n] "=&s"(n), [m] "=&s"(m), [ex] "=&s"(ex) \
+                 : [wxy] "v"(wxy), [wz] "v"(wz), [nx] "v"(nx), [ny] "v"(ny), [nz] "v"(nz), [q] "v"(qAddr), [base] "s"(sLAddr), \
+                   [lim] "s"((1u << (7 * PENDK)) - 1u), [qmax] "n"(QMAX), [lane] "v"(lane) \
                  : "v56", "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc", "memory")
 
 #define SPLIT_MIN 40      // == CLASS_B of light_cull.hip: the hint's first two classes
 #define SPLIT_BLOCKS 2048 // one round of resident blocks (8 per CU)
+static_assert(QMAX < 128 && 7 * PENDK < 32 && 3 * QMAX >= 192, "queue positions are 7 bits each under a sentinel bit; the split blocks park 3 x 64 partial sums in a wave's slots");
 struct ShadeLds {
     float4 sL[KEEP * LREC];
-    float sRes[3 * PENDK * 256];
+    float sRes[4 * 3 * QMAX]; // per wave: [3 colours][queue position]
     uint16_t sQ[4 * QMAX];
     uint32_t sEnd[4];
 };
@@ -378,6 +382,10 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     constexpr bool BAND = ROLE != ROLE_TILE;
     constexpr bool splitRole = ROLE == ROLE_BAND_SPLIT;
     int tid = threadIdx.x;
+    // (the band kernel holds two copies of this body at 64 registers each, and the thread id -- live from the entry through both -- is what the
+    // allocator spills: seven reloads from scratch in the prologue of every ordinary tile.  Put together again from the wave's number, a
+    // scalar, and the lane's, two instructions, it need not live across anything.)
+    if (BAND) tid = (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) << 6) | (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     // (a split block walks several tiles: keep everything derived from the lane id inside the loop body -- hoisted out of the
     // loop those values stay live across the whole body and the 64-register budget spills)
     if (splitRole) asm volatile("" : "+v"(tid));
@@ -529,15 +537,19 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     // ---- 2 + 3. queue the (pixel, light) pairs that can be lit, then shade them one LANE per PAIR ----
     // Window = up to QMAX queued pairs, at most PENDK per pixel; a light whose pairs do not fit ends the window (it is
     // tested again in the next one -- rare: a quadrant of the 4K frame queues ~50 pairs).  A pair's result goes to slot
-    // [its ordinal among the pixel's queued pairs][pixel], which the pixel's own lane adds up afterwards: no atomics
-    // (ds_add_f32 is serialised per lane on this LDS: ~170 cycles per wave instruction, scripts/microbench/lds_ops.hip).
+    // [colour][its position in the queue]; each pixel keeps the positions of its own pairs (7 bits each, in the order queued, under a
+    // sentinel bit) and adds their results up afterwards: no atomics (ds_add_f32 is serialised per lane on this LDS: ~170 cycles
+    // per wave instruction, scripts/microbench/lds_ops.hip).  (Was: slots [colour][ordinal of the pair among its pixel's][pixel] --
+    // 9 KB per block instead of 5, and it is the block's LDS that decides how many blocks share a CU: a block's memory is held until
+    // its slowest wave is done, so with exactly 32 waves' worth of blocks a CU ran 23 waves on average.)
     uint16_t* Q = sQ + wave * QMAX;
     const uint32_t qAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)Q; // its LDS byte address, for the hand-written append below
-    const uint32_t sLAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)sL, recBytes = LREC * 16u;
-    float* res = sRes + tid - lane; // this wave's [3 colours][PENDK][64 pixels] slots, 256 floats apart
+    const uint32_t sLAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)sL;
+    static_assert(LREC == 5, "SHADE_LIGHT_LOOP computes 80 x slot as (5 x slot) << 4");
+    float* res = sRes + wave * (3 * QMAX); // this wave's [3 colours][QMAX queue positions] slots
     for (;;) {
         uint32_t cnt = 0u;      // queued pairs (wave-uniform)
-        uint32_t pc = (uint32_t)lane; // this pixel's queued pairs, kept as (pairs << 13) | lane: the queue entry is one v_or3 with the light's slot
+        uint32_t pc = 1u;       // the queue positions of this pixel's pairs: 1 (sentinel), then 7 bits per pair, the first one queued on top
         // The wave is bound by instruction issue of every kind (a scalar instruction costs what a vector one costs: measured), and the loop
         // around a light is mostly scalar mask arithmetic.  In the usual quadrant -- every pixel inside the frame, none with roughness 0 -- the
         // "force" and "active" masks are the identity, so that case gets its own copy of the loops without them (PLAIN): m = reach & facing.
@@ -550,12 +562,12 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                 // The usual case by hand (see SHADE_LIGHT_LOOP above): the same tests, the same append, 15 instructions around a light out of
                 // reach where the compiler's control flow takes 21.
                 if (todo != 0ull) {
-                    uint32_t bit, n, t0, t1;
+                    uint32_t bit, n;
                     unsigned long long m, ex;
                     if constexpr (kind == 0 && h == 0) SHADE_LIGHT_LOOP("", "", SHADE_TEST_POINT);
                     if constexpr (kind == 0 && h == 1) SHADE_LIGHT_LOOP("s_or_b32 %[bit], %[bit], 64\n\t", "", SHADE_TEST_POINT);
-                    if constexpr (kind == 1 && h == 0) SHADE_LIGHT_LOOP("", "ds_read_b96 v[60:62], %[t0] offset:16\n\t", SHADE_TEST_SPOT);
-                    if constexpr (kind == 1 && h == 1) SHADE_LIGHT_LOOP("s_or_b32 %[bit], %[bit], 64\n\t", "ds_read_b96 v[60:62], %[t0] offset:16\n\t", SHADE_TEST_SPOT);
+                    if constexpr (kind == 1 && h == 0) SHADE_LIGHT_LOOP("", "ds_read_b96 v[60:62], v62 offset:16\n\t", SHADE_TEST_SPOT);
+                    if constexpr (kind == 1 && h == 1) SHADE_LIGHT_LOOP("s_or_b32 %[bit], %[bit], 64\n\t", "ds_read_b96 v[60:62], v62 offset:16\n\t", SHADE_TEST_SPOT);
                 }
             } else {
                 // (one way out of the loop, through its condition: with a `break` in the middle the loop is no single-exit region of its own, falls
@@ -587,8 +599,8 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                     }
                     if (m != 0ull) {
                         // (masks of single compares combined as scalars: a ballot of `mine && ...` goes through a VGPR 0 / 1 and back)
-                        if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= ((uint32_t)PENDK << 13))) != 0ull) { rest = todo; todo = 0ull; continue; }
-                        // The lanes of m append (pc | s << 6) to the queue and count the pair.  Written out with the exec mask set by hand: as
+                        if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= (1u << (7 * PENDK)))) != 0ull) { rest = todo; todo = 0ull; continue; }
+                        // The lanes of m append (s << 6 | lane) to the queue and note the position.  Written out with the exec mask set by hand: as
                         // `if (lane in m) { ... }` this is the only divergent branch of the loops around it, and with it the compiler
                         // structurises them -- a state variable, three more branches and five more scalar instructions per light.  Every
                         // lane is live here (the waves are full and nothing above has diverged), so exec goes back to all ones.
@@ -597,13 +609,13 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                                      "v_mov_b32 %[t0], %[cnt]\n\t"
                                      "v_mbcnt_lo_u32_b32 %[t0], %[mlo], %[t0]\n\t"
                                      "v_mbcnt_hi_u32_b32 %[t0], %[mhi], %[t0]\n\t"   // the count so far rides in as mbcnt's addend
+                                     "v_lshl_or_b32 %[pc], %[pc], 7, %[t0]\n\t"
                                      "v_lshl_add_u32 %[t0], %[t0], 1, %[q]\n\t"
-                                     "v_lshl_or_b32 %[t1], %[s], 6, %[pc]\n\t"
+                                     "v_lshl_or_b32 %[t1], %[s], 6, %[lane]\n\t"
                                      "ds_write_b16 %[t0], %[t1]\n\t"
-                                     "v_add_u32 %[pc], 0x2000, %[pc]\n\t"
                                      "s_mov_b64 exec, -1"
-                                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [pc] "+v"(pc)
-                                     : [m] "s"(m), [mlo] "s"((uint32_t)m), [mhi] "s"((uint32_t)(m >> 32)), [cnt] "s"(cnt), [s] "s"(s), [q] "v"(qAddr)
+                                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [pc] "+&v"(pc)
+                                     : [m] "s"(m), [mlo] "s"((uint32_t)m), [mhi] "s"((uint32_t)(m >> 32)), [cnt] "s"(cnt), [s] "s"(s), [q] "v"(qAddr), [lane] "v"(lane)
                                      : "memory");
                         cnt += (uint32_t)__popcll(m);
                     }
@@ -691,23 +703,26 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                     const float Fx = fmaf(1.0f - pF0x, x5, pF0x), Fy = fmaf(1.0f - pF0y, x5, pF0y), Fz = fmaf(1.0f - pF0z, x5, pF0z);
                     const float4 r4 = R[4];
                     // shadow * ((kd*albedo + F*D*G/denom) * Lradiance * cosLi) * falloff ; kd = mix(1 - F, 0, metallic)
-                    float* o = res + ((e >> 13) * 256u + (e & 63u));
+                    float* o = res + (base + (uint32_t)lane);
                     o[0] = (fmaf(1.0f - Fx, pkdAx, Fx * spec) * r4.x) * scale;
-                    o[PENDK * 256] = (fmaf(1.0f - Fy, pkdAy, Fy * spec) * r4.y) * scale;
-                    o[2 * PENDK * 256] = (fmaf(1.0f - Fz, pkdAz, Fz * spec) * r4.z) * scale;
+                    o[QMAX] = (fmaf(1.0f - Fy, pkdAy, Fy * spec) * r4.y) * scale;
+                    o[2 * QMAX] = (fmaf(1.0f - Fz, pkdAz, Fz * spec) * r4.z) * scale;
                 }
             }
 #undef PULL
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // each pixel adds up the results of its own pairs, in the order they were queued
+        // each pixel adds up the results of its own pairs, in the order they were queued (the position list shifted up against the sentinel:
+        // the first pair's position then sits in bits 30..24, the next one in 23..17, ...)
+        const uint32_t pcTop = pc << __builtin_clz(pc);
 #pragma unroll
         for (uint32_t j = 0; j < (uint32_t)PENDK; j++) {
-            if (__ballot(pc >= ((j + 1u) << 13)) == 0ull) break;
-            if (pc >= ((j + 1u) << 13)) {
-                accX += res[j * 256u + lane];
-                accY += res[(PENDK + j) * 256u + lane];
-                accZ += res[(2 * PENDK + j) * 256u + lane];
+            if (__ballot(pc >= (1u << (7u * (j + 1u)))) == 0ull) break;
+            if (pc >= (1u << (7u * (j + 1u)))) {
+                const float* r = res + ((pcTop >> (24u - 7u * j)) & 127u);
+                accX += r[0];
+                accY += r[QMAX];
+                accZ += r[2 * QMAX];
             }
         }
         if (!overflow) break;
@@ -754,12 +769,12 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     }
     if (BAND && splitRole) { // the four partial sums of each pixel: wave 0 + 1 + 2 + 3
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        res[lane] = accX; res[PENDK * 256 + lane] = accY; res[2 * PENDK * 256 + lane] = accZ;
+        res[lane] = accX; res[64 + lane] = accY; res[128 + lane] = accZ; // (in the wave's own slots: another wave may still be reading its own)
         __syncthreads();
         if (wave != 0) return;
 #pragma unroll
         for (int w = 1; w < 4; w++) {
-            accX += sRes[w * 64 + lane]; accY += sRes[PENDK * 256 + w * 64 + lane]; accZ += sRes[2 * PENDK * 256 + w * 64 + lane];
+            accX += sRes[w * (3 * QMAX) + lane]; accY += sRes[w * (3 * QMAX) + 64 + lane]; accZ += sRes[w * (3 * QMAX) + 128 + lane];
         }
     }
     if (HAS_IBL) {
