@@ -86,12 +86,29 @@ def event_ms(fn, steps):
     return float(t.mean()), float(np.median(t)), float(np.percentile(t, 10)), float(np.percentile(t, 90))
 
 
-def event_batch_ms(fn, steps):
+def event_batch_ms(fn, steps, graph_stream=None):
     """average duration of fn() in ms from ONE HIP event pair around `steps` back-to-back calls on the launch stream: what a launch costs inside a
     running pipeline (the next launch ramps up while the previous one drains), which is also what rocprofv3's kernel trace reports -- its per-kernel
     durations add up to the wall time of the step.  An event pair around every single launch (event_ms) drains the GPU on both sides of the kernel and
-    reads 10-15 % longer for a 0.2 ms kernel."""
+    reads 10-15 % longer for a 0.2 ms kernel.  With graph_stream the `steps` calls are captured into one hipGraph first and the pair brackets its
+    replay: eager launches of one kernel back to back leave the command processor's dispatch gap (5-15 us) between them, which is no part of the
+    kernel; inside a graph the gap is what it is in the timed region."""
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if graph_stream is not None:
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=graph_stream):
+                for _ in range(steps):
+                    fn()
+            g.replay()
+            torch.cuda.synchronize()
+            a.record(graph_stream)
+            g.replay()
+            b.record(graph_stream)
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / steps
+        except Exception as e:  # (a failed capture leaves the eager measurement)
+            print(f"[bench] per-kernel hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
     a.record()
     for _ in range(steps):
         fn()
@@ -770,9 +787,11 @@ def main():
     # ---- per-kernel timing on the launch stream (HIP events) + algorithmic bytes ----
     cull_ms = event_ms(cull, args.steps)
     shade_ms = event_ms(shade, args.steps)
-    cull_batch_ms = event_batch_ms(cull, args.steps)
-    shade_batch_ms = event_batch_ms(shade, args.steps)
+    batch_stream = None if args.no_graph else side
+    cull_batch_ms = event_batch_ms(cull, args.steps, batch_stream)
+    shade_batch_ms = event_batch_ms(shade, args.steps, batch_stream)
     pipeline_ms = event_batch_ms(lambda: (cull(), shade()), args.steps)   # eager cull + shade chains back to back: the step without graphs or overlap
+    cull_eager_ms = event_batch_ms(cull, args.steps)
     g, idx = fp.lists_to_host()
     sum_nt = int(idx[0])
     distinct = int(len(np.unique(idx[1:]))) if sum_nt else 0
@@ -792,10 +811,10 @@ def main():
     shade_kernel = "k2_shade_csm" if csm is not None else ("k2_shade_band" if fp.tile_order and fp.use_tile_order else "k2_shade")
     roofline = {"bound": "hbm", "kernel": shade_kernel, "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
                 "traffic": measured_traffic("k2_shade" if csm is None else "k2_shade_csm", args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_batch_ms,
-                "timing": "one HIP event pair around %d back-to-back launches on the launch stream (agrees with rocprofv3 --kernel-trace --stats); "
+                "timing": "one HIP event pair around %d back-to-back launches on the launch stream, replayed as one hipGraph unless --no-graph (agrees with rocprofv3 --kernel-trace --stats); "
                           "isolated_* = an event pair around every single launch (pipeline drained on both sides)" % args.steps,
                 "isolated_avg_launch_ms": shade_ms[0], "isolated_median_launch_ms": shade_ms[1],
-                "in_pipeline_launch_ms": pipeline_ms - cull_batch_ms,  # eager (cull + shade) x K minus (cull) x K: the kernel between its real neighbours
+                "in_pipeline_launch_ms": pipeline_ms - cull_eager_ms,  # eager (cull + shade) x K minus eager (cull) x K: the kernel between its real neighbours
                 "eager_step_ms": pipeline_ms,
                 "frac_of_measured_copy_peak": shade_gbs / HBM_COPY_GBS,
                 "valu_sidebar": {"pixel_light_evals": evals, "gevals_per_s": evals / (shade_batch_ms * 1e-3) / 1e9,

@@ -444,9 +444,12 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const float cosLo = fmaxf(0.0f, dot3f(nx, ny, nz, Lox, Loy, Loz));
     float accX = 0.0f, accY = 0.0f, accZ = 0.0f;
     const float oneMinusMetal = 1.0f - metallic;
-    const float F0x = fmaf(P2.x, metallic, 0.04f * oneMinusMetal);
-    const float F0y = fmaf(P2.y, metallic, 0.04f * oneMinusMetal);
-    const float F0z = fmaf(P2.z, metallic, 0.04f * oneMinusMetal);
+    // F0 = mix(0.04, albedo, metallic) and, below, F = F0 + (1 - F0) x5 in the oracle's own operations, unfused: the diffuse term is (1 - F) kd albedo,
+    // and on a bright metal (F0 -> 1) a half-ulp difference in F is 1e-4 of 1 - F (scripts/fuzz_parity.py found the pixel: roughness 0, so no
+    // specular term to hide it behind)
+    const float F0x = 0.04f * oneMinusMetal + P2.x * metallic;
+    const float F0y = 0.04f * oneMinusMetal + P2.y * metallic;
+    const float F0z = 0.04f * oneMinusMetal + P2.z * metallic;
     const float kdAx = oneMinusMetal * P2.x, kdAy = oneMinusMetal * P2.y, kdAz = oneMinusMetal * P2.z; // kd = (1 - F)(1 - metallic)
     {
         const unsigned long long bad = __ballot(haveLight && !staged);
@@ -700,7 +703,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                 const float pF0x = PULL(F0x), pF0y = PULL(F0y), pF0z = PULL(F0z);
                 const float pkdAx = PULL(kdAx), pkdAy = PULL(kdAy), pkdAz = PULL(kdAz);
                 if (valid) {
-                    const float Fx = fmaf(1.0f - pF0x, x5, pF0x), Fy = fmaf(1.0f - pF0y, x5, pF0y), Fz = fmaf(1.0f - pF0z, x5, pF0z);
+                    const float Fx = pF0x + (1.0f - pF0x) * x5, Fy = pF0y + (1.0f - pF0y) * x5, Fz = pF0z + (1.0f - pF0z) * x5;
                     const float4 r4 = R[4];
                     // shadow * ((kd*albedo + F*D*G/denom) * Lradiance * cosLi) * falloff ; kd = mix(1 - F, 0, metallic)
                     float* o = res + (base + (uint32_t)lane);
@@ -759,7 +762,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                 const float G = cosLi * rcp_fast(fmaf(cosLi, oneMinusK, k)) * g1Lo;
                 const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * cosLo));
                 const float scale = shadow * cosLi; // falloff = 1 (:287)
-                const float Fx = fmaf(1.0f - F0x, x5, F0x), Fy = fmaf(1.0f - F0y, x5, F0y), Fz = fmaf(1.0f - F0z, x5, F0z);
+                const float Fx = F0x + (1.0f - F0x) * x5, Fy = F0y + (1.0f - F0y) * x5, Fz = F0z + (1.0f - F0z) * x5;
                 accX += (fmaf(1.0f - Fx, kdAx, Fx * spec) * r4.x) * scale;
                 accY += (fmaf(1.0f - Fy, kdAy, Fy * spec) * r4.y) * scale;
                 accZ += (fmaf(1.0f - Fz, kdAz, Fz * spec) * r4.z) * scale;
@@ -785,7 +788,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         // barriers): the pair pass sits exactly at 64 VGPRs, and three more live values across it -- or sixteen float4 gathers
         // in flight here -- push the kernel to ~100 VGPRs = half the occupancy (measured: 0.40 instead of 0.19 ms).
         const float x1 = 1.0f - cosLo, x2 = x1 * x1, x5 = x2 * x2 * x1;                                               // :352 FresnelSchlick(F0, cosLo)
-        const float Fx = fmaf(1.0f - F0x, x5, F0x), Fy = fmaf(1.0f - F0y, x5, F0y), Fz = fmaf(1.0f - F0z, x5, F0z);
+        const float Fx = F0x + (1.0f - F0x) * x5, Fy = F0y + (1.0f - F0y) * x5, Fz = F0z + (1.0f - F0z) * x5;
         {
             int face; float cs, ct;
             cube_face_st(nx, ny, nz, face, cs, ct);

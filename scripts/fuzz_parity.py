@@ -1,6 +1,6 @@
 """Randomised parity sweep (run through gpurun; not part of the test suite -- minutes of oracle time): random small frames, light sets
 (radii, spot share, clusters, directional / NaN / behind-the-eye lights, roughness 0), every cull path and random bands, against the C oracle:
-lists bit for bit, radiance within 1e-4 relative.   usage: fuzz_parity.py [cases] [seed]"""
+lists bit for bit, radiance within 1e-4 relative.   usage: fuzz_parity.py [cases] [seed] [only this case: the others only draw their random numbers]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,6 +10,7 @@ from sailor_amd.forward_plus import HipContext, ForwardPlus, upload_lights
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 ctx = HipContext("cuda:0")
 paths = [_lib.CULL_DEFAULT, _lib.CULL_BRUTE_FORCE, _lib.CULL_INTERVAL_MASKS]
 worst = 0.0
@@ -35,9 +36,13 @@ for c in range(cases):
     surface = synth.make_surface(cam, np.where(np.isfinite(depth), depth, 1000.0).astype(np.float32), seed)
     if rng.random() < 0.3:
         surface[1, :, ::7, 3] = 0.0   # roughness 0 pixels: 0 / 0 in NdfGGX, must see every light
+    Tx, Ty = host.num_tiles(W, H)
+    if only is not None and c != only:
+        for flags in paths:
+            rng.integers(0, Ty + 1); rng.random()
+        continue
     og, oi, _ = oracle.light_cull(cam.frame, W, H, lights, depth)
     orad = oracle.shade(cam.frame, W, H, surface, lights, og, oi, None)
-    Tx, Ty = host.num_tiles(W, H)
     for flags in paths:
         cut = int(rng.integers(0, Ty + 1))
         bands = [None] if rng.random() < 0.5 or Ty < 2 or cut in (0, Ty) else [host.band_from_tile_rows(W, H, 0, cut), host.band_from_tile_rows(W, H, cut, Ty)]
@@ -72,6 +77,14 @@ for c in range(cases):
             err = np.abs(got.astype(np.float64) - ref.astype(np.float64))[fin]
             tol = 1e-4 * np.abs(ref.astype(np.float64))[fin]
             # split tiles of a band differ from the one-block form by the order of four partial sums: same tolerance, checked the same way
+            if only is not None:
+                full_err = np.where(fin, np.abs(got.astype(np.float64) - ref.astype(np.float64)) / (np.abs(ref.astype(np.float64)) + 1e-300), 0.0)
+                y, x, ch = np.unravel_index(np.argmax(full_err), full_err.shape)
+                gy = H - 1 - (y + rows.start); t = (gy // 16) * Tx + x // 16
+                li = oi[og[t, 0]: og[t, 0] + og[t, 1]]
+                print(f"flags {flags} band {None if b is None else (bb.tileRowBegin, bb.tileRowEnd)}: worst rel {full_err.max():.3e} at pixel ({x},{y + rows.start}) ch {ch}: got {got[y, x]} ref {ref[y, x]}")
+                print("  surface", surface[:, y + rows.start, x].tolist(), "list", li.tolist())
+                print("  types", lights["type"][li].tolist(), "radius", lights["bounds"][li, 0].tolist(), "pos", lights["worldPosition"][li].tolist(), "intensity", lights["intensity"][li].tolist())
             assert (err <= tol * (2.0 if b is not None else 1.0)).all(), (c, W, H, N, flags, float((err / (tol + 1e-300)).max()))
             m = np.abs(ref[fin]) > 0
             if m.any(): worst = max(worst, float((err[m] / np.abs(ref[fin][m])).max()))

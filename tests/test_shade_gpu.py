@@ -60,6 +60,27 @@ def test_tiny_point_and_spot(ctx):
     assert_radiance_close(got, ref)
 
 
+def test_bright_metal_without_a_specular_term(ctx):
+    """F0 -> 1 (metallic and albedo near 1) makes the diffuse factor 1 - F a difference of neighbours: a half-ulp difference in F -- a fused
+    multiply-add where the reference rounds twice -- is 1e-4 of it.  Roughness 0 on every other pixel removes the specular term (NdfGGX = 0),
+    so nothing hides it; directional lights so that every pixel is lit.  (Found by scripts/fuzz_parity.py, seed 11 case 222.)"""
+    f = synth.make_frame("tiny")
+    rng = np.random.default_rng(5)
+    H, W = f.surface.shape[1:3]
+    f.surface[2, :, :, :3] = (1.0 - rng.random((H, W, 3)) * 5e-4).astype(np.float32)   # albedo
+    f.surface[2, :, :, 3] = (1.0 - rng.random((H, W)) * 5e-4).astype(np.float32)        # metallic
+    f.surface[1, :, ::2, 3] = 0.0                                                        # roughness
+    f.lights["type"][:4] = host.LIGHT_DIRECTIONAL
+    got, _ = gpu_frame(ctx, f)
+    ref = oracle_frame(f)
+    lit = ref[..., :3][np.isfinite(ref[..., :3])]
+    assert (lit > 0).mean() > 0.2 and np.median(lit[lit > 0]) < 1.0, "the diffuse term alone is small"
+    fin = np.isfinite(ref)
+    np.testing.assert_array_equal(np.isfinite(got), fin)
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))[fin]
+    assert (err <= RTOL * np.abs(ref.astype(np.float64))[fin]).all(), f"worst rel {np.max(err / (np.abs(ref.astype(np.float64))[fin] + 1e-300)):.3e}"
+
+
 def test_tiny_with_csm_evsm_and_pcf(ctx):
     """configs[3] shape at fixture size: light 0 directional + EVSM, 4 cascades (64x64 maps)."""
     f = synth.make_frame("tiny_csm")
