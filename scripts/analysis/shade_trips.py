@@ -50,7 +50,24 @@ for tr in rows:
             sph0 = (np.sqrt(((lp - c0) ** 2).sum(1)) <= lr * 1.0001 + R0) | (ltype != 1)
             c1 = 0.5 * (bmin + bmax); R1 = np.sqrt(((P - c1) ** 2).sum(1).max())
             sph1 = (np.sqrt(((lp - c1) ** 2).sum(1)) <= lr * 1.0001 + R1) | (ltype != 1)
-            alt.append((int(sph0.sum()), int(sph1.sum()), int((sph0 & box_ok).sum())))
+            # finer pre-filters: the union of sub-spheres over the quadrant's halves (lanes 0-31 / 32-63) resp. its four 16-lane rows of two pixel rows
+            def sub_spheres(groups, centres):
+                ok = np.zeros(len(lp), bool)
+                for lanes, c in zip(groups, centres):
+                    cc = P[c]; RR = np.sqrt(((P[lanes] - cc) ** 2).sum(1).max())
+                    ok |= np.sqrt(((lp - cc) ** 2).sum(1)) <= lr * 1.0001 + RR
+                return ok | (ltype != 1)
+            half = sub_spheres([np.arange(0, 32), np.arange(32, 64)], [11, 43])
+            quart = sub_spheres([np.arange(16 * k, 16 * k + 16) for k in range(4)], [3 + 16 * k for k in range(4)])
+            # spot lights against the quadrant's sphere: outside the cone iff angle(c - L, axis) > theta_c + asin(R / |c - L|)
+            v = c0[None, :] - lp; dist = np.sqrt((v ** 2).sum(1)); cosA = (v * (-ldn)).sum(1) / np.maximum(dist, 1e-30)
+            sin_d = np.minimum(R0 / np.maximum(dist, 1e-30), 1.0); cos_d = np.sqrt(1.0 - sin_d ** 2)
+            cos_c = np.clip(cut_y, -1.0, 1.0); sin_c = np.sqrt(1.0 - cos_c ** 2)
+            cone_ok = (dist <= R0) | (cosA >= cos_c * cos_d - sin_c * sin_d) | (cos_c * cos_d - sin_c * sin_d <= -1.0) | (np.arccos(cos_c) + np.arcsin(sin_d) >= np.pi)
+            spot = ltype == 2
+            alt.append((int(sph0.sum()), int(sph1.sum()), int((sph0 & box_ok).sum()), int(half.sum()), int(quart.sum()), int((ltype != 1).sum()),
+                        int((reach & sph0[:, None]).any(1).sum()), int(spot.sum()), int((reach.any(1) & spot).sum()), int((cone_ok & spot).sum()),
+                        int(((reach.any(1) & spot) & ~cone_ok).sum())))
             any_reach = (reach & surv[:, None]).any(1)
             pair = reach & facing & surv[:, None]
             any_pair = pair.any(1)
@@ -65,5 +82,7 @@ print("pair passes (ceil(pairs/64)) mean", passes.mean(), " lane utilisation of 
 print("quadrants with list < 8:", (s[:, 0] < 8).mean(), " < 16:", (s[:, 0] < 16).mean(), " > 64:", (s[:, 0] > 64).mean())
 a = np.array(alt, dtype=np.float64)
 print("survivors: box", s[:, 1].mean(), " sphere@centre pixel", a[:, 0].mean(), " sphere@box centre", a[:, 1].mean(), " both", a[:, 2].mean())
+print("           two half-spheres", a[:, 3].mean(), " four row-pair spheres", a[:, 4].mean(), " of which not point lights", a[:, 5].mean(), " reach >= 1 pixel", a[:, 6].mean())
+print("           spot lights per list", a[:, 7].mean(), " that reach >= 1 pixel", a[:, 8].mean(), " that pass a cone-vs-sphere test", a[:, 9].mean(), " (wrongly rejected:", a[:, 10].sum(), ")")
 short = s[:, 0] < 32
 print("lists < 32 lights: share", short.mean(), " mean list", s[short, 0].mean(), " mean survivors (box)", s[short, 1].mean(), " sphere", a[short, 0].mean())
