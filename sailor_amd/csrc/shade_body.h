@@ -402,7 +402,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const int gx = tx * TILE + (quad & 1) * 8 + (lane & 7);
     const int gy = ty * TILE + (quad >> 1) * 8 + (lane >> 3);
     const int py = A.H - 1 - gy;            // framebuffer row (Standard.shader:414: screenUv.y = H - fragY)
-    const unsigned long long activeMask = __ballot(gx < A.W && py >= 0); // (the mask first, the per-lane flag from it: the other way round costs a VGPR 0 / 1 per use)
+    const unsigned long long activeMask = __ballot(gx < A.W) & __ballot(py >= 0); // (masks of single compares, the per-lane flag from the mask: a ballot of `a && b`, or a flag kept as a bool, costs a VGPR 0 / 1 and a compare per use)
     const bool active = __builtin_amdgcn_inverse_ballot_w64(activeMask);
     const size_t pix = active ? ((size_t)(py - A.fbRow0) * A.W + gx) : 0;
 
@@ -426,7 +426,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     uint32_t index = 0xFFFFFFFFu;
     if (haveLight) index = culled[g.offset + tid];
     // Standard.shader:430-433 "index == uint(-1) -> break" (and out-of-range guard): the list ends at the first such slot
-    const bool staged = haveLight && index < (uint32_t)A.lightsNum;
+    const bool staged = index < (uint32_t)A.lightsNum; // (a lane without a list slot holds uint(-1))
     float4 q0, q1, q2, q3, q4, q5, q6;
     if (staged) {
         const float4* L = reinterpret_cast<const float4*>(lights + index);
@@ -452,7 +452,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const float F0z = 0.04f * oneMinusMetal + P2.z * metallic;
     const float kdAx = oneMinusMetal * P2.x, kdAy = oneMinusMetal * P2.y, kdAz = oneMinusMetal * P2.z; // kd = (1 - F)(1 - metallic)
     {
-        const unsigned long long bad = __ballot(haveLight && !staged);
+        const unsigned long long bad = __ballot(haveLight) & ~__ballot(index < (uint32_t)A.lightsNum);
         if (lane == 0) sEnd[wave] = bad ? (uint32_t)(wave * 64 + __builtin_ctzll(bad)) : 0xFFFFFFFFu;
     }
     if (staged) {
