@@ -279,10 +279,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // with roughness 0), by hand: the wave is bound by instruction issue -- a scalar instruction costs what a vector one costs -- and the
 // compiler's version of this loop spends more instructions on getting around it than on the tests.  Per light: the conservative reach test on
 // rec0 (and rec1 for a cone), out if no pixel passes; the facing test on rec3, out if no pixel passes both; the two overflow checks (queue,
-// pairs per pixel), which end the window with the light still in `rest`; the append of (pairs << 13 | slot << 6 | lane) for the lanes that
+// pairs per pixel), which end the window with the light still in `rest`; the append of (slot << 6 | lane) for the lanes that
 // passed, exec set to them.  Registers v56-v62 hold rec0 and rec1 / rec3 (inline assembly cannot name the parts of a register tuple, so the
-// tuples are fixed ones, and they double as the loop's temporaries); everything else is the compiler's choice.  Hazards (the compiler does not look inside): a v_pk result is not
-// read by the next instruction, a v_rsq result not by the next one either (s_nop).  The arithmetic is instruction for instruction what the
+// tuples are fixed ones, and they double as the loop's temporaries); everything else is the compiler's choice.  Hazards (the compiler does
+// not look inside): a v_pk result is not read by the next instruction, a v_rsq result not by the next one either (s_nop).  The arithmetic is instruction for instruction what the
 // C++ loop beside it compiles to.  (The in / out operands are early-clobber: an input that happens to hold the same value -- the
 // records' base address and the count are both 0 at the first light -- would otherwise share the register.)
 #define SHADE_TEST_POINT \
