@@ -227,7 +227,7 @@ __device__ __forceinline__ float sqrt_exact(float x)
 
 #define LREC 5 // float4 per staged light
 #define PENDK 4  // queued pairs per pixel in one window (their queue positions ride in one register, 7 bits each under a sentinel bit)
-#define QMAX 120 // queued pairs per wave in one window (< 128; 120: the block stays within 17 KB of LDS, 9 blocks per CU)
+#define QMAX 128 // queued pairs per wave in one window (two lights that reach every pixel fit; positions are 7 bits; 17.4 KB of LDS per block, 9 blocks per CU)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // max of a non-negative (or NaN) float's bits over the wave as unsigned integers; the value of lane 63 (which holds the result) is returned.
@@ -359,7 +359,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 
 #define SPLIT_MIN 40      // == CLASS_B of light_cull.hip: the hint's first two classes
 #define SPLIT_BLOCKS 2048 // one round of resident blocks (8 per CU)
-static_assert(QMAX < 128 && 7 * PENDK < 32 && 3 * QMAX >= 192, "queue positions are 7 bits each under a sentinel bit; the split blocks park 3 x 64 partial sums in a wave's slots");
+static_assert(QMAX <= 128 && 7 * PENDK < 32 && 3 * QMAX >= 192, "queue positions are 7 bits each under a sentinel bit; the split blocks park 3 x 64 partial sums in a wave's slots");
 struct ShadeLds {
     float4 sL[KEEP * LREC];
     float sRes[4 * 3 * QMAX]; // per wave: [3 colours][queue position]
