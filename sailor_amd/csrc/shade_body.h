@@ -225,6 +225,18 @@ __device__ __forceinline__ float sqrt_exact(float x)
     return r;
 }
 
+// 1.0f / s for s = a square root -- the same bits, four instructions instead of twelve.  The compiler's IEEE division scales its operands, refines
+// v_rcp_f32 and the quotient with five fma and undoes the scaling (div_scale x 2, div_fmas, div_fixup).  For a numerator of 1 and a denominator
+// in [2^-126, 2^126] one Newton step on v_rcp_f32 plus v_div_fixup_f32 (0, inf, NaN) gives the same bits on every one of the 2^32 inputs
+// (scripts/microbench/rcp_exhaustive.hip: the mismatches are the denormals and |s| > 2^126, where the quotient is a denormal), and the square
+// root of a float lies in [2^-74.5, 2^64] or is 0, inf or NaN.
+__device__ __forceinline__ float rcp_of_sqrt(float s)
+{
+    const float r0 = __builtin_amdgcn_rcpf(s);
+    const float e = fmaf(-s, r0, 1.0f);
+    return __builtin_amdgcn_div_fixupf(fmaf(e, r0, r0), s, 1.0f);
+}
+
 #define LREC 5 // float4 per staged light
 #define PENDK 4  // queued pairs per pixel in one window (their queue positions ride in one register, 7 bits each under a sentinel bit)
 #define QMAX 128 // queued pairs per wave in one window (two lights that reach every pixel fit; positions are 7 bits; 17.4 KB of LDS per block, 9 blocks per CU)
@@ -439,7 +451,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const float nx = P1.x, ny = P1.y, nz = P1.z, roughness = P1.w;
     const float metallic = P2.w;
     const float vx = wx - A.camX, vy = wy - A.camY, vz = wz - A.camZ;
-    const float vinv = 1.0f / sqrt_exact(dot3f(vx, vy, vz, vx, vy, vz));          // exact chain (see header)
+    const float vinv = rcp_of_sqrt(sqrt_exact(dot3f(vx, vy, vz, vx, vy, vz)));          // exact chain (see header)
     const float Lox = -(vx * vinv), Loy = -(vy * vinv), Loz = -(vz * vinv);  // Lo = -viewDirection
     const float cosLo = fmaxf(0.0f, dot3f(nx, ny, nz, Lox, Loy, Loz));
     float accX = 0.0f, accY = 0.0f, accZ = 0.0f;
@@ -459,7 +471,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         const uint32_t type = __float_as_uint(q0.x), shadowType = __float_as_uint(q0.y);
         const float ndx = -q2.x, ndy = -q2.y, ndz = -q2.z;            // Li = -light.direction (:309)
         const float len = sqrt_exact(dot3f(ndx, ndy, ndz, ndx, ndy, ndz)); // normalize(-light.direction) (:298)
-        const float linv = 1.0f / len;
+        const float linv = rcp_of_sqrt(len);
         // A zero factor only annihilates a FINITE product (inf * 0 = NaN in the reference): a light with ANY non-finite parameter --
         // intensity, but also position, direction, attenuation, cone or radius, which reach the product through the falloff -- is never
         // skipped.
@@ -684,7 +696,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                     // ---- Cook-Torrance (Standard.shader:309-340) ----
                     const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
                     float hx = Lix + pLox, hy = Liy + pLoy, hz = Liz + pLoz;
-                    const float hinv = 1.0f / sqrt_exact(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
+                    const float hinv = rcp_of_sqrt(sqrt_exact(dot3f(hx, hy, hz, hx, hy, hz)));          // exact chain: Lh = normalize(Li + Lo)
                     hx *= hinv; hy *= hinv; hz *= hinv;
                     const float cosLi = fmaxf(0.0f, dot3f(pnx, pny, pnz, Lix, Liy, Liz));
                     const float cosLh = fmaxf(0.0f, dot3f(pnx, pny, pnz, hx, hy, hz));
@@ -751,7 +763,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                 // ---- Cook-Torrance (Standard.shader:309-340), as in the pair pass ----
                 const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
                 float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;
-                const float hinv = 1.0f / sqrt_exact(dot3f(hx, hy, hz, hx, hy, hz));          // exact chain: Lh = normalize(Li + Lo)
+                const float hinv = rcp_of_sqrt(sqrt_exact(dot3f(hx, hy, hz, hx, hy, hz)));          // exact chain: Lh = normalize(Li + Lo)
                 hx *= hinv; hy *= hinv; hz *= hinv;
                 const float cosLi = fmaxf(0.0f, dot3f(nx, ny, nz, Lix, Liy, Liz));
                 const float cosLh = fmaxf(0.0f, dot3f(nx, ny, nz, hx, hy, hz));
