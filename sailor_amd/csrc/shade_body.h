@@ -209,22 +209,19 @@ __device__ __forceinline__ float2 lut_sample(const float2* __restrict__ lut, int
 // ---- K2 ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
-// sqrtf for the squared lengths of this file -- the same bits, fewer instructions.  The compiler's correctly rounded sqrtf is v_sqrt_f32 plus
-// two one-ulp corrections, wrapped in a 2^32 scaling for x < 2^-96 and a class check for 0 / inf: 21 instructions and four hazard nops, of
-// which the corrections are nine.  The corrections alone give sqrtf's bits for every input outside 0 < |x| < 2^-96 (all 2^32 patterns
-// compared on the chip: scripts/microbench/sqrt_exhaustive.hip), and a squared length that small does not occur in a scene -- so: the
-// corrections alone, behind a wave-uniform check that sends a wave with such a value to sqrtf itself.
+// sqrtf for the squared lengths of this file -- the same bits, five instructions.  The compiler's correctly rounded sqrtf is v_sqrt_f32 plus two
+// one-ulp corrections, wrapped in a 2^32 scaling for x < 2^-96 and a class check for 0 / inf: 21 instructions and four hazard nops.  One Newton
+// step on v_rsq_f32 -- s0 = x y, s = s0 + (x - s0^2) (y / 2), the residual by fma -- gives sqrtf's bits for EVERY x in [2^-96, inf) (all
+// 1.9 x 10^9 of them compared on the chip: scripts/microbench/sqrt_newton_exhaustive.hip; the two corrections alone do as well, at nine
+// instructions: sqrt_exhaustive.hip).  A wave-uniform check sends a wave that holds anything else -- 0, a squared length below 2^-96, inf, NaN --
+// to sqrtf itself.
 __device__ __forceinline__ float sqrt_exact(float x)
 {
-    if (__builtin_expect(__ballot(__float_as_uint(x) - 1u < 0x0F7FFFFFu) != 0ull, 0)) return sqrtf(x); // 0 < x < 2^-96 (x is never negative here)
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
-    const float rd = fmaf(-sd, s, x), ru = fmaf(-su, s, x);
-    float r = (0.0f >= rd) ? sd : s;
-    r = (0.0f < ru) ? su : r;
-    return r;
+    if (__builtin_expect(__ballot(__float_as_uint(x) - 0x0F800000u >= 0x70000000u) != 0ull, 0)) return sqrtf(x);
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s0 = x * y, h = 0.5f * y;
+    return fmaf(fmaf(-s0, s0, x), h, s0);
 }
-
 // 1.0f / s for s = a square root -- the same bits, four instructions instead of twelve.  The compiler's IEEE division scales its operands, refines
 // v_rcp_f32 and the quotient with five fma and undoes the scaling (div_scale x 2, div_fmas, div_fixup).  For a numerator of 1 and a denominator
 // in [2^-126, 2^126] one Newton step on v_rcp_f32 plus v_div_fixup_f32 (0, inf, NaN) gives the same bits on every one of the 2^32 inputs
