@@ -284,7 +284,7 @@ def test_split_tiles_on_a_band_of_the_4k_frame(ctx):
 
 def test_every_light_reaches_every_pixel(ctx):
     """128 large lights over a small viewport: every tile list is full and every (pixel, light) is a lit pair -- 8 192 pairs per quadrant,
-    i.e. dozens of pair windows per wave, each closed by the 120-pair / 3-per-pixel limits of the queue."""
+    i.e. dozens of pair windows per wave, each closed by the 128-pair / 4-per-pixel limits of the queue."""
     w, h = 64, 48
     cam = synth.make_camera(w, h)
     depth = synth.make_linear_depth(w, h, 9, d_min=40.0, d_max=60.0)
@@ -299,6 +299,36 @@ def test_every_light_reaches_every_pixel(ctx):
     got = fp.shade(cam.frame, torch.from_numpy(surface).to(ctx.device), l, len(lights)).cpu().numpy()
     assert_radiance_close(got, ref)
     assert (ref[..., :3] > 0).all()
+
+
+def test_lengths_outside_the_fast_square_root(ctx):
+    """The kernel's square roots take a short form that is sqrtf's bits on [2^-96, inf) and fall back to sqrtf for anything else in the wave:
+    a point light exactly AT a surface point (squared distance 0), a spot light whose direction is the zero vector (length 0, normalised to
+    NaN) and one with a direction of 1e-25 (squared length a denormal), a light 1e-25 away from a surface point."""
+    f = synth.make_frame("tiny")
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    lights = f.lights.copy()
+    py, px = H // 2, W // 2
+    p0 = f.surface[0, py, px, :3].copy(); p1 = f.surface[0, py + 3, px + 5, :3].copy()
+    lights["type"][0] = host.LIGHT_POINT; lights["worldPosition"][0] = p0; lights["bounds"][0, 0] = 60.0
+    lights["type"][1] = host.LIGHT_SPOT; lights["direction"][1] = 0.0
+    lights["type"][2] = host.LIGHT_SPOT; lights["direction"][2] = (1e-25, 0.0, 0.0)
+    lights["type"][3] = host.LIGHT_POINT; lights["worldPosition"][3] = p1 + np.float32(1e-25); lights["bounds"][3, 0] = 60.0
+    assert np.array_equal(lights["worldPosition"][0], p0)
+    g, idx, _ = oracle.light_cull(f.cam.frame, W, H, lights, f.depth)
+    t = (H - 1 - py) // 16 * ((W + 15) // 16) + px // 16
+    assert 0 in idx[g[t, 0]: g[t, 0] + g[t, 1]], "the light at the pixel is in the pixel's list"
+    with np.errstate(all="ignore"):
+        ref = oracle.shade(f.cam.frame, W, H, f.surface, lights, g, idx)
+    fp = ForwardPlus(ctx, W, H, N)
+    l = upload_lights(lights, ctx.device)
+    fp.cull(f.cam.frame, l, N, torch.from_numpy(f.depth).to(ctx.device))
+    got = fp.shade(f.cam.frame, torch.from_numpy(f.surface).to(ctx.device), l, N).cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_array_equal(np.isinf(got), np.isinf(ref))
+    fin = np.isfinite(ref)
+    err = np.abs(got[fin].astype(np.float64) - ref[fin])
+    assert (err <= RTOL * np.abs(ref[fin])).all(), (err / (np.abs(ref[fin]) + 1e-300)).max()
 
 
 def test_non_finite_terms_propagate_like_the_reference(ctx):
