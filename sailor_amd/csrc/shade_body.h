@@ -217,10 +217,11 @@ __device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsq
 // to sqrtf itself.
 __device__ __forceinline__ float sqrt_exact(float x)
 {
-    if (__builtin_expect(__ballot(__float_as_uint(x) - 0x0F800000u >= 0x70000000u) != 0ull, 0)) return sqrtf(x);
     const float y = __builtin_amdgcn_rsqf(x);
     const float s0 = x * y, h = 0.5f * y;
-    return fmaf(fmaf(-s0, s0, x), h, s0);
+    float s = fmaf(fmaf(-s0, s0, x), h, s0);
+    if (__builtin_expect(__ballot(__float_as_uint(x) - 0x0F800000u >= 0x70000000u) != 0ull, 0)) s = sqrtf(x); // (an `if` without an `else`: one branch)
+    return s;
 }
 // 1.0f / s for s = a square root -- the same bits, four instructions instead of twelve.  The compiler's IEEE division scales its operands, refines
 // v_rcp_f32 and the quotient with five fma and undoes the scaling (div_scale x 2, div_fmas, div_fixup).  For a numerator of 1 and a denominator
