@@ -245,20 +245,16 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // needs 2 wait states after the VALU write.)
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-    asm volatile("s_nop 1\n\t"
-                 "v_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\t"
-                 "v_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\t"
-                 "v_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\t"
-                 "v_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\t"
-                 "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                 "s_nop 1\n\t"
-                 "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-                 "s_nop 1"
-                 : "+v"(v));
+    // (as intrinsics, not inline assembly: the compiler folds each move into a v_max_u32_dpp, knows the two wait states a DPP read needs after
+    // the write of its source and fills them with the per-pixel invariants instead of s_nop)
+#define MAX_STEP(CTRL, ROWS) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, false)) /* (0 = the identity of max: lanes the control leaves out) */
+    MAX_STEP(0xB1, 0xf);  // quad_perm:[1,0,3,2]
+    MAX_STEP(0x4E, 0xf);  // quad_perm:[2,3,0,1]
+    MAX_STEP(0x141, 0xf); // row_half_mirror
+    MAX_STEP(0x140, 0xf); // row_mirror
+    MAX_STEP(0x142, 0xa); // row_bcast:15 into rows 1 and 3
+    MAX_STEP(0x143, 0xc); // row_bcast:31 into rows 2 and 3
+#undef MAX_STEP
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
