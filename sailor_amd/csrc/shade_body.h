@@ -288,7 +288,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // pairs per pixel), which end the window with the light still in `rest`; the append of (slot << 6 | lane) for the lanes that
 // passed, exec set to them.  Registers v56-v62 hold rec0 and rec1 / rec3 (inline assembly cannot name the parts of a register tuple, so the
 // tuples are fixed ones, and they double as the loop's temporaries); everything else is the compiler's choice.  Hazards (the compiler does
-// not look inside): a v_pk result is not read by the next instruction, a v_rsq result not by the next one either (s_nop).  The arithmetic is instruction for instruction what the
+// not look inside): a v_pk result is not read by the next instruction, a v_rsq result not by the next one either.  The arithmetic is instruction for instruction what the
 // C++ loop beside it compiles to.  (The in / out operands are early-clobber: an input that happens to hold the same value -- the
 // records' base address and the count are both 0 at the first light -- would otherwise share the register.)
 #define SHADE_TEST_POINT \
@@ -299,13 +299,12 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 #define SHADE_TEST_SPOT \
     "v_mul_f32 v62, v58, v62\n\t" \
     "v_fmac_f32 v62, v57, v61\n\t" \
-    "v_fmac_f32 v62, v56, v60\n\t" \
-    "v_mul_f32 v60, v58, v58\n\t" \
-    "v_fmac_f32 v60, v57, v57\n\t" \
-    "v_fmac_f32 v60, v56, v56\n\t" \
-    "v_rsq_f32 v60, v60\n\t" \
-    "s_nop 0\n\t" \
-    "v_mul_f32_e64 v62, -v62, v60\n\t" \
+    "v_mul_f32 v61, v58, v58\n\t" \
+    "v_fmac_f32 v61, v57, v57\n\t" \
+    "v_fmac_f32 v61, v56, v56\n\t" \
+    "v_rsq_f32 v61, v61\n\t" \
+    "v_fmac_f32 v62, v56, v60\n\t"      /* (the dot product's last term in the wait state of the v_rsq result) */ \
+    "v_mul_f32_e64 v62, -v62, v61\n\t" \
     "v_cmp_ngt_f32 vcc, v62, v59\n\t"
 #define SHADE_LIGHT_LOOP(H_LINE, LOADS, TEST) \
     asm volatile("s_mov_b64 %[ex], exec\n" \
