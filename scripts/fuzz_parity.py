@@ -14,6 +14,7 @@ only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 ctx = HipContext("cuda:0")
 paths = [_lib.CULL_DEFAULT, _lib.CULL_BRUTE_FORCE, _lib.CULL_INTERVAL_MASKS]
 worst = 0.0
+worst_case = -1
 t0 = time.time()
 for c in range(cases):
     W, H = int(rng.integers(16, 500)), int(rng.integers(16, 300))
@@ -87,6 +88,8 @@ for c in range(cases):
                 print("  types", lights["type"][li].tolist(), "radius", lights["bounds"][li, 0].tolist(), "pos", lights["worldPosition"][li].tolist(), "intensity", lights["intensity"][li].tolist())
             assert (err <= tol * (2.0 if b is not None else 1.0)).all(), (c, W, H, N, flags, float((err / (tol + 1e-300)).max()))
             m = np.abs(ref[fin]) > 0
-            if m.any(): worst = max(worst, float((err[m] / np.abs(ref[fin][m])).max()))
+            if m.any():
+                w = float((err[m] / np.abs(ref[fin][m])).max())
+                if w > worst: worst, worst_case = w, c
     if c % 10 == 9: print(f"{c + 1} cases ok, worst relative radiance error {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
-print("fuzz ok:", cases, "cases, worst relative radiance error", worst)
+print("fuzz ok:", cases, "cases, worst relative radiance error", worst, "in case", worst_case)
