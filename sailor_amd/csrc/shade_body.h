@@ -235,6 +235,19 @@ __device__ __forceinline__ float rcp_of_sqrt(float s)
     return __builtin_amdgcn_div_fixupf(fmaf(e, r0, r0), s, 1.0f);
 }
 
+// a / b with y = RN(1 / b) staged beside b:  q0 = a y;  e = fma(-b, q0, a) (exact);  q = fma(e, y, q0)  -- Markstein's correction step: with y
+// the correctly rounded reciprocal and q0 within an ulp of the quotient, q IS the correctly rounded quotient as long as nothing over- or
+// underflows on the way (4 instructions with v_div_fixup_f32 for 0 / inf / NaN operands against the IEEE division's 12; no mismatch in 2^36
+// random pairs and 36 special divisors x every significand, round 2).  "Nothing overflows" is the stager's business: it leaves NaN instead of
+// a reciprocal when |b| is outside [2^-40, 2^40] (the numerators here are a distance in [2^-48, 2^64] and a cosine difference), and a wave that
+// meets such a light takes the IEEE division (slowUniform, wave-uniform).
+__device__ __forceinline__ float div_stored(float a, float b, float y, bool slowUniform)
+{
+    if (__builtin_expect(slowUniform, 0)) return a / b;
+    const float q0 = a * y;
+    return __builtin_amdgcn_div_fixupf(fmaf(fmaf(-b, q0, a), y, q0), b, a);
+}
+
 #define LREC 5 // float4 per staged light
 #define PENDK 4  // queued pairs per pixel in one window (their queue positions ride in one register, 7 bits each under a sentinel bit)
 #define QMAX 128 // queued pairs per wave in one window (two lights that reach every pixel fit; positions are 7 bits; 17.4 KB of LDS per block, 9 blocks per CU)
@@ -266,7 +279,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 //   rec1 = (normalize(-direction).xyz, bits: type | shadowType << 8 | finite << 16)
 //   rec2 = (attenuation.xyz, B)     B = point: bounds.x          spot: epsilon = cutOff.x - cutOff.y (:297)
 //   rec3 = (Li = -direction.xyz, cutOff.y)
-//   rec4 = (intensity.xyz, -)
+//   rec4 = (intensity.xyz, RN(1 / B) if 2^-40 <= |B| <= 2^40, else NaN: see div_stored)
 //
 // The kernel is VALU-bound (rocprofv3: SQ_INSTS_VALU x 4 cycles on 1024 SIMDs == the duration of the loop-per-light version it
 // replaced), so the shape below is about vector instructions per wave: light kind, finiteness and "survived the box test" are
@@ -485,7 +498,8 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         o[1] = make_float4(ndx * linv, ndy * linv, ndz * linv, __uint_as_float(bits));
         o[2] = make_float4(q4.x, q4.y, q4.z, rb);
         o[3] = make_float4(ndx, ndy, ndz, q5.y);
-        o[4] = make_float4(q3.x, q3.y, q3.z, 0.0f);
+        const uint32_t rbExp = (__float_as_uint(rb) >> 23) & 0xFFu;
+        o[4] = make_float4(q3.x, q3.y, q3.z, (rbExp - 87u <= 80u) ? rcp_of_sqrt(rb) : __builtin_nanf("")); // (rcp_of_sqrt: RN(1 / x) for every |x| in [2^-126, 2^126])
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the records are in LDS (global loads may stay in flight)
     const uint32_t numLights = min(min(listNum, sEnd[0]), min(sEnd[1], min(sEnd[2], sEnd[3])));
@@ -659,20 +673,23 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                 if (type == 1u || type == 2u) {
                     // exact falloff (the oracle's op order where it is ill-conditioned)
                     const float4 r2 = R[2];
+                    const float binv = reinterpret_cast<const float*>(R)[19]; // rec4.w = 1 / r2.w, or NaN
+                    const bool slowDiv = __ballot(binv != binv) != 0ull;
                     const float dx = r0.x - pwx, dy = r0.y - pwy, dz = r0.z - pwz;
                     const float d2 = dot3f(dx, dy, dz, dx, dy, dz);
                     const float dist = sqrt_exact(d2);                                       // exact: feeds 1 - (dist / bounds.x)^2
                     const float att = rcp_fast(fmaf(r2.z, d2, fmaf(r2.y, dist, r2.x))); // 1/(a.x + a.y d + a.z d^2) (:289,:300)
                     const bool isPoint = type == 1u;
-                    // one IEEE division serves both types: point dist / bounds.x (:290), spot 1 / dist (normalize, :298)
-                    const float x = (isPoint ? dist : 1.0f) / (isPoint ? r2.w : dist);
+                    // point: dist / bounds.x (:290); spot: 1 / dist (normalize, :298) -- both in four instructions, both for every lane, then selected
+                    const float xPoint = div_stored(dist, r2.w, binv, slowDiv), xSpot = rcp_of_sqrt(dist);
+                    const float x = isPoint ? xPoint : xSpot;
                     if (isPoint) {
                         const float q = fminf(fmaxf(x, 0.0f), 1.0f);
                         falloff = att * (1.0f - q * q);                                  // (:290)
                     } else {
                         const float theta = dot3f(dx * x, dy * x, dz * x, r1.x, r1.y, r1.z); // dot(normalize(pos - wp), normalize(-dir))
                         const float cutY = r3.w;
-                        falloff = att * fminf(fmaxf((theta - cutY) / r2.w, 0.0f), 1.0f);     // (:301); exact: cancels at the cone edge
+                        falloff = att * fminf(fmaxf(div_stored(theta - cutY, r2.w, binv, slowDiv), 0.0f), 1.0f); // (:301); exact: cancels at the cone edge
                         if (theta < cutY) falloff = 0.0f;                                     // (:303-306)
                     }
                 }

@@ -331,6 +331,35 @@ def test_lengths_outside_the_fast_square_root(ctx):
     assert (err <= RTOL * np.abs(ref[fin])).all(), (err / (np.abs(ref[fin]) + 1e-300)).max()
 
 
+def test_divisors_outside_the_staged_reciprocal(ctx):
+    """dist / bounds.x and (theta - cutOff.y) / epsilon run on a reciprocal staged with the light when the divisor lies in [2^-40, 2^40], and
+    on the IEEE division otherwise (wave-uniform): a point light with a radius of 1e15 (reaches everything, window ~1), one with 1e-15 at a
+    surface point, a spot light whose inner and outer cone coincide (epsilon = 0: x / 0), one with epsilon < 0."""
+    f = synth.make_frame("tiny")
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    lights = f.lights.copy()
+    py, px = H // 2, W // 2
+    lights["type"][0] = host.LIGHT_POINT; lights["bounds"][0, 0] = 1e15
+    lights["type"][1] = host.LIGHT_POINT; lights["bounds"][1, 0] = 1e-15; lights["worldPosition"][1] = f.surface[0, py, px, :3]
+    spots = np.nonzero(lights["type"] == host.LIGHT_SPOT)[0]
+    assert len(spots) >= 2
+    lights["cutOff"][spots[0], 0] = lights["cutOff"][spots[0], 1]
+    lights["cutOff"][spots[1], 0] = lights["cutOff"][spots[1], 1] - np.float32(0.05)
+    g, idx, _ = oracle.light_cull(f.cam.frame, W, H, lights, f.depth)
+    assert (idx[1: 1 + int(g[:, 1].sum())] == 0).sum() >= len(g) // 2, "the 1e15 light is in most lists"
+    with np.errstate(all="ignore"):
+        ref = oracle.shade(f.cam.frame, W, H, f.surface, lights, g, idx)
+    fp = ForwardPlus(ctx, W, H, N)
+    l = upload_lights(lights, ctx.device)
+    fp.cull(f.cam.frame, l, N, torch.from_numpy(f.depth).to(ctx.device))
+    got = fp.shade(f.cam.frame, torch.from_numpy(f.surface).to(ctx.device), l, N).cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_array_equal(np.isinf(got), np.isinf(ref))
+    fin = np.isfinite(ref)
+    err = np.abs(got[fin].astype(np.float64) - ref[fin])
+    assert (err <= RTOL * np.abs(ref[fin])).all(), (err / (np.abs(ref[fin]) + 1e-300)).max()
+
+
 def test_non_finite_terms_propagate_like_the_reference(ctx):
     """0 * inf must stay NaN: a zero window / facing factor only annihilates a FINITE product.  Pixels with roughness 0 (NdfGGX = 0/0) and
     lights with an infinite or NaN intensity may not be skipped by any of the conservative tests; the NaN / inf pattern of the radiance must be
