@@ -481,17 +481,19 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         // A zero factor only annihilates a FINITE product (inf * 0 = NaN in the reference): a light with ANY non-finite parameter --
         // intensity, but also position, direction, attenuation, cone or radius, which reach the product through the falloff -- is never
         // skipped.
-#define NONFINITE(x) __builtin_amdgcn_classf((x), 0x207) /* sNaN | qNaN | -inf | +inf: one v_cmp_class each, the ORs are scalar */
-        const bool finite = !(NONFINITE(q3.x) || NONFINITE(q3.y) || NONFINITE(q3.z) || NONFINITE(q1.x) || NONFINITE(q1.y) || NONFINITE(q1.z) ||
-                              NONFINITE(q2.x) || NONFINITE(q2.y) || NONFINITE(q2.z) || NONFINITE(q4.x) || NONFINITE(q4.y) || NONFINITE(q4.z) ||
-                              NONFINITE(q5.x) || NONFINITE(q5.y) || NONFINITE(q6.x));
-#undef NONFINITE
+        // (staging is the block's critical path -- the other three waves wait at the barrier for the first -- so it is kept short and free of
+        // branches: x * 0 is 0 for a finite x and NaN otherwise, two fma chains collect the fifteen parameters, one compare reads the result)
+        const float z0 = fmaf(q3.x, 0.0f, fmaf(q3.y, 0.0f, fmaf(q3.z, 0.0f, fmaf(q1.x, 0.0f, fmaf(q1.y, 0.0f, fmaf(q1.z, 0.0f, fmaf(q2.x, 0.0f, q2.y * 0.0f)))))));
+        const float z1 = fmaf(q2.z, 0.0f, fmaf(q4.x, 0.0f, fmaf(q4.y, 0.0f, fmaf(q4.z, 0.0f, fmaf(q5.x, 0.0f, fmaf(q5.y, 0.0f, q6.x * 0.0f))))));
+        const float zz = z0 + z1;
+        const bool finite = zz == zz;
         // Conservative "out of reach" threshold of a point light: d^2 > r^2 (1 + 1e-5) => fl(dist / r) >= 1 => the radius
         // window (:290) is exactly 0.  Only for r > 0 (a negative radius clamps to the FULL window in the reference).
         const float r = q6.x;
-        float ra = __builtin_inff(), rb = r;
-        if (type == 1u) { if (finite && r > 0.0f) ra = (r * r) * 1.00001f; }
-        else { if (finite) ra = -(q5.y - 1e-5f); rb = q5.x - q5.y; }
+        const bool isPointLight = type == 1u;
+        const float raFinite = isPointLight ? (r > 0.0f ? (r * r) * 1.00001f : __builtin_inff()) : -(q5.y - 1e-5f);
+        const float ra = finite ? raFinite : __builtin_inff();
+        const float rb = isPointLight ? r : q5.x - q5.y;
         const uint32_t bits = (type < 255u ? type : 255u) | ((shadowType < 255u ? shadowType : 255u) << 8) | (finite ? 0x10000u : 0u);
         float4* o = sL + tid * LREC;
         o[0] = make_float4(q1.x, q1.y, q1.z, ra);
