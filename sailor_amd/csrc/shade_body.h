@@ -440,11 +440,13 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
 #undef NT_LOAD4
     if (ROLE == ROLE_BAND_TILE && g.num >= (uint32_t)SPLIT_MIN) return; // a tile of the split blocks
     const uint32_t listNum = g.num < (uint32_t)KEEP ? g.num : (uint32_t)KEEP;
-    const bool haveLight = (uint32_t)tid < listNum;
+    const unsigned long long haveMask = __ballot((uint32_t)tid < listNum); // (the masks where the compares are: a flag carried across a branch as a bool is a VGPR 0 / 1)
+    const bool haveLight = __builtin_amdgcn_inverse_ballot_w64(haveMask);
     uint32_t index = 0xFFFFFFFFu;
     if (haveLight) index = culled[g.offset + tid];
     // Standard.shader:430-433 "index == uint(-1) -> break" (and out-of-range guard): the list ends at the first such slot
-    const bool staged = index < (uint32_t)A.lightsNum; // (a lane without a list slot holds uint(-1))
+    const unsigned long long stagedMask = __ballot(index < (uint32_t)A.lightsNum); // (a lane without a list slot holds uint(-1))
+    const bool staged = __builtin_amdgcn_inverse_ballot_w64(stagedMask);
     float4 q0, q1, q2, q3, q4, q5, q6;
     if (staged) {
         const float4* L = reinterpret_cast<const float4*>(lights + index);
@@ -470,7 +472,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const float F0z = 0.04f * oneMinusMetal + P2.z * metallic;
     const float kdAx = oneMinusMetal * P2.x, kdAy = oneMinusMetal * P2.y, kdAz = oneMinusMetal * P2.z; // kd = (1 - F)(1 - metallic)
     {
-        const unsigned long long bad = __ballot(haveLight) & ~__ballot(index < (uint32_t)A.lightsNum);
+        const unsigned long long bad = haveMask & ~stagedMask;
         if (lane == 0) sEnd[wave] = bad ? (uint32_t)(wave * 64 + __builtin_ctzll(bad)) : 0xFFFFFFFFu;
     }
     if (staged) {
