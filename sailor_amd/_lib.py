@@ -120,6 +120,7 @@ SIGNATURES = {
     "sailor_hip_evsm_blur": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sailor_hip_evsm_blur_pass": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sailor_hip_compute_brdf_lut": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    "sailor_hip_self_check_exact_math": (C.c_int, [_P, _P, C.POINTER(C.c_uint64)]),
     "sailor_hip_compute_irradiance_map": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32]),
     "sailor_hip_prefilter_env_map": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
     "sailor_hip_equirect_to_cube": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32]),

@@ -101,6 +101,39 @@ __global__ __launch_bounds__(256) void k_brdf_lut(float2* __restrict__ lut, int 
     lut[i] = make_float2(DFG1 * InvNumSamples, DFG2 * InvNumSamples);
 }
 
+// ---- sailor_hip_self_check_exact_math: sqrt_exact / rcp_of_sqrt against sqrtf / the IEEE division, every float of their ranges ----
+__global__ __launch_bounds__(256) void k_self_check_exact_math(unsigned long long* __restrict__ bad)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t badSqrt = 0u, badRcp = 0u;
+    for (uint32_t n = 0; n < (uint32_t)((1ull << 32) / stride); n++, i += stride) {
+        const float x = __uint_as_float(i);
+        if (i >= 0x0F800000u && i < 0x7F800000u) { // [2^-96, inf): the fast form proper (everything else goes to sqrtf by construction)
+            const float y = __builtin_amdgcn_rsqf(x);
+            const float s0 = x * y, h = 0.5f * y;
+            badSqrt += __float_as_uint(fmaf(fmaf(-s0, s0, x), h, s0)) != __float_as_uint(sqrtf(x)) ? 1u : 0u;
+        }
+        const uint32_t m = i & 0x7FFFFFFFu;
+        if (m >= 0x00800000u && m <= 0x7E800000u) // 2^-126 <= |x| <= 2^126
+            badRcp += __float_as_uint(rcp_of_sqrt(x)) != __float_as_uint(1.0f / x) ? 1u : 0u;
+    }
+    if (badSqrt) atomicAdd(&bad[0], (unsigned long long)badSqrt);
+    if (badRcp) atomicAdd(&bad[1], (unsigned long long)badRcp);
+}
+
+extern "C" int sailor_hip_self_check_exact_math(SailorHipContext* ctx, void* dScratch, uint64_t mismatches[2])
+{
+    if (!ctx || !dScratch || !mismatches || ((uintptr_t)dScratch & 7)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    SAILOR_TRY_HIP(ctx, hipMemsetAsync(dScratch, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(k_self_check_exact_math, dim3(4096), dim3(256), 0, ctx->stream, (unsigned long long*)dScratch);
+    SAILOR_CHECK_LAUNCH(ctx, "k_self_check_exact_math");
+    SAILOR_TRY_HIP(ctx, hipMemcpyAsync(mismatches, dScratch, 16, hipMemcpyDeviceToHost, ctx->stream));
+    SAILOR_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SAILOR_HIP_OK;
+}
+
 extern "C" int sailor_hip_compute_brdf_lut(SailorHipContext* ctx, float* dLut, int32_t width, int32_t height)
 {
     if (!ctx || !dLut || width <= 0 || height <= 0 || ((uintptr_t)dLut & 7)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;

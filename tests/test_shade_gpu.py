@@ -301,6 +301,19 @@ def test_every_light_reaches_every_pixel(ctx):
     assert (ref[..., :3] > 0).all()
 
 
+def test_short_forms_of_the_exact_square_root_and_reciprocal_on_this_device(ctx):
+    """normalize() is v * (1 / sqrt(dot(v, v))) with a correctly rounded root and reciprocal; the kernels compute both in a handful of
+    instructions (one Newton step on v_rsq_f32 / v_rcp_f32) instead of the compiler's expansions.  That these are sqrtf's and the IEEE
+    division's bits is a property of the chip's approximation instructions, so it is checked on the chip the tests run on: every float of
+    [2^-96, inf) for the root, every float with 2^-126 <= |x| <= 2^126 for the reciprocal (the library's own self-check, about a second)."""
+    import ctypes
+    scratch = torch.zeros(4, dtype=torch.int32, device=ctx.device)
+    out = (ctypes.c_uint64 * 2)(7, 7)
+    rc = ctx._lib.sailor_hip_self_check_exact_math(ctx.handle, ctypes.c_void_p(scratch.data_ptr()), out)
+    assert rc == 0
+    assert (out[0], out[1]) == (0, 0), f"square root differs on {out[0]} inputs, reciprocal on {out[1]}"
+
+
 def test_lengths_outside_the_fast_square_root(ctx):
     """The kernel's square roots take a short form that is sqrtf's bits on [2^-96, inf) and fall back to sqrtf for anything else in the wave:
     a point light exactly AT a surface point (squared distance 0), a spot light whose direction is the zero vector (length 0, normalised to
