@@ -321,8 +321,10 @@ SAILOR_HIP_API int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFra
  * 21- and 12-instruction expansions: sqrt as one Newton step on v_rsq_f32 for x in [2^-96, inf), 1 / s as one Newton step on v_rcp_f32 for
  * |s| in [2^-126, 2^126] (sailor_amd/csrc/shade_body.h: sqrt_exact, rcp_of_sqrt).  This runs both against sqrtf and 1.0f / s over EVERY float of
  * those ranges on the device the context is bound to (about a second) and writes the number of inputs whose bits differ:
- *   mismatches[0] = square root, mismatches[1] = reciprocal.  Both must be 0; dScratch: device, 16 bytes. */
-SAILOR_HIP_API int sailor_hip_self_check_exact_math(SailorHipContext* ctx, void* dScratch, uint64_t mismatches[2]);
+ *   mismatches[0] = square root, mismatches[1] = reciprocal.  The quotient from a staged reciprocal (div_stored: Markstein's correction step,
+ * exact by theorem when nothing over- or underflows) has 2^64 operand pairs; 2^30 pseudo-random ones in the ranges its callers guarantee are
+ * compared with the IEEE division: mismatches[2].  All three must be 0; dScratch: device, 24 bytes. */
+SAILOR_HIP_API int sailor_hip_self_check_exact_math(SailorHipContext* ctx, void* dScratch, uint64_t mismatches[3]);
 
 /* The split-sum BRDF look-up table sampled by AmbientLighting: Content/Shaders/ComputeBrdfLut.shader:26-71 (1 024 Hammersley /
  * GGX samples per texel), dispatched once at start-up.  dLut: device, height x width float2 (the reference image is RG16F). */

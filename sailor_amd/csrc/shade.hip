@@ -118,18 +118,32 @@ __global__ __launch_bounds__(256) void k_self_check_exact_math(unsigned long lon
         if (m >= 0x00800000u && m <= 0x7E800000u) // 2^-126 <= |x| <= 2^126
             badRcp += __float_as_uint(rcp_of_sqrt(x)) != __float_as_uint(1.0f / x) ? 1u : 0u;
     }
+    // div_stored (the quotient from a staged reciprocal) cannot be compared exhaustively: 2^10 pseudo-random pairs per thread (2^30 in all), the
+    // divisor's exponent in [-40, 40] as the stager guarantees, the numerator's in [-48, 64] (a distance), both signs
+    uint32_t badDiv = 0u;
+    uint64_t rs = 0x9E3779B97F4A7C15ull * (uint64_t)(blockIdx.x * blockDim.x + threadIdx.x + 1u);
+    for (int n = 0; n < 1024; n++) {
+        rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17;
+        const uint32_t ra = (uint32_t)(rs >> 11), rb = (uint32_t)(rs >> 33) ^ (uint32_t)rs;
+        rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17;
+        const uint32_t re = (uint32_t)(rs >> 20);
+        const float a = __uint_as_float((ra & 0x807FFFFFu) | ((79u + (re & 0xFFFu) % 113u) << 23));
+        const float b = __uint_as_float((rb & 0x807FFFFFu) | ((87u + ((re >> 12) & 0xFFFu) % 81u) << 23));
+        badDiv += __float_as_uint(div_stored(a, b, rcp_of_sqrt(b), false)) != __float_as_uint(a / b) ? 1u : 0u;
+    }
     if (badSqrt) atomicAdd(&bad[0], (unsigned long long)badSqrt);
     if (badRcp) atomicAdd(&bad[1], (unsigned long long)badRcp);
+    if (badDiv) atomicAdd(&bad[2], (unsigned long long)badDiv);
 }
 
-extern "C" int sailor_hip_self_check_exact_math(SailorHipContext* ctx, void* dScratch, uint64_t mismatches[2])
+extern "C" int sailor_hip_self_check_exact_math(SailorHipContext* ctx, void* dScratch, uint64_t mismatches[3])
 {
     if (!ctx || !dScratch || !mismatches || ((uintptr_t)dScratch & 7)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
-    SAILOR_TRY_HIP(ctx, hipMemsetAsync(dScratch, 0, 16, ctx->stream));
+    SAILOR_TRY_HIP(ctx, hipMemsetAsync(dScratch, 0, 24, ctx->stream));
     hipLaunchKernelGGL(k_self_check_exact_math, dim3(4096), dim3(256), 0, ctx->stream, (unsigned long long*)dScratch);
     SAILOR_CHECK_LAUNCH(ctx, "k_self_check_exact_math");
-    SAILOR_TRY_HIP(ctx, hipMemcpyAsync(mismatches, dScratch, 16, hipMemcpyDeviceToHost, ctx->stream));
+    SAILOR_TRY_HIP(ctx, hipMemcpyAsync(mismatches, dScratch, 24, hipMemcpyDeviceToHost, ctx->stream));
     SAILOR_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SAILOR_HIP_OK;
 }

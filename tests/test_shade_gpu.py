@@ -307,11 +307,11 @@ def test_short_forms_of_the_exact_square_root_and_reciprocal_on_this_device(ctx)
     division's bits is a property of the chip's approximation instructions, so it is checked on the chip the tests run on: every float of
     [2^-96, inf) for the root, every float with 2^-126 <= |x| <= 2^126 for the reciprocal (the library's own self-check, about a second)."""
     import ctypes
-    scratch = torch.zeros(4, dtype=torch.int32, device=ctx.device)
-    out = (ctypes.c_uint64 * 2)(7, 7)
+    scratch = torch.zeros(6, dtype=torch.int32, device=ctx.device)
+    out = (ctypes.c_uint64 * 3)(7, 7, 7)
     rc = ctx._lib.sailor_hip_self_check_exact_math(ctx.handle, ctypes.c_void_p(scratch.data_ptr()), out)
     assert rc == 0
-    assert (out[0], out[1]) == (0, 0), f"square root differs on {out[0]} inputs, reciprocal on {out[1]}"
+    assert (out[0], out[1], out[2]) == (0, 0, 0), f"square root differs on {out[0]} inputs, reciprocal on {out[1]}, staged-reciprocal quotient on {out[2]} of 2^30 pairs"
 
 
 def test_lengths_outside_the_fast_square_root(ctx):
