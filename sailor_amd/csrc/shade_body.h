@@ -844,6 +844,10 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         accX = fmaf(ambX, ao, accX); accY = fmaf(ambY, ao, accY); accZ = fmaf(ambZ, ao, accZ);                              // :371, :425 ambient + sum over lights
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (active) radiance[(size_t)(py - A.fbRow0) * A.W + gx] = make_float4(accX, accY, accZ, P0.w); // outColor.a = material.albedo.a (:438)
+    if (active) { // outColor.a = material.albedo.a (:438); written once and read by nobody here: non-temporal, like the surface loads
+        float4* o = radiance + ((size_t)(py - A.fbRow0) * A.W + gx);
+        __builtin_nontemporal_store(accX, &o->x); __builtin_nontemporal_store(accY, &o->y);
+        __builtin_nontemporal_store(accZ, &o->z); __builtin_nontemporal_store(P0.w, &o->w);
+    }
 }
 
