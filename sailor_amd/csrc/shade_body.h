@@ -539,14 +539,26 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         const uint32_t li = (uint32_t)(h * 64 + lane);
         const uint32_t lc = li < numLights ? li : 0u; // (lanes past the list read slot 0 and are masked out)
         const float4 c0 = sL[lc * LREC + 0];
-        const uint32_t bits = __float_as_uint(sL[lc * LREC + 1].w);
+        const float4 c1 = sL[lc * LREC + 1];
+        const uint32_t bits = __float_as_uint(c1.w);
         const unsigned long long mIn = __ballot(li < numLights);
         const unsigned long long mFin = __ballot((bits & 0x10000u) != 0u);
         const unsigned long long mPoint = __ballot((bits & 0xFFu) == 1u), mSpot = __ballot((bits & 0xFFu) == 2u), mDir = __ballot((bits & 0xFFu) == 0u);
         const float ex = c0.x - scx, ey = c0.y - scy, ez = c0.z - scz;
         const float t = __builtin_amdgcn_sqrtf(c0.w) * 1.0001f + sphereR; // c0.w = r^2 (1 + 1e-5) (+inf: never reject)
-        const unsigned long long mFar = __ballot(fmaf(ex, ex, fmaf(ey, ey, ez * ez)) > t * t); // only meaningful for finite point lights
-        const unsigned long long dropped = forceMask == 0ull ? (mPoint & mFin & mFar) : 0ull;
+        const float e2 = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
+        const unsigned long long mFar = __ballot(e2 > t * t); // only meaningful for finite point lights
+        // A spot light whose cone misses the sphere: seen from the light the sphere spans the angle delta = asin(R / |e|) around the direction
+        // to its centre, which makes the angle A with the cone's axis; no pixel can do better than cos(A - delta) = cosA cosd + sinA sind, and
+        // the per-pixel test passes from c = cutOff.y - 1e-5 (= -rec0.w) up.  Approximate arithmetic (v_rsq / v_sqrt), hence the 1e-4; a NaN
+        // anywhere (the light inside the sphere: sind > 1; a zero axis) fails the compares and keeps the light.  On the 4K frame 6.0 spot
+        // lights per quadrant come this far, 1.6 reach a pixel, 3.8 pass this test (scripts/analysis/shade_trips.py).
+        const float rinv = rsq_fast(e2);
+        const float sind = sphereR * rinv;
+        const float cosA = fmaf(ex, c1.x, fmaf(ey, c1.y, ez * c1.z)) * rinv;
+        const float cosd = __builtin_amdgcn_sqrtf(fmaf(-sind, sind, 1.0f)), sinA = __builtin_amdgcn_sqrtf(fmaf(-cosA, cosA, 1.0f));
+        const unsigned long long mOut = __ballot(fmaf(sinA, sind, cosA * cosd) < -c0.w - 1e-4f) & __ballot(cosA < cosd); // only meaningful for finite spot lights
+        const unsigned long long dropped = forceMask == 0ull ? (mFin & ((mPoint & mFar) | (mSpot & mOut))) : 0ull;
         const unsigned long long all = mIn & ~dropped;
         seg[h] = all & mFin & mPoint;
         seg[2 + h] = all & mFin & mSpot;
