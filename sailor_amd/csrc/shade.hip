@@ -10,7 +10,7 @@
 // quadrant of the tile (eight 128-byte row segments per float4 plane); radiance goes out as one float4 per lane.  The
 // tile list is conservative (sphere vs tile frustum) while the surface is a thin sheet inside that frustum: on the 4K /
 // 65 536-light frame only ~3 % of the (pixel, light) pairs are actually lit, and the kernel is bound by vector-instruction
-// issue.  So a wave (1) tests its list one LANE per LIGHT against the quadrant's bounding sphere, (2) tests the survivors one
+// issue.  So a wave (1) tests its list one LANE per LIGHT against the quadrant's bounding sphere (a point light's reach, a spot light's cone), (2) tests the survivors one
 // LANE per PIXEL with a 6-instruction conservative reach test + the facing test and queues the (pixel, light) pairs that
 // pass, (3) runs the exact falloff and the BRDF one LANE per PAIR on full waves.  Details at k2_shade_body.  The ambient /
 // IBL term of Standard.shader (:343-372) and the BRDF look-up table it samples are the last two sections of this file.
