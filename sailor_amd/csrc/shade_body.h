@@ -578,8 +578,9 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     // [colour][its position in the queue]; each pixel keeps the positions of its own pairs (7 bits each, in the order queued, under a
     // sentinel bit) and adds their results up afterwards: no atomics (ds_add_f32 is serialised per lane on this LDS: ~170 cycles
     // per wave instruction, scripts/microbench/lds_ops.hip).  (Was: slots [colour][ordinal of the pair among its pixel's][pixel] --
-    // 9 KB per block instead of 5, and it is the block's LDS that decides how many blocks share a CU: a block's memory is held until
-    // its slowest wave is done, so with exactly 32 waves' worth of blocks a CU ran 23 waves on average.)
+    // 9 KB per block instead of 6, a cap of three pairs per pixel and window instead of four, and an address of three instructions in the pair
+    // pass instead of one.  More blocks per CU were NOT what it bought: with room for ten the kernel takes what it takes with eight -- the
+    // 32 wave slots of a CU are the cap.)
     uint16_t* Q = sQ + wave * QMAX;
     const uint32_t qAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)Q; // its LDS byte address, for the hand-written append below
     const uint32_t sLAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)sL;
