@@ -510,7 +510,6 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const float alpha = roughness * roughness, alphaSq = alpha * alpha;
     const float rr = roughness + 1.0f, k = (rr * rr) * 0.125f, oneMinusK = 1.0f - k;
     const float g1Lo = cosLo * rcp_fast(fmaf(cosLo, oneMinusK, k)); // GeometrySchlickG1(cosLo, k)
-    const bool brdfFinite = alphaSq > 0.0f;                       // roughness 0 makes NdfGGX 0/0 in the reference
 
     // ---- which lights can reach this quadrant at all?  One LANE per LIGHT against the bounding SPHERE of the quadrant's 64 surface
     // points: centre = the pixel in its middle (lane 27), radius^2 = the largest squared distance to it (one max-reduction over the
