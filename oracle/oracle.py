@@ -392,3 +392,51 @@ def shadow_resolve_evsm(depth: np.ndarray) -> np.ndarray:
     out = np.zeros(d.shape + (4,), np.float32)
     lib().oracle_shadow_resolve_evsm(_p(d), C.c_int32(d.shape[1]), C.c_int32(d.shape[0]), _p(out))
     return out
+
+
+def lighting_tick_runs(dirty, active, mobility, frame_last_change, owner_frame_last_change, skip_list):
+    """LightingECS::Tick's loop (Runtime/ECS/LightingECS.cpp:93-192) over per-slot flags, in plain Python: returns the copies it issues as
+    (first record slot, [component indices whose records the copy carries]) in issue order; `dirty`, `frame_last_change` (lists) and
+    `skip_list` (list of [first, count]) are updated in place as the reference updates them.  Literal, including what follows from the
+    position of `continue` (:148-149) and of the flush (:182): an inactive slot neither ends nor flushes a run, and a run still open when the loop
+    ends is never copied."""
+    runs, batch = [], []
+    should_write, start, skip_index, n = True, 0, 0, len(dirty)
+    index = 0
+    while index < n:
+        if skip_index < len(skip_list) and index == skip_list[skip_index][0]:          # :95-103
+            index += skip_list[skip_index][1]
+            if index >= n:
+                break
+            skip_index += 1
+        if mobility[index] == 0:                                                        # EMobilityType::Static, :108-146
+            placed = False
+            if skip_index > 0 and index == skip_list[skip_index - 1][0] + skip_list[skip_index - 1][1]:
+                skip_list[skip_index - 1][1] += 1
+                placed = True
+            if not placed and skip_index > 0:
+                for i in range(skip_index - 1, len(skip_list) - 1):
+                    lo = skip_list[i][0] + skip_list[skip_index - 1][1]
+                    hi = skip_list[i + 1][0]
+                    if lo < index < hi:
+                        skip_list.insert(i + 1, [index, 1])
+                        placed = True
+                        skip_index += 1
+                        break
+            if not placed:
+                skip_list.append([index, 1])
+                skip_index += 1
+        if active[index]:                                                               # :148-149 (`continue` otherwise)
+            if dirty[index] or frame_last_change[index] < owner_frame_last_change[index]:   # :152
+                if should_write:
+                    should_write, start = False, index
+                batch.append(index)
+                frame_last_change[index] = owner_frame_last_change[index]
+                dirty[index] = False
+            else:
+                should_write = True
+            if (should_write or index == n - 1) and batch:                              # :182-191
+                runs.append((start, batch))
+                batch = []
+        index += 1
+    return runs

@@ -18,29 +18,83 @@ size_t LightingECS::RegisterComponent(const LightData& data)
     return m_components.size() - 1;
 }
 
-void LightingECS::Tick(RHICommandListPtr cmdList)
+// LightingECS.cpp:93-192, literally -- including what follows from where its `continue` and its flush sit:
+//   * a slot of a static owner joins the skip list the first time the loop meets it (it is still packed on that pass) and is stepped over from
+//     the next Tick on, dirty or not; only ONE skip-list run is applied per loop step;
+//   * an inactive slot leaves the loop body before the "close the run" check (:148-149), so it neither ends a run nor flushes one: a dirty run
+//     that continues behind it is written as ONE copy whose later records land one slot early, and a run still open when the LAST slot is
+//     inactive (or when the skip list steps past the end) is never written, although its lights were marked clean;
+//   * a light is packed when it is dirty OR its owner's transform changed after the frame it was last packed for (:152).
+std::vector<LightUploadRun> LightingECS::CollectDirtyRuns(std::vector<LightData>& components, std::vector<std::pair<uint32_t, uint32_t>>& skipList,
+                                                          std::vector<LightShaderData>& records)
 {
-    auto binding = m_lightsData->GetOrAddShaderBinding("light");
-    std::vector<LightShaderData> batch;
+    std::vector<LightUploadRun> runs;
+    size_t pending = 0; // records packed since the last copy (the reference's shaderDataBatch)
     bool bShouldWrite = true;
     size_t startIndex = 0;
-    for (size_t index = 0; index < m_components.size(); index++) {
-        auto& data = m_components[index];
-        if (data.m_bIsDirty) {
+    uint32_t skipIndex = 0;
+    const size_t num = components.size();
+    for (size_t index = 0; index < num; index++) {
+        if (skipIndex < skipList.size() && index == skipList[skipIndex].first) { // :95-103
+            index += skipList[skipIndex].second;
+            if (index >= num) break;
+            skipIndex++;
+        }
+        LightData& data = components[index];
+        if (data.m_ownerMobility == EMobilityType::Static) { // :108-146
+            bool bPlaced = false;
+            if (skipIndex > 0 && index == (size_t)skipList[skipIndex - 1].first + skipList[skipIndex - 1].second) { // grows the run it follows
+                skipList[skipIndex - 1].second++;
+                bPlaced = true;
+            }
+            if (!bPlaced && skipIndex > 0) { // between two runs (the bound uses run skipIndex-1's length for every i, as the reference does)
+                for (int32_t i = (int32_t)skipIndex - 1; i < (int32_t)skipList.size() - 1; i++) {
+                    const uint32_t start = skipList[i].first + skipList[skipIndex - 1].second, end = skipList[i + 1].first;
+                    if (index > start && index < end) {
+                        skipList.insert(skipList.begin() + (i + 1), std::make_pair((uint32_t)index, 1u));
+                        bPlaced = true;
+                        skipIndex++;
+                        break;
+                    }
+                }
+            }
+            if (!bPlaced) {
+                skipList.emplace_back((uint32_t)index, 1u);
+                skipIndex++;
+            }
+        }
+        if (!data.m_bIsActive) continue; // :148-149
+        if (data.m_bIsDirty || data.m_frameLastChange < data.m_ownerFrameLastChange) { // :152
             if (bShouldWrite) { bShouldWrite = false; startIndex = index; }
             LightShaderData shaderData;
             sailor_host_pack_light((uint32_t)data.m_type, (uint32_t)data.m_shadowType, data.m_worldPosition, data.m_direction, data.m_intensity,
-                                   data.m_attenuation, data.m_cutOff, data.m_bounds, &shaderData); // LightingECS.cpp:163-172
-            batch.push_back(shaderData);
+                                   data.m_attenuation, data.m_cutOff, data.m_bounds, &shaderData); // :162-172
+            records.push_back(shaderData);
+            pending++;
+            data.m_frameLastChange = data.m_ownerFrameLastChange; // :174
             data.m_bIsDirty = false;
         } else bShouldWrite = true;
-        if ((bShouldWrite || index == m_components.size() - 1) && !batch.empty()) { // LightingECS.cpp:182-191: one copy per dirty run
-            Renderer::GetDriverCommands()->UpdateShaderBinding(cmdList, binding, batch.data(), sizeof(LightShaderData) * batch.size(),
-                                                               binding->GetBufferOffset() + sizeof(LightShaderData) * startIndex);
-            batch.clear();
+        if ((bShouldWrite || index == num - 1) && pending > 0) { // :182-191: one copy per run
+            runs.push_back({ startIndex, pending });
+            pending = 0;
         }
     }
-    m_packedCount = m_components.size();
+    records.resize(records.size() - pending); // a run that was never closed is never written
+    return runs;
+}
+
+void LightingECS::Tick(RHICommandListPtr cmdList)
+{
+    auto binding = m_lightsData->GetOrAddShaderBinding("light");
+    std::vector<LightShaderData> records;
+    m_lastUploads = CollectDirtyRuns(m_components, m_skipList, records);
+    size_t at = 0;
+    for (const LightUploadRun& run : m_lastUploads) {
+        Renderer::GetDriverCommands()->UpdateShaderBinding(cmdList, binding, records.data() + at, sizeof(LightShaderData) * run.m_count,
+                                                           binding->GetBufferOffset() + sizeof(LightShaderData) * run.m_startIndex);
+        at += run.m_count;
+    }
+    m_packedCount = m_components.size(); // FillLightingData: m_totalNumLights counts every slot, active or not (:404)
 }
 
 void LightingECS::SetPacked(RHICommandListPtr cmdList, const LightShaderData* records, size_t count)

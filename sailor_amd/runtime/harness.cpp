@@ -256,6 +256,83 @@ RT_API void sailor_rt_tick_lights(SailorRuntime* rt)
     rt->lighting->FillLightingData(rt->snapshot);
 }
 
+// LightComponent setters + MarkDirty (Components/LightComponent.h): new parameters for one light; null pointers leave a field alone
+RT_API int sailor_rt_update_light(SailorRuntime* rt, int index, const float* pos, const float* dir, const float* intensity, const float* bounds,
+                                  const float* cutOffDegrees)
+{
+    if (!rt || index < 0 || (size_t)index >= rt->lighting->Num()) return -1;
+    LightData& d = rt->lighting->GetComponentData((size_t)index);
+    if (pos) memcpy(d.m_worldPosition, pos, 12);
+    if (dir) memcpy(d.m_direction, dir, 12);
+    if (intensity) memcpy(d.m_intensity, intensity, 12);
+    if (bounds) memcpy(d.m_bounds, bounds, 12);
+    if (cutOffDegrees) memcpy(d.m_cutOff, cutOffDegrees, 8);
+    d.m_bIsDirty = true;
+    return 0;
+}
+
+// What Tick asks of the component and its owner besides the parameters: TComponent::SetActive, MarkDirty, the owner's mobility and the frame
+// its transform last changed (GameObject::GetFrameLastChange); a negative value leaves the field alone.
+RT_API int sailor_rt_set_light_state(SailorRuntime* rt, int index, int active, int dirty, int mobility, long long ownerFrameLastChange)
+{
+    if (!rt || index < 0 || (size_t)index >= rt->lighting->Num()) return -1;
+    LightData& d = rt->lighting->GetComponentData((size_t)index);
+    if (active >= 0) d.m_bIsActive = active != 0;
+    if (dirty >= 0) d.m_bIsDirty = dirty != 0;
+    if (mobility >= 0) d.m_ownerMobility = (EMobilityType)mobility;
+    if (ownerFrameLastChange >= 0) d.m_ownerFrameLastChange = (size_t)ownerFrameLastChange;
+    return 0;
+}
+
+// the copies the last sailor_rt_tick_lights recorded: (first record slot, record count) pairs in issue order; returns their number
+RT_API int sailor_rt_light_uploads(SailorRuntime* rt, uint32_t* outStartCount, int maxRuns)
+{
+    const auto& runs = rt->lighting->GetLastUploads();
+    for (int i = 0; i < (int)runs.size() && i < maxRuns; i++) {
+        outStartCount[2 * i] = (uint32_t)runs[(size_t)i].m_startIndex;
+        outStartCount[2 * i + 1] = (uint32_t)runs[(size_t)i].m_count;
+    }
+    return (int)runs.size();
+}
+
+RT_API uint32_t sailor_rt_total_num_lights(SailorRuntime* rt) { return rt->snapshot.m_totalNumLights; }
+
+// LightingECS::Tick's loop without a renderer (no device needed): `count` default lights with the given flags, `ticks` passes in a row with the
+// skip list carried from pass to pass; a light's position is (its slot, pass, 0).  Per pass: outRunCounts[pass] runs appended to outStartCount
+// (pairs), the records of those runs appended to outRecords (112 B each).  Flags are updated in place.  Returns the total number of runs.
+RT_API int sailor_rt_plan_light_uploads(int count, uint8_t* dirty, const uint8_t* active, const uint8_t* mobility, uint64_t* frameLastChange,
+                                        const uint64_t* ownerFrameLastChange, int ticks, const uint8_t* redirtyPerTick, int* outRunCounts,
+                                        uint32_t* outStartCount, int maxRuns, void* outRecords, int maxRecords)
+{
+    std::vector<LightData> comps((size_t)count);
+    for (int i = 0; i < count; i++) {
+        comps[(size_t)i].m_bIsDirty = dirty[i] != 0; comps[(size_t)i].m_bIsActive = active[i] != 0;
+        comps[(size_t)i].m_ownerMobility = (EMobilityType)mobility[i];
+        comps[(size_t)i].m_frameLastChange = (size_t)frameLastChange[i]; comps[(size_t)i].m_ownerFrameLastChange = (size_t)ownerFrameLastChange[i];
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> skipList;
+    int total = 0, totalRecords = 0;
+    for (int t = 0; t < ticks; t++) {
+        for (int i = 0; i < count; i++) {
+            comps[(size_t)i].m_worldPosition[0] = (float)i; comps[(size_t)i].m_worldPosition[1] = (float)t;
+            if (t > 0 && redirtyPerTick && redirtyPerTick[(size_t)(t - 1) * count + i]) comps[(size_t)i].m_bIsDirty = true;
+        }
+        std::vector<SailorLightShaderData> records;
+        const auto runs = LightingECS::CollectDirtyRuns(comps, skipList, records);
+        outRunCounts[t] = (int)runs.size();
+        for (const auto& r : runs) {
+            if (total < maxRuns) { outStartCount[2 * total] = (uint32_t)r.m_startIndex; outStartCount[2 * total + 1] = (uint32_t)r.m_count; }
+            total++;
+        }
+        for (const auto& rec : records) {
+            if (totalRecords < maxRecords) memcpy((uint8_t*)outRecords + sizeof(SailorLightShaderData) * (size_t)totalRecords, &rec, sizeof rec);
+            totalRecords++;
+        }
+    }
+    for (int i = 0; i < count; i++) { dirty[i] = comps[(size_t)i].m_bIsDirty; frameLastChange[i] = comps[(size_t)i].m_frameLastChange; }
+    return total;
+}
+
 // the LinearDepth render target (device memory owned by the caller), wired as the node's "depthStencil" parameter
 RT_API void sailor_rt_set_depth(SailorRuntime* rt, void* devicePtr, int width, int height)
 {
@@ -517,6 +594,12 @@ RT_API void sailor_rt_wait_idle(SailorRuntime*) { Renderer::GetDriver()->WaitIdl
 // device pointers of the node-owned SSBOs, for read-back by the tests
 RT_API void* sailor_rt_buffer(SailorRuntime* rt, const char* name, size_t* outBytes)
 {
+    if (name && !strcmp(name, "light")) { // LightingECS's `light` SSBO (LightingECS.cpp:44)
+        auto lb = rt->lighting->GetLightsData()->Find("light");
+        if (!lb || !lb->m_buffer) return nullptr;
+        if (outBytes) *outBytes = lb->m_buffer->m_size;
+        return lb->m_buffer->m_hip.m_devicePtr;
+    }
     auto node = rt->lightCulling.DynamicCast<LightCullingNode>();
     if (!node || !node->GetCulledLights()) return nullptr;
     auto b = node->GetCulledLights()->Find(name);

@@ -33,6 +33,11 @@ def load() -> C.CDLL:
         rt.sailor_rt_set_lights.argtypes = [P, P, C.c_int]
         rt.sailor_rt_add_light.argtypes = [P, C.c_uint32, C.c_uint32, P, P, P, P, P]
         rt.sailor_rt_tick_lights.argtypes = [P]
+        rt.sailor_rt_update_light.argtypes = [P, C.c_int, P, P, P, P, P]
+        rt.sailor_rt_set_light_state.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong]
+        rt.sailor_rt_light_uploads.argtypes = [P, P, C.c_int]
+        rt.sailor_rt_total_num_lights.restype = C.c_uint32
+        rt.sailor_rt_total_num_lights.argtypes = [P]
         rt.sailor_rt_set_depth.argtypes = [P, P, C.c_int, C.c_int]
         rt.sailor_rt_set_raw_depth.argtypes = [P, P, C.c_int, C.c_int]
         rt.sailor_rt_set_surface.argtypes = [P, P, P, C.c_int, C.c_int]
@@ -109,6 +114,36 @@ class Runtime:
     def set_lights(self, lights: np.ndarray):
         raw = np.ascontiguousarray(lights).view(np.uint8)
         self.rt.sailor_rt_set_lights(self.h, raw.ctypes.data, len(lights))
+
+    @staticmethod
+    def _f3(v):
+        return None if v is None else np.ascontiguousarray(v, np.float32).ctypes.data_as(C.c_void_p)
+
+    def add_light(self, light_type: int, shadow_type: int, position, direction, intensity, bounds, cut_off_degrees=None) -> int:
+        """register one light as a component (LightData; cut-off in degrees); packed by the next tick_lights()"""
+        keep = [np.ascontiguousarray(v, np.float32) for v in (position, direction, intensity, bounds)]
+        cut = np.ascontiguousarray(cut_off_degrees, np.float32) if cut_off_degrees is not None else None
+        return self.rt.sailor_rt_add_light(self.h, light_type, shadow_type, *[k.ctypes.data for k in keep], cut.ctypes.data if cut is not None else None)
+
+    def update_light(self, index: int, position=None, direction=None, intensity=None, bounds=None, cut_off_degrees=None):
+        """new parameters for one light + MarkDirty"""
+        keep = [None if v is None else np.ascontiguousarray(v, np.float32) for v in (position, direction, intensity, bounds, cut_off_degrees)]
+        assert self.rt.sailor_rt_update_light(self.h, index, *[None if k is None else k.ctypes.data for k in keep]) == 0
+
+    def set_light_state(self, index: int, active=None, dirty=None, mobility=None, owner_frame_last_change=None):
+        """TComponent::SetActive / MarkDirty, the owner's mobility (0 static, 1 stationary, 2 dynamic) and GameObject::GetFrameLastChange"""
+        enc = lambda v: -1 if v is None else int(v)
+        assert self.rt.sailor_rt_set_light_state(self.h, index, enc(active), enc(dirty), enc(mobility), enc(owner_frame_last_change)) == 0
+
+    def tick_lights(self):
+        """LightingECS::Tick + FillLightingData; returns the copies it recorded as [(first record slot, record count)]"""
+        self.rt.sailor_rt_tick_lights(self.h)
+        buf = np.zeros(2 * 4096, np.uint32)
+        n = self.rt.sailor_rt_light_uploads(self.h, buf.ctypes.data, 4096)
+        return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(min(n, 4096))]
+
+    def total_num_lights(self) -> int:
+        return self.rt.sailor_rt_total_num_lights(self.h)
 
     def set_depth(self, depth_tensor):
         self.rt.sailor_rt_set_depth(self.h, depth_tensor.data_ptr(), depth_tensor.shape[1], depth_tensor.shape[0])

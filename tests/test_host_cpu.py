@@ -556,3 +556,115 @@ def test_row_costs_charge_long_tiles():
     b0 = sdist.balanced_tile_rows(sdist.row_cost_entries(flat.reshape(-1), 10), 10, 4)
     b1 = sdist.balanced_tile_rows(sdist.row_cost_entries(clustered.reshape(-1), 10), 10, 4)
     assert b0 == [0, 10, 20, 30, 40] and b1[1] < b0[1]
+
+
+# ---- L7: LightingECS::Tick's dirty-run streaming (Runtime/ECS/LightingECS.cpp:93-192) -- the C++ mirror's loop against the Python restatement ----
+def _plan_light_uploads(dirty, active, mobility, frame_last, owner_frame, ticks=1, redirty=None):
+    """sailor_rt_plan_light_uploads: (runs per tick as [(start, count)], records per tick as structured arrays, dirty / frameLastChange afterwards)"""
+    from sailor_amd import runtime_binding
+    rt = runtime_binding.load()
+    n = len(dirty)
+    d = np.array(dirty, np.uint8); a = np.array(active, np.uint8); m = np.array(mobility, np.uint8)
+    fl = np.array(frame_last, np.uint64); of = np.array(owner_frame, np.uint64)
+    rd = np.ascontiguousarray(redirty, np.uint8) if redirty is not None else None
+    counts = np.zeros(ticks, np.int32)
+    max_runs, max_records = ticks * (n + 1), ticks * (n + 1)
+    sc = np.zeros(2 * max_runs, np.uint32)
+    recs = np.zeros(max_records, host.LIGHT_DTYPE)
+    P = C.c_void_p
+    rt.sailor_rt_plan_light_uploads.argtypes = [C.c_int, P, P, P, P, P, C.c_int, P, P, P, C.c_int, P, C.c_int]
+    total = rt.sailor_rt_plan_light_uploads(n, d.ctypes.data, a.ctypes.data, m.ctypes.data, fl.ctypes.data, of.ctypes.data, ticks,
+                                            rd.ctypes.data if rd is not None else None, counts.ctypes.data, sc.ctypes.data, max_runs,
+                                            recs.ctypes.data, max_records)
+    assert total == counts.sum() <= max_runs
+    runs, records, at, rat = [], [], 0, 0
+    for t in range(ticks):
+        r = [(int(sc[2 * (at + i)]), int(sc[2 * (at + i) + 1])) for i in range(counts[t])]
+        at += counts[t]
+        k = sum(c for _s, c in r)
+        runs.append(r); records.append(recs[rat:rat + k]); rat += k
+    return runs, records, d.astype(bool), fl
+
+
+def test_lighting_tick_issues_one_copy_per_contiguous_dirty_run():
+    n = 12
+    clean = [False] * n
+    ones, zeros, stationary = [True] * n, [0] * n, [1] * n
+    # two lights that are not neighbours -> exactly two copies, at their own record slots
+    dirty = list(clean); dirty[3] = dirty[7] = True
+    runs, records, after, _ = _plan_light_uploads(dirty, ones, stationary, zeros, zeros)
+    assert runs == [[(3, 1), (7, 1)]] and not after.any()
+    assert [float(r["worldPosition"][0]) for r in records[0]] == [3.0, 7.0]
+    # neighbours share one copy; a run that reaches the last slot is closed by the `index == Num() - 1` clause
+    dirty = list(clean); dirty[4] = dirty[5] = dirty[6] = dirty[10] = dirty[11] = True
+    runs, records, _, _ = _plan_light_uploads(dirty, ones, stationary, zeros, zeros)
+    assert runs == [[(4, 3), (10, 2)]]
+    assert [float(r["worldPosition"][0]) for r in records[0]] == [4.0, 5.0, 6.0, 10.0, 11.0]
+    # nothing dirty -> nothing copied; everything dirty -> one copy of all
+    assert _plan_light_uploads(clean, ones, stationary, zeros, zeros)[0] == [[]]
+    assert _plan_light_uploads(ones, ones, stationary, zeros, zeros)[0] == [[(0, n)]]
+    # dirtiness also comes from the owner's transform: frameLastChange < owner->GetFrameLastChange() (:152), and the component catches up (:174)
+    owner = list(zeros); owner[2] = 5; owner[9] = 3
+    runs, _, _, fl = _plan_light_uploads(clean, ones, stationary, zeros, owner)
+    assert runs == [[(2, 1), (9, 1)]] and fl[2] == 5 and fl[9] == 3
+
+
+def test_lighting_tick_inactive_slots_follow_the_reference_literally():
+    n = 8
+    ones, zeros, stationary = [True] * n, [0] * n, [1] * n
+    # an inactive light is not packed even when dirty, and stays dirty
+    dirty = [False] * n; dirty[2] = True
+    active = list(ones); active[2] = False
+    runs, _, after, _ = _plan_light_uploads(dirty, active, stationary, zeros, zeros)
+    assert runs == [[]] and after[2]
+    # `continue` sits in front of the flush: an inactive slot inside a dirty run does not end it -- one copy of two records from slot 3 on
+    # (the record of light 5 lands in slot 4: the reference's behaviour, reproduced and pinned here)
+    dirty = [False] * n; dirty[3] = dirty[5] = True
+    active = list(ones); active[4] = False
+    runs, records, _, _ = _plan_light_uploads(dirty, active, stationary, zeros, zeros)
+    assert runs == [[(3, 2)]] and [float(r["worldPosition"][0]) for r in records[0]] == [3.0, 5.0]
+    # ... and a run that is still open when the LAST slot is inactive is never copied, although its lights were marked clean
+    dirty = [False] * n; dirty[6] = True
+    active = list(ones); active[7] = False
+    runs, records, after, _ = _plan_light_uploads(dirty, active, stationary, zeros, zeros)
+    assert runs == [[]] and len(records[0]) == 0 and not after[6]
+
+
+def test_lighting_tick_steps_over_static_lights_from_the_second_pass_on():
+    n = 10
+    ones, zeros = [True] * n, [0] * n
+    mobility = [1] * n
+    mobility[4] = mobility[5] = mobility[8] = 0 # EMobilityType::Static
+    redirty = np.ones((2, n), np.uint8)         # everything marked dirty again before pass 2 and pass 3
+    runs, records, _, _ = _plan_light_uploads(ones, ones, mobility, zeros, zeros, ticks=3, redirty=redirty)
+    assert runs[0] == [(0, n)]                  # the first pass packs the static lights too (and lists them)
+    # afterwards slots 4, 5 and 8 are stepped over, dirty or not.  Stepping over does not close the open run either (the jump happens before
+    # the body, :95-103), so the reference issues ONE copy of the seven remaining records from slot 0 on -- reproduced literally
+    assert runs[1] == [(0, 7)] and runs[2] == runs[1]
+    assert [int(r["worldPosition"][0]) for r in records[1]] == [0, 1, 2, 3, 6, 7, 9]
+    # with the dynamic lights clean, a static light that is dirtied again is never looked at
+    redirty = np.zeros((1, n), np.uint8); redirty[0, 5] = 1
+    runs, _, after, _ = _plan_light_uploads(ones, ones, mobility, zeros, zeros, ticks=2, redirty=redirty)
+    assert runs[1] == [] and after[5]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_lighting_tick_mirror_equals_the_python_restatement(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n, ticks = int(rng.integers(1, 70)), 4
+    dirty = rng.random(n) < 0.4
+    active = rng.random(n) < 0.85
+    mobility = rng.choice([0, 1, 2], size=n, p=[0.2, 0.5, 0.3])
+    frame_last = rng.integers(0, 3, n)
+    owner = rng.integers(0, 4, n)
+    redirty = rng.random((ticks - 1, n)) < 0.3
+    runs, records, after, fl = _plan_light_uploads(dirty, active, mobility, frame_last, owner, ticks=ticks, redirty=redirty)
+    d, f, skip = [bool(x) for x in dirty], [int(x) for x in frame_last], []
+    for t in range(ticks):
+        if t > 0:
+            d = [a or bool(b) for a, b in zip(d, redirty[t - 1])]
+        want = oracle.lighting_tick_runs(d, list(active), list(mobility), f, list(owner), skip)
+        assert runs[t] == [(s, len(b)) for s, b in want]
+        carried = [i for _s, b in want for i in b]
+        assert [int(r["worldPosition"][0]) for r in records[t]] == carried and all(int(r["worldPosition"][1]) == t for r in records[t])
+    assert list(after) == d and [int(x) for x in fl] == f

@@ -476,6 +476,82 @@ def test_world_description_drives_the_lighting_path():
         rt.close()
 
 
+def test_lighting_ecs_streams_dirty_runs_into_the_light_ssbo():
+    """L7 (Runtime/ECS/LightingECS.cpp:148-191, :404): lights registered as components; Tick records ONE UpdateShaderBinding per contiguous dirty
+    run at `offset + 112 * startIndex`; an inactive light keeps its stale record but still counts in m_totalNumLights; the frame culled and shaded
+    from the SSBO the copies produced equals the oracle's for the records one expects there."""
+    f = synth.make_frame("tiny")
+    W, H = f.cam.width, f.cam.height
+    n = len(f.lights)
+    src = f.lights
+    cut_deg = [(20.0 + (i % 7), 35.0 + (i % 11)) for i in range(n)]
+
+    def record(i, position=None, intensity=None):
+        r = np.zeros((), host.LIGHT_DTYPE)
+        r["type"], r["shadowType"] = src["type"][i], src["shadowType"][i]
+        r["worldPosition"] = src["worldPosition"][i] if position is None else position
+        r["direction"] = src["direction"][i]
+        r["intensity"] = src["intensity"][i] if intensity is None else intensity
+        r["attenuation"] = np.float32([1.0, 0.022, 0.0019])            # ECS/LightingECS.h:24 default
+        r["cutOff"] = host.cutoff_cosines(*cut_deg[i])
+        r["bounds"] = src["bounds"][i]
+        return r
+
+    expected = np.array([record(i) for i in range(n)], host.LIGHT_DTYPE)
+    rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        rt.build_graph(["LightCulling", "RenderScene"])
+        rt.set_camera(f.cam)
+        for i in range(n):
+            assert rt.add_light(int(src["type"][i]), int(src["shadowType"][i]), src["worldPosition"][i], src["direction"][i], src["intensity"][i],
+                                src["bounds"][i], cut_deg[i]) == i
+        assert rt.tick_lights() == [(0, n)] and rt.total_num_lights() == n        # every new light is dirty: one copy of all
+        lp, lbytes = rt.buffer("light")
+        assert lbytes >= 112 * n
+        rt.wait_idle()
+        np.testing.assert_array_equal(read_u32(lp, 112 * n), expected.view(np.uint32))
+        assert rt.tick_lights() == []                                             # nothing changed: nothing copied
+
+        # (i) two lights that are not neighbours -> exactly two copies at their own byte offsets; the rest of the buffer is untouched
+        a, b = 3, n - 5
+        pa, ib = src["worldPosition"][a] + np.float32([4.0, -2.0, 1.0]), src["intensity"][b] * np.float32(3.0)
+        rt.update_light(a, position=pa)
+        rt.update_light(b, intensity=ib)
+        assert rt.tick_lights() == [(a, 1), (b, 1)]
+        expected[a], expected[b] = record(a, position=pa), record(b, intensity=ib)
+        # the owner's transform changing (GetFrameLastChange) dirties a light without MarkDirty; neighbours share one copy
+        rt.set_light_state(10, owner_frame_last_change=7)
+        rt.set_light_state(11, owner_frame_last_change=7)
+        assert rt.tick_lights() == [(10, 2)] and rt.tick_lights() == []
+        # (ii) an inactive light is not packed: its record stays stale, and it still counts
+        c = 20
+        rt.set_light_state(c, active=False)
+        rt.update_light(c, intensity=np.float32([9e3, 9e3, 9e3]))
+        assert rt.tick_lights() == [] and rt.total_num_lights() == n
+        rt.wait_idle()
+        np.testing.assert_array_equal(read_u32(lp, 112 * n), expected.view(np.uint32))
+
+        depth = torch.from_numpy(f.depth).cuda()
+        surface = torch.from_numpy(f.surface).cuda()
+        radiance = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        rt.set_depth(depth)
+        rt.set_surface(surface, radiance)
+        assert rt.process_frame() == 0
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        og, oi, _ = oracle.light_cull(f.cam.frame, W, H, expected, f.depth)
+        Tx, Ty = host.num_tiles(W, H)
+        gp, _ = rt.buffer("lightsGrid")
+        cp, _ = rt.buffer("culledLights")
+        np.testing.assert_array_equal(read_u32(gp, Tx * Ty * 8).reshape(-1, 2), og)
+        np.testing.assert_array_equal(read_u32(cp, 4 * (1 + int(oi[0]))), oi[: 1 + int(oi[0])])
+        ref = oracle.shade(f.cam.frame, W, H, f.surface, expected, og, oi, None)
+        err = np.abs(radiance.cpu().numpy().astype(np.float64) - ref)
+        assert (err <= 1e-4 * np.abs(ref)).all(), err.max()
+    finally:
+        rt.close()
+
+
 # ---- split frame: the C++ driver records the band entry points, the exchange goes through the C-ABI over RCCL ------------------------------
 def _single_rank_comm():
     """an ncclComm_t of ONE rank (the one GPU of the test box), created the way a host engine would: ncclGetUniqueId + ncclCommInitRank"""
