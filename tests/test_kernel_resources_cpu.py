@@ -1,0 +1,92 @@
+"""A guard on the hand-written kernels' resource figures.
+
+`shade_body.h` pins v56-v62 in inline assembly, sets `exec` by hand and is laid out for 64 VGPRs / no scratch / 8 waves per SIMD; `k1_tile_cull`
+relies on a small register file footprint for its eight blocks per CU.  A toolchain bump or an innocent edit can silently spill or halve the
+occupancy, and nothing would fail.  This test reads the AMDGPU metadata notes of the code objects inside the built `.o` files
+(objcopy .hip_fatbin -> clang-offload-bundler -> llvm-readelf --notes) and asserts the budgets the design rests on.  No GPU needed."""
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+CSRC = ROOT / "sailor_amd" / "csrc"
+LLVM = Path("/opt/rocm/lib/llvm/bin")
+
+
+def kernel_resources(obj: Path, tmp: Path) -> dict:
+    fat, co = tmp / (obj.stem + ".fatbin"), tmp / (obj.stem + ".co")
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", str(obj), str(fat)], check=True)
+    subprocess.run([str(LLVM / "clang-offload-bundler"), "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}", "--unbundle"],
+                   check=True)
+    notes = subprocess.run([str(LLVM / "llvm-readelf"), "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+    out = {}
+    for block in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        fields = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|sgpr_count|private_segment_fixed_size|group_segment_fixed_size|vgpr_spill_count|sgpr_spill_count|"
+                                                   r"max_flat_workgroup_size):\s+(\d+)", block)}
+        out[name] = fields
+    return out
+
+
+def find(res: dict, key: str) -> dict:
+    """the kernel whose mangled name contains <len><key> (Itanium: the unqualified name prefixed by its length)"""
+    hits = [v for k, v in res.items() if f"{len(key)}{key}" in k]
+    assert len(hits) == 1, (key, list(res))
+    return hits[0]
+
+
+def waves_per_simd(vgprs: int) -> int:
+    # gfx950: 512 VGPRs per SIMD lane, allocated in blocks of 8, at most 8 waves
+    return min(8, 512 // (-(-vgprs // 8) * 8))
+
+
+@pytest.fixture(scope="module")
+def resources(tmp_path_factory):
+    if not (LLVM / "clang-offload-bundler").exists() or not shutil.which("objcopy"):
+        pytest.skip("no ROCm LLVM tools here")
+    tmp = tmp_path_factory.mktemp("co")
+    res = {}
+    for name in ("shade", "light_cull", "ecs_sweep"):
+        obj = CSRC / f"{name}.o"
+        assert obj.exists(), f"{obj} is missing: run __graft_entry__.build()"
+        res[name] = kernel_resources(obj, tmp)
+    return res
+
+
+def test_k2_shade_fits_64_registers_without_scratch(resources):
+    k = find(resources["shade"], "k2_shade")
+    assert k["vgpr_count"] <= 64 and waves_per_simd(k["vgpr_count"]) == 8
+    assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] == 0
+    # eight 256-thread blocks per CU must fit the 160 KB of LDS
+    assert 8 * k["group_segment_fixed_size"] <= 160 * 1024
+
+
+def test_k2_shade_csm_keeps_six_waves_per_simd(resources):
+    k = find(resources["shade"], "k2_shade_csm")
+    assert k["vgpr_count"] <= 80 and waves_per_simd(k["vgpr_count"]) >= 6
+    assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0
+
+
+def test_k2_shade_band_stays_at_eight_waves(resources):
+    k = find(resources["shade"], "k2_shade_band")
+    assert k["vgpr_count"] <= 64
+    assert k["private_segment_fixed_size"] <= 16   # (two copies of the body at 64 registers each: a handful of bytes is what it has always had)
+
+
+def test_cull_kernels_keep_their_occupancy(resources):
+    res = resources["light_cull"]
+    tile = [v for n, v in res.items() if "k1_tile_cull" in n]
+    assert tile, list(res)
+    for k in tile:
+        assert k["vgpr_count"] <= 32 and k["private_segment_fixed_size"] == 0, k
+    for key in ("k01_prepare", "k1_pack", "k1_group_lists"):
+        k = find(res, key)
+        assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (key, k)
+
+
+def test_ecs_sweep_has_no_scratch(resources):
+    for name, k in resources["ecs_sweep"].items():
+        assert k["private_segment_fixed_size"] == 0, (name, k)
