@@ -86,41 +86,85 @@ def event_ms(fn, steps):
     return float(t.mean()), float(np.median(t)), float(np.percentile(t, 10)), float(np.percentile(t, 90))
 
 
-def event_batch_ms(fn, steps, graph_stream=None):
-    """average duration of fn() in ms from ONE HIP event pair around `steps` back-to-back calls on the launch stream: what a launch costs inside a
-    running pipeline (the next launch ramps up while the previous one drains), which is also what rocprofv3's kernel trace reports -- its per-kernel
-    durations add up to the wall time of the step.  An event pair around every single launch (event_ms) drains the GPU on both sides of the kernel and
-    reads 10-15 % longer for a 0.2 ms kernel.  With graph_stream the `steps` calls are captured into one hipGraph first and the pair brackets its
-    replay: eager launches of one kernel back to back leave the command processor's dispatch gap (5-15 us) between them, which is no part of the
-    kernel; inside a graph the gap is what it is in the timed region."""
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+BATCHES = 5          # per-kernel figures: the median of this many batches ...
+BATCH_LAUNCHES = 50  # ... of at least this many back-to-back launches each, whatever --steps is (the driver runs --steps 20)
+
+
+def event_batch_stats(fn, steps, graph_stream=None, batches=BATCHES):
+    """Duration of fn() in ms from HIP event pairs around batches of back-to-back calls on the launch stream: what a launch costs inside a running
+    pipeline (the next launch ramps up while the previous one drains).  `batches` batches of max(steps, BATCH_LAUNCHES) calls each; the figure is
+    the MEDIAN batch (min / max kept alongside), so a short --steps or one disturbed batch does not move it.  An event pair around every single launch
+    (event_ms) drains the GPU on both sides of the kernel and reads 10-15 % longer for a 0.2 ms kernel.  With graph_stream the calls of a batch are
+    captured into one hipGraph first and the pair brackets its replay: eager launches of one kernel back to back leave the command processor's
+    dispatch gap (5-15 us) between them, which is no part of the kernel; inside a graph the gap is what it is in the timed region.  What the pair
+    includes besides the kernels' own durations (rocprofv3's kernel trace reports those): the gap between consecutive launches and the end-of-kernel
+    write-back -- see `launch_gap_ms` in the JSON line."""
+    n = max(int(steps), BATCH_LAUNCHES)
+    times = []
     if graph_stream is not None:
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=graph_stream):
-                for _ in range(steps):
+                for _ in range(n):
                     fn()
             g.replay()
             torch.cuda.synchronize()
-            a.record(graph_stream)
-            g.replay()
-            b.record(graph_stream)
+            pairs = []
+            for _ in range(batches):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(graph_stream)
+                g.replay()
+                b.record(graph_stream)
+                pairs.append((a, b))
             torch.cuda.synchronize()
-            return a.elapsed_time(b) / steps
+            times = [a.elapsed_time(b) / n for a, b in pairs]
         except Exception as e:  # (a failed capture leaves the eager measurement)
             print(f"[bench] per-kernel hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
-    a.record()
-    for _ in range(steps):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / steps
+            times = []
+    if not times:
+        pairs = []
+        for _ in range(batches):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n):
+                fn()
+            b.record()
+            pairs.append((a, b))
+        torch.cuda.synchronize()
+        times = [a.elapsed_time(b) / n for a, b in pairs]
+    t = np.array(times)
+    return {"median": float(np.median(t)), "min": float(t.min()), "max": float(t.max()), "batches": int(len(t)), "launches_per_batch": n}
+
+
+def event_batch_ms(fn, steps, graph_stream=None):
+    """the median batch of event_batch_stats"""
+    return event_batch_stats(fn, steps, graph_stream)["median"]
 
 
 def side_ms(fn, steps):
     """the side blocks' timing: event_batch_ms in event_ms's (mean, median, p10, p90) shape -- one figure, the in-pipeline cost of a launch"""
     b = event_batch_ms(fn, steps)
     return b, b, b, b
+
+
+def trace_kernel_ms(kernel: str, config: str, world: int):
+    """the kernel's average duration in the newest committed `rocprofv3 --kernel-trace --stats` summary of this configuration
+    (profiles/rNN/kernel_stats[_<config>].csv), for comparison with the event figure; None when there is none"""
+    if world != 1:
+        return None
+    prof = os.path.join(ROOT, "profiles")
+    rounds = sorted((d for d in os.listdir(prof) if d.startswith("r") and d[1:].isdigit()), reverse=True) if os.path.isdir(prof) else []
+    name = "kernel_stats.csv" if config == "C3" else f"kernel_stats_{config}.csv"
+    for r in rounds:
+        try:
+            import csv
+            with open(os.path.join(prof, r, name), newline="") as f:
+                for row in csv.DictReader(f):
+                    if row["Name"].startswith(kernel + "(") or row["Name"].startswith("void " + kernel + "("):
+                        return float(row["AverageNs"]) * 1e-6
+        except (OSError, ValueError, KeyError):
+            pass
+    return None
 
 
 def measured_traffic(kernel: str, config: str, world: int):
@@ -788,8 +832,11 @@ def main():
     cull_ms = event_ms(cull, args.steps)
     shade_ms = event_ms(shade, args.steps)
     batch_stream = None if args.no_graph else side
-    cull_batch_ms = event_batch_ms(cull, args.steps, batch_stream)
-    shade_batch_ms = event_batch_ms(shade, args.steps, batch_stream)
+    cull_batch = event_batch_stats(cull, args.steps, batch_stream)
+    shade_batch = event_batch_stats(shade, args.steps, batch_stream)
+    cull_batch_ms, shade_batch_ms = cull_batch["median"], shade_batch["median"]
+    # SURVEY.md 8d's own definition of the step: t(K1 + K2) by events on ONE stream, one frame in flight -- cull, then shade, then the next frame's cull
+    serial = event_batch_stats(lambda: (cull(), shade()), args.steps, batch_stream)
     pipeline_ms = event_batch_ms(lambda: (cull(), shade()), args.steps)   # eager cull + shade chains back to back: the step without graphs or overlap
     cull_eager_ms = event_batch_ms(cull, args.steps)
     g, idx = fp.lists_to_host()
@@ -811,8 +858,12 @@ def main():
     shade_kernel = "k2_shade_csm" if csm is not None else ("k2_shade_band" if fp.tile_order and fp.use_tile_order else "k2_shade")
     roofline = {"bound": "hbm", "kernel": shade_kernel, "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
                 "traffic": measured_traffic("k2_shade" if csm is None else "k2_shade_csm", args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_batch_ms,
-                "timing": "one HIP event pair around %d back-to-back launches on the launch stream, replayed as one hipGraph unless --no-graph (agrees with rocprofv3 --kernel-trace --stats); "
-                          "isolated_* = an event pair around every single launch (pipeline drained on both sides)" % args.steps,
+                "timing": "median of %d batches of %d back-to-back launches, one HIP event pair per batch on the launch stream, each batch one hipGraph replay unless --no-graph; "
+                          "the pair also sees the gap between consecutive launches and the end-of-kernel write-back, so it reads above the kernel's own duration in "
+                          "rocprofv3 --kernel-trace --stats (profiles/<round>/kernel_stats.csv; the difference is quoted there as the per-launch gap); "
+                          "isolated_* = an event pair around every single launch (pipeline drained on both sides)" % (shade_batch["batches"], shade_batch["launches_per_batch"]),
+                "avg_launch_ms_min_max": [shade_batch["min"], shade_batch["max"]],
+                "rocprof_kernel_avg_ms": trace_kernel_ms(shade_kernel, args.config, world),
                 "isolated_avg_launch_ms": shade_ms[0], "isolated_median_launch_ms": shade_ms[1],
                 "in_pipeline_launch_ms": pipeline_ms - cull_eager_ms,  # eager (cull + shade) x K minus eager (cull) x K: the kernel between its real neighbours
                 "eager_step_ms": pipeline_ms,
@@ -959,6 +1010,10 @@ def main():
                        "mean_list_length": sum_nt / max(fp.band_tiles, 1), "sum_num_rank0_band": sum_nt, "distinct_lights_rank0_band": distinct,
                        "generator": {"seed": synth.SEED, "radius_scale": frame.cfg["lights"].radius_scale}},
             "step_ms": step_stats,
+            "value_serial": frames_per_step * W * H / (serial["median"] * 1e-3) / 1e6 if not (weak and world > 1) else None,
+            "serial_step_ms": {"median": serial["median"], "min": serial["min"], "max": serial["max"],
+                               "how": "SURVEY.md 8d: t(K0+K1+K2) of ONE frame in flight -- cull then shade on one stream, %d batches of %d frames, one HIP event pair per batch "
+                                      "(this rank's band when N > 1); `value` above keeps two frames in flight as the reference does (RHI/Renderer.h:34)" % (serial["batches"], serial["launches_per_batch"])},
             "mlights_culled_per_s": N / (cull_batch_ms * 1e-3) / 1e6,
             "cull_ms": cull_batch_ms, "shade_ms": shade_batch_ms,
             "roofline": roofline,

@@ -262,7 +262,9 @@ SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
  * tile with < 40 lights keep their bits; a split tile's radiance differs from the one-block form by the order of four partial sums per
  * pixel (within the shade tolerance).  With shadow maps or the ambient term the hint is ignored.  Produced for split frames only (on the
  * whole frame the split measured no gain): NULL for the whole-frame band, for bands of more than 65 535 tiles and on bad arguments.
- * Valid until the next sailor_hip_light_cull on the same workspace. */
+ * Valid until the next sailor_hip_light_cull on the same workspace.  `lightsCapacity` only has to be a light count the workspace can hold: the
+ * hint's place in the workspace depends on (width, height, band) alone, so a cull with ANY lightsNum <= the capacity leaves it where this
+ * function points (the sections that scale with the light count sit behind it). */
 SAILOR_HIP_API const uint32_t* sailor_hip_light_cull_tile_order(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band,
                                                                 const void* dWorkspace);
 

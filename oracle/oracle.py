@@ -180,8 +180,19 @@ def cube_face_st(direction):
     return face.value, st
 
 
-def light_cull(frame, W: int, H: int, lights: np.ndarray, depth: np.ndarray, tile_rows=None, literal_select: bool = False, want_counts: bool = False):
-    """-> (grid uint32[T,2], indices uint32[1+T*128], counts uint32[T] | None) for the band of tile rows."""
+def host_threads() -> int:
+    """the host threads the whole-frame checkers may use (the GPU box has 256; this container 8)"""
+    import os
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)
+
+
+def light_cull(frame, W: int, H: int, lights: np.ndarray, depth: np.ndarray, tile_rows=None, literal_select: bool = False, want_counts: bool = False,
+               threads: int = 1):
+    """-> (grid uint32[T,2], indices uint32[1+T*128], counts uint32[T] | None) for the band of tile rows.  threads > 1: the same per-tile code with the
+    tile rows spread over host threads (oracle_light_cull_threads) -- the whole-frame checker of the full-size GPU tests."""
     Tx, Ty = num_tiles(W, H)
     r0, r1 = (0, Ty) if tile_rows is None else tile_rows
     T = (r1 - r0) * Tx
@@ -192,12 +203,21 @@ def light_cull(frame, W: int, H: int, lights: np.ndarray, depth: np.ndarray, til
     grid = np.zeros((max(T, 1), 2), np.uint32)
     indices = np.zeros(1 + max(T, 1) * KEEP, np.uint32)
     counts = np.zeros(max(T, 1), np.uint32) if want_counts else None
-    lib().oracle_light_cull(_p(fb), W, H, len(lights), _p(lights), _p(depth), _p(grid), _p(indices), _p(counts), r0, r1, int(literal_select))
+    if threads > 1:
+        fn = lib().oracle_light_cull_threads
+        fn.restype = C.c_uint32
+        used = fn(_p(fb), W, H, len(lights), _p(lights), _p(depth), _p(grid), _p(indices), _p(counts), r0, r1, int(literal_select), C.c_uint32(threads))
+        if used == 0:
+            raise MemoryError("oracle_light_cull_threads")
+    else:
+        lib().oracle_light_cull(_p(fb), W, H, len(lights), _p(lights), _p(depth), _p(grid), _p(indices), _p(counts), r0, r1, int(literal_select))
     return grid[:T], indices, (counts[:T] if want_counts else None)
 
 
-def shade(frame, W: int, H: int, surface: np.ndarray, lights: np.ndarray, grid: np.ndarray, indices: np.ndarray, csm=None, rows=None, ibl=None) -> np.ndarray:
-    """surface float32[3,H,W,4]; grid/indices in the global canonical layout -> radiance float32[H,W,4] (rows outside `rows` are 0)."""
+def shade(frame, W: int, H: int, surface: np.ndarray, lights: np.ndarray, grid: np.ndarray, indices: np.ndarray, csm=None, rows=None, ibl=None,
+          threads: int = 1) -> np.ndarray:
+    """surface float32[3,H,W,4]; grid/indices in the global canonical layout -> radiance float32[H,W,4] (rows outside `rows` are 0).
+    threads > 1: the same per-pixel code with the rows spread over host threads (oracle_shade_threads)."""
     fb = _frame_bytes(frame)
     surface = np.ascontiguousarray(surface, np.float32)
     assert surface.shape == (3, H, W, 4)
@@ -206,7 +226,12 @@ def shade(frame, W: int, H: int, surface: np.ndarray, lights: np.ndarray, grid: 
     lights = np.ascontiguousarray(lights)
     grid = np.ascontiguousarray(grid, np.uint32)
     indices = np.ascontiguousarray(indices, np.uint32)
-    if ibl is not None:
+    if threads > 1:
+        fn = lib().oracle_shade_threads
+        fn.restype = C.c_uint32
+        fn(_p(fb), W, H, _p(surface), _p(lights), _p(grid), _p(indices), C.byref(csm) if csm is not None else None,
+           C.byref(ibl) if ibl is not None else None, _p(out), r0, r1, C.c_uint32(threads))
+    elif ibl is not None:
         lib().oracle_shade_ibl(_p(fb), W, H, _p(surface), _p(lights), _p(grid), _p(indices), C.byref(csm) if csm is not None else None,
                                C.byref(ibl), _p(out), r0, r1)
     else:

@@ -419,16 +419,9 @@ ORACLE_API void oracle_select_emit(const uint32_t* candIdx, const float* candImp
  *   outCandCount : optional, per tile: number of lights that PASS the test, uncapped (statistics only)
  *   literalSelect: 1 = run the shader's partial bubble sort literally, 0 = closed form (must agree)
  */
-ORACLE_API void oracle_light_cull(const void* ubo_, int W, int H, int lightsNum, const void* lights_, const float* depth,
-                                  uint32_t* outGrid, uint32_t* outIndices, uint32_t* outCandCount,
-                                  int tileRowBegin, int tileRowEnd, int literalSelect)
+/* ComputeLightCulling.shader:164-169: the per-light view transform does not depend on the tile */
+static float* light_view_positions(const UboFrameData* ubo, const LightData* lights, int lightsNum)
 {
-    const UboFrameData* ubo = (const UboFrameData*)ubo_;
-    const LightData* lights = (const LightData*)lights_;
-    const int Tx = (W - 1) / TILE + 1; /* FrameGraph/LightCullingNode.cpp:56-57 */
-    const int vpW = ubo->viewportSize[0], vpH = ubo->viewportSize[1];
-
-    /* the per-light view transform does not depend on the tile (ComputeLightCulling.shader:164-169) */
     float* pv = (float*)malloc((size_t)(lightsNum > 0 ? lightsNum : 1) * 4 * sizeof(float));
     for (int j = 0; j < lightsNum; j++) {
         float wp[4] = { lights[j].worldPosition[0], lights[j].worldPosition[1], lights[j].worldPosition[2], 1.0f };
@@ -439,51 +432,69 @@ ORACLE_API void oracle_light_cull(const void* ubo_, int W, int H, int lightsNum,
         p[2] = p[2] * -1.0f;
         memcpy(&pv[j * 4], p, 16);
     }
+    return pv;
+}
 
+/* one tile of the cull (ComputeLightCulling.shader:97-240): its list (<= KEEP indices) and, optionally, the uncapped number of passing lights */
+static void cull_one_tile(const UboFrameData* ubo, const LightData* lights, const float* pv, int lightsNum, const float* depth, int W, int H,
+                          int tx, int ty, int literalSelect, uint32_t* list, uint32_t* num, uint32_t* outPassing)
+{
+    const int vpW = ubo->viewportSize[0], vpH = ubo->viewportSize[1];
+    float minD, maxD;
+    tile_depth_bounds(depth, W, H, tx, ty, &minD, &maxD);
+    ViewFrustum fr;
+    create_tile_frustum(tx, ty, vpW, vpH, ubo->invProjection, &fr);
+
+    /* :171-177 "Add extra bounds" -- swaps near and far, in fp32 */
+    float zFar = maxD, zNear = minD;
+    const float diff = zFar - zNear;
+    zFar -= diff;
+    zNear += diff;
+
+    uint32_t candIdx[CAND]; float candImp[CAND];
+    uint32_t count = 0, passing = 0;
+    for (int j = 0; j < lightsNum; j++) {
+        int pass; float impact;
+        if (lights[j].type == 0) { pass = 1; impact = 0.0f; } /* :153-162 */
+        else {
+            const float radius = lights[j].bounds[0];
+            const float* p = &pv[j * 4];
+            pass = sphere_frustum_overlaps(p, radius, &fr, zNear, zFar);
+            if (pass) {
+                float c[3] = { fr.center[0], fr.center[1], (zFar + zNear) * 0.5f };
+                float d[3] = { p[0] - c[0], p[1] - c[1], p[2] - c[2] };
+                impact = length3(d); /* :187 */
+            } else impact = 0.0f;
+        }
+        if (pass) {
+            passing++;
+            if (count < CAND) { candIdx[count] = (uint32_t)j; candImp[count] = impact; count++; }
+            if (count == CAND && !outPassing) break; /* canonical early-out (:147) */
+        }
+    }
+    oracle_select_emit(candIdx, candImp, count, literalSelect, list, num);
+    if (outPassing) *outPassing = passing;
+}
+
+ORACLE_API void oracle_light_cull(const void* ubo_, int W, int H, int lightsNum, const void* lights_, const float* depth,
+                                  uint32_t* outGrid, uint32_t* outIndices, uint32_t* outCandCount,
+                                  int tileRowBegin, int tileRowEnd, int literalSelect)
+{
+    const UboFrameData* ubo = (const UboFrameData*)ubo_;
+    const LightData* lights = (const LightData*)lights_;
+    const int Tx = (W - 1) / TILE + 1; /* FrameGraph/LightCullingNode.cpp:56-57 */
+    float* pv = light_view_positions(ubo, lights, lightsNum);
     uint32_t running = 0;
     for (int ty = tileRowBegin; ty < tileRowEnd; ty++) {
         for (int tx = 0; tx < Tx; tx++) {
             const int bandTile = (ty - tileRowBegin) * Tx + tx;
-            float minD, maxD;
-            tile_depth_bounds(depth, W, H, tx, ty, &minD, &maxD);
-            ViewFrustum fr;
-            create_tile_frustum(tx, ty, vpW, vpH, ubo->invProjection, &fr);
-
-            /* :171-177 "Add extra bounds" -- swaps near and far, in fp32 */
-            float zFar = maxD, zNear = minD;
-            const float diff = zFar - zNear;
-            zFar -= diff;
-            zNear += diff;
-
-            uint32_t candIdx[CAND]; float candImp[CAND];
-            uint32_t count = 0, passing = 0;
-            for (int j = 0; j < lightsNum; j++) {
-                int pass; float impact;
-                if (lights[j].type == 0) { pass = 1; impact = 0.0f; } /* :153-162 */
-                else {
-                    const float radius = lights[j].bounds[0];
-                    const float* p = &pv[j * 4];
-                    pass = sphere_frustum_overlaps(p, radius, &fr, zNear, zFar);
-                    if (pass) {
-                        float c[3] = { fr.center[0], fr.center[1], (zFar + zNear) * 0.5f };
-                        float d[3] = { p[0] - c[0], p[1] - c[1], p[2] - c[2] };
-                        impact = length3(d); /* :187 */
-                    } else impact = 0.0f;
-                }
-                if (pass) {
-                    passing++;
-                    if (count < CAND) { candIdx[count] = (uint32_t)j; candImp[count] = impact; count++; }
-                    if (count == CAND && !outCandCount) break; /* canonical early-out (:147) */
-                }
-            }
             uint32_t list[KEEP], num;
-            oracle_select_emit(candIdx, candImp, count, literalSelect, list, &num);
+            cull_one_tile(ubo, lights, pv, lightsNum, depth, W, H, tx, ty, literalSelect, list, &num, outCandCount ? &outCandCount[bandTile] : NULL);
             const uint32_t offset = running + 1; /* :229 canonicalised: prefix sum in tile order */
             outGrid[2 * bandTile + 0] = offset;
             outGrid[2 * bandTile + 1] = num;
             for (uint32_t i = 0; i < num; i++) outIndices[offset + i] = list[i];
             running += num;
-            if (outCandCount) outCandCount[bandTile] = passing;
         }
     }
     outIndices[0] = running;
@@ -1528,11 +1539,19 @@ typedef struct {
     const uint32_t* levelOffsets; uint32_t numLevels;
     uint32_t* nextChunk; /* one counter per level */
     pthread_barrier_t* bar;
+    pthread_mutex_t mu; pthread_cond_t cv; int go; /* 0: wait for the barrier to be sized, 1: run, -1: leave */
 } SweepJob;
 
 static void* sweep_worker(void* arg)
 {
-    const SweepJob* j = (const SweepJob*)arg;
+    SweepJob* j = (SweepJob*)arg;
+    /* the barrier is sized only once the number of threads that could be created is known: a worker parks on the condition variable until then
+     * (a thread parked in pthread_barrier_wait cannot be called back: the wait is no cancellation point) */
+    pthread_mutex_lock(&j->mu);
+    while (j->go == 0) pthread_cond_wait(&j->cv, &j->mu);
+    const int go = j->go;
+    pthread_mutex_unlock(&j->mu);
+    if (go < 0) return NULL;
     pthread_barrier_wait(j->bar); /* start */
     for (uint32_t l = 0; l < j->numLevels; l++) {
         const uint32_t lo = j->levelOffsets[l], hi = j->levelOffsets[l + 1];
@@ -1554,30 +1573,133 @@ ORACLE_API double oracle_ecs_sweep_threads(uint32_t numLevels, const uint32_t* l
 {
     if (numThreads < 1) numThreads = 1;
     if (numThreads > 1024) numThreads = 1024;
-    pthread_t tid[1024];
     uint32_t counters[64];
     if (numLevels > 64) return -1.0;
     memset(counters, 0, sizeof counters);
+    pthread_t* tid = (pthread_t*)malloc(sizeof(pthread_t) * numThreads);
+    if (!tid) return -1.0;
     pthread_barrier_t bar;
-    if (pthread_barrier_init(&bar, NULL, numThreads + 1) != 0) return -1.0;
-    SweepJob job = { trs, parent, localAabb, planes, world, worldAabb, visibility, levelOffsets, numLevels, counters, &bar };
+    SweepJob job = { trs, parent, localAabb, planes, world, worldAabb, visibility, levelOffsets, numLevels, counters, &bar,
+                     PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, 0 };
     uint32_t started = 0;
     for (; started < numThreads; started++)
         if (pthread_create(&tid[started], NULL, sweep_worker, &job) != 0) break;
-    if (started != numThreads) { /* cannot release a barrier sized for more threads: give up cleanly */
-        for (uint32_t i = 0; i < started; i++) pthread_cancel(tid[i]);
-        for (uint32_t i = 0; i < started; i++) pthread_join(tid[i], NULL);
-        pthread_barrier_destroy(&bar);
-        return -1.0;
+    /* fewer threads than asked for is fine (the chunks are handed out dynamically); none, or no barrier, is a failure -- the parked workers are told to leave */
+    const int ok = started > 0 && pthread_barrier_init(&bar, NULL, started + 1) == 0;
+    pthread_mutex_lock(&job.mu);
+    job.go = ok ? 1 : -1;
+    pthread_cond_broadcast(&job.cv);
+    pthread_mutex_unlock(&job.mu);
+    double seconds = -1.0;
+    if (ok) {
+        struct timespec t0, t1;
+        pthread_barrier_wait(&bar);
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (uint32_t l = 0; l < numLevels; l++) pthread_barrier_wait(&bar);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     }
-    struct timespec t0, t1;
-    pthread_barrier_wait(&bar);
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (uint32_t l = 0; l < numLevels; l++) pthread_barrier_wait(&bar);
-    clock_gettime(CLOCK_MONOTONIC, &t1);
-    for (uint32_t i = 0; i < numThreads; i++) pthread_join(tid[i], NULL);
-    pthread_barrier_destroy(&bar);
-    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    for (uint32_t i = 0; i < started; i++) pthread_join(tid[i], NULL);
+    if (ok) pthread_barrier_destroy(&bar);
+    free(tid);
+    return seconds;
+}
+
+/* ---- whole-frame checkers on all host cores: the cull and the shade over tile rows / framebuffer rows handed out dynamically -----------------
+ * Same per-tile / per-pixel code as oracle_light_cull / oracle_shade (so: the same bits), only the loop over rows is spread over threads; the
+ * cull's prefix sum over the tiles stays sequential.  They exist so that the GPU tests can compare ENTIRE 4K frames (32 400 tiles x 65 536 lights
+ * = 2.1 G sphere tests) in seconds on the GPU box's host instead of a few sampled tile rows.  A worker that could not be created is simply absent.
+ */
+typedef struct {
+    const UboFrameData* ubo; const LightData* lights; const float* pv; int lightsNum; const float* depth; int W, H, Tx;
+    int rowBegin, rowEnd, literalSelect;
+    uint32_t* nums;   /* per band tile */
+    uint32_t* lists;  /* per band tile: KEEP slots */
+    uint32_t* passing;
+    int next;
+} CullRowsJob;
+
+static void* cull_rows_worker(void* arg)
+{
+    CullRowsJob* j = (CullRowsJob*)arg;
+    for (;;) {
+        const int ty = j->rowBegin + __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
+        if (ty >= j->rowEnd) break;
+        for (int tx = 0; tx < j->Tx; tx++) {
+            const size_t t = (size_t)(ty - j->rowBegin) * j->Tx + tx;
+            cull_one_tile(j->ubo, j->lights, j->pv, j->lightsNum, j->depth, j->W, j->H, tx, ty, j->literalSelect, &j->lists[t * KEEP], &j->nums[t],
+                          j->passing ? &j->passing[t] : NULL);
+        }
+    }
+    return NULL;
+}
+
+static uint32_t run_workers(void* (*fn)(void*), void* job, uint32_t numThreads)
+{
+    if (numThreads < 1) numThreads = 1;
+    if (numThreads > 1024) numThreads = 1024;
+    pthread_t* tid = (pthread_t*)malloc(sizeof(pthread_t) * numThreads);
+    uint32_t started = 0;
+    if (tid)
+        for (; started < numThreads - 1; started++)
+            if (pthread_create(&tid[started], NULL, fn, job) != 0) break;
+    fn(job); /* the calling thread works too: the job completes whatever could be created */
+    for (uint32_t i = 0; i < started; i++) pthread_join(tid[i], NULL);
+    free(tid);
+    return started + 1;
+}
+
+/* as oracle_light_cull; returns the number of threads that worked, 0 on an allocation failure */
+ORACLE_API uint32_t oracle_light_cull_threads(const void* ubo_, int W, int H, int lightsNum, const void* lights_, const float* depth,
+                                              uint32_t* outGrid, uint32_t* outIndices, uint32_t* outCandCount,
+                                              int tileRowBegin, int tileRowEnd, int literalSelect, uint32_t numThreads)
+{
+    const UboFrameData* ubo = (const UboFrameData*)ubo_;
+    const LightData* lights = (const LightData*)lights_;
+    const int Tx = (W - 1) / TILE + 1;
+    const size_t tiles = (size_t)(tileRowEnd > tileRowBegin ? tileRowEnd - tileRowBegin : 0) * Tx;
+    uint32_t* nums = (uint32_t*)malloc((tiles ? tiles : 1) * sizeof(uint32_t));
+    uint32_t* lists = (uint32_t*)malloc((tiles ? tiles : 1) * KEEP * sizeof(uint32_t));
+    if (!nums || !lists) { free(nums); free(lists); return 0; }
+    float* pv = light_view_positions(ubo, lights, lightsNum);
+    CullRowsJob job = { ubo, lights, pv, lightsNum, depth, W, H, Tx, tileRowBegin, tileRowEnd, literalSelect, nums, lists, outCandCount, 0 };
+    const uint32_t used = run_workers(cull_rows_worker, &job, numThreads);
+    uint32_t running = 0;
+    for (size_t t = 0; t < tiles; t++) { /* :229 canonicalised: prefix sum in tile order */
+        const uint32_t offset = running + 1;
+        outGrid[2 * t + 0] = offset;
+        outGrid[2 * t + 1] = nums[t];
+        memcpy(&outIndices[offset], &lists[t * KEEP], nums[t] * sizeof(uint32_t));
+        running += nums[t];
+    }
+    outIndices[0] = running;
+    free(pv); free(nums); free(lists);
+    return used;
+}
+
+typedef struct {
+    const void* ubo; int W, H; const float* surface; const void* lights; const uint32_t* grid; const uint32_t* indices; const void* csm; const OracleIbl* ibl;
+    float* out; int rowBegin, rowEnd, next;
+} ShadeRowsJob;
+
+static void* shade_rows_worker(void* arg)
+{
+    ShadeRowsJob* j = (ShadeRowsJob*)arg;
+    for (;;) {
+        const int r0 = j->rowBegin + 4 * __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
+        if (r0 >= j->rowEnd) break;
+        shade_impl(j->ubo, j->W, j->H, j->surface, j->lights, j->grid, j->indices, j->csm, j->ibl, j->out, r0, r0 + 4 < j->rowEnd ? r0 + 4 : j->rowEnd);
+    }
+    return NULL;
+}
+
+/* as oracle_shade / oracle_shade_ibl (ibl_ may be NULL); returns the number of threads that worked */
+ORACLE_API uint32_t oracle_shade_threads(const void* ubo_, int W, int H, const float* surface, const void* lights_,
+                                         const uint32_t* grid, const uint32_t* indices, const void* csm_, const void* ibl_, float* out,
+                                         int fbRowBegin, int fbRowEnd, uint32_t numThreads)
+{
+    ShadeRowsJob job = { ubo_, W, H, surface, lights_, grid, indices, csm_, (const OracleIbl*)ibl_, out, fbRowBegin, fbRowEnd, 0 };
+    return run_workers(shade_rows_worker, &job, numThreads);
 }
 
 /* ---- Hi-Z pyramid (FrameGraph/DepthHighZNode.cpp:74-96, Content/Shaders/ComputeDepthHighZ.shader) ----------------------------

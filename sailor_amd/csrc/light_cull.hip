@@ -83,21 +83,25 @@ static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
     L.cullBlocks = L.groupsX * L.bandRows;   // one k1_tile_cull block per (group column, tile row)
     L.packBlocks = (L.cullBlocks + PACK_BLOCKS - 1) / PACK_BLOCKS;
     const size_t groups = (size_t)(L.numGroups > 0 ? L.numGroups : 1);
+    // Sections whose size depends on the geometry only come first, those that scale with the light count last: the offset of anything a later
+    // call looks up from (width, height, band) alone -- the tile-order hint -- is then the same for every lightsNum <= the capacity the
+    // workspace was sized for (a cull may run with fewer lights than the capacity; round 2 computed the hint's address from the capacity and
+    // the cull's own layout from lightsNum, which only agree when the two are equal).
+    const size_t cb = (size_t)(L.cullBlocks > 0 ? L.cullBlocks : 1);
     size_t o = 0;
-    L.offLightView = o; o = align_up(o + n * 16, 256);
-    L.offLightType = o; o = align_up(o + n * 4, 256);
     L.offTileInfo = o; o = align_up(o + tiles * 64, 256);
-    L.offMasks = o; o = align_up(o + (size_t)(L.numBands > 0 ? L.numBands : 1) * L.words * 8, 256);
-    L.offDirWords = o; o = align_up(o + (size_t)L.words * 8, 256);
     L.offGroupCount = o; o = align_up(o + groups * 4, 256);
     L.offDirFlag = o; o = align_up(o + 4, 256);
     L.offGroupList = o; o = align_up(o + groups * CAPG * 4, 256);
-    const size_t cb = (size_t)(L.cullBlocks > 0 ? L.cullBlocks : 1);
     L.offTotals = o; o = align_up(o + (cb + PACK_BLOCKS) * 4, 256);
     L.offClsTotals = o; o = align_up(o + (cb + PACK_BLOCKS) * 4, 256);
     L.offTileNum = o; o = align_up(o + tiles * 4, 256);
     L.offStaging = o; o = align_up(o + cb * SLOT * 4, 256);
     L.offTileOrder = o; o = align_up(o + (tiles + 2) * 4, 256); // long tiles (A from the front, B from the back) + their two counts
+    L.offLightView = o; o = align_up(o + n * 16, 256);
+    L.offLightType = o; o = align_up(o + n * 4, 256);
+    L.offMasks = o; o = align_up(o + (size_t)(L.numBands > 0 ? L.numBands : 1) * L.words * 8, 256);
+    L.offDirWords = o; o = align_up(o + (size_t)L.words * 8, 256);
     L.total = o;
     return L;
 }

@@ -36,16 +36,15 @@ def ctx():
     c.close()
 
 
-def daily_tile_row(num_rows: int, fixed: int, span: int = 1) -> int:
-    """A tile row for the oracle-sampled part of a full-size test that changes from day to day (seeded by the date, so a run is
-    reproducible on its day and prints what it used): the fixed row of the test stays, this one widens the coverage over time."""
-    import datetime
-    import random
-    d = datetime.date.today()
-    seed = int(os.environ.get("SAILOR_DAILY_SEED", d.year * 10000 + d.month * 100 + d.day))  # (override: sweep other rows on demand)
-    rng = random.Random(seed)
-    r = rng.randrange(0, num_rows - span + 1)
-    if abs(r - fixed) < span:
-        r = (fixed + span + 7) % (num_rows - span + 1)
-    print(f"[daily oracle row] {d.isoformat()} (seed {seed}): tile rows {r}..{r + span - 1} of {num_rows}")
-    return r
+def oracle_tile_rows(num_rows: int, fixed, whole_from_threads: int = 1):
+    """The tile rows a full-size test holds against the oracle, as (first row, count) spans: the WHOLE frame when the host has at least
+    `whole_from_threads` threads for the threaded checkers (oracle_light_cull_threads / oracle_shade_threads: the GPU box has 256, and the 4K frame
+    takes seconds on 8), otherwise the fixed spans given.  SAILOR_ORACLE_ROWS=r0:n[,r0:n...] overrides both (a failure on some other row is
+    reproduced by naming it); nothing here depends on the date."""
+    from oracle import oracle
+    env = os.environ.get("SAILOR_ORACLE_ROWS")
+    if env:
+        return [tuple(int(v) for v in span.split(":")) for span in env.split(",")]
+    if oracle.host_threads() >= whole_from_threads:
+        return [(0, num_rows)]
+    return list(fixed)

@@ -1,0 +1,53 @@
+"""A bounded slice of the randomised parity sweeps inside `pytest -m gpu`: the same cases as scripts/fuzz_parity.py and
+scripts/fuzz_csm_ecs.py (tests/fuzz_cases.py), fixed seeds, sized for about a minute in all.  The seeds are FIXED so that the gate is hermetic (the
+same commit gives the same verdict on any day); SAILOR_FUZZ_SEEDS=s1,s2,... adds further seeds on demand (a nightly job can pass the date), and the
+scripts run thousands of cases through gpurun.  A failure's message names seed and case: `python scripts/fuzz_parity.py <cases> <seed> <case>` replays it."""
+import os
+
+import numpy as np
+import pytest
+
+import fuzz_cases
+
+pytestmark = pytest.mark.gpu
+
+EXTRA = [int(s) for s in os.environ.get("SAILOR_FUZZ_SEEDS", "").split(",") if s.strip()]
+K1K2_CASES = int(os.environ.get("SAILOR_FUZZ_K1K2_CASES", "90"))
+K3_CASES = int(os.environ.get("SAILOR_FUZZ_K3_CASES", "40"))
+K4_CASES = int(os.environ.get("SAILOR_FUZZ_K4_CASES", "40"))
+
+
+@pytest.mark.parametrize("seed", [20250301] + EXTRA)
+def test_random_frames_through_every_cull_path_and_the_shade(ctx, seed):
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for c in range(K1K2_CASES):
+        try:
+            worst = max(worst, fuzz_cases.k1k2_case(ctx, rng, c))
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed}, case {c} (replay: scripts/fuzz_parity.py {c + 1} {seed} {c}): {e}") from e
+    assert worst <= 1e-4
+    print(f"[fuzz K1+K2] seed {seed}: {K1K2_CASES} cases, worst relative radiance error {worst:.2e}")
+
+
+@pytest.mark.parametrize("seed", [20250302] + EXTRA)
+def test_random_shadowed_frames(ctx, seed):
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for c in range(K3_CASES):
+        try:
+            worst = max(worst, fuzz_cases.k3_case(ctx, rng, c))
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed}, K3 case {c}: {e}") from e
+    assert worst <= 1e-4
+    print(f"[fuzz K3] seed {seed}: {K3_CASES} cases, worst relative radiance error {worst:.2e}")
+
+
+@pytest.mark.parametrize("seed", [20250303] + EXTRA)
+def test_random_hierarchies_through_the_ecs_sweep(ctx, seed):
+    rng = np.random.default_rng(seed)
+    for c in range(K4_CASES):
+        try:
+            fuzz_cases.k4_case(ctx, rng, c)
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed}, K4 case {c}: {e}") from e

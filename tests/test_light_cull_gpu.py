@@ -7,7 +7,7 @@ import torch
 from oracle import oracle
 from sailor_amd import _lib, host, synth
 from sailor_amd.forward_plus import ForwardPlus, upload_lights
-from conftest import daily_tile_row
+from conftest import oracle_tile_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -151,8 +151,8 @@ def test_tile_row_bands_stitch_to_the_whole_frame(ctx, world_size):
 
 def test_c3_4k_65536_lights_default_equals_brute_force_and_invariants(ctx):
     """BASELINE.json configs[2] at full size: too big for the scalar oracle in seconds, so the hierarchical path is checked
-    against the brute-force HIP walk (itself oracle-checked above) plus size-independent invariants, and a sampled band
-    of tile rows against the oracle (three fixed rows, two that change with the date)."""
+    against the brute-force HIP walk (itself oracle-checked above) plus size-independent invariants, and -- round 3 -- the ENTIRE frame
+    against the oracle running on all host threads (on a host with fewer than the default threads it is still the whole frame, only slower)."""
     f = synth.make_frame("C3", with_surface=False)
     W, H, N = 3840, 2160, 65536
     a = gpu_cull(ctx, f.cam, f.lights, f.depth, _lib.CULL_DEFAULT)
@@ -174,13 +174,18 @@ def test_c3_4k_65536_lights_default_equals_brute_force_and_invariants(ctx):
         assert len(np.unique(seg)) == len(seg)
     mean = num.mean()
     assert 16 <= mean <= 32, f"frozen generator: mean list length {mean}"
-    # oracle on 3 fixed tile rows (3 x 240 tiles x 65 536 lights) and on 2 that change with the date
-    for r0, rows in ((60, 3), (daily_tile_row(135, 60, 2), 2)):
-        og, oi, cnt = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(r0, r0 + rows), want_counts=True)
+    # the WHOLE frame against the oracle (32 400 tiles x 65 536 lights = 2.1 G sphere tests on all host threads: seconds)
+    for r0, rows in oracle_tile_rows(135, [(60, 3), (7, 2)]):
+        og, oi, cnt = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(r0, r0 + rows), want_counts=True, threads=oracle.host_threads())
         t0 = r0 * 240
         np.testing.assert_array_equal(g[t0:t0 + rows * 240, 1], og[:, 1])
-        for t in range(rows * 240):
-            np.testing.assert_array_equal(idx[g[t0 + t, 0]: g[t0 + t, 0] + g[t0 + t, 1]], oi[og[t, 0]: og[t, 0] + og[t, 1]])
+        if rows == 135:   # the whole frame: offsets and the compact index array are the oracle's, word for word
+            np.testing.assert_array_equal(g, og)
+            np.testing.assert_array_equal(idx[: 1 + int(oi[0])], oi[: 1 + int(oi[0])])
+            assert (cnt > 196).any() and (cnt > 128).sum() > 100, "the frame exercises the candidate cap and the nearest-128 selection"
+        else:
+            for t in range(rows * 240):
+                np.testing.assert_array_equal(idx[g[t0 + t, 0]: g[t0 + t, 0] + g[t0 + t, 1]], oi[og[t, 0]: og[t, 0] + og[t, 1]])
 
 
 @pytest.mark.parametrize("flags", ALL_PATHS)
@@ -210,7 +215,7 @@ def test_nan_impacts_follow_the_literal_bubble_sort(ctx, flags):
 
 def test_c5_8k_1m_lights_invariants_and_an_oracle_tile_row(ctx):
     """BASELINE.json configs[4] at full size (7680 x 4320, 1 048 576 lights -- sixteen times the reference's 65 535-light cap): list
-    invariants over all 129 600 tiles and one tile row (480 tiles x 1 M lights) against the oracle."""
+    invariants over all 129 600 tiles, and the lists against the oracle -- the whole frame on a host with >= 64 threads, four tile rows otherwise."""
     f = synth.make_frame("C5", with_surface=False)
     W, H, N = 7680, 4320, 1 << 20
     g, idx = gpu_cull(ctx, f.cam, f.lights, f.depth, _lib.CULL_DEFAULT)
@@ -222,12 +227,17 @@ def test_c5_8k_1m_lights_invariants_and_an_oracle_tile_row(ctx):
     for t in np.random.default_rng(1).choice(len(g), 500, replace=False):
         seg = idx[g[t, 0]: g[t, 0] + g[t, 1]]
         assert len(np.unique(seg)) == len(seg)
-    for r0 in (131, daily_tile_row(270, 131)):
-        og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(r0, r0 + 1), want_counts=True)
+    # the oracle: the whole frame (129 600 tiles x 1 M lights) when the host has the threads for it (the GPU box: 256), else four fixed rows
+    for r0, rows in oracle_tile_rows(270, [(131, 1), (5, 1), (200, 1), (268, 1)], whole_from_threads=64):
+        og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(r0, r0 + rows), threads=oracle.host_threads())
         t0 = r0 * 480
-        np.testing.assert_array_equal(g[t0:t0 + 480, 1], og[:, 1])
-        for t in range(480):
-            np.testing.assert_array_equal(idx[g[t0 + t, 0]: g[t0 + t, 0] + g[t0 + t, 1]], oi[og[t, 0]: og[t, 0] + og[t, 1]])
+        np.testing.assert_array_equal(g[t0:t0 + rows * 480, 1], og[:, 1])
+        if rows == 270:
+            np.testing.assert_array_equal(g, og)
+            np.testing.assert_array_equal(idx[: 1 + int(oi[0])], oi[: 1 + int(oi[0])])
+        else:
+            for t in range(rows * 480):
+                np.testing.assert_array_equal(idx[g[t0 + t, 0]: g[t0 + t, 0] + g[t0 + t, 1]], oi[og[t, 0]: og[t, 0] + og[t, 1]])
 
 
 def test_large_light_set_with_directional_lights_on_a_small_frame(ctx):

@@ -831,3 +831,26 @@ def test_rasteriser_fill_rule_against_exact_arithmetic():
         n2 = (draw([[a, c, d]], [[0.5] * 3]) > 0).astype(int)
         assert (n1 + n2).max() <= 1
         np.testing.assert_array_equal(n1 + n2, (_exact_coverage([a, b, c], W, H) | _exact_coverage([a, c, d], W, H)).astype(int))
+
+
+def test_threaded_whole_frame_checkers_equal_the_single_thread_oracle():
+    """oracle_light_cull_threads / oracle_shade_threads (the whole-frame checkers of the full-size GPU tests) are the same per-tile / per-pixel
+    code spread over host threads: same bits, whatever the thread count, with and without a band, with the counts, with shadow maps."""
+    f = synth.make_frame("tiny_csm")
+    W, H = f.cam.width, f.cam.height
+    g1, i1, c1 = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, want_counts=True)
+    for threads in (2, 3, 8):
+        g, i, c = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, want_counts=True, threads=threads)
+        assert np.array_equal(g, g1) and np.array_equal(i, i1) and np.array_equal(c, c1)
+    Ty = oracle.num_tiles(W, H)[1]
+    gb1, ib1, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(1, Ty - 1), literal_select=True)
+    gb, ib, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(1, Ty - 1), literal_select=True, threads=4)
+    assert np.array_equal(gb, gb1) and np.array_equal(ib, ib1)
+    csm, _keep = oracle.make_csm(f.shadows.lights_matrices, f.shadows.maps)
+    r1 = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, g1, i1, csm)
+    for threads in (2, 5):
+        r = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, g1, i1, csm, threads=threads)
+        assert np.array_equal(r.view(np.uint32), r1.view(np.uint32))
+    rb1 = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, g1, i1, csm, rows=(5, H - 9))
+    rb = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, g1, i1, csm, rows=(5, H - 9), threads=3)
+    assert np.array_equal(rb.view(np.uint32), rb1.view(np.uint32))
