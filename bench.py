@@ -42,7 +42,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from sailor_amd import _lib, host, synth  # noqa: E402
-from sailor_amd.forward_plus import EcsSweep, ForwardPlus, HipContext, upload_lights  # noqa: E402
+from sailor_amd.forward_plus import PreparedLights, EcsSweep, ForwardPlus, HipContext, upload_lights  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0       # same table: 6.29 TB/s measured float4 copy
@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--exchange-every-step", action="store_true", help="include the RCCL list exchange in the timed region (N > 1)")
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
                     help="2 (the reference's MaxFramesInQueue, RHI/Renderer.h:34): frame k+1's cull is recorded on a second stream beside frame k's shade")
+    ap.add_argument("--plain-lights", action="store_true", help="no prepared lights: cull and shade read the 112-byte light records (rounds 1-2)")
+    ap.add_argument("--dynamic-lights", action="store_true", help="every light is dirty every frame: sailor_hip_prepare_lights over all N lights inside every step (serial / eager forms only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--equal-bands", action="store_true", help="N > 1: equal tile-row bands instead of cost-balanced ones")
     ap.add_argument("--split-frame", action="store_true", help="N > 1: ONE frame split into tile-row bands is `value` (the default; kept for old command lines)")
@@ -574,7 +576,7 @@ def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev):
 
     def time_band(b):
         """ms per step of band b alone on this GPU, launched the way a rank of the split frame launches it (the main path's pipeline graph)"""
-        fs = [ForwardPlus(ctx, W, H, N, band=b) for _ in range(2 if unroll else 1)]
+        fs = [ForwardPlus(ctx, W, H, N, band=b, prepared=prep) for _ in range(2 if unroll else 1)]
         dd = torch.from_numpy(np.ascontiguousarray(frame.depth[b.fbRowBegin:b.fbRowBegin + b.fbRowCount])).to(dev)
         ds = torch.from_numpy(frame.surface_rows(b.fbRowBegin, b.fbRowBegin + b.fbRowCount)).to(dev)
         for f in fs:
@@ -659,11 +661,16 @@ def main():
     torch.cuda.set_stream(side)
     ctx = HipContext(dev, stream=side)
     d_lights = upload_lights(frame.lights, dev)
+    # The lights' prepared views (sailor_hip_prepare_lights: the cull's 20-byte records, the shade's staged records), derived ONCE here, where the
+    # HIP backend derives them: behind the copy that writes the `light` SSBO (LightingECS::Tick uploads dirty runs only, ECS/LightingECS.cpp:152-191;
+    # the synthetic light set is static).  --dynamic-lights puts the preparation of all N lights into every step (every light dirty every frame);
+    # --plain-lights runs the kernels straight off the 112-byte records as rounds 1-2 did.
+    prep = None if args.plain_lights else PreparedLights(ctx, d_lights, N)
     Tx, Ty = host.num_tiles(W, H)
 
     def resident(b):
         """ForwardPlus for band b with the band's depth rows resident"""
-        f = ForwardPlus(ctx, W, H, N, band=b)
+        f = ForwardPlus(ctx, W, H, N, band=b, prepared=prep)
         dd = torch.from_numpy(np.ascontiguousarray(frame.depth[b.fbRowBegin:b.fbRowBegin + b.fbRowCount])).to(dev)
         return f, dd
 
@@ -707,6 +714,8 @@ def main():
         return
 
     def cull():
+        if args.dynamic_lights and prep is not None:
+            prep.prepare(0, N)
         fp.cull(cam.frame, d_lights, N, d_depth)
 
     def shade():
@@ -882,7 +891,7 @@ def main():
     if dist is not None and not args.no_afr and not weak:
         ok = 1
         try:
-            wf = ForwardPlus(ctx, W, H, N)
+            wf = ForwardPlus(ctx, W, H, N, prepared=prep)
             wd = torch.from_numpy(np.ascontiguousarray(frame.depth)).to(dev)
             ws = torch.from_numpy(frame.surface_rows(0, H)).to(dev)
 

@@ -283,6 +283,31 @@ SAILOR_HIP_API int sailor_hip_linearize_depth(SailorHipContext* ctx, const Sailo
 /* Tuning diagnostics (synchronises): out8 = {numBands, mask bits set, numGroups, sum of group list lengths, overflowed
  * groups, longest group list, 64-bit words per band, bits set in the column masks} for the intermediate pre-filter state
  * left in dWorkspace by the last sailor_hip_light_cull of the same geometry. */
+/* ---- prepared lights: the per-light half of the path, run where the `light` SSBO is WRITTEN instead of where it is read ------------------
+ * The reference re-derives everything per light inside its per-tile / per-fragment loops.  Lights change when LightingECS::Tick uploads a dirty run
+ * (ECS/LightingECS.cpp:182-191 -> IGraphicsDriverCommands::UpdateShaderBinding, RHI/GraphicsDriver.h:303), not every frame, so the HIP backend derives
+ * two views of the records right behind that copy ("pre-split SoA"), for the lights [firstLight, firstLight + count) it carried:
+ *   - the cull's view: (worldPosition, bounds.x) as one float4 and the type, dense arrays -- 20 bytes per light for k01_prepare to stream each frame
+ *     instead of 112;
+ *   - the shade's staged record, 80 bytes: normalised spot axis, reach threshold, 1 / bounds.x, the "every parameter is finite" bit ... -- what every
+ *     shade block otherwise derives again for every slot of its tile's list.
+ * dPrepared is caller-owned device memory of sailor_hip_prepared_lights_size(lightsCapacity) bytes, 16-byte aligned; lightsCapacity fixes its layout
+ * and must be the same in every call that names the buffer.  sailor_hip_light_cull_prepared / sailor_hip_shade_prepared take it beside dLights (NULL =
+ * the entry points above: same lists, same radiance, bit for bit -- the kernels run the same instructions on the same inputs, only elsewhere).
+ * The caller keeps it in step with dLights: a record changed without a prepare of its slot is a stale light, as a missed upload would be. */
+SAILOR_HIP_API size_t sailor_hip_prepared_lights_size(int32_t lightsCapacity);
+SAILOR_HIP_API int sailor_hip_prepare_lights(SailorHipContext* ctx, const SailorLightShaderData* dLights, int32_t firstLight, int32_t count,
+                                             int32_t lightsCapacity, void* dPrepared, size_t preparedBytes);
+/* the three arrays inside dPrepared (float4 posRadius[capacity]; uint32 type[capacity]; float4 staged[capacity][5]); any out pointer may be NULL */
+SAILOR_HIP_API int sailor_hip_prepared_lights_views(int32_t lightsCapacity, const void* dPrepared, const void** outPosRadius, const void** outType,
+                                                    const void** outStaged);
+SAILOR_HIP_API int sailor_hip_light_cull_prepared(SailorHipContext* ctx,
+                                                  const SailorUboFrameData* frame, const SailorLightCullPushConstants* pc,
+                                                  const SailorLightShaderData* dLights, const float* dLinearDepth,
+                                                  SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity,
+                                                  void* dWorkspace, size_t workspaceBytes,
+                                                  const SailorBand* band, uint32_t flags,
+                                                  const void* dPreparedLights /* or NULL */, int32_t preparedCapacity);
 SAILOR_HIP_API int sailor_hip_light_cull_diagnostics(SailorHipContext* ctx, int32_t width, int32_t height, int32_t lightsNum, const SailorBand* band,
                                                      const void* dWorkspace, uint64_t* out8);
 
@@ -317,6 +342,16 @@ SAILOR_HIP_API int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFra
                                        const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
                                        const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance,
                                        const SailorBand* band, const uint32_t* dTileOrder /* sailor_hip_light_cull_tile_order or NULL */);
+
+/* As sailor_hip_shade_ex with the lights' staged records (sailor_hip_prepare_lights, above); dPreparedLights == NULL is sailor_hip_shade_ex.
+ * With it dLights is not read and may be NULL. */
+SAILOR_HIP_API int sailor_hip_shade_prepared(SailorHipContext* ctx, const SailorUboFrameData* frame,
+                                             const float* dSurface, size_t surfacePlaneStride,
+                                             const SailorLightShaderData* dLights, int32_t lightsNum,
+                                             const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
+                                             const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance,
+                                             const SailorBand* band, const uint32_t* dTileOrder,
+                                             const void* dPreparedLights /* or NULL */, int32_t preparedCapacity);
 
 /* Self-check of the shade kernels' short forms of exact arithmetic (no reference counterpart: the shader leaves sqrt and 1 / x to the driver).
  * K2 evaluates normalize() as v * (1 / sqrt(dot(v, v))) with a correctly rounded square root and reciprocal, but not through the compiler's

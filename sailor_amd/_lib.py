@@ -116,6 +116,13 @@ SIGNATURES = {
     "sailor_hip_shade": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_size_t, _P, C.c_int32, _P, _P, C.POINTER(CsmDesc), _P, C.POINTER(Band)]),
     "sailor_hip_shade_ex": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_size_t, _P, C.c_int32, _P, _P, C.POINTER(CsmDesc), C.POINTER(IblDesc), _P,
                                       C.POINTER(Band), _P]),
+    "sailor_hip_prepared_lights_size": (C.c_size_t, [C.c_int32]),
+    "sailor_hip_prepare_lights": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t]),
+    "sailor_hip_prepared_lights_views": (C.c_int, [C.c_int32, _P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "sailor_hip_light_cull_prepared": (C.c_int, [_P, C.POINTER(UboFrameData), C.POINTER(LightCullPushConstants), _P, _P, _P, _P, C.c_size_t,
+                                                 _P, C.c_size_t, C.POINTER(Band), C.c_uint32, _P, C.c_int32]),
+    "sailor_hip_shade_prepared": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_size_t, _P, C.c_int32, _P, _P, C.POINTER(CsmDesc), C.POINTER(IblDesc), _P,
+                                            C.POINTER(Band), _P, _P, C.c_int32]),
     "sailor_hip_light_cull_tile_order": (_P, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band), _P]),
     "sailor_hip_evsm_blur": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sailor_hip_evsm_blur_pass": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

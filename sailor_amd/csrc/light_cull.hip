@@ -154,6 +154,7 @@ __device__ void frustum_from_rect(const Mat4& invProj, float x0, float y0, float
 struct PrepareArgs {
     Mat4 view, invProj;
     const SailorLightShaderData* lights;
+    const float4* soaPosRadius; const uint32_t* soaType; // sailor_hip_prepare_lights' 20-byte view of the lights, or null: read the 112-byte records
     const float* depth;
     float4* lightView; uint32_t* lightType; float4* tileInfo;
     unsigned long long* masks; unsigned long long* dirWords;
@@ -217,14 +218,21 @@ __device__ __forceinline__ void k0_lights(const int lb, unsigned char* __restric
     float4 lv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t type = 1u;
     if (valid) {
-        const SailorLightShaderData* L = a.lights + j;
-        const float x = L->worldPosition[0], y = L->worldPosition[1], z = L->worldPosition[2];
+        float x, y, z, radius;
+        if (a.soaPosRadius) { // two dense arrays, 20 bytes per light
+            const float4 pr = a.soaPosRadius[j];
+            x = pr.x; y = pr.y; z = pr.z; radius = pr.w;
+            type = a.soaType[j];
+        } else {              // the `light` SSBO itself: 20 of every 112 bytes
+            const SailorLightShaderData* L = a.lights + j;
+            x = L->worldPosition[0]; y = L->worldPosition[1]; z = L->worldPosition[2]; radius = L->bounds[0];
+            type = L->type;
+        }
         float4 p = glsl_mul(a.view, x, y, z, 1.0f);
         const float w = p.w;
         p.x = p.x / w; p.y = p.y / w; p.z = p.z / w;
         p.z = p.z * -1.0f; // "Reverse Z"
-        lv = make_float4(p.x, p.y, p.z, L->bounds[0]);
-        type = L->type;
+        lv = make_float4(p.x, p.y, p.z, radius);
         if (split == 0) { a.lightView[j] = lv; a.lightType[j] = type; }
     }
     __syncthreads(); // the planes are in LDS
@@ -1127,9 +1135,20 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
                           SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity,
                           void* dWorkspace, size_t workspaceBytes, const SailorBand* band, uint32_t flags)
 {
+    return sailor_hip_light_cull_prepared(ctx, frame, pc, dLights, dLinearDepth, dLightsGrid, dCulledLights, culledCapacity, dWorkspace, workspaceBytes, band, flags,
+                                          nullptr, 0);
+}
+
+int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameData* frame, const SailorLightCullPushConstants* pc,
+                                   const SailorLightShaderData* dLights, const float* dLinearDepth,
+                                   SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity,
+                                   void* dWorkspace, size_t workspaceBytes, const SailorBand* band, uint32_t flags,
+                                   const void* dPreparedLights, int32_t preparedCapacity)
+{
     if (!ctx || !frame || !pc || !dLinearDepth || !dLightsGrid || !dCulledLights || !dWorkspace) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     const int W = pc->viewportSize[0], H = pc->viewportSize[1], N = pc->lightsNum;
-    if (W <= 0 || H <= 0 || N < 0 || (N > 0 && !dLights)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (W <= 0 || H <= 0 || N < 0 || (N > 0 && !dLights && !dPreparedLights)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (dPreparedLights && (preparedCapacity < N || ((uintptr_t)dPreparedLights & 15))) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (N > 0x3FFFFFFF) return SAILOR_HIP_ERR_UNSUPPORTED; // bit 31 of a candidate entry carries the "directional" flag
     // Appendix A: the depth extent (push constants) and the window viewport (frame UBO) must agree
     if (frame->viewportSize[0] != W || frame->viewportSize[1] != H) return SAILOR_HIP_ERR_UNSUPPORTED;
@@ -1164,6 +1183,12 @@ int sailor_hip_light_cull(SailorHipContext* ctx, const SailorUboFrameData* frame
     memcpy(pa.view.m, frame->view, 64);
     memcpy(pa.invProj.m, frame->invProjection, 64);
     pa.lights = dLights; pa.depth = dLinearDepth;
+    pa.soaPosRadius = nullptr; pa.soaType = nullptr;
+    if (dPreparedLights) {
+        const void *pr = nullptr, *ty = nullptr;
+        sailor_hip_prepared_lights_views(preparedCapacity, dPreparedLights, &pr, &ty, nullptr);
+        pa.soaPosRadius = (const float4*)pr; pa.soaType = (const uint32_t*)ty;
+    }
     pa.lightView = (float4*)(ws + L.offLightView); pa.lightType = (uint32_t*)(ws + L.offLightType); pa.tileInfo = (float4*)(ws + L.offTileInfo);
     pa.masks = (unsigned long long*)(ws + L.offMasks); pa.dirWords = (unsigned long long*)(ws + L.offDirWords);
     pa.N = N; pa.words = L.words;

@@ -30,28 +30,33 @@
 
 // Entry points: without shadow lookups in it the kernel fits 64 VGPRs, and the register allocator is told to stay there
 // (8 waves per SIMD); with the 16-tap PCF inlined it does not, and forcing it would spill.  The ambient term adds a third.
-#define SHADE_ENTRY(NAME, ATTR, CSM, IBL)                                                                                                          \
+#define SHADE_ENTRY(NAME, ATTR, CSM, IBL, PREP)                                                                                                    \
     __global__ __launch_bounds__(256) ATTR void NAME(ShadeArgs A, CsmArgs C, IblArgs I, const float4* __restrict__ surface, size_t planeStride,    \
                                                      const SailorLightShaderData* __restrict__ lights, const SailorLightsGrid* __restrict__ grid, \
                                                      const uint32_t* __restrict__ culled, float4* __restrict__ radiance)                          \
     {                                                                                                                                              \
         __shared__ ShadeLds lds;                                                                                                                   \
-        k2_shade_body<CSM, IBL>(lds, A, C, I, surface, planeStride, lights, grid, culled, radiance);                                               \
+        k2_shade_body<CSM, IBL, ROLE_TILE, PREP>(lds, A, C, I, surface, planeStride, lights, grid, culled, radiance);                              \
     }
 #define FORCE_64_VGPRS __attribute__((amdgpu_waves_per_eu(8, 8)))
-SHADE_ENTRY(k2_shade, FORCE_64_VGPRS, false, false)
-SHADE_ENTRY(k2_shade_csm, , true, false)
-SHADE_ENTRY(k2_shade_ibl, , false, true)
-SHADE_ENTRY(k2_shade_csm_ibl, , true, true)
+SHADE_ENTRY(k2_shade, FORCE_64_VGPRS, false, false, false)
+SHADE_ENTRY(k2_shade_csm, , true, false, false)
+SHADE_ENTRY(k2_shade_ibl, , false, true, false)
+SHADE_ENTRY(k2_shade_csm_ibl, , true, true, false)
+// the same kernels reading the records sailor_hip_prepare_lights staged (`lights` = the staged array)
+SHADE_ENTRY(k2_shade_p, FORCE_64_VGPRS, false, false, true)
+SHADE_ENTRY(k2_shade_csm_p, __attribute__((amdgpu_waves_per_eu(6, 6))), true, false, true)
+SHADE_ENTRY(k2_shade_ibl_p, , false, true, true)
+SHADE_ENTRY(k2_shade_csm_ibl_p, , true, true, true)
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k2_shade_band(ShadeArgs A, CsmArgs C, int bandTiles, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,
-                   const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
+template <bool PREP>
+__device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, int bandTiles, const float4* __restrict__ surface, size_t planeStride,
+                                                   const SailorLightShaderData* __restrict__ lights, const SailorLightsGrid* __restrict__ grid,
+                                                   const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
 {
-    __shared__ ShadeLds lds;
     if (blockIdx.x >= (unsigned)SPLIT_BLOCKS) {
         const int t = (int)blockIdx.x - SPLIT_BLOCKS, ty = t / A.Tx;
-        k2_shade_body<false, false, ROLE_BAND_TILE>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, t - ty * A.Tx, ty, 0);
+        k2_shade_body<false, false, ROLE_BAND_TILE, PREP>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, t - ty * A.Tx, ty, 0);
         return;
     }
     // the cull's hint: order[0 .. nA) = the tiles with >= 96 lights, order[T-1], order[T-2] .. = the nB tiles with 40..95, order[T] = nA, order[T+1] = nB
@@ -59,10 +64,89 @@ void k2_shade_band(ShadeArgs A, CsmArgs C, int bandTiles, const float4* __restri
     for (uint32_t idx = blockIdx.x; idx < limit; idx += (uint32_t)SPLIT_BLOCKS) {
         const uint32_t li = idx >> 2;
         const uint32_t o = A.order[li < nA ? li : (uint32_t)bandTiles - 1u - (li - nA)];
-        k2_shade_body<false, false, ROLE_BAND_SPLIT>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, (int)(o & 0xFFFFu), (int)(o >> 16),
+        k2_shade_body<false, false, ROLE_BAND_SPLIT, PREP>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, (int)(o & 0xFFFFu), (int)(o >> 16),
                                                            (int)(idx & 3u));
         __syncthreads(); // the LDS arrays are reused by the block's next tile
     }
+}
+
+#define SHADE_BAND_ENTRY(NAME, PREP)                                                                                                                                 \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))                                                                                     \
+    void NAME(ShadeArgs A, CsmArgs C, int bandTiles, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,        \
+              const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)                                         \
+    {                                                                                                                                                                \
+        __shared__ ShadeLds lds;                                                                                                                                     \
+        k2_shade_band_body<PREP>(lds, A, C, bandTiles, surface, planeStride, lights, grid, culled, radiance);                                                        \
+    }
+SHADE_BAND_ENTRY(k2_shade_band, false)
+SHADE_BAND_ENTRY(k2_shade_band_p, true)
+
+// ---- sailor_hip_prepare_lights: the per-light half of the path, once per UPLOADED light instead of once per frame and list slot ----
+// One lane per light of [first, first + count): the cull's 20-byte view of it -- (worldPosition, bounds.x) as a float4 and the type, two dense
+// arrays that k01_prepare streams instead of the 112-byte records (7.3 MB for 1.3 at 65 536 lights) -- and the shade's staged record
+// (stage_light_record: what every shade block used to derive for every slot of its list).
+struct PreparedLayout { size_t offPosRadius, offType, offStaged, total; };
+static PreparedLayout prepared_layout(int32_t capacity)
+{
+    const size_t n = (size_t)(capacity > 0 ? capacity : 1);
+    PreparedLayout L;
+    size_t o = 0;
+    L.offPosRadius = o; o = align_up(o + n * 16, 256);
+    L.offType = o; o = align_up(o + n * 4, 256);
+    L.offStaged = o; o = align_up(o + n * (LREC * 16), 256);
+    L.total = o;
+    return L;
+}
+
+__global__ __launch_bounds__(256) void k_prepare_lights(const SailorLightShaderData* __restrict__ lights, int first, int count, float4* __restrict__ posRadius,
+                                                        uint32_t* __restrict__ type, float4* __restrict__ staged)
+{
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= count) return;
+    const int j = first + i;
+    const float4* L = reinterpret_cast<const float4*>(lights + j);
+    const float4 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3], q4 = L[4], q5 = L[5], q6 = L[6];
+    posRadius[j] = make_float4(q1.x, q1.y, q1.z, q6.x);
+    type[j] = __float_as_uint(q0.x);
+    float4 o0, o1, o2, o3, o4;
+    stage_light_record(q0, q1, q2, q3, q4, q5, q6, o0, o1, o2, o3, o4);
+    float4* o = staged + (size_t)j * LREC;
+    o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3; o[4] = o4;
+}
+
+extern "C" size_t sailor_hip_prepared_lights_size(int32_t lightsCapacity)
+{
+    if (lightsCapacity < 0) return 0;
+    return prepared_layout(lightsCapacity).total;
+}
+
+extern "C" int sailor_hip_prepare_lights(SailorHipContext* ctx, const SailorLightShaderData* dLights, int32_t firstLight, int32_t count, int32_t lightsCapacity,
+                                         void* dPrepared, size_t preparedBytes)
+{
+    if (!ctx || !dPrepared || firstLight < 0 || count < 0 || lightsCapacity < 0 || (count > 0 && !dLights)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if ((int64_t)firstLight + count > (int64_t)lightsCapacity) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (((uintptr_t)dLights & 15) || ((uintptr_t)dPrepared & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const PreparedLayout L = prepared_layout(lightsCapacity);
+    if (preparedBytes < L.total) return SAILOR_HIP_ERR_WORKSPACE_TOO_SMALL;
+    if (count == 0) return SAILOR_HIP_OK;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    char* base = (char*)dPrepared;
+    hipLaunchKernelGGL(k_prepare_lights, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, dLights, firstLight, count,
+                       (float4*)(base + L.offPosRadius), (uint32_t*)(base + L.offType), (float4*)(base + L.offStaged));
+    SAILOR_CHECK_LAUNCH(ctx, "k_prepare_lights");
+    return SAILOR_HIP_OK;
+}
+
+// the two arrays the cull reads (light_cull.hip: sailor_hip_light_cull_prepared)
+extern "C" int sailor_hip_prepared_lights_views(int32_t lightsCapacity, const void* dPrepared, const void** outPosRadius, const void** outType, const void** outStaged)
+{
+    if (!dPrepared || lightsCapacity < 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const PreparedLayout L = prepared_layout(lightsCapacity);
+    const char* base = (const char*)dPrepared;
+    if (outPosRadius) *outPosRadius = base + L.offPosRadius;
+    if (outType) *outType = base + L.offType;
+    if (outStaged) *outStaged = base + L.offStaged;
+    return SAILOR_HIP_OK;
 }
 
 // ---- ComputeBrdfLut.shader:26-71 (Lighting.glsl:27-37 SampleGGX, :65-70 GeometrySchlickGGX_IBL, Math.glsl:285-293) ----
@@ -157,13 +241,15 @@ extern "C" int sailor_hip_compute_brdf_lut(SailorHipContext* ctx, float* dLut, i
     return SAILOR_HIP_OK;
 }
 
-extern "C" int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
-                                   const SailorLightShaderData* dLights, int32_t lightsNum,
-                                   const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
-                                   const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance, const SailorBand* band, const uint32_t* dTileOrder)
+extern "C" int sailor_hip_shade_prepared(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
+                                         const SailorLightShaderData* dLights, int32_t lightsNum,
+                                         const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
+                                         const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance, const SailorBand* band, const uint32_t* dTileOrder,
+                                         const void* dPreparedLights, int32_t preparedCapacity)
 {
     if (!ctx || !frame || !dSurface || !dLightsGrid || !dCulledLights || !dRadiance) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-    if (lightsNum < 0 || (lightsNum > 0 && !dLights)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (lightsNum < 0 || (lightsNum > 0 && !dLights && !dPreparedLights)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (dPreparedLights && (preparedCapacity < lightsNum || ((uintptr_t)dPreparedLights & 15))) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     const int W = frame->viewportSize[0], H = frame->viewportSize[1];
     if (W <= 0 || H <= 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     SailorBand whole;
@@ -171,7 +257,7 @@ extern "C" int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFrameDa
     const int Ty = (H - 1) / TILE + 1;
     if (!sailor_hip_band_is_valid(W, H, band)) return SAILOR_HIP_ERR_INVALID_ARGUMENT; // tile rows AND their framebuffer rows, as the cull checks them
     if (surfacePlaneStride < (size_t)band->fbRowCount * W) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-    if (((uintptr_t)dSurface & 15) || ((uintptr_t)dRadiance & 15) || ((uintptr_t)dLights & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (((uintptr_t)dSurface & 15) || ((uintptr_t)dRadiance & 15) || (!dPreparedLights && ((uintptr_t)dLights & 15))) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
 
     SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
     ShadeArgs A;
@@ -215,17 +301,30 @@ extern "C" int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFrameDa
     }
     const float4* S = (const float4*)dSurface;
     float4* Rd = (float4*)dRadiance;
-#define LAUNCH_SHADE(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, ctx->stream, A, C, I, S, surfacePlaneStride, dLights, dLightsGrid, dCulledLights, Rd)
+    // with prepared lights the kernels' `lights` argument is the staged array (LREC float4 per light)
+    const SailorLightShaderData* L = dLights;
+    if (dPreparedLights) L = reinterpret_cast<const SailorLightShaderData*>((const char*)dPreparedLights + prepared_layout(preparedCapacity).offStaged);
+#define LAUNCH_SHADE(K) do { if (dPreparedLights) hipLaunchKernelGGL(K##_p, grid, dim3(256), 0, ctx->stream, A, C, I, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd); \
+                             else hipLaunchKernelGGL(K, grid, dim3(256), 0, ctx->stream, A, C, I, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd); } while (0)
     if (hasCsm && ibl) LAUNCH_SHADE(k2_shade_csm_ibl);
     else if (hasCsm) LAUNCH_SHADE(k2_shade_csm);
     else if (ibl) LAUNCH_SHADE(k2_shade_ibl);
-    else if (dTileOrder && band->tileRowEnd - band->tileRowBegin < Ty) // a band of a split frame: long tiles are split across four blocks
-        hipLaunchKernelGGL(k2_shade_band, dim3((unsigned)SPLIT_BLOCKS + (unsigned)bandTiles), dim3(256), 0, ctx->stream, A, C, bandTiles, S, surfacePlaneStride,
-                           dLights, dLightsGrid, dCulledLights, Rd);
-    else LAUNCH_SHADE(k2_shade);
+    else if (dTileOrder && band->tileRowEnd - band->tileRowBegin < Ty) { // a band of a split frame: long tiles are split across four blocks
+        const dim3 bgrid((unsigned)SPLIT_BLOCKS + (unsigned)bandTiles);
+        if (dPreparedLights) hipLaunchKernelGGL(k2_shade_band_p, bgrid, dim3(256), 0, ctx->stream, A, C, bandTiles, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd);
+        else hipLaunchKernelGGL(k2_shade_band, bgrid, dim3(256), 0, ctx->stream, A, C, bandTiles, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd);
+    } else LAUNCH_SHADE(k2_shade);
 #undef LAUNCH_SHADE
     SAILOR_CHECK_LAUNCH(ctx, "k2_shade");
     return SAILOR_HIP_OK;
+}
+
+extern "C" int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
+                                   const SailorLightShaderData* dLights, int32_t lightsNum,
+                                   const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
+                                   const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance, const SailorBand* band, const uint32_t* dTileOrder)
+{
+    return sailor_hip_shade_prepared(ctx, frame, dSurface, surfacePlaneStride, dLights, lightsNum, dLightsGrid, dCulledLights, csm, ibl, dRadiance, band, dTileOrder, nullptr, 0);
 }
 
 extern "C" int sailor_hip_shade(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,

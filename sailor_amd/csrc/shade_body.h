@@ -249,6 +249,41 @@ __device__ __forceinline__ float div_stored(float a, float b, float y, bool slow
 }
 
 #define LREC 5 // float4 per staged light
+
+// One light's record (SailorLightShaderData as seven float4) -> its staged form (the five float4 described at "Staged light record" below).
+// Used by k2_shade's own staging and by sailor_hip_prepare_lights (shade.hip), which runs it once per uploaded light instead of once per
+// (tile, list slot): the same instructions, so the same bits either way.
+__device__ __forceinline__ void stage_light_record(const float4 q0, const float4 q1, const float4 q2, const float4 q3, const float4 q4, const float4 q5, const float4 q6,
+                                                   float4& o0, float4& o1, float4& o2, float4& o3, float4& o4)
+{
+    const uint32_t type = __float_as_uint(q0.x), shadowType = __float_as_uint(q0.y);
+    const float ndx = -q2.x, ndy = -q2.y, ndz = -q2.z;            // Li = -light.direction (:309)
+    const float len = sqrt_exact(dot3f(ndx, ndy, ndz, ndx, ndy, ndz)); // normalize(-light.direction) (:298)
+    const float linv = rcp_of_sqrt(len);
+    // A zero factor only annihilates a FINITE product (inf * 0 = NaN in the reference): a light with ANY non-finite parameter --
+    // intensity, but also position, direction, attenuation, cone or radius, which reach the product through the falloff -- is never
+    // skipped.
+    // (kept short and free of branches: x * 0 is 0 for a finite x and NaN otherwise, two fma chains collect the fifteen parameters, one
+    // compare reads the result)
+    const float z0 = fmaf(q3.x, 0.0f, fmaf(q3.y, 0.0f, fmaf(q3.z, 0.0f, fmaf(q1.x, 0.0f, fmaf(q1.y, 0.0f, fmaf(q1.z, 0.0f, fmaf(q2.x, 0.0f, q2.y * 0.0f)))))));
+    const float z1 = fmaf(q2.z, 0.0f, fmaf(q4.x, 0.0f, fmaf(q4.y, 0.0f, fmaf(q4.z, 0.0f, fmaf(q5.x, 0.0f, fmaf(q5.y, 0.0f, q6.x * 0.0f))))));
+    const float zz = z0 + z1;
+    const bool finite = zz == zz;
+    // Conservative "out of reach" threshold of a point light: d^2 > r^2 (1 + 1e-5) => fl(dist / r) >= 1 => the radius
+    // window (:290) is exactly 0.  Only for r > 0 (a negative radius clamps to the FULL window in the reference).
+    const float r = q6.x;
+    const bool isPointLight = type == 1u;
+    const float raFinite = isPointLight ? (r > 0.0f ? (r * r) * 1.00001f : __builtin_inff()) : -(q5.y - 1e-5f);
+    const float ra = finite ? raFinite : __builtin_inff();
+    const float rb = isPointLight ? r : q5.x - q5.y;
+    const uint32_t bits = (type < 255u ? type : 255u) | ((shadowType < 255u ? shadowType : 255u) << 8) | (finite ? 0x10000u : 0u);
+    o0 = make_float4(q1.x, q1.y, q1.z, ra);
+    o1 = make_float4(ndx * linv, ndy * linv, ndz * linv, __uint_as_float(bits));
+    o2 = make_float4(q4.x, q4.y, q4.z, rb);
+    o3 = make_float4(ndx, ndy, ndz, q5.y);
+    const uint32_t rbExp = (__float_as_uint(rb) >> 23) & 0xFFu;
+    o4 = make_float4(q3.x, q3.y, q3.z, (rbExp - 87u <= 80u) ? rcp_of_sqrt(rb) : __builtin_nanf("")); // (rcp_of_sqrt: RN(1 / x) for every |x| in [2^-126, 2^126])
+}
 #define PENDK 4  // queued pairs per pixel in one window (their queue positions ride in one register, 7 bits each under a sentinel bit)
 #define QMAX 128 // queued pairs per wave in one window (two lights that reach every pixel fit; positions are 7 bits; 17.4 KB of LDS per block, 9 blocks per CU)
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -387,7 +422,9 @@ struct ShadeLds {
 #define ROLE_TILE 0       // one block per tile, grid (tiles per row, tile rows)
 #define ROLE_BAND_TILE 1  // the same inside k2_shade_band: returns at once on a tile of the split blocks
 #define ROLE_BAND_SPLIT 2 // one block per (long tile, quadrant)
-template <bool HAS_CSM, bool HAS_IBL, int ROLE = ROLE_TILE>
+// PREPARED: `lights` points at the staged records sailor_hip_prepare_lights wrote (LREC float4 per light, indexed like the `light` SSBO) instead of
+// at the SSBO itself: a list slot is then five 16-byte loads and five LDS stores -- no arithmetic on the path the block's other waves wait for.
+template <bool HAS_CSM, bool HAS_IBL, int ROLE = ROLE_TILE, bool PREPARED = false>
 __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, const IblArgs& I, const float4* __restrict__ surface, size_t planeStride,
                                                  const SailorLightShaderData* __restrict__ lights,
                                                  const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled,
@@ -449,8 +486,13 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const bool staged = __builtin_amdgcn_inverse_ballot_w64(stagedMask);
     float4 q0, q1, q2, q3, q4, q5, q6;
     if (staged) {
-        const float4* L = reinterpret_cast<const float4*>(lights + index);
-        q0 = L[0]; q1 = L[1]; q2 = L[2]; q3 = L[3]; q4 = L[4]; q5 = L[5]; q6 = L[6];
+        if constexpr (PREPARED) {
+            const float4* L = reinterpret_cast<const float4*>(lights) + (size_t)index * LREC;
+            q0 = L[0]; q1 = L[1]; q2 = L[2]; q3 = L[3]; q4 = L[4];
+        } else {
+            const float4* L = reinterpret_cast<const float4*>(lights + index);
+            q0 = L[0]; q1 = L[1]; q2 = L[2]; q3 = L[3]; q4 = L[4]; q5 = L[5]; q6 = L[6];
+        }
     }
 
     // ---- per-pixel invariants (Standard.shader:379-401) ----
@@ -476,34 +518,14 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         if (lane == 0) sEnd[wave] = bad ? (uint32_t)(wave * 64 + __builtin_ctzll(bad)) : 0xFFFFFFFFu;
     }
     if (staged) {
-        const uint32_t type = __float_as_uint(q0.x), shadowType = __float_as_uint(q0.y);
-        const float ndx = -q2.x, ndy = -q2.y, ndz = -q2.z;            // Li = -light.direction (:309)
-        const float len = sqrt_exact(dot3f(ndx, ndy, ndz, ndx, ndy, ndz)); // normalize(-light.direction) (:298)
-        const float linv = rcp_of_sqrt(len);
-        // A zero factor only annihilates a FINITE product (inf * 0 = NaN in the reference): a light with ANY non-finite parameter --
-        // intensity, but also position, direction, attenuation, cone or radius, which reach the product through the falloff -- is never
-        // skipped.
-        // (staging is the block's critical path -- the other three waves wait at the barrier for the first -- so it is kept short and free of
-        // branches: x * 0 is 0 for a finite x and NaN otherwise, two fma chains collect the fifteen parameters, one compare reads the result)
-        const float z0 = fmaf(q3.x, 0.0f, fmaf(q3.y, 0.0f, fmaf(q3.z, 0.0f, fmaf(q1.x, 0.0f, fmaf(q1.y, 0.0f, fmaf(q1.z, 0.0f, fmaf(q2.x, 0.0f, q2.y * 0.0f)))))));
-        const float z1 = fmaf(q2.z, 0.0f, fmaf(q4.x, 0.0f, fmaf(q4.y, 0.0f, fmaf(q4.z, 0.0f, fmaf(q5.x, 0.0f, fmaf(q5.y, 0.0f, q6.x * 0.0f))))));
-        const float zz = z0 + z1;
-        const bool finite = zz == zz;
-        // Conservative "out of reach" threshold of a point light: d^2 > r^2 (1 + 1e-5) => fl(dist / r) >= 1 => the radius
-        // window (:290) is exactly 0.  Only for r > 0 (a negative radius clamps to the FULL window in the reference).
-        const float r = q6.x;
-        const bool isPointLight = type == 1u;
-        const float raFinite = isPointLight ? (r > 0.0f ? (r * r) * 1.00001f : __builtin_inff()) : -(q5.y - 1e-5f);
-        const float ra = finite ? raFinite : __builtin_inff();
-        const float rb = isPointLight ? r : q5.x - q5.y;
-        const uint32_t bits = (type < 255u ? type : 255u) | ((shadowType < 255u ? shadowType : 255u) << 8) | (finite ? 0x10000u : 0u);
+        // (staging is the block's critical path -- the other three waves wait at the barrier for the first; with PREPARED records it is a copy)
         float4* o = sL + tid * LREC;
-        o[0] = make_float4(q1.x, q1.y, q1.z, ra);
-        o[1] = make_float4(ndx * linv, ndy * linv, ndz * linv, __uint_as_float(bits));
-        o[2] = make_float4(q4.x, q4.y, q4.z, rb);
-        o[3] = make_float4(ndx, ndy, ndz, q5.y);
-        const uint32_t rbExp = (__float_as_uint(rb) >> 23) & 0xFFu;
-        o[4] = make_float4(q3.x, q3.y, q3.z, (rbExp - 87u <= 80u) ? rcp_of_sqrt(rb) : __builtin_nanf("")); // (rcp_of_sqrt: RN(1 / x) for every |x| in [2^-126, 2^126])
+        if constexpr (PREPARED) { o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3; o[4] = q4; }
+        else {
+            float4 o0, o1, o2, o3, o4;
+            stage_light_record(q0, q1, q2, q3, q4, q5, q6, o0, o1, o2, o3, o4);
+            o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3; o[4] = o4;
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the records are in LDS (global loads may stay in flight)
     const uint32_t numLights = min(min(listNum, sEnd[0]), min(sEnd[1], min(sEnd[2], sEnd[3])));

@@ -64,11 +64,42 @@ def linearize_depth(ctx: "HipContext", frame: UboFrameData, raw: torch.Tensor, o
     return out
 
 
+class PreparedLights:
+    """sailor_hip_prepare_lights' output for a `light` SSBO of `capacity` records: the cull's 20-byte view and the shade's staged records, derived where
+    the records are uploaded (the HIP backend does it behind UpdateShaderBinding) instead of in every frame's kernels.  prepare(first, count) after
+    every change of the records [first, first + count)."""
+
+    def __init__(self, ctx: "HipContext", lights: torch.Tensor, lights_num: int, capacity: int | None = None):
+        self.ctx, self.lights, self.capacity = ctx, lights, max(int(capacity if capacity is not None else lights_num), 1)
+        n = ctx._lib.sailor_hip_prepared_lights_size(self.capacity)
+        self.buffer = torch.empty(n, dtype=torch.uint8, device=ctx.device)
+        self.prepare(0, lights_num)
+
+    def prepare(self, first: int, count: int, ctx: "HipContext | None" = None):
+        ctx = ctx or self.ctx
+        _lib.check(ctx._lib.sailor_hip_prepare_lights(ctx.handle, _ptr(self.lights), first, count, self.capacity, _ptr(self.buffer), self.buffer.numel()),
+                   "sailor_hip_prepare_lights", ctx.handle)
+
+    def views(self):
+        """(posRadius float32 [capacity, 4], type int32 [capacity], staged float32 [capacity, 5, 4]) as tensors over the buffer"""
+        lib = self.ctx._lib
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(lib.sailor_hip_prepared_lights_views(self.capacity, _ptr(self.buffer), C.byref(a), C.byref(b), C.byref(c)), "sailor_hip_prepared_lights_views")
+        base = self.buffer.data_ptr()
+        n = self.capacity
+        f = self.buffer
+        return (f[a.value - base: a.value - base + 16 * n].view(torch.float32).view(n, 4), f[b.value - base: b.value - base + 4 * n].view(torch.int32),
+                f[c.value - base: c.value - base + 80 * n].view(torch.float32).view(n, 5, 4))
+
+
 class ForwardPlus:
     """Cull + shade for one band of a W x H frame on one GPU."""
 
-    def __init__(self, ctx: HipContext, width: int, height: int, max_lights: int, band: Band | None = None):
+    def __init__(self, ctx: HipContext, width: int, height: int, max_lights: int, band: Band | None = None, prepared: "PreparedLights | None" = None):
+        """prepared: the prepared views of the light buffer this object will be used with -- cull() and shade() then go through the prepared entry
+        points unless told otherwise per call"""
         self.ctx, self.W, self.H, self.max_lights = ctx, width, height, max_lights
+        self.prepared = prepared
         self.Tx, self.Ty = host.num_tiles(width, height)
         self.band = band if band is not None else host.band_whole_frame(width, height)
         self.band_tiles = (self.band.tileRowEnd - self.band.tileRowBegin) * self.Tx
@@ -89,23 +120,32 @@ class ForwardPlus:
 
     # -- K0 + K1 --------------------------------------------------------------------------------------------------
     def cull(self, frame: UboFrameData, lights: torch.Tensor, lights_num: int, depth: torch.Tensor, flags: int = _lib.CULL_DEFAULT,
-             ctx: "HipContext | None" = None):
+             ctx: "HipContext | None" = None, prepared: "PreparedLights | None" = None):
         """lights: uint8/any tensor holding lights_num 112-byte records; depth: float32 [band rows, W].
-        ctx: record on another context's stream (frames in flight: next frame's cull beside this frame's shade)."""
+        ctx: record on another context's stream (frames in flight: next frame's cull beside this frame's shade).
+        prepared: the lights' prepared views (the kernel then streams 20 bytes per light instead of the 112-byte records)."""
         assert depth.dtype == torch.float32 and depth.is_contiguous() and depth.shape == (self.band.fbRowCount, self.W), depth.shape
         assert lights_num <= self.max_lights
+        prepared = prepared if prepared is not None else self.prepared
         pc = host.push_constants(frame, self.W, self.H, lights_num)
         ctx = ctx or self.ctx
         lib = ctx._lib
-        _lib.check(lib.sailor_hip_light_cull(ctx.handle, C.byref(frame), C.byref(pc), _ptr(lights), _ptr(depth), _ptr(self.grid), _ptr(self.culled),
-                                             self.culled.numel(), _ptr(self.workspace), self.workspace.numel(), C.byref(self.band), flags),
-                   "sailor_hip_light_cull", ctx.handle)
+        if prepared is not None:
+            assert lights_num <= prepared.capacity
+            _lib.check(lib.sailor_hip_light_cull_prepared(ctx.handle, C.byref(frame), C.byref(pc), _ptr(lights), _ptr(depth), _ptr(self.grid), _ptr(self.culled),
+                                                          self.culled.numel(), _ptr(self.workspace), self.workspace.numel(), C.byref(self.band), flags,
+                                                          _ptr(prepared.buffer), prepared.capacity),
+                       "sailor_hip_light_cull_prepared", ctx.handle)
+        else:
+            _lib.check(lib.sailor_hip_light_cull(ctx.handle, C.byref(frame), C.byref(pc), _ptr(lights), _ptr(depth), _ptr(self.grid), _ptr(self.culled),
+                                                 self.culled.numel(), _ptr(self.workspace), self.workspace.numel(), C.byref(self.band), flags),
+                       "sailor_hip_light_cull", ctx.handle)
         self._culled_once = True
         return self.grid, self.culled
 
     # -- K2 + K3 --------------------------------------------------------------------------------------------------
     def shade(self, frame: UboFrameData, surface: torch.Tensor, lights: torch.Tensor, lights_num: int, csm: CsmDesc | None = None,
-              out: torch.Tensor | None = None, ibl: "_lib.IblDesc | None" = None) -> torch.Tensor:
+              out: torch.Tensor | None = None, ibl: "_lib.IblDesc | None" = None, prepared: "PreparedLights | None" = None) -> torch.Tensor:
         """surface: float32 [3, band rows, W, 4]; returns radiance float32 [band rows, W, 4].  ibl: ambient term (its `ao`
         pointer, if any, holds the band's rows)."""
         rows = self.band.fbRowCount
@@ -115,7 +155,15 @@ class ForwardPlus:
                 self.radiance = torch.empty((rows, self.W, 4), dtype=torch.float32, device=self.ctx.device)
             out = self.radiance
         lib = self.ctx._lib
+        prepared = prepared if prepared is not None else self.prepared
         order = self.tile_order if (self.use_tile_order and self._culled_once) else None  # only lists made by THIS object's cull have an order
+        if prepared is not None:
+            assert lights_num <= prepared.capacity
+            _lib.check(lib.sailor_hip_shade_prepared(self.ctx.handle, C.byref(frame), _ptr(surface), rows * self.W, _ptr(lights), lights_num, _ptr(self.grid),
+                                                     _ptr(self.culled), C.byref(csm) if csm is not None else None, C.byref(ibl) if ibl is not None else None,
+                                                     _ptr(out), C.byref(self.band), order, _ptr(prepared.buffer), prepared.capacity),
+                       "sailor_hip_shade_prepared", self.ctx.handle)
+            return out
         if ibl is not None or order is not None:
             _lib.check(lib.sailor_hip_shade_ex(self.ctx.handle, C.byref(frame), _ptr(surface), rows * self.W, _ptr(lights), lights_num, _ptr(self.grid),
                                                _ptr(self.culled), C.byref(csm) if csm is not None else None, C.byref(ibl) if ibl is not None else None,

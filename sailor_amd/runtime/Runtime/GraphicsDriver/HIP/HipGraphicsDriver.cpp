@@ -310,6 +310,26 @@ void HipGraphicsDriver::UpdateShaderBinding(RHICommandListPtr cmd, RHIShaderBind
         return;
     }
     UpdateBuffer(cmd, binding->m_buffer, data, size, variableOffset);
+    // The `light` SSBO (LightingECS.cpp:44; written only through here, by LightingECS::Tick's dirty runs :182-191): derive the prepared views of the
+    // records this copy carried right behind it -- the cull then streams 20 bytes per light and frame instead of 112, the shade copies staged records
+    // instead of deriving them per tile and list slot (include/sailor_hip.h "prepared lights").
+    if (binding->m_name == "light" && binding->m_type == EShaderBindingType::StorageBuffer && binding->m_buffer && size > 0) {
+        const int32_t capacity = (int32_t)(binding->m_buffer->m_size / sizeof(SailorLightShaderData));
+        if (!binding->m_hipPreparedLights || binding->m_hipPreparedCapacity != capacity) {
+            binding->m_hipPreparedLights = CreateBuffer(sailor_hip_prepared_lights_size(capacity));
+            binding->m_hipPreparedCapacity = capacity;
+        }
+        const int32_t first = (int32_t)(variableOffset / sizeof(SailorLightShaderData));
+        const int32_t last = (int32_t)((variableOffset + size + sizeof(SailorLightShaderData) - 1) / sizeof(SailorLightShaderData)); // (a copy need not start on a record)
+        const int32_t count = (last < capacity ? last : capacity) - first;
+        SailorHipContext* ctx = m_ctx;
+        RHIBufferPtr records = binding->m_buffer, prepared = binding->m_hipPreparedLights;
+        if (prepared && count > 0)
+            cmd->m_hip.m_commands.push_back([ctx, records, prepared, first, count, capacity]() {
+                return sailor_hip_prepare_lights(ctx, (const SailorLightShaderData*)records->m_hip.m_devicePtr, first, count, capacity, prepared->m_hip.m_devicePtr,
+                                                 prepared->m_size);
+            });
+    }
 }
 
 void HipGraphicsDriver::UpdateBuffer(RHICommandListPtr cmd, RHIBufferPtr buffer, const void* data, size_t size, size_t offset)
@@ -376,10 +396,13 @@ int HipGraphicsDriver::RecordLightCulling(const TVector<RHIShaderBindingSetPtr>&
     if (!m_cullWorkspace || m_cullWorkspace->m_size < need) m_cullWorkspace = CreateBuffer(need);
     if (!m_cullWorkspace) return SAILOR_HIP_ERR_OUT_OF_MEMORY;
     m_cullW = pc.viewportSize[0]; m_cullH = pc.viewportSize[1]; m_cullLights = pc.lightsNum; m_cullOrderValid = true; // the shade of this frame may use the order hint
-    return sailor_hip_light_cull(m_ctx, &frame, &pc, (const SailorLightShaderData*)buffer_of(bindings[0], "light"),
-                                 (const float*)depthB->m_textures[0]->m_buffer->m_hip.m_devicePtr,
-                                 (SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (uint32_t*)buffer_of(bindings[1], "culledLights"),
-                                 culledB->m_buffer->m_size / 4, m_cullWorkspace->m_hip.m_devicePtr, m_cullWorkspace->m_size, &band, SAILOR_CULL_DEFAULT);
+    auto lightB = bindings[0]->Find("light");
+    const bool prepared = lightB && lightB->m_hipPreparedLights && lightB->m_hipPreparedCapacity >= pc.lightsNum;
+    return sailor_hip_light_cull_prepared(m_ctx, &frame, &pc, (const SailorLightShaderData*)buffer_of(bindings[0], "light"),
+                                          (const float*)depthB->m_textures[0]->m_buffer->m_hip.m_devicePtr,
+                                          (SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (uint32_t*)buffer_of(bindings[1], "culledLights"),
+                                          culledB->m_buffer->m_size / 4, m_cullWorkspace->m_hip.m_devicePtr, m_cullWorkspace->m_size, &band, SAILOR_CULL_DEFAULT,
+                                          prepared ? lightB->m_hipPreparedLights->m_hip.m_devicePtr : nullptr, prepared ? lightB->m_hipPreparedCapacity : 0);
 }
 
 int HipGraphicsDriver::SetFrameSplit(int rank, int worldSize, void* ncclComm)
@@ -451,11 +474,14 @@ int HipGraphicsDriver::RecordShade(const TVector<RHIShaderBindingSetPtr>& bindin
     const SailorBand* band = (m_worldSize > 1 && m_splitW == W && m_splitH == H) ? &m_band : nullptr; // the band of this frame's light cull
     const size_t planeStride = band ? (size_t)W * band->fbRowCount : (size_t)W * H;
     if (surfaceB->m_buffer->m_size < planeStride * 48) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-    return sailor_hip_shade_ex(m_ctx, &frame, (const float*)surfaceB->m_buffer->m_hip.m_devicePtr, planeStride,
-                               (const SailorLightShaderData*)buffer_of(bindings[1], "light"), lightsNum,
-                               (const SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (const uint32_t*)buffer_of(bindings[1], "culledLights"),
-                               hasCsm ? &csm : nullptr, hasIbl ? &ibl : nullptr, (float*)buffer_of(bindings[2], "radiance"), band,
-                               m_cullOrderValid ? sailor_hip_light_cull_tile_order(m_cullW, m_cullH, m_cullLights, band, m_cullWorkspace->m_hip.m_devicePtr) : nullptr);
+    auto lightB = bindings[1]->Find("light");
+    const bool prepared = lightB && lightB->m_hipPreparedLights && lightB->m_hipPreparedCapacity >= lightsNum;
+    return sailor_hip_shade_prepared(m_ctx, &frame, (const float*)surfaceB->m_buffer->m_hip.m_devicePtr, planeStride,
+                                     (const SailorLightShaderData*)buffer_of(bindings[1], "light"), lightsNum,
+                                     (const SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (const uint32_t*)buffer_of(bindings[1], "culledLights"),
+                                     hasCsm ? &csm : nullptr, hasIbl ? &ibl : nullptr, (float*)buffer_of(bindings[2], "radiance"), band,
+                                     m_cullOrderValid ? sailor_hip_light_cull_tile_order(m_cullW, m_cullH, m_cullLights, band, m_cullWorkspace->m_hip.m_devicePtr) : nullptr,
+                                     prepared ? lightB->m_hipPreparedLights->m_hip.m_devicePtr : nullptr, prepared ? lightB->m_hipPreparedCapacity : 0);
 }
 
 // ---- the render-pass subset: state is kept on the command list, a 6-index draw of a known full-screen material becomes a

@@ -106,6 +106,9 @@ public:
     RHIBufferPtr m_buffer;              // SSBO / UBO storage
     TVector<RHITexturePtr> m_textures;  // sampler (array)
     TVector<uint8_t> m_hostCopy;        // UBOs keep the last uploaded bytes: the HIP entry points take them by value
+    // HIP backend, the `light` SSBO only: the prepared views of its records (sailor_hip_prepare_lights), kept in step by UpdateShaderBinding
+    TRefPtr<class RHIBuffer> m_hipPreparedLights;
+    int32_t m_hipPreparedCapacity = 0;
     size_t GetBufferOffset() const { return 0; }
 };
 using RHIShaderBindingPtr = TRefPtr<RHIShaderBinding>;

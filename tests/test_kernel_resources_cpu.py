@@ -33,7 +33,7 @@ def kernel_resources(obj: Path, tmp: Path) -> dict:
 
 def find(res: dict, key: str) -> dict:
     """the kernel whose mangled name contains <len><key> (Itanium: the unqualified name prefixed by its length)"""
-    hits = [v for k, v in res.items() if f"{len(key)}{key}" in k]
+    hits = [v for k, v in res.items() if k.startswith(f"_Z{len(key)}{key}")]
     assert len(hits) == 1, (key, list(res))
     return hits[0]
 
@@ -56,22 +56,25 @@ def resources(tmp_path_factory):
     return res
 
 
-def test_k2_shade_fits_64_registers_without_scratch(resources):
-    k = find(resources["shade"], "k2_shade")
+@pytest.mark.parametrize("name", ["k2_shade", "k2_shade_p"])
+def test_k2_shade_fits_64_registers_without_scratch(resources, name):
+    k = find(resources["shade"], name)
     assert k["vgpr_count"] <= 64 and waves_per_simd(k["vgpr_count"]) == 8
     assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] == 0
     # eight 256-thread blocks per CU must fit the 160 KB of LDS
     assert 8 * k["group_segment_fixed_size"] <= 160 * 1024
 
 
-def test_k2_shade_csm_keeps_six_waves_per_simd(resources):
-    k = find(resources["shade"], "k2_shade_csm")
+@pytest.mark.parametrize("name", ["k2_shade_csm", "k2_shade_csm_p"])
+def test_k2_shade_csm_keeps_six_waves_per_simd(resources, name):
+    k = find(resources["shade"], name)
     assert k["vgpr_count"] <= 80 and waves_per_simd(k["vgpr_count"]) >= 6
     assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0
 
 
-def test_k2_shade_band_stays_at_eight_waves(resources):
-    k = find(resources["shade"], "k2_shade_band")
+@pytest.mark.parametrize("name", ["k2_shade_band", "k2_shade_band_p"])
+def test_k2_shade_band_stays_at_eight_waves(resources, name):
+    k = find(resources["shade"], name)
     assert k["vgpr_count"] <= 64
     assert k["private_segment_fixed_size"] <= 16   # (two copies of the body at 64 registers each: a handful of bytes is what it has always had)
 
