@@ -248,6 +248,31 @@ __device__ __forceinline__ float div_stored(float a, float b, float y, bool slow
     return __builtin_amdgcn_div_fixupf(fmaf(fmaf(-b, q0, a), y, q0), b, a);
 }
 
+#ifndef SHADE_NO_PK
+typedef float v2f_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f_ fma2(const v2f_ a, const v2f_ b, const v2f_ c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+// (A / B builds: the same expressions on two scalars, for timing the packed form against -- make EXTRA=-DSHADE_NO_PK)
+struct v2f_ { float x, y; };
+__device__ __forceinline__ v2f_ operator+(v2f_ a, v2f_ b) { return { a.x + b.x, a.y + b.y }; }
+__device__ __forceinline__ v2f_ operator-(v2f_ a, v2f_ b) { return { a.x - b.x, a.y - b.y }; }
+__device__ __forceinline__ v2f_ operator*(v2f_ a, v2f_ b) { return { a.x * b.x, a.y * b.y }; }
+__device__ __forceinline__ v2f_ operator*(v2f_ a, float b) { return { a.x * b, a.y * b }; }
+__device__ __forceinline__ v2f_ operator*(float b, v2f_ a) { return { b * a.x, b * a.y }; }
+__device__ __forceinline__ v2f_ operator+(float b, v2f_ a) { return { b + a.x, b + a.y }; }
+__device__ __forceinline__ v2f_ operator-(float b, v2f_ a) { return { b - a.x, b - a.y }; }
+__device__ __forceinline__ v2f_ operator-(v2f_ a) { return { -a.x, -a.y }; }
+__device__ __forceinline__ v2f_& operator*=(v2f_& a, float b) { a.x *= b; a.y *= b; return a; }
+__device__ __forceinline__ v2f_ fma2(const v2f_ a, const v2f_ b, const v2f_ c) { return { fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y) }; }
+#endif
+// dot3f on a float pair + a float: the same three products and two sums in the same association ((ax bx + ay by) + az bz), the two products of
+// the pair as ONE v_pk_mul_f32 (IEEE per component, like v_mul_f32): four instructions for five.
+__device__ __forceinline__ float dot3_pk(const v2f_ axy, const float az, const v2f_ bxy, const float bz)
+{
+    const v2f_ p = axy * bxy;
+    return (p.x + p.y) + az * bz;
+}
+
 #define LREC 5 // float4 per staged light
 
 // One light's record (SailorLightShaderData as seven float4) -> its staged form (the five float4 described at "Staged light record" below).
@@ -287,6 +312,7 @@ __device__ __forceinline__ void stage_light_record(const float4 q0, const float4
 #define PENDK 4  // queued pairs per pixel in one window (their queue positions ride in one register, 7 bits each under a sentinel bit)
 #define QMAX 128 // queued pairs per wave in one window (two lights that reach every pixel fit; positions are 7 bits; 17.4 KB of LDS per block, 9 blocks per CU)
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef v2f_ p2f;
 
 // max of a non-negative (or NaN) float's bits over the wave as unsigned integers; the value of lane 63 (which holds the result) is returned.
 // (xor-1, xor-2, mirror within 8, mirror within 16, then the gfx9 row broadcasts 15 -> row+1 and 31 -> rows 2,3; a DPP read of a VGPR
@@ -496,23 +522,29 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     }
 
     // ---- per-pixel invariants (Standard.shader:379-401) ----
+    // (x / y of every vector and two of the three colour channels as float pairs: see the pair pass)
     const float wx = P0.x, wy = P0.y, wz = P0.z;
     const v2f wxy = { wx, wy };
-    const float nx = P1.x, ny = P1.y, nz = P1.z, roughness = P1.w;
+    const p2f wxyp = { wx, wy };
+    const p2f nxy = { P1.x, P1.y };
+    const float nx = nxy.x, ny = nxy.y, nz = P1.z, roughness = P1.w;
     const float metallic = P2.w;
-    const float vx = wx - A.camX, vy = wy - A.camY, vz = wz - A.camZ;
-    const float vinv = rcp_of_sqrt(sqrt_exact(dot3f(vx, vy, vz, vx, vy, vz)));          // exact chain (see header)
-    const float Lox = -(vx * vinv), Loy = -(vy * vinv), Loz = -(vz * vinv);  // Lo = -viewDirection
-    const float cosLo = fmaxf(0.0f, dot3f(nx, ny, nz, Lox, Loy, Loz));
+    const p2f vxy = wxyp - p2f{ A.camX, A.camY };
+    const float vz = wz - A.camZ;
+    const float vinv = rcp_of_sqrt(sqrt_exact(dot3_pk(vxy, vz, vxy, vz)));          // exact chain (see header)
+    const p2f Loxy = -(vxy * vinv);                                                  // Lo = -viewDirection
+    const float Lox = Loxy.x, Loy = Loxy.y, Loz = -(vz * vinv);
+    const float cosLo = fmaxf(0.0f, dot3_pk(nxy, nz, Loxy, Loz));
     float accX = 0.0f, accY = 0.0f, accZ = 0.0f;
     const float oneMinusMetal = 1.0f - metallic;
     // F0 = mix(0.04, albedo, metallic) and, below, F = F0 + (1 - F0) x5 in the oracle's own operations, unfused: the diffuse term is (1 - F) kd albedo,
     // and on a bright metal (F0 -> 1) a half-ulp difference in F is 1e-4 of 1 - F (scripts/fuzz_parity.py found the pixel: roughness 0, so no
     // specular term to hide it behind)
-    const float F0x = 0.04f * oneMinusMetal + P2.x * metallic;
-    const float F0y = 0.04f * oneMinusMetal + P2.y * metallic;
-    const float F0z = 0.04f * oneMinusMetal + P2.z * metallic;
-    const float kdAx = oneMinusMetal * P2.x, kdAy = oneMinusMetal * P2.y, kdAz = oneMinusMetal * P2.z; // kd = (1 - F)(1 - metallic)
+    const float dielectric = 0.04f * oneMinusMetal;
+    const p2f F0xy = dielectric + p2f{ P2.x, P2.y } * metallic;
+    const float F0x = F0xy.x, F0y = F0xy.y, F0z = dielectric + P2.z * metallic;
+    const p2f kdAxy = oneMinusMetal * p2f{ P2.x, P2.y };                            // kd = (1 - F)(1 - metallic)
+    const float kdAx = kdAxy.x, kdAy = kdAxy.y, kdAz = oneMinusMetal * P2.z;
     {
         const unsigned long long bad = haveMask & ~stagedMask;
         if (lane == 0) sEnd[wave] = bad ? (uint32_t)(wave * 64 + __builtin_ctzll(bad)) : 0xFFFFFFFFu;
@@ -702,9 +734,13 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
             const uint32_t s = (e >> 6) & (uint32_t)(KEEP - 1);
             const float4* R = sL + s * LREC;
 #define PULL(x) __int_as_float(__builtin_amdgcn_ds_bpermute(pa, __float_as_int(x)))
+            // (float pairs where the arithmetic comes in pairs -- x / y of a vector, two of three colour channels: v_pk_{add,mul,fma}_f32 round each
+            // component like the scalar instruction, so the bits are those of the scalar form, at one issue slot per pair instead of two.  The pulled
+            // values and the LDS reads land in adjacent registers by construction, which is what the compiler's own SLP pairing could not arrange.)
             float falloff = 1.0f;
             const float4 r3 = R[3];
-            const float pwx = PULL(wx), pwy = PULL(wy), pwz = PULL(wz);
+            const p2f pwxy = { PULL(wx), PULL(wy) };
+            const float pwz = PULL(wz);
             if (valid) {
                 const float4 r0 = R[0], r1 = R[1];
                 const uint32_t type = __float_as_uint(r1.w) & 0xFFu;
@@ -713,8 +749,9 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                     const float4 r2 = R[2];
                     const float binv = reinterpret_cast<const float*>(R)[19]; // rec4.w = 1 / r2.w, or NaN
                     const bool slowDiv = __ballot(binv != binv) != 0ull;
-                    const float dx = r0.x - pwx, dy = r0.y - pwy, dz = r0.z - pwz;
-                    const float d2 = dot3f(dx, dy, dz, dx, dy, dz);
+                    const p2f dxy = p2f{ r0.x, r0.y } - pwxy;
+                    const float dz = r0.z - pwz;
+                    const float d2 = dot3_pk(dxy, dz, dxy, dz);
                     const float dist = sqrt_exact(d2);                                       // exact: feeds 1 - (dist / bounds.x)^2
                     const float att = rcp_fast(fmaf(r2.z, d2, fmaf(r2.y, dist, r2.x))); // 1/(a.x + a.y d + a.z d^2) (:289,:300)
                     const bool isPoint = type == 1u;
@@ -725,7 +762,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                         const float q = fminf(fmaxf(x, 0.0f), 1.0f);
                         falloff = att * (1.0f - q * q);                                  // (:290)
                     } else {
-                        const float theta = dot3f(dx * x, dy * x, dz * x, r1.x, r1.y, r1.z); // dot(normalize(pos - wp), normalize(-dir))
+                        const float theta = dot3_pk(dxy * x, dz * x, p2f{ r1.x, r1.y }, r1.z); // dot(normalize(pos - wp), normalize(-dir))
                         const float cutY = r3.w;
                         falloff = att * fminf(fmaxf(div_stored(theta - cutY, r2.w, binv, slowDiv), 0.0f), 1.0f); // (:301); exact: cancels at the cone edge
                         if (theta < cutY) falloff = 0.0f;                                     // (:303-306)
@@ -735,20 +772,24 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
             // (the pulls are spread out so that at most ten pulled values are live at a time: 64 VGPRs = 8 waves per SIMD)
             float spec = 0.0f, x5 = 0.0f, scale = 0.0f;
             {
-                const float pnx = PULL(nx), pny = PULL(ny), pnz = PULL(nz);
-                const float pLox = PULL(Lox), pLoy = PULL(Loy), pLoz = PULL(Loz);
+                const p2f pnxy = { PULL(nx), PULL(ny) };
+                const float pnz = PULL(nz);
+                const p2f pLoxy = { PULL(Lox), PULL(Loy) };
+                const float pLoz = PULL(Loz);
                 const float pcosLo = PULL(cosLo), pg1Lo = PULL(g1Lo), palphaSq = PULL(alphaSq);
                 const float pkr = HAS_IBL ? PULL(roughness) : PULL(k); // the ambient term at the end needs the roughness itself: pull it, derive k
                 const float pk = HAS_IBL ? ((pkr + 1.0f) * (pkr + 1.0f)) * 0.125f : pkr;
                 if (valid) {
                     // ---- Cook-Torrance (Standard.shader:309-340) ----
-                    const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
-                    float hx = Lix + pLox, hy = Liy + pLoy, hz = Liz + pLoz;
-                    const float hinv = rcp_of_sqrt(sqrt_exact(dot3f(hx, hy, hz, hx, hy, hz)));          // exact chain: Lh = normalize(Li + Lo)
-                    hx *= hinv; hy *= hinv; hz *= hinv;
-                    const float cosLi = fmaxf(0.0f, dot3f(pnx, pny, pnz, Lix, Liy, Liz));
-                    const float cosLh = fmaxf(0.0f, dot3f(pnx, pny, pnz, hx, hy, hz));
-                    const float x1 = 1.0f - fmaxf(0.0f, dot3f(hx, hy, hz, pLox, pLoy, pLoz));
+                    const p2f Lixy = { r3.x, r3.y };
+                    const float Liz = r3.z;
+                    p2f hxy = Lixy + pLoxy;
+                    float hz = Liz + pLoz;
+                    const float hinv = rcp_of_sqrt(sqrt_exact(dot3_pk(hxy, hz, hxy, hz)));          // exact chain: Lh = normalize(Li + Lo)
+                    hxy *= hinv; hz *= hinv;
+                    const float cosLi = fmaxf(0.0f, dot3_pk(pnxy, pnz, Lixy, Liz));
+                    const float cosLh = fmaxf(0.0f, dot3_pk(pnxy, pnz, hxy, hz));
+                    const float x1 = 1.0f - fmaxf(0.0f, dot3_pk(hxy, hz, pLoxy, pLoz));
                     const float x2 = x1 * x1;
                     x5 = x2 * x2 * x1;                                                        // pow(1 - cosTheta, 5)
                     const float dn = (cosLh * cosLh) * (palphaSq - 1.0f) + 1.0f;                // exact: the cancelling denominator
@@ -760,15 +801,19 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
             }
             __builtin_amdgcn_sched_barrier(0);
             {
-                const float pF0x = PULL(F0x), pF0y = PULL(F0y), pF0z = PULL(F0z);
-                const float pkdAx = PULL(kdAx), pkdAy = PULL(kdAy), pkdAz = PULL(kdAz);
+                const p2f pF0xy = { PULL(F0x), PULL(F0y) };
+                const float pF0z = PULL(F0z);
+                const p2f pkdAxy = { PULL(kdAx), PULL(kdAy) };
+                const float pkdAz = PULL(kdAz);
                 if (valid) {
-                    const float Fx = pF0x + (1.0f - pF0x) * x5, Fy = pF0y + (1.0f - pF0y) * x5, Fz = pF0z + (1.0f - pF0z) * x5;
+                    const p2f Fxy = pF0xy + (1.0f - pF0xy) * x5;
+                    const float Fz = pF0z + (1.0f - pF0z) * x5;
                     const float4 r4 = R[4];
                     // shadow * ((kd*albedo + F*D*G/denom) * Lradiance * cosLi) * falloff ; kd = mix(1 - F, 0, metallic)
                     float* o = res + (base + (uint32_t)lane);
-                    o[0] = (fmaf(1.0f - Fx, pkdAx, Fx * spec) * r4.x) * scale;
-                    o[QMAX] = (fmaf(1.0f - Fy, pkdAy, Fy * spec) * r4.y) * scale;
+                    const p2f oxy = (fma2(1.0f - Fxy, pkdAxy, Fxy * spec) * p2f{ r4.x, r4.y }) * scale;
+                    o[0] = oxy.x;
+                    o[QMAX] = oxy.y;
                     o[2 * QMAX] = (fmaf(1.0f - Fz, pkdAz, Fz * spec) * r4.z) * scale;
                 }
             }
