@@ -64,6 +64,9 @@ def linearize_depth(ctx: "HipContext", frame: UboFrameData, raw: torch.Tensor, o
     return out
 
 
+_ENV_CULL_FLAGS = int(os.environ.get("SAILOR_CULL_FLAGS", "0"))
+
+
 class PreparedLights:
     """sailor_hip_prepare_lights' output for a `light` SSBO of `capacity` records: the cull's 20-byte view and the shade's staged records, derived where
     the records are uploaded (the HIP backend does it behind UpdateShaderBinding) instead of in every frame's kernels.  prepare(first, count) after
@@ -127,6 +130,7 @@ class ForwardPlus:
         assert depth.dtype == torch.float32 and depth.is_contiguous() and depth.shape == (self.band.fbRowCount, self.W), depth.shape
         assert lights_num <= self.max_lights
         prepared = prepared if prepared is not None else self.prepared
+        flags |= _ENV_CULL_FLAGS   # (diagnostics: SAILOR_CULL_FLAGS=8 times the split-lists shape against the default on the same box)
         pc = host.push_constants(frame, self.W, self.H, lights_num)
         ctx = ctx or self.ctx
         lib = ctx._lib
