@@ -559,7 +559,7 @@ def pipeline_unroll(steps: int):
     return u, steps - (steps // u) * u if u else steps
 
 
-def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev):
+def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev, prep=None):
     """Single-GPU estimate of the G-way split: per-band step time (hipGraph replay), equal vs cost-balanced bands."""
     from sailor_amd import dist as sdist
     cam, W, H, N, G = frame.cam, frame.cam.width, frame.cam.height, len(frame.lights), args.simulate_split
@@ -710,7 +710,7 @@ def main():
         csm, keep = upload_shadow_maps(shadows, dev)
 
     if args.simulate_split:
-        simulate_split(args, ctx, frame, d_lights, fp, d_depth, dev)
+        simulate_split(args, ctx, frame, d_lights, fp, d_depth, dev, prep)
         return
 
     def cull():

@@ -40,12 +40,21 @@
     }
 #define FORCE_64_VGPRS __attribute__((amdgpu_waves_per_eu(8, 8)))
 SHADE_ENTRY(k2_shade, FORCE_64_VGPRS, false, false, false)
-SHADE_ENTRY(k2_shade_csm, , true, false, false)
+// (k2_shade_csm settles at 80 VGPRs = six waves per SIMD by itself; its prepared twin came out at 131 unpinned, at 80 without scratch pinned)
+#ifndef CSM_WAVES
+#define CSM_WAVES 6
+#endif
+#ifdef CSM_NO_PIN
+#define SIX_WAVES
+#else
+#define SIX_WAVES __attribute__((amdgpu_waves_per_eu(CSM_WAVES, CSM_WAVES)))
+#endif
+SHADE_ENTRY(k2_shade_csm, SIX_WAVES, true, false, false)
 SHADE_ENTRY(k2_shade_ibl, , false, true, false)
 SHADE_ENTRY(k2_shade_csm_ibl, , true, true, false)
 // the same kernels reading the records sailor_hip_prepare_lights staged (`lights` = the staged array)
 SHADE_ENTRY(k2_shade_p, FORCE_64_VGPRS, false, false, true)
-SHADE_ENTRY(k2_shade_csm_p, __attribute__((amdgpu_waves_per_eu(6, 6))), true, false, true)
+SHADE_ENTRY(k2_shade_csm_p, SIX_WAVES, true, false, true)
 SHADE_ENTRY(k2_shade_ibl_p, , false, true, true)
 SHADE_ENTRY(k2_shade_csm_ibl_p, , true, true, true)
 
