@@ -645,6 +645,20 @@ struct TileCtx {
 };
 
 // Math.glsl:224-239 SphereFrustumOverlaps + ComputeLightCulling.shader:187 impact
+// tile_test for 64 candidates at once, as the wave mask of the lanes that PASS.  Every comparison is evaluated and the six results are combined
+// as scalar masks -- no early outs, no per-lane booleans (a bool lives in a VGPR as 0 / 1 and costs a v_cndmask + v_cmp per use).  With the early
+// outs the test was eight exec-mask save / restore pairs and branches per 64 candidates: ~90 instructions a step, a third of them scalar
+// bookkeeping, in a kernel that SQ counters show to be bound by instruction issue (264 vector + 292 scalar + 57 branch instructions per wave in
+// round 2), not by its round trips.  Same comparisons on the same operands, NaN behaviour included: a comparison that is false next to a NaN
+// rejects nothing, as before.
+__device__ __forceinline__ unsigned long long tile_test_mask(const TileCtx& t, const float4 lv)
+{
+    const float r = lv.w;
+    unsigned long long rej = __ballot(lv.z - r > t.zNear) | __ballot(lv.z + r < t.zFar);
+#pragma unroll
+    for (int k = 0; k < 4; k++) rej |= __ballot(dot3f(t.n[k][0], t.n[k][1], t.n[k][2], lv.x, lv.y, lv.z) < -r);
+    return ~rej;
+}
 __device__ __forceinline__ bool tile_test(const TileCtx& t, const float4 lv)
 {
     const float r = lv.w;
@@ -669,6 +683,15 @@ __device__ __forceinline__ void wave_append(bool pass, uint32_t j, uint32_t& cou
     const uint64_t mask = __ballot(pass);
     const uint32_t pos = count + (uint32_t)__popcll(mask & lanemask_lt());
     if (pass && pos < CAND) sIdx[pos] = j;
+    count += (uint32_t)__popcll(mask);
+}
+
+// the same append from a wave mask (the lanes of `mask` hold a passing candidate j)
+__device__ __forceinline__ void wave_append_mask(const unsigned long long mask, uint32_t j, uint32_t& count, uint32_t* sIdx)
+{
+    const uint32_t pos = count + (uint32_t)__popcll(mask & lanemask_lt());
+    const unsigned long long fits = mask & __ballot(pos < CAND);
+    if (__builtin_amdgcn_inverse_ballot_w64(fits)) sIdx[pos] = j;
     count += (uint32_t)__popcll(mask);
 }
 
@@ -791,14 +814,11 @@ __device__ __forceinline__ void test_staged(const TileCtx& t, const uint32_t cn,
     const uint32_t lane = threadIdx.x & 63;
     for (uint32_t base = 0; base < cn && count < CAND; base += 64u) {
         const uint32_t i = base + lane;
-        bool pass = false;
-        uint32_t ee = 0u;
-        if (i < cn) {
-            ee = sE[i];
-            if (ee & 0x80000000u) pass = true; // directional: always a candidate, impact 0 (:153-162)
-            else pass = tile_test(t, sLV[i]);
-        }
-        wave_append(pass, ee, count, sIdx);
+        // (unconditional reads -- the staging arrays are CHUNK entries whatever the count -- and one combined mask: see tile_test)
+        const uint32_t ee = sE[i & (CHUNK - 1)];
+        const float4 lv = sLV[i & (CHUNK - 1)];
+        const unsigned long long mask = __ballot(i < cn) & (__ballot((int)ee < 0) | tile_test_mask(t, lv)); // directional (bit 31): always a candidate, impact 0 (:153-162)
+        wave_append_mask(mask, ee, count, sIdx);
     }
 }
 
@@ -836,9 +856,11 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     // slot == block index == tile-index order: (tile row, group column).  (Measured: handing every XCD -- block i runs on XCD i % 8 -- a contiguous
     // eighth of the slots, so that a group's four row blocks share one L2 and an XCD's gathers stay inside the lights of its band: 44 us instead of
     // 32 -- the cluster groups all land on one XCD.)
-    const int b = (int)blockIdx.x;
+    // (a 2-D grid, (group column, tile row of the band): the index arithmetic has no division -- by a run-time divisor that is ~35 scalar
+    // instructions, 5 % of what a wave of this kernel issues)
+    const int gx = (int)blockIdx.x, tyLocal = (int)blockIdx.y;
+    const int b = tyLocal * groupsX + gx;
     PROF_T(0);
-    const int gx = b % groupsX, tyLocal = b / groupsX;
     const int g = (tyLocal / GROUP) * groupsX + gx;
     // (the wave index as a scalar: the tile's frustum -- the same 64 bytes for all lanes -- then arrives by scalar loads instead of four vector
     // loads that occupy the CU's vector-memory pipeline for 64 lanes' worth of address processing each)
@@ -1223,7 +1245,7 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     // The hint pays for itself on split frames (a band's shade launch is bounded by its longest tile); on the whole frame it measured nothing.
     ca.classes = layout_has_hint(L) ? 1 : 0;
     if (brute) {
-        hipLaunchKernelGGL(k1_tile_cull<true>, dim3(L.cullBlocks), dim3(256), 0, s, ca);
+        hipLaunchKernelGGL(k1_tile_cull<true>, dim3(L.groupsX, L.bandRows), dim3(256), 0, s, ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull<brute>");
     } else {
         if (L.words >= 4096 && (L.words & 1) == 0)
@@ -1240,7 +1262,7 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
             hipLaunchKernelGGL(k1_group_lists, dim3(L.numGroups), dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
                                (uint32_t*)(ws + L.offGroupList));
         SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
-        hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.cullBlocks), dim3(256), 0, s, ca);
+        hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.groupsX, L.bandRows), dim3(256), 0, s, ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
     }
     PackArgs ka;
