@@ -451,9 +451,10 @@ __global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* 
                                                        int words, int groupsX, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList)
 {
     __shared__ uint32_t sW[4];
-    const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long* __restrict__ c = masks + (size_t)(g % groupsX) * words;
-    const unsigned long long* __restrict__ r = masks + (size_t)(groupsX + g / groupsX) * words;
+    // (2-D grid: group column, group row -- no division by the run-time groupsX)
+    const int g = (int)blockIdx.y * groupsX + (int)blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long* __restrict__ c = masks + (size_t)blockIdx.x * words;
+    const unsigned long long* __restrict__ r = masks + (size_t)(groupsX + (int)blockIdx.y) * words;
     uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
     uint32_t base = 0; // entries written by earlier chunks (block-uniform)
     // GL_WPT consecutive words per thread and round: one block-wide scan (and its two barriers) per 256 * GL_WPT words -- at 1 M lights a group walks
@@ -846,6 +847,9 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     // once -- one staging per group instead of four, but four tiles in sequence per wave: 38.8 us against 32.4.)
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K1_TILE_CULL];
     __shared__ uint32_t sNum[4];
+#ifdef CULL_ROW_FILTER
+    __shared__ uint32_t sKeep[CHUNK / 256][4];
+#endif
     float4* sLV = reinterpret_cast<float4*>(lds);                                                         // [CHUNK] candidate (view pos, radius)
     uint32_t* sE = reinterpret_cast<uint32_t*>(lds + CHUNK * 16);                                         // [CHUNK] candidate light index | directional << 31
     uint32_t (*sIdxAll)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds + CHUNK * 20);                   // [4][CAND]
@@ -913,10 +917,48 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
             float4 lv[CHUNK / 256];
 #pragma unroll
             for (int k = 0; k < CHUNK / 256; k++) lv[k] = lightView[min(e[k] & 0x7FFFFFFFu, (uint32_t)(N - 1))];
+#ifdef CULL_ROW_FILTER
+            // ROW FILTER (make EXTRA=-DCULL_ROW_FILTER; bit-exact, measured: no gain at 4K -- 49.2 us for the chain with and without it: once the
+            // tile test was down to 52 instructions a step the kernel is bound by its blocks' two dependent round trips again -- so it is not built).
+            // The group's list says "may reach this 64 x 64-pixel group"; the block's four tiles are one 16-pixel row of it, so about half of the
+            // candidates lie entirely above or below the row.  The four tiles' top and bottom planes are the SAME two planes (through the eye and
+            // the screen lines y = 16 ty, 16 (ty + 1); each tile computes them from its own corners, so the normals differ in the last bits only):
+            // a candidate beyond one of them by more than the margin the band masks use (1000 x the fp32 error) is rejected by every tile's own
+            // test, and dropping it here -- while the records are still in registers -- changes no tile's candidate sequence.
+            {
+                const float4* ti = a.tileInfo + (size_t)(tyLocal * Tx + gx * GROUP) * 4; // the row's first tile: always inside the frame
+                const float4 p2 = ti[2], p3 = ti[3];                                       // (block-uniform: scalar loads)
+                unsigned long long km[CHUNK / 256];
+#pragma unroll
+                for (int k = 0; k < CHUNK / 256; k++) {
+                    const uint32_t i = threadIdx.x + 256u * k;
+                    const float4 v = lv[k];
+                    const float thr = -(v.w + 1e-3f * ((fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w))));
+                    const unsigned long long out = __ballot(dot3f(p2.x, p2.y, p2.z, v.x, v.y, v.z) < thr) | __ballot(dot3f(p3.x, p3.y, p3.z, v.x, v.y, v.z) < thr);
+                    km[k] = __ballot(i < cn) & (__ballot((int)e[k] < 0) | ~out); // (a directional candidate -- bit 31 -- always stays)
+                    if (lane == 0) sKeep[k][wave] = (uint32_t)__popcll(km[k]);
+                }
+                __syncthreads();
+                uint32_t base = 0u;
+#pragma unroll
+                for (int k = 0; k < CHUNK / 256; k++) {
+                    uint32_t before = base;
+#pragma unroll
+                    for (int w = 0; w < 4; w++) { const uint32_t c = sKeep[k][w]; before += (w < wave) ? c : 0u; base += c; }
+                    if (__builtin_amdgcn_inverse_ballot_w64(km[k])) {
+                        const uint32_t pos = before + (uint32_t)__popcll(km[k] & lanemask_lt());
+                        sE[pos] = e[k]; sLV[pos] = lv[k];
+                    }
+                }
+                __syncthreads();
+                if (active) test_staged(t, base, sE, sLV, count, sIdx);
+            }
+#else
 #pragma unroll
             for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; if (i < cn) { sE[i] = e[k]; sLV[i] = lv[k]; } }
             __syncthreads();
             if (active) test_staged(t, cn, sE, sLV, count, sIdx);
+#endif
         }
     } else if (active) {
         // overflowed group (very dense region / lights around the eye): every tile walks its own two masks
@@ -1259,7 +1301,7 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
                                    (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag));
         }
         else
-            hipLaunchKernelGGL(k1_group_lists, dim3(L.numGroups), dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
+            hipLaunchKernelGGL(k1_group_lists, dim3(L.groupsX, L.groupsY), dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
                                (uint32_t*)(ws + L.offGroupList));
         SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
         hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.groupsX, L.bandRows), dim3(256), 0, s, ca);
