@@ -539,6 +539,21 @@ SAILOR_HIP_API int sailor_hip_stitch_light_lists(SailorHipContext* ctx, int32_t 
                                                  const uint32_t* dSegments, size_t segmentCapacity, const uint32_t* dGrids, size_t gridCapacity,
                                                  SailorLightsGrid* dGlobalGrid, uint32_t* dGlobalCulled, size_t globalCapacity);
 
+/* The same two with the split given explicitly: tileRowBounds[worldSize + 1], rank r's band = tile rows [bounds[r], bounds[r + 1]) (bounds[0] = 0,
+ * bounds[worldSize] = tile rows of the frame, non-decreasing) -- equal bands, cost-balanced bands (sailor_hip_band_from_tile_rows), anything in
+ * between -- and with the capacity of dGlobalGrid in tiles (the stitch writes one entry per tile of the frame: fewer is an error, not an overrun).
+ * The entry points above are these with the bounds of sailor_hip_band_for_rank and a grid of exactly the frame's tiles.  culledLights[0] is clamped
+ * to what was written (globalCapacity - 1) when the segments did not fit. */
+SAILOR_HIP_API size_t sailor_hip_exchange_workspace_size_rows(int32_t width, int32_t height, int32_t worldSize, const int32_t* tileRowBounds);
+SAILOR_HIP_API int sailor_hip_exchange_light_lists_rows(SailorHipContext* ctx, void* comm, int32_t rank, int32_t worldSize, int32_t width, int32_t height,
+                                                        const int32_t* tileRowBounds, const SailorLightsGrid* dBandGrid, const uint32_t* dBandCulled,
+                                                        SailorLightsGrid* dGlobalGrid, size_t globalGridTiles, uint32_t* dGlobalCulled, size_t globalCapacity,
+                                                        void* dWorkspace, size_t workspaceBytes);
+SAILOR_HIP_API int sailor_hip_stitch_light_lists_rows(SailorHipContext* ctx, int32_t width, int32_t height, int32_t worldSize, const int32_t* tileRowBounds,
+                                                      const uint32_t* dTotals, const uint32_t* dSegments, size_t segmentCapacity, const uint32_t* dGrids,
+                                                      size_t gridCapacity, SailorLightsGrid* dGlobalGrid, size_t globalGridTiles, uint32_t* dGlobalCulled,
+                                                      size_t globalCapacity);
+
 /* ---- host-side math of the path (pure CPU, no device needed) ----------------------------------------------- */
 /* Math/Math.cpp:18-21 PerspectiveRH (reversed Z) */
 SAILOR_HIP_API int sailor_host_perspective_rh(float fovRadians, float aspect, float zNear, float zFar, float* outMat4);

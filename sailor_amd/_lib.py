@@ -151,6 +151,9 @@ SIGNATURES = {
     "sailor_hip_exchange_workspace_size": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sailor_hip_exchange_light_lists": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t]),
     "sailor_hip_stitch_light_lists": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_size_t, _P, C.c_size_t, _P, _P, C.c_size_t]),
+    "sailor_hip_exchange_workspace_size_rows": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, _P]),
+    "sailor_hip_exchange_light_lists_rows": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t]),
+    "sailor_hip_stitch_light_lists_rows": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t]),
     "sailor_host_perspective_rh": (C.c_int, [C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]),
     "sailor_host_mat4_inverse": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sailor_host_mat4_mul": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),

@@ -18,6 +18,25 @@ static nccl_allgather_fn resolve_allgather()
     return fn;
 }
 
+// the bands of an equal split as tile-row bounds (world + 1 entries)
+static void equal_row_bounds(int32_t width, int32_t height, int32_t worldSize, int32_t* bounds)
+{
+    for (int r = 0; r < worldSize; r++) {
+        SailorBand b;
+        sailor_hip_band_for_rank(width, height, r, worldSize, &b);
+        bounds[r] = b.tileRowBegin;
+        bounds[r + 1] = b.tileRowEnd;
+    }
+}
+
+static bool row_bounds_valid(const int32_t* bounds, int32_t worldSize, int32_t Ty)
+{
+    if (!bounds || bounds[0] != 0 || bounds[worldSize] != Ty) return false;
+    for (int r = 0; r < worldSize; r++)
+        if (bounds[r] > bounds[r + 1]) return false;
+    return true;
+}
+
 extern "C" int sailor_hip_allgather_u32(SailorHipContext* ctx, void* comm, const uint32_t* dSend, uint32_t* dRecv, size_t countPerRank)
 {
     if (!ctx || !comm || !dSend || !dRecv) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
@@ -58,7 +77,13 @@ __global__ __launch_bounds__(256) void k_stitch_lists(const StitchArgs a)
         a.outGrid[2u * (t0 + i)] = off + base; // Appendix A step 6: canonical global offsets
         a.outGrid[2u * (t0 + i) + 1u] = num;
     }
-    if (r == 0 && first == 0) a.outCulled[0] = all;
+    if (r == 0 && first == 0) a.outCulled[0] = all < a.outCapacity - 1u ? all : a.outCapacity - 1u; // what was written: segments are clipped to the capacity
+}
+
+static size_t exchange_workspace_bytes(int32_t worldSize, size_t maxTiles)
+{
+    return align_up((size_t)worldSize * 4, 256) + align_up((size_t)worldSize * maxTiles * KEEP * 4, 256) + align_up((size_t)worldSize * maxTiles * 8, 256) +
+           align_up(maxTiles * KEEP * 4, 256) + align_up(maxTiles * 8, 256);
 }
 
 extern "C" size_t sailor_hip_exchange_workspace_size(int32_t width, int32_t height, int32_t worldSize)
@@ -67,18 +92,46 @@ extern "C" size_t sailor_hip_exchange_workspace_size(int32_t width, int32_t heig
     int32_t Tx = 0, Ty = 0;
     sailor_hip_num_tiles(width, height, &Tx, &Ty);
     const size_t maxRows = ((size_t)Ty + worldSize - 1) / worldSize; // band_for_rank: floor((g+1) Ty / G) - floor(g Ty / G) <= ceil(Ty / G)
-    const size_t maxTiles = maxRows * Tx;
-    return align_up((size_t)worldSize * 4, 256) + align_up((size_t)worldSize * maxTiles * KEEP * 4, 256) + align_up((size_t)worldSize * maxTiles * 8, 256) +
-           align_up(maxTiles * KEEP * 4, 256) + align_up(maxTiles * 8, 256);
+    return exchange_workspace_bytes(worldSize, maxRows * Tx);
+}
+
+extern "C" size_t sailor_hip_exchange_workspace_size_rows(int32_t width, int32_t height, int32_t worldSize, const int32_t* tileRowBounds)
+{
+    if (width <= 0 || height <= 0 || worldSize < 1 || worldSize > SAILOR_MAX_SPLIT) return 0;
+    int32_t Tx = 0, Ty = 0;
+    sailor_hip_num_tiles(width, height, &Tx, &Ty);
+    if (!row_bounds_valid(tileRowBounds, worldSize, Ty)) return 0;
+    size_t maxRows = 1;
+    for (int r = 0; r < worldSize; r++) maxRows = (size_t)(tileRowBounds[r + 1] - tileRowBounds[r]) > maxRows ? (size_t)(tileRowBounds[r + 1] - tileRowBounds[r]) : maxRows;
+    return exchange_workspace_bytes(worldSize, maxRows * Tx);
 }
 
 extern "C" int sailor_hip_stitch_light_lists(SailorHipContext* ctx, int32_t width, int32_t height, int32_t worldSize, const uint32_t* dTotals,
                                              const uint32_t* dSegments, size_t segmentCapacity, const uint32_t* dGrids, size_t gridCapacity,
                                              SailorLightsGrid* dGlobalGrid, uint32_t* dGlobalCulled, size_t globalCapacity)
 {
+    if (width <= 0 || height <= 0 || worldSize < 1 || worldSize > SAILOR_MAX_SPLIT) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    int32_t bounds[SAILOR_MAX_SPLIT + 1], Tx = 0, Ty = 0;
+    equal_row_bounds(width, height, worldSize, bounds);
+    sailor_hip_num_tiles(width, height, &Tx, &Ty);
+    return sailor_hip_stitch_light_lists_rows(ctx, width, height, worldSize, bounds, dTotals, dSegments, segmentCapacity, dGrids, gridCapacity, dGlobalGrid,
+                                              (size_t)Tx * Ty, dGlobalCulled, globalCapacity);
+}
+
+extern "C" int sailor_hip_stitch_light_lists_rows(SailorHipContext* ctx, int32_t width, int32_t height, int32_t worldSize, const int32_t* tileRowBounds,
+                                                  const uint32_t* dTotals, const uint32_t* dSegments, size_t segmentCapacity, const uint32_t* dGrids,
+                                                  size_t gridCapacity, SailorLightsGrid* dGlobalGrid, size_t globalGridTiles, uint32_t* dGlobalCulled,
+                                                  size_t globalCapacity)
+{
     if (!ctx || !dTotals || !dSegments || !dGrids || !dGlobalGrid || !dGlobalCulled || width <= 0 || height <= 0 || worldSize < 1 || worldSize > SAILOR_MAX_SPLIT)
         return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (globalCapacity < 1 || segmentCapacity > 0xFFFFFFFFull || gridCapacity > 0xFFFFFFFFull) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    {
+        int32_t Tx = 0, Ty = 0;
+        sailor_hip_num_tiles(width, height, &Tx, &Ty);
+        if (!row_bounds_valid(tileRowBounds, worldSize, Ty)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+        if (globalGridTiles < (size_t)Tx * Ty) return SAILOR_HIP_ERR_INVALID_ARGUMENT; // the stitch writes one entry per tile of the frame
+    }
     StitchArgs a;
     a.totals = dTotals; a.segments = dSegments; a.grids = dGrids; a.outGrid = (uint32_t*)dGlobalGrid; a.outCulled = dGlobalCulled;
     a.world = (uint32_t)worldSize; a.segCap = (uint32_t)segmentCapacity; a.gridCap = (uint32_t)gridCapacity;
@@ -86,11 +139,9 @@ extern "C" int sailor_hip_stitch_light_lists(SailorHipContext* ctx, int32_t widt
     a.tiles[0] = 0;
     uint32_t maxTiles = 1;
     for (int r = 0; r < worldSize; r++) {
-        SailorBand b;
-        sailor_hip_band_for_rank(width, height, r, worldSize, &b);
         int32_t Tx = 0, Ty = 0;
         sailor_hip_num_tiles(width, height, &Tx, &Ty);
-        const uint32_t nt = (uint32_t)((b.tileRowEnd - b.tileRowBegin) * Tx);
+        const uint32_t nt = (uint32_t)((tileRowBounds[r + 1] - tileRowBounds[r]) * Tx);
         if ((size_t)nt * 2 > gridCapacity) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
         a.tiles[r + 1] = a.tiles[r] + nt;
         if (nt > maxTiles) maxTiles = nt;
@@ -114,13 +165,29 @@ extern "C" int sailor_hip_exchange_light_lists(SailorHipContext* ctx, void* comm
                                                const SailorLightsGrid* dBandGrid, const uint32_t* dBandCulled, SailorLightsGrid* dGlobalGrid,
                                                uint32_t* dGlobalCulled, size_t globalCapacity, void* dWorkspace, size_t workspaceBytes)
 {
+    if (width <= 0 || height <= 0 || worldSize < 1 || worldSize > SAILOR_MAX_SPLIT) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    int32_t bounds[SAILOR_MAX_SPLIT + 1], Tx = 0, Ty = 0;
+    equal_row_bounds(width, height, worldSize, bounds);
+    sailor_hip_num_tiles(width, height, &Tx, &Ty);
+    return sailor_hip_exchange_light_lists_rows(ctx, comm, rank, worldSize, width, height, bounds, dBandGrid, dBandCulled, dGlobalGrid, (size_t)Tx * Ty, dGlobalCulled,
+                                                globalCapacity, dWorkspace, workspaceBytes);
+}
+
+extern "C" int sailor_hip_exchange_light_lists_rows(SailorHipContext* ctx, void* comm, int32_t rank, int32_t worldSize, int32_t width, int32_t height,
+                                                    const int32_t* tileRowBounds, const SailorLightsGrid* dBandGrid, const uint32_t* dBandCulled,
+                                                    SailorLightsGrid* dGlobalGrid, size_t globalGridTiles, uint32_t* dGlobalCulled, size_t globalCapacity,
+                                                    void* dWorkspace, size_t workspaceBytes)
+{
     if (!ctx || !comm || !dBandGrid || !dBandCulled || !dGlobalGrid || !dGlobalCulled || !dWorkspace || rank < 0 || rank >= worldSize) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
-    const size_t need = sailor_hip_exchange_workspace_size(width, height, worldSize);
+    const size_t need = sailor_hip_exchange_workspace_size_rows(width, height, worldSize, tileRowBounds);
     if (need == 0 || ((uintptr_t)dWorkspace & 255)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (workspaceBytes < need) return SAILOR_HIP_ERR_WORKSPACE_TOO_SMALL;
     int32_t Tx = 0, Ty = 0;
     sailor_hip_num_tiles(width, height, &Tx, &Ty);
-    const size_t maxTiles = (((size_t)Ty + worldSize - 1) / worldSize) * Tx;
+    if (globalGridTiles < (size_t)Tx * Ty) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    size_t maxRows = 1;
+    for (int r = 0; r < worldSize; r++) maxRows = (size_t)(tileRowBounds[r + 1] - tileRowBounds[r]) > maxRows ? (size_t)(tileRowBounds[r + 1] - tileRowBounds[r]) : maxRows;
+    const size_t maxTiles = maxRows * Tx;
     const size_t segCap = maxTiles * KEEP, gridCap = maxTiles * 2;
     char* ws = (char*)dWorkspace;
     uint32_t* totals = (uint32_t*)ws; ws += align_up((size_t)worldSize * 4, 256);
@@ -128,9 +195,7 @@ extern "C" int sailor_hip_exchange_light_lists(SailorHipContext* ctx, void* comm
     uint32_t* grids = (uint32_t*)ws; ws += align_up((size_t)worldSize * gridCap * 4, 256);
     uint32_t* sendSeg = (uint32_t*)ws; ws += align_up(segCap * 4, 256);
     uint32_t* sendGrid = (uint32_t*)ws;
-    SailorBand band;
-    sailor_hip_band_for_rank(width, height, rank, worldSize, &band);
-    const uint32_t myTiles = (uint32_t)((band.tileRowEnd - band.tileRowBegin) * Tx);
+    const uint32_t myTiles = (uint32_t)((tileRowBounds[rank + 1] - tileRowBounds[rank]) * Tx);
     SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
     // fixed-size send slots (what lies behind the valid part is never read by the stitch)
     hipLaunchKernelGGL(k_pad_copy, dim3(256), dim3(256), 0, ctx->stream, dBandCulled + 1, sendSeg, dBandCulled, 0u, (uint32_t)segCap);
@@ -140,5 +205,6 @@ extern "C" int sailor_hip_exchange_light_lists(SailorHipContext* ctx, void* comm
     if (rc == SAILOR_HIP_OK) rc = sailor_hip_allgather_u32(ctx, comm, sendSeg, segments, segCap);   // collective 2: index segments
     if (rc == SAILOR_HIP_OK) rc = sailor_hip_allgather_u32(ctx, comm, sendGrid, grids, gridCap);    // (the grids, 8 bytes per tile)
     if (rc != SAILOR_HIP_OK) return rc;
-    return sailor_hip_stitch_light_lists(ctx, width, height, worldSize, totals, segments, segCap, grids, gridCap, dGlobalGrid, dGlobalCulled, globalCapacity);
+    return sailor_hip_stitch_light_lists_rows(ctx, width, height, worldSize, tileRowBounds, totals, segments, segCap, grids, gridCap, dGlobalGrid, globalGridTiles,
+                                              dGlobalCulled, globalCapacity);
 }

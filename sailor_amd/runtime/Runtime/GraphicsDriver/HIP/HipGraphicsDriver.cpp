@@ -416,6 +416,11 @@ int HipGraphicsDriver::SetFrameSplit(int rank, int worldSize, void* ncclComm)
 int HipGraphicsDriver::ExchangeLightLists(RHIBufferPtr bandGrid, RHIBufferPtr bandCulled, RHIBufferPtr globalGrid, RHIBufferPtr globalCulled)
 {
     if (!bandGrid || !bandCulled || !globalGrid || !globalCulled || !m_comm || m_splitW <= 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    {   // the stitch writes an entry for every tile of the frame: a shorter lightsGrid buffer is refused here, not overrun on the device
+        int32_t Tx = 0, Ty = 0;
+        sailor_hip_num_tiles(m_splitW, m_splitH, &Tx, &Ty);
+        if (globalGrid->m_size < (size_t)Tx * Ty * sizeof(SailorLightsGrid) || globalCulled->m_size < 4) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    }
     const size_t need = sailor_hip_exchange_workspace_size(m_splitW, m_splitH, m_worldSize);
     if (!m_exchangeWorkspace || m_exchangeWorkspace->m_size < need) m_exchangeWorkspace = CreateBuffer(need);
     if (!m_exchangeWorkspace) return SAILOR_HIP_ERR_OUT_OF_MEMORY;

@@ -668,6 +668,45 @@ def test_list_exchange_through_the_c_abi_over_rccl():
         ctx.synchronize()
         np.testing.assert_array_equal(out_grid.cpu().numpy().view(np.uint32).reshape(-1, 2), og)
         np.testing.assert_array_equal(out_cul.cpu().numpy().view(np.uint32)[: 1 + int(oi[0])], oi[: 1 + int(oi[0])])
+        # (c) the same stitch for an UNEQUAL split given as tile-row bounds (cost-balanced bands): three bands, the middle one a single row
+        bounds = np.array([0, 3, 4, Ty], np.int32)
+        world3 = 3
+        rows3 = int(np.diff(bounds).max())
+        seg_cap3, grid_cap3 = rows3 * Tx * 128, rows3 * Tx * 2
+        totals3 = torch.zeros(world3, dtype=torch.int32, device="cuda")
+        segs3 = torch.zeros(world3 * seg_cap3, dtype=torch.int32, device="cuda")
+        grids3 = torch.zeros(world3 * grid_cap3, dtype=torch.int32, device="cuda")
+        for r in range(world3):
+            band = host.band_from_tile_rows(W, H, int(bounds[r]), int(bounds[r + 1]))
+            fp = ForwardPlus(ctx, W, H, N, band=band)
+            d = torch.from_numpy(np.ascontiguousarray(f.depth[band.fbRowBegin:band.fbRowBegin + band.fbRowCount])).cuda()
+            fp.cull(f.cam.frame, lights, N, d)
+            ctx.synchronize()
+            tot = int(fp.culled[0].item())
+            totals3[r] = tot
+            segs3[r * seg_cap3: r * seg_cap3 + tot] = fp.culled[1:1 + tot]
+            grids3[r * grid_cap3: r * grid_cap3 + fp.band_tiles * 2] = fp.grid[: fp.band_tiles * 2]
+        assert lib.sailor_hip_exchange_workspace_size_rows(W, H, world3, bounds.ctypes.data) > 0
+        out_grid.zero_(); out_cul.zero_()
+        stitch = lambda grid_tiles, cul, cul_cap: lib.sailor_hip_stitch_light_lists_rows(
+            ctx.handle, W, H, world3, bounds.ctypes.data, totals3.data_ptr(), segs3.data_ptr(), seg_cap3, grids3.data_ptr(), grid_cap3,
+            out_grid.data_ptr(), grid_tiles, cul.data_ptr(), cul_cap)
+        _lib.check(stitch(Tx * Ty, out_cul, out_cul.numel()), "sailor_hip_stitch_light_lists_rows", ctx.handle)
+        ctx.synchronize()
+        np.testing.assert_array_equal(out_grid.cpu().numpy().view(np.uint32).reshape(-1, 2), og)
+        np.testing.assert_array_equal(out_cul.cpu().numpy().view(np.uint32)[: 1 + int(oi[0])], oi[: 1 + int(oi[0])])
+        # a lightsGrid buffer shorter than the frame's tiles is refused (it used to be overrun); bounds that do not cover the frame are refused;
+        # a culledLights buffer that cannot hold every segment is filled as far as it goes and [0] says how far
+        assert stitch(Tx * Ty - 1, out_cul, out_cul.numel()) == -1  # SAILOR_HIP_ERR_INVALID_ARGUMENT
+        bad = bounds.copy(); bad[-1] -= 1
+        assert lib.sailor_hip_stitch_light_lists_rows(ctx.handle, W, H, world3, bad.ctypes.data, totals3.data_ptr(), segs3.data_ptr(), seg_cap3, grids3.data_ptr(),
+                                                      grid_cap3, out_grid.data_ptr(), Tx * Ty, out_cul.data_ptr(), out_cul.numel()) == -1  # SAILOR_HIP_ERR_INVALID_ARGUMENT
+        short = torch.zeros(1 + int(oi[0]) // 2, dtype=torch.int32, device="cuda")
+        _lib.check(stitch(Tx * Ty, short, short.numel()), "sailor_hip_stitch_light_lists_rows", ctx.handle)
+        ctx.synchronize()
+        got_short = short.cpu().numpy().view(np.uint32)
+        assert got_short[0] == short.numel() - 1
+        np.testing.assert_array_equal(got_short[1:], oi[1: short.numel()])
         # the grid rebase helper gives the same offsets for band 1
         fp1 = keep[1][0]
         g1 = fp1.grid.clone()
