@@ -11,9 +11,10 @@
 // In-place safety: a chunk's destination never lies behind its own source, so it can only overlap the sources of chunks at or
 // before it in the same batch.  A chunk publishes only after its records are in LDS, and a chunk that holds a complete
 // look-back has seen a publication of every predecessor -- so every overlapped source has been read before the first store.
-// Forward progress: a block waits only for blocks of a LOWER index, and the dispatcher starts the blocks of a grid in index order,
-// so whoever is waited for is running or done -- no assumption about how many blocks are co-resident (an earlier version walked
-// the chunks with a persistent grid sized from the CU count, which hangs when fewer blocks than assumed fit the device).
+// Forward progress: a block takes its chunk by TICKET (an atomic counter read when the block starts) and waits only for chunks of a LOWER
+// number -- each of which is held by a block that drew its ticket earlier, i.e. is running or done.  No assumption about the order in which
+// the dispatcher starts a grid's blocks (round 2 took the chunk from blockIdx.x and relied on index-order dispatch, which HIP does not
+// promise) nor about how many blocks are co-resident (round 1 walked the chunks with a persistent grid sized from the CU count).
 // Records that stay where they are (nothing culled in front of them) are not rewritten, as in the shader (:164).
 #include "common.h"
 
@@ -39,7 +40,7 @@ static DrawPlan draw_plan_layout(uint32_t numInstances, uint32_t numBatches)
     // (RHI/Batch.hpp:158-159,183); k4_draw_plan never produces more items than this:
     L.maxItems = numInstances / DC_CHUNK + numBatches + 1;
     L.offItems = o; o = align_up(o + 16ull * L.maxItems, 256);
-    L.offStatus = o; o = align_up(o + 8ull * L.maxItems, 256);
+    L.offStatus = o; o = align_up(o + 8ull * (L.maxItems + 1ull), 256); // (+ 1: the compaction's ticket counter behind the status words)
     L.total = o;
     return L;
 }
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void k4_draw_items(uint32_t numBatches, const 
                                                       unsigned long long* __restrict__ status, uint32_t maxItems)
 {
     const uint32_t item = blockIdx.x * 256 + threadIdx.x;
-    if (item < maxItems) status[item] = 0ull; // "nothing published yet"
+    if (item <= maxItems) status[item] = 0ull; // "nothing published yet"; slot maxItems is k4_draw_compact's ticket counter
     if (item >= itemOffset[numBatches]) return;
     uint32_t lo = 0, hi = numBatches;
     while (hi - lo > 1) {
@@ -117,16 +118,22 @@ __device__ __forceinline__ void dc_store(unsigned long long* p, unsigned long lo
 
 __global__ __launch_bounds__(DC_CHUNK) void k4_draw_compact(float4* __restrict__ inst, uint32_t* __restrict__ batches, uint32_t numBatches,
                                                             const uint32_t* __restrict__ itemOffset, const uint4* __restrict__ items,
-                                                            unsigned long long* __restrict__ status)
+                                                            unsigned long long* __restrict__ status, uint32_t maxItems)
 {
     __shared__ float4 sRec[DC_CHUNK * DC_REC4];
     __shared__ uint16_t sMap[DC_CHUNK];
     __shared__ uint32_t sWaveKept[4];
     __shared__ uint32_t sExcl;
+    __shared__ uint32_t sTicket;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t totalItems = itemOffset[numBatches];
 
-    const uint32_t item = blockIdx.x;
+    // The chunk a block takes is a TICKET drawn when the block starts, not its index in the grid.  A block waits for the chunks in
+    // front of its own; with tickets every one of those is held by a block that is already running, whatever order the dispatcher starts the
+    // grid's blocks in (HIP promises none; with eight XCDs each dispatching its own share the index order was an assumption).
+    if (tid == 0) sTicket = atomicAdd(reinterpret_cast<unsigned int*>(status + maxItems), 1u);
+    __syncthreads();
+    const uint32_t item = sTicket;
     if (item >= totalItems) return;
     {
         const uint4 desc = items[item];
@@ -232,11 +239,11 @@ int sailor_hip_mesh_cull_compact_ex(SailorHipContext* ctx, const SailorUboFrameD
     hipLaunchKernelGGL(k4_draw_plan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)dBatches, numBatches, planFirst, planCount, itemOffset,
                        L.maxItems);
     SAILOR_CHECK_LAUNCH(ctx, "k4_draw_plan");
-    hipLaunchKernelGGL(k4_draw_items, dim3((L.maxItems + 255) / 256), dim3(256), 0, ctx->stream, numBatches, planFirst, planCount, itemOffset, items,
+    hipLaunchKernelGGL(k4_draw_items, dim3((L.maxItems + 256) / 256), dim3(256), 0, ctx->stream, numBatches, planFirst, planCount, itemOffset, items,
                        status, L.maxItems);
     SAILOR_CHECK_LAUNCH(ctx, "k4_draw_items");
     hipLaunchKernelGGL(k4_draw_compact, dim3(L.maxItems), dim3(DC_CHUNK), 0, ctx->stream, (float4*)dInstances, (uint32_t*)dBatches, numBatches, itemOffset,
-                       items, status);
+                       items, status, L.maxItems);
     SAILOR_CHECK_LAUNCH(ctx, "k4_draw_compact");
     return SAILOR_HIP_OK;
 }
