@@ -264,3 +264,193 @@ def ecs_sweep(trs, parent, local_aabb, planes):
     # Bounds.cpp:245-260: for each plane  sum_i max(min_i n_i, max_i n_i) + d > 0
     r = np.maximum(wmin[:, None, :] * pl[None, :, :3], wmax[:, None, :] * pl[None, :, :3]).sum(-1) + pl[None, :, 3]
     return world, np.concatenate([wmin, wmax], 1), (r > 0).all(1), np.abs(r).min(1)
+
+
+# =====================================================================================================================================
+# Round 3: the "next" rows a second time -- EVSM blur, irradiance cube, pre-filtered environment cube -- written from the shader
+# text (Lighting.glsl:83-127, ComputeIrradianceMap.shader, ComputeEnvMap_IBL.shader, Math.glsl:285-293, Lighting.glsl:27-48) and, for what the
+# shaders leave to the sampler, from the Vulkan specification's cube-map rules (major-axis face selection table, (sc / |ma| + 1) / 2, ties: z, then
+# y, then x), bilinear inside the face with clamp-to-edge, linear between the two nearest mips, lod clamped to the chain.  float64, vectorised over
+# samples; only the data layout (level-major / face / row / texel RGBA32F) is shared with the C oracle.  The depth rasteriser's second restatement
+# is the exact-integer / exact-rational one in tests/test_oracle_cpu.py (round 2).
+# =====================================================================================================================================
+EVSM_BLUR_WEIGHTS = np.array([  # Lighting.glsl:87-99
+    [0.5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+    [0.281088, 0.218912, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+    [0.197159, 0.176426, 0.126415, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+    [0.152068, 0.142855, 0.118431, 0.0866459, 0, 0, 0, 0, 0, 0, 0, 0],
+    [0.123827, 0.118971, 0.105518, 0.0863909, 0.0652929, 0, 0, 0, 0, 0, 0, 0],
+    [0.104454, 0.101593, 0.0934699, 0.0813492, 0.0669741, 0.0521595, 0, 0, 0, 0, 0, 0],
+    [0.0903332, 0.0885083, 0.083252, 0.0751759, 0.0651684, 0.0542336, 0.0433285, 0, 0, 0, 0, 0],
+    [0.07958, 0.0783462, 0.0747585, 0.0691403, 0.061977, 0.0538465, 0.0453433, 0.0370081, 0, 0, 0, 0],
+    [0.0711171, 0.0702445, 0.0676904, 0.0636383, 0.0583697, 0.0522315, 0.0455989, 0.0388376, 0.0322721, 0, 0, 0],
+    [0.0642825, 0.0636429, 0.0617619, 0.0587498, 0.0547779, 0.0500633, 0.0448484, 0.0393811, 0.0338957, 0.0285966, 0, 0],
+    [0.0586472, 0.0581645, 0.0567402, 0.0544433, 0.0513831, 0.0476999, 0.0435548, 0.039118, 0.0345572, 0.0300277, 0.0256641, 0],
+    [0.0539209, 0.0535478, 0.0524437, 0.050654, 0.0482506, 0.0453272, 0.0419936, 0.0383686, 0.034573, 0.0307232, 0.0269255, 0.0232718]], np.float64)
+
+
+def evsm_blur_pass(image: np.ndarray, radius_umbra: int, radius_penumbra: int, vertical: bool) -> np.ndarray:
+    """GaussianBlur_Evsm (Lighting.glsl:83-127) as one pass of Blur.shader {EVSM, HORIZONTAL | VERTICAL}: image [H, W, 4], radius = (umbra, penumbra);
+    the taps uv +- i texelSize of a fragment at a texel centre are texel centres: the texel itself, clamp-to-edge."""
+    img = np.asarray(image, np.float64)
+    H, W, _ = img.shape
+    step_count = 12
+    blur_radius = min(max(radius_umbra, radius_penumbra), step_count)
+    r1, r2 = min(radius_umbra, step_count), min(radius_penumbra, step_count)
+    out = np.zeros_like(img)
+    axis, n = (0, H) if vertical else (1, W)
+    idx = np.arange(n)
+    for i in range(blur_radius):
+        plus, minus = np.clip(idx + i, 0, n - 1), np.clip(idx - i, 0, n - 1)
+        both = np.take(img, plus, axis=axis) + np.take(img, minus, axis=axis)
+        if i < radius_umbra:
+            out[..., 2:4] += both[..., 2:4] * EVSM_BLUR_WEIGHTS[r1 - 1][i]
+        if i < radius_penumbra:
+            out[..., 0:2] += both[..., 0:2] * EVSM_BLUR_WEIGHTS[r2 - 1][i]
+    return out
+
+
+def _cube_levels(chain: np.ndarray, size0: int, levels: int):
+    """the flat RGBA32F mip chain as a list of [6, size, size, 4] float64 arrays"""
+    out, o = [], 0
+    flat = np.asarray(chain, np.float64).reshape(-1)
+    for l in range(levels):
+        sz = max(size0 >> l, 1)
+        out.append(flat[o:o + 6 * sz * sz * 4].reshape(6, sz, sz, 4))
+        o += 6 * sz * sz * 4
+    return out
+
+
+def _cube_face_st(d):
+    """Vulkan spec "Cube Map Face Selection": (face, s, t) of direction vectors d [n, 3]; ties go to z, then y, then x"""
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    ax, ay, az = np.abs(x), np.abs(y), np.abs(z)
+    use_z = (az >= ax) & (az >= ay)
+    use_y = ~use_z & (ay >= ax)
+    use_x = ~use_z & ~use_y
+    face = np.where(use_z, np.where(z < 0, 5, 4), np.where(use_y, np.where(y < 0, 3, 2), np.where(x < 0, 1, 0)))
+    sc = np.where(use_z, np.where(z < 0, -x, x), np.where(use_y, x, np.where(x < 0, z, -z)))
+    tc = np.where(use_z, -y, np.where(use_y, np.where(y < 0, -z, z), -y))
+    ma = np.where(use_z, az, np.where(use_y, ay, ax))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return face, 0.5 * (sc / ma + 1.0), 0.5 * (tc / ma + 1.0)
+
+
+def _cube_bilinear(level: np.ndarray, face, s, t):
+    size = level.shape[1]
+    x, y = s * size - 0.5, t * size - 0.5
+    fx, fy = np.floor(x), np.floor(y)
+    ax, ay = (x - fx)[:, None], (y - fy)[:, None]
+    x0, y0 = fx.astype(np.int64), fy.astype(np.int64)
+    x1, y1 = np.clip(x0 + 1, 0, size - 1), np.clip(y0 + 1, 0, size - 1)
+    x0, y0 = np.clip(x0, 0, size - 1), np.clip(y0, 0, size - 1)
+    top = level[face, y0, x0] * (1.0 - ax) + level[face, y0, x1] * ax
+    bot = level[face, y1, x0] * (1.0 - ax) + level[face, y1, x1] * ax
+    return top * (1.0 - ay) + bot * ay
+
+
+def cube_texture_lod(levels_list, d, lod):
+    """textureLod(samplerCube, d, lod): rgba [n, 4]"""
+    face, s, t = _cube_face_st(d)
+    lod = np.clip(lod, 0.0, len(levels_list) - 1.0)
+    l0 = np.floor(lod).astype(np.int64)
+    l1 = np.minimum(l0 + 1, len(levels_list) - 1)
+    f = (lod - l0)[:, None]
+    out = np.zeros((len(d), 4))
+    for l in range(len(levels_list)):
+        m0, m1 = l0 == l, l1 == l
+        if m0.any():
+            out[m0] += _cube_bilinear(levels_list[l], face[m0], s[m0], t[m0]) * (1.0 - f[m0])
+        if m1.any():
+            out[m1] += _cube_bilinear(levels_list[l], face[m1], s[m1], t[m1]) * f[m1]
+    return out
+
+
+def _radical_inverse_vdc(i):
+    """Math.glsl:285-293: the 32-bit reversal of i times 2^-32"""
+    b = np.asarray(i, np.uint64) & 0xFFFFFFFF
+    b = ((b << 16) | (b >> 16)) & 0xFFFFFFFF
+    b = (((b & 0x55555555) << 1) | ((b & 0xAAAAAAAA) >> 1)) & 0xFFFFFFFF
+    b = (((b & 0x33333333) << 2) | ((b & 0xCCCCCCCC) >> 2)) & 0xFFFFFFFF
+    b = (((b & 0x0F0F0F0F) << 4) | ((b & 0xF0F0F0F0) >> 4)) & 0xFFFFFFFF
+    b = (((b & 0x00FF00FF) << 8) | ((b & 0xFF00FF00) >> 8)) & 0xFFFFFFFF
+    return b.astype(np.float64) * 2.3283064365386963e-10
+
+
+def _sampling_vector(gx, gy, face, size):
+    """GetSamplingVector (ComputeIrradianceMap.shader / ComputeEnvMap_IBL.shader): the direction of output texel (gx, gy) of `face`"""
+    st = np.array([gx / size, gy / size])
+    uv = 2.0 * np.array([st[0], 1.0 - st[1]]) - 1.0
+    ret = [(1.0, uv[1], -uv[0]), (-1.0, uv[1], uv[0]), (uv[0], 1.0, -uv[1]), (uv[0], -1.0, uv[1]), (uv[0], uv[1], 1.0), (-uv[0], uv[1], -1.0)][face]
+    ret = np.array(ret, np.float64)
+    return ret / np.linalg.norm(ret)
+
+
+def _basis(N):
+    """ComputeBasisVectors: T = cross(N, up) unless degenerate (dot(T, T) < Epsilon), then cross(N, x); S = normalize(cross(N, T))"""
+    T = np.cross(N, (0.0, 1.0, 0.0))
+    if not (np.dot(T, T) >= 0.00001):   # step(Epsilon, dot(T, T)) == 0
+        T = np.cross(N, (1.0, 0.0, 0.0))
+    T = T / np.linalg.norm(T)
+    S = np.cross(N, T)
+    return S / np.linalg.norm(S), T
+
+
+TWO_PI = 2.0 * PI  # Constants.glsl (TwoPI = 2 * PI with Math.glsl's PI)
+
+
+def compute_irradiance_map(env_chain: np.ndarray, env_size: int, env_levels: int, size: int, num_samples: int = 64 * 1024) -> np.ndarray:
+    """ComputeIrradianceMap.shader main(): [6, size, size, 4] float64 (alpha 1)"""
+    levels_list = _cube_levels(env_chain, env_size, env_levels)
+    i = np.arange(num_samples)
+    u1, u2 = i / float(num_samples), _radical_inverse_vdc(i)          # SampleHammersley: (i * InvNumSamples, RadicalInverse_VdC(i))
+    u1p = np.sqrt(np.maximum(0.0, 1.0 - u1 * u1))                      # SampleHemisphere(u1, u2)
+    hemi = np.stack([np.cos(TWO_PI * u2) * u1p, np.sin(TWO_PI * u2) * u1p, u1], 1)
+    out = np.zeros((6, size, size, 4))
+    for face in range(6):
+        for gy in range(size):
+            for gx in range(size):
+                N = _sampling_vector(gx, gy, face, size)
+                S, T = _basis(N)
+                Li = hemi[:, 0:1] * S + hemi[:, 1:2] * T + hemi[:, 2:3] * N
+                cos_theta = np.maximum(0.0, Li @ N)
+                rgb = cube_texture_lod(levels_list, Li, np.zeros(num_samples))[:, :3]
+                out[face, gy, gx, :3] = (2.0 * rgb * cos_theta[:, None]).sum(0) / num_samples
+                out[face, gy, gx, 3] = 1.0
+    return out
+
+
+def prefilter_env_level(raw_chain: np.ndarray, size0: int, levels: int, level: int, roughness: float, num_samples: int = 1024) -> np.ndarray:
+    """ComputeEnvMap_IBL.shader main() for one output level: [6, s, s, 4] float64 with s = size0 >> level"""
+    levels_list = _cube_levels(raw_chain, size0, levels)
+    s_out = max(size0 >> level, 1)
+    wt = 4.0 * PI / (6.0 * size0 * size0)
+    i = np.arange(num_samples)
+    u1, u2 = i / float(num_samples), _radical_inverse_vdc(i)
+    alpha = roughness * roughness                                       # SampleGGX (Lighting.glsl:27-37)
+    cos_t = np.sqrt((1.0 - u2) / (1.0 + (alpha * alpha - 1.0) * u2))
+    sin_t = np.sqrt(1.0 - cos_t * cos_t)
+    phi = TWO_PI * u1
+    ggx = np.stack([sin_t * np.cos(phi), sin_t * np.sin(phi), cos_t], 1)
+    out = np.zeros((6, s_out, s_out, 4))
+    for face in range(6):
+        for gy in range(s_out):
+            for gx in range(s_out):
+                N = _sampling_vector(gx, gy, face, s_out)
+                S, T = _basis(N)
+                Lh = ggx[:, 0:1] * S + ggx[:, 1:2] * T + ggx[:, 2:3] * N
+                Li = 2.0 * (Lh @ N)[:, None] * Lh - N                   # Lo = N
+                cos_li = Li @ N
+                m = cos_li > 0.0
+                cos_lh = np.maximum(Lh[m] @ N, 0.0)
+                alpha_sq = alpha * alpha                                # NdfGGX (Lighting.glsl:41-48)
+                denom = cos_lh * cos_lh * (alpha_sq - 1.0) + 1.0
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    pdf = alpha_sq / (PI * denom * denom) * 0.25
+                    ws = 1.0 / (num_samples * pdf)
+                    mip = np.maximum(0.5 * np.log2(ws / wt) + 1.0, 0.0)
+                rgb = cube_texture_lod(levels_list, Li[m], mip)[:, :3]
+                weight = cos_li[m].sum()
+                out[face, gy, gx, :3] = (rgb * cos_li[m][:, None]).sum(0) / weight
+                out[face, gy, gx, 3] = 1.0
+    return out

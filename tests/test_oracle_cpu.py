@@ -854,3 +854,65 @@ def test_threaded_whole_frame_checkers_equal_the_single_thread_oracle():
     rb1 = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, g1, i1, csm, rows=(5, H - 9))
     rb = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, g1, i1, csm, rows=(5, H - 9), threads=3)
     assert np.array_equal(rb.view(np.uint32), rb1.view(np.uint32))
+
+
+# ---- round 3: the "next" rows a second time (oracle/oracle_f64.py, written from the shader text): EVSM blur, irradiance cube, pre-filtered env cube ----
+def _smooth_cube(size0, levels):
+    """a cube map whose texels are a smooth function of their direction -- continuous across the faces -- every level evaluated at its own texel
+    centres.  (On random texels a sample direction that lands exactly on a face boundary -- the Hammersley set is full of them for texels on the
+    cube's symmetry planes -- picks one face or the other by the last bit, and the two restatements then read unrelated values.)"""
+    out = []
+    for l in range(levels):
+        s = max(size0 >> l, 1)
+        c = (np.arange(s) + 0.5) / s * 2 - 1
+        u, v = np.meshgrid(c, c)
+        one = np.ones_like(u)
+        faces = []
+        for d in ((one, -v, -u), (-one, -v, u), (u, one, v), (u, -one, -v), (u, -v, one), (-u, -v, -one)):  # the inverse of the face-selection table
+            d = np.stack(d, -1)
+            d /= np.linalg.norm(d, axis=-1, keepdims=True)
+            x, y, z = d[..., 0], d[..., 1], d[..., 2]
+            faces.append(np.stack([1.5 + np.sin(2 * x + y), 1.2 + 0.8 * y * z + 0.3 * x, 2.0 + np.cos(3 * z - x) * 0.7, one], -1))
+        out.append(np.stack(faces).astype(np.float32).reshape(-1))
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("radii", [(2, 5), (1, 4), (1, 3), (1, 2), (12, 7), (20, 3)])
+def test_evsm_blur_against_the_float64_restatement(radii):
+    """GaussianBlur_Evsm (Lighting.glsl:83-127) twice: the C oracle's pass against oracle_f64.evsm_blur_pass, both directions, the reference's four
+    radius pairs (ShadowCascadeBlur, ECS/LightingECS.h:60) and radii at / beyond the shader's cap of 12"""
+    from oracle import oracle_f64
+    rng = np.random.default_rng(31)
+    img = (rng.random((41, 29, 4)) * 6 - 1).astype(np.float32)
+    for vertical in (0, 1):
+        dst = np.zeros_like(img)
+        oracle.lib().oracle_evsm_blur_pass(oracle._p(img), oracle._p(dst), 29, 41, radii[0], radii[1], vertical)
+        ref = oracle_f64.evsm_blur_pass(img, radii[0], radii[1], bool(vertical))
+        assert np.abs(dst - ref).max() <= 2e-6 * np.abs(ref).max()
+    both = oracle.evsm_blur(img, radii[0], radii[1])
+    ref = oracle_f64.evsm_blur_pass(oracle_f64.evsm_blur_pass(img, radii[0], radii[1], False), radii[0], radii[1], True)
+    assert np.abs(both - ref).max() <= 4e-6 * np.abs(ref).max()
+
+
+def test_ibl_bakes_against_the_float64_restatement():
+    """ComputeIrradianceMap.shader and ComputeEnvMap_IBL.shader: the C oracle against oracle_f64 (written from the shader text and the Vulkan cube
+    sampling rules) on a smooth cube.  The irradiance cube (65 536 samples a texel) agrees to 1e-5; the pre-filtered levels to 2e-4 where the
+    samples stay on the finer mips, and to 2e-3 at roughness 1, whose wide lobe reads the coarsest mip (8 x 8 faces: a direction on a face
+    boundary is a tie that the two precisions break differently, and neighbouring faces' edge texels are a texel apart there)."""
+    from oracle import oracle_f64
+    S, L = 32, 3
+    env = _smooth_cube(S, L)
+    offs, total = oracle.cube_level_offsets(S, L)
+    assert env.size == total
+    a = oracle.compute_irradiance_map(env, S, L, 2)
+    b = oracle_f64.compute_irradiance_map(env, S, L, 2)
+    assert (np.abs(a - b) <= 5e-5 * np.abs(b)).all(), (np.abs(a - b) / np.abs(b)).max()
+    p = oracle.prefilter_env_map(env, S, L)
+    np.testing.assert_array_equal(p[: offs[1]], env[: offs[1]])   # level 0 is the raw cube (EnvironmentNode.cpp:196-206: a blit)
+    for level, tol in ((1, 2e-4), (2, 2e-3)):
+        q = oracle_f64.prefilter_env_level(env, S, L, level, level / (L - 1.0))
+        sz = S >> level
+        got = p[offs[level]: offs[level] + 6 * sz * sz * 4].reshape(6, sz, sz, 4)
+        rel = np.abs(got - q) / np.abs(q)
+        assert rel.max() <= tol, (level, rel.max())
+        assert np.percentile(rel, 50) <= tol / 20, (level, np.percentile(rel, 50))
