@@ -113,7 +113,8 @@ __device__ __forceinline__ float sample_r16_pairs(const __half* __restrict__ map
 // Lighting.glsl:242-261 ShadowCalculation_Pcf + :168-197 ManualPCF
 __device__ float shadow_pcf(const void* __restrict__ map, int fmt, int W, int H, float4 lp, float bias)
 {
-    float px = lp.x / lp.w, py = lp.y / lp.w, pz = lp.z / lp.w;
+    float px = lp.x, py = lp.y, pz = lp.z;
+    if (__ballot(lp.w != 1.0f) != 0ull) { px = px / lp.w; py = py / lp.w; pz = pz / lp.w; } // (x / 1 == x: see shadow_evsm)
     px = px * 0.5f + 0.5f; py = py * 0.5f + 0.5f; pz = pz * 0.5f + 0.5f;
     py = 1.0f - py;
     if (px > 1.0f || py > 1.0f || px < 0.0f || py < 0.0f || pz < 0.5f) return 1.0f;
@@ -158,8 +159,10 @@ __device__ __forceinline__ float chebyshev(float m0, float m1, float currentDept
 // Lighting.glsl:263-284 ShadowCalculation_Evsm
 __device__ float shadow_evsm(const void* __restrict__ map, int fmt, int W, int H, float4 lp, float bias, int cascade)
 {
-    float px = lp.x / lp.w, py = lp.y / lp.w;
-    const float pz = lp.z / lp.w;
+    float px = lp.x, py = lp.y, pz = lp.z;
+    // an orthographic cascade: every lane's w is exactly 1 and x / 1 == x -- the three correctly rounded divisions (36 instructions) are skipped
+    // (a wave-uniform branch around them and nothing else: round 2's form of this idea took the kernel from 80 to 103 registers; 275 -> 271 us at C4)
+    if (__ballot(lp.w != 1.0f) != 0ull) { px = px / lp.w; py = py / lp.w; pz = pz / lp.w; }
     px = px * 0.5f + 0.5f; py = py * 0.5f + 0.5f;
     py = 1.0f - py;
     if (px > 1.0f || py > 1.0f || px < 0.0f || py < 0.0f || pz < 0.0f) return 1.0f;

@@ -4,16 +4,16 @@ import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sailor_amd import synth, host  # noqa: E402
-from sailor_amd.forward_plus import HipContext, ForwardPlus, upload_lights, upload_shadow_maps  # noqa: E402
+from sailor_amd.forward_plus import HipContext, ForwardPlus, PreparedLights, upload_lights, upload_shadow_maps  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ctx = HipContext("cuda:0")
 f = synth.make_frame(cfg)
 W, H, N = f.cam.width, f.cam.height, len(f.lights)
-fp = ForwardPlus(ctx, W, H, N)
 d_depth = torch.from_numpy(np.ascontiguousarray(f.depth)).to(ctx.device)
 d_lights = upload_lights(f.lights, ctx.device)
+fp = ForwardPlus(ctx, W, H, N, prepared=None if os.environ.get("SAILOR_PLAIN_LIGHTS") else PreparedLights(ctx, d_lights, N))  # the path as the HIP backend drives it
 d_surface = torch.from_numpy(np.ascontiguousarray(f.surface)).to(ctx.device)
 csm = keep = None
 if f.shadows is not None:
