@@ -865,8 +865,10 @@ def main():
     evals = int((g[:, 1].astype(np.int64) * 256).sum())
     shade_gbs = b_shade / (shade_batch_ms * 1e-3) / 1e9
     shade_kernel = "k2_shade_csm" if csm is not None else ("k2_shade_band" if fp.tile_order and fp.use_tile_order else "k2_shade")
+    if prep is not None:
+        shade_kernel += "_p"   # the entry points that read sailor_hip_prepare_lights' staged records
     roofline = {"bound": "hbm", "kernel": shade_kernel, "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
-                "traffic": measured_traffic("k2_shade" if csm is None else "k2_shade_csm", args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_batch_ms,
+                "traffic": measured_traffic(shade_kernel, args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_batch_ms,
                 "timing": "median of %d batches of %d back-to-back launches, one HIP event pair per batch on the launch stream, each batch one hipGraph replay unless --no-graph; "
                           "the pair also sees the gap between consecutive launches and the end-of-kernel write-back, so it reads above the kernel's own duration in "
                           "rocprofv3 --kernel-trace --stats (profiles/<round>/kernel_stats.csv; the difference is quoted there as the per-launch gap); "

@@ -15,9 +15,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats4 -- python3 $
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python3 $GRAFT_REPO_ROOT/bench.py --config C5 --steps 20 --warmup 3 --no-cpu-baseline --no-graph --frames-in-flight 1 > $OUT/bench_eager_C5.json 2>/dev/null
 cd $GRAFT_REPO_ROOT
 python3 scripts/make_traffic_json.py $OUT/fetch $OUT/write $OUT/traffic.json C3 > /dev/null
-python3 scripts/pmc_summary.py $OUT/sq k2_shade > $OUT/pmc_shade.txt
+python3 scripts/pmc_summary.py $OUT/sq k2_shade_p > $OUT/pmc_shade.txt
 python3 scripts/pmc_summary.py $OUT/sq tile_cull > $OUT/pmc_tile_cull.txt
-python3 scripts/pmc_summary.py $OUT/sq4 k2_shade_csm > $OUT/pmc_shade_csm_C4.txt
+python3 scripts/pmc_summary.py $OUT/sq4 k2_shade_csm_p > $OUT/pmc_shade_csm_C4.txt
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cp $(find $OUT/stats4 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_C4.csv
 cp $(find $OUT/stats5 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_C5.csv
