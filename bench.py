@@ -867,6 +867,7 @@ def main():
     shade_kernel = "k2_shade_csm" if csm is not None else ("k2_shade_band" if fp.tile_order and fp.use_tile_order else "k2_shade")
     if prep is not None:
         shade_kernel += "_p"   # the entry points that read sailor_hip_prepare_lights' staged records
+    trace_ms = trace_kernel_ms(shade_kernel, args.config, world)
     roofline = {"bound": "hbm", "kernel": shade_kernel, "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
                 "traffic": measured_traffic(shade_kernel, args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_batch_ms,
                 "timing": "median of %d batches of %d back-to-back launches, one HIP event pair per batch on the launch stream, each batch one hipGraph replay unless --no-graph; "
@@ -874,7 +875,8 @@ def main():
                           "rocprofv3 --kernel-trace --stats (profiles/<round>/kernel_stats.csv; the difference is quoted there as the per-launch gap); "
                           "isolated_* = an event pair around every single launch (pipeline drained on both sides)" % (shade_batch["batches"], shade_batch["launches_per_batch"]),
                 "avg_launch_ms_min_max": [shade_batch["min"], shade_batch["max"]],
-                "rocprof_kernel_avg_ms": trace_kernel_ms(shade_kernel, args.config, world),
+                "rocprof_kernel_avg_ms": trace_ms,
+                "launch_gap_ms": (shade_batch_ms - trace_ms) if trace_ms is not None else None,  # what the event pair sees between consecutive launches (this run's events against the committed trace's kernel duration)
                 "isolated_avg_launch_ms": shade_ms[0], "isolated_median_launch_ms": shade_ms[1],
                 "in_pipeline_launch_ms": pipeline_ms - cull_eager_ms,  # eager (cull + shade) x K minus eager (cull) x K: the kernel between its real neighbours
                 "eager_step_ms": pipeline_ms,
