@@ -30,10 +30,15 @@ def test_default_line_carries_the_contract():
     assert d["config"]["workload"].startswith("C3: 3840x2160, 65536 ") and "model" not in d["config"]
     assert abs(d["value"] - 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k2_shade"
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k2_shade_p"   # the prepared-lights entry point: the default path
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.05 < r["frac"] < 1.0
     assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["traffic"] is None or r["traffic"] > 0.9 * r["bytes_per_launch"]
+    # round 3: per-kernel figures are medians of >= 5 batches of >= 50 launches whatever --steps is, and the line carries the serial reading of the step
+    assert r["avg_launch_ms_min_max"][0] <= r["avg_launch_ms"] <= r["avg_launch_ms_min_max"][1] and "median of 5 batches of 50" in r["timing"]
+    assert d["value_serial"] > 0 and d["serial_step_ms"]["min"] <= d["serial_step_ms"]["median"] <= d["serial_step_ms"]["max"]
+    assert abs(d["value_serial"] - 3840 * 2160 / (d["serial_step_ms"]["median"] * 1e-3) / 1e6) < 1e-6 * d["value_serial"]
+    assert d["value_serial"] < d["value"] * 1.02, "one frame in flight is not faster than two"
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Mpixels/s" and c["value"] > 0 and "tile rows" in c["sample"]
     for block in ("ecs_sweep", "mesh_cull_compact", "linearize_depth", "ambient_ibl", "evsm_blur", "ibl_prefilter", "shadow_passes"):
