@@ -10,7 +10,7 @@ import torch
 
 from oracle import oracle
 from sailor_amd import _lib, host, synth
-from sailor_amd.forward_plus import EcsSweep, ForwardPlus, upload_lights, upload_shadow_maps
+from sailor_amd.forward_plus import EcsSweep, ForwardPlus, PreparedLights, upload_lights, upload_shadow_maps
 
 CULL_PATHS = [_lib.CULL_DEFAULT, _lib.CULL_BRUTE_FORCE, _lib.CULL_INTERVAL_MASKS]
 
@@ -57,6 +57,9 @@ def k1k2_case(ctx, rng, c, run=True, verbose=False):
             d = torch.from_numpy(np.ascontiguousarray(depth[rows])).to(ctx.device)
             s = torch.from_numpy(np.ascontiguousarray(surface[:, rows])).to(ctx.device)
             l = upload_lights(lights, ctx.device)
+            # every other cull path through the prepared-lights entry points (the path the HIP backend drives), with a capacity above the count
+            prep = PreparedLights(ctx, l, N, capacity=N + 5) if (CULL_PATHS.index(flags) + c) % 2 == 0 else None
+            fp.prepared = prep
             fp.cull(cam.frame, l, N, d, flags)
             g, idx = fp.lists_to_host()
             t0r, t1r = bb.tileRowBegin * Tx, bb.tileRowEnd * Tx
@@ -116,8 +119,8 @@ def k3_case(ctx, rng, c):
     og, oi, _ = oracle.light_cull(f.cam.frame, W, H, lights, depth)
     desc, keep = oracle.make_csm(f.shadows.lights_matrices, f.shadows.maps)
     ref = oracle.shade(f.cam.frame, W, H, f.surface, lights, og, oi, desc)
-    fp = ForwardPlus(ctx, W, H, N)
     l = upload_lights(lights, ctx.device)
+    fp = ForwardPlus(ctx, W, H, N, prepared=PreparedLights(ctx, l, N) if c % 2 == 0 else None)
     fp.cull(f.cam.frame, l, N, torch.from_numpy(np.ascontiguousarray(depth)).to(ctx.device))
     gdesc, gkeep = upload_shadow_maps(f.shadows, ctx.device)
     got = fp.shade(f.cam.frame, torch.from_numpy(np.ascontiguousarray(f.surface)).to(ctx.device), l, N, gdesc).cpu().numpy()

@@ -1,5 +1,5 @@
 """A bounded slice of the randomised parity sweeps inside `pytest -m gpu`: the same cases as scripts/fuzz_parity.py and
-scripts/fuzz_csm_ecs.py (tests/fuzz_cases.py), fixed seeds, sized for about a minute in all.  The seeds are FIXED so that the gate is hermetic (the
+scripts/fuzz_csm_ecs.py (tests/fuzz_cases.py), fixed seeds (300 K1 + K2, 100 K3, 100 K4 cases: under a minute in all), alternating between the plain and the prepared-lights entry points.  The seeds are FIXED so that the gate is hermetic (the
 same commit gives the same verdict on any day); SAILOR_FUZZ_SEEDS=s1,s2,... adds further seeds on demand (a nightly job can pass the date), and the
 scripts run thousands of cases through gpurun.  A failure's message names seed and case: `python scripts/fuzz_parity.py <cases> <seed> <case>` replays it."""
 import os
@@ -12,9 +12,9 @@ import fuzz_cases
 pytestmark = pytest.mark.gpu
 
 EXTRA = [int(s) for s in os.environ.get("SAILOR_FUZZ_SEEDS", "").split(",") if s.strip()]
-K1K2_CASES = int(os.environ.get("SAILOR_FUZZ_K1K2_CASES", "90"))
-K3_CASES = int(os.environ.get("SAILOR_FUZZ_K3_CASES", "40"))
-K4_CASES = int(os.environ.get("SAILOR_FUZZ_K4_CASES", "40"))
+K1K2_CASES = int(os.environ.get("SAILOR_FUZZ_K1K2_CASES", "300"))
+K3_CASES = int(os.environ.get("SAILOR_FUZZ_K3_CASES", "100"))
+K4_CASES = int(os.environ.get("SAILOR_FUZZ_K4_CASES", "100"))
 
 
 @pytest.mark.parametrize("seed", [20250301] + EXTRA)
