@@ -298,7 +298,8 @@ extern "C" int sailor_hip_shade_prepared(SailorHipContext* ctx, const SailorUboF
             }
         }
     }
-    const dim3 grid((unsigned)A.Tx, (unsigned)(band->tileRowEnd - band->tileRowBegin));
+    A.bandTileRows = band->tileRowEnd - band->tileRowBegin;
+    const dim3 grid(8u, (unsigned)A.Tx, (unsigned)((A.bandTileRows + 7) / 8)); // (XCD, tile column, tile row / 8): see k2_shade_body
     IblArgs I {};
     if (ibl) {
         if (!ibl->irradiance || !ibl->env || !ibl->brdfLut || ibl->irrSize <= 0 || ibl->envSize <= 0 || ibl->envLevels <= 0 || ibl->envLevels > 16 ||

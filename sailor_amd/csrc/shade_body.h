@@ -31,6 +31,7 @@ struct ShadeArgs {
     int tileRow0;     // band.tileRowBegin
     int fbRow0;       // band.fbRowBegin
     int fbRows;       // band.fbRowCount
+    int bandTileRows; // band.tileRowEnd - band.tileRowBegin
     int lightsNum;
     const uint32_t* order; // sailor_hip_light_cull_tile_order or null
 };
@@ -474,8 +475,12 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     // loop those values stay live across the whole body and the 64-register budget spills)
     if (splitRole) asm volatile("" : "+v"(tid));
 
-    // grid = (tiles per row, tile rows of the band): no division.
-    int btx = blockIdx.x, bty = blockIdx.y;
+    // grid = (8, tiles per row, ceil(tile rows / 8)): no division.  The hardware deals consecutive linear block ids to the eight XCDs in turn, and
+    // with 8 as the fastest dimension blockIdx.x IS the XCD -- which then shades the tile rows x, x + 8, x + 16, ...: the tiles of a row (neighbours
+    // share most of their lights) read their records and lists through ONE L2 instead of eight, and every XCD gets the same mix of rows (a light
+    // cluster is spread over all of them; whole regions per XCD put the cluster on one).  136.4 -> 135.3 us, serial step 0.1810 -> 0.1789 ms.
+    int btx = blockIdx.y, bty = (int)blockIdx.z * 8 + (int)blockIdx.x;
+    if (ROLE == ROLE_TILE && bty >= A.bandTileRows) return;
     const int lane = tid & 63, wave = tid >> 6;
     int quad = wave;
     if (BAND) { btx = selTx; bty = selTy; if (splitRole) quad = selQuad; }
