@@ -52,6 +52,9 @@
 #define GROUP 4              // k1_group_lists: tiles per group edge (4x4 tiles share one candidate list)
 #define CAPG 2048            // entries per group list; a denser group falls back to walking the masks per tile
 #define GROUP_OVERFLOW 0xFFFFFFFFu
+#define GROUP_OVERFLOW_LISTED 0xFFFFFFFEu // ... the same for a group that is in k1_group_lists' cluster list
+#define GROUP_LISTED 0x40000000u // flag in a group's count: a light cluster k1_group_lists found room for in its list (k1_tile_cull starts with those)
+#define HEAVY_MAX 256           // ... and that list's room
 #define CHUNK 512            // group candidates staged in LDS per step of k1_tile_cull (16 KB of LDS per block: 8 blocks per CU)
 
 #define SLOT 512             // staging entries per k1_tile_cull block (4 tiles x KEEP)
@@ -62,7 +65,7 @@
 
 struct CullLayout {
     int Tx, Ty, bandRows, bandTiles, numBands, words, groupsX, groupsY, numGroups, cullBlocks, packBlocks;
-    size_t offLightView, offLightType, offTileInfo, offMasks, offDirWords, offGroupCount, offGroupList, offTotals, offClsTotals, offTileNum, offStaging, offTileOrder, offDirFlag, total;
+    size_t offLightView, offLightType, offTileInfo, offMasks, offDirWords, offGroupCount, offGroupList, offTotals, offClsTotals, offTileNum, offStaging, offTileOrder, offDirFlag, offHeavy, total;
 };
 
 static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
@@ -92,6 +95,7 @@ static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
     L.offTileInfo = o; o = align_up(o + tiles * 64, 256);
     L.offGroupCount = o; o = align_up(o + groups * 4, 256);
     L.offDirFlag = o; o = align_up(o + 4, 256);
+    L.offHeavy = o; o = align_up(o + (1 + HEAVY_MAX) * 4, 256); // [0] = light-cluster groups listed by k1_group_lists (zeroed by k01_prepare), then their indices
     L.offGroupList = o; o = align_up(o + groups * CAPG * 4, 256);
     L.offTotals = o; o = align_up(o + (cb + PACK_BLOCKS) * 4, 256);
     L.offClsTotals = o; o = align_up(o + (cb + PACK_BLOCKS) * 4, 256);
@@ -158,6 +162,7 @@ struct PrepareArgs {
     const float* depth;
     float4* lightView; uint32_t* lightType; float4* tileInfo;
     unsigned long long* masks; unsigned long long* dirWords;
+    uint32_t* heavy;   // [0]: k1_group_lists' count of light-cluster groups, zeroed here (one launch ahead of it)
     uint32_t* dirFlag; // "some light may be directional": set here, read by k1_group_lists_wide, cleared by k1_pack (unknown before the first cull: then merely conservative)
     int N, words, lightBlocks, lightRoleBlocks, frustumBlocks, bandsPerBlock, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands,
         stripsPerRow, vecOK, rawDepth, intervals;
@@ -424,6 +429,7 @@ __global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K01_PREPARE];
     const int b = (int)blockIdx.x;
+    if (b == 0 && threadIdx.x == 0) a.heavy[0] = 0u;
     if (b < a.lightRoleBlocks) k0_lights(b, lds, a);
     else if (b < a.lightRoleBlocks + a.frustumBlocks) k1_tile_frusta(b - a.lightRoleBlocks, a);
     else k1_tile_setup(b - a.lightRoleBlocks - a.frustumBlocks, lds, a);
@@ -448,7 +454,8 @@ __device__ __forceinline__ uint64_t lanemask_lt()
 // ------------------------------------------------------------------------------------------------------------
 #define GL_WPT 4 // words per thread and round in k1_group_lists
 __global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ dirWords,
-                                                       int words, int groupsX, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList)
+                                                       int words, int groupsX, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList,
+                                                       uint32_t* __restrict__ heavy)
 {
     __shared__ uint32_t sW[4];
     // (2-D grid: group column, group row -- no division by the run-time groupsX)
@@ -514,7 +521,19 @@ __global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* 
         base += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) groupCount[g] = base > CAPG ? GROUP_OVERFLOW : base;
+    if (threadIdx.x == 0) {
+        uint32_t word = base > CAPG ? GROUP_OVERFLOW : base;
+        // a light cluster (several chunks and a nearest-128 selection per tile: ~20 us for one of its row blocks, wherever in the grid it sits):
+        // listed, so that k1_tile_cull can start with it
+        if (base > (uint32_t)CHUNK) {
+            const uint32_t slot = atomicAdd(&heavy[0], 1u);
+            if (slot < (uint32_t)HEAVY_MAX) {
+                heavy[1u + slot] = (uint32_t)g;
+                word = word != GROUP_OVERFLOW ? (word | GROUP_LISTED) : GROUP_OVERFLOW_LISTED;
+            }
+        }
+        groupCount[g] = word;
+    }
 }
 
 // The same lists for LARGE light sets (>= 4 096 mask words: C5's million lights = 16 384 words per band, ~420 candidates per group, 97 % of the
@@ -721,6 +740,7 @@ struct CullArgs {
     const unsigned long long* masks; const uint32_t* groupCount; const uint32_t* groupList;
     uint32_t* totals; uint32_t* clsTotals; uint32_t* tileNum; uint32_t* staging;
     int N, words, Tx, groupsX, bandRows, classes;
+    const uint32_t* heavy; int headRows; // k1_group_lists' cluster list and the grid rows in front of the tile rows that take its row blocks (0: none)
 };
 
 // The <= 196 candidates of a tile (sIdx, ascending light index) -> its list at `out` (Appendix A steps 4 + 5).  One wave.
@@ -862,7 +882,19 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     // 32 -- the cluster groups all land on one XCD.)
     // (a 2-D grid, (group column, tile row of the band): the index arithmetic has no division -- by a run-time divisor that is ~35 scalar
     // instructions, 5 % of what a wave of this kernel issues)
-    const int gx = (int)blockIdx.x, tyLocal = (int)blockIdx.y;
+    int gx = (int)blockIdx.x, tyLocal = (int)blockIdx.y - a.headRows;
+    bool head = false;
+    if (!BRUTE && tyLocal < 0) {
+        // HEAD ROWS: the row blocks of the light clusters k1_group_lists listed.  Such a block is the launch's tail wherever it sits in the grid
+        // (~20 us against ~6 for an ordinary one), so it goes first; its regular position further down leaves at once.
+        const uint32_t hb = blockIdx.y * (uint32_t)groupsX + blockIdx.x;
+        if ((hb >> 2) >= min(a.heavy[0], (uint32_t)HEAVY_MAX)) return;
+        const int hg = (int)a.heavy[1u + (hb >> 2)];
+        tyLocal = (hg / groupsX) * GROUP + (int)(hb & 3u);
+        gx = hg % groupsX;
+        if (tyLocal >= a.bandRows) return;
+        head = true;
+    }
     const int b = tyLocal * groupsX + gx;
     PROF_T(0);
     const int g = (tyLocal / GROUP) * groupsX + gx;
@@ -882,6 +914,8 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
 #pragma unroll
         for (int k = 0; k < CHUNK / 256; k++) e[k] = list[threadIdx.x + 256u * k];
         gn = a.groupCount[g];
+        if (!head && a.headRows > 0 && (gn == GROUP_OVERFLOW_LISTED || (gn != GROUP_OVERFLOW && (gn & GROUP_LISTED)))) return; // a listed cluster: the head rows have it
+        gn = gn >= GROUP_OVERFLOW_LISTED ? GROUP_OVERFLOW : (gn & ~GROUP_LISTED);
     }
 
     const int tx = gx * GROUP + wave;
@@ -1276,6 +1310,7 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     pa.zNearCam = frame->cameraZNearZFar[0];
     pa.planeMargin = 1e-3f;
     pa.dirFlag = (uint32_t*)(ws + L.offDirFlag);
+    pa.heavy = (uint32_t*)(ws + L.offHeavy);
     hipLaunchKernelGGL(k01_prepare, dim3(pa.lightRoleBlocks + pa.frustumBlocks + pa.setupBlocks), dim3(256), 0, s, pa);
     SAILOR_CHECK_LAUNCH(ctx, "k01_prepare");
 
@@ -1286,6 +1321,7 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     ca.N = N; ca.words = L.words; ca.Tx = L.Tx; ca.groupsX = L.groupsX; ca.bandRows = L.bandRows;
     // The hint pays for itself on split frames (a band's shade launch is bounded by its longest tile); on the whole frame it measured nothing.
     ca.classes = layout_has_hint(L) ? 1 : 0;
+    ca.heavy = (const uint32_t*)(ws + L.offHeavy); ca.headRows = 0;
     if (brute) {
         hipLaunchKernelGGL(k1_tile_cull<true>, dim3(L.groupsX, L.bandRows), dim3(256), 0, s, ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull<brute>");
@@ -1300,11 +1336,15 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
                 hipLaunchKernelGGL(k1_group_lists_wide<false>, wideGrid, dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
                                    (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag));
         }
-        else
+        else {
             hipLaunchKernelGGL(k1_group_lists, dim3(L.groupsX, L.groupsY), dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
-                               (uint32_t*)(ws + L.offGroupList));
+                               (uint32_t*)(ws + L.offGroupList), (uint32_t*)(ws + L.offHeavy));
+#ifndef CULL_NO_HEAD_ROWS
+            ca.headRows = (4 * HEAVY_MAX + L.groupsX - 1) / L.groupsX; // grid rows for the listed clusters' row blocks, in front of the tile rows
+#endif
+        }
         SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
-        hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.groupsX, L.bandRows), dim3(256), 0, s, ca);
+        hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.groupsX, ca.headRows + L.bandRows), dim3(256), 0, s, ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
     }
     PackArgs ka;
@@ -1390,7 +1430,8 @@ int sailor_hip_light_cull_diagnostics(SailorHipContext* ctx, int32_t width, int3
         if (i < (size_t)L.groupsX * L.words) colBits += c;
     }
     for (uint32_t c : counts) {
-        if (c == GROUP_OVERFLOW) { over++; continue; }
+        if (c >= GROUP_OVERFLOW_LISTED) { over++; continue; }
+        c &= ~GROUP_LISTED; // (a count may carry k1_group_lists' "listed cluster" flag)
         sum += c;
         if (c > longest) longest = c;
     }
