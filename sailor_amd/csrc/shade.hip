@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_self_check_exact_math(unsigned long lon
         const uint32_t re = (uint32_t)(rs >> 20);
         const float a = __uint_as_float((ra & 0x807FFFFFu) | ((79u + (re & 0xFFFu) % 113u) << 23));
         const float b = __uint_as_float((rb & 0x807FFFFFu) | ((87u + ((re >> 12) & 0xFFFu) % 81u) << 23));
-        badDiv += __float_as_uint(div_stored(a, b, rcp_of_sqrt(b), false)) != __float_as_uint(a / b) ? 1u : 0u;
+        badDiv += __float_as_uint(div_stored(a, b, rcp_of_sqrt(b))) != __float_as_uint(a / b) ? 1u : 0u;
     }
     if (badSqrt) atomicAdd(&bad[0], (unsigned long long)badSqrt);
     if (badRcp) atomicAdd(&bad[1], (unsigned long long)badRcp);

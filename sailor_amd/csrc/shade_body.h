@@ -243,11 +243,11 @@ __device__ __forceinline__ float rcp_of_sqrt(float s)
 // the correctly rounded reciprocal and q0 within an ulp of the quotient, q IS the correctly rounded quotient as long as nothing over- or
 // underflows on the way (4 instructions with v_div_fixup_f32 for 0 / inf / NaN operands against the IEEE division's 12; no mismatch in 2^36
 // random pairs and 36 special divisors x every significand, round 2).  "Nothing overflows" is the stager's business: it leaves NaN instead of
-// a reciprocal when |b| is outside [2^-40, 2^40] (the numerators here are a distance in [2^-48, 2^64] and a cosine difference), and a wave that
-// meets such a light takes the IEEE division (slowUniform, wave-uniform).
-__device__ __forceinline__ float div_stored(float a, float b, float y, bool slowUniform)
+// a reciprocal when |b| is outside [2^-40, 2^40] (the numerators here are a distance in [2^-48, 2^64] and a cosine difference) and marks the
+// light LIGHT_KIND_SLOW: its pairs take the IEEE division on a branch of their own (stage_light_record; was: a wave-uniform check in front
+// of every division -- nine instructions per batch of pairs for a light that practically never occurs).
+__device__ __forceinline__ float div_stored(float a, float b, float y)
 {
-    if (__builtin_expect(slowUniform, 0)) return a / b;
     const float q0 = a * y;
     return __builtin_amdgcn_div_fixupf(fmaf(fmaf(-b, q0, a), y, q0), b, a);
 }
@@ -278,6 +278,7 @@ __device__ __forceinline__ float dot3_pk(const v2f_ axy, const float az, const v
 }
 
 #define LREC 5 // float4 per staged light
+#define LIGHT_SLOW_SHIFT 24 // see stage_light_record
 
 // One light's record (SailorLightShaderData as seven float4) -> its staged form (the five float4 described at "Staged light record" below).
 // Used by k2_shade's own staging and by sailor_hip_prepare_lights (shade.hip), which runs it once per uploaded light instead of once per
@@ -305,18 +306,51 @@ __device__ __forceinline__ void stage_light_record(const float4 q0, const float4
     const float raFinite = isPointLight ? (r > 0.0f ? (r * r) * 1.00001f : __builtin_inff()) : -(q5.y - 1e-5f);
     const float ra = finite ? raFinite : __builtin_inff();
     const float rb = isPointLight ? r : q5.x - q5.y;
-    const uint32_t bits = (type < 255u ? type : 255u) | ((shadowType < 255u ? shadowType : 255u) << 8) | (finite ? 0x10000u : 0u);
+    // The staged KIND (low byte of rec1.w): 1 point, 2 spot, 3 any other type (no falloff: all the reference's branches pass it by), 0 the lights
+    // that are shaded one lane per PIXEL behind the pair queue: the directional ones, and (bits 24-25 = the type) a point / spot light whose
+    // divisor B (bounds.x / the cone's epsilon) lies outside [2^-40, 2^40], where the staged reciprocal cannot stand in for the IEEE division
+    // (see div_stored) -- the pair pass, which every ordinary pair runs, then needs no check for such a light.
+    const uint32_t rbExp = (__float_as_uint(rb) >> 23) & 0xFFu;
+    const bool storedOk = rbExp - 87u <= 80u;
+    const bool slow = (type == 1u || type == 2u) && !storedOk;
+    const uint32_t kind = slow ? 0u : (type < 3u ? type : 3u);
+    const uint32_t bits = kind | ((shadowType < 255u ? shadowType : 255u) << 8) | (finite ? 0x10000u : 0u) | (slow ? type << LIGHT_SLOW_SHIFT : 0u);
     o0 = make_float4(q1.x, q1.y, q1.z, ra);
     o1 = make_float4(ndx * linv, ndy * linv, ndz * linv, __uint_as_float(bits));
     o2 = make_float4(q4.x, q4.y, q4.z, rb);
     o3 = make_float4(ndx, ndy, ndz, q5.y);
-    const uint32_t rbExp = (__float_as_uint(rb) >> 23) & 0xFFu;
-    o4 = make_float4(q3.x, q3.y, q3.z, (rbExp - 87u <= 80u) ? rcp_of_sqrt(rb) : __builtin_nanf("")); // (rcp_of_sqrt: RN(1 / x) for every |x| in [2^-126, 2^126])
+    o4 = make_float4(q3.x, q3.y, q3.z, storedOk ? rcp_of_sqrt(rb) : __builtin_nanf("")); // (rcp_of_sqrt: RN(1 / x) for every |x| in [2^-126, 2^126])
 }
 #define PENDK 4  // queued pairs per pixel in one window (their queue positions ride in one register, 7 bits each under a sentinel bit)
 #define QMAX 128 // queued pairs per wave in one window (two lights that reach every pixel fit; positions are 7 bits; 17.4 KB of LDS per block, 9 blocks per CU)
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef v2f_ p2f;
+
+// The falloff of a point / spot light at one surface point (Standard.shader:286-307), exact: the oracle's op order where it is ill-conditioned.
+// R = the staged record, r0 / r1 = its first two float4, cutY = rec3.w, (wxy, wz) = the surface point.  SLOW: IEEE divisions instead of div_stored.
+template <typename SlowTag>
+__device__ __forceinline__ float exact_falloff(SlowTag, const bool isPoint, const float4* R, const float4 r0, const float4 r1, const float cutY, const p2f wxy, const float wz)
+{
+    constexpr bool SLOW = SlowTag::value;
+    const float4 r2 = R[2];
+    const float binv = reinterpret_cast<const float*>(R)[19]; // rec4.w = RN(1 / r2.w) (NaN for a SLOW light)
+    const p2f dxy = p2f{ r0.x, r0.y } - wxy;
+    const float dz = r0.z - wz;
+    const float d2 = dot3_pk(dxy, dz, dxy, dz);
+    const float dist = sqrt_exact(d2);                                       // exact: feeds 1 - (dist / bounds.x)^2
+    const float att = rcp_fast(fmaf(r2.z, d2, fmaf(r2.y, dist, r2.x))); // 1/(a.x + a.y d + a.z d^2) (:289,:300)
+    // point: dist / bounds.x (:290); spot: 1 / dist (normalize, :298)
+    const float xPoint = SLOW ? dist / r2.w : div_stored(dist, r2.w, binv), xSpot = rcp_of_sqrt(dist);
+    const float x = isPoint ? xPoint : xSpot;
+    if (isPoint) {
+        const float q = fminf(fmaxf(x, 0.0f), 1.0f);
+        return att * (1.0f - q * q);                                     // (:290)
+    }
+    const float theta = dot3_pk(dxy * x, dz * x, p2f{ r1.x, r1.y }, r1.z); // dot(normalize(pos - wp), normalize(-dir))
+    const float t = SLOW ? (theta - cutY) / r2.w : div_stored(theta - cutY, r2.w, binv);
+    const float f = att * fminf(fmaxf(t, 0.0f), 1.0f);                    // (:301); exact: cancels at the cone edge
+    return theta < cutY ? 0.0f : f;                                       // (:303-306)
+}
 
 // max of a non-negative (or NaN) float's bits over the wave as unsigned integers; the value of lane 63 (which holds the result) is returned.
 // (xor-1, xor-2, mirror within 8, mirror within 16, then the gfx9 row broadcasts 15 -> row+1 and 31 -> rows 2,3; a DPP read of a VGPR
@@ -736,8 +770,17 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         for (uint32_t base = 0u; base < cnt; base += 64u) {
             // one LANE per PAIR.  The pixel's invariants are pulled from its lane's registers (ds_bpermute: the LDS crossbar,
             // no LDS memory), the light record from LDS.  All 64 lanes execute the pulls (a disabled source lane returns 0).
+            // (the lanes past the last pair repeat the batch's FIRST pair and store the result in their own slot, which no pixel looks at: every
+            // lane runs the same straight code -- no `if (valid)` around the three stretches of arithmetic, which was 13 instructions of
+            // exec-mask bookkeeping and zero-initialisation per batch)
+#ifndef SHADE_MASK_TAIL
+            const uint32_t qi = base + (uint32_t)lane;
+            const uint32_t e = Q[qi < cnt ? qi : base];
+            constexpr bool valid = true;
+#else
             const uint32_t e = Q[base + (uint32_t)lane];
             const bool valid = base + (uint32_t)lane < cnt;
+#endif
             const int pa = (int)((e & 63u) << 2);
             const uint32_t s = (e >> 6) & (uint32_t)(KEEP - 1);
             const float4* R = sL + s * LREC;
@@ -752,30 +795,8 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
             if (valid) {
                 const float4 r0 = R[0], r1 = R[1];
                 const uint32_t type = __float_as_uint(r1.w) & 0xFFu;
-                if (type == 1u || type == 2u) {
-                    // exact falloff (the oracle's op order where it is ill-conditioned)
-                    const float4 r2 = R[2];
-                    const float binv = reinterpret_cast<const float*>(R)[19]; // rec4.w = 1 / r2.w, or NaN
-                    const bool slowDiv = __ballot(binv != binv) != 0ull;
-                    const p2f dxy = p2f{ r0.x, r0.y } - pwxy;
-                    const float dz = r0.z - pwz;
-                    const float d2 = dot3_pk(dxy, dz, dxy, dz);
-                    const float dist = sqrt_exact(d2);                                       // exact: feeds 1 - (dist / bounds.x)^2
-                    const float att = rcp_fast(fmaf(r2.z, d2, fmaf(r2.y, dist, r2.x))); // 1/(a.x + a.y d + a.z d^2) (:289,:300)
-                    const bool isPoint = type == 1u;
-                    // point: dist / bounds.x (:290); spot: 1 / dist (normalize, :298) -- both in four instructions, both for every lane, then selected
-                    const float xPoint = div_stored(dist, r2.w, binv, slowDiv), xSpot = rcp_of_sqrt(dist);
-                    const float x = isPoint ? xPoint : xSpot;
-                    if (isPoint) {
-                        const float q = fminf(fmaxf(x, 0.0f), 1.0f);
-                        falloff = att * (1.0f - q * q);                                  // (:290)
-                    } else {
-                        const float theta = dot3_pk(dxy * x, dz * x, p2f{ r1.x, r1.y }, r1.z); // dot(normalize(pos - wp), normalize(-dir))
-                        const float cutY = r3.w;
-                        falloff = att * fminf(fmaxf(div_stored(theta - cutY, r2.w, binv, slowDiv), 0.0f), 1.0f); // (:301); exact: cancels at the cone edge
-                        if (theta < cutY) falloff = 0.0f;                                     // (:303-306)
-                    }
-                }
+                if (type == 1u || type == 2u) // exact falloff (the oracle's op order where it is ill-conditioned)
+                    falloff = exact_falloff(std::false_type{}, type == 1u, R, r0, r1, r3.w, pwxy, pwz);
             }
             // (the pulls are spread out so that at most ten pulled values are live at a time: 64 VGPRs = 8 waves per SIMD)
             float spec = 0.0f, x5 = 0.0f, scale = 0.0f;
@@ -844,7 +865,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         if (!overflow) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    // ---- directional lights (type 0): every pixel is a pair, so they are shaded one LANE per PIXEL from the pixel's own registers -- no
+    // ---- directional lights (staged kind 0, with the odd point / spot light of stage_light_record): every pixel is a pair, so they are shaded one LANE per PIXEL from the pixel's own registers -- no
     // queue, no pulls -- in list order, nothing skipped (cosLi = 0 and non-finite intensities take their natural course).  K3, their
     // shadow factor (Standard.shader:266-283), is looked up here: a quadrant's pixels mostly share a cascade, so a wave rarely runs both
     // the EVSM and the 16-tap PCF path.  (Measured at C4: lookups in the pair pass 0.523 ms, here 0.448 ms; as a pass of their own that
@@ -858,9 +879,12 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
                 const int bit = __builtin_ctzll(todo);
                 const float4* R = sL + (uint32_t)(h * 64 + bit) * LREC;
                 const float4 r3 = R[3], r4 = R[4];
-                float shadow = 1.0f;
-                if (HAS_CSM)
-                    shadow = directional_shadow(A, C, (__float_as_uint(R[1].w) >> 8) & 0xFFu, -r3.x, -r3.y, -r3.z, nx, ny, nz, wx, wy, wz);
+                float shadow = 1.0f; // (for a light from far outside the staged reciprocal's range -- stage_light_record -- this is the falloff: IEEE divisions)
+                const uint32_t lbits = __builtin_amdgcn_readfirstlane(__float_as_uint(R[1].w));
+                if (__builtin_expect((lbits >> LIGHT_SLOW_SHIFT) != 0u, 0))
+                    shadow = exact_falloff(std::true_type{}, (lbits >> LIGHT_SLOW_SHIFT) == 1u, R, R[0], R[1], r3.w, wxyp, wz);
+                else if (HAS_CSM)
+                    shadow = directional_shadow(A, C, (lbits >> 8) & 0xFFu, -r3.x, -r3.y, -r3.z, nx, ny, nz, wx, wy, wz);
                 // ---- Cook-Torrance (Standard.shader:309-340), as in the pair pass ----
                 const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
                 float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;

@@ -8,7 +8,7 @@ import torch
 from oracle import oracle
 from sailor_amd import _lib, host, synth
 from conftest import oracle_tile_rows
-from sailor_amd.forward_plus import ForwardPlus, upload_lights, upload_shadow_maps
+from sailor_amd.forward_plus import ForwardPlus, PreparedLights, upload_lights, upload_shadow_maps
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
@@ -376,9 +376,10 @@ def test_lengths_outside_the_fast_square_root(ctx):
     assert (err <= RTOL * np.abs(ref[fin])).all(), (err / (np.abs(ref[fin]) + 1e-300)).max()
 
 
-def test_divisors_outside_the_staged_reciprocal(ctx):
+@pytest.mark.parametrize("prepared", [False, True])
+def test_divisors_outside_the_staged_reciprocal(ctx, prepared):
     """dist / bounds.x and (theta - cutOff.y) / epsilon run on a reciprocal staged with the light when the divisor lies in [2^-40, 2^40], and
-    on the IEEE division otherwise (wave-uniform): a point light with a radius of 1e15 (reaches everything, window ~1), one with 1e-15 at a
+    on the IEEE division otherwise (such a light is shaded one lane per pixel, behind the pair queue): a point light with a radius of 1e15 (reaches everything, window ~1), one with 1e-15 at a
     surface point, a spot light whose inner and outer cone coincide (epsilon = 0: x / 0), one with epsilon < 0."""
     f = synth.make_frame("tiny")
     W, H, N = f.cam.width, f.cam.height, len(f.lights)
@@ -394,8 +395,8 @@ def test_divisors_outside_the_staged_reciprocal(ctx):
     assert (idx[1: 1 + int(g[:, 1].sum())] == 0).sum() >= len(g) // 2, "the 1e15 light is in most lists"
     with np.errstate(all="ignore"):
         ref = oracle.shade(f.cam.frame, W, H, f.surface, lights, g, idx)
-    fp = ForwardPlus(ctx, W, H, N)
     l = upload_lights(lights, ctx.device)
+    fp = ForwardPlus(ctx, W, H, N, prepared=PreparedLights(ctx, l, N) if prepared else None)
     fp.cull(f.cam.frame, l, N, torch.from_numpy(f.depth).to(ctx.device))
     got = fp.shade(f.cam.frame, torch.from_numpy(f.surface).to(ctx.device), l, N).cpu().numpy()
     np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
