@@ -40,23 +40,25 @@
     }
 #define FORCE_64_VGPRS __attribute__((amdgpu_waves_per_eu(8, 8)))
 SHADE_ENTRY(k2_shade, FORCE_64_VGPRS, false, false, false)
-// (k2_shade_csm settles at 80 VGPRs = six waves per SIMD by itself; its prepared twin came out at 131 unpinned, at 80 without scratch pinned)
+// (the K3 kernels: 64 registers like the others since the shadow look-ups run before the view / material terms -- "K3 first" in shade_body.h; it
+// was 80 = six waves per SIMD.  The pin matters: unpinned, the prepared twins come out at 116-134.)
 #ifndef CSM_WAVES
-#define CSM_WAVES 6
+#define CSM_WAVES 8
 #endif
 #ifdef CSM_NO_PIN
 #define SIX_WAVES
 #else
 #define SIX_WAVES __attribute__((amdgpu_waves_per_eu(CSM_WAVES, CSM_WAVES)))
 #endif
+#define FIVE_WAVES __attribute__((amdgpu_waves_per_eu(5, 5))) // (K3 + ambient: 88-91 registers by itself; its prepared twin 134 unpinned)
 SHADE_ENTRY(k2_shade_csm, SIX_WAVES, true, false, false)
 SHADE_ENTRY(k2_shade_ibl, , false, true, false)
-SHADE_ENTRY(k2_shade_csm_ibl, , true, true, false)
+SHADE_ENTRY(k2_shade_csm_ibl, FIVE_WAVES, true, true, false)
 // the same kernels reading the records sailor_hip_prepare_lights staged (`lights` = the staged array)
 SHADE_ENTRY(k2_shade_p, FORCE_64_VGPRS, false, false, true)
 SHADE_ENTRY(k2_shade_csm_p, SIX_WAVES, true, false, true)
 SHADE_ENTRY(k2_shade_ibl_p, , false, true, true)
-SHADE_ENTRY(k2_shade_csm_ibl_p, , true, true, true)
+SHADE_ENTRY(k2_shade_csm_ibl_p, FIVE_WAVES, true, true, true)
 
 template <bool PREP>
 __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, int bandTiles, const float4* __restrict__ surface, size_t planeStride,
@@ -292,6 +294,7 @@ extern "C" int sailor_hip_shade_prepared(SailorHipContext* ctx, const SailorUboF
             memcpy(C.lightsMatrices[k].m, csm->lightsMatrices[k], 64);
             C.maps[k] = csm->maps[k];
             C.width[k] = csm->width[k]; C.height[k] = csm->height[k]; C.format[k] = csm->format[k];
+            C.texelW[k] = 1.0f / (float)csm->width[k]; C.texelH[k] = 1.0f / (float)csm->height[k];
             if (csm->maps[k]) {
                 if (csm->width[k] <= 0 || csm->height[k] <= 0 || csm->format[k] < 0 || csm->format[k] > 2) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
                 hasCsm = true;

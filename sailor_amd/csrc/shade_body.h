@@ -13,6 +13,7 @@ struct CsmArgs {
     int width[SAILOR_NUM_CSM_CASCADES];
     int height[SAILOR_NUM_CSM_CASCADES];
     int format[SAILOR_NUM_CSM_CASCADES];
+    float texelW[SAILOR_NUM_CSM_CASCADES], texelH[SAILOR_NUM_CSM_CASCADES]; // 1.0f / width, 1.0f / height (Lighting.glsl:171 texelSize), divided once on the host: the same IEEE quotient
 };
 
 struct IblArgs { // SailorIblDesc by value
@@ -112,14 +113,13 @@ __device__ __forceinline__ float sample_r16_pairs(const __half* __restrict__ map
 }
 
 // Lighting.glsl:242-261 ShadowCalculation_Pcf + :168-197 ManualPCF
-__device__ float shadow_pcf(const void* __restrict__ map, int fmt, int W, int H, float4 lp, float bias)
+__device__ float shadow_pcf(const void* __restrict__ map, int fmt, int W, int H, const float tsx, const float tsy, float4 lp, float bias)
 {
     float px = lp.x, py = lp.y, pz = lp.z;
     if (__ballot(lp.w != 1.0f) != 0ull) { px = px / lp.w; py = py / lp.w; pz = pz / lp.w; } // (x / 1 == x: see shadow_evsm)
     px = px * 0.5f + 0.5f; py = py * 0.5f + 0.5f; pz = pz * 0.5f + 0.5f;
     py = 1.0f - py;
     if (px > 1.0f || py > 1.0f || px < 0.0f || py < 0.0f || pz < 0.5f) return 1.0f;
-    const float tsx = 1.0f / (float)W, tsy = 1.0f / (float)H;
     float shadow = 0.0f;
     if (fmt == SAILOR_SHADOWMAP_R16_SFLOAT && W >= 2) {
         // the cascades' own format (ECS/LightingECS.h:57-58): 2 requests per tap, 8 taps = 16 requests in flight (the wave is bound by the
@@ -178,27 +178,42 @@ __device__ float shadow_evsm(const void* __restrict__ map, int fmt, int W, int H
 }
 
 // Standard.shader:266-283 + Lighting.glsl:200-216 SelectCascade
+// The look-up in one cascade.  `cascade` is either the wave's common cascade (a scalar: the matrix, the map and its size then come by scalar loads
+// from the argument segment and the matrix multiplies read them as scalar operands) or the lane's own (per-lane loads from the segment).
+__device__ __forceinline__ float cascade_shadow(const CsmArgs& C, const int cascade, const uint32_t shadowType, const float ndl, const float wx, const float wy, const float wz)
+{
+    const void* map = C.maps[cascade];
+    if (!map) return 1.0f;
+    const float4 lp = glsl_mul(C.lightsMatrices[cascade], wx, wy, wz, 1.0f);
+    if (shadowType == 2u && cascade == 0) {
+        const float bias = (1.0f - ndl) * (float)(1 + cascade);
+        return shadow_evsm(map, C.format[cascade], C.width[cascade], C.height[cascade], lp, bias, cascade);
+    }
+    const float bias = fmaxf(0.000075f * (1.0f - ndl), 0.000005f);
+    return shadow_pcf(map, C.format[cascade], C.width[cascade], C.height[cascade], C.texelW[cascade], C.texelH[cascade], lp, bias);
+}
+
 __device__ float directional_shadow(const ShadeArgs& A, const CsmArgs& C, uint32_t shadowType,
                                     float dirX, float dirY, float dirZ, float nx, float ny, float nz, float wx, float wy, float wz)
 {
     const float4 pv = glsl_mul(A.view, wx, wy, wz, 1.0f);
-    const float depthValue = fabsf(pv.z / pv.w);
+    // (a view matrix is affine: w is exactly 1 in every lane and z / 1 == z -- the correctly rounded division, 12 instructions, only where it is not)
+    float depthValue = pv.z;
+    if (__ballot(pv.w != 1.0f) != 0ull) depthValue = pv.z / pv.w;
+    depthValue = fabsf(depthValue);
     int cascade = SAILOR_NUM_CSM_CASCADES;
     const float levels[4] = { 0.05f, 0.1f, 0.333333f, 0.5f }; // Constants.glsl:24
 #pragma unroll
     for (int i = SAILOR_NUM_CSM_CASCADES - 1; i >= 0; i--)
         if (depthValue < A.zFar * levels[i]) cascade = i;
     cascade = min(cascade, SAILOR_NUM_CSM_CASCADES - 1);
-    const void* map = C.maps[cascade];
-    if (!map) return 1.0f;
-    const float4 lp = glsl_mul(C.lightsMatrices[cascade], wx, wy, wz, 1.0f);
     const float ndl = dot3f(nx, ny, nz, dirX, dirY, dirZ);
-    if (shadowType == 2u && cascade == 0) {
-        const float bias = (1.0f - ndl) * (float)(1 + cascade);
-        return shadow_evsm(map, C.format[cascade], C.width[cascade], C.height[cascade], lp, bias, cascade);
-    }
-    const float bias = fmaxf(0.000075f * (1.0f - ndl), 0.000005f);
-    return shadow_pcf(map, C.format[cascade], C.width[cascade], C.height[cascade], lp, bias);
+#ifndef CSM_PER_LANE_ONLY
+    // a wave is an 8 x 8-pixel quadrant: nearly always inside one cascade
+    const int common = __builtin_amdgcn_readfirstlane(cascade);
+    if (__ballot(cascade != common) == 0ull) return cascade_shadow(C, common, shadowType, ndl, wx, wy, wz);
+#endif
+    return cascade_shadow(C, cascade, shadowType, ndl, wx, wy, wz);
 }
 
 // ---- ambient / IBL term (Standard.shader:343-372), canonical samplers == oracle/sailor_oracle.c (tolerance-checked) ----
@@ -570,23 +585,36 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const p2f wxyp = { wx, wy };
     const p2f nxy = { P1.x, P1.y };
     const float nx = nxy.x, ny = nxy.y, nz = P1.z, roughness = P1.w;
-    const float metallic = P2.w;
-    const p2f vxy = wxyp - p2f{ A.camX, A.camY };
-    const float vz = wz - A.camZ;
-    const float vinv = rcp_of_sqrt(sqrt_exact(dot3_pk(vxy, vz, vxy, vz)));          // exact chain (see header)
-    const p2f Loxy = -(vxy * vinv);                                                  // Lo = -viewDirection
-    const float Lox = Loxy.x, Loy = Loxy.y, Loz = -(vz * vinv);
-    const float cosLo = fmaxf(0.0f, dot3_pk(nxy, nz, Loxy, Loz));
     float accX = 0.0f, accY = 0.0f, accZ = 0.0f;
-    const float oneMinusMetal = 1.0f - metallic;
-    // F0 = mix(0.04, albedo, metallic) and, below, F = F0 + (1 - F0) x5 in the oracle's own operations, unfused: the diffuse term is (1 - F) kd albedo,
-    // and on a bright metal (F0 -> 1) a half-ulp difference in F is 1e-4 of 1 - F (scripts/fuzz_parity.py found the pixel: roughness 0, so no
-    // specular term to hide it behind)
-    const float dielectric = 0.04f * oneMinusMetal;
-    const p2f F0xy = dielectric + p2f{ P2.x, P2.y } * metallic;
-    const float F0x = F0xy.x, F0y = F0xy.y, F0z = dielectric + P2.z * metallic;
-    const p2f kdAxy = oneMinusMetal * p2f{ P2.x, P2.y };                            // kd = (1 - F)(1 - metallic)
-    const float kdAx = kdAxy.x, kdAy = kdAxy.y, kdAz = oneMinusMetal * P2.z;
+    // The view vector, F0, kd * albedo and the Schlick-GGX terms of the view direction.  Computed HERE, while the light records are in flight, by
+    // the kernels without shadow maps; by the K3 kernels only after the shadow look-ups of the tile's directional lights ("K3 first" below): the
+    // look-up -- four 16-byte texels or eight PCF taps in flight -- and these 13 values are then never live together, and the K3 kernels fit the
+    // 64 registers of 8 waves per SIMD like the others (was: 80 registers, 6 waves).
+    p2f Loxy, F0xy, kdAxy;
+    float Lox, Loy, Loz, cosLo, F0x, F0y, F0z, kdAx, kdAy, kdAz, k, oneMinusK, g1Lo;
+    auto view_and_material = [&](const float camX, const float camY, const float camZ, const float one) {
+        const float metallic = P2.w;
+        const p2f vxy = wxyp - p2f{ camX, camY };
+        const float vz = wz - camZ;
+        const float vinv = rcp_of_sqrt(sqrt_exact(dot3_pk(vxy, vz, vxy, vz)));          // exact chain (see header)
+        Loxy = -(vxy * vinv);                                                            // Lo = -viewDirection
+        Lox = Loxy.x; Loy = Loxy.y; Loz = -(vz * vinv);
+        cosLo = fmaxf(0.0f, dot3_pk(nxy, nz, Loxy, Loz));
+        const float oneMinusMetal = one - metallic;
+        // F0 = mix(0.04, albedo, metallic) and, below, F = F0 + (1 - F0) x5 in the oracle's own operations, unfused: the diffuse term is (1 - F) kd albedo,
+        // and on a bright metal (F0 -> 1) a half-ulp difference in F is 1e-4 of 1 - F (scripts/fuzz_parity.py found the pixel: roughness 0, so no
+        // specular term to hide it behind)
+        const float dielectric = 0.04f * oneMinusMetal;
+        F0xy = dielectric + p2f{ P2.x, P2.y } * metallic;
+        F0x = F0xy.x; F0y = F0xy.y; F0z = dielectric + P2.z * metallic;
+        kdAxy = oneMinusMetal * p2f{ P2.x, P2.y };                                      // kd = (1 - F)(1 - metallic)
+        kdAx = kdAxy.x; kdAy = kdAxy.y; kdAz = oneMinusMetal * P2.z;
+        const float rr = roughness + one;
+        k = (rr * rr) * 0.125f; oneMinusK = one - k;
+        g1Lo = cosLo * rcp_fast(fmaf(cosLo, oneMinusK, k)); // GeometrySchlickG1(cosLo, k)
+    };
+    constexpr bool K3_FIRST = HAS_CSM && !HAS_IBL; // (the ambient term keeps the view and material terms live to the very end: with them the K3 + IBL kernels need 91 registers one way, 136 the other)
+    if constexpr (!K3_FIRST) view_and_material(A.camX, A.camY, A.camZ, 1.0f);
     {
         const unsigned long long bad = haveMask & ~stagedMask;
         if (lane == 0) sEnd[wave] = bad ? (uint32_t)(wave * 64 + __builtin_ctzll(bad)) : 0xFFFFFFFFu;
@@ -604,8 +632,6 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the records are in LDS (global loads may stay in flight)
     const uint32_t numLights = min(min(listNum, sEnd[0]), min(sEnd[1], min(sEnd[2], sEnd[3])));
     const float alpha = roughness * roughness, alphaSq = alpha * alpha;
-    const float rr = roughness + 1.0f, k = (rr * rr) * 0.125f, oneMinusK = 1.0f - k;
-    const float g1Lo = cosLo * rcp_fast(fmaf(cosLo, oneMinusK, k)); // GeometrySchlickG1(cosLo, k)
 
     // ---- which lights can reach this quadrant at all?  One LANE per LIGHT against the bounding SPHERE of the quadrant's 64 surface
     // points: centre = the pixel in its middle (lane 27), radius^2 = the largest squared distance to it (one max-reduction over the
@@ -665,6 +691,62 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         const unsigned long long share = 0x1111111111111111ull << __builtin_amdgcn_readfirstlane(wave); // (scalar: the masks stay in SGPRs)
 #pragma unroll
         for (int q = 0; q < 8; q++) seg[q] &= share;
+    }
+
+    // ---- directional lights (staged kind 0, with the odd point / spot light of stage_light_record): every pixel is a pair, so they are shaded one
+    // LANE per PIXEL from the pixel's own registers -- no queue, no pulls -- in list order, nothing skipped (cosLi = 0 and non-finite intensities
+    // take their natural course).  `shadow` = the light's K3 factor (Standard.shader:266-283), or the exact falloff of an odd light.
+    auto shade_directional = [&](const float4* R, const float shadow) {
+        const float4 r3 = R[3], r4 = R[4];
+        // ---- Cook-Torrance (Standard.shader:309-340), as in the pair pass ----
+        const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
+        float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;
+        const float hinv = rcp_of_sqrt(sqrt_exact(dot3f(hx, hy, hz, hx, hy, hz)));          // exact chain: Lh = normalize(Li + Lo)
+        hx *= hinv; hy *= hinv; hz *= hinv;
+        const float cosLi = fmaxf(0.0f, dot3f(nx, ny, nz, Lix, Liy, Liz));
+        const float cosLh = fmaxf(0.0f, dot3f(nx, ny, nz, hx, hy, hz));
+        const float x1 = 1.0f - fmaxf(0.0f, dot3f(hx, hy, hz, Lox, Loy, Loz));
+        const float x2 = x1 * x1, x5 = x2 * x2 * x1;
+        const float dn = (cosLh * cosLh) * (alphaSq - 1.0f) + 1.0f;
+        const float D = alphaSq * rcp_fast(3.14159265359f * dn * dn);
+        const float G = cosLi * rcp_fast(fmaf(cosLi, oneMinusK, k)) * g1Lo;
+        const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * cosLo));
+        const float scale = shadow * cosLi; // falloff = 1 (:287)
+        const float Fx = F0x + (1.0f - F0x) * x5, Fy = F0y + (1.0f - F0y) * x5, Fz = F0z + (1.0f - F0z) * x5;
+        accX += (fmaf(1.0f - Fx, kdAx, Fx * spec) * r4.x) * scale;
+        accY += (fmaf(1.0f - Fy, kdAy, Fy * spec) * r4.y) * scale;
+        accZ += (fmaf(1.0f - Fz, kdAz, Fz * spec) * r4.z) * scale;
+    };
+    // the factor of the light in list slot `slot`: its shadow look-up (K3), or the IEEE falloff of a light from far outside the staged reciprocal's range
+    auto directional_factor = [&](const int slot) -> float {
+        const float4* R = sL + (uint32_t)slot * LREC;
+        const uint32_t lbits = __builtin_amdgcn_readfirstlane(__float_as_uint(R[1].w));
+        if (__builtin_expect((lbits >> LIGHT_SLOW_SHIFT) != 0u, 0))
+            return exact_falloff(std::true_type{}, (lbits >> LIGHT_SLOW_SHIFT) == 1u, R, R[0], R[1], R[3].w, wxyp, wz);
+        if constexpr (HAS_CSM) {
+            const float4 r3 = R[3];
+            return directional_shadow(A, C, (lbits >> 8) & 0xFFu, -r3.x, -r3.y, -r3.z, nx, ny, nz, wx, wy, wz);
+        }
+        return 1.0f;
+    };
+    if constexpr (K3_FIRST) {
+        // ---- K3 first: per directional light its factor (one register), THEN the view / material terms, then the light's Cook-Torrance term.
+        // One round in practice (a tile with several directional lights repeats it and recomputes the terms: the camera position and the
+        // constant 1 they are computed from are made opaque, so that the compiler cannot hoist them out of the loop and across the look-up).
+        unsigned long long d0 = seg[6], d1 = seg[7];
+        do {
+            int slot = -1;
+            float f = 1.0f;
+            if ((d0 | d1) != 0ull) {
+                slot = d0 != 0ull ? __builtin_ctzll(d0) : 64 + __builtin_ctzll(d1);
+                if (d0 != 0ull) d0 &= d0 - 1ull; else d1 &= d1 - 1ull;
+                f = directional_factor(slot);
+            }
+            float camX = A.camX, camY = A.camY, camZ = A.camZ, one = 1.0f;
+            asm volatile("" : "+s"(camX), "+s"(camY), "+s"(camZ), "+s"(one));
+            view_and_material(camX, camY, camZ, one);
+            if (slot >= 0) shade_directional(sL + (uint32_t)slot * LREC, f);
+        } while ((d0 | d1) != 0ull);
     }
 
     // ---- 2 + 3. queue the (pixel, light) pairs that can be lit, then shade them one LANE per PAIR ----
@@ -865,45 +947,16 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         if (!overflow) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    // ---- directional lights (staged kind 0, with the odd point / spot light of stage_light_record): every pixel is a pair, so they are shaded one LANE per PIXEL from the pixel's own registers -- no
-    // queue, no pulls -- in list order, nothing skipped (cosLi = 0 and non-finite intensities take their natural course).  K3, their
-    // shadow factor (Standard.shader:266-283), is looked up here: a quadrant's pixels mostly share a cascade, so a wave rarely runs both
-    // the EVSM and the 16-tap PCF path.  (Measured at C4: lookups in the pair pass 0.523 ms, here 0.448 ms; as a pass of their own that
-    // leaves the factors for a 64-register shade kernel, 0.32 + 0.22 ms -- the lookups are bound by the scattered 16-byte texel reads of
-    // the 268 MB moments map, not by the registers around them.)
-    if ((seg[6] | seg[7]) != 0ull) {
+    if constexpr (!K3_FIRST) {
+        if ((seg[6] | seg[7]) != 0ull) {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            unsigned long long todo = seg[6 + h];
-            while (todo) {
-                const int bit = __builtin_ctzll(todo);
-                const float4* R = sL + (uint32_t)(h * 64 + bit) * LREC;
-                const float4 r3 = R[3], r4 = R[4];
-                float shadow = 1.0f; // (for a light from far outside the staged reciprocal's range -- stage_light_record -- this is the falloff: IEEE divisions)
-                const uint32_t lbits = __builtin_amdgcn_readfirstlane(__float_as_uint(R[1].w));
-                if (__builtin_expect((lbits >> LIGHT_SLOW_SHIFT) != 0u, 0))
-                    shadow = exact_falloff(std::true_type{}, (lbits >> LIGHT_SLOW_SHIFT) == 1u, R, R[0], R[1], r3.w, wxyp, wz);
-                else if (HAS_CSM)
-                    shadow = directional_shadow(A, C, (lbits >> 8) & 0xFFu, -r3.x, -r3.y, -r3.z, nx, ny, nz, wx, wy, wz);
-                // ---- Cook-Torrance (Standard.shader:309-340), as in the pair pass ----
-                const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
-                float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;
-                const float hinv = rcp_of_sqrt(sqrt_exact(dot3f(hx, hy, hz, hx, hy, hz)));          // exact chain: Lh = normalize(Li + Lo)
-                hx *= hinv; hy *= hinv; hz *= hinv;
-                const float cosLi = fmaxf(0.0f, dot3f(nx, ny, nz, Lix, Liy, Liz));
-                const float cosLh = fmaxf(0.0f, dot3f(nx, ny, nz, hx, hy, hz));
-                const float x1 = 1.0f - fmaxf(0.0f, dot3f(hx, hy, hz, Lox, Loy, Loz));
-                const float x2 = x1 * x1, x5 = x2 * x2 * x1;
-                const float dn = (cosLh * cosLh) * (alphaSq - 1.0f) + 1.0f;
-                const float D = alphaSq * rcp_fast(3.14159265359f * dn * dn);
-                const float G = cosLi * rcp_fast(fmaf(cosLi, oneMinusK, k)) * g1Lo;
-                const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * cosLo));
-                const float scale = shadow * cosLi; // falloff = 1 (:287)
-                const float Fx = F0x + (1.0f - F0x) * x5, Fy = F0y + (1.0f - F0y) * x5, Fz = F0z + (1.0f - F0z) * x5;
-                accX += (fmaf(1.0f - Fx, kdAx, Fx * spec) * r4.x) * scale;
-                accY += (fmaf(1.0f - Fy, kdAy, Fy * spec) * r4.y) * scale;
-                accZ += (fmaf(1.0f - Fz, kdAz, Fz * spec) * r4.z) * scale;
-                todo &= todo - 1ull;
+            for (int h = 0; h < 2; h++) {
+                unsigned long long todo = seg[6 + h];
+                while (todo) {
+                    const int slot = h * 64 + __builtin_ctzll(todo);
+                    shade_directional(sL + (uint32_t)slot * LREC, directional_factor(slot));
+                    todo &= todo - 1ull;
+                }
             }
         }
     }

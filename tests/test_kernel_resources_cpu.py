@@ -66,9 +66,18 @@ def test_k2_shade_fits_64_registers_without_scratch(resources, name):
 
 
 @pytest.mark.parametrize("name", ["k2_shade_csm", "k2_shade_csm_p"])
-def test_k2_shade_csm_keeps_six_waves_per_simd(resources, name):
+def test_k2_shade_csm_fits_64_registers_without_scratch(resources, name):
+    """The K3 kernels run their shadow look-ups before the view / material terms exist ("K3 first", shade_body.h) and so fit 8 waves per SIMD; with
+    24 bytes of scratch the same kernel was 310 us instead of 262 on C4 -- so no scratch at all."""
     k = find(resources["shade"], name)
-    assert k["vgpr_count"] <= 80 and waves_per_simd(k["vgpr_count"]) >= 6
+    assert k["vgpr_count"] <= 64 and waves_per_simd(k["vgpr_count"]) == 8
+    assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0
+
+
+@pytest.mark.parametrize("name", ["k2_shade_csm_ibl", "k2_shade_csm_ibl_p"])
+def test_k2_shade_csm_ibl_keeps_five_waves_per_simd(resources, name):
+    k = find(resources["shade"], name)
+    assert k["vgpr_count"] <= 96 and waves_per_simd(k["vgpr_count"]) >= 5
     assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0
 
 
