@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tile-rows", type=int, default=96)
     ap.add_argument("--exchange-every-step", action="store_true", help="include the RCCL list exchange in the timed region (N > 1)")
+    ap.add_argument("--list-sets", type=int, default=3, choices=[2, 3],
+                    help="sets of list buffers (grid / culledLights / workspace) the two-frames-in-flight pipeline rotates through: see capture_frame_pipeline")
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
                     help="2 (the reference's MaxFramesInQueue, RHI/Renderer.h:34): frame k+1's cull is recorded on a second stream beside frame k's shade")
     ap.add_argument("--plain-lights", action="store_true", help="no prepared lights: cull and shade read the 112-byte light records (rounds 1-2)")
@@ -524,38 +526,44 @@ def blur_block(ctx, steps: int):
 
 
 def capture_frame_pipeline(side, side2, unroll, shade_fns, cull_fns):
-    """One hipGraph holding `unroll` (even) steps of the two-frames-in-flight pipeline over two list sets: shade_fns[p]() records frame k's shade
-    from set p = k & 1 on `side`, cull_fns[p]() records frame k + 1's cull into set p on `side2`.  The only dependencies are the frames' own:
-    shade(k) waits for cull(k), cull(k + 1) for shade(k - 1) (it overwrites the set that frame read); one join at the end of the graph.  The
-    lists of frame 0 (set 0) must exist before the first replay."""
+    """One hipGraph holding `unroll` steps (a multiple of the number S of list sets) of the two-frames-in-flight pipeline: shade_fns[p]() records
+    frame k's shade from set p = k % S on `side`, cull_fns[q]() records frame k + 1's cull into set q = (k + 1) % S on `side2`.  The only
+    dependencies are the frames' own: shade(k) waits for cull(k), cull(k + 1) for the shade that last read its set, shade(k + 1 - S); one join at
+    the end of the graph.  The lists of frame 0 (set 0) must exist before the first replay.
+    S = 3 (the default): with two sets cull(k + 1) and shade(k) both start the moment shade(k - 1) ends, and the cross-queue wait sits on the
+    critical path -- the kernel trace shows ~10 us between the end of one shade and the start of the next (scripts/analysis/pipeline_timeline.py);
+    with a third set the cull waits for a shade that ended a frame ago, and the shades follow each other like launches on one stream."""
+    S = len(shade_fns)
+    assert len(cull_fns) == S
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=side):
-        shade_done = [None, None]
+        shade_done = [None] * S
         cull_done = None
         for k in range(unroll):
-            p = k & 1
+            p, q = k % S, (k + 1) % S
             if cull_done is not None:
                 side.wait_event(cull_done)
             shade_fns[p]()
             shade_done[p] = torch.cuda.Event(); shade_done[p].record(side)
-            if shade_done[1 - p] is not None:
-                side2.wait_event(shade_done[1 - p])
+            if shade_done[q] is not None:
+                side2.wait_event(shade_done[q])
             elif k == 0:
                 side2.wait_stream(side)  # fork
             with torch.cuda.stream(side2):
-                cull_fns[1 - p]()
+                cull_fns[q]()
                 cull_done = torch.cuda.Event(); cull_done.record(side2)
         side.wait_stream(side2)  # join
     return g
 
 
-def pipeline_unroll(steps: int):
-    """(U, r): the K timed steps are K // U replays of a U-step pipeline graph (U even: with two list sets a replay ends where it began) plus one
-    replay of an r-step graph for the rest, so that the timed region is exactly K steps whatever K is.  U = 0: only the tail graph (K = 1)."""
-    u = next((u for u in (16, 14, 12, 10, 8, 6, 4, 2) if steps % u == 0), 0)
+def pipeline_unroll(steps: int, sets: int = 2):
+    """(U, r): the K timed steps are K // U replays of a U-step pipeline graph (U a multiple of the number of list sets: a replay ends where it
+    began) plus one replay of an r-step graph for the rest, so that the timed region is exactly K steps whatever K is.  U = 0: only the tail graph."""
+    cands = [u for u in range(18, 0, -1) if u % sets == 0 and u >= 2]
+    u = next((u for u in cands if steps % u == 0), 0)
     if u:
         return u, 0
-    u = 10 if steps >= 10 else (steps - 1 if steps >= 3 else 0)
+    u = next((u for u in cands if u <= max(steps - 1, 0) and u <= 12), 0)
     return u, steps - (steps // u) * u if u else steps
 
 
@@ -569,14 +577,14 @@ def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev, prep=
     row_entries = sdist.row_cost_entries(g[:, 1].astype(np.int64), Tx)
     out = {"config": args.config, "split": G}
 
-    unroll = 0 if args.frames_in_flight == 1 else pipeline_unroll(args.steps)[0]
+    unroll = 0 if args.frames_in_flight == 1 else pipeline_unroll(args.steps, args.list_sets)[0]
     side = torch.cuda.current_stream()
-    side2 = torch.cuda.Stream(device=dev)
+    side2 = torch.cuda.Stream(device=dev, priority=int(os.environ.get('SAILOR_CULL_PRIORITY', '0')))
     ctx2 = HipContext(dev, stream=side2)
 
     def time_band(b):
         """ms per step of band b alone on this GPU, launched the way a rank of the split frame launches it (the main path's pipeline graph)"""
-        fs = [ForwardPlus(ctx, W, H, N, band=b, prepared=prep) for _ in range(2 if unroll else 1)]
+        fs = [ForwardPlus(ctx, W, H, N, band=b, prepared=prep) for _ in range(args.list_sets if unroll else 1)]
         dd = torch.from_numpy(np.ascontiguousarray(frame.depth[b.fbRowBegin:b.fbRowBegin + b.fbRowCount])).to(dev)
         ds = torch.from_numpy(frame.surface_rows(b.fbRowBegin, b.fbRowBegin + b.fbRowCount)).to(dev)
         for f in fs:
@@ -614,7 +622,7 @@ def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev, prep=
         ms = [time_band(host.band_from_tile_rows(W, H, bounds[r], bounds[r + 1])) for r in range(G)]
         out[name] = {"bounds": [int(b) for b in bounds], "band_ms": ms, "max_ms": max(ms), "predicted_speedup": whole / max(ms)}
     out["whole_frame_ms"] = whole
-    out["launch"] = f"hipGraph replay ({unroll} steps of the frame pipeline per graph), 2 frames in flight" if unroll else "hipGraph replay, 1 frame in flight"
+    out["launch"] = f"hipGraph replay ({unroll} steps of the frame pipeline per graph), 2 frames in flight over {args.list_sets} list sets" if unroll else "hipGraph replay, 1 frame in flight"
     print(json.dumps(out), flush=True)
 
 
@@ -749,13 +757,12 @@ def main():
     # kernels slides under the neighbouring shades (0.219 ms, measured first with eager launches on two streams: scripts/cu_mask_probe.py).
     # The main graph's length is even (two list sets: a replay ends where it began); a K that no even length divides gets a second, shorter graph
     # for the rest, so the timed region is exactly K steps (pipeline_unroll).
-    unroll, tail = pipeline_unroll(args.steps)
+    unroll, tail = pipeline_unroll(args.steps, args.list_sets)
     if pipelined:
         try:
-            side2 = torch.cuda.Stream(device=dev)
+            side2 = torch.cuda.Stream(device=dev, priority=int(os.environ.get('SAILOR_CULL_PRIORITY', '0')))
             ctx2 = HipContext(dev, stream=side2)
-            fp2, _dd = resident(band)   # second set of grid / culledLights / workspace
-            fps = (fp, fp2)
+            fps = (fp,) + tuple(resident(band)[0] for _ in range(args.list_sets - 1))   # further sets of grid / culledLights / workspace
             for f in fps:               # eager warm-up of both sets (also sizes every internal buffer before capture)
                 f.cull(cam.frame, d_lights, N, d_depth)
                 f.shade(cam.frame, d_surface, d_lights, N, csm)
@@ -1016,7 +1023,7 @@ def main():
         out = {
             "metric": "lit Mpixels/s (K0+K1 tile light cull + K2 PBR shade over per-tile lists)", "value": value, "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_ms": args.spinup_ms, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak" if weak else "strong", "launch": f"hipGraph replay ({per_run} steps of the frame pipeline per graph" + (f", {tail} in the last" if unroll and tail else "") + "), 2 frames in flight" if pipelined else ("hipGraph replay" if graph is not None else "eager"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if weak else "strong", "launch": f"hipGraph replay ({per_run} steps of the frame pipeline per graph" + (f", {tail} in the last" if unroll and tail else "") + f"), 2 frames in flight over {args.list_sets} list sets" if pipelined else ("hipGraph replay" if graph is not None else "eager"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H}, {N} point+spot lights, 16x16 tiles ({fp.Tx}x{fp.Ty}), cull + PBR shade"
                                    + (" + 4-cascade CSM" if csm is not None else ""),
                        "width": W, "height": H, "lights": N, "parallelism": (f"dp{world}: a whole frame per GPU" if weak else f"tile-row bands x{world}"), "partition": partition,
