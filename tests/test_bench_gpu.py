@@ -25,7 +25,7 @@ def test_default_line_carries_the_contract():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert key in d, key
     assert d["unit"] == "Mpixels/s" and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
-    assert "4 steps of the frame pipeline per graph, 1 in the last" in d["launch"]   # an odd K: exactly K steps all the same
+    assert "3 steps of the frame pipeline per graph, 2 in the last" in d["launch"] and "3 list sets" in d["launch"]   # K not a multiple of the list sets: exactly K steps all the same
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and d["scaling"] in ("weak", "strong")
     assert d["config"]["workload"].startswith("C3: 3840x2160, 65536 ") and "model" not in d["config"]
     assert abs(d["value"] - 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
@@ -60,16 +60,18 @@ def test_one_rank_process_group_runs_both_multi_gpu_modes(split_primary):
     assert d["step_ms"]["p10"] <= d["step_ms"]["median"] <= d["step_ms"]["p90"]
 
 
-def test_even_step_counts_run_the_frame_pipeline_graph():
-    d = _run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2", "--spinup-ms", "50", "--no-cpu-baseline"])
-    assert "8 steps of the frame pipeline per graph" in d["launch"] and d["steps"] == 8
+@pytest.mark.parametrize("sets, steps", [(3, 12), (2, 8)])
+def test_step_counts_the_list_sets_divide_run_one_pipeline_graph(sets, steps):
+    d = _run([sys.executable, "bench.py", "--steps", str(steps), "--warmup", "2", "--spinup-ms", "50", "--no-cpu-baseline", "--list-sets", str(sets)])
+    assert f"{steps} steps of the frame pipeline per graph)" in d["launch"] and f"{sets} list sets" in d["launch"] and d["steps"] == steps
     assert abs(d["value"] - 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
     assert d["step_ms"]["p10"] <= d["step_ms"]["median"] <= d["step_ms"]["p90"]
 
 
-def test_the_frame_pipeline_graph_leaves_the_frames_results():
-    """The pipeline graph orders two streams by the frames' own dependencies only (shade(k) after cull(k), cull(k + 1) after shade(k - 1)).  Run it
-    with DIFFERENT light sets in the two list sets -- a missing dependency would shade a frame from the other frame's lists -- and compare what
+@pytest.mark.parametrize("sets", [2, 3])
+def test_the_frame_pipeline_graph_leaves_the_frames_results(sets):
+    """The pipeline graph orders two streams by the frames' own dependencies only (shade(k) after cull(k), cull(k + 1) after the shade that last
+    read its list set).  Run it with DIFFERENT light sets in the list sets -- a missing dependency would shade a frame from the other frame's lists -- and compare what
     every set holds afterwards with plain stream-ordered launches."""
     import numpy as np
     import torch
@@ -85,30 +87,32 @@ def test_the_frame_pipeline_graph_leaves_the_frames_results():
         ctx, ctx2 = HipContext(dev, stream=side), HipContext(dev, stream=side2)
         d_depth = torch.from_numpy(np.ascontiguousarray(f.depth)).to(dev)
         d_surface = torch.from_numpy(np.ascontiguousarray(f.surface)).to(dev)
-        lights_b = f.lights.copy()
-        lights_b["worldPosition"][:, 0] += 3.0   # the other frame: every light moved
-        d_l = [upload_lights(f.lights, dev), upload_lights(lights_b, dev)]
-        fps = [ForwardPlus(ctx, W, H, N) for _ in range(2)]
-        outs = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        d_l = []
+        for p in range(sets):   # the other frames: every light moved
+            lights_p = f.lights.copy()
+            lights_p["worldPosition"][:, 0] += 3.0 * p
+            d_l.append(upload_lights(lights_p, dev))
+        fps = [ForwardPlus(ctx, W, H, N) for _ in range(sets)]
+        outs = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(sets)]
         ref = []
-        for p in range(2):   # reference: stream order, one frame after the other
+        for p in range(sets):   # reference: stream order, one frame after the other
             fps[p].cull(cam.frame, d_l[p], N, d_depth)
             fps[p].shade(cam.frame, d_surface, d_l[p], N, None, out=outs[p])
             torch.cuda.synchronize()
             g, idx = fps[p].lists_to_host()
             ref.append((g, idx, outs[p].cpu().numpy().copy()))
             outs[p].zero_()
-        assert not np.array_equal(ref[0][1], ref[1][1])
+        assert all(not np.array_equal(ref[0][1], ref[p][1]) for p in range(1, sets))
         torch.cuda.synchronize()
         graph = bench.capture_frame_pipeline(side, side2, 6,
-                                             [lambda p=p: fps[p].shade(cam.frame, d_surface, d_l[p], N, None, out=outs[p]) for p in range(2)],
-                                             [lambda p=p: fps[p].cull(cam.frame, d_l[p], N, d_depth, ctx=ctx2) for p in range(2)])
+                                             [lambda p=p: fps[p].shade(cam.frame, d_surface, d_l[p], N, None, out=outs[p]) for p in range(sets)],
+                                             [lambda p=p: fps[p].cull(cam.frame, d_l[p], N, d_depth, ctx=ctx2) for p in range(sets)])
         fps[0].cull(cam.frame, d_l[0], N, d_depth)   # the prologue: frame 0's lists
         torch.cuda.synchronize()
         for _ in range(3):
             graph.replay()
         torch.cuda.synchronize()
-        for p in range(2):
+        for p in range(sets):
             g, idx = fps[p].lists_to_host()
             np.testing.assert_array_equal(g, ref[p][0])
             np.testing.assert_array_equal(idx, ref[p][1])
