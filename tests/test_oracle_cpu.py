@@ -916,3 +916,81 @@ def test_ibl_bakes_against_the_float64_restatement():
         rel = np.abs(got - q) / np.abs(q)
         assert rel.max() <= tol, (level, rel.max())
         assert np.percentile(rel, 50) <= tol / 20, (level, np.percentile(rel, 50))
+
+
+# ---- known answers worked out by hand from the shader's formulas (Standard.shader:286-340): independent of both restatements ----
+from known_answers import one_light_frame as _one_light_frame, point_light_at_normal_incidence  # noqa: E402
+
+
+@pytest.mark.parametrize("roughness, metallic", [(1.0, 0.0), (0.5, 0.0), (0.7, 1.0), (0.35, 0.6)])
+def test_known_answer_point_light_at_normal_incidence(roughness, metallic):
+    """n = Lo = Li = Lh: F = F0 (Schlick at cos = 1), NdfGGX = 1 / (pi a^2) with a = roughness^2 (:316-322: a2 / (pi (cos^2 (a2 - 1) + 1)^2) at
+    cos = 1), both Schlick-GGX G1 terms are 1 (x / (x (1 - k) + k) at x = 1), so specular = F0 / (4 pi a^2); kd = (1 - F0)(1 - metallic); the
+    point falloff is (1 - (d / r)^2) / (a.x + a.y d + a.z d^2) (:289-290).  radiance = (kd albedo + specular) intensity falloff."""
+    got, want = point_light_at_normal_incidence(roughness, metallic)
+    np.testing.assert_allclose(got[:3], want, rtol=3e-5)
+
+
+def test_known_answer_point_light_window_and_attenuation():
+    """On the sphere of radius bounds.x the window 1 - (d / r)^2 is exactly 0 and beyond it clamps to 0 (:290); at d = r / 2 it is 3 / 4."""
+    albedo, intensity, att = (1.0, 1.0, 1.0), (1.0, 1.0, 1.0), (1.0, 0.0, 0.0)
+    inside, _, d_in = _one_light_frame(host.LIGHT_POINT, 1.0, 0.0, albedo, 50.0, 100.0, att, intensity)
+    beyond, _, _ = _one_light_frame(host.LIGHT_POINT, 1.0, 0.0, albedo, 150.0, 100.0, att, intensity)
+    base = 0.96 + 0.04 / (4 * np.pi)   # kd albedo + F0 / (4 pi a^2) at roughness 1
+    np.testing.assert_allclose(inside[:3], base * (1 - (d_in / 100.0) ** 2), rtol=3e-5)
+    assert (beyond[:3] == 0).all()
+
+
+def test_known_answer_spot_light_cone():
+    """theta = cos of the angle between the light's axis and the direction to the surface point; intensity = clamp((theta - cutOff.y) / (cutOff.x -
+    cutOff.y), 0, 1) times 1 / (a.x + a.y d + a.z d^2), and exactly 0 outside the outer cone (:297-306).  On the axis: 1; half way between the
+    cones' cosines: 1 / 2; outside: 0."""
+    albedo, intensity, att, d = (0.5, 0.5, 0.5), (2.0, 2.0, 2.0), (1.0, 0.01, 0.0), 30.0
+    c_in, c_out = np.cos(np.radians(20.0)), np.cos(np.radians(40.0))
+    base = (0.96 * 0.5 + 0.04 / (4 * np.pi)) * 2.0
+
+    def want(theta, d32):
+        return base * min(max((theta - c_out) / (c_in - c_out), 0.0), 1.0) / (att[0] + att[1] * d32)
+
+    on_axis, _, d32 = _one_light_frame(host.LIGHT_SPOT, 1.0, 0.0, albedo, d, 1e9, att, intensity, cut_off=(c_in, c_out), off_axis=0.0)
+    np.testing.assert_allclose(on_axis[:3], want(1.0, d32), rtol=3e-5)
+    mid_angle = np.arccos((c_in + c_out) / 2)
+    mid, _, d32 = _one_light_frame(host.LIGHT_SPOT, 1.0, 0.0, albedo, d, 1e9, att, intensity, cut_off=(c_in, c_out), off_axis=mid_angle)
+    # (tilting the axis tilts Li = -direction with it: cosLi = cosLh-chain changes, so compare the CONE factor through the ratio to a wide cone)
+    wide, _, _ = _one_light_frame(host.LIGHT_SPOT, 1.0, 0.0, albedo, d, 1e9, att, intensity, cut_off=(np.cos(mid_angle) - 1e-3, -1.0), off_axis=mid_angle)
+    np.testing.assert_allclose(mid[:3] / wide[:3], 0.5, rtol=2e-4)
+    outside, _, _ = _one_light_frame(host.LIGHT_SPOT, 1.0, 0.0, albedo, d, 1e9, att, intensity, cut_off=(c_in, c_out), off_axis=np.radians(50.0))
+    assert (outside[:3] == 0).all()
+
+
+def test_known_answer_light_cull_membership():
+    """K1 from its definition: a small sphere in the middle of one tile's frustum slab is in that tile's list and in no other; a sphere behind the
+    eye is in none; a sphere that contains the whole view volume is in every tile that has depth.  (Positions through the camera's own matrices:
+    view space looks down -z, Appendix D.)"""
+    f = synth.make_frame("tiny")
+    W, H = f.cam.width, f.cam.height
+    Tx, Ty = oracle.num_tiles(W, H)
+    depth = np.full((H, W), 100.0, np.float32)           # a wall 100 units in front of the eye
+    world = np.asarray(f.cam.world, np.float64).reshape(4, 4)   # column-major: rows of this array are the matrix' columns
+    tan_half = np.tan(np.radians(f.cam.fov) / 2)
+    aspect = W / H
+
+    def view_to_world(x, y, z):
+        return (world[0, :3] * x + world[1, :3] * y + world[2, :3] * z + world[3, :3]).astype(np.float32)
+
+    def centre_of_tile(tx, ty, dist):   # the view-space point `dist` in front of the eye on the ray through the tile's centre (tile row 0 = the BOTTOM 16 rows: Appendix D)
+        ndc_x = (tx * 16 + 8) / W * 2 - 1
+        ndc_y = (ty * 16 + 8) / H * 2 - 1
+        return view_to_world(ndc_x * tan_half * aspect * dist, ndc_y * tan_half * dist, -dist)
+
+    lights = np.zeros(3, host.LIGHT_DTYPE)
+    lights["type"] = host.LIGHT_POINT
+    tx, ty = Tx // 2, Ty // 3
+    lights["worldPosition"][0] = centre_of_tile(tx, ty, 100.0); lights["bounds"][0] = 0.05    # 0.05 units: far inside one tile (a tile is ~ 100 * 2 tan / H * 16 wide)
+    lights["worldPosition"][1] = view_to_world(0.0, 0.0, +50.0); lights["bounds"][1] = 10.0   # behind the eye
+    lights["worldPosition"][2] = view_to_world(0.0, 0.0, -100.0); lights["bounds"][2] = 1e6   # contains everything
+    g, idx, _ = oracle.light_cull(f.cam.frame, W, H, lights, depth)
+    lists = [set(idx[o: o + n].tolist()) for o, n in g]
+    for t, l in enumerate(lists):
+        assert 1 not in l and 2 in l
+        assert (0 in l) == (t == ty * Tx + tx), (t, ty * Tx + tx)

@@ -482,3 +482,21 @@ def test_c5_shade_8k(ctx):
     del b, f2
     spans = [(r, 1) for r in range(7, 270, 24)] if oracle.host_threads() >= 32 else [(131, 1), (17, 1)]
     assert_oracle_rows(f, a, oracle_tile_rows(270, spans, whole_from_threads=1 << 30), gpu_lists=(g, idx))
+
+
+@pytest.mark.parametrize("prepared", [False, True])
+@pytest.mark.parametrize("roughness, metallic", [(1.0, 0.0), (0.5, 0.0), (0.35, 0.6)])
+def test_known_answer_point_light_at_normal_incidence_on_the_hip_path(ctx, roughness, metallic, prepared):
+    """The closed form of tests/known_answers.py (worked out by hand from Standard.shader:286-340, no oracle involved) against the HIP path itself."""
+    from known_answers import point_light_at_normal_incidence
+
+    def hip_shade(frame, W, H, surface, lights, grid, idx):
+        N = len(lights)
+        l = upload_lights(lights, ctx.device)
+        fp = ForwardPlus(ctx, W, H, N, prepared=PreparedLights(ctx, l, N) if prepared else None)
+        fp.grid.copy_(torch.from_numpy(grid.astype(np.int32).reshape(-1)).to(ctx.device).view(fp.grid.dtype)[: fp.grid.numel()])
+        fp.culled[: len(idx)].copy_(torch.from_numpy(idx.astype(np.int32)).to(ctx.device).view(fp.culled.dtype))
+        return fp.shade(frame, torch.from_numpy(surface).to(ctx.device), l, N).cpu().numpy()
+
+    got, want = point_light_at_normal_incidence(roughness, metallic, shade=hip_shade)
+    np.testing.assert_allclose(got[:3], want, rtol=3e-5)
