@@ -6,7 +6,7 @@ from oracle import oracle
 from sailor_amd import host, synth
 
 
-def one_light_frame(light_type, roughness, metallic, albedo, dist, radius, attenuation, intensity, cut_off=None, off_axis=None, shade=None):
+def one_light_frame(light_type, roughness, metallic, albedo, dist, radius, attenuation, intensity, cut_off=None, off_axis=None, shade=None, shadow_type=0, csm=None):
     """The tiny frame with ONE pixel set up for a closed form: its normal points at the camera (n = Lo), the light hangs `dist` along the normal and
     its `direction` field is -n (the shader's Li is -light.direction for every type), so cosLi = cosLh = cosLo = 1 and Lh = n."""
     f = synth.make_frame("tiny")
@@ -21,6 +21,7 @@ def one_light_frame(light_type, roughness, metallic, albedo, dist, radius, atten
     surface[2, py, px] = np.float32(list(albedo) + [metallic])
     lights = np.zeros(1, host.LIGHT_DTYPE)
     lights["type"] = light_type
+    lights["shadowType"] = shadow_type
     pos = wp + n * dist
     axis = n
     if off_axis is not None:   # a spot light whose axis is tilted by `off_axis` radians away from the direction to the surface point
@@ -36,7 +37,7 @@ def one_light_frame(light_type, roughness, metallic, albedo, dist, radius, atten
     Tx, Ty = oracle.num_tiles(W, H)
     grid = np.zeros((Tx * Ty, 2), np.uint32); grid[:, 0] = 1 + np.arange(Tx * Ty); grid[:, 1] = 1   # every tile: the list [0]
     idx = np.zeros(1 + Tx * Ty, np.uint32); idx[0] = Tx * Ty
-    out = (shade or oracle.shade)(f.cam.frame, W, H, surface, lights, grid, idx)
+    out = (shade or oracle.shade)(f.cam.frame, W, H, surface, lights, grid, idx, *([csm] if csm is not None else []))
     # what float32 storage made of the set-up (the closed form is evaluated on the stored values)
     n32 = surface[1, py, px, :3].astype(np.float64)
     d32 = np.linalg.norm(lights["worldPosition"][0].astype(np.float64) - wp)

@@ -994,3 +994,22 @@ def test_known_answer_light_cull_membership():
     for t, l in enumerate(lists):
         assert 1 not in l and 2 in l
         assert (0 in l) == (t == ty * Tx + tx), (t, ty * Tx + tx)
+
+
+def test_known_answer_directional_light_behind_a_constant_shadow_map():
+    """K3's PCF from its definition (Lighting.glsl:168-197, :242-261): a light matrix that sends every point to the middle of the map at clip depth z0,
+    maps holding the constant v.  Stored depth = v / 2 + 1 / 2, the fragment's = z0 / 2 + 1 / 2: all sixteen taps pass (factor 1) when the fragment is
+    nearer than the map (reversed Z: larger), none (factor 0, radiance exactly 0) when it is farther, and 1 without a look-up below depth 1 / 2.  The
+    unshadowed radiance is the normal-incidence closed form with falloff 1 (:287)."""
+    albedo, intensity = (0.8, 0.5, 0.25), (3.0, 2.0, 5.0)
+    F0 = 0.04
+    want = ((1 - F0) * np.array(albedo) + F0 / (4 * np.pi)) * np.array(intensity)   # roughness 1, metallic 0
+    v = 0.2
+    maps = [np.zeros((64, 64, 4), np.float32)] + [np.full((64, 64), v, np.float16) for _ in range(3)]
+    maps[0][..., 0] = v   # a PCF light reads cascade 0's red channel
+    for z0, factor in ((0.6, 1.0), (0.1, 0.0), (-0.5, 1.0)):
+        lm = np.zeros((4, 16), np.float32)
+        lm[:, 14] = z0; lm[:, 15] = 1.0   # column-major: the last column = (0, 0, z0, 1)
+        csm, _keep = oracle.make_csm(lm, maps)
+        got, _, _ = _one_light_frame(host.LIGHT_DIRECTIONAL, 1.0, 0.0, albedo, 1.0, 1.0, (1.0, 0.0, 0.0), intensity, shadow_type=host.SHADOW_PCF, csm=csm)
+        np.testing.assert_allclose(got[:3], want * factor, rtol=3e-5, atol=0.0)
