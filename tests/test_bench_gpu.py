@@ -36,6 +36,9 @@ def test_default_line_carries_the_contract():
     assert r["traffic"] is None or r["traffic"] > 0.9 * r["bytes_per_launch"]
     # round 3: per-kernel figures are medians of >= 5 batches of >= 50 launches whatever --steps is, and the line carries the serial reading of the step
     assert r["avg_launch_ms_min_max"][0] <= r["avg_launch_ms"] <= r["avg_launch_ms_min_max"][1] and "median of 5 batches of 50" in r["timing"]
+    # the in-frame figure (serial step minus cull chain) and the back-to-back one: the former within 10 % of the committed trace, the latter above it
+    assert abs(r["avg_launch_ms"] - (d["serial_step_ms"]["median"] - d["cull_ms"])) < 1e-9
+    assert r["back_to_back_launch_ms"] > 0 and abs(r["avg_launch_ms"] / r["rocprof_kernel_avg_ms"] - 1.0) < 0.10
     assert d["value_serial"] > 0 and d["serial_step_ms"]["min"] <= d["serial_step_ms"]["median"] <= d["serial_step_ms"]["max"]
     assert abs(d["value_serial"] - 3840 * 2160 / (d["serial_step_ms"]["median"] * 1e-3) / 1e6) < 1e-6 * d["value_serial"]
     assert d["value_serial"] < d["value"] * 1.02, "one frame in flight is not faster than two"
