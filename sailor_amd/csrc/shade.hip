@@ -46,17 +46,17 @@ SHADE_ENTRY(k2_shade, FORCE_64_VGPRS, false, false, false)
 #define CSM_WAVES 8
 #endif
 #ifdef CSM_NO_PIN
-#define SIX_WAVES
+#define CSM_PIN
 #else
-#define SIX_WAVES __attribute__((amdgpu_waves_per_eu(CSM_WAVES, CSM_WAVES)))
+#define CSM_PIN __attribute__((amdgpu_waves_per_eu(CSM_WAVES, CSM_WAVES)))
 #endif
 #define FIVE_WAVES __attribute__((amdgpu_waves_per_eu(5, 5))) // (K3 + ambient: 88-91 registers by itself; its prepared twin 134 unpinned)
-SHADE_ENTRY(k2_shade_csm, SIX_WAVES, true, false, false)
+SHADE_ENTRY(k2_shade_csm, CSM_PIN, true, false, false)
 SHADE_ENTRY(k2_shade_ibl, , false, true, false)
 SHADE_ENTRY(k2_shade_csm_ibl, FIVE_WAVES, true, true, false)
 // the same kernels reading the records sailor_hip_prepare_lights staged (`lights` = the staged array)
 SHADE_ENTRY(k2_shade_p, FORCE_64_VGPRS, false, false, true)
-SHADE_ENTRY(k2_shade_csm_p, SIX_WAVES, true, false, true)
+SHADE_ENTRY(k2_shade_csm_p, CSM_PIN, true, false, true)
 SHADE_ENTRY(k2_shade_ibl_p, , false, true, true)
 SHADE_ENTRY(k2_shade_csm_ibl_p, FIVE_WAVES, true, true, true)
 
