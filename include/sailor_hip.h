@@ -523,8 +523,9 @@ SAILOR_HIP_API int sailor_hip_allgather_u32(SailorHipContext* ctx, void* comm, c
 /* The whole exchange of a split frame (the reference's single Dispatch at FrameGraph/LightCullingNode.cpp:74-77 fills ONE pair of
  * buffers, a split frame has one pair per band): every rank hands in the lists of its band (sailor_hip_band_for_rank(width, height, rank,
  * worldSize), as sailor_hip_light_cull left them) and gets the reference's global `lightsGrid` (tiles x {offset, num}) and `culledLights`
- * ([0] = sum of num, then the lists at the canonical offsets) -- three ncclAllGather of fixed-size slots on the context's stream (band total;
- * index segment; grid) and one stitch kernel that takes each band's global base from the gathered totals on the device.  Nothing synchronises.
+ * ([0] = sum of num, then the lists at the canonical offsets) -- three ncclAllGather on the context's stream (band total; index segments in slots
+ * of the largest band's total; grid) and one stitch kernel that takes each band's global base from the gathered totals on the device.  The
+ * gathered totals are read back once (a few words and a stream synchronisation) to size the second gather: the call must not be stream-captured.
  *   comm          : an ncclComm_t of `worldSize` ranks created by the host (RCCL over xGMI)
  *   dGlobalCulled : globalCapacity uints, 1 + tiles * 128 holds every result
  *   dWorkspace    : sailor_hip_exchange_workspace_size(width, height, worldSize) bytes, 256-byte aligned */

@@ -50,9 +50,9 @@ extern "C" int sailor_hip_allgather_u32(SailorHipContext* ctx, void* comm, const
 }
 
 // ---- the whole exchange of a split frame: band lists -> the reference's global lightsGrid / culledLights on every rank --------
-// Three all-gathers of fixed-size slots (band total; index segment padded to the largest band's worst case; grid padded to the largest
-// band) into the workspace, then ONE kernel per rank that turns the gathered slots into the canonical buffers: global offset of band r =
-// sum of the totals of the bands before it (read from the gathered totals on the device: no host round trip anywhere in the exchange).
+// Three all-gathers (band total; index segments in slots of the largest band's total, known from the first; grid padded to the largest band)
+// into the workspace, then ONE kernel per rank that turns the gathered slots into the canonical buffers: global offset of band r = sum of the
+// totals of the bands before it (read from the gathered totals on the device).  One host read, of the gathered totals, sizes the second gather.
 struct StitchArgs {
     const uint32_t* totals;   // [world]
     const uint32_t* segments; // [world][segCap]  (a band's culledLights[1 ..])
@@ -197,14 +197,25 @@ extern "C" int sailor_hip_exchange_light_lists_rows(SailorHipContext* ctx, void*
     uint32_t* sendGrid = (uint32_t*)ws;
     const uint32_t myTiles = (uint32_t)((tileRowBounds[rank + 1] - tileRowBounds[rank]) * Tx);
     SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
-    // fixed-size send slots (what lies behind the valid part is never read by the stitch)
+    // send slots (what lies behind the valid part is never read by the stitch)
     hipLaunchKernelGGL(k_pad_copy, dim3(256), dim3(256), 0, ctx->stream, dBandCulled + 1, sendSeg, dBandCulled, 0u, (uint32_t)segCap);
     hipLaunchKernelGGL(k_pad_copy, dim3(64), dim3(256), 0, ctx->stream, (const uint32_t*)dBandGrid, sendGrid, (const uint32_t*)nullptr, myTiles * 2u, (uint32_t)gridCap);
     SAILOR_CHECK_LAUNCH(ctx, "k_pad_copy");
     int rc = sailor_hip_allgather_u32(ctx, comm, dBandCulled, totals, 1);             // collective 1: band totals
-    if (rc == SAILOR_HIP_OK) rc = sailor_hip_allgather_u32(ctx, comm, sendSeg, segments, segCap);   // collective 2: index segments
+    if (rc != SAILOR_HIP_OK) return rc;
+    // Collective 2 is sized by collective 1: the index segments travel as slots of the LARGEST band's total (every rank reads the same gathered
+    // totals, so every rank arrives at the same count), not of the worst case maxTiles * 128 -- 16.7 MB per rank at C3 for ~3 MB of lists.  This
+    // is the exchange's one host read (a few words, then a stream synchronisation); the exchange is off the per-frame data path.
+    uint32_t hTotals[SAILOR_MAX_SPLIT];
+    SAILOR_TRY_HIP(ctx, hipMemcpyAsync(hTotals, totals, (size_t)worldSize * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SAILOR_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    size_t segCount = 1;
+    for (int r = 0; r < worldSize; r++) segCount = hTotals[r] > segCount ? hTotals[r] : segCount;
+    segCount = (segCount + 63) / 64 * 64;          // (whole 256-byte lines)
+    if (segCount > segCap) segCount = segCap;      // (a band's total cannot exceed its tiles' worst case; a corrupt total must not overrun the slots)
+    rc = sailor_hip_allgather_u32(ctx, comm, sendSeg, segments, segCount);             // collective 2: index segments, stride segCount
     if (rc == SAILOR_HIP_OK) rc = sailor_hip_allgather_u32(ctx, comm, sendGrid, grids, gridCap);    // (the grids, 8 bytes per tile)
     if (rc != SAILOR_HIP_OK) return rc;
-    return sailor_hip_stitch_light_lists_rows(ctx, width, height, worldSize, tileRowBounds, totals, segments, segCap, grids, gridCap, dGlobalGrid, globalGridTiles,
+    return sailor_hip_stitch_light_lists_rows(ctx, width, height, worldSize, tileRowBounds, totals, segments, segCount, grids, gridCap, dGlobalGrid, globalGridTiles,
                                               dGlobalCulled, globalCapacity);
 }
