@@ -911,11 +911,14 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
         // L2 / HBM), so the first chunk's list entries are requested together with the group's count, not after it:
         // slots past the count hold stale entries of an earlier frame or nothing at all, hence the clamp to N - 1.
         const uint32_t* __restrict__ list = a.groupList + (size_t)g * CAPG;
-#pragma unroll
-        for (int k = 0; k < CHUNK / 256; k++) e[k] = list[threadIdx.x + 256u * k];
+        // (the first 256 slots ahead of the count, the second 256 only for a group that has them: 1 KB per block that three groups in four
+        // never look at -- 8 of the kernel's 25 MB)
+        e[0] = list[threadIdx.x];
         gn = a.groupCount[g];
         if (!head && a.headRows > 0 && (gn == GROUP_OVERFLOW_LISTED || (gn != GROUP_OVERFLOW && (gn & GROUP_LISTED)))) return; // a listed cluster: the head rows have it
         gn = gn >= GROUP_OVERFLOW_LISTED ? GROUP_OVERFLOW : (gn & ~GROUP_LISTED);
+#pragma unroll
+        for (int k = 1; k < CHUNK / 256; k++) e[k] = (gn != GROUP_OVERFLOW && gn > 256u * k) ? list[threadIdx.x + 256u * k] : 0u;
     }
 
     const int tx = gx * GROUP + wave;
