@@ -33,6 +33,10 @@ def k1k2_case(ctx, rng, c, run=True, verbose=False):
         if rng.random() < 0.3: lights["intensity"][k[3], 0] = np.inf
         if rng.random() < 0.5: lights["worldPosition"][k[4]] = (0.0, 150.0, 50.0); lights["bounds"][k[4], 0] = 400.0   # around / behind the eye
         if rng.random() < 0.3: lights["bounds"][k[5], 0] = -5.0
+        if rng.random() < 0.3:   # divisors far outside the staged reciprocal's range (shaded per pixel, behind the pair queue; splits bands' long tiles too)
+            j = rng.integers(0, N, 2)
+            lights["type"][j[0]] = host.LIGHT_POINT; lights["bounds"][j[0], 0] = np.float32(rng.choice([1e15, 1e-15]))
+            lights["type"][j[1]] = host.LIGHT_SPOT; lights["cutOff"][j[1], 0] = lights["cutOff"][j[1], 1] - np.float32(rng.choice([0.0, 1e-15]))
     if rng.random() < 0.2:
         depth = depth.copy(); depth[: H // 3] = np.inf   # sky: NaN frustum centres
     surface = synth.make_surface(cam, np.where(np.isfinite(depth), depth, 1000.0).astype(np.float32), seed)
@@ -112,6 +116,10 @@ def k3_case(ctx, rng, c):
         lights["type"][k] = host.LIGHT_DIRECTIONAL
         lights["shadowType"][k] = rng.choice([host.SHADOW_NONE, host.SHADOW_PCF, host.SHADOW_EVSM], 3)
         lights["direction"][k, :3] = rng.normal(size=(3, 3)).astype(np.float32)
+    if N >= 3 and rng.random() < 0.3:   # divisors far outside the staged reciprocal's range: these lights are shaded per pixel, beside the directional ones
+        k = rng.integers(1, N, 2)
+        lights["type"][k[0]] = host.LIGHT_POINT; lights["bounds"][k[0], 0] = np.float32(rng.choice([1e15, 1e-15]))
+        lights["type"][k[1]] = host.LIGHT_SPOT; lights["cutOff"][k[1], 0] = lights["cutOff"][k[1], 1] - np.float32(rng.choice([0.0, 1e-15]))
     depth = f.depth
     if rng.random() < 0.5:  # stretch the depth so that the far cascades are selected too
         depth = (depth * np.float32(rng.choice([3.0, 8.0]))).astype(np.float32)
