@@ -302,7 +302,8 @@ extern "C" int sailor_hip_shade_prepared(SailorHipContext* ctx, const SailorUboF
         }
     }
     A.bandTileRows = band->tileRowEnd - band->tileRowBegin;
-    const dim3 grid(8u, (unsigned)A.Tx, (unsigned)((A.bandTileRows + 7) / 8)); // (XCD, tile column, tile row / 8): see k2_shade_body
+    // (XCD + 8 x tile within the piece, piece, tile row): see k2_shade_body
+    const dim3 grid(8u * (unsigned)((A.Tx + 8 * SHADE_XCD_PIECES - 1) / (8 * SHADE_XCD_PIECES)), (unsigned)SHADE_XCD_PIECES, (unsigned)A.bandTileRows);
     IblArgs I {};
     if (ibl) {
         if (!ibl->irradiance || !ibl->env || !ibl->brdfLut || ibl->irrSize <= 0 || ibl->envSize <= 0 || ibl->envLevels <= 0 || ibl->envLevels > 16 ||

@@ -293,6 +293,9 @@ __device__ __forceinline__ float dot3_pk(const v2f_ axy, const float az, const v
 }
 
 #define LREC 5 // float4 per staged light
+#ifndef SHADE_XCD_PIECES
+#define SHADE_XCD_PIECES 10 // pieces of a tile row per XCD (see the grid mapping in k2_shade_body)
+#endif
 #define LIGHT_SLOW_SHIFT 24 // see stage_light_record
 
 // One light's record (SailorLightShaderData as seven float4) -> its staged form (the five float4 described at "Staged light record" below).
@@ -524,12 +527,15 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     // loop those values stay live across the whole body and the 64-register budget spills)
     if (splitRole) asm volatile("" : "+v"(tid));
 
-    // grid = (8, tiles per row, ceil(tile rows / 8)): no division.  The hardware deals consecutive linear block ids to the eight XCDs in turn, and
-    // with 8 as the fastest dimension blockIdx.x IS the XCD -- which then shades the tile rows x, x + 8, x + 16, ...: the tiles of a row (neighbours
-    // share most of their lights) read their records and lists through ONE L2 instead of eight, and every XCD gets the same mix of rows (a light
-    // cluster is spread over all of them; whole regions per XCD put the cluster on one).  136.4 -> 135.3 us, serial step 0.1810 -> 0.1789 ms.
-    int btx = blockIdx.y, bty = (int)blockIdx.z * 8 + (int)blockIdx.x;
-    if (ROLE == ROLE_TILE && bty >= A.bandTileRows) return;
+    // grid = (8 x tiles per piece, pieces, tile rows): no division.  The hardware deals consecutive linear block ids to the eight XCDs in turn, and
+    // with a multiple of 8 as the fastest dimension blockIdx.x & 7 IS the XCD (blockIdx.x >> 3 = the tile within the piece).  Every tile row is cut into 8 * SHADE_XCD_PIECES pieces of a few tiles; XCD x takes the pieces
+    // ((x - row) mod 8) + 8 c of row `row`: every XCD gets a share of EVERY row (a light cluster's rows are spread over all eight -- whole rows per
+    // XCD, x, x + 8, ..., measured 1-2 % slower; PAIRS of rows per XCD 7 % slower: some XCDs then hold two cluster rows, others one), a piece's
+    // tiles (neighbours share most of their lights) read their records through one L2, and the blocks an XCD runs at a time form a compact patch
+    // of the frame.  Pieces of three tiles at 4K (10 per XCD and row); pieces of 6, 15, 30 or single tiles were all within 1.5 %.
+    int bty = (int)blockIdx.z;
+    int btx = ((int)((blockIdx.x - (unsigned)bty) & 7u) + 8 * (int)blockIdx.y) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (ROLE == ROLE_TILE && btx >= A.Tx) return;
     const int lane = tid & 63, wave = tid >> 6;
     int quad = wave;
     if (BAND) { btx = selTx; bty = selTy; if (splitRole) quad = selQuad; }
