@@ -529,12 +529,16 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
 
     // grid = (8 x tiles per piece, pieces, tile rows): no division.  The hardware deals consecutive linear block ids to the eight XCDs in turn, and
     // with a multiple of 8 as the fastest dimension blockIdx.x & 7 IS the XCD (blockIdx.x >> 3 = the tile within the piece).  Every tile row is cut into 8 * SHADE_XCD_PIECES pieces of a few tiles; XCD x takes the pieces
-    // ((x - row) mod 8) + 8 c of row `row`: every XCD gets a share of EVERY row (a light cluster's rows are spread over all eight -- whole rows per
+    // ((x - row) mod 8) + 8 c of row `row`: every XCD gets a share of EVERY row, a different one from row to row (a light cluster is spread over all eight -- whole rows per
     // XCD, x, x + 8, ..., measured 1-2 % slower; PAIRS of rows per XCD 7 % slower: some XCDs then hold two cluster rows, others one), a piece's
     // tiles (neighbours share most of their lights) read their records through one L2, and the blocks an XCD runs at a time form a compact patch
     // of the frame.  Pieces of three tiles at 4K (10 per XCD and row); pieces of 6, 15, 30 or single tiles were all within 1.5 %.
     int bty = (int)blockIdx.z;
-    int btx = ((int)((blockIdx.x - (unsigned)bty) & 7u) + 8 * (int)blockIdx.y) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    // (the K3 kernels do NOT rotate the pieces with the row: an XCD then owns the same columns in every row, and the shadow-map texels of
+    // vertically adjacent tiles meet in one L2 -- k2_shade_csm_p 234 -> 225 us on C4; the plain kernel, which has no texels to share, pays 4.6 %
+    // for that: the light cluster's columns land on three of the eight XCDs.)
+    constexpr unsigned rot = HAS_CSM ? 0u : 1u;
+    int btx = ((int)((blockIdx.x - (unsigned)bty * rot) & 7u) + 8 * (int)blockIdx.y) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     if (ROLE == ROLE_TILE && btx >= A.Tx) return;
     const int lane = tid & 63, wave = tid >> 6;
     int quad = wave;
