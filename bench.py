@@ -2,22 +2,27 @@
 """Headline benchmark of the MI355X-native Forward+ lighting path (BASELINE.json: "lit Mpixels/s + Mlights culled/s at
 4K / 65 536 lights; 1/2/4/8-GPU scaling").
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: this process starts the N ranks itself, as child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One step = one pass of the hot path over one synthetic frame: K0 light view transform + K1 tile light cull + K2 PBR shade
 over the per-tile lists (BASELINE.json configs[2]: 4K, 65 536 point+spot lights, synthetic G-buffer/surface tiles), with
 every input already resident in HBM.  With N > 1 the step is ONE frame cut into N cost-balanced tile-row bands, one band per
 rank (BASELINE.json's multi-GPU metric, SURVEY.md 8e: strong scaling; cull + shade need no collective), and
-`value` = W*H*K / max-over-ranks(time); after the timed steps the band lists are exchanged once over RCCL (count all-gather +
-index all-gather) and the stitched global buffers are summarised by a checksum, so the distributed path is exercised end to
-end (`--exchange-every-step` puts the exchange inside the timed region).  The same invocation also measures the other way of
-using N GPUs -- every rank renders whole frames of its own -- and reports it as `alternate_frame_rendering`, together with
-`speedup_vs_one_gpu_whole_frame` = that whole-frame step time / the split step time.  `--frame-per-gpu` swaps the roles.
+`value` = W*H*K / max-over-ranks(time); after the timed steps the band lists are exchanged once through the SHIPPED exchange --
+sailor_hip_exchange_light_lists_rows (exchange.hip: three ncclAllGather on an ncclComm_t of the job's ranks + one stitch kernel), the
+call HipGraphicsDriver::ExchangeLightLists makes -- and the stitched global buffers are summarised by a checksum, so the distributed
+path is exercised end to end (`--exchange-every-step` puts the exchange inside the timed region).  The same invocation also measures
+the other way of using N GPUs -- every rank renders whole frames of its own -- and reports it as `alternate_frame_rendering`, together
+with `speedup_vs_one_gpu_whole_frame` = that whole-frame step time / the split step time.  `--frame-per-gpu` swaps the roles.
+
+Lights: static (the prepared views derived once, outside the timed region) or dynamic (every light dirty every frame: the
+preparation of all N lights inside every step).  C5 ("1 M dynamic lights") is quoted dynamic, the others static; the line always
+carries both step times (`value_dynamic_lights` / `ms_per_step_dynamic`, resp. `..._static`) and `lights.mode` says which is `value`.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k2_shade): algorithmic bytes per launch
-/ its launch duration from one HIP event pair around K back-to-back launches on the launch stream.  `cpu_baseline` = the
-CPU oracle (a port: the reference cannot be built here) timed on a bounded
+/ its launch duration read DIRECTLY: one HIP event pair around every launch, each launch between its real neighbours
+(kernel_in_frame_ms).  `cpu_baseline` = the CPU oracle (a port: the reference cannot be built here) timed on a bounded
 sample of the same workload on this box's host cores.
 """
 from __future__ import annotations
@@ -49,13 +54,13 @@ HBM_COPY_GBS = 6290.0       # same table: 6.29 TB/s measured float4 copy
 FP32_VALU_TFLOPS = 157.3
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--spinup-ms", type=float, default=300.0, help="untimed clock spin-up before the warm-up steps (0 = none)")
-    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5", "tiny"], help="`tiny` (128 x 96, 512 lights) is the CPU control-flow test's frame, not a bench line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tile-rows", type=int, default=96)
     ap.add_argument("--exchange-every-step", action="store_true", help="include the RCCL list exchange in the timed region (N > 1)")
@@ -64,7 +69,10 @@ def parse():
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
                     help="2 (the reference's MaxFramesInQueue, RHI/Renderer.h:34): frame k+1's cull is recorded on a second stream beside frame k's shade")
     ap.add_argument("--plain-lights", action="store_true", help="no prepared lights: cull and shade read the 112-byte light records (rounds 1-2)")
-    ap.add_argument("--dynamic-lights", action="store_true", help="every light is dirty every frame: sailor_hip_prepare_lights over all N lights inside every step (serial / eager forms only)")
+    ap.add_argument("--dynamic-lights", action="store_true", default=None,
+                    help="every light is dirty every frame (LightingECS::Tick re-uploads it, ECS/LightingECS.cpp:152-191): sailor_hip_prepare_lights over all N lights inside "
+                         "every step, in front of the cull.  The default for C5 (\"1 M dynamic lights\"); the other configurations report it beside `value` as value_dynamic_lights")
+    ap.add_argument("--static-lights", dest="dynamic_lights", action="store_false", help="the lights' prepared views are derived once, outside the timed region (the default except for C5)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--equal-bands", action="store_true", help="N > 1: equal tile-row bands instead of cost-balanced ones")
     ap.add_argument("--split-frame", action="store_true", help="N > 1: ONE frame split into tile-row bands is `value` (the default; kept for old command lines)")
@@ -75,19 +83,124 @@ def parse():
     ap.add_argument("--simulate-split", type=int, default=0, help="G: time each band of a cost-balanced G-way split one after the other on this GPU and print the predicted speed-up; diagnostic")
     ap.add_argument("--simulate-band", default=None, help="R/G: time only band R of a G-way split in this single process (no collectives); diagnostic")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the list exchange even with one rank")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+class HipDevice:
+    """The device layer of this benchmark: torch-ROCm streams, events and hipGraphs around the C-ABI library.  Everything main() does to a GPU goes
+    through one of these, so that tests/test_bench_dist_cpu.py can drive the SAME main() -- rank arithmetic, calibration, band set-up, exchange, JSON
+    assembly -- through a stand-in with this interface on a `gloo` group of two (the oracle as the kernels): a rank-count bug must not first appear
+    on an 8-GPU box.  There is no such stand-in in the product or in this file: without a HIP device this class refuses to exist."""
+    dist_backend = "nccl"   # = RCCL on ROCm
+
+    def __init__(self, local_rank: int):
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device: the path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        self._comm = None
+
+    # -- streams, events, graphs
+    def stream(self, priority: int = 0):
+        return torch.cuda.Stream(device=self.device, priority=priority)
+
+    def set_stream(self, stream):
+        torch.cuda.set_stream(stream)
+
+    def on_stream(self, stream):
+        return torch.cuda.stream(stream)
+
+    def synchronize(self):
+        torch.cuda.synchronize()
+
+    def event(self, timing: bool = True):
+        return torch.cuda.Event(enable_timing=timing)
+
+    def capture(self, stream, body):
+        """body() recorded into one hipGraph on `stream`; .replay() launches it"""
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            body()
+        return g
+
+    # -- the path (C-ABI) and its buffers
+    def context(self, stream):
+        return HipContext(self.device, stream=stream)
+
+    def upload(self, array):
+        return torch.from_numpy(np.ascontiguousarray(array)).to(self.device)
+
+    def upload_lights(self, lights):
+        return upload_lights(lights, self.device)
+
+    def prepared_lights(self, ctx, d_lights, n):
+        return PreparedLights(ctx, d_lights, n)
+
+    def forward_plus(self, ctx, W, H, N, band, prepared):
+        return ForwardPlus(ctx, W, H, N, band=band, prepared=prepared)
+
+    def upload_shadow_maps(self, shadows):
+        from sailor_amd.forward_plus import upload_shadow_maps
+        return upload_shadow_maps(shadows, self.device)
+
+    # -- the split frame's exchange: the SHIPPED one (exchange.hip over an ncclComm_t), not torch.distributed's collectives
+    def make_comm(self, rank: int, world: int):
+        from sailor_amd import dist as sdist
+        self._comm = sdist.RcclComm(rank, world)
+
+    def exchange(self, ctx, W, H, bounds, fp):
+        """this rank's band lists -> the frame's canonical (lightsGrid, culledLights) on every rank: sailor_hip_exchange_light_lists_rows"""
+        from sailor_amd import dist as sdist
+        return sdist.exchange_lists_rccl(ctx, self._comm, W, H, bounds, fp.grid[: fp.band_tiles * 2], fp.culled)
+
+    exchange_how = "sailor_hip_exchange_light_lists_rows (C-ABI: 3 x ncclAllGather on an ncclComm_t of the job's ranks + one stitch kernel)"
+
+    def close(self):
+        if self._comm is not None:
+            self._comm.close()
+            self._comm = None
+
+
+_DEV = None   # the device layer the timing helpers below use (set by main(); a HipDevice of the current device otherwise)
+
+
+def _dev():
+    global _DEV
+    if _DEV is None:
+        _DEV = HipDevice(torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return _DEV
 
 
 def event_ms(fn, steps):
     """average duration of fn() in ms, HIP events on the current (= launch) stream, one pair per call."""
+    dev = _dev()
     pairs = []
     for _ in range(steps):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a, b = dev.event(), dev.event()
         a.record(); fn(); b.record()
         pairs.append((a, b))
-    torch.cuda.synchronize()
+    dev.synchronize()
     t = np.array([a.elapsed_time(b) for a, b in pairs])
     return float(t.mean()), float(np.median(t)), float(np.percentile(t, 10)), float(np.percentile(t, 90))
+
+
+def kernel_in_frame_ms(before, kernel, launches):
+    """The duration of ONE kernel by a HIP event pair around EVERY launch of it, each launch between its real neighbours: before(); [a] kernel() [b];
+    before(); ... on the launch stream, eagerly.  before() = the rest of the frame (the cull chain), so the kernel starts on the cache and write-back
+    state its predecessors leave and is followed at once by the next frame's work -- nothing is subtracted and no two medians are combined: every
+    sample is the kernel itself plus the two event packets at its edges.  (Fifty launches of the kernel back to back -- back_to_back_launch_ms -- run
+    into each other's write-back; a pair around a launch with the GPU drained on both sides -- isolated_* -- includes ramp-up from idle.)"""
+    dev = _dev()
+    pairs = []
+    for _ in range(launches):
+        before()
+        a, b = dev.event(), dev.event()
+        a.record(); kernel(); b.record()
+        pairs.append((a, b))
+    dev.synchronize()
+    t = np.array([a.elapsed_time(b) for a, b in pairs])
+    return {"mean": float(t.mean()), "median": float(np.median(t)), "p10": float(np.percentile(t, 10)), "p90": float(np.percentile(t, 90)),
+            "min": float(t.min()), "max": float(t.max()), "launches": int(len(t))}
 
 
 BATCHES = 5          # per-kernel figures: the median of this many batches ...
@@ -103,24 +216,25 @@ def event_batch_stats(fn, steps, graph_stream=None, batches=BATCHES):
     dispatch gap (5-15 us) between them, which is no part of the kernel; inside a graph the gap is what it is in the timed region.  What the pair
     includes besides the kernels' own durations (rocprofv3's kernel trace reports those): the gap between consecutive launches and the end-of-kernel
     write-back -- see `launch_gap_ms` in the JSON line."""
+    dev = _dev()
     n = max(int(steps), BATCH_LAUNCHES)
     times = []
     if graph_stream is not None:
         try:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=graph_stream):
+            def body():
                 for _ in range(n):
                     fn()
+            g = dev.capture(graph_stream, body)
             g.replay()
-            torch.cuda.synchronize()
+            dev.synchronize()
             pairs = []
             for _ in range(batches):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a, b = dev.event(), dev.event()
                 a.record(graph_stream)
                 g.replay()
                 b.record(graph_stream)
                 pairs.append((a, b))
-            torch.cuda.synchronize()
+            dev.synchronize()
             times = [a.elapsed_time(b) / n for a, b in pairs]
         except Exception as e:  # (a failed capture leaves the eager measurement)
             print(f"[bench] per-kernel hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
@@ -128,13 +242,13 @@ def event_batch_stats(fn, steps, graph_stream=None, batches=BATCHES):
     if not times:
         pairs = []
         for _ in range(batches):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a, b = dev.event(), dev.event()
             a.record()
             for _ in range(n):
                 fn()
             b.record()
             pairs.append((a, b))
-        torch.cuda.synchronize()
+        dev.synchronize()
         times = [a.elapsed_time(b) / n for a, b in pairs]
     t = np.array(times)
     return {"median": float(np.median(t)), "min": float(t.min()), "max": float(t.max()), "batches": int(len(t)), "launches_per_batch": n}
@@ -525,7 +639,7 @@ def blur_block(ctx, steps: int):
             "cpu_1thread_mtexels_per_s": 512 * 512 / t_cpu / 1e6, "kind": "port"}
 
 
-def capture_frame_pipeline(side, side2, unroll, shade_fns, cull_fns):
+def capture_frame_pipeline(side, side2, unroll, shade_fns, cull_fns, dev=None):
     """One hipGraph holding `unroll` steps (a multiple of the number S of list sets) of the two-frames-in-flight pipeline: shade_fns[p]() records
     frame k's shade from set p = k % S on `side`, cull_fns[q]() records frame k + 1's cull into set q = (k + 1) % S on `side2`.  The only
     dependencies are the frames' own: shade(k) waits for cull(k), cull(k + 1) for the shade that last read its set, shade(k + 1 - S); one join at
@@ -533,10 +647,11 @@ def capture_frame_pipeline(side, side2, unroll, shade_fns, cull_fns):
     S = 3 (the default): with two sets cull(k + 1) and shade(k) both start the moment shade(k - 1) ends, and the cross-queue wait sits on the
     critical path -- the kernel trace shows ~10 us between the end of one shade and the start of the next (scripts/analysis/pipeline_timeline.py);
     with a third set the cull waits for a shade that ended a frame ago, and the shades follow each other like launches on one stream."""
+    dev = dev or _dev()
     S = len(shade_fns)
     assert len(cull_fns) == S
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
+
+    def body():
         shade_done = [None] * S
         cull_done = None
         for k in range(unroll):
@@ -544,16 +659,16 @@ def capture_frame_pipeline(side, side2, unroll, shade_fns, cull_fns):
             if cull_done is not None:
                 side.wait_event(cull_done)
             shade_fns[p]()
-            shade_done[p] = torch.cuda.Event(); shade_done[p].record(side)
+            shade_done[p] = dev.event(False); shade_done[p].record(side)
             if shade_done[q] is not None:
                 side2.wait_event(shade_done[q])
             elif k == 0:
                 side2.wait_stream(side)  # fork
-            with torch.cuda.stream(side2):
+            with dev.on_stream(side2):
                 cull_fns[q]()
-                cull_done = torch.cuda.Event(); cull_done.record(side2)
+                cull_done = dev.event(False); cull_done.record(side2)
         side.wait_stream(side2)  # join
-    return g
+    return dev.capture(side, body)
 
 
 def pipeline_unroll(steps: int, sets: int = 2):
@@ -567,7 +682,7 @@ def pipeline_unroll(steps: int, sets: int = 2):
     return u, steps - (steps // u) * u if u else steps
 
 
-def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev, prep=None):
+def simulate_split(args, dev, ctx, side, frame, d_lights, fp_full, d_depth_full, prep=None):
     """Single-GPU estimate of the G-way split: per-band step time (hipGraph replay), equal vs cost-balanced bands."""
     from sailor_amd import dist as sdist
     cam, W, H, N, G = frame.cam, frame.cam.width, frame.cam.height, len(frame.lights), args.simulate_split
@@ -578,42 +693,38 @@ def simulate_split(args, ctx, frame, d_lights, fp_full, d_depth_full, dev, prep=
     out = {"config": args.config, "split": G}
 
     unroll = 0 if args.frames_in_flight == 1 else pipeline_unroll(args.steps, args.list_sets)[0]
-    side = torch.cuda.current_stream()
-    side2 = torch.cuda.Stream(device=dev, priority=int(os.environ.get('SAILOR_CULL_PRIORITY', '0')))
-    ctx2 = HipContext(dev, stream=side2)
+    side2 = dev.stream(priority=int(os.environ.get('SAILOR_CULL_PRIORITY', '0')))
+    ctx2 = dev.context(side2)
 
     def time_band(b):
         """ms per step of band b alone on this GPU, launched the way a rank of the split frame launches it (the main path's pipeline graph)"""
-        fs = [ForwardPlus(ctx, W, H, N, band=b, prepared=prep) for _ in range(args.list_sets if unroll else 1)]
-        dd = torch.from_numpy(np.ascontiguousarray(frame.depth[b.fbRowBegin:b.fbRowBegin + b.fbRowCount])).to(dev)
-        ds = torch.from_numpy(frame.surface_rows(b.fbRowBegin, b.fbRowBegin + b.fbRowCount)).to(dev)
+        fs = [dev.forward_plus(ctx, W, H, N, b, prep) for _ in range(args.list_sets if unroll else 1)]
+        dd = dev.upload(frame.depth[b.fbRowBegin:b.fbRowBegin + b.fbRowCount])
+        ds = dev.upload(frame.surface_rows(b.fbRowBegin, b.fbRowBegin + b.fbRowCount))
         for f in fs:
             f.cull(cam.frame, d_lights, N, dd)
             f.shade(cam.frame, ds, d_lights, N, None)
-        torch.cuda.synchronize()
+        dev.synchronize()
         if unroll:
             graph = capture_frame_pipeline(side, side2, unroll, [lambda f=f: f.shade(cam.frame, ds, d_lights, N, None) for f in fs],
-                                           [lambda f=f: f.cull(cam.frame, d_lights, N, dd, ctx=ctx2) for f in fs])
+                                           [lambda f=f: f.cull(cam.frame, d_lights, N, dd, ctx=ctx2) for f in fs], dev)
             fs[0].cull(cam.frame, d_lights, N, dd)
             per = unroll
         else:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                fs[0].cull(cam.frame, d_lights, N, dd)
-                fs[0].shade(cam.frame, ds, d_lights, N, None)
+            graph = dev.capture(side, lambda: (fs[0].cull(cam.frame, d_lights, N, dd), fs[0].shade(cam.frame, ds, d_lights, N, None)))
             per = 1
         t_spin = time.perf_counter()   # the same clock spin-up as the main path (a band's K steps are over in 2-4 ms)
         while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
             for _ in range(8):
                 graph.replay()
-            torch.cuda.synchronize()
+            dev.synchronize()
         for _ in range((args.warmup + per - 1) // per):
             graph.replay()
-        torch.cuda.synchronize()
+        dev.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps // per):
             graph.replay()
-        torch.cuda.synchronize()
+        dev.synchronize()
         return (time.perf_counter() - t0) / (args.steps // per * per) * 1e3
 
     whole = time_band(host.band_whole_frame(W, H))
@@ -640,49 +751,72 @@ class BenchFrame:
         return synth.make_surface(self.cam, self.depth, row_begin=r0, row_end=r1)
 
 
-def main():
-    args = parse()
+def launch_ranks(n: int, argv):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): this process starts the N ranks itself, as CHILD processes of
+    `python -m torch.distributed.run`, and leaves with their exit code.  It has not touched the GPU at this point and never does (importing torch
+    initialises nothing; an exec from a process that has is what takes a box down) -- rank 0 of the children prints the JSON line on the shared stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd)
+
+
+def main(argv=None, device_factory=None):
+    """device_factory: the device layer (HipDevice; the CPU control-flow test passes its stand-in)"""
+    global _DEV
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and device_factory is None:
+        raise SystemExit(launch_ranks(args.gpus, argv))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = _DEV = (device_factory or HipDevice)(local_rank)
+    device = dev.device
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dev.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(dev.dist_backend, rank=rank, world_size=world)
+        dev.make_comm(rank, world)   # the ncclComm_t of the shipped exchange (exchange.hip), beside torch's own
 
     frame = BenchFrame(args.config)
     cam, W, H = frame.cam, frame.cam.width, frame.cam.height
     N = len(frame.lights)
     # everything runs on one side stream: the C-ABI records on it, torch events time it, and a hipGraph can capture it
-    side = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(side)
-    ctx = HipContext(dev, stream=side)
-    d_lights = upload_lights(frame.lights, dev)
-    # The lights' prepared views (sailor_hip_prepare_lights: the cull's 20-byte records, the shade's staged records), derived ONCE here, where the
-    # HIP backend derives them: behind the copy that writes the `light` SSBO (LightingECS::Tick uploads dirty runs only, ECS/LightingECS.cpp:152-191;
-    # the synthetic light set is static).  --dynamic-lights puts the preparation of all N lights into every step (every light dirty every frame);
-    # --plain-lights runs the kernels straight off the 112-byte records as rounds 1-2 did.
-    prep = None if args.plain_lights else PreparedLights(ctx, d_lights, N)
+    side = dev.stream()
+    dev.set_stream(side)
+    ctx = dev.context(side)
+    d_lights = dev.upload_lights(frame.lights)
+    # The lights' prepared views (sailor_hip_prepare_lights: the cull's 20-byte records, the shade's staged records) are derived where the HIP backend
+    # derives them: behind the copy that writes the `light` SSBO (LightingECS::Tick uploads dirty runs only, ECS/LightingECS.cpp:152-191).  STATIC lights
+    # (the default for C2-C4: the synthetic set does not move): once, here, outside the timed region.  DYNAMIC lights (the default for C5, "1 M dynamic
+    # lights"; --dynamic-lights elsewhere): every light is dirty every frame, so the preparation of all N runs inside every step, in front of the
+    # cull, on the cull's stream.  The line always carries both step times.  --plain-lights: the kernels read the 112-byte records as rounds 1-2 did.
+    prep = None if args.plain_lights else dev.prepared_lights(ctx, d_lights, N)
+    dynamic = (args.dynamic_lights if args.dynamic_lights is not None else args.config == "C5") and prep is not None
     Tx, Ty = host.num_tiles(W, H)
 
-    def resident(b):
-        """ForwardPlus for band b with the band's depth rows resident"""
-        f = ForwardPlus(ctx, W, H, N, band=b, prepared=prep)
-        dd = torch.from_numpy(np.ascontiguousarray(frame.depth[b.fbRowBegin:b.fbRowBegin + b.fbRowCount])).to(dev)
+    def resident(b, own_views=False):
+        """ForwardPlus for band b with the band's depth rows resident.  own_views: a further list set of the frame pipeline -- with its own copy of the
+        lights' prepared views, so that frame k + 1's re-preparation (dynamic lights, on the cull's stream) never writes what frame k's shade reads"""
+        f = dev.forward_plus(ctx, W, H, N, b, dev.prepared_lights(ctx, d_lights, N) if (own_views and prep is not None) else prep)
+        dd = dev.upload(frame.depth[b.fbRowBegin:b.fbRowBegin + b.fbRowCount])
         return f, dd
 
     band = host.band_for_rank(W, H, rank, world)
+    bounds = [host.band_for_rank(W, H, r, world).tileRowBegin for r in range(world)] + [Ty]   # tile-row boundaries of the split (equal bands)
     partition = "whole frame"
     # N > 1, default: ONE frame cut into tile-row bands, one per GPU (BASELINE.json's metric: strong scaling).  --frame-per-gpu: every GPU
     # takes a whole frame per step (per-GPU work fixed: weak scaling, no collective on the data path).
@@ -696,9 +830,9 @@ def main():
         from sailor_amd import dist as sdist
         f0, d0 = resident(band)
         f0.cull(cam.frame, d_lights, N, d0)
-        torch.cuda.synchronize()
+        dev.synchronize()
         rows_entries = sdist.gather_row_entries(f0.grid[: f0.band_tiles * 2], Tx, band.tileRowEnd - band.tileRowBegin, Ty, band.tileRowBegin)
-        bounds = sdist.balanced_tile_rows(rows_entries, Tx, world)
+        bounds = [int(b) for b in sdist.balanced_tile_rows(rows_entries, Tx, world)]
         band = host.band_from_tile_rows(W, H, bounds[rank], bounds[rank + 1])
         partition = f"cost-balanced tile rows {bounds}"
         del f0, d0
@@ -710,139 +844,146 @@ def main():
         partition = f"diagnostic: band {r_} of an equal {g_}-way tile-row split, alone on this GPU"
     rows = slice(band.fbRowBegin, band.fbRowBegin + band.fbRowCount)
     fp, d_depth = resident(band)
-    d_surface = torch.from_numpy(frame.surface_rows(rows.start, rows.stop)).to(dev)
+    d_surface = dev.upload(frame.surface_rows(rows.start, rows.stop))
     csm = keep = None
     if frame.cfg.get("shadow_size"):
-        from sailor_amd.forward_plus import upload_shadow_maps
         shadows = synth.make_shadow_set(cam, frame.cfg["shadow_size"])
-        csm, keep = upload_shadow_maps(shadows, dev)
+        csm, keep = dev.upload_shadow_maps(shadows)
 
     if args.simulate_split:
-        simulate_split(args, ctx, frame, d_lights, fp, d_depth, dev, prep)
+        simulate_split(args, dev, ctx, side, frame, d_lights, fp, d_depth, prep)
         return
 
+    def cull_of(f, c, dyn):
+        """one frame's cull chain into f's list set, recorded on context c's stream (None: the launch stream); with dynamic lights the preparation
+        of every light goes in front of it, on the same stream"""
+        if dyn:
+            f.prepared.prepare(0, N, ctx=c)
+        f.cull(cam.frame, d_lights, N, d_depth, ctx=c)
+
     def cull():
-        if args.dynamic_lights and prep is not None:
-            prep.prepare(0, N)
-        fp.cull(cam.frame, d_lights, N, d_depth)
+        cull_of(fp, None, dynamic)
 
     def shade():
         fp.shade(cam.frame, d_surface, d_lights, N, csm)
 
     def exchange():
-        from sailor_amd import dist as sdist
-        return sdist.exchange_lists(fp.grid[: fp.band_tiles * 2], fp.culled)
-
-    def step():
-        cull()
-        shade()
-        if world > 1 and args.exchange_every_step:
-            exchange()
+        return dev.exchange(ctx, W, H, bounds, fp)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev.synchronize()
 
     # One frame = 8 short kernels: at N = 8 a band's kernels last ~50 us in total, less than eight eager launches cost
     # on the host.  Capture the step once and replay it (launch-bound inner loop -> hipGraph).
     # Frames in flight = 2 (the reference keeps MaxFramesInQueue = 2, RHI/Renderer.h:34): a step then shades frame k from
     # one set of list buffers while frame k+1's cull -- a chain of short, latency-bound kernels -- fills the other set on
     # a second stream.  Every step still performs exactly one cull and one shade of a frame.
-    pipelined = args.frames_in_flight == 2 and not args.no_graph and not args.exchange_every_step
-    graphs = []
     # One replay = `unroll` steps of the software pipeline, with the dependencies of the frames themselves and nothing else: shade(k) waits for
     # cull(k), cull(k + 1) for shade(k - 1) (it overwrites the list set that frame read).  One fork / join per STEP -- round 1's form, two graphs of
     # one step each -- makes every step last as long as the longer of its two branches plus the join (0.2335 ms); without it the chain of cull
     # kernels slides under the neighbouring shades (0.219 ms, measured first with eager launches on two streams: scripts/cu_mask_probe.py).
-    # The main graph's length is even (two list sets: a replay ends where it began); a K that no even length divides gets a second, shorter graph
-    # for the rest, so the timed region is exactly K steps (pipeline_unroll).
+    # The main graph's length is a multiple of the number of list sets (a replay ends where it began); a K that no such length divides gets a
+    # second, shorter graph for the rest, so the timed region is exactly K steps (pipeline_unroll).
+    want_pipeline = args.frames_in_flight == 2 and not args.no_graph and not args.exchange_every_step
     unroll, tail = pipeline_unroll(args.steps, args.list_sets)
-    if pipelined:
-        try:
-            side2 = torch.cuda.Stream(device=dev, priority=int(os.environ.get('SAILOR_CULL_PRIORITY', '0')))
-            ctx2 = HipContext(dev, stream=side2)
-            fps = (fp,) + tuple(resident(band)[0] for _ in range(args.list_sets - 1))   # further sets of grid / culledLights / workspace
-            for f in fps:               # eager warm-up of both sets (also sizes every internal buffer before capture)
-                f.cull(cam.frame, d_lights, N, d_depth)
-                f.shade(cam.frame, d_surface, d_lights, N, csm)
-            torch.cuda.synchronize()
-            for length in (unroll, tail):
-                graphs.append(capture_frame_pipeline(side, side2, length,
-                                                     [lambda f=f: f.shade(cam.frame, d_surface, d_lights, N, csm) for f in fps],
-                                                     [lambda f=f: f.cull(cam.frame, d_lights, N, d_depth, ctx=ctx2) for f in fps]) if length else None)
-            fps[0].cull(cam.frame, d_lights, N, d_depth)                     # prologue: frame 0's lists
-            torch.cuda.synchronize()
-        except Exception as e:
-            print(f"[bench] two-frames-in-flight capture failed ({type(e).__name__}: {e}); falling back to one frame in flight", file=sys.stderr)
-            graphs, pipelined = [], False
-            torch.cuda.synchronize()
-    graph = None
-    if not pipelined and not args.no_graph and not args.exchange_every_step:
-        try:
-            step(); torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                step()
-        except Exception as e:  # capture unsupported: stay eager, say so in the JSON line
-            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
+    side2 = ctx2 = None
+    fps = (fp,)
+    if want_pipeline:
+        side2 = dev.stream(priority=int(os.environ.get('SAILOR_CULL_PRIORITY', '0')))
+        ctx2 = dev.context(side2)
+        fps = (fp,) + tuple(resident(band, True)[0] for _ in range(args.list_sets - 1))   # further sets of grid / culledLights / workspace / prepared views
+        for f in fps:               # eager warm-up of every set (also sizes every internal buffer before capture)
+            f.cull(cam.frame, d_lights, N, d_depth)
+            f.shade(cam.frame, d_surface, d_lights, N, csm)
+        dev.synchronize()
 
-    # a "run" is `per_run` steps: the main pipeline graph, or one step of the other forms; `finish()` is the pipeline's shorter graph for the rest of K
-    per_run = (unroll if unroll else tail) if pipelined else 1
+    def build_runner(dyn):
+        """-> (run, finish, per_run, launch): run() = `per_run` steps (the main pipeline graph, or one step of the other forms), finish() = the
+        pipeline's shorter graph for the rest of K, launch = how the steps are launched (for the JSON line)"""
+        def step():
+            cull_of(fp, None, dyn)
+            shade()
+            if world > 1 and args.exchange_every_step:
+                exchange()
+        if want_pipeline:
+            try:
+                graphs = [capture_frame_pipeline(side, side2, length, [lambda f=f: f.shade(cam.frame, d_surface, d_lights, N, csm) for f in fps],
+                                                 [lambda f=f: cull_of(f, ctx2, dyn) for f in fps], dev) if length else None for length in (unroll, tail)]
+                cull_of(fps[0], None, dyn)                     # prologue: frame 0's lists
+                dev.synchronize()
+                main_graph = graphs[0] if graphs[0] is not None else graphs[1]
+                rest = graphs[1] if graphs[0] is not None else None
+                per = unroll if unroll else tail
+                how = (f"hipGraph replay ({per} steps of the frame pipeline per graph" + (f", {tail} in the last" if unroll and tail else "") +
+                       f"), 2 frames in flight over {args.list_sets} list sets")
+                return main_graph.replay, (rest.replay if rest is not None else (lambda: None)), per, how
+            except Exception as e:
+                print(f"[bench] two-frames-in-flight capture failed ({type(e).__name__}: {e}); falling back to one frame in flight", file=sys.stderr)
+                dev.synchronize()
+        if not args.no_graph and not args.exchange_every_step:
+            try:
+                step(); dev.synchronize()
+                return dev.capture(side, step).replay, (lambda: None), 1, "hipGraph replay"
+            except Exception as e:  # capture unsupported: stay eager, say so in the JSON line
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
+                dev.synchronize()
+        return step, (lambda: None), 1, "eager"
 
-    def run():
-        if pipelined:
-            (graphs[0] if graphs[0] is not None else graphs[1]).replay()
-        elif graph is not None:
-            graph.replay()
-        else:
-            step()
+    def time_steps(run, finish, per):
+        """W warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides; the MAX over ranks, in seconds"""
+        # Clock spin-up (untimed, before the W warm-up steps): K steps of a 0.17 ms frame are over in a few milliseconds, less than the GPU
+        # needs to leave its idle power state -- a renderer runs continuously, so the steady state is what the K timed steps should see.
+        if args.spinup_ms > 0:
+            t_spin = time.perf_counter()
+            while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+                for _ in range(max(1, 32 // per)):
+                    run()
+                dev.synchronize()
+        for _ in range((args.warmup + per - 1) // per):   # at least W warm-up steps
+            run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps // per):
+            run()
+        finish()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
-    def finish():
-        if pipelined and graphs[0] is not None and graphs[1] is not None:
-            graphs[1].replay()
-
-    # Clock spin-up (untimed, before the W warm-up steps): K steps of a 0.22 ms frame are over in a few milliseconds, less than the GPU
-    # needs to leave its idle power state -- a renderer runs continuously, so the steady state is what the K timed steps should see.
-    if args.spinup_ms > 0:
-        t_spin = time.perf_counter()
-        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
-            for _ in range(max(1, 32 // per_run)):
-                run()
-            torch.cuda.synchronize()
-    for _ in range((args.warmup + per_run - 1) // per_run):   # at least W warm-up steps
-        run()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps // per_run):
-        run()
-    finish()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    run, finish, per_run, launch = build_runner(dynamic)
+    elapsed = time_steps(run, finish, per_run)
     ms_per_step = elapsed / args.steps * 1e3
     frames_per_step = world if (weak and world > 1) else 1
     # per-step distribution (SURVEY.md 8d: median, p10 / p90): a second pass of K steps with one HIP event per step on the launch stream --
     # outside the timed region above, which stays free of event records
-    n_runs = args.steps // per_run
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_runs + 1)]
+    n_runs = max(args.steps // per_run, 1)
+    evs = [dev.event() for _ in range(n_runs + 1)]
     evs[0].record(side)
     for i in range(n_runs):
         run()
         evs[i + 1].record(side)
-    torch.cuda.synchronize()
+    dev.synchronize()
     per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n_runs)]) / per_run
     step_stats = {"median": float(np.median(per_step)), "p10": float(np.percentile(per_step, 10)), "p90": float(np.percentile(per_step, 90)),
                   "how": ("HIP events between consecutive steps on the launch stream" if per_run == 1 else
                           f"HIP events between consecutive replays of the {per_run}-step pipeline graph on the launch stream, divided by {per_run}") +
                          ", a separate pass of K steps (this rank)"}
     value = frames_per_step * W * H * args.steps / elapsed / 1e6
+
+    # ---- the other light mode, same launch form, same K steps: static lights beside a dynamic headline and the other way round ----
+    other_mode = None
+    if prep is not None:
+        run2, finish2, per2, _ = build_runner(not dynamic)
+        el2 = time_steps(run2, finish2, per2)
+        other_mode = {"ms_per_step": el2 / args.steps * 1e3, "value": frames_per_step * W * H * args.steps / el2 / 1e6}
+        prep.prepare(0, N)   # (the views as the per-kernel measurements below expect them)
+        dev.synchronize()
 
     # ---- per-kernel timing on the launch stream (HIP events) + algorithmic bytes ----
     cull_ms = event_ms(cull, args.steps)
@@ -851,10 +992,19 @@ def main():
     cull_batch = event_batch_stats(cull, args.steps, batch_stream)
     shade_batch = event_batch_stats(shade, args.steps, batch_stream)
     cull_batch_ms, shade_batch_ms = cull_batch["median"], shade_batch["median"]
+    prepare_ms = event_batch_ms(lambda: prep.prepare(0, N), args.steps, batch_stream) if prep is not None else None
     # SURVEY.md 8d's own definition of the step: t(K1 + K2) by events on ONE stream, one frame in flight -- cull, then shade, then the next frame's cull
     serial = event_batch_stats(lambda: (cull(), shade()), args.steps, batch_stream)
+    serial_max = serial["median"]
+    if dist is not None:   # (N > 1: the frame is done when its slowest band is)
+        t = torch.tensor([serial_max], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        serial_max = float(t.item())
     pipeline_ms = event_batch_ms(lambda: (cull(), shade()), args.steps)   # eager cull + shade chains back to back: the step without graphs or overlap
     cull_eager_ms = event_batch_ms(cull, args.steps)
+    # THE ROOFLINE'S DURATION: one HIP event pair around every launch of the dominant kernel, each launch between its real neighbours (the cull
+    # chain in front, the next frame's behind) -- a direct reading of the kernel, no difference of two measurements (VERDICT r03 / ADVICE r03)
+    direct = kernel_in_frame_ms(cull, shade, max(args.steps, BATCH_LAUNCHES))
     g, idx = fp.lists_to_host()
     sum_nt = int(idx[0])
     distinct = int(len(np.unique(idx[1:]))) if sum_nt else 0
@@ -868,81 +1018,82 @@ def main():
         b_shade += b_csm
         csm_info = {"distinct_texels_per_cascade": d_c, "bytes": b_csm}
         del surf_host
-    b_cull = 20 * N + 4 * band_pixels + 8 * fp.band_tiles + 4 * sum_nt + 4
+    b_cull = 20 * N + 4 * band_pixels + 8 * fp.band_tiles + 4 * sum_nt + 4 + (112 * N if dynamic else 0)   # (dynamic: + the records the preparation reads)
     evals = int((g[:, 1].astype(np.int64) * 256).sum())
-    # The shade's launch duration IN THE FRAME: the one-frame-in-flight step (cull chain, then the shade, on one stream) minus the cull chain, both as
-    # medians of event-bracketed batches on the launch stream.  This is the figure that agrees with rocprofv3's kernel trace of the same frame
-    # (profiles/r03: 131.3 us in the trace, 128.7 here, 141.1 for fifty shades back to back): launches of the SAME kernel back to back run into
-    # their predecessor's write-back of 133 MB of radiance, which between its real neighbours -- 48 us of cull -- has drained.  (If anything the
-    # difference over-states the shade: the cull chain alone, batch after batch, finds its lights and masks in L2, which after a shade it does not.)
-    shade_frame_ms = serial["median"] - cull_batch_ms
-    shade_frame_min_max = [serial["min"] - cull_batch_ms, serial["max"] - cull_batch_ms]
-    shade_gbs = b_shade / (shade_frame_ms * 1e-3) / 1e9
+    shade_launch_ms = direct["mean"]
+    shade_gbs = b_shade / (shade_launch_ms * 1e-3) / 1e9
+    # the same kernel as the difference (one-frame-in-flight step) - (cull chain alone), medians of event-bracketed graph batches: round 3's figure,
+    # kept beside the direct one (it reads a few per cent lower: the next cull's head overlaps the shade's drain)
+    shade_diff_ms = serial["median"] - cull_batch_ms
     shade_kernel = "k2_shade_csm" if csm is not None else ("k2_shade_band" if fp.tile_order and fp.use_tile_order else "k2_shade")
     if prep is not None:
         shade_kernel += "_p"   # the entry points that read sailor_hip_prepare_lights' staged records
     trace_ms = trace_kernel_ms(shade_kernel, args.config, world)
     roofline = {"bound": "hbm", "kernel": shade_kernel, "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
-                "traffic": measured_traffic(shade_kernel, args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_frame_ms,
-                "timing": "the kernel between its real neighbours: median of %d batches of %d one-frame-in-flight steps (cull chain, then this kernel, one stream) minus the median of "
-                          "as many batches of the cull chain alone -- one HIP event pair per batch on the launch stream, each batch one hipGraph replay unless --no-graph; "
-                          "compare rocprof_kernel_avg_ms, the kernel's own duration in rocprofv3 --kernel-trace --stats of the same frame (profiles/<round>/kernel_stats.csv). "
-                          "back_to_back_launch_ms = the same kernel fifty times in a row (each launch runs into its predecessor's write-back of the radiance: above the trace); "
-                          "isolated_* = an event pair around every single launch (pipeline drained on both sides)" % (serial["batches"], serial["launches_per_batch"]),
-                "avg_launch_ms_min_max": shade_frame_min_max,
+                "traffic": measured_traffic(shade_kernel, args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_launch_ms,
+                "timing": "the kernel's own launches, measured directly: one HIP event pair around EVERY launch on the launch stream, each launch between its real neighbours "
+                          "(this frame's cull chain in front of it, the next frame's behind it; eager launches, one frame in flight), mean of %d launches -- compare "
+                          "rocprof_kernel_avg_ms, the kernel's duration in rocprofv3 --kernel-trace --stats of the same frame (profiles/<round>/kernel_stats.csv).  "
+                          "in_frame_by_difference_ms = median(serial step) - median(cull chain alone), event-bracketed hipGraph batches (round 3's figure); "
+                          "back_to_back_launch_ms = the same kernel fifty times in a row (each launch runs into its predecessor's write-back of the radiance); "
+                          "isolated_* = an event pair around every single launch with the GPU drained on both sides" % direct["launches"],
+                "avg_launch_ms_stats": direct,
+                "in_frame_by_difference_ms": shade_diff_ms, "frac_in_frame_by_difference": b_shade / (shade_diff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if shade_diff_ms > 0 else None,
                 "back_to_back_launch_ms": shade_batch_ms, "back_to_back_launch_ms_min_max": [shade_batch["min"], shade_batch["max"]],
+                "frac_back_to_back": b_shade / (shade_batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "rocprof_kernel_avg_ms": trace_ms,
                 "launch_gap_ms": (shade_batch_ms - trace_ms) if trace_ms is not None else None,  # back-to-back launches against the committed trace's kernel duration
                 "isolated_avg_launch_ms": shade_ms[0], "isolated_median_launch_ms": shade_ms[1],
-                "in_pipeline_launch_ms": pipeline_ms - cull_eager_ms,  # eager (cull + shade) x K minus eager (cull) x K: the kernel between its real neighbours
+                "in_pipeline_launch_ms": pipeline_ms - cull_eager_ms,  # eager (cull + shade) x K minus eager (cull) x K
                 "eager_step_ms": pipeline_ms,
                 "frac_of_measured_copy_peak": shade_gbs / HBM_COPY_GBS,
-                "valu_sidebar": {"pixel_light_evals": evals, "gevals_per_s": evals / (shade_frame_ms * 1e-3) / 1e9,
+                "valu_sidebar": {"pixel_light_evals": evals, "gevals_per_s": evals / (shade_launch_ms * 1e-3) / 1e9,
                                  "note": "~110 fp32 ops per (pixel,light): VALU-bound once mean list length exceeds ~10 (SURVEY.md 7, hard part 2)"},
                 "csm": csm_info,
-                "cull": {"kernels": "k01_prepare+k1_*", "avg_ms": cull_batch_ms, "isolated_avg_ms": cull_ms[0], "isolated_median_ms": cull_ms[1], "bytes": b_cull,
-                         "achieved_gbs": b_cull / (cull_batch_ms * 1e-3) / 1e9, "frac": b_cull / (cull_batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                "cull": {"kernels": ("k_prepare_lights+" if dynamic else "") + "k01_prepare+k1_*", "avg_ms": cull_batch_ms, "isolated_avg_ms": cull_ms[0], "isolated_median_ms": cull_ms[1],
+                         "bytes": b_cull, "achieved_gbs": b_cull / (cull_batch_ms * 1e-3) / 1e9, "frac": b_cull / (cull_batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "whole_path": {"what": "cull chain + shade, SURVEY.md 8d's bytes of both over the serial step (one frame in flight) and over `ms_per_step`",
+                               "bytes": b_cull + b_shade, "frac_serial": (b_cull + b_shade) / (serial["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "frac_pipelined": (b_cull + b_shade) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS if world == 1 else None}}
 
-    # ---- supplementary, N > 1 only: alternate-frame rendering.  The split frame above is latency-bound (a 0.25 ms frame leaves ~30 us
+    # ---- supplementary, N > 1 only: alternate-frame rendering.  The split frame above is latency-bound (a 0.17 ms frame leaves ~20 us
     # per GPU); the reference keeps two frames in flight (RHI/Renderer.h:34), and whole frames are independent, so a node can also give
     # every GPU its own frame.  Same step (one cull + one shade of the whole frame) on every rank, K steps, max over ranks; reported next
     # to `value`, never instead of it.  Every rank takes part in the collectives below whether or not its own set-up succeeded.
     afr = None
     if dist is not None and not args.no_afr and not weak:
         ok = 1
+        wrun = None
         try:
-            wf = ForwardPlus(ctx, W, H, N, prepared=prep)
-            wd = torch.from_numpy(np.ascontiguousarray(frame.depth)).to(dev)
-            ws = torch.from_numpy(frame.surface_rows(0, H)).to(dev)
+            wf = dev.forward_plus(ctx, W, H, N, host.band_whole_frame(W, H), prep)
+            wd = dev.upload(frame.depth)
+            ws = dev.upload(frame.surface_rows(0, H))
 
             def wstep():
                 wf.cull(cam.frame, d_lights, N, wd)
                 wf.shade(cam.frame, ws, d_lights, N, csm)
-            wstep(); torch.cuda.synchronize()
-            wgraph = None
+            wstep(); dev.synchronize()
+            wrun = wstep
             if not args.no_graph:
                 try:
-                    wgraph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(wgraph, stream=side):
-                        wstep()
+                    wrun = dev.capture(side, wstep).replay
                 except Exception:
-                    wgraph = None
-                    torch.cuda.synchronize()
+                    wrun = wstep
+                    dev.synchronize()
         except Exception as e:
             ok = 0
             print(f"[bench] rank {rank}: alternate-frame set-up failed ({type(e).__name__}: {e})", file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
-            run = (wgraph.replay if wgraph is not None else wstep)
             for _ in range(args.warmup):
-                run()
+                wrun()
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                run()
+                wrun()
             barrier()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             afr_elapsed = float(t.item())
             afr = {"what": "every GPU renders whole frames of its own (frames are independent; one frame in flight per GPU)", "scaling": "weak",
@@ -950,14 +1101,14 @@ def main():
         else:
             afr = {"error": "set-up failed on some rank"}
 
-    # ---- supplementary in the default (weak) mode: ONE frame split into cost-balanced tile-row bands, one band per GPU -- the strong-scaling reading,
-    # with the RCCL exchange that rebuilds the reference's global lists.  Set-up failures are agreed on by all ranks before any further collective.
+    # ---- supplementary in the --frame-per-gpu (weak) mode: ONE frame split into cost-balanced tile-row bands, one band per GPU -- the strong-scaling
+    # reading, with the exchange that rebuilds the reference's global lists.  Set-up failures are agreed on by all ranks before any further collective.
     split = None
     if dist is not None and not args.no_afr and weak:
         from sailor_amd import dist as sdist
 
         def all_ok(flag_value):
-            fl = torch.tensor([flag_value], dtype=torch.int32, device=dev)
+            fl = torch.tensor([flag_value], dtype=torch.int32, device=device)
             dist.all_reduce(fl, op=dist.ReduceOp.MIN)
             return int(fl.item()) == 1
 
@@ -966,7 +1117,7 @@ def main():
             b0 = host.band_for_rank(W, H, rank, world)
             f0, d0 = resident(b0)
             f0.cull(cam.frame, d_lights, N, d0)
-            torch.cuda.synchronize()
+            dev.synchronize()
         except Exception as e:
             ok = 0
             print(f"[bench] rank {rank}: split-frame calibration failed ({type(e).__name__}: {e})", file=sys.stderr)
@@ -974,33 +1125,31 @@ def main():
             split = {"error": "calibration failed on some rank"}
         else:
             rows_entries = sdist.gather_row_entries(f0.grid[: f0.band_tiles * 2], Tx, b0.tileRowEnd - b0.tileRowBegin, Ty, b0.tileRowBegin)
-            bounds = sdist.balanced_tile_rows(rows_entries, Tx, world)
+            sbounds = [int(b) for b in sdist.balanced_tile_rows(rows_entries, Tx, world)]
             del f0, d0
-            ok, bgraph = 1, None
+            ok, brun = 1, None
             try:
-                bb = host.band_from_tile_rows(W, H, bounds[rank], bounds[rank + 1])
+                bb = host.band_from_tile_rows(W, H, sbounds[rank], sbounds[rank + 1])
                 bf, bd = resident(bb)
-                bs = torch.from_numpy(frame.surface_rows(bb.fbRowBegin, bb.fbRowBegin + bb.fbRowCount)).to(dev)
+                bs = dev.upload(frame.surface_rows(bb.fbRowBegin, bb.fbRowBegin + bb.fbRowCount))
 
                 def bstep():
                     bf.cull(cam.frame, d_lights, N, bd)
                     bf.shade(cam.frame, bs, d_lights, N, csm)
-                bstep(); torch.cuda.synchronize()
+                bstep(); dev.synchronize()
+                brun = bstep
                 if not args.no_graph:
                     try:
-                        bgraph = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(bgraph, stream=side):
-                            bstep()
+                        brun = dev.capture(side, bstep).replay
                     except Exception:
-                        bgraph = None
-                        torch.cuda.synchronize()
+                        brun = bstep
+                        dev.synchronize()
             except Exception as e:
                 ok = 0
                 print(f"[bench] rank {rank}: split-frame set-up failed ({type(e).__name__}: {e})", file=sys.stderr)
             if not all_ok(ok):
                 split = {"error": "set-up failed on some rank"}
             else:
-                brun = bgraph.replay if bgraph is not None else bstep
                 for _ in range(max(args.warmup, 20)):
                     brun()
                 barrier()
@@ -1008,45 +1157,57 @@ def main():
                 for _ in range(args.steps):
                     brun()
                 barrier()
-                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 split_elapsed = float(t.item())
-                gg, gi = sdist.exchange_lists(bf.grid[: bf.band_tiles * 2], bf.culled)
-                torch.cuda.synchronize()
+                gg, gi = dev.exchange(ctx, W, H, sbounds, bf)
+                dev.synchronize()
                 tot = int(gi[0].item())
                 split = {"what": "ONE frame split into cost-balanced tile-row bands, one band per GPU; cull and shade need no collective, an RCCL all-gather "
                                  "rebuilds the reference's global lists for consumers that want them (outside the timed steps)",
                          "scaling": "strong", "value": W * H * args.steps / split_elapsed / 1e6, "unit": "Mpixels/s",
                          "ms_per_step": split_elapsed / args.steps * 1e3, "speedup_vs_one_gpu_whole_frame": ms_per_step / (split_elapsed / args.steps * 1e3),
-                         "tile_row_bounds": [int(b) for b in bounds],
-                         "exchange": {"global_sum_num": tot, "checksum": int(gi[1:1 + tot].to(torch.int64).sum().item()), "tiles": int(gg.numel() // 2)}}
+                         "tile_row_bounds": sbounds,
+                         "exchange": {"global_sum_num": tot, "checksum": int(gi[1:1 + tot].to(torch.int64).sum().item()), "tiles": int(gg.numel() // 2), "how": dev.exchange_how}}
 
     exchange_info = None
     if dist is not None and not weak:
         gg, gi = exchange()
-        torch.cuda.synchronize()
+        dev.synchronize()
         tot = int(gi[0].item())
-        exchange_info = {"global_sum_num": tot, "checksum": int(gi[1:1 + tot].to(torch.int64).sum().item()), "tiles": int(gg.numel() // 2)}
+        exchange_info = {"global_sum_num": tot, "checksum": int(gi[1:1 + tot].to(torch.int64).sum().item()), "tiles": int(gg.numel() // 2), "how": dev.exchange_how,
+                         "tile_row_bounds": bounds}
 
+    line = None
     if rank == 0:
+        mode = ("dynamic: every light dirty every frame -- sailor_hip_prepare_lights over all %d lights inside every step, in front of the cull" % N) if dynamic else \
+               ("static: the lights' prepared views derived ONCE, outside the timed region (LightingECS::Tick uploads dirty runs only; the synthetic set does not move)" if prep is not None
+                else "plain: no prepared views, cull and shade read the 112-byte records")
         out = {
             "metric": "lit Mpixels/s (K0+K1 tile light cull + K2 PBR shade over per-tile lists)", "value": value, "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_ms": args.spinup_ms, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak" if weak else "strong", "launch": f"hipGraph replay ({per_run} steps of the frame pipeline per graph" + (f", {tail} in the last" if unroll and tail else "") + f"), 2 frames in flight over {args.list_sets} list sets" if pipelined else ("hipGraph replay" if graph is not None else "eager"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {W}x{H}, {N} point+spot lights, 16x16 tiles ({fp.Tx}x{fp.Ty}), cull + PBR shade"
+            "scaling": "weak" if weak else "strong", "launch": launch, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {W}x{H}, {N} point+spot lights" + (" (all dirty every frame)" if dynamic else "") + f", 16x16 tiles ({fp.Tx}x{fp.Ty}), cull + PBR shade"
                                    + (" + 4-cascade CSM" if csm is not None else ""),
                        "width": W, "height": H, "lights": N, "parallelism": (f"dp{world}: a whole frame per GPU" if weak else f"tile-row bands x{world}"), "partition": partition,
                        "mean_list_length": sum_nt / max(fp.band_tiles, 1), "sum_num_rank0_band": sum_nt, "distinct_lights_rank0_band": distinct,
                        "generator": {"seed": synth.SEED, "radius_scale": frame.cfg["lights"].radius_scale}},
+            "lights": {"mode": mode, "prepare_lights_ms": prepare_ms,
+                       "prepare_lights_how": "sailor_hip_prepare_lights(0, N) back to back, median of event-bracketed batches (what one frame's re-upload of every light adds)"},
             "step_ms": step_stats,
-            "value_serial": frames_per_step * W * H / (serial["median"] * 1e-3) / 1e6 if not (weak and world > 1) else None,
-            "serial_step_ms": {"median": serial["median"], "min": serial["min"], "max": serial["max"],
+            "value_serial": frames_per_step * W * H / (serial_max * 1e-3) / 1e6 if not (weak and world > 1) else None,
+            "serial_step_ms": {"median": serial["median"], "min": serial["min"], "max": serial["max"], "max_over_ranks": serial_max,
                                "how": "SURVEY.md 8d: t(K0+K1+K2) of ONE frame in flight -- cull then shade on one stream, %d batches of %d frames, one HIP event pair per batch "
-                                      "(this rank's band when N > 1); `value` above keeps two frames in flight as the reference does (RHI/Renderer.h:34)" % (serial["batches"], serial["launches_per_batch"])},
+                                      "(median / min / max: this rank's band when N > 1; value_serial divides by the slowest rank's median); `value` above keeps two frames in "
+                                      "flight as the reference does (RHI/Renderer.h:34)" % (serial["batches"], serial["launches_per_batch"])},
             "mlights_culled_per_s": N / (cull_batch_ms * 1e-3) / 1e6,
-            "cull_ms": cull_batch_ms, "shade_ms": shade_frame_ms, "shade_back_to_back_ms": shade_batch_ms,
+            "cull_ms": cull_batch_ms, "shade_ms": shade_launch_ms, "shade_back_to_back_ms": shade_batch_ms,
             "roofline": roofline,
         }
+        if other_mode is not None:
+            tag = "static_lights" if dynamic else "dynamic_lights"
+            out["value_" + tag] = other_mode["value"]
+            out["ms_per_step_" + ("static" if dynamic else "dynamic")] = other_mode["ms_per_step"]
         if exchange_info:
             out["exchange"] = exchange_info
         if afr:
@@ -1068,6 +1229,7 @@ def main():
         line = json.dumps(out)
     if dist is not None:
         dist.barrier()
+        dev.close()
         dist.destroy_process_group()
     if rank == 0:
         # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which would otherwise be flushed behind it at exit
@@ -1075,6 +1237,7 @@ def main():
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
         print(line, flush=True)
+    return line
 
 
 if __name__ == "__main__":

@@ -2,8 +2,19 @@
 // single-GPU path runs) on hosts without RCCL; the collective itself is recorded on the context stream.
 #include "common.h"
 #include <dlfcn.h>
+#include <link.h>
+#include <string.h>
 
 typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, void* /*ncclComm_t*/, hipStream_t);
+
+// The communicator the caller hands over was made by SOME copy of librccl; the collective must come from the same copy (a PyTorch process carries its own
+// under torch/lib beside the one in /opt/rocm/lib: two libraries with separate state).  So: a librccl that is already mapped into the process wins,
+// whatever its path; only a process without one gets the loader's default.
+static int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out)
+{
+    if (info->dlpi_name && strstr(info->dlpi_name, "librccl.so")) { *(const char**)out = info->dlpi_name; return 1; }
+    return 0;
+}
 
 static nccl_allgather_fn resolve_allgather()
 {
@@ -11,7 +22,11 @@ static nccl_allgather_fn resolve_allgather()
     static bool tried = false;
     if (!tried) {
         tried = true;
-        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        void* h = nullptr;
+        const char* loaded = nullptr;
+        dl_iterate_phdr(find_loaded_rccl, &loaded);
+        if (loaded) h = dlopen(loaded, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (h) fn = (nccl_allgather_fn)dlsym(h, "ncclAllGather");
     }

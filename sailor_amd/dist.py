@@ -121,3 +121,84 @@ def gather_rows(band_rows: torch.Tensor, group=None) -> torch.Tensor:
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([parts[r][: counts[r]] for r in reversed(range(world))], 0)
+
+
+# ---- the shipped exchange: sailor_hip_exchange_light_lists_rows over an ncclComm_t (exchange.hip) -------------------------------
+def _load_rccl():
+    """The librccl this process already has mapped (torch brings its own copy under torch/lib; exchange.hip looks for the same one), else the loader's."""
+    import ctypes as C
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(" ", 1)[-1].strip()
+                if "librccl.so" in path:
+                    return C.CDLL(path)
+    except OSError:
+        pass
+    try:
+        return C.CDLL("librccl.so.1")
+    except OSError:
+        return C.CDLL("librccl.so")
+
+
+class RcclComm:
+    """An ncclComm_t over the ranks of a torch.distributed group, created the way a host engine creates one: rank 0's ncclGetUniqueId travels over the
+    existing group, every rank calls ncclCommInitRank.  `handle` is what the C-ABI's `comm` arguments take.  One rank per GPU (RCCL refuses two ranks
+    on one device)."""
+
+    def __init__(self, rank: int, world_size: int, group=None):
+        import ctypes as C
+        self.lib = _load_rccl()
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        uid = UniqueId()
+        if rank == 0 and self.lib.ncclGetUniqueId(C.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        if world_size > 1:
+            box = [bytes(bytearray(uid)) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            C.memmove(C.byref(uid), box[0], 128)
+        comm = C.c_void_p()
+        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        rc = self.lib.ncclCommInitRank(C.byref(comm), world_size, uid, rank)
+        if rc != 0:
+            raise RuntimeError(f"ncclCommInitRank failed: {rc}")
+        self.handle, self.rank, self.world_size = comm, rank, world_size
+
+    def close(self):
+        if getattr(self, "handle", None):
+            import ctypes as C
+            self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
+            self.lib.ncclCommDestroy(self.handle)
+            self.handle = None
+
+
+def exchange_lists_rccl(ctx, comm: "RcclComm", width: int, height: int, tile_row_bounds, band_grid: torch.Tensor, band_culled: torch.Tensor):
+    """The split frame's exchange as the C++ host runs it (HipGraphicsDriver::ExchangeLightLists -> sailor_hip_exchange_light_lists_rows: three
+    ncclAllGather on `comm` and the context's stream + one stitch kernel).  tile_row_bounds: world + 1 tile-row boundaries (equal or cost-balanced
+    bands).  Returns (global_grid int32[T*2], global_culled int32[1 + T*128]) on this rank, canonical layout; exchange_lists above is the same
+    exchange over torch.distributed (the gloo tests' stand-in)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib
+    lib = ctx._lib
+    world = comm.world_size
+    bounds = np.ascontiguousarray(tile_row_bounds, np.int32)
+    assert len(bounds) == world + 1
+    Tx, Ty = host.num_tiles(width, height)
+    need = lib.sailor_hip_exchange_workspace_size_rows(width, height, world, bounds.ctypes.data)
+    if need == 0:
+        raise ValueError(f"invalid tile-row bounds {bounds.tolist()} for {width}x{height} over {world} ranks")
+    dev = band_culled.device
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    out_grid = torch.zeros(Tx * Ty * 2, dtype=torch.int32, device=dev)
+    out_culled = torch.zeros(1 + Tx * Ty * _lib.LIGHTS_PER_TILE, dtype=torch.int32, device=dev)
+    _lib.check(lib.sailor_hip_exchange_light_lists_rows(ctx.handle, comm.handle, comm.rank, world, width, height, bounds.ctypes.data, band_grid.data_ptr(),
+                                                         band_culled.data_ptr(), out_grid.data_ptr(), Tx * Ty, out_culled.data_ptr(), out_culled.numel(),
+                                                         ws.data_ptr(), ws.numel()),
+               "sailor_hip_exchange_light_lists_rows", ctx.handle)
+    ctx.synchronize()   # (the workspace is released on return)
+    return out_grid, out_culled

@@ -36,10 +36,10 @@ def ctx():
     c.close()
 
 
-def oracle_tile_rows(num_rows: int, fixed, whole_from_threads: int = 1):
+def oracle_tile_rows(num_rows: int, fixed, whole_from_threads: int = 32):
     """The tile rows a full-size test holds against the oracle, as (first row, count) spans: the WHOLE frame when the host has at least
     `whole_from_threads` threads for the threaded checkers (oracle_light_cull_threads / oracle_shade_threads: the GPU box has 256, and the 4K frame
-    takes seconds on 8), otherwise the fixed spans given.  SAILOR_ORACLE_ROWS=r0:n[,r0:n...] overrides both (a failure on some other row is
+    takes seconds there; a host with fewer than 32 threads checks the fixed spans instead of spending a minute per frame -- ADVICE r03), otherwise the fixed spans given.  SAILOR_ORACLE_ROWS=r0:n[,r0:n...] overrides both (a failure on some other row is
     reproduced by naming it); nothing here depends on the date."""
     from oracle import oracle
     env = os.environ.get("SAILOR_ORACLE_ROWS")
