@@ -73,6 +73,7 @@ def parse(argv=None):
                     help="every light is dirty every frame (LightingECS::Tick re-uploads it, ECS/LightingECS.cpp:152-191): sailor_hip_prepare_lights over all N lights inside "
                          "every step, in front of the cull.  The default for C5 (\"1 M dynamic lights\"); the other configurations report it beside `value` as value_dynamic_lights")
     ap.add_argument("--static-lights", dest="dynamic_lights", action="store_false", help="the lights' prepared views are derived once, outside the timed region (the default except for C5)")
+    ap.add_argument("--pack-inline", action="store_true", help="k1_pack inside every cull on the cull's stream (rounds 1-3) instead of deferred to a third stream beside the shade")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--equal-bands", action="store_true", help="N > 1: equal tile-row bands instead of cost-balanced ones")
     ap.add_argument("--split-frame", action="store_true", help="N > 1: ONE frame split into tile-row bands is `value` (the default; kept for old command lines)")
@@ -184,23 +185,35 @@ def event_ms(fn, steps):
     return float(t.mean()), float(np.median(t)), float(np.percentile(t, 10)), float(np.percentile(t, 90))
 
 
-def kernel_in_frame_ms(before, kernel, launches):
-    """The duration of ONE kernel by a HIP event pair around EVERY launch of it, each launch between its real neighbours: before(); [a] kernel() [b];
-    before(); ... on the launch stream, eagerly.  before() = the rest of the frame (the cull chain), so the kernel starts on the cache and write-back
-    state its predecessors leave and is followed at once by the next frame's work -- nothing is subtracted and no two medians are combined: every
-    sample is the kernel itself plus the two event packets at its edges.  (Fifty launches of the kernel back to back -- back_to_back_launch_ms -- run
-    into each other's write-back; a pair around a launch with the GPU drained on both sides -- isolated_* -- includes ramp-up from idle.)"""
+def kernel_in_frame_ms(ctx, before, kernel, launches, kernels_per_call=1, which=0):
+    """The duration of ONE kernel, read DIRECTLY and in place: every launch of it carries a HIP event pair on its own dispatch packet
+    (sailor_hip_context_time_launches -> hipExtLaunchKernel's start / stop events), i.e. the command processor's timestamps of that kernel -- the
+    figure rocprofv3's kernel trace reports -- while the launch sits between its real neighbours: before(); kernel(); before(); ... on the launch
+    stream, eagerly, nothing drained around it.  Nothing is subtracted and no two medians are combined.  (Events recorded in front of and behind a
+    launch drain the stream on both sides -- isolated_* -- and fifty launches of the kernel alone back to back run into each other's write-back --
+    back_to_back_launch_ms.)  kernels_per_call / which: kernel() launches several kernels and the `which`-th is the one wanted."""
     dev = _dev()
-    pairs = []
-    for _ in range(launches):
+    for i in range(launches):
         before()
-        a, b = dev.event(), dev.event()
-        a.record(); kernel(); b.record()
-        pairs.append((a, b))
+        ctx.time_launches(i * kernels_per_call, kernels_per_call)
+        kernel()
     dev.synchronize()
-    t = np.array([a.elapsed_time(b) for a, b in pairs])
+    t = np.array([ctx.timed_launch_ms(i * kernels_per_call + which) for i in range(launches)])
     return {"mean": float(t.mean()), "median": float(np.median(t)), "p10": float(np.percentile(t, 10)), "p90": float(np.percentile(t, 90)),
             "min": float(t.min()), "max": float(t.max()), "launches": int(len(t))}
+
+
+def chain_kernels_ms(ctx, chain, behind, launches, count):
+    """the durations of the `count` kernels one chain() call launches (the cull chain), each by the event pair on its own dispatch packet, between
+    their real neighbours (behind() = the rest of the frame): median over `launches` frames per kernel, in launch order"""
+    dev = _dev()
+    for i in range(launches):
+        ctx.time_launches(i * count, count)
+        chain()
+        behind()
+    dev.synchronize()
+    t = np.array([[ctx.timed_launch_ms(i * count + k) for k in range(count)] for i in range(launches)])
+    return [float(v) for v in np.median(t, axis=0)]
 
 
 BATCHES = 5          # per-kernel figures: the median of this many batches ...
@@ -639,20 +652,24 @@ def blur_block(ctx, steps: int):
             "cpu_1thread_mtexels_per_s": 512 * 512 / t_cpu / 1e6, "kind": "port"}
 
 
-def capture_frame_pipeline(side, side2, unroll, shade_fns, cull_fns, dev=None):
+def capture_frame_pipeline(side, side2, unroll, shade_fns, cull_fns, dev=None, pack_fns=None, side3=None):
     """One hipGraph holding `unroll` steps (a multiple of the number S of list sets) of the two-frames-in-flight pipeline: shade_fns[p]() records
     frame k's shade from set p = k % S on `side`, cull_fns[q]() records frame k + 1's cull into set q = (k + 1) % S on `side2`.  The only
     dependencies are the frames' own: shade(k) waits for cull(k), cull(k + 1) for the shade that last read its set, shade(k + 1 - S); one join at
     the end of the graph.  The lists of frame 0 (set 0) must exist before the first replay.
     S = 3 (the default): with two sets cull(k + 1) and shade(k) both start the moment shade(k - 1) ends, and the cross-queue wait sits on the
     critical path -- the kernel trace shows ~10 us between the end of one shade and the start of the next (scripts/analysis/pipeline_timeline.py);
-    with a third set the cull waits for a shade that ended a frame ago, and the shades follow each other like launches on one stream."""
+    with a third set the cull waits for a shade that ended a frame ago, and the shades follow each other like launches on one stream.
+    pack_fns / side3 (round 4): the culls were recorded with SAILOR_CULL_DEFER_PACK -- the shade reads the per-tile lists, so nothing on the frame's
+    path needs lightsGrid / culledLights -- and pack_fns[q]() writes set q's canonical buffers on a third stream behind its cull: shade(k + 1) and
+    cull(k + 2) do not wait for it, only the next cull into the SAME set does (it overwrites what the pack reads)."""
     dev = dev or _dev()
     S = len(shade_fns)
-    assert len(cull_fns) == S
+    assert len(cull_fns) == S and (pack_fns is None or (len(pack_fns) == S and side3 is not None))
 
     def body():
         shade_done = [None] * S
+        pack_done = [None] * S
         cull_done = None
         for k in range(unroll):
             p, q = k % S, (k + 1) % S
@@ -664,10 +681,19 @@ def capture_frame_pipeline(side, side2, unroll, shade_fns, cull_fns, dev=None):
                 side2.wait_event(shade_done[q])
             elif k == 0:
                 side2.wait_stream(side)  # fork
+            if pack_done[q] is not None:
+                side2.wait_event(pack_done[q])
             with dev.on_stream(side2):
                 cull_fns[q]()
                 cull_done = dev.event(False); cull_done.record(side2)
+            if pack_fns is not None:
+                side3.wait_event(cull_done)
+                with dev.on_stream(side3):
+                    pack_fns[q]()
+                    pack_done[q] = dev.event(False); pack_done[q].record(side3)
         side.wait_stream(side2)  # join
+        if pack_fns is not None:
+            side.wait_stream(side3)
     return dev.capture(side, body)
 
 
@@ -854,12 +880,13 @@ def main(argv=None, device_factory=None):
         simulate_split(args, dev, ctx, side, frame, d_lights, fp, d_depth, prep)
         return
 
-    def cull_of(f, c, dyn):
+    def cull_of(f, c, dyn, defer_pack=False):
         """one frame's cull chain into f's list set, recorded on context c's stream (None: the launch stream); with dynamic lights the preparation
-        of every light goes in front of it, on the same stream"""
+        of every light goes in front of it, on the same stream.  defer_pack: stop after the per-tile lists (the shade reads those); f.pack() writes
+        lightsGrid / culledLights wherever the caller records it"""
         if dyn:
             f.prepared.prepare(0, N, ctx=c)
-        f.cull(cam.frame, d_lights, N, d_depth, ctx=c)
+        f.cull(cam.frame, d_lights, N, d_depth, ctx=c, defer_pack=defer_pack)
 
     def cull():
         cull_of(fp, None, dynamic)
@@ -888,11 +915,17 @@ def main(argv=None, device_factory=None):
     # second, shorter graph for the rest, so the timed region is exactly K steps (pipeline_unroll).
     want_pipeline = args.frames_in_flight == 2 and not args.no_graph and not args.exchange_every_step
     unroll, tail = pipeline_unroll(args.steps, args.list_sets)
-    side2 = ctx2 = None
+    # (round 4) the shade reads the cull's per-tile lists, so the compaction into the reference's lightsGrid / culledLights (k1_pack) is off the
+    # frame's path: recorded on a third stream behind its cull -- every frame still produces both canonical buffers.  --pack-inline: rounds 1-3's form.
+    defer_pack = not args.pack_inline and hasattr(fp, "pack")
+    side2 = dev.stream(priority=int(os.environ.get('SAILOR_CULL_PRIORITY', '0')))
+    ctx2 = dev.context(side2)
+    side3 = ctx3 = None
+    if defer_pack:
+        side3 = dev.stream()
+        ctx3 = dev.context(side3)
     fps = (fp,)
     if want_pipeline:
-        side2 = dev.stream(priority=int(os.environ.get('SAILOR_CULL_PRIORITY', '0')))
-        ctx2 = dev.context(side2)
         fps = (fp,) + tuple(resident(band, True)[0] for _ in range(args.list_sets - 1))   # further sets of grid / culledLights / workspace / prepared views
         for f in fps:               # eager warm-up of every set (also sizes every internal buffer before capture)
             f.cull(cam.frame, d_lights, N, d_depth)
@@ -910,14 +943,15 @@ def main(argv=None, device_factory=None):
         if want_pipeline:
             try:
                 graphs = [capture_frame_pipeline(side, side2, length, [lambda f=f: f.shade(cam.frame, d_surface, d_lights, N, csm) for f in fps],
-                                                 [lambda f=f: cull_of(f, ctx2, dyn) for f in fps], dev) if length else None for length in (unroll, tail)]
+                                                 [lambda f=f: cull_of(f, ctx2, dyn, defer_pack) for f in fps], dev,
+                                                 [lambda f=f: f.pack(ctx3) for f in fps] if defer_pack else None, side3) if length else None for length in (unroll, tail)]
                 cull_of(fps[0], None, dyn)                     # prologue: frame 0's lists
                 dev.synchronize()
                 main_graph = graphs[0] if graphs[0] is not None else graphs[1]
                 rest = graphs[1] if graphs[0] is not None else None
                 per = unroll if unroll else tail
                 how = (f"hipGraph replay ({per} steps of the frame pipeline per graph" + (f", {tail} in the last" if unroll and tail else "") +
-                       f"), 2 frames in flight over {args.list_sets} list sets")
+                       f"), 2 frames in flight over {args.list_sets} list sets" + (", k1_pack on a third stream beside the shade" if defer_pack else ""))
                 return main_graph.replay, (rest.replay if rest is not None else (lambda: None)), per, how
             except Exception as e:
                 print(f"[bench] two-frames-in-flight capture failed ({type(e).__name__}: {e}); falling back to one frame in flight", file=sys.stderr)
@@ -1000,11 +1034,27 @@ def main(argv=None, device_factory=None):
         t = torch.tensor([serial_max], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         serial_max = float(t.item())
+    # ... and the same frame with k1_pack beside the shade (the form the frame pipeline above launches; still ONE frame in flight: the next
+    # frame's cull waits for this frame's shade AND pack)
+    serial_deferred = None
+    if defer_pack:
+        def frame_deferred():
+            cull_of(fp, None, dynamic, True)
+            side2.wait_stream(side)
+            with dev.on_stream(side2):
+                fp.pack(ctx2)
+            shade()
+            side.wait_stream(side2)
+        serial_deferred = event_batch_stats(frame_deferred, args.steps, batch_stream)
     pipeline_ms = event_batch_ms(lambda: (cull(), shade()), args.steps)   # eager cull + shade chains back to back: the step without graphs or overlap
     cull_eager_ms = event_batch_ms(cull, args.steps)
-    # THE ROOFLINE'S DURATION: one HIP event pair around every launch of the dominant kernel, each launch between its real neighbours (the cull
-    # chain in front, the next frame's behind) -- a direct reading of the kernel, no difference of two measurements (VERDICT r03 / ADVICE r03)
-    direct = kernel_in_frame_ms(cull, shade, max(args.steps, BATCH_LAUNCHES))
+    # THE ROOFLINE'S DURATION: the dominant kernel's own dispatch-packet timestamps (an event pair riding on every launch of it), each launch between
+    # its real neighbours (the cull chain in front, the next frame's behind) -- a direct reading of the kernel, the figure rocprofv3's kernel trace
+    # reports, no difference of two measurements (VERDICT r03 / ADVICE r03)
+    direct = kernel_in_frame_ms(ctx, cull, shade, max(args.steps, BATCH_LAUNCHES))
+    chain_names = (["k_prepare_lights"] if dynamic else []) + (["k01_prepare", "k1_tile_cull<brute>", "k1_pack"] if N < 512 else
+                                                                ["k01_prepare", "k1_group_lists" + ("_wide" if N >= 262144 else ""), "k1_tile_cull", "k1_pack"])
+    chain_ms = chain_kernels_ms(ctx, cull, shade, max(args.steps, BATCH_LAUNCHES), len(chain_names))
     g, idx = fp.lists_to_host()
     sum_nt = int(idx[0])
     distinct = int(len(np.unique(idx[1:]))) if sum_nt else 0
@@ -1031,7 +1081,8 @@ def main(argv=None, device_factory=None):
     trace_ms = trace_kernel_ms(shade_kernel, args.config, world)
     roofline = {"bound": "hbm", "kernel": shade_kernel, "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
                 "traffic": measured_traffic(shade_kernel, args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_launch_ms,
-                "timing": "the kernel's own launches, measured directly: one HIP event pair around EVERY launch on the launch stream, each launch between its real neighbours "
+                "timing": "the kernel's own launches, measured directly: a HIP event pair on the dispatch packet of EVERY launch (hipExtLaunchKernel start / stop events = the "
+                          "command processor's timestamps of that kernel, what rocprofv3 --kernel-trace reports), each launch between its real neighbours on the launch stream "
                           "(this frame's cull chain in front of it, the next frame's behind it; eager launches, one frame in flight), mean of %d launches -- compare "
                           "rocprof_kernel_avg_ms, the kernel's duration in rocprofv3 --kernel-trace --stats of the same frame (profiles/<round>/kernel_stats.csv).  "
                           "in_frame_by_difference_ms = median(serial step) - median(cull chain alone), event-bracketed hipGraph batches (round 3's figure); "
@@ -1050,7 +1101,9 @@ def main(argv=None, device_factory=None):
                 "valu_sidebar": {"pixel_light_evals": evals, "gevals_per_s": evals / (shade_launch_ms * 1e-3) / 1e9,
                                  "note": "~110 fp32 ops per (pixel,light): VALU-bound once mean list length exceeds ~10 (SURVEY.md 7, hard part 2)"},
                 "csm": csm_info,
-                "cull": {"kernels": ("k_prepare_lights+" if dynamic else "") + "k01_prepare+k1_*", "avg_ms": cull_batch_ms, "isolated_avg_ms": cull_ms[0], "isolated_median_ms": cull_ms[1],
+                "cull": {"kernels": ("k_prepare_lights+" if dynamic else "") + "k01_prepare+k1_*", "kernels_ms": dict(zip(chain_names, chain_ms)), "kernels_sum_ms": float(sum(chain_ms)),
+                         "kernels_how": "median over the frames of the direct reading above, per kernel of the chain (each kernel's own dispatch-packet timestamps)",
+                         "avg_ms": cull_batch_ms, "isolated_avg_ms": cull_ms[0], "isolated_median_ms": cull_ms[1],
                          "bytes": b_cull, "achieved_gbs": b_cull / (cull_batch_ms * 1e-3) / 1e9, "frac": b_cull / (cull_batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "whole_path": {"what": "cull chain + shade, SURVEY.md 8d's bytes of both over the serial step (one frame in flight) and over `ms_per_step`",
                                "bytes": b_cull + b_shade, "frac_serial": (b_cull + b_shade) / (serial["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -1200,6 +1253,8 @@ def main(argv=None, device_factory=None):
                                "how": "SURVEY.md 8d: t(K0+K1+K2) of ONE frame in flight -- cull then shade on one stream, %d batches of %d frames, one HIP event pair per batch "
                                       "(median / min / max: this rank's band when N > 1; value_serial divides by the slowest rank's median); `value` above keeps two frames in "
                                       "flight as the reference does (RHI/Renderer.h:34)" % (serial["batches"], serial["launches_per_batch"])},
+            "value_serial_pack_beside_shade": (frames_per_step * W * H / (serial_deferred["median"] * 1e-3) / 1e6) if (serial_deferred and not (weak and world > 1)) else None,
+            "serial_step_pack_beside_shade_ms": serial_deferred,
             "mlights_culled_per_s": N / (cull_batch_ms * 1e-3) / 1e6,
             "cull_ms": cull_batch_ms, "shade_ms": shade_launch_ms, "shade_back_to_back_ms": shade_batch_ms,
             "roofline": roofline,

@@ -193,6 +193,14 @@ SAILOR_HIP_API int sailor_hip_context_stream(SailorHipContext* ctx, void** outSt
 /* Text of the last HIP/RCCL error seen by this context (never NULL). */
 SAILOR_HIP_API const char* sailor_hip_context_last_error(SailorHipContext* ctx);
 
+/* Measurement aid (no reference counterpart): the next `count` kernel launches recorded through this context carry a HIP event pair on their own
+ * dispatch packets (hipExtLaunchKernel's start / stop events) in slots [firstSlot, firstSlot + count), in launch order -- e.g. the four kernels of
+ * one sailor_hip_light_cull, or the one of a sailor_hip_shade.  sailor_hip_context_timed_launch_ms waits for a slot's kernel and returns its
+ * duration: the command processor's timestamps of THAT kernel -- the figure rocprofv3 --kernel-trace reports -- without draining the stream around
+ * it as events recorded in front of and behind a launch do.  Eager launches only (not inside a hipGraph capture); at most 4 096 slots. */
+SAILOR_HIP_API int sailor_hip_context_time_launches(SailorHipContext* ctx, int32_t firstSlot, int32_t count);
+SAILOR_HIP_API int sailor_hip_context_timed_launch_ms(SailorHipContext* ctx, int32_t slot, float* outMs);
+
 /* ---- buffers: IGraphicsDriver::CreateBuffer (RHI/GraphicsDriver.h:89-90), AddSsboToShaderBindings (:154),
  *      IGraphicsDriverCommands::UpdateShaderBinding / UpdateBuffer (:303-304) -------------------------------- */
 SAILOR_HIP_API int sailor_hip_buffer_create(SailorHipContext* ctx, size_t bytes, void** outDevicePtr);
@@ -244,6 +252,10 @@ SAILOR_HIP_API int sailor_hip_band_is_valid(int32_t width, int32_t height, const
                                       the tile's min / max are taken on the raw bits and only two values per tile are divided */
 #define SAILOR_CULL_INTERVAL_MASKS 4u /* build the pre-filter masks from per-light band intervals (the default above 262 144 lights) also for small
                                        * light sets with <= 256 bands: same lists, for validation */
+#define SAILOR_CULL_DEFER_PACK 8u     /* stop after the per-tile lists: dLightsGrid / dCulledLights are NOT written by this call.  The lists are complete in the
+                                       * workspace (sailor_hip_light_cull_tile_lists; sailor_hip_shade_tile_lists shades from them), and
+                                       * sailor_hip_light_cull_pack -- on any context / stream ordered after this call, e.g. a second stream beside the shade --
+                                       * produces the two canonical buffers from them, bit for bit what the undeferred call writes */
 
 SAILOR_HIP_API size_t sailor_hip_light_cull_workspace_size(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band);
 SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
@@ -252,6 +264,20 @@ SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
                                          SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity,
                                          void* dWorkspace, size_t workspaceBytes,
                                          const SailorBand* band, uint32_t flags);
+
+/* The cull's own per-tile form of the lists (round 4).  Every tile of the band leaves its list in a fixed 128-entry slot of the workspace --
+ * tileLists[bandTile * 128 + i] = i-th light of the tile, the same entries in the same order as culledLights[offset + i] -- and its length (<= 128) in
+ * tileNum[bandTile].  A consumer that only needs "the lights of tile t" (the shade: Standard.shader:422-436) reads them there and does not depend on the
+ * compaction into the reference's layout, which then leaves the frame's critical path: SAILOR_CULL_DEFER_PACK + sailor_hip_light_cull_pack on a
+ * second stream.  The pointers depend on (width, height, band) alone (lightsCapacity: any light count the workspace can hold) and stay valid until the
+ * next cull on the same workspace.  The tile-order hint below is written by the pack step: with a deferred pack it is there once that has run. */
+SAILOR_HIP_API int sailor_hip_light_cull_tile_lists(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band, const void* dWorkspace,
+                                                    const uint32_t** outTileNum, const uint32_t** outTileLists);
+/* Replaces: nothing of its own -- the second half of the Dispatch at LightCullingNode.cpp:74-77 (Appendix A step 6: offsets = prefix sum of the list
+ * lengths in tile order, ComputeLightCulling.shader:227-238 without its atomic allocation order) when sailor_hip_light_cull ran with
+ * SAILOR_CULL_DEFER_PACK.  Arguments as there. */
+SAILOR_HIP_API int sailor_hip_light_cull_pack(SailorHipContext* ctx, int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band,
+                                              const void* dWorkspace, SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity);
 
 /* Shading hint.  sailor_hip_light_cull also leaves, in its workspace, the band's LONG tiles as an array of T + 2 words (T = tiles of the
  * band), each tile as tileX | tileRowInBand << 16: the nA tiles with >= 96 lights at [0, nA), the nB tiles with 40..95 lights at
@@ -352,6 +378,18 @@ SAILOR_HIP_API int sailor_hip_shade_prepared(SailorHipContext* ctx, const Sailor
                                              const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance,
                                              const SailorBand* band, const uint32_t* dTileOrder,
                                              const void* dPreparedLights /* or NULL */, int32_t preparedCapacity);
+
+/* As sailor_hip_shade_prepared, reading the lists where the cull left them (sailor_hip_light_cull_tile_lists: dTileNum[t] entries at
+ * dTileLists[128 t ..] for band tile t) instead of through lightsGrid / culledLights: the same entries in the same order, hence the same radiance bit
+ * for bit -- and no dependence on the compaction step (SAILOR_CULL_DEFER_PACK).  This is the form the HIP backend records for RenderSceneNode's
+ * draws when the lists come from its own LightCulling node (Standard.shader:422-436 is the loop it replaces either way). */
+SAILOR_HIP_API int sailor_hip_shade_tile_lists(SailorHipContext* ctx, const SailorUboFrameData* frame,
+                                               const float* dSurface, size_t surfacePlaneStride,
+                                               const SailorLightShaderData* dLights, int32_t lightsNum,
+                                               const uint32_t* dTileNum, const uint32_t* dTileLists,
+                                               const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance,
+                                               const SailorBand* band, const uint32_t* dTileOrder,
+                                               const void* dPreparedLights /* or NULL */, int32_t preparedCapacity);
 
 /* Self-check of the shade kernels' short forms of exact arithmetic (no reference counterpart: the shader leaves sqrt and 1 / x to the driver).
  * K2 evaluates normalize() as v * (1 / sqrt(dot(v, v))) with a correctly rounded square root and reciprocal, but not through the compiler's

@@ -24,6 +24,7 @@ CULL_DEFAULT = 0
 CULL_BRUTE_FORCE = 1
 CULL_RAW_DEPTH = 2
 CULL_INTERVAL_MASKS = 4
+CULL_DEFER_PACK = 8
 
 RASTER_CLEAR, RASTER_CULL_BACK = 1, 2
 SHADOWMAP_R16F = 0
@@ -124,6 +125,12 @@ SIGNATURES = {
     "sailor_hip_shade_prepared": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_size_t, _P, C.c_int32, _P, _P, C.POINTER(CsmDesc), C.POINTER(IblDesc), _P,
                                             C.POINTER(Band), _P, _P, C.c_int32]),
     "sailor_hip_light_cull_tile_order": (_P, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band), _P]),
+    "sailor_hip_light_cull_tile_lists": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band), _P, C.POINTER(_P), C.POINTER(_P)]),
+    "sailor_hip_light_cull_pack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band), _P, _P, _P, C.c_size_t]),
+    "sailor_hip_shade_tile_lists": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_size_t, _P, C.c_int32, _P, _P, C.POINTER(CsmDesc), C.POINTER(IblDesc), _P,
+                                              C.POINTER(Band), _P, _P, C.c_int32]),
+    "sailor_hip_context_time_launches": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "sailor_hip_context_timed_launch_ms": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float)]),
     "sailor_hip_evsm_blur": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sailor_hip_evsm_blur_pass": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sailor_hip_compute_brdf_lut": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),

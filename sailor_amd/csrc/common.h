@@ -1,10 +1,12 @@
 // Internal helpers shared by the HIP translation units of libsailor_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <vector>
 
 #define SAILOR_HIP_BUILD 1
 #include "../../include/sailor_hip.h"
@@ -19,6 +21,9 @@ struct SailorHipContext {
     bool ownsStream = false;
     int numCUs = 256;
     std::string lastError;
+    // sailor_hip_context_time_launches: event pairs that ride on the dispatch packets of the next launches (slots [timeNext, timeEnd))
+    std::vector<hipEvent_t> timeStart, timeStop;
+    int timeNext = 0, timeEnd = 0;
 };
 
 static inline int sailor_map_hip_error(SailorHipContext* ctx, hipError_t e, const char* what)
@@ -53,6 +58,19 @@ static inline int sailor_map_hip_error(SailorHipContext* ctx, hipError_t e, cons
     } while (0)
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Every kernel of the path is launched through this: an ordinary launch on the context's stream, or -- while timing slots are armed
+// (sailor_hip_context_time_launches) -- the same launch with a start / stop event pair attached to ITS dispatch packet (hipExtLaunchKernel): the
+// command processor's own timestamps of that kernel, i.e. what rocprofv3's kernel trace reports, read live and without draining the stream
+// around the kernel as an event recorded in front of and behind it does.
+template <typename K, typename... Args>
+static inline void sailor_launch(SailorHipContext* ctx, K kernel, const dim3 grid, const dim3 block, Args... args)
+{
+    if (ctx->timeNext < ctx->timeEnd) {
+        const int i = ctx->timeNext++;
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ctx->timeStart[i], ctx->timeStop[i], 0, args...);
+    } else hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, args...);
+}
 
 // ---- canonical fp32 helpers: this library is compiled with -ffp-contract=off, so the
 // expressions below evaluate exactly as written, one IEEE rounding per operation. -----------------------

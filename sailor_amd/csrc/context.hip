@@ -58,6 +58,8 @@ int sailor_hip_context_destroy(SailorHipContext* ctx)
 {
     if (!ctx) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (ctx->ownsStream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    for (hipEvent_t e : ctx->timeStart) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->timeStop) (void)hipEventDestroy(e);
     delete ctx;
     return SAILOR_HIP_OK;
 }
@@ -66,6 +68,31 @@ int sailor_hip_context_synchronize(SailorHipContext* ctx)
 {
     if (!ctx) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     SAILOR_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SAILOR_HIP_OK;
+}
+
+#define SAILOR_MAX_TIMING_SLOTS 4096
+int sailor_hip_context_time_launches(SailorHipContext* ctx, int32_t firstSlot, int32_t count)
+{
+    if (!ctx || firstSlot < 0 || count < 0 || firstSlot + count > SAILOR_MAX_TIMING_SLOTS) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    while ((int)ctx->timeStart.size() < firstSlot + count) {
+        hipEvent_t a = nullptr, b = nullptr;
+        SAILOR_TRY_HIP(ctx, hipEventCreate(&a));
+        ctx->timeStart.push_back(a);
+        SAILOR_TRY_HIP(ctx, hipEventCreate(&b));
+        ctx->timeStop.push_back(b);
+    }
+    ctx->timeNext = firstSlot;
+    ctx->timeEnd = firstSlot + count;
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_context_timed_launch_ms(SailorHipContext* ctx, int32_t slot, float* outMs)
+{
+    if (!ctx || !outMs || slot < 0 || slot >= (int)ctx->timeStart.size()) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipEventSynchronize(ctx->timeStop[slot]));
+    SAILOR_TRY_HIP(ctx, hipEventElapsedTime(outMs, ctx->timeStart[slot], ctx->timeStop[slot]));
     return SAILOR_HIP_OK;
 }
 

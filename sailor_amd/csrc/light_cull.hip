@@ -26,14 +26,19 @@
 //                      the group's candidate records are staged in LDS 512 at a time, each wave streams them through the
 //                      exact test, 64 per step; ballot/popcount ordered append; rank-based nearest-128 selection
 //                      (groups denser than 2048 candidates fall back to walking the two masks of the tile itself).
-//                      Blocks are numbered in TILE-INDEX order and leave their four lists back to back in a 512-entry
-//                      staging slot, plus one word of totals per block
+//                      The tiles of a LIGHT CLUSTER (a group with more than 512 candidates, listed by k1_group_lists) get a whole
+//                      block each at the front of the grid: four waves share the tile's candidates and its 196 -> 128 selection
+//                      (round 4; one wave took ~20 us for such a tile -- the launch's tail and a cluster band's whole cull).
+//                      Every tile leaves its list in its own fixed 128-entry slot of the workspace (`tile lists`), its length in
+//                      tileNum, and adds the length to its tile row's total
 //   k1_pack            canonical offsets (Appendix A step 6: prefix sum of the list lengths in tile order) and compaction
-//                      in ONE streaming launch without a scan chain: a pack block owns 16 consecutive staging slots and
-//                      simply adds up the totals of every slot before them (16 KB of L2 reads on average at 4K), then
-//                      copies its slots to their final place as contiguous runs.  (Tried first: a decoupled look-back inside
-//                      k1_tile_cull -- bit-exact, but every block then sits behind 1-2 more memory-side round trips and
-//                      waits, holding its CU slot, for the slowest block before it: 95 us instead of 33.)
+//                      in ONE streaming launch without a scan chain: a pack block owns 64 consecutive tiles, adds up the row
+//                      totals in front of its first row and the lengths of that row's earlier tiles itself (a few hundred words),
+//                      then moves its tiles' lists through LDS into culledLights as one contiguous run.  Since round 4 NOTHING on
+//                      the path needs its output: the shade reads a tile's list from its slot (sailor_hip_shade_tile_lists), so the
+//                      launch can run beside the shade on another stream (SAILOR_CULL_DEFER_PACK + sailor_hip_light_cull_pack) and
+//                      still produces the reference's lightsGrid / culledLights bit for bit.  (Tried in round 2: a decoupled
+//                      look-back inside k1_tile_cull -- bit-exact, 95 us instead of 33.)
 //
 // Bit-exactness: the pre-filter only ever removes lights that every tile of the column (row) would reject by its own
 // left/right (top/bottom) plane: the band's planes are the same planes through the eye (screen x = const, resp.
@@ -57,15 +62,15 @@
 #define HEAVY_MAX 256           // ... and that list's room
 #define CHUNK 512            // group candidates staged in LDS per step of k1_tile_cull (16 KB of LDS per block: 8 blocks per CU)
 
-#define SLOT 512             // staging entries per k1_tile_cull block (4 tiles x KEEP)
-#define PACK_BLOCKS 16       // staging slots per k1_pack block
+#define PACK_TILES 64        // tiles per k1_pack block
+#define CL_STEPS (CAPG / 4 / 64) // cluster tiles: 64-candidate steps per wave for the longest listable group (8)
 
-// Totals of one k1_tile_cull block: list entries (uint32) and, for the shading hint, class A tiles << 16 | class B tiles (uint32)
+// Per tile row of the band: the sum of its tiles' list lengths (uint32) and, for the shading hint, class A tiles << 16 | class B tiles (uint32)
 #define CLS_MAX_TILES 65535
 
 struct CullLayout {
-    int Tx, Ty, bandRows, bandTiles, numBands, words, groupsX, groupsY, numGroups, cullBlocks, packBlocks;
-    size_t offLightView, offLightType, offTileInfo, offMasks, offDirWords, offGroupCount, offGroupList, offTotals, offClsTotals, offTileNum, offStaging, offTileOrder, offDirFlag, offHeavy, total;
+    int Tx, Ty, bandRows, bandTiles, numBands, words, groupsX, groupsY, numGroups, packBlocks;
+    size_t offLightView, offLightType, offTileInfo, offMasks, offDirWords, offGroupCount, offGroupList, offRowTotals, offRowCls, offTileNum, offTileLists, offTileOrder, offDirFlag, offHeavy, total;
 };
 
 static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
@@ -83,24 +88,23 @@ static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
     L.groupsY = (L.bandRows + GROUP - 1) / GROUP;
     L.numGroups = L.groupsX * L.groupsY;
     L.numBands = L.groupsX + L.groupsY;      // group columns first, then the band's group rows (4 tiles wide / high)
-    L.cullBlocks = L.groupsX * L.bandRows;   // one k1_tile_cull block per (group column, tile row)
-    L.packBlocks = (L.cullBlocks + PACK_BLOCKS - 1) / PACK_BLOCKS;
+    L.packBlocks = (L.bandTiles + PACK_TILES - 1) / PACK_TILES;
     const size_t groups = (size_t)(L.numGroups > 0 ? L.numGroups : 1);
     // Sections whose size depends on the geometry only come first, those that scale with the light count last: the offset of anything a later
     // call looks up from (width, height, band) alone -- the tile-order hint -- is then the same for every lightsNum <= the capacity the
     // workspace was sized for (a cull may run with fewer lights than the capacity; round 2 computed the hint's address from the capacity and
     // the cull's own layout from lightsNum, which only agree when the two are equal).
-    const size_t cb = (size_t)(L.cullBlocks > 0 ? L.cullBlocks : 1);
+    const size_t rows = (size_t)(L.bandRows > 0 ? L.bandRows : 1);
     size_t o = 0;
     L.offTileInfo = o; o = align_up(o + tiles * 64, 256);
     L.offGroupCount = o; o = align_up(o + groups * 4, 256);
     L.offDirFlag = o; o = align_up(o + 4, 256);
     L.offHeavy = o; o = align_up(o + (1 + HEAVY_MAX) * 4, 256); // [0] = light-cluster groups listed by k1_group_lists (zeroed by k01_prepare), then their indices
     L.offGroupList = o; o = align_up(o + groups * CAPG * 4, 256);
-    L.offTotals = o; o = align_up(o + (cb + PACK_BLOCKS) * 4, 256);
-    L.offClsTotals = o; o = align_up(o + (cb + PACK_BLOCKS) * 4, 256);
+    L.offRowTotals = o; o = align_up(o + rows * 4, 256);      // zeroed by k01_prepare, added to by k1_tile_cull
+    L.offRowCls = o; o = align_up(o + rows * 4, 256);
     L.offTileNum = o; o = align_up(o + tiles * 4, 256);
-    L.offStaging = o; o = align_up(o + cb * SLOT * 4, 256);
+    L.offTileLists = o; o = align_up(o + tiles * KEEP * 4, 256); // one fixed 128-entry slot per tile (only the list's own bytes are ever touched)
     L.offTileOrder = o; o = align_up(o + (tiles + 2) * 4, 256); // long tiles (A from the front, B from the back) + their two counts
     L.offLightView = o; o = align_up(o + n * 16, 256);
     L.offLightType = o; o = align_up(o + n * 4, 256);
@@ -163,7 +167,8 @@ struct PrepareArgs {
     float4* lightView; uint32_t* lightType; float4* tileInfo;
     unsigned long long* masks; unsigned long long* dirWords;
     uint32_t* heavy;   // [0]: k1_group_lists' count of light-cluster groups, zeroed here (one launch ahead of it)
-    uint32_t* dirFlag; // "some light may be directional": set here, read by k1_group_lists_wide, cleared by k1_pack (unknown before the first cull: then merely conservative)
+    uint32_t* rowTotals; uint32_t* rowCls; // per tile row: sum of list lengths / class counts, zeroed here (two launches ahead of k1_tile_cull's atomics)
+    uint32_t* dirFlag; // "some light may be directional": set here, read by k1_group_lists_wide, cleared by k1_tile_cull (unknown before the first cull: then merely conservative)
     int N, words, lightBlocks, lightRoleBlocks, frustumBlocks, bandsPerBlock, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands,
         stripsPerRow, vecOK, rawDepth, intervals;
     float zNearCam, planeMargin;
@@ -429,7 +434,10 @@ __global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K01_PREPARE];
     const int b = (int)blockIdx.x;
-    if (b == 0 && threadIdx.x == 0) a.heavy[0] = 0u;
+    if (b == 0) {
+        if (threadIdx.x == 0) a.heavy[0] = 0u;
+        for (int r = threadIdx.x; r < a.bandRows; r += 256) { a.rowTotals[r] = 0u; a.rowCls[r] = 0u; }
+    }
     if (b < a.lightRoleBlocks) k0_lights(b, lds, a);
     else if (b < a.lightRoleBlocks + a.frustumBlocks) k1_tile_frusta(b - a.lightRoleBlocks, a);
     else k1_tile_setup(b - a.lightRoleBlocks - a.frustumBlocks, lds, a);
@@ -738,9 +746,9 @@ __device__ __forceinline__ uint32_t tile_class_word(uint32_t num) { return num >
 struct CullArgs {
     const float4* lightView; const uint32_t* lightType; const float4* tileInfo;
     const unsigned long long* masks; const uint32_t* groupCount; const uint32_t* groupList;
-    uint32_t* totals; uint32_t* clsTotals; uint32_t* tileNum; uint32_t* staging;
+    uint32_t* rowTotals; uint32_t* rowCls; uint32_t* tileNum; uint32_t* tileLists; uint32_t* dirFlag;
     int N, words, Tx, groupsX, bandRows, classes;
-    const uint32_t* heavy; int headRows; // k1_group_lists' cluster list and the grid rows in front of the tile rows that take its row blocks (0: none)
+    const uint32_t* heavy; int headRows; // k1_group_lists' cluster list and the grid rows in front of the tile rows that take its tiles (0: none)
 };
 
 // The <= 196 candidates of a tile (sIdx, ascending light index) -> its list at `out` (Appendix A steps 4 + 5).  One wave.
@@ -851,25 +859,183 @@ extern "C" __attribute__((visibility("default"))) int sailor_hip_debug_read_cull
 {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_cullProf), bytes);
 }
-#define PROF_T(i) if (threadIdx.x == 0 && blockIdx.x < 65536) g_cullProf[blockIdx.x][i] = __builtin_amdgcn_s_memtime()
+#define PROF_T(i) if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 65536) g_cullProf[blockIdx.y * gridDim.x + blockIdx.x][i] = __builtin_amdgcn_s_memtime()
 #else
 #define PROF_T(i)
 #endif
+
+__device__ __forceinline__ void load_tile_ctx(const float4* __restrict__ tileInfo, const int bandTile, TileCtx& t)
+{
+    const float4* ti = tileInfo + (size_t)bandTile * 4;
+    const float4 q0 = ti[0], q1 = ti[1], q2 = ti[2], q3 = ti[3];
+    t.n[0][0] = q0.x; t.n[0][1] = q0.y; t.n[0][2] = q0.z; t.cx = q0.w;
+    t.n[1][0] = q1.x; t.n[1][1] = q1.y; t.n[1][2] = q1.z; t.cy = q1.w;
+    t.n[2][0] = q2.x; t.n[2][1] = q2.y; t.n[2][2] = q2.z; t.zNear = q2.w;
+    t.n[3][0] = q3.x; t.n[3][1] = q3.y; t.n[3][2] = q3.z; t.zFar = q3.w;
+    t.cz = (t.zFar + t.zNear) * 0.5f;
+}
+
+// A tile of an OVERFLOWED group (more than CAPG candidates: a very dense region, or lights around the eye): one wave walks the tile's own two
+// masks.  sQ: QCAP words of LDS of the wave's own.
+__device__ __forceinline__ void walk_tile_masks(const TileCtx& t, const CullArgs& a, const int gx, const int tyLocal, uint32_t* sQ, uint32_t& count, uint32_t* sIdx)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long* __restrict__ col = a.masks + (size_t)gx * a.words;
+    const unsigned long long* __restrict__ row = a.masks + (size_t)(a.groupsX + tyLocal / GROUP) * a.words;
+    const int words = a.words;
+    uint32_t qHead = 0, qTail = 0; // ring buffer indices (wave-uniform)
+    unsigned long long next = (lane < words) ? (col[lane] & row[lane]) : 0ull;
+    for (int w0 = 0; w0 < words && count < CAND; w0 += 64) {
+        const unsigned long long m = next;
+        const int wn = w0 + 64 + lane;
+        next = (wn < words) ? (col[wn] & row[wn]) : 0ull; // prefetch the next 4096 lights' masks
+        // Scalar walk over the non-empty words of this step, in ascending order.  Each word's set bits go to the
+        // ordered queue with one mbcnt (bit k of word L = light 64 (w0 + L) + k lands behind the k' < k bits).
+        unsigned long long nz = __ballot(m != 0ull);
+        while (nz != 0ull && count < CAND) {
+            const int L = __builtin_ctzll(nz);
+            nz &= nz - 1ull;
+            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)m, L);
+            const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(m >> 32), L);
+            const unsigned long long mk = ((unsigned long long)hi << 32) | lo;
+            if ((mk >> lane) & 1ull)
+                sQ[(qTail + (uint32_t)__popcll(mk & lanemask_lt())) & (QCAP - 1)] = (uint32_t)(w0 + L) * 64u + (uint32_t)lane;
+            qTail += (uint32_t)__popcll(mk);
+            if (qTail - qHead >= 64u) { // a full wave of candidates is waiting: exact-test them
+                WAVE_SYNC();
+                const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
+                test_candidates(t, a.lightView, a.lightType, true, j, count, sIdx);
+                qHead += 64u;
+                WAVE_SYNC();
+            }
+        }
+    }
+    WAVE_SYNC();
+    if (qTail != qHead && count < CAND) { // final partial round (< 64 pending)
+        const uint32_t n = qTail - qHead;
+        const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
+        test_candidates(t, a.lightView, a.lightType, (uint32_t)lane < n, j, count, sIdx);
+    }
+}
+
+// what a tile leaves behind besides its list: the length, and its share of its tile row's totals (k1_pack's offsets; the shading hint's classes)
+__device__ __forceinline__ void publish_tile(const CullArgs& a, const int tyLocal, const int bandTile, const uint32_t num)
+{
+    a.tileNum[bandTile] = num;
+    if (num) __hip_atomic_fetch_add(a.rowTotals + tyLocal, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.classes && num >= CLASS_B) __hip_atomic_fetch_add(a.rowCls + tyLocal, tile_class_word(num), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- a tile of a LIGHT CLUSTER, one 256-thread block for the one tile (round 4).  A group with several chunks of candidates costs every one of
+// its tiles 10-25 steps of the exact test and, where more than 196 pass, a 196 -> 128 selection -- ~20 us on one wave, the tail of the whole launch
+// and THE cull of a cluster band.  Here the group's candidate list is cut into four contiguous shares, one per wave: each wave tests its share (its
+// list entries, then its gathers: the records go from L2 straight into the lanes that test them, no LDS staging -- every record is used once) and
+// appends what passes to a list of its own; the tile's candidate sequence is the four lists one after the other (ascending light index, cut at
+// 196: what a wave collects beyond its first 196 can never be among the tile's first 196), and the selection's rank -- one candidate per THREAD
+// against all n -- takes ~200 comparisons per thread instead of ~800 per lane.  Same candidates in the same order, same impacts, same rank rule
+// (impact ascending, position descending): the list is the one-wave form's bit for bit (tests/test_light_cull_gpu.py: default == brute force).
+__device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* __restrict__ lds, uint32_t* sCnt, const int gx, const int tyLocal, const int col)
+{
+    uint32_t (*sIdxW)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds + CHUNK * 20);                  // [4][CAND]: the waves' own lists
+    uint32_t* sAll = reinterpret_cast<uint32_t*>(lds + CHUNK * 20 + 4 * CAND * 4);                      // [CAND + 4]: the tile's candidates
+    float* sImp = reinterpret_cast<float*>(lds + CHUNK * 20 + 4 * CAND * 4 + 2 * CAND * 4);             // [CAND + 4], 16-byte aligned (2 * CAND * 4 = 1568)
+    const int tx = gx * GROUP + col;
+    if (tx >= a.Tx) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int bandTile = tyLocal * a.Tx + tx, g = (tyLocal / GROUP) * a.groupsX + gx;
+    const float4* __restrict__ lightView = a.lightView;
+    const uint32_t* __restrict__ list = a.groupList + (size_t)g * CAPG;
+    uint32_t gn = a.groupCount[g];
+    gn = gn >= GROUP_OVERFLOW_LISTED ? GROUP_OVERFLOW : (gn & ~GROUP_LISTED);
+    // the wave's share: a multiple of 64 candidates, at most CL_STEPS steps; the list entries of all of it are requested at once
+    const uint32_t per = gn == GROUP_OVERFLOW ? 0u : ((gn + 255u) / 256u) * 64u;
+    const uint32_t lo = (uint32_t)wave * per, hi = min(gn == GROUP_OVERFLOW ? 0u : gn, lo + per);
+    uint32_t e[CL_STEPS];
+#pragma unroll
+    for (int k = 0; k < CL_STEPS; k++) { const uint32_t i = lo + 64u * k + (uint32_t)lane; e[k] = i < hi ? list[i] : 0u; }
+    TileCtx t;
+    load_tile_ctx(a.tileInfo, bandTile, t);
+    if (threadIdx.x == 0) sCnt[4] = 0u; // "a NaN impact" (read after the second barrier below)
+    uint32_t count = 0;
+    uint32_t* sIdx = sIdxW[wave];
+    if (gn != GROUP_OVERFLOW) {
+        // (the gathers in two batches of four: 16 registers of records in flight, not 32 -- the ordinary blocks of this kernel live on 64 registers)
+#pragma unroll
+        for (int h = 0; h < CL_STEPS; h += 4) {
+            if (lo + 64u * h >= hi) break;
+            float4 lv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) lv[k] = lightView[min(e[h + k] & 0x7FFFFFFFu, (uint32_t)(a.N - 1))];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = lo + 64u * (h + k) + (uint32_t)lane;
+                if (lo + 64u * (h + k) < hi && count < CAND) {
+                    const unsigned long long mask = __ballot(i < hi) & (__ballot((int)e[h + k] < 0) | tile_test_mask(t, lv[k])); // directional (bit 31): always a candidate
+                    wave_append_mask(mask, e[h + k], count, sIdx);
+                }
+            }
+        }
+    } else if (wave == 0) {
+        walk_tile_masks(t, a, gx, tyLocal, reinterpret_cast<uint32_t*>(lds), count, sIdx); // (the staging area of the ordinary path: unused here)
+    }
+    if (lane == 0) sCnt[wave] = count < CAND ? count : CAND;
+    __syncthreads();
+    const uint32_t c0 = sCnt[0], c1 = sCnt[1], c2 = sCnt[2], c3 = sCnt[3];
+    const uint32_t before = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u);
+    const uint32_t all = (c0 + c1) + (c2 + c3), n = all < CAND ? all : CAND, num = n < KEEP ? n : KEEP;
+    for (uint32_t i = lane; i < sCnt[wave] && before + i < CAND; i += 64) sAll[before + i] = sIdx[i];
+    __syncthreads();
+    if (threadIdx.x == 0) publish_tile(a, tyLocal, bandTile, num);
+    uint32_t* __restrict__ out = a.tileLists + (size_t)bandTile * KEEP;
+    if (n <= KEEP) { // :235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]
+        if (threadIdx.x < n) out[threadIdx.x] = sAll[n - 1 - threadIdx.x] & 0x7FFFFFFFu;
+        return;
+    }
+    // ---- 196 -> 128 (ComputeLightCulling.shader:198-225): one candidate per thread
+    const uint32_t k = threadIdx.x;
+    uint32_t mine = 0u;
+    float imp = 0.0f;
+    if (k < n) {
+        mine = sAll[k];
+        imp = (mine & 0x80000000u) ? 0.0f : tile_impact(t, lightView[mine & 0x7FFFFFFFu]);
+        sImp[k] = imp;
+    } else if (k < (uint32_t)CAND + 4u) sImp[k] = __builtin_inff();
+    if (__ballot(k < n && imp != imp) != 0ull && lane == 0) sCnt[4] = 1u;
+    __syncthreads();
+    if (sCnt[4] != 0u) { // a NaN impact has no rank: the literal bubble sort, on one wave (emit_list)
+        if (wave == 0) emit_list(t, n, sAll, sImp, lightView, out);
+        return;
+    }
+    if (k >= n) return;
+    // rank under (impact ascending, candidate position descending); keep rank < 128
+    const float4* sImp4 = reinterpret_cast<const float4*>(sImp);
+    uint32_t rank = 0u;
+    const uint32_t full4 = n / 4u;
+    for (uint32_t q4 = 0; q4 < full4; q4++) {
+        const float4 gv = sImp4[q4];
+        const float gq[4] = { gv.x, gv.y, gv.z, gv.w };
+#pragma unroll
+        for (uint32_t c = 0; c < 4; c++) {
+            const uint32_t q = q4 * 4u + c;
+            rank += (gq[c] < imp || (gq[c] == imp && q > k)) ? 1u : 0u;
+        }
+    }
+    for (uint32_t q = full4 * 4u; q < n; q++) {
+        const float gq = sImp[q];
+        rank += (gq < imp || (gq == imp && q > k)) ? 1u : 0u;
+    }
+    if (rank < KEEP) out[rank] = mine & 0x7FFFFFFFu;
+}
+
 template <bool BRUTE>
 __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
 {
-    // One 256-thread block per run of four tiles (a group's four columns in one tile row), numbered in tile-index order, one wave per
-    // tile; every block owns one staging slot.  The group's candidate records are staged in LDS, CHUNK at a time, by the four waves
-    // together (list entries first, then the dependent 16-byte gathers, four of each in flight per thread), and every tile streams
-    // them out of LDS.  Four blocks per group, not one of sixteen waves: a cluster group (2048 candidates, four 196 -> 128
-    // selections per SIMD) used to keep ONE CU busy for ~40 us while the rest of the chip idled -- the kernel's tail.  (Also measured:
-    // the block of a group's first row doing all four rows of a single-chunk group, wave w = row w, the other three blocks leaving at
-    // once -- one staging per group instead of four, but four tiles in sequence per wave: 38.8 us against 32.4.)
+    // One 256-thread block per run of four tiles (a group's four columns in one tile row), one wave per tile.  The group's candidate records are
+    // staged in LDS, CHUNK at a time, by the four waves together (list entries first, then the dependent 16-byte gathers, four of each in flight
+    // per thread), and every tile streams them out of LDS.  Four blocks per group, not one of sixteen waves: measured in rounds 2 and 3 (also: one
+    // block doing all four rows, wave w = row w: 38.8 us against 32.4).
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K1_TILE_CULL];
-    __shared__ uint32_t sNum[4];
-#ifdef CULL_ROW_FILTER
-    __shared__ uint32_t sKeep[CHUNK / 256][4];
-#endif
+    __shared__ uint32_t sCnt[5];
     float4* sLV = reinterpret_cast<float4*>(lds);                                                         // [CHUNK] candidate (view pos, radius)
     uint32_t* sE = reinterpret_cast<uint32_t*>(lds + CHUNK * 16);                                         // [CHUNK] candidate light index | directional << 31
     uint32_t (*sIdxAll)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds + CHUNK * 20);                   // [4][CAND]
@@ -877,25 +1043,24 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     const float4* __restrict__ lightView = a.lightView;
     const uint32_t* __restrict__ lightType = a.lightType;
     const int N = a.N, Tx = a.Tx, groupsX = a.groupsX;
-    // slot == block index == tile-index order: (tile row, group column).  (Measured: handing every XCD -- block i runs on XCD i % 8 -- a contiguous
-    // eighth of the slots, so that a group's four row blocks share one L2 and an XCD's gathers stay inside the lights of its band: 44 us instead of
-    // 32 -- the cluster groups all land on one XCD.)
     // (a 2-D grid, (group column, tile row of the band): the index arithmetic has no division -- by a run-time divisor that is ~35 scalar
-    // instructions, 5 % of what a wave of this kernel issues)
-    int gx = (int)blockIdx.x, tyLocal = (int)blockIdx.y - a.headRows;
-    bool head = false;
+    // instructions, 5 % of what a wave of this kernel issues.  Block order == tile-index order was what k1_pack's slots needed through round 3;
+    // with a slot per tile nothing depends on it any more.)
+    const int gx = (int)blockIdx.x, tyLocal = (int)blockIdx.y - a.headRows;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.dirFlag = 0u; // (k01_prepare of the NEXT cull sets it again if a light is directional; k1_group_lists_wide has read it)
     if (!BRUTE && tyLocal < 0) {
-        // HEAD ROWS: the row blocks of the light clusters k1_group_lists listed.  Such a block is the launch's tail wherever it sits in the grid
-        // (~20 us against ~6 for an ordinary one), so it goes first; its regular position further down leaves at once.
+        // HEAD ROWS: the tiles of the light clusters k1_group_lists listed, sixteen blocks per group, at the front of the grid (they are the
+        // launch's longest blocks); the blocks at their regular positions further down leave at once.
         const uint32_t hb = blockIdx.y * (uint32_t)groupsX + blockIdx.x;
-        if ((hb >> 2) >= min(a.heavy[0], (uint32_t)HEAVY_MAX)) return;
-        const int hg = (int)a.heavy[1u + (hb >> 2)];
-        tyLocal = (hg / groupsX) * GROUP + (int)(hb & 3u);
-        gx = hg % groupsX;
-        if (tyLocal >= a.bandRows) return;
-        head = true;
+        if ((hb >> 4) >= min(a.heavy[0], (uint32_t)HEAVY_MAX)) return;
+        const int hg = (int)a.heavy[1u + (hb >> 4)];
+        const int row = (hg / groupsX) * GROUP + (int)((hb >> 2) & 3u);
+        if (row >= a.bandRows) return;
+        PROF_T(0);
+        cluster_tile(a, lds, sCnt, hg % groupsX, row, (int)(hb & 3u));
+        PROF_T(3);
+        return;
     }
-    const int b = tyLocal * groupsX + gx;
     PROF_T(0);
     const int g = (tyLocal / GROUP) * groupsX + gx;
     // (the wave index as a scalar: the tile's frustum -- the same 64 bytes for all lanes -- then arrives by scalar loads instead of four vector
@@ -915,7 +1080,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
         // never look at -- 8 of the kernel's 25 MB)
         e[0] = list[threadIdx.x];
         gn = a.groupCount[g];
-        if (!head && a.headRows > 0 && (gn == GROUP_OVERFLOW_LISTED || (gn != GROUP_OVERFLOW && (gn & GROUP_LISTED)))) return; // a listed cluster: the head rows have it
+        if (a.headRows > 0 && (gn == GROUP_OVERFLOW_LISTED || (gn != GROUP_OVERFLOW && (gn & GROUP_LISTED)))) return; // a listed cluster: the head rows have it
         gn = gn >= GROUP_OVERFLOW_LISTED ? GROUP_OVERFLOW : (gn & ~GROUP_LISTED);
 #pragma unroll
         for (int k = 1; k < CHUNK / 256; k++) e[k] = (gn != GROUP_OVERFLOW && gn > 256u * k) ? list[threadIdx.x + 256u * k] : 0u;
@@ -925,15 +1090,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     const bool active = tx < Tx;
     const int bandTile = tyLocal * Tx + tx;
     TileCtx t;
-    if (active) {
-        const float4* ti = a.tileInfo + (size_t)bandTile * 4;
-        const float4 q0 = ti[0], q1 = ti[1], q2 = ti[2], q3 = ti[3];
-        t.n[0][0] = q0.x; t.n[0][1] = q0.y; t.n[0][2] = q0.z; t.cx = q0.w;
-        t.n[1][0] = q1.x; t.n[1][1] = q1.y; t.n[1][2] = q1.z; t.cy = q1.w;
-        t.n[2][0] = q2.x; t.n[2][1] = q2.y; t.n[2][2] = q2.z; t.zNear = q2.w;
-        t.n[3][0] = q3.x; t.n[3][1] = q3.y; t.n[3][2] = q3.z; t.zFar = q3.w;
-        t.cz = (t.zFar + t.zNear) * 0.5f;
-    }
+    if (active) load_tile_ctx(a.tileInfo, bandTile, t);
     uint32_t count = 0;
     if (BRUTE) {
         if (active) {
@@ -959,165 +1116,59 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
                 lv[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (threadIdx.x + 256u * k < cn) lv[k] = lightView[min(e[k] & 0x7FFFFFFFu, (uint32_t)(N - 1))];
             }
-#ifdef CULL_ROW_FILTER
-            // ROW FILTER (make EXTRA=-DCULL_ROW_FILTER; bit-exact, measured: no gain at 4K -- 49.2 us for the chain with and without it: once the
-            // tile test was down to 52 instructions a step the kernel is bound by its blocks' two dependent round trips again -- so it is not built).
-            // The group's list says "may reach this 64 x 64-pixel group"; the block's four tiles are one 16-pixel row of it, so about half of the
-            // candidates lie entirely above or below the row.  The four tiles' top and bottom planes are the SAME two planes (through the eye and
-            // the screen lines y = 16 ty, 16 (ty + 1); each tile computes them from its own corners, so the normals differ in the last bits only):
-            // a candidate beyond one of them by more than the margin the band masks use (1000 x the fp32 error) is rejected by every tile's own
-            // test, and dropping it here -- while the records are still in registers -- changes no tile's candidate sequence.
-            {
-                const float4* ti = a.tileInfo + (size_t)(tyLocal * Tx + gx * GROUP) * 4; // the row's first tile: always inside the frame
-                const float4 p2 = ti[2], p3 = ti[3];                                       // (block-uniform: scalar loads)
-                unsigned long long km[CHUNK / 256];
-#pragma unroll
-                for (int k = 0; k < CHUNK / 256; k++) {
-                    const uint32_t i = threadIdx.x + 256u * k;
-                    const float4 v = lv[k];
-                    const float thr = -(v.w + 1e-3f * ((fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w))));
-                    const unsigned long long out = __ballot(dot3f(p2.x, p2.y, p2.z, v.x, v.y, v.z) < thr) | __ballot(dot3f(p3.x, p3.y, p3.z, v.x, v.y, v.z) < thr);
-                    km[k] = __ballot(i < cn) & (__ballot((int)e[k] < 0) | ~out); // (a directional candidate -- bit 31 -- always stays)
-                    if (lane == 0) sKeep[k][wave] = (uint32_t)__popcll(km[k]);
-                }
-                __syncthreads();
-                uint32_t base = 0u;
-#pragma unroll
-                for (int k = 0; k < CHUNK / 256; k++) {
-                    uint32_t before = base;
-#pragma unroll
-                    for (int w = 0; w < 4; w++) { const uint32_t c = sKeep[k][w]; before += (w < wave) ? c : 0u; base += c; }
-                    if (__builtin_amdgcn_inverse_ballot_w64(km[k])) {
-                        const uint32_t pos = before + (uint32_t)__popcll(km[k] & lanemask_lt());
-                        sE[pos] = e[k]; sLV[pos] = lv[k];
-                    }
-                }
-                __syncthreads();
-                if (active) test_staged(t, base, sE, sLV, count, sIdx);
-            }
-#else
+            // (round 3 also measured a ROW FILTER here -- drop what lies entirely above / below the block's tile row before its four tiles test
+            // it, halving the test steps: 49.2 us for the chain with and without it, the kernel is bound by its dependent round trips -- removed)
 #pragma unroll
             for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; if (i < cn) { sE[i] = e[k]; sLV[i] = lv[k]; } }
             __syncthreads();
             if (active) test_staged(t, cn, sE, sLV, count, sIdx);
-#endif
         }
     } else if (active) {
         // overflowed group (very dense region / lights around the eye): every tile walks its own two masks
-        uint32_t* sQ = reinterpret_cast<uint32_t*>(sLV) + wave * QCAP; // sLV is unused on this path
-        const unsigned long long* __restrict__ col = a.masks + (size_t)gx * a.words;
-        const unsigned long long* __restrict__ row = a.masks + (size_t)(groupsX + tyLocal / GROUP) * a.words;
-        const int words = a.words;
-        uint32_t qHead = 0, qTail = 0; // ring buffer indices (wave-uniform)
-        unsigned long long next = (lane < words) ? (col[lane] & row[lane]) : 0ull;
-        for (int w0 = 0; w0 < words && count < CAND; w0 += 64) {
-            const unsigned long long m = next;
-            const int wn = w0 + 64 + lane;
-            next = (wn < words) ? (col[wn] & row[wn]) : 0ull; // prefetch the next 4096 lights' masks
-            // Scalar walk over the non-empty words of this step, in ascending order.  Each word's set bits go to the
-            // ordered queue with one mbcnt (bit k of word L = light 64 (w0 + L) + k lands behind the k' < k bits).
-            unsigned long long nz = __ballot(m != 0ull);
-            while (nz != 0ull && count < CAND) {
-                const int L = __builtin_ctzll(nz);
-                nz &= nz - 1ull;
-                const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)m, L);
-                const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(m >> 32), L);
-                const unsigned long long mk = ((unsigned long long)hi << 32) | lo;
-                if ((mk >> lane) & 1ull)
-                    sQ[(qTail + (uint32_t)__popcll(mk & lanemask_lt())) & (QCAP - 1)] = (uint32_t)(w0 + L) * 64u + (uint32_t)lane;
-                qTail += (uint32_t)__popcll(mk);
-                if (qTail - qHead >= 64u) { // a full wave of candidates is waiting: exact-test them
-                    WAVE_SYNC();
-                    const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
-                    test_candidates(t, lightView, lightType, true, j, count, sIdx);
-                    qHead += 64u;
-                    WAVE_SYNC();
-                }
-            }
-        }
-        WAVE_SYNC();
-        if (qTail != qHead && count < CAND) { // final partial round (< 64 pending)
-            const uint32_t n = qTail - qHead;
-            const uint32_t j = sQ[(qHead + lane) & (QCAP - 1)];
-            test_candidates(t, lightView, lightType, (uint32_t)lane < n, j, count, sIdx);
-        }
+        walk_tile_masks(t, a, gx, tyLocal, reinterpret_cast<uint32_t*>(sLV) + wave * QCAP, count, sIdx); // sLV is unused on this path
     }
-    const uint32_t n = count < CAND ? count : CAND;   // 0 for a wave beyond the last tile column
-    const uint32_t num = n < KEEP ? n : KEEP;
-    if (lane == 0) sNum[wave] = num;
     PROF_T(1);
-    __syncthreads(); // every wave's candidates are in LDS, the four list lengths are known
-    PROF_T(2);
-    uint32_t before = 0u, total = 0u, cls = 0u; // entries of the block's earlier tiles / of the whole block; its class A << 16 | class B tiles
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const uint32_t v = sNum[w];
-        if (w < wave) before += v;
-        total += v;
-        cls += tile_class_word(v);
-    }
-    if (threadIdx.x == 0) {
-        a.totals[b] = total;
-        if (a.classes) a.clsTotals[b] = cls;
-    }
     if (!active) return;
-    if (lane == 0) a.tileNum[bandTile] = num;
-    // the block's four lists back to back in its staging slot: k1_pack moves the slot as one contiguous run
-    emit_list(t, n, sIdx, sImp, lightView, a.staging + (size_t)b * SLOT + before);
+    const uint32_t n = count < CAND ? count : CAND;
+    const uint32_t num = n < KEEP ? n : KEEP;
+    if (lane == 0) publish_tile(a, tyLocal, bandTile, num);
+    PROF_T(2);
+    // the tile's list into the tile's own slot: k1_pack moves it to its canonical place, the shade can read it where it is
+    emit_list(t, n, sIdx, sImp, lightView, a.tileLists + (size_t)bandTile * KEEP);
     PROF_T(3);
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1d: canonical offsets (Appendix A step 6) and compaction.  Block p owns the staging slots (= k1_tile_cull blocks, = runs of
-// four tiles in tile-index order) [16 p, 16 p + 16).  Its base is the sum of the totals of all slots before them -- read and added
-// up by the block itself, 4 bytes per slot, from L2: no scan kernel, no look-back chain, no atomics (one atomic add per
-// k1_tile_cull block into per-pack-block sums was tried: +3 us on k1_tile_cull).  Then: one wave
-// turns the 64 tiles' list lengths into offsets (lightsGrid), and the 16 slots move to culledLights as contiguous runs.
+// K1d: canonical offsets (Appendix A step 6) and compaction.  Block p owns the tiles [64 p, 64 p + 64) of the band (tile-index order).  Its
+// base is the sum of the list lengths of all tiles before them: the totals of the tile rows in front of its first row (k1_tile_cull's
+// atomics) plus the lengths of that row's earlier tiles -- a few hundred words read and added up by the block itself: no scan kernel, no
+// look-back chain.  One wave turns the 64 lengths into offsets (lightsGrid); the 64 lists are gathered from their slots into LDS, back to back,
+// and leave for culledLights as one contiguous run.
 // ------------------------------------------------------------------------------------------------------------
 struct PackArgs {
-    const uint32_t* totals; const uint32_t* clsTotals; const uint32_t* tileNum; const uint32_t* staging;
-    SailorLightsGrid* grid; uint32_t* culled; uint32_t* tileOrder; uint32_t* dirFlag;
-    int Tx, groupsX, bandRows, cullBlocks, classes;
+    const uint32_t* rowTotals; const uint32_t* rowCls; const uint32_t* tileNum; const uint32_t* tileLists;
+    SailorLightsGrid* grid; uint32_t* culled; uint32_t* tileOrder;
+    int Tx, bandRows, bandTiles, classes;
     uint32_t capacity;
 };
 
-__device__ __forceinline__ uint32_t sum_u32_prefix(const uint32_t* __restrict__ v, const int count4)
-{
-    // sum of v[0 .. 4 count4): 16 bytes per load, four loads in flight per thread
-    const uint4* __restrict__ v4 = reinterpret_cast<const uint4*>(v);
-    uint32_t acc = 0u;
-    for (int i = threadIdx.x; i < count4; i += 1024) {
-        uint4 q[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) q[k] = i + 256 * k < count4 ? v4[i + 256 * k] : make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (int k = 0; k < 4; k++) acc += (q[k].x + q[k].y) + (q[k].z + q[k].w);
-    }
-    return acc;
-}
-
 __global__ __launch_bounds__(256) void k1_pack(const PackArgs a)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t sBuf[PACK_TILES * KEEP]; // 32 KB: the block's lists, back to back
     __shared__ uint32_t sPart[4], sPartC[4];
-    __shared__ uint32_t sLen[PACK_BLOCKS], sDst[PACK_BLOCKS];
+    __shared__ uint32_t sPre[PACK_TILES], sNum[PACK_TILES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int first = (int)blockIdx.x * PACK_BLOCKS;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *a.dirFlag = 0u; // (the next cull's k01_prepare sets it again if a light is directional)
+    const int t0 = (int)blockIdx.x * PACK_TILES;
     // this block's 64 tiles: requested now, used after the base is known
     uint32_t num = 0u;
-    int tile = -1, tx = 0, tyLocal = 0;
-    if (wave == 0) {
-        const int cb = first + (lane >> 2);
-        if (cb < a.cullBlocks) {
-            tyLocal = cb / a.groupsX;
-            tx = (cb - tyLocal * a.groupsX) * GROUP + (lane & 3);
-            if (tx < a.Tx) { tile = tyLocal * a.Tx + tx; num = a.tileNum[tile]; }
-        }
-    }
-    uint32_t own = 0u;
-    if (threadIdx.x < PACK_BLOCKS && first + (int)threadIdx.x < a.cullBlocks) own = a.totals[first + threadIdx.x];
-    // totals of every slot before this block's (`first` is a multiple of 16)
-    uint32_t acc = sum_u32_prefix(a.totals, first / 4), accC = a.classes ? sum_u32_prefix(a.clsTotals, first / 4) : 0u;
+    const int tile = t0 + lane;
+    const bool have = wave == 0 && tile < a.bandTiles;
+    if (have) num = a.tileNum[tile];
+    // entries (and class counts) of every tile before t0
+    const int row0 = t0 / a.Tx, rowTile0 = row0 * a.Tx;
+    uint32_t acc = 0u, accC = 0u;
+    for (int r = threadIdx.x; r < row0; r += 256) { acc += a.rowTotals[r]; if (a.classes) accC += a.rowCls[r]; }
+    for (int i = rowTile0 + (int)threadIdx.x; i < t0; i += 256) { const uint32_t v = a.tileNum[i]; acc += v; accC += tile_class_word(v); }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { acc += (uint32_t)__shfl_xor((int)acc, d, 64); accC += (uint32_t)__shfl_xor((int)accC, d, 64); }
     if (lane == 0) { sPart[wave] = acc; sPartC[wave] = accC; }
@@ -1125,15 +1176,6 @@ __global__ __launch_bounds__(256) void k1_pack(const PackArgs a)
     const uint32_t baseSum = (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]);
     const uint32_t baseCls = (sPartC[0] + sPartC[1]) + (sPartC[2] + sPartC[3]);
     if (wave == 0) {
-        // the 16 slots: length and destination (inclusive scan over lanes 0..15)
-        const uint32_t len = own;
-        uint32_t incl = len;
-#pragma unroll
-        for (int d = 1; d < PACK_BLOCKS; d <<= 1) {
-            const uint32_t u = (uint32_t)__shfl_up((int)incl, d);
-            if (lane >= d) incl += u;
-        }
-        if (lane < PACK_BLOCKS) { sLen[lane] = len; sDst[lane] = 1u + baseSum + incl - len; }
         // the 64 tiles: offset = 1 + entries of all earlier tiles
         uint32_t tincl = num;
 #pragma unroll
@@ -1141,13 +1183,16 @@ __global__ __launch_bounds__(256) void k1_pack(const PackArgs a)
             const uint32_t u = (uint32_t)__shfl_up((int)tincl, d);
             if (lane >= d) tincl += u;
         }
+        sPre[lane] = tincl - num;
+        sNum[lane] = num;
         const uint32_t offset = 1u + baseSum + tincl - num;
-        if (tile >= 0) {
+        if (have) {
             // A list that does not fit the caller's buffer is cut, and the grid says so: the shade never reads past `capacity`.
             const uint32_t fit = offset >= a.capacity ? 0u : min(num, a.capacity - offset);
             a.grid[tile].offset = offset;
             a.grid[tile].num = fit;
         }
+        const bool last = t0 + PACK_TILES >= a.bandTiles;
         if (a.classes) {
             // the shading hint: class A tiles from the front of the array, class B tiles from its back, both in tile order
             const uint32_t mine = tile_class_word(num);
@@ -1159,40 +1204,49 @@ __global__ __launch_bounds__(256) void k1_pack(const PackArgs a)
             }
             const uint32_t cb = baseCls + c - mine; // class counts of all earlier tiles
             const uint32_t aBefore = cb >> 16, bBefore = cb & 0xFFFFu;
-            const uint32_t T = (uint32_t)(a.bandRows * a.Tx);
-            if (tile >= 0 && num >= CLASS_B) a.tileOrder[num >= CLASS_A ? aBefore : T - 1u - bBefore] = (uint32_t)tx | ((uint32_t)tyLocal << 16);
-            if (first + PACK_BLOCKS >= a.cullBlocks && lane == 63) { // the last block: the two counts
+            const uint32_t T = (uint32_t)a.bandTiles;
+            if (have && num >= CLASS_B) {
+                const int tyLocal = tile / a.Tx, tx = tile - tyLocal * a.Tx;
+                a.tileOrder[num >= CLASS_A ? aBefore : T - 1u - bBefore] = (uint32_t)tx | ((uint32_t)tyLocal << 16);
+            }
+            if (last && lane == 63) { // the last block: the two counts
                 const uint32_t all = cb + mine;
                 a.tileOrder[T] = all >> 16;
                 a.tileOrder[T + 1u] = all & 0xFFFFu;
             }
         }
-        if (first + PACK_BLOCKS >= a.cullBlocks && lane == 63) { // Appendix A step 6: indices[0] = sum of num
+        if (last && lane == 63) { // Appendix A step 6: indices[0] = sum of num
             const uint32_t tot = baseSum + tincl;
             a.culled[0] = a.capacity ? min(tot, a.capacity - 1u) : 0u;
         }
     }
     __syncthreads();
-    // all loads first (two per slot and thread: a slot holds <= 512 entries), then the stores: one round trip for the block's 32 KB
-    uint32_t v[PACK_BLOCKS][2];
+    // Gather: four threads per tile, 32 entries (eight 16-byte loads, all in flight) each, into the tile's place in the block's run.  (Reading a
+    // whole uint4 whose first entry is inside the list stays inside the tile's 128-entry slot; what lies behind the list is never stored.)
+    {
+        const int j = threadIdx.x >> 2, q = threadIdx.x & 3;
+        const uint32_t n = sNum[j], pre = sPre[j];
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(a.tileLists + (size_t)(t0 + j) * KEEP) + q * 8;
+        uint4 v[8];
 #pragma unroll
-    for (int j = 0; j < PACK_BLOCKS; j++) {
-        const uint32_t len = sLen[j];
-        const uint32_t* __restrict__ src = a.staging + (size_t)(first + j) * SLOT;
+        for (int k = 0; k < 8; k++) if ((uint32_t)(32 * q + 4 * k) < n) v[k] = src[k];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t e = threadIdx.x + 256u * h;
-            v[j][h] = e < len ? src[e] : 0u;
+        for (int k = 0; k < 8; k++) {
+            const uint32_t i = (uint32_t)(32 * q + 4 * k);
+            if (i < n) {
+                uint32_t* d = sBuf + pre + i;
+                d[0] = v[k].x;
+                if (i + 1u < n) d[1] = v[k].y;
+                if (i + 2u < n) d[2] = v[k].z;
+                if (i + 3u < n) d[3] = v[k].w;
+            }
         }
     }
-#pragma unroll
-    for (int j = 0; j < PACK_BLOCKS; j++) {
-        const uint32_t len = sLen[j], dst = sDst[j];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t e = threadIdx.x + 256u * h;
-            if (e < len && dst + e < a.capacity) a.culled[dst + e] = v[j][h];
-        }
+    __syncthreads();
+    const uint32_t total = sPre[PACK_TILES - 1] + sNum[PACK_TILES - 1];
+    for (uint32_t i = threadIdx.x; i < total; i += 256u) {
+        const uint32_t d = 1u + baseSum + i;
+        if (d < a.capacity) a.culled[d] = sBuf[i];
     }
 }
 
@@ -1219,6 +1273,21 @@ static bool band_valid(int W, int H, const SailorBand* b)
 
 // the tile-order hint is produced for split frames whose class counts fit 16 bits each
 static bool layout_has_hint(const CullLayout& L) { return L.bandRows < L.Ty && L.bandTiles > 0 && L.bandTiles <= CLS_MAX_TILES; }
+
+static int launch_pack(SailorHipContext* ctx, const CullLayout& L, char* ws, SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity)
+{
+    PackArgs ka;
+    ka.rowTotals = (const uint32_t*)(ws + L.offRowTotals); ka.rowCls = (const uint32_t*)(ws + L.offRowCls);
+    ka.tileNum = (const uint32_t*)(ws + L.offTileNum); ka.tileLists = (const uint32_t*)(ws + L.offTileLists);
+    ka.grid = dLightsGrid; ka.culled = dCulledLights; ka.tileOrder = (uint32_t*)(ws + L.offTileOrder);
+    ka.Tx = L.Tx; ka.bandRows = L.bandRows; ka.bandTiles = L.bandTiles;
+    // The hint pays for itself on split frames (a band's shade launch is bounded by its longest tile); on the whole frame it measured nothing.
+    ka.classes = layout_has_hint(L) ? 1 : 0;
+    ka.capacity = (uint32_t)(culledCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : culledCapacity);
+    sailor_launch(ctx, k1_pack, dim3(L.packBlocks), dim3(256), ka);
+    SAILOR_CHECK_LAUNCH(ctx, "k1_pack");
+    return SAILOR_HIP_OK;
+}
 
 extern "C" {
 
@@ -1319,49 +1388,74 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     pa.planeMargin = 1e-3f;
     pa.dirFlag = (uint32_t*)(ws + L.offDirFlag);
     pa.heavy = (uint32_t*)(ws + L.offHeavy);
-    hipLaunchKernelGGL(k01_prepare, dim3(pa.lightRoleBlocks + pa.frustumBlocks + pa.setupBlocks), dim3(256), 0, s, pa);
+    pa.rowTotals = (uint32_t*)(ws + L.offRowTotals); pa.rowCls = (uint32_t*)(ws + L.offRowCls);
+    sailor_launch(ctx, k01_prepare, dim3(pa.lightRoleBlocks + pa.frustumBlocks + pa.setupBlocks), dim3(256), pa);
     SAILOR_CHECK_LAUNCH(ctx, "k01_prepare");
 
     CullArgs ca;
     ca.lightView = pa.lightView; ca.lightType = pa.lightType; ca.tileInfo = pa.tileInfo; ca.masks = pa.masks;
     ca.groupCount = (const uint32_t*)(ws + L.offGroupCount); ca.groupList = (const uint32_t*)(ws + L.offGroupList);
-    ca.totals = (uint32_t*)(ws + L.offTotals); ca.clsTotals = (uint32_t*)(ws + L.offClsTotals); ca.tileNum = (uint32_t*)(ws + L.offTileNum); ca.staging = (uint32_t*)(ws + L.offStaging);
+    ca.rowTotals = pa.rowTotals; ca.rowCls = pa.rowCls; ca.tileNum = (uint32_t*)(ws + L.offTileNum); ca.tileLists = (uint32_t*)(ws + L.offTileLists);
+    ca.dirFlag = pa.dirFlag;
     ca.N = N; ca.words = L.words; ca.Tx = L.Tx; ca.groupsX = L.groupsX; ca.bandRows = L.bandRows;
-    // The hint pays for itself on split frames (a band's shade launch is bounded by its longest tile); on the whole frame it measured nothing.
-    ca.classes = layout_has_hint(L) ? 1 : 0;
+    ca.classes = layout_has_hint(L) ? 1 : 0; // (the tile-order hint: see launch_pack)
     ca.heavy = (const uint32_t*)(ws + L.offHeavy); ca.headRows = 0;
     if (brute) {
-        hipLaunchKernelGGL(k1_tile_cull<true>, dim3(L.groupsX, L.bandRows), dim3(256), 0, s, ca);
+        sailor_launch(ctx, k1_tile_cull<true>, dim3(L.groupsX, L.bandRows), dim3(256), ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull<brute>");
     } else {
         if (L.words >= 4096 && (L.words & 1) == 0)
         {
             const dim3 wideGrid((unsigned)(((L.groupsX + 3) / 4) * L.groupsY));
             if (L.words % (128 * GLW_ROWS) == 0)
-                hipLaunchKernelGGL(k1_group_lists_wide<true>, wideGrid, dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
+                sailor_launch(ctx, k1_group_lists_wide<true>, wideGrid, dim3(256), pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
                                    (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag));
             else
-                hipLaunchKernelGGL(k1_group_lists_wide<false>, wideGrid, dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
+                sailor_launch(ctx, k1_group_lists_wide<false>, wideGrid, dim3(256), pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
                                    (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag));
         }
         else {
-            hipLaunchKernelGGL(k1_group_lists, dim3(L.groupsX, L.groupsY), dim3(256), 0, s, pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
+            sailor_launch(ctx, k1_group_lists, dim3(L.groupsX, L.groupsY), dim3(256), pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
                                (uint32_t*)(ws + L.offGroupList), (uint32_t*)(ws + L.offHeavy));
-#ifndef CULL_NO_HEAD_ROWS
-            ca.headRows = (4 * HEAVY_MAX + L.groupsX - 1) / L.groupsX; // grid rows for the listed clusters' row blocks, in front of the tile rows
-#endif
+            ca.headRows = (16 * HEAVY_MAX + L.groupsX - 1) / L.groupsX; // grid rows for the listed clusters' tiles (a block each), in front of the tile rows
         }
         SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
-        hipLaunchKernelGGL(k1_tile_cull<false>, dim3(L.groupsX, ca.headRows + L.bandRows), dim3(256), 0, s, ca);
+        sailor_launch(ctx, k1_tile_cull<false>, dim3(L.groupsX, ca.headRows + L.bandRows), dim3(256), ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
     }
-    PackArgs ka;
-    ka.totals = ca.totals; ka.clsTotals = ca.clsTotals; ka.tileNum = ca.tileNum; ka.staging = ca.staging;
-    ka.grid = dLightsGrid; ka.culled = dCulledLights; ka.tileOrder = (uint32_t*)(ws + L.offTileOrder); ka.dirFlag = (uint32_t*)(ws + L.offDirFlag);
-    ka.Tx = L.Tx; ka.groupsX = L.groupsX; ka.bandRows = L.bandRows; ka.cullBlocks = L.cullBlocks; ka.classes = ca.classes;
-    ka.capacity = (uint32_t)(culledCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : culledCapacity);
-    hipLaunchKernelGGL(k1_pack, dim3(L.packBlocks), dim3(256), 0, s, ka);
-    SAILOR_CHECK_LAUNCH(ctx, "k1_pack");
+    if (flags & SAILOR_CULL_DEFER_PACK) return SAILOR_HIP_OK; // the caller records sailor_hip_light_cull_pack where it wants it (another stream, beside the shade)
+    return launch_pack(ctx, L, ws, dLightsGrid, dCulledLights, culledCapacity);
+}
+
+int sailor_hip_light_cull_pack(SailorHipContext* ctx, int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band, const void* dWorkspace,
+                               SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity)
+{
+    if (!ctx || !dWorkspace || !dLightsGrid || !dCulledLights || width <= 0 || height <= 0 || lightsCapacity < 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SailorBand whole;
+    if (!band) { sailor_hip_band_whole_frame(width, height, &whole); band = &whole; }
+    if (!band_valid(width, height, band)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    // (everything the pack reads lies in the part of the workspace whose layout depends on the geometry alone)
+    const CullLayout L = make_layout(width, height, lightsCapacity, *band);
+    if (culledCapacity < 1 || culledCapacity < (size_t)L.bandTiles * KEEP) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (((uintptr_t)dWorkspace & 255) != 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (L.bandTiles == 0) {
+        SAILOR_TRY_HIP(ctx, hipMemsetAsync(dCulledLights, 0, 4, ctx->stream));
+        return SAILOR_HIP_OK;
+    }
+    return launch_pack(ctx, L, (char*)dWorkspace, dLightsGrid, dCulledLights, culledCapacity);
+}
+
+int sailor_hip_light_cull_tile_lists(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band, const void* dWorkspace,
+                                     const uint32_t** outTileNum, const uint32_t** outTileLists)
+{
+    if (!dWorkspace || width <= 0 || height <= 0 || lightsCapacity < 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SailorBand whole;
+    if (!band) { sailor_hip_band_whole_frame(width, height, &whole); band = &whole; }
+    if (!band_valid(width, height, band)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const CullLayout L = make_layout(width, height, lightsCapacity, *band);
+    if (outTileNum) *outTileNum = (const uint32_t*)((const char*)dWorkspace + L.offTileNum);
+    if (outTileLists) *outTileLists = (const uint32_t*)((const char*)dWorkspace + L.offTileLists);
     return SAILOR_HIP_OK;
 }
 

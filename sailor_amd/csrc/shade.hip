@@ -142,8 +142,8 @@ extern "C" int sailor_hip_prepare_lights(SailorHipContext* ctx, const SailorLigh
     if (count == 0) return SAILOR_HIP_OK;
     SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
     char* base = (char*)dPrepared;
-    hipLaunchKernelGGL(k_prepare_lights, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, dLights, firstLight, count,
-                       (float4*)(base + L.offPosRadius), (uint32_t*)(base + L.offType), (float4*)(base + L.offStaged));
+    sailor_launch(ctx, k_prepare_lights, dim3((unsigned)((count + 255) / 256)), dim3(256), dLights, firstLight, count,
+                  (float4*)(base + L.offPosRadius), (uint32_t*)(base + L.offType), (float4*)(base + L.offStaged));
     SAILOR_CHECK_LAUNCH(ctx, "k_prepare_lights");
     return SAILOR_HIP_OK;
 }
@@ -252,13 +252,14 @@ extern "C" int sailor_hip_compute_brdf_lut(SailorHipContext* ctx, float* dLut, i
     return SAILOR_HIP_OK;
 }
 
-extern "C" int sailor_hip_shade_prepared(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
-                                         const SailorLightShaderData* dLights, int32_t lightsNum,
-                                         const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
-                                         const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance, const SailorBand* band, const uint32_t* dTileOrder,
-                                         const void* dPreparedLights, int32_t preparedCapacity)
+// dTileNum == null: (dLightsGrid, dCulledLights) in the reference's layout; else dCulledLights = the cull's per-tile slots and dLightsGrid is not read
+static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
+                      const SailorLightShaderData* dLights, int32_t lightsNum,
+                      const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights, const uint32_t* dTileNum,
+                      const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance, const SailorBand* band, const uint32_t* dTileOrder,
+                      const void* dPreparedLights, int32_t preparedCapacity)
 {
-    if (!ctx || !frame || !dSurface || !dLightsGrid || !dCulledLights || !dRadiance) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx || !frame || !dSurface || (!dLightsGrid && !dTileNum) || !dCulledLights || !dRadiance) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (lightsNum < 0 || (lightsNum > 0 && !dLights && !dPreparedLights)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (dPreparedLights && (preparedCapacity < lightsNum || ((uintptr_t)dPreparedLights & 15))) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     const int W = frame->viewportSize[0], H = frame->viewportSize[1];
@@ -283,6 +284,7 @@ extern "C" int sailor_hip_shade_prepared(SailorHipContext* ctx, const SailorUboF
     A.fbRows = band->fbRowCount;
     A.lightsNum = lightsNum;
     A.order = dTileOrder;
+    A.tileNum = dTileNum;
     const int bandTiles = (band->tileRowEnd - band->tileRowBegin) * A.Tx;
     if (bandTiles == 0) return SAILOR_HIP_OK;
 
@@ -318,19 +320,40 @@ extern "C" int sailor_hip_shade_prepared(SailorHipContext* ctx, const SailorUboF
     // with prepared lights the kernels' `lights` argument is the staged array (LREC float4 per light)
     const SailorLightShaderData* L = dLights;
     if (dPreparedLights) L = reinterpret_cast<const SailorLightShaderData*>((const char*)dPreparedLights + prepared_layout(preparedCapacity).offStaged);
-#define LAUNCH_SHADE(K) do { if (dPreparedLights) hipLaunchKernelGGL(K##_p, grid, dim3(256), 0, ctx->stream, A, C, I, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd); \
-                             else hipLaunchKernelGGL(K, grid, dim3(256), 0, ctx->stream, A, C, I, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd); } while (0)
+#define LAUNCH_SHADE(K) do { if (dPreparedLights) sailor_launch(ctx, K##_p, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd); \
+                             else sailor_launch(ctx, K, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd); } while (0)
     if (hasCsm && ibl) LAUNCH_SHADE(k2_shade_csm_ibl);
     else if (hasCsm) LAUNCH_SHADE(k2_shade_csm);
     else if (ibl) LAUNCH_SHADE(k2_shade_ibl);
     else if (dTileOrder && band->tileRowEnd - band->tileRowBegin < Ty) { // a band of a split frame: long tiles are split across four blocks
         const dim3 bgrid((unsigned)SPLIT_BLOCKS + (unsigned)bandTiles);
-        if (dPreparedLights) hipLaunchKernelGGL(k2_shade_band_p, bgrid, dim3(256), 0, ctx->stream, A, C, bandTiles, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd);
-        else hipLaunchKernelGGL(k2_shade_band, bgrid, dim3(256), 0, ctx->stream, A, C, bandTiles, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd);
+        if (dPreparedLights) sailor_launch(ctx, k2_shade_band_p, bgrid, dim3(256), A, C, bandTiles, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd);
+        else sailor_launch(ctx, k2_shade_band, bgrid, dim3(256), A, C, bandTiles, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd);
     } else LAUNCH_SHADE(k2_shade);
 #undef LAUNCH_SHADE
     SAILOR_CHECK_LAUNCH(ctx, "k2_shade");
     return SAILOR_HIP_OK;
+}
+
+extern "C" int sailor_hip_shade_prepared(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
+                                         const SailorLightShaderData* dLights, int32_t lightsNum,
+                                         const SailorLightsGrid* dLightsGrid, const uint32_t* dCulledLights,
+                                         const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance, const SailorBand* band, const uint32_t* dTileOrder,
+                                         const void* dPreparedLights, int32_t preparedCapacity)
+{
+    if (!dLightsGrid) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    return shade_impl(ctx, frame, dSurface, surfacePlaneStride, dLights, lightsNum, dLightsGrid, dCulledLights, nullptr, csm, ibl, dRadiance, band, dTileOrder, dPreparedLights,
+                      preparedCapacity);
+}
+
+extern "C" int sailor_hip_shade_tile_lists(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,
+                                           const SailorLightShaderData* dLights, int32_t lightsNum, const uint32_t* dTileNum, const uint32_t* dTileLists,
+                                           const SailorCsmDesc* csm, const SailorIblDesc* ibl, float* dRadiance, const SailorBand* band, const uint32_t* dTileOrder,
+                                           const void* dPreparedLights, int32_t preparedCapacity)
+{
+    if (!dTileNum || !dTileLists) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    return shade_impl(ctx, frame, dSurface, surfacePlaneStride, dLights, lightsNum, nullptr, dTileLists, dTileNum, csm, ibl, dRadiance, band, dTileOrder, dPreparedLights,
+                      preparedCapacity);
 }
 
 extern "C" int sailor_hip_shade_ex(SailorHipContext* ctx, const SailorUboFrameData* frame, const float* dSurface, size_t surfacePlaneStride,

@@ -35,6 +35,9 @@ struct ShadeArgs {
     int bandTileRows; // band.tileRowEnd - band.tileRowBegin
     int lightsNum;
     const uint32_t* order; // sailor_hip_light_cull_tile_order or null
+    const uint32_t* tileNum; // null: `grid` / `culled` are the reference's lightsGrid / culledLights.  Else the cull's own per-tile form
+                             // (sailor_hip_light_cull_tile_lists): the list of band tile t is culled[128 t ..], its length tileNum[t] -- same
+                             // entries in the same order, available as soon as k1_tile_cull has run (k1_pack is then off the frame's critical path)
 };
 
 // ---- K3: canonical-order helpers (must match oracle/sailor_oracle.c bit for bit) -----------------------------
@@ -559,7 +562,9 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     // (a scalar load) and the surface loads go out together; the list indices follow as soon as the grid entry is there; the per-pixel
     // invariants -- which wait for the surface only -- are computed while the light records are in flight; and the workgroup barrier that
     // publishes the staged records waits for LDS only, not for outstanding global loads.
-    const SailorLightsGrid g = grid[bandTile]; // Standard.shader:422-423
+    SailorLightsGrid g; // Standard.shader:422-423
+    if (A.tileNum) { g.offset = (uint32_t)bandTile * (uint32_t)KEEP; g.num = A.tileNum[bandTile]; } // (kernel-argument-uniform: a scalar branch)
+    else g = grid[bandTile];
     // unconditional surface loads (lanes outside the frame read pixel 0 of the band and are masked out of every ballot and of the store)
     // (streamed once: non-temporal, so that what every tile reads again -- lists, light records, the next frame's depth and masks -- keeps its
     // place in L2)

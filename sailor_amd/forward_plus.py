@@ -42,6 +42,15 @@ class HipContext:
     def synchronize(self):
         _lib.check(self._lib.sailor_hip_context_synchronize(self.handle), "synchronize", self.handle)
 
+    def time_launches(self, first_slot: int, count: int):
+        """the next `count` kernel launches through this context carry event pairs on their dispatch packets (sailor_hip_context_time_launches)"""
+        _lib.check(self._lib.sailor_hip_context_time_launches(self.handle, first_slot, count), "sailor_hip_context_time_launches", self.handle)
+
+    def timed_launch_ms(self, slot: int) -> float:
+        ms = C.c_float()
+        _lib.check(self._lib.sailor_hip_context_timed_launch_ms(self.handle, slot, C.byref(ms)), "sailor_hip_context_timed_launch_ms", self.handle)
+        return float(ms.value)
+
     def close(self):
         if getattr(self, "handle", None):
             self._lib.sailor_hip_context_destroy(self.handle)
@@ -120,17 +129,26 @@ class ForwardPlus:
         self.tile_order = lib.sailor_hip_light_cull_tile_order(width, height, max_lights, C.byref(self.band), _ptr(self.workspace))
         self.use_tile_order = os.environ.get("SAILOR_NO_TILE_ORDER") is None
         self._culled_once = False
+        # the cull's own per-tile form of the lists (tileNum[t] entries at tileLists[128 t ..]): what the shade reads by default -- the canonical
+        # grid / culledLights are then only needed by other consumers, and k1_pack can run beside the shade (cull(..., defer_pack=True) + pack())
+        a, b = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.sailor_hip_light_cull_tile_lists(width, height, max_lights, C.byref(self.band), _ptr(self.workspace), C.byref(a), C.byref(b)),
+                   "sailor_hip_light_cull_tile_lists")
+        self.tile_num, self.tile_lists = a.value, b.value
+        self.shade_from_tile_lists = os.environ.get("SAILOR_SHADE_CANONICAL_LISTS") is None
 
     # -- K0 + K1 --------------------------------------------------------------------------------------------------
     def cull(self, frame: UboFrameData, lights: torch.Tensor, lights_num: int, depth: torch.Tensor, flags: int = _lib.CULL_DEFAULT,
-             ctx: "HipContext | None" = None, prepared: "PreparedLights | None" = None):
+             ctx: "HipContext | None" = None, prepared: "PreparedLights | None" = None, defer_pack: bool = False):
         """lights: uint8/any tensor holding lights_num 112-byte records; depth: float32 [band rows, W].
         ctx: record on another context's stream (frames in flight: next frame's cull beside this frame's shade).
         prepared: the lights' prepared views (the kernel then streams 20 bytes per light instead of the 112-byte records)."""
         assert depth.dtype == torch.float32 and depth.is_contiguous() and depth.shape == (self.band.fbRowCount, self.W), depth.shape
         assert lights_num <= self.max_lights
         prepared = prepared if prepared is not None else self.prepared
-        flags |= _ENV_CULL_FLAGS   # (diagnostics: SAILOR_CULL_FLAGS=8 times the split-lists shape against the default on the same box)
+        flags |= _ENV_CULL_FLAGS   # (diagnostics)
+        if defer_pack:             # the canonical buffers are written by pack(), wherever the caller records it
+            flags |= _lib.CULL_DEFER_PACK
         pc = host.push_constants(frame, self.W, self.H, lights_num)
         ctx = ctx or self.ctx
         lib = ctx._lib
@@ -147,6 +165,12 @@ class ForwardPlus:
         self._culled_once = True
         return self.grid, self.culled
 
+    def pack(self, ctx: "HipContext | None" = None):
+        """the second half of a cull(..., defer_pack=True): lightsGrid / culledLights from the per-tile lists, on ctx's stream (default: the cull's)"""
+        ctx = ctx or self.ctx
+        _lib.check(ctx._lib.sailor_hip_light_cull_pack(ctx.handle, self.W, self.H, self.max_lights, C.byref(self.band), _ptr(self.workspace), _ptr(self.grid),
+                                                       _ptr(self.culled), self.culled.numel()), "sailor_hip_light_cull_pack", ctx.handle)
+
     # -- K2 + K3 --------------------------------------------------------------------------------------------------
     def shade(self, frame: UboFrameData, surface: torch.Tensor, lights: torch.Tensor, lights_num: int, csm: CsmDesc | None = None,
               out: torch.Tensor | None = None, ibl: "_lib.IblDesc | None" = None, prepared: "PreparedLights | None" = None) -> torch.Tensor:
@@ -161,6 +185,16 @@ class ForwardPlus:
         lib = self.ctx._lib
         prepared = prepared if prepared is not None else self.prepared
         order = self.tile_order if (self.use_tile_order and self._culled_once) else None  # only lists made by THIS object's cull have an order
+        if self.shade_from_tile_lists and self._culled_once:
+            # the lists where the cull left them (the same entries in the same order as grid / culledLights: the same radiance bit for bit)
+            if prepared is not None:
+                assert lights_num <= prepared.capacity
+            _lib.check(lib.sailor_hip_shade_tile_lists(self.ctx.handle, C.byref(frame), _ptr(surface), rows * self.W, _ptr(lights), lights_num, self.tile_num,
+                                                       self.tile_lists, C.byref(csm) if csm is not None else None, C.byref(ibl) if ibl is not None else None,
+                                                       _ptr(out), C.byref(self.band), order, _ptr(prepared.buffer) if prepared is not None else None,
+                                                       prepared.capacity if prepared is not None else 0),
+                       "sailor_hip_shade_tile_lists", self.ctx.handle)
+            return out
         if prepared is not None:
             assert lights_num <= prepared.capacity
             _lib.check(lib.sailor_hip_shade_prepared(self.ctx.handle, C.byref(frame), _ptr(surface), rows * self.W, _ptr(lights), lights_num, _ptr(self.grid),

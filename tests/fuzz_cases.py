@@ -93,11 +93,11 @@ def k1k2_case(ctx, rng, c, run=True, verbose=False):
                 print(f"flags {flags} band {None if b is None else (bb.tileRowBegin, bb.tileRowEnd)}: worst rel {full_err.max():.3e} at pixel ({x},{y + rows.start}) ch {ch}: got {got[y, x]} ref {ref[y, x]}")
                 print("  surface", surface[:, y + rows.start, x].tolist(), "list", li.tolist())
                 print("  types", lights["type"][li].tolist(), "radius", lights["bounds"][li, 0].tolist(), "pos", lights["worldPosition"][li].tolist(), "intensity", lights["intensity"][li].tolist())
-            # split tiles of a band differ from the one-block form by the order of four partial sums: twice the tolerance there
-            assert (err <= tol * (2.0 if b is not None else 1.0)).all(), (what, flags, "radiance", float((err / (tol + 1e-300)).max()))
+            # (a band's split tiles add four partial sums in a fixed order: the same 1e-4 against the oracle as everything else -- VERDICT r03 item 3)
+            assert (err <= tol).all(), (what, flags, "radiance", float((err / (tol + 1e-300)).max()))
             m = np.abs(ref[fin]) > 0
             if m.any():
-                worst = max(worst, float((err[m] / np.abs(ref[fin][m])).max()) / (2.0 if b is not None else 1.0))
+                worst = max(worst, float((err[m] / np.abs(ref[fin][m])).max()))
     return worst
 
 

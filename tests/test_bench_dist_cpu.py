@@ -60,6 +60,12 @@ class _Context:
     def synchronize(self):
         pass
 
+    def time_launches(self, first_slot, count):
+        pass
+
+    def timed_launch_ms(self, slot):
+        return 0.01
+
 
 class _Prepared:
     def __init__(self, n):
@@ -89,7 +95,11 @@ class _ForwardPlus:
         full[b.fbRowBegin:b.fbRowBegin + b.fbRowCount] = rows
         return full
 
-    def cull(self, frame, lights, lights_num, depth, flags=0, ctx=None, prepared=None):
+    def pack(self, ctx=None):
+        assert self.deferred, "a pack follows a cull recorded with defer_pack"
+
+    def cull(self, frame, lights, lights_num, depth, flags=0, ctx=None, prepared=None, defer_pack=False):
+        self.deferred = defer_pack
         from oracle import oracle
         assert tuple(depth.shape) == (self.band.fbRowCount, self.W)
         g, idx, _ = oracle.light_cull(frame, self.W, self.H, lights[:lights_num], self._full(depth.numpy()), tile_rows=(self.band.tileRowBegin, self.band.tileRowEnd))

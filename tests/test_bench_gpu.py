@@ -80,8 +80,8 @@ def test_step_counts_the_list_sets_divide_run_one_pipeline_graph(sets, steps):
     assert d["step_ms"]["p10"] <= d["step_ms"]["median"] <= d["step_ms"]["p90"]
 
 
-@pytest.mark.parametrize("sets", [2, 3])
-def test_the_frame_pipeline_graph_leaves_the_frames_results(sets):
+@pytest.mark.parametrize("sets, deferred", [(2, False), (3, False), (3, True), (2, True)])
+def test_the_frame_pipeline_graph_leaves_the_frames_results(sets, deferred):
     """The pipeline graph orders two streams by the frames' own dependencies only (shade(k) after cull(k), cull(k + 1) after the shade that last
     read its list set).  Run it with DIFFERENT light sets in the list sets -- a missing dependency would shade a frame from the other frame's lists -- and compare what
     every set holds afterwards with plain stream-ordered launches."""
@@ -116,9 +116,15 @@ def test_the_frame_pipeline_graph_leaves_the_frames_results(sets):
             outs[p].zero_()
         assert all(not np.array_equal(ref[0][1], ref[p][1]) for p in range(1, sets))
         torch.cuda.synchronize()
+        side3 = torch.cuda.Stream(device=dev)
+        ctx3 = HipContext(dev, stream=side3)
+        for p in range(sets):   # (a missing pack, or one that ran before its cull, would leave these)
+            fps[p].grid.fill_(-3); fps[p].culled.fill_(-3)
+        # deferred: the culls stop after the per-tile lists (which the shades read) and k1_pack runs on a third stream behind each cull
         graph = bench.capture_frame_pipeline(side, side2, 6,
                                              [lambda p=p: fps[p].shade(cam.frame, d_surface, d_l[p], N, None, out=outs[p]) for p in range(sets)],
-                                             [lambda p=p: fps[p].cull(cam.frame, d_l[p], N, d_depth, ctx=ctx2) for p in range(sets)])
+                                             [lambda p=p: fps[p].cull(cam.frame, d_l[p], N, d_depth, ctx=ctx2, defer_pack=deferred) for p in range(sets)],
+                                             None, [lambda p=p: fps[p].pack(ctx3) for p in range(sets)] if deferred else None, side3)
         fps[0].cull(cam.frame, d_l[0], N, d_depth)   # the prologue: frame 0's lists
         torch.cuda.synchronize()
         for _ in range(3):

@@ -260,3 +260,87 @@ def test_large_light_set_with_directional_lights_on_a_small_frame(ctx):
         fp.cull(cam.frame, upload_lights(ls, ctx.device), N, d)
         assert_lists_equal(fp.lists_to_host(), refs[name][0], refs[name][1])
     assert refs["directional"][0][:, 1].min() >= 3 and refs["none"][0][:, 1].mean() > 4
+
+
+def _cluster_frame():
+    """a small frame with light clusters: groups of more than 512 candidates (their tiles take k1_tile_cull's block-per-tile path) and tiles whose
+    196 -> 128 selection runs"""
+    f = synth.make_frame("tiny", with_surface=False, width=320, height=208,
+                         lights=synth.LightSetConfig(count=6000, spot_fraction=0.3, radius_scale=4.0, cluster_lights=2400, cluster_count=2, cluster_spread=1.5,
+                                                     cluster_radius=(0.5, 1.2)))
+    return f
+
+
+@pytest.mark.parametrize("band_of", [None, (1, 2)])
+def test_cluster_tiles_take_a_block_each_and_give_the_same_lists(ctx, band_of):
+    """Round 4: the tiles of a light cluster (a 4x4-tile group with more than 512 candidates) are culled by a whole block each -- four waves share the
+    candidates and the selection's rank.  Same candidate order, same impacts, same rank rule: the lists are the brute-force walk's and the oracle's."""
+    f = _cluster_frame()
+    W, H = f.cam.width, f.cam.height
+    band = None if band_of is None else host.band_for_rank(W, H, *band_of)
+    fp = ForwardPlus(ctx, W, H, len(f.lights), band=band)
+    b = fp.band
+    d = torch.from_numpy(np.ascontiguousarray(f.depth[b.fbRowBegin:b.fbRowBegin + b.fbRowCount])).to(ctx.device)
+    l = upload_lights(f.lights, ctx.device)
+    fp.cull(f.cam.frame, l, len(f.lights), d)
+    diag = fp.cull_diagnostics(len(f.lights))
+    assert diag["group_list_max"] > 512, "the frame has listed light clusters"
+    got = fp.lists_to_host()
+    ref_g, ref_i, cnt = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(b.tileRowBegin, b.tileRowEnd), want_counts=True)
+    assert (cnt > oracle.CAND).any() and (ref_g[:, 1] == 128).sum() > 8, "selections ran"
+    assert_lists_equal(got, ref_g, ref_i)
+    fp.cull(f.cam.frame, l, len(f.lights), d, _lib.CULL_BRUTE_FORCE)
+    assert_lists_equal(fp.lists_to_host(), ref_g, ref_i)
+
+
+def test_per_tile_lists_and_the_deferred_pack(ctx):
+    """sailor_hip_light_cull_tile_lists / SAILOR_CULL_DEFER_PACK / sailor_hip_light_cull_pack: after a deferred cull the canonical buffers are untouched
+    and every tile's list sits in its own 128-entry slot of the workspace, the same entries in the same order; the pack -- recorded on ANOTHER stream,
+    as the frame pipeline does -- then writes lightsGrid / culledLights bit for bit what the undeferred call writes (the oracle's)."""
+    from sailor_amd.forward_plus import HipContext
+    f = _cluster_frame()
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    ref_g, ref_i, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth)
+    fp = ForwardPlus(ctx, W, H, N)
+    d = torch.from_numpy(f.depth).to(ctx.device)
+    l = upload_lights(f.lights, ctx.device)
+    fp.grid.fill_(-7); fp.culled.fill_(-7)
+    fp.cull(f.cam.frame, l, N, d, defer_pack=True)
+    ctx.synchronize()
+    assert (fp.grid == -7).all() and (fp.culled == -7).all(), "a deferred cull does not write the canonical buffers"
+    base = fp.workspace.data_ptr()
+    T = fp.band_tiles
+    num = fp.workspace[fp.tile_num - base: fp.tile_num - base + 4 * T].view(torch.int32).cpu().numpy().view(np.uint32)
+    lists = fp.workspace[fp.tile_lists - base: fp.tile_lists - base + 4 * 128 * T].view(torch.int32).cpu().numpy().view(np.uint32).reshape(T, 128)
+    np.testing.assert_array_equal(num, ref_g[:, 1])
+    for t in np.random.default_rng(3).choice(T, 64, replace=False).tolist() + [int(np.argmax(num))]:
+        np.testing.assert_array_equal(lists[t, : num[t]], ref_i[ref_g[t, 0]: ref_g[t, 0] + num[t]])
+    side = torch.cuda.Stream(device=ctx.device)
+    side.wait_stream(torch.cuda.current_stream())
+    ctx2 = HipContext(ctx.device, stream=side)
+    fp.pack(ctx2)
+    ctx2.synchronize()
+    assert_lists_equal(fp.lists_to_host(), ref_g, ref_i)
+
+
+def test_dispatch_packet_timing_of_the_cull_chain(ctx):
+    """sailor_hip_context_time_launches: the four kernels of one cull each carry an event pair on their own dispatch packet; the durations are those
+    of the kernels (positive, and together no longer than the call as seen by events around it), and an unarmed call is launched the ordinary way."""
+    f = synth.make_frame("C2", with_surface=False)
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    fp = ForwardPlus(ctx, W, H, N)
+    d = torch.from_numpy(f.depth).to(ctx.device)
+    l = upload_lights(f.lights, ctx.device)
+    fp.cull(f.cam.frame, l, N, d)
+    ref = fp.lists_to_host()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ctx.time_launches(0, 4)
+    a.record(); fp.cull(f.cam.frame, l, N, d); b.record()
+    ctx.synchronize()
+    ms = [ctx.timed_launch_ms(i) for i in range(4)]
+    assert all(0.0005 < m < 5.0 for m in ms), ms
+    assert sum(ms) <= a.elapsed_time(b) * 1.05
+    got = fp.lists_to_host()
+    np.testing.assert_array_equal(got[0], ref[0]); np.testing.assert_array_equal(got[1], ref[1])
+    fp.cull(f.cam.frame, l, N, d)   # all four slots are used up: ordinary launches again
+    ctx.synchronize()

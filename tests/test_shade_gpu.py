@@ -284,7 +284,7 @@ def test_tile_order_hint_with_fewer_lights_than_the_workspace_capacity(ctx):
 
 def test_split_tiles_on_a_band_of_the_4k_frame(ctx):
     """configs[2], band 3 of 8 (it crosses a light cluster: hundreds of tiles with 40..128 lights go to the split blocks): the split form and
-    the one-block-per-tile form agree to twice the oracle tolerance everywhere, bit for bit on the short tiles, and an oracle-checked strip
+    the one-block-per-tile form agree within the oracle tolerance everywhere, bit for bit on the short tiles, and an oracle-checked strip
     of the band is within tolerance."""
     f = synth.make_frame("C3")
     W, H, N = f.cam.width, f.cam.height, len(f.lights)
@@ -301,7 +301,7 @@ def test_split_tiles_on_a_band_of_the_4k_frame(ctx):
     num = g[:, 1].reshape(-1, fp.Tx)
     assert (num >= 40).sum() > 100 and (num == 128).any()
     err = np.abs(split.astype(np.float64) - plain)
-    assert (err <= 2 * RTOL * np.abs(plain) + 2 * atol_of(plain[..., :3])).all()
+    assert (err <= RTOL * np.abs(plain)).all()   # (measured: 2e-6; the two forms differ by the association of one sum of non-negative terms)
     long_px = np.repeat(np.repeat(num[::-1] >= 40, 16, 0), 16, 1)[-band.fbRowCount:, :W]  # tile row 0 of the band = its bottom rows
     assert (split[~long_px] == plain[~long_px]).all() and err[long_px].max() > 0
     # the oracle on the band's first tile row (16 framebuffer rows)
@@ -312,6 +312,57 @@ def test_split_tiles_on_a_band_of_the_4k_frame(ctx):
     r0, r1 = H - 16 * (tr0 + 1), H - 16 * tr0
     ref = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, grid, oi, None, rows=(r0, r1))
     assert_radiance_close(split[r0 - band.fbRowBegin:r1 - band.fbRowBegin], ref[r0:r1])
+
+
+def test_all_eight_bands_of_the_4k_frame_through_the_band_kernel_against_the_oracle(ctx):
+    """The kernel every rank of an N > 1 run executes, held against the ORACLE over the ENTIRE frame at north_star's 1e-4: the
+    eight bands of configs[2], each culled with the tile-order hint and shaded by k2_shade_band_p (prepared lights, long tiles through the split
+    blocks whose four waves add their partial sums in a fixed order), stitched and compared with oracle_shade_threads' whole frame -- not with the
+    one-block form and not at a relaxed tolerance.  (Standard.shader:427-436 sums the lights in list order; every term is >= 0 here, so a different
+    association moves the sum by at most n * 2^-24 of itself.)"""
+    f = synth.make_frame("C3")
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    lights = upload_lights(f.lights, ctx.device)
+    prep = PreparedLights(ctx, lights, N)
+    got = np.empty((H, W, 4), np.float32)
+    grids, segs, long_tiles, base = [], [], 0, 0
+    for r in range(8):
+        band = host.band_for_rank(W, H, r, 8)
+        rows = slice(band.fbRowBegin, band.fbRowBegin + band.fbRowCount)
+        fp = ForwardPlus(ctx, W, H, N, band=band, prepared=prep)
+        assert fp.tile_order and fp.use_tile_order
+        fp.cull(f.cam.frame, lights, N, torch.from_numpy(np.ascontiguousarray(f.depth[rows])).to(ctx.device))
+        got[rows] = fp.shade(f.cam.frame, torch.from_numpy(np.ascontiguousarray(f.surface[:, rows])).to(ctx.device), lights, N).cpu().numpy()
+        g, idx = fp.lists_to_host()
+        long_tiles += int((g[:, 1] >= 40).sum())
+        g = g.copy(); g[:, 0] += base
+        base += int(idx[0])
+        grids.append(g); segs.append(idx[1:])
+    assert long_tiles > 1000, "the split blocks had work in this frame"
+    g_all = np.concatenate(grids)
+    idx_all = np.concatenate([np.uint32([base])] + segs)
+    assert_oracle_rows(f, got, oracle_tile_rows(135, [(16, 1), (50, 2), (84, 1), (118, 1)]), gpu_lists=(g_all, idx_all))
+
+
+def test_shading_from_the_per_tile_lists_is_shading_from_the_canonical_buffers(ctx):
+    """sailor_hip_shade_tile_lists (the default of ForwardPlus.shade since round 4) reads tile t's list at tileLists[128 t ..] / tileNum[t], the entry
+    points of rounds 1-3 through lightsGrid / culledLights: the same entries in the same order, so the radiance is the same BITS -- plain and prepared
+    lights, whole frame and a band with its split tiles."""
+    f = synth.make_frame("tiny")
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    lights = upload_lights(f.lights, ctx.device)
+    for prep in (None, PreparedLights(ctx, lights, N)):
+        for band in (None, host.band_for_rank(W, H, 1, 2)):
+            fp = ForwardPlus(ctx, W, H, N, band=band, prepared=prep)
+            rows = slice(fp.band.fbRowBegin, fp.band.fbRowBegin + fp.band.fbRowCount)
+            fp.cull(f.cam.frame, lights, N, torch.from_numpy(np.ascontiguousarray(f.depth[rows])).to(ctx.device))
+            s = torch.from_numpy(np.ascontiguousarray(f.surface[:, rows])).to(ctx.device)
+            assert fp.shade_from_tile_lists
+            a = fp.shade(f.cam.frame, s, lights, N).cpu().numpy().copy()
+            fp.shade_from_tile_lists = False
+            b = fp.shade(f.cam.frame, s, lights, N).cpu().numpy()
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+            assert_radiance_close(a, oracle_frame(f)[rows])
 
 
 def test_every_light_reaches_every_pixel(ctx):
