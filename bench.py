@@ -73,6 +73,8 @@ def parse(argv=None):
                     help="every light is dirty every frame (LightingECS::Tick re-uploads it, ECS/LightingECS.cpp:152-191): sailor_hip_prepare_lights over all N lights inside "
                          "every step, in front of the cull.  The default for C5 (\"1 M dynamic lights\"); the other configurations report it beside `value` as value_dynamic_lights")
     ap.add_argument("--static-lights", dest="dynamic_lights", action="store_false", help="the lights' prepared views are derived once, outside the timed region (the default except for C5)")
+    ap.add_argument("--separate-prepare", action="store_true", help="dynamic lights: sailor_hip_prepare_lights as a launch of its own in front of every cull (round 3) instead of "
+                                                                    "folded into the cull's per-light pass (SAILOR_CULL_PREPARE_LIGHTS)")
     ap.add_argument("--pack-inline", action="store_true", help="k1_pack inside every cull on the cull's stream (rounds 1-3) instead of deferred to a third stream beside the shade")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--equal-bands", action="store_true", help="N > 1: equal tile-row bands instead of cost-balanced ones")
@@ -661,8 +663,11 @@ def capture_frame_pipeline(side, side2, unroll, shade_fns, cull_fns, dev=None, p
     critical path -- the kernel trace shows ~10 us between the end of one shade and the start of the next (scripts/analysis/pipeline_timeline.py);
     with a third set the cull waits for a shade that ended a frame ago, and the shades follow each other like launches on one stream.
     pack_fns / side3 (round 4): the culls were recorded with SAILOR_CULL_DEFER_PACK -- the shade reads the per-tile lists, so nothing on the frame's
-    path needs lightsGrid / culledLights -- and pack_fns[q]() writes set q's canonical buffers on a third stream behind its cull: shade(k + 1) and
-    cull(k + 2) do not wait for it, only the next cull into the SAME set does (it overwrites what the pack reads)."""
+    path needs lightsGrid / culledLights -- and pack_fns[q]() writes set q's canonical buffers behind the event shade(k + 1) waits for: on the cull's
+    own stream (side3 is side2: the form bench.py uses -- in order with everything else that touches the set, no further dependency) or on a third
+    stream (cull(k + 2) then does not wait for it either, only the next cull into the SAME set does).  The third-stream form makes hipGraph capture on
+    ROCm 7.0 / torch 2.10 fall over (a segmentation fault in capture_end as soon as a forked stream waits for an event of another forked stream:
+    scripts/pipeline3_probe.py); eager launches take it."""
     dev = dev or _dev()
     S = len(shade_fns)
     assert len(cull_fns) == S and (pack_fns is None or (len(pack_fns) == S and side3 is not None))
@@ -687,12 +692,16 @@ def capture_frame_pipeline(side, side2, unroll, shade_fns, cull_fns, dev=None, p
                 cull_fns[q]()
                 cull_done = dev.event(False); cull_done.record(side2)
             if pack_fns is not None:
-                side3.wait_event(cull_done)
-                with dev.on_stream(side3):
-                    pack_fns[q]()
-                    pack_done[q] = dev.event(False); pack_done[q].record(side3)
+                if side3 is side2:   # behind the event shade(k + 1) waits for, on the cull's own stream: in order with everything that touches the set
+                    with dev.on_stream(side2):
+                        pack_fns[q]()
+                else:
+                    side3.wait_event(cull_done)
+                    with dev.on_stream(side3):
+                        pack_fns[q]()
+                        pack_done[q] = dev.event(False); pack_done[q].record(side3)
         side.wait_stream(side2)  # join
-        if pack_fns is not None:
+        if pack_fns is not None and side3 is not side2:
             side.wait_stream(side3)
     return dev.capture(side, body)
 
@@ -884,9 +893,9 @@ def main(argv=None, device_factory=None):
         """one frame's cull chain into f's list set, recorded on context c's stream (None: the launch stream); with dynamic lights the preparation
         of every light goes in front of it, on the same stream.  defer_pack: stop after the per-tile lists (the shade reads those); f.pack() writes
         lightsGrid / culledLights wherever the caller records it"""
-        if dyn:
+        if dyn and args.separate_prepare:
             f.prepared.prepare(0, N, ctx=c)
-        f.cull(cam.frame, d_lights, N, d_depth, ctx=c, defer_pack=defer_pack)
+        f.cull(cam.frame, d_lights, N, d_depth, ctx=c, defer_pack=defer_pack, prepare_lights=dyn and not args.separate_prepare)
 
     def cull():
         cull_of(fp, None, dynamic)
@@ -920,10 +929,7 @@ def main(argv=None, device_factory=None):
     defer_pack = not args.pack_inline and hasattr(fp, "pack")
     side2 = dev.stream(priority=int(os.environ.get('SAILOR_CULL_PRIORITY', '0')))
     ctx2 = dev.context(side2)
-    side3 = ctx3 = None
-    if defer_pack:
-        side3 = dev.stream()
-        ctx3 = dev.context(side3)
+    side3, ctx3 = side2, ctx2   # (the pack's stream: the cull's own -- see capture_frame_pipeline)
     fps = (fp,)
     if want_pipeline:
         fps = (fp,) + tuple(resident(band, True)[0] for _ in range(args.list_sets - 1))   # further sets of grid / culledLights / workspace / prepared views
@@ -951,7 +957,7 @@ def main(argv=None, device_factory=None):
                 rest = graphs[1] if graphs[0] is not None else None
                 per = unroll if unroll else tail
                 how = (f"hipGraph replay ({per} steps of the frame pipeline per graph" + (f", {tail} in the last" if unroll and tail else "") +
-                       f"), 2 frames in flight over {args.list_sets} list sets" + (", k1_pack on a third stream beside the shade" if defer_pack else ""))
+                       f"), 2 frames in flight over {args.list_sets} list sets" + (", k1_pack behind the event the shade waits for" if defer_pack else ""))
                 return main_graph.replay, (rest.replay if rest is not None else (lambda: None)), per, how
             except Exception as e:
                 print(f"[bench] two-frames-in-flight capture failed ({type(e).__name__}: {e}); falling back to one frame in flight", file=sys.stderr)
@@ -1052,7 +1058,7 @@ def main(argv=None, device_factory=None):
     # its real neighbours (the cull chain in front, the next frame's behind) -- a direct reading of the kernel, the figure rocprofv3's kernel trace
     # reports, no difference of two measurements (VERDICT r03 / ADVICE r03)
     direct = kernel_in_frame_ms(ctx, cull, shade, max(args.steps, BATCH_LAUNCHES))
-    chain_names = (["k_prepare_lights"] if dynamic else []) + (["k01_prepare", "k1_tile_cull<brute>", "k1_pack"] if N < 512 else
+    chain_names = (["k_prepare_lights"] if (dynamic and args.separate_prepare) else []) + (["k01_prepare", "k1_tile_cull<brute>", "k1_pack"] if N < 512 else
                                                                 ["k01_prepare", "k1_group_lists" + ("_wide" if N >= 262144 else ""), "k1_tile_cull", "k1_pack"])
     chain_ms = chain_kernels_ms(ctx, cull, shade, max(args.steps, BATCH_LAUNCHES), len(chain_names))
     g, idx = fp.lists_to_host()
@@ -1101,7 +1107,7 @@ def main(argv=None, device_factory=None):
                 "valu_sidebar": {"pixel_light_evals": evals, "gevals_per_s": evals / (shade_launch_ms * 1e-3) / 1e9,
                                  "note": "~110 fp32 ops per (pixel,light): VALU-bound once mean list length exceeds ~10 (SURVEY.md 7, hard part 2)"},
                 "csm": csm_info,
-                "cull": {"kernels": ("k_prepare_lights+" if dynamic else "") + "k01_prepare+k1_*", "kernels_ms": dict(zip(chain_names, chain_ms)), "kernels_sum_ms": float(sum(chain_ms)),
+                "cull": {"kernels": (("k_prepare_lights+" if args.separate_prepare else "(lights prepared inside) ") if dynamic else "") + "k01_prepare+k1_*", "kernels_ms": dict(zip(chain_names, chain_ms)), "kernels_sum_ms": float(sum(chain_ms)),
                          "kernels_how": "median over the frames of the direct reading above, per kernel of the chain (each kernel's own dispatch-packet timestamps)",
                          "avg_ms": cull_batch_ms, "isolated_avg_ms": cull_ms[0], "isolated_median_ms": cull_ms[1],
                          "bytes": b_cull, "achieved_gbs": b_cull / (cull_batch_ms * 1e-3) / 1e9, "frac": b_cull / (cull_batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -1233,7 +1239,8 @@ def main(argv=None, device_factory=None):
 
     line = None
     if rank == 0:
-        mode = ("dynamic: every light dirty every frame -- sailor_hip_prepare_lights over all %d lights inside every step, in front of the cull" % N) if dynamic else \
+        mode = (("dynamic: every light dirty every frame -- the prepared views of all %d lights re-derived inside every step, " % N) +
+                ("by sailor_hip_prepare_lights in front of the cull" if args.separate_prepare else "folded into the cull's per-light pass (SAILOR_CULL_PREPARE_LIGHTS)")) if dynamic else \
                ("static: the lights' prepared views derived ONCE, outside the timed region (LightingECS::Tick uploads dirty runs only; the synthetic set does not move)" if prep is not None
                 else "plain: no prepared views, cull and shade read the 112-byte records")
         out = {

@@ -193,6 +193,11 @@ SAILOR_HIP_API int sailor_hip_context_stream(SailorHipContext* ctx, void** outSt
 /* Text of the last HIP/RCCL error seen by this context (never NULL). */
 SAILOR_HIP_API const char* sailor_hip_context_last_error(SailorHipContext* ctx);
 
+/* Orders two contexts of one device: everything recorded on `waiter` after this call starts after everything recorded on `signaller` before it
+ * (an event on the signaller's stream, a wait on the waiter's: the Vulkan backend's semaphore between two queues, VulkanGraphicsDriver.cpp
+ * SubmitCommandList's wait / signal lists).  Used by the HIP backend to run the cull's compaction step beside the shade (SAILOR_CULL_DEFER_PACK). */
+SAILOR_HIP_API int sailor_hip_context_wait_for(SailorHipContext* waiter, SailorHipContext* signaller);
+
 /* Measurement aid (no reference counterpart): the next `count` kernel launches recorded through this context carry a HIP event pair on their own
  * dispatch packets (hipExtLaunchKernel's start / stop events) in slots [firstSlot, firstSlot + count), in launch order -- e.g. the four kernels of
  * one sailor_hip_light_cull, or the one of a sailor_hip_shade.  sailor_hip_context_timed_launch_ms waits for a slot's kernel and returns its
@@ -257,6 +262,10 @@ SAILOR_HIP_API int sailor_hip_band_is_valid(int32_t width, int32_t height, const
                                        * sailor_hip_light_cull_pack -- on any context / stream ordered after this call, e.g. a second stream beside the shade --
                                        * produces the two canonical buffers from them, bit for bit what the undeferred call writes */
 
+#define SAILOR_CULL_PREPARE_LIGHTS 16u /* sailor_hip_light_cull_prepared only: EVERY light is dirty this frame (LightingECS::Tick re-uploaded the whole set,
+                                        * ECS/LightingECS.cpp:152-191).  The cull's per-light pass reads the 112-byte records in dLights and WRITES the prepared
+                                        * views of all pc->lightsNum lights into dPreparedLights on the way -- sailor_hip_prepare_lights(0, lightsNum) folded
+                                        * into the cull: one pass over the records instead of two, one launch less; the same bits in the views, the same lists */
 SAILOR_HIP_API size_t sailor_hip_light_cull_workspace_size(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band);
 SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
                                          const SailorUboFrameData* frame, const SailorLightCullPushConstants* pc,

@@ -25,6 +25,7 @@ CULL_BRUTE_FORCE = 1
 CULL_RAW_DEPTH = 2
 CULL_INTERVAL_MASKS = 4
 CULL_DEFER_PACK = 8
+CULL_PREPARE_LIGHTS = 16
 
 RASTER_CLEAR, RASTER_CULL_BACK = 1, 2
 SHADOWMAP_R16F = 0
@@ -129,6 +130,7 @@ SIGNATURES = {
     "sailor_hip_light_cull_pack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band), _P, _P, _P, C.c_size_t]),
     "sailor_hip_shade_tile_lists": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_size_t, _P, C.c_int32, _P, _P, C.POINTER(CsmDesc), C.POINTER(IblDesc), _P,
                                               C.POINTER(Band), _P, _P, C.c_int32]),
+    "sailor_hip_context_wait_for": (C.c_int, [_P, _P]),
     "sailor_hip_context_time_launches": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "sailor_hip_context_timed_launch_ms": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float)]),
     "sailor_hip_evsm_blur": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

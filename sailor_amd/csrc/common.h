@@ -24,6 +24,7 @@ struct SailorHipContext {
     // sailor_hip_context_time_launches: event pairs that ride on the dispatch packets of the next launches (slots [timeNext, timeEnd))
     std::vector<hipEvent_t> timeStart, timeStop;
     int timeNext = 0, timeEnd = 0;
+    hipEvent_t orderEvent = nullptr; // sailor_hip_context_wait_for: "everything recorded on this context so far"
 };
 
 static inline int sailor_map_hip_error(SailorHipContext* ctx, hipError_t e, const char* what)

@@ -58,6 +58,7 @@ int sailor_hip_context_destroy(SailorHipContext* ctx)
 {
     if (!ctx) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (ctx->ownsStream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    if (ctx->orderEvent) (void)hipEventDestroy(ctx->orderEvent);
     for (hipEvent_t e : ctx->timeStart) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->timeStop) (void)hipEventDestroy(e);
     delete ctx;
@@ -68,6 +69,17 @@ int sailor_hip_context_synchronize(SailorHipContext* ctx)
 {
     if (!ctx) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     SAILOR_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_context_wait_for(SailorHipContext* waiter, SailorHipContext* signaller)
+{
+    if (!waiter || !signaller || waiter->device != signaller->device) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (waiter->stream == signaller->stream) return SAILOR_HIP_OK; // one in-order stream: already ordered
+    SAILOR_TRY_HIP(waiter, hipSetDevice(waiter->device));
+    if (!signaller->orderEvent) SAILOR_TRY_HIP(signaller, hipEventCreateWithFlags(&signaller->orderEvent, hipEventDisableTiming));
+    SAILOR_TRY_HIP(signaller, hipEventRecord(signaller->orderEvent, signaller->stream));
+    SAILOR_TRY_HIP(waiter, hipStreamWaitEvent(waiter->stream, signaller->orderEvent, 0));
     return SAILOR_HIP_OK;
 }
 

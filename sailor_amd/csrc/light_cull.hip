@@ -29,12 +29,12 @@
 //                      The tiles of a LIGHT CLUSTER (a group with more than 512 candidates, listed by k1_group_lists) get a whole
 //                      block each at the front of the grid: four waves share the tile's candidates and its 196 -> 128 selection
 //                      (round 4; one wave took ~20 us for such a tile -- the launch's tail and a cluster band's whole cull).
-//                      Every tile leaves its list in its own fixed 128-entry slot of the workspace (`tile lists`), its length in
-//                      tileNum, and adds the length to its tile row's total
+//                      Every tile leaves its list in its own fixed 128-entry slot of the workspace (`tile lists`) and its length in
+//                      tileNum
 //   k1_pack            canonical offsets (Appendix A step 6: prefix sum of the list lengths in tile order) and compaction
-//                      in ONE streaming launch without a scan chain: a pack block owns 64 consecutive tiles, adds up the row
-//                      totals in front of its first row and the lengths of that row's earlier tiles itself (a few hundred words),
-//                      then moves its tiles' lists through LDS into culledLights as one contiguous run.  Since round 4 NOTHING on
+//                      in ONE streaming launch without a scan chain: a pack block owns 64 consecutive tiles, adds up the lengths
+//                      of all tiles in front of them itself (tileNum: L2-resident), then moves its tiles' lists through LDS into
+//                      culledLights as one contiguous run.  Since round 4 NOTHING on
 //                      the path needs its output: the shade reads a tile's list from its slot (sailor_hip_shade_tile_lists), so the
 //                      launch can run beside the shade on another stream (SAILOR_CULL_DEFER_PACK + sailor_hip_light_cull_pack) and
 //                      still produces the reference's lightsGrid / culledLights bit for bit.  (Tried in round 2: a decoupled
@@ -49,6 +49,7 @@
 //
 // No MFMA: sphere/plane tests and compaction, not a contraction.  Compiled with -ffp-contract=off.
 #include "common.h"
+#include "light_record.h"
 #include <vector>
 
 #define BANDS_PER_BLOCK 24   // group columns / rows whose masks one light block of k01_prepare builds when the lights alone do not fill the chip
@@ -59,18 +60,18 @@
 #define GROUP_OVERFLOW 0xFFFFFFFFu
 #define GROUP_OVERFLOW_LISTED 0xFFFFFFFEu // ... the same for a group that is in k1_group_lists' cluster list
 #define GROUP_LISTED 0x40000000u // flag in a group's count: a light cluster k1_group_lists found room for in its list (k1_tile_cull starts with those)
-#define HEAVY_MAX 256           // ... and that list's room
+#define HEAVY_MAX 96            // ... and that list's room (16 head blocks of k1_tile_cull per entry: the empty ones are dispatched in front of everything else -- 4 096 of them cost ~3 us)
 #define CHUNK 512            // group candidates staged in LDS per step of k1_tile_cull (16 KB of LDS per block: 8 blocks per CU)
 
 #define PACK_TILES 64        // tiles per k1_pack block
 #define CL_STEPS (CAPG / 4 / 64) // cluster tiles: 64-candidate steps per wave for the longest listable group (8)
 
-// Per tile row of the band: the sum of its tiles' list lengths (uint32) and, for the shading hint, class A tiles << 16 | class B tiles (uint32)
+// the shading hint's class counts travel as class A tiles << 16 | class B tiles in one uint32
 #define CLS_MAX_TILES 65535
 
 struct CullLayout {
     int Tx, Ty, bandRows, bandTiles, numBands, words, groupsX, groupsY, numGroups, packBlocks;
-    size_t offLightView, offLightType, offTileInfo, offMasks, offDirWords, offGroupCount, offGroupList, offRowTotals, offRowCls, offTileNum, offTileLists, offTileOrder, offDirFlag, offHeavy, total;
+    size_t offLightView, offLightType, offTileInfo, offMasks, offDirWords, offGroupCount, offGroupList, offTileNum, offTileNum8, offTileLists, offTileOrder, offDirFlag, offHeavy, total;
 };
 
 static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
@@ -94,16 +95,14 @@ static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
     // call looks up from (width, height, band) alone -- the tile-order hint -- is then the same for every lightsNum <= the capacity the
     // workspace was sized for (a cull may run with fewer lights than the capacity; round 2 computed the hint's address from the capacity and
     // the cull's own layout from lightsNum, which only agree when the two are equal).
-    const size_t rows = (size_t)(L.bandRows > 0 ? L.bandRows : 1);
     size_t o = 0;
     L.offTileInfo = o; o = align_up(o + tiles * 64, 256);
     L.offGroupCount = o; o = align_up(o + groups * 4, 256);
     L.offDirFlag = o; o = align_up(o + 4, 256);
     L.offHeavy = o; o = align_up(o + (1 + HEAVY_MAX) * 4, 256); // [0] = light-cluster groups listed by k1_group_lists (zeroed by k01_prepare), then their indices
     L.offGroupList = o; o = align_up(o + groups * CAPG * 4, 256);
-    L.offRowTotals = o; o = align_up(o + rows * 4, 256);      // zeroed by k01_prepare, added to by k1_tile_cull
-    L.offRowCls = o; o = align_up(o + rows * 4, 256);
     L.offTileNum = o; o = align_up(o + tiles * 4, 256);
+    L.offTileNum8 = o; o = align_up(o + tiles + 64, 256);      // the same lengths (<= 128) as bytes: what k1_pack adds up for its base (32 KB at 4K instead of 130)
     L.offTileLists = o; o = align_up(o + tiles * KEEP * 4, 256); // one fixed 128-entry slot per tile (only the list's own bytes are ever touched)
     L.offTileOrder = o; o = align_up(o + (tiles + 2) * 4, 256); // long tiles (A from the front, B from the back) + their two counts
     L.offLightView = o; o = align_up(o + n * 16, 256);
@@ -163,11 +162,11 @@ struct PrepareArgs {
     Mat4 view, invProj;
     const SailorLightShaderData* lights;
     const float4* soaPosRadius; const uint32_t* soaType; // sailor_hip_prepare_lights' 20-byte view of the lights, or null: read the 112-byte records
+    float4* prepPosRadius; uint32_t* prepType; float4* prepStaged; // SAILOR_CULL_PREPARE_LIGHTS: the prepared views, WRITTEN here from the records (else null)
     const float* depth;
     float4* lightView; uint32_t* lightType; float4* tileInfo;
     unsigned long long* masks; unsigned long long* dirWords;
     uint32_t* heavy;   // [0]: k1_group_lists' count of light-cluster groups, zeroed here (one launch ahead of it)
-    uint32_t* rowTotals; uint32_t* rowCls; // per tile row: sum of list lengths / class counts, zeroed here (two launches ahead of k1_tile_cull's atomics)
     uint32_t* dirFlag; // "some light may be directional": set here, read by k1_group_lists_wide, cleared by k1_tile_cull (unknown before the first cull: then merely conservative)
     int N, words, lightBlocks, lightRoleBlocks, frustumBlocks, bandsPerBlock, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands,
         stripsPerRow, vecOK, rawDepth, intervals;
@@ -229,7 +228,22 @@ __device__ __forceinline__ void k0_lights(const int lb, unsigned char* __restric
     uint32_t type = 1u;
     if (valid) {
         float x, y, z, radius;
-        if (a.soaPosRadius) { // two dense arrays, 20 bytes per light
+        if (a.prepStaged) {   // every light is dirty (SAILOR_CULL_PREPARE_LIGHTS): ONE pass over the 112-byte records derives the prepared views too --
+            // what sailor_hip_prepare_lights(0, N) in front of this cull does in a launch of its own (k_prepare_lights: the same instructions,
+            // the same bits), without reading the records a second time and the 20-byte view back
+            const float4* L = reinterpret_cast<const float4*>(a.lights + j);
+            const float4 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3], q4 = L[4], q5 = L[5], q6 = L[6];
+            x = q1.x; y = q1.y; z = q1.z; radius = q6.x;
+            type = __float_as_uint(q0.x);
+            if (split == 0) {
+                a.prepPosRadius[j] = make_float4(x, y, z, radius);
+                a.prepType[j] = type;
+                float4 o0, o1, o2, o3, o4;
+                stage_light_record(q0, q1, q2, q3, q4, q5, q6, o0, o1, o2, o3, o4);
+                float4* o = a.prepStaged + (size_t)j * LREC;
+                o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3; o[4] = o4;
+            }
+        } else if (a.soaPosRadius) { // two dense arrays, 20 bytes per light
             const float4 pr = a.soaPosRadius[j];
             x = pr.x; y = pr.y; z = pr.z; radius = pr.w;
             type = a.soaType[j];
@@ -434,10 +448,7 @@ __global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K01_PREPARE];
     const int b = (int)blockIdx.x;
-    if (b == 0) {
-        if (threadIdx.x == 0) a.heavy[0] = 0u;
-        for (int r = threadIdx.x; r < a.bandRows; r += 256) { a.rowTotals[r] = 0u; a.rowCls[r] = 0u; }
-    }
+    if (b == 0 && threadIdx.x == 0) a.heavy[0] = 0u;
     if (b < a.lightRoleBlocks) k0_lights(b, lds, a);
     else if (b < a.lightRoleBlocks + a.frustumBlocks) k1_tile_frusta(b - a.lightRoleBlocks, a);
     else k1_tile_setup(b - a.lightRoleBlocks - a.frustumBlocks, lds, a);
@@ -746,8 +757,8 @@ __device__ __forceinline__ uint32_t tile_class_word(uint32_t num) { return num >
 struct CullArgs {
     const float4* lightView; const uint32_t* lightType; const float4* tileInfo;
     const unsigned long long* masks; const uint32_t* groupCount; const uint32_t* groupList;
-    uint32_t* rowTotals; uint32_t* rowCls; uint32_t* tileNum; uint32_t* tileLists; uint32_t* dirFlag;
-    int N, words, Tx, groupsX, bandRows, classes;
+    uint32_t* tileNum; uint8_t* tileNum8; uint32_t* tileLists; uint32_t* dirFlag;
+    int N, words, Tx, groupsX, bandRows;
     const uint32_t* heavy; int headRows; // k1_group_lists' cluster list and the grid rows in front of the tile rows that take its tiles (0: none)
 };
 
@@ -852,14 +863,15 @@ __device__ __forceinline__ void test_staged(const TileCtx& t, const uint32_t cn,
 }
 
 #define LDS_K1_TILE_CULL (CHUNK * 16 + CHUNK * 4 + 4 * CAND * 4 + 4 * CAND * 4)
-// make EXTRA=-DCULL_PROF + scripts/cull_prof.py: per-block phase times (s_memtime; comparable within a block only -- the counter is per XCD)
+// make EXTRA=-DCULL_PROF + scripts/cull_prof.py: per-block phase times (s_memrealtime: the 100 MHz constant clock, one time base for the whole chip)
 #ifdef CULL_PROF
 __device__ unsigned long long g_cullProf[65536][4];
 extern "C" __attribute__((visibility("default"))) int sailor_hip_debug_read_cull_prof(void* dst, size_t bytes)
 {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_cullProf), bytes);
 }
-#define PROF_T(i) if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 65536) g_cullProf[blockIdx.y * gridDim.x + blockIdx.x][i] = __builtin_amdgcn_s_memtime()
+#define PROF_T(i) if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 65536) { g_cullProf[blockIdx.y * gridDim.x + blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); \
+                                                                                        if ((i) == 0) g_cullProf[blockIdx.y * gridDim.x + blockIdx.x][2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF; } /* [2] = HW_REG_XCC_ID (id 20), bits 0..3 */
 #else
 #define PROF_T(i)
 #endif
@@ -918,12 +930,13 @@ __device__ __forceinline__ void walk_tile_masks(const TileCtx& t, const CullArgs
     }
 }
 
-// what a tile leaves behind besides its list: the length, and its share of its tile row's totals (k1_pack's offsets; the shading hint's classes)
-__device__ __forceinline__ void publish_tile(const CullArgs& a, const int tyLocal, const int bandTile, const uint32_t num)
+// What a tile leaves behind besides its list: the length.  (Measured and dropped: the length also added to a per-tile-row total with a relaxed
+// device-scope atomic, for k1_pack's offsets -- 32 400 atomics on 135 words = five cache lines serialise at the memory side: k1_tile_cull 26 ->
+// 140 us.  k1_pack adds up the lengths of the tiles in front of its own instead: 64 KB of L2 reads per block on average.)
+__device__ __forceinline__ void publish_tile(const CullArgs& a, const int bandTile, const uint32_t num)
 {
     a.tileNum[bandTile] = num;
-    if (num) __hip_atomic_fetch_add(a.rowTotals + tyLocal, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.classes && num >= CLASS_B) __hip_atomic_fetch_add(a.rowCls + tyLocal, tile_class_word(num), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.tileNum8[bandTile] = (uint8_t)num;
 }
 
 // ---- a tile of a LIGHT CLUSTER, one 256-thread block for the one tile (round 4).  A group with several chunks of candidates costs every one of
@@ -985,7 +998,7 @@ __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* _
     const uint32_t all = (c0 + c1) + (c2 + c3), n = all < CAND ? all : CAND, num = n < KEEP ? n : KEEP;
     for (uint32_t i = lane; i < sCnt[wave] && before + i < CAND; i += 64) sAll[before + i] = sIdx[i];
     __syncthreads();
-    if (threadIdx.x == 0) publish_tile(a, tyLocal, bandTile, num);
+    if (threadIdx.x == 0) publish_tile(a, bandTile, num);
     uint32_t* __restrict__ out = a.tileLists + (size_t)bandTile * KEEP;
     if (n <= KEEP) { // :235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]
         if (threadIdx.x < n) out[threadIdx.x] = sAll[n - 1 - threadIdx.x] & 0x7FFFFFFFu;
@@ -1027,28 +1040,106 @@ __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* _
     if (rank < KEEP) out[rank] = mine & 0x7FFFFFFFu;
 }
 
-template <bool BRUTE>
+// The validation path (SAILOR_CULL_BRUTE_FORCE; also tiny light sets and odd projections): no pre-filter, no staging, no cooperation between
+// waves -- every tile walks ALL lights by itself, 64 per step, and selects with emit_list on its own wave.  One block per run of four tiles.
+__global__ __launch_bounds__(256) void k1_tile_cull_brute(const CullArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 4 * CAND * 4];
+    uint32_t (*sIdxAll)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds);
+    float (*sImpAll)[CAND] = reinterpret_cast<float (*)[CAND]>(lds + 4 * CAND * 4);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.dirFlag = 0u;
+    const int gx = (int)blockIdx.x, tyLocal = (int)blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int tx = gx * GROUP + wave;
+    if (tx >= a.Tx) return;
+    const int bandTile = tyLocal * a.Tx + tx;
+    TileCtx t;
+    load_tile_ctx(a.tileInfo, bandTile, t);
+    uint32_t count = 0;
+    for (int base = 0; base < a.N && count < CAND; base += 64) {
+        const int j = base + lane;
+        test_candidates(t, a.lightView, a.lightType, j < a.N, (uint32_t)j, count, sIdxAll[wave]);
+    }
+    const uint32_t n = count < CAND ? count : CAND;
+    if (lane == 0) publish_tile(a, bandTile, n < KEEP ? n : KEEP);
+    emit_list(t, n, sIdxAll[wave], sImpAll[wave], a.lightView, a.tileLists + (size_t)bandTile * KEEP);
+}
+
+// The 196 -> 128 selection of ONE tile by the whole block (ComputeLightCulling.shader:198-225): one candidate per thread.  sIdx: the tile's n > 128
+// candidates (ascending light index, bit 31 = directional); sImp: room for CAND + 4 floats, 16-byte aligned.  Every thread of the block calls it
+// (two barriers inside).  A NaN impact has no rank: the literal bubble sort, on one wave (emit_list).
+__device__ __forceinline__ void block_select(const CullArgs& a, const int bandTile, const uint32_t n, uint32_t* sIdx, float* sImp, uint32_t* sFlag)
+{
+    const uint32_t k = threadIdx.x, lane = threadIdx.x & 63;
+    const float4* __restrict__ lightView = a.lightView;
+    uint32_t* __restrict__ out = a.tileLists + (size_t)bandTile * KEEP;
+    const float4* ti = a.tileInfo + (size_t)bandTile * 4; // (block-uniform: scalar loads)
+    const float cx = ti[0].w, cy = ti[1].w, cz = (ti[3].w + ti[2].w) * 0.5f;
+    uint32_t mine = 0u;
+    float imp = 0.0f;
+    if (k < n) {
+        mine = sIdx[k];
+        if (!(mine & 0x80000000u)) { // :187 impact = distance(light, frustum centre); a directional light's is 0 (:153-162)
+            const float4 lv = lightView[mine & 0x7FFFFFFFu];
+            const float dx = lv.x - cx, dy = lv.y - cy, dz = lv.z - cz;
+            imp = sqrtf(dot3f(dx, dy, dz, dx, dy, dz));
+        }
+        sImp[k] = imp;
+    }
+    if (__ballot(k < n && imp != imp) != 0ull && lane == 0) *sFlag = 1u;
+    __syncthreads();
+    if (*sFlag != 0u) {
+        if (threadIdx.x < 64) {
+            TileCtx t;
+            load_tile_ctx(a.tileInfo, bandTile, t);
+            emit_list(t, n, sIdx, sImp, lightView, out);
+        }
+    } else if (k < n) {
+        // rank under (impact ascending, candidate position descending); keep rank < 128
+        const float4* sImp4 = reinterpret_cast<const float4*>(sImp);
+        uint32_t rank = 0u;
+        const uint32_t full4 = n / 4u;
+        for (uint32_t q4 = 0; q4 < full4; q4++) {
+            const float4 gv = sImp4[q4];
+            const float gq[4] = { gv.x, gv.y, gv.z, gv.w };
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                const uint32_t q = q4 * 4u + c;
+                rank += (gq[c] < imp || (gq[c] == imp && q > k)) ? 1u : 0u;
+            }
+        }
+        for (uint32_t q = full4 * 4u; q < n; q++) {
+            const float gq = sImp[q];
+            rank += (gq < imp || (gq == imp && q > k)) ? 1u : 0u;
+        }
+        if (rank < KEEP) out[rank] = mine & 0x7FFFFFFFu;
+    }
+    __syncthreads(); // (sImp / sFlag are the next tile's)
+}
+
 __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
 {
     // One 256-thread block per run of four tiles (a group's four columns in one tile row), one wave per tile.  The group's candidate records are
     // staged in LDS, CHUNK at a time, by the four waves together (list entries first, then the dependent 16-byte gathers, four of each in flight
-    // per thread), and every tile streams them out of LDS.  Four blocks per group, not one of sixteen waves: measured in rounds 2 and 3 (also: one
-    // block doing all four rows, wave w = row w: 38.8 us against 32.4).
+    // per thread), and every tile streams them out of LDS.  A tile with more than 128 candidates gets its 196 -> 128 selection from the WHOLE block
+    // (block_select: ~3 us instead of ~12 on the one wave -- the launch's tail once the light clusters had blocks of their own, profiles/r04).
+    // Measured and dropped in round 4 (scripts/cull_prof.py: the per-block timeline on the 100 MHz clock): TWO tile rows per block, the staged
+    // candidates serving both -- half the blocks, half the staging traffic, 90 % of the block slots filled instead of 70 % -- but a block then lives
+    // 8.9 us instead of 3.3: the waves spend their time in the tests, not in the round trips, once the CU is full; chain 57 us against 48.
+    // (Rounds 2 and 3: one block per group with a wave per tile row, 38.8 us against 32.4.)
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K1_TILE_CULL];
-    __shared__ uint32_t sCnt[5];
+    __shared__ uint32_t sCnt[8]; // [0..3] the waves' candidate counts, [4..7] "a NaN impact" per tile (cluster_tile: [4])
     float4* sLV = reinterpret_cast<float4*>(lds);                                                         // [CHUNK] candidate (view pos, radius)
-    uint32_t* sE = reinterpret_cast<uint32_t*>(lds + CHUNK * 16);                                         // [CHUNK] candidate light index | directional << 31
+    uint32_t* sE = reinterpret_cast<uint32_t*>(lds + CHUNK * 20 - CHUNK * 4);                             // [CHUNK] candidate light index | directional << 31
     uint32_t (*sIdxAll)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds + CHUNK * 20);                   // [4][CAND]
-    float (*sImpAll)[CAND] = reinterpret_cast<float (*)[CAND]>(lds + CHUNK * 20 + 4 * CAND * 4);          // [4][CAND], 16-byte aligned (CAND * 4 = 784)
+    float* sImpBlock = reinterpret_cast<float*>(lds + CHUNK * 20 + 4 * CAND * 4);                         // [CAND + 4] of block_select (16-byte aligned), or:
+    float (*sImpAll)[CAND] = reinterpret_cast<float (*)[CAND]>(lds + CHUNK * 20 + 4 * CAND * 4);          // [4][CAND] (overflowed groups: emit_list per wave)
     const float4* __restrict__ lightView = a.lightView;
-    const uint32_t* __restrict__ lightType = a.lightType;
     const int N = a.N, Tx = a.Tx, groupsX = a.groupsX;
-    // (a 2-D grid, (group column, tile row of the band): the index arithmetic has no division -- by a run-time divisor that is ~35 scalar
-    // instructions, 5 % of what a wave of this kernel issues.  Block order == tile-index order was what k1_pack's slots needed through round 3;
-    // with a slot per tile nothing depends on it any more.)
-    const int gx = (int)blockIdx.x, tyLocal = (int)blockIdx.y - a.headRows;
+    // (a 2-D grid, (group column, head rows + tile rows): no division by a run-time divisor)
+    const int gx = (int)blockIdx.x, pairRow = (int)blockIdx.y - a.headRows;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.dirFlag = 0u; // (k01_prepare of the NEXT cull sets it again if a light is directional; k1_group_lists_wide has read it)
-    if (!BRUTE && tyLocal < 0) {
+    if (pairRow < 0) {
         // HEAD ROWS: the tiles of the light clusters k1_group_lists listed, sixteen blocks per group, at the front of the grid (they are the
         // launch's longest blocks); the blocks at their regular positions further down leave at once.
         const uint32_t hb = blockIdx.y * (uint32_t)groupsX + blockIdx.x;
@@ -1062,91 +1153,89 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
         return;
     }
     PROF_T(0);
-    const int g = (tyLocal / GROUP) * groupsX + gx;
-    // (the wave index as a scalar: the tile's frustum -- the same 64 bytes for all lanes -- then arrives by scalar loads instead of four vector
-    // loads that occupy the CU's vector-memory pipeline for 64 lanes' worth of address processing each)
+    const int row0 = pairRow, nrows = 1; // (the loop below takes `nrows` consecutive tile rows of one group: 1 -- see the note on two rows above)
+    const int g = (row0 / GROUP) * groupsX + gx;
+    // (the wave index as a scalar: a tile's frustum -- the same 64 bytes for all lanes -- then arrives by scalar loads)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     uint32_t* sIdx = sIdxAll[wave];
-    float* sImp = sImpAll[wave];
 
+    // The kernel is bound by the latency of its dependent loads, so the first chunk's list entries are requested together with the group's count,
+    // not after it: slots past the count hold stale entries of an earlier frame or nothing at all, hence the clamp to N - 1.
+    const uint32_t* __restrict__ list = a.groupList + (size_t)g * CAPG;
     uint32_t e[CHUNK / 256];
-    uint32_t gn = 0u;
-    if (!BRUTE) {
-        // The kernel is bound by the latency of its dependent loads (a block has ~1 us of work behind 2-3 round trips to
-        // L2 / HBM), so the first chunk's list entries are requested together with the group's count, not after it:
-        // slots past the count hold stale entries of an earlier frame or nothing at all, hence the clamp to N - 1.
-        const uint32_t* __restrict__ list = a.groupList + (size_t)g * CAPG;
-        // (the first 256 slots ahead of the count, the second 256 only for a group that has them: 1 KB per block that three groups in four
-        // never look at -- 8 of the kernel's 25 MB)
-        e[0] = list[threadIdx.x];
-        gn = a.groupCount[g];
-        if (a.headRows > 0 && (gn == GROUP_OVERFLOW_LISTED || (gn != GROUP_OVERFLOW && (gn & GROUP_LISTED)))) return; // a listed cluster: the head rows have it
-        gn = gn >= GROUP_OVERFLOW_LISTED ? GROUP_OVERFLOW : (gn & ~GROUP_LISTED);
+    e[0] = list[threadIdx.x];
+    uint32_t gn = a.groupCount[g];
+    if (a.headRows > 0 && (gn == GROUP_OVERFLOW_LISTED || (gn != GROUP_OVERFLOW && (gn & GROUP_LISTED)))) return; // a listed cluster: the head rows have it
+    gn = gn >= GROUP_OVERFLOW_LISTED ? GROUP_OVERFLOW : (gn & ~GROUP_LISTED);
 #pragma unroll
-        for (int k = 1; k < CHUNK / 256; k++) e[k] = (gn != GROUP_OVERFLOW && gn > 256u * k) ? list[threadIdx.x + 256u * k] : 0u;
-    }
+    for (int k = 1; k < CHUNK / 256; k++) e[k] = (gn != GROUP_OVERFLOW && gn > 256u * k) ? list[threadIdx.x + 256u * k] : 0u;
 
     const int tx = gx * GROUP + wave;
     const bool active = tx < Tx;
-    const int bandTile = tyLocal * Tx + tx;
-    TileCtx t;
-    if (active) load_tile_ctx(a.tileInfo, bandTile, t);
-    uint32_t count = 0;
-    if (BRUTE) {
-        if (active) {
-            for (int base = 0; base < N && count < CAND; base += 64) {
-                const int j = base + lane;
-                test_candidates(t, lightView, lightType, j < N, (uint32_t)j, count, sIdx);
+    for (int r = 0; r < nrows; r++) {
+        const int tyLocal = row0 + r, bandTile = tyLocal * Tx + tx;
+        TileCtx t;
+        if (active) load_tile_ctx(a.tileInfo, bandTile, t);
+        uint32_t count = 0;
+        if (gn != GROUP_OVERFLOW) {
+            for (uint32_t c0 = 0; c0 < gn; c0 += CHUNK) {
+                const uint32_t cn = min((uint32_t)CHUNK, gn - c0);
+                if (r == 0 || gn > (uint32_t)CHUNK) { // (a group of one chunk -- all but the odd unlisted cluster -- is staged once, for both rows)
+                    if (c0 || r) {
+                        __syncthreads(); // every wave is done with what is staged
+#pragma unroll
+                        for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; e[k] = i < cn ? list[c0 + i] : 0u; }
+                    }
+                    float4 lv[CHUNK / 256];
+                    // (only the slots below the count: a gather through a stale entry of an earlier frame is a random 16-byte request for nothing)
+#pragma unroll
+                    for (int k = 0; k < CHUNK / 256; k++) {
+                        lv[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (threadIdx.x + 256u * k < cn) lv[k] = lightView[min(e[k] & 0x7FFFFFFFu, (uint32_t)(N - 1))];
+                    }
+#pragma unroll
+                    for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; if (i < cn) { sE[i] = e[k]; sLV[i] = lv[k]; } }
+                    __syncthreads();
+                }
+                if (active) test_staged(t, cn, sE, sLV, count, sIdx);
             }
+        } else if (active) {
+            // overflowed group (very dense region / lights around the eye): every tile walks its own two masks
+            walk_tile_masks(t, a, gx, tyLocal, reinterpret_cast<uint32_t*>(sLV) + wave * QCAP, count, sIdx); // sLV is unused on this path
         }
-    } else if (gn != GROUP_OVERFLOW) {
-        const uint32_t* __restrict__ list = a.groupList + (size_t)g * CAPG;
-        for (uint32_t c0 = 0; c0 < gn; c0 += CHUNK) {
-            const uint32_t cn = min((uint32_t)CHUNK, gn - c0);
-            if (c0) {
-                __syncthreads(); // every wave is done with the previous chunk
-#pragma unroll
-                for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; e[k] = i < cn ? list[c0 + i] : 0u; }
-            }
-            float4 lv[CHUNK / 256];
-            // (only the slots below the count: the count arrives with the entries, and a gather through a stale entry of an earlier frame is a
-            // random 16-byte request for nothing -- two thirds of the 512 slots on the 4K frame.  Traffic, not time: 48.1 us either way.)
-#pragma unroll
-            for (int k = 0; k < CHUNK / 256; k++) {
-                lv[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (threadIdx.x + 256u * k < cn) lv[k] = lightView[min(e[k] & 0x7FFFFFFFu, (uint32_t)(N - 1))];
-            }
-            // (round 3 also measured a ROW FILTER here -- drop what lies entirely above / below the block's tile row before its four tiles test
-            // it, halving the test steps: 49.2 us for the chain with and without it, the kernel is bound by its dependent round trips -- removed)
-#pragma unroll
-            for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; if (i < cn) { sE[i] = e[k]; sLV[i] = lv[k]; } }
-            __syncthreads();
-            if (active) test_staged(t, cn, sE, sLV, count, sIdx);
+        if (r == 0) PROF_T(1);
+        const uint32_t n = count < CAND ? count : CAND; // (0 for a wave beyond the last tile column)
+        if (active && lane == 0) publish_tile(a, bandTile, n < KEEP ? n : KEEP);
+        if (gn == GROUP_OVERFLOW) { // (rare, and its staging area is the waves' queues: every wave selects for itself)
+            if (active) emit_list(t, n, sIdx, sImpAll[wave], lightView, a.tileLists + (size_t)bandTile * KEEP);
+            continue;
         }
-    } else if (active) {
-        // overflowed group (very dense region / lights around the eye): every tile walks its own two masks
-        walk_tile_masks(t, a, gx, tyLocal, reinterpret_cast<uint32_t*>(sLV) + wave * QCAP, count, sIdx); // sLV is unused on this path
+        // short lists leave at once (:235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]); the others wait for the block
+        if (lane == 0) sCnt[wave] = n;
+        if (threadIdx.x < 4) sCnt[4 + threadIdx.x] = 0u; // block_select's "a NaN impact", one flag per tile
+        if (active && n <= KEEP) {
+            WAVE_SYNC();
+            uint32_t* __restrict__ out = a.tileLists + (size_t)bandTile * KEEP;
+            for (uint32_t i = lane; i < n; i += 64) out[i] = sIdx[n - 1 - i] & 0x7FFFFFFFu;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint32_t nw = sCnt[w];
+            if (nw > (uint32_t)KEEP) block_select(a, tyLocal * Tx + gx * GROUP + w, nw, sIdxAll[w], sImpBlock, sCnt + 4 + w); // (block-uniform)
+        }
     }
-    PROF_T(1);
-    if (!active) return;
-    const uint32_t n = count < CAND ? count : CAND;
-    const uint32_t num = n < KEEP ? n : KEEP;
-    if (lane == 0) publish_tile(a, tyLocal, bandTile, num);
-    PROF_T(2);
-    // the tile's list into the tile's own slot: k1_pack moves it to its canonical place, the shade can read it where it is
-    emit_list(t, n, sIdx, sImp, lightView, a.tileLists + (size_t)bandTile * KEEP);
     PROF_T(3);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // K1d: canonical offsets (Appendix A step 6) and compaction.  Block p owns the tiles [64 p, 64 p + 64) of the band (tile-index order).  Its
-// base is the sum of the list lengths of all tiles before them: the totals of the tile rows in front of its first row (k1_tile_cull's
-// atomics) plus the lengths of that row's earlier tiles -- a few hundred words read and added up by the block itself: no scan kernel, no
-// look-back chain.  One wave turns the 64 lengths into offsets (lightsGrid); the 64 lists are gathered from their slots into LDS, back to back,
+// base is the sum of the list lengths of all tiles before them, read (the lengths as bytes: <= 32 KB at 4K, L2-resident) and added up by the block itself:
+// no scan kernel, no look-back chain, no atomics.  One wave turns the 64 lengths into offsets (lightsGrid); the 64 lists are gathered from their slots into LDS, back to back,
 // and leave for culledLights as one contiguous run.
 // ------------------------------------------------------------------------------------------------------------
 struct PackArgs {
-    const uint32_t* rowTotals; const uint32_t* rowCls; const uint32_t* tileNum; const uint32_t* tileLists;
+    const uint32_t* tileNum; const uint8_t* tileNum8; const uint32_t* tileLists;
     SailorLightsGrid* grid; uint32_t* culled; uint32_t* tileOrder;
     int Tx, bandRows, bandTiles, classes;
     uint32_t capacity;
@@ -1164,11 +1253,30 @@ __global__ __launch_bounds__(256) void k1_pack(const PackArgs a)
     const int tile = t0 + lane;
     const bool have = wave == 0 && tile < a.bandTiles;
     if (have) num = a.tileNum[tile];
-    // entries (and class counts) of every tile before t0
-    const int row0 = t0 / a.Tx, rowTile0 = row0 * a.Tx;
+    // entries (and class counts) of every tile before t0 (a multiple of 64): the lengths as BYTES, sixteen tiles per 16-byte load, four loads in flight
+    // per thread -- at most 32 KB at 4K, L2-resident (v_sad_u8 adds the four bytes of a word to the accumulator)
     uint32_t acc = 0u, accC = 0u;
-    for (int r = threadIdx.x; r < row0; r += 256) { acc += a.rowTotals[r]; if (a.classes) accC += a.rowCls[r]; }
-    for (int i = rowTile0 + (int)threadIdx.x; i < t0; i += 256) { const uint32_t v = a.tileNum[i]; acc += v; accC += tile_class_word(v); }
+    {
+        const uint4* __restrict__ v4 = reinterpret_cast<const uint4*>(a.tileNum8);
+        const int count4 = t0 / 16;
+        for (int i = threadIdx.x; i < count4; i += 1024) {
+            uint4 q[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[k] = i + 256 * k < count4 ? v4[i + 256 * k] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t w[4] = { q[k].x, q[k].y, q[k].z, q[k].w };
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    acc = __builtin_amdgcn_sad_u8(w[c], 0u, acc);
+                    if (a.classes) {
+#pragma unroll
+                        for (int b = 0; b < 4; b++) accC += tile_class_word((w[c] >> (8 * b)) & 0xFFu);
+                    }
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { acc += (uint32_t)__shfl_xor((int)acc, d, 64); accC += (uint32_t)__shfl_xor((int)accC, d, 64); }
     if (lane == 0) { sPart[wave] = acc; sPartC[wave] = accC; }
@@ -1277,8 +1385,7 @@ static bool layout_has_hint(const CullLayout& L) { return L.bandRows < L.Ty && L
 static int launch_pack(SailorHipContext* ctx, const CullLayout& L, char* ws, SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity)
 {
     PackArgs ka;
-    ka.rowTotals = (const uint32_t*)(ws + L.offRowTotals); ka.rowCls = (const uint32_t*)(ws + L.offRowCls);
-    ka.tileNum = (const uint32_t*)(ws + L.offTileNum); ka.tileLists = (const uint32_t*)(ws + L.offTileLists);
+    ka.tileNum = (const uint32_t*)(ws + L.offTileNum); ka.tileNum8 = (const uint8_t*)(ws + L.offTileNum8); ka.tileLists = (const uint32_t*)(ws + L.offTileLists);
     ka.grid = dLightsGrid; ka.culled = dCulledLights; ka.tileOrder = (uint32_t*)(ws + L.offTileOrder);
     ka.Tx = L.Tx; ka.bandRows = L.bandRows; ka.bandTiles = L.bandTiles;
     // The hint pays for itself on split frames (a band's shade launch is bounded by its longest tile); on the whole frame it measured nothing.
@@ -1324,6 +1431,7 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     const int W = pc->viewportSize[0], H = pc->viewportSize[1], N = pc->lightsNum;
     if (W <= 0 || H <= 0 || N < 0 || (N > 0 && !dLights && !dPreparedLights)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (dPreparedLights && (preparedCapacity < N || ((uintptr_t)dPreparedLights & 15))) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if ((flags & SAILOR_CULL_PREPARE_LIGHTS) && (!dPreparedLights || (N > 0 && (!dLights || ((uintptr_t)dLights & 15))))) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (N > 0x3FFFFFFF) return SAILOR_HIP_ERR_UNSUPPORTED; // bit 31 of a candidate entry carries the "directional" flag
     // Appendix A: the depth extent (push constants) and the window viewport (frame UBO) must agree
     if (frame->viewportSize[0] != W || frame->viewportSize[1] != H) return SAILOR_HIP_ERR_UNSUPPORTED;
@@ -1359,10 +1467,13 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     memcpy(pa.invProj.m, frame->invProjection, 64);
     pa.lights = dLights; pa.depth = dLinearDepth;
     pa.soaPosRadius = nullptr; pa.soaType = nullptr;
+    pa.prepPosRadius = nullptr; pa.prepType = nullptr; pa.prepStaged = nullptr;
     if (dPreparedLights) {
-        const void *pr = nullptr, *ty = nullptr;
-        sailor_hip_prepared_lights_views(preparedCapacity, dPreparedLights, &pr, &ty, nullptr);
-        pa.soaPosRadius = (const float4*)pr; pa.soaType = (const uint32_t*)ty;
+        const void *pr = nullptr, *ty = nullptr, *st = nullptr;
+        sailor_hip_prepared_lights_views(preparedCapacity, dPreparedLights, &pr, &ty, &st);
+        if (flags & SAILOR_CULL_PREPARE_LIGHTS) { // the views are this call's OUTPUT (for the shade and for later culls); the light role reads the records
+            pa.prepPosRadius = (float4*)pr; pa.prepType = (uint32_t*)ty; pa.prepStaged = (float4*)st;
+        } else { pa.soaPosRadius = (const float4*)pr; pa.soaType = (const uint32_t*)ty; }
     }
     pa.lightView = (float4*)(ws + L.offLightView); pa.lightType = (uint32_t*)(ws + L.offLightType); pa.tileInfo = (float4*)(ws + L.offTileInfo);
     pa.masks = (unsigned long long*)(ws + L.offMasks); pa.dirWords = (unsigned long long*)(ws + L.offDirWords);
@@ -1388,20 +1499,18 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     pa.planeMargin = 1e-3f;
     pa.dirFlag = (uint32_t*)(ws + L.offDirFlag);
     pa.heavy = (uint32_t*)(ws + L.offHeavy);
-    pa.rowTotals = (uint32_t*)(ws + L.offRowTotals); pa.rowCls = (uint32_t*)(ws + L.offRowCls);
     sailor_launch(ctx, k01_prepare, dim3(pa.lightRoleBlocks + pa.frustumBlocks + pa.setupBlocks), dim3(256), pa);
     SAILOR_CHECK_LAUNCH(ctx, "k01_prepare");
 
     CullArgs ca;
     ca.lightView = pa.lightView; ca.lightType = pa.lightType; ca.tileInfo = pa.tileInfo; ca.masks = pa.masks;
     ca.groupCount = (const uint32_t*)(ws + L.offGroupCount); ca.groupList = (const uint32_t*)(ws + L.offGroupList);
-    ca.rowTotals = pa.rowTotals; ca.rowCls = pa.rowCls; ca.tileNum = (uint32_t*)(ws + L.offTileNum); ca.tileLists = (uint32_t*)(ws + L.offTileLists);
+    ca.tileNum = (uint32_t*)(ws + L.offTileNum); ca.tileNum8 = (uint8_t*)(ws + L.offTileNum8); ca.tileLists = (uint32_t*)(ws + L.offTileLists);
     ca.dirFlag = pa.dirFlag;
     ca.N = N; ca.words = L.words; ca.Tx = L.Tx; ca.groupsX = L.groupsX; ca.bandRows = L.bandRows;
-    ca.classes = layout_has_hint(L) ? 1 : 0; // (the tile-order hint: see launch_pack)
     ca.heavy = (const uint32_t*)(ws + L.offHeavy); ca.headRows = 0;
     if (brute) {
-        sailor_launch(ctx, k1_tile_cull<true>, dim3(L.groupsX, L.bandRows), dim3(256), ca);
+        sailor_launch(ctx, k1_tile_cull_brute, dim3(L.groupsX, L.bandRows), dim3(256), ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull<brute>");
     } else {
         if (L.words >= 4096 && (L.words & 1) == 0)
@@ -1420,7 +1529,7 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
             ca.headRows = (16 * HEAVY_MAX + L.groupsX - 1) / L.groupsX; // grid rows for the listed clusters' tiles (a block each), in front of the tile rows
         }
         SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
-        sailor_launch(ctx, k1_tile_cull<false>, dim3(L.groupsX, ca.headRows + L.bandRows), dim3(256), ca);
+        sailor_launch(ctx, k1_tile_cull, dim3(L.groupsX, ca.headRows + L.bandRows), dim3(256), ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
     }
     if (flags & SAILOR_CULL_DEFER_PACK) return SAILOR_HIP_OK; // the caller records sailor_hip_light_cull_pack where it wants it (another stream, beside the shade)

@@ -42,14 +42,7 @@
 SHADE_ENTRY(k2_shade, FORCE_64_VGPRS, false, false, false)
 // (the K3 kernels: 64 registers like the others since the shadow look-ups run before the view / material terms -- "K3 first" in shade_body.h; it
 // was 80 = six waves per SIMD.  The pin matters: unpinned, the prepared twins come out at 116-134.)
-#ifndef CSM_WAVES
-#define CSM_WAVES 8
-#endif
-#ifdef CSM_NO_PIN
-#define CSM_PIN
-#else
-#define CSM_PIN __attribute__((amdgpu_waves_per_eu(CSM_WAVES, CSM_WAVES)))
-#endif
+#define CSM_PIN __attribute__((amdgpu_waves_per_eu(8, 8)))
 #define FIVE_WAVES __attribute__((amdgpu_waves_per_eu(5, 5))) // (K3 + ambient: 88-91 registers by itself; its prepared twin 134 unpinned)
 SHADE_ENTRY(k2_shade_csm, CSM_PIN, true, false, false)
 SHADE_ENTRY(k2_shade_ibl, , false, true, false)

@@ -139,7 +139,7 @@ class ForwardPlus:
 
     # -- K0 + K1 --------------------------------------------------------------------------------------------------
     def cull(self, frame: UboFrameData, lights: torch.Tensor, lights_num: int, depth: torch.Tensor, flags: int = _lib.CULL_DEFAULT,
-             ctx: "HipContext | None" = None, prepared: "PreparedLights | None" = None, defer_pack: bool = False):
+             ctx: "HipContext | None" = None, prepared: "PreparedLights | None" = None, defer_pack: bool = False, prepare_lights: bool = False):
         """lights: uint8/any tensor holding lights_num 112-byte records; depth: float32 [band rows, W].
         ctx: record on another context's stream (frames in flight: next frame's cull beside this frame's shade).
         prepared: the lights' prepared views (the kernel then streams 20 bytes per light instead of the 112-byte records)."""
@@ -149,6 +149,9 @@ class ForwardPlus:
         flags |= _ENV_CULL_FLAGS   # (diagnostics)
         if defer_pack:             # the canonical buffers are written by pack(), wherever the caller records it
             flags |= _lib.CULL_DEFER_PACK
+        if prepare_lights:         # every light dirty: the prepared views of all lights_num lights are (re)derived inside this cull
+            assert prepared is not None
+            flags |= _lib.CULL_PREPARE_LIGHTS
         pc = host.push_constants(frame, self.W, self.H, lights_num)
         ctx = ctx or self.ctx
         lib = ctx._lib

@@ -35,6 +35,8 @@ HipGraphicsDriver::HipGraphicsDriver(int deviceOrdinal, void* stream, bool ownSt
 {
     m_status = sailor_hip_context_create(deviceOrdinal, stream, ownStream ? SAILOR_CTX_OWN_STREAM : 0u, &m_ctx);
     if (m_ctx) m_ctxOwner = std::shared_ptr<SailorHipContext>(m_ctx, [](SailorHipContext* c) { sailor_hip_context_destroy(c); });
+    // the second queue (k1_pack beside the shade); without it the cull packs inline as in rounds 1-3
+    if (m_ctx && sailor_hip_context_create(deviceOrdinal, nullptr, SAILOR_CTX_OWN_STREAM, &m_ctxAux) != SAILOR_HIP_OK) m_ctxAux = nullptr;
 }
 
 HipGraphicsDriver::~HipGraphicsDriver()
@@ -42,12 +44,17 @@ HipGraphicsDriver::~HipGraphicsDriver()
     m_cullWorkspace.Clear();
     m_meshCullWorkspace.Clear();
     m_exchangeWorkspace.Clear();
+    if (m_ctxAux) { sailor_hip_context_synchronize(m_ctxAux); sailor_hip_context_destroy(m_ctxAux); m_ctxAux = nullptr; }
     if (m_ctx) sailor_hip_context_synchronize(m_ctx);
     m_ctx = nullptr;
     m_ctxOwner.reset(); // the context itself goes with the last buffer that refers to it
 }
 
-void HipGraphicsDriver::WaitIdle() { if (m_ctx) sailor_hip_context_synchronize(m_ctx); }
+void HipGraphicsDriver::WaitIdle()
+{
+    if (m_ctxAux) sailor_hip_context_synchronize(m_ctxAux);
+    if (m_ctx) sailor_hip_context_synchronize(m_ctx);
+}
 
 RHICommandListPtr HipGraphicsDriver::CreateCommandList(bool) { return RHICommandListPtr::Make(); }
 
@@ -161,6 +168,9 @@ void HipGraphicsDriver::SubmitCommandList(RHICommandListPtr commandList)
         if (st != SAILOR_HIP_OK) { m_lastDispatchStatus = st; fprintf(stderr, "[HIP driver] command failed: %s (%s)\n", sailor_hip_status_string(st), sailor_hip_context_last_error(m_ctx)); }
     }
     commandList->m_hip.m_commands.clear();
+    // a cull of this submit left its compaction on the second queue: what is recorded from here on (other nodes, the exchange, the next frame's
+    // cull into the same workspace) comes after it
+    if (m_packPending) { sailor_hip_context_wait_for(m_ctx, m_ctxAux); m_packPending = false; }
 }
 
 RHIMaterialPtr HipGraphicsDriver::CreateMaterial(RHIShaderPtr shader) { return RHIMaterialPtr::Make(std::move(shader)); }
@@ -420,11 +430,26 @@ int HipGraphicsDriver::RecordLightCulling(const TVector<RHIShaderBindingSetPtr>&
     m_cullW = pc.viewportSize[0]; m_cullH = pc.viewportSize[1]; m_cullLights = pc.lightsNum; m_cullOrderValid = true; // the shade of this frame may use the order hint
     auto lightB = bindings[0]->Find("light");
     const bool prepared = lightB && lightB->m_hipPreparedLights && lightB->m_hipPreparedCapacity >= pc.lightsNum;
-    return sailor_hip_light_cull_prepared(m_ctx, &frame, &pc, (const SailorLightShaderData*)buffer_of(bindings[0], "light"),
-                                          (const float*)depthB->m_textures[0]->m_buffer->m_hip.m_devicePtr,
-                                          (SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (uint32_t*)buffer_of(bindings[1], "culledLights"),
-                                          culledB->m_buffer->m_size / 4, m_cullWorkspace->m_hip.m_devicePtr, m_cullWorkspace->m_size, &band, SAILOR_CULL_DEFAULT,
-                                          prepared ? lightB->m_hipPreparedLights->m_hip.m_devicePtr : nullptr, prepared ? lightB->m_hipPreparedCapacity : 0);
+    SailorLightsGrid* grid = (SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid");
+    uint32_t* culled = (uint32_t*)buffer_of(bindings[1], "culledLights");
+    if (m_packPending) { sailor_hip_context_wait_for(m_ctx, m_ctxAux); m_packPending = false; } // (a second cull in one submit: its workspace is the one the pending pack reads)
+    const bool defer = m_ctxAux != nullptr;
+    const int st = sailor_hip_light_cull_prepared(m_ctx, &frame, &pc, (const SailorLightShaderData*)buffer_of(bindings[0], "light"),
+                                                  (const float*)depthB->m_textures[0]->m_buffer->m_hip.m_devicePtr, grid, culled,
+                                                  culledB->m_buffer->m_size / 4, m_cullWorkspace->m_hip.m_devicePtr, m_cullWorkspace->m_size, &band,
+                                                  defer ? SAILOR_CULL_DEFER_PACK : SAILOR_CULL_DEFAULT,
+                                                  prepared ? lightB->m_hipPreparedLights->m_hip.m_devicePtr : nullptr, prepared ? lightB->m_hipPreparedCapacity : 0);
+    m_ownGrid = nullptr; m_ownCulled = nullptr;
+    if (st != SAILOR_HIP_OK) return st;
+    m_ownGrid = grid; m_ownCulled = culled; // a shade handed these two SSBOs reads this cull's per-tile lists
+    if (!defer) return st;
+    // the node's two SSBOs in the reference's layout, bit for bit, written on the second queue behind the cull's last kernel
+    int st2 = sailor_hip_context_wait_for(m_ctxAux, m_ctx);
+    if (st2 == SAILOR_HIP_OK)
+        st2 = sailor_hip_light_cull_pack(m_ctxAux, pc.viewportSize[0], pc.viewportSize[1], pc.lightsNum, &band, m_cullWorkspace->m_hip.m_devicePtr, grid, culled,
+                                         culledB->m_buffer->m_size / 4);
+    m_packPending = true;
+    return st2;
 }
 
 int HipGraphicsDriver::SetFrameSplit(int rank, int worldSize, void* ncclComm)
@@ -443,6 +468,7 @@ int HipGraphicsDriver::ExchangeLightLists(RHIBufferPtr bandGrid, RHIBufferPtr ba
         sailor_hip_num_tiles(m_splitW, m_splitH, &Tx, &Ty);
         if (globalGrid->m_size < (size_t)Tx * Ty * sizeof(SailorLightsGrid) || globalCulled->m_size < 4) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     }
+    if (m_packPending) { sailor_hip_context_wait_for(m_ctx, m_ctxAux); m_packPending = false; } // the band's canonical buffers are the pack's output
     const size_t need = sailor_hip_exchange_workspace_size(m_splitW, m_splitH, m_worldSize);
     if (!m_exchangeWorkspace || m_exchangeWorkspace->m_size < need) m_exchangeWorkspace = CreateBuffer(need);
     if (!m_exchangeWorkspace) return SAILOR_HIP_ERR_OUT_OF_MEMORY;
@@ -503,11 +529,27 @@ int HipGraphicsDriver::RecordShade(const TVector<RHIShaderBindingSetPtr>& bindin
     if (surfaceB->m_buffer->m_size < planeStride * 48) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     auto lightB = bindings[1]->Find("light");
     const bool prepared = lightB && lightB->m_hipPreparedLights && lightB->m_hipPreparedCapacity >= lightsNum;
+    const uint32_t* order = m_cullOrderValid ? sailor_hip_light_cull_tile_order(m_cullW, m_cullH, m_cullLights, band, m_cullWorkspace->m_hip.m_devicePtr) : nullptr;
+    const SailorLightsGrid* grid = (const SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid");
+    const uint32_t* culled = (const uint32_t*)buffer_of(bindings[1], "culledLights");
+    // The lists of this frame's own LightCulling node (the usual graph: LightCullingNode.cpp:69-70 registers its SSBOs into the lights set that
+    // RenderScene binds): read them where the cull left them -- the same entries in the same order as the two SSBOs hold, without waiting for the
+    // compaction that fills those.  Lists from anywhere else (SSBOs the caller filled): through lightsGrid / culledLights, behind a pending pack.
+    const uint32_t *tileNum = nullptr, *tileLists = nullptr;
+    const bool own = m_cullWorkspace && grid && culled && grid == m_ownGrid && culled == m_ownCulled && m_cullW == W && m_cullH == H &&
+                     sailor_hip_light_cull_tile_lists(m_cullW, m_cullH, m_cullLights, band, m_cullWorkspace->m_hip.m_devicePtr, &tileNum, &tileLists) == SAILOR_HIP_OK;
+    if (own) {
+        // (the tile-order hint is written by the pack step: a band's split blocks need it, so on a split frame the shade comes behind the pack)
+        if (order && m_packPending) { sailor_hip_context_wait_for(m_ctx, m_ctxAux); m_packPending = false; }
+        return sailor_hip_shade_tile_lists(m_ctx, &frame, (const float*)surfaceB->m_buffer->m_hip.m_devicePtr, planeStride,
+                                           (const SailorLightShaderData*)buffer_of(bindings[1], "light"), lightsNum, tileNum, tileLists,
+                                           hasCsm ? &csm : nullptr, hasIbl ? &ibl : nullptr, (float*)buffer_of(bindings[2], "radiance"), band, order,
+                                           prepared ? lightB->m_hipPreparedLights->m_hip.m_devicePtr : nullptr, prepared ? lightB->m_hipPreparedCapacity : 0);
+    }
+    if (m_packPending) { sailor_hip_context_wait_for(m_ctx, m_ctxAux); m_packPending = false; }
     return sailor_hip_shade_prepared(m_ctx, &frame, (const float*)surfaceB->m_buffer->m_hip.m_devicePtr, planeStride,
-                                     (const SailorLightShaderData*)buffer_of(bindings[1], "light"), lightsNum,
-                                     (const SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid"), (const uint32_t*)buffer_of(bindings[1], "culledLights"),
-                                     hasCsm ? &csm : nullptr, hasIbl ? &ibl : nullptr, (float*)buffer_of(bindings[2], "radiance"), band,
-                                     m_cullOrderValid ? sailor_hip_light_cull_tile_order(m_cullW, m_cullH, m_cullLights, band, m_cullWorkspace->m_hip.m_devicePtr) : nullptr,
+                                     (const SailorLightShaderData*)buffer_of(bindings[1], "light"), lightsNum, grid, culled,
+                                     hasCsm ? &csm : nullptr, hasIbl ? &ibl : nullptr, (float*)buffer_of(bindings[2], "radiance"), band, order,
                                      prepared ? lightB->m_hipPreparedLights->m_hip.m_devicePtr : nullptr, prepared ? lightB->m_hipPreparedCapacity : 0);
 }
 

@@ -25,19 +25,46 @@ fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert fn(buf.ctypes.data, buf.nbytes) == 0
 Tx, Ty = host.num_tiles(W, H)
 groupsX = (Tx + 3) // 4
-nb = groupsX * (band.tileRowEnd - band.tileRowBegin)
+rows = band.tileRowEnd - band.tileRowBegin
+head_rows = (16 * 96 + groupsX - 1) // groupsX      # light_cull.hip: 16 * HEAVY_MAX head blocks (a block per cluster tile) in front of the tile rows
+nh = head_rows * groupsX
+nb = nh + groupsX * rows
+assert nb <= 65536
 p = buf[:nb].astype(np.int64)
-t0 = p[:, 0][p[:, 0] > 0].min()
-dur = (p[:, 3] - p[:, 0]) / 100.0   # s_memtime: 100 MHz -> us
-print("blocks", nb, "kernel span us", (p[:, 3].max() - t0) / 100.0)
-print("block duration us: mean %.2f median %.2f p99 %.2f max %.2f" % (dur.mean(), np.median(dur), np.percentile(dur, 99), dur.max()))
-order = np.argsort(-(p[:, 3] - t0))[:12]
+ran = p[:, 3] > 0
+t0 = p[ran, 0].min()
+us = lambda v: (v - t0) / 100.0   # s_memrealtime: 100 MHz
+dur = np.where(ran, (p[:, 3] - p[:, 0]) / 100.0, 0.0)
+print("grid blocks", nb, "head blocks that ran (cluster tiles)", int(ran[:nh].sum()), "ordinary blocks that ran", int(ran[nh:].sum()), "kernel span us %.2f" % us(p[ran, 3].max()))
+for name, sel in (("cluster tile", np.arange(nh)[ran[:nh]]), ("ordinary", nh + np.arange(nb - nh)[ran[nh:]])):
+    if len(sel) == 0:
+        continue
+    d = dur[sel]
+    print("%-12s blocks: n %5d  duration us mean %.2f median %.2f p90 %.2f p99 %.2f max %.2f;  first start %.2f last end %.2f" %
+          (name, len(sel), d.mean(), np.median(d), np.percentile(d, 90), np.percentile(d, 99), d.max(), us(p[sel, 0].min()), us(p[sel, 3].max())))
+    lat = (p[sel, 1] - p[sel, 0]) / 100.0
+    print("             start -> tests done: mean %.2f p90 %.2f max %.2f" % (lat.mean(), np.percentile(lat, 90), lat.max()))
+order = np.argsort(-np.where(ran, p[:, 3], 0))[:10]
+print("last to end:")
 for b in order:
-    print("block %5d (tile row %3d, group col %2d): start %6.2f  test-done %6.2f  synced %6.2f  end %6.2f us" % (b, b // groupsX, b % groupsX, (p[b, 0] - t0) / 100.0, (p[b, 1] - t0) / 100.0, (p[b, 2] - t0) / 100.0, (p[b, 3] - t0) / 100.0))
-print("longest blocks:")
-for b in np.argsort(-dur)[:6]:
-    print("block %5d (tile row %3d, group col %2d): start %6.2f  test-done %6.2f  synced %6.2f  end %6.2f" % (b, b // groupsX, b % groupsX, (p[b, 0] - t0) / 100.0, (p[b, 1] - t0) / 100.0, (p[b, 2] - t0) / 100.0, (p[b, 3] - t0) / 100.0))
-starts = np.sort((p[:, 0] - t0) / 100.0)
-print("block start times (units of 100 ticks): p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(starts, [10, 50, 90, 100])))
-g, idx = fp.lists_to_host()
-print("lists of the latest block's tiles:", g[order[0] * 4:order[0] * 4 + 4, 1] if nb * 4 <= len(g) + 3 else "")
+    kind = "cluster tile" if b < nh else "ordinary (tile row %3d, group col %2d)" % ((b - nh) // groupsX, (b - nh) % groupsX)
+    print("  block %5d %s: start %6.2f end %6.2f us" % (b, kind, us(p[b, 0]), us(p[b, 3])))
+starts = np.sort(us(p[ran, 0]))
+print("block start times us: p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(starts, [10, 50, 90, 100])))
+
+# per XCD (HW_REG_XCC_ID as read by the block itself; s_memtime is comparable inside one XCD): the timeline of the launch
+print("per XCD: blocks, span (us), mean resident blocks per CU, time by which 50 / 90 / 99 / 100 %% of the blocks have ended, kind of the last")
+for x in range(8):
+    sel = np.arange(nb)[(p[:, 2] == x) & ran]
+    if len(sel) == 0:
+        continue
+    s0 = p[sel, 0].min()
+    ends = np.sort(p[sel, 3] - s0) / 100.0
+    span = ends[-1]
+    conc = ((p[sel, 3] - p[sel, 0]).sum() / 100.0) / span / 32.0
+    last = sel[np.argmax(p[sel, 3])]
+    # resident blocks over time: sample at 10 points
+    ts = np.linspace(0, span, 11)[1:-1]
+    res = [int((((p[sel, 0] - s0) / 100.0 <= t) & ((p[sel, 3] - s0) / 100.0 > t)).sum()) for t in ts]
+    print("  xcd %d: %5d blocks, span %7.1f, resident/CU %.2f, ended 50%% %6.1f 90%% %6.1f 99%% %6.1f; last = %s; resident blocks at 10..90%% of the span: %s" %
+          (x, len(sel), span, conc, ends[len(ends) // 2], ends[int(len(ends) * 0.9)], ends[int(len(ends) * 0.99)], "cluster tile" if last < nh else "ordinary", res))

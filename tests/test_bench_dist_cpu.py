@@ -98,8 +98,10 @@ class _ForwardPlus:
     def pack(self, ctx=None):
         assert self.deferred, "a pack follows a cull recorded with defer_pack"
 
-    def cull(self, frame, lights, lights_num, depth, flags=0, ctx=None, prepared=None, defer_pack=False):
+    def cull(self, frame, lights, lights_num, depth, flags=0, ctx=None, prepared=None, defer_pack=False, prepare_lights=False):
         self.deferred = defer_pack
+        if prepare_lights:
+            self.prepared.prepare(0, lights_num)
         from oracle import oracle
         assert tuple(depth.shape) == (self.band.fbRowCount, self.W)
         g, idx, _ = oracle.light_cull(frame, self.W, self.H, lights[:lights_num], self._full(depth.numpy()), tile_rows=(self.band.tileRowBegin, self.band.tileRowEnd))

@@ -116,3 +116,36 @@ def test_prepared_path_on_the_4k_frame(ctx):
     for x, y in zip(got, ref):
         np.testing.assert_array_equal(x, y)
     assert int(ref[1][0]) > 500_000
+
+
+@pytest.mark.parametrize("flags", [_lib.CULL_DEFAULT, _lib.CULL_INTERVAL_MASKS, _lib.CULL_BRUTE_FORCE])
+def test_preparation_folded_into_the_cull_writes_the_same_views_and_lists(ctx, flags):
+    """SAILOR_CULL_PREPARE_LIGHTS (dynamic lights: every record dirty every frame): the cull's per-light pass reads the 112-byte records and writes the
+    prepared views on the way.  The views are sailor_hip_prepare_lights' bit for bit, the lists are the same, and a shade from the views it wrote is the
+    shade from prepared lights -- for the plane-test masks, the interval masks (C5's form) and the brute-force walk."""
+    f = synth.make_frame("tiny", width=320, height=208, lights=synth.LightSetConfig(count=3000, spot_fraction=0.3, radius_scale=5.0, cluster_lights=600))
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    dev = upload_lights(f.lights, ctx.device)
+    ref = PreparedLights(ctx, dev, N, capacity=N + 5)
+    ctx.synchronize()
+    want = [t.cpu().numpy().copy() for t in ref.views()]
+    d = torch.from_numpy(f.depth).to(ctx.device)
+    s = torch.from_numpy(f.surface).to(ctx.device)
+    fp0 = ForwardPlus(ctx, W, H, N, prepared=ref)
+    fp0.cull(f.cam.frame, dev, N, d, flags)
+    g0, i0 = fp0.lists_to_host()
+    r0 = fp0.shade(f.cam.frame, s, dev, N).cpu().numpy().copy()
+    mine = PreparedLights(ctx, dev, 0, capacity=N + 5)      # nothing prepared: the buffer holds whatever the allocator left
+    mine.buffer.fill_(0x5A)
+    fp = ForwardPlus(ctx, W, H, N, prepared=mine)
+    fp.cull(f.cam.frame, dev, N, d, flags, prepare_lights=True)
+    g, i = fp.lists_to_host()
+    np.testing.assert_array_equal(g, g0)
+    np.testing.assert_array_equal(i, i0)
+    for a, b in zip((t.cpu().numpy() for t in mine.views()), want):
+        np.testing.assert_array_equal(a[:N].view(np.uint32), b[:N].view(np.uint32))
+    r = fp.shade(f.cam.frame, s, dev, N).cpu().numpy()
+    np.testing.assert_array_equal(r.view(np.uint32), r0.view(np.uint32))
+    og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth)
+    np.testing.assert_array_equal(g, og)
+    np.testing.assert_array_equal(i, oi[: 1 + int(oi[0])])

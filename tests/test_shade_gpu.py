@@ -161,17 +161,24 @@ def test_bands_shade_identically(ctx, world_size):
     np.testing.assert_array_equal(np.concatenate(parts, 0), whole)
 
 
-def test_sentinel_index_stops_the_light_loop(ctx):
-    """Standard.shader:430-433: an index of 0xFFFFFFFF ends the tile's loop."""
+@pytest.mark.parametrize("from_tile_lists", [False, True])
+def test_sentinel_index_stops_the_light_loop(ctx, from_tile_lists):
+    """Standard.shader:430-433: an index of 0xFFFFFFFF ends the tile's loop -- in culledLights (the reference's buffers) and likewise in the cull's
+    per-tile slot when the shade reads the lists there."""
     f = synth.make_frame("tiny")
     W, H = f.cam.width, f.cam.height
     got, fp = gpu_frame(ctx, f)
     g, idx = fp.lists_to_host()
     t = int(np.argmax(g[:, 1]))
     cut = int(g[t, 0]) + 2
-    culled = fp.culled.clone()
-    culled[cut] = -1
-    fp.culled = culled
+    if from_tile_lists:   # the third entry of tile t's 128-entry slot
+        at = fp.tile_lists - fp.workspace.data_ptr() + 4 * (128 * t + 2)
+        fp.workspace[at: at + 4] = 255
+    else:
+        culled = fp.culled.clone()
+        culled[cut] = -1
+        fp.culled = culled
+    fp.shade_from_tile_lists = from_tile_lists
     s = torch.from_numpy(f.surface).to(ctx.device)
     out = fp.shade(f.cam.frame, s, upload_lights(f.lights, ctx.device), len(f.lights), None).cpu().numpy()
     ref_idx = np.zeros(1 + len(g) * 128, np.uint32); ref_idx[: len(idx)] = idx; ref_idx[cut] = 0xFFFFFFFF
