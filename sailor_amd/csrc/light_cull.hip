@@ -939,6 +939,32 @@ __device__ __forceinline__ void publish_tile(const CullArgs& a, const int bandTi
     a.tileNum8[bandTile] = (uint8_t)num;
 }
 
+// The selection's rank of candidate k (ComputeLightCulling.shader:198-225: the partial bubble sort == rank under (impact ascending, candidate position
+// descending); rank < 128 stays): the number of candidates q with impact_q < impact_k, or impact_q == impact_k and q > k.  Impacts are non-negative
+// floats here (a NaN impact is sent to the literal sort before this is called), so they order like their BITS, and on integers
+//     bits_q < bits_k  or  (bits_q == bits_k and q > k)   <=>   bits_q < bits_k + (q > k ? 1 : 0):
+// one unsigned compare and one add-with-carry per candidate, the threshold chosen once per four candidates (the four that hold k itself are compared
+// with bits_k, and the at most three behind k that tie with it are added afterwards) -- 2.75 instructions per candidate where the float form took
+// six: a selection by the block 4.4 -> ~2 us.  sImp: n impacts, padded with 0xFFFFFFFF (above every threshold) to a multiple of four, 16-byte aligned.
+__device__ __forceinline__ uint32_t rank_among(const float* sImp, const uint32_t n, const uint32_t k, const float imp)
+{
+    const uint4* s4 = reinterpret_cast<const uint4*>(sImp);
+    const uint32_t t0 = __float_as_uint(imp), t1 = t0 + 1u;
+    const uint32_t n4 = (n + 3u) / 4u;
+    uint32_t rank = 0u;
+    // (measured: four or eight reads in flight per trip change nothing -- a block's lone wave per SIMD issues one dependent instruction per ~10
+    // cycles whatever the LDS does; a block whose four tiles ALL select spends ~11 us here, the tail of a cluster band's launch)
+    for (uint32_t q4 = 0; q4 < n4; q4++) {
+        const uint4 v = s4[q4];
+        const uint32_t thr = 4u * q4 > k ? t1 : t0;
+        rank += (v.x < thr ? 1u : 0u) + (v.y < thr ? 1u : 0u) + (v.z < thr ? 1u : 0u) + (v.w < thr ? 1u : 0u);
+    }
+    const uint4 own = s4[k >> 2];
+    const uint32_t c = k & 3u;
+    rank += (c < 1u && own.y == t0 ? 1u : 0u) + (c < 2u && own.z == t0 ? 1u : 0u) + (c < 3u && own.w == t0 ? 1u : 0u);
+    return rank;
+}
+
 // ---- a tile of a LIGHT CLUSTER, one 256-thread block for the one tile (round 4).  A group with several chunks of candidates costs every one of
 // its tiles 10-25 steps of the exact test and, where more than 196 pass, a 196 -> 128 selection -- ~20 us on one wave, the tail of the whole launch
 // and THE cull of a cluster band.  Here the group's candidate list is cut into four contiguous shares, one per wave: each wave tests its share (its
@@ -1012,7 +1038,7 @@ __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* _
         mine = sAll[k];
         imp = (mine & 0x80000000u) ? 0.0f : tile_impact(t, lightView[mine & 0x7FFFFFFFu]);
         sImp[k] = imp;
-    } else if (k < (uint32_t)CAND + 4u) sImp[k] = __builtin_inff();
+    } else if (k < (uint32_t)CAND + 4u) reinterpret_cast<uint32_t*>(sImp)[k] = 0xFFFFFFFFu; // (rank_among's padding)
     if (__ballot(k < n && imp != imp) != 0ull && lane == 0) sCnt[4] = 1u;
     __syncthreads();
     if (sCnt[4] != 0u) { // a NaN impact has no rank: the literal bubble sort, on one wave (emit_list)
@@ -1020,23 +1046,7 @@ __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* _
         return;
     }
     if (k >= n) return;
-    // rank under (impact ascending, candidate position descending); keep rank < 128
-    const float4* sImp4 = reinterpret_cast<const float4*>(sImp);
-    uint32_t rank = 0u;
-    const uint32_t full4 = n / 4u;
-    for (uint32_t q4 = 0; q4 < full4; q4++) {
-        const float4 gv = sImp4[q4];
-        const float gq[4] = { gv.x, gv.y, gv.z, gv.w };
-#pragma unroll
-        for (uint32_t c = 0; c < 4; c++) {
-            const uint32_t q = q4 * 4u + c;
-            rank += (gq[c] < imp || (gq[c] == imp && q > k)) ? 1u : 0u;
-        }
-    }
-    for (uint32_t q = full4 * 4u; q < n; q++) {
-        const float gq = sImp[q];
-        rank += (gq < imp || (gq == imp && q > k)) ? 1u : 0u;
-    }
+    const uint32_t rank = rank_among(sImp, n, k, imp);
     if (rank < KEEP) out[rank] = mine & 0x7FFFFFFFu;
 }
 
@@ -1065,56 +1075,51 @@ __global__ __launch_bounds__(256) void k1_tile_cull_brute(const CullArgs a)
     emit_list(t, n, sIdxAll[wave], sImpAll[wave], a.lightView, a.tileLists + (size_t)bandTile * KEEP);
 }
 
-// The 196 -> 128 selection of ONE tile by the whole block (ComputeLightCulling.shader:198-225): one candidate per thread.  sIdx: the tile's n > 128
-// candidates (ascending light index, bit 31 = directional); sImp: room for CAND + 4 floats, 16-byte aligned.  Every thread of the block calls it
-// (two barriers inside).  A NaN impact has no rank: the literal bubble sort, on one wave (emit_list).
-__device__ __forceinline__ void block_select(const CullArgs& a, const int bandTile, const uint32_t n, uint32_t* sIdx, float* sImp, uint32_t* sFlag)
+// The 196 -> 128 selections of a block's tiles by the WHOLE block (ComputeLightCulling.shader:198-225): one candidate per thread and tile.  sIdxAll[w]:
+// tile w's candidates (ascending light index, bit 31 = directional), sCnt[w] their number (selection needed where > 128), sImpAll[w]: CAND floats of
+// its own, 16-byte aligned.  Two phases with ONE barrier between them: the impacts of every tile that needs a selection (the gathers of up to four
+// tiles in flight together), then the ranks.  A tile with a NaN impact has no rank: the literal bubble sort, on one wave (emit_list).
+__device__ __forceinline__ void block_select(const CullArgs& a, const int firstBandTile, const uint32_t* sCnt, uint32_t (*sIdxAll)[CAND], float (*sImpAll)[CAND], uint32_t* sFlags)
 {
     const uint32_t k = threadIdx.x, lane = threadIdx.x & 63;
     const float4* __restrict__ lightView = a.lightView;
-    uint32_t* __restrict__ out = a.tileLists + (size_t)bandTile * KEEP;
-    const float4* ti = a.tileInfo + (size_t)bandTile * 4; // (block-uniform: scalar loads)
-    const float cx = ti[0].w, cy = ti[1].w, cz = (ti[3].w + ti[2].w) * 0.5f;
-    uint32_t mine = 0u;
-    float imp = 0.0f;
-    if (k < n) {
-        mine = sIdx[k];
-        if (!(mine & 0x80000000u)) { // :187 impact = distance(light, frustum centre); a directional light's is 0 (:153-162)
-            const float4 lv = lightView[mine & 0x7FFFFFFFu];
-            const float dx = lv.x - cx, dy = lv.y - cy, dz = lv.z - cz;
-            imp = sqrtf(dot3f(dx, dy, dz, dx, dy, dz));
-        }
-        sImp[k] = imp;
-    }
-    if (__ballot(k < n && imp != imp) != 0ull && lane == 0) *sFlag = 1u;
-    __syncthreads();
-    if (*sFlag != 0u) {
-        if (threadIdx.x < 64) {
-            TileCtx t;
-            load_tile_ctx(a.tileInfo, bandTile, t);
-            emit_list(t, n, sIdx, sImp, lightView, out);
-        }
-    } else if (k < n) {
-        // rank under (impact ascending, candidate position descending); keep rank < 128
-        const float4* sImp4 = reinterpret_cast<const float4*>(sImp);
-        uint32_t rank = 0u;
-        const uint32_t full4 = n / 4u;
-        for (uint32_t q4 = 0; q4 < full4; q4++) {
-            const float4 gv = sImp4[q4];
-            const float gq[4] = { gv.x, gv.y, gv.z, gv.w };
+    uint32_t mine[4];
+    float imp[4];
 #pragma unroll
-            for (uint32_t c = 0; c < 4; c++) {
-                const uint32_t q = q4 * 4u + c;
-                rank += (gq[c] < imp || (gq[c] == imp && q > k)) ? 1u : 0u;
+    for (int w = 0; w < 4; w++) {
+        const uint32_t n = sCnt[w];
+        mine[w] = 0u; imp[w] = 0.0f;
+        if (n <= (uint32_t)KEEP) continue; // (block-uniform)
+        const float4* ti = a.tileInfo + (size_t)(firstBandTile + w) * 4; // (block-uniform: scalar loads)
+        const float cx = ti[0].w, cy = ti[1].w, cz = (ti[3].w + ti[2].w) * 0.5f;
+        if (k < n) {
+            mine[w] = sIdxAll[w][k];
+            if (!(mine[w] & 0x80000000u)) { // :187 impact = distance(light, frustum centre); a directional light's is 0 (:153-162)
+                const float4 lv = lightView[mine[w] & 0x7FFFFFFFu];
+                const float dx = lv.x - cx, dy = lv.y - cy, dz = lv.z - cz;
+                imp[w] = sqrtf(dot3f(dx, dy, dz, dx, dy, dz));
             }
-        }
-        for (uint32_t q = full4 * 4u; q < n; q++) {
-            const float gq = sImp[q];
-            rank += (gq < imp || (gq == imp && q > k)) ? 1u : 0u;
-        }
-        if (rank < KEEP) out[rank] = mine & 0x7FFFFFFFu;
+            sImpAll[w][k] = imp[w];
+        } else if (k < (uint32_t)CAND) reinterpret_cast<uint32_t*>(sImpAll[w])[k] = 0xFFFFFFFFu; // (rank_among's padding)
+        if (__ballot(k < n && imp[w] != imp[w]) != 0ull && lane == 0) sFlags[w] = 1u;
     }
-    __syncthreads(); // (sImp / sFlag are the next tile's)
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t n = sCnt[w];
+        if (n <= (uint32_t)KEEP) continue;
+        uint32_t* __restrict__ out = a.tileLists + (size_t)(firstBandTile + w) * KEEP;
+        if (sFlags[w] != 0u) {
+            if (threadIdx.x < 64) {
+                TileCtx t;
+                load_tile_ctx(a.tileInfo, firstBandTile + w, t);
+                emit_list(t, n, sIdxAll[w], sImpAll[w], lightView, out);
+            }
+        } else if (k < n) {
+            const uint32_t rank = rank_among(sImpAll[w], n, k, imp[w]);
+            if (rank < KEEP) out[rank] = mine[w] & 0x7FFFFFFFu;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
@@ -1132,8 +1137,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     float4* sLV = reinterpret_cast<float4*>(lds);                                                         // [CHUNK] candidate (view pos, radius)
     uint32_t* sE = reinterpret_cast<uint32_t*>(lds + CHUNK * 20 - CHUNK * 4);                             // [CHUNK] candidate light index | directional << 31
     uint32_t (*sIdxAll)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds + CHUNK * 20);                   // [4][CAND]
-    float* sImpBlock = reinterpret_cast<float*>(lds + CHUNK * 20 + 4 * CAND * 4);                         // [CAND + 4] of block_select (16-byte aligned), or:
-    float (*sImpAll)[CAND] = reinterpret_cast<float (*)[CAND]>(lds + CHUNK * 20 + 4 * CAND * 4);          // [4][CAND] (overflowed groups: emit_list per wave)
+    float (*sImpAll)[CAND] = reinterpret_cast<float (*)[CAND]>(lds + CHUNK * 20 + 4 * CAND * 4);          // [4][CAND], 16-byte aligned (CAND * 4 = 784)
     const float4* __restrict__ lightView = a.lightView;
     const int N = a.N, Tx = a.Tx, groupsX = a.groupsX;
     // (a 2-D grid, (group column, head rows + tile rows): no division by a run-time divisor)
@@ -1219,11 +1223,8 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
             for (uint32_t i = lane; i < n; i += 64) out[i] = sIdx[n - 1 - i] & 0x7FFFFFFFu;
         }
         __syncthreads();
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const uint32_t nw = sCnt[w];
-            if (nw > (uint32_t)KEEP) block_select(a, tyLocal * Tx + gx * GROUP + w, nw, sIdxAll[w], sImpBlock, sCnt + 4 + w); // (block-uniform)
-        }
+        if (((sCnt[0] > (uint32_t)KEEP) | (sCnt[1] > (uint32_t)KEEP)) | ((sCnt[2] > (uint32_t)KEEP) | (sCnt[3] > (uint32_t)KEEP))) // (block-uniform)
+            block_select(a, tyLocal * Tx + gx * GROUP, sCnt, sIdxAll, sImpAll, sCnt + 4);
     }
     PROF_T(3);
 }

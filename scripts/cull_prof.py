@@ -49,6 +49,13 @@ print("last to end:")
 for b in order:
     kind = "cluster tile" if b < nh else "ordinary (tile row %3d, group col %2d)" % ((b - nh) // groupsX, (b - nh) % groupsX)
     print("  block %5d %s: start %6.2f end %6.2f us" % (b, kind, us(p[b, 0]), us(p[b, 3])))
+g_host, _ = fp.lists_to_host()
+og, oi, cnt = None, None, None
+print("longest ordinary blocks and their four tiles' list lengths (128 = a 196 -> 128 selection ran if the tile had more candidates):")
+for b in (nh + np.argsort(-dur[nh:]))[:6]:
+    r, c = (b - nh) // groupsX, (b - nh) % groupsX
+    tiles = [r * Tx + 4 * c + w for w in range(4) if 4 * c + w < Tx]
+    print("  block %5d (tile row %3d, group col %2d): %.2f us, tests done after %.2f us; list lengths %s" % (b, r, c, dur[b], (p[b, 1] - p[b, 0]) / 100.0, g_host[tiles, 1].tolist()))
 starts = np.sort(us(p[ran, 0]))
 print("block start times us: p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(starts, [10, 50, 90, 100])))
 
