@@ -26,7 +26,7 @@
 //                      the group's candidate records are staged in LDS 512 at a time, each wave streams them through the
 //                      exact test, 64 per step; ballot/popcount ordered append; rank-based nearest-128 selection
 //                      (groups denser than 2048 candidates fall back to walking the two masks of the tile itself).
-//                      The tiles of a LIGHT CLUSTER (a group with more than 512 candidates, listed by k1_group_lists) get a whole
+//                      The tiles of a LIGHT CLUSTER (a group with more than HEAVY_MIN = 384 candidates, listed by k1_group_lists) get a whole
 //                      block each at the front of the grid: four waves share the tile's candidates and its 196 -> 128 selection
 //                      (round 4; one wave took ~20 us for such a tile -- the launch's tail and a cluster band's whole cull).
 //                      Every tile leaves its list in its own fixed 128-entry slot of the workspace (`tile lists`) and its length in
@@ -60,6 +60,10 @@
 #define GROUP_OVERFLOW 0xFFFFFFFFu
 #define GROUP_OVERFLOW_LISTED 0xFFFFFFFEu // ... the same for a group that is in k1_group_lists' cluster list
 #define GROUP_LISTED 0x40000000u // flag in a group's count: a light cluster k1_group_lists found room for in its list (k1_tile_cull starts with those)
+#ifndef HEAVY_MIN
+#define HEAVY_MIN 384           // a group with more candidates than this is listed as a light cluster: its tiles get a block each (measured 512 / 384 / 256:
+                                // whole frame 25.5 / 26.1 / 30.6 us, a cluster band of an 8-way split 15.4 / 9.7 / 8.0 -- below 384 too many groups qualify)
+#endif
 #define HEAVY_MAX 96            // ... and that list's room (16 head blocks of k1_tile_cull per entry: the empty ones are dispatched in front of everything else -- 4 096 of them cost ~3 us)
 #define CHUNK 512            // group candidates staged in LDS per step of k1_tile_cull (16 KB of LDS per block: 8 blocks per CU)
 
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* 
         uint32_t word = base > CAPG ? GROUP_OVERFLOW : base;
         // a light cluster (several chunks and a nearest-128 selection per tile: ~20 us for one of its row blocks, wherever in the grid it sits):
         // listed, so that k1_tile_cull can start with it
-        if (base > (uint32_t)CHUNK) {
+        if (base > (uint32_t)HEAVY_MIN) {
             const uint32_t slot = atomicAdd(&heavy[0], 1u);
             if (slot < (uint32_t)HEAVY_MAX) {
                 heavy[1u + slot] = (uint32_t)g;
