@@ -75,6 +75,9 @@ def parse(argv=None):
     ap.add_argument("--static-lights", dest="dynamic_lights", action="store_false", help="the lights' prepared views are derived once, outside the timed region (the default except for C5)")
     ap.add_argument("--separate-prepare", action="store_true", help="dynamic lights: sailor_hip_prepare_lights as a launch of its own in front of every cull (round 3) instead of "
                                                                     "folded into the cull's per-light pass (SAILOR_CULL_PREPARE_LIGHTS)")
+    ap.add_argument("--single-mode", action="store_true", help="profiling runs (rocprofv3 kernel stats, PMC passes): only the headline's light mode and launch form -- no second "
+                                                               "pass in the other light mode, no one-frame-in-flight reading with the pack beside the shade -- so that every kernel of the "
+                                                               "trace was launched the same way")
     ap.add_argument("--pack-inline", action="store_true", help="k1_pack inside every cull on the cull's stream (rounds 1-3) instead of deferred to a third stream beside the shade")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--equal-bands", action="store_true", help="N > 1: equal tile-row bands instead of cost-balanced ones")
@@ -1018,7 +1021,7 @@ def main(argv=None, device_factory=None):
 
     # ---- the other light mode, same launch form, same K steps: static lights beside a dynamic headline and the other way round ----
     other_mode = None
-    if prep is not None:
+    if prep is not None and not args.single_mode:
         run2, finish2, per2, _ = build_runner(not dynamic)
         el2 = time_steps(run2, finish2, per2)
         other_mode = {"ms_per_step": el2 / args.steps * 1e3, "value": frames_per_step * W * H * args.steps / el2 / 1e6}
@@ -1043,7 +1046,7 @@ def main(argv=None, device_factory=None):
     # ... and the same frame with k1_pack beside the shade (the form the frame pipeline above launches; still ONE frame in flight: the next
     # frame's cull waits for this frame's shade AND pack)
     serial_deferred = None
-    if defer_pack:
+    if defer_pack and not args.single_mode:
         def frame_deferred():
             cull_of(fp, None, dynamic, True)
             side2.wait_stream(side)

@@ -26,7 +26,7 @@
 //                      the group's candidate records are staged in LDS 512 at a time, each wave streams them through the
 //                      exact test, 64 per step; ballot/popcount ordered append; rank-based nearest-128 selection
 //                      (groups denser than 2048 candidates fall back to walking the two masks of the tile itself).
-//                      The tiles of a LIGHT CLUSTER (a group with more than HEAVY_MIN = 384 candidates, listed by k1_group_lists) get a whole
+//                      The tiles of a LIGHT CLUSTER (a group with more than 512 candidates -- 384 on a band of a split frame --, listed by k1_group_lists) get a whole
 //                      block each at the front of the grid: four waves share the tile's candidates and its 196 -> 128 selection
 //                      (round 4; one wave took ~20 us for such a tile -- the launch's tail and a cluster band's whole cull).
 //                      Every tile leaves its list in its own fixed 128-entry slot of the workspace (`tile lists`) and its length in
@@ -60,10 +60,11 @@
 #define GROUP_OVERFLOW 0xFFFFFFFFu
 #define GROUP_OVERFLOW_LISTED 0xFFFFFFFEu // ... the same for a group that is in k1_group_lists' cluster list
 #define GROUP_LISTED 0x40000000u // flag in a group's count: a light cluster k1_group_lists found room for in its list (k1_tile_cull starts with those)
-#ifndef HEAVY_MIN
-#define HEAVY_MIN 384           // a group with more candidates than this is listed as a light cluster: its tiles get a block each (measured 512 / 384 / 256:
-                                // whole frame 25.5 / 26.1 / 30.6 us, a cluster band of an 8-way split 15.4 / 9.7 / 8.0 -- below 384 too many groups qualify)
-#endif
+// A group with more candidates than this is listed as a light cluster: its tiles get a block each.  Measured 512 / 384 / 256: whole frame 25.5 / 26.1 /
+// 30.6 us for k1_tile_cull, a cluster band of an 8-way split 15.4 / 9.7 / 8.0 -- the whole frame hides a long block behind its other 8 000, a band
+// IS its longest block; below 384 too many groups qualify.  So: by the size of the band.
+#define HEAVY_MIN_FRAME 512
+#define HEAVY_MIN_BAND 384
 #define HEAVY_MAX 96            // ... and that list's room (16 head blocks of k1_tile_cull per entry: the empty ones are dispatched in front of everything else -- 4 096 of them cost ~3 us)
 #define CHUNK 512            // group candidates staged in LDS per step of k1_tile_cull (16 KB of LDS per block: 8 blocks per CU)
 
@@ -478,7 +479,7 @@ __device__ __forceinline__ uint64_t lanemask_lt()
 #define GL_WPT 4 // words per thread and round in k1_group_lists
 __global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ dirWords,
                                                        int words, int groupsX, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList,
-                                                       uint32_t* __restrict__ heavy)
+                                                       uint32_t* __restrict__ heavy, uint32_t heavyMin)
 {
     __shared__ uint32_t sW[4];
     // (2-D grid: group column, group row -- no division by the run-time groupsX)
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* 
         uint32_t word = base > CAPG ? GROUP_OVERFLOW : base;
         // a light cluster (several chunks and a nearest-128 selection per tile: ~20 us for one of its row blocks, wherever in the grid it sits):
         // listed, so that k1_tile_cull can start with it
-        if (base > (uint32_t)HEAVY_MIN) {
+        if (base > heavyMin) {
             const uint32_t slot = atomicAdd(&heavy[0], 1u);
             if (slot < (uint32_t)HEAVY_MAX) {
                 heavy[1u + slot] = (uint32_t)g;
@@ -1079,65 +1080,17 @@ __global__ __launch_bounds__(256) void k1_tile_cull_brute(const CullArgs a)
     emit_list(t, n, sIdxAll[wave], sImpAll[wave], a.lightView, a.tileLists + (size_t)bandTile * KEEP);
 }
 
-// The 196 -> 128 selections of a block's tiles by the WHOLE block (ComputeLightCulling.shader:198-225): one candidate per thread and tile.  sIdxAll[w]:
-// tile w's candidates (ascending light index, bit 31 = directional), sCnt[w] their number (selection needed where > 128), sImpAll[w]: CAND floats of
-// its own, 16-byte aligned.  Two phases with ONE barrier between them: the impacts of every tile that needs a selection (the gathers of up to four
-// tiles in flight together), then the ranks.  A tile with a NaN impact has no rank: the literal bubble sort, on one wave (emit_list).
-__device__ __forceinline__ void block_select(const CullArgs& a, const int firstBandTile, const uint32_t* sCnt, uint32_t (*sIdxAll)[CAND], float (*sImpAll)[CAND], uint32_t* sFlags)
-{
-    const uint32_t k = threadIdx.x, lane = threadIdx.x & 63;
-    const float4* __restrict__ lightView = a.lightView;
-    uint32_t mine[4];
-    float imp[4];
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const uint32_t n = sCnt[w];
-        mine[w] = 0u; imp[w] = 0.0f;
-        if (n <= (uint32_t)KEEP) continue; // (block-uniform)
-        const float4* ti = a.tileInfo + (size_t)(firstBandTile + w) * 4; // (block-uniform: scalar loads)
-        const float cx = ti[0].w, cy = ti[1].w, cz = (ti[3].w + ti[2].w) * 0.5f;
-        if (k < n) {
-            mine[w] = sIdxAll[w][k];
-            if (!(mine[w] & 0x80000000u)) { // :187 impact = distance(light, frustum centre); a directional light's is 0 (:153-162)
-                const float4 lv = lightView[mine[w] & 0x7FFFFFFFu];
-                const float dx = lv.x - cx, dy = lv.y - cy, dz = lv.z - cz;
-                imp[w] = sqrtf(dot3f(dx, dy, dz, dx, dy, dz));
-            }
-            sImpAll[w][k] = imp[w];
-        } else if (k < (uint32_t)CAND) reinterpret_cast<uint32_t*>(sImpAll[w])[k] = 0xFFFFFFFFu; // (rank_among's padding)
-        if (__ballot(k < n && imp[w] != imp[w]) != 0ull && lane == 0) sFlags[w] = 1u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const uint32_t n = sCnt[w];
-        if (n <= (uint32_t)KEEP) continue;
-        uint32_t* __restrict__ out = a.tileLists + (size_t)(firstBandTile + w) * KEEP;
-        if (sFlags[w] != 0u) {
-            if (threadIdx.x < 64) {
-                TileCtx t;
-                load_tile_ctx(a.tileInfo, firstBandTile + w, t);
-                emit_list(t, n, sIdxAll[w], sImpAll[w], lightView, out);
-            }
-        } else if (k < n) {
-            const uint32_t rank = rank_among(sImpAll[w], n, k, imp[w]);
-            if (rank < KEEP) out[rank] = mine[w] & 0x7FFFFFFFu;
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
 {
     // One 256-thread block per run of four tiles (a group's four columns in one tile row), one wave per tile.  The group's candidate records are
     // staged in LDS, CHUNK at a time, by the four waves together (list entries first, then the dependent 16-byte gathers, four of each in flight
-    // per thread), and every tile streams them out of LDS.  A tile with more than 128 candidates gets its 196 -> 128 selection from the WHOLE block
-    // (block_select: ~3 us instead of ~12 on the one wave -- the launch's tail once the light clusters had blocks of their own, profiles/r04).
+    // per thread), and every tile streams them out of LDS.
     // Measured and dropped in round 4 (scripts/cull_prof.py: the per-block timeline on the 100 MHz clock): TWO tile rows per block, the staged
     // candidates serving both -- half the blocks, half the staging traffic, 90 % of the block slots filled instead of 70 % -- but a block then lives
     // 8.9 us instead of 3.3: the waves spend their time in the tests, not in the round trips, once the CU is full; chain 57 us against 48.
     // (Rounds 2 and 3: one block per group with a wave per tile row, 38.8 us against 32.4.)
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K1_TILE_CULL];
-    __shared__ uint32_t sCnt[8]; // [0..3] the waves' candidate counts, [4..7] "a NaN impact" per tile (cluster_tile: [4])
+    __shared__ uint32_t sCnt[5]; // cluster_tile: [0..3] the waves' candidate counts, [4] "a NaN impact"
     float4* sLV = reinterpret_cast<float4*>(lds);                                                         // [CHUNK] candidate (view pos, radius)
     uint32_t* sE = reinterpret_cast<uint32_t*>(lds + CHUNK * 20 - CHUNK * 4);                             // [CHUNK] candidate light index | directional << 31
     uint32_t (*sIdxAll)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds + CHUNK * 20);                   // [4][CAND]
@@ -1145,9 +1098,9 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     const float4* __restrict__ lightView = a.lightView;
     const int N = a.N, Tx = a.Tx, groupsX = a.groupsX;
     // (a 2-D grid, (group column, head rows + tile rows): no division by a run-time divisor)
-    const int gx = (int)blockIdx.x, pairRow = (int)blockIdx.y - a.headRows;
+    const int gx = (int)blockIdx.x, tyLocal = (int)blockIdx.y - a.headRows;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.dirFlag = 0u; // (k01_prepare of the NEXT cull sets it again if a light is directional; k1_group_lists_wide has read it)
-    if (pairRow < 0) {
+    if (tyLocal < 0) {
         // HEAD ROWS: the tiles of the light clusters k1_group_lists listed, sixteen blocks per group, at the front of the grid (they are the
         // launch's longest blocks); the blocks at their regular positions further down leave at once.
         const uint32_t hb = blockIdx.y * (uint32_t)groupsX + blockIdx.x;
@@ -1161,8 +1114,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
         return;
     }
     PROF_T(0);
-    const int row0 = pairRow, nrows = 1; // (the loop below takes `nrows` consecutive tile rows of one group: 1 -- see the note on two rows above)
-    const int g = (row0 / GROUP) * groupsX + gx;
+    const int g = (tyLocal / GROUP) * groupsX + gx;
     // (the wave index as a scalar: a tile's frustum -- the same 64 bytes for all lanes -- then arrives by scalar loads)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     uint32_t* sIdx = sIdxAll[wave];
@@ -1180,56 +1132,43 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
 
     const int tx = gx * GROUP + wave;
     const bool active = tx < Tx;
-    for (int r = 0; r < nrows; r++) {
-        const int tyLocal = row0 + r, bandTile = tyLocal * Tx + tx;
-        TileCtx t;
-        if (active) load_tile_ctx(a.tileInfo, bandTile, t);
-        uint32_t count = 0;
-        if (gn != GROUP_OVERFLOW) {
-            for (uint32_t c0 = 0; c0 < gn; c0 += CHUNK) {
-                const uint32_t cn = min((uint32_t)CHUNK, gn - c0);
-                if (r == 0 || gn > (uint32_t)CHUNK) { // (a group of one chunk -- all but the odd unlisted cluster -- is staged once, for both rows)
-                    if (c0 || r) {
-                        __syncthreads(); // every wave is done with what is staged
+    const int bandTile = tyLocal * Tx + tx;
+    TileCtx t;
+    if (active) load_tile_ctx(a.tileInfo, bandTile, t);
+    uint32_t count = 0;
+    if (gn != GROUP_OVERFLOW) {
+        for (uint32_t c0 = 0; c0 < gn; c0 += CHUNK) {
+            const uint32_t cn = min((uint32_t)CHUNK, gn - c0);
+            if (c0) {
+                __syncthreads(); // every wave is done with the previous chunk
 #pragma unroll
-                        for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; e[k] = i < cn ? list[c0 + i] : 0u; }
-                    }
-                    float4 lv[CHUNK / 256];
-                    // (only the slots below the count: a gather through a stale entry of an earlier frame is a random 16-byte request for nothing)
-#pragma unroll
-                    for (int k = 0; k < CHUNK / 256; k++) {
-                        lv[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        if (threadIdx.x + 256u * k < cn) lv[k] = lightView[min(e[k] & 0x7FFFFFFFu, (uint32_t)(N - 1))];
-                    }
-#pragma unroll
-                    for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; if (i < cn) { sE[i] = e[k]; sLV[i] = lv[k]; } }
-                    __syncthreads();
-                }
-                if (active) test_staged(t, cn, sE, sLV, count, sIdx);
+                for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; e[k] = i < cn ? list[c0 + i] : 0u; }
             }
-        } else if (active) {
-            // overflowed group (very dense region / lights around the eye): every tile walks its own two masks
-            walk_tile_masks(t, a, gx, tyLocal, reinterpret_cast<uint32_t*>(sLV) + wave * QCAP, count, sIdx); // sLV is unused on this path
+            float4 lv[CHUNK / 256];
+            // (only the slots below the count: a gather through a stale entry of an earlier frame is a random 16-byte request for nothing)
+#pragma unroll
+            for (int k = 0; k < CHUNK / 256; k++) {
+                lv[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (threadIdx.x + 256u * k < cn) lv[k] = lightView[min(e[k] & 0x7FFFFFFFu, (uint32_t)(N - 1))];
+            }
+#pragma unroll
+            for (int k = 0; k < CHUNK / 256; k++) { const uint32_t i = threadIdx.x + 256u * k; if (i < cn) { sE[i] = e[k]; sLV[i] = lv[k]; } }
+            __syncthreads();
+            if (active) test_staged(t, cn, sE, sLV, count, sIdx);
         }
-        if (r == 0) PROF_T(1);
-        const uint32_t n = count < CAND ? count : CAND; // (0 for a wave beyond the last tile column)
-        if (active && lane == 0) publish_tile(a, bandTile, n < KEEP ? n : KEEP);
-        if (gn == GROUP_OVERFLOW) { // (rare, and its staging area is the waves' queues: every wave selects for itself)
-            if (active) emit_list(t, n, sIdx, sImpAll[wave], lightView, a.tileLists + (size_t)bandTile * KEEP);
-            continue;
-        }
-        // short lists leave at once (:235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]); the others wait for the block
-        if (lane == 0) sCnt[wave] = n;
-        if (threadIdx.x < 4) sCnt[4 + threadIdx.x] = 0u; // block_select's "a NaN impact", one flag per tile
-        if (active && n <= KEEP) {
-            WAVE_SYNC();
-            uint32_t* __restrict__ out = a.tileLists + (size_t)bandTile * KEEP;
-            for (uint32_t i = lane; i < n; i += 64) out[i] = sIdx[n - 1 - i] & 0x7FFFFFFFu;
-        }
-        __syncthreads();
-        if (((sCnt[0] > (uint32_t)KEEP) | (sCnt[1] > (uint32_t)KEEP)) | ((sCnt[2] > (uint32_t)KEEP) | (sCnt[3] > (uint32_t)KEEP))) // (block-uniform)
-            block_select(a, tyLocal * Tx + gx * GROUP, sCnt, sIdxAll, sImpAll, sCnt + 4);
+    } else if (active) {
+        // overflowed group (very dense region / lights around the eye): every tile walks its own two masks
+        walk_tile_masks(t, a, gx, tyLocal, reinterpret_cast<uint32_t*>(sLV) + wave * QCAP, count, sIdx); // sLV is unused on this path
     }
+    PROF_T(1);
+    if (!active) return;
+    const uint32_t n = count < CAND ? count : CAND;
+    if (lane == 0) publish_tile(a, bandTile, n < KEEP ? n : KEEP);
+    // The tile's list into the tile's own slot: k1_pack moves it to its canonical place, the shade reads it where it is.  A tile with more than 128
+    // candidates selects on its own wave (emit_list).  Measured and dropped in round 4: the selection by the WHOLE block (one candidate per thread,
+    // integer-threshold rank: 2.8 us a tile instead of ~9) behind a barrier that every block then pays -- a block whose four tiles all select takes
+    // 11 us either way, and the launch's throughput phase lost what its tail gained (C5: 99 -> 114 us); what shortens a cluster band is the lower HEAVY_MIN_BAND.
+    emit_list(t, n, sIdx, sImpAll[wave], lightView, a.tileLists + (size_t)bandTile * KEEP);
     PROF_T(3);
 }
 
@@ -1530,7 +1469,7 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
         }
         else {
             sailor_launch(ctx, k1_group_lists, dim3(L.groupsX, L.groupsY), dim3(256), pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
-                               (uint32_t*)(ws + L.offGroupList), (uint32_t*)(ws + L.offHeavy));
+                               (uint32_t*)(ws + L.offGroupList), (uint32_t*)(ws + L.offHeavy), (uint32_t)(L.bandRows * 2 > L.Ty ? HEAVY_MIN_FRAME : HEAVY_MIN_BAND));
             ca.headRows = (16 * HEAVY_MAX + L.groupsX - 1) / L.groupsX; // grid rows for the listed clusters' tiles (a block each), in front of the tile rows
         }
         SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");

@@ -8,7 +8,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B=$GRAFT_REPO_ROOT/bench.py
-EAGER="--no-cpu-baseline --no-graph --frames-in-flight 1"
+EAGER="--no-cpu-baseline --no-graph --frames-in-flight 1 --single-mode"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $B --steps 50 --warmup 5 $EAGER > $OUT/bench_eager.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $B --steps 5 --warmup 2 $EAGER > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $B --steps 5 --warmup 2 $EAGER > /dev/null 2>&1

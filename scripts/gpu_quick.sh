@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 if [ $# -gt 0 ]; then timeout 1200 python -m pytest "$@" -x -q -m gpu 2>&1 | tail -15; fi
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-graph --frames-in-flight 1 ${BENCH_ARGS} > $OUT/bench_eager.json 2> $OUT/bench_eager.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-graph --frames-in-flight 1 --single-mode ${BENCH_ARGS} > $OUT/bench_eager.json 2> $OUT/bench_eager.err
 cd $GRAFT_REPO_ROOT
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 rm -rf $OUT/stats
