@@ -151,12 +151,29 @@ class HipDevice:
 
     # -- the split frame's exchange: the SHIPPED one (exchange.hip over an ncclComm_t), not torch.distributed's collectives
     def make_comm(self, rank: int, world: int):
+        """the job's ncclComm_t for the C-ABI exchange.  If it cannot be had on EVERY rank (agreed by an all-reduce: a rank that went on alone would hang
+        the others in the first collective), the exchange falls back to torch.distributed's collectives and the line says so."""
+        import torch.distributed as dist
         from sailor_amd import dist as sdist
-        self._comm = sdist.RcclComm(rank, world)
+        ok = 1
+        try:
+            self._comm = sdist.RcclComm(rank, world)
+        except Exception as e:
+            ok = 0
+            print(f"[bench] rank {rank}: no ncclComm_t for the C-ABI exchange ({type(e).__name__}: {e})", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            if self._comm is not None:
+                self._comm.close()
+            self._comm = None
+            self.exchange_how = "sailor_amd.dist.exchange_lists over torch.distributed (nccl = RCCL): the C-ABI exchange's own communicator could not be created on every rank"
 
     def exchange(self, ctx, W, H, bounds, fp):
         """this rank's band lists -> the frame's canonical (lightsGrid, culledLights) on every rank: sailor_hip_exchange_light_lists_rows"""
         from sailor_amd import dist as sdist
+        if self._comm is None:
+            return sdist.exchange_lists(fp.grid[: fp.band_tiles * 2], fp.culled)
         return sdist.exchange_lists_rccl(ctx, self._comm, W, H, bounds, fp.grid[: fp.band_tiles * 2], fp.culled)
 
     exchange_how = "sailor_hip_exchange_light_lists_rows (C-ABI: 3 x ncclAllGather on an ncclComm_t of the job's ranks + one stitch kernel)"

@@ -148,17 +148,28 @@ class RcclComm:
 
     def __init__(self, rank: int, world_size: int, group=None):
         import ctypes as C
-        self.lib = _load_rccl()
+        try:
+            self.lib = _load_rccl()
+        except OSError:
+            self.lib = None   # (raised below, behind the broadcast every rank takes part in)
 
         class UniqueId(C.Structure):
             _fields_ = [("internal", C.c_char * 128)]
         uid = UniqueId()
-        if rank == 0 and self.lib.ncclGetUniqueId(C.byref(uid)) != 0:
-            raise RuntimeError("ncclGetUniqueId failed")
-        if world_size > 1:
-            box = [bytes(bytearray(uid)) if rank == 0 else None]
+        payload = None
+        if rank == 0:
+            try:
+                if self.lib is not None and self.lib.ncclGetUniqueId(C.byref(uid)) == 0:
+                    payload = bytes(bytearray(uid))
+            except Exception:
+                payload = None
+        if world_size > 1:   # (every rank takes part in the broadcast whatever rank 0 found: a failure travels as None)
+            box = [payload]
             dist.broadcast_object_list(box, src=0, group=group)
-            C.memmove(C.byref(uid), box[0], 128)
+            payload = box[0]
+        if payload is None or self.lib is None:
+            raise RuntimeError("no librccl on this rank" if self.lib is None else "ncclGetUniqueId failed on rank 0")
+        C.memmove(C.byref(uid), payload, 128)
         comm = C.c_void_p()
         self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
         rc = self.lib.ncclCommInitRank(C.byref(comm), world_size, uid, rank)
