@@ -1080,6 +1080,57 @@ __global__ __launch_bounds__(256) void k1_tile_cull_brute(const CullArgs a)
     emit_list(t, n, sIdxAll[wave], sImpAll[wave], a.lightView, a.tileLists + (size_t)bandTile * KEEP);
 }
 
+// The 196 -> 128 selections of a block's tiles by the WHOLE block (ComputeLightCulling.shader:198-225): one candidate per thread and tile.  sIdxAll[w]:
+// tile w's candidates (ascending light index, bit 31 = directional), sCnt[w] their number (selection needed where > 128), sImpAll[w]: CAND floats of
+// its own, 16-byte aligned.  Two phases with ONE barrier between them: the impacts of every tile that needs a selection (the gathers of up to four
+// tiles in flight together), then the ranks.  A tile with a NaN impact has no rank: the literal bubble sort, on one wave (emit_list).
+__device__ __forceinline__ void block_select(const CullArgs& a, const int firstBandTile, const uint32_t* sCnt, uint32_t (*sIdxAll)[CAND], float (*sImpAll)[CAND], uint32_t* sFlags)
+{
+    const uint32_t k = threadIdx.x, lane = threadIdx.x & 63;
+    const float4* __restrict__ lightView = a.lightView;
+    uint32_t mine[4];
+    float imp[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t n = sCnt[w];
+        mine[w] = 0u; imp[w] = 0.0f;
+        if (n <= (uint32_t)KEEP) continue; // (block-uniform)
+        const float4* ti = a.tileInfo + (size_t)(firstBandTile + w) * 4; // (block-uniform: scalar loads)
+        const float cx = ti[0].w, cy = ti[1].w, cz = (ti[3].w + ti[2].w) * 0.5f;
+        if (k < n) {
+            mine[w] = sIdxAll[w][k];
+            if (!(mine[w] & 0x80000000u)) { // :187 impact = distance(light, frustum centre); a directional light's is 0 (:153-162)
+                const float4 lv = lightView[mine[w] & 0x7FFFFFFFu];
+                const float dx = lv.x - cx, dy = lv.y - cy, dz = lv.z - cz;
+                imp[w] = sqrtf(dot3f(dx, dy, dz, dx, dy, dz));
+            }
+            sImpAll[w][k] = imp[w];
+        } else if (k < (uint32_t)CAND) reinterpret_cast<uint32_t*>(sImpAll[w])[k] = 0xFFFFFFFFu; // (rank_among's padding)
+        if (__ballot(k < n && imp[w] != imp[w]) != 0ull && lane == 0) sFlags[w] = 1u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t n = sCnt[w];
+        if (n <= (uint32_t)KEEP) continue;
+        uint32_t* __restrict__ out = a.tileLists + (size_t)(firstBandTile + w) * KEEP;
+        if (sFlags[w] != 0u) {
+            if (threadIdx.x < 64) {
+                TileCtx t;
+                load_tile_ctx(a.tileInfo, firstBandTile + w, t);
+                emit_list(t, n, sIdxAll[w], sImpAll[w], lightView, out);
+            }
+        } else if (k < n) {
+            const uint32_t rank = rank_among(sImpAll[w], n, k, imp[w]);
+            if (rank < KEEP) out[rank] = mine[w] & 0x7FFFFFFFu;
+        }
+    }
+}
+
+// COOP: the band form (bands of a split frame: a band IS its longest block).  Tiles with more than 128 candidates get their selection from the whole
+// block (block_select) behind a barrier every block pays; the whole frame hides such a block behind its other 8 000 and keeps the per-wave form, whose
+// throughput phase the barrier would cost 15 % of at 8K (measured: k1_tile_cull on C5 99 -> 114 us, on a cluster band of an 8-way split 14.7 -> 9.7).
+template <bool COOP>
 __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
 {
     // One 256-thread block per run of four tiles (a group's four columns in one tile row), one wave per tile.  The group's candidate records are
@@ -1090,7 +1141,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     // 8.9 us instead of 3.3: the waves spend their time in the tests, not in the round trips, once the CU is full; chain 57 us against 48.
     // (Rounds 2 and 3: one block per group with a wave per tile row, 38.8 us against 32.4.)
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K1_TILE_CULL];
-    __shared__ uint32_t sCnt[5]; // cluster_tile: [0..3] the waves' candidate counts, [4] "a NaN impact"
+    __shared__ uint32_t sCnt[8]; // [0..3] the waves' candidate counts, [4..7] "a NaN impact" per tile (cluster_tile: [4])
     float4* sLV = reinterpret_cast<float4*>(lds);                                                         // [CHUNK] candidate (view pos, radius)
     uint32_t* sE = reinterpret_cast<uint32_t*>(lds + CHUNK * 20 - CHUNK * 4);                             // [CHUNK] candidate light index | directional << 31
     uint32_t (*sIdxAll)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds + CHUNK * 20);                   // [4][CAND]
@@ -1161,14 +1212,25 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
         walk_tile_masks(t, a, gx, tyLocal, reinterpret_cast<uint32_t*>(sLV) + wave * QCAP, count, sIdx); // sLV is unused on this path
     }
     PROF_T(1);
-    if (!active) return;
-    const uint32_t n = count < CAND ? count : CAND;
-    if (lane == 0) publish_tile(a, bandTile, n < KEEP ? n : KEEP);
-    // The tile's list into the tile's own slot: k1_pack moves it to its canonical place, the shade reads it where it is.  A tile with more than 128
-    // candidates selects on its own wave (emit_list).  Measured and dropped in round 4: the selection by the WHOLE block (one candidate per thread,
-    // integer-threshold rank: 2.8 us a tile instead of ~9) behind a barrier that every block then pays -- a block whose four tiles all select takes
-    // 11 us either way, and the launch's throughput phase lost what its tail gained (C5: 99 -> 114 us); what shortens a cluster band is the lower HEAVY_MIN_BAND.
-    emit_list(t, n, sIdx, sImpAll[wave], lightView, a.tileLists + (size_t)bandTile * KEEP);
+    const uint32_t n = count < CAND ? count : CAND; // (0 for a wave beyond the last tile column)
+    if (active && lane == 0) publish_tile(a, bandTile, n < KEEP ? n : KEEP);
+    // The tile's list into the tile's own slot: k1_pack moves it to its canonical place, the shade reads it where it is.
+    if (!COOP || gn == GROUP_OVERFLOW) { // (an overflowed group's staging area is the waves' queues: every wave selects for itself)
+        // a tile with more than 128 candidates selects on its own wave (emit_list: ~9 us)
+        if (active) emit_list(t, n, sIdx, sImpAll[wave], lightView, a.tileLists + (size_t)bandTile * KEEP);
+    } else {
+        // short lists leave at once (:235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]); the others wait for the block
+        if (lane == 0) sCnt[wave] = n;
+        if (threadIdx.x < 4) sCnt[4 + threadIdx.x] = 0u; // block_select's "a NaN impact", one flag per tile
+        if (active && n <= KEEP) {
+            WAVE_SYNC();
+            uint32_t* __restrict__ out = a.tileLists + (size_t)bandTile * KEEP;
+            for (uint32_t i = lane; i < n; i += 64) out[i] = sIdx[n - 1 - i] & 0x7FFFFFFFu;
+        }
+        __syncthreads();
+        if (((sCnt[0] > (uint32_t)KEEP) | (sCnt[1] > (uint32_t)KEEP)) | ((sCnt[2] > (uint32_t)KEEP) | (sCnt[3] > (uint32_t)KEEP))) // (block-uniform)
+            block_select(a, tyLocal * Tx + gx * GROUP, sCnt, sIdxAll, sImpAll, sCnt + 4);
+    }
     PROF_T(3);
 }
 
@@ -1473,7 +1535,8 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
             ca.headRows = (16 * HEAVY_MAX + L.groupsX - 1) / L.groupsX; // grid rows for the listed clusters' tiles (a block each), in front of the tile rows
         }
         SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
-        sailor_launch(ctx, k1_tile_cull, dim3(L.groupsX, ca.headRows + L.bandRows), dim3(256), ca);
+        if (L.bandRows * 2 > L.Ty) sailor_launch(ctx, k1_tile_cull<false>, dim3(L.groupsX, ca.headRows + L.bandRows), dim3(256), ca);
+        else sailor_launch(ctx, k1_tile_cull<true>, dim3(L.groupsX, ca.headRows + L.bandRows), dim3(256), ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
     }
     if (flags & SAILOR_CULL_DEFER_PACK) return SAILOR_HIP_OK; // the caller records sailor_hip_light_cull_pack where it wants it (another stream, beside the shade)

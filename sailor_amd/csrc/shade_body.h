@@ -410,7 +410,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
                  : "v56", "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc", "memory")
 
 #define SPLIT_MIN 40      // == CLASS_B of light_cull.hip: the hint's first two classes
+#ifndef SPLIT_BLOCKS
 #define SPLIT_BLOCKS 2048 // one round of resident blocks (8 per CU)
+#endif
 static_assert(QMAX <= 128 && 7 * PENDK < 32 && 3 * QMAX >= 192, "queue positions are 7 bits each under a sentinel bit; the split blocks park 3 x 64 partial sums in a wave's slots");
 struct ShadeLds {
     float4 sL[KEEP * LREC];

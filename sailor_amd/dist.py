@@ -22,14 +22,15 @@ def bands(width: int, height: int, world_size: int):
     return [host.band_for_rank(width, height, r, world_size) for r in range(world_size)]
 
 
-# Relative cost of one tile (streaming its 256 pixels + fixed per-tile work) and of one light-list entry, from the single-GPU
-# profile of the 4K / 65 536-light frame (profiles/r01): ~4.1 ns per tile + ~0.28 ns per entry on an MI355X.
-TILE_COST, ENTRY_COST = 4.1, 0.28
-# A tile in a light cluster (>= LONG_TILE lights) costs its band far more than its entries: the cluster blocks of k1_tile_cull are the band's
-# whole cull time (24 against 6 us on an eighth of the 4K frame) and its shade goes through the split blocks.  Charged as LONG_TILE_ENTRIES
-# extra entries per such tile -- measured on the 8-way split of the 4K / 65 536-light frame (bench.py --simulate-split 8): the bands' steps
-# go from 0.059 .. 0.072 ms to 0.062 .. 0.068 ms, the predicted speed-up from 3.0x to 3.2x.
-LONG_TILE, LONG_TILE_ENTRIES = 96, 1000
+# Relative cost of one tile (streaming its 256 pixels + fixed per-tile work) and of one light-list entry.  Round 4 re-fit on the bands of an 8-way split
+# of the 4K / 65 536-light frame (bench.py --simulate-split 8): with equal bands the step of a band is ~25 us of launch floors plus (a) 21.7 us for an
+# edge band (4 080 tiles, ~10 entries a tile) and (b) 32 us for a middle band (~35 entries a tile) -- a ratio of 1.47, which fixes tile : entry at 43 : 1
+# (round 1's 4.1 : 0.28 = 15 : 1 came from the whole frame's kernels and gave the edge bands 24 rows of 135: they became the slowest).
+TILE_COST, ENTRY_COST = 12.0, 0.28
+# A tile in a light cluster (>= LONG_TILE lights) costs its band more than its entries: its cull goes through a block of its own and its shade through the
+# split blocks.  Charged as LONG_TILE_ENTRIES extra entries per such tile (round 2: 1000, when a cluster row block took 24 us of a band's cull; since round
+# 4's block-per-tile cull and block-wide selection the cluster band's cull is 9 against 6 us).
+LONG_TILE, LONG_TILE_ENTRIES = 96, 300
 
 
 def row_cost_entries(num_per_tile, tiles_per_row: int):
