@@ -1102,8 +1102,9 @@ def main(argv=None, device_factory=None):
     # kept beside the direct one (it reads a few per cent lower: the next cull's head overlaps the shade's drain)
     shade_diff_ms = serial["median"] - cull_batch_ms
     shade_kernel = "k2_shade_csm" if csm is not None else ("k2_shade_band" if fp.tile_order and fp.use_tile_order else "k2_shade")
-    if prep is not None:
-        shade_kernel += "_p"   # the entry points that read sailor_hip_prepare_lights' staged records
+    tl = bool(getattr(fp, "shade_from_tile_lists", False))
+    if prep is not None or tl:   # _p: the entry points that read sailor_hip_prepare_lights' staged records; ..t: the lists from the cull's per-tile slots
+        shade_kernel += "_" + ("p" if prep is not None else "") + ("t" if tl else "")
     trace_ms = trace_kernel_ms(shade_kernel, args.config, world)
     roofline = {"bound": "hbm", "kernel": shade_kernel, "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
                 "traffic": measured_traffic(shade_kernel, args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_launch_ms,

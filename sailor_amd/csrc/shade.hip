@@ -30,37 +30,39 @@
 
 // Entry points: without shadow lookups in it the kernel fits 64 VGPRs, and the register allocator is told to stay there
 // (8 waves per SIMD); with the 16-tap PCF inlined it does not, and forcing it would spill.  The ambient term adds a third.
-#define SHADE_ENTRY(NAME, ATTR, CSM, IBL, PREP)                                                                                                    \
+#define SHADE_ENTRY(NAME, ATTR, CSM, IBL, PREP, TL)                                                                                                \
     __global__ __launch_bounds__(256) ATTR void NAME(ShadeArgs A, CsmArgs C, IblArgs I, const float4* __restrict__ surface, size_t planeStride,    \
                                                      const SailorLightShaderData* __restrict__ lights, const SailorLightsGrid* __restrict__ grid, \
                                                      const uint32_t* __restrict__ culled, float4* __restrict__ radiance)                          \
     {                                                                                                                                              \
         __shared__ ShadeLds lds;                                                                                                                   \
-        k2_shade_body<CSM, IBL, ROLE_TILE, PREP>(lds, A, C, I, surface, planeStride, lights, grid, culled, radiance);                              \
+        k2_shade_body<CSM, IBL, ROLE_TILE, PREP, TL>(lds, A, C, I, surface, planeStride, lights, grid, culled, radiance);                          \
     }
 #define FORCE_64_VGPRS __attribute__((amdgpu_waves_per_eu(8, 8)))
-SHADE_ENTRY(k2_shade, FORCE_64_VGPRS, false, false, false)
 // (the K3 kernels: 64 registers like the others since the shadow look-ups run before the view / material terms -- "K3 first" in shade_body.h; it
 // was 80 = six waves per SIMD.  The pin matters: unpinned, the prepared twins come out at 116-134.)
 #define CSM_PIN __attribute__((amdgpu_waves_per_eu(8, 8)))
 #define FIVE_WAVES __attribute__((amdgpu_waves_per_eu(5, 5))) // (K3 + ambient: 88-91 registers by itself; its prepared twin 134 unpinned)
-SHADE_ENTRY(k2_shade_csm, CSM_PIN, true, false, false)
-SHADE_ENTRY(k2_shade_ibl, , false, true, false)
-SHADE_ENTRY(k2_shade_csm_ibl, FIVE_WAVES, true, true, false)
-// the same kernels reading the records sailor_hip_prepare_lights staged (`lights` = the staged array)
-SHADE_ENTRY(k2_shade_p, FORCE_64_VGPRS, false, false, true)
-SHADE_ENTRY(k2_shade_csm_p, CSM_PIN, true, false, true)
-SHADE_ENTRY(k2_shade_ibl_p, , false, true, true)
-SHADE_ENTRY(k2_shade_csm_ibl_p, FIVE_WAVES, true, true, true)
+// Four kernels (plain, K3, ambient, K3 + ambient) x the lights as 112-byte records or as sailor_hip_prepare_lights' staged records (_p: `lights` = the
+// staged array) x the lists in the reference's lightsGrid / culledLights or in the cull's per-tile slots (..t: `grid` = tileNum, `culled` = the slots)
+#define SHADE_ENTRIES(SUFFIX, PREP, TL)                                          \
+    SHADE_ENTRY(k2_shade##SUFFIX, FORCE_64_VGPRS, false, false, PREP, TL)         \
+    SHADE_ENTRY(k2_shade_csm##SUFFIX, CSM_PIN, true, false, PREP, TL)             \
+    SHADE_ENTRY(k2_shade_ibl##SUFFIX, , false, true, PREP, TL)                    \
+    SHADE_ENTRY(k2_shade_csm_ibl##SUFFIX, FIVE_WAVES, true, true, PREP, TL)
+SHADE_ENTRIES(, false, false)
+SHADE_ENTRIES(_p, true, false)
+SHADE_ENTRIES(_t, false, true)
+SHADE_ENTRIES(_pt, true, true)
 
-template <bool PREP>
+template <bool PREP, bool TL>
 __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, int bandTiles, const float4* __restrict__ surface, size_t planeStride,
                                                    const SailorLightShaderData* __restrict__ lights, const SailorLightsGrid* __restrict__ grid,
                                                    const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
 {
     if (blockIdx.x >= (unsigned)SPLIT_BLOCKS) {
         const int t = (int)blockIdx.x - SPLIT_BLOCKS, ty = t / A.Tx;
-        k2_shade_body<false, false, ROLE_BAND_TILE, PREP>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, t - ty * A.Tx, ty, 0);
+        k2_shade_body<false, false, ROLE_BAND_TILE, PREP, TL>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, t - ty * A.Tx, ty, 0);
         return;
     }
     // the cull's hint: order[0 .. nA) = the tiles with >= 96 lights, order[T-1], order[T-2] .. = the nB tiles with 40..95, order[T] = nA, order[T+1] = nB
@@ -68,22 +70,24 @@ __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArg
     for (uint32_t idx = blockIdx.x; idx < limit; idx += (uint32_t)SPLIT_BLOCKS) {
         const uint32_t li = idx >> 2;
         const uint32_t o = A.order[li < nA ? li : (uint32_t)bandTiles - 1u - (li - nA)];
-        k2_shade_body<false, false, ROLE_BAND_SPLIT, PREP>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, (int)(o & 0xFFFFu), (int)(o >> 16),
+        k2_shade_body<false, false, ROLE_BAND_SPLIT, PREP, TL>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, (int)(o & 0xFFFFu), (int)(o >> 16),
                                                            (int)(idx & 3u));
         __syncthreads(); // the LDS arrays are reused by the block's next tile
     }
 }
 
-#define SHADE_BAND_ENTRY(NAME, PREP)                                                                                                                                 \
+#define SHADE_BAND_ENTRY(NAME, PREP, TL)                                                                                                                               \
     __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))                                                                                     \
     void NAME(ShadeArgs A, CsmArgs C, int bandTiles, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,        \
               const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)                                         \
     {                                                                                                                                                                \
         __shared__ ShadeLds lds;                                                                                                                                     \
-        k2_shade_band_body<PREP>(lds, A, C, bandTiles, surface, planeStride, lights, grid, culled, radiance);                                                        \
+        k2_shade_band_body<PREP, TL>(lds, A, C, bandTiles, surface, planeStride, lights, grid, culled, radiance);                                                        \
     }
-SHADE_BAND_ENTRY(k2_shade_band, false)
-SHADE_BAND_ENTRY(k2_shade_band_p, true)
+SHADE_BAND_ENTRY(k2_shade_band, false, false)
+SHADE_BAND_ENTRY(k2_shade_band_p, true, false)
+SHADE_BAND_ENTRY(k2_shade_band_t, false, true)
+SHADE_BAND_ENTRY(k2_shade_band_pt, true, true)
 
 // ---- sailor_hip_prepare_lights: the per-light half of the path, once per UPLOADED light instead of once per frame and list slot ----
 // One lane per light of [first, first + count): the cull's 20-byte view of it -- (worldPosition, bounds.x) as a float4 and the type, two dense
@@ -277,7 +281,6 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
     A.fbRows = band->fbRowCount;
     A.lightsNum = lightsNum;
     A.order = dTileOrder;
-    A.tileNum = dTileNum;
     const int bandTiles = (band->tileRowEnd - band->tileRowBegin) * A.Tx;
     if (bandTiles == 0) return SAILOR_HIP_OK;
 
@@ -313,15 +316,21 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
     // with prepared lights the kernels' `lights` argument is the staged array (LREC float4 per light)
     const SailorLightShaderData* L = dLights;
     if (dPreparedLights) L = reinterpret_cast<const SailorLightShaderData*>((const char*)dPreparedLights + prepared_layout(preparedCapacity).offStaged);
-#define LAUNCH_SHADE(K) do { if (dPreparedLights) sailor_launch(ctx, K##_p, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd); \
-                             else sailor_launch(ctx, K, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd); } while (0)
+    // (tile lists: the kernels' `grid` argument is tileNum, their `culled` the per-tile slots -- see k2_shade_body)
+    const SailorLightsGrid* G = dTileNum ? reinterpret_cast<const SailorLightsGrid*>(dTileNum) : dLightsGrid;
+#define LAUNCH_SHADE(K) do { if (dPreparedLights && dTileNum) sailor_launch(ctx, K##_pt, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); \
+                             else if (dPreparedLights) sailor_launch(ctx, K##_p, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); \
+                             else if (dTileNum) sailor_launch(ctx, K##_t, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); \
+                             else sailor_launch(ctx, K, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } while (0)
     if (hasCsm && ibl) LAUNCH_SHADE(k2_shade_csm_ibl);
     else if (hasCsm) LAUNCH_SHADE(k2_shade_csm);
     else if (ibl) LAUNCH_SHADE(k2_shade_ibl);
     else if (dTileOrder && band->tileRowEnd - band->tileRowBegin < Ty) { // a band of a split frame: long tiles are split across four blocks
         const dim3 bgrid((unsigned)SPLIT_BLOCKS + (unsigned)bandTiles);
-        if (dPreparedLights) sailor_launch(ctx, k2_shade_band_p, bgrid, dim3(256), A, C, bandTiles, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd);
-        else sailor_launch(ctx, k2_shade_band, bgrid, dim3(256), A, C, bandTiles, S, surfacePlaneStride, L, dLightsGrid, dCulledLights, Rd);
+        if (dPreparedLights && dTileNum) sailor_launch(ctx, k2_shade_band_pt, bgrid, dim3(256), A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
+        else if (dPreparedLights) sailor_launch(ctx, k2_shade_band_p, bgrid, dim3(256), A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
+        else if (dTileNum) sailor_launch(ctx, k2_shade_band_t, bgrid, dim3(256), A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
+        else sailor_launch(ctx, k2_shade_band, bgrid, dim3(256), A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
     } else LAUNCH_SHADE(k2_shade);
 #undef LAUNCH_SHADE
     SAILOR_CHECK_LAUNCH(ctx, "k2_shade");

@@ -36,9 +36,6 @@ struct ShadeArgs {
     int bandTileRows; // band.tileRowEnd - band.tileRowBegin
     int lightsNum;
     const uint32_t* order; // sailor_hip_light_cull_tile_order or null
-    const uint32_t* tileNum; // null: `grid` / `culled` are the reference's lightsGrid / culledLights.  Else the cull's own per-tile form
-                             // (sailor_hip_light_cull_tile_lists): the list of band tile t is culled[128 t ..], its length tileNum[t] -- same
-                             // entries in the same order, available as soon as k1_tile_cull has run (k1_pack is then off the frame's critical path)
 };
 
 // ---- K3: canonical-order helpers (must match oracle/sailor_oracle.c bit for bit) -----------------------------
@@ -425,7 +422,11 @@ struct ShadeLds {
 #define ROLE_BAND_SPLIT 2 // one block per (long tile, quadrant)
 // PREPARED: `lights` points at the staged records sailor_hip_prepare_lights wrote (LREC float4 per light, indexed like the `light` SSBO) instead of
 // at the SSBO itself: a list slot is then five 16-byte loads and five LDS stores -- no arithmetic on the path the block's other waves wait for.
-template <bool HAS_CSM, bool HAS_IBL, int ROLE = ROLE_TILE, bool PREPARED = false>
+// TILE_LISTS: `grid` / `culled` are not the reference's lightsGrid / culledLights but the cull's own per-tile form (sailor_hip_light_cull_tile_lists):
+// `grid` points at tileNum (uint32 per band tile), the list of band tile t is culled[128 t ..] -- the same entries in the same order, available as
+// soon as k1_tile_cull has run (k1_pack is then off the frame's critical path).  A template parameter, not a run-time switch: as a kernel-argument
+// branch it cost every wave 12 scalar + 4 vector instructions (SQ counters, round 4).
+template <bool HAS_CSM, bool HAS_IBL, int ROLE = ROLE_TILE, bool PREPARED = false, bool TILE_LISTS = false>
 __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, const IblArgs& I, const float4* __restrict__ surface, size_t planeStride,
                                                  const SailorLightShaderData* __restrict__ lights,
                                                  const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled,
@@ -479,7 +480,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     // invariants -- which wait for the surface only -- are computed while the light records are in flight; and the workgroup barrier that
     // publishes the staged records waits for LDS only, not for outstanding global loads.
     SailorLightsGrid g; // Standard.shader:422-423
-    if (A.tileNum) { g.offset = (uint32_t)bandTile * (uint32_t)KEEP; g.num = A.tileNum[bandTile]; } // (kernel-argument-uniform: a scalar branch)
+    if constexpr (TILE_LISTS) { g.offset = (uint32_t)bandTile * (uint32_t)KEEP; g.num = reinterpret_cast<const uint32_t*>(grid)[bandTile]; }
     else g = grid[bandTile];
     // unconditional surface loads (lanes outside the frame read pixel 0 of the band and are masked out of every ballot and of the store)
     // (streamed once: non-temporal, so that what every tile reads again -- lists, light records, the next frame's depth and masks -- keeps its

@@ -24,9 +24,9 @@ rocprofv3 --kernel-trace --output-format csv -d $OUT/pipeband -- python3 $B --st
 cd $GRAFT_REPO_ROOT
 python3 scripts/make_traffic_json.py $OUT/fetch $OUT/write $OUT/traffic.json C3 > /dev/null
 python3 scripts/make_traffic_json.py $OUT/fetch4 $OUT/write4 $OUT/traffic_C4.json C4 > /dev/null
-python3 scripts/pmc_summary.py $OUT/sq k2_shade_p > $OUT/pmc_shade.txt
+python3 scripts/pmc_summary.py $OUT/sq k2_shade_pt > $OUT/pmc_shade.txt
 python3 scripts/pmc_summary.py $OUT/sq tile_cull > $OUT/pmc_tile_cull.txt
-python3 scripts/pmc_summary.py $OUT/sq4 k2_shade_csm_p > $OUT/pmc_shade_csm_C4.txt
+python3 scripts/pmc_summary.py $OUT/sq4 k2_shade_csm_pt > $OUT/pmc_shade_csm_C4.txt
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cp $(find $OUT/stats4 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_C4.csv
 cp $(find $OUT/stats5 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_C5.csv

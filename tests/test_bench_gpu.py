@@ -30,7 +30,7 @@ def test_default_line_carries_the_contract():
     assert d["config"]["workload"].startswith("C3: 3840x2160, 65536 ") and "model" not in d["config"]
     assert abs(d["value"] - 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k2_shade_p"   # the prepared-lights entry point: the default path
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k2_shade_pt"   # prepared lights, lists from the cull's per-tile slots: the default path
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.05 < r["frac"] < 1.0
     assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["traffic"] is None or r["traffic"] > 0.9 * r["bytes_per_launch"]

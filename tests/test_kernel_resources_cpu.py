@@ -56,7 +56,7 @@ def resources(tmp_path_factory):
     return res
 
 
-@pytest.mark.parametrize("name", ["k2_shade", "k2_shade_p"])
+@pytest.mark.parametrize("name", ["k2_shade", "k2_shade_p", "k2_shade_t", "k2_shade_pt"])
 def test_k2_shade_fits_64_registers_without_scratch(resources, name):
     k = find(resources["shade"], name)
     assert k["vgpr_count"] <= 64 and waves_per_simd(k["vgpr_count"]) == 8
@@ -65,7 +65,7 @@ def test_k2_shade_fits_64_registers_without_scratch(resources, name):
     assert 8 * k["group_segment_fixed_size"] <= 160 * 1024
 
 
-@pytest.mark.parametrize("name", ["k2_shade_csm", "k2_shade_csm_p"])
+@pytest.mark.parametrize("name", ["k2_shade_csm", "k2_shade_csm_p", "k2_shade_csm_t", "k2_shade_csm_pt"])
 def test_k2_shade_csm_fits_64_registers_without_scratch(resources, name):
     """The K3 kernels run their shadow look-ups before the view / material terms exist ("K3 first", shade_body.h) and so fit 8 waves per SIMD; with
     24 bytes of scratch the same kernel was 310 us instead of 262 on C4 -- so no scratch at all."""
@@ -74,14 +74,14 @@ def test_k2_shade_csm_fits_64_registers_without_scratch(resources, name):
     assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0
 
 
-@pytest.mark.parametrize("name", ["k2_shade_csm_ibl", "k2_shade_csm_ibl_p"])
+@pytest.mark.parametrize("name", ["k2_shade_csm_ibl", "k2_shade_csm_ibl_p", "k2_shade_csm_ibl_pt"])
 def test_k2_shade_csm_ibl_keeps_five_waves_per_simd(resources, name):
     k = find(resources["shade"], name)
     assert k["vgpr_count"] <= 96 and waves_per_simd(k["vgpr_count"]) >= 5
     assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0
 
 
-@pytest.mark.parametrize("name", ["k2_shade_band", "k2_shade_band_p"])
+@pytest.mark.parametrize("name", ["k2_shade_band", "k2_shade_band_p", "k2_shade_band_pt"])
 def test_k2_shade_band_stays_at_eight_waves(resources, name):
     k = find(resources["shade"], name)
     assert k["vgpr_count"] <= 64
