@@ -1127,9 +1127,11 @@ __device__ __forceinline__ void block_select(const CullArgs& a, const int firstB
     }
 }
 
-// COOP: the band form (bands of a split frame: a band IS its longest block).  Tiles with more than 128 candidates get their selection from the whole
-// block (block_select) behind a barrier every block pays; the whole frame hides such a block behind its other 8 000 and keeps the per-wave form, whose
-// throughput phase the barrier would cost 15 % of at 8K (measured: k1_tile_cull on C5 99 -> 114 us, on a cluster band of an 8-way split 14.7 -> 9.7).
+// COOP: tiles with more than 128 candidates get their selection from the whole block (block_select: 2.8 us a tile) behind a barrier every block pays,
+// instead of from their own wave (emit_list: ~11 us on a block's lone wave -- the launch's tail, profiles/r04/cull_block_timeline.txt: blocks with ONE
+// full tile that start 10-20 us into the launch and end at 24-29 while 99 % of the blocks are done at 22).  On for the 4K frame and its bands (a band
+// IS its longest block: k1_tile_cull 14.7 -> 9.7 us on a cluster band of an 8-way split), off on the wide path's 420-candidate lists (8K, a million
+// lights: no listed clusters, seven test steps per tile, and the barrier costs the throughput phase 15 %: 99 -> 114 us).
 template <bool COOP>
 __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
 {
@@ -1535,7 +1537,8 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
             ca.headRows = (16 * HEAVY_MAX + L.groupsX - 1) / L.groupsX; // grid rows for the listed clusters' tiles (a block each), in front of the tile rows
         }
         SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
-        if (L.bandRows * 2 > L.Ty) sailor_launch(ctx, k1_tile_cull<false>, dim3(L.groupsX, ca.headRows + L.bandRows), dim3(256), ca);
+        // (the block-wide selection everywhere but on the long lists of the wide path: see k1_tile_cull)
+        if (ca.headRows == 0) sailor_launch(ctx, k1_tile_cull<false>, dim3(L.groupsX, ca.headRows + L.bandRows), dim3(256), ca);
         else sailor_launch(ctx, k1_tile_cull<true>, dim3(L.groupsX, ca.headRows + L.bandRows), dim3(256), ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
     }
