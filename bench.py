@@ -102,6 +102,13 @@ class HipDevice:
     def __init__(self, local_rank: int):
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a HIP device: the path has no CPU fallback")
+        # SAILOR_BENCH_SHARE_GPU=1 (diagnostic, 1-GPU boxes): every rank of an N > 1 run takes device 0 and the process group is `gloo` -- RCCL refuses two
+        # ranks on one device, so the communicator of the shipped exchange is not created either and the ranks agree on the torch.distributed
+        # exchange.  The ranks time-share the GPU: the throughput means nothing, but the N > 1 path runs for real on a GPU (band kernels,
+        # calibration, re-split, exchange, every collective of main()): tests/test_bench_gpu.py::test_two_ranks_sharing_the_gpu.
+        if os.environ.get("SAILOR_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
+            self.dist_backend = "gloo"
         torch.cuda.set_device(local_rank)
         self.device = torch.device("cuda", local_rank)
         self._comm = None
@@ -157,6 +164,8 @@ class HipDevice:
         from sailor_amd import dist as sdist
         ok = 1
         try:
+            if self.dist_backend != "nccl":
+                raise RuntimeError("the ranks share one device (SAILOR_BENCH_SHARE_GPU): RCCL takes one rank per device")
             self._comm = sdist.RcclComm(rank, world)
         except Exception as e:
             ok = 0
@@ -167,7 +176,7 @@ class HipDevice:
             if self._comm is not None:
                 self._comm.close()
             self._comm = None
-            self.exchange_how = "sailor_amd.dist.exchange_lists over torch.distributed (nccl = RCCL): the C-ABI exchange's own communicator could not be created on every rank"
+            self.exchange_how = f"sailor_amd.dist.exchange_lists over torch.distributed ({self.dist_backend}): the C-ABI exchange's own communicator could not be created on every rank"
 
     def exchange(self, ctx, W, H, bounds, fp):
         """this rank's band lists -> the frame's canonical (lightsGrid, culledLights) on every rank: sailor_hip_exchange_light_lists_rows"""

@@ -35,6 +35,8 @@ python3 scripts/analysis/pipeline_timeline.py $(find $OUT/pipeband -name "*kerne
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --config C4 --no-cpu-baseline > $OUT/bench_C4.json 2> $OUT/bench_C4.err
 python3 bench.py --config C5 --no-cpu-baseline --steps 20 > $OUT/bench_C5.json 2> $OUT/bench_C5.err
+# N > 1 as the driver types it, on this ONE-GPU box: the ranks share device 0 over gloo (figures meaningless; the path and the exchanged lists are real)
+for G in 2 4; do SAILOR_BENCH_SHARE_GPU=1 python3 bench.py --gpus $G --steps 12 --no-cpu-baseline > $OUT/bench_${G}ranks_sharing_one_gpu.json 2> $OUT/bench_${G}ranks_sharing_one_gpu.err; done
 for G in 2 4 8; do python3 bench.py --simulate-split $G --steps 30 > $OUT/simulate_split$G.json 2> $OUT/simulate_split$G.err; done
 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/cull_prof.py > $OUT/cull_block_timeline.txt 2>&1
 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/cull_prof.py 2/8 > $OUT/cull_block_timeline_band2of8.txt 2>&1

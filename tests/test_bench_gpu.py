@@ -72,6 +72,28 @@ def test_one_rank_process_group_runs_both_multi_gpu_modes(split_primary):
     assert d["step_ms"]["p10"] <= d["step_ms"]["median"] <= d["step_ms"]["p90"]
 
 
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_ranks_sharing_the_gpu_run_the_split_frame_for_real(ranks):
+    """`python bench.py --gpus N` as the driver types it (no launcher: bench.py starts its ranks itself), N > 1, on a ONE-GPU box: with
+    SAILOR_BENCH_SHARE_GPU=1 every rank takes device 0 over a `gloo` group.  The figures mean nothing (the ranks time-share the device); the path is the
+    real one -- calibration cull, cost-balanced re-split, band kernels inside the pipeline graph, every collective of main(), the list exchange -- and the
+    exchanged global lists must be the ones a single rank holds for the whole frame."""
+    common = ["--steps", "6", "--warmup", "2", "--spinup-ms", "50", "--no-cpu-baseline"]
+    env1 = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = _run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--no-afr"] + common, env1)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SAILOR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    d = _run([sys.executable, "bench.py", "--gpus", str(ranks)] + common, env)
+    assert d["n_gpus"] == ranks and d["scaling"] == "strong" and d["steps"] == 6 and f"tile-row bands x{ranks}" == d["config"]["parallelism"]
+    bounds = d["exchange"]["tile_row_bounds"]
+    assert len(bounds) == ranks + 1 and bounds[0] == 0 and bounds[-1] == 135 and all(a < b for a, b in zip(bounds, bounds[1:])) and "cost-balanced" in d["config"]["partition"]
+    assert abs(d["value"] - 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]      # ONE frame per step, whatever the rank count
+    for key in ("tiles", "global_sum_num", "checksum"):                                             # the frame's lists, rebuilt from the bands == one rank's whole frame
+        assert d["exchange"][key] == one["exchange"][key], key
+    assert "torch.distributed (gloo)" in d["exchange"]["how"]                                       # RCCL takes one rank per device: all ranks agreed on the fallback
+    assert d["alternate_frame_rendering"]["value"] > 0 and "error" not in d["alternate_frame_rendering"]
+
+
 @pytest.mark.parametrize("sets, steps", [(3, 12), (2, 8)])
 def test_step_counts_the_list_sets_divide_run_one_pipeline_graph(sets, steps):
     d = _run([sys.executable, "bench.py", "--steps", str(steps), "--warmup", "2", "--spinup-ms", "50", "--no-cpu-baseline", "--list-sets", str(sets)])
