@@ -770,8 +770,10 @@ def simulate_split(args, dev, ctx, side, frame, d_lights, fp_full, d_depth_full,
             f.shade(cam.frame, ds, d_lights, N, None)
         dev.synchronize()
         if unroll:
+            defer = not args.pack_inline   # as the main path records it: k1_pack behind the event the shade waits for, on the cull's own stream
             graph = capture_frame_pipeline(side, side2, unroll, [lambda f=f: f.shade(cam.frame, ds, d_lights, N, None) for f in fs],
-                                           [lambda f=f: f.cull(cam.frame, d_lights, N, dd, ctx=ctx2) for f in fs], dev)
+                                           [lambda f=f: f.cull(cam.frame, d_lights, N, dd, ctx=ctx2, defer_pack=defer) for f in fs], dev,
+                                           [lambda f=f: f.pack(ctx2) for f in fs] if defer else None, side2)
             fs[0].cull(cam.frame, d_lights, N, dd)
             per = unroll
         else:
@@ -955,6 +957,7 @@ def main(argv=None, device_factory=None):
     unroll, tail = pipeline_unroll(args.steps, args.list_sets)
     # (round 4) the shade reads the cull's per-tile lists, so the compaction into the reference's lightsGrid / culledLights (k1_pack) is off the
     # frame's path: recorded on a third stream behind its cull -- every frame still produces both canonical buffers.  --pack-inline: rounds 1-3's form.
+    # (a band's shade takes its long tiles from the order hint: written by k1_tile_cull, not by k1_pack, so the band's pack is deferred like the frame's)
     defer_pack = not args.pack_inline and hasattr(fp, "pack")
     side2 = dev.stream(priority=int(os.environ.get('SAILOR_CULL_PRIORITY', '0')))
     ctx2 = dev.context(side2)

@@ -65,12 +65,17 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // command processor's own timestamps of that kernel, i.e. what rocprofv3's kernel trace reports, read live and without draining the stream
 // around the kernel as an event recorded in front of and behind it does.
 template <typename K, typename... Args>
-static inline void sailor_launch(SailorHipContext* ctx, K kernel, const dim3 grid, const dim3 block, Args... args)
+static inline void sailor_launch_lds(SailorHipContext* ctx, K kernel, const dim3 grid, const dim3 block, const unsigned dynamicLdsBytes, Args... args)
 {
     if (ctx->timeNext < ctx->timeEnd) {
         const int i = ctx->timeNext++;
-        hipExtLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ctx->timeStart[i], ctx->timeStop[i], 0, args...);
-    } else hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, args...);
+        hipExtLaunchKernelGGL(kernel, grid, block, dynamicLdsBytes, ctx->stream, ctx->timeStart[i], ctx->timeStop[i], 0, args...);
+    } else hipLaunchKernelGGL(kernel, grid, block, dynamicLdsBytes, ctx->stream, args...);
+}
+template <typename K, typename... Args>
+static inline void sailor_launch(SailorHipContext* ctx, K kernel, const dim3 grid, const dim3 block, Args... args)
+{
+    sailor_launch_lds(ctx, kernel, grid, block, 0u, args...);
 }
 
 // ---- canonical fp32 helpers: this library is compiled with -ffp-contract=off, so the

@@ -172,6 +172,7 @@ struct PrepareArgs {
     float4* lightView; uint32_t* lightType; float4* tileInfo;
     unsigned long long* masks; unsigned long long* dirWords;
     uint32_t* heavy;   // [0]: k1_group_lists' count of light-cluster groups, zeroed here (one launch ahead of it)
+    uint32_t* orderCounts; // the shading hint's two class counts (tileOrder[T], [T + 1]; null: whole frame, no hint), zeroed here for k1_tile_cull
     uint32_t* dirFlag; // "some light may be directional": set here, read by k1_group_lists_wide, cleared by k1_tile_cull (unknown before the first cull: then merely conservative)
     int N, words, lightBlocks, lightRoleBlocks, frustumBlocks, bandsPerBlock, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands,
         stripsPerRow, vecOK, rawDepth, intervals;
@@ -453,7 +454,10 @@ __global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K01_PREPARE];
     const int b = (int)blockIdx.x;
-    if (b == 0 && threadIdx.x == 0) a.heavy[0] = 0u;
+    if (b == 0 && threadIdx.x == 0) {
+        a.heavy[0] = 0u;
+        if (a.orderCounts) { a.orderCounts[0] = 0u; a.orderCounts[1] = 0u; }
+    }
     if (b < a.lightRoleBlocks) k0_lights(b, lds, a);
     else if (b < a.lightRoleBlocks + a.frustumBlocks) k1_tile_frusta(b - a.lightRoleBlocks, a);
     else k1_tile_setup(b - a.lightRoleBlocks - a.frustumBlocks, lds, a);
@@ -757,13 +761,13 @@ __device__ __forceinline__ void test_candidates(const TileCtx& t, const float4* 
 // Tile classes for the shading hint (sailor_hip_light_cull_tile_order): A = lists of >= CLASS_A entries, B = >= CLASS_B.
 #define CLASS_A 96u
 #define CLASS_B 40u
-__device__ __forceinline__ uint32_t tile_class_word(uint32_t num) { return num >= CLASS_A ? 0x10000u : (num >= CLASS_B ? 1u : 0u); }
 
 struct CullArgs {
     const float4* lightView; const uint32_t* lightType; const float4* tileInfo;
     const unsigned long long* masks; const uint32_t* groupCount; const uint32_t* groupList;
     uint32_t* tileNum; uint8_t* tileNum8; uint32_t* tileLists; uint32_t* dirFlag;
     int N, words, Tx, groupsX, bandRows;
+    uint32_t* tileOrder; int bandTiles; // the shading hint (null: none): see publish_tile
     const uint32_t* heavy; int headRows; // k1_group_lists' cluster list and the grid rows in front of the tile rows that take its tiles (0: none)
 };
 
@@ -938,10 +942,25 @@ __device__ __forceinline__ void walk_tile_masks(const TileCtx& t, const CullArgs
 // What a tile leaves behind besides its list: the length.  (Measured and dropped: the length also added to a per-tile-row total with a relaxed
 // device-scope atomic, for k1_pack's offsets -- 32 400 atomics on 135 words = five cache lines serialise at the memory side: k1_tile_cull 26 ->
 // 140 us.  k1_pack adds up the lengths of the tiles in front of its own instead: 64 KB of L2 reads per block on average.)
-__device__ __forceinline__ void publish_tile(const CullArgs& a, const int bandTile, const uint32_t num)
+// The shading hint of a band (sailor_hip_light_cull_tile_order): the tiles with >= CLASS_A entries from the front of tileOrder, those with >= CLASS_B from
+// its back, the two counts behind the T slots.  Appended HERE since round 4 (k1_pack wrote it through round 3, in tile order): the band's shade kernel
+// takes its long tiles from this array, and it must not have to wait for k1_pack.  The order within a class is whatever the atomics make it -- it decides
+// which block shades a tile, not what comes out -- and only the band's few hundred long tiles draw one (a whole frame has no hint).  Cost: ~3 us on the
+// kernel (the round trip of the last tiles' atomics), against the ~5 us of k1_pack that leave the band's chain.
+__device__ __forceinline__ uint32_t publish_tile(const CullArgs& a, const int bandTile, const uint32_t num)
 {
     a.tileNum[bandTile] = num;
     a.tileNum8[bandTile] = (uint8_t)num;
+    uint32_t pos = 0u;
+    if (a.tileOrder && num >= CLASS_B) pos = __hip_atomic_fetch_add(a.tileOrder + (uint32_t)a.bandTiles + (num >= CLASS_A ? 0u : 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return pos; // for publish_order, once the tile's list has left
+}
+__device__ __forceinline__ void publish_order(const CullArgs& a, const int bandTile, const uint32_t num, const uint32_t pos)
+{
+    if (a.tileOrder && num >= CLASS_B) {
+        const int tyLocal = bandTile / a.Tx, tx = bandTile - tyLocal * a.Tx;
+        a.tileOrder[num >= CLASS_A ? pos : (uint32_t)a.bandTiles - 1u - pos] = (uint32_t)tx | ((uint32_t)tyLocal << 16);
+    }
 }
 
 // The selection's rank of candidate k (ComputeLightCulling.shader:198-225: the partial bubble sort == rank under (impact ascending, candidate position
@@ -1029,10 +1048,12 @@ __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* _
     const uint32_t all = (c0 + c1) + (c2 + c3), n = all < CAND ? all : CAND, num = n < KEEP ? n : KEEP;
     for (uint32_t i = lane; i < sCnt[wave] && before + i < CAND; i += 64) sAll[before + i] = sIdx[i];
     __syncthreads();
-    if (threadIdx.x == 0) publish_tile(a, bandTile, num);
+    uint32_t pos = 0u;
+    if (threadIdx.x == 0) pos = publish_tile(a, bandTile, num); // (the entry in the hint is completed at each way out, behind the list)
     uint32_t* __restrict__ out = a.tileLists + (size_t)bandTile * KEEP;
     if (n <= KEEP) { // :235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]
         if (threadIdx.x < n) out[threadIdx.x] = sAll[n - 1 - threadIdx.x] & 0x7FFFFFFFu;
+        if (threadIdx.x == 0) publish_order(a, bandTile, num, pos);
         return;
     }
     // ---- 196 -> 128 (ComputeLightCulling.shader:198-225): one candidate per thread
@@ -1048,11 +1069,13 @@ __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* _
     __syncthreads();
     if (sCnt[4] != 0u) { // a NaN impact has no rank: the literal bubble sort, on one wave (emit_list)
         if (wave == 0) emit_list(t, n, sAll, sImp, lightView, out);
+        if (threadIdx.x == 0) publish_order(a, bandTile, num, pos);
         return;
     }
     if (k >= n) return;
     const uint32_t rank = rank_among(sImp, n, k, imp);
     if (rank < KEEP) out[rank] = mine & 0x7FFFFFFFu;
+    if (threadIdx.x == 0) publish_order(a, bandTile, num, pos); // (thread 0 holds candidate 0 < n: it comes this way)
 }
 
 // The validation path (SAILOR_CULL_BRUTE_FORCE; also tiny light sets and odd projections): no pre-filter, no staging, no cooperation between
@@ -1076,8 +1099,10 @@ __global__ __launch_bounds__(256) void k1_tile_cull_brute(const CullArgs a)
         test_candidates(t, a.lightView, a.lightType, j < a.N, (uint32_t)j, count, sIdxAll[wave]);
     }
     const uint32_t n = count < CAND ? count : CAND;
-    if (lane == 0) publish_tile(a, bandTile, n < KEEP ? n : KEEP);
+    uint32_t pos = 0u;
+    if (lane == 0) pos = publish_tile(a, bandTile, n < KEEP ? n : KEEP);
     emit_list(t, n, sIdxAll[wave], sImpAll[wave], a.lightView, a.tileLists + (size_t)bandTile * KEEP);
+    if (lane == 0) publish_order(a, bandTile, n < KEEP ? n : KEEP, pos);
 }
 
 // The 196 -> 128 selections of a block's tiles by the WHOLE block (ComputeLightCulling.shader:198-225): one candidate per thread and tile.  sIdxAll[w]:
@@ -1215,7 +1240,8 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     }
     PROF_T(1);
     const uint32_t n = count < CAND ? count : CAND; // (0 for a wave beyond the last tile column)
-    if (active && lane == 0) publish_tile(a, bandTile, n < KEEP ? n : KEEP);
+    uint32_t pos = 0u;
+    if (active && lane == 0) pos = publish_tile(a, bandTile, n < KEEP ? n : KEEP);
     // The tile's list into the tile's own slot: k1_pack moves it to its canonical place, the shade reads it where it is.
     if (!COOP || gn == GROUP_OVERFLOW) { // (an overflowed group's staging area is the waves' queues: every wave selects for itself)
         // a tile with more than 128 candidates selects on its own wave (emit_list: ~9 us)
@@ -1233,6 +1259,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
         if (((sCnt[0] > (uint32_t)KEEP) | (sCnt[1] > (uint32_t)KEEP)) | ((sCnt[2] > (uint32_t)KEEP) | (sCnt[3] > (uint32_t)KEEP))) // (block-uniform)
             block_select(a, tyLocal * Tx + gx * GROUP, sCnt, sIdxAll, sImpAll, sCnt + 4);
     }
+    if (active && lane == 0) publish_order(a, bandTile, n < KEEP ? n : KEEP, pos);
     PROF_T(3);
 }
 
@@ -1244,15 +1271,15 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
 // ------------------------------------------------------------------------------------------------------------
 struct PackArgs {
     const uint32_t* tileNum; const uint8_t* tileNum8; const uint32_t* tileLists;
-    SailorLightsGrid* grid; uint32_t* culled; uint32_t* tileOrder;
-    int Tx, bandRows, bandTiles, classes;
+    SailorLightsGrid* grid; uint32_t* culled;
+    int Tx, bandRows, bandTiles;
     uint32_t capacity;
 };
 
 __global__ __launch_bounds__(256) void k1_pack(const PackArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t sBuf[PACK_TILES * KEEP]; // 32 KB: the block's lists, back to back
-    __shared__ uint32_t sPart[4], sPartC[4];
+    __shared__ uint32_t sPart[4];
     __shared__ uint32_t sPre[PACK_TILES], sNum[PACK_TILES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t0 = (int)blockIdx.x * PACK_TILES;
@@ -1263,7 +1290,7 @@ __global__ __launch_bounds__(256) void k1_pack(const PackArgs a)
     if (have) num = a.tileNum[tile];
     // entries (and class counts) of every tile before t0 (a multiple of 64): the lengths as BYTES, sixteen tiles per 16-byte load, four loads in flight
     // per thread -- at most 32 KB at 4K, L2-resident (v_sad_u8 adds the four bytes of a word to the accumulator)
-    uint32_t acc = 0u, accC = 0u;
+    uint32_t acc = 0u;
     {
         const uint4* __restrict__ v4 = reinterpret_cast<const uint4*>(a.tileNum8);
         const int count4 = t0 / 16;
@@ -1277,20 +1304,15 @@ __global__ __launch_bounds__(256) void k1_pack(const PackArgs a)
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     acc = __builtin_amdgcn_sad_u8(w[c], 0u, acc);
-                    if (a.classes) {
-#pragma unroll
-                        for (int b = 0; b < 4; b++) accC += tile_class_word((w[c] >> (8 * b)) & 0xFFu);
-                    }
                 }
             }
         }
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { acc += (uint32_t)__shfl_xor((int)acc, d, 64); accC += (uint32_t)__shfl_xor((int)accC, d, 64); }
-    if (lane == 0) { sPart[wave] = acc; sPartC[wave] = accC; }
+    for (int d = 32; d > 0; d >>= 1) acc += (uint32_t)__shfl_xor((int)acc, d, 64);
+    if (lane == 0) sPart[wave] = acc;
     __syncthreads();
     const uint32_t baseSum = (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]);
-    const uint32_t baseCls = (sPartC[0] + sPartC[1]) + (sPartC[2] + sPartC[3]);
     if (wave == 0) {
         // the 64 tiles: offset = 1 + entries of all earlier tiles
         uint32_t tincl = num;
@@ -1309,28 +1331,6 @@ __global__ __launch_bounds__(256) void k1_pack(const PackArgs a)
             a.grid[tile].num = fit;
         }
         const bool last = t0 + PACK_TILES >= a.bandTiles;
-        if (a.classes) {
-            // the shading hint: class A tiles from the front of the array, class B tiles from its back, both in tile order
-            const uint32_t mine = tile_class_word(num);
-            uint32_t c = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t uc = (uint32_t)__shfl_up((int)c, d);
-                if (lane >= d) c += uc;
-            }
-            const uint32_t cb = baseCls + c - mine; // class counts of all earlier tiles
-            const uint32_t aBefore = cb >> 16, bBefore = cb & 0xFFFFu;
-            const uint32_t T = (uint32_t)a.bandTiles;
-            if (have && num >= CLASS_B) {
-                const int tyLocal = tile / a.Tx, tx = tile - tyLocal * a.Tx;
-                a.tileOrder[num >= CLASS_A ? aBefore : T - 1u - bBefore] = (uint32_t)tx | ((uint32_t)tyLocal << 16);
-            }
-            if (last && lane == 63) { // the last block: the two counts
-                const uint32_t all = cb + mine;
-                a.tileOrder[T] = all >> 16;
-                a.tileOrder[T + 1u] = all & 0xFFFFu;
-            }
-        }
         if (last && lane == 63) { // Appendix A step 6: indices[0] = sum of num
             const uint32_t tot = baseSum + tincl;
             a.culled[0] = a.capacity ? min(tot, a.capacity - 1u) : 0u;
@@ -1394,10 +1394,8 @@ static int launch_pack(SailorHipContext* ctx, const CullLayout& L, char* ws, Sai
 {
     PackArgs ka;
     ka.tileNum = (const uint32_t*)(ws + L.offTileNum); ka.tileNum8 = (const uint8_t*)(ws + L.offTileNum8); ka.tileLists = (const uint32_t*)(ws + L.offTileLists);
-    ka.grid = dLightsGrid; ka.culled = dCulledLights; ka.tileOrder = (uint32_t*)(ws + L.offTileOrder);
+    ka.grid = dLightsGrid; ka.culled = dCulledLights;
     ka.Tx = L.Tx; ka.bandRows = L.bandRows; ka.bandTiles = L.bandTiles;
-    // The hint pays for itself on split frames (a band's shade launch is bounded by its longest tile); on the whole frame it measured nothing.
-    ka.classes = layout_has_hint(L) ? 1 : 0;
     ka.capacity = (uint32_t)(culledCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : culledCapacity);
     sailor_launch(ctx, k1_pack, dim3(L.packBlocks), dim3(256), ka);
     SAILOR_CHECK_LAUNCH(ctx, "k1_pack");
@@ -1507,6 +1505,7 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     pa.planeMargin = 1e-3f;
     pa.dirFlag = (uint32_t*)(ws + L.offDirFlag);
     pa.heavy = (uint32_t*)(ws + L.offHeavy);
+    pa.orderCounts = layout_has_hint(L) ? (uint32_t*)(ws + L.offTileOrder) + L.bandTiles : nullptr;
     sailor_launch(ctx, k01_prepare, dim3(pa.lightRoleBlocks + pa.frustumBlocks + pa.setupBlocks), dim3(256), pa);
     SAILOR_CHECK_LAUNCH(ctx, "k01_prepare");
 
@@ -1517,6 +1516,7 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     ca.dirFlag = pa.dirFlag;
     ca.N = N; ca.words = L.words; ca.Tx = L.Tx; ca.groupsX = L.groupsX; ca.bandRows = L.bandRows;
     ca.heavy = (const uint32_t*)(ws + L.offHeavy); ca.headRows = 0;
+    ca.tileOrder = layout_has_hint(L) ? (uint32_t*)(ws + L.offTileOrder) : nullptr; ca.bandTiles = L.bandTiles;
     if (brute) {
         sailor_launch(ctx, k1_tile_cull_brute, dim3(L.groupsX, L.bandRows), dim3(256), ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull<brute>");

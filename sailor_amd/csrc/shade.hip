@@ -55,6 +55,24 @@ SHADE_ENTRIES(_p, true, false)
 SHADE_ENTRIES(_t, false, true)
 SHADE_ENTRIES(_pt, true, true)
 
+// make EXTRA=-DSHADE_PROF + scripts/shade_prof.py: start / end of every block of the band kernel on the 100 MHz constant clock, its XCD and hardware id
+#ifdef SHADE_PROF
+__device__ unsigned long long g_shadeProf[65536][4];
+extern "C" __attribute__((visibility("default"))) int sailor_hip_debug_read_shade_prof(void* dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_shadeProf), bytes);
+}
+__device__ __forceinline__ void sprof_mark(const int i)
+{
+    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long h = ((unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    if (threadIdx.x == 0 && blockIdx.x < 65536) { g_shadeProf[blockIdx.x][i] = t; if (i == 0) g_shadeProf[blockIdx.x][2] = h; }
+}
+#define SPROF_T(i) sprof_mark(i);
+#else
+#define SPROF_T(i)
+#endif
+
 template <bool PREP, bool TL>
 __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, int bandTiles, const float4* __restrict__ surface, size_t planeStride,
                                                    const SailorLightShaderData* __restrict__ lights, const SailorLightsGrid* __restrict__ grid,
@@ -62,9 +80,12 @@ __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArg
 {
     if (blockIdx.x >= (unsigned)SPLIT_BLOCKS) {
         const int t = (int)blockIdx.x - SPLIT_BLOCKS, ty = t / A.Tx;
+        SPROF_T(0)
         k2_shade_body<false, false, ROLE_BAND_TILE, PREP, TL>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, t - ty * A.Tx, ty, 0);
+        SPROF_T(3)
         return;
     }
+    SPROF_T(0)
     // the cull's hint: order[0 .. nA) = the tiles with >= 96 lights, order[T-1], order[T-2] .. = the nB tiles with 40..95, order[T] = nA, order[T+1] = nB
     const uint32_t nA = A.order[bandTiles], limit = 4u * (nA + A.order[bandTiles + 1]);
     for (uint32_t idx = blockIdx.x; idx < limit; idx += (uint32_t)SPLIT_BLOCKS) {
@@ -74,6 +95,7 @@ __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArg
                                                            (int)(idx & 3u));
         __syncthreads(); // the LDS arrays are reused by the block's next tile
     }
+    SPROF_T(3)
 }
 
 #define SHADE_BAND_ENTRY(NAME, PREP, TL)                                                                                                                               \
@@ -327,10 +349,15 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
     else if (ibl) LAUNCH_SHADE(k2_shade_ibl);
     else if (dTileOrder && band->tileRowEnd - band->tileRowBegin < Ty) { // a band of a split frame: long tiles are split across four blocks
         const dim3 bgrid((unsigned)SPLIT_BLOCKS + (unsigned)bandTiles);
-        if (dPreparedLights && dTileNum) sailor_launch(ctx, k2_shade_band_pt, bgrid, dim3(256), A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
-        else if (dPreparedLights) sailor_launch(ctx, k2_shade_band_p, bgrid, dim3(256), A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
-        else if (dTileNum) sailor_launch(ctx, k2_shade_band_t, bgrid, dim3(256), A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
-        else sailor_launch(ctx, k2_shade_band, bgrid, dim3(256), A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
+        // A band's shade does not take the whole chip: SHADE_BAND_RESERVE bytes of dynamic LDS that nobody touches cap it at six blocks (24 of 32 wave slots)
+        // per CU.  A split frame is a pipeline of short launches -- the NEXT frame's cull chain runs beside this kernel on another stream -- and with every wave
+        // slot taken by shade blocks each of the chain's four launches queues behind them: measured on 1/8 bands of the 4K frame, alone the kernel takes
+        // ~3 us longer (30 -> 33 us), the pipelined step ~8 us less (53 -> 45 us).  SAILOR_BAND_SHADE_LDS=<bytes> overrides (0: eight blocks).
+        static const unsigned bandLds = [] { const char* e = getenv("SAILOR_BAND_SHADE_LDS"); return e ? (unsigned)atoi(e) : (unsigned)SHADE_BAND_RESERVE; }();
+        if (dPreparedLights && dTileNum) sailor_launch_lds(ctx, k2_shade_band_pt, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
+        else if (dPreparedLights) sailor_launch_lds(ctx, k2_shade_band_p, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
+        else if (dTileNum) sailor_launch_lds(ctx, k2_shade_band_t, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
+        else sailor_launch_lds(ctx, k2_shade_band, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
     } else LAUNCH_SHADE(k2_shade);
 #undef LAUNCH_SHADE
     SAILOR_CHECK_LAUNCH(ctx, "k2_shade");

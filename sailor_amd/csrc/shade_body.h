@@ -407,6 +407,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
                  : "v56", "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc", "memory")
 
 #define SPLIT_MIN 40      // == CLASS_B of light_cull.hip: the hint's first two classes
+#define SHADE_BAND_RESERVE 9000 // bytes of untouched dynamic LDS per block of k2_shade_band*: six blocks per CU instead of eight (see its launch)
 #ifndef SPLIT_BLOCKS
 #define SPLIT_BLOCKS 2048 // one round of resident blocks (8 per CU)
 #endif

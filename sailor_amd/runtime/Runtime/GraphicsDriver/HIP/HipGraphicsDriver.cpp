@@ -539,8 +539,8 @@ int HipGraphicsDriver::RecordShade(const TVector<RHIShaderBindingSetPtr>& bindin
     const bool own = m_cullWorkspace && grid && culled && grid == m_ownGrid && culled == m_ownCulled && m_cullW == W && m_cullH == H &&
                      sailor_hip_light_cull_tile_lists(m_cullW, m_cullH, m_cullLights, band, m_cullWorkspace->m_hip.m_devicePtr, &tileNum, &tileLists) == SAILOR_HIP_OK;
     if (own) {
-        // (the tile-order hint is written by the pack step: a band's split blocks need it, so on a split frame the shade comes behind the pack)
-        if (order && m_packPending) { sailor_hip_context_wait_for(m_ctx, m_ctxAux); m_packPending = false; }
+        // (the tile-order hint a band's split blocks need is written by k1_tile_cull itself since round 4 -- through round 3 by the pack step, and a
+        // split frame's shade had to come behind it)
         return sailor_hip_shade_tile_lists(m_ctx, &frame, (const float*)surfaceB->m_buffer->m_hip.m_devicePtr, planeStride,
                                            (const SailorLightShaderData*)buffer_of(bindings[1], "light"), lightsNum, tileNum, tileLists,
                                            hasCsm ? &csm : nullptr, hasIbl ? &ibl : nullptr, (float*)buffer_of(bindings[2], "radiance"), band, order,

@@ -219,7 +219,7 @@ def test_c4_4k_with_cascaded_shadow_maps(ctx):
 
 def test_tile_order_hint_lists_the_long_tiles_and_they_are_split(ctx):
     """sailor_hip_light_cull_tile_order (split frames only): the band's tiles with >= 96 lights from the front of the array, those with
-    40..95 from its back (tile order both), then the two counts.  Shading a band with the hint hands
+    40..95 from its back, then the two counts (written by k1_tile_cull: also after a cull with a deferred pack).  Shading a band with the hint hands
     those tiles to the split blocks (four waves share one quadrant's list): tiles below 40 lights keep their bits, the split ones differ from
     the one-block form by the order of four partial sums only -- both within the radiance tolerance of the oracle."""
     import ctypes as C
@@ -244,8 +244,9 @@ def test_tile_order_hint_lists_the_long_tiles_and_they_are_split(ctx):
     n_a, n_b = int(order[T]), int(order[T + 1])
     assert n_a == (cls == 0).sum() and n_b == (cls == 1).sum()
     as_tile = lambda o: (o >> 16).astype(np.int64) * fp.Tx + (o & 0xFFFF)
-    np.testing.assert_array_equal(as_tile(order[:n_a]), np.nonzero(cls == 0)[0])
-    np.testing.assert_array_equal(as_tile(order[T - n_b:T][::-1]), np.nonzero(cls == 1)[0])
+    # (each class in whatever order k1_tile_cull's blocks got there: the order decides which block shades a tile, not what comes out)
+    np.testing.assert_array_equal(np.sort(as_tile(order[:n_a])), np.nonzero(cls == 0)[0])
+    np.testing.assert_array_equal(np.sort(as_tile(order[T - n_b:T])), np.nonzero(cls == 1)[0])
     s = torch.from_numpy(np.ascontiguousarray(f.surface[:, rows])).to(ctx.device)
     with_hint = fp.shade(f.cam.frame, s, lights, N).cpu().numpy()
     fp.use_tile_order = False
@@ -263,6 +264,36 @@ def test_tile_order_hint_lists_the_long_tiles_and_they_are_split(ctx):
         if num[t] < 40:
             np.testing.assert_array_equal(a, b)
     assert np.abs(with_hint - without).max() > 0, "the long tiles took the split path"
+
+
+def test_a_band_is_shaded_from_a_cull_whose_pack_is_still_deferred(ctx):
+    """Round 4: the hint a band's split blocks take their long tiles from is written by k1_tile_cull, so a band's shade needs nothing of k1_pack --
+    shading right behind cull(defer_pack=True), with the canonical buffers not written yet, gives the bits of the ordinary sequence."""
+    f = synth.make_frame("tiny")
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    band = host.band_for_rank(W, H, 1, 2)
+    rows = slice(band.fbRowBegin, band.fbRowBegin + band.fbRowCount)
+    lights = upload_lights(f.lights, ctx.device)
+    d = torch.from_numpy(np.ascontiguousarray(f.depth[rows])).to(ctx.device)
+    s = torch.from_numpy(np.ascontiguousarray(f.surface[:, rows])).to(ctx.device)
+    fp = ForwardPlus(ctx, W, H, N, band=band)
+    fp.cull(f.cam.frame, lights, N, d)
+    g, _ = fp.lists_to_host()
+    assert (g[:, 1] >= 40).any(), "the band has tiles for the split blocks"
+    usual = fp.shade(f.cam.frame, s, lights, N).cpu().numpy()
+    fp2 = ForwardPlus(ctx, W, H, N, band=band)
+    fp2.grid.fill_(-1); fp2.culled.fill_(-1)           # what k1_pack would write: untouched until pack()
+    fp2.cull(f.cam.frame, lights, N, d, defer_pack=True)
+    assert fp2.tile_order and fp2.use_tile_order
+    deferred = fp2.shade(f.cam.frame, s, lights, N).cpu().numpy()
+    assert int(fp2.grid[1].item()) == -1, "the pack has not run"
+    np.testing.assert_array_equal(deferred, usual)
+    assert_radiance_close(deferred, oracle_frame(f)[rows])
+    fp2.pack()
+    g2, i2 = fp2.lists_to_host()
+    g1, i1 = fp.lists_to_host()
+    np.testing.assert_array_equal(g2, g1)
+    np.testing.assert_array_equal(i2[: 1 + int(i2[0])], i1[: 1 + int(i1[0])])
 
 
 def test_tile_order_hint_with_fewer_lights_than_the_workspace_capacity(ctx):
