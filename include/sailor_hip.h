@@ -279,7 +279,8 @@ SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
  * tileNum[bandTile].  A consumer that only needs "the lights of tile t" (the shade: Standard.shader:422-436) reads them there and does not depend on the
  * compaction into the reference's layout, which then leaves the frame's critical path: SAILOR_CULL_DEFER_PACK + sailor_hip_light_cull_pack on a
  * second stream.  The pointers depend on (width, height, band) alone (lightsCapacity: any light count the workspace can hold) and stay valid until the
- * next cull on the same workspace.  The tile-order hint below is written by the pack step: with a deferred pack it is there once that has run. */
+ * next cull on the same workspace.  The tile-order hint below is written by the cull itself (k1_tile_cull, since round 4): it is there with a deferred
+ * pack too, so a band's shade does not wait for the compaction either. */
 SAILOR_HIP_API int sailor_hip_light_cull_tile_lists(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band, const void* dWorkspace,
                                                     const uint32_t** outTileNum, const uint32_t** outTileLists);
 /* Replaces: nothing of its own -- the second half of the Dispatch at LightCullingNode.cpp:74-77 (Appendix A step 6: offsets = prefix sum of the list
@@ -290,7 +291,8 @@ SAILOR_HIP_API int sailor_hip_light_cull_pack(SailorHipContext* ctx, int32_t wid
 
 /* Shading hint.  sailor_hip_light_cull also leaves, in its workspace, the band's LONG tiles as an array of T + 2 words (T = tiles of the
  * band), each tile as tileX | tileRowInBand << 16: the nA tiles with >= 96 lights at [0, nA), the nB tiles with 40..95 lights at
- * [T-1], [T-2], ... (both in tile order), then [T] = nA and [T+1] = nB.  A band of a split frame is a round or two of blocks, so its longest
+ * [T-1], [T-2], ... (each class in the order the cull's blocks got there: it decides which block shades a tile, not what comes out), then
+ * [T] = nA and [T+1] = nB.  A band of a split frame is a round or two of blocks, so its longest
  * tile is its duration, and a tile in the middle of a light cluster keeps one block busy ~100x longer than an average one.  Handing this
  * pointer to sailor_hip_shade_ex (band smaller than the frame, no shadow maps, no ambient term) makes the launch give those tiles to
  * "split" blocks -- one per (tile, 8x8 quadrant), four waves sharing the quadrant's list -- at the front of the grid.  Lists and every
