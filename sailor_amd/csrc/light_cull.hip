@@ -947,17 +947,21 @@ __device__ __forceinline__ void walk_tile_masks(const TileCtx& t, const CullArgs
 // takes its long tiles from this array, and it must not have to wait for k1_pack.  The order within a class is whatever the atomics make it -- it decides
 // which block shades a tile, not what comes out -- and only the band's few hundred long tiles draw one (a whole frame has no hint).  Cost: ~3 us on the
 // kernel (the round trip of the last tiles' atomics), against the ~5 us of k1_pack that leave the band's chain.
+// (HINT: a template parameter of the kernels -- the whole frame's instantiations carry none of this; as a run-time test of a.tileOrder it cost the 4K
+// frame's k1_tile_cull 1.6-2 us)
+template <bool HINT>
 __device__ __forceinline__ uint32_t publish_tile(const CullArgs& a, const int bandTile, const uint32_t num)
 {
     a.tileNum[bandTile] = num;
     a.tileNum8[bandTile] = (uint8_t)num;
     uint32_t pos = 0u;
-    if (a.tileOrder && num >= CLASS_B) pos = __hip_atomic_fetch_add(a.tileOrder + (uint32_t)a.bandTiles + (num >= CLASS_A ? 0u : 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (HINT) if (num >= CLASS_B) pos = __hip_atomic_fetch_add(a.tileOrder + (uint32_t)a.bandTiles + (num >= CLASS_A ? 0u : 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return pos; // for publish_order, once the tile's list has left
 }
+template <bool HINT>
 __device__ __forceinline__ void publish_order(const CullArgs& a, const int bandTile, const uint32_t num, const uint32_t pos)
 {
-    if (a.tileOrder && num >= CLASS_B) {
+    if constexpr (HINT) if (num >= CLASS_B) {
         const int tyLocal = bandTile / a.Tx, tx = bandTile - tyLocal * a.Tx;
         a.tileOrder[num >= CLASS_A ? pos : (uint32_t)a.bandTiles - 1u - pos] = (uint32_t)tx | ((uint32_t)tyLocal << 16);
     }
@@ -997,6 +1001,7 @@ __device__ __forceinline__ uint32_t rank_among(const float* sImp, const uint32_t
 // 196: what a wave collects beyond its first 196 can never be among the tile's first 196), and the selection's rank -- one candidate per THREAD
 // against all n -- takes ~200 comparisons per thread instead of ~800 per lane.  Same candidates in the same order, same impacts, same rank rule
 // (impact ascending, position descending): the list is the one-wave form's bit for bit (tests/test_light_cull_gpu.py: default == brute force).
+template <bool HINT>
 __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* __restrict__ lds, uint32_t* sCnt, const int gx, const int tyLocal, const int col)
 {
     uint32_t (*sIdxW)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds + CHUNK * 20);                  // [4][CAND]: the waves' own lists
@@ -1049,11 +1054,11 @@ __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* _
     for (uint32_t i = lane; i < sCnt[wave] && before + i < CAND; i += 64) sAll[before + i] = sIdx[i];
     __syncthreads();
     uint32_t pos = 0u;
-    if (threadIdx.x == 0) pos = publish_tile(a, bandTile, num); // (the entry in the hint is completed at each way out, behind the list)
+    if (threadIdx.x == 0) pos = publish_tile<HINT>(a, bandTile, num); // (the entry in the hint is completed at each way out, behind the list)
     uint32_t* __restrict__ out = a.tileLists + (size_t)bandTile * KEEP;
     if (n <= KEEP) { // :235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]
         if (threadIdx.x < n) out[threadIdx.x] = sAll[n - 1 - threadIdx.x] & 0x7FFFFFFFu;
-        if (threadIdx.x == 0) publish_order(a, bandTile, num, pos);
+        if (threadIdx.x == 0) publish_order<HINT>(a, bandTile, num, pos);
         return;
     }
     // ---- 196 -> 128 (ComputeLightCulling.shader:198-225): one candidate per thread
@@ -1069,17 +1074,18 @@ __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* _
     __syncthreads();
     if (sCnt[4] != 0u) { // a NaN impact has no rank: the literal bubble sort, on one wave (emit_list)
         if (wave == 0) emit_list(t, n, sAll, sImp, lightView, out);
-        if (threadIdx.x == 0) publish_order(a, bandTile, num, pos);
+        if (threadIdx.x == 0) publish_order<HINT>(a, bandTile, num, pos);
         return;
     }
     if (k >= n) return;
     const uint32_t rank = rank_among(sImp, n, k, imp);
     if (rank < KEEP) out[rank] = mine & 0x7FFFFFFFu;
-    if (threadIdx.x == 0) publish_order(a, bandTile, num, pos); // (thread 0 holds candidate 0 < n: it comes this way)
+    if (threadIdx.x == 0) publish_order<HINT>(a, bandTile, num, pos); // (thread 0 holds candidate 0 < n: it comes this way)
 }
 
 // The validation path (SAILOR_CULL_BRUTE_FORCE; also tiny light sets and odd projections): no pre-filter, no staging, no cooperation between
 // waves -- every tile walks ALL lights by itself, 64 per step, and selects with emit_list on its own wave.  One block per run of four tiles.
+template <bool HINT>
 __global__ __launch_bounds__(256) void k1_tile_cull_brute(const CullArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 4 * CAND * 4];
@@ -1100,9 +1106,9 @@ __global__ __launch_bounds__(256) void k1_tile_cull_brute(const CullArgs a)
     }
     const uint32_t n = count < CAND ? count : CAND;
     uint32_t pos = 0u;
-    if (lane == 0) pos = publish_tile(a, bandTile, n < KEEP ? n : KEEP);
+    if (lane == 0) pos = publish_tile<HINT>(a, bandTile, n < KEEP ? n : KEEP);
     emit_list(t, n, sIdxAll[wave], sImpAll[wave], a.lightView, a.tileLists + (size_t)bandTile * KEEP);
-    if (lane == 0) publish_order(a, bandTile, n < KEEP ? n : KEEP, pos);
+    if (lane == 0) publish_order<HINT>(a, bandTile, n < KEEP ? n : KEEP, pos);
 }
 
 // The 196 -> 128 selections of a block's tiles by the WHOLE block (ComputeLightCulling.shader:198-225): one candidate per thread and tile.  sIdxAll[w]:
@@ -1157,7 +1163,7 @@ __device__ __forceinline__ void block_select(const CullArgs& a, const int firstB
 // full tile that start 10-20 us into the launch and end at 24-29 while 99 % of the blocks are done at 22).  On for the 4K frame and its bands (a band
 // IS its longest block: k1_tile_cull 14.7 -> 9.7 us on a cluster band of an 8-way split), off on the wide path's 420-candidate lists (8K, a million
 // lights: no listed clusters, seven test steps per tile, and the barrier costs the throughput phase 15 %: 99 -> 114 us).
-template <bool COOP>
+template <bool COOP, bool HINT>
 __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
 {
     // One 256-thread block per run of four tiles (a group's four columns in one tile row), one wave per tile.  The group's candidate records are
@@ -1187,7 +1193,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
         const int row = (hg / groupsX) * GROUP + (int)((hb >> 2) & 3u);
         if (row >= a.bandRows) return;
         PROF_T(0);
-        cluster_tile(a, lds, sCnt, hg % groupsX, row, (int)(hb & 3u));
+        cluster_tile<HINT>(a, lds, sCnt, hg % groupsX, row, (int)(hb & 3u));
         PROF_T(3);
         return;
     }
@@ -1241,7 +1247,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     PROF_T(1);
     const uint32_t n = count < CAND ? count : CAND; // (0 for a wave beyond the last tile column)
     uint32_t pos = 0u;
-    if (active && lane == 0) pos = publish_tile(a, bandTile, n < KEEP ? n : KEEP);
+    if (active && lane == 0) pos = publish_tile<HINT>(a, bandTile, n < KEEP ? n : KEEP);
     // The tile's list into the tile's own slot: k1_pack moves it to its canonical place, the shade reads it where it is.
     if (!COOP || gn == GROUP_OVERFLOW) { // (an overflowed group's staging area is the waves' queues: every wave selects for itself)
         // a tile with more than 128 candidates selects on its own wave (emit_list: ~9 us)
@@ -1259,7 +1265,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
         if (((sCnt[0] > (uint32_t)KEEP) | (sCnt[1] > (uint32_t)KEEP)) | ((sCnt[2] > (uint32_t)KEEP) | (sCnt[3] > (uint32_t)KEEP))) // (block-uniform)
             block_select(a, tyLocal * Tx + gx * GROUP, sCnt, sIdxAll, sImpAll, sCnt + 4);
     }
-    if (active && lane == 0) publish_order(a, bandTile, n < KEEP ? n : KEEP, pos);
+    if (active && lane == 0) publish_order<HINT>(a, bandTile, n < KEEP ? n : KEEP, pos);
     PROF_T(3);
 }
 
@@ -1518,7 +1524,8 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     ca.heavy = (const uint32_t*)(ws + L.offHeavy); ca.headRows = 0;
     ca.tileOrder = layout_has_hint(L) ? (uint32_t*)(ws + L.offTileOrder) : nullptr; ca.bandTiles = L.bandTiles;
     if (brute) {
-        sailor_launch(ctx, k1_tile_cull_brute, dim3(L.groupsX, L.bandRows), dim3(256), ca);
+        if (ca.tileOrder) sailor_launch(ctx, k1_tile_cull_brute<true>, dim3(L.groupsX, L.bandRows), dim3(256), ca);
+        else sailor_launch(ctx, k1_tile_cull_brute<false>, dim3(L.groupsX, L.bandRows), dim3(256), ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull<brute>");
     } else {
         if (L.words >= 4096 && (L.words & 1) == 0)
@@ -1538,8 +1545,12 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
         }
         SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
         // (the block-wide selection everywhere but on the long lists of the wide path: see k1_tile_cull)
-        if (ca.headRows == 0) sailor_launch(ctx, k1_tile_cull<false>, dim3(L.groupsX, ca.headRows + L.bandRows), dim3(256), ca);
-        else sailor_launch(ctx, k1_tile_cull<true>, dim3(L.groupsX, ca.headRows + L.bandRows), dim3(256), ca);
+        const dim3 cgrid(L.groupsX, ca.headRows + L.bandRows);
+        if (ca.tileOrder) { // a band of a split frame: the kernels that append the shading hint
+            if (ca.headRows == 0) sailor_launch(ctx, k1_tile_cull<false, true>, cgrid, dim3(256), ca);
+            else sailor_launch(ctx, k1_tile_cull<true, true>, cgrid, dim3(256), ca);
+        } else if (ca.headRows == 0) sailor_launch(ctx, k1_tile_cull<false, false>, cgrid, dim3(256), ca);
+        else sailor_launch(ctx, k1_tile_cull<true, false>, cgrid, dim3(256), ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
     }
     if (flags & SAILOR_CULL_DEFER_PACK) return SAILOR_HIP_OK; // the caller records sailor_hip_light_cull_pack where it wants it (another stream, beside the shade)

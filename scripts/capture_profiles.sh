@@ -2,6 +2,7 @@
 # Captures the judged artefacts of a round on the GPU box (run through gpurun from the repo root):
 #   kernel stats of the bench command (C3, C4, C5), the PMC traffic passes (C3 AND C4), the SQ counter passes of the shade / cull kernels (C3 and the C4
 #   shade), the bench lines (C3, C4, C5), the split simulations (2 / 4 / 8 bands), the frame pipeline's kernel timelines (whole frame; one band).
+#   (libsailor_hip_prof.so: scripts/ab_build.sh prof "-DCULL_PROF -DSHADE_PROF")
 #   usage: bash scripts/capture_profiles.sh <tag>      -> gpurun_out/<tag>/...   (copy what is to be judged into profiles/<round>/)
 TAG=${1:-cap}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
@@ -19,8 +20,8 @@ rocprofv3 -i $GRAFT_REPO_ROOT/scripts/pmc_shade.txt --kernel-trace --output-form
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats4 -- python3 $B --config C4 --steps 30 --warmup 5 $EAGER > $OUT/bench_eager_C4.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python3 $B --config C5 --steps 20 --warmup 3 $EAGER > $OUT/bench_eager_C5.json 2>/dev/null
 # the frame pipeline as the default line launches it (hipGraph, two frames in flight): the kernels' start / end times inside it
-rocprofv3 --kernel-trace --output-format csv -d $OUT/pipe -- python3 $B --steps 48 --warmup 6 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv -d $OUT/pipeband -- python3 $B --steps 48 --warmup 6 --no-cpu-baseline --simulate-band 2/8 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/pipe -- python3 $B --steps 48 --warmup 6 --no-cpu-baseline --single-mode > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/pipeband -- python3 $B --steps 48 --warmup 6 --no-cpu-baseline --single-mode --simulate-band 2/8 > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 python3 scripts/make_traffic_json.py $OUT/fetch $OUT/write $OUT/traffic.json C3 > /dev/null
 python3 scripts/make_traffic_json.py $OUT/fetch4 $OUT/write4 $OUT/traffic_C4.json C4 > /dev/null
@@ -40,5 +41,8 @@ for G in 2 4; do SAILOR_BENCH_SHARE_GPU=1 python3 bench.py --gpus $G --steps 12 
 for G in 2 4 8; do python3 bench.py --simulate-split $G --steps 30 > $OUT/simulate_split$G.json 2> $OUT/simulate_split$G.err; done
 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/cull_prof.py > $OUT/cull_block_timeline.txt 2>&1
 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/cull_prof.py 2/8 > $OUT/cull_block_timeline_band2of8.txt 2>&1
+SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/shade_prof.py 2/8 > $OUT/shade_block_timeline_band2of8.txt 2>&1
+SAILOR_BAND_SHADE_LDS=0 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/shade_prof.py 2/8 > $OUT/shade_block_timeline_band2of8_8blocks.txt 2>&1
+SAILOR_BAND_SHADE_LDS=0 python3 bench.py --simulate-split 8 --steps 30 > $OUT/simulate_split8_8blocks_per_cu.json 2> /dev/null
 rm -rf $OUT/stats $OUT/stats4 $OUT/stats5 $OUT/fetch $OUT/write $OUT/fetch4 $OUT/write4 $OUT/sq $OUT/sq4 $OUT/pipe $OUT/pipeband
 ls -la $OUT
