@@ -266,6 +266,10 @@ SAILOR_HIP_API int sailor_hip_band_is_valid(int32_t width, int32_t height, const
                                         * ECS/LightingECS.cpp:152-191).  The cull's per-light pass reads the 112-byte records in dLights and WRITES the prepared
                                         * views of all pc->lightsNum lights into dPreparedLights on the way -- sailor_hip_prepare_lights(0, lightsNum) folded
                                         * into the cull: one pass over the records instead of two, one launch less; the same bits in the views, the same lists */
+#define SAILOR_CULL_BAND_SELECT 32u    /* a band of a split frame: select the lights that can reach the band's rows first (k0_band_select: an ordered compaction on the band's
+                                        * top / bottom planes) and run the chain on those -- the default from 131 072 lights on; this flag forces it for smaller sets
+                                        * (same lists bit for bit; validation) */
+#define SAILOR_CULL_NO_BAND_SELECT 64u /* ... never (same lists; A / B) */
 SAILOR_HIP_API size_t sailor_hip_light_cull_workspace_size(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band);
 SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
                                          const SailorUboFrameData* frame, const SailorLightCullPushConstants* pc,

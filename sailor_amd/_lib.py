@@ -26,6 +26,8 @@ CULL_RAW_DEPTH = 2
 CULL_INTERVAL_MASKS = 4
 CULL_DEFER_PACK = 8
 CULL_PREPARE_LIGHTS = 16
+CULL_BAND_SELECT = 32
+CULL_NO_BAND_SELECT = 64
 
 RASTER_CLEAR, RASTER_CULL_BACK = 1, 2
 SHADOWMAP_R16F = 0

@@ -69,6 +69,7 @@
 #define CHUNK 512            // group candidates staged in LDS per step of k1_tile_cull (16 KB of LDS per block: 8 blocks per CU)
 
 #define PACK_TILES 64        // tiles per k1_pack block
+#define SEL_LIGHTS 1024      // lights per block of k0_band_select
 #define CL_STEPS (CAPG / 4 / 64) // cluster tiles: 64-candidate steps per wave for the longest listable group (8)
 
 // the shading hint's class counts travel as class A tiles << 16 | class B tiles in one uint32
@@ -76,7 +77,9 @@
 
 struct CullLayout {
     int Tx, Ty, bandRows, bandTiles, numBands, words, groupsX, groupsY, numGroups, packBlocks;
-    size_t offLightView, offLightType, offTileInfo, offMasks, offDirWords, offGroupCount, offGroupList, offTileNum, offTileNum8, offTileLists, offTileOrder, offDirFlag, offHeavy, total;
+    size_t offLightView, offLightType, offTileInfo, offMasks, offDirWords, offGroupCount, offGroupList, offTileNum, offTileNum8, offTileLists, offTileOrder, offDirFlag, offHeavy,
+           offLightMap, offSelState, total;
+    int selBlocks;
 };
 
 static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
@@ -114,6 +117,10 @@ static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
     L.offLightType = o; o = align_up(o + n * 4, 256);
     L.offMasks = o; o = align_up(o + (size_t)(L.numBands > 0 ? L.numBands : 1) * L.words * 8, 256);
     L.offDirWords = o; o = align_up(o + (size_t)L.words * 8, 256);
+    // k0_band_select (split frames with large light sets): compact index -> light index, and [0] the number of selected lights, [2 + b] block b's count + 1
+    L.selBlocks = (int)((n + SEL_LIGHTS - 1) / SEL_LIGHTS);
+    L.offLightMap = o; o = align_up(o + n * 4, 256);
+    L.offSelState = o; o = align_up(o + (size_t)(2 + L.selBlocks) * 4, 256);
     L.total = o;
     return L;
 }
@@ -172,6 +179,7 @@ struct PrepareArgs {
     float4* lightView; uint32_t* lightType; float4* tileInfo;
     unsigned long long* masks; unsigned long long* dirWords;
     uint32_t* heavy;   // [0]: k1_group_lists' count of light-cluster groups, zeroed here (one launch ahead of it)
+    const uint32_t* selCount; // k0_band_select ran (null: it did not): the light role works on lightView / lightType [0, *selCount), already in view space
     uint32_t* orderCounts; // the shading hint's two class counts (tileOrder[T], [T + 1]; null: whole frame, no hint), zeroed here for k1_tile_cull
     uint32_t* dirFlag; // "some light may be directional": set here, read by k1_group_lists_wide, cleared by k1_tile_cull (unknown before the first cull: then merely conservative)
     int N, words, lightBlocks, lightRoleBlocks, frustumBlocks, bandsPerBlock, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands,
@@ -211,6 +219,7 @@ __device__ __forceinline__ void k0_lights(const int lb, unsigned char* __restric
     const int wordBlock = lb % a.lightBlocks, split = lb / a.lightBlocks;
     const int b0 = split * a.bandsPerBlock;
     const int nb = min(a.bandsPerBlock, a.numBands - b0); // <= 0: no pre-filter (brute-force walk)
+    if (a.selCount && wordBlock * 4 >= min((int)(((*a.selCount + 63u) / 64u + 1u) & ~1u), a.words)) return; // (behind k0_band_select: a block past the selected lights -- the grid is sized for all of them)
     if ((int)threadIdx.x < nb) {
         const int b = b0 + (int)threadIdx.x;
         Frustum4 f;
@@ -229,10 +238,15 @@ __device__ __forceinline__ void k0_lights(const int lb, unsigned char* __restric
     const int word = wordBlock * 4 + (int)(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int j = word * 64 + lane;
-    const bool valid = j < a.N;
+    // (behind k0_band_select the light set is the selected one: *selCount lights, compact, ascending light index, view-space records in lightView; the mask
+    // words behind the last one are not written -- nobody reads them -- but for the odd word that completes a 16-byte pair, which gets zeros)
+    const int nEff = a.selCount ? (int)*a.selCount : a.N;
+    const int wordsEff = a.selCount ? min(((nEff + 63) / 64 + 1) & ~1, a.words) : a.words; // (never past the row: with an odd stride and every light selected there is no pair to complete)
+    const bool valid = j < nEff;
     float4 lv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t type = 1u;
-    if (valid) {
+    if (valid && a.selCount) { lv = a.lightView[j]; type = a.lightType[j]; }
+    else if (valid) {
         float x, y, z, radius;
         if (a.prepStaged) {   // every light is dirty (SAILOR_CULL_PREPARE_LIGHTS): ONE pass over the 112-byte records derives the prepared views too --
             // what sailor_hip_prepare_lights(0, N) in front of this cull does in a launch of its own (k_prepare_lights: the same instructions,
@@ -266,7 +280,7 @@ __device__ __forceinline__ void k0_lights(const int lb, unsigned char* __restric
         if (split == 0) { a.lightView[j] = lv; a.lightType[j] = type; }
     }
     __syncthreads(); // the planes are in LDS
-    if (nb <= 0 || word >= a.words) return;
+    if (nb <= 0 || word >= wordsEff) return;
     const float r = lv.w;
     const float m = a.planeMargin * ((fabsf(lv.x) + fabsf(lv.y)) + (fabsf(lv.z) + fabsf(r)));
     const bool inFront = (lv.z - r) > m; // false for NaN => never plane-culled
@@ -449,6 +463,127 @@ __device__ __forceinline__ void k1_tile_frusta(const int block, const PrepareArg
     o2[4] = f.n[3][0]; o2[5] = f.n[3][1]; o2[6] = f.n[3][2];
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// K0': the light set of a BAND (split frames, large light sets).  Every rank of a split frame used to transform all N lights and build masks over all N
+// for a band that an eighth of them can reach: at C5 (1 M lights) a band's k01_prepare and k1_group_lists_wide were 74 of its 117 us.  This kernel
+// keeps the lights whose sphere is not entirely beyond the band's top or bottom plane -- the SAME test, on the same planes, that keeps a light out of
+// the band's first / last row mask, so no light a tile of the band could list is dropped -- and writes them, transformed, in ascending light index:
+// lightView / lightType [0, M) + lightMap (compact -> light index).  The rest of the chain then runs on M lights (k0_lights reads the compact records,
+// the group lists hold compact indices, k1_tile_cull translates them when a list leaves).  With SAILOR_CULL_PREPARE_LIGHTS the prepared views of ALL
+// lights are derived here (they outlive the band).
+// Ordered compaction in one pass: a block takes 1 024 lights (four per thread, all in registers), publishes its count, adds up the counts of the
+// blocks in front of it (every thread polls a few of them; the grid is at most four blocks per CU -- all resident -- and blocks are dispatched in
+// index order, so a block only ever waits for blocks that are running or done), and writes its lights behind them.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t lanemask_lt();
+struct SelectArgs {
+    Mat4 view, invProj;
+    const SailorLightShaderData* lights;
+    const float4* soaPosRadius; const uint32_t* soaType;
+    float4* prepPosRadius; uint32_t* prepType; float4* prepStaged;
+    float4* lightView; uint32_t* lightType; uint32_t* lightMap;
+    uint32_t* state; // [0] = M, [2 + b] = block b's count + 1 (zeroed in front of the launch)
+    int N, vpW, vpH, Tx, tileRow0, bandRows;
+    float planeMargin;
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k0_band_select(const SelectArgs a)
+{
+    __shared__ float4 sPl[2];
+    __shared__ uint32_t sCnt[4][4], sPart[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        Frustum4 f;
+        frustum_from_rect(a.invProj, 0.0f, (float)(a.tileRow0 * TILE), (float)(a.Tx * TILE), (float)((a.tileRow0 + a.bandRows) * TILE), a.vpW, a.vpH, f);
+        sPl[0] = make_float4(f.n[2][0], f.n[2][1], f.n[2][2], 0.0f); // top: the first row band's
+        sPl[1] = make_float4(f.n[3][0], f.n[3][1], f.n[3][2], 0.0f); // bottom: the last row band's
+    }
+    float4 lv[4];
+    uint32_t type[4];
+    unsigned long long keep[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = (int)blockIdx.x * SEL_LIGHTS + k * 256 + (int)threadIdx.x;
+        lv[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        type[k] = 1u;
+        if (j < a.N) {
+            float x, y, z, radius;
+            if (a.prepStaged) { // every light is dirty: the prepared views of all of them, as k0_lights derives them without this kernel in front of it
+                const float4* L = reinterpret_cast<const float4*>(a.lights + j);
+                const float4 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3], q4 = L[4], q5 = L[5], q6 = L[6];
+                x = q1.x; y = q1.y; z = q1.z; radius = q6.x;
+                type[k] = __float_as_uint(q0.x);
+                a.prepPosRadius[j] = make_float4(x, y, z, radius);
+                a.prepType[j] = type[k];
+                float4 o0, o1, o2, o3, o4;
+                stage_light_record(q0, q1, q2, q3, q4, q5, q6, o0, o1, o2, o3, o4);
+                float4* o = a.prepStaged + (size_t)j * LREC;
+                o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3; o[4] = o4;
+            } else if (a.soaPosRadius) {
+                const float4 pr = a.soaPosRadius[j];
+                x = pr.x; y = pr.y; z = pr.z; radius = pr.w;
+                type[k] = a.soaType[j];
+            } else {
+                const SailorLightShaderData* L = a.lights + j;
+                x = L->worldPosition[0]; y = L->worldPosition[1]; z = L->worldPosition[2]; radius = L->bounds[0];
+                type[k] = L->type;
+            }
+            float4 p = glsl_mul(a.view, x, y, z, 1.0f); // (k0_lights' operations: the records the tile tests read are the same bits)
+            const float w = p.w;
+            p.x = p.x / w; p.y = p.y / w; p.z = p.z / w;
+            p.z = p.z * -1.0f; // "Reverse Z"
+            lv[k] = make_float4(p.x, p.y, p.z, radius);
+        }
+    }
+    __syncthreads(); // the planes are in LDS
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = (int)blockIdx.x * SEL_LIGHTS + k * 256 + (int)threadIdx.x;
+        const bool valid = j < a.N;
+        const float r = lv[k].w;
+        const float m = a.planeMargin * ((fabsf(lv[k].x) + fabsf(lv[k].y)) + (fabsf(lv[k].z) + fabsf(r)));
+        const bool inFront = (lv[k].z - r) > m; // false for NaN => never plane-culled
+        const float thr = -(r + m);
+        const bool keepAlways = valid && (type[k] == 0u || !inFront);
+        const float4 nA = sPl[0], nB = sPl[1];
+        const bool out = dot3f(nA.x, nA.y, nA.z, lv[k].x, lv[k].y, lv[k].z) < thr || dot3f(nB.x, nB.y, nB.z, lv[k].x, lv[k].y, lv[k].z) < thr;
+        keep[k] = __ballot(keepAlways || (valid && !out));
+        if (lane == 0) sCnt[k][wave] = (uint32_t)__popcll(keep[k]);
+    }
+    __syncthreads();
+    // this block's lights in front of mine: rounds before k (all waves), waves before mine in round k, lanes before mine
+    uint32_t before[4], total = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        before[k] = total;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const uint32_t c = sCnt[k][w]; if (w < wave) before[k] += c; total += c; }
+    }
+    const uint32_t b = blockIdx.x;
+    // (relaxed: the word IS the message -- nothing else passes between blocks; a release here is a write-back of the XCD's whole L2, per block: 100 us)
+    if (threadIdx.x == 0) __hip_atomic_store(a.state + 2u + b, total + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t acc = 0u;
+    for (uint32_t i = threadIdx.x; i < b; i += 256u) {
+        uint32_t v;
+        while ((v = __hip_atomic_load(a.state + 2u + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(2);
+        acc += v - 1u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += (uint32_t)__shfl_xor((int)acc, d, 64);
+    if (lane == 0) sPart[wave] = acc;
+    __syncthreads();
+    const uint32_t base = (sPart[0] + sPart[1]) + (sPart[2] + sPart[3]);
+    if (b == gridDim.x - 1u && threadIdx.x == 0) a.state[0] = base + total;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if ((keep[k] >> lane) & 1ull) {
+            const uint32_t c = base + before[k] + (uint32_t)__popcll(keep[k] & lanemask_lt());
+            a.lightView[c] = lv[k];
+            a.lightType[c] = type[k];
+            a.lightMap[c] = (uint32_t)((int)blockIdx.x * SEL_LIGHTS + k * 256 + (int)threadIdx.x);
+        }
+    }
+}
+
 #define LDS_K01_PREPARE (2 * MAX_BANDS_PER_BLOCK * 16)
 __global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
 {
@@ -482,14 +617,15 @@ __device__ __forceinline__ uint64_t lanemask_lt()
 // ------------------------------------------------------------------------------------------------------------
 #define GL_WPT 4 // words per thread and round in k1_group_lists
 __global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ dirWords,
-                                                       int words, int groupsX, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList,
-                                                       uint32_t* __restrict__ heavy, uint32_t heavyMin)
+                                                       int stride, int groupsX, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList,
+                                                       uint32_t* __restrict__ heavy, uint32_t heavyMin, const uint32_t* __restrict__ selCount)
 {
     __shared__ uint32_t sW[4];
     // (2-D grid: group column, group row -- no division by the run-time groupsX)
     const int g = (int)blockIdx.y * groupsX + (int)blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long* __restrict__ c = masks + (size_t)blockIdx.x * words;
-    const unsigned long long* __restrict__ r = masks + (size_t)(groupsX + (int)blockIdx.y) * words;
+    const unsigned long long* __restrict__ c = masks + (size_t)blockIdx.x * stride;
+    const unsigned long long* __restrict__ r = masks + (size_t)(groupsX + (int)blockIdx.y) * stride;
+    const int words = selCount ? min((int)(((*selCount + 63u) / 64u + 1u) & ~1u), stride) : stride; // (behind k0_band_select: the selected lights' words; the masks keep the capacity's stride)
     uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
     uint32_t base = 0; // entries written by earlier chunks (block-uniform)
     // GL_WPT consecutive words per thread and round: one block-wide scan (and its two barriers) per 256 * GL_WPT words -- at 1 M lights a group walks
@@ -600,9 +736,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 #define GLW_Q 256   // queued words per wave (ring; < 64 pending + <= 128 new per row)
 template <bool EXACT> // EXACT: words is a multiple of 128 * GLW_ROWS, no load needs a bounds check
 __global__ __launch_bounds__(256) void k1_group_lists_wide(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ dirWords,
-                                                            int words, int groupsX, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList,
-                                                            const uint32_t* __restrict__ dirFlag)
+                                                            int stride, int groupsX, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList,
+                                                            const uint32_t* __restrict__ dirFlag, const uint32_t* __restrict__ selCount)
 {
+    const int words = (!EXACT && selCount) ? min((int)(((*selCount + 63u) / 64u + 1u) & ~1u), stride) : stride; // (behind k0_band_select: the selected lights' words)
     __shared__ __attribute__((aligned(16))) unsigned long long sRow[2][GLW_ROWS][128];
     const bool anyDir = *dirFlag != 0u; // no directional light in the set (the usual case): the draining waves need not wait for their words of dirWords
     __shared__ unsigned long long sQBits[4][GLW_Q];
@@ -612,8 +749,8 @@ __global__ __launch_bounds__(256) void k1_group_lists_wide(const unsigned long l
     const int gy = (int)blockIdx.x / blocksX, gx = ((int)blockIdx.x % blocksX) * 4 + wave;
     const bool mine = gx < groupsX; // (a wave beyond the last column still fetches its share of the row band's mask)
     const int g = gy * groupsX + (mine ? gx : groupsX - 1);
-    const unsigned long long* __restrict__ c = masks + (size_t)(mine ? gx : groupsX - 1) * words;
-    const unsigned long long* __restrict__ r = masks + (size_t)(groupsX + gy) * words;
+    const unsigned long long* __restrict__ c = masks + (size_t)(mine ? gx : groupsX - 1) * stride;
+    const unsigned long long* __restrict__ r = masks + (size_t)(groupsX + gy) * stride;
     uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
     unsigned long long* qBits = sQBits[wave];
     uint32_t* qWord = sQWord[wave];
@@ -768,19 +905,24 @@ struct CullArgs {
     uint32_t* tileNum; uint8_t* tileNum8; uint32_t* tileLists; uint32_t* dirFlag;
     int N, words, Tx, groupsX, bandRows;
     uint32_t* tileOrder; int bandTiles; // the shading hint (null: none): see publish_tile
+    const uint32_t* lightMap; const uint32_t* selCount; // behind k0_band_select (kernels with SEL): compact index -> light index; the number of selected lights
     const uint32_t* heavy; int headRows; // k1_group_lists' cluster list and the grid rows in front of the tile rows that take its tiles (0: none)
 };
 
 // The <= 196 candidates of a tile (sIdx, ascending light index) -> its list at `out` (Appendix A steps 4 + 5).  One wave.
+// (SEL: the candidates are compact indices of k0_band_select's light set -- ascending like the light indices they stand for, so every rank and tie-break
+// below is the one of the full set -- and `map` turns an entry into its light index on the way out)
+template <bool SEL>
 __device__ __forceinline__ void emit_list(const TileCtx& t, const uint32_t n, uint32_t* sIdx, float* sImp, const float4* __restrict__ lightView,
-                                          uint32_t* __restrict__ out)
+                                          uint32_t* __restrict__ out, const uint32_t* __restrict__ map)
 {
+    auto light_of = [&](const uint32_t e) -> uint32_t { const uint32_t i = e & 0x7FFFFFFFu; if constexpr (SEL) return map[i]; else return i; };
     const int lane = threadIdx.x & 63;
     const uint32_t num = n < KEEP ? n : KEEP;
     WAVE_SYNC(); // orders the wave's LDS writes (the appends) with the reads below
     if (n <= KEEP) {
         // :235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]
-        for (uint32_t i = lane; i < num; i += 64) out[i] = sIdx[n - 1 - i] & 0x7FFFFFFFu;
+        for (uint32_t i = lane; i < num; i += 64) out[i] = light_of(sIdx[n - 1 - i]);
         return;
     }
     // ---- 196 -> 128 selection (ComputeLightCulling.shader:198-225)
@@ -815,7 +957,7 @@ __device__ __forceinline__ void emit_list(const TileCtx& t, const uint32_t n, ui
             }
             WAVE_SYNC();
         }
-        for (uint32_t i = lane; i < num; i += 64) out[i] = sIdx[n - 1 - i] & 0x7FFFFFFFu; // :235-238
+        for (uint32_t i = lane; i < num; i += 64) out[i] = light_of(sIdx[n - 1 - i]); // :235-238
         return;
     }
     // :198-225 partial bubble sort == rank under (impact ascending, candidate position descending); keep rank < 128
@@ -853,7 +995,7 @@ __device__ __forceinline__ void emit_list(const TileCtx& t, const uint32_t n, ui
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t k = lane + 64u * i;
-        if (k < n && rank[i] < KEEP) out[rank[i]] = sIdx[k] & 0x7FFFFFFFu;
+        if (k < n && rank[i] < KEEP) out[rank[i]] = light_of(sIdx[k]);
     }
 }
 
@@ -903,7 +1045,7 @@ __device__ __forceinline__ void walk_tile_masks(const TileCtx& t, const CullArgs
     const int lane = threadIdx.x & 63;
     const unsigned long long* __restrict__ col = a.masks + (size_t)gx * a.words;
     const unsigned long long* __restrict__ row = a.masks + (size_t)(a.groupsX + tyLocal / GROUP) * a.words;
-    const int words = a.words;
+    const int words = a.selCount ? (int)((*a.selCount + 63u) / 64u) : a.words; // (behind k0_band_select: the selected lights' words)
     uint32_t qHead = 0, qTail = 0; // ring buffer indices (wave-uniform)
     unsigned long long next = (lane < words) ? (col[lane] & row[lane]) : 0ull;
     for (int w0 = 0; w0 < words && count < CAND; w0 += 64) {
@@ -1001,7 +1143,7 @@ __device__ __forceinline__ uint32_t rank_among(const float* sImp, const uint32_t
 // 196: what a wave collects beyond its first 196 can never be among the tile's first 196), and the selection's rank -- one candidate per THREAD
 // against all n -- takes ~200 comparisons per thread instead of ~800 per lane.  Same candidates in the same order, same impacts, same rank rule
 // (impact ascending, position descending): the list is the one-wave form's bit for bit (tests/test_light_cull_gpu.py: default == brute force).
-template <bool HINT>
+template <bool HINT, bool SEL>
 __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* __restrict__ lds, uint32_t* sCnt, const int gx, const int tyLocal, const int col)
 {
     uint32_t (*sIdxW)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds + CHUNK * 20);                  // [4][CAND]: the waves' own lists
@@ -1057,7 +1199,7 @@ __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* _
     if (threadIdx.x == 0) pos = publish_tile<HINT>(a, bandTile, num); // (the entry in the hint is completed at each way out, behind the list)
     uint32_t* __restrict__ out = a.tileLists + (size_t)bandTile * KEEP;
     if (n <= KEEP) { // :235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]
-        if (threadIdx.x < n) out[threadIdx.x] = sAll[n - 1 - threadIdx.x] & 0x7FFFFFFFu;
+        if (threadIdx.x < n) { const uint32_t i = sAll[n - 1 - threadIdx.x] & 0x7FFFFFFFu; out[threadIdx.x] = SEL ? a.lightMap[i] : i; }
         if (threadIdx.x == 0) publish_order<HINT>(a, bandTile, num, pos);
         return;
     }
@@ -1073,13 +1215,13 @@ __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* _
     if (__ballot(k < n && imp != imp) != 0ull && lane == 0) sCnt[4] = 1u;
     __syncthreads();
     if (sCnt[4] != 0u) { // a NaN impact has no rank: the literal bubble sort, on one wave (emit_list)
-        if (wave == 0) emit_list(t, n, sAll, sImp, lightView, out);
+        if (wave == 0) emit_list<SEL>(t, n, sAll, sImp, lightView, out, a.lightMap);
         if (threadIdx.x == 0) publish_order<HINT>(a, bandTile, num, pos);
         return;
     }
     if (k >= n) return;
     const uint32_t rank = rank_among(sImp, n, k, imp);
-    if (rank < KEEP) out[rank] = mine & 0x7FFFFFFFu;
+    if (rank < KEEP) { const uint32_t i = mine & 0x7FFFFFFFu; out[rank] = SEL ? a.lightMap[i] : i; }
     if (threadIdx.x == 0) publish_order<HINT>(a, bandTile, num, pos); // (thread 0 holds candidate 0 < n: it comes this way)
 }
 
@@ -1107,7 +1249,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull_brute(const CullArgs a)
     const uint32_t n = count < CAND ? count : CAND;
     uint32_t pos = 0u;
     if (lane == 0) pos = publish_tile<HINT>(a, bandTile, n < KEEP ? n : KEEP);
-    emit_list(t, n, sIdxAll[wave], sImpAll[wave], a.lightView, a.tileLists + (size_t)bandTile * KEEP);
+    emit_list<false>(t, n, sIdxAll[wave], sImpAll[wave], a.lightView, a.tileLists + (size_t)bandTile * KEEP, nullptr);
     if (lane == 0) publish_order<HINT>(a, bandTile, n < KEEP ? n : KEEP, pos);
 }
 
@@ -1115,6 +1257,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull_brute(const CullArgs a)
 // tile w's candidates (ascending light index, bit 31 = directional), sCnt[w] their number (selection needed where > 128), sImpAll[w]: CAND floats of
 // its own, 16-byte aligned.  Two phases with ONE barrier between them: the impacts of every tile that needs a selection (the gathers of up to four
 // tiles in flight together), then the ranks.  A tile with a NaN impact has no rank: the literal bubble sort, on one wave (emit_list).
+template <bool SEL>
 __device__ __forceinline__ void block_select(const CullArgs& a, const int firstBandTile, const uint32_t* sCnt, uint32_t (*sIdxAll)[CAND], float (*sImpAll)[CAND], uint32_t* sFlags)
 {
     const uint32_t k = threadIdx.x, lane = threadIdx.x & 63;
@@ -1149,11 +1292,11 @@ __device__ __forceinline__ void block_select(const CullArgs& a, const int firstB
             if (threadIdx.x < 64) {
                 TileCtx t;
                 load_tile_ctx(a.tileInfo, firstBandTile + w, t);
-                emit_list(t, n, sIdxAll[w], sImpAll[w], lightView, out);
+                emit_list<SEL>(t, n, sIdxAll[w], sImpAll[w], lightView, out, a.lightMap);
             }
         } else if (k < n) {
             const uint32_t rank = rank_among(sImpAll[w], n, k, imp[w]);
-            if (rank < KEEP) out[rank] = mine[w] & 0x7FFFFFFFu;
+            if (rank < KEEP) { const uint32_t i = mine[w] & 0x7FFFFFFFu; out[rank] = SEL ? a.lightMap[i] : i; }
         }
     }
 }
@@ -1163,7 +1306,7 @@ __device__ __forceinline__ void block_select(const CullArgs& a, const int firstB
 // full tile that start 10-20 us into the launch and end at 24-29 while 99 % of the blocks are done at 22).  On for the 4K frame and its bands (a band
 // IS its longest block: k1_tile_cull 14.7 -> 9.7 us on a cluster band of an 8-way split), off on the wide path's 420-candidate lists (8K, a million
 // lights: no listed clusters, seven test steps per tile, and the barrier costs the throughput phase 15 %: 99 -> 114 us).
-template <bool COOP, bool HINT>
+template <bool COOP, bool HINT, bool SEL>
 __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
 {
     // One 256-thread block per run of four tiles (a group's four columns in one tile row), one wave per tile.  The group's candidate records are
@@ -1193,7 +1336,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
         const int row = (hg / groupsX) * GROUP + (int)((hb >> 2) & 3u);
         if (row >= a.bandRows) return;
         PROF_T(0);
-        cluster_tile<HINT>(a, lds, sCnt, hg % groupsX, row, (int)(hb & 3u));
+        cluster_tile<HINT, SEL>(a, lds, sCnt, hg % groupsX, row, (int)(hb & 3u));
         PROF_T(3);
         return;
     }
@@ -1251,7 +1394,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     // The tile's list into the tile's own slot: k1_pack moves it to its canonical place, the shade reads it where it is.
     if (!COOP || gn == GROUP_OVERFLOW) { // (an overflowed group's staging area is the waves' queues: every wave selects for itself)
         // a tile with more than 128 candidates selects on its own wave (emit_list: ~9 us)
-        if (active) emit_list(t, n, sIdx, sImpAll[wave], lightView, a.tileLists + (size_t)bandTile * KEEP);
+        if (active) emit_list<SEL>(t, n, sIdx, sImpAll[wave], lightView, a.tileLists + (size_t)bandTile * KEEP, a.lightMap);
     } else {
         // short lists leave at once (:235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]); the others wait for the block
         if (lane == 0) sCnt[wave] = n;
@@ -1259,11 +1402,11 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
         if (active && n <= KEEP) {
             WAVE_SYNC();
             uint32_t* __restrict__ out = a.tileLists + (size_t)bandTile * KEEP;
-            for (uint32_t i = lane; i < n; i += 64) out[i] = sIdx[n - 1 - i] & 0x7FFFFFFFu;
+            for (uint32_t i = lane; i < n; i += 64) { const uint32_t c = sIdx[n - 1 - i] & 0x7FFFFFFFu; out[i] = SEL ? a.lightMap[c] : c; }
         }
         __syncthreads();
         if (((sCnt[0] > (uint32_t)KEEP) | (sCnt[1] > (uint32_t)KEEP)) | ((sCnt[2] > (uint32_t)KEEP) | (sCnt[3] > (uint32_t)KEEP))) // (block-uniform)
-            block_select(a, tyLocal * Tx + gx * GROUP, sCnt, sIdxAll, sImpAll, sCnt + 4);
+            block_select<SEL>(a, tyLocal * Tx + gx * GROUP, sCnt, sIdxAll, sImpAll, sCnt + 4);
     }
     if (active && lane == 0) publish_order<HINT>(a, bandTile, n < KEEP ? n : KEEP, pos);
     PROF_T(3);
@@ -1488,6 +1631,28 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
         } else { pa.soaPosRadius = (const float4*)pr; pa.soaType = (const uint32_t*)ty; }
     }
     pa.lightView = (float4*)(ws + L.offLightView); pa.lightType = (uint32_t*)(ws + L.offLightType); pa.tileInfo = (float4*)(ws + L.offTileInfo);
+    // A band of a split frame with a large light set: the lights that can reach the band are selected first (k0_band_select) and the chain runs on them.
+    // From 131 072 lights on (below, the light role and the group lists of a band sit at their launch floors whatever the count); SAILOR_CULL_BAND_SELECT
+    // forces it for any set the pre-filter runs on, SAILOR_CULL_NO_BAND_SELECT switches it off.  The grid must be resident as a whole (four blocks per CU).
+    uint32_t* selState = (uint32_t*)(ws + L.offSelState);
+    const bool select = !brute && L.bandRows < L.Ty && !(flags & SAILOR_CULL_NO_BAND_SELECT) && ((flags & SAILOR_CULL_BAND_SELECT) || N >= 131072) &&
+                        L.selBlocks <= 4 * ctx->numCUs;
+    pa.selCount = nullptr;
+    if (select) {
+        SelectArgs sa;
+        memcpy(sa.view.m, frame->view, 64);
+        memcpy(sa.invProj.m, frame->invProjection, 64);
+        sa.lights = dLights; sa.soaPosRadius = pa.soaPosRadius; sa.soaType = pa.soaType;
+        sa.prepPosRadius = pa.prepPosRadius; sa.prepType = pa.prepType; sa.prepStaged = pa.prepStaged;
+        sa.lightView = pa.lightView; sa.lightType = pa.lightType; sa.lightMap = (uint32_t*)(ws + L.offLightMap); sa.state = selState;
+        sa.N = N; sa.vpW = frame->viewportSize[0]; sa.vpH = frame->viewportSize[1]; sa.Tx = L.Tx; sa.tileRow0 = band->tileRowBegin; sa.bandRows = L.bandRows;
+        sa.planeMargin = 1e-3f;
+        SAILOR_TRY_HIP(ctx, hipMemsetAsync(selState, 0, (size_t)(2 + L.selBlocks) * 4, s));
+        sailor_launch(ctx, k0_band_select, dim3((unsigned)L.selBlocks), dim3(256), sa);
+        SAILOR_CHECK_LAUNCH(ctx, "k0_band_select");
+        pa.selCount = selState;
+        pa.prepPosRadius = nullptr; pa.prepType = nullptr; pa.prepStaged = nullptr; // (derived by k0_band_select; the light role reads the compact records)
+    }
     pa.masks = (unsigned long long*)(ws + L.offMasks); pa.dirWords = (unsigned long long*)(ws + L.offDirWords);
     pa.N = N; pa.words = L.words;
     pa.lightBlocks = (N + 255) / 256;
@@ -1523,6 +1688,7 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     ca.N = N; ca.words = L.words; ca.Tx = L.Tx; ca.groupsX = L.groupsX; ca.bandRows = L.bandRows;
     ca.heavy = (const uint32_t*)(ws + L.offHeavy); ca.headRows = 0;
     ca.tileOrder = layout_has_hint(L) ? (uint32_t*)(ws + L.offTileOrder) : nullptr; ca.bandTiles = L.bandTiles;
+    ca.lightMap = select ? (const uint32_t*)(ws + L.offLightMap) : nullptr; ca.selCount = pa.selCount;
     if (brute) {
         if (ca.tileOrder) sailor_launch(ctx, k1_tile_cull_brute<true>, dim3(L.groupsX, L.bandRows), dim3(256), ca);
         else sailor_launch(ctx, k1_tile_cull_brute<false>, dim3(L.groupsX, L.bandRows), dim3(256), ca);
@@ -1531,26 +1697,29 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
         if (L.words >= 4096 && (L.words & 1) == 0)
         {
             const dim3 wideGrid((unsigned)(((L.groupsX + 3) / 4) * L.groupsY));
-            if (L.words % (128 * GLW_ROWS) == 0)
+            if (L.words % (128 * GLW_ROWS) == 0 && !select)
                 sailor_launch(ctx, k1_group_lists_wide<true>, wideGrid, dim3(256), pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
-                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag));
+                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag), (const uint32_t*)nullptr);
             else
                 sailor_launch(ctx, k1_group_lists_wide<false>, wideGrid, dim3(256), pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
-                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag));
+                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag), pa.selCount);
         }
         else {
             sailor_launch(ctx, k1_group_lists, dim3(L.groupsX, L.groupsY), dim3(256), pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
-                               (uint32_t*)(ws + L.offGroupList), (uint32_t*)(ws + L.offHeavy), (uint32_t)(L.bandRows * 2 > L.Ty ? HEAVY_MIN_FRAME : HEAVY_MIN_BAND));
+                               (uint32_t*)(ws + L.offGroupList), (uint32_t*)(ws + L.offHeavy), (uint32_t)(L.bandRows * 2 > L.Ty ? HEAVY_MIN_FRAME : HEAVY_MIN_BAND), pa.selCount);
             ca.headRows = (16 * HEAVY_MAX + L.groupsX - 1) / L.groupsX; // grid rows for the listed clusters' tiles (a block each), in front of the tile rows
         }
         SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
         // (the block-wide selection everywhere but on the long lists of the wide path: see k1_tile_cull)
         const dim3 cgrid(L.groupsX, ca.headRows + L.bandRows);
-        if (ca.tileOrder) { // a band of a split frame: the kernels that append the shading hint
-            if (ca.headRows == 0) sailor_launch(ctx, k1_tile_cull<false, true>, cgrid, dim3(256), ca);
-            else sailor_launch(ctx, k1_tile_cull<true, true>, cgrid, dim3(256), ca);
-        } else if (ca.headRows == 0) sailor_launch(ctx, k1_tile_cull<false, false>, cgrid, dim3(256), ca);
-        else sailor_launch(ctx, k1_tile_cull<true, false>, cgrid, dim3(256), ca);
+        if (select) { // (a band by definition: the hint's kernels)
+            if (ca.headRows == 0) sailor_launch(ctx, k1_tile_cull<false, true, true>, cgrid, dim3(256), ca);
+            else sailor_launch(ctx, k1_tile_cull<true, true, true>, cgrid, dim3(256), ca);
+        } else if (ca.tileOrder) { // a band of a split frame: the kernels that append the shading hint
+            if (ca.headRows == 0) sailor_launch(ctx, k1_tile_cull<false, true, false>, cgrid, dim3(256), ca);
+            else sailor_launch(ctx, k1_tile_cull<true, true, false>, cgrid, dim3(256), ca);
+        } else if (ca.headRows == 0) sailor_launch(ctx, k1_tile_cull<false, false, false>, cgrid, dim3(256), ca);
+        else sailor_launch(ctx, k1_tile_cull<true, false, false>, cgrid, dim3(256), ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
     }
     if (flags & SAILOR_CULL_DEFER_PACK) return SAILOR_HIP_OK; // the caller records sailor_hip_light_cull_pack where it wants it (another stream, beside the shade)

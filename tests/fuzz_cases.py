@@ -13,6 +13,7 @@ from sailor_amd import _lib, host, synth
 from sailor_amd.forward_plus import EcsSweep, ForwardPlus, PreparedLights, upload_lights, upload_shadow_maps
 
 CULL_PATHS = [_lib.CULL_DEFAULT, _lib.CULL_BRUTE_FORCE, _lib.CULL_INTERVAL_MASKS]
+BAND_SELECT_EVERY = 2   # every second case's bands go through k0_band_select as well (round 4: the band-local light selection, forced on these small sets)
 
 
 def k1k2_case(ctx, rng, c, run=True, verbose=False):
@@ -64,7 +65,7 @@ def k1k2_case(ctx, rng, c, run=True, verbose=False):
             # every other cull path through the prepared-lights entry points (the path the HIP backend drives), with a capacity above the count
             prep = PreparedLights(ctx, l, N, capacity=N + 5) if (CULL_PATHS.index(flags) + c) % 2 == 0 else None
             fp.prepared = prep
-            fp.cull(cam.frame, l, N, d, flags)
+            fp.cull(cam.frame, l, N, d, flags | (_lib.CULL_BAND_SELECT if (b is not None and c % BAND_SELECT_EVERY == 0) else 0))
             g, idx = fp.lists_to_host()
             t0r, t1r = bb.tileRowBegin * Tx, bb.tileRowEnd * Tx
             assert np.array_equal(g[:, 1], og[t0r:t1r, 1]), (what, flags, "num")

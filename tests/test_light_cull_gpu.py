@@ -149,6 +149,48 @@ def test_tile_row_bands_stitch_to_the_whole_frame(ctx, world_size):
     assert base == int(ref_i[0])
 
 
+@pytest.mark.parametrize("n_lights, radius_scale, extra", [(5000, 3.0, 0), (4000, 40.0, 0), (4000, 0.5, _lib.CULL_INTERVAL_MASKS), (1100, 6.0, 0)])
+@pytest.mark.parametrize("world_size", [2, 5])
+def test_band_local_light_selection_gives_the_same_lists(ctx, world_size, n_lights, radius_scale, extra):
+    """k0_band_select (the default on bands from 131 072 lights on, forced here by SAILOR_CULL_BAND_SELECT): the lights that can reach a band are
+    compacted -- in ascending index, view space -- in front of the chain, which then runs on compact indices and translates them when a list leaves.
+    Same lists bit for bit as without it and as the oracle's: few lights kept (small radii), ALL kept with an odd number of mask words (4 000 lights,
+    huge radii: no pad word to zero), directional / NaN / behind-the-eye lights (always kept), several selection blocks, both mask forms."""
+    cam, depth, lights = frame(1000, 562, n_lights, radius_scale=radius_scale, spot_fraction=0.25, cluster_lights=300, seed=17)
+    lights["type"][[3, n_lights // 2, n_lights - 1]] = host.LIGHT_DIRECTIONAL
+    lights["worldPosition"][7] = np.nan
+    lights["worldPosition"][11] = (0.0, 150.0, 50.0); lights["bounds"][11, 0] = 400.0
+    for r in range(world_size):
+        band = host.band_for_rank(1000, 562, r, world_size)
+        og, oi, _ = oracle.light_cull(cam.frame, 1000, 562, lights, depth, tile_rows=(band.tileRowBegin, band.tileRowEnd))
+        with_sel = gpu_cull(ctx, cam, lights, depth, _lib.CULL_BAND_SELECT | extra, band=band)
+        without = gpu_cull(ctx, cam, lights, depth, _lib.CULL_NO_BAND_SELECT | extra, band=band)
+        assert_lists_equal(with_sel, og, oi)
+        assert_lists_equal(without, og, oi)
+
+
+def test_band_selection_with_the_preparation_folded_in(ctx):
+    """... and with SAILOR_CULL_PREPARE_LIGHTS: k0_band_select derives the prepared views of ALL lights (they outlive the band), bit for bit
+    sailor_hip_prepare_lights' own."""
+    from sailor_amd.forward_plus import PreparedLights
+    cam, depth, lights = frame(640, 400, 3000, radius_scale=2.0, spot_fraction=0.3, cluster_lights=400, seed=5)
+    N = len(lights)
+    dev = upload_lights(lights, ctx.device)
+    ref = PreparedLights(ctx, dev, N)
+    ctx.synchronize()
+    want = [t.cpu().numpy().copy() for t in ref.views()]
+    band = host.band_for_rank(640, 400, 1, 3)
+    d = torch.from_numpy(np.ascontiguousarray(depth[band.fbRowBegin:band.fbRowBegin + band.fbRowCount])).to(ctx.device)
+    mine = PreparedLights(ctx, dev, 0, capacity=N)
+    mine.buffer.fill_(0x5A)
+    fp = ForwardPlus(ctx, 640, 400, N, band=band, prepared=mine)
+    fp.cull(cam.frame, dev, N, d, _lib.CULL_BAND_SELECT, prepare_lights=True)
+    og, oi, _ = oracle.light_cull(cam.frame, 640, 400, lights, depth, tile_rows=(band.tileRowBegin, band.tileRowEnd))
+    assert_lists_equal(fp.lists_to_host(), og, oi)
+    for a, b in zip((t.cpu().numpy() for t in mine.views()), want):
+        np.testing.assert_array_equal(a[:N].view(np.uint32), b[:N].view(np.uint32))
+
+
 def test_c3_4k_65536_lights_default_equals_brute_force_and_invariants(ctx):
     """BASELINE.json configs[2] at full size: too big for the scalar oracle in seconds, so the hierarchical path is checked
     against the brute-force HIP walk (itself oracle-checked above) plus size-independent invariants, and -- round 3 -- the ENTIRE frame
