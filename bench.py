@@ -746,7 +746,7 @@ def pipeline_unroll(steps: int, sets: int = 2):
     return u, steps - (steps // u) * u if u else steps
 
 
-def simulate_split(args, dev, ctx, side, frame, d_lights, fp_full, d_depth_full, prep=None):
+def simulate_split(args, dev, ctx, side, frame, d_lights, fp_full, d_depth_full, prep=None, csm=None):
     """Single-GPU estimate of the G-way split: per-band step time (hipGraph replay), equal vs cost-balanced bands."""
     from sailor_amd import dist as sdist
     cam, W, H, N, G = frame.cam, frame.cam.width, frame.cam.height, len(frame.lights), args.simulate_split
@@ -767,17 +767,17 @@ def simulate_split(args, dev, ctx, side, frame, d_lights, fp_full, d_depth_full,
         ds = dev.upload(frame.surface_rows(b.fbRowBegin, b.fbRowBegin + b.fbRowCount))
         for f in fs:
             f.cull(cam.frame, d_lights, N, dd)
-            f.shade(cam.frame, ds, d_lights, N, None)
+            f.shade(cam.frame, ds, d_lights, N, csm)
         dev.synchronize()
         if unroll:
             defer = not args.pack_inline   # as the main path records it: k1_pack behind the event the shade waits for, on the cull's own stream
-            graph = capture_frame_pipeline(side, side2, unroll, [lambda f=f: f.shade(cam.frame, ds, d_lights, N, None) for f in fs],
+            graph = capture_frame_pipeline(side, side2, unroll, [lambda f=f: f.shade(cam.frame, ds, d_lights, N, csm) for f in fs],
                                            [lambda f=f: f.cull(cam.frame, d_lights, N, dd, ctx=ctx2, defer_pack=defer) for f in fs], dev,
                                            [lambda f=f: f.pack(ctx2) for f in fs] if defer else None, side2)
             fs[0].cull(cam.frame, d_lights, N, dd)
             per = unroll
         else:
-            graph = dev.capture(side, lambda: (fs[0].cull(cam.frame, d_lights, N, dd), fs[0].shade(cam.frame, ds, d_lights, N, None)))
+            graph = dev.capture(side, lambda: (fs[0].cull(cam.frame, d_lights, N, dd), fs[0].shade(cam.frame, ds, d_lights, N, csm)))
             per = 1
         t_spin = time.perf_counter()   # the same clock spin-up as the main path (a band's K steps are over in 2-4 ms)
         while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
@@ -917,7 +917,7 @@ def main(argv=None, device_factory=None):
         csm, keep = dev.upload_shadow_maps(shadows)
 
     if args.simulate_split:
-        simulate_split(args, dev, ctx, side, frame, d_lights, fp, d_depth, prep)
+        simulate_split(args, dev, ctx, side, frame, d_lights, fp, d_depth, prep, csm)
         return
 
     def cull_of(f, c, dyn, defer_pack=False):

@@ -1647,7 +1647,7 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
         sa.lightView = pa.lightView; sa.lightType = pa.lightType; sa.lightMap = (uint32_t*)(ws + L.offLightMap); sa.state = selState;
         sa.N = N; sa.vpW = frame->viewportSize[0]; sa.vpH = frame->viewportSize[1]; sa.Tx = L.Tx; sa.tileRow0 = band->tileRowBegin; sa.bandRows = L.bandRows;
         sa.planeMargin = 1e-3f;
-        SAILOR_TRY_HIP(ctx, hipMemsetAsync(selState, 0, (size_t)(2 + L.selBlocks) * 4, s));
+        SAILOR_TRY_HIP(ctx, hipMemsetAsync(selState, 0, align_up((size_t)(2 + L.selBlocks) * 4, 256), s)); // (the section's whole 256-byte-aligned extent: one fill kernel, not two)
         sailor_launch(ctx, k0_band_select, dim3((unsigned)L.selBlocks), dim3(256), sa);
         SAILOR_CHECK_LAUNCH(ctx, "k0_band_select");
         pa.selCount = selState;

@@ -353,10 +353,11 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
         // per CU.  A split frame is a pipeline of short launches -- the NEXT frame's cull chain runs beside this kernel on another stream -- and with every wave
         // slot taken by shade blocks each of the chain's four launches queues behind them: measured on 1/8 bands of the 4K frame, alone the kernel takes
         // ~3 us longer (30 -> 33 us), the pipelined step ~8 us less (53 -> 45 us).  SAILOR_BAND_SHADE_LDS=<bytes> overrides (0: eight blocks).
-        // Only for bands of up to three rounds of resident blocks (an eighth of the 4K frame is two): a larger band is bound by the shade's throughput like the
-        // whole frame, and the cap costs it what it costs there (half the 4K frame: 108 -> 120 us per step).
+        // For bands of up to three rounds of resident blocks (an eighth of the 4K frame is two) -- a larger band is bound by the shade's throughput like the
+        // whole frame, and the cap costs it what it costs there (half the 4K frame: 108 -> 120 us per step) -- and for any band under a large light set, whose
+        // cull chain is as long as its shade (an eighth of the 8K frame under a million lights: 16 320 tiles, 80 us of cull beside 78 us of shade; 152 -> 134 us).
         static const int bandLdsEnv = [] { const char* e = getenv("SAILOR_BAND_SHADE_LDS"); return e ? atoi(e) : -1; }();
-        const unsigned bandLds = bandLdsEnv >= 0 ? (unsigned)bandLdsEnv : (bandTiles <= 3 * 8 * ctx->numCUs ? (unsigned)SHADE_BAND_RESERVE : 0u);
+        const unsigned bandLds = bandLdsEnv >= 0 ? (unsigned)bandLdsEnv : ((bandTiles <= 3 * 8 * ctx->numCUs || lightsNum >= 131072) ? (unsigned)SHADE_BAND_RESERVE : 0u);
         if (dPreparedLights && dTileNum) sailor_launch_lds(ctx, k2_shade_band_pt, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
         else if (dPreparedLights) sailor_launch_lds(ctx, k2_shade_band_p, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
         else if (dTileNum) sailor_launch_lds(ctx, k2_shade_band_t, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);

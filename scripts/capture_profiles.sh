@@ -39,6 +39,12 @@ python3 bench.py --config C5 --no-cpu-baseline --steps 20 > $OUT/bench_C5.json 2
 # N > 1 as the driver types it, on this ONE-GPU box: the ranks share device 0 over gloo (figures meaningless; the path and the exchanged lists are real)
 for G in 2 4; do SAILOR_BENCH_SHARE_GPU=1 python3 bench.py --gpus $G --steps 12 --no-cpu-baseline > $OUT/bench_${G}ranks_sharing_one_gpu.json 2> $OUT/bench_${G}ranks_sharing_one_gpu.err; done
 for G in 2 4 8; do python3 bench.py --simulate-split $G --steps 30 > $OUT/simulate_split$G.json 2> $OUT/simulate_split$G.err; done
+# the 8-GPU configurations of BASELINE.json (configs[3], configs[4]) band by band: C4 with its shadow maps, C5 (static lights; the band-local light selection on, and off for comparison)
+python3 bench.py --simulate-split 8 --steps 24 --config C4 > $OUT/simulate_split8_C4.json 2> /dev/null
+python3 bench.py --simulate-split 8 --steps 24 --config C5 > $OUT/simulate_split8_C5.json 2> /dev/null
+SAILOR_CULL_FLAGS=64 python3 bench.py --simulate-split 8 --steps 24 --config C5 > $OUT/simulate_split8_C5_no_band_select.json 2> /dev/null
+python3 scripts/band_subset_probe.py C5 3/8 > $OUT/band_chain_C5_band3of8.txt 2>&1
+SAILOR_CULL_FLAGS=64 python3 scripts/band_subset_probe.py C5 3/8 > $OUT/band_chain_C5_band3of8_no_band_select.txt 2>&1
 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/cull_prof.py > $OUT/cull_block_timeline.txt 2>&1
 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/cull_prof.py 2/8 > $OUT/cull_block_timeline_band2of8.txt 2>&1
 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/shade_prof.py 2/8 > $OUT/shade_block_timeline_band2of8.txt 2>&1
