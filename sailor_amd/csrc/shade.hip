@@ -28,6 +28,35 @@
 #include "common.h"
 #include "shade_body.h"
 
+// make EXTRA=-DSHADE_PROF + scripts/shade_prof.py: start / end of every block of the band kernel on the 100 MHz constant clock, its XCD and hardware id
+#ifdef SHADE_PROF
+__device__ unsigned long long g_shadeProf[65536][4];
+extern "C" __attribute__((visibility("default"))) int sailor_hip_debug_read_shade_prof(void* dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_shadeProf), bytes);
+}
+__device__ __forceinline__ void sprof_mark(const int i)
+{
+    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long h = ((unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    if (threadIdx.x == 0 && blockIdx.x < 65536) { g_shadeProf[blockIdx.x][i] = t; if (i == 0) g_shadeProf[blockIdx.x][2] = h; }
+}
+#define SPROF_T(i) sprof_mark(i);
+template <bool ON> __device__ __forceinline__ void sprof_mark_grid(const int i)   // (the per-tile grid's kernels: by linear block index)
+{
+    if constexpr (ON) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long h = ((unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        const uint32_t id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (threadIdx.x == 0 && id < 65536u) { g_shadeProf[id][i] = t; if (i == 0) g_shadeProf[id][2] = h; }
+    }
+}
+#define SPROF_TG(i, ON) sprof_mark_grid<(ON)>(i);
+#else
+#define SPROF_T(i)
+#define SPROF_TG(i, ON)
+#endif
+
 // Entry points: without shadow lookups in it the kernel fits 64 VGPRs, and the register allocator is told to stay there
 // (8 waves per SIMD); with the 16-tap PCF inlined it does not, and forcing it would spill.  The ambient term adds a third.
 #define SHADE_ENTRY(NAME, ATTR, CSM, IBL, PREP, TL)                                                                                                \
@@ -36,7 +65,9 @@
                                                      const uint32_t* __restrict__ culled, float4* __restrict__ radiance)                          \
     {                                                                                                                                              \
         __shared__ ShadeLds lds;                                                                                                                   \
+        SPROF_TG(0, (CSM) && !(IBL))                                                                                                               \
         k2_shade_body<CSM, IBL, ROLE_TILE, PREP, TL>(lds, A, C, I, surface, planeStride, lights, grid, culled, radiance);                          \
+        SPROF_TG(3, (CSM) && !(IBL))                                                                                                               \
     }
 #define FORCE_64_VGPRS __attribute__((amdgpu_waves_per_eu(8, 8)))
 // (the K3 kernels: 64 registers like the others since the shadow look-ups run before the view / material terms -- "K3 first" in shade_body.h; it
@@ -55,25 +86,7 @@ SHADE_ENTRIES(_p, true, false)
 SHADE_ENTRIES(_t, false, true)
 SHADE_ENTRIES(_pt, true, true)
 
-// make EXTRA=-DSHADE_PROF + scripts/shade_prof.py: start / end of every block of the band kernel on the 100 MHz constant clock, its XCD and hardware id
-#ifdef SHADE_PROF
-__device__ unsigned long long g_shadeProf[65536][4];
-extern "C" __attribute__((visibility("default"))) int sailor_hip_debug_read_shade_prof(void* dst, size_t bytes)
-{
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_shadeProf), bytes);
-}
-__device__ __forceinline__ void sprof_mark(const int i)
-{
-    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long h = ((unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-    if (threadIdx.x == 0 && blockIdx.x < 65536) { g_shadeProf[blockIdx.x][i] = t; if (i == 0) g_shadeProf[blockIdx.x][2] = h; }
-}
-#define SPROF_T(i) sprof_mark(i);
-#else
-#define SPROF_T(i)
-#endif
-
-template <bool PREP, bool TL>
+template <bool PREP, bool TL, bool CSM>
 __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, int bandTiles, const float4* __restrict__ surface, size_t planeStride,
                                                    const SailorLightShaderData* __restrict__ lights, const SailorLightsGrid* __restrict__ grid,
                                                    const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
@@ -81,7 +94,7 @@ __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArg
     if (blockIdx.x >= (unsigned)SPLIT_BLOCKS) {
         const int t = (int)blockIdx.x - SPLIT_BLOCKS, ty = t / A.Tx;
         SPROF_T(0)
-        k2_shade_body<false, false, ROLE_BAND_TILE, PREP, TL>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, t - ty * A.Tx, ty, 0);
+        k2_shade_body<CSM, false, ROLE_BAND_TILE, PREP, TL>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, t - ty * A.Tx, ty, 0);
         SPROF_T(3)
         return;
     }
@@ -91,25 +104,32 @@ __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArg
     for (uint32_t idx = blockIdx.x; idx < limit; idx += (uint32_t)SPLIT_BLOCKS) {
         const uint32_t li = idx >> 2;
         const uint32_t o = A.order[li < nA ? li : (uint32_t)bandTiles - 1u - (li - nA)];
-        k2_shade_body<false, false, ROLE_BAND_SPLIT, PREP, TL>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, (int)(o & 0xFFFFu), (int)(o >> 16),
+        k2_shade_body<CSM, false, ROLE_BAND_SPLIT, PREP, TL>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, (int)(o & 0xFFFFu), (int)(o >> 16),
                                                            (int)(idx & 3u));
         __syncthreads(); // the LDS arrays are reused by the block's next tile
     }
     SPROF_T(3)
 }
 
-#define SHADE_BAND_ENTRY(NAME, PREP, TL)                                                                                                                               \
-    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))                                                                                     \
+#define SHADE_BAND_ENTRY(NAME, PREP, TL, CSM, WAVES)                                                                                                                   \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))                                                                                   \
     void NAME(ShadeArgs A, CsmArgs C, int bandTiles, const float4* __restrict__ surface, size_t planeStride, const SailorLightShaderData* __restrict__ lights,        \
               const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled, float4* __restrict__ radiance)                                         \
     {                                                                                                                                                                \
         __shared__ ShadeLds lds;                                                                                                                                     \
-        k2_shade_band_body<PREP, TL>(lds, A, C, bandTiles, surface, planeStride, lights, grid, culled, radiance);                                                        \
+        k2_shade_band_body<PREP, TL, CSM>(lds, A, C, bandTiles, surface, planeStride, lights, grid, culled, radiance);                                                   \
     }
-SHADE_BAND_ENTRY(k2_shade_band, false, false)
-SHADE_BAND_ENTRY(k2_shade_band_p, true, false)
-SHADE_BAND_ENTRY(k2_shade_band_t, false, true)
-SHADE_BAND_ENTRY(k2_shade_band_pt, true, true)
+SHADE_BAND_ENTRY(k2_shade_band, false, false, false, 8)
+SHADE_BAND_ENTRY(k2_shade_band_p, true, false, false, 8)
+SHADE_BAND_ENTRY(k2_shade_band_t, false, true, false, 8)
+SHADE_BAND_ENTRY(k2_shade_band_pt, true, true, false, 8)
+// (round 4: with shadow maps too -- a band of C4 was its longest tile: 63 us for 25 us of block-slot time, scripts/shade_prof_csm.py.  Two copies of the
+// K3 body do not fit 64 registers without scratch (24 bytes, 6-7 spilled registers); six waves per SIMD -- what the band kernels' wave-slot reserve leaves
+// a CU anyway -- give them 80)
+SHADE_BAND_ENTRY(k2_shade_band_csm, false, false, true, 6)
+SHADE_BAND_ENTRY(k2_shade_band_csm_p, true, false, true, 6)
+SHADE_BAND_ENTRY(k2_shade_band_csm_t, false, true, true, 6)
+SHADE_BAND_ENTRY(k2_shade_band_csm_pt, true, true, true, 6)
 
 // ---- sailor_hip_prepare_lights: the per-light half of the path, once per UPLOADED light instead of once per frame and list slot ----
 // One lane per light of [first, first + count): the cull's 20-byte view of it -- (worldPosition, bounds.x) as a float4 and the type, two dense
@@ -344,10 +364,11 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
                              else if (dPreparedLights) sailor_launch(ctx, K##_p, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); \
                              else if (dTileNum) sailor_launch(ctx, K##_t, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); \
                              else sailor_launch(ctx, K, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } while (0)
+    const bool splitBand = dTileOrder && band->tileRowEnd - band->tileRowBegin < Ty && !ibl; // a band of a split frame: long tiles are split across four blocks
     if (hasCsm && ibl) LAUNCH_SHADE(k2_shade_csm_ibl);
-    else if (hasCsm) LAUNCH_SHADE(k2_shade_csm);
+    else if (hasCsm && !splitBand) LAUNCH_SHADE(k2_shade_csm);
     else if (ibl) LAUNCH_SHADE(k2_shade_ibl);
-    else if (dTileOrder && band->tileRowEnd - band->tileRowBegin < Ty) { // a band of a split frame: long tiles are split across four blocks
+    else if (splitBand) {
         const dim3 bgrid((unsigned)SPLIT_BLOCKS + (unsigned)bandTiles);
         // A band's shade does not take the whole chip: SHADE_BAND_RESERVE bytes of dynamic LDS that nobody touches cap it at six blocks (24 of 32 wave slots)
         // per CU.  A split frame is a pipeline of short launches -- the NEXT frame's cull chain runs beside this kernel on another stream -- and with every wave
@@ -358,10 +379,13 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
         // cull chain is as long as its shade (an eighth of the 8K frame under a million lights: 16 320 tiles, 80 us of cull beside 78 us of shade; 152 -> 134 us).
         static const int bandLdsEnv = [] { const char* e = getenv("SAILOR_BAND_SHADE_LDS"); return e ? atoi(e) : -1; }();
         const unsigned bandLds = bandLdsEnv >= 0 ? (unsigned)bandLdsEnv : ((bandTiles <= 3 * 8 * ctx->numCUs || lightsNum >= 131072) ? (unsigned)SHADE_BAND_RESERVE : 0u);
-        if (dPreparedLights && dTileNum) sailor_launch_lds(ctx, k2_shade_band_pt, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
-        else if (dPreparedLights) sailor_launch_lds(ctx, k2_shade_band_p, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
-        else if (dTileNum) sailor_launch_lds(ctx, k2_shade_band_t, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
-        else sailor_launch_lds(ctx, k2_shade_band, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd);
+#define LAUNCH_BAND(K) do { if (dPreparedLights && dTileNum) sailor_launch_lds(ctx, K##_pt, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); \
+                            else if (dPreparedLights) sailor_launch_lds(ctx, K##_p, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); \
+                            else if (dTileNum) sailor_launch_lds(ctx, K##_t, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); \
+                            else sailor_launch_lds(ctx, K, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); } while (0)
+        if (hasCsm) LAUNCH_BAND(k2_shade_band_csm);
+        else LAUNCH_BAND(k2_shade_band);
+#undef LAUNCH_BAND
     } else LAUNCH_SHADE(k2_shade);
 #undef LAUNCH_SHADE
     SAILOR_CHECK_LAUNCH(ctx, "k2_shade");

@@ -1,11 +1,13 @@
-"""Per-block start / end times of the band shade kernel (library built with EXTRA=-DSHADE_PROF): where do a band's ~29 us go?  usage: shade_prof.py [R/G]"""
+"""Per-block start / end times of the band shade kernel (library built with EXTRA=-DSHADE_PROF): where do a band's ~29 us go?  usage: shade_prof.py [R/G] [C3 | C4]
+(C4: with the shadow cascades -- k2_shade_band_csm*)"""
 import ctypes, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
 from sailor_amd import host, _lib
 from sailor_amd.forward_plus import HipContext, ForwardPlus, upload_lights, PreparedLights
 import bench
-frame = bench.BenchFrame("C3")
+cfg = sys.argv[2] if len(sys.argv) > 2 else "C3"
+frame = bench.BenchFrame(cfg)
 cam, W, H = frame.cam, frame.cam.width, frame.cam.height
 N = len(frame.lights)
 dev = torch.device("cuda", 0)
@@ -19,12 +21,17 @@ fp = ForwardPlus(ctx, W, H, N, band=band, prepared=prep)
 rows = slice(band.fbRowBegin, band.fbRowBegin + band.fbRowCount)
 dd = torch.from_numpy(np.ascontiguousarray(frame.depth[rows])).to(dev)
 ds = torch.from_numpy(frame.surface_rows(rows.start, rows.stop)).to(dev)
+csm = None
+if frame.cfg.get("shadow_size"):
+    from sailor_amd import synth
+    from sailor_amd.forward_plus import upload_shadow_maps
+    csm, keep = upload_shadow_maps(synth.make_shadow_set(cam, frame.cfg["shadow_size"]), dev)
 fp.cull(cam.frame, dl, N, dd)
 for _ in range(4):
-    fp.shade(cam.frame, ds, dl, N, None)
+    fp.shade(cam.frame, ds, dl, N, csm)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); fp.shade(cam.frame, ds, dl, N, None); e1.record(); torch.cuda.synchronize()
+e0.record(); fp.shade(cam.frame, ds, dl, N, csm); e1.record(); torch.cuda.synchronize()
 lib = _lib.load()
 buf = np.zeros((65536, 4), dtype=np.uint64)
 fn = lib.sailor_hip_debug_read_shade_prof

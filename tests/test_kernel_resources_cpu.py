@@ -88,6 +88,14 @@ def test_k2_shade_band_stays_at_eight_waves(resources, name):
     assert k["private_segment_fixed_size"] <= 16   # (two copies of the body at 64 registers each: a handful of bytes is what it has always had)
 
 
+@pytest.mark.parametrize("name", ["k2_shade_band_csm", "k2_shade_band_csm_p", "k2_shade_band_csm_t", "k2_shade_band_csm_pt"])
+def test_the_shadowed_band_kernels_fit_six_waves_without_scratch(resources, name):
+    # (round 4: two copies of the K3 body spill at 64 registers -- 24 bytes of scratch cost the whole-frame K3 kernel a third of its speed in round 3 --
+    # so these are pinned to six waves per SIMD = 80 registers, what the band kernels' wave-slot reserve leaves a CU anyway)
+    k = find(resources["shade"], name)
+    assert waves_per_simd(k["vgpr_count"]) >= 6 and k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0
+
+
 def test_cull_kernels_keep_their_occupancy(resources):
     res = resources["light_cull"]
     tile = [v for n, v in res.items() if "k1_tile_cull" in n]

@@ -73,6 +73,20 @@ def assert_radiance_close(got, ref):
     np.testing.assert_array_equal(got[..., 3], ref[..., 3])  # outColor.a = albedo.a, passed through
 
 
+def assert_bands_match_whole(parts, whole, whole_fp, H):
+    """bands (bottom rows first in `parts`) against the whole frame's radiance: bit for bit on every tile whose list is shorter than the split blocks' 40
+    entries; a band's longer tiles go to the split blocks (four waves share a quadrant's list, shadow maps or not since round 4) and differ by the order
+    of four partial sums -- within the radiance tolerance"""
+    got = np.concatenate(parts, 0)
+    assert_radiance_close(got, whole)
+    g, _ = whole_fp.lists_to_host()
+    Tx, Ty = whole_fp.Tx, whole_fp.Ty
+    short = (g[:, 1].reshape(Ty, Tx) < 40)
+    rows = H - 1 - np.arange(H)                      # framebuffer row -> shader row (tile rows count from the bottom)
+    mask = np.repeat(np.repeat(short, 16, 0)[rows], 16, 1)[:, : got.shape[1]]
+    np.testing.assert_array_equal(got[mask], whole[mask])
+
+
 def test_tiny_point_and_spot(ctx):
     f = synth.make_frame("tiny")
     got, _ = gpu_frame(ctx, f)
@@ -152,13 +166,16 @@ def test_deep_scene_reaches_all_cascades(ctx):
 def test_bands_shade_identically(ctx, world_size):
     f = synth.make_frame("tiny_csm", width=320, height=200,
                          lights=synth.LightSetConfig(count=2000, spot_fraction=0.3, radius_scale=5.0, directional_first=True), shadow_size=64)
-    whole, _ = gpu_frame(ctx, f)
+    whole, wfp = gpu_frame(ctx, f)
     parts = []
     for r in reversed(range(world_size)):  # band 0 = bottom rows of the framebuffer
         band = host.band_for_rank(320, 200, r, world_size)
         got, _ = gpu_frame(ctx, f, band=band)
         parts.append(got)
-    np.testing.assert_array_equal(np.concatenate(parts, 0), whole)
+    assert_bands_match_whole(parts, whole, wfp, 200)
+    g, _ = wfp.lists_to_host()
+    assert (g[:, 1] >= 40).any(), "the bands have tiles for the split blocks (shadowed: k2_shade_band_csm*)"
+    assert_radiance_close(np.concatenate(parts, 0), oracle_frame(f))
 
 
 @pytest.mark.parametrize("from_tile_lists", [False, True])
@@ -202,7 +219,8 @@ def test_linearity_in_light_intensity_at_4k(ctx):
 
 def test_c4_4k_with_cascaded_shadow_maps(ctx):
     """BASELINE.json configs[3] at full size (C3 + a directional EVSM light over four 4096^2 cascades): shadowing only ever removes light
-    (factor in [0, 1], every term non-negative), two bands reproduce the whole frame bit for bit (the split of configs[3]), and the
+    (factor in [0, 1], every term non-negative), two bands reproduce the whole frame (the split of configs[3]: bit for bit but for the long tiles the
+    band kernel splits), and the
     ENTIRE frame -- lists and shadowed radiance -- is held against the oracle."""
     f = synth.make_frame("C4")
     W, H = f.cam.width, f.cam.height
@@ -212,7 +230,7 @@ def test_c4_4k_with_cascaded_shadow_maps(ctx):
     assert (whole[..., :3] <= unshadowed[..., :3] * (1 + 1e-5) + 1e-6).all()
     assert (whole[..., :3] < unshadowed[..., :3] * 0.99).mean() > 0.01, "the directional light is shadowed somewhere"
     parts = [gpu_frame(ctx, f, band=host.band_for_rank(W, H, r, 2))[0] for r in (1, 0)]  # band 0 = bottom rows
-    np.testing.assert_array_equal(np.concatenate(parts, 0), whole)
+    assert_bands_match_whole(parts, whole, fp, H)
     desc, keep = oracle.make_csm(f.shadows.lights_matrices, f.shadows.maps)
     assert_oracle_rows(f, whole, oracle_tile_rows(135, [(77, 1), (20, 1)]), csm_desc=desc, gpu_lists=fp.lists_to_host())
 
