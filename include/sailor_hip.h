@@ -298,10 +298,10 @@ SAILOR_HIP_API int sailor_hip_light_cull_pack(SailorHipContext* ctx, int32_t wid
  * [T-1], [T-2], ... (each class in the order the cull's blocks got there: it decides which block shades a tile, not what comes out), then
  * [T] = nA and [T+1] = nB.  A band of a split frame is a round or two of blocks, so its longest
  * tile is its duration, and a tile in the middle of a light cluster keeps one block busy ~100x longer than an average one.  Handing this
- * pointer to sailor_hip_shade_ex (band smaller than the frame, no shadow maps, no ambient term) makes the launch give those tiles to
+ * pointer to sailor_hip_shade_ex (band smaller than the frame, no ambient term; with or without shadow maps) makes the launch give those tiles to
  * "split" blocks -- one per (tile, 8x8 quadrant), four waves sharing the quadrant's list -- at the front of the grid.  Lists and every
  * tile with < 40 lights keep their bits; a split tile's radiance differs from the one-block form by the order of four partial sums per
- * pixel (within the shade tolerance).  With shadow maps or the ambient term the hint is ignored.  Produced for split frames only (on the
+ * pixel (within the shade tolerance).  With the ambient term the hint is ignored (with shadow maps it was, through round 3).  Produced for split frames only (on the
  * whole frame the split measured no gain): NULL for the whole-frame band, for bands of more than 65 535 tiles and on bad arguments.
  * Valid until the next sailor_hip_light_cull on the same workspace.  `lightsCapacity` only has to be a light count the workspace can hold: the
  * hint's place in the workspace depends on (width, height, band) alone, so a cull with ANY lightsNum <= the capacity leaves it where this

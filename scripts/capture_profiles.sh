@@ -48,6 +48,9 @@ SAILOR_CULL_FLAGS=64 python3 scripts/band_subset_probe.py C5 3/8 > $OUT/band_cha
 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/cull_prof.py > $OUT/cull_block_timeline.txt 2>&1
 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/cull_prof.py 2/8 > $OUT/cull_block_timeline_band2of8.txt 2>&1
 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/shade_prof.py 2/8 > $OUT/shade_block_timeline_band2of8.txt 2>&1
+SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/shade_prof.py 2/8 C4 > $OUT/shade_block_timeline_band2of8_C4.txt 2>&1
+SAILOR_NO_TILE_ORDER=1 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/shade_prof_csm.py 2/8 > $OUT/shade_block_timeline_band2of8_C4_per_tile_grid.txt 2>&1
+SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/shade_prof_csm.py 0/1 > $OUT/shade_block_timeline_C4.txt 2>&1
 SAILOR_BAND_SHADE_LDS=0 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/shade_prof.py 2/8 > $OUT/shade_block_timeline_band2of8_8blocks.txt 2>&1
 SAILOR_BAND_SHADE_LDS=0 python3 bench.py --simulate-split 8 --steps 30 > $OUT/simulate_split8_8blocks_per_cu.json 2> /dev/null
 rm -rf $OUT/stats $OUT/stats4 $OUT/stats5 $OUT/fetch $OUT/write $OUT/fetch4 $OUT/write4 $OUT/sq $OUT/sq4 $OUT/pipe $OUT/pipeband
