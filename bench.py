@@ -926,7 +926,11 @@ def main(argv=None, device_factory=None):
         lightsGrid / culledLights wherever the caller records it"""
         if dyn and args.separate_prepare:
             f.prepared.prepare(0, N, ctx=c)
-        f.cull(cam.frame, d_lights, N, d_depth, ctx=c, defer_pack=defer_pack, prepare_lights=dyn and not args.separate_prepare)
+        # (a band with every light dirty every frame: the staged shade records only of the lights the band's selection keeps -- SAILOR_CULL_PREPARE_SELECTED; no
+        # effect where no selection runs: the whole frame, bands under fewer than 131 072 lights)
+        from sailor_amd import _lib as slib
+        fl = slib.CULL_PREPARE_SELECTED if (dyn and not args.separate_prepare and (world > 1 or args.simulate_band)) else slib.CULL_DEFAULT
+        f.cull(cam.frame, d_lights, N, d_depth, fl, ctx=c, defer_pack=defer_pack, prepare_lights=dyn and not args.separate_prepare)
 
     def cull():
         cull_of(fp, None, dynamic)
@@ -1090,7 +1094,9 @@ def main(argv=None, device_factory=None):
     # its real neighbours (the cull chain in front, the next frame's behind) -- a direct reading of the kernel, the figure rocprofv3's kernel trace
     # reports, no difference of two measurements (VERDICT r03 / ADVICE r03)
     direct = kernel_in_frame_ms(ctx, cull, shade, max(args.steps, BATCH_LAUNCHES))
-    chain_names = (["k_prepare_lights"] if (dynamic and args.separate_prepare) else []) + (["k01_prepare", "k1_tile_cull<brute>", "k1_pack"] if N < 512 else
+    env_flags = int(os.environ.get("SAILOR_CULL_FLAGS", "0"))
+    band_select = (fp.tile_order is not None and fp.tile_order) and N >= 512 and not (env_flags & 64) and (N >= 131072 or (env_flags & 32))   # light_cull.hip: k0_band_select in front of a band's chain
+    chain_names = (["k_prepare_lights"] if (dynamic and args.separate_prepare) else []) + (["k0_band_select"] if band_select else []) + (["k01_prepare", "k1_tile_cull<brute>", "k1_pack"] if N < 512 else
                                                                 ["k01_prepare", "k1_group_lists" + ("_wide" if N >= 262144 else ""), "k1_tile_cull", "k1_pack"])
     chain_ms = chain_kernels_ms(ctx, cull, shade, max(args.steps, BATCH_LAUNCHES), len(chain_names))
     g, idx = fp.lists_to_host()

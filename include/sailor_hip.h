@@ -270,6 +270,11 @@ SAILOR_HIP_API int sailor_hip_band_is_valid(int32_t width, int32_t height, const
                                         * top / bottom planes) and run the chain on those -- the default from 131 072 lights on; this flag forces it for smaller sets
                                         * (same lists bit for bit; validation) */
 #define SAILOR_CULL_NO_BAND_SELECT 64u /* ... never (same lists; A / B) */
+#define SAILOR_CULL_PREPARE_SELECTED 128u /* with SAILOR_CULL_PREPARE_LIGHTS on a band whose lights are selected (above): the staged SHADE records are derived only for
+                                        * the selected lights -- all this band's shade of THIS frame can read -- instead of for all of them (the 20-byte cull views
+                                        * still for all).  For hosts that re-prepare every frame (every light dirty every frame): a record of a light outside the
+                                        * selection keeps whatever an earlier call left there, so a later frame that culls WITHOUT re-preparing must not follow.
+                                        * Ignored where no selection runs */
 SAILOR_HIP_API size_t sailor_hip_light_cull_workspace_size(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band);
 SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
                                          const SailorUboFrameData* frame, const SailorLightCullPushConstants* pc,

@@ -28,6 +28,7 @@ CULL_DEFER_PACK = 8
 CULL_PREPARE_LIGHTS = 16
 CULL_BAND_SELECT = 32
 CULL_NO_BAND_SELECT = 64
+CULL_PREPARE_SELECTED = 128
 
 RASTER_CLEAR, RASTER_CULL_BACK = 1, 2
 SHADOWMAP_R16F = 0

@@ -191,6 +191,43 @@ def test_band_selection_with_the_preparation_folded_in(ctx):
         np.testing.assert_array_equal(a[:N].view(np.uint32), b[:N].view(np.uint32))
 
 
+def test_band_selection_staging_only_the_selected_lights(ctx):
+    """SAILOR_CULL_PREPARE_SELECTED (hosts that re-prepare every frame): the staged shade records only of the lights the band's selection keeps -- those are
+    the bits sailor_hip_prepare_lights writes, the others are left alone, the 20-byte cull views are there for all -- and the band's shade is the ordinary one."""
+    from sailor_amd.forward_plus import PreparedLights
+    cam, depth, lights = frame(640, 400, 3000, radius_scale=0.6, spot_fraction=0.3, cluster_lights=400, seed=5)
+    N = len(lights)
+    surface = synth.make_surface(cam, depth, 5)
+    dev = upload_lights(lights, ctx.device)
+    ref = PreparedLights(ctx, dev, N)
+    ctx.synchronize()
+    want = [t.cpu().numpy().copy() for t in ref.views()]
+    band = host.band_for_rank(640, 400, 1, 3)
+    rows = slice(band.fbRowBegin, band.fbRowBegin + band.fbRowCount)
+    d = torch.from_numpy(np.ascontiguousarray(depth[rows])).to(ctx.device)
+    s = torch.from_numpy(np.ascontiguousarray(surface[:, rows])).to(ctx.device)
+    fp0 = ForwardPlus(ctx, 640, 400, N, band=band, prepared=ref)
+    fp0.cull(cam.frame, dev, N, d)
+    usual = fp0.shade(cam.frame, s, dev, N).cpu().numpy().copy()
+    mine = PreparedLights(ctx, dev, 0, capacity=N)
+    mine.buffer.fill_(0x5A)
+    fp = ForwardPlus(ctx, 640, 400, N, band=band, prepared=mine)
+    fp.cull(cam.frame, dev, N, d, _lib.CULL_BAND_SELECT | _lib.CULL_PREPARE_SELECTED, prepare_lights=True)
+    got = fp.shade(cam.frame, s, dev, N).cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint32), usual.view(np.uint32))
+    g, idx = fp.lists_to_host()
+    og, oi, _ = oracle.light_cull(cam.frame, 640, 400, lights, depth, tile_rows=(band.tileRowBegin, band.tileRowEnd))
+    assert_lists_equal((g, idx), og, oi)
+    listed = np.unique(idx[1:1 + int(idx[0])])
+    pr, ty, st = (t.cpu().numpy() for t in mine.views())
+    np.testing.assert_array_equal(pr[:N].view(np.uint32), want[0][:N].view(np.uint32))
+    np.testing.assert_array_equal(ty[:N], want[1][:N])
+    np.testing.assert_array_equal(st[listed].view(np.uint32), want[2][listed].view(np.uint32))          # every light a tile of the band lists is staged
+    untouched = (st[:N].view(np.uint32).reshape(N, -1) == 0x5A5A5A5A).all(axis=1)
+    assert 0.2 < untouched.mean() < 0.95, "most lights cannot reach a third of the frame with these radii: their staged records were not written"
+    assert not untouched[listed].any()
+
+
 def test_c3_4k_65536_lights_default_equals_brute_force_and_invariants(ctx):
     """BASELINE.json configs[2] at full size: too big for the scalar oracle in seconds, so the hierarchical path is checked
     against the brute-force HIP walk (itself oracle-checked above) plus size-independent invariants, and -- round 3 -- the ENTIRE frame
