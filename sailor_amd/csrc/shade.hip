@@ -92,9 +92,13 @@ __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArg
                                                    const uint32_t* __restrict__ culled, float4* __restrict__ radiance)
 {
     if (blockIdx.x >= (unsigned)SPLIT_BLOCKS) {
-        const int t = (int)blockIdx.x - SPLIT_BLOCKS, ty = t / A.Tx;
+        const int t = (int)blockIdx.x - SPLIT_BLOCKS, tr = t / A.Tx;
+        // (with shadow maps the band's tile rows are taken from the far end: tile rows count up with the distance on a ground plane, the far rows lie in the
+        // PCF cascades -- 16 taps against the EVSM cascade's four -- and a band's launch ends with its longest blocks unless they start first; 1-3 % of a
+        // C4 band's step)
+        const int ty = CSM ? A.bandTileRows - 1 - tr : tr;
         SPROF_T(0)
-        k2_shade_body<CSM, false, ROLE_BAND_TILE, PREP, TL>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, t - ty * A.Tx, ty, 0);
+        k2_shade_body<CSM, false, ROLE_BAND_TILE, PREP, TL>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, t - tr * A.Tx, ty, 0);
         SPROF_T(3)
         return;
     }
