@@ -1644,10 +1644,11 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     pa.lightView = (float4*)(ws + L.offLightView); pa.lightType = (uint32_t*)(ws + L.offLightType); pa.tileInfo = (float4*)(ws + L.offTileInfo);
     // A band of a split frame with a large light set: the lights that can reach the band are selected first (k0_band_select) and the chain runs on them.
     // From 131 072 lights on (below, the light role and the group lists of a band sit at their launch floors whatever the count); SAILOR_CULL_BAND_SELECT
-    // forces it for any set the pre-filter runs on, SAILOR_CULL_NO_BAND_SELECT switches it off.  The grid must be resident as a whole (four blocks per CU).
+    // forces it for any set the pre-filter runs on, SAILOR_CULL_NO_BAND_SELECT switches it off.  The grid must be resident as a whole (four blocks per CU: up to
+    // 1 M lights on 256 CUs; beyond that the chain runs on all lights as before).
     uint32_t* selState = (uint32_t*)(ws + L.offSelState);
     const bool select = !brute && L.bandRows < L.Ty && !(flags & SAILOR_CULL_NO_BAND_SELECT) && ((flags & SAILOR_CULL_BAND_SELECT) || N >= 131072) &&
-                        L.selBlocks <= 4 * ctx->numCUs;
+                        L.selBlocks <= 4 * ctx->numCUs; // (at most 128 registers, 108 bytes of LDS: four blocks per CU at least, tests/test_kernel_resources_cpu.py)
     pa.selCount = nullptr;
     if (select) {
         SelectArgs sa;
