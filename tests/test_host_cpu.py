@@ -32,6 +32,19 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert _lib.load().sailor_hip_version() >= 1
 
 
+def test_binding_flag_constants_are_the_headers():
+    """the ctypes binding's cull flags are the header's #defines (a flag added on one side only would silently be another flag)"""
+    import re
+    header = (ROOT / "include" / "sailor_hip.h").read_text()
+    defines = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define SAILOR_(CULL_[A-Z_]+) (\d+)u", header)}
+    assert {"CULL_DEFAULT", "CULL_BRUTE_FORCE", "CULL_RAW_DEPTH", "CULL_INTERVAL_MASKS", "CULL_DEFER_PACK", "CULL_PREPARE_LIGHTS", "CULL_BAND_SELECT",
+            "CULL_NO_BAND_SELECT", "CULL_PREPARE_SELECTED"} <= set(defines)
+    for name, value in defines.items():
+        assert getattr(_lib, name) == value, name
+    bits = [v for v in defines.values() if v]
+    assert len(set(bits)) == len(bits) and all(v & (v - 1) == 0 for v in bits), "one bit each"
+
+
 def test_struct_sizes_match_the_reference_layouts():
     assert C.sizeof(_lib.UboFrameData) == 232          # RHI/Types.h:751-761
     assert C.sizeof(_lib.LightCullPushConstants) == 88  # FrameGraph/LightCullingNode.h:25-31
