@@ -1119,7 +1119,7 @@ def main(argv=None, device_factory=None):
     # the same kernel as the difference (one-frame-in-flight step) - (cull chain alone), medians of event-bracketed graph batches: round 3's figure,
     # kept beside the direct one (it reads a few per cent lower: the next cull's head overlaps the shade's drain)
     shade_diff_ms = serial["median"] - cull_batch_ms
-    shade_kernel = "k2_shade_csm" if csm is not None else ("k2_shade_band" if fp.tile_order and fp.use_tile_order else "k2_shade")
+    shade_kernel = ("k2_shade_band" if fp.tile_order and fp.use_tile_order else "k2_shade") + ("_csm" if csm is not None else "")   # (a band is shaded by the band kernel, shadow maps or not, since round 4)
     tl = bool(getattr(fp, "shade_from_tile_lists", False))
     if prep is not None or tl:   # _p: the entry points that read sailor_hip_prepare_lights' staged records; ..t: the lists from the cull's per-tile slots
         shade_kernel += "_" + ("p" if prep is not None else "") + ("t" if tl else "")
