@@ -142,7 +142,25 @@ def k3_case(ctx, rng, c):
         bad = np.argwhere(np.abs(got.astype(np.float64) - ref) > 1e-4 * np.abs(ref))
         raise AssertionError(f"{what}: {len(bad)} values off, first {bad[0]}, got {got[tuple(bad[0][:2])]} ref {ref[tuple(bad[0][:2])]}")
     m = np.abs(ref[fin]) > 0
-    return float((err[m] / np.abs(ref[fin][m])).max()) if m.any() else 0.0
+    worst = float((err[m] / np.abs(ref[fin][m])).max()) if m.any() else 0.0
+    # every second case also as two bands of a split frame (round 4: a band's long tiles go to the split blocks under shadow maps too -- k2_shade_band_csm*)
+    Tx, Ty = host.num_tiles(W, H)
+    if c % 2 == 1 and Ty >= 2:
+        cut = int(rng.integers(1, Ty))
+        for b in (host.band_from_tile_rows(W, H, 0, cut), host.band_from_tile_rows(W, H, cut, Ty)):
+            fpb = ForwardPlus(ctx, W, H, N, band=b, prepared=PreparedLights(ctx, l, N) if c % 4 == 1 else None)
+            rows = slice(b.fbRowBegin, b.fbRowBegin + b.fbRowCount)
+            fpb.cull(f.cam.frame, l, N, torch.from_numpy(np.ascontiguousarray(depth[rows])).to(ctx.device))
+            gb = fpb.shade(f.cam.frame, torch.from_numpy(np.ascontiguousarray(f.surface[:, rows])).to(ctx.device), l, N, gdesc).cpu().numpy()
+            rb = ref[rows]
+            fb = np.isfinite(rb)
+            assert np.array_equal(np.isfinite(gb), fb), (what, "band", (b.tileRowBegin, b.tileRowEnd), "finiteness")
+            eb = np.abs(gb.astype(np.float64) - rb.astype(np.float64))[fb]
+            assert (eb <= 1e-4 * np.abs(rb.astype(np.float64))[fb]).all(), (what, "band", (b.tileRowBegin, b.tileRowEnd), float(eb.max()))
+            mb = np.abs(rb[fb]) > 0
+            if mb.any():
+                worst = max(worst, float((eb[mb] / np.abs(rb[fb][mb])).max()))
+    return worst
 
 
 _K4_PLANES = None
