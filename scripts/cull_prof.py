@@ -1,11 +1,11 @@
-"""Per-block phase times of k1_tile_cull (library built with EXTRA=-DCULL_PROF): which blocks are the kernel's tail?  usage: cull_prof.py [R/G]"""
+"""Per-block phase times of k1_tile_cull (library built with EXTRA=-DCULL_PROF): which blocks are the kernel's tail?  usage: cull_prof.py [R/G] [C3 | C5]"""
 import ctypes, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
 from sailor_amd import host, synth, _lib
 from sailor_amd.forward_plus import HipContext, ForwardPlus, upload_lights
 import bench
-frame = bench.BenchFrame("C3")
+frame = bench.BenchFrame(sys.argv[2] if len(sys.argv) > 2 else "C3")
 cam, W, H = frame.cam, frame.cam.width, frame.cam.height
 dev = torch.device("cuda", 0)
 ctx = HipContext(dev)
@@ -27,6 +27,8 @@ Tx, Ty = host.num_tiles(W, H)
 groupsX = (Tx + 3) // 4
 rows = band.tileRowEnd - band.tileRowBegin
 head_rows = (16 * 96 + groupsX - 1) // groupsX      # light_cull.hip: 16 * HEAVY_MAX head blocks (a block per cluster tile) in front of the tile rows
+if len(frame.lights) >= 262144:
+    head_rows = 0                                    # ... not on the wide path (k1_group_lists_wide lists no clusters)
 nh = head_rows * groupsX
 nb = nh + groupsX * rows
 assert nb <= 65536
