@@ -89,6 +89,10 @@ def parse(argv=None):
     ap.add_argument("--simulate-split", type=int, default=0, help="G: time each band of a cost-balanced G-way split one after the other on this GPU and print the predicted speed-up; diagnostic")
     ap.add_argument("--simulate-band", default=None, help="R/G: time only band R of a G-way split in this single process (no collectives); diagnostic")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the list exchange even with one rank")
+    ap.add_argument("--split-configs", default=None,
+                    help="N > 1: comma-separated configurations whose split frame gets a bounded reading (~20 steps each) appended to the line as `split_configs`; "
+                         "default: C4,C5 -- the two BASELINE.json names for eight GPUs -- when the headline is C3, none otherwise; '' = none")
+    ap.add_argument("--split-config-steps", type=int, default=24)
     return ap.parse_args(argv)
 
 
@@ -155,6 +159,29 @@ class HipDevice:
     def upload_shadow_maps(self, shadows):
         from sailor_amd.forward_plus import upload_shadow_maps
         return upload_shadow_maps(shadows, self.device)
+
+    def ecs_sweep(self, ctx, entities, rank=0, world=1):
+        """K4 over this rank's slice of an equal split of the entities (the whole set when world == 1)"""
+        return EcsSweep(ctx, entities, rank, world)
+
+    def exchange_visibility(self, sweep):
+        """the slices' visibility words -> the whole bitmask on every rank: sailor_hip_exchange_visibility on the job's ncclComm_t, or the same all-gather
+        over torch.distributed where there is none"""
+        return sweep.exchange_visibility(self._comm)
+
+    def copy_probe_ms(self, ctx, nbytes=512 << 20, launches=20):
+        """THIS box's yardstick: a float4 streaming copy of `nbytes` (sailor_hip_copy_probe), each launch's own dispatch-packet timestamps; median ms"""
+        src = torch.empty(nbytes, dtype=torch.uint8, device=self.device).fill_(1)
+        dst = torch.empty_like(src)
+        lib = ctx._lib
+        for _ in range(3):
+            _lib.check(lib.sailor_hip_copy_probe(ctx.handle, src.data_ptr(), dst.data_ptr(), nbytes), "sailor_hip_copy_probe", ctx.handle)
+        ctx.synchronize()
+        for i in range(launches):
+            ctx.time_launches(i, 1)
+            _lib.check(lib.sailor_hip_copy_probe(ctx.handle, src.data_ptr(), dst.data_ptr(), nbytes), "sailor_hip_copy_probe", ctx.handle)
+        ctx.synchronize()
+        return float(np.median([ctx.timed_launch_ms(i) for i in range(launches)]))
 
     # -- the split frame's exchange: the SHIPPED one (exchange.hip over an ncclComm_t), not torch.distributed's collectives
     def make_comm(self, rank: int, world: int):
@@ -803,6 +830,162 @@ def simulate_split(args, dev, ctx, side, frame, d_lights, fp_full, d_depth_full,
     print(json.dumps(out), flush=True)
 
 
+def ecs_split_block(dev, ctx, dist, rank: int, world: int, count: int, steps: int, simulate=()):
+    """K4 across the ranks of a node (contiguous entity ranges, one all-gather of the visibility words) beside K4 replicated (every rank
+    sweeps the whole set: no collective, and every rank holds every world matrix).  world > 1: both forms timed on the job's ranks (max over ranks);
+    world == 1: the slices of a G-way split timed one after the other on this GPU for G in `simulate` (the all-gather cannot be timed on one GPU).
+    The default of the path is the REPLICATED sweep: DESIGN.md 6 has the arithmetic."""
+    ents = synth.make_entities(count)
+    cam = synth.make_camera(3840, 2160)
+    planes, _ = host.extract_frustum_planes(cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+    whole = dev.ecs_sweep(ctx, ents)
+    for _ in range(3):
+        whole.run(planes)
+    rep_ms = event_batch_ms(lambda: whole.run(planes), steps)
+    out = {"entities": count, "replicated_ms": rep_ms, "default": "replicated",
+           "why": "a split saves at most the sweep's 1-GPU time minus a slice's (~30 us at 1 M entities) and pays an all-gather of the visibility words (128 KB: "
+                  "a latency-bound RCCL collective) -- and leaves world matrices / boxes on the rank that computed them, which the draws of every rank need "
+                  "(64 + 24 B per entity over xGMI cost more than the whole sweep); built, tested, off by default (DESIGN.md 6)"}
+    if world > 1:
+        mine = dev.ecs_sweep(ctx, ents, rank, world)
+        for _ in range(3):
+            mine.run(planes)
+            dev.exchange_visibility(mine)
+        dev.synchronize()
+        slice_ms = event_batch_ms(lambda: mine.run(planes), steps)
+        both_ms = event_batch_ms(lambda: (mine.run(planes), dev.exchange_visibility(mine)), steps)
+        t = torch.tensor([rep_ms, slice_ms, both_ms], dtype=torch.float64, device=dev.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rep_ms, slice_ms, both_ms = (float(v) for v in t.tolist())
+        # the gathered bitmask against the replicated sweep's, on every rank
+        whole.run(planes); mine.run(planes); dev.exchange_visibility(mine)
+        dev.synchronize()
+        words = (count + 63) // 64
+        same = bool(torch.equal(whole.visibility[:words].cpu(), mine.visibility[:words].cpu()))
+        ok = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        out.update({"replicated_ms": rep_ms, "split": {"ranks": world, "slice_ms": slice_ms, "slice_plus_allgather_ms": both_ms, "allgather_ms": both_ms - slice_ms,
+                                                       "visibility_words_per_rank": mine.words_per_rank, "bitmask_equals_replicated_on_every_rank": bool(int(ok.item()))},
+                    "split_vs_replicated": rep_ms / both_ms if both_ms > 0 else None})
+    for G in simulate:
+        ms = []
+        for r in range(G):
+            sw = dev.ecs_sweep(ctx, ents, r, G)
+            sw.run(planes)
+            ms.append(event_batch_ms(lambda sw=sw: sw.run(planes), steps))
+            del sw
+        out.setdefault("split_simulated_on_one_gpu", {})[str(G)] = {"slice_ms_max": max(ms), "slice_ms_min": min(ms),
+                                                                    "allgather_must_cost_less_than_ms": rep_ms - max(ms)}
+    return out
+
+
+def split_config_reading(name: str, args, dev, dist, ctx, side, side2, ctx2, rank: int, world: int, steps: int):
+    """A BOUNDED reading of another configuration's split frame inside an N > 1 run (BASELINE.json names C4 and C5 for eight GPUs, the headline is C3):
+    cost-balanced tile-row bands, the band kernels in the two-frames-in-flight pipeline graph exactly as the headline launches them, `steps` timed steps
+    between barriers, max over ranks -- and the whole frame on every rank's own GPU (one frame in flight) for the speed-up.  C5 with every light
+    dirty every frame (its headline mode).  Every rank takes part in every collective whether or not its own set-up succeeded."""
+    from sailor_amd import dist as sdist
+    from sailor_amd import _lib as slib
+
+    def all_ok(flag_value):
+        fl = torch.tensor([flag_value], dtype=torch.int32, device=dev.device)
+        dist.all_reduce(fl, op=dist.ReduceOp.MIN)
+        return int(fl.item()) == 1
+
+    def max_over_ranks(v):
+        t = torch.tensor([v], dtype=torch.float64, device=dev.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    t_setup = time.perf_counter()
+    ok, st = 1, {}
+    try:
+        frame = BenchFrame(name)
+        cam, W, H, N = frame.cam, frame.cam.width, frame.cam.height, len(frame.lights)
+        Tx, Ty = host.num_tiles(W, H)
+        d_lights = dev.upload_lights(frame.lights)
+        prep = dev.prepared_lights(ctx, d_lights, N)
+        dyn = name == "C5"
+        csm = keep = None
+        if frame.cfg.get("shadow_size"):
+            csm, keep = dev.upload_shadow_maps(synth.make_shadow_set(cam, frame.cfg["shadow_size"]))
+        b0 = host.band_for_rank(W, H, rank, world)
+        f0 = dev.forward_plus(ctx, W, H, N, b0, prep)
+        f0.cull(cam.frame, d_lights, N, dev.upload(frame.depth[b0.fbRowBegin:b0.fbRowBegin + b0.fbRowCount]))
+        dev.synchronize()
+        st = dict(frame=frame, cam=cam, W=W, H=H, N=N, Tx=Tx, Ty=Ty, d_lights=d_lights, prep=prep, dyn=dyn, csm=csm, keep=keep, b0=b0, f0=f0)
+    except Exception as e:
+        ok = 0
+        print(f"[bench] rank {rank}: split reading of {name}: calibration failed ({type(e).__name__}: {e})", file=sys.stderr)
+    if not all_ok(ok):
+        return {"config": name, "error": "calibration failed on some rank"}
+    frame, cam, W, H, N, Tx, Ty, d_lights, prep, dyn, csm, b0, f0 = (st[k] for k in ("frame", "cam", "W", "H", "N", "Tx", "Ty", "d_lights", "prep", "dyn", "csm", "b0", "f0"))
+    rows_entries = sdist.gather_row_entries(f0.grid[: f0.band_tiles * 2], Tx, b0.tileRowEnd - b0.tileRowBegin, Ty, b0.tileRowBegin)
+    bounds = [int(b) for b in sdist.balanced_tile_rows(rows_entries, Tx, world)]
+    del f0, st
+    ok, run, per, wrun = 1, None, 1, None
+    try:
+        band = host.band_from_tile_rows(W, H, bounds[rank], bounds[rank + 1])
+        dd = dev.upload(frame.depth[band.fbRowBegin:band.fbRowBegin + band.fbRowCount])
+        ds = dev.upload(frame.surface_rows(band.fbRowBegin, band.fbRowBegin + band.fbRowCount))
+        fs = [dev.forward_plus(ctx, W, H, N, band, prep if i == 0 else dev.prepared_lights(ctx, d_lights, N)) for i in range(args.list_sets)]
+
+        def cull_of(f, c, defer):
+            fl = slib.CULL_PREPARE_SELECTED if dyn else slib.CULL_DEFAULT
+            f.cull(cam.frame, d_lights, N, dd, fl, ctx=c, defer_pack=defer, prepare_lights=dyn)
+        for f in fs:
+            cull_of(f, None, False)
+            f.shade(cam.frame, ds, d_lights, N, csm)
+        dev.synchronize()
+        per = pipeline_unroll(steps, args.list_sets)[0] or args.list_sets
+        defer = hasattr(fs[0], "pack")
+        graph = capture_frame_pipeline(side, side2, per, [lambda f=f: f.shade(cam.frame, ds, d_lights, N, csm) for f in fs],
+                                       [lambda f=f: cull_of(f, ctx2, defer) for f in fs], dev, [lambda f=f: f.pack(ctx2) for f in fs] if defer else None, side2)
+        cull_of(fs[0], None, False)
+        dev.synchronize()
+        run = graph.replay
+        # the whole frame on this rank's own GPU (one frame in flight), for the speed-up
+        wf = dev.forward_plus(ctx, W, H, N, host.band_whole_frame(W, H), prep)
+        wd, wsf = dev.upload(frame.depth), dev.upload(frame.surface_rows(0, H))
+
+        def wstep():
+            wf.cull(cam.frame, d_lights, N, wd, prepare_lights=dyn)
+            wf.shade(cam.frame, wsf, d_lights, N, csm)
+        wstep(); dev.synchronize()
+        try:
+            wrun = dev.capture(side, wstep).replay
+        except Exception:
+            wrun = wstep
+            dev.synchronize()
+    except Exception as e:
+        ok = 0
+        print(f"[bench] rank {rank}: split reading of {name}: set-up failed ({type(e).__name__}: {e})", file=sys.stderr)
+    if not all_ok(ok):
+        return {"config": name, "error": "set-up failed on some rank", "tile_row_bounds": bounds}
+    setup_s = time.perf_counter() - t_setup
+    reps = max(steps // per, 1)
+    out = {"config": name, "tile_row_bounds": bounds, "steps": reps * per, "lights": "dynamic (all dirty every frame, SAILOR_CULL_PREPARE_SELECTED on the bands)" if dyn else "static"}
+    for key, fn, n_steps in (("split", run, reps * per), ("whole_frame_per_gpu", wrun, reps * per)):
+        calls = reps if key == "split" else n_steps
+        for _ in range(max(2, calls // 4)):
+            fn()
+        if dist is not None:
+            dist.barrier()
+        dev.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            fn()
+        if dist is not None:
+            dist.barrier()
+        dev.synchronize()
+        out[key + "_ms_per_step"] = max_over_ranks(time.perf_counter() - t0) / n_steps * 1e3
+    out["value"] = W * H / (out["split_ms_per_step"] * 1e-3) / 1e6
+    out["unit"] = "Mpixels/s"
+    out["speedup_vs_one_gpu_whole_frame"] = out["whole_frame_per_gpu_ms_per_step"] / out["split_ms_per_step"]
+    out["setup_s"] = setup_s
+    return out
+
+
 class BenchFrame:
     """Synthetic frame with lazily generated surface rows (the full 4K surface is 531 MB; ranks only make their band)."""
 
@@ -1094,11 +1277,19 @@ def main(argv=None, device_factory=None):
     # its real neighbours (the cull chain in front, the next frame's behind) -- a direct reading of the kernel, the figure rocprofv3's kernel trace
     # reports, no difference of two measurements (VERDICT r03 / ADVICE r03)
     direct = kernel_in_frame_ms(ctx, cull, shade, max(args.steps, BATCH_LAUNCHES))
-    env_flags = int(os.environ.get("SAILOR_CULL_FLAGS", "0"))
-    band_select = (fp.tile_order is not None and fp.tile_order) and N >= 512 and not (env_flags & 64) and (N >= 131072 or (env_flags & 32))   # light_cull.hip: k0_band_select in front of a band's chain
-    chain_names = (["k_prepare_lights"] if (dynamic and args.separate_prepare) else []) + (["k0_band_select"] if band_select else []) + (["k01_prepare", "k1_tile_cull<brute>", "k1_pack"] if N < 512 else
-                                                                ["k01_prepare", "k1_group_lists" + ("_wide" if N >= 262144 else ""), "k1_tile_cull", "k1_pack"])
+    # which kernels one cull consists of (a selection in front of a band's chain or not, the wide list builder, brute force ...) is the LIBRARY's
+    # decision: read from its launch log (sailor_hip_context_launch_log), not re-derived here -- one timing slot per kernel it names
+    chain_names = ctx.launches_of(cull)
     chain_ms = chain_kernels_ms(ctx, cull, shade, max(args.steps, BATCH_LAUNCHES), len(chain_names))
+    # THIS box's yardstick, in this process: a float4 streaming copy of 512 MB timed like the kernels above (boxes of the pool differ by +-5 %: a
+    # slower line on a slower box shows as the same frac_of_box_copy)
+    box = None
+    if hasattr(dev, "copy_probe_ms"):
+        nbytes = 512 << 20
+        copy_ms = dev.copy_probe_ms(ctx, nbytes)
+        box = {"copy_gbs": 2 * nbytes / (copy_ms * 1e-3) / 1e9, "copy_ms": copy_ms, "copy_bytes": nbytes,
+               "how": "sailor_hip_copy_probe: float4 per lane, 512 MB read + 512 MB written, median of 20 launches by their own dispatch-packet timestamps, this process, this rank",
+               "guide_copy_gbs": HBM_COPY_GBS}
     g, idx = fp.lists_to_host()
     sum_nt = int(idx[0])
     distinct = int(len(np.unique(idx[1:]))) if sum_nt else 0
@@ -1142,7 +1333,8 @@ def main(argv=None, device_factory=None):
                 "isolated_avg_launch_ms": shade_ms[0], "isolated_median_launch_ms": shade_ms[1],
                 "in_pipeline_launch_ms": pipeline_ms - cull_eager_ms,  # eager (cull + shade) x K minus eager (cull) x K
                 "eager_step_ms": pipeline_ms,
-                "frac_of_measured_copy_peak": shade_gbs / HBM_COPY_GBS,
+                "frac_of_measured_copy_peak": shade_gbs / HBM_COPY_GBS,   # (the guide's 6.29 TB/s constant; frac_of_box_copy divides by THIS box's own copy)
+                "frac_of_box_copy": (shade_gbs / box["copy_gbs"]) if box else None,
                 "valu_sidebar": {"pixel_light_evals": evals, "gevals_per_s": evals / (shade_launch_ms * 1e-3) / 1e9,
                                  "note": "~110 fp32 ops per (pixel,light): VALU-bound once mean list length exceeds ~10 (SURVEY.md 7, hard part 2)"},
                 "csm": csm_info,
@@ -1276,6 +1468,16 @@ def main(argv=None, device_factory=None):
         exchange_info = {"global_sum_num": tot, "checksum": int(gi[1:1 + tot].to(torch.int64).sum().item()), "tiles": int(gg.numel() // 2), "how": dev.exchange_how,
                          "tile_row_bounds": bounds}
 
+    # ---- N > 1: the other configurations BASELINE.json names for a node (C4, C5), bounded, and K4 across the ranks beside K4 replicated
+    split_configs = None
+    ecs_split = None
+    if dist is not None and world > 1:
+        names = args.split_configs if args.split_configs is not None else ("C4,C5" if args.config == "C3" else "")
+        for nm in [n for n in names.split(",") if n]:
+            split_configs = split_configs or {}
+            split_configs[nm] = split_config_reading(nm, args, dev, dist, ctx, side, side2, ctx2, rank, world, args.split_config_steps)
+        ecs_split = ecs_split_block(dev, ctx, dist, rank, world, (1 << 20) if args.config != "tiny" else 5000, 10)
+
     line = None
     if rank == 0:
         mode = (("dynamic: every light dirty every frame -- the prepared views of all %d lights re-derived inside every step, " % N) +
@@ -1304,6 +1506,7 @@ def main(argv=None, device_factory=None):
             "mlights_culled_per_s": N / (cull_batch_ms * 1e-3) / 1e6,
             "cull_ms": cull_batch_ms, "shade_ms": shade_launch_ms, "shade_back_to_back_ms": shade_batch_ms,
             "roofline": roofline,
+            "box": box,
         }
         if other_mode is not None:
             tag = "static_lights" if dynamic else "dynamic_lights"
@@ -1317,9 +1520,14 @@ def main(argv=None, device_factory=None):
                 out["speedup_vs_one_gpu_whole_frame"] = afr["ms_per_frame_per_gpu"] / ms_per_step
         if split:
             out["split_frame"] = split
+        if split_configs:
+            out["split_configs"] = split_configs
+        if ecs_split:
+            out["ecs_sweep"] = {"split": ecs_split, "note": "K4 replicated on every rank (the default); `split` = the entity ranges + visibility all-gather form, timed beside it"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frame, args.cpu_sample_tile_rows)
             out["ecs_sweep"] = ecs_baseline(ctx, 1 << 20, 20)
+            out["ecs_sweep"]["split"] = ecs_split_block(dev, ctx, None, 0, 1, 1 << 20, 10, simulate=(2, 4, 8))
             out["mesh_cull_compact"] = mesh_cull_block(ctx, 1 << 20, 4096, 20)
             out["linearize_depth"] = linearize_block(ctx, frame, fp, d_lights, 30)
             if csm is None:

@@ -205,6 +205,16 @@ SAILOR_HIP_API int sailor_hip_context_wait_for(SailorHipContext* waiter, SailorH
  * it as events recorded in front of and behind a launch do.  Eager launches only (not inside a hipGraph capture); at most 4 096 slots. */
 SAILOR_HIP_API int sailor_hip_context_time_launches(SailorHipContext* ctx, int32_t firstSlot, int32_t count);
 SAILOR_HIP_API int sailor_hip_context_timed_launch_ms(SailorHipContext* ctx, int32_t slot, float* outMs);
+/* Measurement aid (no reference counterpart): *outCount = the number of kernels the path's entry points have launched through this context since it was
+ * created (exactly the launches that take a timing slot above); outNames[0 .. n) = the names of the last n = min(maxNames, 16, *outCount) of them,
+ * oldest first (static strings; further entries NULL).  A caller that wants the kernels of ONE call reads the count in front of and behind it -- which
+ * kernels a cull chain consists of (k0_band_select or not, the wide list builder or not, brute force) is the library's decision, not the caller's guess.
+ * sailor_hip_context_time_launches is refused (SAILOR_HIP_ERR_UNSUPPORTED) while the context's stream is being captured into a hipGraph. */
+SAILOR_HIP_API int sailor_hip_context_launch_log(SailorHipContext* ctx, uint64_t* outCount, const char** outNames, int32_t maxNames);
+/* Measurement aid (no reference counterpart): one float4-per-lane streaming copy of `bytes` (a multiple of 16; both pointers 16-byte aligned) from dSrc to
+ * dDst on the context's stream -- the yardstick of THIS box and process for the roofline figures (2 x bytes of HBM traffic per call; time it with
+ * sailor_hip_context_time_launches like any kernel of the path).  Boxes of the pool differ by +-5 %; the guide's 6.29 TB/s is one of them. */
+SAILOR_HIP_API int sailor_hip_copy_probe(SailorHipContext* ctx, const void* dSrc, void* dDst, size_t bytes);
 
 /* ---- buffers: IGraphicsDriver::CreateBuffer (RHI/GraphicsDriver.h:89-90), AddSsboToShaderBindings (:154),
  *      IGraphicsDriverCommands::UpdateShaderBinding / UpdateBuffer (:303-304) -------------------------------- */
@@ -356,6 +366,12 @@ SAILOR_HIP_API int sailor_hip_light_cull_prepared(SailorHipContext* ctx,
                                                   const void* dPreparedLights /* or NULL */, int32_t preparedCapacity);
 SAILOR_HIP_API int sailor_hip_light_cull_diagnostics(SailorHipContext* ctx, int32_t width, int32_t height, int32_t lightsNum, const SailorBand* band,
                                                      const void* dWorkspace, uint64_t* out8);
+/* The band-local light selection (SAILOR_CULL_BAND_SELECT and its default above) as the last cull with this geometry and pc->lightsNum == lightsNum left
+ * it in dWorkspace: *outSelectedCount -> one device uint32, the number M of lights that can reach the band; *outLightMap -> M device uint32, the
+ * selected lights' indices in ascending order.  Meaningful only if that cull ran the selection (sailor_hip_context_launch_log names a call's kernels:
+ * "k0_band_select" is the first of the chain then).  Tests and diagnostics; either out pointer may be NULL. */
+SAILOR_HIP_API int sailor_hip_light_cull_band_selection(int32_t width, int32_t height, int32_t lightsNum, const SailorBand* band, const void* dWorkspace,
+                                                        const uint32_t** outSelectedCount, const uint32_t** outLightMap);
 
 /* Multi-GPU stitch helpers.  After an all-gather of the per-band totals, rebase a band's grid
  * to the canonical global offsets: offset += globalBase (globalBase = sum of num over all earlier bands). */
@@ -483,14 +499,32 @@ SAILOR_HIP_API int sailor_hip_evsm_blur_pass(SailorHipContext* ctx, const float*
  *   dWorld         : device out, mat4 per entity (m_cachedWorldMatrix)
  *   dWorldAabb     : device out, SailorAABB per entity
  *   dVisibility    : device out, 1 bit per entity, LSB-first in uint64 words, ceil(n/64) words
- *   [entityBegin, entityEnd) restricts the sweep to a slice of every level (multi-GPU entity sharding needs the
- *   parents' world matrices, so a slice must contain its ancestors: use whole levels or root-closed ranges).
  */
 SAILOR_HIP_API int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntities,
                                         const SailorTransform* dTransforms, const uint32_t* dParent,
                                         const uint32_t* levelOffsets, uint32_t numLevels,
                                         const SailorAABB* dLocalAabb, const float* planes,
                                         float* dWorld, SailorAABB* dWorldAabb, uint64_t* dVisibility);
+/* K4 split across the ranks of a node (the reference fans the same sweep out in 1 024-entity chunks over its worker threads,
+ * ECS/StaticMeshRendererECS.cpp:17-150): the sweep of the slice [entityBegin, entityEnd) of the entity array only -- its entries of dWorld / dWorldAabb,
+ * its bits of dVisibility.  A hierarchy of at most four levels (the one-launch form: an entity rebuilds its ancestors' relative matrices from their TRS
+ * records, the same bits as the level-by-level product) takes ANY slice and needs nothing another rank computes; a deeper one reads its parents' world
+ * matrices and is refused unless the slice is the whole set (SAILOR_HIP_ERR_UNSUPPORTED: sweep it replicated).
+ * sailor_hip_ecs_range_for_rank: rank r's slice of an equal split in whole 64-entity visibility words, ceil(words / worldSize) = *outWordsPerRank per
+ * rank (the last ranks may get fewer entities, or none).  sailor_hip_exchange_visibility: ONE in-place ncclAllGather of those words on `comm` and the
+ * context's stream -- dVisibility must hold worldSize * wordsPerRank uint64 -- after which every rank holds the whole bitmask (C5: 128 KB).  World
+ * matrices and boxes stay where they were computed: a consumer that needs ALL of them on every rank (instance data for draws) is better served by the
+ * replicated sweep -- 64 B + 24 B per entity over xGMI cost more than the 38 us the whole sweep takes on one GPU. */
+SAILOR_HIP_API int sailor_hip_ecs_sweep_range(SailorHipContext* ctx, uint32_t numEntities,
+                                              const SailorTransform* dTransforms, const uint32_t* dParent,
+                                              const uint32_t* levelOffsets, uint32_t numLevels,
+                                              const SailorAABB* dLocalAabb, const float* planes,
+                                              float* dWorld, SailorAABB* dWorldAabb, uint64_t* dVisibility,
+                                              uint32_t entityBegin, uint32_t entityEnd);
+SAILOR_HIP_API int sailor_hip_ecs_range_for_rank(uint32_t numEntities, int32_t rank, int32_t worldSize, uint32_t* outBegin, uint32_t* outEnd,
+                                                 uint32_t* outWordsPerRank /* or NULL */);
+SAILOR_HIP_API int sailor_hip_exchange_visibility(SailorHipContext* ctx, void* comm, int32_t rank, int32_t worldSize, uint32_t numEntities,
+                                                  uint64_t* dVisibility);
 
 #define SAILOR_RASTER_CLEAR 1u
 #define SAILOR_RASTER_CULL_BACK 2u

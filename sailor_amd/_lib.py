@@ -136,6 +136,9 @@ SIGNATURES = {
     "sailor_hip_context_wait_for": (C.c_int, [_P, _P]),
     "sailor_hip_context_time_launches": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "sailor_hip_context_timed_launch_ms": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float)]),
+    "sailor_hip_copy_probe": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "sailor_hip_context_launch_log": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_char_p), C.c_int32]),
+    "sailor_hip_light_cull_band_selection": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band), _P, C.POINTER(_P), C.POINTER(_P)]),
     "sailor_hip_evsm_blur": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sailor_hip_evsm_blur_pass": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sailor_hip_compute_brdf_lut": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
@@ -147,6 +150,9 @@ SIGNATURES = {
     "sailor_hip_prefilter_env_level": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float]),
     "sailor_hip_buffer_copy": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t]),
     "sailor_hip_ecs_sweep": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_uint32), C.c_uint32, _P, C.POINTER(C.c_float), _P, _P, _P]),
+    "sailor_hip_ecs_sweep_range": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_uint32), C.c_uint32, _P, C.POINTER(C.c_float), _P, _P, _P, C.c_uint32, C.c_uint32]),
+    "sailor_hip_ecs_range_for_rank": (C.c_int, [C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "sailor_hip_exchange_visibility": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_uint32, _P]),
     "sailor_hip_mesh_frustum_cull": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_uint32, C.c_uint32]),
     "sailor_hip_raster_coarse_words": (C.c_size_t, [C.c_int32, C.c_int32]),
     "sailor_hip_raster_depth": (C.c_int, [_P, C.POINTER(C.c_float), _P, _P, C.c_uint32, _P, _P, C.c_uint32, C.c_int32, C.c_int32, _P, C.c_uint32, _P]),

@@ -25,6 +25,9 @@ struct SailorHipContext {
     std::vector<hipEvent_t> timeStart, timeStop;
     int timeNext = 0, timeEnd = 0;
     hipEvent_t orderEvent = nullptr; // sailor_hip_context_wait_for: "everything recorded on this context so far"
+    // sailor_hip_context_launch_log: how many kernels the path's entry points have launched through this context, and the names of the last few
+    uint64_t launchCount = 0, launchNoted = 0;
+    const char* launchNames[16] = {};
 };
 
 static inline int sailor_map_hip_error(SailorHipContext* ctx, hipError_t e, const char* what)
@@ -52,8 +55,13 @@ static inline int sailor_map_hip_error(SailorHipContext* ctx, hipError_t e, cons
         if (_e != hipSuccess) return sailor_map_hip_error((ctx), _e, #expr);        \
     } while (0)
 
+// (also names the launch in the context's log: the last sailor_launch, if nothing has named it yet)
 #define SAILOR_CHECK_LAUNCH(ctx, name)                                              \
     do {                                                                            \
+        if ((ctx)->launchNoted != (ctx)->launchCount) {                             \
+            (ctx)->launchNames[((ctx)->launchCount - 1) & 15] = name;               \
+            (ctx)->launchNoted = (ctx)->launchCount;                                \
+        }                                                                           \
         hipError_t _e = hipGetLastError();                                          \
         if (_e != hipSuccess) return sailor_map_hip_error((ctx), _e, name);         \
     } while (0)
@@ -67,6 +75,8 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 template <typename K, typename... Args>
 static inline void sailor_launch_lds(SailorHipContext* ctx, K kernel, const dim3 grid, const dim3 block, const unsigned dynamicLdsBytes, Args... args)
 {
+    ctx->launchNames[ctx->launchCount & 15] = "?";
+    ctx->launchCount++;
     if (ctx->timeNext < ctx->timeEnd) {
         const int i = ctx->timeNext++;
         hipExtLaunchKernelGGL(kernel, grid, block, dynamicLdsBytes, ctx->stream, ctx->timeStart[i], ctx->timeStop[i], 0, args...);

@@ -88,11 +88,19 @@ int sailor_hip_context_time_launches(SailorHipContext* ctx, int32_t firstSlot, i
 {
     if (!ctx || firstSlot < 0 || count < 0 || firstSlot + count > SAILOR_MAX_TIMING_SLOTS) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    // (a launch with events on its dispatch packet cannot be part of a hipGraph: refused while the stream is being captured)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        ctx->lastError = "sailor_hip_context_time_launches: the context's stream is being captured";
+        return SAILOR_HIP_ERR_UNSUPPORTED;
+    }
     while ((int)ctx->timeStart.size() < firstSlot + count) {
+        // both events of a slot exist before either is kept: timeStart and timeStop always have the same length
         hipEvent_t a = nullptr, b = nullptr;
         SAILOR_TRY_HIP(ctx, hipEventCreate(&a));
+        const hipError_t eb = hipEventCreate(&b);
+        if (eb != hipSuccess) { (void)hipEventDestroy(a); return sailor_map_hip_error(ctx, eb, "hipEventCreate"); }
         ctx->timeStart.push_back(a);
-        SAILOR_TRY_HIP(ctx, hipEventCreate(&b));
         ctx->timeStop.push_back(b);
     }
     ctx->timeNext = firstSlot;
@@ -100,9 +108,20 @@ int sailor_hip_context_time_launches(SailorHipContext* ctx, int32_t firstSlot, i
     return SAILOR_HIP_OK;
 }
 
+int sailor_hip_context_launch_log(SailorHipContext* ctx, uint64_t* outCount, const char** outNames, int32_t maxNames)
+{
+    if (!ctx || !outCount || maxNames < 0 || (maxNames > 0 && !outNames)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    *outCount = ctx->launchCount;
+    uint64_t n = ctx->launchCount < 16 ? ctx->launchCount : 16;
+    if (n > (uint64_t)maxNames) n = (uint64_t)maxNames;
+    for (uint64_t k = 0; k < n; k++) outNames[k] = ctx->launchNames[(ctx->launchCount - n + k) & 15]; // oldest first
+    for (int32_t k = (int32_t)n; k < maxNames; k++) outNames[k] = nullptr;
+    return SAILOR_HIP_OK;
+}
+
 int sailor_hip_context_timed_launch_ms(SailorHipContext* ctx, int32_t slot, float* outMs)
 {
-    if (!ctx || !outMs || slot < 0 || slot >= (int)ctx->timeStart.size()) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx || !outMs || slot < 0 || slot >= (int)ctx->timeStart.size() || slot >= (int)ctx->timeStop.size()) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     SAILOR_TRY_HIP(ctx, hipEventSynchronize(ctx->timeStop[slot]));
     SAILOR_TRY_HIP(ctx, hipEventElapsedTime(outMs, ctx->timeStart[slot], ctx->timeStop[slot]));
     return SAILOR_HIP_OK;
@@ -162,6 +181,26 @@ __global__ void k_fill_u32(uint32_t* dst, uint32_t value, size_t count)
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < count; i += stride) dst[i] = value;
+}
+
+// sailor_hip_copy_probe: the box's yardstick -- a float4-per-lane streaming copy, the access pattern MI355X_MICROARCH.md's 6.29 TB/s figure was taken with
+__global__ __launch_bounds__(256) void k_copy_probe(const float4* __restrict__ src, float4* __restrict__ dst, size_t count4)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += stride) dst[i] = src[i];
+}
+
+int sailor_hip_copy_probe(SailorHipContext* ctx, const void* dSrc, void* dDst, size_t bytes)
+{
+    if (!ctx || !dSrc || !dDst || (bytes & 15) || (((uintptr_t)dSrc | (uintptr_t)dDst) & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (!bytes) return SAILOR_HIP_OK;
+    const size_t count4 = bytes / 16;
+    size_t blocks = (count4 + 255) / 256;
+    if (blocks > (size_t)ctx->numCUs * 32) blocks = (size_t)ctx->numCUs * 32; // 32 blocks per CU, grid-stride beyond
+    sailor_launch(ctx, k_copy_probe, dim3((unsigned)blocks), dim3(256), (const float4*)dSrc, (float4*)dDst, count4);
+    SAILOR_CHECK_LAUNCH(ctx, "k_copy_probe");
+    return SAILOR_HIP_OK;
 }
 
 int sailor_hip_buffer_copy(SailorHipContext* ctx, void* dstDevice, size_t dstOffset, const void* srcDevice, size_t srcOffset, size_t bytes)

@@ -429,13 +429,19 @@ __global__ __launch_bounds__(256) void k4_mesh_frustum_cull(Mat4 view, Mat4 invP
 
 extern "C" {
 
-int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntities, const SailorTransform* dTransforms, const uint32_t* dParent,
-                         const uint32_t* levelOffsets, uint32_t numLevels, const SailorAABB* dLocalAabb, const float* planes,
-                         float* dWorld, SailorAABB* dWorldAabb, uint64_t* dVisibility)
+// [entityBegin, entityEnd): the slice of the entity array this call sweeps (the split of K4 across the ranks of a node, SURVEY.md 8e: contiguous index
+// ranges, one all-gather of the visibility words behind it).  Hierarchies of up to ECS_FUSED_LEVELS levels -- the one-launch form, in which an entity
+// rebuilds its ancestors' relative matrices from their TRS records and so needs nothing another rank computes -- take any slice; a deeper hierarchy
+// reads its parents' WORLD matrices, which only a sweep of the whole set has: a proper slice of one is refused (SAILOR_HIP_ERR_UNSUPPORTED: sweep it whole
+// on every rank).  Only the slice's entries of dWorld / dWorldAabb and the slice's bits of dVisibility are written.
+int sailor_hip_ecs_sweep_range(SailorHipContext* ctx, uint32_t numEntities, const SailorTransform* dTransforms, const uint32_t* dParent,
+                               const uint32_t* levelOffsets, uint32_t numLevels, const SailorAABB* dLocalAabb, const float* planes,
+                               float* dWorld, SailorAABB* dWorldAabb, uint64_t* dVisibility, uint32_t entityBegin, uint32_t entityEnd)
 {
     if (!ctx || !levelOffsets || !planes) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device)); // a host thread may drive several contexts
-    if (numEntities == 0) return SAILOR_HIP_OK;
+    if (entityBegin > entityEnd || entityEnd > numEntities) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (numEntities == 0 || entityBegin == entityEnd) return SAILOR_HIP_OK;
     if (!dTransforms || !dParent || !dLocalAabb || !dWorld || !dWorldAabb || !dVisibility) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (numLevels == 0 || levelOffsets[0] != 0 || levelOffsets[numLevels] != numEntities) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (((uintptr_t)dTransforms & 15) || ((uintptr_t)dWorld & 15)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
@@ -445,12 +451,13 @@ int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntities, const Sail
     for (uint32_t l = 0; l < numLevels; l++)
         if (levelOffsets[l + 1] < levelOffsets[l] || levelOffsets[l + 1] > numEntities) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (numLevels <= ECS_FUSED_LEVELS) { // shallow hierarchy: every level in one launch (ancestors' relative matrices are recomputed)
-        const uint32_t words = (numEntities + 63) >> 6;
-        hipLaunchKernelGGL(k4_ecs_level<true>, dim3((words + 3) / 4), dim3(256), 0, ctx->stream, 0u, numEntities, (const float4*)dTransforms, dParent,
+        const uint32_t words = ((entityEnd + 63) >> 6) - (entityBegin >> 6);
+        hipLaunchKernelGGL(k4_ecs_level<true>, dim3((words + 3) / 4), dim3(256), 0, ctx->stream, entityBegin, entityEnd, (const float4*)dTransforms, dParent,
                            (const float*)dLocalAabb, P, boxVec, (float4*)dWorld, (float*)dWorldAabb, (unsigned long long*)dVisibility);
         SAILOR_CHECK_LAUNCH(ctx, "k4_ecs_level<fused>");
         return SAILOR_HIP_OK;
     }
+    if (entityBegin != 0 || entityEnd != numEntities) return SAILOR_HIP_ERR_UNSUPPORTED;
     for (uint32_t l = 0; l < numLevels; l++) {
         const uint32_t lo = levelOffsets[l], hi = levelOffsets[l + 1];
         if (hi == lo) continue;
@@ -459,6 +466,29 @@ int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntities, const Sail
                            (const float*)dLocalAabb, P, boxVec, (float4*)dWorld, (float*)dWorldAabb, (unsigned long long*)dVisibility);
         SAILOR_CHECK_LAUNCH(ctx, "k4_ecs_level");
     }
+    return SAILOR_HIP_OK;
+}
+
+int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntities, const SailorTransform* dTransforms, const uint32_t* dParent,
+                         const uint32_t* levelOffsets, uint32_t numLevels, const SailorAABB* dLocalAabb, const float* planes,
+                         float* dWorld, SailorAABB* dWorldAabb, uint64_t* dVisibility)
+{
+    return sailor_hip_ecs_sweep_range(ctx, numEntities, dTransforms, dParent, levelOffsets, numLevels, dLocalAabb, planes, dWorld, dWorldAabb, dVisibility, 0u, numEntities);
+}
+
+// The slice of rank `rank` of `worldSize` for sailor_hip_ecs_sweep_range: whole 64-entity visibility words, ceil(words / worldSize) of them per rank
+// (the last ranks may get fewer, or none), so that the ranks' visibility words are disjoint runs of equal length: ONE in-place ncclAllGather of
+// *outWordsPerRank uint64 per rank over a buffer of worldSize * *outWordsPerRank words rebuilds the whole bitmask on every rank.
+int sailor_hip_ecs_range_for_rank(uint32_t numEntities, int32_t rank, int32_t worldSize, uint32_t* outBegin, uint32_t* outEnd, uint32_t* outWordsPerRank)
+{
+    if (worldSize <= 0 || rank < 0 || rank >= worldSize || !outBegin || !outEnd) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const uint64_t words = ((uint64_t)numEntities + 63) >> 6;
+    const uint64_t per = (words + (uint64_t)worldSize - 1) / (uint64_t)worldSize;
+    uint64_t b = per * (uint64_t)rank * 64, e = per * (uint64_t)(rank + 1) * 64;
+    if (b > numEntities) b = numEntities;
+    if (e > numEntities) e = numEntities;
+    *outBegin = (uint32_t)b; *outEnd = (uint32_t)e;
+    if (outWordsPerRank) *outWordsPerRank = (uint32_t)per;
     return SAILOR_HIP_OK;
 }
 

@@ -64,6 +64,19 @@ extern "C" int sailor_hip_allgather_u32(SailorHipContext* ctx, void* comm, const
     return SAILOR_HIP_OK;
 }
 
+// ---- K4 split across the ranks ("Entities: contiguous index ranges ... one all-gather of the visibility bitmask"): every rank has swept
+// its slice (sailor_hip_ecs_range_for_rank / sailor_hip_ecs_sweep_range: whole 64-entity words, the same number per rank) into ITS part of dVisibility;
+// one in-place ncclAllGather completes the bitmask on every rank.  dVisibility holds worldSize * wordsPerRank uint64.
+extern "C" int sailor_hip_exchange_visibility(SailorHipContext* ctx, void* comm, int32_t rank, int32_t worldSize, uint32_t numEntities, uint64_t* dVisibility)
+{
+    if (!ctx || !comm || !dVisibility || worldSize <= 0 || rank < 0 || rank >= worldSize) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    uint32_t b = 0, e = 0, per = 0;
+    if (sailor_hip_ecs_range_for_rank(numEntities, rank, worldSize, &b, &e, &per) != SAILOR_HIP_OK) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (per == 0) return SAILOR_HIP_OK;
+    // (in place: a rank's send buffer is its own slot of the receive buffer, which is what ncclAllGather's in-place form asks for)
+    return sailor_hip_allgather_u32(ctx, comm, (const uint32_t*)(dVisibility + (size_t)rank * per), (uint32_t*)dVisibility, (size_t)per * 2);
+}
+
 // ---- the whole exchange of a split frame: band lists -> the reference's global lightsGrid / culledLights on every rank --------
 // Three all-gathers (band total; index segments in slots of the largest band's total, known from the first; grid padded to the largest band)
 // into the workspace, then ONE kernel per rank that turns the gathered slots into the canonical buffers: global offset of band r = sum of the

@@ -472,8 +472,11 @@ __device__ __forceinline__ void k1_tile_frusta(const int block, const PrepareArg
 // the group lists hold compact indices, k1_tile_cull translates them when a list leaves).  With SAILOR_CULL_PREPARE_LIGHTS the prepared views of ALL
 // lights are derived here (they outlive the band).
 // Ordered compaction in one pass: a block takes 1 024 lights (four per thread, all in registers), publishes its count, adds up the counts of the
-// blocks in front of it (every thread polls a few of them; the grid is at most four blocks per CU -- all resident -- and blocks are dispatched in
-// index order, so a block only ever waits for blocks that are running or done), and writes its lights behind them.
+// blocks in front of it (every thread polls a few of them) and writes its lights behind them.  WHICH 1 024 lights a block takes is decided by a
+// TICKET it draws when it starts (one relaxed atomic on state[1], as CUB's decoupled look-back numbers its tiles): a block only ever waits for
+// lower tickets, whose holders are running or done and publish before they wait for anything -- forward progress without any assumption about
+// the order in which the hardware starts blocks or about how many of them are resident (the next frame's cull runs beside the previous frame's
+// band shade, which holds most wave slots; round 4's form numbered the ranges by blockIdx and relied on both).
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t lanemask_lt();
 struct SelectArgs {
@@ -482,28 +485,32 @@ struct SelectArgs {
     const float4* soaPosRadius; const uint32_t* soaType;
     float4* prepPosRadius; uint32_t* prepType; float4* prepStaged;
     float4* lightView; uint32_t* lightType; uint32_t* lightMap;
-    uint32_t* state; // [0] = M, [2 + b] = block b's count + 1 (zeroed in front of the launch)
+    uint32_t* state; // [0] = M, [1] = the ticket counter, [2 + b] = the count + 1 of the block with ticket b (all zeroed in front of the launch)
     int N, vpW, vpH, Tx, tileRow0, bandRows;
     int stageSelectedOnly; // SAILOR_CULL_PREPARE_SELECTED: the staged shade records only of the lights that are kept (the 20-byte cull views of all)
     float planeMargin;
 };
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k0_band_select(const SelectArgs a)
+__global__ __launch_bounds__(256) void k0_band_select(const SelectArgs a)
 {
     __shared__ float4 sPl[2];
-    __shared__ uint32_t sCnt[4][4], sPart[4];
+    __shared__ uint32_t sCnt[4][4], sPart[4], sTicket;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) {
+    // (relaxed: the ticket orders nothing but the blocks' numbering)
+    if (threadIdx.x == 0) sTicket = __hip_atomic_fetch_add(a.state + 1u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 64) { // (another wave than the ticket's: the planes are built while the atomic is on its way)
         Frustum4 f;
         frustum_from_rect(a.invProj, 0.0f, (float)(a.tileRow0 * TILE), (float)(a.Tx * TILE), (float)((a.tileRow0 + a.bandRows) * TILE), a.vpW, a.vpH, f);
         sPl[0] = make_float4(f.n[2][0], f.n[2][1], f.n[2][2], 0.0f); // top: the first row band's
         sPl[1] = make_float4(f.n[3][0], f.n[3][1], f.n[3][2], 0.0f); // bottom: the last row band's
     }
+    __syncthreads(); // the ticket (and the planes) are in LDS
+    const uint32_t b = sTicket; // this block's place in the light order: lights [1024 b, 1024 b + 1024)
     float4 lv[4];
     uint32_t type[4];
     unsigned long long keep[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int j = (int)blockIdx.x * SEL_LIGHTS + k * 256 + (int)threadIdx.x;
+        const int j = (int)b * SEL_LIGHTS + k * 256 + (int)threadIdx.x;
         lv[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         type[k] = 1u;
         if (j < a.N) {
@@ -537,10 +544,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             lv[k] = make_float4(p.x, p.y, p.z, radius);
         }
     }
-    __syncthreads(); // the planes are in LDS
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int j = (int)blockIdx.x * SEL_LIGHTS + k * 256 + (int)threadIdx.x;
+        const int j = (int)b * SEL_LIGHTS + k * 256 + (int)threadIdx.x;
         const bool valid = j < a.N;
         const float r = lv[k].w;
         const float m = a.planeMargin * ((fabsf(lv[k].x) + fabsf(lv[k].y)) + (fabsf(lv[k].z) + fabsf(r)));
@@ -561,7 +567,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 #pragma unroll
         for (int w = 0; w < 4; w++) { const uint32_t c = sCnt[k][w]; if (w < wave) before[k] += c; total += c; }
     }
-    const uint32_t b = blockIdx.x;
     // (relaxed: the word IS the message -- nothing else passes between blocks; a release here is a write-back of the XCD's whole L2, per block: 100 us)
     if (threadIdx.x == 0) __hip_atomic_store(a.state + 2u + b, total + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t acc = 0u;
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     for (int k = 0; k < 4; k++) {
         if ((keep[k] >> lane) & 1ull) {
             const uint32_t c = base + before[k] + (uint32_t)__popcll(keep[k] & lanemask_lt());
-            const int j = (int)blockIdx.x * SEL_LIGHTS + k * 256 + (int)threadIdx.x;
+            const int j = (int)b * SEL_LIGHTS + k * 256 + (int)threadIdx.x;
             a.lightView[c] = lv[k];
             a.lightType[c] = type[k];
             a.lightMap[c] = (uint32_t)j;
@@ -1644,11 +1649,10 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     pa.lightView = (float4*)(ws + L.offLightView); pa.lightType = (uint32_t*)(ws + L.offLightType); pa.tileInfo = (float4*)(ws + L.offTileInfo);
     // A band of a split frame with a large light set: the lights that can reach the band are selected first (k0_band_select) and the chain runs on them.
     // From 131 072 lights on (below, the light role and the group lists of a band sit at their launch floors whatever the count); SAILOR_CULL_BAND_SELECT
-    // forces it for any set the pre-filter runs on, SAILOR_CULL_NO_BAND_SELECT switches it off.  The grid must be resident as a whole (four blocks per CU: up to
-    // 1 M lights on 256 CUs; beyond that the chain runs on all lights as before).
+    // forces it for any set the pre-filter runs on, SAILOR_CULL_NO_BAND_SELECT switches it off.  (Any number of blocks: they take their light ranges by
+    // ticket, so the grid need not be resident as a whole.)
     uint32_t* selState = (uint32_t*)(ws + L.offSelState);
-    const bool select = !brute && L.bandRows < L.Ty && !(flags & SAILOR_CULL_NO_BAND_SELECT) && ((flags & SAILOR_CULL_BAND_SELECT) || N >= 131072) &&
-                        L.selBlocks <= 4 * ctx->numCUs; // (at most 128 registers, 108 bytes of LDS: four blocks per CU at least, tests/test_kernel_resources_cpu.py)
+    const bool select = !brute && L.bandRows < L.Ty && !(flags & SAILOR_CULL_NO_BAND_SELECT) && ((flags & SAILOR_CULL_BAND_SELECT) || N >= 131072);
     pa.selCount = nullptr;
     if (select) {
         SelectArgs sa;
@@ -1707,7 +1711,8 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
         else sailor_launch(ctx, k1_tile_cull_brute<false>, dim3(L.groupsX, L.bandRows), dim3(256), ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull<brute>");
     } else {
-        if (L.words >= 4096 && (L.words & 1) == 0)
+        const bool wide = L.words >= 4096 && (L.words & 1) == 0;
+        if (wide)
         {
             const dim3 wideGrid((unsigned)(((L.groupsX + 3) / 4) * L.groupsY));
             if (L.words % (128 * GLW_ROWS) == 0 && !select)
@@ -1722,7 +1727,7 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
                                (uint32_t*)(ws + L.offGroupList), (uint32_t*)(ws + L.offHeavy), (uint32_t)(L.bandRows * 2 > L.Ty ? HEAVY_MIN_FRAME : HEAVY_MIN_BAND), pa.selCount);
             ca.headRows = (16 * HEAVY_MAX + L.groupsX - 1) / L.groupsX; // grid rows for the listed clusters' tiles (a block each), in front of the tile rows
         }
-        SAILOR_CHECK_LAUNCH(ctx, "k1_group_lists");
+        SAILOR_CHECK_LAUNCH(ctx, wide ? "k1_group_lists_wide" : "k1_group_lists");
         // (the block-wide selection everywhere but on the long lists of the wide path: see k1_tile_cull)
         const dim3 cgrid(L.groupsX, ca.headRows + L.bandRows);
         if (select) { // (a band by definition: the hint's kernels)
@@ -1818,6 +1823,22 @@ const uint32_t* sailor_hip_light_cull_tile_order(int32_t width, int32_t height, 
     const CullLayout L = make_layout(width, height, lightsCapacity, *band);
     if (!layout_has_hint(L)) return nullptr; // whole frame: no hint is produced (raster order)
     return (const uint32_t*)((const char*)dWorkspace + L.offTileOrder);
+}
+
+// The band's own light set as the last cull of this geometry AND light count left it (k0_band_select): the number of selected lights and
+// lightMap (compact index -> light index, ascending).  Both lie in the part of the workspace whose place depends on the light count, hence
+// lightsNum = that cull's pc->lightsNum.  Meaningful only if that cull ran the selection (sailor_hip_context_launch_log names its kernels).
+int sailor_hip_light_cull_band_selection(int32_t width, int32_t height, int32_t lightsNum, const SailorBand* band, const void* dWorkspace,
+                                         const uint32_t** outSelectedCount, const uint32_t** outLightMap)
+{
+    if (!dWorkspace || width <= 0 || height <= 0 || lightsNum < 0) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SailorBand whole;
+    if (!band) { sailor_hip_band_whole_frame(width, height, &whole); band = &whole; }
+    if (!band_valid(width, height, band)) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    const CullLayout L = make_layout(width, height, lightsNum, *band);
+    if (outSelectedCount) *outSelectedCount = (const uint32_t*)((const char*)dWorkspace + L.offSelState);
+    if (outLightMap) *outLightMap = (const uint32_t*)((const char*)dWorkspace + L.offLightMap);
+    return SAILOR_HIP_OK;
 }
 
 // Diagnostics for benchmarks / tuning (synchronises): density of the band masks and of the group candidate lists left in

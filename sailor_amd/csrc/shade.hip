@@ -364,10 +364,11 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
     if (dPreparedLights) L = reinterpret_cast<const SailorLightShaderData*>((const char*)dPreparedLights + prepared_layout(preparedCapacity).offStaged);
     // (tile lists: the kernels' `grid` argument is tileNum, their `culled` the per-tile slots -- see k2_shade_body)
     const SailorLightsGrid* G = dTileNum ? reinterpret_cast<const SailorLightsGrid*>(dTileNum) : dLightsGrid;
-#define LAUNCH_SHADE(K) do { if (dPreparedLights && dTileNum) sailor_launch(ctx, K##_pt, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); \
-                             else if (dPreparedLights) sailor_launch(ctx, K##_p, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); \
-                             else if (dTileNum) sailor_launch(ctx, K##_t, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); \
-                             else sailor_launch(ctx, K, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } while (0)
+    const char* kname = "k2_shade"; // (the launched variant's name, for sailor_hip_context_launch_log)
+#define LAUNCH_SHADE(K) do { if (dPreparedLights && dTileNum) { kname = #K "_pt"; sailor_launch(ctx, K##_pt, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
+                             else if (dPreparedLights) { kname = #K "_p"; sailor_launch(ctx, K##_p, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
+                             else if (dTileNum) { kname = #K "_t"; sailor_launch(ctx, K##_t, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
+                             else { kname = #K; sailor_launch(ctx, K, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } } while (0)
     const bool splitBand = dTileOrder && band->tileRowEnd - band->tileRowBegin < Ty && !ibl; // a band of a split frame: long tiles are split across four blocks
     if (hasCsm && ibl) LAUNCH_SHADE(k2_shade_csm_ibl);
     else if (hasCsm && !splitBand) LAUNCH_SHADE(k2_shade_csm);
@@ -383,16 +384,16 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
         // cull chain is as long as its shade (an eighth of the 8K frame under a million lights: 16 320 tiles, 80 us of cull beside 78 us of shade; 152 -> 134 us).
         static const int bandLdsEnv = [] { const char* e = getenv("SAILOR_BAND_SHADE_LDS"); return e ? atoi(e) : -1; }();
         const unsigned bandLds = bandLdsEnv >= 0 ? (unsigned)bandLdsEnv : ((bandTiles <= 3 * 8 * ctx->numCUs || lightsNum >= 131072) ? (unsigned)SHADE_BAND_RESERVE : 0u);
-#define LAUNCH_BAND(K) do { if (dPreparedLights && dTileNum) sailor_launch_lds(ctx, K##_pt, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); \
-                            else if (dPreparedLights) sailor_launch_lds(ctx, K##_p, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); \
-                            else if (dTileNum) sailor_launch_lds(ctx, K##_t, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); \
-                            else sailor_launch_lds(ctx, K, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); } while (0)
+#define LAUNCH_BAND(K) do { if (dPreparedLights && dTileNum) { kname = #K "_pt"; sailor_launch_lds(ctx, K##_pt, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
+                            else if (dPreparedLights) { kname = #K "_p"; sailor_launch_lds(ctx, K##_p, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
+                            else if (dTileNum) { kname = #K "_t"; sailor_launch_lds(ctx, K##_t, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
+                            else { kname = #K; sailor_launch_lds(ctx, K, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); } } while (0)
         if (hasCsm) LAUNCH_BAND(k2_shade_band_csm);
         else LAUNCH_BAND(k2_shade_band);
 #undef LAUNCH_BAND
     } else LAUNCH_SHADE(k2_shade);
 #undef LAUNCH_SHADE
-    SAILOR_CHECK_LAUNCH(ctx, "k2_shade");
+    SAILOR_CHECK_LAUNCH(ctx, kname);
     return SAILOR_HIP_OK;
 }
 

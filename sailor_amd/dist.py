@@ -124,6 +124,19 @@ def gather_rows(band_rows: torch.Tensor, group=None) -> torch.Tensor:
     return torch.cat([parts[r][: counts[r]] for r in reversed(range(world))], 0)
 
 
+def allgather_visibility(visibility: torch.Tensor, rank: int, world: int, words_per_rank: int, group=None) -> torch.Tensor:
+    """K4 split across ranks: rank r has swept the entities of words [r * words_per_rank, (r + 1) * words_per_rank) into its part of
+    `visibility` (int64 [>= world * words_per_rank]); one all-gather completes the bitmask on every rank, in place.  The torch.distributed form of
+    sailor_hip_exchange_visibility (gloo in the CPU tests, RCCL through torch on a node)."""
+    if world == 1 or words_per_rank == 0:
+        return visibility
+    mine = visibility[rank * words_per_rank:(rank + 1) * words_per_rank].clone()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    visibility[: world * words_per_rank] = torch.cat(parts)
+    return visibility
+
+
 # ---- the shipped exchange: sailor_hip_exchange_light_lists_rows over an ncclComm_t (exchange.hip; INTEGRATION.md 5) -------------------------------
 def _load_rccl():
     """The librccl this process already has mapped (torch brings its own copy under torch/lib; exchange.hip looks for the same one), else the loader's."""
@@ -164,18 +177,36 @@ class RcclComm:
                     payload = bytes(bytearray(uid))
             except Exception:
                 payload = None
-        if world_size > 1:   # (every rank takes part in the broadcast whatever rank 0 found: a failure travels as None)
+        everyone_has_lib = self.lib is not None
+        if world_size > 1:
+            # Every rank takes part in both collectives whatever it found: rank 0's id (None on failure) travels to all, and every rank tells all whether
+            # it has the library -- ncclCommInitRank is itself collective, so a rank that raised here alone would leave the others blocked in it forever
+            # (ADVICE r04).  Only when ALL ranks can go on does any of them go on.
             box = [payload]
             dist.broadcast_object_list(box, src=0, group=group)
             payload = box[0]
-        if payload is None or self.lib is None:
-            raise RuntimeError("no librccl on this rank" if self.lib is None else "ncclGetUniqueId failed on rank 0")
+            have = [None] * world_size
+            dist.all_gather_object(have, self.lib is not None, group=group)
+            everyone_has_lib = all(have)
+        if payload is None or not everyone_has_lib:
+            raise RuntimeError("no librccl on this rank" if self.lib is None else
+                               ("ncclGetUniqueId failed on rank 0" if payload is None else "another rank has no librccl"))
         C.memmove(C.byref(uid), payload, 128)
         comm = C.c_void_p()
         self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
         rc = self.lib.ncclCommInitRank(C.byref(comm), world_size, uid, rank)
-        if rc != 0:
-            raise RuntimeError(f"ncclCommInitRank failed: {rc}")
+        ok = rc == 0
+        if world_size > 1:   # (a failure on some rank only: every rank learns of it and none keeps a communicator the others do not have)
+            oks = [None] * world_size
+            dist.all_gather_object(oks, ok, group=group)
+            ok_all = all(oks)
+        else:
+            ok_all = ok
+        if not ok_all:
+            if ok:
+                self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
+                self.lib.ncclCommDestroy(comm)
+            raise RuntimeError(f"ncclCommInitRank failed: {rc}" if not ok else "ncclCommInitRank failed on another rank")
         self.handle, self.rank, self.world_size = comm, rank, world_size
 
     def close(self):

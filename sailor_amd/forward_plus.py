@@ -51,6 +51,23 @@ class HipContext:
         _lib.check(self._lib.sailor_hip_context_timed_launch_ms(self.handle, slot, C.byref(ms)), "sailor_hip_context_timed_launch_ms", self.handle)
         return float(ms.value)
 
+    def launch_log(self, max_names: int = 16):
+        """(count, names): how many kernels the path's entry points have launched through this context, and the names of the last few, oldest first
+        (sailor_hip_context_launch_log).  The kernels of ONE call = the names behind the count read in front of it."""
+        count = C.c_uint64()
+        names = (C.c_char_p * max_names)()
+        _lib.check(self._lib.sailor_hip_context_launch_log(self.handle, C.byref(count), names, max_names), "sailor_hip_context_launch_log", self.handle)
+        return int(count.value), [n.decode() for n in names if n is not None]
+
+    def launches_of(self, fn):
+        """the names of the kernels fn() launches through this context (at most 16)"""
+        before, _ = self.launch_log(0)
+        fn()
+        after, names = self.launch_log(16)
+        n = after - before
+        assert n <= 16, n
+        return names[len(names) - n:] if n else []
+
     def close(self):
         if getattr(self, "handle", None):
             self._lib.sailor_hip_context_destroy(self.handle)
@@ -224,6 +241,17 @@ class ForwardPlus:
         keys = ["bands", "mask_bits", "groups", "group_list_sum", "groups_overflowed", "group_list_max", "words_per_band", "column_mask_bits"]
         return dict(zip(keys, [int(v) for v in out]))
 
+    def band_selection(self, lights_num: int):
+        """(M, lightMap uint32[M]) of the last cull with lights_num lights, if that cull ran k0_band_select (the caller knows: HipContext.launches_of)"""
+        a, b = C.c_void_p(), C.c_void_p()
+        _lib.check(self.ctx._lib.sailor_hip_light_cull_band_selection(self.W, self.H, lights_num, C.byref(self.band), _ptr(self.workspace), C.byref(a), C.byref(b)),
+                   "sailor_hip_light_cull_band_selection")
+        self.ctx.synchronize()
+        base = self.workspace.data_ptr()
+        m = int(self.workspace[a.value - base: a.value - base + 4].view(torch.int32).cpu().numpy().view(np.uint32)[0])
+        lm = self.workspace[b.value - base: b.value - base + 4 * m].view(torch.int32).cpu().numpy().view(np.uint32).copy()
+        return m, lm
+
     def lists_to_host(self):
         """(grid uint32[T,2], indices uint32[1 + total]) of this band, band-local offsets."""
         self.ctx.synchronize()
@@ -314,30 +342,61 @@ def raw_env_cubemap(ctx: "HipContext", equirect: torch.Tensor, size: int, levels
     return chain
 
 
-class EcsSweep:
-    """K4 on one GPU over level-sorted entities."""
+def ecs_range_for_rank(n: int, rank: int, world: int):
+    """(begin, end, words per rank) of rank's slice of an equal split of n entities in whole visibility words (sailor_hip_ecs_range_for_rank; pure host
+    arithmetic, no device)"""
+    b, e, per = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    _lib.check(_lib.load().sailor_hip_ecs_range_for_rank(n, rank, world, C.byref(b), C.byref(e), C.byref(per)), "sailor_hip_ecs_range_for_rank")
+    return int(b.value), int(e.value), int(per.value)
 
-    def __init__(self, ctx: HipContext, entities):
+
+class EcsSweep:
+    """K4 on one GPU over level-sorted entities.  rank / world: this GPU sweeps its slice of an equal split only (sailor_hip_ecs_sweep_range); the
+    visibility buffer then has room for every rank's words and exchange_visibility() completes it."""
+
+    def __init__(self, ctx: HipContext, entities, rank: int = 0, world: int = 1):
         self.ctx = ctx
         dev = ctx.device
         self.n = len(entities.parent)
+        self.rank, self.world = rank, world
+        self.begin, self.end, self.words_per_rank = ecs_range_for_rank(self.n, rank, world)
         self.trs = torch.from_numpy(entities.transforms).to(dev)
         self.parent = torch.from_numpy(entities.parent.view(np.int32)).to(dev)
         self.local_aabb = torch.from_numpy(entities.local_aabb).to(dev)
         self.level_offsets = np.ascontiguousarray(entities.level_offsets, np.uint32)
         self.world = torch.empty((self.n, 16), dtype=torch.float32, device=dev)
         self.world_aabb = torch.empty((self.n, 6), dtype=torch.float32, device=dev)
-        self.visibility = torch.zeros((self.n + 63) // 64, dtype=torch.int64, device=dev)
+        self.visibility = torch.zeros(max((self.n + 63) // 64, world * self.words_per_rank), dtype=torch.int64, device=dev)
 
     def run(self, planes: np.ndarray):
         planes = np.ascontiguousarray(planes, np.float32).reshape(24)
         lib = self.ctx._lib
-        _lib.check(lib.sailor_hip_ecs_sweep(self.ctx.handle, self.n, _ptr(self.trs), _ptr(self.parent),
-                                            self.level_offsets.ctypes.data_as(C.POINTER(C.c_uint32)), len(self.level_offsets) - 1,
-                                            _ptr(self.local_aabb), planes.ctypes.data_as(C.POINTER(C.c_float)),
-                                            _ptr(self.world), _ptr(self.world_aabb), _ptr(self.visibility)),
-                   "sailor_hip_ecs_sweep", self.ctx.handle)
+        if self.world == 1:
+            _lib.check(lib.sailor_hip_ecs_sweep(self.ctx.handle, self.n, _ptr(self.trs), _ptr(self.parent),
+                                                self.level_offsets.ctypes.data_as(C.POINTER(C.c_uint32)), len(self.level_offsets) - 1,
+                                                _ptr(self.local_aabb), planes.ctypes.data_as(C.POINTER(C.c_float)),
+                                                _ptr(self.world), _ptr(self.world_aabb), _ptr(self.visibility)),
+                       "sailor_hip_ecs_sweep", self.ctx.handle)
+        else:
+            _lib.check(lib.sailor_hip_ecs_sweep_range(self.ctx.handle, self.n, _ptr(self.trs), _ptr(self.parent),
+                                                      self.level_offsets.ctypes.data_as(C.POINTER(C.c_uint32)), len(self.level_offsets) - 1,
+                                                      _ptr(self.local_aabb), planes.ctypes.data_as(C.POINTER(C.c_float)),
+                                                      _ptr(self.world), _ptr(self.world_aabb), _ptr(self.visibility), self.begin, self.end),
+                       "sailor_hip_ecs_sweep_range", self.ctx.handle)
         return self.world, self.world_aabb, self.visibility
+
+    def exchange_visibility(self, comm=None, group=None):
+        """every rank's visibility words -> the whole bitmask on every rank: sailor_hip_exchange_visibility on an ncclComm_t (dist.RcclComm), or the same
+        all-gather over torch.distributed when there is none (gloo tests, ranks sharing a GPU)"""
+        if self.world == 1:
+            return self.visibility
+        if comm is not None:
+            _lib.check(self.ctx._lib.sailor_hip_exchange_visibility(self.ctx.handle, comm.handle, self.rank, self.world, self.n, _ptr(self.visibility)),
+                       "sailor_hip_exchange_visibility", self.ctx.handle)
+        else:
+            from . import dist as sdist
+            sdist.allgather_visibility(self.visibility, self.rank, self.world, self.words_per_rank, group)
+        return self.visibility
 
 
 def raster_depth(ctx: "HipContext", light_matrix, positions: torch.Tensor, indices: torch.Tensor, models: torch.Tensor, width: int, height: int,

@@ -66,6 +66,36 @@ class _Context:
     def timed_launch_ms(self, slot):
         return 0.01
 
+    def launches_of(self, fn):   # (HipContext.launches_of: the kernels fn() launched, as the library's launch log names them)
+        fn()
+        return ["k01_prepare", "k1_group_lists", "k1_tile_cull", "k1_pack"]
+
+
+class _EcsSweep:
+    """EcsSweep's surface with the oracle behind it: a rank's slice fills its own words of the bitmask and nothing else"""
+
+    def __init__(self, ents, rank, world):
+        from sailor_amd.forward_plus import ecs_range_for_rank
+        self.ents, self.rank, self.world = ents, rank, world
+        self.n = len(ents.parent)
+        self.begin, self.end, self.words_per_rank = ecs_range_for_rank(self.n, rank, world)
+        self.visibility = torch.full((max((self.n + 63) // 64, world * self.words_per_rank),), -1, dtype=torch.int64)
+
+    def run(self, planes):
+        from oracle import oracle
+        _, _, ov = oracle.ecs_sweep(self.ents.transforms, self.ents.parent, self.ents.local_aabb, planes)
+        lo, hi = self.begin // 64, (self.end + 63) // 64
+        if self.world == 1:
+            self.visibility[: len(ov)] = torch.from_numpy(ov.view(np.int64).copy())
+        else:
+            self.visibility[self.rank * self.words_per_rank:(self.rank + 1) * self.words_per_rank] = 0
+            self.visibility[lo:hi] = torch.from_numpy(ov[lo:hi].view(np.int64).copy())
+        return None, None, self.visibility
+
+    def exchange_visibility(self, comm=None, group=None):
+        from sailor_amd import dist as sdist
+        return sdist.allgather_visibility(self.visibility, self.rank, self.world, self.words_per_rank, group)
+
 
 class _Prepared:
     def __init__(self, n):
@@ -171,6 +201,15 @@ class _Device:
     def forward_plus(self, ctx, W, H, N, band, prepared):
         return _ForwardPlus(W, H, N, band, prepared)
 
+    def upload_shadow_maps(self, shadows):
+        return None, None   # (the stand-in's shade ignores the shadow maps: the control flow is what is under test)
+
+    def ecs_sweep(self, ctx, entities, rank=0, world=1):
+        return _EcsSweep(entities, rank, world)
+
+    def exchange_visibility(self, sweep):
+        return sweep.exchange_visibility()
+
     def make_comm(self, rank, world):
         self.rank, self.world = rank, world
 
@@ -211,8 +250,9 @@ def _oracle_whole_frame():
     return g, idx
 
 
-@pytest.mark.parametrize("extra", [(), ("--equal-bands",), ("--frame-per-gpu",), ("--dynamic-lights", "--list-sets", "2"), ("--exchange-every-step",)],
-                         ids=["balanced", "equal", "frame_per_gpu", "dynamic_two_sets", "exchange_every_step"])
+@pytest.mark.parametrize("extra", [(), ("--equal-bands",), ("--frame-per-gpu",), ("--dynamic-lights", "--list-sets", "2"), ("--exchange-every-step",),
+                                   ("--split-configs", "tiny_csm,tiny", "--split-config-steps", "3")],
+                         ids=["balanced", "equal", "frame_per_gpu", "dynamic_two_sets", "exchange_every_step", "split_configs"])
 def test_two_ranks_run_the_whole_of_bench_main(extra, tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), extra, str(tmp_path)), nprocs=world, join=True)
@@ -250,6 +290,20 @@ def test_two_ranks_run_the_whole_of_bench_main(extra, tmp_path):
         assert res[0]["exchanges"] == res[1]["exchanges"] == 1
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["avg_launch_ms"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert list(r["cull"]["kernels_ms"]) == ["k01_prepare", "k1_group_lists", "k1_tile_cull", "k1_pack"], "the chain's kernels as the library's launch log names them"
+    # K4 across the ranks (entity ranges + one all-gather of the visibility words) beside K4 replicated, and the gathered bitmask is the replicated one
+    e = d["ecs_sweep"]["split"]
+    assert e["default"] == "replicated" and e["replicated_ms"] > 0 and e["split"]["ranks"] == 2 and e["split"]["bitmask_equals_replicated_on_every_rank"] is True
+    assert e["split"]["slice_plus_allgather_ms"] >= e["split"]["slice_ms"] * 0.5
+    if "--split-configs" in extra:
+        sc = d["split_configs"]
+        assert list(sc) == ["tiny_csm", "tiny"]
+        for name, v in sc.items():
+            assert v["config"] == name and v["split_ms_per_step"] > 0 and v["whole_frame_per_gpu_ms_per_step"] > 0 and v["value"] > 0, v
+            assert v["tile_row_bounds"][0] == 0 and v["tile_row_bounds"][-1] == 6 and len(v["tile_row_bounds"]) == 3
+            assert abs(v["speedup_vs_one_gpu_whole_frame"] - v["whole_frame_per_gpu_ms_per_step"] / v["split_ms_per_step"]) < 1e-9
+    else:
+        assert "split_configs" not in d
 
 
 def test_a_bare_gpus_n_starts_its_ranks_as_child_processes(monkeypatch):

@@ -63,3 +63,53 @@ def test_band_lists_stitch_to_the_canonical_global_buffers(world, tmp_path):
         np.testing.assert_array_equal(z["grid"].view(np.uint32).reshape(-1, 2), ref_g)
         np.testing.assert_array_equal(z["culled"].view(np.uint32), ref_i[: 1 + total])
         np.testing.assert_array_equal(z["rows"][:, 0], np.arange(h, dtype=np.float32))  # bands re-assembled top to bottom
+
+
+def _ecs_worker(rank, world, port, count, out_dir):
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    from oracle import oracle
+    from sailor_amd import dist as sdist, host, synth
+    from sailor_amd.forward_plus import ecs_range_for_rank
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ents = synth.make_entities(count)
+        cam = synth.make_camera(1920, 1080)
+        planes, _ = host.extract_frustum_planes(cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+        begin, end, per = ecs_range_for_rank(count, rank, world)
+        # this rank's slice as sailor_hip_ecs_sweep_range leaves it: only the slice's words of the bitmask are its own (the oracle is the kernel here)
+        _, _, ov = oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes)
+        vis = torch.full((max((count + 63) // 64, world * per),), -1, dtype=torch.int64)   # (garbage outside the slice)
+        mine = ov[begin // 64:(end + 63) // 64].view(np.int64)
+        vis[rank * per:rank * per + len(mine)] = torch.from_numpy(mine.copy())
+        if len(mine) < per:
+            vis[rank * per + len(mine):(rank + 1) * per] = 0
+        sdist.allgather_visibility(vis, rank, world, per)
+        np.save(Path(out_dir) / f"vis{rank}.npy", vis.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world, count", [(2, 5000), (3, 1000), (3, 130)])
+def test_entity_slices_all_gather_to_the_whole_visibility_bitmask(world, count, tmp_path):
+    """contiguous entity ranges per rank (whole 64-entity words: sailor_hip_ecs_range_for_rank), one all-gather of the visibility
+    words -- on every rank the oracle's bitmask of the whole set."""
+    port = _free_port()
+    mp.spawn(_ecs_worker, args=(world, port, count, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, str(ROOT))
+    from oracle import oracle
+    from sailor_amd import host, synth
+    from sailor_amd.forward_plus import ecs_range_for_rank
+    ents = synth.make_entities(count)
+    cam = synth.make_camera(1920, 1080)
+    planes, _ = host.extract_frustum_planes(cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+    _, _, ov = oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes)
+    words = (count + 63) // 64
+    spans = [ecs_range_for_rank(count, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == count and all(spans[r][1] == spans[r + 1][0] for r in range(world - 1)), spans
+    assert all(b % 64 == 0 for b, _, _ in spans) and len({p for _, _, p in spans}) == 1
+    for r in range(world):
+        got = np.load(tmp_path / f"vis{r}.npy").view(np.uint64)
+        np.testing.assert_array_equal(got[:words], ov)

@@ -146,3 +146,55 @@ def test_cascade_caster_sets_from_the_sweeps_world_boxes(ctx):
     got = csm_caster_masks(ctx, aabb[:1000], planes[:2])
     ctx.synchronize()
     np.testing.assert_array_equal(got.cpu().numpy().view(np.uint64), oracle.csm_caster_masks(aabb[:1000].cpu().numpy(), planes[:2]))
+
+
+@pytest.mark.parametrize("world, count", [(2, 100000), (3, 1000), (8, 1 << 20), (5, 130)])
+def test_entity_slices_of_the_sweep_are_the_whole_sweeps_bits(ctx, world, count):
+    """K4 split across the ranks of a node (sailor_hip_ecs_range_for_rank / sailor_hip_ecs_sweep_range): every rank sweeps a slice of
+    whole visibility words -- children rebuild their ancestors' relative matrices, so a slice needs nothing of another rank's -- and the slices'
+    matrices, boxes and visibility words, laid side by side as the all-gather lays them, are the whole sweep's and the oracle's, bit for bit.
+    (Ragged ends: ranks with fewer entities than the others, ranks with none.)"""
+    ents = synth.make_entities(count)
+    cam = synth.make_camera(1920, 1080)
+    planes = camera_planes(cam)
+    ow, oa, ov = oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes)
+    words = (count + 63) // 64
+    gathered, covered = [], 0
+    for r in range(world):
+        sw = EcsSweep(ctx, ents, rank=r, world=world)
+        assert sw.begin % 64 == 0 and (sw.end % 64 == 0 or sw.end == count) and sw.begin == min(r * sw.words_per_rank * 64, count)
+        sw.world.fill_(-7.0); sw.world_aabb.fill_(-7.0)
+        w, a, v = sw.run(planes)
+        ctx.synchronize()
+        w, a, v = w.cpu().numpy(), a.cpu().numpy(), v.cpu().numpy().view(np.uint64)
+        lo, hi = sw.begin, sw.end
+        np.testing.assert_array_equal(w[lo:hi].view(np.uint32), ow[lo:hi].view(np.uint32))
+        np.testing.assert_array_equal(a[lo:hi].view(np.uint32), oa[lo:hi].view(np.uint32))
+        assert (w[:lo] == -7.0).all() and (w[hi:] == -7.0).all() and (a[:lo] == -7.0).all() and (a[hi:] == -7.0).all(), "nothing outside the slice is written"
+        assert v.shape[0] >= world * sw.words_per_rank
+        gathered.append(v[r * sw.words_per_rank:(r + 1) * sw.words_per_rank])   # this rank's slot of the in-place all-gather
+        covered += hi - lo
+    assert covered == count
+    np.testing.assert_array_equal(np.concatenate(gathered)[:words], ov)
+
+
+def test_a_slice_of_a_deep_hierarchy_is_refused(ctx):
+    """More than four levels: an entity reads its parent's WORLD matrix, which only the sweep of the whole set has on this rank -- a proper slice is
+    SAILOR_HIP_ERR_UNSUPPORTED (sweep it replicated), the whole range is the ordinary sweep."""
+    levels, per = 6, 101
+    ents = synth.make_entities(per * levels, editor_world=False)
+    ents.level_offsets = np.arange(levels + 1, dtype=np.uint32) * per
+    ents.parent[:] = 0xFFFFFFFF
+    for lvl in range(1, levels):
+        ents.parent[lvl * per:(lvl + 1) * per] = np.arange((lvl - 1) * per, lvl * per, dtype=np.uint32)
+        ents.transforms[lvl * per:(lvl + 1) * per, 8:11] = 1.0
+    planes = camera_planes(synth.make_camera(1920, 1080))
+    sw = EcsSweep(ctx, ents, rank=1, world=2)
+    with pytest.raises(_lib.SailorHipError) as e:
+        sw.run(planes)
+    assert e.value.status == -7
+    world, aabb, vis = EcsSweep(ctx, ents).run(planes)
+    ctx.synchronize()
+    ow, oa, ov = oracle.ecs_sweep(ents.transforms, ents.parent, ents.local_aabb, planes)
+    np.testing.assert_array_equal(world.cpu().numpy().view(np.uint32), ow.view(np.uint32))
+    np.testing.assert_array_equal(vis.cpu().numpy().view(np.uint64), ov)
