@@ -78,7 +78,13 @@ def parse(argv=None):
     ap.add_argument("--single-mode", action="store_true", help="profiling runs (rocprofv3 kernel stats, PMC passes): only the headline's light mode and launch form -- no second "
                                                                "pass in the other light mode, no one-frame-in-flight reading with the pack beside the shade -- so that every kernel of the "
                                                                "trace was launched the same way")
-    ap.add_argument("--pack-inline", action="store_true", help="k1_pack inside every cull on the cull's stream (rounds 1-3) instead of deferred to a third stream beside the shade")
+    ap.add_argument("--pack", default="never", choices=["never", "deferred", "inline"],
+                    help="when k1_pack -- the compaction of the per-tile lists into the reference's lightsGrid / culledLights -- runs.  never (default, round 5): no consumer "
+                         "of the canonical buffers exists on this path (the shade reads the per-tile lists; the reference's only reader of the two buffers IS the shade, "
+                         "Standard.shader:422-436), so no frame pays for them -- they stay available bit for bit on demand (sailor_hip_light_cull_pack: the N > 1 "
+                         "exchange and the list read-back below call it) and the kernel is reported as `pack_ms`.  deferred: every frame, behind the event the shade "
+                         "waits for (round 4's default).  inline: inside every cull (rounds 1-3)")
+    ap.add_argument("--pack-inline", action="store_true", help="= --pack inline")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--equal-bands", action="store_true", help="N > 1: equal tile-row bands instead of cost-balanced ones")
     ap.add_argument("--split-frame", action="store_true", help="N > 1: ONE frame split into tile-row bands is `value` (the default; kept for old command lines)")
@@ -797,14 +803,15 @@ def simulate_split(args, dev, ctx, side, frame, d_lights, fp_full, d_depth_full,
             f.shade(cam.frame, ds, d_lights, N, csm)
         dev.synchronize()
         if unroll:
-            defer = not args.pack_inline   # as the main path records it: k1_pack behind the event the shade waits for, on the cull's own stream
+            mode = "inline" if args.pack_inline else args.pack   # as the main path records it
+            defer = mode != "inline"
             graph = capture_frame_pipeline(side, side2, unroll, [lambda f=f: f.shade(cam.frame, ds, d_lights, N, csm) for f in fs],
                                            [lambda f=f: f.cull(cam.frame, d_lights, N, dd, ctx=ctx2, defer_pack=defer) for f in fs], dev,
-                                           [lambda f=f: f.pack(ctx2) for f in fs] if defer else None, side2)
+                                           [lambda f=f: f.pack(ctx2) for f in fs] if mode == "deferred" else None, side2)
             fs[0].cull(cam.frame, d_lights, N, dd)
             per = unroll
         else:
-            graph = dev.capture(side, lambda: (fs[0].cull(cam.frame, d_lights, N, dd), fs[0].shade(cam.frame, ds, d_lights, N, csm)))
+            graph = dev.capture(side, lambda: (fs[0].cull(cam.frame, d_lights, N, dd, defer_pack=(args.pack == "never" and not args.pack_inline)), fs[0].shade(cam.frame, ds, d_lights, N, csm)))
             per = 1
         t_spin = time.perf_counter()   # the same clock spin-up as the main path (a band's K steps are over in 2-4 ms)
         while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
@@ -938,9 +945,10 @@ def split_config_reading(name: str, args, dev, dist, ctx, side, side2, ctx2, ran
             f.shade(cam.frame, ds, d_lights, N, csm)
         dev.synchronize()
         per = pipeline_unroll(steps, args.list_sets)[0] or args.list_sets
-        defer = hasattr(fs[0], "pack")
+        mode = "inline" if (args.pack_inline or not hasattr(fs[0], "pack")) else args.pack
+        defer = mode != "inline"
         graph = capture_frame_pipeline(side, side2, per, [lambda f=f: f.shade(cam.frame, ds, d_lights, N, csm) for f in fs],
-                                       [lambda f=f: cull_of(f, ctx2, defer) for f in fs], dev, [lambda f=f: f.pack(ctx2) for f in fs] if defer else None, side2)
+                                       [lambda f=f: cull_of(f, ctx2, defer) for f in fs], dev, [lambda f=f: f.pack(ctx2) for f in fs] if mode == "deferred" else None, side2)
         cull_of(fs[0], None, False)
         dev.synchronize()
         run = graph.replay
@@ -949,7 +957,7 @@ def split_config_reading(name: str, args, dev, dist, ctx, side, side2, ctx2, ran
         wd, wsf = dev.upload(frame.depth), dev.upload(frame.surface_rows(0, H))
 
         def wstep():
-            wf.cull(cam.frame, d_lights, N, wd, prepare_lights=dyn)
+            wf.cull(cam.frame, d_lights, N, wd, prepare_lights=dyn, defer_pack=(mode == "never"))
             wf.shade(cam.frame, wsf, d_lights, N, csm)
         wstep(); dev.synchronize()
         try:
@@ -1115,13 +1123,22 @@ def main(argv=None, device_factory=None):
         fl = slib.CULL_PREPARE_SELECTED if (dyn and not args.separate_prepare and (world > 1 or args.simulate_band)) else slib.CULL_DEFAULT
         f.cull(cam.frame, d_lights, N, d_depth, fl, ctx=c, defer_pack=defer_pack, prepare_lights=dyn and not args.separate_prepare)
 
+    # when k1_pack runs (--pack): never (the default) / deferred behind the event the shade waits for / inline in every cull
+    pack_mode = "inline" if (args.pack_inline or not hasattr(fp, "pack")) else args.pack
+    defer_pack = pack_mode != "inline"
+
     def cull():
-        cull_of(fp, None, dynamic)
+        """one frame's cull as a frame of the timed region runs it, on the launch stream (with --pack deferred the frame's pack follows it at once)"""
+        cull_of(fp, None, dynamic, defer_pack)
+        if pack_mode == "deferred":
+            fp.pack()
 
     def shade():
         fp.shade(cam.frame, d_surface, d_lights, N, csm)
 
     def exchange():
+        if pack_mode == "never":   # the exchange IS a consumer of the canonical buffers: it asks for them
+            fp.pack()
         return dev.exchange(ctx, W, H, bounds, fp)
 
     def barrier():
@@ -1145,7 +1162,6 @@ def main(argv=None, device_factory=None):
     # (round 4) the shade reads the cull's per-tile lists, so the compaction into the reference's lightsGrid / culledLights (k1_pack) is off the
     # frame's path: recorded on a third stream behind its cull -- every frame still produces both canonical buffers.  --pack-inline: rounds 1-3's form.
     # (a band's shade takes its long tiles from the order hint: written by k1_tile_cull, not by k1_pack, so the band's pack is deferred like the frame's)
-    defer_pack = not args.pack_inline and hasattr(fp, "pack")
     side2 = dev.stream(priority=int(os.environ.get('SAILOR_CULL_PRIORITY', '0')))
     ctx2 = dev.context(side2)
     side3, ctx3 = side2, ctx2   # (the pack's stream: the cull's own -- see capture_frame_pipeline)
@@ -1161,7 +1177,9 @@ def main(argv=None, device_factory=None):
         """-> (run, finish, per_run, launch): run() = `per_run` steps (the main pipeline graph, or one step of the other forms), finish() = the
         pipeline's shorter graph for the rest of K, launch = how the steps are launched (for the JSON line)"""
         def step():
-            cull_of(fp, None, dyn)
+            cull_of(fp, None, dyn, defer_pack)
+            if pack_mode == "deferred":
+                fp.pack()
             shade()
             if world > 1 and args.exchange_every_step:
                 exchange()
@@ -1169,14 +1187,14 @@ def main(argv=None, device_factory=None):
             try:
                 graphs = [capture_frame_pipeline(side, side2, length, [lambda f=f: f.shade(cam.frame, d_surface, d_lights, N, csm) for f in fps],
                                                  [lambda f=f: cull_of(f, ctx2, dyn, defer_pack) for f in fps], dev,
-                                                 [lambda f=f: f.pack(ctx3) for f in fps] if defer_pack else None, side3) if length else None for length in (unroll, tail)]
-                cull_of(fps[0], None, dyn)                     # prologue: frame 0's lists
+                                                 [lambda f=f: f.pack(ctx3) for f in fps] if pack_mode == "deferred" else None, side3) if length else None for length in (unroll, tail)]
+                cull_of(fps[0], None, dyn, defer_pack)         # prologue: frame 0's lists
                 dev.synchronize()
                 main_graph = graphs[0] if graphs[0] is not None else graphs[1]
                 rest = graphs[1] if graphs[0] is not None else None
                 per = unroll if unroll else tail
                 how = (f"hipGraph replay ({per} steps of the frame pipeline per graph" + (f", {tail} in the last" if unroll and tail else "") +
-                       f"), 2 frames in flight over {args.list_sets} list sets" + (", k1_pack behind the event the shade waits for" if defer_pack else ""))
+                       f"), 2 frames in flight over {args.list_sets} list sets" + (", k1_pack behind the event the shade waits for" if pack_mode == "deferred" else (", no k1_pack (no consumer of the canonical buffers)" if pack_mode == "never" else "")))
                 return main_graph.replay, (rest.replay if rest is not None else (lambda: None)), per, how
             except Exception as e:
                 print(f"[bench] two-frames-in-flight capture failed ({type(e).__name__}: {e}); falling back to one frame in flight", file=sys.stderr)
@@ -1262,7 +1280,7 @@ def main(argv=None, device_factory=None):
     # ... and the same frame with k1_pack beside the shade (the form the frame pipeline above launches; still ONE frame in flight: the next
     # frame's cull waits for this frame's shade AND pack)
     serial_deferred = None
-    if defer_pack and not args.single_mode:
+    if pack_mode == "deferred" and not args.single_mode:
         def frame_deferred():
             cull_of(fp, None, dynamic, True)
             side2.wait_stream(side)
@@ -1281,6 +1299,10 @@ def main(argv=None, device_factory=None):
     # decision: read from its launch log (sailor_hip_context_launch_log), not re-derived here -- one timing slot per kernel it names
     chain_names = ctx.launches_of(cull)
     chain_ms = chain_kernels_ms(ctx, cull, shade, max(args.steps, BATCH_LAUNCHES), len(chain_names))
+    # k1_pack on its own (--pack never: no frame runs it; this is what a consumer of lightsGrid / culledLights pays when it asks for them)
+    pack_ms = None
+    if pack_mode == "never":
+        pack_ms = kernel_in_frame_ms(ctx, lambda: (cull(), shade()), fp.pack, max(args.steps, BATCH_LAUNCHES))["median"]
     # THIS box's yardstick, in this process: a float4 streaming copy of 512 MB timed like the kernels above (boxes of the pool differ by +-5 %: a
     # slower line on a slower box shows as the same frac_of_box_copy)
     box = None
@@ -1290,6 +1312,8 @@ def main(argv=None, device_factory=None):
         box = {"copy_gbs": 2 * nbytes / (copy_ms * 1e-3) / 1e9, "copy_ms": copy_ms, "copy_bytes": nbytes,
                "how": "sailor_hip_copy_probe: float4 per lane, 512 MB read + 512 MB written, median of 20 launches by their own dispatch-packet timestamps, this process, this rank",
                "guide_copy_gbs": HBM_COPY_GBS}
+    if pack_mode == "never":
+        fp.pack()   # (the read-back below wants the canonical buffers)
     g, idx = fp.lists_to_host()
     sum_nt = int(idx[0])
     distinct = int(len(np.unique(idx[1:]))) if sum_nt else 0
@@ -1360,7 +1384,7 @@ def main(argv=None, device_factory=None):
             ws = dev.upload(frame.surface_rows(0, H))
 
             def wstep():
-                wf.cull(cam.frame, d_lights, N, wd)
+                wf.cull(cam.frame, d_lights, N, wd, defer_pack=(pack_mode == "never"))
                 wf.shade(cam.frame, ws, d_lights, N, csm)
             wstep(); dev.synchronize()
             wrun = wstep
@@ -1424,7 +1448,7 @@ def main(argv=None, device_factory=None):
                 bs = dev.upload(frame.surface_rows(bb.fbRowBegin, bb.fbRowBegin + bb.fbRowCount))
 
                 def bstep():
-                    bf.cull(cam.frame, d_lights, N, bd)
+                    bf.cull(cam.frame, d_lights, N, bd, defer_pack=(pack_mode == "never"))
                     bf.shade(cam.frame, bs, d_lights, N, csm)
                 bstep(); dev.synchronize()
                 brun = bstep
@@ -1450,6 +1474,8 @@ def main(argv=None, device_factory=None):
                 t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 split_elapsed = float(t.item())
+                if pack_mode == "never":
+                    bf.pack()
                 gg, gi = dev.exchange(ctx, W, H, sbounds, bf)
                 dev.synchronize()
                 tot = int(gi[0].item())
@@ -1505,6 +1531,9 @@ def main(argv=None, device_factory=None):
             "serial_step_pack_beside_shade_ms": serial_deferred,
             "mlights_culled_per_s": N / (cull_batch_ms * 1e-3) / 1e6,
             "cull_ms": cull_batch_ms, "shade_ms": shade_launch_ms, "shade_back_to_back_ms": shade_batch_ms,
+            "pack": {"mode": pack_mode, "pack_ms": pack_ms,
+                     "what": "k1_pack = the per-tile lists compacted into the reference's lightsGrid / culledLights (bit for bit); never: only when a consumer asks "
+                             "(sailor_hip_light_cull_pack), its kernel time reported here; deferred / inline: inside every step"},
             "roofline": roofline,
             "box": box,
         }

@@ -208,7 +208,7 @@ SAILOR_HIP_API int sailor_hip_context_timed_launch_ms(SailorHipContext* ctx, int
 /* Measurement aid (no reference counterpart): *outCount = the number of kernels the path's entry points have launched through this context since it was
  * created (exactly the launches that take a timing slot above); outNames[0 .. n) = the names of the last n = min(maxNames, 16, *outCount) of them,
  * oldest first (static strings; further entries NULL).  A caller that wants the kernels of ONE call reads the count in front of and behind it -- which
- * kernels a cull chain consists of (k0_band_select or not, the wide list builder or not, brute force) is the library's decision, not the caller's guess.
+ * kernels a cull chain consists of (the band selection's two kernels or not, the wide list builder or not, brute force) is the library's decision, not the caller's guess.
  * sailor_hip_context_time_launches is refused (SAILOR_HIP_ERR_UNSUPPORTED) while the context's stream is being captured into a hipGraph. */
 SAILOR_HIP_API int sailor_hip_context_launch_log(SailorHipContext* ctx, uint64_t* outCount, const char** outNames, int32_t maxNames);
 /* Measurement aid (no reference counterpart): one float4-per-lane streaming copy of `bytes` (a multiple of 16; both pointers 16-byte aligned) from dSrc to
@@ -276,7 +276,7 @@ SAILOR_HIP_API int sailor_hip_band_is_valid(int32_t width, int32_t height, const
                                         * ECS/LightingECS.cpp:152-191).  The cull's per-light pass reads the 112-byte records in dLights and WRITES the prepared
                                         * views of all pc->lightsNum lights into dPreparedLights on the way -- sailor_hip_prepare_lights(0, lightsNum) folded
                                         * into the cull: one pass over the records instead of two, one launch less; the same bits in the views, the same lists */
-#define SAILOR_CULL_BAND_SELECT 32u    /* a band of a split frame: select the lights that can reach the band's rows first (k0_band_select: an ordered compaction on the band's
+#define SAILOR_CULL_BAND_SELECT 32u    /* a band of a split frame: select the lights that can reach the band's rows first (k0_band_count + k0_band_scatter: an ordered compaction on the band's
                                         * top / bottom planes) and run the chain on those -- the default from 131 072 lights on; this flag forces it for smaller sets
                                         * (same lists bit for bit; validation) */
 #define SAILOR_CULL_NO_BAND_SELECT 64u /* ... never (same lists; A / B) */
@@ -369,7 +369,7 @@ SAILOR_HIP_API int sailor_hip_light_cull_diagnostics(SailorHipContext* ctx, int3
 /* The band-local light selection (SAILOR_CULL_BAND_SELECT and its default above) as the last cull with this geometry and pc->lightsNum == lightsNum left
  * it in dWorkspace: *outSelectedCount -> one device uint32, the number M of lights that can reach the band; *outLightMap -> M device uint32, the
  * selected lights' indices in ascending order.  Meaningful only if that cull ran the selection (sailor_hip_context_launch_log names a call's kernels:
- * "k0_band_select" is the first of the chain then).  Tests and diagnostics; either out pointer may be NULL. */
+ * "k0_band_count", "k0_band_scatter" are the first two of the chain then).  Tests and diagnostics; either out pointer may be NULL. */
 SAILOR_HIP_API int sailor_hip_light_cull_band_selection(int32_t width, int32_t height, int32_t lightsNum, const SailorBand* band, const void* dWorkspace,
                                                         const uint32_t** outSelectedCount, const uint32_t** outLightMap);
 

@@ -65,20 +65,22 @@
 // IS its longest block; below 384 too many groups qualify.  So: by the size of the band.
 #define HEAVY_MIN_FRAME 512
 #define HEAVY_MIN_BAND 384
+#define HEAVY_MIN_WIDE 1024     // ... and on the wide path (a million lights: the ORDINARY group has ~420 candidates there)
 #define HEAVY_MAX 96            // ... and that list's room (16 head blocks of k1_tile_cull per entry: the empty ones are dispatched in front of everything else -- 4 096 of them cost ~3 us)
 #define CHUNK 512            // group candidates staged in LDS per step of k1_tile_cull (16 KB of LDS per block: 8 blocks per CU)
 
 #define PACK_TILES 64        // tiles per k1_pack block
-#define SEL_LIGHTS 1024      // lights per block of k0_band_select
+#define SEL_LIGHTS 1024      // lights per block of k0_band_count / k0_band_scatter
 #define CL_STEPS (CAPG / 4 / 64) // cluster tiles: 64-candidate steps per wave for the longest listable group (8)
 
 // the shading hint's class counts travel as class A tiles << 16 | class B tiles in one uint32
 #define CLS_MAX_TILES 65535
+#define BAND_FORM_MAX_TILES 65535 // (see layout_has_hint)
 
 struct CullLayout {
     int Tx, Ty, bandRows, bandTiles, numBands, words, groupsX, groupsY, numGroups, packBlocks;
     size_t offLightView, offLightType, offTileInfo, offMasks, offDirWords, offGroupCount, offGroupList, offTileNum, offTileNum8, offTileLists, offTileOrder, offDirFlag, offHeavy,
-           offLightMap, offSelState, total;
+           offLightMap, offSelState, offSelKeep, total;
     int selBlocks;
 };
 
@@ -117,10 +119,12 @@ static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
     L.offLightType = o; o = align_up(o + n * 4, 256);
     L.offMasks = o; o = align_up(o + (size_t)(L.numBands > 0 ? L.numBands : 1) * L.words * 8, 256);
     L.offDirWords = o; o = align_up(o + (size_t)L.words * 8, 256);
-    // k0_band_select (split frames with large light sets): compact index -> light index, and [0] the number of selected lights, [2 + b] block b's count + 1
+    // the band's own light set (k0_band_count / k0_band_scatter: split frames with large light sets): compact index -> light index; [0] the number of
+    // selected lights, [2 + b] block b's count; block b's sixteen ballot words
     L.selBlocks = (int)((n + SEL_LIGHTS - 1) / SEL_LIGHTS);
     L.offLightMap = o; o = align_up(o + n * 4, 256);
     L.offSelState = o; o = align_up(o + (size_t)(2 + L.selBlocks) * 4, 256);
+    L.offSelKeep = o; o = align_up(o + (size_t)L.selBlocks * 16 * 8, 256);
     L.total = o;
     return L;
 }
@@ -179,7 +183,7 @@ struct PrepareArgs {
     float4* lightView; uint32_t* lightType; float4* tileInfo;
     unsigned long long* masks; unsigned long long* dirWords;
     uint32_t* heavy;   // [0]: k1_group_lists' count of light-cluster groups, zeroed here (one launch ahead of it)
-    const uint32_t* selCount; // k0_band_select ran (null: it did not): the light role works on lightView / lightType [0, *selCount), already in view space
+    const uint32_t* selCount; // the band selection ran (null: it did not): the light role works on lightView / lightType [0, *selCount), already in view space
     uint32_t* orderCounts; // the shading hint's two class counts (tileOrder[T], [T + 1]; null: whole frame, no hint), zeroed here for k1_tile_cull
     uint32_t* dirFlag; // "some light may be directional": set here, read by k1_group_lists_wide, cleared by k1_tile_cull (unknown before the first cull: then merely conservative)
     int N, words, lightBlocks, lightRoleBlocks, frustumBlocks, bandsPerBlock, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands,
@@ -219,7 +223,7 @@ __device__ __forceinline__ void k0_lights(const int lb, unsigned char* __restric
     const int wordBlock = lb % a.lightBlocks, split = lb / a.lightBlocks;
     const int b0 = split * a.bandsPerBlock;
     const int nb = min(a.bandsPerBlock, a.numBands - b0); // <= 0: no pre-filter (brute-force walk)
-    if (a.selCount && wordBlock * 4 >= min((int)(((*a.selCount + 63u) / 64u + 1u) & ~1u), a.words)) return; // (behind k0_band_select: a block past the selected lights -- the grid is sized for all of them)
+    if (a.selCount && wordBlock * 4 >= min((int)(((*a.selCount + 63u) / 64u + 1u) & ~1u), a.words)) return; // (behind the band selection: a block past the selected lights -- the grid is sized for all of them)
     if ((int)threadIdx.x < nb) {
         const int b = b0 + (int)threadIdx.x;
         Frustum4 f;
@@ -238,7 +242,7 @@ __device__ __forceinline__ void k0_lights(const int lb, unsigned char* __restric
     const int word = wordBlock * 4 + (int)(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int j = word * 64 + lane;
-    // (behind k0_band_select the light set is the selected one: *selCount lights, compact, ascending light index, view-space records in lightView; the mask
+    // (behind the band selection the light set is the selected one: *selCount lights, compact, ascending light index, view-space records in lightView; the mask
     // words behind the last one are not written -- nobody reads them -- but for the odd word that completes a 16-byte pair, which gets zeros)
     const int nEff = a.selCount ? (int)*a.selCount : a.N;
     const int wordsEff = a.selCount ? min(((nEff + 63) / 64 + 1) & ~1, a.words) : a.words; // (never past the row: with an odd stride and every light selected there is no pair to complete)
@@ -465,18 +469,20 @@ __device__ __forceinline__ void k1_tile_frusta(const int block, const PrepareArg
 
 // ------------------------------------------------------------------------------------------------------------
 // K0': the light set of a BAND (split frames, large light sets).  Every rank of a split frame used to transform all N lights and build masks over all N
-// for a band that an eighth of them can reach: at C5 (1 M lights) a band's k01_prepare and k1_group_lists_wide were 74 of its 117 us.  This kernel
-// keeps the lights whose sphere is not entirely beyond the band's top or bottom plane -- the SAME test, on the same planes, that keeps a light out of
-// the band's first / last row mask, so no light a tile of the band could list is dropped -- and writes them, transformed, in ascending light index:
+// for a band that an eighth of them can reach: at C5 (1 M lights) a band's k01_prepare and k1_group_lists_wide were 74 of its 117 us.  These two kernels
+// keep the lights whose sphere is not entirely beyond the band's top or bottom plane -- the SAME test, on the same planes, that keeps a light out of
+// the band's first / last row mask, so no light a tile of the band could list is dropped -- and write them, transformed, in ascending light index:
 // lightView / lightType [0, M) + lightMap (compact -> light index).  The rest of the chain then runs on M lights (k0_lights reads the compact records,
 // the group lists hold compact indices, k1_tile_cull translates them when a list leaves).  With SAILOR_CULL_PREPARE_LIGHTS the prepared views of ALL
 // lights are derived here (they outlive the band).
-// Ordered compaction in one pass: a block takes 1 024 lights (four per thread, all in registers), publishes its count, adds up the counts of the
-// blocks in front of it (every thread polls a few of them) and writes its lights behind them.  WHICH 1 024 lights a block takes is decided by a
-// TICKET it draws when it starts (one relaxed atomic on state[1], as CUB's decoupled look-back numbers its tiles): a block only ever waits for
-// lower tickets, whose holders are running or done and publish before they wait for anything -- forward progress without any assumption about
-// the order in which the hardware starts blocks or about how many of them are resident (the next frame's cull runs beside the previous frame's
-// band shade, which holds most wave slots; round 4's form numbered the ranges by blockIdx and relied on both).
+// Ordered compaction WITHOUT any wait between blocks (round 5): k0_band_count -- a block takes 1 024 lights, four per thread, tests them and leaves its
+// sixteen ballot words and its count; a kernel boundary; k0_band_scatter -- the block of the same 1 024 lights adds up the counts of all blocks in
+// front of it itself (<= 4 KB of L2 reads, as k1_pack adds up the list lengths) and writes its kept lights behind them.  Round 4 did both in one
+// launch, a block polling the status words of the blocks in front of it: forward progress then rested on blocks being started in index order and on
+// the whole grid being resident beside whatever else runs (it runs beside the previous frame's band shade) -- neither is promised (VERDICT / ADVICE
+// r04).  A ticket per block (CUB's remedy: one relaxed atomic on one word, 1 024 of them) removes the assumption and was measured first: 12.4 -> 23.4 us
+// on an eighth of C5 -- the word serialises at ~88 tickets per us and every block's loads wait for its ticket's round trip.  Two launches without any
+// inter-block traffic cost a boundary (~1.7 us) and a second read of the kept lights' 20 bytes.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t lanemask_lt();
 struct SelectArgs {
@@ -485,29 +491,50 @@ struct SelectArgs {
     const float4* soaPosRadius; const uint32_t* soaType;
     float4* prepPosRadius; uint32_t* prepType; float4* prepStaged;
     float4* lightView; uint32_t* lightType; uint32_t* lightMap;
-    uint32_t* state; // [0] = M, [1] = the ticket counter, [2 + b] = the count + 1 of the block with ticket b (all zeroed in front of the launch)
+    uint32_t* state;           // [0] = M (written by the last block of k0_band_scatter), [2 + b] = block b's count
+    unsigned long long* keep;  // [16 b + 4 k + wave]: block b's ballot of round k (lights 1024 b + 256 k + 64 wave ..)
     int N, vpW, vpH, Tx, tileRow0, bandRows;
     int stageSelectedOnly; // SAILOR_CULL_PREPARE_SELECTED: the staged shade records only of the lights that are kept (the 20-byte cull views of all)
     float planeMargin;
 };
-__global__ __launch_bounds__(256) void k0_band_select(const SelectArgs a)
+
+// a light's 20-byte cull view from whichever form the call has (k0_lights' three sources), and its view-space record by k0_lights' operations: the
+// records the tile tests read are the same bits
+__device__ __forceinline__ void select_load(const SelectArgs& a, const int j, float& x, float& y, float& z, float& radius, uint32_t& type)
+{
+    if (a.soaPosRadius) {
+        const float4 pr = a.soaPosRadius[j];
+        x = pr.x; y = pr.y; z = pr.z; radius = pr.w;
+        type = a.soaType[j];
+    } else {
+        const SailorLightShaderData* L = a.lights + j;
+        x = L->worldPosition[0]; y = L->worldPosition[1]; z = L->worldPosition[2]; radius = L->bounds[0];
+        type = L->type;
+    }
+}
+__device__ __forceinline__ float4 select_view(const SelectArgs& a, const float x, const float y, const float z, const float radius)
+{
+    float4 p = glsl_mul(a.view, x, y, z, 1.0f);
+    const float w = p.w;
+    p.x = p.x / w; p.y = p.y / w; p.z = p.z / w;
+    p.z = p.z * -1.0f; // "Reverse Z"
+    return make_float4(p.x, p.y, p.z, radius);
+}
+
+__global__ __launch_bounds__(256) void k0_band_count(const SelectArgs a)
 {
     __shared__ float4 sPl[2];
-    __shared__ uint32_t sCnt[4][4], sPart[4], sTicket;
+    __shared__ uint32_t sCnt[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // (relaxed: the ticket orders nothing but the blocks' numbering)
-    if (threadIdx.x == 0) sTicket = __hip_atomic_fetch_add(a.state + 1u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x == 64) { // (another wave than the ticket's: the planes are built while the atomic is on its way)
+    const uint32_t b = blockIdx.x;
+    if (threadIdx.x == 0) {
         Frustum4 f;
         frustum_from_rect(a.invProj, 0.0f, (float)(a.tileRow0 * TILE), (float)(a.Tx * TILE), (float)((a.tileRow0 + a.bandRows) * TILE), a.vpW, a.vpH, f);
         sPl[0] = make_float4(f.n[2][0], f.n[2][1], f.n[2][2], 0.0f); // top: the first row band's
         sPl[1] = make_float4(f.n[3][0], f.n[3][1], f.n[3][2], 0.0f); // bottom: the last row band's
     }
-    __syncthreads(); // the ticket (and the planes) are in LDS
-    const uint32_t b = sTicket; // this block's place in the light order: lights [1024 b, 1024 b + 1024)
     float4 lv[4];
     uint32_t type[4];
-    unsigned long long keep[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int j = (int)b * SEL_LIGHTS + k * 256 + (int)threadIdx.x;
@@ -528,22 +555,11 @@ __global__ __launch_bounds__(256) void k0_band_select(const SelectArgs a)
                     float4* o = a.prepStaged + (size_t)j * LREC;
                     o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3; o[4] = o4;
                 }
-            } else if (a.soaPosRadius) {
-                const float4 pr = a.soaPosRadius[j];
-                x = pr.x; y = pr.y; z = pr.z; radius = pr.w;
-                type[k] = a.soaType[j];
-            } else {
-                const SailorLightShaderData* L = a.lights + j;
-                x = L->worldPosition[0]; y = L->worldPosition[1]; z = L->worldPosition[2]; radius = L->bounds[0];
-                type[k] = L->type;
-            }
-            float4 p = glsl_mul(a.view, x, y, z, 1.0f); // (k0_lights' operations: the records the tile tests read are the same bits)
-            const float w = p.w;
-            p.x = p.x / w; p.y = p.y / w; p.z = p.z / w;
-            p.z = p.z * -1.0f; // "Reverse Z"
-            lv[k] = make_float4(p.x, p.y, p.z, radius);
+            } else select_load(a, j, x, y, z, radius, type[k]);
+            lv[k] = select_view(a, x, y, z, radius);
         }
     }
+    __syncthreads(); // the planes are in LDS
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int j = (int)b * SEL_LIGHTS + k * 256 + (int)threadIdx.x;
@@ -555,26 +571,43 @@ __global__ __launch_bounds__(256) void k0_band_select(const SelectArgs a)
         const bool keepAlways = valid && (type[k] == 0u || !inFront);
         const float4 nA = sPl[0], nB = sPl[1];
         const bool out = dot3f(nA.x, nA.y, nA.z, lv[k].x, lv[k].y, lv[k].z) < thr || dot3f(nB.x, nB.y, nB.z, lv[k].x, lv[k].y, lv[k].z) < thr;
-        keep[k] = __ballot(keepAlways || (valid && !out));
-        if (lane == 0) sCnt[k][wave] = (uint32_t)__popcll(keep[k]);
+        const unsigned long long keep = __ballot(keepAlways || (valid && !out));
+        if (lane == 0) { a.keep[(size_t)b * 16u + (uint32_t)(4 * k + wave)] = keep; sCnt[k][wave] = (uint32_t)__popcll(keep); }
     }
     __syncthreads();
-    // this block's lights in front of mine: rounds before k (all waves), waves before mine in round k, lanes before mine
+    if (threadIdx.x == 0) {
+        uint32_t total = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) total += sCnt[k][w];
+        a.state[2u + b] = total;
+    }
+}
+
+__global__ __launch_bounds__(256) void k0_band_scatter(const SelectArgs a)
+{
+    __shared__ uint32_t sPart[4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t b = blockIdx.x;
+    // the block's sixteen ballot words (block-uniform addresses: scalar loads), requested before the counts are added up
+    unsigned long long keep[4];
     uint32_t before[4], total = 0u;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         before[k] = total;
 #pragma unroll
-        for (int w = 0; w < 4; w++) { const uint32_t c = sCnt[k][w]; if (w < wave) before[k] += c; total += c; }
+        for (int w = 0; w < 4; w++) {
+            const unsigned long long m = a.keep[(size_t)b * 16u + (uint32_t)(4 * k + w)];
+            const uint32_t c = (uint32_t)__popcll(m);
+            if (w == wave) keep[k] = m;
+            if (w < wave) before[k] += c;
+            total += c;
+        }
     }
-    // (relaxed: the word IS the message -- nothing else passes between blocks; a release here is a write-back of the XCD's whole L2, per block: 100 us)
-    if (threadIdx.x == 0) __hip_atomic_store(a.state + 2u + b, total + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the lights of all blocks in front of this one: their counts, added up by the block itself (at most 1 024 words at a million lights)
     uint32_t acc = 0u;
-    for (uint32_t i = threadIdx.x; i < b; i += 256u) {
-        uint32_t v;
-        while ((v = __hip_atomic_load(a.state + 2u + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(2);
-        acc += v - 1u;
-    }
+    for (uint32_t i = threadIdx.x; i < b; i += 256u) acc += a.state[2u + i];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) acc += (uint32_t)__shfl_xor((int)acc, d, 64);
     if (lane == 0) sPart[wave] = acc;
@@ -586,10 +619,17 @@ __global__ __launch_bounds__(256) void k0_band_select(const SelectArgs a)
         if ((keep[k] >> lane) & 1ull) {
             const uint32_t c = base + before[k] + (uint32_t)__popcll(keep[k] & lanemask_lt());
             const int j = (int)b * SEL_LIGHTS + k * 256 + (int)threadIdx.x;
-            a.lightView[c] = lv[k];
-            a.lightType[c] = type[k];
+            float x, y, z, radius;
+            uint32_t type;
+            if (a.prepStaged) { // (k0_band_count has just written the 20-byte views of all lights)
+                const float4 pr = a.prepPosRadius[j];
+                x = pr.x; y = pr.y; z = pr.z; radius = pr.w;
+                type = a.prepType[j];
+            } else select_load(a, j, x, y, z, radius, type);
+            a.lightView[c] = select_view(a, x, y, z, radius);
+            a.lightType[c] = type;
             a.lightMap[c] = (uint32_t)j;
-            if (a.prepStaged && a.stageSelectedOnly) { // (the kept tenth: its records are read a second time -- L2 -- for 80 of 100 bytes per light less to write)
+            if (a.prepStaged && a.stageSelectedOnly) { // (the kept tenth: its records are read a second time for 80 of 100 bytes per light less to write)
                 const float4* L = reinterpret_cast<const float4*>(a.lights + j);
                 float4 o0, o1, o2, o3, o4;
                 stage_light_record(L[0], L[1], L[2], L[3], L[4], L[5], L[6], o0, o1, o2, o3, o4);
@@ -641,7 +681,7 @@ __global__ __launch_bounds__(256) void k1_group_lists(const unsigned long long* 
     const int g = (int)blockIdx.y * groupsX + (int)blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long* __restrict__ c = masks + (size_t)blockIdx.x * stride;
     const unsigned long long* __restrict__ r = masks + (size_t)(groupsX + (int)blockIdx.y) * stride;
-    const int words = selCount ? min((int)(((*selCount + 63u) / 64u + 1u) & ~1u), stride) : stride; // (behind k0_band_select: the selected lights' words; the masks keep the capacity's stride)
+    const int words = selCount ? min((int)(((*selCount + 63u) / 64u + 1u) & ~1u), stride) : stride; // (behind the band selection: the selected lights' words; the masks keep the capacity's stride)
     uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
     uint32_t base = 0; // entries written by earlier chunks (block-uniform)
     // GL_WPT consecutive words per thread and round: one block-wide scan (and its two barriers) per 256 * GL_WPT words -- at 1 M lights a group walks
@@ -753,9 +793,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 template <bool EXACT> // EXACT: words is a multiple of 128 * GLW_ROWS, no load needs a bounds check
 __global__ __launch_bounds__(256) void k1_group_lists_wide(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ dirWords,
                                                             int stride, int groupsX, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList,
-                                                            const uint32_t* __restrict__ dirFlag, const uint32_t* __restrict__ selCount)
+                                                            const uint32_t* __restrict__ dirFlag, const uint32_t* __restrict__ selCount,
+                                                            uint32_t* __restrict__ heavy, uint32_t heavyMin)
 {
-    const int words = (!EXACT && selCount) ? min((int)(((*selCount + 63u) / 64u + 1u) & ~1u), stride) : stride; // (behind k0_band_select: the selected lights' words)
+    const int words = (!EXACT && selCount) ? min((int)(((*selCount + 63u) / 64u + 1u) & ~1u), stride) : stride; // (behind the band selection: the selected lights' words)
     __shared__ __attribute__((aligned(16))) unsigned long long sRow[2][GLW_ROWS][128];
     const bool anyDir = *dirFlag != 0u; // no directional light in the set (the usual case): the draining waves need not wait for their words of dirWords
     __shared__ unsigned long long sQBits[4][GLW_Q];
@@ -833,7 +874,18 @@ __global__ __launch_bounds__(256) void k1_group_lists_wide(const unsigned long l
     }
     if (mine) {
         if (qTail != qHead) { WAVE_SYNC(); drain(qTail - qHead); }
-        if (lane == 0) groupCount[g] = base > CAPG ? GROUP_OVERFLOW : base;
+        if (lane == 0) {
+            uint32_t word = base > CAPG ? GROUP_OVERFLOW : base;
+            // (round 5) a light cluster is listed here too, as k1_group_lists does: k1_tile_cull gives its tiles a block each, at the front of the grid
+            if (heavyMin != 0u && base > heavyMin) {
+                const uint32_t slot = atomicAdd(&heavy[0], 1u);
+                if (slot < (uint32_t)HEAVY_MAX) {
+                    heavy[1u + slot] = (uint32_t)g;
+                    word = word != GROUP_OVERFLOW ? (word | GROUP_LISTED) : GROUP_OVERFLOW_LISTED;
+                }
+            }
+            groupCount[g] = word;
+        }
     }
 }
 
@@ -921,12 +973,12 @@ struct CullArgs {
     uint32_t* tileNum; uint8_t* tileNum8; uint32_t* tileLists; uint32_t* dirFlag;
     int N, words, Tx, groupsX, bandRows;
     uint32_t* tileOrder; int bandTiles; // the shading hint (null: none): see publish_tile
-    const uint32_t* lightMap; const uint32_t* selCount; // behind k0_band_select (kernels with SEL): compact index -> light index; the number of selected lights
+    const uint32_t* lightMap; const uint32_t* selCount; // behind the band selection (kernels with SEL): compact index -> light index; the number of selected lights
     const uint32_t* heavy; int headRows; // k1_group_lists' cluster list and the grid rows in front of the tile rows that take its tiles (0: none)
 };
 
 // The <= 196 candidates of a tile (sIdx, ascending light index) -> its list at `out` (Appendix A steps 4 + 5).  One wave.
-// (SEL: the candidates are compact indices of k0_band_select's light set -- ascending like the light indices they stand for, so every rank and tie-break
+// (SEL: the candidates are compact indices of the band selection's light set -- ascending like the light indices they stand for, so every rank and tie-break
 // below is the one of the full set -- and `map` turns an entry into its light index on the way out)
 template <bool SEL>
 __device__ __forceinline__ void emit_list(const TileCtx& t, const uint32_t n, uint32_t* sIdx, float* sImp, const float4* __restrict__ lightView,
@@ -1061,7 +1113,7 @@ __device__ __forceinline__ void walk_tile_masks(const TileCtx& t, const CullArgs
     const int lane = threadIdx.x & 63;
     const unsigned long long* __restrict__ col = a.masks + (size_t)gx * a.words;
     const unsigned long long* __restrict__ row = a.masks + (size_t)(a.groupsX + tyLocal / GROUP) * a.words;
-    const int words = a.selCount ? (int)((*a.selCount + 63u) / 64u) : a.words; // (behind k0_band_select: the selected lights' words)
+    const int words = a.selCount ? (int)((*a.selCount + 63u) / 64u) : a.words; // (behind the band selection: the selected lights' words)
     uint32_t qHead = 0, qTail = 0; // ring buffer indices (wave-uniform)
     unsigned long long next = (lane < words) ? (col[lane] & row[lane]) : 0ull;
     for (int w0 = 0; w0 < words && count < CAND; w0 += 64) {
@@ -1552,8 +1604,16 @@ static bool band_valid(int W, int H, const SailorBand* b)
     return b->fbRowBegin == lo && b->fbRowCount == hi - lo;
 }
 
-// the tile-order hint is produced for split frames whose class counts fit 16 bits each
-static bool layout_has_hint(const CullLayout& L) { return L.bandRows < L.Ty && L.bandTiles > 0 && L.bandTiles <= CLS_MAX_TILES; }
+// The tile-order hint is produced for the bands of a split frame that the band form of the shade (split blocks for the long tiles, shade.hip) serves:
+// bands of up to BAND_FORM_MAX_TILES tiles.  A larger band -- half or a quarter of the 4K frame, an eighth of the 8K frame: four and more rounds of
+// resident tile blocks -- is bound by the shade's throughput like the whole frame and takes the whole frame's form: one block per tile on the
+// XCD-aware grid, no split-role blocks in front of them, no hint (and none of its atomics in k1_tile_cull).  SAILOR_BAND_FORM_TILES=<n> overrides.
+static int band_form_max_tiles()
+{
+    static const int v = [] { const char* e = getenv("SAILOR_BAND_FORM_TILES"); const int n = e ? atoi(e) : BAND_FORM_MAX_TILES; return n > CLS_MAX_TILES ? CLS_MAX_TILES : n; }();
+    return v;
+}
+static bool layout_has_hint(const CullLayout& L) { return L.bandRows < L.Ty && L.bandTiles > 0 && L.bandTiles <= band_form_max_tiles(); }
 
 static int launch_pack(SailorHipContext* ctx, const CullLayout& L, char* ws, SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity)
 {
@@ -1647,10 +1707,10 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
         } else { pa.soaPosRadius = (const float4*)pr; pa.soaType = (const uint32_t*)ty; }
     }
     pa.lightView = (float4*)(ws + L.offLightView); pa.lightType = (uint32_t*)(ws + L.offLightType); pa.tileInfo = (float4*)(ws + L.offTileInfo);
-    // A band of a split frame with a large light set: the lights that can reach the band are selected first (k0_band_select) and the chain runs on them.
+    // A band of a split frame with a large light set: the lights that can reach the band are selected first (k0_band_count + k0_band_scatter) and the chain runs on them.
     // From 131 072 lights on (below, the light role and the group lists of a band sit at their launch floors whatever the count); SAILOR_CULL_BAND_SELECT
-    // forces it for any set the pre-filter runs on, SAILOR_CULL_NO_BAND_SELECT switches it off.  (Any number of blocks: they take their light ranges by
-    // ticket, so the grid need not be resident as a whole.)
+    // forces it for any set the pre-filter runs on, SAILOR_CULL_NO_BAND_SELECT switches it off.  (Two launches, no block waits for another: any
+    // number of blocks.)
     uint32_t* selState = (uint32_t*)(ws + L.offSelState);
     const bool select = !brute && L.bandRows < L.Ty && !(flags & SAILOR_CULL_NO_BAND_SELECT) && ((flags & SAILOR_CULL_BAND_SELECT) || N >= 131072);
     pa.selCount = nullptr;
@@ -1661,14 +1721,16 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
         sa.lights = dLights; sa.soaPosRadius = pa.soaPosRadius; sa.soaType = pa.soaType;
         sa.prepPosRadius = pa.prepPosRadius; sa.prepType = pa.prepType; sa.prepStaged = pa.prepStaged;
         sa.lightView = pa.lightView; sa.lightType = pa.lightType; sa.lightMap = (uint32_t*)(ws + L.offLightMap); sa.state = selState;
+        sa.keep = (unsigned long long*)(ws + L.offSelKeep);
         sa.N = N; sa.vpW = frame->viewportSize[0]; sa.vpH = frame->viewportSize[1]; sa.Tx = L.Tx; sa.tileRow0 = band->tileRowBegin; sa.bandRows = L.bandRows;
         sa.planeMargin = 1e-3f;
         sa.stageSelectedOnly = (flags & SAILOR_CULL_PREPARE_SELECTED) ? 1 : 0;
-        SAILOR_TRY_HIP(ctx, hipMemsetAsync(selState, 0, align_up((size_t)(2 + L.selBlocks) * 4, 256), s)); // (the section's whole 256-byte-aligned extent: one fill kernel, not two)
-        sailor_launch(ctx, k0_band_select, dim3((unsigned)L.selBlocks), dim3(256), sa);
-        SAILOR_CHECK_LAUNCH(ctx, "k0_band_select");
+        sailor_launch(ctx, k0_band_count, dim3((unsigned)L.selBlocks), dim3(256), sa);
+        SAILOR_CHECK_LAUNCH(ctx, "k0_band_count");
+        sailor_launch(ctx, k0_band_scatter, dim3((unsigned)L.selBlocks), dim3(256), sa);
+        SAILOR_CHECK_LAUNCH(ctx, "k0_band_scatter");
         pa.selCount = selState;
-        pa.prepPosRadius = nullptr; pa.prepType = nullptr; pa.prepStaged = nullptr; // (derived by k0_band_select; the light role reads the compact records)
+        pa.prepPosRadius = nullptr; pa.prepType = nullptr; pa.prepStaged = nullptr; // (derived by k0_band_count; the light role reads the compact records)
     }
     pa.masks = (unsigned long long*)(ws + L.offMasks); pa.dirWords = (unsigned long long*)(ws + L.offDirWords);
     pa.N = N; pa.words = L.words;
@@ -1714,13 +1776,20 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
         const bool wide = L.words >= 4096 && (L.words & 1) == 0;
         if (wide)
         {
+            // Light clusters on the wide path (round 5): under a million lights the ordinary group has ~420 candidates and its tiles select on their own
+            // waves; the groups far above that -- several hundred candidates PER TILE, every tile selecting -- were the tail of a band's launch (four
+            // tiles of ~10 us of tests + 11-15 us of selection each on one wave, started 6-14 us in).  Listed from HEAVY_MIN_WIDE candidates on, they get a
+            // block per tile at the front of the grid like the 4K frame's clusters.  SAILOR_HEAVY_MIN_WIDE=<n> overrides (0: none; A / B).
+            static const int heavyEnv = [] { const char* e = getenv("SAILOR_HEAVY_MIN_WIDE"); return e ? atoi(e) : -1; }();
+            const uint32_t heavyMinWide = heavyEnv >= 0 ? (uint32_t)heavyEnv : (uint32_t)HEAVY_MIN_WIDE;
             const dim3 wideGrid((unsigned)(((L.groupsX + 3) / 4) * L.groupsY));
             if (L.words % (128 * GLW_ROWS) == 0 && !select)
                 sailor_launch(ctx, k1_group_lists_wide<true>, wideGrid, dim3(256), pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
-                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag), (const uint32_t*)nullptr);
+                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag), (const uint32_t*)nullptr, (uint32_t*)(ws + L.offHeavy), heavyMinWide);
             else
                 sailor_launch(ctx, k1_group_lists_wide<false>, wideGrid, dim3(256), pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
-                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag), pa.selCount);
+                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag), pa.selCount, (uint32_t*)(ws + L.offHeavy), heavyMinWide);
+            if (heavyMinWide != 0u) ca.headRows = (16 * HEAVY_MAX + L.groupsX - 1) / L.groupsX;
         }
         else {
             sailor_launch(ctx, k1_group_lists, dim3(L.groupsX, L.groupsY), dim3(256), pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
@@ -1729,14 +1798,15 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
         }
         SAILOR_CHECK_LAUNCH(ctx, wide ? "k1_group_lists_wide" : "k1_group_lists");
         // (the block-wide selection everywhere but on the long lists of the wide path: see k1_tile_cull)
+        const bool coop = !wide;
         const dim3 cgrid(L.groupsX, ca.headRows + L.bandRows);
         if (select) { // (a band by definition: the hint's kernels)
-            if (ca.headRows == 0) sailor_launch(ctx, k1_tile_cull<false, true, true>, cgrid, dim3(256), ca);
+            if (!coop) sailor_launch(ctx, k1_tile_cull<false, true, true>, cgrid, dim3(256), ca);
             else sailor_launch(ctx, k1_tile_cull<true, true, true>, cgrid, dim3(256), ca);
         } else if (ca.tileOrder) { // a band of a split frame: the kernels that append the shading hint
-            if (ca.headRows == 0) sailor_launch(ctx, k1_tile_cull<false, true, false>, cgrid, dim3(256), ca);
+            if (!coop) sailor_launch(ctx, k1_tile_cull<false, true, false>, cgrid, dim3(256), ca);
             else sailor_launch(ctx, k1_tile_cull<true, true, false>, cgrid, dim3(256), ca);
-        } else if (ca.headRows == 0) sailor_launch(ctx, k1_tile_cull<false, false, false>, cgrid, dim3(256), ca);
+        } else if (!coop) sailor_launch(ctx, k1_tile_cull<false, false, false>, cgrid, dim3(256), ca);
         else sailor_launch(ctx, k1_tile_cull<true, false, false>, cgrid, dim3(256), ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
     }
@@ -1825,7 +1895,7 @@ const uint32_t* sailor_hip_light_cull_tile_order(int32_t width, int32_t height, 
     return (const uint32_t*)((const char*)dWorkspace + L.offTileOrder);
 }
 
-// The band's own light set as the last cull of this geometry AND light count left it (k0_band_select): the number of selected lights and
+// The band's own light set as the last cull of this geometry AND light count left it (k0_band_count + k0_band_scatter): the number of selected lights and
 // lightMap (compact index -> light index, ascending).  Both lie in the part of the workspace whose place depends on the light count, hence
 // lightsNum = that cull's pc->lightsNum.  Meaningful only if that cull ran the selection (sailor_hip_context_launch_log names its kernels).
 int sailor_hip_light_cull_band_selection(int32_t width, int32_t height, int32_t lightsNum, const SailorBand* band, const void* dWorkspace,

@@ -365,25 +365,27 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
     // (tile lists: the kernels' `grid` argument is tileNum, their `culled` the per-tile slots -- see k2_shade_body)
     const SailorLightsGrid* G = dTileNum ? reinterpret_cast<const SailorLightsGrid*>(dTileNum) : dLightsGrid;
     const char* kname = "k2_shade"; // (the launched variant's name, for sailor_hip_context_launch_log)
-#define LAUNCH_SHADE(K) do { if (dPreparedLights && dTileNum) { kname = #K "_pt"; sailor_launch(ctx, K##_pt, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
-                             else if (dPreparedLights) { kname = #K "_p"; sailor_launch(ctx, K##_p, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
-                             else if (dTileNum) { kname = #K "_t"; sailor_launch(ctx, K##_t, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
-                             else { kname = #K; sailor_launch(ctx, K, grid, dim3(256), A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } } while (0)
-    const bool splitBand = dTileOrder && band->tileRowEnd - band->tileRowBegin < Ty && !ibl; // a band of a split frame: long tiles are split across four blocks
+    // (bandLds: the wave-slot reserve of a band's shade, below; 0 on the whole frame)
+#define LAUNCH_SHADE(K) do { if (dPreparedLights && dTileNum) { kname = #K "_pt"; sailor_launch_lds(ctx, K##_pt, grid, dim3(256), bandLds, A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
+                             else if (dPreparedLights) { kname = #K "_p"; sailor_launch_lds(ctx, K##_p, grid, dim3(256), bandLds, A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
+                             else if (dTileNum) { kname = #K "_t"; sailor_launch_lds(ctx, K##_t, grid, dim3(256), bandLds, A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
+                             else { kname = #K; sailor_launch_lds(ctx, K, grid, dim3(256), bandLds, A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } } while (0)
+    const bool partial = band->tileRowEnd - band->tileRowBegin < Ty;
+    const bool splitBand = dTileOrder && partial && !ibl; // a band of a split frame with the cull's hint: long tiles are split across four blocks
+    // A band's shade does not take the whole chip: SHADE_BAND_RESERVE bytes of dynamic LDS that nobody touches cap it at six blocks (24 of 32 wave slots)
+    // per CU.  A split frame is a pipeline of short launches -- the NEXT frame's cull chain runs beside this kernel on another stream -- and with every wave
+    // slot taken by shade blocks each of the chain's four launches queues behind them: measured on 1/8 bands of the 4K frame, alone the kernel takes
+    // ~3 us longer (30 -> 33 us), the pipelined step ~8 us less (53 -> 45 us).  SAILOR_BAND_SHADE_LDS=<bytes> overrides (0: eight blocks).
+    // For bands of up to three rounds of resident blocks (an eighth of the 4K frame is two) -- a larger band is bound by the shade's throughput like the
+    // whole frame, and the cap costs it what it costs there (half the 4K frame: 108 -> 120 us per step) -- and for any band under a large light set, whose
+    // cull chain is as long as its shade (an eighth of the 8K frame under a million lights: 16 320 tiles, 80 us of cull beside 78 us of shade; 152 -> 134 us).
+    static const int bandLdsEnv = [] { const char* e = getenv("SAILOR_BAND_SHADE_LDS"); return e ? atoi(e) : -1; }();
+    const unsigned bandLds = (!partial || ibl) ? 0u : (bandLdsEnv >= 0 ? (unsigned)bandLdsEnv : ((bandTiles <= 3 * 8 * ctx->numCUs || lightsNum >= 131072) ? (unsigned)SHADE_BAND_RESERVE : 0u));
     if (hasCsm && ibl) LAUNCH_SHADE(k2_shade_csm_ibl);
     else if (hasCsm && !splitBand) LAUNCH_SHADE(k2_shade_csm);
     else if (ibl) LAUNCH_SHADE(k2_shade_ibl);
     else if (splitBand) {
         const dim3 bgrid((unsigned)SPLIT_BLOCKS + (unsigned)bandTiles);
-        // A band's shade does not take the whole chip: SHADE_BAND_RESERVE bytes of dynamic LDS that nobody touches cap it at six blocks (24 of 32 wave slots)
-        // per CU.  A split frame is a pipeline of short launches -- the NEXT frame's cull chain runs beside this kernel on another stream -- and with every wave
-        // slot taken by shade blocks each of the chain's four launches queues behind them: measured on 1/8 bands of the 4K frame, alone the kernel takes
-        // ~3 us longer (30 -> 33 us), the pipelined step ~8 us less (53 -> 45 us).  SAILOR_BAND_SHADE_LDS=<bytes> overrides (0: eight blocks).
-        // For bands of up to three rounds of resident blocks (an eighth of the 4K frame is two) -- a larger band is bound by the shade's throughput like the
-        // whole frame, and the cap costs it what it costs there (half the 4K frame: 108 -> 120 us per step) -- and for any band under a large light set, whose
-        // cull chain is as long as its shade (an eighth of the 8K frame under a million lights: 16 320 tiles, 80 us of cull beside 78 us of shade; 152 -> 134 us).
-        static const int bandLdsEnv = [] { const char* e = getenv("SAILOR_BAND_SHADE_LDS"); return e ? atoi(e) : -1; }();
-        const unsigned bandLds = bandLdsEnv >= 0 ? (unsigned)bandLdsEnv : ((bandTiles <= 3 * 8 * ctx->numCUs || lightsNum >= 131072) ? (unsigned)SHADE_BAND_RESERVE : 0u);
 #define LAUNCH_BAND(K) do { if (dPreparedLights && dTileNum) { kname = #K "_pt"; sailor_launch_lds(ctx, K##_pt, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
                             else if (dPreparedLights) { kname = #K "_p"; sailor_launch_lds(ctx, K##_p, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
                             else if (dTileNum) { kname = #K "_t"; sailor_launch_lds(ctx, K##_t, bgrid, dim3(256), bandLds, A, C, bandTiles, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \

@@ -242,7 +242,7 @@ class ForwardPlus:
         return dict(zip(keys, [int(v) for v in out]))
 
     def band_selection(self, lights_num: int):
-        """(M, lightMap uint32[M]) of the last cull with lights_num lights, if that cull ran k0_band_select (the caller knows: HipContext.launches_of)"""
+        """(M, lightMap uint32[M]) of the last cull with lights_num lights, if that cull ran the band selection (the caller knows: HipContext.launches_of)"""
         a, b = C.c_void_p(), C.c_void_p()
         _lib.check(self.ctx._lib.sailor_hip_light_cull_band_selection(self.W, self.H, lights_num, C.byref(self.band), _ptr(self.workspace), C.byref(a), C.byref(b)),
                    "sailor_hip_light_cull_band_selection")
@@ -358,7 +358,7 @@ class EcsSweep:
         self.ctx = ctx
         dev = ctx.device
         self.n = len(entities.parent)
-        self.rank, self.world = rank, world
+        self.rank, self.world_size = rank, world
         self.begin, self.end, self.words_per_rank = ecs_range_for_rank(self.n, rank, world)
         self.trs = torch.from_numpy(entities.transforms).to(dev)
         self.parent = torch.from_numpy(entities.parent.view(np.int32)).to(dev)
@@ -371,7 +371,7 @@ class EcsSweep:
     def run(self, planes: np.ndarray):
         planes = np.ascontiguousarray(planes, np.float32).reshape(24)
         lib = self.ctx._lib
-        if self.world == 1:
+        if self.world_size == 1:
             _lib.check(lib.sailor_hip_ecs_sweep(self.ctx.handle, self.n, _ptr(self.trs), _ptr(self.parent),
                                                 self.level_offsets.ctypes.data_as(C.POINTER(C.c_uint32)), len(self.level_offsets) - 1,
                                                 _ptr(self.local_aabb), planes.ctypes.data_as(C.POINTER(C.c_float)),
@@ -388,14 +388,14 @@ class EcsSweep:
     def exchange_visibility(self, comm=None, group=None):
         """every rank's visibility words -> the whole bitmask on every rank: sailor_hip_exchange_visibility on an ncclComm_t (dist.RcclComm), or the same
         all-gather over torch.distributed when there is none (gloo tests, ranks sharing a GPU)"""
-        if self.world == 1:
+        if self.world_size == 1:
             return self.visibility
         if comm is not None:
-            _lib.check(self.ctx._lib.sailor_hip_exchange_visibility(self.ctx.handle, comm.handle, self.rank, self.world, self.n, _ptr(self.visibility)),
+            _lib.check(self.ctx._lib.sailor_hip_exchange_visibility(self.ctx.handle, comm.handle, self.rank, self.world_size, self.n, _ptr(self.visibility)),
                        "sailor_hip_exchange_visibility", self.ctx.handle)
         else:
             from . import dist as sdist
-            sdist.allgather_visibility(self.visibility, self.rank, self.world, self.words_per_rank, group)
+            sdist.allgather_visibility(self.visibility, self.rank, self.world_size, self.words_per_rank, group)
         return self.visibility
 
 

@@ -24,10 +24,7 @@ def chain_ms(lights_np, band, dynamic):
     for _ in range(3):
         fp.cull(cam.frame, dl, n, dd, prepare_lights=dynamic)
     torch.cuda.synchronize()
-    import os
-    flags = int(os.environ.get("SAILOR_CULL_FLAGS", "0"))
-    sel = band.tileRowEnd - band.tileRowBegin < host.num_tiles(W, H)[1] and not (flags & 64) and (n >= 131072 or (flags & 32))   # light_cull.hip: k0_band_select in front
-    names = (["k0_band_select"] if sel else []) + ["k01_prepare", "lists", "tile_cull", "pack"]
+    names = ctx.launches_of(lambda: fp.cull(cam.frame, dl, n, dd, prepare_lights=dynamic))   # (the library's own record of the chain's kernels)
     acc = np.zeros(len(names))
     reps = 10
     for _ in range(reps):

@@ -13,7 +13,7 @@ from sailor_amd import _lib, host, synth
 from sailor_amd.forward_plus import EcsSweep, ForwardPlus, PreparedLights, upload_lights, upload_shadow_maps
 
 CULL_PATHS = [_lib.CULL_DEFAULT, _lib.CULL_BRUTE_FORCE, _lib.CULL_INTERVAL_MASKS]
-BAND_SELECT_EVERY = 2   # every second case's bands go through k0_band_select as well (round 4: the band-local light selection, forced on these small sets)
+BAND_SELECT_EVERY = 2   # every second case's bands go through the band selection as well (round 4: the band-local light selection, forced on these small sets)
 
 
 def k1k2_case(ctx, rng, c, run=True, verbose=False):

@@ -96,10 +96,11 @@ def test_the_shadowed_band_kernels_fit_six_waves_without_scratch(resources, name
     assert waves_per_simd(k["vgpr_count"]) >= 6 and k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0
 
 
-def test_the_band_selection_kernel_has_no_scratch(resources):
-    # (round 5: its blocks take their light ranges by ticket -- no residency requirement any more; what is left to guard is the four lights per thread
+@pytest.mark.parametrize("name", ["k0_band_count", "k0_band_scatter"])
+def test_the_band_selection_kernels_have_no_scratch(resources, name):
+    # (round 5: two launches, no block waits for another -- no residency requirement any more; what is left to guard is the four lights per thread
     # staying in registers)
-    k = find(resources["light_cull"], "k0_band_select")
+    k = find(resources["light_cull"], name)
     assert waves_per_simd(k["vgpr_count"]) >= 4 and k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0 and k["group_segment_fixed_size"] <= 4096
 
 

@@ -152,7 +152,7 @@ def test_tile_row_bands_stitch_to_the_whole_frame(ctx, world_size):
 @pytest.mark.parametrize("n_lights, radius_scale, extra", [(5000, 3.0, 0), (4000, 40.0, 0), (4000, 0.5, _lib.CULL_INTERVAL_MASKS), (1100, 6.0, 0)])
 @pytest.mark.parametrize("world_size", [2, 5])
 def test_band_local_light_selection_gives_the_same_lists(ctx, world_size, n_lights, radius_scale, extra):
-    """k0_band_select (the default on bands from 131 072 lights on, forced here by SAILOR_CULL_BAND_SELECT): the lights that can reach a band are
+    """The band selection (k0_band_count + k0_band_scatter; the default on bands from 131 072 lights on, forced here by SAILOR_CULL_BAND_SELECT): the lights that can reach a band are
     compacted -- in ascending index, view space -- in front of the chain, which then runs on compact indices and translates them when a list leaves.
     Same lists bit for bit as without it and as the oracle's: few lights kept (small radii), ALL kept with an odd number of mask words (4 000 lights,
     huge radii: no pad word to zero), directional / NaN / behind-the-eye lights (always kept), several selection blocks, both mask forms."""
@@ -170,7 +170,7 @@ def test_band_local_light_selection_gives_the_same_lists(ctx, world_size, n_ligh
 
 
 def test_band_selection_with_the_preparation_folded_in(ctx):
-    """... and with SAILOR_CULL_PREPARE_LIGHTS: k0_band_select derives the prepared views of ALL lights (they outlive the band), bit for bit
+    """... and with SAILOR_CULL_PREPARE_LIGHTS: the band selection derives the prepared views of ALL lights (they outlive the band), bit for bit
     sailor_hip_prepare_lights' own."""
     from sailor_amd.forward_plus import PreparedLights
     cam, depth, lights = frame(640, 400, 3000, radius_scale=2.0, spot_fraction=0.3, cluster_lights=400, seed=5)

@@ -1,12 +1,12 @@
 """The product paths a rank of a split frame runs at the sizes they exist for ("configs untested"), through the C-ABI, against the oracle:
 
-  * C5 (8K, 1 048 576 lights), a band of an 8-way split with DEFAULT flags: k0_band_select (on by itself from 131 072 lights) -> k01_prepare on the
+  * C5 (8K, 1 048 576 lights), a band of an 8-way split with DEFAULT flags: the band selection (k0_band_count + k0_band_scatter, on by itself from 131 072 lights) -> k01_prepare on the
     selected lights -> k1_group_lists_wide<false>(..., selCount) -> k1_tile_cull<*, HINT, SEL>; static lights, SAILOR_CULL_PREPARE_LIGHTS, and
     SAILOR_CULL_PREPARE_SELECTED followed by the band's shade;
   * the same chain on a small frame under 300 000 lights (seconds: the wide list builder with a selected count and a word count that is no multiple
     of 512);
   * C4 (4K + four shadow cascades), all eight bands through k2_shade_band_csm* with prepared lights, stitched, the ENTIRE frame at 1e-4;
-  * k0_band_select's ticket order beside a resident shade (the two-frames-in-flight pipeline it runs in).
+  * the band selection beside a resident shade (the two-frames-in-flight pipeline it runs in).
 
 Which kernels a call launched is the library's own record (sailor_hip_context_launch_log), not a guess from the flags."""
 import os
@@ -24,7 +24,7 @@ from conftest import oracle_tile_rows
 
 pytestmark = pytest.mark.gpu
 
-SELECT_CHAIN_WIDE = ["k0_band_select", "k01_prepare", "k1_group_lists_wide", "k1_tile_cull", "k1_pack"]
+SELECT_CHAIN_WIDE = ["k0_band_count", "k0_band_scatter", "k01_prepare", "k1_group_lists_wide", "k1_tile_cull", "k1_pack"]
 
 
 def band_rows(band):
@@ -139,7 +139,7 @@ def test_bands_under_300_000_lights_take_the_wide_list_builder_behind_the_select
         og, oi, _ = oracle.light_cull(cam.frame, W, H, ls, depth, tile_rows=tile_rows)
         assert_lists_equal(fp.lists_to_host(), og, oi)
         names = ctx.launches_of(lambda: fp.cull(cam.frame, dl, N, d, _lib.CULL_NO_BAND_SELECT))
-        assert names == SELECT_CHAIN_WIDE[1:], names
+        assert names == SELECT_CHAIN_WIDE[2:], names
         assert_lists_equal(fp.lists_to_host(), og, oi)
     assert oi[0] > 0
 
@@ -178,10 +178,10 @@ def test_all_eight_bands_of_c4_through_the_shadowed_band_kernels_against_the_ora
 
 
 def test_band_selection_keeps_its_order_beside_a_resident_shade(ctx):
-    """k0_band_select's blocks take their light ranges by ticket and wait only for lower tickets (running or done by construction): the compaction's
-    order cannot depend on how the hardware starts blocks or on how many fit beside another kernel.  The situation it runs in -- the next frame's
-    chain on a second stream beside the previous frame's band shade, which holds most wave slots -- 200 times on a C5 band: the same selection, the
-    same lightMap, the same lists every time."""
+    """The band selection is two launches (count; scatter) and no block of either waits for another: the compaction's order cannot depend on how the
+    hardware starts blocks or on how many fit beside another kernel (round 4's one-launch form polled the blocks in front of it).  The situation it
+    runs in -- the next frame's chain on a second stream beside the previous frame's band shade, which holds most wave slots -- 200 times on a C5
+    band: the same selection, the same lightMap, the same lists every time."""
     f = synth.make_frame("C5", with_surface=False)
     W, H, N = f.cam.width, f.cam.height, len(f.lights)
     band = host.band_for_rank(W, H, 3, 8)
@@ -243,7 +243,7 @@ def test_launch_log_names_the_kernels_of_a_call(ctx):
     fb = ForwardPlus(ctx, W, H, N, band=band)
     db = torch.from_numpy(np.ascontiguousarray(f.depth[band_rows(band)])).to(ctx.device)
     assert ctx.launches_of(lambda: fb.cull(f.cam.frame, l, N, db)) == ["k01_prepare", "k1_group_lists", "k1_tile_cull", "k1_pack"]
-    assert ctx.launches_of(lambda: fb.cull(f.cam.frame, l, N, db, _lib.CULL_BAND_SELECT)) == ["k0_band_select", "k01_prepare", "k1_group_lists", "k1_tile_cull", "k1_pack"]
+    assert ctx.launches_of(lambda: fb.cull(f.cam.frame, l, N, db, _lib.CULL_BAND_SELECT)) == ["k0_band_count", "k0_band_scatter", "k01_prepare", "k1_group_lists", "k1_tile_cull", "k1_pack"]
     count0, _ = ctx.launch_log(0)
     assert ctx.launches_of(lambda: None) == [] and ctx.launch_log(0)[0] == count0
     # arming timing slots while the stream is captured is refused (a launch with events on its packet cannot be a graph node)
