@@ -1334,10 +1334,16 @@ def main(argv=None, device_factory=None):
     # the same kernel as the difference (one-frame-in-flight step) - (cull chain alone), medians of event-bracketed graph batches: round 3's figure,
     # kept beside the direct one (it reads a few per cent lower: the next cull's head overlaps the shade's drain)
     shade_diff_ms = serial["median"] - cull_batch_ms
-    shade_kernel = ("k2_shade_band" if fp.tile_order and fp.use_tile_order else "k2_shade") + ("_csm" if csm is not None else "")   # (a band is shaded by the band kernel, shadow maps or not, since round 4)
-    tl = bool(getattr(fp, "shade_from_tile_lists", False))
-    if prep is not None or tl:   # _p: the entry points that read sailor_hip_prepare_lights' staged records; ..t: the lists from the cull's per-tile slots
-        shade_kernel += "_" + ("p" if prep is not None else "") + ("t" if tl else "")
+    # the shade's kernel as the library's launch log names it (k2_shade[_band][_csm][_p|_t|_pt]: the band form or not, shadow maps, prepared lights, the
+    # lists from the cull's per-tile slots -- the library's decisions); the stand-in of the CPU control-flow test has no log of its own
+    logged = [n for n in ctx.launches_of(shade) if n.startswith("k2_shade")]
+    if logged:
+        shade_kernel = logged[-1]
+    else:
+        shade_kernel = ("k2_shade_band" if fp.tile_order and fp.use_tile_order else "k2_shade") + ("_csm" if csm is not None else "")
+        tl = bool(getattr(fp, "shade_from_tile_lists", False))
+        if prep is not None or tl:
+            shade_kernel += "_" + ("p" if prep is not None else "") + ("t" if tl else "")
     trace_ms = trace_kernel_ms(shade_kernel, args.config, world)
     roofline = {"bound": "hbm", "kernel": shade_kernel, "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
                 "traffic": measured_traffic(shade_kernel, args.config, world), "bytes_per_launch": b_shade, "avg_launch_ms": shade_launch_ms,

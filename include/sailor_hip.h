@@ -215,6 +215,9 @@ SAILOR_HIP_API int sailor_hip_context_launch_log(SailorHipContext* ctx, uint64_t
  * dDst on the context's stream -- the yardstick of THIS box and process for the roofline figures (2 x bytes of HBM traffic per call; time it with
  * sailor_hip_context_time_launches like any kernel of the path).  Boxes of the pool differ by +-5 %; the guide's 6.29 TB/s is one of them. */
 SAILOR_HIP_API int sailor_hip_copy_probe(SailorHipContext* ctx, const void* dSrc, void* dDst, size_t bytes);
+/* Measurement aid (no reference counterpart): an empty one-wave kernel on the context's stream.  A kernel's dispatch-packet timestamps begin when its packet is
+ * taken up and so include the wait for its predecessor's last blocks; a marker in front of a kernel takes that wait onto its own reading. */
+SAILOR_HIP_API int sailor_hip_marker(SailorHipContext* ctx);
 
 /* ---- buffers: IGraphicsDriver::CreateBuffer (RHI/GraphicsDriver.h:89-90), AddSsboToShaderBindings (:154),
  *      IGraphicsDriverCommands::UpdateShaderBinding / UpdateBuffer (:303-304) -------------------------------- */
@@ -298,7 +301,7 @@ SAILOR_HIP_API int sailor_hip_light_cull(SailorHipContext* ctx,
  * tileNum[bandTile].  A consumer that only needs "the lights of tile t" (the shade: Standard.shader:422-436) reads them there and does not depend on the
  * compaction into the reference's layout, which then leaves the frame's critical path: SAILOR_CULL_DEFER_PACK + sailor_hip_light_cull_pack on a
  * second stream.  The pointers depend on (width, height, band) alone (lightsCapacity: any light count the workspace can hold) and stay valid until the
- * next cull on the same workspace.  The tile-order hint below is written by the cull itself (k1_tile_cull, since round 4): it is there with a deferred
+ * next cull on the same workspace.  The band shade's hint below (the lengths as bytes) is written by k1_tile_cull as well: it is there with a deferred
  * pack too, so a band's shade does not wait for the compaction either. */
 SAILOR_HIP_API int sailor_hip_light_cull_tile_lists(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band, const void* dWorkspace,
                                                     const uint32_t** outTileNum, const uint32_t** outTileLists);
@@ -308,19 +311,16 @@ SAILOR_HIP_API int sailor_hip_light_cull_tile_lists(int32_t width, int32_t heigh
 SAILOR_HIP_API int sailor_hip_light_cull_pack(SailorHipContext* ctx, int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band,
                                               const void* dWorkspace, SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity);
 
-/* Shading hint.  sailor_hip_light_cull also leaves, in its workspace, the band's LONG tiles as an array of T + 2 words (T = tiles of the
- * band), each tile as tileX | tileRowInBand << 16: the nA tiles with >= 96 lights at [0, nA), the nB tiles with 40..95 lights at
- * [T-1], [T-2], ... (each class in the order the cull's blocks got there: it decides which block shades a tile, not what comes out), then
- * [T] = nA and [T+1] = nB.  A band of a split frame is a round or two of blocks, so its longest
- * tile is its duration, and a tile in the middle of a light cluster keeps one block busy ~100x longer than an average one.  Handing this
- * pointer to sailor_hip_shade_ex (band smaller than the frame, no ambient term; with or without shadow maps) makes the launch give those tiles to
- * "split" blocks -- one per (tile, 8x8 quadrant), four waves sharing the quadrant's list -- at the front of the grid.  Lists and every
- * tile with < 40 lights keep their bits; a split tile's radiance differs from the one-block form by the order of four partial sums per
- * pixel (within the shade tolerance).  With the ambient term the hint is ignored (with shadow maps it was, through round 3).  Produced for split frames only (on the
- * whole frame the split measured no gain): NULL for the whole-frame band, for bands of more than 65 535 tiles and on bad arguments.
- * Valid until the next sailor_hip_light_cull on the same workspace.  `lightsCapacity` only has to be a light count the workspace can hold: the
- * hint's place in the workspace depends on (width, height, band) alone, so a cull with ANY lightsNum <= the capacity leaves it where this
- * function points (the sections that scale with the light count sit behind it). */
+/* Shading hint of a band.  A band of a split frame is a round or two of blocks, so its longest tile is its duration, and a tile in the middle of a light
+ * cluster keeps one block busy ~100x longer than an average one.  This returns the band's per-tile list lengths as BYTES (T bytes, tile order, <= 128 each;
+ * every sailor_hip_light_cull writes them beside tileNum -- nothing extra, no atomics: round 4's form, a list of the long tiles appended through two
+ * device-scope counters, cost the cull up to 12.7 us on half a 4K frame).  Handing the pointer to sailor_hip_shade_ex (band smaller than the frame, no
+ * ambient term; with or without shadow maps) switches the BAND FORM of the launch on: the tiles with >= 40 lights go to "split" blocks -- one per (tile, 8x8
+ * quadrant), four waves sharing the quadrant's list -- at the front of the grid, which find them in these bytes.  Lists and every tile with < 40 lights keep
+ * their bits; a split tile's radiance differs from the one-block form by the order of four partial sums per pixel (within the shade tolerance).  With the
+ * ambient term the pointer is ignored.  NULL for the whole-frame band (on the whole frame the split measured no gain) and on bad arguments.  Valid until
+ * the next sailor_hip_light_cull on the same workspace.  `lightsCapacity` only has to be a light count the workspace can hold: the bytes' place in the
+ * workspace depends on (width, height, band) alone.  (The return type is kept from round 2's word array; the data are bytes.) */
 SAILOR_HIP_API const uint32_t* sailor_hip_light_cull_tile_order(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band,
                                                                 const void* dWorkspace);
 

@@ -137,6 +137,7 @@ SIGNATURES = {
     "sailor_hip_context_time_launches": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "sailor_hip_context_timed_launch_ms": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float)]),
     "sailor_hip_copy_probe": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "sailor_hip_marker": (C.c_int, [_P]),
     "sailor_hip_context_launch_log": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_char_p), C.c_int32]),
     "sailor_hip_light_cull_band_selection": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(Band), _P, C.POINTER(_P), C.POINTER(_P)]),
     "sailor_hip_evsm_blur": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -203,6 +203,20 @@ int sailor_hip_copy_probe(SailorHipContext* ctx, const void* dSrc, void* dDst, s
     return SAILOR_HIP_OK;
 }
 
+// sailor_hip_marker: an empty one-wave kernel.  A launch's dispatch-packet timestamps (sailor_hip_context_time_launches, rocprofv3's kernel trace) start when
+// the packet is taken up, i.e. they include the wait for the PREDECESSOR's last blocks to drain -- 5-8 us behind k1_tile_cull, whose launch ends in a tail of
+// single blocks.  With a marker between the two the drain lands on the marker's reading and the kernel behind it reads its own execution.
+__global__ void k_marker() {}
+
+int sailor_hip_marker(SailorHipContext* ctx)
+{
+    if (!ctx) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    sailor_launch(ctx, k_marker, dim3(1), dim3(64));
+    SAILOR_CHECK_LAUNCH(ctx, "k_marker");
+    return SAILOR_HIP_OK;
+}
+
 int sailor_hip_buffer_copy(SailorHipContext* ctx, void* dstDevice, size_t dstOffset, const void* srcDevice, size_t srcOffset, size_t bytes)
 {
     if (!ctx || (bytes && (!dstDevice || !srcDevice))) return SAILOR_HIP_ERR_INVALID_ARGUMENT;

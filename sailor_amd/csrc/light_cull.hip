@@ -73,13 +73,11 @@
 #define SEL_LIGHTS 1024      // lights per block of k0_band_count / k0_band_scatter
 #define CL_STEPS (CAPG / 4 / 64) // cluster tiles: 64-candidate steps per wave for the longest listable group (8)
 
-// the shading hint's class counts travel as class A tiles << 16 | class B tiles in one uint32
-#define CLS_MAX_TILES 65535
-#define BAND_FORM_MAX_TILES 65535 // (see layout_has_hint)
+#define BAND_FORM_MAX_TILES (1 << 30) // (see layout_has_hint)
 
 struct CullLayout {
     int Tx, Ty, bandRows, bandTiles, numBands, words, groupsX, groupsY, numGroups, packBlocks;
-    size_t offLightView, offLightType, offTileInfo, offMasks, offDirWords, offGroupCount, offGroupList, offTileNum, offTileNum8, offTileLists, offTileOrder, offDirFlag, offHeavy,
+    size_t offLightView, offLightType, offTileInfo, offMasks, offDirWords, offGroupCount, offGroupList, offTileNum, offTileNum8, offTileLists, offDirFlag, offHeavy,
            offLightMap, offSelState, offSelKeep, total;
     int selBlocks;
 };
@@ -102,7 +100,7 @@ static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
     L.packBlocks = (L.bandTiles + PACK_TILES - 1) / PACK_TILES;
     const size_t groups = (size_t)(L.numGroups > 0 ? L.numGroups : 1);
     // Sections whose size depends on the geometry only come first, those that scale with the light count last: the offset of anything a later
-    // call looks up from (width, height, band) alone -- the tile-order hint -- is then the same for every lightsNum <= the capacity the
+    // call looks up from (width, height, band) alone -- the per-tile lists, their lengths -- is then the same for every lightsNum <= the capacity the
     // workspace was sized for (a cull may run with fewer lights than the capacity; round 2 computed the hint's address from the capacity and
     // the cull's own layout from lightsNum, which only agree when the two are equal).
     size_t o = 0;
@@ -114,7 +112,6 @@ static CullLayout make_layout(int W, int H, int N, const SailorBand& band)
     L.offTileNum = o; o = align_up(o + tiles * 4, 256);
     L.offTileNum8 = o; o = align_up(o + tiles + 64, 256);      // the same lengths (<= 128) as bytes: what k1_pack adds up for its base (32 KB at 4K instead of 130)
     L.offTileLists = o; o = align_up(o + tiles * KEEP * 4, 256); // one fixed 128-entry slot per tile (only the list's own bytes are ever touched)
-    L.offTileOrder = o; o = align_up(o + (tiles + 2) * 4, 256); // long tiles (A from the front, B from the back) + their two counts
     L.offLightView = o; o = align_up(o + n * 16, 256);
     L.offLightType = o; o = align_up(o + n * 4, 256);
     L.offMasks = o; o = align_up(o + (size_t)(L.numBands > 0 ? L.numBands : 1) * L.words * 8, 256);
@@ -184,7 +181,6 @@ struct PrepareArgs {
     unsigned long long* masks; unsigned long long* dirWords;
     uint32_t* heavy;   // [0]: k1_group_lists' count of light-cluster groups, zeroed here (one launch ahead of it)
     const uint32_t* selCount; // the band selection ran (null: it did not): the light role works on lightView / lightType [0, *selCount), already in view space
-    uint32_t* orderCounts; // the shading hint's two class counts (tileOrder[T], [T + 1]; null: whole frame, no hint), zeroed here for k1_tile_cull
     uint32_t* dirFlag; // "some light may be directional": set here, read by k1_group_lists_wide, cleared by k1_tile_cull (unknown before the first cull: then merely conservative)
     int N, words, lightBlocks, lightRoleBlocks, frustumBlocks, bandsPerBlock, setupBlocks, vpW, vpH, W, H, Tx, Ty, tileRow0, bandRow0, bandRows, groupsX, numBands,
         stripsPerRow, vecOK, rawDepth, intervals;
@@ -645,10 +641,7 @@ __global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K01_PREPARE];
     const int b = (int)blockIdx.x;
-    if (b == 0 && threadIdx.x == 0) {
-        a.heavy[0] = 0u;
-        if (a.orderCounts) { a.orderCounts[0] = 0u; a.orderCounts[1] = 0u; }
-    }
+    if (b == 0 && threadIdx.x == 0) a.heavy[0] = 0u;
     if (b < a.lightRoleBlocks) k0_lights(b, lds, a);
     else if (b < a.lightRoleBlocks + a.frustumBlocks) k1_tile_frusta(b - a.lightRoleBlocks, a);
     else k1_tile_setup(b - a.lightRoleBlocks - a.frustumBlocks, lds, a);
@@ -963,16 +956,12 @@ __device__ __forceinline__ void test_candidates(const TileCtx& t, const float4* 
 }
 
 
-// Tile classes for the shading hint (sailor_hip_light_cull_tile_order): A = lists of >= CLASS_A entries, B = >= CLASS_B.
-#define CLASS_A 96u
-#define CLASS_B 40u
 
 struct CullArgs {
     const float4* lightView; const uint32_t* lightType; const float4* tileInfo;
     const unsigned long long* masks; const uint32_t* groupCount; const uint32_t* groupList;
     uint32_t* tileNum; uint8_t* tileNum8; uint32_t* tileLists; uint32_t* dirFlag;
     int N, words, Tx, groupsX, bandRows;
-    uint32_t* tileOrder; int bandTiles; // the shading hint (null: none): see publish_tile
     const uint32_t* lightMap; const uint32_t* selCount; // behind the band selection (kernels with SEL): compact index -> light index; the number of selected lights
     const uint32_t* heavy; int headRows; // k1_group_lists' cluster list and the grid rows in front of the tile rows that take its tiles (0: none)
 };
@@ -1149,32 +1138,16 @@ __device__ __forceinline__ void walk_tile_masks(const TileCtx& t, const CullArgs
     }
 }
 
-// What a tile leaves behind besides its list: the length.  (Measured and dropped: the length also added to a per-tile-row total with a relaxed
-// device-scope atomic, for k1_pack's offsets -- 32 400 atomics on 135 words = five cache lines serialise at the memory side: k1_tile_cull 26 ->
-// 140 us.  k1_pack adds up the lengths of the tiles in front of its own instead: 64 KB of L2 reads per block on average.)
-// The shading hint of a band (sailor_hip_light_cull_tile_order): the tiles with >= CLASS_A entries from the front of tileOrder, those with >= CLASS_B from
-// its back, the two counts behind the T slots.  Appended HERE since round 4 (k1_pack wrote it through round 3, in tile order): the band's shade kernel
-// takes its long tiles from this array, and it must not have to wait for k1_pack.  The order within a class is whatever the atomics make it -- it decides
-// which block shades a tile, not what comes out -- and only the band's few hundred long tiles draw one (a whole frame has no hint).  Cost: ~3 us on the
-// kernel (the round trip of the last tiles' atomics), against the ~5 us of k1_pack that leave the band's chain.
-// (HINT: a template parameter of the kernels -- the whole frame's instantiations carry none of this; as a run-time test of a.tileOrder it cost the 4K
-// frame's k1_tile_cull 1.6-2 us)
-template <bool HINT>
-__device__ __forceinline__ uint32_t publish_tile(const CullArgs& a, const int bandTile, const uint32_t num)
+// What a tile leaves behind besides its list: the length, as a word (the shade's grid entry, k1_pack's scan) and as a byte (k1_pack's base sums; the
+// band shade's split blocks find the band's long tiles in the bytes: sailor_hip_light_cull_tile_order).  (Measured and dropped: the length also added
+// to a per-tile-row total with a relaxed device-scope atomic, for k1_pack's offsets -- 32 400 atomics on 135 words = five cache lines serialise at
+// the memory side: k1_tile_cull 26 -> 140 us.  Round 4's shading hint -- the long tiles appended to a list by two device-scope counters -- paid the
+// same way as soon as a band had more than a few hundred long tiles: +3 us on an eighth of the 4K frame, +6 on a quarter, +12.7 on a half (17.0 ->
+// 29.7 us); round 5's split blocks read the length bytes instead and nothing here is atomic.)
+__device__ __forceinline__ void publish_tile(const CullArgs& a, const int bandTile, const uint32_t num)
 {
     a.tileNum[bandTile] = num;
     a.tileNum8[bandTile] = (uint8_t)num;
-    uint32_t pos = 0u;
-    if constexpr (HINT) if (num >= CLASS_B) pos = __hip_atomic_fetch_add(a.tileOrder + (uint32_t)a.bandTiles + (num >= CLASS_A ? 0u : 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return pos; // for publish_order, once the tile's list has left
-}
-template <bool HINT>
-__device__ __forceinline__ void publish_order(const CullArgs& a, const int bandTile, const uint32_t num, const uint32_t pos)
-{
-    if constexpr (HINT) if (num >= CLASS_B) {
-        const int tyLocal = bandTile / a.Tx, tx = bandTile - tyLocal * a.Tx;
-        a.tileOrder[num >= CLASS_A ? pos : (uint32_t)a.bandTiles - 1u - pos] = (uint32_t)tx | ((uint32_t)tyLocal << 16);
-    }
 }
 
 // The selection's rank of candidate k (ComputeLightCulling.shader:198-225: the partial bubble sort == rank under (impact ascending, candidate position
@@ -1211,7 +1184,7 @@ __device__ __forceinline__ uint32_t rank_among(const float* sImp, const uint32_t
 // 196: what a wave collects beyond its first 196 can never be among the tile's first 196), and the selection's rank -- one candidate per THREAD
 // against all n -- takes ~200 comparisons per thread instead of ~800 per lane.  Same candidates in the same order, same impacts, same rank rule
 // (impact ascending, position descending): the list is the one-wave form's bit for bit (tests/test_light_cull_gpu.py: default == brute force).
-template <bool HINT, bool SEL>
+template <bool SEL>
 __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* __restrict__ lds, uint32_t* sCnt, const int gx, const int tyLocal, const int col)
 {
     uint32_t (*sIdxW)[CAND] = reinterpret_cast<uint32_t (*)[CAND]>(lds + CHUNK * 20);                  // [4][CAND]: the waves' own lists
@@ -1263,12 +1236,10 @@ __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* _
     const uint32_t all = (c0 + c1) + (c2 + c3), n = all < CAND ? all : CAND, num = n < KEEP ? n : KEEP;
     for (uint32_t i = lane; i < sCnt[wave] && before + i < CAND; i += 64) sAll[before + i] = sIdx[i];
     __syncthreads();
-    uint32_t pos = 0u;
-    if (threadIdx.x == 0) pos = publish_tile<HINT>(a, bandTile, num); // (the entry in the hint is completed at each way out, behind the list)
+    if (threadIdx.x == 0) publish_tile(a, bandTile, num);
     uint32_t* __restrict__ out = a.tileLists + (size_t)bandTile * KEEP;
     if (n <= KEEP) { // :235-238 culledLights.indices[offset + i] = candidateIndices[numCandidates - i - 1]
         if (threadIdx.x < n) { const uint32_t i = sAll[n - 1 - threadIdx.x] & 0x7FFFFFFFu; out[threadIdx.x] = SEL ? a.lightMap[i] : i; }
-        if (threadIdx.x == 0) publish_order<HINT>(a, bandTile, num, pos);
         return;
     }
     // ---- 196 -> 128 (ComputeLightCulling.shader:198-225): one candidate per thread
@@ -1284,18 +1255,15 @@ __device__ __forceinline__ void cluster_tile(const CullArgs& a, unsigned char* _
     __syncthreads();
     if (sCnt[4] != 0u) { // a NaN impact has no rank: the literal bubble sort, on one wave (emit_list)
         if (wave == 0) emit_list<SEL>(t, n, sAll, sImp, lightView, out, a.lightMap);
-        if (threadIdx.x == 0) publish_order<HINT>(a, bandTile, num, pos);
         return;
     }
     if (k >= n) return;
     const uint32_t rank = rank_among(sImp, n, k, imp);
     if (rank < KEEP) { const uint32_t i = mine & 0x7FFFFFFFu; out[rank] = SEL ? a.lightMap[i] : i; }
-    if (threadIdx.x == 0) publish_order<HINT>(a, bandTile, num, pos); // (thread 0 holds candidate 0 < n: it comes this way)
 }
 
 // The validation path (SAILOR_CULL_BRUTE_FORCE; also tiny light sets and odd projections): no pre-filter, no staging, no cooperation between
 // waves -- every tile walks ALL lights by itself, 64 per step, and selects with emit_list on its own wave.  One block per run of four tiles.
-template <bool HINT>
 __global__ __launch_bounds__(256) void k1_tile_cull_brute(const CullArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 4 * CAND * 4];
@@ -1315,10 +1283,8 @@ __global__ __launch_bounds__(256) void k1_tile_cull_brute(const CullArgs a)
         test_candidates(t, a.lightView, a.lightType, j < a.N, (uint32_t)j, count, sIdxAll[wave]);
     }
     const uint32_t n = count < CAND ? count : CAND;
-    uint32_t pos = 0u;
-    if (lane == 0) pos = publish_tile<HINT>(a, bandTile, n < KEEP ? n : KEEP);
+    if (lane == 0) publish_tile(a, bandTile, n < KEEP ? n : KEEP);
     emit_list<false>(t, n, sIdxAll[wave], sImpAll[wave], a.lightView, a.tileLists + (size_t)bandTile * KEEP, nullptr);
-    if (lane == 0) publish_order<HINT>(a, bandTile, n < KEEP ? n : KEEP, pos);
 }
 
 // The 196 -> 128 selections of a block's tiles by the WHOLE block (ComputeLightCulling.shader:198-225): one candidate per thread and tile.  sIdxAll[w]:
@@ -1374,7 +1340,7 @@ __device__ __forceinline__ void block_select(const CullArgs& a, const int firstB
 // full tile that start 10-20 us into the launch and end at 24-29 while 99 % of the blocks are done at 22).  On for the 4K frame and its bands (a band
 // IS its longest block: k1_tile_cull 14.7 -> 9.7 us on a cluster band of an 8-way split), off on the wide path's 420-candidate lists (8K, a million
 // lights: no listed clusters, seven test steps per tile, and the barrier costs the throughput phase 15 %: 99 -> 114 us).
-template <bool COOP, bool HINT, bool SEL>
+template <bool COOP, bool SEL>
 __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
 {
     // One 256-thread block per run of four tiles (a group's four columns in one tile row), one wave per tile.  The group's candidate records are
@@ -1404,7 +1370,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
         const int row = (hg / groupsX) * GROUP + (int)((hb >> 2) & 3u);
         if (row >= a.bandRows) return;
         PROF_T(0);
-        cluster_tile<HINT, SEL>(a, lds, sCnt, hg % groupsX, row, (int)(hb & 3u));
+        cluster_tile<SEL>(a, lds, sCnt, hg % groupsX, row, (int)(hb & 3u));
         PROF_T(3);
         return;
     }
@@ -1457,8 +1423,7 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
     }
     PROF_T(1);
     const uint32_t n = count < CAND ? count : CAND; // (0 for a wave beyond the last tile column)
-    uint32_t pos = 0u;
-    if (active && lane == 0) pos = publish_tile<HINT>(a, bandTile, n < KEEP ? n : KEEP);
+    if (active && lane == 0) publish_tile(a, bandTile, n < KEEP ? n : KEEP);
     // The tile's list into the tile's own slot: k1_pack moves it to its canonical place, the shade reads it where it is.
     if (!COOP || gn == GROUP_OVERFLOW) { // (an overflowed group's staging area is the waves' queues: every wave selects for itself)
         // a tile with more than 128 candidates selects on its own wave (emit_list: ~9 us)
@@ -1476,7 +1441,6 @@ __global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
         if (((sCnt[0] > (uint32_t)KEEP) | (sCnt[1] > (uint32_t)KEEP)) | ((sCnt[2] > (uint32_t)KEEP) | (sCnt[3] > (uint32_t)KEEP))) // (block-uniform)
             block_select<SEL>(a, tyLocal * Tx + gx * GROUP, sCnt, sIdxAll, sImpAll, sCnt + 4);
     }
-    if (active && lane == 0) publish_order<HINT>(a, bandTile, n < KEEP ? n : KEEP, pos);
     PROF_T(3);
 }
 
@@ -1604,13 +1568,12 @@ static bool band_valid(int W, int H, const SailorBand* b)
     return b->fbRowBegin == lo && b->fbRowCount == hi - lo;
 }
 
-// The tile-order hint is produced for the bands of a split frame that the band form of the shade (split blocks for the long tiles, shade.hip) serves:
-// bands of up to BAND_FORM_MAX_TILES tiles.  A larger band -- half or a quarter of the 4K frame, an eighth of the 8K frame: four and more rounds of
-// resident tile blocks -- is bound by the shade's throughput like the whole frame and takes the whole frame's form: one block per tile on the
-// XCD-aware grid, no split-role blocks in front of them, no hint (and none of its atomics in k1_tile_cull).  SAILOR_BAND_FORM_TILES=<n> overrides.
+// The BAND FORM of the shade (shade.hip: split blocks for the long tiles in front of the one-block-per-tile grid) is for the bands of a split frame of up
+// to BAND_FORM_MAX_TILES tiles; sailor_hip_light_cull_tile_order hands such a band's per-tile list lengths to the shade, which is what switches the form
+// on.  SAILOR_BAND_FORM_TILES=<n> overrides the limit (A / B).
 static int band_form_max_tiles()
 {
-    static const int v = [] { const char* e = getenv("SAILOR_BAND_FORM_TILES"); const int n = e ? atoi(e) : BAND_FORM_MAX_TILES; return n > CLS_MAX_TILES ? CLS_MAX_TILES : n; }();
+    static const int v = [] { const char* e = getenv("SAILOR_BAND_FORM_TILES"); return e ? atoi(e) : BAND_FORM_MAX_TILES; }();
     return v;
 }
 static bool layout_has_hint(const CullLayout& L) { return L.bandRows < L.Ty && L.bandTiles > 0 && L.bandTiles <= band_form_max_tiles(); }
@@ -1755,7 +1718,6 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     pa.planeMargin = 1e-3f;
     pa.dirFlag = (uint32_t*)(ws + L.offDirFlag);
     pa.heavy = (uint32_t*)(ws + L.offHeavy);
-    pa.orderCounts = layout_has_hint(L) ? (uint32_t*)(ws + L.offTileOrder) + L.bandTiles : nullptr;
     sailor_launch(ctx, k01_prepare, dim3(pa.lightRoleBlocks + pa.frustumBlocks + pa.setupBlocks), dim3(256), pa);
     SAILOR_CHECK_LAUNCH(ctx, "k01_prepare");
 
@@ -1766,11 +1728,9 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
     ca.dirFlag = pa.dirFlag;
     ca.N = N; ca.words = L.words; ca.Tx = L.Tx; ca.groupsX = L.groupsX; ca.bandRows = L.bandRows;
     ca.heavy = (const uint32_t*)(ws + L.offHeavy); ca.headRows = 0;
-    ca.tileOrder = layout_has_hint(L) ? (uint32_t*)(ws + L.offTileOrder) : nullptr; ca.bandTiles = L.bandTiles;
     ca.lightMap = select ? (const uint32_t*)(ws + L.offLightMap) : nullptr; ca.selCount = pa.selCount;
     if (brute) {
-        if (ca.tileOrder) sailor_launch(ctx, k1_tile_cull_brute<true>, dim3(L.groupsX, L.bandRows), dim3(256), ca);
-        else sailor_launch(ctx, k1_tile_cull_brute<false>, dim3(L.groupsX, L.bandRows), dim3(256), ca);
+        sailor_launch(ctx, k1_tile_cull_brute, dim3(L.groupsX, L.bandRows), dim3(256), ca);
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull<brute>");
     } else {
         const bool wide = L.words >= 4096 && (L.words & 1) == 0;
@@ -1800,14 +1760,9 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
         // (the block-wide selection everywhere but on the long lists of the wide path: see k1_tile_cull)
         const bool coop = !wide;
         const dim3 cgrid(L.groupsX, ca.headRows + L.bandRows);
-        if (select) { // (a band by definition: the hint's kernels)
-            if (!coop) sailor_launch(ctx, k1_tile_cull<false, true, true>, cgrid, dim3(256), ca);
-            else sailor_launch(ctx, k1_tile_cull<true, true, true>, cgrid, dim3(256), ca);
-        } else if (ca.tileOrder) { // a band of a split frame: the kernels that append the shading hint
-            if (!coop) sailor_launch(ctx, k1_tile_cull<false, true, false>, cgrid, dim3(256), ca);
-            else sailor_launch(ctx, k1_tile_cull<true, true, false>, cgrid, dim3(256), ca);
-        } else if (!coop) sailor_launch(ctx, k1_tile_cull<false, false, false>, cgrid, dim3(256), ca);
-        else sailor_launch(ctx, k1_tile_cull<true, false, false>, cgrid, dim3(256), ca);
+        // (COOP: the block-wide selection; SEL: behind the band selection -- compact indices, translated when a list leaves)
+        if (coop) { if (select) sailor_launch(ctx, k1_tile_cull<true, true>, cgrid, dim3(256), ca); else sailor_launch(ctx, k1_tile_cull<true, false>, cgrid, dim3(256), ca); }
+        else { if (select) sailor_launch(ctx, k1_tile_cull<false, true>, cgrid, dim3(256), ca); else sailor_launch(ctx, k1_tile_cull<false, false>, cgrid, dim3(256), ca); }
         SAILOR_CHECK_LAUNCH(ctx, "k1_tile_cull");
     }
     if (flags & SAILOR_CULL_DEFER_PACK) return SAILOR_HIP_OK; // the caller records sailor_hip_light_cull_pack where it wants it (another stream, beside the shade)
@@ -1889,10 +1844,10 @@ const uint32_t* sailor_hip_light_cull_tile_order(int32_t width, int32_t height, 
     SailorBand whole;
     if (!band) { sailor_hip_band_whole_frame(width, height, &whole); band = &whole; }
     if (!band_valid(width, height, band)) return nullptr;
-    if (width > 16 * 65535 || height > 16 * 65535) return nullptr; // packed as two 16-bit tile coordinates
     const CullLayout L = make_layout(width, height, lightsCapacity, *band);
-    if (!layout_has_hint(L)) return nullptr; // whole frame: no hint is produced (raster order)
-    return (const uint32_t*)((const char*)dWorkspace + L.offTileOrder);
+    if (!layout_has_hint(L)) return nullptr; // whole frame: the one-block-per-tile form in raster order
+    // (the band's list lengths as bytes, one per tile in tile order -- every cull writes them: the band shade's split blocks find the long tiles there)
+    return (const uint32_t*)((const char*)dWorkspace + L.offTileNum8);
 }
 
 // The band's own light set as the last cull of this geometry AND light count left it (k0_band_count + k0_band_scatter): the number of selected lights and

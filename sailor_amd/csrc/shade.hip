@@ -103,14 +103,27 @@ __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArg
         return;
     }
     SPROF_T(0)
-    // the cull's hint: order[0 .. nA) = the tiles with >= 96 lights, order[T-1], order[T-2] .. = the nB tiles with 40..95, order[T] = nA, order[T+1] = nB
-    const uint32_t nA = A.order[bandTiles], limit = 4u * (nA + A.order[bandTiles + 1]);
-    for (uint32_t idx = blockIdx.x; idx < limit; idx += (uint32_t)SPLIT_BLOCKS) {
-        const uint32_t li = idx >> 2;
-        const uint32_t o = A.order[li < nA ? li : (uint32_t)bandTiles - 1u - (li - nA)];
-        k2_shade_body<CSM, false, ROLE_BAND_SPLIT, PREP, TL>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, (int)(o & 0xFFFFu), (int)(o >> 16),
-                                                           (int)(idx & 3u));
-        __syncthreads(); // the LDS arrays are reused by the block's next tile
+    // The band's long tiles, found by the split blocks themselves (round 5): the (tile, quadrant) items are numbered 4 * tile + quadrant and split block b
+    // takes the items b, b + SPLIT_BLOCKS, b + 2 * SPLIT_BLOCKS, ...; it reads the list lengths of 64 of them at a time (A.order: one byte per tile, written
+    // by k1_tile_cull; one load, the bytes 512 tiles apart), and the ballot of the long ones is what it shades.  Round 4 had k1_tile_cull append the long
+    // tiles to a list through two device-scope counters: every long tile one atomic on one word -- +3 us on that kernel on an eighth of the 4K frame, +12.7
+    // on half of it.  (Neighbouring tiles' items go to different blocks, a cluster is spread over all of them; all four waves of the block run the
+    // same scalar-uniform scan.)
+    const uint32_t items = 4u * (uint32_t)bandTiles;
+    const uint32_t lane = (uint32_t)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    for (uint32_t base = blockIdx.x; base < items; base += (uint32_t)SPLIT_BLOCKS * 64u) {
+        const uint32_t it = base + lane * (uint32_t)SPLIT_BLOCKS;
+        const uint32_t num = it < items ? (uint32_t)A.order[it >> 2] : 0u;
+        unsigned long long todo = __ballot(num >= (uint32_t)SPLIT_MIN);
+        while (todo != 0ull) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint32_t item = base + l * (uint32_t)SPLIT_BLOCKS, tile = item >> 2;
+            const uint32_t ty = tile / (uint32_t)A.Tx;
+            k2_shade_body<CSM, false, ROLE_BAND_SPLIT, PREP, TL>(lds, A, C, IblArgs(), surface, planeStride, lights, grid, culled, radiance, (int)(tile - ty * (uint32_t)A.Tx), (int)ty,
+                                                               (int)(item & 3u));
+            __syncthreads(); // the LDS arrays are reused by the block's next tile
+        }
     }
     SPROF_T(3)
 }
@@ -326,7 +339,7 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
     A.fbRow0 = band->fbRowBegin;
     A.fbRows = band->fbRowCount;
     A.lightsNum = lightsNum;
-    A.order = dTileOrder;
+    A.order = reinterpret_cast<const uint8_t*>(dTileOrder); // (the band's list lengths as bytes: sailor_hip_light_cull_tile_order)
     const int bandTiles = (band->tileRowEnd - band->tileRowBegin) * A.Tx;
     if (bandTiles == 0) return SAILOR_HIP_OK;
 
@@ -371,7 +384,7 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
                              else if (dTileNum) { kname = #K "_t"; sailor_launch_lds(ctx, K##_t, grid, dim3(256), bandLds, A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } \
                              else { kname = #K; sailor_launch_lds(ctx, K, grid, dim3(256), bandLds, A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); } } while (0)
     const bool partial = band->tileRowEnd - band->tileRowBegin < Ty;
-    const bool splitBand = dTileOrder && partial && !ibl; // a band of a split frame with the cull's hint: long tiles are split across four blocks
+    const bool splitBand = dTileOrder && partial && !ibl; // a band of a split frame with the cull's length bytes: long tiles are split across four blocks
     // A band's shade does not take the whole chip: SHADE_BAND_RESERVE bytes of dynamic LDS that nobody touches cap it at six blocks (24 of 32 wave slots)
     // per CU.  A split frame is a pipeline of short launches -- the NEXT frame's cull chain runs beside this kernel on another stream -- and with every wave
     // slot taken by shade blocks each of the chain's four launches queues behind them: measured on 1/8 bands of the 4K frame, alone the kernel takes

@@ -35,7 +35,7 @@ struct ShadeArgs {
     int fbRows;       // band.fbRowCount
     int bandTileRows; // band.tileRowEnd - band.tileRowBegin
     int lightsNum;
-    const uint32_t* order; // sailor_hip_light_cull_tile_order or null
+    const uint8_t* order;  // sailor_hip_light_cull_tile_order (the band's list lengths as bytes, one per tile) or null
 };
 
 // ---- K3: canonical-order helpers (must match oracle/sailor_oracle.c bit for bit) -----------------------------
@@ -317,14 +317,13 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // wave-uniform 64-bit masks (scalar registers, scalar branches, six static segments -- no per-light type branches), the reach
 // test feeds the scalar branch directly, and the ~130-instruction exact falloff + BRDF only ever runs on queued pairs.
 //
-// BAND (split frames: sailor_hip_shade_ex on a sub-band with the cull's tile-order hint): a band of a split frame has too few
+// BAND (split frames: sailor_hip_shade_ex on a sub-band with the cull's per-tile list lengths): a band of a split frame has too few
 // tiles to hide its longest one -- a tile in the middle of a light cluster (128 lights reaching all 256 pixels = 128 pair passes
-// per wave) kept its block busy for ~65 us while the rest of a 1/8 band took 25.  The hint lists the band's tiles by list-length
-// class (>= 96 lights from the front of the array, >= SPLIT_MIN from its back, then the two counts).  Those tiles are taken by "split"
+// per wave) kept its block busy for ~65 us while the rest of a 1/8 band took 25.  The tiles with >= SPLIT_MIN lights are taken by "split"
 // blocks, one per (tile, 8x8 quadrant): the block's four waves take every fourth list slot each over the SAME 64 pixels and add
-// their partial sums up through LDS (wave 0 + 1 + 2 + 3, a fixed order).  The grid is 1-D: SPLIT_BLOCKS split blocks first (they
-// walk the long tiles with a grid stride, so the long tiles start first), then one ordinary block per tile, which returns at
-// once if the tile belongs to the split blocks.
+// their partial sums up through LDS (wave 0 + 1 + 2 + 3, a fixed order).  The grid is 1-D: SPLIT_BLOCKS split blocks first (split block b
+// looks at the (tile, quadrant) items b, b + SPLIT_BLOCKS, ... -- the lengths of up to 64 of them in one load, a ballot of the long ones --
+// so the long tiles start first), then one ordinary block per tile, which returns at once if the tile belongs to the split blocks.
 // The loop over the point / spot lights of one list half that may reach a quadrant, for the usual quadrant (every pixel inside the frame, none
 // with roughness 0), by hand: the wave is bound by instruction issue -- a scalar instruction costs what a vector one costs -- and the
 // compiler's version of this loop spends more instructions on getting around it than on the tests.  Per light: the conservative reach test on
@@ -406,7 +405,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
                    [lim] "s"((1u << (7 * PENDK)) - 1u), [qmax] "n"(QMAX), [lane] "v"(lane) \
                  : "v56", "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc", "memory")
 
-#define SPLIT_MIN 40      // == CLASS_B of light_cull.hip: the hint's first two classes
+#define SPLIT_MIN 40      // a tile with at least this many lights goes to the split blocks
 #define SHADE_BAND_RESERVE 9000 // bytes of untouched dynamic LDS per block of k2_shade_band*: six blocks per CU instead of eight (see its launch)
 #ifndef SPLIT_BLOCKS
 #define SPLIT_BLOCKS 2048 // one round of resident blocks (8 per CU)

@@ -162,7 +162,7 @@ def test_entity_slices_of_the_sweep_are_the_whole_sweeps_bits(ctx, world, count)
     gathered, covered = [], 0
     for r in range(world):
         sw = EcsSweep(ctx, ents, rank=r, world=world)
-        assert sw.begin % 64 == 0 and (sw.end % 64 == 0 or sw.end == count) and sw.begin == min(r * sw.words_per_rank * 64, count)
+        assert (sw.begin % 64 == 0 or sw.begin == count) and (sw.end % 64 == 0 or sw.end == count) and sw.begin == min(r * sw.words_per_rank * 64, count)
         sw.world.fill_(-7.0); sw.world_aabb.fill_(-7.0)
         w, a, v = sw.run(planes)
         ctx.synchronize()
