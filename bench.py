@@ -78,12 +78,12 @@ def parse(argv=None):
     ap.add_argument("--single-mode", action="store_true", help="profiling runs (rocprofv3 kernel stats, PMC passes): only the headline's light mode and launch form -- no second "
                                                                "pass in the other light mode, no one-frame-in-flight reading with the pack beside the shade -- so that every kernel of the "
                                                                "trace was launched the same way")
-    ap.add_argument("--pack", default="never", choices=["never", "deferred", "inline"],
-                    help="when k1_pack -- the compaction of the per-tile lists into the reference's lightsGrid / culledLights -- runs.  never (default, round 5): no consumer "
-                         "of the canonical buffers exists on this path (the shade reads the per-tile lists; the reference's only reader of the two buffers IS the shade, "
-                         "Standard.shader:422-436), so no frame pays for them -- they stay available bit for bit on demand (sailor_hip_light_cull_pack: the N > 1 "
-                         "exchange and the list read-back below call it) and the kernel is reported as `pack_ms`.  deferred: every frame, behind the event the shade "
-                         "waits for (round 4's default).  inline: inside every cull (rounds 1-3)")
+    ap.add_argument("--pack", default="deferred", choices=["never", "deferred", "inline"],
+                    help="when k1_pack -- the compaction of the per-tile lists into the reference's lightsGrid / culledLights -- runs.  deferred (default): every frame, "
+                         "behind the event the shade waits for.  never: no frame runs it (the shade reads the per-tile lists; the reference's only reader of the two buffers "
+                         "IS the shade, Standard.shader:422-436) -- they stay available bit for bit on demand (sailor_hip_light_cull_pack: the N > 1 exchange and the list "
+                         "read-back call it) and the kernel is reported as `pack_ms`; measured in round 5: no gain -- the frame pipeline hides the launch, and a shade that "
+                         "follows k1_tile_cull directly takes ~9 us LONGER than one that follows the pack (profiles/r05/README.md).  inline: inside every cull (rounds 1-3)")
     ap.add_argument("--pack-inline", action="store_true", help="= --pack inline")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--equal-bands", action="store_true", help="N > 1: equal tile-row bands instead of cost-balanced ones")
@@ -99,6 +99,9 @@ def parse(argv=None):
                     help="N > 1: comma-separated configurations whose split frame gets a bounded reading (~20 steps each) appended to the line as `split_configs`; "
                          "default: C4,C5 -- the two BASELINE.json names for eight GPUs -- when the headline is C3, none otherwise; '' = none")
     ap.add_argument("--split-config-steps", type=int, default=24)
+    ap.add_argument("--rebalance", type=int, default=2,
+                    help="N > 1 (and --simulate-split): rounds of re-cutting the cost-balanced bands on MEASURED band times (a renderer has the previous frame's); 0 = the "
+                         "list-volume model alone")
     return ap.parse_args(argv)
 
 
@@ -821,17 +824,32 @@ def simulate_split(args, dev, ctx, side, frame, d_lights, fp_full, d_depth_full,
         for _ in range((args.warmup + per - 1) // per):
             graph.replay()
         dev.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps // per):
-            graph.replay()
-        dev.synchronize()
-        return (time.perf_counter() - t0) / (args.steps // per * per) * 1e3
+        reps = []
+        for _ in range(5):   # (the median of five timed runs of K steps: a band's K steps are over in 1-2 ms and single runs scatter by +-10 %)
+            t0 = time.perf_counter()
+            for _ in range(args.steps // per):
+                graph.replay()
+            dev.synchronize()
+            reps.append((time.perf_counter() - t0) / (args.steps // per * per) * 1e3)
+        return float(np.median(reps))
 
     whole = time_band(host.band_whole_frame(W, H))
     for name, bounds in (("equal", [host.band_for_rank(W, H, r, G).tileRowBegin for r in range(G)] + [Ty]),
                          ("balanced", sdist.balanced_tile_rows(row_entries, Tx, G))):
         ms = [time_band(host.band_from_tile_rows(W, H, bounds[r], bounds[r + 1])) for r in range(G)]
         out[name] = {"bounds": [int(b) for b in bounds], "band_ms": ms, "max_ms": max(ms), "predicted_speedup": whole / max(ms)}
+    # ... and re-cut on the measured band times, as a renderer re-cuts on the previous frame's (sdist.rebalance_on_measured_times; what main() does for N > 1):
+    # `--rebalance` rounds, each from the round before
+    prev = out["balanced"]
+    for it in range(args.rebalance):
+        bounds = sdist.rebalance_on_measured_times(prev["bounds"], prev["band_ms"], row_entries, Tx)
+        if bounds == prev["bounds"]:
+            break
+        ms = [time_band(host.band_from_tile_rows(W, H, bounds[r], bounds[r + 1])) for r in range(G)]
+        cur = {"bounds": [int(b) for b in bounds], "band_ms": ms, "max_ms": max(ms), "predicted_speedup": whole / max(ms), "round": it + 1}
+        if cur["max_ms"] < out.get("rebalanced", prev)["max_ms"]:
+            out["rebalanced"] = cur
+        prev = cur
     out["whole_frame_ms"] = whole
     out["launch"] = f"hipGraph replay ({unroll} steps of the frame pipeline per graph), 2 frames in flight over {args.list_sets} list sets" if unroll else "hipGraph replay, 1 frame in flight"
     print(json.dumps(out), flush=True)
@@ -1072,6 +1090,11 @@ def main(argv=None, device_factory=None):
         dd = dev.upload(frame.depth[b.fbRowBegin:b.fbRowBegin + b.fbRowCount])
         return f, dd
 
+    csm = keep = None
+    if frame.cfg.get("shadow_size"):
+        shadows = synth.make_shadow_set(cam, frame.cfg["shadow_size"])
+        csm, keep = dev.upload_shadow_maps(shadows)
+
     band = host.band_for_rank(W, H, rank, world)
     bounds = [host.band_for_rank(W, H, r, world).tileRowBegin for r in range(world)] + [Ty]   # tile-row boundaries of the split (equal bands)
     partition = "whole frame"
@@ -1091,8 +1114,30 @@ def main(argv=None, device_factory=None):
         rows_entries = sdist.gather_row_entries(f0.grid[: f0.band_tiles * 2], Tx, band.tileRowEnd - band.tileRowBegin, Ty, band.tileRowBegin)
         bounds = [int(b) for b in sdist.balanced_tile_rows(rows_entries, Tx, world)]
         band = host.band_from_tile_rows(W, H, bounds[rank], bounds[rank + 1])
-        partition = f"cost-balanced tile rows {bounds}"
         del f0, d0
+        # ... then re-cut on MEASURED band times (sdist.rebalance_on_measured_times: a renderer re-cuts on the previous frame's): every rank times its
+        # band's cull + shade (eager, one stream), all ranks learn all times, the boundaries move; `--rebalance` rounds.  Not in the timed region.
+        rebalanced = 0
+        for _ in range(args.rebalance):
+            fb, db = resident(band)
+            sb = dev.upload(frame.surface_rows(band.fbRowBegin, band.fbRowBegin + band.fbRowCount))
+
+            def band_step():
+                fb.cull(cam.frame, d_lights, N, db)
+                fb.shade(cam.frame, sb, d_lights, N, csm)
+            for _w in range(3):
+                band_step()
+            dev.synchronize()
+            t = torch.zeros(world, dtype=torch.float64, device=device)
+            t[rank] = event_batch_ms(band_step, 10)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            del fb, db, sb
+            new = [int(b) for b in sdist.rebalance_on_measured_times(bounds, t.tolist(), rows_entries, Tx)]
+            if new == bounds:
+                break
+            bounds, rebalanced = new, rebalanced + 1
+            band = host.band_from_tile_rows(W, H, bounds[rank], bounds[rank + 1])
+        partition = f"cost-balanced tile rows {bounds}" + (f" (re-cut {rebalanced}x on measured band times)" if rebalanced else "")
     elif world > 1:
         partition = "equal tile rows"
     if args.simulate_band:
@@ -1102,10 +1147,6 @@ def main(argv=None, device_factory=None):
     rows = slice(band.fbRowBegin, band.fbRowBegin + band.fbRowCount)
     fp, d_depth = resident(band)
     d_surface = dev.upload(frame.surface_rows(rows.start, rows.stop))
-    csm = keep = None
-    if frame.cfg.get("shadow_size"):
-        shadows = synth.make_shadow_set(cam, frame.cfg["shadow_size"])
-        csm, keep = dev.upload_shadow_maps(shadows)
 
     if args.simulate_split:
         simulate_split(args, dev, ctx, side, frame, d_lights, fp, d_depth, prep, csm)

@@ -65,7 +65,6 @@
 // IS its longest block; below 384 too many groups qualify.  So: by the size of the band.
 #define HEAVY_MIN_FRAME 512
 #define HEAVY_MIN_BAND 384
-#define HEAVY_MIN_WIDE 1024     // ... and on the wide path (a million lights: the ORDINARY group has ~420 candidates there)
 #define HEAVY_MAX 96            // ... and that list's room (16 head blocks of k1_tile_cull per entry: the empty ones are dispatched in front of everything else -- 4 096 of them cost ~3 us)
 #define CHUNK 512            // group candidates staged in LDS per step of k1_tile_cull (16 KB of LDS per block: 8 blocks per CU)
 
@@ -73,7 +72,7 @@
 #define SEL_LIGHTS 1024      // lights per block of k0_band_count / k0_band_scatter
 #define CL_STEPS (CAPG / 4 / 64) // cluster tiles: 64-candidate steps per wave for the longest listable group (8)
 
-#define BAND_FORM_MAX_TILES (1 << 30) // (see layout_has_hint)
+#define BAND_FORM_MAX_TILES 12000 // (see layout_has_hint)
 
 struct CullLayout {
     int Tx, Ty, bandRows, bandTiles, numBands, words, groupsX, groupsY, numGroups, packBlocks;
@@ -786,8 +785,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 template <bool EXACT> // EXACT: words is a multiple of 128 * GLW_ROWS, no load needs a bounds check
 __global__ __launch_bounds__(256) void k1_group_lists_wide(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ dirWords,
                                                             int stride, int groupsX, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList,
-                                                            const uint32_t* __restrict__ dirFlag, const uint32_t* __restrict__ selCount,
-                                                            uint32_t* __restrict__ heavy, uint32_t heavyMin)
+                                                            const uint32_t* __restrict__ dirFlag, const uint32_t* __restrict__ selCount)
 {
     const int words = (!EXACT && selCount) ? min((int)(((*selCount + 63u) / 64u + 1u) & ~1u), stride) : stride; // (behind the band selection: the selected lights' words)
     __shared__ __attribute__((aligned(16))) unsigned long long sRow[2][GLW_ROWS][128];
@@ -867,18 +865,10 @@ __global__ __launch_bounds__(256) void k1_group_lists_wide(const unsigned long l
     }
     if (mine) {
         if (qTail != qHead) { WAVE_SYNC(); drain(qTail - qHead); }
-        if (lane == 0) {
-            uint32_t word = base > CAPG ? GROUP_OVERFLOW : base;
-            // (round 5) a light cluster is listed here too, as k1_group_lists does: k1_tile_cull gives its tiles a block each, at the front of the grid
-            if (heavyMin != 0u && base > heavyMin) {
-                const uint32_t slot = atomicAdd(&heavy[0], 1u);
-                if (slot < (uint32_t)HEAVY_MAX) {
-                    heavy[1u + slot] = (uint32_t)g;
-                    word = word != GROUP_OVERFLOW ? (word | GROUP_LISTED) : GROUP_OVERFLOW_LISTED;
-                }
-            }
-            groupCount[g] = word;
-        }
+        // (round 5, measured and dropped: light clusters listed here too, as k1_group_lists does, their tiles a block each at the front of k1_tile_cull's grid
+        // -- thresholds of 768 / 1 024 / 1 536 candidates on an eighth of the 8K frame under a million lights: 27.0 / 27.7 / 27.8 us against 27.6 without;
+        // what that launch lost there was the shading hint's atomics, 37.6 -> 27.7 us)
+        if (lane == 0) groupCount[g] = base > CAPG ? GROUP_OVERFLOW : base;
     }
 }
 
@@ -1570,7 +1560,10 @@ static bool band_valid(int W, int H, const SailorBand* b)
 
 // The BAND FORM of the shade (shade.hip: split blocks for the long tiles in front of the one-block-per-tile grid) is for the bands of a split frame of up
 // to BAND_FORM_MAX_TILES tiles; sailor_hip_light_cull_tile_order hands such a band's per-tile list lengths to the shade, which is what switches the form
-// on.  SAILOR_BAND_FORM_TILES=<n> overrides the limit (A / B).
+// on.  A larger band -- half the 4K frame (16 200 tiles), an eighth of the 8K frame (16 320) -- is eight rounds of resident blocks, bound by the
+// shade's throughput like the whole frame, and takes the whole frame's form: one block per tile on the XCD-aware grid, nothing in front of them
+// (measured, same box, step of the frame pipeline: half the 4K frame 109.0 against 109.6 us; an eighth of the 8K frame under a million lights 121 against
+// 133; a quarter of the 4K frame -- 8 100 tiles -- 75.9 against 68.9: the band form).  SAILOR_BAND_FORM_TILES=<n> overrides the limit (A / B).
 static int band_form_max_tiles()
 {
     static const int v = [] { const char* e = getenv("SAILOR_BAND_FORM_TILES"); return e ? atoi(e) : BAND_FORM_MAX_TILES; }();
@@ -1736,20 +1729,13 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
         const bool wide = L.words >= 4096 && (L.words & 1) == 0;
         if (wide)
         {
-            // Light clusters on the wide path (round 5): under a million lights the ordinary group has ~420 candidates and its tiles select on their own
-            // waves; the groups far above that -- several hundred candidates PER TILE, every tile selecting -- were the tail of a band's launch (four
-            // tiles of ~10 us of tests + 11-15 us of selection each on one wave, started 6-14 us in).  Listed from HEAVY_MIN_WIDE candidates on, they get a
-            // block per tile at the front of the grid like the 4K frame's clusters.  SAILOR_HEAVY_MIN_WIDE=<n> overrides (0: none; A / B).
-            static const int heavyEnv = [] { const char* e = getenv("SAILOR_HEAVY_MIN_WIDE"); return e ? atoi(e) : -1; }();
-            const uint32_t heavyMinWide = heavyEnv >= 0 ? (uint32_t)heavyEnv : (uint32_t)HEAVY_MIN_WIDE;
             const dim3 wideGrid((unsigned)(((L.groupsX + 3) / 4) * L.groupsY));
             if (L.words % (128 * GLW_ROWS) == 0 && !select)
                 sailor_launch(ctx, k1_group_lists_wide<true>, wideGrid, dim3(256), pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
-                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag), (const uint32_t*)nullptr, (uint32_t*)(ws + L.offHeavy), heavyMinWide);
+                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag), (const uint32_t*)nullptr);
             else
                 sailor_launch(ctx, k1_group_lists_wide<false>, wideGrid, dim3(256), pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
-                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag), pa.selCount, (uint32_t*)(ws + L.offHeavy), heavyMinWide);
-            if (heavyMinWide != 0u) ca.headRows = (16 * HEAVY_MAX + L.groupsX - 1) / L.groupsX;
+                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag), pa.selCount);
         }
         else {
             sailor_launch(ctx, k1_group_lists, dim3(L.groupsX, L.groupsY), dim3(256), pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),

@@ -65,9 +65,9 @@ template <bool ON> __device__ __forceinline__ void sprof_mark_grid(const int i) 
                                                      const uint32_t* __restrict__ culled, float4* __restrict__ radiance)                          \
     {                                                                                                                                              \
         __shared__ ShadeLds lds;                                                                                                                   \
-        SPROF_TG(0, (CSM) && !(IBL))                                                                                                               \
+        SPROF_TG(0, !(IBL))                                                                                                               \
         k2_shade_body<CSM, IBL, ROLE_TILE, PREP, TL>(lds, A, C, I, surface, planeStride, lights, grid, culled, radiance);                          \
-        SPROF_TG(3, (CSM) && !(IBL))                                                                                                               \
+        SPROF_TG(3, !(IBL))                                                                                                               \
     }
 #define FORCE_64_VGPRS __attribute__((amdgpu_waves_per_eu(8, 8)))
 // (the K3 kernels: 64 registers like the others since the shadow look-ups run before the view / material terms -- "K3 first" in shade_body.h; it

@@ -63,6 +63,37 @@ def balanced_tile_rows(row_entries, tiles_per_row: int, world_size: int):
     return bounds
 
 
+def rebalance_on_measured_times(bounds, band_ms, row_entries, tiles_per_row: int):
+    """Tile-row boundaries re-cut on MEASURED band times (a renderer has the previous frame's band times; a model that knows list lengths
+    does not know cascades, clusters or launch floors).  bounds: the world + 1 boundaries the times were taken with; band_ms[r]: band r's step time;
+    row_entries: the model's per-row list volumes (row_cost_entries).  Every row's model cost is scaled so that each band's modelled cost equals its
+    measured time -- the model keeps the variation INSIDE a band, the measurement fixes the level of each band -- and the rows are cut again into
+    bands of equal cost.  Returns the new boundaries (same conventions as balanced_tile_rows: non-decreasing, every band non-empty where possible)."""
+    import numpy as np
+    world = len(bounds) - 1
+    model = tiles_per_row * TILE_COST + np.asarray(row_entries, dtype=np.float64) * ENTRY_COST
+    n = len(model)
+    cost = np.zeros(n, np.float64)
+    for r in range(world):
+        lo, hi = int(bounds[r]), int(bounds[r + 1])
+        if hi <= lo:
+            continue
+        m = model[lo:hi]
+        cost[lo:hi] = m * (float(band_ms[r]) / max(float(m.sum()), 1e-30))
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    out = [0]
+    for g in range(1, world):
+        target = cum[-1] * g / world
+        r = int(np.searchsorted(cum, target))
+        if r > 0 and abs(cum[r - 1] - target) <= abs(cum[min(r, n)] - target):
+            r -= 1
+        r = max(r, out[-1] + (1 if n - out[-1] > world - g else 0))
+        r = min(r, n - (world - g) if n >= world else n)
+        out.append(max(r, out[-1]))
+    out.append(n)
+    return out
+
+
 def gather_row_entries(band_grid: torch.Tensor, tiles_per_row: int, band_rows: int, total_rows: int, row_begin: int, group=None):
     """All-gather of the per-tile-row costs (row_cost_entries) of every rank's band -> float64 numpy [total_rows] on every rank."""
     num = row_cost_entries(band_grid.reshape(-1, 2)[:, 1].to(torch.int64), tiles_per_row) if band_rows else torch.zeros(0, dtype=torch.int64, device=band_grid.device)

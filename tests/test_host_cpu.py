@@ -681,3 +681,20 @@ def test_lighting_tick_mirror_equals_the_python_restatement(seed):
         carried = [i for _s, b in want for i in b]
         assert [int(r["worldPosition"][0]) for r in records[t]] == carried and all(int(r["worldPosition"][1]) == t for r in records[t])
     assert list(after) == d and [int(x) for x in fl] == f
+
+
+def test_bands_recut_on_measured_times_move_rows_from_the_slow_bands_to_the_fast_ones():
+    """sailor_amd.dist.rebalance_on_measured_times: a band measured slower than the rest gives rows away, one measured faster takes rows, equal times leave
+    the boundaries alone, and the conventions of balanced_tile_rows hold (non-decreasing, first 0, last = rows, no empty band while rows last)."""
+    from sailor_amd import dist as sdist
+    rows = np.full(135, 240 * 20.0)
+    rows[30:60] *= 3
+    b = sdist.balanced_tile_rows(rows, 240, 8)
+    same = sdist.rebalance_on_measured_times(b, [40.0] * 8, rows, 240)
+    assert max(abs(x - y) for x, y in zip(same, b)) <= 1, (b, same)
+    ms = [40, 44, 60, 47, 41, 41, 40, 30]
+    nb = sdist.rebalance_on_measured_times(b, ms, rows, 240)
+    assert nb[0] == 0 and nb[-1] == 135 and all(x < y for x, y in zip(nb, nb[1:]))
+    width = lambda bb, r: bb[r + 1] - bb[r]
+    assert width(nb, 2) < width(b, 2) and width(nb, 7) > width(b, 7)
+    assert sdist.rebalance_on_measured_times([0, 1, 2], [5.0, 1.0], np.ones(2), 8) == [0, 1, 2], "two rows, two bands: nothing to move"
