@@ -114,7 +114,7 @@ __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArg
     for (uint32_t base = blockIdx.x; base < items; base += (uint32_t)SPLIT_BLOCKS * 64u) {
         const uint32_t it = base + lane * (uint32_t)SPLIT_BLOCKS;
         const uint32_t num = it < items ? (uint32_t)A.order[it >> 2] : 0u;
-        unsigned long long todo = __ballot(num >= (uint32_t)SPLIT_MIN);
+        unsigned long long todo = __ballot(num >= (uint32_t)A.splitMin);
         while (todo != 0ull) {
             const uint32_t l = (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1ull;
@@ -339,9 +339,11 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
     A.fbRow0 = band->fbRowBegin;
     A.fbRows = band->fbRowCount;
     A.lightsNum = lightsNum;
+    static const int splitMinEnv = [] { const char* e = getenv("SAILOR_SPLIT_MIN"); return e ? atoi(e) : -1; }();
     A.order = reinterpret_cast<const uint8_t*>(dTileOrder); // (the band's list lengths as bytes: sailor_hip_light_cull_tile_order)
     const int bandTiles = (band->tileRowEnd - band->tileRowBegin) * A.Tx;
     if (bandTiles == 0) return SAILOR_HIP_OK;
+    A.splitMin = splitMinEnv > 0 ? splitMinEnv : (bandTiles <= SPLIT_SMALL_TILES ? SPLIT_MIN_SMALL : SPLIT_MIN_LARGE); // (SAILOR_SPLIT_MIN=<n>: A / B)
 
     CsmArgs C;
     memset(&C, 0, sizeof C);

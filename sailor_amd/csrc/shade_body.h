@@ -35,6 +35,7 @@ struct ShadeArgs {
     int fbRows;       // band.fbRowCount
     int bandTileRows; // band.tileRowEnd - band.tileRowBegin
     int lightsNum;
+    int splitMin;     // band form: a tile with at least this many lights goes to the split blocks (SPLIT_MIN_* by the band's size)
     const uint8_t* order;  // sailor_hip_light_cull_tile_order (the band's list lengths as bytes, one per tile) or null
 };
 
@@ -319,7 +320,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 //
 // BAND (split frames: sailor_hip_shade_ex on a sub-band with the cull's per-tile list lengths): a band of a split frame has too few
 // tiles to hide its longest one -- a tile in the middle of a light cluster (128 lights reaching all 256 pixels = 128 pair passes
-// per wave) kept its block busy for ~65 us while the rest of a 1/8 band took 25.  The tiles with >= SPLIT_MIN lights are taken by "split"
+// per wave) kept its block busy for ~65 us while the rest of a 1/8 band took 25.  The tiles with >= ShadeArgs::splitMin lights are taken by "split"
 // blocks, one per (tile, 8x8 quadrant): the block's four waves take every fourth list slot each over the SAME 64 pixels and add
 // their partial sums up through LDS (wave 0 + 1 + 2 + 3, a fixed order).  The grid is 1-D: SPLIT_BLOCKS split blocks first (split block b
 // looks at the (tile, quadrant) items b, b + SPLIT_BLOCKS, ... -- the lengths of up to 64 of them in one load, a ballot of the long ones --
@@ -405,7 +406,13 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
                    [lim] "s"((1u << (7 * PENDK)) - 1u), [qmax] "n"(QMAX), [lane] "v"(lane) \
                  : "v56", "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc", "memory")
 
-#define SPLIT_MIN 40      // a tile with at least this many lights goes to the split blocks
+// A tile with at least ShadeArgs::splitMin lights goes to the split blocks.  By the band's size (round 5, scripts/shade_prof*.py block timelines): a band IS
+// its longest block only while it is a few rounds of blocks -- an eighth of the 4K frame: every tile from 40 lights on is split four ways; on a larger band
+// the split blocks' extra work (four waves load the same 64 pixels; +20 % block-slot time over the tiles they take) and the slots they hold while the tile
+// blocks wait cost more than the tail they cut, and only the tiles that WOULD be the tail -- 96 lights and more: 16-42 us as one block -- are split.
+#define SPLIT_MIN_SMALL 40   // bands of up to SPLIT_SMALL_TILES tiles
+#define SPLIT_MIN_LARGE 96   // larger bands
+#define SPLIT_SMALL_TILES 6144
 #define SHADE_BAND_RESERVE 9000 // bytes of untouched dynamic LDS per block of k2_shade_band*: six blocks per CU instead of eight (see its launch)
 #ifndef SPLIT_BLOCKS
 #define SPLIT_BLOCKS 2048 // one round of resident blocks (8 per CU)
@@ -490,7 +497,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const float4 P1 = NT_LOAD4(surface[planeStride + pix]);
     const float4 P2 = NT_LOAD4(surface[2 * planeStride + pix]);
 #undef NT_LOAD4
-    if (ROLE == ROLE_BAND_TILE && g.num >= (uint32_t)SPLIT_MIN) return; // a tile of the split blocks
+    if (ROLE == ROLE_BAND_TILE && g.num >= (uint32_t)A.splitMin) return; // a tile of the split blocks
     const uint32_t listNum = g.num < (uint32_t)KEEP ? g.num : (uint32_t)KEEP;
     const unsigned long long haveMask = __ballot((uint32_t)tid < listNum); // (the masks where the compares are: a flag carried across a branch as a bool is a VGPR 0 / 1)
     const bool haveLight = __builtin_amdgcn_inverse_ballot_w64(haveMask);

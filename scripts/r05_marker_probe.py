@@ -1,5 +1,6 @@
 """Does a kernel's dispatch-packet reading include its predecessor's drain?  The C3 frame, eager, one stream:
   A: cull chain (no pack) -> shade          B: ... -> marker -> shade          C: ... -> k1_pack -> shade
+  D: ... -> a torch reduction over tileNum (130 KB read) -> shade           E: ... -> a torch reduction over the whole tile-list slot region (16.6 MB read) -> shade
 per-kernel direct readings and the event-bracketed time of the whole sequence (what really passes)."""
 import sys
 import numpy as np, torch
@@ -20,14 +21,23 @@ fp = ForwardPlus(ctx, W, H, N, prepared=prep)
 dd = torch.from_numpy(frame.depth).to(dev)
 ds = torch.from_numpy(frame.surface_rows(0, H)).to(dev)
 lib = ctx._lib
+base = fp.workspace.data_ptr()
+T = fp.band_tiles
+v_num = fp.workspace[fp.tile_num - base: fp.tile_num - base + 4 * T].view(torch.int32)
+v_lists = fp.workspace[fp.tile_lists - base: fp.tile_lists - base + 4 * 128 * T].view(torch.int32)
+sink = torch.zeros(1, dtype=torch.int64, device=dev)
 def seq(kind):
     fp.cull(cam.frame, dl, N, dd, defer_pack=True)
     if kind == "B":
         _lib.check(lib.sailor_hip_marker(ctx.handle), "marker", ctx.handle)
     if kind == "C":
         fp.pack()
+    if kind == "D":
+        sink.copy_(v_num.sum())
+    if kind == "E":
+        sink.copy_(v_lists.sum())
     fp.shade(cam.frame, ds, dl, N)
-for kind in "ABC":
+for kind in "ABCDE":
     names = ctx.launches_of(lambda: seq(kind))
     for _ in range(20):
         seq(kind)
