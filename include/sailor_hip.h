@@ -318,7 +318,8 @@ SAILOR_HIP_API int sailor_hip_light_cull_pack(SailorHipContext* ctx, int32_t wid
  * ambient term; with or without shadow maps) switches the BAND FORM of the launch on: the tiles with >= 40 lights go to "split" blocks -- one per (tile, 8x8
  * quadrant), four waves sharing the quadrant's list -- at the front of the grid, which find them in these bytes.  Lists and every tile with < 40 lights keep
  * their bits; a split tile's radiance differs from the one-block form by the order of four partial sums per pixel (within the shade tolerance).  With the
- * ambient term the pointer is ignored.  NULL for the whole-frame band (on the whole frame the split measured no gain) and on bad arguments.  Valid until
+ * ambient term the pointer is ignored.  NULL for the whole-frame band (on the whole frame the split measured no gain), for a band of more than 12 000
+ * tiles when lightsCapacity >= 131 072 (short lists, no long tiles to split: the whole frame's launch form pipelines better there) and on bad arguments.  Valid until
  * the next sailor_hip_light_cull on the same workspace.  `lightsCapacity` only has to be a light count the workspace can hold: the bytes' place in the
  * workspace depends on (width, height, band) alone.  (The return type is kept from round 2's word array; the data are bytes.) */
 SAILOR_HIP_API const uint32_t* sailor_hip_light_cull_tile_order(int32_t width, int32_t height, int32_t lightsCapacity, const SailorBand* band,

@@ -1558,18 +1558,25 @@ static bool band_valid(int W, int H, const SailorBand* b)
     return b->fbRowBegin == lo && b->fbRowCount == hi - lo;
 }
 
-// The BAND FORM of the shade (shade.hip: split blocks for the long tiles in front of the one-block-per-tile grid) is for the bands of a split frame of up
-// to BAND_FORM_MAX_TILES tiles; sailor_hip_light_cull_tile_order hands such a band's per-tile list lengths to the shade, which is what switches the form
-// on.  A larger band -- half the 4K frame (16 200 tiles), an eighth of the 8K frame (16 320) -- is eight rounds of resident blocks, bound by the
-// shade's throughput like the whole frame, and takes the whole frame's form: one block per tile on the XCD-aware grid, nothing in front of them
-// (measured, same box, step of the frame pipeline: half the 4K frame 109.0 against 109.6 us; an eighth of the 8K frame under a million lights 121 against
-// 133; a quarter of the 4K frame -- 8 100 tiles -- 75.9 against 68.9: the band form).  SAILOR_BAND_FORM_TILES=<n> overrides the limit (A / B).
+// The BAND FORM of the shade (shade.hip: split blocks for the long tiles in front of the one-block-per-tile grid) is what sailor_hip_light_cull_tile_order
+// switches on by handing a band's per-tile list lengths to the shade.  Every band of a split frame gets it -- the split threshold rises with the band's
+// size (shade_body.h: SPLIT_MIN_*) -- but a band of more than BAND_FORM_MAX_TILES tiles under a LARGE light set (from 131 072 lights on: an eighth of the
+// 8K frame under a million lights, 16 320 tiles): such a set means short lists and next to no long tiles (225 of 16 320 there), so there is no tail to cut,
+// and the band takes the whole frame's form -- one block per tile on the XCD-aware grid -- whose launch pipelines better beside the next frame's cull
+// (step 116.5 against 126.3 us, same box; the 4K frame's halves under 65 536 lights: 103.2 / 95.7 us in the band form, 108.0 / 91.9 in the other).
+// SAILOR_BAND_FORM_TILES=<n> overrides the limit (A / B; 0: never the band form).
 static int band_form_max_tiles()
 {
-    static const int v = [] { const char* e = getenv("SAILOR_BAND_FORM_TILES"); return e ? atoi(e) : BAND_FORM_MAX_TILES; }();
+    static const int v = [] { const char* e = getenv("SAILOR_BAND_FORM_TILES"); return e ? atoi(e) : -1; }();
     return v;
 }
-static bool layout_has_hint(const CullLayout& L) { return L.bandRows < L.Ty && L.bandTiles > 0 && L.bandTiles <= band_form_max_tiles(); }
+static bool layout_has_hint(const CullLayout& L, const int lightsCapacity)
+{
+    if (L.bandRows >= L.Ty || L.bandTiles <= 0) return false;
+    const int limit = band_form_max_tiles();
+    if (limit >= 0) return L.bandTiles <= limit;
+    return L.bandTiles <= BAND_FORM_MAX_TILES || lightsCapacity < 131072;
+}
 
 static int launch_pack(SailorHipContext* ctx, const CullLayout& L, char* ws, SailorLightsGrid* dLightsGrid, uint32_t* dCulledLights, size_t culledCapacity)
 {
@@ -1831,7 +1838,7 @@ const uint32_t* sailor_hip_light_cull_tile_order(int32_t width, int32_t height, 
     if (!band) { sailor_hip_band_whole_frame(width, height, &whole); band = &whole; }
     if (!band_valid(width, height, band)) return nullptr;
     const CullLayout L = make_layout(width, height, lightsCapacity, *band);
-    if (!layout_has_hint(L)) return nullptr; // whole frame: the one-block-per-tile form in raster order
+    if (!layout_has_hint(L, lightsCapacity)) return nullptr; // whole frame: the one-block-per-tile form in raster order
     // (the band's list lengths as bytes, one per tile in tile order -- every cull writes them: the band shade's split blocks find the long tiles there)
     return (const uint32_t*)((const char*)dWorkspace + L.offTileNum8);
 }

@@ -406,13 +406,14 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
                    [lim] "s"((1u << (7 * PENDK)) - 1u), [qmax] "n"(QMAX), [lane] "v"(lane) \
                  : "v56", "v57", "v58", "v59", "v60", "v61", "v62", "vcc", "scc", "memory")
 
-// A tile with at least ShadeArgs::splitMin lights goes to the split blocks.  By the band's size (round 5, scripts/shade_prof*.py block timelines): a band IS
-// its longest block only while it is a few rounds of blocks -- an eighth of the 4K frame: every tile from 40 lights on is split four ways; on a larger band
-// the split blocks' extra work (four waves load the same 64 pixels; +20 % block-slot time over the tiles they take) and the slots they hold while the tile
-// blocks wait cost more than the tail they cut, and only the tiles that WOULD be the tail -- 96 lights and more: 16-42 us as one block -- are split.
-#define SPLIT_MIN_SMALL 40   // bands of up to SPLIT_SMALL_TILES tiles
+// A tile with at least ShadeArgs::splitMin lights goes to the split blocks.  By the band's size (round 5; profiles/r05/README.md: block timelines and the step
+// of the frame pipeline, same box): a band IS its longest block only while it is a few rounds of blocks; on a larger band the split blocks' extra work (four
+// waves load the same 64 pixels: +20 % block-slot time over the tiles they take) and the slots they hold while the tile blocks wait cost more than the tail
+// they cut, and only the tiles that WOULD be the tail -- 96 lights and more: 16-42 us as one block -- are split.  Step of an eighth / a quarter / the lower
+// half of the 4K frame at thresholds 40 / 64 / 96 / 128: 53.3 / 48.6 / 50.9 / 54.4, 71.9 / 68.4 / 68.8 / 70.6, 110.4 / 105.8 / 103.2 / 103.9 us.
+#define SPLIT_MIN_SMALL 64   // bands of up to SPLIT_SMALL_TILES tiles (round 4: 40 everywhere)
 #define SPLIT_MIN_LARGE 96   // larger bands
-#define SPLIT_SMALL_TILES 6144
+#define SPLIT_SMALL_TILES 12000
 #define SHADE_BAND_RESERVE 9000 // bytes of untouched dynamic LDS per block of k2_shade_band*: six blocks per CU instead of eight (see its launch)
 #ifndef SPLIT_BLOCKS
 #define SPLIT_BLOCKS 2048 // one round of resident blocks (8 per CU)
