@@ -42,6 +42,12 @@ __device__ __forceinline__ void sprof_mark(const int i)
     if (threadIdx.x == 0 && blockIdx.x < 65536) { g_shadeProf[blockIdx.x][i] = t; if (i == 0) g_shadeProf[blockIdx.x][2] = h; }
 }
 #define SPROF_T(i) sprof_mark(i);
+// (per WAVE as well: [w] = start, [4 + w] = end, [8 + w] = XCD << 32 | HW_ID of wave w -- scripts/shade_wave_prof.py: how long a finished wave's slot stays empty)
+__device__ unsigned long long g_shadeWaveProf[65536][12];
+extern "C" __attribute__((visibility("default"))) int sailor_hip_debug_read_shade_wave_prof(void* dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_shadeWaveProf), bytes);
+}
 template <bool ON> __device__ __forceinline__ void sprof_mark_grid(const int i)   // (the per-tile grid's kernels: by linear block index)
 {
     if constexpr (ON) {
@@ -49,6 +55,11 @@ template <bool ON> __device__ __forceinline__ void sprof_mark_grid(const int i) 
         const unsigned long long h = ((unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
         const uint32_t id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         if (threadIdx.x == 0 && id < 65536u) { g_shadeProf[id][i] = t; if (i == 0) g_shadeProf[id][2] = h; }
+        if ((threadIdx.x & 63u) == 0u && id < 65536u) {
+            const uint32_t w = threadIdx.x >> 6;
+            g_shadeWaveProf[id][(i == 0 ? 0u : 4u) + w] = t;
+            if (i == 0) g_shadeWaveProf[id][8u + w] = h;
+        }
     }
 }
 #define SPROF_TG(i, ON) sprof_mark_grid<(ON)>(i);
@@ -70,6 +81,9 @@ template <bool ON> __device__ __forceinline__ void sprof_mark_grid(const int i) 
         SPROF_TG(3, !(IBL))                                                                                                               \
     }
 #define FORCE_64_VGPRS __attribute__((amdgpu_waves_per_eu(8, 8)))
+#ifndef SHADE_QUAD_DEFAULT
+#define SHADE_QUAD_DEFAULT false // (the single-wave form of the plain shade: see shade_impl)
+#endif
 // (the K3 kernels: 64 registers like the others since the shadow look-ups run before the view / material terms -- "K3 first" in shade_body.h; it
 // was 80 = six waves per SIMD.  The pin matters: unpinned, the prepared twins come out at 116-134.)
 #define CSM_PIN __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -85,6 +99,18 @@ SHADE_ENTRIES(, false, false)
 SHADE_ENTRIES(_p, true, false)
 SHADE_ENTRIES(_t, false, true)
 SHADE_ENTRIES(_pt, true, true)
+
+// The single-wave form (ROLE_QUAD, shade_body.h): one 64-thread block per (tile, 8x8 quadrant), prepared lights, no shadow maps, no ambient term
+#define SHADE_QUAD_ENTRY(NAME, TL)                                                                                                                \
+    __global__ __launch_bounds__(64) FORCE_64_VGPRS void NAME(ShadeArgs A, const float4* __restrict__ surface, size_t planeStride,                \
+                                                              const SailorLightShaderData* __restrict__ lights, const SailorLightsGrid* __restrict__ grid, \
+                                                              const uint32_t* __restrict__ culled, float4* __restrict__ radiance)                \
+    {                                                                                                                                              \
+        __shared__ ShadeLdsQ lds;                                                                                                                  \
+        k2_shade_body<false, false, ROLE_QUAD, true, TL, ShadeLdsQ>(lds, A, CsmArgs(), IblArgs(), surface, planeStride, lights, grid, culled, radiance); \
+    }
+SHADE_QUAD_ENTRY(k2_shade_q_p, false)
+SHADE_QUAD_ENTRY(k2_shade_q_pt, true)
 
 template <bool PREP, bool TL, bool CSM>
 __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, int bandTiles, const float4* __restrict__ surface, size_t planeStride,
@@ -408,7 +434,16 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
         if (hasCsm) LAUNCH_BAND(k2_shade_band_csm);
         else LAUNCH_BAND(k2_shade_band);
 #undef LAUNCH_BAND
-    } else LAUNCH_SHADE(k2_shade);
+    } else {
+        // the single-wave form for the plain shade over prepared lights (SAILOR_SHADE_QUAD=0 / 1 overrides)
+        static const int quadEnv = [] { const char* e = getenv("SAILOR_SHADE_QUAD"); return e ? atoi(e) : -1; }();
+        const bool quadForm = dPreparedLights && lightsNum < (1 << 28) && (quadEnv >= 0 ? quadEnv != 0 : SHADE_QUAD_DEFAULT);
+        if (quadForm) {
+            const dim3 qgrid(grid.x, 4u * grid.y, grid.z);
+            if (dTileNum) { kname = "k2_shade_q_pt"; sailor_launch_lds(ctx, k2_shade_q_pt, qgrid, dim3(64), bandLds / 4u, A, S, surfacePlaneStride, L, G, dCulledLights, Rd); }
+            else { kname = "k2_shade_q_p"; sailor_launch_lds(ctx, k2_shade_q_p, qgrid, dim3(64), bandLds / 4u, A, S, surfacePlaneStride, L, G, dCulledLights, Rd); }
+        } else LAUNCH_SHADE(k2_shade);
+    }
 #undef LAUNCH_SHADE
     SAILOR_CHECK_LAUNCH(ctx, kname);
     return SAILOR_HIP_OK;
