@@ -538,7 +538,12 @@ __device__ __forceinline__ void k2_shade_body(LDS& lds, const ShadeArgs& A, cons
         hiPossible = badLo == 0ull && listNum > 64u;
         const float4* L = reinterpret_cast<const float4*>(lights);
         const uint32_t iLo = (uint32_t)tid < numLightsQ ? index : 0u; // (lanes past the list read light 0 and are masked out)
-        if (numLightsQ > 0u) { qc0 = L[(size_t)iLo * LREC + 0]; qc1 = L[(size_t)iLo * LREC + 1]; }
+        // (a list of up to 64 lights -- 99 % of the 4K frame's tiles: the whole record now, and the lanes whose light passes the quadrant's test put it
+        // into LDS themselves, no second round trip; a longer list: the two float4 the test reads, the records of what passes gathered afterwards)
+        if (numLightsQ > 0u) {
+            qc0 = L[(size_t)iLo * LREC + 0]; qc1 = L[(size_t)iLo * LREC + 1];
+            if (!hiPossible) { q2 = L[(size_t)iLo * LREC + 2]; q3 = L[(size_t)iLo * LREC + 3]; q4 = L[(size_t)iLo * LREC + 4]; }
+        }
     } else if (staged) {
         if constexpr (PREPARED) {
             const float4* L = reinterpret_cast<const float4*>(lights) + (size_t)index * LREC;
@@ -585,7 +590,7 @@ __device__ __forceinline__ void k2_shade_body(LDS& lds, const ShadeArgs& A, cons
         g1Lo = cosLo * rcp_fast(fmaf(cosLo, oneMinusK, k)); // GeometrySchlickG1(cosLo, k)
     };
     constexpr bool K3_FIRST = HAS_CSM && !HAS_IBL; // (the ambient term keeps the view and material terms live to the very end: with them the K3 + IBL kernels need 91 registers one way, 136 the other)
-    if constexpr (!K3_FIRST) view_and_material(A.camX, A.camY, A.camZ, 1.0f);
+    if constexpr (!K3_FIRST && !QUAD) view_and_material(A.camX, A.camY, A.camZ, 1.0f); // (QUAD: behind the quadrant's test, when the records' registers are free)
     uint32_t numLights = numLightsQ;
     if constexpr (!QUAD) {
         {
@@ -679,10 +684,18 @@ __device__ __forceinline__ void k2_shade_body(LDS& lds, const ShadeArgs& A, cons
             const unsigned long long sv = (seg[h] | seg[2 + h]) | (seg[4 + h] | seg[6 + h]);
             const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
             const uint32_t code = ((seg[h] >> lane) & 1ull) ? 0u : (((seg[2 + h] >> lane) & 1ull) ? 1u : (((seg[4 + h] >> lane) & 1ull) ? 2u : 3u));
-            if ((sv >> lane) & 1ull) sEnd[survTotal + (uint32_t)__popcll(sv & lt)] = index | (code << 28);
+            const uint32_t r = survTotal + (uint32_t)__popcll(sv & lt);
+            if ((sv >> lane) & 1ull) {
+                sEnd[r] = index | (code << 28);
+                if (!hiPossible && r < (uint32_t)QUAD_CHUNK) { // (h == 0, the whole list: the first chunk's records straight from the registers)
+                    float4* o = sL + r * LREC;
+                    o[0] = qc0; o[1] = qc1; o[2] = q2; o[3] = q3; o[4] = q4;
+                }
+            }
             survTotal += (uint32_t)__popcll(sv);
         }
     }
+    if constexpr (QUAD) view_and_material(A.camX, A.camY, A.camZ, 1.0f);
 
     if (BAND && splitRole) { // this wave's share of the list: every fourth slot
         const unsigned long long share = 0x1111111111111111ull << __builtin_amdgcn_readfirstlane(wave); // (scalar: the masks stay in SGPRs)
@@ -774,10 +787,12 @@ __device__ __forceinline__ void k2_shade_body(LDS& lds, const ShadeArgs& A, cons
         // budget spills five of them)
         uint32_t ln = (uint32_t)lane;
         asm volatile("" : "+v"(ln));
+        if (hiPossible || chunkBase != 0u) { // (else: the lanes have put the chunk's records there themselves)
 #pragma unroll
         for (int it = 0; it < 3; it++) { // 5 float4 per light, one lane per float4
             const uint32_t item = (uint32_t)(it * 64) + ln, c = (item * 205u) >> 10, part = item - 5u * c; // (item / 5 for item < 1024)
             if (c < n) sL[item] = L[(size_t)(sEnd[chunkBase + c] & 0x0FFFFFFFu) * LREC + part];
+        }
         }
         const uint32_t kc = ln < n ? (sEnd[chunkBase + ln] >> 28) : 7u;
         seg[0] = __ballot(kc == 0u); seg[2] = __ballot(kc == 1u); seg[4] = __ballot(kc == 2u); seg[6] = __ballot(kc == 3u);
