@@ -30,7 +30,8 @@
 
 // make EXTRA=-DSHADE_PROF + scripts/shade_prof.py: start / end of every block of the band kernel on the 100 MHz constant clock, its XCD and hardware id
 #ifdef SHADE_PROF
-__device__ unsigned long long g_shadeProf[65536][4];
+#define SPROF_BLOCKS 262144
+__device__ unsigned long long g_shadeProf[SPROF_BLOCKS][4];
 extern "C" __attribute__((visibility("default"))) int sailor_hip_debug_read_shade_prof(void* dst, size_t bytes)
 {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_shadeProf), bytes);
@@ -39,7 +40,7 @@ __device__ __forceinline__ void sprof_mark(const int i)
 {
     const unsigned long long t = __builtin_amdgcn_s_memrealtime();
     const unsigned long long h = ((unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-    if (threadIdx.x == 0 && blockIdx.x < 65536) { g_shadeProf[blockIdx.x][i] = t; if (i == 0) g_shadeProf[blockIdx.x][2] = h; }
+    if (threadIdx.x == 0 && blockIdx.x < SPROF_BLOCKS) { g_shadeProf[blockIdx.x][i] = t; if (i == 0) g_shadeProf[blockIdx.x][2] = h; }
 }
 #define SPROF_T(i) sprof_mark(i);
 // (per WAVE as well: [w] = start, [4 + w] = end, [8 + w] = XCD << 32 | HW_ID of wave w -- scripts/shade_wave_prof.py: how long a finished wave's slot stays empty)
@@ -54,7 +55,7 @@ template <bool ON> __device__ __forceinline__ void sprof_mark_grid(const int i) 
         const unsigned long long t = __builtin_amdgcn_s_memrealtime();
         const unsigned long long h = ((unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
         const uint32_t id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if (threadIdx.x == 0 && id < 65536u) { g_shadeProf[id][i] = t; if (i == 0) g_shadeProf[id][2] = h; }
+        if (threadIdx.x == 0 && id < (uint32_t)SPROF_BLOCKS) { g_shadeProf[id][i] = t; if (i == 0) g_shadeProf[id][2] = h; }
         if ((threadIdx.x & 63u) == 0u && id < 65536u) {
             const uint32_t w = threadIdx.x >> 6;
             g_shadeWaveProf[id][(i == 0 ? 0u : 4u) + w] = t;
@@ -107,7 +108,9 @@ SHADE_ENTRIES(_pt, true, true)
                                                               const uint32_t* __restrict__ culled, float4* __restrict__ radiance)                \
     {                                                                                                                                              \
         __shared__ ShadeLdsQ lds;                                                                                                                  \
+        SPROF_TG(0, true)                                                                                                                          \
         k2_shade_body<false, false, ROLE_QUAD, true, TL, ShadeLdsQ>(lds, A, CsmArgs(), IblArgs(), surface, planeStride, lights, grid, culled, radiance); \
+        SPROF_TG(3, true)                                                                                                                          \
     }
 SHADE_QUAD_ENTRY(k2_shade_q_p, false)
 SHADE_QUAD_ENTRY(k2_shade_q_pt, true)

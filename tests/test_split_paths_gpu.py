@@ -68,7 +68,7 @@ def test_c5_band_of_an_eight_way_split_runs_the_selection_chain_and_gives_the_or
     # (i) static lights: the prepared views exist, the chain reads them
     prep = PreparedLights(ctx, lights, N)
     fp = ForwardPlus(ctx, W, H, N, band=band, prepared=prep)
-    assert fp.tile_order, "a band: the hint's kernels"
+    assert not fp.tile_order, "16 320 tiles under a million lights: short lists, no long tiles to split -- the band takes the whole frame's launch form"
     names = ctx.launches_of(lambda: fp.cull(f.cam.frame, lights, N, d))
     assert names == SELECT_CHAIN_WIDE, names
     M, lm = fp.band_selection(N)
@@ -104,7 +104,10 @@ def test_c5_band_of_an_eight_way_split_runs_the_selection_chain_and_gives_the_or
     untouched = (st[:N].view(np.uint32).reshape(N, -1) == 0x5A5A5A5A).all(axis=1)
     assert untouched.mean() > 0.5 and not untouched[lm].any(), "the staged records of the selected lights, and of those only"
     surface = synth.make_surface(f.cam, f.depth, row_begin=rows.start, row_end=rows.stop)
-    rad = fp3.shade(f.cam.frame, torch.from_numpy(surface).to(ctx.device), lights, N).cpu().numpy()
+    ds = torch.from_numpy(surface).to(ctx.device)
+    names = ctx.launches_of(lambda: fp3.shade(f.cam.frame, ds, lights, N))
+    assert len(names) == 1 and names[0].startswith("k2_shade") and "band" not in names[0] and names[0].endswith("_pt"), names
+    rad = fp3.radiance.cpu().numpy()
     assert np.isfinite(rad).all()
     planes = np.zeros((3, H, W, 4), np.float32)   # (the oracle addresses rows of full-frame planes; untouched pages stay virtual)
     planes[:, rows] = surface
