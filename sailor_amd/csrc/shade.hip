@@ -82,9 +82,6 @@ template <bool ON> __device__ __forceinline__ void sprof_mark_grid(const int i) 
         SPROF_TG(3, !(IBL))                                                                                                               \
     }
 #define FORCE_64_VGPRS __attribute__((amdgpu_waves_per_eu(8, 8)))
-#ifndef SHADE_QUAD_DEFAULT
-#define SHADE_QUAD_DEFAULT false // (the single-wave form of the plain shade: see shade_impl)
-#endif
 // (the K3 kernels: 64 registers like the others since the shadow look-ups run before the view / material terms -- "K3 first" in shade_body.h; it
 // was 80 = six waves per SIMD.  The pin matters: unpinned, the prepared twins come out at 116-134.)
 #define CSM_PIN __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -100,20 +97,6 @@ SHADE_ENTRIES(, false, false)
 SHADE_ENTRIES(_p, true, false)
 SHADE_ENTRIES(_t, false, true)
 SHADE_ENTRIES(_pt, true, true)
-
-// The single-wave form (ROLE_QUAD, shade_body.h): one 64-thread block per (tile, 8x8 quadrant), prepared lights, no shadow maps, no ambient term
-#define SHADE_QUAD_ENTRY(NAME, TL)                                                                                                                \
-    __global__ __launch_bounds__(64) FORCE_64_VGPRS void NAME(ShadeArgs A, const float4* __restrict__ surface, size_t planeStride,                \
-                                                              const SailorLightShaderData* __restrict__ lights, const SailorLightsGrid* __restrict__ grid, \
-                                                              const uint32_t* __restrict__ culled, float4* __restrict__ radiance)                \
-    {                                                                                                                                              \
-        __shared__ ShadeLdsQ lds;                                                                                                                  \
-        SPROF_TG(0, true)                                                                                                                          \
-        k2_shade_body<false, false, ROLE_QUAD, true, TL, ShadeLdsQ>(lds, A, CsmArgs(), IblArgs(), surface, planeStride, lights, grid, culled, radiance); \
-        SPROF_TG(3, true)                                                                                                                          \
-    }
-SHADE_QUAD_ENTRY(k2_shade_q_p, false)
-SHADE_QUAD_ENTRY(k2_shade_q_pt, true)
 
 template <bool PREP, bool TL, bool CSM>
 __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, int bandTiles, const float4* __restrict__ surface, size_t planeStride,
@@ -437,16 +420,7 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
         if (hasCsm) LAUNCH_BAND(k2_shade_band_csm);
         else LAUNCH_BAND(k2_shade_band);
 #undef LAUNCH_BAND
-    } else {
-        // the single-wave form for the plain shade over prepared lights (SAILOR_SHADE_QUAD=0 / 1 overrides)
-        static const int quadEnv = [] { const char* e = getenv("SAILOR_SHADE_QUAD"); return e ? atoi(e) : -1; }();
-        const bool quadForm = dPreparedLights && lightsNum < (1 << 28) && (quadEnv >= 0 ? quadEnv != 0 : SHADE_QUAD_DEFAULT);
-        if (quadForm) {
-            const dim3 qgrid(grid.x, 4u * grid.y, grid.z);
-            if (dTileNum) { kname = "k2_shade_q_pt"; sailor_launch_lds(ctx, k2_shade_q_pt, qgrid, dim3(64), bandLds / 4u, A, S, surfacePlaneStride, L, G, dCulledLights, Rd); }
-            else { kname = "k2_shade_q_p"; sailor_launch_lds(ctx, k2_shade_q_p, qgrid, dim3(64), bandLds / 4u, A, S, surfacePlaneStride, L, G, dCulledLights, Rd); }
-        } else LAUNCH_SHADE(k2_shade);
-    }
+    } else LAUNCH_SHADE(k2_shade);
 #undef LAUNCH_SHADE
     SAILOR_CHECK_LAUNCH(ctx, kname);
     return SAILOR_HIP_OK;

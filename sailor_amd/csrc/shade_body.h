@@ -428,29 +428,21 @@ struct ShadeLds {
 #define ROLE_TILE 0       // one block per tile, grid (tiles per row, tile rows)
 #define ROLE_BAND_TILE 1  // the same inside k2_shade_band: returns at once on a tile of the split blocks
 #define ROLE_BAND_SPLIT 2 // one block per (long tile, quadrant)
-#define ROLE_QUAD 3       // one WAVE per block (round 5): a 64-thread block shades one 8x8 quadrant on its own -- see "QUAD" in k2_shade_body
-#define QUAD_CHUNK 32     // ... staging the records of up to this many lights that may reach the quadrant at a time
-struct ShadeLdsQ {        // 4 864 bytes: 32 single-wave blocks per CU
-    float4 sL[QUAD_CHUNK * LREC];
-    float sRes[3 * QMAX];
-    uint16_t sQ[QMAX];
-    uint32_t sEnd[KEEP];       // (here: the lights that may reach the quadrant, in list order: light index | kind code << 28)
-};
 // PREPARED: `lights` points at the staged records sailor_hip_prepare_lights wrote (LREC float4 per light, indexed like the `light` SSBO) instead of
 // at the SSBO itself: a list slot is then five 16-byte loads and five LDS stores -- no arithmetic on the path the block's other waves wait for.
 // TILE_LISTS: `grid` / `culled` are not the reference's lightsGrid / culledLights but the cull's own per-tile form (sailor_hip_light_cull_tile_lists):
 // `grid` points at tileNum (uint32 per band tile), the list of band tile t is culled[128 t ..] -- the same entries in the same order, available as
 // soon as k1_tile_cull has run (k1_pack is then off the frame's critical path).  A template parameter, not a run-time switch: as a kernel-argument
 // branch it cost every wave 12 scalar + 4 vector instructions (SQ counters, round 4).
-// QUAD (round 5; scripts/shade_wave_prof.py): a 256-thread block's four waves sit one on each SIMD of a CU, so a new block needs a free wave slot on ALL
-// four -- and its LDS -- at once: on the 4K frame a finished wave's slot then stays empty for 1.5 us of a 6.8 us wave life (7.3 of 8 blocks alive per CU,
-// their waves busy 89 % of the block's life: 26 of 32 wave slots used).  A single-wave block needs one slot, has nobody to wait for at a barrier and
-// nobody's slowest quadrant to sit out.  What the four waves of a tile shared was the staging of the tile's light records; here every wave reads the
-// list and the first two float4 of each record itself (L2 hits), runs the quadrant's sphere / cone test from registers, and stages only the records of
-// the lights that pass -- 12 of 23 on the 4K frame -- QUAD_CHUNK at a time, into 2.5 KB of LDS of its own.  Same tests, same queue, same pair pass;
-// the pairs of a pixel are added up chunk by chunk (a different order of the same non-negative terms from a tile's 33rd surviving light on).
-template <bool HAS_CSM, bool HAS_IBL, int ROLE = ROLE_TILE, bool PREPARED = false, bool TILE_LISTS = false, typename LDS = ShadeLds>
-__device__ __forceinline__ void k2_shade_body(LDS& lds, const ShadeArgs& A, const CsmArgs& C, const IblArgs& I, const float4* __restrict__ surface, size_t planeStride,
+// (Round 5, measured and taken out again -- scripts/shade_wave_prof.py, profiles/r05/shade_waves_*.txt: a 256-thread block's four waves sit one on each
+// SIMD of a CU, so a new block needs a free wave slot on ALL four at once; on the 4K frame a finished wave's slot then stays empty for 1.5 us of a 6.8 us
+// wave life -- 7.3 of 8 blocks alive per CU, their waves busy 89 % of the block's life: 26 of 32 wave slots in use.  A form with ONE wave per block -- a
+// 64-thread block per 8x8 quadrant that reads the list itself, tests it from registers and stages only the records that pass, 32 at a time, into 2.5 KB
+// of LDS of its own: no barrier, nobody's slowest quadrant to sit out -- fills 90 % of the slots (the gap shrinks to 0.8 us) but every wave then does the
+// list's loads and the compaction itself: wave life 7.44 us, kernel 140 against 135 us, and the frame pipeline's step 176 against 166 us because the next
+// frame's cull blocks no longer find four free slots beside it.  Oracle parity was green; profiles/r05/ab_quad_form.txt.)
+template <bool HAS_CSM, bool HAS_IBL, int ROLE = ROLE_TILE, bool PREPARED = false, bool TILE_LISTS = false>
+__device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, const IblArgs& I, const float4* __restrict__ surface, size_t planeStride,
                                                  const SailorLightShaderData* __restrict__ lights,
                                                  const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled,
                                                  float4* __restrict__ radiance, int selTx = 0, int selTy = 0, int selQuad = 0)
@@ -459,9 +451,7 @@ __device__ __forceinline__ void k2_shade_body(LDS& lds, const ShadeArgs& A, cons
     float* const sRes = lds.sRes;
     uint16_t* const sQ = lds.sQ;
     uint32_t* const sEnd = lds.sEnd;
-    constexpr bool QUAD = ROLE == ROLE_QUAD;
-    static_assert(!QUAD || (PREPARED && !HAS_CSM && !HAS_IBL), "the single-wave form exists for the plain shade over prepared lights");
-    constexpr bool BAND = ROLE == ROLE_BAND_TILE || ROLE == ROLE_BAND_SPLIT;
+    constexpr bool BAND = ROLE != ROLE_TILE;
     constexpr bool splitRole = ROLE == ROLE_BAND_SPLIT;
     int tid = threadIdx.x;
     // (the band kernel holds two copies of this body at 64 registers each, and the thread id -- live from the entry through both -- is what the
@@ -483,12 +473,10 @@ __device__ __forceinline__ void k2_shade_body(LDS& lds, const ShadeArgs& A, cons
     // vertically adjacent tiles meet in one L2 -- k2_shade_csm_p 234 -> 225 us on C4; the plain kernel, which has no texels to share, pays 4.6 %
     // for that: the light cluster's columns land on three of the eight XCDs.)
     constexpr unsigned rot = HAS_CSM ? 0u : 1u;
-    // (QUAD: grid (8 x tiles per piece, 4 x pieces, tile rows) -- blockIdx.y = 4 piece + quadrant: a tile's four quadrant blocks on one XCD)
-    const unsigned piece = QUAD ? (blockIdx.y >> 2) : blockIdx.y;
-    int btx = ((int)((blockIdx.x - (unsigned)bty * rot) & 7u) + 8 * (int)piece) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-    if ((ROLE == ROLE_TILE || QUAD) && btx >= A.Tx) return;
-    const int lane = tid & 63, wave = QUAD ? 0 : (tid >> 6);
-    int quad = QUAD ? (int)(blockIdx.y & 3u) : wave;
+    int btx = ((int)((blockIdx.x - (unsigned)bty * rot) & 7u) + 8 * (int)blockIdx.y) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (ROLE == ROLE_TILE && btx >= A.Tx) return;
+    const int lane = tid & 63, wave = tid >> 6;
+    int quad = wave;
     if (BAND) { btx = selTx; bty = selTy; if (splitRole) quad = selQuad; }
     const int tx = btx, ty = A.tileRow0 + bty;
     const int bandTile = bty * A.Tx + btx;
@@ -527,24 +515,7 @@ __device__ __forceinline__ void k2_shade_body(LDS& lds, const ShadeArgs& A, cons
     const unsigned long long stagedMask = __ballot(index < (uint32_t)A.lightsNum); // (a lane without a list slot holds uint(-1))
     const bool staged = __builtin_amdgcn_inverse_ballot_w64(stagedMask);
     float4 q0, q1, q2, q3, q4, q5, q6;
-    // QUAD: the wave's own view of the whole list -- slots 0..63 (index) and 64..127 (indexHi) -- and, per slot, the first two float4 of the light's
-    // staged record straight from global memory into the lane that tests it
-    uint32_t numLightsQ = 0u;
-    bool hiPossible = false; // (QUAD: the list goes on behind slot 63 -- 1 % of the 4K frame's tiles; that half is fetched when its turn comes)
-    float4 qc0, qc1;
-    if constexpr (QUAD) {
-        const unsigned long long badLo = haveMask & ~stagedMask;
-        numLightsQ = badLo ? (uint32_t)__builtin_ctzll(badLo) : min(listNum, 64u);
-        hiPossible = badLo == 0ull && listNum > 64u;
-        const float4* L = reinterpret_cast<const float4*>(lights);
-        const uint32_t iLo = (uint32_t)tid < numLightsQ ? index : 0u; // (lanes past the list read light 0 and are masked out)
-        // (a list of up to 64 lights -- 99 % of the 4K frame's tiles: the whole record now, and the lanes whose light passes the quadrant's test put it
-        // into LDS themselves, no second round trip; a longer list: the two float4 the test reads, the records of what passes gathered afterwards)
-        if (numLightsQ > 0u) {
-            qc0 = L[(size_t)iLo * LREC + 0]; qc1 = L[(size_t)iLo * LREC + 1];
-            if (!hiPossible) { q2 = L[(size_t)iLo * LREC + 2]; q3 = L[(size_t)iLo * LREC + 3]; q4 = L[(size_t)iLo * LREC + 4]; }
-        }
-    } else if (staged) {
+    if (staged) {
         if constexpr (PREPARED) {
             const float4* L = reinterpret_cast<const float4*>(lights) + (size_t)index * LREC;
             q0 = L[0]; q1 = L[1]; q2 = L[2]; q3 = L[3]; q4 = L[4];
@@ -590,26 +561,23 @@ __device__ __forceinline__ void k2_shade_body(LDS& lds, const ShadeArgs& A, cons
         g1Lo = cosLo * rcp_fast(fmaf(cosLo, oneMinusK, k)); // GeometrySchlickG1(cosLo, k)
     };
     constexpr bool K3_FIRST = HAS_CSM && !HAS_IBL; // (the ambient term keeps the view and material terms live to the very end: with them the K3 + IBL kernels need 91 registers one way, 136 the other)
-    if constexpr (!K3_FIRST && !QUAD) view_and_material(A.camX, A.camY, A.camZ, 1.0f); // (QUAD: behind the quadrant's test, when the records' registers are free)
-    uint32_t numLights = numLightsQ;
-    if constexpr (!QUAD) {
-        {
-            const unsigned long long bad = haveMask & ~stagedMask;
-            if (lane == 0) sEnd[wave] = bad ? (uint32_t)(wave * 64 + __builtin_ctzll(bad)) : 0xFFFFFFFFu;
-        }
-        if (staged) {
-            // (staging is the block's critical path -- the other three waves wait at the barrier for the first; with PREPARED records it is a copy)
-            float4* o = sL + tid * LREC;
-            if constexpr (PREPARED) { o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3; o[4] = q4; }
-            else {
-                float4 o0, o1, o2, o3, o4;
-                stage_light_record(q0, q1, q2, q3, q4, q5, q6, o0, o1, o2, o3, o4);
-                o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3; o[4] = o4;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the records are in LDS (global loads may stay in flight)
-        numLights = min(min(listNum, sEnd[0]), min(sEnd[1], min(sEnd[2], sEnd[3])));
+    if constexpr (!K3_FIRST) view_and_material(A.camX, A.camY, A.camZ, 1.0f);
+    {
+        const unsigned long long bad = haveMask & ~stagedMask;
+        if (lane == 0) sEnd[wave] = bad ? (uint32_t)(wave * 64 + __builtin_ctzll(bad)) : 0xFFFFFFFFu;
     }
+    if (staged) {
+        // (staging is the block's critical path -- the other three waves wait at the barrier for the first; with PREPARED records it is a copy)
+        float4* o = sL + tid * LREC;
+        if constexpr (PREPARED) { o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3; o[4] = q4; }
+        else {
+            float4 o0, o1, o2, o3, o4;
+            stage_light_record(q0, q1, q2, q3, q4, q5, q6, o0, o1, o2, o3, o4);
+            o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3; o[4] = o4;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the records are in LDS (global loads may stay in flight)
+    const uint32_t numLights = min(min(listNum, sEnd[0]), min(sEnd[1], min(sEnd[2], sEnd[3])));
     const float alpha = roughness * roughness, alphaSq = alpha * alpha;
 
     // ---- which lights can reach this quadrant at all?  One LANE per LIGHT against the bounding SPHERE of the quadrant's 64 surface
@@ -631,31 +599,15 @@ __device__ __forceinline__ void k2_shade_body(LDS& lds, const ShadeArgs& A, cons
     // survivors by kind: [0,1] finite point lights, [2,3] finite spot lights, [4,5] the rest (directional, unknown type,
     // non-finite intensity: every pixel is a pair) -- for list slots 0..63 and 64..127
     unsigned long long seg[8] = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull }; // [6,7]: directional lights (type 0), see the loop behind the queue
-    uint32_t survTotal = 0u; // (QUAD: how many of the list's lights pass)
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        if constexpr (QUAD) {
-            if (h == 1) { // the list's second half: its indices and records now (rare)
-                if (!hiPossible) break;
-                const unsigned long long haveHi = __ballot((uint32_t)tid + 64u < listNum);
-                index = 0xFFFFFFFFu;
-                if (__builtin_amdgcn_inverse_ballot_w64(haveHi)) index = culled[g.offset + 64u + (uint32_t)tid];
-                const unsigned long long badHi = haveHi & ~__ballot(index < (uint32_t)A.lightsNum);
-                numLights = badHi ? 64u + (uint32_t)__builtin_ctzll(badHi) : listNum;
-                if (numLights <= 64u) break;
-                const float4* L = reinterpret_cast<const float4*>(lights);
-                const uint32_t iHi = (uint32_t)tid + 64u < numLights ? index : 0u;
-                qc0 = L[(size_t)iHi * LREC + 0]; qc1 = L[(size_t)iHi * LREC + 1];
-            }
-        }
         if ((uint32_t)(h * 64) >= numLights) break;
         // (every condition as a wave mask of ONE simple compare, the combinations as scalar mask arithmetic: a bool that is assigned in branches
         // lives in a VGPR as 0 / 1 and costs a v_cndmask + v_cmp per use)
         const uint32_t li = (uint32_t)(h * 64 + lane);
         const uint32_t lc = li < numLights ? li : 0u; // (lanes past the list read slot 0 and are masked out)
-        float4 c0, c1;
-        if constexpr (QUAD) { c0 = qc0; c1 = qc1; }
-        else { c0 = sL[lc * LREC + 0]; c1 = sL[lc * LREC + 1]; }
+        const float4 c0 = sL[lc * LREC + 0];
+        const float4 c1 = sL[lc * LREC + 1];
         const uint32_t bits = __float_as_uint(c1.w);
         const unsigned long long mIn = __ballot(li < numLights);
         const unsigned long long mFin = __ballot((bits & 0x10000u) != 0u);
@@ -680,22 +632,7 @@ __device__ __forceinline__ void k2_shade_body(LDS& lds, const ShadeArgs& A, cons
         seg[2 + h] = all & mFin & mSpot;
         seg[6 + h] = mIn & mDir;
         seg[4 + h] = all & ~(seg[h] | seg[2 + h] | seg[6 + h]);
-        if constexpr (QUAD) { // the lights that may reach the quadrant, in list order, with their kind: light index | kind code << 28
-            const unsigned long long sv = (seg[h] | seg[2 + h]) | (seg[4 + h] | seg[6 + h]);
-            const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-            const uint32_t code = ((seg[h] >> lane) & 1ull) ? 0u : (((seg[2 + h] >> lane) & 1ull) ? 1u : (((seg[4 + h] >> lane) & 1ull) ? 2u : 3u));
-            const uint32_t r = survTotal + (uint32_t)__popcll(sv & lt);
-            if ((sv >> lane) & 1ull) {
-                sEnd[r] = index | (code << 28);
-                if (!hiPossible && r < (uint32_t)QUAD_CHUNK) { // (h == 0, the whole list: the first chunk's records straight from the registers)
-                    float4* o = sL + r * LREC;
-                    o[0] = qc0; o[1] = qc1; o[2] = q2; o[3] = q3; o[4] = q4;
-                }
-            }
-            survTotal += (uint32_t)__popcll(sv);
-        }
     }
-    if constexpr (QUAD) view_and_material(A.camX, A.camY, A.camZ, 1.0f);
 
     if (BAND && splitRole) { // this wave's share of the list: every fourth slot
         const unsigned long long share = 0x1111111111111111ull << __builtin_amdgcn_readfirstlane(wave); // (scalar: the masks stay in SGPRs)
@@ -773,32 +710,6 @@ __device__ __forceinline__ void k2_shade_body(LDS& lds, const ShadeArgs& A, cons
     const uint32_t sLAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)sL;
     static_assert(LREC == 5, "SHADE_LIGHT_LOOP computes 80 x slot as (5 x slot) << 4");
     float* res = sRes + wave * (3 * QMAX); // this wave's [3 colours][QMAX queue positions] slots
-    // QUAD: the lights that may reach the quadrant, QUAD_CHUNK at a time -- their records staged by this wave into its own LDS, the masks of the four
-    // kinds re-made over the chunk's (compact) slots; everything below then runs per chunk exactly as it runs once over a tile's staged list
-    uint32_t chunkBase = 0u;
-    do {
-    if constexpr (QUAD) {
-        if (survTotal == 0u) break;
-        static_assert(QUAD_CHUNK == 32 && QUAD_CHUNK * LREC <= 192, "three staging passes of 64 lanes; the kind masks are ballots over 32 lanes");
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // (the survivors' entries are in LDS; the previous chunk's records are done with)
-        const uint32_t n = min((uint32_t)QUAD_CHUNK, survTotal - chunkBase);
-        const float4* L = reinterpret_cast<const float4*>(lights);
-        // (the lane id made opaque: hoisted out of the chunk loop, the three items' addresses stay live across the whole body below and the 64-register
-        // budget spills five of them)
-        uint32_t ln = (uint32_t)lane;
-        asm volatile("" : "+v"(ln));
-        if (hiPossible || chunkBase != 0u) { // (else: the lanes have put the chunk's records there themselves)
-#pragma unroll
-        for (int it = 0; it < 3; it++) { // 5 float4 per light, one lane per float4
-            const uint32_t item = (uint32_t)(it * 64) + ln, c = (item * 205u) >> 10, part = item - 5u * c; // (item / 5 for item < 1024)
-            if (c < n) sL[item] = L[(size_t)(sEnd[chunkBase + c] & 0x0FFFFFFFu) * LREC + part];
-        }
-        }
-        const uint32_t kc = ln < n ? (sEnd[chunkBase + ln] >> 28) : 7u;
-        seg[0] = __ballot(kc == 0u); seg[2] = __ballot(kc == 1u); seg[4] = __ballot(kc == 2u); seg[6] = __ballot(kc == 3u);
-        seg[1] = 0ull; seg[3] = 0ull; seg[5] = 0ull; seg[7] = 0ull;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the records are in LDS
-    }
     for (;;) {
         uint32_t cnt = 0u;      // queued pairs (wave-uniform)
         uint32_t pc = 1u;       // the queue positions of this pixel's pairs: 1 (sentinel), then 7 bits per pair, the first one queued on top
@@ -991,8 +902,6 @@ __device__ __forceinline__ void k2_shade_body(LDS& lds, const ShadeArgs& A, cons
             }
         }
     }
-    chunkBase += (uint32_t)QUAD_CHUNK;
-    } while (QUAD && chunkBase < survTotal);
     if (BAND && splitRole) { // the four partial sums of each pixel: wave 0 + 1 + 2 + 3
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         res[lane] = accX; res[64 + lane] = accY; res[128 + lane] = accZ; // (in the wave's own slots: another wave may still be reading its own)
