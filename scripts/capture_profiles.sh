@@ -15,6 +15,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- p
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $B --steps 5 --warmup 2 $EAGER > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch4 -- python3 $B --config C4 --steps 5 --warmup 2 $EAGER > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write4 -- python3 $B --config C4 --steps 5 --warmup 2 $EAGER > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch5 -- python3 $B --config C5 --steps 3 --warmup 1 $EAGER > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write5 -- python3 $B --config C5 --steps 3 --warmup 1 $EAGER > /dev/null 2>&1
 rocprofv3 -i $GRAFT_REPO_ROOT/scripts/pmc_shade.txt --kernel-trace --output-format csv -d $OUT/sq -- python3 $GRAFT_REPO_ROOT/scripts/prof_frame.py C3 2 > /dev/null 2>&1
 rocprofv3 -i $GRAFT_REPO_ROOT/scripts/pmc_shade.txt --kernel-trace --output-format csv -d $OUT/sq4 -- python3 $GRAFT_REPO_ROOT/scripts/prof_frame.py C4 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats4 -- python3 $B --config C4 --steps 30 --warmup 5 $EAGER > $OUT/bench_eager_C4.json 2>/dev/null
@@ -25,6 +27,7 @@ rocprofv3 --kernel-trace --output-format csv -d $OUT/pipeband -- python3 $B --st
 cd $GRAFT_REPO_ROOT
 python3 scripts/make_traffic_json.py $OUT/fetch $OUT/write $OUT/traffic.json C3 > /dev/null
 python3 scripts/make_traffic_json.py $OUT/fetch4 $OUT/write4 $OUT/traffic_C4.json C4 > /dev/null
+python3 scripts/make_traffic_json.py $OUT/fetch5 $OUT/write5 $OUT/traffic_C5.json C5 > /dev/null
 python3 scripts/pmc_summary.py $OUT/sq k2_shade_pt > $OUT/pmc_shade.txt
 python3 scripts/pmc_summary.py $OUT/sq tile_cull > $OUT/pmc_tile_cull.txt
 python3 scripts/pmc_summary.py $OUT/sq4 k2_shade_csm_pt > $OUT/pmc_shade_csm_C4.txt
@@ -39,19 +42,24 @@ python3 bench.py --config C5 --no-cpu-baseline --steps 20 > $OUT/bench_C5.json 2
 # N > 1 as the driver types it, on this ONE-GPU box: the ranks share device 0 over gloo (figures meaningless; the path and the exchanged lists are real)
 for G in 2 4; do SAILOR_BENCH_SHARE_GPU=1 python3 bench.py --gpus $G --steps 12 --no-cpu-baseline > $OUT/bench_${G}ranks_sharing_one_gpu.json 2> $OUT/bench_${G}ranks_sharing_one_gpu.err; done
 for G in 2 4 8; do python3 bench.py --simulate-split $G --steps 30 > $OUT/simulate_split$G.json 2> $OUT/simulate_split$G.err; done
-# the 8-GPU configurations of BASELINE.json (configs[3], configs[4]) band by band: C4 with its shadow maps, C5 (static lights; the band-local light selection on, and off for comparison)
+# the 8-GPU configurations of BASELINE.json (configs[3], configs[4]) band by band: C4 with its shadow maps, C5 static and with every light dirty every frame
 python3 bench.py --simulate-split 8 --steps 24 --config C4 > $OUT/simulate_split8_C4.json 2> /dev/null
-python3 bench.py --simulate-split 8 --steps 24 --config C5 > $OUT/simulate_split8_C5.json 2> /dev/null
-SAILOR_CULL_FLAGS=64 python3 bench.py --simulate-split 8 --steps 24 --config C5 > $OUT/simulate_split8_C5_no_band_select.json 2> /dev/null
-python3 scripts/band_subset_probe.py C5 3/8 > $OUT/band_chain_C5_band3of8.txt 2>&1
-SAILOR_CULL_FLAGS=64 python3 scripts/band_subset_probe.py C5 3/8 > $OUT/band_chain_C5_band3of8_no_band_select.txt 2>&1
-SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/cull_prof.py > $OUT/cull_block_timeline.txt 2>&1
-SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/cull_prof.py 2/8 > $OUT/cull_block_timeline_band2of8.txt 2>&1
-SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/shade_prof.py 2/8 > $OUT/shade_block_timeline_band2of8.txt 2>&1
-SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/shade_prof.py 2/8 C4 > $OUT/shade_block_timeline_band2of8_C4.txt 2>&1
-SAILOR_NO_TILE_ORDER=1 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/shade_prof_csm.py 2/8 > $OUT/shade_block_timeline_band2of8_C4_per_tile_grid.txt 2>&1
-SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/shade_prof_csm.py 0/1 > $OUT/shade_block_timeline_C4.txt 2>&1
-SAILOR_BAND_SHADE_LDS=0 SAILOR_HIP_LIB=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so python3 scripts/shade_prof.py 2/8 > $OUT/shade_block_timeline_band2of8_8blocks.txt 2>&1
-SAILOR_BAND_SHADE_LDS=0 python3 bench.py --simulate-split 8 --steps 30 > $OUT/simulate_split8_8blocks_per_cu.json 2> /dev/null
-rm -rf $OUT/stats $OUT/stats4 $OUT/stats5 $OUT/fetch $OUT/write $OUT/fetch4 $OUT/write4 $OUT/sq $OUT/sq4 $OUT/pipe $OUT/pipeband
+python3 bench.py --simulate-split 8 --steps 24 --config C5 --static-lights > $OUT/simulate_split8_C5.json 2> /dev/null
+python3 bench.py --simulate-split 8 --steps 24 --config C5 > $OUT/simulate_split8_C5_dynamic.json 2> /dev/null
+# a rank's line of an 8-way, a 4-way and a 2-way split, kernel by kernel (dispatch-packet readings): C3 bands and a C5 band
+for b in 0/2 1/2 1/4 2/4 3/8; do python3 bench.py --simulate-band $b --no-cpu-baseline --steps 48 > $OUT/bench_C3_band$(echo $b | tr / of).json 2> /dev/null; done
+python3 bench.py --config C5 --simulate-band 3/8 --no-cpu-baseline --steps 24 --static-lights > $OUT/bench_C5_band3of8_static.json 2> /dev/null
+python3 bench.py --config C5 --simulate-band 3/8 --no-cpu-baseline --steps 24 > $OUT/bench_C5_band3of8_dynamic.json 2> /dev/null
+# block timelines (prof build): the shade of half / a quarter / an eighth of the 4K frame in the band form, the whole frame and a C5 band on the per-tile grid; per-wave slots
+PROF=$PWD/sailor_amd/csrc/ab/libsailor_hip_prof.so
+SAILOR_HIP_LIB=$PROF python3 scripts/shade_prof.py 0/2 > $OUT/shade_block_timeline_C3_band0of2.txt 2>&1
+SAILOR_HIP_LIB=$PROF python3 scripts/shade_prof.py 1/4 > $OUT/shade_block_timeline_C3_band1of4.txt 2>&1
+SAILOR_HIP_LIB=$PROF python3 scripts/shade_prof.py 2/8 > $OUT/shade_block_timeline_C3_band2of8.txt 2>&1
+SAILOR_BAND_FORM_TILES=0 SAILOR_HIP_LIB=$PROF python3 scripts/shade_prof_grid.py 0/2 C3 > $OUT/shade_block_timeline_C3_band0of2_per_tile_grid.txt 2>&1
+SAILOR_HIP_LIB=$PROF python3 scripts/shade_prof_grid.py 0/1 C3 > $OUT/shade_block_timeline_C3_whole.txt 2>&1
+SAILOR_HIP_LIB=$PROF python3 scripts/shade_prof_grid.py 3/8 C5 > $OUT/shade_block_timeline_C5_band3of8.txt 2>&1
+SAILOR_HIP_LIB=$PROF python3 scripts/shade_wave_prof.py 0/1 C3 > $OUT/shade_waves_C3_whole.txt 2>&1
+SAILOR_HIP_LIB=$PROF python3 scripts/shade_prof.py 2/8 C4 > $OUT/shade_block_timeline_C4_band2of8.txt 2>&1
+python3 scripts/r05_marker_probe.py C3 > $OUT/shade_behind_pack_marker_probe.txt 2>&1
+rm -rf $OUT/stats $OUT/stats4 $OUT/stats5 $OUT/fetch $OUT/write $OUT/fetch4 $OUT/write4 $OUT/fetch5 $OUT/write5 $OUT/sq $OUT/sq4 $OUT/pipe $OUT/pipeband
 ls -la $OUT

@@ -16,6 +16,7 @@ fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "W
 out = {
     "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph --frames-in-flight 1   (and a second, separate pass with --pmc WRITE_SIZE)",
     "correction": "MI355X_MICROARCH.md, HBM section: counters are in KB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (check: the depth pass reads the 33.2 MB depth image)",
+    "caveat": "the x2 on FETCH_SIZE is calibrated for 16-byte-per-lane STREAMING loads only (MI355X_MICROARCH.md, HBM section: other access widths and WRITE_SIZE are uncalibrated); for kernels dominated by 4-16-byte GATHERS -- k1_tile_cull's light records, the K3 texel look-ups of k2_shade_csm* -- the figure is an upper bound (a 64-byte request tallied once would be counted twice), and Infinity-Cache hits are included: it bounds fabric requests, not DRAM bytes",
     "config": sys.argv[4],
     "kernels": {},
 }
