@@ -54,6 +54,12 @@ def test_default_line_carries_the_contract():
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Mpixels/s" and c["value"] > 0 and "tile rows" in c["sample"]
     for block in ("ecs_sweep", "mesh_cull_compact", "linearize_depth", "ambient_ibl", "evsm_blur", "ibl_prefilter", "shadow_passes"):
         assert block in d, block
+    # round 5: the box's own yardstick (a float4 copy timed in this process) beside the guide's constant, the chain's kernels as the library names them,
+    # when k1_pack runs, and K4's slices of a 2- / 4- / 8-way entity split timed on this one GPU
+    assert 2000.0 < d["box"]["copy_gbs"] < 8000.0 and abs(r["frac_of_box_copy"] - r["achieved"] / d["box"]["copy_gbs"]) < 1e-9
+    assert list(r["cull"]["kernels_ms"]) == ["k01_prepare", "k1_group_lists", "k1_tile_cull", "k1_pack"] and d["pack"]["mode"] == "deferred"
+    sim = d["ecs_sweep"]["split"]["split_simulated_on_one_gpu"]
+    assert set(sim) == {"2", "4", "8"} and all(v["slice_ms_max"] > 0 for v in sim.values()) and d["ecs_sweep"]["split"]["default"] == "replicated"
 
 
 @pytest.mark.parametrize("split_primary", [True, False])
@@ -92,6 +98,17 @@ def test_ranks_sharing_the_gpu_run_the_split_frame_for_real(ranks):
         assert d["exchange"][key] == one["exchange"][key], key
     assert "torch.distributed (gloo)" in d["exchange"]["how"]                                       # RCCL takes one rank per device: all ranks agreed on the fallback
     assert d["alternate_frame_rendering"]["value"] > 0 and "error" not in d["alternate_frame_rendering"]
+    # round 5: an N > 1 line of the headline also carries bounded split readings of the two configurations BASELINE.json names for a node, the bands re-cut
+    # on measured times, and K4 across the ranks (entity ranges + one all-gather of the visibility words) beside K4 replicated -- the gathered bitmask is
+    # the replicated sweep's on every rank
+    assert list(d["split_configs"]) == ["C4", "C5"]
+    for name, v in d["split_configs"].items():
+        assert "error" not in v and v["split_ms_per_step"] > 0 and v["whole_frame_per_gpu_ms_per_step"] > 0 and v["speedup_vs_one_gpu_whole_frame"] > 0, (name, v)
+        assert v["tile_row_bounds"][0] == 0 and len(v["tile_row_bounds"]) == ranks + 1
+    assert d["split_configs"]["C5"]["lights"].startswith("dynamic") and d["split_configs"]["C5"]["tile_row_bounds"][-1] == 270
+    e = d["ecs_sweep"]["split"]
+    assert e["default"] == "replicated" and e["entities"] == 1 << 20 and e["split"]["ranks"] == ranks and e["split"]["bitmask_equals_replicated_on_every_rank"] is True
+    assert e["split"]["slice_ms"] < e["replicated_ms"] * 1.5
 
 
 @pytest.mark.parametrize("sets, steps", [(3, 12), (2, 8)])
