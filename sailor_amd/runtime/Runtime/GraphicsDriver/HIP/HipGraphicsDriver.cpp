@@ -171,6 +171,18 @@ void HipGraphicsDriver::SubmitCommandList(RHICommandListPtr commandList)
     // a cull of this submit left its compaction on the second queue: what is recorded from here on (other nodes, the exchange, the next frame's
     // cull into the same workspace) comes after it
     if (m_packPending) { sailor_hip_context_wait_for(m_ctx, m_ctxAux); m_packPending = false; }
+    // "these two SSBOs hold this cull's lists" ends with the submit: a later shade handed the same pointers (a frame whose cull node was skipped, a
+    // buffer freed and allocated again at the same address) reads lightsGrid / culledLights themselves, not the workspace
+    m_ownGrid = nullptr; m_ownCulled = nullptr;
+}
+
+// A command is about to WRITE this buffer: if it is one of the two SSBOs the last cull filled, the shade must read what the write leaves there, not the
+// cull's per-tile lists -- and the write must come behind the compaction that is still filling the buffer on the second queue.
+void HipGraphicsDriver::BeforeBufferWrite(const void* devicePtr)
+{
+    if (!devicePtr || (devicePtr != m_ownGrid && devicePtr != m_ownCulled)) return;
+    if (m_packPending) { sailor_hip_context_wait_for(m_ctx, m_ctxAux); m_packPending = false; }
+    m_ownGrid = nullptr; m_ownCulled = nullptr;
 }
 
 RHIMaterialPtr HipGraphicsDriver::CreateMaterial(RHIShaderPtr shader) { return RHIMaterialPtr::Make(std::move(shader)); }
@@ -303,7 +315,8 @@ bool HipGraphicsDriver::BlitImage(RHICommandListPtr cmd, RHITexturePtr src, RHIT
         return false;
     const size_t bytes = (size_t)(src->m_bCubemap ? 6 : 1) * src->GetExtent().x * src->GetExtent().y * texel_size(src->m_format);
     SailorHipContext* ctx = m_ctx;
-    cmd->m_hip.m_commands.push_back([ctx, src, dst, bytes]() {
+    cmd->m_hip.m_commands.push_back([this, ctx, src, dst, bytes]() {
+        BeforeBufferWrite(dst->m_buffer->m_hip.m_devicePtr);
         return sailor_hip_buffer_copy(ctx, dst->m_buffer->m_hip.m_devicePtr, 0, src->m_buffer->m_hip.m_devicePtr, 0, bytes);
     });
     return true;
@@ -368,7 +381,8 @@ void HipGraphicsDriver::UpdateBuffer(RHICommandListPtr cmd, RHIBufferPtr buffer,
 {
     TVector<uint8_t> staged((const uint8_t*)data, (const uint8_t*)data + size); // payload captured at record time
     SailorHipContext* ctx = m_ctx;
-    cmd->m_hip.m_commands.push_back([ctx, buffer, staged = std::move(staged), offset]() {
+    cmd->m_hip.m_commands.push_back([this, ctx, buffer, staged = std::move(staged), offset]() {
+        BeforeBufferWrite(buffer->m_hip.m_devicePtr);
         return sailor_hip_buffer_upload(ctx, buffer->m_hip.m_devicePtr, offset, staged.data(), staged.size());
     });
 }
@@ -442,6 +456,7 @@ int HipGraphicsDriver::RecordLightCulling(const TVector<RHIShaderBindingSetPtr>&
     m_ownGrid = nullptr; m_ownCulled = nullptr;
     if (st != SAILOR_HIP_OK) return st;
     m_ownGrid = grid; m_ownCulled = culled; // a shade handed these two SSBOs reads this cull's per-tile lists
+    m_cullBand = band;                      // ... if it shades the band this cull ran on
     if (!defer) return st;
     // the node's two SSBOs in the reference's layout, bit for bit, written on the second queue behind the cull's last kernel
     int st2 = sailor_hip_context_wait_for(m_ctxAux, m_ctx);
@@ -529,14 +544,19 @@ int HipGraphicsDriver::RecordShade(const TVector<RHIShaderBindingSetPtr>& bindin
     if (surfaceB->m_buffer->m_size < planeStride * 48) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     auto lightB = bindings[1]->Find("light");
     const bool prepared = lightB && lightB->m_hipPreparedLights && lightB->m_hipPreparedCapacity >= lightsNum;
-    const uint32_t* order = m_cullOrderValid ? sailor_hip_light_cull_tile_order(m_cullW, m_cullH, m_cullLights, band, m_cullWorkspace->m_hip.m_devicePtr) : nullptr;
+    // (the band's list lengths as bytes -- what switches the band form of the shade on: only from the workspace of a cull that ran on THIS band)
+    const uint32_t* order = (m_cullOrderValid && m_cullWorkspace && band && band->tileRowBegin == m_cullBand.tileRowBegin && band->tileRowEnd == m_cullBand.tileRowEnd)
+                                ? sailor_hip_light_cull_tile_order(m_cullW, m_cullH, m_cullLights, band, m_cullWorkspace->m_hip.m_devicePtr) : nullptr;
     const SailorLightsGrid* grid = (const SailorLightsGrid*)buffer_of(bindings[1], "lightsGrid");
     const uint32_t* culled = (const uint32_t*)buffer_of(bindings[1], "culledLights");
     // The lists of this frame's own LightCulling node (the usual graph: LightCullingNode.cpp:69-70 registers its SSBOs into the lights set that
     // RenderScene binds): read them where the cull left them -- the same entries in the same order as the two SSBOs hold, without waiting for the
     // compaction that fills those.  Lists from anywhere else (SSBOs the caller filled): through lightsGrid / culledLights, behind a pending pack.
     const uint32_t *tileNum = nullptr, *tileLists = nullptr;
-    const bool own = m_cullWorkspace && grid && culled && grid == m_ownGrid && culled == m_ownCulled && m_cullW == W && m_cullH == H &&
+    SailorBand shadeBand;
+    if (band) shadeBand = *band; else sailor_hip_band_whole_frame(W, H, &shadeBand);
+    const bool sameBand = shadeBand.tileRowBegin == m_cullBand.tileRowBegin && shadeBand.tileRowEnd == m_cullBand.tileRowEnd; // (SetFrameSplit between the two: not this cull's lists)
+    const bool own = m_cullWorkspace && grid && culled && grid == m_ownGrid && culled == m_ownCulled && m_cullW == W && m_cullH == H && sameBand &&
                      sailor_hip_light_cull_tile_lists(m_cullW, m_cullH, m_cullLights, band, m_cullWorkspace->m_hip.m_devicePtr, &tileNum, &tileLists) == SAILOR_HIP_OK;
     if (own) {
         // (the tile-order hint a band's split blocks need is written by k1_tile_cull itself since round 4 -- through round 3 by the pack step, and a

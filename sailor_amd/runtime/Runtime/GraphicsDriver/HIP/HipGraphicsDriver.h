@@ -115,6 +115,8 @@ private:
     // it is handed are the ones this frame's cull owns.  The main stream joins the second one at the end of the submit that recorded the cull.
     SailorHipContext* m_ctxAux = nullptr;
     bool m_packPending = false;
+    void BeforeBufferWrite(const void* devicePtr);
+    SailorBand m_cullBand {};          // the band the last recorded cull ran on
     const void* m_ownGrid = nullptr;   // the SSBOs the last recorded cull fills
     const void* m_ownCulled = nullptr;
     int m_rank = 0, m_worldSize = 1; // the frame split
