@@ -61,8 +61,10 @@ for name, sel in (("split-role blocks", np.arange(SPLIT)), ("tile blocks", SPLIT
     print("%-18s n %5d  duration us mean %.2f median %.2f p90 %.2f p99 %.2f max %.2f; starts %.2f .. %.2f (median %.2f), last end %.2f" %
           (name, len(sel), d.mean(), np.median(d), np.percentile(d, 90), np.percentile(d, 99), d.max(), us(p[sel, 0].min()), us(p[sel, 0].max()), np.median(us(p[sel, 0])), us(p[sel, 3].max())))
 tiles = SPLIT + np.arange(fp.band_tiles)
-own = (num < 40) | (g == 1)     # tiles the ordinary blocks shade themselves (the others return at once: the split blocks take them)
-print("tile blocks that shade (num < 40): %d, mean duration %.2f us;  that return at once: %d, mean duration %.2f us" % (own.sum(), dur[tiles][own].mean(), (~own).sum(), dur[tiles][~own].mean() if (~own).any() else 0.0))
+import os
+split_min = int(os.environ.get("SAILOR_SPLIT_MIN", "0")) or (64 if fp.band_tiles <= 12000 else 96)   # shade_body.h: SPLIT_MIN_SMALL / _LARGE by the band's size
+own = (num < split_min) | (g == 1)     # tiles the ordinary blocks shade themselves (the others return at once: the split blocks take them)
+print("tile blocks that shade (num < %d): %d, mean duration %.2f us;  that return at once: %d, mean duration %.2f us" % (split_min, own.sum(), dur[tiles][own].mean(), (~own).sum(), dur[tiles][~own].mean() if (~own).any() else 0.0))
 bins = [0, 1, 8, 16, 24, 32, 40, 64, 96, 129]
 for lo, hi in zip(bins[:-1], bins[1:]):
     m = own & (num >= lo) & (num < hi)
