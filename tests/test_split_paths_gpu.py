@@ -264,3 +264,20 @@ def test_launch_log_names_the_kernels_of_a_call(ctx):
     g.replay()
     torch.cuda.synchronize()
     c2.close()
+    # the two measurement kernels are launches of the path like any other: named in the log, timed by their own dispatch packets
+    import ctypes as C
+    n = 64 << 20
+    src = torch.full((n,), 7, dtype=torch.uint8, device=ctx.device)
+    dst = torch.zeros_like(src)
+
+    def probe():
+        _lib.check(ctx._lib.sailor_hip_marker(ctx.handle), "sailor_hip_marker", ctx.handle)
+        _lib.check(ctx._lib.sailor_hip_copy_probe(ctx.handle, src.data_ptr(), dst.data_ptr(), n), "sailor_hip_copy_probe", ctx.handle)
+    assert ctx.launches_of(probe) == ["k_marker", "k_copy_probe"]
+    ctx.time_launches(0, 2)
+    probe()
+    ctx.synchronize()
+    assert torch.equal(dst, src)
+    marker_ms, copy_ms = ctx.timed_launch_ms(0), ctx.timed_launch_ms(1)
+    assert 0.0 < marker_ms < 0.05 and 2 * n / (copy_ms * 1e-3) / 1e9 > 1000.0, (marker_ms, copy_ms)   # an empty kernel; a 64 MB copy at more than 1 TB/s
+    assert ctx._lib.sailor_hip_copy_probe(ctx.handle, src.data_ptr() + 4, dst.data_ptr(), n - 16) == -1, "unaligned pointers are refused"
