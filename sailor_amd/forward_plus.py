@@ -193,10 +193,20 @@ class ForwardPlus:
 
     # -- K2 + K3 --------------------------------------------------------------------------------------------------
     def shade(self, frame: UboFrameData, surface: torch.Tensor, lights: torch.Tensor, lights_num: int, csm: CsmDesc | None = None,
-              out: torch.Tensor | None = None, ibl: "_lib.IblDesc | None" = None, prepared: "PreparedLights | None" = None) -> torch.Tensor:
+              out: torch.Tensor | None = None, ibl: "_lib.IblDesc | None" = None, prepared: "PreparedLights | None" = None,
+              ctx: "HipContext | None" = None) -> torch.Tensor:
         """surface: float32 [3, band rows, W, 4]; returns radiance float32 [band rows, W, 4].  ibl: ambient term (its `ao`
-        pointer, if any, holds the band's rows)."""
+        pointer, if any, holds the band's rows).  ctx: record on another context's stream."""
         rows = self.band.fbRowCount
+        own_ctx = self.ctx
+        if ctx is not None:
+            self.ctx = ctx
+        try:
+            return self._shade(frame, surface, lights, lights_num, csm, out, ibl, prepared, rows)
+        finally:
+            self.ctx = own_ctx
+
+    def _shade(self, frame, surface, lights, lights_num, csm, out, ibl, prepared, rows):
         assert surface.dtype == torch.float32 and surface.is_contiguous() and surface.shape == (3, rows, self.W, 4), surface.shape
         if out is None:
             if self.radiance is None:
