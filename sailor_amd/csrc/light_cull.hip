@@ -636,7 +636,10 @@ __global__ __launch_bounds__(256) void k0_band_scatter(const SelectArgs a)
 }
 
 #define LDS_K01_PREPARE (2 * MAX_BANDS_PER_BLOCK * 16)
-__global__ __launch_bounds__(256) void k01_prepare(PrepareArgs a)
+#ifndef CULL_SGPR_CAP_PREPARE
+#define CULL_SGPR_CAP_PREPARE 80 // (as k1_tile_cull: eight blocks per CU instead of seven)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(CULL_SGPR_CAP_PREPARE))) void k01_prepare(PrepareArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_K01_PREPARE];
     const int b = (int)blockIdx.x;
@@ -1330,8 +1333,16 @@ __device__ __forceinline__ void block_select(const CullArgs& a, const int firstB
 // full tile that start 10-20 us into the launch and end at 24-29 while 99 % of the blocks are done at 22).  On for the 4K frame and its bands (a band
 // IS its longest block: k1_tile_cull 14.7 -> 9.7 us on a cluster band of an 8-way split), off on the wide path's 420-candidate lists (8K, a million
 // lights: no listed clusters, seven test steps per tile, and the barrier costs the throughput phase 15 %: 99 -> 114 us).
+// (The scalar registers capped at 80 -- round 5: a CU admits 256-thread blocks up to floor(800 / (ceil(sgprs / 16) 16 + 16)) of them (MI355X_MICROARCH.md), i.e.
+// eight with up to 80 scalar registers, SEVEN with the 81-95 this kernel takes by itself; 25-42 of them then live in the lanes of a vector register.  Same
+// box, alternating: the frame pipeline's step 166-168 -> 162-164 us.  Measured with it and dropped: the candidates' RECORDS written beside the group lists'
+// indices by k1_group_lists, so that this kernel stages them in one round trip instead of a dependent gather -- k1_tile_cull 24.2 -> 22.7 us, but
+// k1_group_lists, one round of blocks whose life IS the launch, 5.7 -> 8.8 us; a band's step +1.5 us.)
+#ifndef CULL_SGPR_CAP
+#define CULL_SGPR_CAP 80
+#endif
 template <bool COOP, bool SEL>
-__global__ __launch_bounds__(256) void k1_tile_cull(const CullArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(CULL_SGPR_CAP))) void k1_tile_cull(const CullArgs a)
 {
     // One 256-thread block per run of four tiles (a group's four columns in one tile row), one wave per tile.  The group's candidate records are
     // staged in LDS, CHUNK at a time, by the four waves together (list entries first, then the dependent 16-byte gathers, four of each in flight
