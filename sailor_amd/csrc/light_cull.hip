@@ -636,8 +636,10 @@ __global__ __launch_bounds__(256) void k0_band_scatter(const SelectArgs a)
 }
 
 #define LDS_K01_PREPARE (2 * MAX_BANDS_PER_BLOCK * 16)
+// (82 scalar registers = seven blocks per CU; capped at 80 as k1_tile_cull is, the lower half band's step went 102-104 -> 107-109 us beside the previous frame's
+// shade and nothing else moved: left alone -- profiles/r05/ab_sgpr_cap.txt)
 #ifndef CULL_SGPR_CAP_PREPARE
-#define CULL_SGPR_CAP_PREPARE 80 // (as k1_tile_cull: eight blocks per CU instead of seven)
+#define CULL_SGPR_CAP_PREPARE 96
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(CULL_SGPR_CAP_PREPARE))) void k01_prepare(PrepareArgs a)
 {
@@ -1335,7 +1337,7 @@ __device__ __forceinline__ void block_select(const CullArgs& a, const int firstB
 // lights: no listed clusters, seven test steps per tile, and the barrier costs the throughput phase 15 %: 99 -> 114 us).
 // (The scalar registers capped at 80 -- round 5: a CU admits 256-thread blocks up to floor(800 / (ceil(sgprs / 16) 16 + 16)) of them (MI355X_MICROARCH.md), i.e.
 // eight with up to 80 scalar registers, SEVEN with the 81-95 this kernel takes by itself; 25-42 of them then live in the lanes of a vector register.  Same
-// box, alternating: the frame pipeline's step 166-168 -> 162-164 us.  Measured with it and dropped: the candidates' RECORDS written beside the group lists'
+// box, alternating: the frame pipeline's step 166-167 -> 162-164 us, a quarter band's 62 -> 58.  Measured with it and dropped: the candidates' RECORDS written beside the group lists'
 // indices by k1_group_lists, so that this kernel stages them in one round trip instead of a dependent gather -- k1_tile_cull 24.2 -> 22.7 us, but
 // k1_group_lists, one round of blocks whose life IS the launch, 5.7 -> 8.8 us; a band's step +1.5 us.)
 #ifndef CULL_SGPR_CAP

@@ -43,6 +43,11 @@ def waves_per_simd(vgprs: int) -> int:
     return min(8, 512 // (-(-vgprs // 8) * 8))
 
 
+def blocks_per_cu_by_sgprs(sgprs: int) -> int:
+    # gfx950: 800 scalar registers per SIMD, allocated in sixteens plus sixteen for the trap handler / VCC; one wave of a 256-thread block per SIMD
+    return min(8, 800 // (-(-sgprs // 16) * 16 + 16))
+
+
 @pytest.fixture(scope="module")
 def resources(tmp_path_factory):
     if not (LLVM / "clang-offload-bundler").exists() or not shutil.which("objcopy"):
@@ -113,6 +118,9 @@ def test_cull_kernels_keep_their_occupancy(resources):
         # records per lane, the kernel went from 32 to ~55)
         assert k["vgpr_count"] <= 64 and waves_per_simd(k["vgpr_count"]) == 8 and k["private_segment_fixed_size"] <= 32, k   # (pinned to eight waves: a few bytes of scratch on the cluster tiles' path)
         assert 8 * k["group_segment_fixed_size"] <= 160 * 1024
+        # (round 5: a CU admits min(8, 800 / (ceil(sgprs / 16) 16 + 16)) 256-thread blocks -- MI355X_MICROARCH.md; at 93-95 scalar registers that was
+        # seven. Capped at 80: the frame pipeline's step 165.7 -> 161.5 us, profiles/r05/ab_sgpr_cap.txt)
+        assert blocks_per_cu_by_sgprs(k["sgpr_count"]) == 8, k
     for key in ("k01_prepare", "k1_pack", "k1_group_lists"):
         k = find(res, key)
         assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (key, k)
