@@ -114,8 +114,89 @@ __device__ __forceinline__ float sample_r16_pairs(const __half* __restrict__ map
     return lerp2(a00, a10, a01, a11, t.ax, t.ay);
 }
 
+// The 16 taps of an R16F cascade out of ONE 6 x 6-texel window (round 5).  The Poisson offsets are +-2 texels (Lighting.glsl:171-185: disk * 2 * texelSize),
+// so the sixteen 2 x 2 footprints of a pixel all lie in the texels [cx - 2, cx + 3] x [cy - 2, cy + 3] around the centre's own footprint: six 12-byte row
+// reads per pixel in place of thirty-two 4-byte ones -- the kernel is bound by the texel path's address rate (its lanes' footprints are ~100 texels apart:
+// every lane of every request is a line of its own), not by bytes or arithmetic.  A tap's footprint origin is floor(frac + offset) texels from the
+// centre's, i.e. one of TWO compile-time positions per axis: the selection is four conditional moves on row dwords and one funnel shift per row.  Same
+// texels, same weights (the tap's own bilinear_taps arithmetic), same lerp2 as sample_r: same bits.  The sum of sixteen 0 / 1 terms is exact in any order.
+// Lanes whose window would cross the map's left / right edge, and any wave in which a tap's origin is not where the arithmetic above puts it (never seen;
+// the guard costs two instructions a tap), take the tap-by-tap path below.
+// Register budget (the K3 kernels sit at exactly 64): the window is walked in two phases of four rows -- taps whose footprints start in window rows 0-1, then
+// rows 2-3 -- so twelve dwords are live, not eighteen (the tap-by-tap path holds sixteen).  The disk happens to put each of the four column origins exactly
+// once into each of the four row origins: ordered that way, tap j of either phase has the same compile-time origin (column j & 3, row j >> 2 of the phase's
+// four rows) and only its offset differs -- the phases are one rolled loop reading the offsets as scalars.
+struct __attribute__((packed, aligned(2))) PcfRow { uint32_t d[3]; };
+__constant__ float kPcfDisk[2][8][2] = { // kPoissonDisk in the order { 5, 2, 8, 1, 0, 10, 15, 9 }, { 4, 6, 3, 11, 13, 12, 14, 7 }: by (row origin, column origin)
+    { { -0.81544232f, -0.87912464f }, { -0.094184101f, -0.92938870f }, { 0.44323325f, -0.97511554f }, { 0.94558609f, -0.76890725f }, { -0.94201624f, -0.39906216f }, { -0.26496911f, -0.41893023f }, { 0.14383161f, -0.14100790f }, { 0.53742981f, -0.47373420f } },
+    { { -0.91588581f, 0.45771432f }, { -0.38277543f, 0.27676845f }, { 0.34495938f, 0.29387760f }, { 0.79197514f, 0.19090188f }, { -0.81409955f, 0.91437590f }, { -0.24188840f, 0.99706507f }, { 0.19984126f, 0.78641367f }, { 0.97484398f, 0.75648379f } },
+};
+
+// Where a tap's footprint starts.  With x_c = RN(RN(px W) - 0.5) the centre's coordinate and x_t = RN(RN(RN(px + RN(2 p RN(1 / W))) W) - 0.5) the tap's, the
+// roundings move x_t - x_c at most 3e-7 W texels away from the offset 2 p; no 2 p of the disk is nearer than 0.0059 to an integer, so for W <= 8192
+// (2.5e-3 texels) floor(x_t) - floor(x_c) is floor(2 p) or floor(2 p) + 1 -- the window's two compile-time origins -- and nothing else.  Larger maps take the
+// tap-by-tap path.
+#define PCF_WINDOW_MAX_SIZE 8192
+
+// (Measured with it and dropped, round 5: the window's least and greatest texel -- taken on the halves' bits, six row reads and ~110 instructions -- decide all
+// sixteen compares of a lane whose reference depth is above / below every value a tap can take, and a wave whose 64 lanes are all decided skips the taps'
+// ~45 instructions each.  Bit-exact on every map of tests/test_shade_gpu.py's hostile set; on C4 it buys nothing -- k2_shade_csm_pt 215 us with it, 212
+// without (profiles/r05/ab_pcf_window.txt): the synthetic surface's depth noise puts a wave's 64 pixels ~100 texels apart in the map, some 5 % of the map lies
+// within a window of an occluder's edge, and ONE undecided lane keeps its wave in the loop (0.95^64: a few waves in a hundred skip it).  A scene with
+// coherent depth is where it would pay.)
+// (addresses: the map's base plus a 32-bit byte offset -- a map of at most 8192 x 8192 halves is 128 MB -- so that a wave-uniform base stays scalar)
+__device__ __forceinline__ PcfRow pcf_row(const __half* __restrict__ m16, uint32_t colBytes, int y, int W, int H)
+{
+    const uint32_t off = (uint32_t)min(max(y, 0), H - 1) * (uint32_t)W * 2u + colBytes;
+    return *reinterpret_cast<const PcfRow*>(reinterpret_cast<const char*>(m16) + off);
+}
+
+__device__ __forceinline__ float shadow_pcf_window(const __half* __restrict__ m16, float cxf, float cyf, int W, int H, const float tsx, const float tsy,
+                                                   float px, float py, float ref)
+{
+    // (the window's origin is kept as the two floats the taps compare against; the rows' addresses are put together from them where a row is read -- two
+    // integer copies of the same numbers held across the taps are two registers the 64-register kernels spill)
+    uint32_t w[4][3];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const PcfRow row = pcf_row(m16, (uint32_t)((int)cxf - 2) * 2u, (int)cyf - 2 + r, W, H);
+        w[2 + r][0] = row.d[0]; w[2 + r][1] = row.d[1]; w[2 + r][2] = row.d[2];
+    }
+    int count = 0;
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            w[r][0] = w[2 + r][0]; w[r][1] = w[2 + r][1]; w[r][2] = w[2 + r][2];
+            const PcfRow row = pcf_row(m16, (uint32_t)((int)cxf - 2) * 2u, (int)cyf + 2 * h + r, W, H);
+            w[2 + r][0] = row.d[0]; w[2 + r][1] = row.d[1]; w[2 + r][2] = row.d[2];
+        }
+        const float rowf = cyf + (float)(2 * h - 2); // the phase's first row as a float (small integers: exact)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float ox = kPcfDisk[h][j][0] * 2.0f * tsx, oy = kPcfDisk[h][j][1] * 2.0f * tsy;
+            const float x = (px + ox) * (float)W - 0.5f, y = (py + oy) * (float)H - 0.5f; // bilinear_taps' own arithmetic
+            const float fx = floorf(x), fy = floorf(y);
+            const float ax = x - fx, ay = y - fy;
+            const int KX = j & 3, KY = j >> 2; // (compile-time once unrolled)
+            const bool sx = fx - cxf != (float)(KX - 2), sy = fy - rowf != (float)KY; // the footprint starts one texel right of / below its first origin
+            const int d0 = KX >> 1;
+            const uint32_t aLo = sy ? w[KY + 1][d0] : w[KY][d0], aHi = sy ? w[KY + 1][d0 + 1] : w[KY][d0 + 1];
+            const uint32_t bLo = sy ? w[KY + 2][d0] : w[KY + 1][d0], bHi = sy ? w[KY + 2][d0 + 1] : w[KY + 1][d0 + 1];
+            const uint32_t aMid = __builtin_amdgcn_alignbit(aHi, aLo, 16), bMid = __builtin_amdgcn_alignbit(bHi, bLo, 16);
+            const uint32_t pa = (KX & 1) ? (sx ? aHi : aMid) : (sx ? aMid : aLo);
+            const uint32_t pb = (KX & 1) ? (sx ? bHi : bMid) : (sx ? bMid : bLo);
+            const float a00 = __half2float(__ushort_as_half((unsigned short)(pa & 0xFFFFu))), a10 = __half2float(__ushort_as_half((unsigned short)(pa >> 16)));
+            const float a01 = __half2float(__ushort_as_half((unsigned short)(pb & 0xFFFFu))), a11 = __half2float(__ushort_as_half((unsigned short)(pb >> 16)));
+            const float d = lerp2(a00, a10, a01, a11, ax, ay) * 0.5f + 0.5f;
+            count += (ref > d) ? 1 : 0;
+        }
+    }
+    return (float)count;
+}
+
 // Lighting.glsl:242-261 ShadowCalculation_Pcf + :168-197 ManualPCF
-__device__ float shadow_pcf(const void* __restrict__ map, int fmt, int W, int H, const float tsx, const float tsy, float4 lp, float bias)
+__device__ __forceinline__ float shadow_pcf(const void* __restrict__ map, int fmt, int W, int H, const float tsx, const float tsy, float4 lp, float bias)
 {
     float px = lp.x, py = lp.y, pz = lp.z;
     if (__ballot(lp.w != 1.0f) != 0ull) { px = px / lp.w; py = py / lp.w; pz = pz / lp.w; } // (x / 1 == x: see shadow_evsm)
@@ -124,9 +205,21 @@ __device__ float shadow_pcf(const void* __restrict__ map, int fmt, int W, int H,
     if (px > 1.0f || py > 1.0f || px < 0.0f || py < 0.0f || pz < 0.5f) return 1.0f;
     float shadow = 0.0f;
     if (fmt == SAILOR_SHADOWMAP_R16_SFLOAT && W >= 2) {
-        // the cascades' own format (ECS/LightingECS.h:57-58): 2 requests per tap, 8 taps = 16 requests in flight (the wave is bound by the
-        // round trips of its scattered texel reads, not by arithmetic)
         const __half* m16 = reinterpret_cast<const __half*>(map);
+#ifndef PCF_NO_WINDOW
+        const float cxf = floorf(px * (float)W - 0.5f), cyf = floorf(py * (float)H - 0.5f);
+        const int wx0 = (int)cxf - 2;
+        if (wx0 >= 0 && wx0 + 5 <= W - 1 && max(W, H) <= PCF_WINDOW_MAX_SIZE)
+            return shadow_pcf_window(m16, cxf, cyf, W, H, tsx, tsy, px, py, pz + bias) / 16.0f;
+        // (the lanes at a map's left / right edge: one tap at a time -- what this loop needs in registers, the whole kernel needs)
+#pragma unroll 1
+        for (int i = 0; i < 16; i++) {
+            const float ox = kPoissonDisk[i][0] * 2.0f * tsx, oy = kPoissonDisk[i][1] * 2.0f * tsy;
+            shadow += (pz + bias > sample_r16_pairs(m16, W, H, px + ox, py + oy) * 0.5f + 0.5f) ? 1.0f : 0.0f;
+        }
+        return shadow / 16.0f;
+#endif
+        // the cascades' own format (ECS/LightingECS.h:57-58), tap by tap: 2 requests per tap, 8 taps = 16 requests in flight
 #pragma unroll 1
         for (int i0 = 0; i0 < 16; i0 += 8) {
             float d[8];
@@ -182,6 +275,7 @@ __device__ float shadow_evsm(const void* __restrict__ map, int fmt, int W, int H
 // Standard.shader:266-283 + Lighting.glsl:200-216 SelectCascade
 // The look-up in one cascade.  `cascade` is either the wave's common cascade (a scalar: the matrix, the map and its size then come by scalar loads
 // from the argument segment and the matrix multiplies read them as scalar operands) or the lane's own (per-lane loads from the segment).
+template <bool UNIFORM>
 __device__ __forceinline__ float cascade_shadow(const CsmArgs& C, const int cascade, const uint32_t shadowType, const float ndl, const float wx, const float wy, const float wz)
 {
     const void* map = C.maps[cascade];
@@ -211,9 +305,12 @@ __device__ float directional_shadow(const ShadeArgs& A, const CsmArgs& C, uint32
     cascade = min(cascade, SAILOR_NUM_CSM_CASCADES - 1);
     const float ndl = dot3f(nx, ny, nz, dirX, dirY, dirZ);
     // a wave is an 8 x 8-pixel quadrant: nearly always inside one cascade
+    // (Measured and dropped, round 5: ONE copy of the look-up code, run once per cascade present in the wave with that cascade's lanes alone active -- always a
+    // scalar cascade, a fifth less code.  The loop keeps fourteen more values live than the kernel has registers for: 52 bytes of scratch a pixel, and a
+    // kernel that moves 1 GB at 4.7 TB/s has no room for 0.9 GB of spill traffic -- k2_shade_csm_pt 213 -> 287 us.)
     const int common = __builtin_amdgcn_readfirstlane(cascade);
-    if (__ballot(cascade != common) == 0ull) return cascade_shadow(C, common, shadowType, ndl, wx, wy, wz);
-    return cascade_shadow(C, cascade, shadowType, ndl, wx, wy, wz);
+    if (__ballot(cascade != common) == 0ull) return cascade_shadow<true>(C, common, shadowType, ndl, wx, wy, wz);
+    return cascade_shadow<false>(C, cascade, shadowType, ndl, wx, wy, wz);
 }
 
 // ---- ambient / IBL term (Standard.shader:343-372), canonical samplers == oracle/sailor_oracle.c (tolerance-checked) ----
@@ -951,7 +1048,14 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         __builtin_amdgcn_sched_barrier(0);
     }
     if (active) { // outColor.a = material.albedo.a (:438); written once and read by nobody here: non-temporal, like the surface loads
-        float4* o = radiance + ((size_t)(py - A.fbRow0) * A.W + gx);
+        // (the pixel's coordinates put together AGAIN from the lane's number -- two instructions -- and the scalars of the tile and the quadrant: held from
+        // the prologue to here they are two registers live across the whole kernel, which at 64 registers and no scratch is two too many for the K3 kernels)
+        int lane2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane2));
+        const int quadS = __builtin_amdgcn_readfirstlane(quad);
+        const int gx2 = tx * TILE + (quadS & 1) * 8 + (lane2 & 7);
+        const int py2 = A.H - 1 - (ty * TILE + (quadS >> 1) * 8 + (lane2 >> 3));
+        float4* o = radiance + ((size_t)(py2 - A.fbRow0) * A.W + gx2);
         __builtin_nontemporal_store(accX, &o->x); __builtin_nontemporal_store(accY, &o->y);
         __builtin_nontemporal_store(accZ, &o->z); __builtin_nontemporal_store(P0.w, &o->w);
     }

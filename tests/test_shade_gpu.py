@@ -162,6 +162,69 @@ def test_deep_scene_reaches_all_cascades(ctx):
     assert_radiance_close(got, oracle_frame(f))
 
 
+def _deep_frame(w=256, h=144, seed=21):
+    cam = synth.make_camera(w, h)
+    ramp = 60.0 * 300.0 ** ((np.arange(w) + 0.5) / w)  # 60 .. 18 000 across the frame: every cascade is reached
+    depth = (ramp[None, :] * (0.8 + 0.4 * synth.uniforms(synth.STREAM_DEPTH, w * h, 77).reshape(h, w))).astype(np.float32)
+    cfg = synth.LightSetConfig(count=2000, spot_fraction=0.25, radius_scale=6.0, directional_first=True, d_min=50.0, d_max=12000.0)
+    return synth.Frame("deep", cam, depth, synth.make_lights(cam, depth, cfg, seed), synth.make_surface(cam, depth, seed), synth.make_shadow_set(cam, 128, seed))
+
+
+def _hostile_map(kind: str, shape, seed: int) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    if kind == "noise":          # no window is flat: every pixel's sixteen taps are computed from the window
+        return rng.uniform(0.2, 0.9, shape).astype(np.float16)
+    if kind == "flat":           # every window is flat: the reference depth against one value, both outcomes and the margin between them
+        return np.full(shape, 0.43, np.float16)
+    if kind == "steps":          # flat patches of a few texels: windows on, beside and across their edges
+        coarse = rng.uniform(-0.2, 0.6, (-(-shape[0] // 5), -(-shape[1] // 7)))
+        return np.kron(coarse, np.ones((5, 7)))[: shape[0], : shape[1]].astype(np.float16)
+    if kind == "signed_denormal":  # negative texels, both zeros, half denormals: the extremes are taken on the bits
+        vals = np.array([-0.5, -6e-8, -0.0, 0.0, 6e-8, 3e-5, -3e-5, 0.43, 0.47], np.float16)
+        return vals[rng.integers(0, len(vals), shape)]
+    if kind == "nonfinite":      # an infinity or a NaN in the window: never decided by the extremes, the taps propagate them as the reference does
+        m = rng.uniform(0.0, 0.3, shape).astype(np.float16)
+        bad = rng.uniform(size=shape)
+        m[bad < 0.02] = np.float16(np.inf); m[(bad >= 0.02) & (bad < 0.04)] = np.float16(-np.inf); m[(bad >= 0.04) & (bad < 0.06)] = np.float16(np.nan)
+        return m
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["noise", "flat", "steps", "signed_denormal", "nonfinite"])
+@pytest.mark.parametrize("shape", [(128, 128), (96, 160), (40, 5), (8, 8200)])
+def test_pcf_window_against_the_oracle_on_hostile_maps(ctx, kind, shape):
+    """Round 5: the sixteen PCF taps of an R16F cascade come out of one 6 x 6-texel window, and the window's extremes decide all sixteen compares where
+    they can (shade_body.h).  Maps built to sit on every branch of that -- not flat anywhere, flat everywhere, small flat patches, signed / zero /
+    denormal texels, infinities and NaNs -- in shapes that are square, ragged, narrower than a window (every lane takes the tap-by-tap path) and wider
+    than PCF_WINDOW_MAX_SIZE (likewise): the picture is the oracle's."""
+    f = _deep_frame()
+    for k in (1, 2, 3):
+        f.shadows.maps[k] = _hostile_map(kind, shape, 1000 + k)
+    got, _ = gpu_frame(ctx, f)
+    ref = oracle_frame(f)
+    unshadowed = oracle_frame(f, csm=False)
+    if kind != "flat":
+        assert np.abs(ref - unshadowed).max() > 0.0
+    assert_radiance_close(got, ref)
+
+
+def test_pcf_partial_shadow_counts_occur_on_the_noise_map(ctx):
+    """(the test above would pass vacuously if every pixel's count were 0 or 16: on the noise map the directional light's shadow factor takes many of
+    the seventeen values)"""
+    f = _deep_frame()
+    for k in (1, 2, 3):
+        f.shadows.maps[k] = _hostile_map("noise", (128, 128), 1000 + k)
+    f.lights = f.lights[:1].copy()     # the directional light alone: radiance = shadow * its unshadowed term
+    lit = oracle_frame(f, csm=False)
+    ref = oracle_frame(f)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = np.where(lit[..., 0] > 0, ref[..., 0] / lit[..., 0], np.nan)
+    sixteenths = np.unique(np.round(ratio[np.isfinite(ratio)] * 16).astype(int))
+    assert len(sixteenths) >= 8, sixteenths
+    got, _ = gpu_frame(ctx, f)
+    assert_radiance_close(got, ref)
+
+
 @pytest.mark.parametrize("world_size", [2, 3])
 def test_bands_shade_identically(ctx, world_size):
     f = synth.make_frame("tiny_csm", width=320, height=200,
