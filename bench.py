@@ -852,7 +852,7 @@ def simulate_split(args, dev, ctx, side, frame, d_lights, fp_full, d_depth_full,
         prev = cur
     out["whole_frame_ms"] = whole
     out["launch"] = f"hipGraph replay ({unroll} steps of the frame pipeline per graph), 2 frames in flight over {args.list_sets} list sets" if unroll else "hipGraph replay, 1 frame in flight"
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
 
 
 def ecs_split_block(dev, ctx, dist, rank: int, world: int, count: int, steps: int, simulate=()):
@@ -1617,13 +1617,40 @@ def main(argv=None, device_factory=None):
         dev.close()
         dist.destroy_process_group()
     if rank == 0:
-        # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which would otherwise be flushed behind it at exit
-        import ctypes
-        sys.stdout.flush()
-        ctypes.CDLL(None).fflush(None)
-        print(line, flush=True)
+        emit(line)
     return line
 
 
+_JSON_FD = None   # set when this process is run as a rank: the descriptor stdout had at start-up
+
+
+def emit(line: str):
+    """The JSON line, alone on stdout.  Run as a program, a rank moves descriptor 1 onto stderr before anything else runs (`claim_stdout`), so what libraries
+    print through C stdio -- RCCL's version banner, Gloo's connection notes, on every rank -- lands on stderr, and rank 0 writes its line to the real one."""
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if _JSON_FD is None:
+        print(line, flush=True)
+    else:
+        os.write(_JSON_FD, (line + "\n").encode())
+
+
+def claim_stdout(argv):
+    """(not in the parent of `--gpus N` without a launcher: its children are the ranks and inherit the real stdout)"""
+    global _JSON_FD
+    gpus = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            gpus = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            gpus = int(a.split("=", 1)[1])
+    if "WORLD_SIZE" in os.environ or gpus <= 1:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
 if __name__ == "__main__":
+    claim_stdout(sys.argv[1:])
     main()

@@ -155,10 +155,13 @@ SHADE_BAND_ENTRY(k2_shade_band_pt, true, true, false, 8)
 // (round 4: with shadow maps too -- a band of C4 was its longest tile: 63 us for 25 us of block-slot time, scripts/shade_prof_csm.py.  Two copies of the
 // K3 body do not fit 64 registers without scratch (24 bytes, 6-7 spilled registers); six waves per SIMD -- what the band kernels' wave-slot reserve leaves
 // a CU anyway -- give them 80)
-SHADE_BAND_ENTRY(k2_shade_band_csm, false, false, true, 6)
-SHADE_BAND_ENTRY(k2_shade_band_csm_p, true, false, true, 6)
-SHADE_BAND_ENTRY(k2_shade_band_csm_t, false, true, true, 6)
-SHADE_BAND_ENTRY(k2_shade_band_csm_pt, true, true, true, 6)
+#ifndef BAND_CSM_WAVES
+#define BAND_CSM_WAVES 6
+#endif
+SHADE_BAND_ENTRY(k2_shade_band_csm, false, false, true, BAND_CSM_WAVES)
+SHADE_BAND_ENTRY(k2_shade_band_csm_p, true, false, true, BAND_CSM_WAVES)
+SHADE_BAND_ENTRY(k2_shade_band_csm_t, false, true, true, BAND_CSM_WAVES)
+SHADE_BAND_ENTRY(k2_shade_band_csm_pt, true, true, true, BAND_CSM_WAVES)
 
 // ---- sailor_hip_prepare_lights: the per-light half of the path, once per UPLOADED light instead of once per frame and list slot ----
 // One lane per light of [first, first + count): the cull's 20-byte view of it -- (worldPosition, bounds.x) as a float4 and the type, two dense

@@ -17,6 +17,8 @@ def _run(cmd, env=None):
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "rank 0 prints ONE JSON line"
+    # ... and nothing else reaches stdout: what RCCL / Gloo / the other ranks print through C stdio is on stderr (bench.claim_stdout)
+    assert p.stdout.strip() == lines[0], p.stdout[:400]
     return json.loads(lines[0])
 
 
