@@ -153,10 +153,11 @@ SHADE_BAND_ENTRY(k2_shade_band_p, true, false, false, 8)
 SHADE_BAND_ENTRY(k2_shade_band_t, false, true, false, 8)
 SHADE_BAND_ENTRY(k2_shade_band_pt, true, true, false, 8)
 // (round 4: with shadow maps too -- a band of C4 was its longest tile: 63 us for 25 us of block-slot time, scripts/shade_prof_csm.py.  Two copies of the
-// K3 body do not fit 64 registers without scratch (24 bytes, 6-7 spilled registers); six waves per SIMD -- what the band kernels' wave-slot reserve leaves
-// a CU anyway -- give them 80)
+// K3 body do not fit 64 registers without scratch (4-5 spilled registers even with round 5's window look-ups).  Seven waves per SIMD = 72 registers, none
+// spilled, 94 scalar registers = seven blocks per CU by that file too; round 4's six (80) had more than the body needs: a quarter band of C4 94 -> 90 us,
+// an eighth -- held to six blocks by the wave-slot reserve anyway -- unchanged: gpurun r05y, profiles/r05/ab_band_csm_waves.txt)
 #ifndef BAND_CSM_WAVES
-#define BAND_CSM_WAVES 6
+#define BAND_CSM_WAVES 7
 #endif
 SHADE_BAND_ENTRY(k2_shade_band_csm, false, false, true, BAND_CSM_WAVES)
 SHADE_BAND_ENTRY(k2_shade_band_csm_p, true, false, true, BAND_CSM_WAVES)
