@@ -132,7 +132,9 @@ typedef struct SailorAABB {
 #define SAILOR_SHADOWMAP_R32_SFLOAT 2
 
 /* The CSM inputs of Standard.shader: binding 6 `lightsMatrices` and binding 8 `shadowMaps[cascade]`
- * (Standard.shader:223-233).  Maps are linear row-major images in device memory, row 0 first. */
+ * (Standard.shader:223-233).  Maps are linear row-major images in device memory, row 0 first.
+ * (An R16F cascade of up to 8192 x 8192 texels has the sixteen PCF taps of a pixel read as one 6 x 6-texel window -- Lighting.glsl:168-197's
+ * disk is +-2 texels --, a larger one tap by tap: the same bits either way; tests/test_shade_gpu.py runs both against the oracle.) */
 typedef struct SailorCsmDesc {
     float lightsMatrices[SAILOR_NUM_CSM_CASCADES][16];
     const void* maps[SAILOR_NUM_CSM_CASCADES]; /* device pointers; NULL = no map bound => shadow factor 1 */
