@@ -191,12 +191,12 @@ def _hostile_map(kind: str, shape, seed: int) -> np.ndarray:
 
 
 @pytest.mark.parametrize("kind", ["noise", "flat", "steps", "signed_denormal", "nonfinite"])
-@pytest.mark.parametrize("shape", [(128, 128), (96, 160), (40, 5), (8, 8200)])
+@pytest.mark.parametrize("shape", [(128, 128), (96, 160), (40, 5), (12, 8192), (8, 8200)])
 def test_pcf_window_against_the_oracle_on_hostile_maps(ctx, kind, shape):
     """Round 5: the sixteen PCF taps of an R16F cascade come out of one 6 x 6-texel window, and the window's extremes decide all sixteen compares where
     they can (shade_body.h).  Maps built to sit on every branch of that -- not flat anywhere, flat everywhere, small flat patches, signed / zero /
     denormal texels, infinities and NaNs -- in shapes that are square, ragged, narrower than a window (every lane takes the tap-by-tap path) and wider
-    than PCF_WINDOW_MAX_SIZE (likewise): the picture is the oracle's."""
+    than PCF_WINDOW_MAX_SIZE (likewise; 8192 itself is the widest map the window takes): the picture is the oracle's."""
     f = _deep_frame()
     for k in (1, 2, 3):
         f.shadows.maps[k] = _hostile_map(kind, shape, 1000 + k)
@@ -206,6 +206,19 @@ def test_pcf_window_against_the_oracle_on_hostile_maps(ctx, kind, shape):
     if kind != "flat":
         assert np.abs(ref - unshadowed).max() > 0.0
     assert_radiance_close(got, ref)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_pcf_window_on_noise_maps_of_odd_sizes(ctx, seed):
+    """The window's two-origins rule rests on 1 / W being close enough to exact and on the disk's offsets staying clear of the integers (shade_body.h):
+    noise maps (every tap computed) of sizes that are no powers of two, three different ones per frame, against the oracle."""
+    rng = np.random.default_rng(4000 + seed)
+    f = _deep_frame(seed=21 + seed)
+    for k in (1, 2, 3):
+        shape = (int(rng.integers(6, 700)), int(rng.integers(6, 700)))
+        f.shadows.maps[k] = _hostile_map("noise" if k != 2 else "steps", shape, 5000 + 10 * seed + k)
+    got, _ = gpu_frame(ctx, f)
+    assert_radiance_close(got, oracle_frame(f))
 
 
 def test_pcf_partial_shadow_counts_occur_on_the_noise_map(ctx):
