@@ -411,7 +411,10 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
     // whole frame, and the cap costs it what it costs there (half the 4K frame: 108 -> 120 us per step) -- and for any band under a large light set, whose
     // cull chain is as long as its shade (an eighth of the 8K frame under a million lights: 16 320 tiles, 80 us of cull beside 78 us of shade; 152 -> 134 us).
     static const int bandLdsEnv = [] { const char* e = getenv("SAILOR_BAND_SHADE_LDS"); return e ? atoi(e) : -1; }();
-    const unsigned bandLds = (!partial || ibl) ? 0u : (bandLdsEnv >= 0 ? (unsigned)bandLdsEnv : ((bandTiles <= 3 * 8 * ctx->numCUs || lightsNum >= 131072) ? (unsigned)SHADE_BAND_RESERVE : 0u));
+    // (round 5: NOT for the shadowed band kernels -- seven waves per SIMD by their registers, so a CU's eighth block slot is the chain's already; capped at six
+    // an eighth of C4 took 62.2 us per step instead of 56.8: profiles/r05/ab_band_csm_waves.txt, probe Q)
+    const bool reserve = (bandTiles <= 3 * 8 * ctx->numCUs || lightsNum >= 131072) && !(hasCsm && splitBand);
+    const unsigned bandLds = (!partial || ibl) ? 0u : (bandLdsEnv >= 0 ? (unsigned)bandLdsEnv : (reserve ? (unsigned)SHADE_BAND_RESERVE : 0u));
     if (hasCsm && ibl) LAUNCH_SHADE(k2_shade_csm_ibl);
     else if (hasCsm && !splitBand) LAUNCH_SHADE(k2_shade_csm);
     else if (ibl) LAUNCH_SHADE(k2_shade_ibl);
