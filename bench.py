@@ -125,6 +125,7 @@ class HipDevice:
         torch.cuda.set_device(local_rank)
         self.device = torch.device("cuda", local_rank)
         self._comm = None
+        self._exchanges, self._last_exchange = {}, None
 
     # -- streams, events, graphs
     def stream(self, priority: int = 0):
@@ -215,15 +216,32 @@ class HipDevice:
             self.exchange_how = f"sailor_amd.dist.exchange_lists over torch.distributed ({self.dist_backend}): the C-ABI exchange's own communicator could not be created on every rank"
 
     def exchange(self, ctx, W, H, bounds, fp):
-        """this rank's band lists -> the frame's canonical (lightsGrid, culledLights) on every rank: sailor_hip_exchange_light_lists_rows"""
+        """this rank's band lists -> the frame's canonical (lightsGrid, culledLights) on every rank: sailor_hip_exchange_light_lists_rows, RECORDED on the
+        context's stream (round 6: the call reads nothing back and does not wait; workspace and global buffers are kept from call to call)"""
         from sailor_amd import dist as sdist
         if self._comm is None:
             return sdist.exchange_lists(fp.grid[: fp.band_tiles * 2], fp.culled)
-        return sdist.exchange_lists_rccl(ctx, self._comm, W, H, bounds, fp.grid[: fp.band_tiles * 2], fp.culled)
+        key = (id(ctx), W, H, tuple(int(b) for b in bounds))
+        ex = self._exchanges.get(key)
+        if ex is None:
+            ex = self._exchanges[key] = sdist.ListExchange(ctx, self._comm, W, H, bounds, fp.culled.device)
+        self._last_exchange = ex
+        return ex.record(fp.grid[: fp.band_tiles * 2], fp.culled)
+
+    def exchange_adapt(self):
+        """sailor_hip_exchange_adapt on the context of the last exchange (every rank, same point): {largest_band_total, clipped, slot_words, bytes_gathered}"""
+        ex = self._last_exchange
+        if ex is None:
+            return None
+        largest, clipped, slot = ex.adapt()
+        return {"largest_band_total": largest, "clipped": clipped, "slot_words": slot, "worst_case_slot_words": ex.worst_case_slot_words,
+                "bytes_gathered_per_rank": ex.bytes_gathered()}
 
     exchange_how = "sailor_hip_exchange_light_lists_rows (C-ABI: 3 x ncclAllGather on an ncclComm_t of the job's ranks + one stitch kernel)"
 
     def close(self):
+        self._exchanges.clear()
+        self._last_exchange = None
         if self._comm is not None:
             self._comm.close()
             self._comm = None
@@ -237,6 +255,48 @@ def _dev():
     if _DEV is None:
         _DEV = HipDevice(torch.cuda.current_device() if torch.cuda.is_available() else 0)
     return _DEV
+
+
+EXCHANGE_TIMED = 10   # event-timed exchanges per reading (after one on the worst-case slots and the adapt call)
+
+
+def exchange_stats(dev, do_exchange, stream, dist=None, device=None, n=EXCHANGE_TIMED):
+    """The split frame's exchange, timed: ONE exchange on the worst-case slots, sailor_hip_exchange_adapt on every rank (the slots of the
+    second gather sized from that exchange's gathered totals), then `n` exchanges, each between a HIP event pair on the launch stream.  -> (global grid,
+    global culledLights, {ms_median, ms_p90, ms_min, ms_first_worst_case_slots, bytes_gathered, ...}); the medians are the MAX over the ranks."""
+    a0, b0 = dev.event(), dev.event()
+    a0.record(stream)
+    gg, gi = do_exchange()
+    b0.record(stream)
+    dev.synchronize()
+    first_ms = a0.elapsed_time(b0)
+    adapt = dev.exchange_adapt() if hasattr(dev, "exchange_adapt") else None
+    pairs = []
+    for _ in range(n):
+        a, b = dev.event(), dev.event()
+        a.record(stream)
+        gg, gi = do_exchange()
+        b.record(stream)
+        pairs.append((a, b))
+    dev.synchronize()
+    ms = np.array([a.elapsed_time(b) for a, b in pairs])
+    after = dev.exchange_adapt() if hasattr(dev, "exchange_adapt") else None
+    med, p90, mn = float(np.median(ms)), float(np.percentile(ms, 90)), float(ms.min())
+    if dist is not None:
+        t = torch.tensor([med, p90, first_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        med, p90, first_ms = (float(v) for v in t.tolist())
+    out = {"ms_median": med, "ms_p90": p90, "ms_min": mn, "timed_exchanges": n, "ms_first_worst_case_slots": first_ms,
+           "how": "one exchange on the worst-case slots, sailor_hip_exchange_adapt on every rank, then %d exchanges each between a HIP event pair on the launch "
+                  "stream (record-only calls: nothing read back, no stream synchronisation inside); median / p90 = the max over the ranks" % n}
+    if adapt is not None:
+        out.update({"bytes_gathered": adapt["bytes_gathered_per_rank"], "slot_words": adapt["slot_words"], "worst_case_slot_words": adapt["worst_case_slot_words"],
+                    "largest_band_total": adapt["largest_band_total"], "clipped": bool(after["clipped"]) if after else None})
+    else:
+        tot = int(gi[0].item())
+        out.update({"bytes_gathered": 4 * (1 + tot) + 8 * int(gg.numel() // 2), "slot_words": None,
+                    "note": "torch.distributed stand-in (no ncclComm_t on this job): bytes_gathered = the global lists' own size"})
+    return gg, gi, out
 
 
 def event_ms(fn, steps):
@@ -1008,6 +1068,19 @@ def split_config_reading(name: str, args, dev, dist, ctx, side, side2, ctx2, ran
     out["value"] = W * H / (out["split_ms_per_step"] * 1e-3) / 1e6
     out["unit"] = "Mpixels/s"
     out["speedup_vs_one_gpu_whole_frame"] = out["whole_frame_per_gpu_ms_per_step"] / out["split_ms_per_step"]
+    # the exchange of THIS configuration's band lists, timed like the headline's (exchange_stats), and what a step with it in it would cost
+    try:
+        fx = fs[0]
+        if mode != "inline":
+            fx.pack()
+        dev.synchronize()
+        _, gi, xs = exchange_stats(dev, lambda: dev.exchange(ctx, W, H, bounds, fx), side, dist, dev.device)
+        xs["global_sum_num"] = int(gi[0].item())
+        out["exchange"] = xs
+        out["value_exchange_every_step"] = W * H / ((out["split_ms_per_step"] + xs["ms_median"]) * 1e-3) / 1e6
+        out["value_exchange_every_step_how"] = "split_ms_per_step + exchange.ms_median (the exchange behind every step on the same stream: an upper bound on its cost)"
+    except Exception as e:
+        out["exchange"] = {"error": f"{type(e).__name__}: {e}"}
     out["setup_s"] = setup_s
     return out
 
@@ -1098,6 +1171,7 @@ def main(argv=None, device_factory=None):
     band = host.band_for_rank(W, H, rank, world)
     bounds = [host.band_for_rank(W, H, r, world).tileRowBegin for r in range(world)] + [Ty]   # tile-row boundaries of the split (equal bands)
     partition = "whole frame"
+    rebalance_info = None
     # N > 1, default: ONE frame cut into tile-row bands, one per GPU (BASELINE.json's metric: strong scaling).  --frame-per-gpu: every GPU
     # takes a whole frame per step (per-GPU work fixed: weak scaling, no collective on the data path).
     weak = args.frame_per_gpu
@@ -1117,8 +1191,12 @@ def main(argv=None, device_factory=None):
         del f0, d0
         # ... then re-cut on MEASURED band times (sdist.rebalance_on_measured_times: a renderer re-cuts on the previous frame's): every rank times its
         # band's cull + shade (eager, one stream), all ranks learn all times, the boundaries move; `--rebalance` rounds.  Not in the timed region.
+        # A re-cut is KEPT only if the slowest band it gives measures faster than the best cut so far (the readings are ten eager steps on one
+        # stream, not the two-frames-in-flight graph that is timed below -- a noisy reading must not move the headline onto worse bounds; simulate_split
+        # applies the same rule).  `rebalance_log` = the slowest band's ms of every cut measured, in order; the first entry is the model's balanced cut.
         rebalanced = 0
-        for _ in range(args.rebalance):
+        best_bounds, best_max, rebalance_log = list(bounds), None, []
+        for it in range(args.rebalance + 1):
             fb, db = resident(band)
             sb = dev.upload(frame.surface_rows(band.fbRowBegin, band.fbRowBegin + band.fbRowCount))
 
@@ -1132,11 +1210,23 @@ def main(argv=None, device_factory=None):
             t[rank] = event_batch_ms(band_step, 10)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             del fb, db, sb
+            worst = float(t.max())
+            rebalance_log.append(round(worst, 4))
+            if best_max is None or worst < best_max:
+                best_bounds, best_max = list(bounds), worst
+            if it == args.rebalance:
+                break
             new = [int(b) for b in sdist.rebalance_on_measured_times(bounds, t.tolist(), rows_entries, Tx)]
             if new == bounds:
                 break
             bounds, rebalanced = new, rebalanced + 1
             band = host.band_from_tile_rows(W, H, bounds[rank], bounds[rank + 1])
+        if args.rebalance > 0:
+            kept = best_bounds != bounds
+            bounds = best_bounds
+            band = host.band_from_tile_rows(W, H, bounds[rank], bounds[rank + 1])
+            rebalance_info = {"slowest_band_ms_per_cut": rebalance_log, "slowest_band_ms_balanced": rebalance_log[0], "slowest_band_ms_kept": round(best_max, 4),
+                              "cuts_measured": len(rebalance_log), "kept": "an earlier cut (the last re-cut measured slower)" if kept else "the last cut measured"}
         partition = f"cost-balanced tile rows {bounds}" + (f" (re-cut {rebalanced}x on measured band times)" if rebalanced else "")
     elif world > 1:
         partition = "equal tile rows"
@@ -1523,8 +1613,7 @@ def main(argv=None, device_factory=None):
                 split_elapsed = float(t.item())
                 if pack_mode == "never":
                     bf.pack()
-                gg, gi = dev.exchange(ctx, W, H, sbounds, bf)
-                dev.synchronize()
+                gg, gi, sx_stats = exchange_stats(dev, lambda: dev.exchange(ctx, W, H, sbounds, bf), side, dist, device)
                 tot = int(gi[0].item())
                 split = {"what": "ONE frame split into cost-balanced tile-row bands, one band per GPU; cull and shade need no collective, an RCCL all-gather "
                                  "rebuilds the reference's global lists for consumers that want them (outside the timed steps)",
@@ -1532,14 +1621,47 @@ def main(argv=None, device_factory=None):
                          "ms_per_step": split_elapsed / args.steps * 1e3, "speedup_vs_one_gpu_whole_frame": ms_per_step / (split_elapsed / args.steps * 1e3),
                          "tile_row_bounds": sbounds,
                          "exchange": {"global_sum_num": tot, "checksum": int(gi[1:1 + tot].to(torch.int64).sum().item()), "tiles": int(gg.numel() // 2), "how": dev.exchange_how}}
+                split["exchange"].update(sx_stats)
 
     exchange_info = None
+    exchange_step = None
     if dist is not None and not weak:
-        gg, gi = exchange()
-        dev.synchronize()
+        gg, gi, ex_stats = exchange_stats(dev, exchange, side, dist, device)
         tot = int(gi[0].item())
         exchange_info = {"global_sum_num": tot, "checksum": int(gi[1:1 + tot].to(torch.int64).sum().item()), "tiles": int(gg.numel() // 2), "how": dev.exchange_how,
                          "tile_row_bounds": bounds}
+        exchange_info.update(ex_stats)
+        # ... and the step WITH the exchange in it (a consumer that wants the global lists of every frame): one frame in flight -- cull chain with k1_pack,
+        # shade, exchange -- against the same form without the exchange; the kernels of the step replayed from a hipGraph, the exchange's calls recorded
+        # behind every replay (eagerly: whether three RCCL collectives may sit in a hipGraph on a node is not something this box can try at N > 1)
+        if world > 1 and not args.exchange_every_step and not args.single_mode:
+            def step_kernels():
+                cull_of(fp, None, dynamic, False)
+                shade()
+            run_k = step_kernels
+            if not args.no_graph:
+                try:
+                    step_kernels(); dev.synchronize()
+                    run_k = dev.capture(side, step_kernels).replay
+                except Exception:
+                    dev.synchronize()
+            def timed_steps(fn):   # (a fixed number of calls on every rank -- the exchange is collective; no time-based spin-up here)
+                for _ in range(max(args.warmup, 2)):
+                    fn()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    fn()
+                barrier()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t.item())
+            el_x = timed_steps(lambda: (run_k(), exchange()))
+            el_n = timed_steps(run_k)
+            exchange_step = {"value_exchange_every_step": W * H * args.steps / el_x / 1e6, "ms_per_step_exchange_every_step": el_x / args.steps * 1e3,
+                             "ms_per_step_same_form_without_exchange": el_n / args.steps * 1e3,
+                             "form": "one frame in flight: cull chain (k1_pack inline) + shade" + (" replayed from a hipGraph" if run_k is not step_kernels else " launched eagerly") +
+                                     ", the exchange's calls recorded behind every step; K steps between barriers, max over ranks"}
 
     # ---- N > 1: the other configurations BASELINE.json names for a node (C4, C5), bounded, and K4 across the ranks beside K4 replicated
     split_configs = None
@@ -1563,7 +1685,7 @@ def main(argv=None, device_factory=None):
             "scaling": "weak" if weak else "strong", "launch": launch, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H}, {N} point+spot lights" + (" (all dirty every frame)" if dynamic else "") + f", 16x16 tiles ({fp.Tx}x{fp.Ty}), cull + PBR shade"
                                    + (" + 4-cascade CSM" if csm is not None else ""),
-                       "width": W, "height": H, "lights": N, "parallelism": (f"dp{world}: a whole frame per GPU" if weak else f"tile-row bands x{world}"), "partition": partition,
+                       "width": W, "height": H, "lights": N, "parallelism": (f"dp{world}: a whole frame per GPU" if weak else f"tile-row bands x{world}"), "partition": partition, "rebalance": rebalance_info,
                        "mean_list_length": sum_nt / max(fp.band_tiles, 1), "sum_num_rank0_band": sum_nt, "distinct_lights_rank0_band": distinct,
                        "generator": {"seed": synth.SEED, "radius_scale": frame.cfg["lights"].radius_scale}},
             "lights": {"mode": mode, "prepare_lights_ms": prepare_ms,
@@ -1590,6 +1712,8 @@ def main(argv=None, device_factory=None):
             out["ms_per_step_" + ("static" if dynamic else "dynamic")] = other_mode["ms_per_step"]
         if exchange_info:
             out["exchange"] = exchange_info
+        if exchange_step:
+            out.update(exchange_step)
         if afr:
             out["alternate_frame_rendering"] = afr
             if "ms_per_frame_per_gpu" in afr:

@@ -317,8 +317,9 @@ SAILOR_HIP_API int sailor_hip_light_cull_pack(SailorHipContext* ctx, int32_t wid
  * cluster keeps one block busy ~100x longer than an average one.  This returns the band's per-tile list lengths as BYTES (T bytes, tile order, <= 128 each;
  * every sailor_hip_light_cull writes them beside tileNum -- nothing extra, no atomics: round 4's form, a list of the long tiles appended through two
  * device-scope counters, cost the cull up to 12.7 us on half a 4K frame).  Handing the pointer to sailor_hip_shade_ex (band smaller than the frame, no
- * ambient term; with or without shadow maps) switches the BAND FORM of the launch on: the tiles with >= 40 lights go to "split" blocks -- one per (tile, 8x8
- * quadrant), four waves sharing the quadrant's list -- at the front of the grid, which find them in these bytes.  Lists and every tile with < 40 lights keep
+ * ambient term; with or without shadow maps) switches the BAND FORM of the launch on: the tiles with at least `splitMin` lights -- 64 on a band of up to
+ * 12 000 tiles, 96 on a larger one; SAILOR_SPLIT_MIN=<1..128> overrides for A / B runs -- go to "split" blocks -- one per (tile, 8x8
+ * quadrant), four waves sharing the quadrant's list -- at the front of the grid, which find them in these bytes.  Lists and every tile below the threshold keep
  * their bits; a split tile's radiance differs from the one-block form by the order of four partial sums per pixel (within the shade tolerance).  With the
  * ambient term the pointer is ignored.  NULL for the whole-frame band (on the whole frame the split measured no gain), for a band of more than 12 000
  * tiles when lightsCapacity >= 131 072 (short lists, no long tiles to split: the whole frame's launch form pipelines better there) and on bad arguments.  Valid until
@@ -515,7 +516,9 @@ SAILOR_HIP_API int sailor_hip_ecs_sweep(SailorHipContext* ctx, uint32_t numEntit
  * matrices and is refused unless the slice is the whole set (SAILOR_HIP_ERR_UNSUPPORTED: sweep it replicated).
  * sailor_hip_ecs_range_for_rank: rank r's slice of an equal split in whole 64-entity visibility words, ceil(words / worldSize) = *outWordsPerRank per
  * rank (the last ranks may get fewer entities, or none).  sailor_hip_exchange_visibility: ONE in-place ncclAllGather of those words on `comm` and the
- * context's stream -- dVisibility must hold worldSize * wordsPerRank uint64 -- after which every rank holds the whole bitmask (C5: 128 KB).  World
+ * context's stream -- dVisibility must hold worldSize * wordsPerRank uint64, which is MORE than sailor_hip_ecs_sweep's ceil(n / 64) when the words do
+ * not divide evenly (n = 100 on 8 ranks: 8 words, not 2); `visibilityWords` is the buffer's capacity in uint64 and a smaller one is refused
+ * (SAILOR_HIP_ERR_INVALID_ARGUMENT) instead of overrun -- after which every rank holds the whole bitmask (C5: 128 KB).  World
  * matrices and boxes stay where they were computed: a consumer that needs ALL of them on every rank (instance data for draws) is better served by the
  * replicated sweep -- 64 B + 24 B per entity over xGMI cost more than the 38 us the whole sweep takes on one GPU. */
 SAILOR_HIP_API int sailor_hip_ecs_sweep_range(SailorHipContext* ctx, uint32_t numEntities,
@@ -527,7 +530,7 @@ SAILOR_HIP_API int sailor_hip_ecs_sweep_range(SailorHipContext* ctx, uint32_t nu
 SAILOR_HIP_API int sailor_hip_ecs_range_for_rank(uint32_t numEntities, int32_t rank, int32_t worldSize, uint32_t* outBegin, uint32_t* outEnd,
                                                  uint32_t* outWordsPerRank /* or NULL */);
 SAILOR_HIP_API int sailor_hip_exchange_visibility(SailorHipContext* ctx, void* comm, int32_t rank, int32_t worldSize, uint32_t numEntities,
-                                                  uint64_t* dVisibility);
+                                                  uint64_t* dVisibility, size_t visibilityWords);
 
 #define SAILOR_RASTER_CLEAR 1u
 #define SAILOR_RASTER_CULL_BACK 2u
@@ -619,8 +622,9 @@ SAILOR_HIP_API int sailor_hip_allgather_u32(SailorHipContext* ctx, void* comm, c
  * buffers, a split frame has one pair per band): every rank hands in the lists of its band (sailor_hip_band_for_rank(width, height, rank,
  * worldSize), as sailor_hip_light_cull left them) and gets the reference's global `lightsGrid` (tiles x {offset, num}) and `culledLights`
  * ([0] = sum of num, then the lists at the canonical offsets) -- three ncclAllGather on the context's stream (band total; index segments in slots
- * of the largest band's total; grid) and one stitch kernel that takes each band's global base from the gathered totals on the device.  The
- * gathered totals are read back once (a few words and a stream synchronisation) to size the second gather: the call must not be stream-captured.
+ * sized by sailor_hip_exchange_adapt from an earlier exchange's totals, or of the worst case; grid) and one stitch kernel that takes each band's global
+ * base from the gathered totals on the device.  The call only RECORDS (round 6; round 5 read the gathered totals back and synchronised the stream to
+ * size the second gather): nothing is read back, nothing waits, and it may be captured into a hipGraph.
  *   comm          : an ncclComm_t of `worldSize` ranks created by the host (RCCL over xGMI)
  *   dGlobalCulled : globalCapacity uints, 1 + tiles * 128 holds every result
  *   dWorkspace    : sailor_hip_exchange_workspace_size(width, height, worldSize) bytes, 256-byte aligned */
@@ -649,6 +653,17 @@ SAILOR_HIP_API int sailor_hip_stitch_light_lists_rows(SailorHipContext* ctx, int
                                                       const uint32_t* dTotals, const uint32_t* dSegments, size_t segmentCapacity, const uint32_t* dGrids,
                                                       size_t gridCapacity, SailorLightsGrid* dGlobalGrid, size_t globalGridTiles, uint32_t* dGlobalCulled,
                                                       size_t globalCapacity);
+
+/* The slot size of the exchange's second gather.  A context starts with the worst case (tiles of the largest band x 128 indices per rank: 16.7 MB gathered
+ * per rank at C3 / 8 ranks for ~3 MB of lists).  sailor_hip_exchange_adapt is the exchange's one SYNCHRONISING call (like sailor_hip_context_synchronize):
+ * it waits for the last exchange recorded through `ctx` -- its own event, not the stream's later work -- reads the three status words that exchange's
+ * stitch kernel left in pinned host memory, and sizes the next exchange's slots from the largest band total it gathered (+ 25 %, whole 256-byte lines).
+ * If that exchange was CLIPPED -- a band's total had outgrown a slot sized from an earlier frame: its global lists are incomplete -- *outClipped is 1, the
+ * context's error text says which, and the next exchange goes back to the worst case.  The totals are the same on every rank, so the slot sizes are too,
+ * PROVIDED every rank of the communicator calls this at the same point of its call sequence (the HIP backend: in front of every exchange but the first).
+ * sailor_hip_exchange_set_slot_words sets the size explicitly (0 = the worst case).  Outputs may be NULL. */
+SAILOR_HIP_API int sailor_hip_exchange_adapt(SailorHipContext* ctx, uint32_t* outLargestBandTotal, int32_t* outClipped, size_t* outSlotWords);
+SAILOR_HIP_API int sailor_hip_exchange_set_slot_words(SailorHipContext* ctx, size_t slotWords);
 
 /* ---- host-side math of the path (pure CPU, no device needed) ----------------------------------------------- */
 /* Math/Math.cpp:18-21 PerspectiveRH (reversed Z) */

@@ -153,7 +153,9 @@ SIGNATURES = {
     "sailor_hip_ecs_sweep": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_uint32), C.c_uint32, _P, C.POINTER(C.c_float), _P, _P, _P]),
     "sailor_hip_ecs_sweep_range": (C.c_int, [_P, C.c_uint32, _P, _P, C.POINTER(C.c_uint32), C.c_uint32, _P, C.POINTER(C.c_float), _P, _P, _P, C.c_uint32, C.c_uint32]),
     "sailor_hip_ecs_range_for_rank": (C.c_int, [C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
-    "sailor_hip_exchange_visibility": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_uint32, _P]),
+    "sailor_hip_exchange_adapt": (C.c_int, [_P, _P, _P, _P]),
+    "sailor_hip_exchange_set_slot_words": (C.c_int, [_P, C.c_size_t]),
+    "sailor_hip_exchange_visibility": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_uint32, _P, C.c_size_t]),
     "sailor_hip_mesh_frustum_cull": (C.c_int, [_P, C.POINTER(UboFrameData), _P, C.c_uint32, C.c_uint32]),
     "sailor_hip_raster_coarse_words": (C.c_size_t, [C.c_int32, C.c_int32]),
     "sailor_hip_raster_depth": (C.c_int, [_P, C.POINTER(C.c_float), _P, _P, C.c_uint32, _P, _P, C.c_uint32, C.c_int32, C.c_int32, _P, C.c_uint32, _P]),

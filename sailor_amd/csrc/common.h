@@ -28,6 +28,15 @@ struct SailorHipContext {
     // sailor_hip_context_launch_log: how many kernels the path's entry points have launched through this context, and the names of the last few
     uint64_t launchCount = 0, launchNoted = 0;
     const char* launchNames[16] = {};
+    // the split frame's exchange (exchange.hip): the slot size of its second gather is kept from one exchange to the next, so that the call itself never reads
+    // anything back.  exchangeStatus = three words of pinned host memory the stitch kernel writes: [0] the number of the exchange it belongs to, [1] the largest
+    // band total that exchange gathered, [2] 1 if a band's segment was clipped to its slot.  sailor_hip_exchange_adapt reads them (behind exchangeEvent).
+    uint32_t* exchangeStatus = nullptr;
+    uint32_t exchangeSeq = 0;          // exchanges recorded through this context
+    size_t exchangeLastSegCount = 0;   // the slot size the last recorded exchange used
+    size_t exchangeSegHint = 0;        // slot size (uint32) of the next exchange's second gather; 0 = the worst case (tiles of the largest band x 128)
+    hipEvent_t exchangeEvent = nullptr;
+    bool exchangeEventValid = false;   // (an exchange recorded under stream capture leaves no event to wait on: adapt then waits for the stream)
 };
 
 static inline int sailor_map_hip_error(SailorHipContext* ctx, hipError_t e, const char* what)

@@ -59,6 +59,8 @@ int sailor_hip_context_destroy(SailorHipContext* ctx)
     if (!ctx) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (ctx->ownsStream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (ctx->orderEvent) (void)hipEventDestroy(ctx->orderEvent);
+    if (ctx->exchangeEvent) (void)hipEventDestroy(ctx->exchangeEvent);
+    if (ctx->exchangeStatus) (void)hipHostFree(ctx->exchangeStatus);
     for (hipEvent_t e : ctx->timeStart) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->timeStop) (void)hipEventDestroy(e);
     delete ctx;

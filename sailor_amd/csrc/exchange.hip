@@ -67,12 +67,15 @@ extern "C" int sailor_hip_allgather_u32(SailorHipContext* ctx, void* comm, const
 // ---- K4 split across the ranks ("Entities: contiguous index ranges ... one all-gather of the visibility bitmask"): every rank has swept
 // its slice (sailor_hip_ecs_range_for_rank / sailor_hip_ecs_sweep_range: whole 64-entity words, the same number per rank) into ITS part of dVisibility;
 // one in-place ncclAllGather completes the bitmask on every rank.  dVisibility holds worldSize * wordsPerRank uint64.
-extern "C" int sailor_hip_exchange_visibility(SailorHipContext* ctx, void* comm, int32_t rank, int32_t worldSize, uint32_t numEntities, uint64_t* dVisibility)
+extern "C" int sailor_hip_exchange_visibility(SailorHipContext* ctx, void* comm, int32_t rank, int32_t worldSize, uint32_t numEntities, uint64_t* dVisibility,
+                                              size_t visibilityWords)
 {
     if (!ctx || !comm || !dVisibility || worldSize <= 0 || rank < 0 || rank >= worldSize) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     uint32_t b = 0, e = 0, per = 0;
     if (sailor_hip_ecs_range_for_rank(numEntities, rank, worldSize, &b, &e, &per) != SAILOR_HIP_OK) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
     if (per == 0) return SAILOR_HIP_OK;
+    // (the gather writes worldSize * per words: more than ceil(n / 64) when the words do not divide evenly -- ADVICE r05)
+    if (visibilityWords < (size_t)worldSize * per) { ctx->lastError = "sailor_hip_exchange_visibility: dVisibility holds fewer than worldSize * wordsPerRank words"; return SAILOR_HIP_ERR_INVALID_ARGUMENT; }
     // (in place: a rank's send buffer is its own slot of the receive buffer, which is what ncclAllGather's in-place form asks for)
     return sailor_hip_allgather_u32(ctx, comm, (const uint32_t*)(dVisibility + (size_t)rank * per), (uint32_t*)dVisibility, (size_t)per * 2);
 }
@@ -88,6 +91,7 @@ struct StitchArgs {
     uint32_t* outGrid; uint32_t* outCulled;
     uint32_t world, segCap, gridCap, outCapacity;
     uint32_t tiles[SAILOR_MAX_SPLIT + 1]; // prefix sums of the bands' tile counts
+    uint32_t* status; uint32_t seq;       // the exchange's three status words in pinned host memory (SailorHipContext::exchangeStatus) or null, and its number
 };
 
 __global__ __launch_bounds__(256) void k_stitch_lists(const StitchArgs a)
@@ -105,7 +109,17 @@ __global__ __launch_bounds__(256) void k_stitch_lists(const StitchArgs a)
         a.outGrid[2u * (t0 + i)] = off + base; // Appendix A step 6: canonical global offsets
         a.outGrid[2u * (t0 + i) + 1u] = num;
     }
-    if (r == 0 && first == 0) a.outCulled[0] = all < a.outCapacity - 1u ? all : a.outCapacity - 1u; // what was written: segments are clipped to the capacity
+    if (r == 0 && first == 0) {
+        a.outCulled[0] = all < a.outCapacity - 1u ? all : a.outCapacity - 1u; // what was written: segments are clipped to the capacity
+        if (a.status) { // what sailor_hip_exchange_adapt sizes the NEXT exchange's slots from; a band whose total did not fit its slot arrived clipped
+            uint32_t largest = 0;
+            for (uint32_t q = 0; q < a.world; q++) largest = a.totals[q] > largest ? a.totals[q] : largest;
+            a.status[1] = largest;
+            a.status[2] = largest > a.segCap ? 1u : 0u;
+            __threadfence_system();
+            __hip_atomic_store(&a.status[0], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 static size_t exchange_workspace_bytes(int32_t worldSize, size_t maxTiles)
@@ -146,10 +160,22 @@ extern "C" int sailor_hip_stitch_light_lists(SailorHipContext* ctx, int32_t widt
                                               (size_t)Tx * Ty, dGlobalCulled, globalCapacity);
 }
 
+static int stitch_rows(SailorHipContext* ctx, int32_t width, int32_t height, int32_t worldSize, const int32_t* tileRowBounds, const uint32_t* dTotals,
+                       const uint32_t* dSegments, size_t segmentCapacity, const uint32_t* dGrids, size_t gridCapacity, SailorLightsGrid* dGlobalGrid,
+                       size_t globalGridTiles, uint32_t* dGlobalCulled, size_t globalCapacity, uint32_t* status, uint32_t seq);
+
 extern "C" int sailor_hip_stitch_light_lists_rows(SailorHipContext* ctx, int32_t width, int32_t height, int32_t worldSize, const int32_t* tileRowBounds,
                                                   const uint32_t* dTotals, const uint32_t* dSegments, size_t segmentCapacity, const uint32_t* dGrids,
                                                   size_t gridCapacity, SailorLightsGrid* dGlobalGrid, size_t globalGridTiles, uint32_t* dGlobalCulled,
                                                   size_t globalCapacity)
+{
+    return stitch_rows(ctx, width, height, worldSize, tileRowBounds, dTotals, dSegments, segmentCapacity, dGrids, gridCapacity, dGlobalGrid, globalGridTiles, dGlobalCulled,
+                       globalCapacity, nullptr, 0u);
+}
+
+static int stitch_rows(SailorHipContext* ctx, int32_t width, int32_t height, int32_t worldSize, const int32_t* tileRowBounds, const uint32_t* dTotals,
+                       const uint32_t* dSegments, size_t segmentCapacity, const uint32_t* dGrids, size_t gridCapacity, SailorLightsGrid* dGlobalGrid,
+                       size_t globalGridTiles, uint32_t* dGlobalCulled, size_t globalCapacity, uint32_t* status, uint32_t seq)
 {
     if (!ctx || !dTotals || !dSegments || !dGrids || !dGlobalGrid || !dGlobalCulled || width <= 0 || height <= 0 || worldSize < 1 || worldSize > SAILOR_MAX_SPLIT)
         return SAILOR_HIP_ERR_INVALID_ARGUMENT;
@@ -164,6 +190,7 @@ extern "C" int sailor_hip_stitch_light_lists_rows(SailorHipContext* ctx, int32_t
     a.totals = dTotals; a.segments = dSegments; a.grids = dGrids; a.outGrid = (uint32_t*)dGlobalGrid; a.outCulled = dGlobalCulled;
     a.world = (uint32_t)worldSize; a.segCap = (uint32_t)segmentCapacity; a.gridCap = (uint32_t)gridCapacity;
     a.outCapacity = (uint32_t)(globalCapacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : globalCapacity);
+    a.status = status; a.seq = seq;
     a.tiles[0] = 0;
     uint32_t maxTiles = 1;
     for (int r = 0; r < worldSize; r++) {
@@ -231,19 +258,74 @@ extern "C" int sailor_hip_exchange_light_lists_rows(SailorHipContext* ctx, void*
     SAILOR_CHECK_LAUNCH(ctx, "k_pad_copy");
     int rc = sailor_hip_allgather_u32(ctx, comm, dBandCulled, totals, 1);             // collective 1: band totals
     if (rc != SAILOR_HIP_OK) return rc;
-    // Collective 2 is sized by collective 1: the index segments travel as slots of the LARGEST band's total (every rank reads the same gathered
-    // totals, so every rank arrives at the same count), not of the worst case maxTiles * 128 -- 16.7 MB per rank at C3 for ~3 MB of lists.  This
-    // is the exchange's one host read (a few words, then a stream synchronisation); the exchange is off the per-frame data path.
-    uint32_t hTotals[SAILOR_MAX_SPLIT];
-    SAILOR_TRY_HIP(ctx, hipMemcpyAsync(hTotals, totals, (size_t)worldSize * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SAILOR_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    size_t segCount = 1;
-    for (int r = 0; r < worldSize; r++) segCount = hTotals[r] > segCount ? hTotals[r] : segCount;
-    segCount = (segCount + 63) / 64 * 64;          // (whole 256-byte lines)
-    if (segCount > segCap) segCount = segCap;      // (a band's total cannot exceed its tiles' worst case; a corrupt total must not overrun the slots)
+    // Collective 2: the index segments travel in slots of ctx->exchangeSegHint words -- what sailor_hip_exchange_adapt made of an EARLIER exchange's gathered
+    // totals (every rank read the same totals there, so every rank arrives at the same count) -- or, until that has been called, of the worst case
+    // maxTiles * 128: 16.7 MB per rank at C3 for ~3 MB of lists.  Nothing is read back here and nothing waits (round 5 read the totals of collective 1 and
+    // synchronised the stream to size collective 2): the call only records, and can be captured into a hipGraph.  A band whose total outgrew the slot
+    // arrives clipped; the stitch kernel notes that in the context's status words and the next sailor_hip_exchange_adapt reports it and widens the slots.
+    size_t segCount = ctx->exchangeSegHint ? ctx->exchangeSegHint : segCap;
+    if (segCount > segCap) segCount = segCap;      // (a band's total cannot exceed its tiles' worst case)
     rc = sailor_hip_allgather_u32(ctx, comm, sendSeg, segments, segCount);             // collective 2: index segments, stride segCount
     if (rc == SAILOR_HIP_OK) rc = sailor_hip_allgather_u32(ctx, comm, sendGrid, grids, gridCap);    // (the grids, 8 bytes per tile)
     if (rc != SAILOR_HIP_OK) return rc;
-    return sailor_hip_stitch_light_lists_rows(ctx, width, height, worldSize, tileRowBounds, totals, segments, segCount, grids, gridCap, dGlobalGrid, globalGridTiles,
-                                              dGlobalCulled, globalCapacity);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (!ctx->exchangeStatus && !capturing) { // (three words of pinned host memory, once per context; a first exchange recorded under capture goes without)
+        SAILOR_TRY_HIP(ctx, hipHostMalloc((void**)&ctx->exchangeStatus, 64, hipHostMallocDefault));
+        ctx->exchangeStatus[0] = ctx->exchangeStatus[1] = ctx->exchangeStatus[2] = 0u;
+    }
+    ctx->exchangeSeq++;
+    ctx->exchangeLastSegCount = segCount;
+    rc = stitch_rows(ctx, width, height, worldSize, tileRowBounds, totals, segments, segCount, grids, gridCap, dGlobalGrid, globalGridTiles, dGlobalCulled, globalCapacity,
+                     ctx->exchangeStatus, ctx->exchangeSeq);
+    if (rc != SAILOR_HIP_OK) return rc;
+    ctx->exchangeEventValid = false;
+    if (!capturing) {
+        if (!ctx->exchangeEvent) SAILOR_TRY_HIP(ctx, hipEventCreateWithFlags(&ctx->exchangeEvent, hipEventDisableTiming));
+        SAILOR_TRY_HIP(ctx, hipEventRecord(ctx->exchangeEvent, ctx->stream));
+        ctx->exchangeEventValid = true;
+    }
+    return SAILOR_HIP_OK;
+}
+
+// The one synchronising call of the exchange: waits for the LAST exchange recorded through this context (its event; the whole stream if that exchange was
+// captured), reads the three status words its stitch kernel left, and sizes the next exchange's slots from the largest band total it gathered: + 25 %,
+// whole 256-byte lines.  If that exchange was clipped (a band outgrew a slot sized from an earlier frame) the next one goes back to the worst case, the
+// call says so through *outClipped and the context's error text, and the call after it adapts again.  Every rank of the communicator must call this at the
+// same point of its call sequence: the totals -- hence the slot sizes -- are the same on every rank, and only then do the ranks' gathers agree.
+extern "C" int sailor_hip_exchange_adapt(SailorHipContext* ctx, uint32_t* outLargestBandTotal, int32_t* outClipped, size_t* outSlotWords)
+{
+    if (!ctx) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    if (outLargestBandTotal) *outLargestBandTotal = 0;
+    if (outClipped) *outClipped = 0;
+    if (outSlotWords) *outSlotWords = ctx->exchangeSegHint;
+    if (ctx->exchangeSeq == 0 || !ctx->exchangeStatus) return SAILOR_HIP_OK; // nothing exchanged yet: the worst case stays
+    SAILOR_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->exchangeEventValid) SAILOR_TRY_HIP(ctx, hipEventSynchronize(ctx->exchangeEvent));
+    else SAILOR_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t seq = __atomic_load_n(&ctx->exchangeStatus[0], __ATOMIC_ACQUIRE);
+    if (seq != ctx->exchangeSeq) return SAILOR_HIP_OK; // (a captured exchange that has not been replayed yet: nothing new to learn)
+    const uint32_t largest = ctx->exchangeStatus[1], clipped = ctx->exchangeStatus[2];
+    if (outLargestBandTotal) *outLargestBandTotal = largest;
+    if (outClipped) *outClipped = (int32_t)clipped;
+    if (clipped) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "exchange #%u: a band total of %u did not fit its slot of %zu indices; the next exchange uses the worst-case slots", seq, largest,
+                 ctx->exchangeLastSegCount);
+        ctx->lastError = buf;
+        ctx->exchangeSegHint = 0;
+    } else {
+        size_t want = (size_t)largest + (size_t)largest / 4 + 1;
+        ctx->exchangeSegHint = (want + 63) / 64 * 64;
+    }
+    if (outSlotWords) *outSlotWords = ctx->exchangeSegHint;
+    return SAILOR_HIP_OK;
+}
+
+// an explicit slot size (0: the worst case) -- for a host that knows its lists, and for the tests
+extern "C" int sailor_hip_exchange_set_slot_words(SailorHipContext* ctx, size_t slotWords)
+{
+    if (!ctx) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    ctx->exchangeSegHint = slotWords ? (slotWords + 63) / 64 * 64 : 0;
+    return SAILOR_HIP_OK;
 }

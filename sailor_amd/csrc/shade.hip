@@ -355,7 +355,11 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
     A.fbRow0 = band->fbRowBegin;
     A.fbRows = band->fbRowCount;
     A.lightsNum = lightsNum;
-    static const int splitMinEnv = [] { const char* e = getenv("SAILOR_SPLIT_MIN"); return e ? atoi(e) : -1; }();
+    // (A / B knobs, read once; a value outside its range is ignored and says so: [1, 128] -- a list has at most 128 entries)
+    static const int splitMinRaw = [] { const char* e = getenv("SAILOR_SPLIT_MIN"); return e ? atoi(e) : -1; }();
+    static const bool splitMinSet = getenv("SAILOR_SPLIT_MIN") != nullptr;
+    const int splitMinEnv = (splitMinRaw >= 1 && splitMinRaw <= KEEP) ? splitMinRaw : -1;
+    if (splitMinSet && splitMinEnv < 0) ctx->lastError = "SAILOR_SPLIT_MIN outside [1, 128]: ignored";
     A.order = reinterpret_cast<const uint8_t*>(dTileOrder); // (the band's list lengths as bytes: sailor_hip_light_cull_tile_order)
     const int bandTiles = (band->tileRowEnd - band->tileRowBegin) * A.Tx;
     if (bandTiles == 0) return SAILOR_HIP_OK;
@@ -410,7 +414,11 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
     // For bands of up to three rounds of resident blocks (an eighth of the 4K frame is two) -- a larger band is bound by the shade's throughput like the
     // whole frame, and the cap costs it what it costs there (half the 4K frame: 108 -> 120 us per step) -- and for any band under a large light set, whose
     // cull chain is as long as its shade (an eighth of the 8K frame under a million lights: 16 320 tiles, 80 us of cull beside 78 us of shade; 152 -> 134 us).
-    static const int bandLdsEnv = [] { const char* e = getenv("SAILOR_BAND_SHADE_LDS"); return e ? atoi(e) : -1; }();
+    static const int bandLdsRaw = [] { const char* e = getenv("SAILOR_BAND_SHADE_LDS"); return e ? atoi(e) : -1; }();
+    static const bool bandLdsSet = getenv("SAILOR_BAND_SHADE_LDS") != nullptr;
+    // (a launch may claim 64 KB of LDS in all; the kernels' static ShadeLds comes off that)
+    const int bandLdsEnv = (bandLdsRaw >= 0 && (size_t)bandLdsRaw + sizeof(ShadeLds) <= 65536u) ? bandLdsRaw : -1;
+    if (bandLdsSet && bandLdsEnv < 0) ctx->lastError = "SAILOR_BAND_SHADE_LDS negative or beyond 64 KB minus the kernel's own LDS: ignored";
     // (round 5: NOT for the shadowed band kernels -- seven waves per SIMD by their registers, so a CU's eighth block slot is the chain's already; capped at six
     // an eighth of C4 took 62.2 us per step instead of 56.8: profiles/r05/ab_band_csm_waves.txt, probe Q)
     const bool reserve = (bandTiles <= 3 * 8 * ctx->numCUs || lightsNum >= 131072) && !(hasCsm && splitBand);

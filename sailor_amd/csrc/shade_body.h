@@ -120,8 +120,8 @@ __device__ __forceinline__ float sample_r16_pairs(const __half* __restrict__ map
 // every lane of every request is a line of its own), not by bytes or arithmetic.  A tap's footprint origin is floor(frac + offset) texels from the
 // centre's, i.e. one of TWO compile-time positions per axis: the selection is four conditional moves on row dwords and one funnel shift per row.  Same
 // texels, same weights (the tap's own bilinear_taps arithmetic), same lerp2 as sample_r: same bits.  The sum of sixteen 0 / 1 terms is exact in any order.
-// Lanes whose window would cross the map's left / right edge, and any wave in which a tap's origin is not where the arithmetic above puts it (never seen;
-// the guard costs two instructions a tap), take the tap-by-tap path below.
+// Lanes whose window would cross the map's left / right edge and maps larger than PCF_WINDOW_MAX_SIZE take the tap-by-tap path below.  There is NO per-tap
+// guard on the origin: that it is one of the two positions is arithmetic (see PCF_WINDOW_MAX_SIZE), and the size limit is what the arithmetic needs.
 // Register budget (the K3 kernels sit at exactly 64): the window is walked in two phases of four rows -- taps whose footprints start in window rows 0-1, then
 // rows 2-3 -- so twelve dwords are live, not eighteen (the tap-by-tap path holds sixteen).  The disk happens to put each of the four column origins exactly
 // once into each of the four row origins: ordered that way, tap j of either phase has the same compile-time origin (column j & 3, row j >> 2 of the phase's

@@ -248,6 +248,56 @@ class RcclComm:
             self.handle = None
 
 
+class ListExchange:
+    """The split frame's exchange with its buffers kept: workspace and the two global buffers are allocated once, record() only RECORDS on the
+    context's stream (sailor_hip_exchange_light_lists_rows: three ncclAllGather + one stitch kernel; nothing read back, nothing waits), adapt() is the
+    one synchronising call (sailor_hip_exchange_adapt: waits for the last recorded exchange, sizes the next one's slots from its gathered totals).
+    Every rank must call record / adapt in the same order."""
+
+    def __init__(self, ctx, comm: "RcclComm", width: int, height: int, tile_row_bounds, device):
+        import numpy as np
+
+        from . import _lib
+        self.ctx, self.comm, self.W, self.H = ctx, comm, width, height
+        self.world = comm.world_size
+        self.bounds = np.ascontiguousarray(tile_row_bounds, np.int32)
+        assert len(self.bounds) == self.world + 1
+        self.Tx, self.Ty = host.num_tiles(width, height)
+        need = ctx._lib.sailor_hip_exchange_workspace_size_rows(width, height, self.world, self.bounds.ctypes.data)
+        if need == 0:
+            raise ValueError(f"invalid tile-row bounds {self.bounds.tolist()} for {width}x{height} over {self.world} ranks")
+        self.ws = torch.empty(need, dtype=torch.uint8, device=device)
+        self.out_grid = torch.zeros(self.Tx * self.Ty * 2, dtype=torch.int32, device=device)
+        self.out_culled = torch.zeros(1 + self.Tx * self.Ty * _lib.LIGHTS_PER_TILE, dtype=torch.int32, device=device)
+        self.max_tiles = int(max(self.bounds[1:] - self.bounds[:-1])) * self.Tx
+        self.worst_case_slot_words = self.max_tiles * _lib.LIGHTS_PER_TILE
+        self.slot_words = 0   # what the context will use for the next record(): 0 = the worst case
+
+    def record(self, band_grid: torch.Tensor, band_culled: torch.Tensor):
+        from . import _lib
+        lib = self.ctx._lib
+        _lib.check(lib.sailor_hip_exchange_light_lists_rows(self.ctx.handle, self.comm.handle, self.comm.rank, self.world, self.W, self.H, self.bounds.ctypes.data,
+                                                             band_grid.data_ptr(), band_culled.data_ptr(), self.out_grid.data_ptr(), self.Tx * self.Ty,
+                                                             self.out_culled.data_ptr(), self.out_culled.numel(), self.ws.data_ptr(), self.ws.numel()),
+                   "sailor_hip_exchange_light_lists_rows", self.ctx.handle)
+        return self.out_grid, self.out_culled
+
+    def adapt(self):
+        """-> (largest band total of the last exchange, clipped?, slot words of the next one)"""
+        import ctypes as C
+
+        from . import _lib
+        largest, clipped, slot = C.c_uint32(0), C.c_int32(0), C.c_size_t(0)
+        _lib.check(self.ctx._lib.sailor_hip_exchange_adapt(self.ctx.handle, C.byref(largest), C.byref(clipped), C.byref(slot)), "sailor_hip_exchange_adapt", self.ctx.handle)
+        self.slot_words = int(slot.value)
+        return int(largest.value), bool(clipped.value), int(slot.value)
+
+    def bytes_gathered(self) -> int:
+        """what ONE rank receives per exchange at the current slot size: world x (total word + index slot + grid slot)"""
+        slot = self.slot_words or self.worst_case_slot_words
+        return self.world * 4 * (1 + slot + 2 * self.max_tiles)
+
+
 def exchange_lists_rccl(ctx, comm: "RcclComm", width: int, height: int, tile_row_bounds, band_grid: torch.Tensor, band_culled: torch.Tensor):
     """The split frame's exchange as the C++ host runs it (HipGraphicsDriver::ExchangeLightLists -> sailor_hip_exchange_light_lists_rows: three
     ncclAllGather on `comm` and the context's stream + one stitch kernel).  tile_row_bounds: world + 1 tile-row boundaries (equal or cost-balanced

@@ -401,7 +401,8 @@ class EcsSweep:
         if self.world_size == 1:
             return self.visibility
         if comm is not None:
-            _lib.check(self.ctx._lib.sailor_hip_exchange_visibility(self.ctx.handle, comm.handle, self.rank, self.world_size, self.n, _ptr(self.visibility)),
+            _lib.check(self.ctx._lib.sailor_hip_exchange_visibility(self.ctx.handle, comm.handle, self.rank, self.world_size, self.n, _ptr(self.visibility),
+                                                                        self.visibility.numel()),
                        "sailor_hip_exchange_visibility", self.ctx.handle)
         else:
             from . import dist as sdist

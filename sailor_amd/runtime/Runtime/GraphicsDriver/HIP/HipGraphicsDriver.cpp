@@ -183,6 +183,7 @@ void HipGraphicsDriver::BeforeBufferWrite(const void* devicePtr)
     if (!devicePtr || (devicePtr != m_ownGrid && devicePtr != m_ownCulled)) return;
     if (m_packPending) { sailor_hip_context_wait_for(m_ctx, m_ctxAux); m_packPending = false; }
     m_ownGrid = nullptr; m_ownCulled = nullptr;
+    m_cullOrderValid = false; // (the workspace's length bytes describe the cull's lists, not what the write leaves in the SSBOs)
 }
 
 RHIMaterialPtr HipGraphicsDriver::CreateMaterial(RHIShaderPtr shader) { return RHIMaterialPtr::Make(std::move(shader)); }
@@ -487,6 +488,16 @@ int HipGraphicsDriver::ExchangeLightLists(RHIBufferPtr bandGrid, RHIBufferPtr ba
     const size_t need = sailor_hip_exchange_workspace_size(m_splitW, m_splitH, m_worldSize);
     if (!m_exchangeWorkspace || m_exchangeWorkspace->m_size < need) m_exchangeWorkspace = CreateBuffer(need);
     if (!m_exchangeWorkspace) return SAILOR_HIP_ERR_OUT_OF_MEMORY;
+    // The slots of the exchange's second gather follow the PREVIOUS exchange's gathered totals (sailor_hip_exchange_adapt: waits for that exchange's own
+    // event -- a frame old by now -- not for anything this frame recorded; the first exchange takes the worst-case slots).  Every rank's driver runs the
+    // same sequence, so every rank arrives at the same slot size.  A clipped exchange (a band's total grew by more than the 25 % of slack from one frame to
+    // the next) is reported here, one exchange late, and the next one is back on the worst case.
+    {
+        int32_t clipped = 0;
+        const int st = sailor_hip_exchange_adapt(m_ctx, nullptr, &clipped, nullptr);
+        if (st != SAILOR_HIP_OK) return st;
+        if (clipped) { m_exchangesClipped++; fprintf(stderr, "[HIP driver] %s\n", sailor_hip_context_last_error(m_ctx)); }
+    }
     return sailor_hip_exchange_light_lists(m_ctx, m_comm, m_rank, m_worldSize, m_splitW, m_splitH, (const SailorLightsGrid*)bandGrid->m_hip.m_devicePtr,
                                            (const uint32_t*)bandCulled->m_hip.m_devicePtr, (SailorLightsGrid*)globalGrid->m_hip.m_devicePtr,
                                            (uint32_t*)globalCulled->m_hip.m_devicePtr, globalCulled->m_size / 4, m_exchangeWorkspace->m_hip.m_devicePtr,
@@ -567,9 +578,11 @@ int HipGraphicsDriver::RecordShade(const TVector<RHIShaderBindingSetPtr>& bindin
                                            prepared ? lightB->m_hipPreparedLights->m_hip.m_devicePtr : nullptr, prepared ? lightB->m_hipPreparedCapacity : 0);
     }
     if (m_packPending) { sailor_hip_context_wait_for(m_ctx, m_ctxAux); m_packPending = false; }
+    // (lists that are not this cull's: NO order hint.  The band form's tile blocks decide "split or not" on the grid entry they read, its split blocks on
+    // the workspace's length bytes -- of the OLD cull here -- and a tile the two disagree on would be shaded by nobody: ADVICE r05)
     return sailor_hip_shade_prepared(m_ctx, &frame, (const float*)surfaceB->m_buffer->m_hip.m_devicePtr, planeStride,
                                      (const SailorLightShaderData*)buffer_of(bindings[1], "light"), lightsNum, grid, culled,
-                                     hasCsm ? &csm : nullptr, hasIbl ? &ibl : nullptr, (float*)buffer_of(bindings[2], "radiance"), band, order,
+                                     hasCsm ? &csm : nullptr, hasIbl ? &ibl : nullptr, (float*)buffer_of(bindings[2], "radiance"), band, nullptr,
                                      prepared ? lightB->m_hipPreparedLights->m_hip.m_devicePtr : nullptr, prepared ? lightB->m_hipPreparedCapacity : 0);
 }
 

@@ -110,6 +110,7 @@ private:
     RHI::RHIBufferPtr m_meshCullWorkspace;
     int32_t m_cullW = 0, m_cullH = 0, m_cullLights = 0; // geometry of the last light cull: locates its shading-order hint in the workspace
     bool m_cullOrderValid = false;
+    uint32_t m_exchangesClipped = 0; // exchanges whose global lists arrived clipped (reported by the exchange after them)
     // Round 4: the light cull stops after its per-tile lists (SAILOR_CULL_DEFER_PACK); the compaction into the node's `lightsGrid` / `culledLights`
     // SSBOs is recorded on a second context (own stream) and runs BESIDE the RenderScene shade, which reads the per-tile lists when the two SSBOs
     // it is handed are the ones this frame's cull owns.  The main stream joins the second one at the end of the submit that recorded the cull.

@@ -589,6 +589,32 @@ RT_API int sailor_rt_process_frame(SailorRuntime* rt)
     return static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(Renderer::GetDriver())->GetLastDispatchStatus();
 }
 
+// One frame in which ANOTHER command overwrites the cull's two SSBOs between the LightCulling node and RenderScene (what a debug pass or a host-side
+// list editor would record): the shade must read what the write leaves there -- on a split frame too, where the band form's tile blocks and split
+// blocks must decide "long tile" on the same bytes.  gridData / culledData: host bytes for lightsGrid / culledLights (either may be null).
+RT_API int sailor_rt_process_frame_overwriting_lists(SailorRuntime* rt, const void* gridData, size_t gridBytes, const void* culledData, size_t culledBytes)
+{
+    auto driver = Renderer::GetDriver();
+    auto commands = Renderer::GetDriverCommands();
+    auto node = rt->lightCulling.DynamicCast<LightCullingNode>();
+    if (!node) return SAILOR_HIP_ERR_INVALID_ARGUMENT;
+    auto transferCmdList = driver->CreateCommandList();
+    auto cmdList = driver->CreateCommandList();
+    rt->graph.FillFrameData(transferCmdList, rt->snapshot, rt->snapshot.m_deltaTime, rt->snapshot.m_currentTime);
+    for (auto& n : rt->graph.GetGraph()) n->Prepare(&rt->graph, rt->snapshot);
+    for (auto& n : rt->graph.GetGraph()) {
+        n->Process(&rt->graph, transferCmdList, cmdList, rt->snapshot);
+        if (n.GetRawPtr() != rt->lightCulling.GetRawPtr() || !node->GetCulledLights()) continue;
+        auto g = node->GetCulledLights()->Find("lightsGrid"), c = node->GetCulledLights()->Find("culledLights");
+        if (gridData && g && g->m_buffer && gridBytes <= g->m_buffer->m_size) commands->UpdateBuffer(cmdList, g->m_buffer, gridData, gridBytes, 0);
+        if (culledData && c && c->m_buffer && culledBytes <= c->m_buffer->m_size) commands->UpdateBuffer(cmdList, c->m_buffer, culledData, culledBytes, 0);
+    }
+    driver->SubmitCommandList(transferCmdList);
+    driver->SubmitCommandList(cmdList);
+    rt->frames++;
+    return static_cast<GraphicsDriver::HIP::HipGraphicsDriver*>(driver)->GetLastDispatchStatus();
+}
+
 RT_API void sailor_rt_wait_idle(SailorRuntime*) { Renderer::GetDriver()->WaitIdle(); }
 
 // device pointers of the node-owned SSBOs, for read-back by the tests

@@ -59,6 +59,7 @@ def load() -> C.CDLL:
         rt.sailor_rt_shadow_pass.argtypes = [P, C.POINTER(C.c_float), P, C.c_uint32, P, C.c_uint32, P, C.c_uint32, C.c_uint32, P, C.c_int, C.c_int, C.c_float, C.c_float]
         rt.sailor_rt_gpu_culling.argtypes = [P, P, C.c_uint32, C.c_uint32, P, C.c_uint32]
         rt.sailor_rt_process_frame.argtypes = [P]
+        rt.sailor_rt_process_frame_overwriting_lists.argtypes = [P, P, C.c_size_t, P, C.c_size_t]
         rt.sailor_rt_set_frame_split.argtypes = [P, C.c_int, C.c_int, P]
         rt.sailor_rt_exchange_light_lists.argtypes = [P, P, C.c_size_t, P, C.c_size_t]
         rt.sailor_rt_wait_idle.argtypes = [P]
@@ -245,6 +246,14 @@ class Runtime:
 
     def process_frame(self) -> int:
         return self.rt.sailor_rt_process_frame(self.h)
+
+    def process_frame_overwriting_lists(self, grid, culled) -> int:
+        """one frame with an UpdateBuffer of lightsGrid / culledLights (numpy uint32 arrays or None) recorded between the LightCulling node and RenderScene"""
+        import numpy as np
+        g = None if grid is None else np.ascontiguousarray(grid, np.uint32)
+        c = None if culled is None else np.ascontiguousarray(culled, np.uint32)
+        return self.rt.sailor_rt_process_frame_overwriting_lists(self.h, None if g is None else g.ctypes.data, 0 if g is None else g.nbytes,
+                                                                 None if c is None else c.ctypes.data, 0 if c is None else c.nbytes)
 
     def wait_idle(self):
         self.rt.sailor_rt_wait_idle(self.h)

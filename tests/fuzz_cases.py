@@ -16,6 +16,24 @@ CULL_PATHS = [_lib.CULL_DEFAULT, _lib.CULL_BRUTE_FORCE, _lib.CULL_INTERVAL_MASKS
 BAND_SELECT_EVERY = 2   # every second case's bands go through the band selection as well (round 4: the band-local light selection, forced on these small sets)
 
 
+
+def nonfinite_mismatch(got, ref):
+    """the non-finite values compared BY CLASS -- a NaN where the oracle has an infinity, or an infinity of the other sign, is a mismatch
+    (np.isfinite alone lets both through).  -> None, or (class name, index array of the first mismatching values)"""
+    for name, fn in (("NaN", np.isnan), ("+Inf", np.isposinf), ("-Inf", np.isneginf)):
+        a, b = fn(got), fn(ref)
+        if not np.array_equal(a, b):
+            return name, np.argwhere(a != b)
+    return None
+
+
+def finite_abs_diff(got, ref, fin):
+    """|got - ref| in float64 where `fin` (both finite), 0 elsewhere: no Inf - Inf on the way (the RuntimeWarning the old form printed came from exactly that)"""
+    full = np.zeros(ref.shape, np.float64)
+    full[fin] = np.abs(got[fin].astype(np.float64) - ref[fin].astype(np.float64))
+    return full
+
+
 def k1k2_case(ctx, rng, c, run=True, verbose=False):
     """one K1 + K2 case; run=False only draws the case's random numbers (replaying a later case of the same seed).  Returns the worst relative
     radiance error over the case's finite, non-zero values."""
@@ -76,14 +94,15 @@ def k1k2_case(ctx, rng, c, run=True, verbose=False):
             got = out.cpu().numpy()
             ref = orad[rows]
             fin = np.isfinite(ref)
-            if not np.array_equal(np.isfinite(got), fin):
-                bad = np.argwhere(np.isfinite(got) != fin)
+            mism = nonfinite_mismatch(got, ref)
+            if mism is not None:
+                cls, bad = mism
                 y, x, ch = bad[0]
                 gy = H - 1 - (y + rows.start); t = (gy // 16) * Tx + x // 16
                 li = oi[og[t, 0]: og[t, 0] + og[t, 1]]
-                raise AssertionError(f"{what}, flags {flags}: finiteness differs at {len(bad)} values; first {bad[0].tolist()}: got {got[y, x]} ref {ref[y, x]} "
+                raise AssertionError(f"{what}, flags {flags}: the {cls} masks differ at {len(bad)} values; first {bad[0].tolist()}: got {got[y, x]} ref {ref[y, x]} "
                                      f"surface {surface[:, y + rows.start, x].tolist()} tile {t} list {li[:20].tolist()} types {lights['type'][li][:20].tolist()}")
-            full = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+            full = finite_abs_diff(got, ref, fin)
             err = full[fin]
             tol = 1e-4 * np.abs(ref.astype(np.float64))[fin]
             if verbose:
@@ -135,8 +154,8 @@ def k3_case(ctx, rng, c):
     got = fp.shade(f.cam.frame, torch.from_numpy(np.ascontiguousarray(f.surface)).to(ctx.device), l, N, gdesc).cpu().numpy()
     what = f"K3 case {c}: {W}x{H}, {N} lights, shadow size {f.shadows.size}, type {lights['shadowType'][0]}"
     fin = np.isfinite(ref)
-    assert np.array_equal(np.isfinite(got), fin), (what, "finiteness")
-    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))[fin]
+    assert nonfinite_mismatch(got, ref) is None, (what, "non-finite classes", nonfinite_mismatch(got, ref)[0])
+    err = finite_abs_diff(got, ref, fin)[fin]
     tol = 1e-4 * np.abs(ref.astype(np.float64))[fin]
     if not (err <= tol).all():
         bad = np.argwhere(np.abs(got.astype(np.float64) - ref) > 1e-4 * np.abs(ref))
@@ -154,8 +173,8 @@ def k3_case(ctx, rng, c):
             gb = fpb.shade(f.cam.frame, torch.from_numpy(np.ascontiguousarray(f.surface[:, rows])).to(ctx.device), l, N, gdesc).cpu().numpy()
             rb = ref[rows]
             fb = np.isfinite(rb)
-            assert np.array_equal(np.isfinite(gb), fb), (what, "band", (b.tileRowBegin, b.tileRowEnd), "finiteness")
-            eb = np.abs(gb.astype(np.float64) - rb.astype(np.float64))[fb]
+            assert nonfinite_mismatch(gb, rb) is None, (what, "band", (b.tileRowBegin, b.tileRowEnd), "non-finite classes", nonfinite_mismatch(gb, rb)[0])
+            eb = finite_abs_diff(gb, rb, fb)[fb]
             assert (eb <= 1e-4 * np.abs(rb.astype(np.float64))[fb]).all(), (what, "band", (b.tileRowBegin, b.tileRowEnd), float(eb.max()))
             mb = np.abs(rb[fb]) > 0
             if mb.any():

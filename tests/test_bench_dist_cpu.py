@@ -284,10 +284,21 @@ def test_two_ranks_run_the_whole_of_bench_main(extra, tmp_path):
     assert d[f"value_{other}_lights"] > 0 and d[f"ms_per_step_{other}"] > 0
     if "--list-sets" in extra:
         assert "2 list sets" in d["launch"]
+    import bench
+    timed = 1 + bench.EXCHANGE_TIMED   # (one exchange on the worst-case slots, then the event-timed ones: bench.exchange_stats)
     if "--exchange-every-step" in extra:
-        assert d["launch"] == "eager" and res[0]["exchanges"] == res[1]["exchanges"] > 3   # every rank took part in every exchange
+        assert d["launch"] == "eager" and res[0]["exchanges"] == res[1]["exchanges"] > 3 + timed   # every rank took part in every exchange
+    elif weak:
+        assert res[0]["exchanges"] == res[1]["exchanges"] == timed
     else:
-        assert res[0]["exchanges"] == res[1]["exchanges"] == 1
+        per_config = timed * (len(d["split_configs"]) if d.get("split_configs") else 0)
+        assert res[0]["exchanges"] == res[1]["exchanges"] == timed + max(d["warmup"], 2) + d["steps"] + per_config
+        # round 6: the exchange's cost is in the line -- its own event-timed duration, the bytes a rank gathers, and the step with it in it
+        assert ex["ms_median"] > 0 and ex["ms_p90"] >= ex["ms_median"] and ex["timed_exchanges"] == bench.EXCHANGE_TIMED and ex["bytes_gathered"] > 0
+        assert d["value_exchange_every_step"] > 0 and d["ms_per_step_exchange_every_step"] > 0 and d["ms_per_step_same_form_without_exchange"] > 0
+    if weak:
+        sx = d["split_frame"]["exchange"]
+        assert sx["ms_median"] > 0 and sx["timed_exchanges"] == bench.EXCHANGE_TIMED
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["avg_launch_ms"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert list(r["cull"]["kernels_ms"]) == ["k01_prepare", "k1_group_lists", "k1_tile_cull", "k1_pack"], "the chain's kernels as the library's launch log names them"

@@ -75,6 +75,11 @@ def test_one_rank_process_group_runs_both_multi_gpu_modes(split_primary):
     ex = d["exchange"] if split_primary else d["split_frame"]["exchange"]
     assert ex["tiles"] == 240 * 135 and ex["global_sum_num"] == d["config"]["sum_num_rank0_band"] and ex["checksum"] > 0
     assert "sailor_hip_exchange_light_lists_rows" in ex["how"]   # the shipped exchange (C-ABI over an ncclComm_t), not torch.distributed's collectives
+    # round 6: the exchange's own cost is in the line -- event-timed record-only calls, the slots of the second gather sized by sailor_hip_exchange_adapt
+    assert ex["timed_exchanges"] >= 10 and 0 < ex["ms_min"] <= ex["ms_median"] <= ex["ms_p90"] and ex["ms_first_worst_case_slots"] > 0
+    assert ex["largest_band_total"] == ex["global_sum_num"] and ex["clipped"] is False
+    assert ex["slot_words"] == (ex["global_sum_num"] + ex["global_sum_num"] // 4 + 1 + 63) // 64 * 64 < ex["worst_case_slot_words"] == 240 * 135 * 128
+    assert ex["bytes_gathered"] == 4 * (1 + ex["slot_words"] + 2 * 240 * 135)
     if split_primary:
         assert d["speedup_vs_one_gpu_whole_frame"] > 0
     assert d["step_ms"]["p10"] <= d["step_ms"]["median"] <= d["step_ms"]["p90"]
@@ -99,6 +104,9 @@ def test_ranks_sharing_the_gpu_run_the_split_frame_for_real(ranks):
     for key in ("tiles", "global_sum_num", "checksum"):                                             # the frame's lists, rebuilt from the bands == one rank's whole frame
         assert d["exchange"][key] == one["exchange"][key], key
     assert "torch.distributed (gloo)" in d["exchange"]["how"]                                       # RCCL takes one rank per device: all ranks agreed on the fallback
+    # round 6: what the exchange costs is in every N > 1 line: its event-timed duration, the bytes gathered, and the step with the exchange in it
+    assert d["exchange"]["timed_exchanges"] >= 10 and 0 < d["exchange"]["ms_median"] <= d["exchange"]["ms_p90"] and d["exchange"]["bytes_gathered"] > 0
+    assert 0 < d["value_exchange_every_step"] and d["ms_per_step_exchange_every_step"] > d["ms_per_step_same_form_without_exchange"] * 0.5 > 0
     assert d["alternate_frame_rendering"]["value"] > 0 and "error" not in d["alternate_frame_rendering"]
     # round 5: an N > 1 line of the headline also carries bounded split readings of the two configurations BASELINE.json names for a node, the bands re-cut
     # on measured times, and K4 across the ranks (entity ranges + one all-gather of the visibility words) beside K4 replicated -- the gathered bitmask is
@@ -107,6 +115,7 @@ def test_ranks_sharing_the_gpu_run_the_split_frame_for_real(ranks):
     for name, v in d["split_configs"].items():
         assert "error" not in v and v["split_ms_per_step"] > 0 and v["whole_frame_per_gpu_ms_per_step"] > 0 and v["speedup_vs_one_gpu_whole_frame"] > 0, (name, v)
         assert v["tile_row_bounds"][0] == 0 and len(v["tile_row_bounds"]) == ranks + 1
+        assert v["exchange"]["ms_median"] > 0 and v["exchange"]["bytes_gathered"] > 0 and 0 < v["value_exchange_every_step"] < v["value"], (name, v.get("exchange"))
     assert d["split_configs"]["C5"]["lights"].startswith("dynamic") and d["split_configs"]["C5"]["tile_row_bounds"][-1] == 270
     e = d["ecs_sweep"]["split"]
     assert e["default"] == "replicated" and e["entities"] == 1 << 20 and e["split"]["ranks"] == ranks and e["split"]["bitmask_equals_replicated_on_every_rank"] is True

@@ -679,6 +679,58 @@ def test_split_frame_bands_through_the_cpp_driver(world):
     assert rows_seen == H
 
 
+@pytest.mark.parametrize("world", [1, 2])
+def test_lists_overwritten_between_the_cull_and_the_shade_are_what_the_shade_reads(world):
+    """ADVICE r05: a command that writes lightsGrid / culledLights between the LightCulling node and RenderScene (HipGraphicsDriver::BeforeBufferWrite).
+    The shade must then read the SSBOs, not the cull's per-tile lists -- and on a band of a split frame it must not take the band form's order hint from
+    the cull's workspace: the tile blocks decide "long tile" on the grid entry they read, the split blocks on the old cull's length bytes, and a tile the two
+    disagree on was shaded by nobody.  The overwrite rotates the band's lists among its tiles (long lists land on short tiles and the other way round)."""
+    f = synth.make_frame("tiny", width=320, height=208, lights=synth.LightSetConfig(count=3000, spot_fraction=0.3, radius_scale=5.0))
+    W, H = f.cam.width, f.cam.height
+    Tx, Ty = host.num_tiles(W, H)
+    band = host.band_for_rank(W, H, 0, world)
+    r0, r1 = band.fbRowBegin, band.fbRowBegin + band.fbRowCount
+    bg, bi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth, tile_rows=(band.tileRowBegin, band.tileRowEnd))
+    tiles = (band.tileRowEnd - band.tileRowBegin) * Tx
+    assert (bg[:, 1] >= 64).any() and (bg[:, 1] < 64).any(), "the frame must have tiles on both sides of the split threshold"
+    lists = [bi[o: o + n] for o, n in bg]
+    shift = 7
+    edited = [lists[(t + shift) % tiles] for t in range(tiles)]
+    assert sum((len(a) >= 64) != (len(b) >= 64) for a, b in zip(lists, edited)) > 10
+    eg = np.zeros((tiles, 2), np.uint32)
+    ei = [np.array([sum(len(e) for e in edited)], np.uint32)]
+    o = 1
+    for t, e in enumerate(edited):
+        eg[t] = (o, len(e)); o += len(e); ei.append(e)
+    ei = np.concatenate(ei)
+    # the oracle takes the global layout: the band's tiles at their place in the frame, nothing anywhere else
+    gg = np.zeros((Tx * Ty, 2), np.uint32)
+    gg[band.tileRowBegin * Tx: band.tileRowEnd * Tx] = eg
+    ref = oracle.shade(f.cam.frame, W, H, f.surface, f.lights, gg, ei, None, rows=(r0, r1))
+    rt = Runtime(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        rt.build_graph(["LightCulling", "RenderScene"])
+        if world > 1:
+            rt.set_frame_split(0, world)
+        rt.set_camera(f.cam)
+        rt.set_lights(f.lights)
+        depth = torch.from_numpy(np.ascontiguousarray(f.depth[r0:r1])).cuda()
+        surface = torch.from_numpy(np.ascontiguousarray(f.surface[:, r0:r1])).cuda()
+        radiance = torch.full((r1 - r0, W, 4), -1.0, dtype=torch.float32, device="cuda")  # (a tile nobody shades keeps its -1)
+        rt.set_depth(depth)
+        rt.set_surface(surface, radiance)
+        assert rt.process_frame_overwriting_lists(eg, ei) == 0
+        rt.wait_idle(); torch.cuda.synchronize()
+        gp, _ = rt.buffer("lightsGrid"); cp, _ = rt.buffer("culledLights")
+        np.testing.assert_array_equal(read_u32(gp, tiles * 8).reshape(-1, 2), eg)   # the write came behind the cull's compaction
+        np.testing.assert_array_equal(read_u32(cp, 4 * len(ei)), ei)
+        got = radiance.cpu().numpy().astype(np.float64)
+        assert (got[..., 3] >= 0).all(), "pixels that no block wrote"
+        assert (np.abs(got - ref[r0:r1]) <= 1e-4 * np.abs(ref[r0:r1])).all()
+    finally:
+        rt.close()
+
+
 def test_list_exchange_through_the_c_abi_over_rccl():
     """sailor_hip_exchange_light_lists / sailor_hip_allgather_u32 / sailor_hip_stitch_light_lists with a real ncclComm_t.  The box has one GPU,
     so (a) the whole exchange runs with a one-rank communicator through the C++ driver (HipGraphicsDriver::ExchangeLightLists): the global
@@ -785,4 +837,75 @@ def test_list_exchange_through_the_c_abi_over_rccl():
         np.testing.assert_array_equal(g1.cpu().numpy().view(np.uint32)[: fp1.band_tiles * 2].reshape(-1, 2), og[t0:])
         ctx.close()
     finally:
+        rccl.ncclCommDestroy(comm)
+
+
+def test_the_exchange_only_records_adapts_its_slots_and_can_be_captured():
+    """Round 6: sailor_hip_exchange_light_lists_rows reads nothing back and does not wait -- the slot size of its second gather lives on the
+    context (the worst case first; sailor_hip_exchange_adapt makes it the previous exchange's largest band total + 25 %), a band that outgrew its slot is
+    noted by the stitch kernel and reported by the NEXT adapt, which goes back to the worst case -- and the whole call sits in a hipGraph.  One-rank
+    ncclComm_t (the box has one GPU); every result against the oracle's whole-frame buffers."""
+    from sailor_amd import dist as sdist
+    from sailor_amd.forward_plus import ForwardPlus, HipContext, upload_lights
+    f = synth.make_frame("tiny", width=320, height=208, lights=synth.LightSetConfig(count=3000, spot_fraction=0.3, radius_scale=5.0))
+    W, H, N = f.cam.width, f.cam.height, len(f.lights)
+    Tx, Ty = host.num_tiles(W, H)
+    og, oi, _ = oracle.light_cull(f.cam.frame, W, H, f.lights, f.depth)
+    total = int(oi[0])
+    rccl, comm = _single_rank_comm()
+
+    class OneRank:   # what ListExchange wants of dist.RcclComm
+        rank, world_size, handle = 0, 1, comm
+
+    def check(ex, upto=total):
+        np.testing.assert_array_equal(ex.out_grid.cpu().numpy().view(np.uint32).reshape(-1, 2), og)
+        np.testing.assert_array_equal(ex.out_culled.cpu().numpy().view(np.uint32)[1: 1 + upto], oi[1: 1 + upto])
+        assert int(ex.out_culled[0].item()) == total
+
+    try:
+        side = torch.cuda.Stream()
+        ctx = HipContext("cuda:0", stream=side)
+        with torch.cuda.stream(side):
+            lights = upload_lights(f.lights, ctx.device)
+            fp = ForwardPlus(ctx, W, H, N)
+            fp.cull(f.cam.frame, lights, N, torch.from_numpy(f.depth).cuda())
+            ex = sdist.ListExchange(ctx, OneRank, W, H, [0, Ty], ctx.device)
+            band_grid = fp.grid[: fp.band_tiles * 2]
+            assert ex.adapt() == (0, False, 0)                           # nothing exchanged yet: the worst case stays
+            ex.record(band_grid, fp.culled)                              # 1: worst-case slots
+            ctx.synchronize(); check(ex)
+            largest, clipped, slot = ex.adapt()
+            assert (largest, clipped) == (total, False) and slot == (total + total // 4 + 1 + 63) // 64 * 64 and slot < ex.worst_case_slot_words
+            assert ex.bytes_gathered() == 4 * (1 + slot + 2 * Tx * Ty)
+            ex.out_grid.zero_(); ex.out_culled.zero_()
+            ex.record(band_grid, fp.culled)                              # 2: slots sized from exchange 1
+            ctx.synchronize(); check(ex)
+            # a slot the band has outgrown: the lists arrive clipped, the NEXT adapt says so and goes back to the worst case
+            small = 64 * ((total // 2) // 64)
+            assert small > 0
+            _lib.check(ctx._lib.sailor_hip_exchange_set_slot_words(ctx.handle, small), "sailor_hip_exchange_set_slot_words", ctx.handle)
+            ex.out_grid.zero_(); ex.out_culled.zero_()
+            ex.record(band_grid, fp.culled)                              # 3: clipped
+            largest, clipped, slot = ex.adapt()
+            assert (largest, clipped, slot) == (total, True, 0) and b"did not fit" in ctx._lib.sailor_hip_context_last_error(ctx.handle)
+            check(ex, upto=small)                                        # (what fitted is in place; the grid is whole)
+            ex.out_grid.zero_(); ex.out_culled.zero_()
+            ex.record(band_grid, fp.culled)                              # 4: worst case again
+            assert ex.adapt()[:2] == (total, False)
+            check(ex)
+        # captured: the call records three collectives and three kernels and nothing else -- replayed twice on cleared outputs
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            ex.record(band_grid, fp.culled)
+        for _ in range(2):
+            ex.out_grid.zero_(); ex.out_culled.zero_()
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            check(ex)
+        assert ex.adapt()[:2] == (total, False)                          # (a captured exchange leaves no event: adapt waits for the stream instead)
+        del g
+    finally:
+        torch.cuda.synchronize()
         rccl.ncclCommDestroy(comm)

@@ -111,8 +111,10 @@ def test_bright_metal_without_a_specular_term(ctx):
     lit = ref[..., :3][np.isfinite(ref[..., :3])]
     assert (lit > 0).mean() > 0.2 and np.median(lit[lit > 0]) < 1.0, "the diffuse term alone is small"
     fin = np.isfinite(ref)
-    np.testing.assert_array_equal(np.isfinite(got), fin)
-    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))[fin]
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_array_equal(np.isposinf(got), np.isposinf(ref))
+    np.testing.assert_array_equal(np.isneginf(got), np.isneginf(ref))
+    err = np.abs(got[fin].astype(np.float64) - ref[fin].astype(np.float64))
     assert (err <= RTOL * np.abs(ref.astype(np.float64))[fin]).all(), f"worst rel {np.max(err / (np.abs(ref.astype(np.float64))[fin] + 1e-300)):.3e}"
 
 
@@ -179,10 +181,10 @@ def _hostile_map(kind: str, shape, seed: int) -> np.ndarray:
     if kind == "steps":          # flat patches of a few texels: windows on, beside and across their edges
         coarse = rng.uniform(-0.2, 0.6, (-(-shape[0] // 5), -(-shape[1] // 7)))
         return np.kron(coarse, np.ones((5, 7)))[: shape[0], : shape[1]].astype(np.float16)
-    if kind == "signed_denormal":  # negative texels, both zeros, half denormals: the extremes are taken on the bits
+    if kind == "signed_denormal":  # negative texels, both zeros, half denormals: the halves are picked by their bits and converted, sign and all
         vals = np.array([-0.5, -6e-8, -0.0, 0.0, 6e-8, 3e-5, -3e-5, 0.43, 0.47], np.float16)
         return vals[rng.integers(0, len(vals), shape)]
-    if kind == "nonfinite":      # an infinity or a NaN in the window: never decided by the extremes, the taps propagate them as the reference does
+    if kind == "nonfinite":      # an infinity or a NaN in the window: the taps propagate them as the reference does
         m = rng.uniform(0.0, 0.3, shape).astype(np.float16)
         bad = rng.uniform(size=shape)
         m[bad < 0.02] = np.float16(np.inf); m[(bad >= 0.02) & (bad < 0.04)] = np.float16(-np.inf); m[(bad >= 0.04) & (bad < 0.06)] = np.float16(np.nan)
@@ -193,8 +195,9 @@ def _hostile_map(kind: str, shape, seed: int) -> np.ndarray:
 @pytest.mark.parametrize("kind", ["noise", "flat", "steps", "signed_denormal", "nonfinite"])
 @pytest.mark.parametrize("shape", [(128, 128), (96, 160), (40, 5), (12, 8192), (8, 8200)])
 def test_pcf_window_against_the_oracle_on_hostile_maps(ctx, kind, shape):
-    """Round 5: the sixteen PCF taps of an R16F cascade come out of one 6 x 6-texel window, and the window's extremes decide all sixteen compares where
-    they can (shade_body.h).  Maps built to sit on every branch of that -- not flat anywhere, flat everywhere, small flat patches, signed / zero /
+    """Round 5: the sixteen PCF taps of an R16F cascade come out of one 6 x 6-texel window (shade_body.h: shadow_pcf_window; the form in which the window's
+    extremes decided all sixteen compares at once was measured and dropped -- every tap is computed).  Maps built for every branch of the window's texel
+    selection and of the compares -- not flat anywhere, flat everywhere, small flat patches, signed / zero /
     denormal texels, infinities and NaNs -- in shapes that are square, ragged, narrower than a window (every lane takes the tap-by-tap path) and wider
     than PCF_WINDOW_MAX_SIZE (likewise; 8192 itself is the widest map the window takes): the picture is the oracle's."""
     f = _deep_frame()
@@ -548,7 +551,8 @@ def test_lengths_outside_the_fast_square_root(ctx):
     fp.cull(f.cam.frame, l, N, torch.from_numpy(f.depth).to(ctx.device))
     got = fp.shade(f.cam.frame, torch.from_numpy(f.surface).to(ctx.device), l, N).cpu().numpy()
     np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
-    np.testing.assert_array_equal(np.isinf(got), np.isinf(ref))
+    np.testing.assert_array_equal(np.isposinf(got), np.isposinf(ref))
+    np.testing.assert_array_equal(np.isneginf(got), np.isneginf(ref))
     fin = np.isfinite(ref)
     err = np.abs(got[fin].astype(np.float64) - ref[fin])
     assert (err <= RTOL * np.abs(ref[fin])).all(), (err / (np.abs(ref[fin]) + 1e-300)).max()
@@ -578,7 +582,8 @@ def test_divisors_outside_the_staged_reciprocal(ctx, prepared):
     fp.cull(f.cam.frame, l, N, torch.from_numpy(f.depth).to(ctx.device))
     got = fp.shade(f.cam.frame, torch.from_numpy(f.surface).to(ctx.device), l, N).cpu().numpy()
     np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
-    np.testing.assert_array_equal(np.isinf(got), np.isinf(ref))
+    np.testing.assert_array_equal(np.isposinf(got), np.isposinf(ref))
+    np.testing.assert_array_equal(np.isneginf(got), np.isneginf(ref))
     fin = np.isfinite(ref)
     err = np.abs(got[fin].astype(np.float64) - ref[fin])
     assert (err <= RTOL * np.abs(ref[fin])).all(), (err / (np.abs(ref[fin]) + 1e-300)).max()
