@@ -287,7 +287,7 @@ def exchange_stats(dev, do_exchange, stream, dist=None, device=None, n=EXCHANGE_
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         med, p90, first_ms = (float(v) for v in t.tolist())
     out = {"ms_median": med, "ms_p90": p90, "ms_min": mn, "timed_exchanges": n, "ms_first_worst_case_slots": first_ms,
-           "how": "one exchange on the worst-case slots, sailor_hip_exchange_adapt on every rank, then %d exchanges each between a HIP event pair on the launch "
+           "timing": "one exchange on the worst-case slots, sailor_hip_exchange_adapt on every rank, then %d exchanges each between a HIP event pair on the launch "
                   "stream (record-only calls: nothing read back, no stream synchronisation inside); median / p90 = the max over the ranks" % n}
     if adapt is not None:
         out.update({"bytes_gathered": adapt["bytes_gathered_per_rank"], "slot_words": adapt["slot_words"], "worst_case_slot_words": adapt["worst_case_slot_words"],

@@ -465,3 +465,23 @@ def lighting_tick_runs(dirty, active, mobility, frame_last_change, owner_frame_l
                 batch = []
         index += 1
     return runs
+
+
+OCTREE_ROOT_SIZE, OCTREE_MIN_SIZE = 16536 * 16, 4   # RHI/SceneView.h:91-92
+
+
+def trace_scene_octree_boxes(world_aabb: np.ndarray, planes: np.ndarray, root_size: int = OCTREE_ROOT_SIZE, min_size: int = OCTREE_MIN_SIZE):
+    """E4 as the reference runs it (Containers/Octree.h:239-274 over the integer-truncated boxes of ECS/StaticMeshRendererECS.cpp:81,96,132): the world
+    boxes go into a TOctree restated literally, the frustum is traced through it.  -> (visible words, inserted words, int boxes [n, 6] = position + extents,
+    stats {nodes, visited, not_inserted, smallest_node})"""
+    world_aabb = np.ascontiguousarray(world_aabb, np.float32).reshape(-1, 6)
+    planes = np.ascontiguousarray(planes, np.float32).reshape(24)
+    n = len(world_aabb)
+    words = (n + 63) // 64
+    vis, ins = np.zeros(words, np.uint64), np.zeros(words, np.uint64)
+    boxes = np.zeros((n, 6), np.int32)
+    stats = np.zeros(4, np.uint64)
+    rc = lib().oracle_trace_scene_octree_boxes(C.c_uint32(n), _p(world_aabb), _p(planes), C.c_uint32(root_size), C.c_uint32(min_size), _p(vis), _p(ins), _p(boxes), _p(stats))
+    if rc != 0:
+        raise MemoryError("oracle_trace_scene_octree_boxes")
+    return vis, ins, boxes, {"nodes": int(stats[0]), "visited": int(stats[1]), "not_inserted": int(stats[2]), "smallest_node": int(stats[3])}

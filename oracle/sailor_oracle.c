@@ -2099,3 +2099,137 @@ ORACLE_API void oracle_shadow_resolve_evsm(const float* depth, int32_t W, int32_
         } else { o[0] = o[1] = o[2] = o[3] = 0.0f; }
     }
 }
+
+/* ==== E4 as the reference runs it: RHISceneView::TraceScene over TOctree ==========================================
+ * The product sweeps FLAT float boxes ("octree stores integer-truncated boxes -- N").  This restates the reference's own
+ * structure so that the size of that divergence can be COUNTED (tests/test_oracle_cpu.py: which entities' visibility flips):
+ *   ECS/StaticMeshRendererECS.cpp:81,96,132  octree.Update(glm::vec4(aabb.GetCenter(), 1), aabb.GetExtents(), proxy) -- the parameters are
+ *                                            `const glm::ivec3&`: centre and extents are TRUNCATED towards zero, component by component
+ *                                            (Math/Bounds.cpp:455-463 GetCenter = (min + max) * 0.5f, GetExtents = (max - min) * 0.5f)
+ *   RHI/SceneView.h:91-92                    TOctree{ ivec3(0), 16536 * 16, 4 }: root size 264 576, minimum node size 4
+ *   Containers/Octree.h:44-53,397-437        TNode::Contains (strict, integers), Insert_Internal; :22 NumElementsInNode = 8
+ *   Containers/Octree.h:43                   GetIndex(x, y, z) = (z < 0 ? 0 : 1) + (x < 0 ? 1 : 0) * 2 + (y < 0 ? 0 : 1) * 4
+ *   Containers/Octree.h:439-459              Subdivide: quarter = size / 4, child size = 2 quarter, centres = offset[i] * quarter + centre
+ *   Containers/Octree.h:239-274              Trace / Trace_Internal: Frustum::OverlapsAABB(AABB(ivec3 position, ivec3 extents)) per stored element,
+ *                                            AABB(centre, size * 0.5f) per child node (Math/Bounds.cpp:473-477: min = c - e, max = c + e)
+ * An element the root does not strictly contain is NOT inserted (Insert returns false): it is never drawn.  The reference walks a node's elements in
+ * its hash map's order; here in insertion order -- the traced SET cannot depend on it (OverlapsAABB is monotone in the box, every element lies inside
+ * every node on its path: the hierarchical walk visits exactly the elements whose own integer box passes; the test holds this against the flat form). */
+typedef struct OctNode {
+    uint32_t size; int32_t c[3];
+    int32_t child;              /* index of the first of eight children, -1 = leaf */
+    uint32_t num, cap; uint32_t* el;
+} OctNode;
+typedef struct Octree { OctNode* nodes; size_t numNodes, capNodes; uint32_t minSize; const int32_t* pos; const int32_t* ext; } Octree;
+
+static int oct_contains(const OctNode* n, const int32_t* p, const int32_t* e)
+{
+    const int32_t h = (int32_t)(n->size / 2);
+    return n->c[0] - h < p[0] - e[0] && n->c[1] - h < p[1] - e[1] && n->c[2] - h < p[2] - e[2] &&
+           n->c[0] + h > p[0] + e[0] && n->c[1] + h > p[1] + e[1] && n->c[2] + h > p[2] + e[2];
+}
+static void oct_add(OctNode* n, uint32_t el)
+{
+    if (n->num == n->cap) { n->cap = n->cap ? n->cap * 2 : 8; n->el = (uint32_t*)realloc(n->el, n->cap * sizeof(uint32_t)); }
+    n->el[n->num++] = el;
+}
+static void oct_subdivide(Octree* t, size_t ni)
+{
+    static const int32_t off[8][3] = { { 1, -1, -1 }, { 1, -1, 1 }, { -1, -1, -1 }, { -1, -1, 1 }, { 1, 1, -1 }, { 1, 1, 1 }, { -1, 1, -1 }, { -1, 1, 1 } };
+    if (t->numNodes + 8 > t->capNodes) { t->capNodes = t->capNodes * 2 + 8; t->nodes = (OctNode*)realloc(t->nodes, t->capNodes * sizeof(OctNode)); }
+    OctNode* n = &t->nodes[ni];
+    const int32_t quarter = (int32_t)(n->size / 4);
+    n->child = (int32_t)t->numNodes;
+    for (int i = 0; i < 8; i++) {
+        OctNode* k = &t->nodes[t->numNodes + i];
+        memset(k, 0, sizeof *k);
+        k->size = (uint32_t)(quarter * 2); k->child = -1;
+        for (int a = 0; a < 3; a++) k->c[a] = off[i][a] * quarter + n->c[a];
+    }
+    t->numNodes += 8;
+}
+static int oct_insert(Octree* t, size_t ni, uint32_t el)
+{
+    const int32_t* p = t->pos + 3 * (size_t)el; const int32_t* e = t->ext + 3 * (size_t)el;
+    const int leaf = t->nodes[ni].child < 0;
+    if (!oct_contains(&t->nodes[ni], p, e)) return 0;
+    if (leaf) {
+        oct_add(&t->nodes[ni], el);
+        if (t->nodes[ni].num == 8u && t->nodes[ni].size > t->minSize) {
+            uint32_t moved[8];
+            memcpy(moved, t->nodes[ni].el, sizeof moved);
+            t->nodes[ni].num = 0;
+            oct_subdivide(t, ni);                                   /* (may move t->nodes) */
+            for (int i = 0; i < 8; i++) (void)oct_insert(t, ni, moved[i]);
+        }
+        return 1;
+    }
+    const int32_t dx = p[0] - t->nodes[ni].c[0], dy = p[1] - t->nodes[ni].c[1], dz = p[2] - t->nodes[ni].c[2];
+    const int idx = (dz < 0 ? 0 : 1) + (dx < 0 ? 1 : 0) * 2 + (dy < 0 ? 0 : 1) * 4;
+    if (oct_insert(t, (size_t)t->nodes[ni].child + (size_t)idx, el)) return 1;
+    oct_add(&t->nodes[ni], el);
+    return 1;
+}
+static int oct_overlaps_int_box(const float* planes, const int32_t* p, const int32_t* e)
+{
+    float box[6]; /* AABB(glm::vec3(ivec3 position), glm::vec3(ivec3 extents)): min = centre - extents, max = centre + extents (floats) */
+    for (int a = 0; a < 3; a++) { box[a] = (float)p[a] - (float)e[a]; box[3 + a] = (float)p[a] + (float)e[a]; }
+    return overlaps_aabb(planes, box);
+}
+static void oct_trace(const Octree* t, size_t ni, const float* planes, uint64_t* visible, uint64_t* visited)
+{
+    const OctNode* n = &t->nodes[ni];
+    for (uint32_t i = 0; i < n->num; i++) {
+        const uint32_t el = n->el[i];
+        (*visited)++;
+        if (oct_overlaps_int_box(planes, t->pos + 3 * (size_t)el, t->ext + 3 * (size_t)el)) visible[el >> 6] |= 1ull << (el & 63);
+    }
+    if (n->child < 0) return;
+    for (int i = 0; i < 8; i++) {
+        const OctNode* k = &t->nodes[(size_t)n->child + (size_t)i];
+        const float h = (float)k->size * 0.5f;
+        const float box[6] = { (float)k->c[0] - h, (float)k->c[1] - h, (float)k->c[2] - h, (float)k->c[0] + h, (float)k->c[1] + h, (float)k->c[2] + h };
+        if (overlaps_aabb(planes, box)) oct_trace(t, (size_t)n->child + (size_t)i, planes, visible, visited);
+    }
+}
+/* worldAabb: n x {min.xyz, max.xyz} (what K4 / oracle_ecs_sweep produce).  outVisible / outInserted: ceil(n / 64) words.  outIntBoxes (or NULL): n x
+ * {position.xyz, extents.xyz} as int32 -- the truncated boxes, for the flat cross-check.  stats[4]: nodes, elements visited by the trace, elements not
+ * inserted, deepest node size.  Returns 0, or -1 when out of memory. */
+ORACLE_API int oracle_trace_scene_octree_boxes(uint32_t n, const float* worldAabb, const float* planes, uint32_t rootSize, uint32_t minSize,
+                                               uint64_t* outVisible, uint64_t* outInserted, int32_t* outIntBoxes, uint64_t* stats)
+{
+    const uint32_t words = (n + 63) / 64;
+    memset(outVisible, 0, (size_t)words * 8);
+    memset(outInserted, 0, (size_t)words * 8);
+    int32_t* pos = (int32_t*)malloc((size_t)(n ? n : 1) * 3 * sizeof(int32_t));
+    int32_t* ext = (int32_t*)malloc((size_t)(n ? n : 1) * 3 * sizeof(int32_t));
+    Octree t; memset(&t, 0, sizeof t);
+    t.capNodes = 1024; t.nodes = (OctNode*)malloc(t.capNodes * sizeof(OctNode));
+    if (!pos || !ext || !t.nodes) { free(pos); free(ext); free(t.nodes); return -1; }
+    memset(&t.nodes[0], 0, sizeof(OctNode));
+    t.nodes[0].size = rootSize; t.nodes[0].child = -1; t.numNodes = 1; t.minSize = minSize; t.pos = pos; t.ext = ext;
+    uint64_t notInserted = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const float* b = worldAabb + 6 * (size_t)i;
+        for (int a = 0; a < 3; a++) {
+            const float c = (b[a] + b[3 + a]) * 0.5f, e = (b[3 + a] - b[a]) * 0.5f;   /* GetCenter / GetExtents */
+            pos[3 * (size_t)i + a] = (int32_t)c;                                        /* glm::ivec3(glm::vec4 / glm::vec3): truncation */
+            ext[3 * (size_t)i + a] = (int32_t)e;
+        }
+        if (outIntBoxes) { memcpy(outIntBoxes + 6 * (size_t)i, pos + 3 * (size_t)i, 12); memcpy(outIntBoxes + 6 * (size_t)i + 3, ext + 3 * (size_t)i, 12); }
+        if (oct_insert(&t, 0, i)) outInserted[i >> 6] |= 1ull << (i & 63);
+        else notInserted++;
+    }
+    uint64_t visited = 0;
+    {   /* Trace (:239-247): the root's own box first */
+        const float h = (float)t.nodes[0].size * 0.5f;
+        const float box[6] = { (float)t.nodes[0].c[0] - h, (float)t.nodes[0].c[1] - h, (float)t.nodes[0].c[2] - h,
+                               (float)t.nodes[0].c[0] + h, (float)t.nodes[0].c[1] + h, (float)t.nodes[0].c[2] + h };
+        if (overlaps_aabb(planes, box)) oct_trace(&t, 0, planes, outVisible, &visited);
+    }
+    uint32_t smallest = rootSize;
+    for (size_t k = 0; k < t.numNodes; k++) { if (t.nodes[k].size < smallest) smallest = t.nodes[k].size; free(t.nodes[k].el); }
+    if (stats) { stats[0] = t.numNodes; stats[1] = visited; stats[2] = notInserted; stats[3] = smallest; }
+    free(t.nodes); free(pos); free(ext);
+    return 0;
+}
