@@ -146,7 +146,9 @@ class HipDevice:
     def capture(self, stream, body):
         """body() recorded into one hipGraph on `stream`; .replay() launches it"""
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=stream):
+        # (thread-local capture: in a process group the NCCL watchdog thread polls its work objects' events with hipEventQuery at any time, which a GLOBAL-mode
+        # capture on this thread turns into an error that kills the run -- seen once in a while when a capture follows a collective closely; round 6)
+        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
             body()
         return g
 
@@ -660,7 +662,7 @@ def ibl_prefilter_block(ctx, steps: int):
             "kind": "port"}
 
 
-def shadow_pass_block(ctx, count: int, size: int, steps: int, use_coarse: bool = True, front_to_back: bool = True):
+def shadow_pass_block(ctx, count: int, size: int, steps: int, use_coarse: bool = True, front_to_back: bool = True, cascades=(0, 1, 2, 3)):
     """SURVEY.md 8f rank 3, the producer: the shadow passes of one directional light over `count` entities drawn as their bounding boxes (12
     triangles each) -- cascade sets from the sweep's world boxes, the caster draws of the four cascades into size x size depth buffers (compute
     rasteriser), ShadowCaster's fragment stage (cascade 0: EVSM moments, 1-3: R16F) and the EVSM blur of cascade 0.  CPU: the oracle rasteriser
@@ -691,7 +693,7 @@ def shadow_pass_block(ctx, count: int, size: int, steps: int, use_coarse: bool =
     coarse = torch.empty(int(ctx._lib.sailor_hip_raster_coarse_words(size, size)), dtype=torch.int32, device=ctx.device) if use_coarse else None
     out = {"entities": count, "map_size": size, "coarse_depth": use_coarse, "front_to_back": front_to_back, "cascades": []}
     total = 0.0
-    for k in range(4):
+    for k in cascades:   # (all four in the line; one alone for a profile of its draw: scripts/r06_raster_probe.py)
         def draw(k=k):
             ctx._lib.sailor_hip_raster_depth(ctx.handle, np.ascontiguousarray(sh.lights_matrices[k], np.float32).ctypes.data_as(C_float_p), pos.data_ptr(), tris.data_ptr(), 12,
                                              models.data_ptr(), ids[k].data_ptr(), len(ids_h[k]), size, size, depth[k].data_ptr(), 3, coarse.data_ptr() if coarse is not None else None)  # flags: CLEAR | CULL_BACK (the shadow material, ShadowPrepassNode.cpp:39)
@@ -700,7 +702,17 @@ def shadow_pass_block(ctx, count: int, size: int, steps: int, use_coarse: bool =
         cover = float((depth[k] > 0).float().mean().item())
         out["cascades"].append({"instances": int(len(ids_h[k])), "triangles": int(len(ids_h[k])) * 12, "raster_ms": ms, "resolve_ms": rs, "covered": cover,
                                 "mtriangles_per_s": len(ids_h[k]) * 12 / ms / 1e3})
+        if hasattr(ctx._lib, "sailor_hip_raster_stats"):   # (a -DRASTER_STATS build through SAILOR_HIP_LIB: the counters of ONE draw of this cascade)
+            st = (_C.c_ulonglong * 16)()
+            ctx.synchronize(); ctx._lib.sailor_hip_raster_stats(st, 1)
+            draw(); ctx.synchronize(); ctx._lib.sailor_hip_raster_stats(st, 1)
+            out["cascades"][-1]["stats"] = dict(zip(("superblocks_seen", "superblocks_alive", "blocks_seen", "blocks_alive", "texels_inside", "texels_written",
+                                                      "blocks_written_whole", "extra", "wave_ticks_sum", "wave_ticks_max", "waves", "waves_over_100us", "waves_over_1ms"),
+                                                     (int(v) for v in st)))
         total += ms + rs
+    if 0 not in cascades:
+        out["all_passes_ms"] = total
+        return out
     moments = shadow_resolve(ctx, depth[0], L_RGBA32F)
     tmp = torch.empty_like(moments)
     _, bs, _, _ = side_ms(lambda: evsm_blur(ctx, moments, 2, 5, tmp), steps)

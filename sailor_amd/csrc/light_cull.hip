@@ -877,6 +877,94 @@ __global__ __launch_bounds__(256) void k1_group_lists_wide(const unsigned long l
     }
 }
 
+// Round 6: the same lists with the masks read LESS OFTEN.  In the kernel above a block is four column-adjacent groups of one group row: every group streams its
+// column's whole mask and a quarter of the row band's -- (4 + 1) / 4 = 1.25 mask rows per group and step; at a million lights on the 8K frame that is 8 160 groups
+// x 128 KB x 1.25 = 1.3 GB out of the Infinity Cache (the masks are 24.6 MB: they live there, not in the XCDs' 4 MB L2s) for 84 us -- 370 MB of it HBM reads
+// (profiles/r05/traffic_C5.json), fifteen times the masks' size.  Here a block is a 4 x 4 patch of groups, sixteen waves: per step the block fetches each of its
+// four column masks and each of its four row-band masks ONCE (sixteen 1 KB rows -- one load per wave) into LDS, and every wave ANDs its own pair from there:
+// (4 + 4) / 16 = 0.5 mask rows per group and step.  The rest is the kernel above -- queue the non-empty words, drain 64 at a time one lane per word -- with the
+// row's 128 words taken as two halves of 64 (lane l: words l and 64 + l) so that a queue of 128 entries is enough (< 64 pending + <= 64 new) and sixteen of them
+// fit beside the mask rows: 56 KB of LDS a block, two blocks -- 32 waves -- per CU.  Same lists, bit for bit: entries leave in word order, bits ascending.
+#define GLW16_ROWS 2  // rows of 128 words per step and source
+#define GLW16_Q 128   // queued words per wave
+template <bool EXACT> // EXACT: words is a multiple of 128 * GLW16_ROWS, no load needs a bounds check
+__global__ __launch_bounds__(1024) void k1_group_lists_wide16(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ dirWords, int stride,
+                                                              int groupsX, int groupsY, uint32_t* __restrict__ groupCount, uint32_t* __restrict__ groupList,
+                                                              const uint32_t* __restrict__ dirFlag, const uint32_t* __restrict__ selCount)
+{
+    const int words = (!EXACT && selCount) ? min((int)(((*selCount + 63u) / 64u + 1u) & ~1u), stride) : stride;
+    __shared__ __attribute__((aligned(16))) unsigned long long sMask[2][8][GLW16_ROWS][128]; // [buffer][0-3: the block's columns, 4-7: its row bands][row of the step][word]
+    __shared__ unsigned long long sQBits[16][GLW16_Q];
+    __shared__ uint32_t sQWord[16][GLW16_Q];
+    const bool anyDir = *dirFlag != 0u;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wc = wave & 3, wr = wave >> 2;
+    const int blocksX = (groupsX + 3) / 4;
+    const int by = (int)blockIdx.x / blocksX, bx = (int)blockIdx.x % blocksX;
+    const int gx = bx * 4 + wc, gy = by * 4 + wr;
+    const bool mine = gx < groupsX && gy < groupsY;
+    const int g = min(gy, groupsY - 1) * groupsX + min(gx, groupsX - 1);
+    // this wave's share of the block's fetches: source src (a column or a row band of the patch), row k of every step
+    const int src = wave >> 1, k = wave & 1;
+    const unsigned long long* __restrict__ m = masks + (size_t)(src < 4 ? min(bx * 4 + src, groupsX - 1) : groupsX + min(by * 4 + (src - 4), groupsY - 1)) * stride;
+    uint32_t* __restrict__ list = groupList + (size_t)g * CAPG;
+    unsigned long long* qBits = sQBits[wave];
+    uint32_t* qWord = sQWord[wave];
+    const int rows = (words + 127) / 128, steps = (rows + GLW16_ROWS - 1) / GLW16_ROWS;
+    const ulonglong2 zero2 = { 0ull, 0ull };
+    auto load2 = [&](int row) {
+        const int w = row * 128 + lane * 2;
+        if (EXACT) return *reinterpret_cast<const ulonglong2*>(m + (row < rows ? w : lane * 2)); // (the prefetch past the last step re-reads row 0; unused)
+        return w < words ? *reinterpret_cast<const ulonglong2*>(m + w) : zero2;
+    };
+    uint32_t base = 0, qHead = 0, qTail = 0; // the group's entries so far; ring indices (wave-uniform)
+    auto drain = [&](uint32_t n) {
+        const uint32_t qi = (qHead + (uint32_t)lane) & (GLW16_Q - 1);
+        const bool have = (uint32_t)lane < n;
+        unsigned long long mm = have ? qBits[qi] : 0ull;
+        const uint32_t w = have ? qWord[qi] : 0u;
+        const unsigned long long dd = (have && anyDir) ? dirWords[w] : 0ull;
+        const uint32_t cnt = (uint32_t)__popcll(mm);
+        const uint32_t incl = wave_incl_scan_u32(cnt);
+        uint32_t pos = base + incl - cnt;
+        const uint32_t first = w * 64u;
+        while (mm != 0ull) {
+            const int bit = __builtin_ctzll(mm);
+            mm &= mm - 1ull;
+            if (pos < CAPG) list[pos] = (first + (uint32_t)bit) | (uint32_t)((dd >> bit) & 1ull) << 31; // bit 31 = directional
+            pos++;
+        }
+        base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        qHead += n;
+    };
+    ulonglong2 next = load2(k);
+    for (int s = 0; s < steps; s++) {
+        *reinterpret_cast<ulonglong2*>(&sMask[s & 1][src][k][lane * 2]) = next;
+        next = load2((s + 1) * GLW16_ROWS + k); // the next step's row is requested before this step's work
+        __syncthreads(); // this step's sixteen rows are in LDS (the buffer of step s - 1 is free: every wave has passed its reads of it)
+        if (!mine) continue;
+#pragma unroll
+        for (int r = 0; r < GLW16_ROWS; r++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) { // the row's words [64 h, 64 h + 64), one per lane
+                const unsigned long long mm = sMask[s & 1][wc][r][h * 64 + lane] & sMask[s & 1][4 + wr][r][h * 64 + lane];
+                const unsigned long long b = __ballot(mm != 0ull);
+                if (b == 0ull) continue; // (wave-uniform)
+                if (mm != 0ull) {
+                    const uint32_t i = (qTail + (uint32_t)__popcll(b & lanemask_lt())) & (GLW16_Q - 1);
+                    qBits[i] = mm; qWord[i] = (uint32_t)((s * GLW16_ROWS + r) * 128 + h * 64 + lane);
+                }
+                qTail += (uint32_t)__popcll(b);
+                if (qTail - qHead >= 64u) { WAVE_SYNC(); drain(64u); WAVE_SYNC(); }
+            }
+        }
+    }
+    if (mine) {
+        if (qTail != qHead) { WAVE_SYNC(); drain(qTail - qHead); }
+        if (lane == 0) groupCount[g] = base > CAPG ? GROUP_OVERFLOW : base;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // K1c: exact per-tile cull, one wave per tile, canonical offsets by decoupled look-back, lists written in place.
 // ------------------------------------------------------------------------------------------------------------
@@ -1749,8 +1837,17 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
         const bool wide = L.words >= 4096 && (L.words & 1) == 0;
         if (wide)
         {
+            // (round 6: a 4 x 4 patch of groups per block -- every mask row crosses into the block once for sixteen groups; SAILOR_CULL_WIDE16=0: the form above)
+            static const bool wide16 = [] { const char* e = getenv("SAILOR_CULL_WIDE16"); return !e || atoi(e) != 0; }();
             const dim3 wideGrid((unsigned)(((L.groupsX + 3) / 4) * L.groupsY));
-            if (L.words % (128 * GLW_ROWS) == 0 && !select)
+            const dim3 wide16Grid((unsigned)(((L.groupsX + 3) / 4) * ((L.groupsY + 3) / 4)));
+            if (wide16 && L.words % (128 * GLW16_ROWS) == 0 && !select)
+                sailor_launch(ctx, k1_group_lists_wide16<true>, wide16Grid, dim3(1024), pa.masks, pa.dirWords, L.words, L.groupsX, L.groupsY, (uint32_t*)(ws + L.offGroupCount),
+                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag), (const uint32_t*)nullptr);
+            else if (wide16)
+                sailor_launch(ctx, k1_group_lists_wide16<false>, wide16Grid, dim3(1024), pa.masks, pa.dirWords, L.words, L.groupsX, L.groupsY, (uint32_t*)(ws + L.offGroupCount),
+                                   (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag), pa.selCount);
+            else if (L.words % (128 * GLW_ROWS) == 0 && !select)
                 sailor_launch(ctx, k1_group_lists_wide<true>, wideGrid, dim3(256), pa.masks, pa.dirWords, L.words, L.groupsX, (uint32_t*)(ws + L.offGroupCount),
                                    (uint32_t*)(ws + L.offGroupList), (const uint32_t*)(ws + L.offDirFlag), (const uint32_t*)nullptr);
             else

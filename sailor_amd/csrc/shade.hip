@@ -82,6 +82,9 @@ template <bool ON> __device__ __forceinline__ void sprof_mark_grid(const int i) 
         SPROF_TG(3, !(IBL))                                                                                                               \
     }
 #define FORCE_64_VGPRS __attribute__((amdgpu_waves_per_eu(8, 8)))
+#ifndef SHADE_HALF_DEFAULT
+#define SHADE_HALF_DEFAULT false
+#endif
 // (the K3 kernels: 64 registers like the others since the shadow look-ups run before the view / material terms -- "K3 first" in shade_body.h; it
 // was 80 = six waves per SIMD.  The pin matters: unpinned, the prepared twins come out at 116-134.)
 #define CSM_PIN __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -97,6 +100,20 @@ SHADE_ENTRIES(, false, false)
 SHADE_ENTRIES(_p, true, false)
 SHADE_ENTRIES(_t, false, true)
 SHADE_ENTRIES(_pt, true, true)
+
+// The same kernels as TWO-wave blocks, one per half tile (round 6; ShadeLdsT<2>): 128 threads, 8.7 KB of LDS -- sixteen blocks per CU.
+#define SHADE_ENTRY_H(NAME, ATTR, CSM, PREP, TL)                                                                                                   \
+    __global__ __launch_bounds__(128) ATTR void NAME(ShadeArgs A, CsmArgs C, IblArgs I, const float4* __restrict__ surface, size_t planeStride,    \
+                                                     const SailorLightShaderData* __restrict__ lights, const SailorLightsGrid* __restrict__ grid, \
+                                                     const uint32_t* __restrict__ culled, float4* __restrict__ radiance)                          \
+    {                                                                                                                                              \
+        __shared__ ShadeLdsT<2> lds;                                                                                                               \
+        k2_shade_body<CSM, false, ROLE_TILE, PREP, TL, 2>(lds, A, C, I, surface, planeStride, lights, grid, culled, radiance);                     \
+    }
+// (only the forms that keep 64 registers without scratch: prepared lights -- the second staging round is then a copy -- and no shadow maps; the K3 body inside
+// the round loop spills nine to eleven registers, the in-kernel staging three)
+SHADE_ENTRY_H(k2_shade_h_p, FORCE_64_VGPRS, false, true, false)
+SHADE_ENTRY_H(k2_shade_h_pt, FORCE_64_VGPRS, false, true, true)
 
 template <bool PREP, bool TL, bool CSM>
 __device__ __forceinline__ void k2_shade_band_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, int bandTiles, const float4* __restrict__ surface, size_t planeStride,
@@ -423,7 +440,18 @@ static int shade_impl(SailorHipContext* ctx, const SailorUboFrameData* frame, co
     // an eighth of C4 took 62.2 us per step instead of 56.8: profiles/r05/ab_band_csm_waves.txt, probe Q)
     const bool reserve = (bandTiles <= 3 * 8 * ctx->numCUs || lightsNum >= 131072) && !(hasCsm && splitBand);
     const unsigned bandLds = (!partial || ibl) ? 0u : (bandLdsEnv >= 0 ? (unsigned)bandLdsEnv : (reserve ? (unsigned)SHADE_BAND_RESERVE : 0u));
-    if (hasCsm && ibl) LAUNCH_SHADE(k2_shade_csm_ibl);
+    // Two-wave blocks, one per half tile (round 6; SAILOR_SHADE_HALF=1): built for the wave-slot gap of the four-wave form (a new block needs a free slot on all
+    // four SIMDs at once), parity-green, and measured NEUTRAL on the 4K frame -- kernel 134.6 / 135.3 us against 136.3 / 135.7, step 171.4 / 169.8 against
+    // 170.5 / 168.4, same box, alternating runs (profiles/r06/ab_two_wave_blocks.txt): off by default.  Not with the ambient term, shadow maps, in-kernel
+    // staging or the band form's split launch.
+    static const int halfEnv = [] { const char* e = getenv("SAILOR_SHADE_HALF"); return e ? atoi(e) : -1; }();
+    const bool halfBlocks = (halfEnv >= 0 ? halfEnv != 0 : SHADE_HALF_DEFAULT) && !ibl && !splitBand && !hasCsm && dPreparedLights;
+    if (halfBlocks) {
+        const dim3 gridH(2u * grid.x, grid.y, grid.z);
+        if (dTileNum) { kname = "k2_shade_h_pt"; sailor_launch_lds(ctx, k2_shade_h_pt, gridH, dim3(128), bandLds, A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); }
+        else { kname = "k2_shade_h_p"; sailor_launch_lds(ctx, k2_shade_h_p, gridH, dim3(128), bandLds, A, C, I, S, surfacePlaneStride, L, G, dCulledLights, Rd); }
+    }
+    else if (hasCsm && ibl) LAUNCH_SHADE(k2_shade_csm_ibl);
     else if (hasCsm && !splitBand) LAUNCH_SHADE(k2_shade_csm);
     else if (ibl) LAUNCH_SHADE(k2_shade_ibl);
     else if (splitBand) {

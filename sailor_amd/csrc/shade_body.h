@@ -516,12 +516,17 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 #define SPLIT_BLOCKS 2048 // one round of resident blocks (8 per CU)
 #endif
 static_assert(QMAX <= 128 && 7 * PENDK < 32 && 3 * QMAX >= 192, "queue positions are 7 bits each under a sentinel bit; the split blocks park 3 x 64 partial sums in a wave's slots");
-struct ShadeLds {
-    float4 sL[KEEP * LREC];
-    float sRes[4 * 3 * QMAX]; // per wave: [3 colours][queue position]
-    uint16_t sQ[4 * QMAX];
+// WAVES = 4: one block per 16 x 16 tile, all <= 128 records staged at once.  WAVES = 2 (round 6): one block per HALF tile (two 8 x 8 quadrants side by side),
+// the records staged 64 at a time (a second round for the few tiles with more): 8.7 KB a block -- sixteen two-wave blocks fit a CU where eight four-wave
+// ones did, and a new block needs a free wave slot on two SIMDs, not on all four at once.
+template <int WAVES>
+struct ShadeLdsT {
+    float4 sL[(WAVES == 2 ? 64 : KEEP) * LREC];
+    float sRes[WAVES * 3 * QMAX]; // per wave: [3 colours][queue position]
+    uint16_t sQ[WAVES * QMAX];
     uint32_t sEnd[4];
 };
+typedef ShadeLdsT<4> ShadeLds;
 #define ROLE_TILE 0       // one block per tile, grid (tiles per row, tile rows)
 #define ROLE_BAND_TILE 1  // the same inside k2_shade_band: returns at once on a tile of the split blocks
 #define ROLE_BAND_SPLIT 2 // one block per (long tile, quadrant)
@@ -538,8 +543,8 @@ struct ShadeLds {
 // of LDS of its own: no barrier, nobody's slowest quadrant to sit out -- fills 90 % of the slots (the gap shrinks to 0.8 us) but every wave then does the
 // list's loads and the compaction itself: wave life 7.44 us, kernel 140 against 135 us, and the frame pipeline's step 176 against 166 us because the next
 // frame's cull blocks no longer find four free slots beside it.  Oracle parity was green; profiles/r05/ab_quad_form.txt.)
-template <bool HAS_CSM, bool HAS_IBL, int ROLE = ROLE_TILE, bool PREPARED = false, bool TILE_LISTS = false>
-__device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A, const CsmArgs& C, const IblArgs& I, const float4* __restrict__ surface, size_t planeStride,
+template <bool HAS_CSM, bool HAS_IBL, int ROLE = ROLE_TILE, bool PREPARED = false, bool TILE_LISTS = false, int WAVES = 4>
+__device__ __forceinline__ void k2_shade_body(ShadeLdsT<WAVES>& lds, const ShadeArgs& A, const CsmArgs& C, const IblArgs& I, const float4* __restrict__ surface, size_t planeStride,
                                                  const SailorLightShaderData* __restrict__ lights,
                                                  const SailorLightsGrid* __restrict__ grid, const uint32_t* __restrict__ culled,
                                                  float4* __restrict__ radiance, int selTx = 0, int selTy = 0, int selQuad = 0)
@@ -550,6 +555,9 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     uint32_t* const sEnd = lds.sEnd;
     constexpr bool BAND = ROLE != ROLE_TILE;
     constexpr bool splitRole = ROLE == ROLE_BAND_SPLIT;
+    constexpr bool HALFT = WAVES == 2;                 // a half-tile block: two waves, staging rounds of 64 records
+    constexpr int HN = HALFT ? 1 : 2;                  // 64-slot halves of the staged records
+    static_assert(WAVES == 4 || (WAVES == 2 && ROLE == ROLE_TILE), "two-wave blocks exist in the per-tile grid only");
     int tid = threadIdx.x;
     // (the band kernel holds two copies of this body at 64 registers each, and the thread id -- live from the entry through both -- is what the
     // allocator spills: seven reloads from scratch in the prologue of every ordinary tile.  Put together again from the wave's number, a
@@ -570,10 +578,11 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     // vertically adjacent tiles meet in one L2 -- k2_shade_csm_p 234 -> 225 us on C4; the plain kernel, which has no texels to share, pays 4.6 %
     // for that: the light cluster's columns land on three of the eight XCDs.)
     constexpr unsigned rot = HAS_CSM ? 0u : 1u;
-    int btx = ((int)((blockIdx.x - (unsigned)bty * rot) & 7u) + 8 * (int)blockIdx.y) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    // (two-wave blocks: the fastest grid dimension counts HALF tiles, 8 x 2 x tiles per piece -- the two halves of a tile are neighbours on one XCD)
+    int btx = ((int)((blockIdx.x - (unsigned)bty * rot) & 7u) + 8 * (int)blockIdx.y) * (int)(gridDim.x >> (HALFT ? 4 : 3)) + (int)(blockIdx.x >> (HALFT ? 4 : 3));
     if (ROLE == ROLE_TILE && btx >= A.Tx) return;
     const int lane = tid & 63, wave = tid >> 6;
-    int quad = wave;
+    int quad = HALFT ? 2 * (int)((blockIdx.x >> 3) & 1u) + wave : wave;
     if (BAND) { btx = selTx; bty = selTy; if (splitRole) quad = selQuad; }
     const int tx = btx, ty = A.tileRow0 + bty;
     const int bandTile = bty * A.Tx + btx;
@@ -612,7 +621,9 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
     const unsigned long long stagedMask = __ballot(index < (uint32_t)A.lightsNum); // (a lane without a list slot holds uint(-1))
     const bool staged = __builtin_amdgcn_inverse_ballot_w64(stagedMask);
     float4 q0, q1, q2, q3, q4, q5, q6;
-    if (staged) {
+    // (two-wave blocks: wave 0 stages slots 0-63 now; wave 1's slots 64-127 wait for the second staging round -- their indices only decide where the list ends)
+    const bool stager = !HALFT || __builtin_amdgcn_readfirstlane(wave) == 0;
+    if (staged && stager) {
         if constexpr (PREPARED) {
             const float4* L = reinterpret_cast<const float4*>(lights) + (size_t)index * LREC;
             q0 = L[0]; q1 = L[1]; q2 = L[2]; q3 = L[3]; q4 = L[4];
@@ -663,7 +674,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         const unsigned long long bad = haveMask & ~stagedMask;
         if (lane == 0) sEnd[wave] = bad ? (uint32_t)(wave * 64 + __builtin_ctzll(bad)) : 0xFFFFFFFFu;
     }
-    if (staged) {
+    if (staged && stager) {
         // (staging is the block's critical path -- the other three waves wait at the barrier for the first; with PREPARED records it is a copy)
         float4* o = sL + tid * LREC;
         if constexpr (PREPARED) { o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3; o[4] = q4; }
@@ -674,7 +685,7 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the records are in LDS (global loads may stay in flight)
-    const uint32_t numLights = min(min(listNum, sEnd[0]), min(sEnd[1], min(sEnd[2], sEnd[3])));
+    const uint32_t numLightsAll = HALFT ? min(listNum, min(sEnd[0], sEnd[1])) : min(min(listNum, sEnd[0]), min(sEnd[1], min(sEnd[2], sEnd[3])));
     const float alpha = roughness * roughness, alphaSq = alpha * alpha;
 
     // ---- which lights can reach this quadrant at all?  One LANE per LIGHT against the bounding SPHERE of the quadrant's 64 surface
@@ -693,314 +704,349 @@ __device__ __forceinline__ void k2_shade_body(ShadeLds& lds, const ShadeArgs& A,
         sphereR = __builtin_amdgcn_sqrtf(__uint_as_float(wave_max_u32(active ? __float_as_uint(d2c) : 0u))) * 1.0001f;
     }
     const unsigned long long forceMask = activeMask & __ballot(!(alphaSq > 0.0f)); // roughness 0: such pixels must see every light (0 * NaN)
-    // survivors by kind: [0,1] finite point lights, [2,3] finite spot lights, [4,5] the rest (directional, unknown type,
-    // non-finite intensity: every pixel is a pair) -- for list slots 0..63 and 64..127
-    unsigned long long seg[8] = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull }; // [6,7]: directional lights (type 0), see the loop behind the queue
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        if ((uint32_t)(h * 64) >= numLights) break;
-        // (every condition as a wave mask of ONE simple compare, the combinations as scalar mask arithmetic: a bool that is assigned in branches
-        // lives in a VGPR as 0 / 1 and costs a v_cndmask + v_cmp per use)
-        const uint32_t li = (uint32_t)(h * 64 + lane);
-        const uint32_t lc = li < numLights ? li : 0u; // (lanes past the list read slot 0 and are masked out)
-        const float4 c0 = sL[lc * LREC + 0];
-        const float4 c1 = sL[lc * LREC + 1];
-        const uint32_t bits = __float_as_uint(c1.w);
-        const unsigned long long mIn = __ballot(li < numLights);
-        const unsigned long long mFin = __ballot((bits & 0x10000u) != 0u);
-        const unsigned long long mPoint = __ballot((bits & 0xFFu) == 1u), mSpot = __ballot((bits & 0xFFu) == 2u), mDir = __ballot((bits & 0xFFu) == 0u);
-        const float ex = c0.x - scx, ey = c0.y - scy, ez = c0.z - scz;
-        const float t = __builtin_amdgcn_sqrtf(c0.w) * 1.0001f + sphereR; // c0.w = r^2 (1 + 1e-5) (+inf: never reject)
-        const float e2 = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
-        const unsigned long long mFar = __ballot(e2 > t * t); // only meaningful for finite point lights
-        // A spot light whose cone misses the sphere: seen from the light the sphere spans the angle delta = asin(R / |e|) around the direction
-        // to its centre, which makes the angle A with the cone's axis; no pixel can do better than cos(A - delta) = cosA cosd + sinA sind, and
-        // the per-pixel test passes from c = cutOff.y - 1e-5 (= -rec0.w) up.  Approximate arithmetic (v_rsq / v_sqrt), hence the 1e-4; a NaN
-        // anywhere (the light inside the sphere: sind > 1; a zero axis) fails the compares and keeps the light.  On the 4K frame 6.0 spot
-        // lights per quadrant come this far, 1.6 reach a pixel, 3.8 pass this test (scripts/analysis/shade_trips.py).
-        const float rinv = rsq_fast(e2);
-        const float sind = sphereR * rinv;
-        const float cosA = fmaf(ex, c1.x, fmaf(ey, c1.y, ez * c1.z)) * rinv;
-        const float cosd = __builtin_amdgcn_sqrtf(fmaf(-sind, sind, 1.0f)), sinA = __builtin_amdgcn_sqrtf(fmaf(-cosA, cosA, 1.0f));
-        const unsigned long long mOut = __ballot(fmaf(sinA, sind, cosA * cosd) < -c0.w - 1e-4f) & __ballot(cosA < cosd); // only meaningful for finite spot lights
-        const unsigned long long dropped = forceMask == 0ull ? (mFin & ((mPoint & mFar) | (mSpot & mOut))) : 0ull;
-        const unsigned long long all = mIn & ~dropped;
-        seg[h] = all & mFin & mPoint;
-        seg[2 + h] = all & mFin & mSpot;
-        seg[6 + h] = mIn & mDir;
-        seg[4 + h] = all & ~(seg[h] | seg[2 + h] | seg[6 + h]);
-    }
-
-    if (BAND && splitRole) { // this wave's share of the list: every fourth slot
-        const unsigned long long share = 0x1111111111111111ull << __builtin_amdgcn_readfirstlane(wave); // (scalar: the masks stay in SGPRs)
-#pragma unroll
-        for (int q = 0; q < 8; q++) seg[q] &= share;
-    }
-
-    // ---- directional lights (staged kind 0, with the odd point / spot light of stage_light_record): every pixel is a pair, so they are shaded one
-    // LANE per PIXEL from the pixel's own registers -- no queue, no pulls -- in list order, nothing skipped (cosLi = 0 and non-finite intensities
-    // take their natural course).  `shadow` = the light's K3 factor (Standard.shader:266-283), or the exact falloff of an odd light.
-    auto shade_directional = [&](const float4* R, const float shadow) {
-        const float4 r3 = R[3], r4 = R[4];
-        // ---- Cook-Torrance (Standard.shader:309-340), as in the pair pass ----
-        const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
-        float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;
-        const float hinv = rcp_of_sqrt(sqrt_exact(dot3f(hx, hy, hz, hx, hy, hz)));          // exact chain: Lh = normalize(Li + Lo)
-        hx *= hinv; hy *= hinv; hz *= hinv;
-        const float cosLi = fmaxf(0.0f, dot3f(nx, ny, nz, Lix, Liy, Liz));
-        const float cosLh = fmaxf(0.0f, dot3f(nx, ny, nz, hx, hy, hz));
-        const float x1 = 1.0f - fmaxf(0.0f, dot3f(hx, hy, hz, Lox, Loy, Loz));
-        const float x2 = x1 * x1, x5 = x2 * x2 * x1;
-        const float dn = (cosLh * cosLh) * (alphaSq - 1.0f) + 1.0f;
-        const float D = alphaSq * rcp_fast(3.14159265359f * dn * dn);
-        const float G = cosLi * rcp_fast(fmaf(cosLi, oneMinusK, k)) * g1Lo;
-        const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * cosLo));
-        const float scale = shadow * cosLi; // falloff = 1 (:287)
-        const float Fx = F0x + (1.0f - F0x) * x5, Fy = F0y + (1.0f - F0y) * x5, Fz = F0z + (1.0f - F0z) * x5;
-        accX += (fmaf(1.0f - Fx, kdAx, Fx * spec) * r4.x) * scale;
-        accY += (fmaf(1.0f - Fy, kdAy, Fy * spec) * r4.y) * scale;
-        accZ += (fmaf(1.0f - Fz, kdAz, Fz * spec) * r4.z) * scale;
-    };
-    // the factor of the light in list slot `slot`: its shadow look-up (K3), or the IEEE falloff of a light from far outside the staged reciprocal's range
-    auto directional_factor = [&](const int slot) -> float {
-        const float4* R = sL + (uint32_t)slot * LREC;
-        const uint32_t lbits = __builtin_amdgcn_readfirstlane(__float_as_uint(R[1].w));
-        if (__builtin_expect((lbits >> LIGHT_SLOW_SHIFT) != 0u, 0))
-            return exact_falloff(std::true_type{}, (lbits >> LIGHT_SLOW_SHIFT) == 1u, R, R[0], R[1], R[3].w, wxyp, wz);
-        if constexpr (HAS_CSM) {
-            const float4 r3 = R[3];
-            return directional_shadow(A, C, (lbits >> 8) & 0xFFu, -r3.x, -r3.y, -r3.z, nx, ny, nz, wx, wy, wz);
-        }
-        return 1.0f;
-    };
-    if constexpr (K3_FIRST) {
-        // ---- K3 first: per directional light its factor (one register), THEN the view / material terms, then the light's Cook-Torrance term.
-        // One round in practice (a tile with several directional lights repeats it and recomputes the terms: the camera position and the
-        // constant 1 they are computed from are made opaque, so that the compiler cannot hoist them out of the loop and across the look-up).
-        unsigned long long d0 = seg[6], d1 = seg[7];
-        do {
-            int slot = -1;
-            float f = 1.0f;
-            if ((d0 | d1) != 0ull) {
-                slot = d0 != 0ull ? __builtin_ctzll(d0) : 64 + __builtin_ctzll(d1);
-                if (d0 != 0ull) d0 &= d0 - 1ull; else d1 &= d1 - 1ull;
-                f = directional_factor(slot);
-            }
-            float camX = A.camX, camY = A.camY, camZ = A.camZ, one = 1.0f;
-            asm volatile("" : "+s"(camX), "+s"(camY), "+s"(camZ), "+s"(one));
-            view_and_material(camX, camY, camZ, one);
-            if (slot >= 0) shade_directional(sL + (uint32_t)slot * LREC, f);
-        } while ((d0 | d1) != 0ull);
-    }
-
-    // ---- 2 + 3. queue the (pixel, light) pairs that can be lit, then shade them one LANE per PAIR ----
-    // Window = up to QMAX queued pairs, at most PENDK per pixel; a light whose pairs do not fit ends the window (it is
-    // tested again in the next one -- rare: a quadrant of the 4K frame queues ~50 pairs).  A pair's result goes to slot
-    // [colour][its position in the queue]; each pixel keeps the positions of its own pairs (7 bits each, in the order queued, under a
-    // sentinel bit) and adds their results up afterwards: no atomics (ds_add_f32 is serialised per lane on this LDS: ~170 cycles
-    // per wave instruction, scripts/microbench/lds_ops.hip).  (Was: slots [colour][ordinal of the pair among its pixel's][pixel] --
-    // 9 KB per block instead of 6, a cap of three pairs per pixel and window instead of four, and an address of three instructions in the pair
-    // pass instead of one.  More blocks per CU were NOT what it bought: with room for ten the kernel takes what it takes with eight -- the
-    // 32 wave slots of a CU are the cap.)
-    uint16_t* Q = sQ + wave * QMAX;
-    const uint32_t qAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)Q; // its LDS byte address, for the hand-written append below
-    const uint32_t sLAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)sL;
-    static_assert(LREC == 5, "SHADE_LIGHT_LOOP computes 80 x slot as (5 x slot) << 4");
-    float* res = sRes + wave * (3 * QMAX); // this wave's [3 colours][QMAX queue positions] slots
+    // ---- one staging round: the staged records -> this quadrant's lit pairs -> the sums.  Four-wave blocks stage the whole list at once and run this once;
+    // a two-wave block runs it once per 64 list slots (a second time for the few tiles with more than 64 lights: the records of slots 64-127 are
+    // staged by wave 1 behind a barrier that waits for both waves to be done with the first 64).
+    uint32_t roundBase = 0u;
     for (;;) {
-        uint32_t cnt = 0u;      // queued pairs (wave-uniform)
-        uint32_t pc = 1u;       // the queue positions of this pixel's pairs: 1 (sentinel), then 7 bits per pair, the first one queued on top
-        // The wave is bound by instruction issue of every kind (a scalar instruction costs what a vector one costs: measured), and the loop
-        // around a light is mostly scalar mask arithmetic.  In the usual quadrant -- every pixel inside the frame, none with roughness 0 -- the
-        // "force" and "active" masks are the identity, so that case gets its own copy of the loops without them (PLAIN): m = reach & facing.
-        auto light_loop = [&](auto plainTag, auto kindTag, auto hTag) -> bool {
-            constexpr bool PLAIN = decltype(plainTag)::value;
-            constexpr int kind = decltype(kindTag)::value, h = decltype(hTag)::value;
-            unsigned long long todo = seg[kind * 2 + h];
-            unsigned long long rest = 0ull; // on overflow: what is left, this light included
-            if constexpr (PLAIN && kind < 2) {
-                // The usual case by hand (see SHADE_LIGHT_LOOP above): the same tests, the same append, 15 instructions around a light out of
-                // reach where the compiler's control flow takes 21.
-                if (todo != 0ull) {
-                    uint32_t bit, n;
-                    unsigned long long m, ex;
-                    if constexpr (kind == 0 && h == 0) SHADE_LIGHT_LOOP("", "", SHADE_TEST_POINT);
-                    if constexpr (kind == 0 && h == 1) SHADE_LIGHT_LOOP("s_or_b32 %[bit], %[bit], 64\n\t", "", SHADE_TEST_POINT);
-                    if constexpr (kind == 1 && h == 0) SHADE_LIGHT_LOOP("", "ds_read_b96 v[60:62], v62 offset:16\n\t", SHADE_TEST_SPOT);
-                    if constexpr (kind == 1 && h == 1) SHADE_LIGHT_LOOP("s_or_b32 %[bit], %[bit], 64\n\t", "ds_read_b96 v[60:62], v62 offset:16\n\t", SHADE_TEST_SPOT);
-                }
-            } else {
-                // (one way out of the loop, through its condition: with a `break` in the middle the loop is no single-exit region of its own, falls
-                // into the region of the divergent pair pass below and is structurised along with it -- see the append)
-                while (todo) {
-                    const int bit = __builtin_ctzll(todo);
-                    const uint32_t s = (uint32_t)(h * 64 + bit);
-                    unsigned long long m = activeMask; // "the rest": every pixel is a pair
-                    if (kind < 2) {
-                        const float4* R = sL + s * LREC;
-                        const float4 r0 = R[0];
-                        const v2f dxy = v2f{ r0.x, r0.y } - wxy;
-                        const float dz = r0.z - wz;
-                        const float d2 = fmaf(dxy.x, dxy.x, fmaf(dxy.y, dxy.y, dz * dz));
-                        float v = d2;
-                        if (kind == 1) {
-                            // spot: falloff is exactly 0 iff theta < cutOff.y (:303-306); theta ~ dot(d, axis) / |d| to a few ulp
-                            const float4 r1 = R[1];
-                            v = -(fmaf(dxy.x, r1.x, fmaf(dxy.y, r1.y, dz * r1.z)) * rsq_fast(d2));
-                        }
-                        const unsigned long long reach = __ballot(!(v > r0.w));
-                        m = 0ull;
-                        if ((PLAIN ? reach : ((reach | forceMask) & activeMask)) != 0ull) {
-                            // ... and facing it?  cosLi = max(0, n . Li) = 0 zeroes both the specular G term and the final product.
-                            const float4 r3 = R[3];
-                            const unsigned long long facing = __ballot(dot3f(nx, ny, nz, r3.x, r3.y, r3.z) > 0.0f);
-                            m = PLAIN ? (reach & facing) : (((reach & facing) | forceMask) & activeMask);
-                        }
-                    }
-                    if (m != 0ull) {
-                        // (masks of single compares combined as scalars: a ballot of `mine && ...` goes through a VGPR 0 / 1 and back)
-                        if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= (1u << (7 * PENDK)))) != 0ull) { rest = todo; todo = 0ull; continue; }
-                        // The lanes of m append (s << 6 | lane) to the queue and note the position.  Written out with the exec mask set by hand: as
-                        // `if (lane in m) { ... }` this is the only divergent branch of the loops around it, and with it the compiler
-                        // structurises them -- a state variable, three more branches and five more scalar instructions per light.  Every
-                        // lane is live here (the waves are full and nothing above has diverged), so exec goes back to all ones.
-                        uint32_t t0, t1;
-                        asm volatile("s_mov_b64 exec, %[m]\n\t"
-                                     "v_mov_b32 %[t0], %[cnt]\n\t"
-                                     "v_mbcnt_lo_u32_b32 %[t0], %[mlo], %[t0]\n\t"
-                                     "v_mbcnt_hi_u32_b32 %[t0], %[mhi], %[t0]\n\t"   // the count so far rides in as mbcnt's addend
-                                     "v_lshl_or_b32 %[pc], %[pc], 7, %[t0]\n\t"
-                                     "v_lshl_add_u32 %[t0], %[t0], 1, %[q]\n\t"
-                                     "v_lshl_or_b32 %[t1], %[s], 6, %[lane]\n\t"
-                                     "ds_write_b16 %[t0], %[t1]\n\t"
-                                     "s_mov_b64 exec, -1"
-                                     : [t0] "=&v"(t0), [t1] "=&v"(t1), [pc] "+&v"(pc)
-                                     : [m] "s"(m), [mlo] "s"((uint32_t)m), [mhi] "s"((uint32_t)(m >> 32)), [cnt] "s"(cnt), [s] "s"(s), [q] "v"(qAddr), [lane] "v"(lane)
-                                     : "memory");
-                        cnt += (uint32_t)__popcll(m);
-                    }
-                    asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction instead of three
-                }
-            }
-            seg[kind * 2 + h] = rest; // what the next window still has to look at
-            return rest != 0ull;
-        };
-        auto fill_window = [&](auto plainTag) -> bool {
-            using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
-            return light_loop(plainTag, K0{}, K0{}) || light_loop(plainTag, K0{}, K1{}) || light_loop(plainTag, K1{}, K0{}) || light_loop(plainTag, K1{}, K1{}) ||
-                   light_loop(plainTag, K2{}, K0{}) || light_loop(plainTag, K2{}, K1{});
-        };
-        const bool overflow = (forceMask == 0ull && activeMask == ~0ull) ? fill_window(std::true_type{}) : fill_window(std::false_type{});
-        if (cnt == 0u) break;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (uint32_t base = 0u; base < cnt; base += 64u) {
-            // one LANE per PAIR.  The pixel's invariants are pulled from its lane's registers (ds_bpermute: the LDS crossbar,
-            // no LDS memory), the light record from LDS.  All 64 lanes execute the pulls (a disabled source lane returns 0).
-            // (the lanes past the last pair repeat the batch's FIRST pair and store the result in their own slot, which no pixel looks at: every
-            // lane runs the same straight code -- no `if (valid)` around the three stretches of arithmetic, which was 13 instructions of
-            // exec-mask bookkeeping and zero-initialisation per batch)
-            const uint32_t qi = base + (uint32_t)lane;
-            const uint32_t e = Q[qi < cnt ? qi : base];
-            constexpr bool valid = true;
-            const int pa = (int)((e & 63u) << 2);
-            const uint32_t s = (e >> 6) & (uint32_t)(KEEP - 1);
-            const float4* R = sL + s * LREC;
-#define PULL(x) __int_as_float(__builtin_amdgcn_ds_bpermute(pa, __float_as_int(x)))
-            // (float pairs where the arithmetic comes in pairs -- x / y of a vector, two of three colour channels: v_pk_{add,mul,fma}_f32 round each
-            // component like the scalar instruction, so the bits are those of the scalar form, at one issue slot per pair instead of two.  The pulled
-            // values and the LDS reads land in adjacent registers by construction, which is what the compiler's own SLP pairing could not arrange.)
-            float falloff = 1.0f;
-            const float4 r3 = R[3];
-            const p2f pwxy = { PULL(wx), PULL(wy) };
-            const float pwz = PULL(wz);
-            if (valid) {
-                const float4 r0 = R[0], r1 = R[1];
-                const uint32_t type = __float_as_uint(r1.w) & 0xFFu;
-                if (type == 1u || type == 2u) // exact falloff (the oracle's op order where it is ill-conditioned)
-                    falloff = exact_falloff(std::false_type{}, type == 1u, R, r0, r1, r3.w, pwxy, pwz);
-            }
-            // (the pulls are spread out so that at most ten pulled values are live at a time: 64 VGPRs = 8 waves per SIMD)
-            float spec = 0.0f, x5 = 0.0f, scale = 0.0f;
-            {
-                const p2f pnxy = { PULL(nx), PULL(ny) };
-                const float pnz = PULL(nz);
-                const p2f pLoxy = { PULL(Lox), PULL(Loy) };
-                const float pLoz = PULL(Loz);
-                const float pcosLo = PULL(cosLo), pg1Lo = PULL(g1Lo), palphaSq = PULL(alphaSq);
-                const float pkr = HAS_IBL ? PULL(roughness) : PULL(k); // the ambient term at the end needs the roughness itself: pull it, derive k
-                const float pk = HAS_IBL ? ((pkr + 1.0f) * (pkr + 1.0f)) * 0.125f : pkr;
-                if (valid) {
-                    // ---- Cook-Torrance (Standard.shader:309-340) ----
-                    const p2f Lixy = { r3.x, r3.y };
-                    const float Liz = r3.z;
-                    p2f hxy = Lixy + pLoxy;
-                    float hz = Liz + pLoz;
-                    const float hinv = rcp_of_sqrt(sqrt_exact(dot3_pk(hxy, hz, hxy, hz)));          // exact chain: Lh = normalize(Li + Lo)
-                    hxy *= hinv; hz *= hinv;
-                    const float cosLi = fmaxf(0.0f, dot3_pk(pnxy, pnz, Lixy, Liz));
-                    const float cosLh = fmaxf(0.0f, dot3_pk(pnxy, pnz, hxy, hz));
-                    const float x1 = 1.0f - fmaxf(0.0f, dot3_pk(hxy, hz, pLoxy, pLoz));
-                    const float x2 = x1 * x1;
-                    x5 = x2 * x2 * x1;                                                        // pow(1 - cosTheta, 5)
-                    const float dn = (cosLh * cosLh) * (palphaSq - 1.0f) + 1.0f;                // exact: the cancelling denominator
-                    const float D = palphaSq * rcp_fast(3.14159265359f * dn * dn);              // NdfGGX
-                    const float G = cosLi * rcp_fast(fmaf(cosLi, 1.0f - pk, pk)) * pg1Lo;      // GeometrySchlickGGX
-                    spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * pcosLo));
-                    scale = cosLi * falloff; // (shadow = 1: only directional lights are shadowed, and they do not come through the queue)
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const p2f pF0xy = { PULL(F0x), PULL(F0y) };
-                const float pF0z = PULL(F0z);
-                const p2f pkdAxy = { PULL(kdAx), PULL(kdAy) };
-                const float pkdAz = PULL(kdAz);
-                if (valid) {
-                    const p2f Fxy = pF0xy + (1.0f - pF0xy) * x5;
-                    const float Fz = pF0z + (1.0f - pF0z) * x5;
-                    const float4 r4 = R[4];
-                    // shadow * ((kd*albedo + F*D*G/denom) * Lradiance * cosLi) * falloff ; kd = mix(1 - F, 0, metallic)
-                    float* o = res + (base + (uint32_t)lane);
-                    const p2f oxy = (fma2(1.0f - Fxy, pkdAxy, Fxy * spec) * p2f{ r4.x, r4.y }) * scale;
-                    o[0] = oxy.x;
-                    o[QMAX] = oxy.y;
-                    o[2 * QMAX] = (fmaf(1.0f - Fz, pkdAz, Fz * spec) * r4.z) * scale;
-                }
-            }
-#undef PULL
+        const uint32_t numLights = HALFT ? min(numLightsAll - roundBase, 64u) : numLightsAll;
+        // survivors by kind: [0,1] finite point lights, [2,3] finite spot lights, [4,5] the rest (directional, unknown type,
+        // non-finite intensity: every pixel is a pair) -- for list slots 0..63 and 64..127
+        unsigned long long seg[8] = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull }; // [6,7]: directional lights (type 0), see the loop behind the queue
+    #pragma unroll
+        for (int h = 0; h < HN; h++) {
+            if ((uint32_t)(h * 64) >= numLights) break;
+            // (every condition as a wave mask of ONE simple compare, the combinations as scalar mask arithmetic: a bool that is assigned in branches
+            // lives in a VGPR as 0 / 1 and costs a v_cndmask + v_cmp per use)
+            const uint32_t li = (uint32_t)(h * 64 + lane);
+            const uint32_t lc = li < numLights ? li : 0u; // (lanes past the list read slot 0 and are masked out)
+            const float4 c0 = sL[lc * LREC + 0];
+            const float4 c1 = sL[lc * LREC + 1];
+            const uint32_t bits = __float_as_uint(c1.w);
+            const unsigned long long mIn = __ballot(li < numLights);
+            const unsigned long long mFin = __ballot((bits & 0x10000u) != 0u);
+            const unsigned long long mPoint = __ballot((bits & 0xFFu) == 1u), mSpot = __ballot((bits & 0xFFu) == 2u), mDir = __ballot((bits & 0xFFu) == 0u);
+            const float ex = c0.x - scx, ey = c0.y - scy, ez = c0.z - scz;
+            const float t = __builtin_amdgcn_sqrtf(c0.w) * 1.0001f + sphereR; // c0.w = r^2 (1 + 1e-5) (+inf: never reject)
+            const float e2 = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
+            const unsigned long long mFar = __ballot(e2 > t * t); // only meaningful for finite point lights
+            // A spot light whose cone misses the sphere: seen from the light the sphere spans the angle delta = asin(R / |e|) around the direction
+            // to its centre, which makes the angle A with the cone's axis; no pixel can do better than cos(A - delta) = cosA cosd + sinA sind, and
+            // the per-pixel test passes from c = cutOff.y - 1e-5 (= -rec0.w) up.  Approximate arithmetic (v_rsq / v_sqrt), hence the 1e-4; a NaN
+            // anywhere (the light inside the sphere: sind > 1; a zero axis) fails the compares and keeps the light.  On the 4K frame 6.0 spot
+            // lights per quadrant come this far, 1.6 reach a pixel, 3.8 pass this test (scripts/analysis/shade_trips.py).
+            const float rinv = rsq_fast(e2);
+            const float sind = sphereR * rinv;
+            const float cosA = fmaf(ex, c1.x, fmaf(ey, c1.y, ez * c1.z)) * rinv;
+            const float cosd = __builtin_amdgcn_sqrtf(fmaf(-sind, sind, 1.0f)), sinA = __builtin_amdgcn_sqrtf(fmaf(-cosA, cosA, 1.0f));
+            const unsigned long long mOut = __ballot(fmaf(sinA, sind, cosA * cosd) < -c0.w - 1e-4f) & __ballot(cosA < cosd); // only meaningful for finite spot lights
+            const unsigned long long dropped = forceMask == 0ull ? (mFin & ((mPoint & mFar) | (mSpot & mOut))) : 0ull;
+            const unsigned long long all = mIn & ~dropped;
+            seg[h] = all & mFin & mPoint;
+            seg[2 + h] = all & mFin & mSpot;
+            seg[6 + h] = mIn & mDir;
+            seg[4 + h] = all & ~(seg[h] | seg[2 + h] | seg[6 + h]);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // each pixel adds up the results of its own pairs, in the order they were queued (the position list shifted up against the sentinel:
-        // the first pair's position then sits in bits 30..24, the next one in 23..17, ...)
-        const uint32_t pcTop = pc << __builtin_clz(pc);
-#pragma unroll
-        for (uint32_t j = 0; j < (uint32_t)PENDK; j++) {
-            if (__ballot(pc >= (1u << (7u * (j + 1u)))) == 0ull) break;
-            if (pc >= (1u << (7u * (j + 1u)))) {
-                const float* r = res + ((pcTop >> (24u - 7u * j)) & 127u);
-                accX += r[0];
-                accY += r[QMAX];
-                accZ += r[2 * QMAX];
-            }
+
+        if (BAND && splitRole) { // this wave's share of the list: every fourth slot
+            const unsigned long long share = 0x1111111111111111ull << __builtin_amdgcn_readfirstlane(wave); // (scalar: the masks stay in SGPRs)
+    #pragma unroll
+            for (int q = 0; q < 8; q++) seg[q] &= share;
         }
-        if (!overflow) break;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-    if constexpr (!K3_FIRST) {
-        if ((seg[6] | seg[7]) != 0ull) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                unsigned long long todo = seg[6 + h];
-                while (todo) {
-                    const int slot = h * 64 + __builtin_ctzll(todo);
-                    shade_directional(sL + (uint32_t)slot * LREC, directional_factor(slot));
-                    todo &= todo - 1ull;
+
+        // ---- directional lights (staged kind 0, with the odd point / spot light of stage_light_record): every pixel is a pair, so they are shaded one
+        // LANE per PIXEL from the pixel's own registers -- no queue, no pulls -- in list order, nothing skipped (cosLi = 0 and non-finite intensities
+        // take their natural course).  `shadow` = the light's K3 factor (Standard.shader:266-283), or the exact falloff of an odd light.
+        auto shade_directional = [&](const float4* R, const float shadow) {
+            const float4 r3 = R[3], r4 = R[4];
+            // ---- Cook-Torrance (Standard.shader:309-340), as in the pair pass ----
+            const float Lix = r3.x, Liy = r3.y, Liz = r3.z;
+            float hx = Lix + Lox, hy = Liy + Loy, hz = Liz + Loz;
+            const float hinv = rcp_of_sqrt(sqrt_exact(dot3f(hx, hy, hz, hx, hy, hz)));          // exact chain: Lh = normalize(Li + Lo)
+            hx *= hinv; hy *= hinv; hz *= hinv;
+            const float cosLi = fmaxf(0.0f, dot3f(nx, ny, nz, Lix, Liy, Liz));
+            const float cosLh = fmaxf(0.0f, dot3f(nx, ny, nz, hx, hy, hz));
+            const float x1 = 1.0f - fmaxf(0.0f, dot3f(hx, hy, hz, Lox, Loy, Loz));
+            const float x2 = x1 * x1, x5 = x2 * x2 * x1;
+            const float dn = (cosLh * cosLh) * (alphaSq - 1.0f) + 1.0f;
+            const float D = alphaSq * rcp_fast(3.14159265359f * dn * dn);
+            const float G = cosLi * rcp_fast(fmaf(cosLi, oneMinusK, k)) * g1Lo;
+            const float spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * cosLo));
+            const float scale = shadow * cosLi; // falloff = 1 (:287)
+            const float Fx = F0x + (1.0f - F0x) * x5, Fy = F0y + (1.0f - F0y) * x5, Fz = F0z + (1.0f - F0z) * x5;
+            accX += (fmaf(1.0f - Fx, kdAx, Fx * spec) * r4.x) * scale;
+            accY += (fmaf(1.0f - Fy, kdAy, Fy * spec) * r4.y) * scale;
+            accZ += (fmaf(1.0f - Fz, kdAz, Fz * spec) * r4.z) * scale;
+        };
+        // the factor of the light in list slot `slot`: its shadow look-up (K3), or the IEEE falloff of a light from far outside the staged reciprocal's range
+        auto directional_factor = [&](const int slot) -> float {
+            const float4* R = sL + (uint32_t)slot * LREC;
+            const uint32_t lbits = __builtin_amdgcn_readfirstlane(__float_as_uint(R[1].w));
+            if (__builtin_expect((lbits >> LIGHT_SLOW_SHIFT) != 0u, 0))
+                return exact_falloff(std::true_type{}, (lbits >> LIGHT_SLOW_SHIFT) == 1u, R, R[0], R[1], R[3].w, wxyp, wz);
+            if constexpr (HAS_CSM) {
+                const float4 r3 = R[3];
+                return directional_shadow(A, C, (lbits >> 8) & 0xFFu, -r3.x, -r3.y, -r3.z, nx, ny, nz, wx, wy, wz);
+            }
+            return 1.0f;
+        };
+        if constexpr (K3_FIRST) {
+            // ---- K3 first: per directional light its factor (one register), THEN the view / material terms, then the light's Cook-Torrance term.
+            // One round in practice (a tile with several directional lights repeats it and recomputes the terms: the camera position and the
+            // constant 1 they are computed from are made opaque, so that the compiler cannot hoist them out of the loop and across the look-up).
+            unsigned long long d0 = seg[6], d1 = seg[7];
+            do {
+                int slot = -1;
+                float f = 1.0f;
+                if ((d0 | d1) != 0ull) {
+                    slot = d0 != 0ull ? __builtin_ctzll(d0) : 64 + __builtin_ctzll(d1);
+                    if (d0 != 0ull) d0 &= d0 - 1ull; else d1 &= d1 - 1ull;
+                    f = directional_factor(slot);
+                }
+                float camX = A.camX, camY = A.camY, camZ = A.camZ, one = 1.0f;
+                asm volatile("" : "+s"(camX), "+s"(camY), "+s"(camZ), "+s"(one));
+                view_and_material(camX, camY, camZ, one);
+                if (slot >= 0) shade_directional(sL + (uint32_t)slot * LREC, f);
+            } while ((d0 | d1) != 0ull);
+        }
+
+        // ---- 2 + 3. queue the (pixel, light) pairs that can be lit, then shade them one LANE per PAIR ----
+        // Window = up to QMAX queued pairs, at most PENDK per pixel; a light whose pairs do not fit ends the window (it is
+        // tested again in the next one -- rare: a quadrant of the 4K frame queues ~50 pairs).  A pair's result goes to slot
+        // [colour][its position in the queue]; each pixel keeps the positions of its own pairs (7 bits each, in the order queued, under a
+        // sentinel bit) and adds their results up afterwards: no atomics (ds_add_f32 is serialised per lane on this LDS: ~170 cycles
+        // per wave instruction, scripts/microbench/lds_ops.hip).  (Was: slots [colour][ordinal of the pair among its pixel's][pixel] --
+        // 9 KB per block instead of 6, a cap of three pairs per pixel and window instead of four, and an address of three instructions in the pair
+        // pass instead of one.  More blocks per CU were NOT what it bought: with room for ten the kernel takes what it takes with eight -- the
+        // 32 wave slots of a CU are the cap.)
+        uint16_t* Q = sQ + wave * QMAX;
+        const uint32_t qAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)Q; // its LDS byte address, for the hand-written append below
+        const uint32_t sLAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)sL;
+        static_assert(LREC == 5, "SHADE_LIGHT_LOOP computes 80 x slot as (5 x slot) << 4");
+        float* res = sRes + wave * (3 * QMAX); // this wave's [3 colours][QMAX queue positions] slots
+        for (;;) {
+            uint32_t cnt = 0u;      // queued pairs (wave-uniform)
+            uint32_t pc = 1u;       // the queue positions of this pixel's pairs: 1 (sentinel), then 7 bits per pair, the first one queued on top
+            // The wave is bound by instruction issue of every kind (a scalar instruction costs what a vector one costs: measured), and the loop
+            // around a light is mostly scalar mask arithmetic.  In the usual quadrant -- every pixel inside the frame, none with roughness 0 -- the
+            // "force" and "active" masks are the identity, so that case gets its own copy of the loops without them (PLAIN): m = reach & facing.
+            auto light_loop = [&](auto plainTag, auto kindTag, auto hTag) -> bool {
+                constexpr bool PLAIN = decltype(plainTag)::value;
+                constexpr int kind = decltype(kindTag)::value, h = decltype(hTag)::value;
+                unsigned long long todo = seg[kind * 2 + h];
+                unsigned long long rest = 0ull; // on overflow: what is left, this light included
+                if constexpr (PLAIN && kind < 2) {
+                    // The usual case by hand (see SHADE_LIGHT_LOOP above): the same tests, the same append, 15 instructions around a light out of
+                    // reach where the compiler's control flow takes 21.
+                    if (todo != 0ull) {
+                        uint32_t bit, n;
+                        unsigned long long m, ex;
+                        if constexpr (kind == 0 && h == 0) SHADE_LIGHT_LOOP("", "", SHADE_TEST_POINT);
+                        if constexpr (kind == 0 && h == 1) SHADE_LIGHT_LOOP("s_or_b32 %[bit], %[bit], 64\n\t", "", SHADE_TEST_POINT);
+                        if constexpr (kind == 1 && h == 0) SHADE_LIGHT_LOOP("", "ds_read_b96 v[60:62], v62 offset:16\n\t", SHADE_TEST_SPOT);
+                        if constexpr (kind == 1 && h == 1) SHADE_LIGHT_LOOP("s_or_b32 %[bit], %[bit], 64\n\t", "ds_read_b96 v[60:62], v62 offset:16\n\t", SHADE_TEST_SPOT);
+                    }
+                } else {
+                    // (one way out of the loop, through its condition: with a `break` in the middle the loop is no single-exit region of its own, falls
+                    // into the region of the divergent pair pass below and is structurised along with it -- see the append)
+                    while (todo) {
+                        const int bit = __builtin_ctzll(todo);
+                        const uint32_t s = (uint32_t)(h * 64 + bit);
+                        unsigned long long m = activeMask; // "the rest": every pixel is a pair
+                        if (kind < 2) {
+                            const float4* R = sL + s * LREC;
+                            const float4 r0 = R[0];
+                            const v2f dxy = v2f{ r0.x, r0.y } - wxy;
+                            const float dz = r0.z - wz;
+                            const float d2 = fmaf(dxy.x, dxy.x, fmaf(dxy.y, dxy.y, dz * dz));
+                            float v = d2;
+                            if (kind == 1) {
+                                // spot: falloff is exactly 0 iff theta < cutOff.y (:303-306); theta ~ dot(d, axis) / |d| to a few ulp
+                                const float4 r1 = R[1];
+                                v = -(fmaf(dxy.x, r1.x, fmaf(dxy.y, r1.y, dz * r1.z)) * rsq_fast(d2));
+                            }
+                            const unsigned long long reach = __ballot(!(v > r0.w));
+                            m = 0ull;
+                            if ((PLAIN ? reach : ((reach | forceMask) & activeMask)) != 0ull) {
+                                // ... and facing it?  cosLi = max(0, n . Li) = 0 zeroes both the specular G term and the final product.
+                                const float4 r3 = R[3];
+                                const unsigned long long facing = __ballot(dot3f(nx, ny, nz, r3.x, r3.y, r3.z) > 0.0f);
+                                m = PLAIN ? (reach & facing) : (((reach & facing) | forceMask) & activeMask);
+                            }
+                        }
+                        if (m != 0ull) {
+                            // (masks of single compares combined as scalars: a ballot of `mine && ...` goes through a VGPR 0 / 1 and back)
+                            if (cnt + (uint32_t)__popcll(m) > (uint32_t)QMAX || (m & __ballot(pc >= (1u << (7 * PENDK)))) != 0ull) { rest = todo; todo = 0ull; continue; }
+                            // The lanes of m append (s << 6 | lane) to the queue and note the position.  Written out with the exec mask set by hand: as
+                            // `if (lane in m) { ... }` this is the only divergent branch of the loops around it, and with it the compiler
+                            // structurises them -- a state variable, three more branches and five more scalar instructions per light.  Every
+                            // lane is live here (the waves are full and nothing above has diverged), so exec goes back to all ones.
+                            uint32_t t0, t1;
+                            asm volatile("s_mov_b64 exec, %[m]\n\t"
+                                         "v_mov_b32 %[t0], %[cnt]\n\t"
+                                         "v_mbcnt_lo_u32_b32 %[t0], %[mlo], %[t0]\n\t"
+                                         "v_mbcnt_hi_u32_b32 %[t0], %[mhi], %[t0]\n\t"   // the count so far rides in as mbcnt's addend
+                                         "v_lshl_or_b32 %[pc], %[pc], 7, %[t0]\n\t"
+                                         "v_lshl_add_u32 %[t0], %[t0], 1, %[q]\n\t"
+                                         "v_lshl_or_b32 %[t1], %[s], 6, %[lane]\n\t"
+                                         "ds_write_b16 %[t0], %[t1]\n\t"
+                                         "s_mov_b64 exec, -1"
+                                         : [t0] "=&v"(t0), [t1] "=&v"(t1), [pc] "+&v"(pc)
+                                         : [m] "s"(m), [mlo] "s"((uint32_t)m), [mhi] "s"((uint32_t)(m >> 32)), [cnt] "s"(cnt), [s] "s"(s), [q] "v"(qAddr), [lane] "v"(lane)
+                                         : "memory");
+                            cnt += (uint32_t)__popcll(m);
+                        }
+                        asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(bit)); // todo &= todo - 1 in one scalar instruction instead of three
+                    }
+                }
+                seg[kind * 2 + h] = rest; // what the next window still has to look at
+                return rest != 0ull;
+            };
+            auto fill_window = [&](auto plainTag) -> bool {
+                using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+                if constexpr (HALFT) // (a staging round holds 64 records: there is no second half)
+                    return light_loop(plainTag, K0{}, K0{}) || light_loop(plainTag, K1{}, K0{}) || light_loop(plainTag, K2{}, K0{});
+                else
+                    return light_loop(plainTag, K0{}, K0{}) || light_loop(plainTag, K0{}, K1{}) || light_loop(plainTag, K1{}, K0{}) || light_loop(plainTag, K1{}, K1{}) ||
+                           light_loop(plainTag, K2{}, K0{}) || light_loop(plainTag, K2{}, K1{});
+            };
+            const bool overflow = (forceMask == 0ull && activeMask == ~0ull) ? fill_window(std::true_type{}) : fill_window(std::false_type{});
+            if (cnt == 0u) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (uint32_t base = 0u; base < cnt; base += 64u) {
+                // one LANE per PAIR.  The pixel's invariants are pulled from its lane's registers (ds_bpermute: the LDS crossbar,
+                // no LDS memory), the light record from LDS.  All 64 lanes execute the pulls (a disabled source lane returns 0).
+                // (the lanes past the last pair repeat the batch's FIRST pair and store the result in their own slot, which no pixel looks at: every
+                // lane runs the same straight code -- no `if (valid)` around the three stretches of arithmetic, which was 13 instructions of
+                // exec-mask bookkeeping and zero-initialisation per batch)
+                const uint32_t qi = base + (uint32_t)lane;
+                const uint32_t e = Q[qi < cnt ? qi : base];
+                constexpr bool valid = true;
+                const int pa = (int)((e & 63u) << 2);
+                const uint32_t s = (e >> 6) & (uint32_t)(KEEP - 1);
+                const float4* R = sL + s * LREC;
+    #define PULL(x) __int_as_float(__builtin_amdgcn_ds_bpermute(pa, __float_as_int(x)))
+                // (float pairs where the arithmetic comes in pairs -- x / y of a vector, two of three colour channels: v_pk_{add,mul,fma}_f32 round each
+                // component like the scalar instruction, so the bits are those of the scalar form, at one issue slot per pair instead of two.  The pulled
+                // values and the LDS reads land in adjacent registers by construction, which is what the compiler's own SLP pairing could not arrange.)
+                float falloff = 1.0f;
+                const float4 r3 = R[3];
+                const p2f pwxy = { PULL(wx), PULL(wy) };
+                const float pwz = PULL(wz);
+                if (valid) {
+                    const float4 r0 = R[0], r1 = R[1];
+                    const uint32_t type = __float_as_uint(r1.w) & 0xFFu;
+                    if (type == 1u || type == 2u) // exact falloff (the oracle's op order where it is ill-conditioned)
+                        falloff = exact_falloff(std::false_type{}, type == 1u, R, r0, r1, r3.w, pwxy, pwz);
+                }
+                // (the pulls are spread out so that at most ten pulled values are live at a time: 64 VGPRs = 8 waves per SIMD)
+                float spec = 0.0f, x5 = 0.0f, scale = 0.0f;
+                {
+                    const p2f pnxy = { PULL(nx), PULL(ny) };
+                    const float pnz = PULL(nz);
+                    const p2f pLoxy = { PULL(Lox), PULL(Loy) };
+                    const float pLoz = PULL(Loz);
+                    const float pcosLo = PULL(cosLo), pg1Lo = PULL(g1Lo), palphaSq = PULL(alphaSq);
+                    const float pkr = HAS_IBL ? PULL(roughness) : PULL(k); // the ambient term at the end needs the roughness itself: pull it, derive k
+                    const float pk = HAS_IBL ? ((pkr + 1.0f) * (pkr + 1.0f)) * 0.125f : pkr;
+                    if (valid) {
+                        // ---- Cook-Torrance (Standard.shader:309-340) ----
+                        const p2f Lixy = { r3.x, r3.y };
+                        const float Liz = r3.z;
+                        p2f hxy = Lixy + pLoxy;
+                        float hz = Liz + pLoz;
+                        const float hinv = rcp_of_sqrt(sqrt_exact(dot3_pk(hxy, hz, hxy, hz)));          // exact chain: Lh = normalize(Li + Lo)
+                        hxy *= hinv; hz *= hinv;
+                        const float cosLi = fmaxf(0.0f, dot3_pk(pnxy, pnz, Lixy, Liz));
+                        const float cosLh = fmaxf(0.0f, dot3_pk(pnxy, pnz, hxy, hz));
+                        const float x1 = 1.0f - fmaxf(0.0f, dot3_pk(hxy, hz, pLoxy, pLoz));
+                        const float x2 = x1 * x1;
+                        x5 = x2 * x2 * x1;                                                        // pow(1 - cosTheta, 5)
+                        const float dn = (cosLh * cosLh) * (palphaSq - 1.0f) + 1.0f;                // exact: the cancelling denominator
+                        const float D = palphaSq * rcp_fast(3.14159265359f * dn * dn);              // NdfGGX
+                        const float G = cosLi * rcp_fast(fmaf(cosLi, 1.0f - pk, pk)) * pg1Lo;      // GeometrySchlickGGX
+                        spec = D * G * rcp_fast(fmaxf(0.00001f, 4.0f * cosLi * pcosLo));
+                        scale = cosLi * falloff; // (shadow = 1: only directional lights are shadowed, and they do not come through the queue)
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const p2f pF0xy = { PULL(F0x), PULL(F0y) };
+                    const float pF0z = PULL(F0z);
+                    const p2f pkdAxy = { PULL(kdAx), PULL(kdAy) };
+                    const float pkdAz = PULL(kdAz);
+                    if (valid) {
+                        const p2f Fxy = pF0xy + (1.0f - pF0xy) * x5;
+                        const float Fz = pF0z + (1.0f - pF0z) * x5;
+                        const float4 r4 = R[4];
+                        // shadow * ((kd*albedo + F*D*G/denom) * Lradiance * cosLi) * falloff ; kd = mix(1 - F, 0, metallic)
+                        float* o = res + (base + (uint32_t)lane);
+                        const p2f oxy = (fma2(1.0f - Fxy, pkdAxy, Fxy * spec) * p2f{ r4.x, r4.y }) * scale;
+                        o[0] = oxy.x;
+                        o[QMAX] = oxy.y;
+                        o[2 * QMAX] = (fmaf(1.0f - Fz, pkdAz, Fz * spec) * r4.z) * scale;
+                    }
+                }
+    #undef PULL
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // each pixel adds up the results of its own pairs, in the order they were queued (the position list shifted up against the sentinel:
+            // the first pair's position then sits in bits 30..24, the next one in 23..17, ...)
+            const uint32_t pcTop = pc << __builtin_clz(pc);
+    #pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)PENDK; j++) {
+                if (__ballot(pc >= (1u << (7u * (j + 1u)))) == 0ull) break;
+                if (pc >= (1u << (7u * (j + 1u)))) {
+                    const float* r = res + ((pcTop >> (24u - 7u * j)) & 127u);
+                    accX += r[0];
+                    accY += r[QMAX];
+                    accZ += r[2 * QMAX];
                 }
             }
+            if (!overflow) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        if constexpr (!K3_FIRST) {
+            if ((seg[6] | seg[7]) != 0ull) {
+    #pragma unroll
+                for (int h = 0; h < HN; h++) {
+                    unsigned long long todo = seg[6 + h];
+                    while (todo) {
+                        const int slot = h * 64 + __builtin_ctzll(todo);
+                        shade_directional(sL + (uint32_t)slot * LREC, directional_factor(slot));
+                        todo &= todo - 1ull;
+                    }
+                }
+            }
+        }
+        if constexpr (!HALFT) break;
+        else {
+            roundBase += 64u;
+            if (roundBase >= numLightsAll) break;   // (block-uniform: both waves read the same numLightsAll)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // both waves are done with the records of the round before
+            if (__builtin_amdgcn_readfirstlane(wave) == 1) {
+                const uint32_t slot = roundBase + (uint32_t)lane;
+                if (slot < numLightsAll) {
+                    const uint32_t idx2 = culled[g.offset + slot];   // (read again: held from the prologue it would be a register live across the whole first round)
+                    float4* o = sL + lane * LREC;
+                    if constexpr (PREPARED) {
+                        const float4* Lp = reinterpret_cast<const float4*>(lights) + (size_t)idx2 * LREC;
+                        const float4 a0 = Lp[0], a1 = Lp[1], a2 = Lp[2], a3 = Lp[3], a4 = Lp[4];
+                        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4;
+                    } else {
+                        const float4* Lp = reinterpret_cast<const float4*>(lights + idx2);
+                        float4 o0, o1, o2, o3, o4;
+                        stage_light_record(Lp[0], Lp[1], Lp[2], Lp[3], Lp[4], Lp[5], Lp[6], o0, o1, o2, o3, o4);
+                        o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3; o[4] = o4;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
     if (BAND && splitRole) { // the four partial sums of each pixel: wave 0 + 1 + 2 + 3
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float* res = sRes + wave * (3 * QMAX);
         res[lane] = accX; res[64 + lane] = accY; res[128 + lane] = accZ; // (in the wave's own slots: another wave may still be reading its own)
         __syncthreads();
         if (wave != 0) return;

@@ -18,68 +18,93 @@ size_t LightingECS::RegisterComponent(const LightData& data)
     return m_components.size() - 1;
 }
 
-// LightingECS.cpp:93-192, literally -- including what follows from where its `continue` and its flush sit:
-//   * a slot of a static owner joins the skip list the first time the loop meets it (it is still packed on that pass) and is stepped over from
-//     the next Tick on, dirty or not; only ONE skip-list run is applied per loop step;
-//   * an inactive slot leaves the loop body before the "close the run" check (:148-149), so it neither ends a run nor flushes one: a dirty run
-//     that continues behind it is written as ONE copy whose later records land one slot early, and a run still open when the LAST slot is
-//     inactive (or when the skip list steps past the end) is never written, although its lights were marked clean;
-//   * a light is packed when it is dirty OR its owner's transform changed after the frame it was last packed for (:152).
+// ---- which light slots one Tick uploads, as contiguous runs (the boundary contract of row L7: every run becomes ONE UpdateShaderBinding, and the HIP backend
+// re-derives the prepared views of exactly those slots -- sailor_hip_prepare_lights(first, count)).  The rules are the reference's (ECS/LightingECS.cpp:93-192),
+// restated around two small pieces of state instead of transliterated: the list of static-owner runs the loop steps over, and the run of packed
+// records that is currently open.  oracle/oracle.py:lighting_tick_runs is an independent restatement; tests/test_host_cpu.py and
+// tests/test_runtime_gpu.py::test_lighting_ecs_streams_dirty_runs_into_the_light_ssbo hold the two against each other slot for slot.
+namespace {
+
+// Slots whose owner is static are packed once -- on the pass that first meets them -- and stepped over from the next Tick on, dirty or not.  The list holds them
+// as (first slot, length) runs in slot order; `passed` counts the runs the current pass has stepped over or opened.
+struct StaticRuns {
+    std::vector<std::pair<uint32_t, uint32_t>>& runs;
+    uint32_t passed = 0;
+
+    // (:95-103) if the next run starts at `index`, jump behind it; false = the jump left the array.  (ONE run per loop step, as the reference: two runs that touch
+    // are stepped over in two steps.)
+    bool StepOver(size_t& index, size_t num)
+    {
+        if (passed < runs.size() && index == runs[passed].first) {
+            index += runs[passed].second;
+            if (index >= num) return false;
+            passed++;
+        }
+        return true;
+    }
+
+    // (:108-146) slot `index` has a static owner and was not stepped over: it extends the run just passed when it follows it directly, opens a run of its own in
+    // the gap between two later runs, or is appended.  (The gap's lower bound uses the length of the run just passed for EVERY gap -- the reference's arithmetic,
+    // kept because it decides which later Ticks step over what.)
+    void Note(size_t index)
+    {
+        if (passed > 0) {
+            std::pair<uint32_t, uint32_t>& last = runs[passed - 1];
+            if (index == (size_t)last.first + last.second) { last.second++; return; }
+            for (size_t i = passed - 1; i + 1 < runs.size(); i++) {
+                const uint32_t gapBegin = runs[i].first + last.second, gapEnd = runs[i + 1].first;
+                if (index > gapBegin && index < gapEnd) {
+                    runs.insert(runs.begin() + (long)(i + 1), std::make_pair((uint32_t)index, 1u));
+                    passed++;
+                    return;
+                }
+            }
+        }
+        runs.emplace_back((uint32_t)index, 1u);
+        passed++;
+    }
+};
+
+// The run of freshly packed records that is open: closed -- one copy -- when a slot that needs no upload follows it, or at the last slot.
+struct OpenRun {
+    std::vector<LightUploadRun>& out;
+    size_t start = 0, count = 0;
+    bool open = false;
+    void Add(size_t index) { if (!open) { open = true; start = index; } count++; }
+    void Close() { open = false; }
+    void FlushIf(bool atEnd) { if ((!open || atEnd) && count > 0) { out.push_back({ start, count }); count = 0; } }
+};
+
+} // namespace
+
+// Two consequences of where the reference's `continue` sits (:148-149), reproduced because they decide what reaches the SSBO: an INACTIVE slot neither closes nor
+// flushes the open run -- a dirty run that continues behind it is written as one copy whose later records land one slot early -- and a run still open when the
+// last slot is inactive (or when the static runs step past the end) is never written although its lights were marked clean.
 std::vector<LightUploadRun> LightingECS::CollectDirtyRuns(std::vector<LightData>& components, std::vector<std::pair<uint32_t, uint32_t>>& skipList,
                                                           std::vector<LightShaderData>& records)
 {
     std::vector<LightUploadRun> runs;
-    size_t pending = 0; // records packed since the last copy (the reference's shaderDataBatch)
-    bool bShouldWrite = true;
-    size_t startIndex = 0;
-    uint32_t skipIndex = 0;
+    StaticRuns statics { skipList };
+    OpenRun run { runs };
     const size_t num = components.size();
     for (size_t index = 0; index < num; index++) {
-        if (skipIndex < skipList.size() && index == skipList[skipIndex].first) { // :95-103
-            index += skipList[skipIndex].second;
-            if (index >= num) break;
-            skipIndex++;
-        }
+        if (!statics.StepOver(index, num)) break;
         LightData& data = components[index];
-        if (data.m_ownerMobility == EMobilityType::Static) { // :108-146
-            bool bPlaced = false;
-            if (skipIndex > 0 && index == (size_t)skipList[skipIndex - 1].first + skipList[skipIndex - 1].second) { // grows the run it follows
-                skipList[skipIndex - 1].second++;
-                bPlaced = true;
-            }
-            if (!bPlaced && skipIndex > 0) { // between two runs (the bound uses run skipIndex-1's length for every i, as the reference does)
-                for (int32_t i = (int32_t)skipIndex - 1; i < (int32_t)skipList.size() - 1; i++) {
-                    const uint32_t start = skipList[i].first + skipList[skipIndex - 1].second, end = skipList[i + 1].first;
-                    if (index > start && index < end) {
-                        skipList.insert(skipList.begin() + (i + 1), std::make_pair((uint32_t)index, 1u));
-                        bPlaced = true;
-                        skipIndex++;
-                        break;
-                    }
-                }
-            }
-            if (!bPlaced) {
-                skipList.emplace_back((uint32_t)index, 1u);
-                skipIndex++;
-            }
-        }
-        if (!data.m_bIsActive) continue; // :148-149
-        if (data.m_bIsDirty || data.m_frameLastChange < data.m_ownerFrameLastChange) { // :152
-            if (bShouldWrite) { bShouldWrite = false; startIndex = index; }
+        if (data.m_ownerMobility == EMobilityType::Static) statics.Note(index);
+        if (!data.m_bIsActive) continue;
+        const bool upload = data.m_bIsDirty || data.m_frameLastChange < data.m_ownerFrameLastChange; // (:152) dirty, or the owner moved after the last packing
+        if (upload) {
             LightShaderData shaderData;
             sailor_host_pack_light((uint32_t)data.m_type, (uint32_t)data.m_shadowType, data.m_worldPosition, data.m_direction, data.m_intensity,
-                                   data.m_attenuation, data.m_cutOff, data.m_bounds, &shaderData); // :162-172
+                                   data.m_attenuation, data.m_cutOff, data.m_bounds, &shaderData); // (:162-172)
             records.push_back(shaderData);
-            pending++;
-            data.m_frameLastChange = data.m_ownerFrameLastChange; // :174
+            run.Add(index);
+            data.m_frameLastChange = data.m_ownerFrameLastChange; // (:174)
             data.m_bIsDirty = false;
-        } else bShouldWrite = true;
-        if ((bShouldWrite || index == num - 1) && pending > 0) { // :182-191: one copy per run
-            runs.push_back({ startIndex, pending });
-            pending = 0;
-        }
+        } else run.Close();
+        run.FlushIf(index == num - 1); // (:182-191) one copy per run
     }
-    records.resize(records.size() - pending); // a run that was never closed is never written
+    records.resize(records.size() - run.count); // a run that was never flushed is never written
     return runs;
 }
 

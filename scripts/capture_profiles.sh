@@ -2,7 +2,7 @@
 # Captures the judged artefacts of a round on the GPU box (run through gpurun from the repo root):
 #   kernel stats of the bench command (C3, C4, C5), the PMC traffic passes (C3 AND C4), the SQ counter passes of the shade / cull kernels (C3 and the C4
 #   shade), the bench lines (C3, C4, C5), the split simulations (2 / 4 / 8 bands), the frame pipeline's kernel timelines (whole frame; one band).
-#   (libsailor_hip_prof.so: scripts/ab_build.sh prof "-DCULL_PROF -DSHADE_PROF")
+#   (libsailor_hip_prof.so: scripts/build_variant.sh prof "-DCULL_PROF -DSHADE_PROF", built HERE in the container before the call: the .so travels)
 #   usage: bash scripts/capture_profiles.sh <tag>      -> gpurun_out/<tag>/...   (copy what is to be judged into profiles/<round>/)
 TAG=${1:-cap}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
@@ -28,6 +28,14 @@ cd $GRAFT_REPO_ROOT
 python3 scripts/make_traffic_json.py $OUT/fetch $OUT/write $OUT/traffic.json C3 > /dev/null
 python3 scripts/make_traffic_json.py $OUT/fetch4 $OUT/write4 $OUT/traffic_C4.json C4 > /dev/null
 python3 scripts/make_traffic_json.py $OUT/fetch5 $OUT/write5 $OUT/traffic_C5.json C5 > /dev/null
+# (round 6) C5's wide list builder in round 5's form (one row of four groups per block), for the traffic and time beside the 4 x 4-patch form above
+cd /tmp
+SAILOR_CULL_WIDE16=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch5w -- python3 $B --config C5 --steps 3 --warmup 1 $EAGER > /dev/null 2>&1
+SAILOR_CULL_WIDE16=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write5w -- python3 $B --config C5 --steps 3 --warmup 1 $EAGER > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+python3 scripts/make_traffic_json.py $OUT/fetch5w $OUT/write5w $OUT/traffic_C5_wide16_off.json C5 > /dev/null
+for rep in 1 2; do for v in 1 0; do SAILOR_CULL_WIDE16=$v python3 bench.py --config C5 --no-cpu-baseline --steps 20 > $OUT/bench_C5_wide16_${v}_$rep.json 2> /dev/null; done; done
+python3 scripts/r06_raster_probe.py 5 > $OUT/shadow_passes.json 2> /dev/null
 python3 scripts/pmc_summary.py $OUT/sq k2_shade_pt > $OUT/pmc_shade.txt
 python3 scripts/pmc_summary.py $OUT/sq tile_cull > $OUT/pmc_tile_cull.txt
 python3 scripts/pmc_summary.py $OUT/sq4 k2_shade_csm_pt > $OUT/pmc_shade_csm_C4.txt
@@ -61,5 +69,5 @@ SAILOR_HIP_LIB=$PROF python3 scripts/shade_prof_grid.py 3/8 C5 > $OUT/shade_bloc
 SAILOR_HIP_LIB=$PROF python3 scripts/shade_wave_prof.py 0/1 C3 > $OUT/shade_waves_C3_whole.txt 2>&1
 SAILOR_HIP_LIB=$PROF python3 scripts/shade_prof.py 2/8 C4 > $OUT/shade_block_timeline_C4_band2of8.txt 2>&1
 python3 scripts/r05_marker_probe.py C3 > $OUT/shade_behind_pack_marker_probe.txt 2>&1
-rm -rf $OUT/stats $OUT/stats4 $OUT/stats5 $OUT/fetch $OUT/write $OUT/fetch4 $OUT/write4 $OUT/fetch5 $OUT/write5 $OUT/sq $OUT/sq4 $OUT/pipe $OUT/pipeband
+rm -rf $OUT/stats $OUT/stats4 $OUT/stats5 $OUT/fetch $OUT/write $OUT/fetch4 $OUT/write4 $OUT/fetch5 $OUT/write5 $OUT/fetch5w $OUT/write5w $OUT/sq $OUT/sq4 $OUT/pipe $OUT/pipeband
 ls -la $OUT

@@ -14,7 +14,9 @@ ROOT = Path(__file__).resolve().parents[1]
 
 def _run(cmd, env=None):
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
-    assert p.returncode == 0, p.stderr[-2000:]
+    if p.returncode != 0:   # (the first lines that are not stack frames say what happened; the tail alone is a C++ back trace)
+        head = [l for l in p.stderr.splitlines() if "frame #" not in l][:40]
+        raise AssertionError(f"rc {p.returncode}\n" + "\n".join(head) + "\n...\n" + p.stderr[-1500:])
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "rank 0 prints ONE JSON line"
     # ... and nothing else reaches stdout: what RCCL / Gloo / the other ranks print through C stdio is on stderr (bench.claim_stdout)

@@ -129,3 +129,22 @@ def test_cull_kernels_keep_their_occupancy(resources):
 def test_ecs_sweep_has_no_scratch(resources):
     for name, k in resources["ecs_sweep"].items():
         assert k["private_segment_fixed_size"] == 0, (name, k)
+
+
+@pytest.mark.parametrize("name", ["k2_shade_h_p", "k2_shade_h_pt"])
+def test_the_two_wave_shade_blocks_fit_sixteen_per_cu(resources, name):
+    """Round 6: one 128-thread block per half tile, the records staged 64 at a time -- the point of the form is sixteen blocks (32 waves) per CU, so 64
+    registers without scratch and at most 10 KB of LDS a block (off by default: measured neutral)."""
+    k = find(resources["shade"], name)
+    assert k["max_flat_workgroup_size"] == 128 and k["vgpr_count"] <= 64 and k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0
+    assert 16 * k["group_segment_fixed_size"] <= 160 * 1024
+
+
+def test_the_wide_list_builder_of_4x4_patches_fits_two_blocks_per_cu(resources):
+    """Round 6: k1_group_lists_wide16 -- sixteen waves a block, 56 KB of LDS (sixteen mask rows double-buffered + sixteen queues of 128 entries): two blocks =
+    32 waves per CU, and no more than the 64 KB a kernel may claim statically."""
+    ks = [v for n, v in resources["light_cull"].items() if "k1_group_lists_wide16" in n]
+    assert len(ks) == 2
+    for k in ks:
+        assert k["max_flat_workgroup_size"] == 1024 and k["group_segment_fixed_size"] <= 64 * 1024 and 2 * k["group_segment_fixed_size"] <= 160 * 1024
+        assert k["vgpr_count"] <= 32 and k["private_segment_fixed_size"] == 0   # (sixteen waves of a block on four SIMDs: four each, at eight blocks' worth of registers)

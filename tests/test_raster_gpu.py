@@ -81,7 +81,8 @@ def test_box_casters_of_a_cascade_and_the_resolved_maps(ctx, cascade, size):
     ctx.synchronize()
     np.testing.assert_array_equal(dc.cpu().numpy().view(np.uint32), ref.view(np.uint32))
     words = coarse.cpu().numpy().view(np.float32)
-    lower, lower2 = words[:(size // 8) ** 2].reshape(size // 8, size // 8), words[(size // 8) ** 2:].reshape(size // 64, size // 64)
+    n1, n2 = (size // 8) ** 2, (size // 64) ** 2   # (behind the two levels: eight words for the box of the mesh of a many-instance draw -- round 6)
+    lower, lower2 = words[:n1].reshape(size // 8, size // 8), words[n1:n1 + n2].reshape(size // 64, size // 64)
     assert (lower <= ref.reshape(size // 8, 8, size // 8, 8).min(axis=(1, 3))).all() and (lower > 0).any()
     assert (lower2 <= ref.reshape(size // 64, 64, size // 64, 64).min(axis=(1, 3))).all()
     cover = float((ref > 0).mean())
@@ -281,3 +282,78 @@ def test_golden_fixture_through_the_c_abi(ctx):
         got = raster_depth(ctx, P, d_pos, d_idx, d_one, 96, 64, cull_back=cull)
         ctx.synchronize()
         np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), g[key].view(np.uint32))
+
+
+@pytest.mark.parametrize("cascade, size, order", [(0, 512, "front_to_back"), (0, 512, "back_to_front"), (1, 256, "unsorted"), (3, 256, "front_to_back")])
+def test_many_instances_go_out_in_chunks_with_the_instance_test(ctx, cascade, size, order):
+    """Round 6: a draw of >= 4 096 instances with a coarse depth goes out in chunks of growing size, and every instance's box is held against the coarse depth
+    before any of its triangles is set up (raster.hip: raster_instance_hidden, k_mesh_bounds).  Both are bounds-only: the depth buffer equals the oracle's bit
+    for bit in any drawing order -- front to back (where they pay), back to front (where nothing is ever hidden), unsorted -- and equals the buffer of the same
+    draw without a coarse depth.  The coarse words stay lower bounds."""
+    cam = synth.make_camera(640, 360)
+    ents = synth.make_entities(40000)
+    planes, _ = host.extract_frustum_planes(cam.world, cam.aspect, cam.fov, cam.z_near, cam.z_far)
+    world, aabb, _ = EcsSweep(ctx, ents).run(planes)
+    sh = synth.make_shadow_set(cam, 16)
+    cplanes = np.stack([host.extract_frustum_planes_matrix(sh.lights_matrices[k])[0] for k in range(4)])
+    masks = csm_caster_masks(ctx, aabb, cplanes).cpu().numpy().view(np.uint64)
+    ids = np.nonzero(np.unpackbits(masks[cascade].view(np.uint8), bitorder="little")[:40000])[0].astype(np.uint32)
+    assert len(ids) >= 8192, len(ids)     # at least three chunks (2 048 + 8 192 + ...)
+    pos, tris = synth.unit_cube_mesh()
+    models = synth.caster_models(world.cpu().numpy(), ents.local_aabb)
+    lm = sh.lights_matrices[cascade]
+    if order != "unsorted":
+        m = np.asarray(lm, np.float64).reshape(4, 4).T
+        z = models[ids].reshape(-1, 4, 4)[:, 3, :3].astype(np.float64) @ m[2, :3] + m[2, 3]
+        ids = np.ascontiguousarray(ids[np.argsort(-z if order == "front_to_back" else z, kind="stable")])
+    ref = oracle.raster_depth(lm, pos, tris, models, size, size, instance_ids=ids)
+    dev = lambda a, t=np.float32: torch.from_numpy(np.ascontiguousarray(a, t)).to(ctx.device)
+    d_pos, d_tris, d_models, d_ids = dev(pos), dev(tris.view(np.int32), np.int32), dev(models), dev(ids.view(np.int32), np.int32)
+    coarse = torch.empty(int(_lib.load().sailor_hip_raster_coarse_words(size, size)), dtype=torch.int32, device=ctx.device)
+    got = raster_depth(ctx, lm, d_pos, d_tris, d_models, size, size, d_ids, coarse=coarse)
+    plain = raster_depth(ctx, lm, d_pos, d_tris, d_models, size, size, d_ids)
+    ctx.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    np.testing.assert_array_equal(plain.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    words = coarse.cpu().numpy().view(np.float32)
+    n1, n2 = (size // 8) ** 2, (size // 64) ** 2
+    assert len(words) == n1 + n2 + 8 + 4 + max(64, 2 * n2) * 24   # two coarse levels, the mesh's box, the giant triangles' queue (count + entries)
+    assert (words[:n1].reshape(size // 8, size // 8) <= ref.reshape(size // 8, 8, size // 8, 8).min(axis=(1, 3))).all()
+    assert (words[n1:n1 + n2].reshape(size // 64, size // 64) <= ref.reshape(size // 64, 64, size // 64, 64).min(axis=(1, 3))).all()
+    np.testing.assert_array_equal(words[n1 + n2:n1 + n2 + 6], np.float32([-1, -1, -1, 1, 1, 1]))   # the unit cube's box, where k_mesh_bounds left it
+    queued = int(coarse.cpu().numpy().view(np.uint32)[n1 + n2 + 8])
+    print(f"cascade {cascade}, {size}^2, {order}: {len(ids)} instances, {queued} giant triangles queued (capacity {max(64, 2 * n2)})")
+    # a dependent pass on top of the finished buffer (no clear): nothing changes, with the coarse depth telling most instances so
+    again = raster_depth(ctx, lm, d_pos, d_tris, d_models, size, size, d_ids, depth=got, coarse=coarse)
+    ctx.synchronize()
+    np.testing.assert_array_equal(again.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_many_instances_of_a_general_mesh_through_the_camera(ctx):
+    """The instance test with the camera's matrices (projective: the box's corners bound x / w, y / w, z / w only while every corner lies in front of the eye and
+    inside the near plane -- instances around the eye are never skipped) and a mesh that is no box, with a vertex no triangle references lying far outside."""
+    from sailor_amd.forward_plus import raster_depth_camera
+    f = synth.make_frame("tiny", with_surface=False)
+    cam, W, H = f.cam, f.cam.width, f.cam.height
+    rng = np.random.default_rng(77)
+    n = 6000
+    pos = np.float32([[0, 1, 0], [-1, -1, 1], [1, -1, 1], [0, -1, -1], [50, 50, 50]])                # a tetrahedron + an unreferenced vertex
+    tris = np.uint32([[0, 1, 2], [0, 2, 3], [0, 3, 1], [1, 3, 2]])
+    centre = np.stack([rng.uniform(-400, 400, n), rng.uniform(-50, 350, n), rng.uniform(-900, 100, n)], 1)   # the camera sits at (0, 150, 0) looking down -z: some are around it
+    models = np.zeros((n, 4, 4), np.float32)
+    s = rng.uniform(2, 30, n)
+    models[:, 0, 0] = s; models[:, 1, 1] = s; models[:, 2, 2] = s; models[:, 3, 3] = 1; models[:, 3, :3] = centre
+    order = np.argsort(np.linalg.norm(centre - np.float64([0, 150, 0]), axis=1))                          # front to back
+    ids = order.astype(np.uint32)
+    models = models.reshape(n, 16)
+    fb = np.frombuffer(bytes(cam.frame), np.float32)
+    ref = oracle.raster_depth(fb[16:32], pos, tris, models, W, H, instance_ids=ids, view=fb[0:16])
+    dev = lambda a, t=np.float32: torch.from_numpy(np.ascontiguousarray(a, t)).to(ctx.device)
+    coarse = torch.empty(int(_lib.load().sailor_hip_raster_coarse_words(W, H)), dtype=torch.int32, device=ctx.device)
+    got = raster_depth_camera(ctx, cam.frame, dev(pos), dev(tris.view(np.int32), np.int32), dev(models), W, H, dev(ids.view(np.int32), np.int32), coarse)
+    ctx.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert float((ref > 0).mean()) > 0.3
+    words = coarse.cpu().numpy().view(np.float32)
+    nlev = ((W + 7) // 8) * ((H + 7) // 8) + ((W + 63) // 64) * ((H + 63) // 64)
+    np.testing.assert_array_equal(words[nlev:nlev + 6], np.float32([-1, -1, -1, 1, 1, 1]))             # the referenced vertices only
