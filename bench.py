@@ -146,8 +146,14 @@ class HipDevice:
     def capture(self, stream, body):
         """body() recorded into one hipGraph on `stream`; .replay() launches it"""
         g = torch.cuda.CUDAGraph()
-        # (thread-local capture: in a process group the NCCL watchdog thread polls its work objects' events with hipEventQuery at any time, which a GLOBAL-mode
-        # capture on this thread turns into an error that kills the run -- seen once in a while when a capture follows a collective closely; round 6)
+        # In an NCCL process group the watchdog thread polls its work objects' events with hipEventQuery until it has seen them complete (every 100 ms), and a
+        # query that lands inside a stream capture of this thread fails -- the watchdog then takes the process down with a C++ back trace.  Seen about once in
+        # fifteen one-rank runs when a capture follows a collective closely (round 6).  Two defences: the capture is THREAD-LOCAL (other threads' calls are then
+        # legal by the API's own rules), and -- because one failure was seen with that alone -- no collective is left for the watchdog to poll: everything this
+        # rank enqueued is complete (synchronize) and the watchdog gets two of its periods to retire it.  Outside every timed region.
+        if self.dist_backend == "nccl" and torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.cuda.synchronize(self.device)
+            time.sleep(0.25)
         with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
             body()
         return g

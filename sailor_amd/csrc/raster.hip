@@ -304,6 +304,7 @@ __device__ __forceinline__ void raster_superblock(const RasterTri& b, const Rast
 #define RASTER_GIANT_ALIVE 4
 #endif
 #define RASTER_GIANT_WORDS 24 // x0 y0 x1 y1 x2 y2 (int64 each), z0 z1 z2, i0 i1 j0 j1, zmax, pad
+#define RASTER_GIANT_GRID 1024u // queue entries that get blocks of their own in one launch of k_raster_giant (x 16 blocks of four waves each)
 __device__ __forceinline__ bool raster_giant_push(unsigned int* __restrict__ giants, unsigned int giantCap, const RasterTri& b, float zmaxB, int lane)
 {
     unsigned int slot = 0;
@@ -326,8 +327,10 @@ __global__ __launch_bounds__(256) void k_raster_giant(const unsigned int* __rest
                                                       unsigned int* __restrict__ coarse)
 {
     const unsigned int count = min(giants[0], giantCap);
-    if (blockIdx.x >= count) return;
-    const unsigned int* e = giants + 4 + (size_t)blockIdx.x * RASTER_GIANT_WORDS;
+    // (the grid holds at most RASTER_GIANT_GRID entries' worth of blocks -- a launch of the queue's full capacity is 131 072 blocks at 4096^2, 35 us of empty
+    // blocks behind every chunk of every draw -- and walks the queue in strides)
+    for (unsigned int entry = blockIdx.x; entry < count; entry += gridDim.x) {
+    const unsigned int* e = giants + 4 + (size_t)entry * RASTER_GIANT_WORDS;
     RasterTri b;
     long long xy[6];
 #pragma unroll
@@ -349,6 +352,7 @@ __global__ __launch_bounds__(256) void k_raster_giant(const unsigned int* __rest
         bool alive = false;
         if (lane == 0) alive = raster_superblock_alive(b, E, zmaxB, si + si0, sj + sj0, W, H, coarse2, SW);
         if (__shfl((int)alive, 0, 64)) raster_superblock(b, E, zmaxB, si + si0, sj + sj0, lane, W, H, depthBits, coarse, coarse2, CW, SW);
+    }
     }
 }
 
@@ -677,7 +681,7 @@ static int raster_depth_launch(SailorHipContext* ctx, const float* lightMatrix, 
                            dPositions, dIndices, numTriangles, dModels, dInstanceIds, first, n, width, height, (unsigned int*)dDepth, (unsigned int*)dCoarseDepth, meshBounds,
                            interleaveOn ? 1 : 0, giants, giantCap);
         // (a chunk's giants behind the chunk: what they write -- and what they make of the coarse depth -- is there for the next chunk)
-        if (giants) hipLaunchKernelGGL(k_raster_giant, dim3(giantCap, 16), dim3(256), 0, ctx->stream, giants, giantCap, width, height, (unsigned int*)dDepth, (unsigned int*)dCoarseDepth);
+        if (giants) hipLaunchKernelGGL(k_raster_giant, dim3(giantCap < RASTER_GIANT_GRID ? giantCap : RASTER_GIANT_GRID, 16), dim3(256), 0, ctx->stream, giants, giantCap, width, height, (unsigned int*)dDepth, (unsigned int*)dCoarseDepth);
         first += n;
         if (chunk < 0x40000000u / chunkGrowth) chunk *= chunkGrowth;
     }
