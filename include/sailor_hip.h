@@ -544,7 +544,13 @@ SAILOR_HIP_API int sailor_hip_exchange_visibility(SailorHipContext* ctx, void* c
  *   flags        : SAILOR_RASTER_CLEAR clears dDepth (and the coarse depth) to 0 first -- a dependent pass (:250-261) draws on top without it;
  *                  SAILOR_RASTER_CULL_BACK discards back faces as the reference's materials do (ECullMode::Back, frontFace counter-clockwise)
  *   dCoarseDepth : device scratch or NULL, sailor_hip_raster_coarse_words(width, height) words belonging to dDepth (cleared with it): lower bounds of the
- *                  depths stored in each 8 x 8 block and each 64 x 64 superblock, used to skip what cannot win any more.  The result does not depend on it. */
+ *                  depths stored in each 8 x 8 block and each 64 x 64 superblock, used to skip what cannot win any more -- whole triangles, blocks, and
+ *                  (round 6, draws of >= 4 096 instances) whole INSTANCES: the box of the mesh's referenced vertices through the instance's matrix -- and,
+ *                  behind those, the box itself (8 words) and a queue of "giant" triangles (4 + 24 words per entry, two entries per superblock): a
+ *                  triangle that is visible and large on the map is drawn by sixty-four waves of a second kernel instead of block by block by the wave
+ *                  that set it up, and a draw of many instances goes out in up to six launches of growing size so that a launch's giants are on the map
+ *                  before the next launch starts (a caller that sorts its instances front to back gets most of the later ones skipped).  All of it is
+ *                  bounds and scheduling only: the depth buffer is bit for bit the same with and without the workspace, in any drawing order. */
 SAILOR_HIP_API size_t sailor_hip_raster_coarse_words(int32_t width, int32_t height);
 SAILOR_HIP_API int sailor_hip_raster_depth(SailorHipContext* ctx, const float* lightMatrix, const float* dPositions, const uint32_t* dIndices,
                                            uint32_t numTriangles, const float* dModels, const uint32_t* dInstanceIds, uint32_t numDrawn,

@@ -1837,8 +1837,11 @@ int sailor_hip_light_cull_prepared(SailorHipContext* ctx, const SailorUboFrameDa
         const bool wide = L.words >= 4096 && (L.words & 1) == 0;
         if (wide)
         {
-            // (round 6: a 4 x 4 patch of groups per block -- every mask row crosses into the block once for sixteen groups; SAILOR_CULL_WIDE16=0: the form above)
-            static const bool wide16 = [] { const char* e = getenv("SAILOR_CULL_WIDE16"); return !e || atoi(e) != 0; }();
+            // (round 6: a 4 x 4 patch of groups per block -- every mask row crosses into the block once for sixteen groups.  SAILOR_CULL_WIDE16=1; OFF by default:
+            // on C5 it halves the kernel's traffic, 370 -> 194 MB, leaves its duration where it was, 84.1 -> 85.3 us -- the kernel is its waves' 128-step chains,
+            // not bandwidth -- and its 1 024-thread, 56 KB blocks find room beside the previous frame's shade later than 256-thread ones do: the serial step
+            // 762 -> 756 us, the frame pipeline's step 746 -> 784 us, same box, two runs each: profiles/r06/README.md section 3)
+            static const bool wide16 = [] { const char* e = getenv("SAILOR_CULL_WIDE16"); return e && atoi(e) != 0; }();
             const dim3 wideGrid((unsigned)(((L.groupsX + 3) / 4) * L.groupsY));
             const dim3 wide16Grid((unsigned)(((L.groupsX + 3) / 4) * ((L.groupsY + 3) / 4)));
             if (wide16 && L.words % (128 * GLW16_ROWS) == 0 && !select)

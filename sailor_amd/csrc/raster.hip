@@ -16,7 +16,9 @@
 #include "common.h"
 #include <hip/hip_fp16.h>
 
+#ifndef RASTER_SMALL_BOX
 #define RASTER_SMALL_BOX 64 // pixels a lane fills on its own
+#endif
 // (RASTER_PRETEST builds only) how the depth test reads the stored depth in front of its atomic: a plain load (this XCD's L2: possibly stale, never too high) or --
 // RASTER_PRETEST_COHERENT -- a relaxed device-scope atomic load (the memory side: current, dearer)
 #ifdef RASTER_PRETEST_COHERENT
@@ -156,18 +158,6 @@ __device__ __forceinline__ void raster_depth_test(unsigned int* __restrict__ p, 
     if (zb > RASTER_PRETEST_LOAD(p))
 #endif
         atomicMax(p, zb);
-}
-
-__device__ __forceinline__ void raster_pixel(const RasterTri& t, float area, bool tl0, bool tl1, bool tl2, int i, int j, int W, unsigned int* __restrict__ depthBits)
-{
-    const long long px = 256ll * i + 128, py = 256ll * j + 128;
-    const long long e0 = raster_edge(t.x1, t.y1, t.x2, t.y2, px, py), e1 = raster_edge(t.x2, t.y2, t.x0, t.y0, px, py), e2 = raster_edge(t.x0, t.y0, t.x1, t.y1, px, py);
-    if (e0 < 0 || e1 < 0 || e2 < 0) return;
-    if ((e0 == 0 && !tl0) || (e1 == 0 && !tl1) || (e2 == 0 && !tl2)) return;
-    const float w1 = (float)e1 / area, w2 = (float)e2 / area;
-    const float z = (t.z0 + (t.z1 - t.z0) * w1) + (t.z2 - t.z0) * w2;
-    if (!(z > 0.0f && z <= 1.0f)) return; // z == 0 never passes GREATER against the cleared 0 either
-    raster_depth_test(depthBits + (size_t)j * W + i, z);
 }
 
 __device__ __forceinline__ long long bcast64(long long v, int src)
@@ -469,14 +459,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (t.valid && fminf(t.z0, fminf(t.z1, t.z2)) - RASTER_Z_MARGIN > 1.0f) t.valid = false; // ... or z <= 1
         const bool small = t.valid && (long long)(t.i1 - t.i0 + 1) * (t.j1 - t.j0 + 1) <= RASTER_SMALL_BOX;
         if (small) {
+            // (its box against the coarse depth of the blocks it touches, where those are at most 2 x 2 -- round 6; one block through round 5)
             bool hidden = false;
-            if (coarse && (t.i0 >> 3) == (t.i1 >> 3) && (t.j0 >> 3) == (t.j1 >> 3))
-                hidden = zmaxTri <= __uint_as_float(coarse[(size_t)(t.j0 >> 3) * CW + (t.i0 >> 3)]);
+            if (coarse && (t.i1 >> 3) - (t.i0 >> 3) <= 1 && (t.j1 >> 3) - (t.j0 >> 3) <= 1) {
+                const unsigned int* r0 = coarse + (size_t)(t.j0 >> 3) * CW, *r1 = coarse + (size_t)(t.j1 >> 3) * CW;
+                hidden = zmaxTri <= fminf(fminf(__uint_as_float(r0[t.i0 >> 3]), __uint_as_float(r0[t.i1 >> 3])), fminf(__uint_as_float(r1[t.i0 >> 3]), __uint_as_float(r1[t.i1 >> 3])));
+            }
             if (!hidden) {
                 const float area = (float)raster_edge(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2);
                 const bool tl0 = raster_top_left(t.x1, t.y1, t.x2, t.y2), tl1 = raster_top_left(t.x2, t.y2, t.x0, t.y0), tl2 = raster_top_left(t.x0, t.y0, t.x1, t.y1);
-                for (int j = t.j0; j <= t.j1; j++)
-                    for (int i = t.i0; i <= t.i1; i++) raster_pixel(t, area, tl0, tl1, tl2, i, j, W, depthBits);
+                // (round 6: the three edge functions walked texel by texel -- exact integer steps of 256 sub-pixels, -256 (by - ay) along x and 256 (bx - ax)
+                // along y -- instead of six 64-bit multiplications per texel: the far cascades are made of these triangles)
+                const long long px0 = 256ll * t.i0 + 128, py0 = 256ll * t.j0 + 128;
+                long long r0 = raster_edge(t.x1, t.y1, t.x2, t.y2, px0, py0), r1 = raster_edge(t.x2, t.y2, t.x0, t.y0, px0, py0), r2 = raster_edge(t.x0, t.y0, t.x1, t.y1, px0, py0);
+                const long long dx0 = -256ll * (t.y2 - t.y1), dx1 = -256ll * (t.y0 - t.y2), dx2 = -256ll * (t.y1 - t.y0);
+                const long long dy0 = 256ll * (t.x2 - t.x1), dy1 = 256ll * (t.x0 - t.x2), dy2 = 256ll * (t.x1 - t.x0);
+                for (int j = t.j0; j <= t.j1; j++, r0 += dy0, r1 += dy1, r2 += dy2) {
+                    long long e0 = r0, e1 = r1, e2 = r2;
+                    for (int i = t.i0; i <= t.i1; i++, e0 += dx0, e1 += dx1, e2 += dx2) {
+                        if (e0 < 0 || e1 < 0 || e2 < 0) continue;
+                        if ((e0 == 0 && !tl0) || (e1 == 0 && !tl1) || (e2 == 0 && !tl2)) continue;
+                        const float z = (t.z0 + (t.z1 - t.z0) * ((float)e1 / area)) + (t.z2 - t.z0) * ((float)e2 / area);
+                        if (z > 0.0f && z <= 1.0f) raster_depth_test(depthBits + (size_t)j * W + i, z); // (z == 0 never passes GREATER against the cleared 0 either)
+                    }
+                }
             }
         }
         // the large ones: the whole wave on one triangle at a time
@@ -496,6 +502,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             // ---- level 2: 64 x 64-texel superblocks, one per lane ----
             const int si0 = b.i0 >> 6, sj0 = b.j0 >> 6, sw = (b.i1 >> 6) - si0 + 1, sh = (b.j1 >> 6) - sj0 + 1;
             const int ns = sw * sh;
+            // (measured and dropped, round 6: a triangle inside ONE superblock sent straight to its blocks, without the superblock's own test -- 15.4 -> 16.2 ms over
+            // the four cascades: the one coarse word of level 2 spares most of these triangles the sixty-four of level 1)
             // (round 6) a triangle with many superblocks left after the coarse test -- visible, large on the map, thousands of blocks to fill -- is not this wave's
             // to fill: see k_raster_giant.  One that spans several batches of superblocks has them counted first (the test alone: a round trip per batch).
             if (giants && ns > 64) {

@@ -423,3 +423,19 @@ def test_dispatch_packet_timing_of_the_cull_chain(ctx):
     np.testing.assert_array_equal(got[0], ref[0]); np.testing.assert_array_equal(got[1], ref[1])
     fp.cull(f.cam.frame, l, N, d)   # all four slots are used up: ordinary launches again
     ctx.synchronize()
+
+
+def test_the_4x4_patch_form_of_the_wide_list_builder_gives_the_same_lists():
+    """Round 6: k1_group_lists_wide16 (SAILOR_CULL_WIDE16=1: a block per 4 x 4 patch of groups, every mask row fetched once for sixteen groups) is off by
+    default -- it halves the kernel's traffic and shortens nothing -- and stays under the oracle: the large-light-set tests of this file and the band tests
+    of test_split_paths_gpu.py (the form behind the band selection: a selected count that is no multiple of 256 words) in a child process with the switch on
+    (the library reads it once per process)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SAILOR_CULL_WIDE16="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_light_cull_gpu.py", "tests/test_split_paths_gpu.py", "-m", "gpu", "-q", "-x",
+                        "-k", "large_light_set or 300_000_lights"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
+    assert " passed" in p.stdout and "no tests ran" not in p.stdout, p.stdout[-500:]
