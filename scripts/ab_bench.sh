@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A / B of bench.py over the builds of scripts/ab_build.sh (run through gpurun): scripts/ab_bench.sh [bench args] -- NAME...
+# Same-box A / B of bench.py over the builds of scripts/build_variant.sh (run through gpurun): scripts/ab_bench.sh [bench args] -- NAME...
 # Prints cull / shade / step per build, each build twice in alternation (drift shows up as disagreement between the two rounds).
 args=()
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do args+=("$1"); shift; done
