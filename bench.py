@@ -1161,7 +1161,7 @@ def main(argv=None, device_factory=None):
     cam, W, H = frame.cam, frame.cam.width, frame.cam.height
     N = len(frame.lights)
     # everything runs on one side stream: the C-ABI records on it, torch events time it, and a hipGraph can capture it
-    side = dev.stream()
+    side = dev.stream(priority=int(os.environ.get('SAILOR_SHADE_PRIORITY', '0')))   # (A / B knob: -1 = the launch stream above the cull's)
     dev.set_stream(side)
     ctx = dev.context(side)
     d_lights = dev.upload_lights(frame.lights)

@@ -679,7 +679,7 @@ static int raster_depth_launch(SailorHipContext* ctx, const float* lightMatrix, 
     uint32_t first = 0, chunk = (manyInstances && chunksOn && giants) ? chunkFirst : numDrawn, launches = 0;
     // (Measured and not kept: letting the DEVICE decide after the first chunk whether chunks pay -- its giants' count against a threshold, the second launch sized
     // for everything that is left.  Only the farthest cascade of the million-box scene prefers one launch, by 0.4 of its 5 ms; the other three want every chunk:
-    // cascade 1 3.4 -> 9.4 ms, cascade 2 4.8 -> 6.4 without them -- profiles/r06/raster_chunk_sweeps.txt.)
+    // cascade 1 3.4 -> 9.4 ms, cascade 2 4.8 -> 6.4 without them -- profiles/r06/raster_experiments.txt, blocks 8-10.)
     while (first < numDrawn) {
         // (the last of at most chunkMax launches takes whatever is left)
         const uint32_t n = (numDrawn - first < chunk || ++launches >= chunkMax) ? numDrawn - first : chunk;
