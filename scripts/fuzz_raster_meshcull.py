@@ -20,6 +20,9 @@ cube_pos, cube_tris = synth.unit_cube_mesh()
 for c in range(cases):
     W, H = int(rng.integers(1, 200)), int(rng.integers(1, 200))
     n = int(rng.choice([1, 2, 30, 400]))
+    if c % 5 == 4:   # (round 6) draws of >= 4 096 instances on larger maps: chunked launches, the instance test, the giant triangles' queue and its overflow
+        W, H = int(rng.integers(100, 700)), int(rng.integers(100, 700))
+        n = int(rng.choice([4096, 5000, 9000]))
     cam = synth.make_camera(max(W, 16), max(H, 16))
     cull_back = bool(rng.integers(0, 2))
     if rng.random() < 0.5:
@@ -38,7 +41,8 @@ for c in range(cases):
         models[:, 12:15] = (rng.normal(size=(n, 3)) * 400.0 + np.array([0.0, 150.0, -300.0])).astype(np.float32)
         ref = oracle.raster_depth(np.array(cam.frame.projection, np.float32), pos, tris, models, W, H, instance_ids=ids,
                                   view=np.array(cam.frame.view, np.float32), cull_back=cull_back)
-        got = raster_depth_camera(ctx, cam.frame, t(pos), ti(tris), t(models), W, H, None if ids is None else ti(ids), cull_back=cull_back)
+        ccoarse = torch.zeros(int(ctx._lib.sailor_hip_raster_coarse_words(W, H)), dtype=torch.int32, device=dev) if n >= 4096 else None
+        got = raster_depth_camera(ctx, cam.frame, t(pos), ti(tris), t(models), W, H, None if ids is None else ti(ids), ccoarse, cull_back=cull_back)
     else:
         sh = synth.make_shadow_set(cam, 2, int(rng.integers(1, 1000)))
         lm = sh.lights_matrices[int(rng.integers(0, 4))]
@@ -48,7 +52,7 @@ for c in range(cases):
             base = oracle.raster_depth(lm, cube_pos, cube_tris, models[:1] * 1.0, W, H)
         ref = oracle.raster_depth(lm, pos, tris, models, W, H, instance_ids=ids, depth=base, cull_back=cull_back)
         coarse = None
-        if rng.random() < 0.5 and base is None:
+        if (rng.random() < 0.5 and base is None) or (n >= 4096 and rng.random() < 0.8):   # (a dependent pass with a coarse depth: the bounds start from zero -- valid, merely loose)
             words = ctx._lib.sailor_hip_raster_coarse_words(W, H)
             coarse = torch.zeros(int(words), dtype=torch.int32, device=dev)
         got = raster_depth(ctx, lm, t(pos), ti(tris), t(models), W, H, None if ids is None else ti(ids), None if base is None else t(base), coarse, cull_back)

@@ -51,3 +51,16 @@ def test_random_hierarchies_through_the_ecs_sweep(ctx, seed):
             fuzz_cases.k4_case(ctx, rng, c)
         except AssertionError as e:
             raise AssertionError(f"seed {seed}, K4 case {c}: {e}") from e
+
+
+def test_random_caster_draws_and_indirect_draw_compactions():
+    """Round 6: a bounded slice of scripts/fuzz_raster_meshcull.py inside the suite (60 rasteriser cases -- every fifth a draw of >= 4 096 instances on a larger
+    map: chunked launches, the instance test, the giant triangles' queue and its overflow, dependent passes on a coarse depth that starts from zero -- and 60
+    compaction cases), depth buffers and instance buffers bit for bit; a child process, as the script is run through gpurun by the thousand."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    p = subprocess.run([sys.executable, "scripts/fuzz_raster_meshcull.py", "60", "20250304"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+    assert "raster fuzz ok: 60 cases" in p.stdout and "mesh cull fuzz ok: 60 cases" in p.stdout, p.stdout[-500:]
