@@ -108,7 +108,9 @@ SHADE_ENTRIES(_pt, true, true)
                                                      const uint32_t* __restrict__ culled, float4* __restrict__ radiance)                          \
     {                                                                                                                                              \
         __shared__ ShadeLdsT<2> lds;                                                                                                               \
+        SPROF_TG(0, true)                                                                                                                          \
         k2_shade_body<CSM, false, ROLE_TILE, PREP, TL, 2>(lds, A, C, I, surface, planeStride, lights, grid, culled, radiance);                     \
+        SPROF_TG(3, true)                                                                                                                          \
     }
 // (only the forms that keep 64 registers without scratch: prepared lights -- the second staging round is then a copy -- and no shadow maps; the K3 body inside
 // the round loop spills nine to eleven registers, the in-kernel staging three)

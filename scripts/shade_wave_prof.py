@@ -32,16 +32,18 @@ buf = np.zeros((65536, 12), dtype=np.uint64)
 fn = lib.sailor_hip_debug_read_shade_wave_prof
 fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert fn(buf.ctypes.data, buf.nbytes) == 0
-Tx = fp.Tx; tpp = (Tx + 79) // 80; gx = 8 * tpp
+import os
+WPB = 2 if os.environ.get("SAILOR_SHADE_HALF") == "1" else 4   # waves per block: the two-wave form (round 6) has two blocks per tile, half tiles side by side in x
+Tx = fp.Tx; tpp = (Tx + 79) // 80; gx = 8 * tpp * (4 // WPB)
 nrows = band.tileRowEnd - band.tileRowBegin
 nb = min(gx * 10 * nrows, 65536)
 lin = np.arange(nb); bx, by, bz = lin % gx, (lin // gx) % 10, lin // (gx * 10)
-btx = (((bx - bz) & 7) + 8 * by) * tpp + (bx >> 3)
+btx = (((bx - bz) & 7) + 8 * by) * tpp + (bx >> (3 if WPB == 4 else 4))
 real = btx < Tx
 p = buf[:nb][real].astype(np.int64)
-t0 = p[:, 0:4].min()
-st, en = (p[:, 0:4] - t0) / 100.0, (p[:, 4:8] - t0) / 100.0     # us
-hw = p[:, 8:12]
+t0 = p[:, 0:WPB].min()
+st, en = (p[:, 0:WPB] - t0) / 100.0, (p[:, 4:4 + WPB] - t0) / 100.0     # us
+hw = p[:, 8:8 + WPB]
 xcd = (hw >> 32) & 0xF
 h = hw & 0xFFFFFFFF
 cu = (xcd << 8) | (((h >> 13) & 7) << 5) | (((h >> 12) & 1) << 4) | ((h >> 8) & 0xF)   # (XCD, SE, SH, CU)
@@ -53,7 +55,7 @@ span = en.max()
 life = en - st
 print("%s %s: %d blocks, span %.1f us" % (cfg, "band %d/%d" % (r, g) if g > 1 else "whole frame", len(p), span))
 print("wave life us: mean %.2f median %.2f p90 %.2f;  per block: slowest wave %.2f, fastest %.2f, mean %.2f  => a block's waves are busy %.0f %% of the block's life" %
-      (life.mean(), np.median(life), np.percentile(life, 90), life.max(1).mean(), life.min(1).mean(), life.mean(1).mean(), 100 * life.sum() / (4 * (en.max(1) - st.min(1))).sum()))
+      (life.mean(), np.median(life), np.percentile(life, 90), life.max(1).mean(), life.min(1).mean(), life.mean(1).mean(), 100 * life.sum() / (WPB * (en.max(1) - st.min(1))).sum()))
 print("start skew inside a block (last wave's start - first wave's): mean %.2f us p90 %.2f" % ((st.max(1) - st.min(1)).mean(), np.percentile(st.max(1) - st.min(1), 90)))
 # wave-slot occupancy over the steady part of the launch: per (CU, SIMD, slot) sort the waves that ran there, gaps between one's end and the next one's start
 key = (cu.astype(np.int64) << 8) | (simd.astype(np.int64) << 4) | slot.astype(np.int64)
