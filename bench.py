@@ -724,6 +724,51 @@ def shadow_pass_block(ctx, count: int, size: int, steps: int, use_coarse: bool =
     _, bs, _, _ = side_ms(lambda: evsm_blur(ctx, moments, 2, 5, tmp), steps)
     out["blur_cascade0_ms"] = bs
     out["all_passes_ms"] = total + bs
+    # The same four passes with nothing between them but their own dependencies (round 6): the cascades' draws write different targets, so they may run side by
+    # side -- one stream and one coarse-depth workspace per cascade (a context per stream), draw -> resolve (-> blur for cascade 0) in order on each, one event
+    # pair on the launch stream around the fork and the join.  What that buys is the launches' tails: a draw ends in a few long waves while the chip idles.
+    # `all_passes_ms` above stays the sum of the passes timed one by one.
+    try:
+        from sailor_amd.forward_plus import HipContext
+        main = torch.cuda.current_stream(ctx.device)
+        streams = [torch.cuda.Stream(device=ctx.device) for _ in cascades]
+        ctxs = [HipContext(ctx.device, stream=st) for st in streams]
+        coarses = [torch.empty_like(coarse) for _ in cascades] if coarse is not None else [None] * len(cascades)
+        outs = [torch.empty((size, size, 4), dtype=torch.float32, device=ctx.device) if k == 0 else torch.empty((size, size), dtype=torch.float16, device=ctx.device) for k in cascades]
+        lms = [np.ascontiguousarray(sh.lights_matrices[k], np.float32) for k in cascades]
+
+        def all_at_once():
+            fork = torch.cuda.Event(); fork.record(main)
+            for i, k in enumerate(cascades):
+                c, st = ctxs[i], streams[i]
+                st.wait_event(fork)
+                c._lib.sailor_hip_raster_depth(c.handle, lms[i].ctypes.data_as(C_float_p), pos.data_ptr(), tris.data_ptr(), 12, models.data_ptr(), ids[k].data_ptr(), len(ids_h[k]),
+                                               size, size, depth[k].data_ptr(), 3, coarses[i].data_ptr() if coarses[i] is not None else None)
+                c._lib.sailor_hip_shadow_resolve(c.handle, depth[k].data_ptr(), size, size, L_RGBA32F if k == 0 else L_R16F, outs[i].data_ptr())
+                if k == 0:
+                    c._lib.sailor_hip_evsm_blur(c.handle, outs[i].data_ptr(), tmp.data_ptr(), size, size, 2, 5)
+                done = torch.cuda.Event(); done.record(st)
+                main.wait_event(done)
+        one_by_one = [depth[k].clone() for k in cascades]   # (the buffers the passes above left, drawn one after the other)
+        for _ in range(2):
+            all_at_once()
+        torch.cuda.synchronize(ctx.device)
+        out["side_by_side_equals_one_by_one"] = all(bool(torch.equal(depth[k].view(torch.int32), one_by_one[i].view(torch.int32))) for i, k in enumerate(cascades))
+        del one_by_one
+        evs = []
+        for _ in range(steps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(main); all_at_once(); b.record(main)
+            evs.append((a, b))
+        torch.cuda.synchronize(ctx.device)
+        out["all_passes_side_by_side_ms"] = float(np.median([a.elapsed_time(b) for a, b in evs]))
+        out["all_passes_side_by_side_how"] = ("the four cascades' draw -> resolve (-> blur) chains on four streams between one fork and one join, median of %d; "
+                                              "all_passes_ms = the same passes timed one by one and added up" % steps)
+        for c in ctxs:
+            c.close()
+    except Exception as e:   # (a probe beside the figure of record: it must not take the line down)
+        out["all_passes_side_by_side_ms"] = None
+        out["all_passes_side_by_side_how"] = f"not measured ({type(e).__name__}: {e})"
     sample = ids_h[3][:: max(1, len(ids_h[3]) // 20000)]
     t0 = time.perf_counter()
     oracle.raster_depth(sh.lights_matrices[3], pos_h, tris_h, models_h, size, size, instance_ids=sample)

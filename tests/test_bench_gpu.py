@@ -58,6 +58,9 @@ def test_default_line_carries_the_contract():
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Mpixels/s" and c["value"] > 0 and "tile rows" in c["sample"]
     for block in ("ecs_sweep", "mesh_cull_compact", "linearize_depth", "ambient_ibl", "evsm_blur", "ibl_prefilter", "shadow_passes"):
         assert block in d, block
+    # round 6: the shadow passes one by one (the figure of record) and side by side on four streams -- the same depth buffers, bit for bit
+    sp = d["shadow_passes"]
+    assert sp["all_passes_ms"] > 0 and sp["side_by_side_equals_one_by_one"] is True and 0 < sp["all_passes_side_by_side_ms"] <= sp["all_passes_ms"] * 1.1
     # round 5: the box's own yardstick (a float4 copy timed in this process) beside the guide's constant, the chain's kernels as the library names them,
     # when k1_pack runs, and K4's slices of a 2- / 4- / 8-way entity split timed on this one GPU
     assert 2000.0 < d["box"]["copy_gbs"] < 8000.0 and abs(r["frac_of_box_copy"] - r["achieved"] / d["box"]["copy_gbs"]) < 1e-9
