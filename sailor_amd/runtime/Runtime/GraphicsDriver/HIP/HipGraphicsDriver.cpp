@@ -180,6 +180,7 @@ void HipGraphicsDriver::SubmitCommandList(RHICommandListPtr commandList)
 // cull's per-tile lists -- and the write must come behind the compaction that is still filling the buffer on the second queue.
 void HipGraphicsDriver::BeforeBufferWrite(const void* devicePtr)
 {
+    if (devicePtr) m_rasterWorkspaces.erase(devicePtr); // (a depth attachment written by anything but caster draws: its coarse depth no longer bounds it)
     if (!devicePtr || (devicePtr != m_ownGrid && devicePtr != m_ownCulled)) return;
     if (m_packPending) { sailor_hip_context_wait_for(m_ctx, m_ctxAux); m_packPending = false; }
     m_ownGrid = nullptr; m_ownCulled = nullptr;
@@ -640,16 +641,25 @@ void HipGraphicsDriver::DrawIndexed(RHICommandListPtr cmd, uint32_t indexCount, 
         const bool first = cmd->m_casterDraws++ == 0;
         TVector<uint8_t> pc = cmd->m_pushConstants;
         SailorHipContext* ctx = m_ctx;
-        cmd->m_hip.m_commands.push_back([ctx, depth, vb, ib, instances, pc, first, indexCount, instanceCount, firstIndex, vertexOffset, firstInstance]() {
+        cmd->m_hip.m_commands.push_back([this, ctx, depth, vb, ib, instances, pc, first, indexCount, instanceCount, firstIndex, vertexOffset, firstInstance]() {
             if (!depth || !vb || !ib || !instances || pc.size() < 64 || depth->m_format != EFormat::R32_SFLOAT) return (int)SAILOR_HIP_ERR_INVALID_ARGUMENT;
             float lightMatrix[16];
             memcpy(lightMatrix, pc.data(), 64);
+            // The rasteriser's workspace of this depth attachment (round 6: through round 5 the backend drew without one): coarse depth, the mesh's box, the giant
+            // triangles' queue -- bounds and scheduling only, the same depth buffer.  One per attachment, created at its first cleared draw, valid as long as
+            // nothing but caster draws writes the attachment (BeforeBufferWrite drops it otherwise; a draw that does not clear and finds none goes without).
+            const void* key = depth->m_buffer->m_hip.m_devicePtr;
+            const size_t words = sailor_hip_raster_coarse_words(depth->GetExtent().x, depth->GetExtent().y);
+            RHIBufferPtr ws;
+            auto it = m_rasterWorkspaces.find(key);
+            if (it != m_rasterWorkspaces.end() && it->second && it->second->m_size >= words * 4) ws = it->second;
+            else if (first) { ws = CreateBuffer(words * 4); m_rasterWorkspaces[key] = ws; }
             // the render pass clears the depth attachment (ShadowPrepassNode.cpp:239-248); the material culls back faces (:39)
             return sailor_hip_raster_depth(ctx, lightMatrix, (const float*)vb->m_hip.m_devicePtr + 3 * (size_t)vertexOffset,
                                            (const uint32_t*)ib->m_hip.m_devicePtr + firstIndex, indexCount / 3,
                                            (const float*)instances->m_hip.m_devicePtr + 16 * (size_t)firstInstance, nullptr, instanceCount, depth->GetExtent().x,
                                            depth->GetExtent().y, (float*)depth->m_buffer->m_hip.m_devicePtr, (first ? SAILOR_RASTER_CLEAR : 0u) | SAILOR_RASTER_CULL_BACK,
-                                           nullptr);
+                                           ws ? (uint32_t*)ws->m_hip.m_devicePtr : nullptr);
         });
         return;
     }

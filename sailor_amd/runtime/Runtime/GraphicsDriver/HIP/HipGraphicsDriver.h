@@ -16,6 +16,7 @@
 //   "Shaders/ShadowCaster.shader" [EVSM]  -> sailor_hip_raster_depth into the pass' depth attachment, and at EndRenderPass sailor_hip_shadow_resolve
 //                                            into its colour attachment (push constant lightMatrix, set 1 `data`, vertex positions, 32-bit indices)
 #pragma once
+#include <map>
 #include <memory>
 #include "../../RHI/GraphicsDriver.h"
 
@@ -110,6 +111,7 @@ private:
     RHI::RHIBufferPtr m_meshCullWorkspace;
     int32_t m_cullW = 0, m_cullH = 0, m_cullLights = 0; // geometry of the last light cull: locates its shading-order hint in the workspace
     bool m_cullOrderValid = false;
+    std::map<const void*, RHI::RHIBufferPtr> m_rasterWorkspaces; // depth attachment -> the rasteriser's workspace (coarse depth, mesh box, giants' queue)
     uint32_t m_exchangesClipped = 0; // exchanges whose global lists arrived clipped (reported by the exchange after them)
     // Round 4: the light cull stops after its per-tile lists (SAILOR_CULL_DEFER_PACK); the compaction into the node's `lightsGrid` / `culledLights`
     // SSBOs is recorded on a second context (own stream) and runs BESIDE the RenderScene shade, which reads the per-tile lists when the two SSBOs
