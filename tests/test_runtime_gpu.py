@@ -909,3 +909,29 @@ def test_the_exchange_only_records_adapts_its_slots_and_can_be_captured():
     finally:
         torch.cuda.synchronize()
         rccl.ncclCommDestroy(comm)
+
+
+def test_exchange_visibility_checks_the_buffer_it_gathers_into():
+    """sailor_hip_exchange_visibility gathers worldSize * wordsPerRank uint64 in place -- more than sailor_hip_ecs_sweep's ceil(n / 64) when the words
+    do not divide evenly -- and now takes the buffer's capacity: a smaller one is refused (nothing is gathered, the error text says why), a sufficient one is
+    gathered.  One-rank ncclComm_t; the arithmetic for eight ranks is checked on the host entry point sailor_hip_ecs_range_for_rank."""
+    from sailor_amd.forward_plus import HipContext
+    lib = _lib.load()
+    b, e, per = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    assert lib.sailor_hip_ecs_range_for_rank(100, 7, 8, C.byref(b), C.byref(e), C.byref(per)) == 0 and per.value == 1   # 100 entities = 2 words over 8 ranks: 1 word each, 8 gathered
+    rccl, comm = _single_rank_comm()
+    try:
+        ctx = HipContext("cuda:0")
+        n = 1000                                            # 16 words
+        vis = torch.arange(16, dtype=torch.int64, device="cuda")
+        before = vis.clone()
+        assert lib.sailor_hip_exchange_visibility(ctx.handle, comm, 0, 1, n, vis.data_ptr(), 15) == -1        # SAILOR_HIP_ERR_INVALID_ARGUMENT
+        assert b"fewer than worldSize * wordsPerRank" in lib.sailor_hip_context_last_error(ctx.handle)
+        ctx.synchronize()
+        assert torch.equal(vis, before)
+        _lib.check(lib.sailor_hip_exchange_visibility(ctx.handle, comm, 0, 1, n, vis.data_ptr(), 16), "sailor_hip_exchange_visibility", ctx.handle)
+        ctx.synchronize()
+        assert torch.equal(vis, before)                     # (one rank: the in-place gather of its own words)
+    finally:
+        torch.cuda.synchronize()
+        rccl.ncclCommDestroy(comm)
