@@ -266,7 +266,16 @@ __device__ float shadow_evsm(const void* __restrict__ map, int fmt, int W, int H
     float p05 = 1.0f;
     for (int i = 0; i < cascade; i++) p05 = p05 * 0.5f;
     const float currentDepth = canonical_expf(40.0f * (pz + 0.003f * bias * p05));
+#ifndef EVSM_NO_EARLY_OUT
+    // (round 6) Chebyshev returns exactly 1 where the fragment lies behind the stored moment (d < 0), and 1 - max(1, anything) clamps to exactly +0 -- a NaN on
+    // the other side included (fmax returns the number).  A wave in which EVERY lane is such a fragment needs neither the second exponential nor the two
+    // correctly rounded divisions; likewise for the negative pair once its exponential is there.  Wave-uniform branches, the same bits.
+    if (__ballot(!(currentDepth - s.x < 0.0f)) == 0ull) return 0.0f;
+#endif
     const float negCurrentDepth = -canonical_expf(-40.0f * (pz + 0.0001f * bias));
+#ifndef EVSM_NO_EARLY_OUT
+    if (cascade <= 2 && __ballot(!(negCurrentDepth - s.z < 0.0f)) == 0ull) return 0.0f;
+#endif
     const float posValue = chebyshev(s.x, s.y, currentDepth, 0.01f, 0.0f);
     const float negValue = chebyshev(s.z, s.w, negCurrentDepth, 0.0f, 0.0f) * (cascade > 2 ? 0.0f : 1.0f);
     return fminf(fmaxf(1.0f - fmaxf(posValue, negValue), 0.0f), 1.0f);
